@@ -1,0 +1,191 @@
+/*
+ * stringsext_amd.h — C-ABI of the MI355X-native replacement for stringsext's
+ * per-Mission byte-stream scan.
+ *
+ * The reference (getreu/stringsext v2.3.5, Rust) has no FFI layer; its seam is
+ *
+ *     FindingCollection::from(ss: &mut ScannerState, input_file_id: Option<u8>,
+ *                             input_buffer: &[u8], is_last_input_buffer: bool)
+ *         -> Pin<Box<FindingCollection>>                 src/finding_collection.rs:84-89
+ *
+ * called once per Mission per 4096-byte slice from the loop in
+ * src/main.rs:153-168 and drained by the merger in src/main.rs:118-136.  A
+ * 4 KiB call is useless for a GPU, so this library replaces that LOOP for one
+ * large chunk of one input file: sx_scan() returns exactly the findings the
+ * loop would have pushed to the merger for the chunk's slices, already in the
+ * merger's order, and carries the same state between calls that ScannerState
+ * carries between slices (src/scanner.rs:40-69).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative SX_E_* code, with text from sx_last_error(); the
+ * caller owns inputs, the library owns sx_result until sx_result_free(); a
+ * context is bound to ONE HIP device and is not thread-safe; internally one
+ * HIP stream per Mission (the reference's one thread per Mission,
+ * src/main.rs:97,151).  There is no CPU fallback: without a HIP device
+ * sx_create() fails with SX_E_NO_DEVICE.
+ */
+#ifndef STRINGSEXT_AMD_H
+#define STRINGSEXT_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SX_ABI_VERSION 1
+
+enum {
+    SX_OK = 0,
+    SX_E_INVALID = -1,     /* bad argument / unsupported mission */
+    SX_E_NO_DEVICE = -2,   /* no usable HIP device: the product never runs on the CPU */
+    SX_E_HIP = -3,         /* a HIP call failed */
+    SX_E_NOMEM = -4,
+    SX_E_STATE = -5        /* call not valid for this context (e.g. device scan on a host-only ctx) */
+};
+
+/* Encoding ids == `Encoding::name()` of encoding_rs as used at src/mission.rs:681,
+ * src/finding.rs:147.  "ascii" is x-user-defined + print_encoding_as_ascii
+ * (src/mission.rs:675-679). */
+enum {
+    SX_ENC_X_USER_DEFINED = 0, SX_ENC_UTF8 = 1, SX_ENC_UTF16LE = 2, SX_ENC_UTF16BE = 3,
+    SX_ENC_KOI8_R = 16, SX_ENC_IBM866 = 17, SX_ENC_ISO_8859_2 = 18, SX_ENC_ISO_8859_5 = 19,
+    SX_ENC_ISO_8859_15 = 20, SX_ENC_WINDOWS_1251 = 21, SX_ENC_WINDOWS_1252 = 22
+};
+
+/* `Precision` — src/finding.rs:34-46 */
+enum { SX_PRECISION_BEFORE = 0, SX_PRECISION_EXACT = 1, SX_PRECISION_AFTER = 2 };
+
+/* The fields of `Mission` the scan reads — src/mission.rs:382-421; `filter` is
+ * `Utf8Filter{af: u128, ubf: u64, grep_char: Option<u8>}` (src/mission.rs:307-327). */
+typedef struct sx_mission {
+    uint8_t  mission_id;
+    uint8_t  encoding;                   /* SX_ENC_* */
+    uint8_t  chars_min_nb;
+    uint8_t  require_same_unicode_block;
+    int16_t  grep_char;                  /* -1 = None */
+    uint8_t  print_encoding_as_ascii;
+    uint8_t  reserved;
+    uint32_t output_line_char_nb_max;
+    uint64_t af_lo, af_hi;
+    uint64_t ubf;
+    uint64_t counter_offset;
+} sx_mission;
+
+/* `Finding` — src/finding.rs:51-74 (`s` = arena[str_off .. str_off+str_len], UTF-8). */
+typedef struct sx_finding {
+    uint64_t position;
+    uint32_t str_off, str_len;
+    uint8_t  precision;
+    uint8_t  completes_previous;         /* s_completes_previous_s */
+    uint8_t  mission_id;
+    uint8_t  reserved;
+    int16_t  input_file_id;              /* Option<u8>: -1 = None */
+    uint16_t reserved2;
+    uint32_t slice_index;                /* 4 KiB slice of this chunk that produced it */
+} sx_finding;
+
+/* Device run record: one maximal stretch of bytes belonging to valid,
+ * filter-accepted characters (ignoring -g / -r), with its character count. */
+typedef struct sx_run {
+    uint64_t start;                      /* byte offset of the first byte, chunk relative */
+    uint64_t end;                        /* one past the last byte */
+    uint64_t chars;
+} sx_run;
+
+typedef struct sx_stats {
+    uint64_t bytes_scanned;              /* input bytes x missions examined on the device */
+    uint64_t run_records;                /* long-run records the device reported (all missions) */
+    uint64_t replay_bytes;               /* input bytes the host replayed (all missions) */
+    uint64_t findings;
+    double   kernel_ms[16];              /* per mission: device scan kernel, HIP events on its stream */
+    double   device_ms;                  /* all mission streams, first launch -> last completion */
+    double   h2d_ms, d2h_ms, replay_ms, total_ms;
+} sx_stats;
+
+typedef struct sx_ctx sx_ctx;
+typedef struct sx_result sx_result;
+
+/* Tunables (0 = library default). */
+typedef struct sx_options {
+    uint32_t subchunk_bytes;             /* bytes one wavefront streams sequentially (multiple of 1024) */
+    uint32_t record_capacity;            /* device run-record slots per mission */
+    uint32_t replay_threads;             /* host threads for the exact replay */
+    uint32_t flags;                      /* SX_OPT_* */
+} sx_options;
+enum { SX_OPT_GENERIC_KERNELS = 1u  /* force the table-driven classifiers (testing) */ };
+
+int  sx_abi_version(void);
+
+/* hip_device >= 0: bind to that device.  hip_device == SX_HOST_ONLY: a context
+ * without device that supports ONLY sx_replay_runs() (used when run records
+ * come from elsewhere: other ranks, tests). */
+#define SX_HOST_ONLY (-1)
+int  sx_create(sx_ctx** out, const sx_mission* missions, int n_missions, int hip_device,
+               const sx_options* opt);
+void sx_destroy(sx_ctx* ctx);
+const char* sx_last_error(const sx_ctx* ctx); /* ctx may be NULL: last sx_create failure */
+
+/* Replaces the loop src/main.rs:153-168 for `len` bytes of ONE input file.
+ * The chunk starts on the reference's slice grid (a multiple of 4096 bytes
+ * into the file, src/input.rs:22,121-123); every chunk except the last one of
+ * a file is a multiple of 4096 long.  `is_last_input_buffer` reaches the final
+ * slice of the chunk exactly as the Slicer's third tuple member would
+ * (src/input.rs:118,166) — the reference CLI always passes false.
+ * sx_scan: bytes in host memory (copied to HBM first);
+ * sx_scan_device: bytes already resident in HBM on this context's device. */
+int sx_scan(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_file_id,
+            int is_last_input_buffer, sx_result** out);
+int sx_scan_device(sx_ctx* ctx, const void* device_bytes, uint64_t len, int input_file_id,
+                   int is_last_input_buffer, sx_result** out);
+
+/* Reset the carried ScannerState of every mission (scanner.rs:73-88). */
+int sx_reset(sx_ctx* ctx);
+
+/* Lower level, stage A: device long-run records of one mission for a
+ * device-resident buffer (stream_parity = (stream offset of byte 0) & 1).
+ * Returns all maximal runs with >= min_chars characters, sorted by start.
+ * *runs is malloc'd; release with sx_free(). */
+int sx_device_runs(sx_ctx* ctx, int mission_index, const void* device_bytes, uint64_t len,
+                   int stream_parity, uint64_t min_chars, sx_run** runs, uint64_t* n_runs);
+
+/* Lower level, stage B: exact replay on the host given run records per
+ * mission (runs[m] sorted by start, chunk-relative).  Works on SX_HOST_ONLY
+ * contexts; same carry semantics and result as sx_scan. */
+int sx_replay_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_file_id,
+                   int is_last_input_buffer, const sx_run* const* runs, const uint64_t* n_runs,
+                   sx_result** out);
+
+uint64_t          sx_result_count(const sx_result* r);
+const sx_finding* sx_result_findings(const sx_result* r);
+const uint8_t*    sx_result_arena(const sx_result* r, uint64_t* len);
+void              sx_result_free(sx_result* r);
+
+/* `Finding::print` for every finding of a result — src/finding.rs:112-155.
+ * n_inputs = ARGS.inputs.len(); radix 0 (no -t) | 'x' | 'd' | 'o'.  The caller
+ * frames the whole output with SX_OUTPUT_BOM and a final "\n"
+ * (src/main.rs:116,138).  *out is malloc'd; release with sx_free(). */
+#define SX_OUTPUT_BOM "\xEF\xBB\xBF"
+int sx_print_findings(const sx_ctx* ctx, const sx_result* r, int n_inputs, int radix,
+                      int no_metadata, uint8_t** out, uint64_t* out_len);
+
+int  sx_get_stats(const sx_ctx* ctx, sx_stats* out); /* of the last scan call */
+void sx_free(void* p);
+
+/* Synthetic input: fills device memory with the background
+ * byte stream, byte i = little-endian byte (i&7) of splitmix64-mix(seed + ((i>>3)+1)*phi). */
+int sx_fill_background_device(sx_ctx* ctx, void* device_bytes, uint64_t first_byte_index,
+                              uint64_t len, uint64_t seed);
+/* Device memory helpers so that callers without a HIP binding can stage data. */
+int sx_device_alloc(sx_ctx* ctx, uint64_t bytes, void** device_ptr);
+int sx_device_free(sx_ctx* ctx, void* device_ptr);
+int sx_device_upload(sx_ctx* ctx, void* device_dst, const void* host_src, uint64_t bytes);
+int sx_device_download(sx_ctx* ctx, void* host_dst, const void* device_src, uint64_t bytes);
+/* Read-only streaming pass over a device buffer (measured HBM read ceiling). */
+int sx_device_read_bandwidth(sx_ctx* ctx, const void* device_bytes, uint64_t len, int repeats,
+                             double* gbytes_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

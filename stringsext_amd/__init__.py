@@ -1,0 +1,268 @@
+"""stringsext_amd — MI355X-native replacement for stringsext's per-Mission byte-stream scan.
+
+This package is only a ctypes shim over the C-ABI in include/stringsext_amd.h
+(libstringsext_amd.so: hand-written HIP kernels for gfx950 + a C++ host that
+replays the reference's exact window semantics around the runs the device
+reports).  Names follow the reference: Mission (src/mission.rs:382-421),
+Finding / Precision (src/finding.rs:34-74).  There is no CPU fallback: creating a
+Scanner without a HIP device raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstringsext_amd.so")
+
+SX_OK, SX_E_INVALID, SX_E_NO_DEVICE, SX_E_HIP, SX_E_NOMEM, SX_E_STATE = 0, -1, -2, -3, -4, -5
+SX_HOST_ONLY = -1
+SX_OPT_GENERIC_KERNELS = 1
+ENC = {"x-user-defined": 0, "utf-8": 1, "utf-16le": 2, "utf-16be": 3, "koi8-r": 16, "ibm866": 17,
+       "iso-8859-2": 18, "iso-8859-5": 19, "iso-8859-15": 20, "windows-1251": 21, "windows-1252": 22}
+PRECISION = {0: "Before", 1: "Exact", 2: "After"}
+
+# every symbol include/stringsext_amd.h declares
+EXPORTS = ["sx_abi_version", "sx_create", "sx_destroy", "sx_last_error", "sx_scan", "sx_scan_device", "sx_reset",
+           "sx_device_runs", "sx_replay_runs", "sx_result_count", "sx_result_findings", "sx_result_arena",
+           "sx_result_free", "sx_print_findings", "sx_get_stats", "sx_free", "sx_fill_background_device",
+           "sx_device_alloc", "sx_device_free", "sx_device_upload", "sx_device_download",
+           "sx_device_read_bandwidth"]
+
+
+class Mission(C.Structure):
+    """sx_mission — the fields of `Mission` the scan reads."""
+    _fields_ = [("mission_id", C.c_uint8), ("encoding", C.c_uint8), ("chars_min_nb", C.c_uint8),
+                ("require_same_unicode_block", C.c_uint8), ("grep_char", C.c_int16),
+                ("print_encoding_as_ascii", C.c_uint8), ("reserved", C.c_uint8),
+                ("output_line_char_nb_max", C.c_uint32), ("af_lo", C.c_uint64), ("af_hi", C.c_uint64),
+                ("ubf", C.c_uint64), ("counter_offset", C.c_uint64)]
+
+    @classmethod
+    def from_dict(cls, d):
+        m = cls()
+        m.mission_id = d["mission_id"]
+        m.encoding = d["encoding"]
+        m.chars_min_nb = d["chars_min_nb"]
+        m.require_same_unicode_block = 1 if d["require_same_unicode_block"] else 0
+        m.grep_char = -1 if d["grep_char"] is None else d["grep_char"]
+        m.print_encoding_as_ascii = 1 if d["print_encoding_as_ascii"] else 0
+        m.output_line_char_nb_max = d["output_line_char_nb_max"]
+        m.af_lo = d["af"] & 0xFFFFFFFFFFFFFFFF
+        m.af_hi = d["af"] >> 64
+        m.ubf = d["ubf"]
+        m.counter_offset = d["counter_offset"]
+        return m
+
+
+class Finding(C.Structure):
+    _fields_ = [("position", C.c_uint64), ("str_off", C.c_uint32), ("str_len", C.c_uint32),
+                ("precision", C.c_uint8), ("completes_previous", C.c_uint8), ("mission_id", C.c_uint8),
+                ("reserved", C.c_uint8), ("input_file_id", C.c_int16), ("reserved2", C.c_uint16),
+                ("slice_index", C.c_uint32)]
+
+
+class Run(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("end", C.c_uint64), ("chars", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("bytes_scanned", C.c_uint64), ("run_records", C.c_uint64), ("replay_bytes", C.c_uint64),
+                ("findings", C.c_uint64), ("kernel_ms", C.c_double * 16), ("device_ms", C.c_double),
+                ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("replay_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+
+class Options(C.Structure):
+    _fields_ = [("subchunk_bytes", C.c_uint32), ("record_capacity", C.c_uint32), ("replay_threads", C.c_uint32),
+                ("flags", C.c_uint32)]
+
+
+class SxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"stringsext_amd error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libstringsext_amd.so; fail loudly if the HIP extension was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C stringsext_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, cp = C.c_void_p, C.c_uint64, C.c_char_p
+    L.sx_abi_version.restype = C.c_int
+    L.sx_create.argtypes = [C.POINTER(vp), C.POINTER(Mission), C.c_int, C.c_int, C.POINTER(Options)]
+    L.sx_destroy.argtypes = [vp]
+    L.sx_last_error.restype = cp
+    L.sx_last_error.argtypes = [vp]
+    L.sx_scan.argtypes = [vp, cp, u64, C.c_int, C.c_int, C.POINTER(vp)]
+    L.sx_scan_device.argtypes = [vp, vp, u64, C.c_int, C.c_int, C.POINTER(vp)]
+    L.sx_reset.argtypes = [vp]
+    L.sx_device_runs.argtypes = [vp, C.c_int, vp, u64, C.c_int, u64, C.POINTER(C.POINTER(Run)), C.POINTER(u64)]
+    L.sx_replay_runs.argtypes = [vp, cp, u64, C.c_int, C.c_int, C.POINTER(C.POINTER(Run)), C.POINTER(u64),
+                                 C.POINTER(vp)]
+    L.sx_result_count.restype = u64
+    L.sx_result_count.argtypes = [vp]
+    L.sx_result_findings.restype = C.POINTER(Finding)
+    L.sx_result_findings.argtypes = [vp]
+    L.sx_result_arena.restype = C.POINTER(C.c_uint8)
+    L.sx_result_arena.argtypes = [vp, C.POINTER(u64)]
+    L.sx_result_free.argtypes = [vp]
+    L.sx_print_findings.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
+                                    C.POINTER(u64)]
+    L.sx_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.sx_free.argtypes = [vp]
+    L.sx_fill_background_device.argtypes = [vp, vp, u64, u64, u64]
+    L.sx_device_alloc.argtypes = [vp, u64, C.POINTER(vp)]
+    L.sx_device_free.argtypes = [vp, vp]
+    L.sx_device_upload.argtypes = [vp, vp, cp, u64]
+    L.sx_device_download.argtypes = [vp, vp, vp, u64]
+    L.sx_device_read_bandwidth.argtypes = [vp, vp, u64, C.c_int, C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+class Result:
+    """Findings of one sx_scan call, in the reference merger's order (src/main.rs:118-136)."""
+
+    def __init__(self, scanner, handle):
+        self._s, self.h = scanner, handle
+
+    def __len__(self):
+        return lib().sx_result_count(self.h)
+
+    def findings(self):
+        L = lib()
+        n = L.sx_result_count(self.h)
+        v = L.sx_result_findings(self.h)
+        alen = C.c_uint64()
+        ap = L.sx_result_arena(self.h, C.byref(alen))
+        arena = C.string_at(ap, alen.value) if alen.value else b""
+        return [dict(position=v[i].position, precision=PRECISION[v[i].precision],
+                     s=arena[v[i].str_off:v[i].str_off + v[i].str_len].decode("utf-8"),
+                     completes=bool(v[i].completes_previous), mission_id=v[i].mission_id,
+                     file_id=v[i].input_file_id, slice_index=v[i].slice_index) for i in range(n)]
+
+    def printed(self, n_inputs=1, radix=None, no_metadata=False):
+        """Finding::print of every finding (src/finding.rs:112-155), without BOM / final newline."""
+        out = C.POINTER(C.c_uint8)()
+        n = C.c_uint64()
+        self._s._chk(lib().sx_print_findings(self._s.h, self.h, n_inputs, ord(radix) if radix else 0,
+                                             int(no_metadata), C.byref(out), C.byref(n)))
+        b = C.string_at(out, n.value)
+        lib().sx_free(out)
+        return b
+
+    def free(self):
+        if self.h:
+            lib().sx_result_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Scanner:
+    """One sx_ctx: N missions bound to one HIP device (device=SX_HOST_ONLY: replay stage only)."""
+
+    def __init__(self, mission_dicts, device=0, subchunk_bytes=0, record_capacity=0, generic_kernels=False):
+        L = lib()
+        self.n = len(mission_dicts)
+        self._ms = (Mission * self.n)(*[Mission.from_dict(d) for d in mission_dicts])
+        opt = Options(subchunk_bytes, record_capacity, 0, SX_OPT_GENERIC_KERNELS if generic_kernels else 0)
+        self.h = C.c_void_p()
+        rc = L.sx_create(C.byref(self.h), self._ms, self.n, device, C.byref(opt))
+        if rc != SX_OK:
+            self.h = None
+            raise SxError(rc, L.sx_last_error(None).decode())
+
+    def _chk(self, rc):
+        if rc != SX_OK:
+            raise SxError(rc, lib().sx_last_error(self.h).decode())
+
+    def scan(self, data, file_id=-1, is_last=False):
+        """sx_scan: replaces the loop src/main.rs:153-168 for one chunk held in host memory."""
+        data = bytes(data)
+        r = C.c_void_p()
+        self._chk(lib().sx_scan(self.h, data, len(data), file_id, int(is_last), C.byref(r)))
+        return Result(self, r)
+
+    def scan_device(self, dptr, length, file_id=-1, is_last=False):
+        r = C.c_void_p()
+        self._chk(lib().sx_scan_device(self.h, dptr, length, file_id, int(is_last), C.byref(r)))
+        return Result(self, r)
+
+    def replay_runs(self, data, runs_per_mission, file_id=-1, is_last=False):
+        """sx_replay_runs: stage B only; runs_per_mission[m] = [(start, end, chars), ...] sorted."""
+        data = bytes(data)
+        arrs = [(Run * max(1, len(rs)))(*[Run(*t) for t in rs]) for rs in runs_per_mission]
+        ptrs = (C.POINTER(Run) * self.n)(*[C.cast(a, C.POINTER(Run)) for a in arrs])
+        ns = (C.c_uint64 * self.n)(*[len(rs) for rs in runs_per_mission])
+        r = C.c_void_p()
+        self._chk(lib().sx_replay_runs(self.h, data, len(data), file_id, int(is_last), ptrs, ns, C.byref(r)))
+        return Result(self, r)
+
+    def device_runs(self, mission_index, dptr, length, stream_parity=0, min_chars=1):
+        runs = C.POINTER(Run)()
+        n = C.c_uint64()
+        self._chk(lib().sx_device_runs(self.h, mission_index, dptr, length, stream_parity, min_chars,
+                                       C.byref(runs), C.byref(n)))
+        out = [(runs[i].start, runs[i].end, runs[i].chars) for i in range(n.value)]
+        lib().sx_free(runs)
+        return out
+
+    def reset(self):
+        self._chk(lib().sx_reset(self.h))
+
+    def stats(self):
+        s = Stats()
+        self._chk(lib().sx_get_stats(self.h, C.byref(s)))
+        return s
+
+    # device memory helpers
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(lib().sx_device_alloc(self.h, nbytes, C.byref(p)))
+        return p
+
+    def free(self, dptr):
+        self._chk(lib().sx_device_free(self.h, dptr))
+
+    def upload(self, dptr, data):
+        data = bytes(data)
+        self._chk(lib().sx_device_upload(self.h, dptr, data, len(data)))
+
+    def download(self, dptr, nbytes):
+        b = C.create_string_buffer(nbytes)
+        self._chk(lib().sx_device_download(self.h, b, dptr, nbytes))
+        return b.raw
+
+    def fill_background(self, dptr, first_index, nbytes, seed=0x5EED5EED5EED5EED):
+        self._chk(lib().sx_fill_background_device(self.h, dptr, first_index, nbytes, seed))
+
+    def read_bandwidth(self, dptr, nbytes, repeats=5):
+        g = C.c_double()
+        self._chk(lib().sx_device_read_bandwidth(self.h, dptr, nbytes, repeats, C.byref(g)))
+        return g.value
+
+    def close(self):
+        if self.h:
+            lib().sx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+OUTPUT_BOM = b"\xEF\xBB\xBF"

@@ -1,0 +1,483 @@
+// sx_api.cpp — the C-ABI of include/stringsext_amd.h: context, HIP resources (one stream
+// per Mission, the reference's one thread per Mission: src/main.rs:97,151), the two scan
+// entry points that replace the loop src/main.rs:153-168, and the lower-level stages.
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "sx_host.hpp"
+
+using namespace sx;
+
+namespace {
+
+std::string g_create_error;
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+struct MissionDev {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevRun* d_recs = nullptr;
+    uint32_t* d_counters = nullptr;
+    uint32_t capacity = 0;
+};
+
+}  // namespace
+
+struct sx_result {
+    Result r;
+};
+
+struct sx_ctx {
+    std::vector<Mission> missions;
+    std::vector<ScannerState> states;
+    std::vector<MissionDev> dev;
+    bool host_only = false;
+    int device = -1;
+    sx_options opt{};
+    std::string err;
+    sx_stats stats{};
+    uint8_t* d_input = nullptr;  // staging for host input
+    uint64_t d_input_cap = 0;
+    uint64_t ondemand_fetches = 0;
+};
+
+#define HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            return SX_E_HIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+namespace {
+
+// Device-resident chunk of which only some byte ranges were downloaded.
+class SparseDeviceBytes : public ByteView {
+public:
+    SparseDeviceBytes(sx_ctx* ctx, const uint8_t* d_base) : ctx_(ctx), d_base_(d_base) {}
+    void add(uint64_t lo, uint64_t hi, const uint8_t* p) { segs_.push_back({ lo, hi, p }); }
+    const uint8_t* span(uint64_t off, size_t n) override {
+        // segments are sorted and disjoint
+        size_t a = 0, b = segs_.size();
+        while (a < b) {
+            size_t mid = (a + b) / 2;
+            if (segs_[mid].hi <= off) a = mid + 1; else b = mid;
+        }
+        if (a < segs_.size() && segs_[a].lo <= off && off + n <= segs_[a].hi) return segs_[a].p + (off - segs_[a].lo);
+        // rare: the replay ran further than planned — fetch exactly what is asked for
+        std::lock_guard<std::mutex> g(mu_);
+        extra_.emplace_back(n);
+        if (hipMemcpy(extra_.back().data(), d_base_ + off, n, hipMemcpyDeviceToHost) != hipSuccess)
+            memset(extra_.back().data(), 0, n);
+        ctx_->ondemand_fetches++;
+        return extra_.back().data();
+    }
+
+private:
+    struct Seg { uint64_t lo, hi; const uint8_t* p; };
+    sx_ctx* ctx_;
+    const uint8_t* d_base_;
+    std::vector<Seg> segs_;
+    std::deque<std::vector<uint8_t>> extra_;
+    std::mutex mu_;
+};
+
+int ensure_capacity(sx_ctx* ctx, MissionDev& d, uint32_t cap) {
+    if (d.capacity >= cap) return SX_OK;
+    if (d.d_recs) HIP_TRY(ctx, hipFree(d.d_recs));
+    d.d_recs = nullptr; d.capacity = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&d.d_recs, (size_t)cap * sizeof(DevRun)));
+    d.capacity = cap;
+    return SX_OK;
+}
+
+// Stage A for a set of missions: launch every mission's kernel on its own stream, then
+// collect, growing a record buffer and re-running that mission if it overflowed.
+int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
+                const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars,
+                std::vector<std::vector<sx_run>>* out) {
+    out->assign(which.size(), {});
+    if (len == 0) return SX_OK;
+    uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 64u * 1024u;
+    sub = std::max<uint32_t>(kTileBytes, sub / kTileBytes * kTileBytes);
+    const double t0 = now_ms();
+    std::vector<bool> pending(which.size(), true);
+    for (int round = 0; round < 8; round++) {
+        bool any = false;
+        for (size_t k = 0; k < which.size(); k++) {
+            if (!pending[k]) continue;
+            any = true;
+            const Mission& m = ctx->missions[which[k]];
+            MissionDev& d = ctx->dev[which[k]];
+            ScanParams p = m.proto;
+            p.data = d_bytes; p.len = len; p.subchunk = sub; p.parity = parity[k];
+            p.min_chars = (uint32_t)std::min<uint64_t>(min_chars[k], kRecCharsMask);
+            if (p.min_chars == 0) p.min_chars = 1;
+            p.cand_bytes = std::min<uint32_t>(p.min_chars * (m.is_utf16() ? 2u : 1u), 17u);
+            p.capacity = d.capacity; p.recs = d.d_recs; p.counters = d.d_counters;
+            HIP_TRY(ctx, hipMemsetAsync(d.d_counters, 0, 4 * sizeof(uint32_t), d.stream));
+            HIP_TRY(ctx, hipEventRecord(d.ev0, d.stream));
+            HIP_TRY(ctx, launch_scan(m.kind, p, d.stream));
+            HIP_TRY(ctx, hipEventRecord(d.ev1, d.stream));
+        }
+        if (!any) break;
+        for (size_t k = 0; k < which.size(); k++) {
+            if (!pending[k]) continue;
+            MissionDev& d = ctx->dev[which[k]];
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+            float ms = 0;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, d.ev0, d.ev1));
+            if (which[k] < 16) ctx->stats.kernel_ms[which[k]] = ms;
+            uint32_t counters[4] = { 0, 0, 0, 0 };
+            HIP_TRY(ctx, hipMemcpy(counters, d.d_counters, sizeof counters, hipMemcpyDeviceToHost));
+            if (counters[0] > d.capacity) {  // overflow: grow and run this mission again
+                int rc = ensure_capacity(ctx, d, counters[0] + counters[0] / 8 + 1024);
+                if (rc != SX_OK) return rc;
+                continue;
+            }
+            std::vector<DevRun> recs(counters[0]);
+            if (counters[0])
+                HIP_TRY(ctx, hipMemcpy(recs.data(), d.d_recs, (size_t)counters[0] * sizeof(DevRun), hipMemcpyDeviceToHost));
+            merge_device_runs(recs.data(), recs.size(), min_chars[k], &(*out)[k]);
+            ctx->stats.run_records += (*out)[k].size();
+            ctx->stats.bytes_scanned += len;
+            pending[k] = false;
+        }
+    }
+    for (size_t k = 0; k < which.size(); k++)
+        if (pending[k]) { ctx->err = "device run-record buffer kept overflowing"; return SX_E_NOMEM; }
+    ctx->stats.device_ms += now_ms() - t0;
+    return SX_OK;
+}
+
+int replay_all(sx_ctx* ctx, ByteView& bytes, uint64_t len, int file_id, bool is_last,
+               const std::vector<std::vector<sx_run>>& runs, sx_result** out) {
+    const double t0 = now_ms();
+    const size_t nm = ctx->missions.size();
+    std::vector<MissionFindings> per(nm);
+    auto work = [&](size_t k) {
+        replay_chunk(ctx->missions[k], ctx->states[k], bytes, len, file_id, is_last, runs[k].data(), runs[k].size(),
+                     &per[k]);
+    };
+    if (nm == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < nm; k++) th.emplace_back(work, k);
+        for (auto& t : th) t.join();
+    }
+    sx_result* r = new sx_result();
+    merge_findings(per, &r->r);
+    for (auto& mf : per) ctx->stats.replay_bytes += mf.replay_bytes;
+    ctx->stats.findings += r->r.findings.size();
+    ctx->stats.replay_ms += now_ms() - t0;
+    *out = r;
+    return SX_OK;
+}
+
+void begin_call(sx_ctx* ctx) {
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->err.clear();
+}
+
+}  // namespace
+
+extern "C" {
+
+int sx_abi_version(void) { return SX_ABI_VERSION; }
+
+int sx_create(sx_ctx** out, const sx_mission* missions, int n_missions, int hip_device, const sx_options* opt) {
+    if (!out || !missions || n_missions <= 0 || n_missions > 26) { g_create_error = "bad arguments"; return SX_E_INVALID; }
+    sx_ctx* ctx = new sx_ctx();
+    if (opt) ctx->opt = *opt;
+    ctx->missions.resize((size_t)n_missions);
+    ctx->states.resize((size_t)n_missions);
+    for (int k = 0; k < n_missions; k++) {
+        std::string err;
+        int rc = Mission::from_c(missions[k], (ctx->opt.flags & SX_OPT_GENERIC_KERNELS) != 0, &ctx->missions[(size_t)k], &err);
+        if (rc != SX_OK) { g_create_error = "mission " + std::to_string(k) + ": " + err; delete ctx; return rc; }
+        ctx->states[(size_t)k].reset(ctx->missions[(size_t)k]);
+    }
+    if (hip_device == SX_HOST_ONLY) { ctx->host_only = true; *out = ctx; return SX_OK; }
+
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0 || hip_device < 0 || hip_device >= n_dev) {
+        g_create_error = std::string("no usable HIP device (hipGetDeviceCount: ")
+                         + (e == hipSuccess ? "ok" : hipGetErrorString(e)) + ", devices=" + std::to_string(n_dev)
+                         + ", requested=" + std::to_string(hip_device) + "); the scan only runs on the GPU";
+        delete ctx;
+        return SX_E_NO_DEVICE;
+    }
+    ctx->device = hip_device;
+    auto fail = [&](const char* what, hipError_t err) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        sx_destroy(ctx);
+        return SX_E_HIP;
+    };
+    if ((e = hipSetDevice(hip_device)) != hipSuccess) return fail("hipSetDevice", e);
+    ctx->dev.resize((size_t)n_missions);
+    const uint32_t cap = ctx->opt.record_capacity ? ctx->opt.record_capacity : (1u << 20);
+    for (auto& d : ctx->dev) {
+        if ((e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+        if ((e = hipEventCreate(&d.ev0)) != hipSuccess) return fail("hipEventCreate", e);
+        if ((e = hipEventCreate(&d.ev1)) != hipSuccess) return fail("hipEventCreate", e);
+        if ((e = hipMalloc((void**)&d.d_counters, 4 * sizeof(uint32_t))) != hipSuccess) return fail("hipMalloc", e);
+        if ((e = hipMalloc((void**)&d.d_recs, (size_t)cap * sizeof(DevRun))) != hipSuccess) return fail("hipMalloc", e);
+        d.capacity = cap;
+    }
+    *out = ctx;
+    return SX_OK;
+}
+
+void sx_destroy(sx_ctx* ctx) {
+    if (!ctx) return;
+    if (!ctx->host_only && ctx->device >= 0) {
+        (void)hipSetDevice(ctx->device);
+        for (auto& d : ctx->dev) {
+            if (d.stream) (void)hipStreamSynchronize(d.stream);
+            if (d.d_recs) (void)hipFree(d.d_recs);
+            if (d.d_counters) (void)hipFree(d.d_counters);
+            if (d.ev0) (void)hipEventDestroy(d.ev0);
+            if (d.ev1) (void)hipEventDestroy(d.ev1);
+            if (d.stream) (void)hipStreamDestroy(d.stream);
+        }
+        if (ctx->d_input) (void)hipFree(ctx->d_input);
+    }
+    delete ctx;
+}
+
+const char* sx_last_error(const sx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int sx_reset(sx_ctx* ctx) {
+    if (!ctx) return SX_E_INVALID;
+    for (size_t k = 0; k < ctx->missions.size(); k++) ctx->states[k].reset(ctx->missions[k]);
+    return SX_OK;
+}
+
+static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len, int file_id,
+                       int is_last, sx_result** out) {
+    const double t_begin = now_ms();
+    const size_t nm = ctx->missions.size();
+    std::vector<int> which(nm);
+    std::vector<uint32_t> parity(nm);
+    std::vector<uint64_t> minc(nm);
+    for (size_t k = 0; k < nm; k++) {
+        which[k] = (int)k;
+        parity[k] = (uint32_t)(ctx->states[k].stream_bytes & 1);
+        minc[k] = ctx->missions[k].long_run;
+    }
+    std::vector<std::vector<sx_run>> runs;
+    int rc = device_runs(ctx, which, d_bytes, len, parity, minc, &runs);
+    if (rc != SX_OK) return rc;
+
+    if (host_bytes) {
+        HostBytes view(host_bytes);
+        rc = replay_all(ctx, view, len, file_id, is_last != 0, runs, out);
+    } else {
+        // download only what the replay will look at
+        const double t0 = now_ms();
+        std::vector<std::pair<uint64_t, uint64_t>> rg;
+        for (size_t k = 0; k < nm; k++) replay_ranges(ctx->missions[k], ctx->states[k], len, runs[k].data(), runs[k].size(), &rg);
+        std::sort(rg.begin(), rg.end());
+        std::vector<std::pair<uint64_t, uint64_t>> mg;
+        for (auto& r : rg) {
+            if (!mg.empty() && r.first <= mg.back().second) mg.back().second = std::max(mg.back().second, r.second);
+            else mg.push_back(r);
+        }
+        // split long ranges so that one gather wavefront never copies more than 64 KiB
+        std::vector<uint64_t> seg_src, seg_dst;
+        std::vector<uint32_t> seg_len;
+        uint64_t total = 0;
+        for (auto& r : mg)
+            for (uint64_t a = r.first; a < r.second; a += 65536) {
+                const uint64_t n = std::min<uint64_t>(65536, r.second - a);
+                seg_src.push_back(a); seg_dst.push_back(total); seg_len.push_back((uint32_t)n);
+                total += n;
+            }
+        std::vector<uint8_t> host(total ? total : 1);
+        SparseDeviceBytes view(ctx, d_bytes);
+        if (total) {
+            hipStream_t s = ctx->dev[0].stream;
+            uint8_t* d_out = nullptr;
+            uint64_t *d_src = nullptr, *d_dst = nullptr;
+            uint32_t* d_len = nullptr;
+            const size_t ns = seg_src.size();
+            HIP_TRY(ctx, hipMalloc((void**)&d_out, total));
+            HIP_TRY(ctx, hipMalloc((void**)&d_src, ns * 8));
+            HIP_TRY(ctx, hipMalloc((void**)&d_dst, ns * 8));
+            HIP_TRY(ctx, hipMalloc((void**)&d_len, ns * 4));
+            HIP_TRY(ctx, hipMemcpyAsync(d_src, seg_src.data(), ns * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync(d_dst, seg_dst.data(), ns * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync(d_len, seg_len.data(), ns * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, launch_gather(d_bytes, d_out, d_src, d_dst, d_len, (uint32_t)ns, s));
+            HIP_TRY(ctx, hipMemcpyAsync(host.data(), d_out, total, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            (void)hipFree(d_out); (void)hipFree(d_src); (void)hipFree(d_dst); (void)hipFree(d_len);
+            uint64_t off = 0;
+            for (auto& r : mg) { view.add(r.first, r.second, host.data() + off); off += r.second - r.first; }
+        }
+        ctx->stats.d2h_ms += now_ms() - t0;
+        rc = replay_all(ctx, view, len, file_id, is_last != 0, runs, out);
+    }
+    ctx->stats.total_ms = now_ms() - t_begin;
+    return rc;
+}
+
+int sx_scan(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_file_id, int is_last_input_buffer,
+            sx_result** out) {
+    if (!ctx || !out || (!bytes && len)) return SX_E_INVALID;
+    begin_call(ctx);
+    if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const double t0 = now_ms();
+    if (len > ctx->d_input_cap) {
+        if (ctx->d_input) HIP_TRY(ctx, hipFree(ctx->d_input));
+        ctx->d_input = nullptr; ctx->d_input_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_input, len));
+        ctx->d_input_cap = len;
+    }
+    if (len) HIP_TRY(ctx, hipMemcpy(ctx->d_input, bytes, len, hipMemcpyHostToDevice));
+    const double h2d = now_ms() - t0;
+    int rc = scan_common(ctx, bytes ? bytes : (const uint8_t*)"", ctx->d_input, len, input_file_id, is_last_input_buffer, out);
+    ctx->stats.h2d_ms = h2d;
+    ctx->stats.total_ms += h2d;
+    return rc;
+}
+
+int sx_scan_device(sx_ctx* ctx, const void* device_bytes, uint64_t len, int input_file_id, int is_last_input_buffer,
+                   sx_result** out) {
+    if (!ctx || !out || (!device_bytes && len)) return SX_E_INVALID;
+    begin_call(ctx);
+    if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return scan_common(ctx, nullptr, (const uint8_t*)device_bytes, len, input_file_id, is_last_input_buffer, out);
+}
+
+int sx_device_runs(sx_ctx* ctx, int mission_index, const void* device_bytes, uint64_t len, int stream_parity,
+                   uint64_t min_chars, sx_run** runs, uint64_t* n_runs) {
+    if (!ctx || !runs || !n_runs || mission_index < 0 || (size_t)mission_index >= ctx->missions.size()) return SX_E_INVALID;
+    begin_call(ctx);
+    if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<std::vector<sx_run>> out;
+    int rc = device_runs(ctx, { mission_index }, (const uint8_t*)device_bytes, len, { (uint32_t)(stream_parity & 1) },
+                         { min_chars }, &out);
+    if (rc != SX_OK) return rc;
+    *n_runs = out[0].size();
+    *runs = (sx_run*)malloc(sizeof(sx_run) * (out[0].size() ? out[0].size() : 1));
+    if (!*runs) return SX_E_NOMEM;
+    memcpy(*runs, out[0].data(), sizeof(sx_run) * out[0].size());
+    return SX_OK;
+}
+
+int sx_replay_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_file_id, int is_last_input_buffer,
+                   const sx_run* const* runs, const uint64_t* n_runs, sx_result** out) {
+    if (!ctx || !out || (!bytes && len) || !runs || !n_runs) return SX_E_INVALID;
+    begin_call(ctx);
+    std::vector<std::vector<sx_run>> r(ctx->missions.size());
+    for (size_t k = 0; k < r.size(); k++) r[k].assign(runs[k], runs[k] + n_runs[k]);
+    HostBytes view(bytes ? bytes : (const uint8_t*)"");
+    return replay_all(ctx, view, len, input_file_id, is_last_input_buffer != 0, r, out);
+}
+
+uint64_t sx_result_count(const sx_result* r) { return r ? r->r.findings.size() : 0; }
+const sx_finding* sx_result_findings(const sx_result* r) { return r ? r->r.findings.data() : nullptr; }
+const uint8_t* sx_result_arena(const sx_result* r, uint64_t* len) {
+    if (!r) return nullptr;
+    if (len) *len = r->r.arena.size();
+    return (const uint8_t*)r->r.arena.data();
+}
+void sx_result_free(sx_result* r) { delete r; }
+
+int sx_print_findings(const sx_ctx* ctx, const sx_result* r, int n_inputs, int radix, int no_metadata, uint8_t** out,
+                      uint64_t* out_len) {
+    if (!ctx || !r || !out || !out_len) return SX_E_INVALID;
+    if (radix != 0 && radix != 'x' && radix != 'd' && radix != 'o') return SX_E_INVALID;
+    std::string s;
+    print_findings(ctx->missions, r->r, n_inputs, radix, no_metadata != 0, &s);
+    *out = (uint8_t*)malloc(s.size() ? s.size() : 1);
+    if (!*out) return SX_E_NOMEM;
+    memcpy(*out, s.data(), s.size());
+    *out_len = s.size();
+    return SX_OK;
+}
+
+int sx_get_stats(const sx_ctx* ctx, sx_stats* out) {
+    if (!ctx || !out) return SX_E_INVALID;
+    *out = ctx->stats;
+    return SX_OK;
+}
+
+void sx_free(void* p) { free(p); }
+
+int sx_fill_background_device(sx_ctx* ctx, void* device_bytes, uint64_t first_byte_index, uint64_t len, uint64_t seed) {
+    if (!ctx || ctx->host_only) return SX_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_fill_background((uint8_t*)device_bytes, first_byte_index, len, seed, ctx->dev[0].stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->dev[0].stream));
+    return SX_OK;
+}
+
+int sx_device_alloc(sx_ctx* ctx, uint64_t bytes, void** device_ptr) {
+    if (!ctx || ctx->host_only || !device_ptr) return SX_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(device_ptr, bytes ? bytes : 1));
+    return SX_OK;
+}
+int sx_device_free(sx_ctx* ctx, void* device_ptr) {
+    if (!ctx || ctx->host_only) return SX_E_STATE;
+    HIP_TRY(ctx, hipFree(device_ptr));
+    return SX_OK;
+}
+int sx_device_upload(sx_ctx* ctx, void* device_dst, const void* host_src, uint64_t bytes) {
+    if (!ctx || ctx->host_only) return SX_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(device_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return SX_OK;
+}
+int sx_device_download(sx_ctx* ctx, void* host_dst, const void* device_src, uint64_t bytes) {
+    if (!ctx || ctx->host_only) return SX_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(host_dst, device_src, bytes, hipMemcpyDeviceToHost));
+    return SX_OK;
+}
+
+int sx_device_read_bandwidth(sx_ctx* ctx, const void* device_bytes, uint64_t len, int repeats, double* gbytes_per_s) {
+    if (!ctx || ctx->host_only || !gbytes_per_s || repeats <= 0) return SX_E_STATE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    MissionDev& d = ctx->dev[0];
+    uint64_t* d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_out, 8));
+    HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 8, d.stream));
+    HIP_TRY(ctx, launch_read_sum((const uint8_t*)device_bytes, len, d_out, d.stream));  // warm-up
+    float best = 1e30f;
+    for (int i = 0; i < repeats; i++) {
+        HIP_TRY(ctx, hipEventRecord(d.ev0, d.stream));
+        HIP_TRY(ctx, launch_read_sum((const uint8_t*)device_bytes, len, d_out, d.stream));
+        HIP_TRY(ctx, hipEventRecord(d.ev1, d.stream));
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, d.ev0, d.ev1));
+        if (ms < best) best = ms;
+    }
+    (void)hipFree(d_out);
+    *gbytes_per_s = (double)(len / 16 * 16) / (best * 1e-3) / 1e9;
+    return SX_OK;
+}
+
+}  // extern "C"

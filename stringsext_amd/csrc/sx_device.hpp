@@ -1,0 +1,65 @@
+// sx_device.hpp — interface between the host code and the HIP translation unit.
+//
+// Stage A of the scan: for one Mission, the device classifies every input byte
+// ("does this byte belong to a valid character of the Mission's encoding that
+// passes the af/ubf filter?", the work of encoding_rs' decoders plus
+// Utf8Filter::pass_af_filter/pass_ubf_filter, reference src/mission.rs:333-348)
+// and reports every maximal stretch of such bytes that holds enough characters
+// to be able to produce a Finding (reference src/helper.rs:315-322: a string
+// needs >= chars_min_nb chars, or output_line_char_nb_max to be cut).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace sx {
+
+// One wavefront streams `subchunk` consecutive bytes in 1 KiB tiles.
+constexpr uint32_t kTileBytes = 1024;
+
+// Device run record (16 bytes).
+struct DevRun {
+    uint64_t start;        // chunk-relative offset of the first byte
+    uint32_t len;          // bytes
+    uint32_t chars_flags;  // low 30 bits: characters (saturating); flags below
+};
+constexpr uint32_t kRecStartOpen = 0x80000000u;  // stretch begins at a sub-chunk start (may continue a previous one)
+constexpr uint32_t kRecEndOpen = 0x40000000u;    // stretch reaches the sub-chunk end (may be continued)
+constexpr uint32_t kRecCharsMask = 0x3FFFFFFFu;
+
+enum ClassifierKind : uint32_t {
+    kClsSingleByteLut = 0,  // x-user-defined and WHATWG single-byte tables: 256-entry accept LUT
+    kClsUtf8Lut = 1,        // UTF-8, any af/ubf: 256-entry class LUT + SWAR validity
+    kClsUtf16Lut = 2,       // UTF-16LE/BE, any af/ubf: two 256-entry LUTs (high byte / low byte)
+    kClsUtf8Range2 = 3,     // UTF-8, af = one range, ubf = one range of 2-byte leads: pure SWAR, no LUT
+    kClsUtf16Range = 4,     // UTF-16, af = one range, ubf = one range below U+0800, no astral: pure SWAR
+    kClsSingleByteRange = 5 // single byte, accept set = one range of bytes < 0x80 (+ all/none of >= 0x80)
+};
+
+struct ScanParams {
+    const uint8_t* data;   // device pointer, chunk byte 0
+    uint64_t len;          // chunk bytes
+    uint32_t subchunk;     // bytes per wavefront (multiple of kTileBytes)
+    uint32_t min_chars;    // report stretches with >= min_chars characters
+    uint32_t cand_bytes;   // a stretch shorter than this many bytes can never qualify (2..17)
+    uint32_t parity;       // UTF-16: (stream offset of byte 0) & 1
+    uint32_t big_endian;   // UTF-16BE
+    uint32_t capacity;     // record slots
+    DevRun* recs;
+    uint32_t* counters;    // [0] records appended (may exceed capacity = overflow), [1] slow-path tiles
+    // range classifiers
+    uint32_t a_lo, a_hi;   // accepted ASCII / single-unit range (inclusive)
+    uint32_t u_lo, u_hi;   // UTF-8: accepted 2-byte lead range; UTF-16: accepted unit range [u_lo,u_hi]
+    uint32_t high_all;     // single-byte range: every byte >= 0x80 accepted
+    // table classifiers
+    uint8_t lut[512];
+};
+
+hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t stream);
+hipError_t launch_fill_background(uint8_t* dst, uint64_t first_index, uint64_t len, uint64_t seed,
+                                  hipStream_t stream);
+hipError_t launch_read_sum(const uint8_t* src, uint64_t len, uint64_t* out, hipStream_t stream);
+// dst[seg_dst[i] .. ] = src[seg_src[i] .. seg_src[i]+seg_len[i]) for i < n
+hipError_t launch_gather(const uint8_t* src, uint8_t* dst, const uint64_t* seg_src, const uint64_t* seg_dst,
+                         const uint32_t* seg_len, uint32_t n, hipStream_t stream);
+
+}  // namespace sx

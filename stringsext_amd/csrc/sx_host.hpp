@@ -1,0 +1,191 @@
+// sx_host.hpp — host side of the scan (C++17).  Mirrors the reference's operator
+// interface for the path: Mission (src/mission.rs:382-421), Utf8Filter (:307-349),
+// Decoder (encoding_rs 0.8.34 as used at src/finding_collection.rs:138-143),
+// SplitStr (src/helper.rs:58-433), ScannerState (src/scanner.rs:40-89),
+// Finding / Precision (src/finding.rs:34-74), FindingCollection::from
+// (src/finding_collection.rs:84-342).
+//
+// Stage B: the device reports where a Finding can arise (long runs); the code here
+// re-runs the reference's exact sequential semantics over just those windows, so that
+// positions, precision marks, line cuts and `+` continuations are bit-exact.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/stringsext_amd.h"
+#include "sx_device.hpp"
+
+namespace sx {
+
+constexpr size_t kInputBufLen = 4096;  // INPUT_BUF_LEN, src/input.rs:22
+
+// ---------------------------------------------------------------------------------------
+// Utf8Filter — src/mission.rs:307-349
+// ---------------------------------------------------------------------------------------
+struct Utf8Filter {
+    uint64_t af_lo = 0, af_hi = 0, ubf = 0;
+    int grep_char = -1;
+    bool pass_af_filter(uint8_t b) const {
+        b &= 127;
+        return ((b < 64 ? af_lo >> b : af_hi >> (b - 64)) & 1) != 0;
+    }
+    bool pass_ubf_filter(uint8_t b) const { return ((ubf >> (b & 0x3F)) & 1) != 0; }
+    // the filter applied to a whole character, via its UTF-8 lead byte
+    bool pass_lead(uint8_t lead) const { return (lead & 0x80) ? pass_ubf_filter(lead) : pass_af_filter(lead); }
+};
+
+// ---------------------------------------------------------------------------------------
+// Mission — src/mission.rs:382-421, plus what the device needs for it
+// ---------------------------------------------------------------------------------------
+struct Mission {
+    sx_mission c{};
+    Utf8Filter filter;
+    size_t q = 64;          // output_line_char_nb_max
+    size_t window = 128;    // decoder_input_window = 2*q, src/finding_collection.rs:120
+    uint32_t long_run = 4;  // min(chars_min_nb, q): fewer chars can never yield a Finding
+    bool is_utf16() const { return c.encoding == SX_ENC_UTF16LE || c.encoding == SX_ENC_UTF16BE; }
+    const char* encoding_name() const;
+
+    // device classifier for this mission
+    ClassifierKind kind = kClsSingleByteLut;
+    ScanParams proto{};  // a_lo.., lut filled in; data/len/recs set per launch
+    static int from_c(const sx_mission& in, bool force_generic, Mission* out, std::string* err);
+};
+
+// ---------------------------------------------------------------------------------------
+// Decoder — encoding_rs `Decoder` restricted to decode_to_str_without_replacement
+// ---------------------------------------------------------------------------------------
+enum class DecoderResult { InputEmpty, OutputFull, Malformed };
+struct DecodeStep {
+    DecoderResult result;
+    size_t read, written;
+};
+
+class Decoder {
+public:
+    explicit Decoder(int encoding = SX_ENC_UTF8) { reset(encoding); }
+    void reset(int encoding);
+    int encoding() const { return enc_; }
+    Decoder new_decoder_without_bom_handling() const { return Decoder(enc_); }
+    DecodeStep decode_to_str_without_replacement(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, bool last);
+
+private:
+    DecodeStep utf8(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, bool last);
+    DecodeStep utf16(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, bool last);
+    DecodeStep single(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+    int enc_ = SX_ENC_UTF8;
+    // UTF-8
+    uint32_t cp_ = 0;
+    uint8_t seen_ = 0, needed_ = 0, lower_ = 0x80, upper_ = 0xBF;
+    // UTF-16
+    int lead_byte_ = -1;
+    uint16_t lead_surrogate_ = 0;
+    bool pending_bmp_ = false;
+    // single byte
+    const uint16_t* table_ = nullptr;
+};
+const uint16_t* single_byte_table(int encoding);  // nullptr for x-user-defined / non-table encodings
+const char* encoding_name(int encoding);
+
+// ---------------------------------------------------------------------------------------
+// SplitStr — src/helper.rs:58-433
+// ---------------------------------------------------------------------------------------
+struct SplitStrResult {
+    const uint8_t* s = nullptr;
+    size_t len = 0;
+    bool s_completes_previous_s = false, s_is_maybe_cut = false, s_is_to_be_filtered_again = false;
+    bool s_satisfies_min_char_rule = false, s_satisfies_grep_char_rule = false;
+};
+class SplitStr {
+public:
+    SplitStr(const uint8_t* inp, size_t len, uint8_t chars_min_nb, bool require_same_unicode_block,
+             bool last_s_was_maybe_cut, bool invalid_bytes_after_inp, const Utf8Filter& f, size_t s_char_nb_max)
+        : inp_start_(inp), inp_end_(inp + len), p_(inp), chars_min_nb_(chars_min_nb),
+          same_block_(require_same_unicode_block), last_cut_(last_s_was_maybe_cut),
+          invalid_after_(invalid_bytes_after_inp), f_(f), max_(s_char_nb_max) {}
+    bool next(SplitStrResult* out);
+
+private:
+    const uint8_t *inp_start_, *inp_end_, *p_;
+    uint8_t chars_min_nb_;
+    bool same_block_, last_cut_, invalid_after_;
+    Utf8Filter f_;
+    size_t max_;
+};
+
+// ---------------------------------------------------------------------------------------
+// ScannerState — src/scanner.rs:40-89
+// ---------------------------------------------------------------------------------------
+struct ScannerState {
+    Decoder decoder;
+    std::string last_scan_run_leftover;
+    bool last_run_str_was_printed_and_is_maybe_cut_str = false;
+    uint64_t consumed_bytes = 0;  // starts at counter_offset
+    uint64_t stream_bytes = 0;    // bytes fed to the decoder since it was created (UTF-16 unit parity)
+    void reset(const Mission& m) {
+        decoder.reset(m.c.encoding);
+        last_scan_run_leftover.clear();
+        last_run_str_was_printed_and_is_maybe_cut_str = false;
+        consumed_bytes = m.c.counter_offset;
+        stream_bytes = 0;
+    }
+    bool clean() const { return last_scan_run_leftover.empty() && !last_run_str_was_printed_and_is_maybe_cut_str; }
+};
+
+// ---------------------------------------------------------------------------------------
+// Bytes of the current chunk, possibly only partly present on the host
+// ---------------------------------------------------------------------------------------
+class ByteView {
+public:
+    virtual ~ByteView() {}
+    // pointer to bytes [off, off+n) of the chunk; n <= 4096; the pointer stays valid until
+    // the next call from the same thread
+    virtual const uint8_t* span(uint64_t off, size_t n) = 0;
+};
+class HostBytes : public ByteView {
+public:
+    explicit HostBytes(const uint8_t* p) : p_(p) {}
+    const uint8_t* span(uint64_t off, size_t) override { return p_ + off; }
+private:
+    const uint8_t* p_;
+};
+
+// ---------------------------------------------------------------------------------------
+// Findings of one mission for one chunk
+// ---------------------------------------------------------------------------------------
+struct MissionFindings {
+    std::vector<sx_finding> v;  // str_off relative to `arena`
+    std::string arena;
+    uint64_t replay_bytes = 0;
+};
+
+// Exact replay of FindingCollection::from over the windows that matter.
+// `st` is the carried ScannerState (exact on entry, exact on return).
+void replay_chunk(const Mission& m, ScannerState& st, ByteView& bytes, uint64_t len, int input_file_id,
+                  bool is_last_input_buffer, const sx_run* runs, uint64_t n_runs, MissionFindings* out);
+
+// Byte ranges of the chunk that replay_chunk() will (very likely) touch, for sparse
+// download of device-resident input.  Appends [lo,hi) pairs (unsorted, may overlap).
+void replay_ranges(const Mission& m, const ScannerState& st, uint64_t len, const sx_run* runs, uint64_t n_runs,
+                   std::vector<std::pair<uint64_t, uint64_t>>* ranges);
+
+// Turn raw device records (any order, sub-chunk pieces flagged open) into maximal runs
+// with >= min_chars characters, sorted by start.
+void merge_device_runs(const DevRun* recs, size_t n, uint64_t min_chars, std::vector<sx_run>* out);
+
+// k-way merge in the reference's order: slice by slice, then (position, mission_id)
+// — src/main.rs:118-136, src/finding.rs:92-109.
+struct Result {
+    std::vector<sx_finding> findings;
+    std::string arena;
+};
+void merge_findings(std::vector<MissionFindings>& per_mission, Result* out);
+
+// Finding::print — src/finding.rs:112-155
+void print_findings(const std::vector<Mission>& missions, const Result& r, int n_inputs, int radix, bool no_metadata,
+                    std::string* out);
+
+}  // namespace sx

@@ -1,0 +1,624 @@
+// sx_kernels.hip — hand-written HIP for gfx950 (MI355X / CDNA4).  Stage A of the scan.
+//
+// What the reference does per Mission and per byte (src/finding_collection.rs:134-143
+// decoder call, src/helper.rs:237-332 filter loop, src/mission.rs:333-348 bit tests) is
+// split here into a data-parallel part that runs on the device and an exact sequential
+// replay that only runs where a Finding can actually arise (host, sx_replay.cpp):
+//
+//   device: per byte, G = "belongs to a valid character of the encoding whose UTF-8 lead
+//           byte passes af/ubf" and S = "is the first byte of such a character";
+//           report every maximal stretch of G with >= min_chars set S bits.
+//
+// Memory-bound integer work (no MFMA): one wavefront streams a contiguous sub-chunk in
+// 1 KiB tiles, 16 bytes per lane (`buffer_load_dwordx4`, fully coalesced, hardware
+// bounds check at the chunk end).  Classification is SWAR on 32-bit registers; the four
+// byte-flag dwords become a 16-bit lane mask with `v_dot4_u32_u8`; neighbouring lanes
+// exchange their edge bits with DPP wave shifts; tile-to-tile state lives in SGPRs
+// (readlane).  A wave-uniform ballot test ("is there any stretch of >= cand_bytes
+// bytes, or an open long stretch carried in?") keeps >99 % of tiles of binary data on
+// a short fast path; the slow path resolves stretches across lanes with a ballot-guided
+// look-back and appends records with one atomic per wave.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sx_device.hpp"
+
+namespace sx {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+#define SX_DEV __device__ __forceinline__
+
+constexpr u32 kM = 0x80808080u;  // byte flag position
+
+// ------------------------------------------------------------------------------------------
+// cross-lane helpers (wave64)
+// ------------------------------------------------------------------------------------------
+SX_DEV u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// lane i <- lane i+1 ; lane 63 <- edge
+SX_DEV u32 from_next(u32 v, u32 edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xF, 0xF, false); }
+// lane i <- lane i-1 ; lane 0 <- edge
+SX_DEV u32 from_prev(u32 v, u32 edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xF, 0xF, false); }
+SX_DEV u32 bcast(u32 v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+SX_DEV u32 shfl(u32 v, u32 src_lane) { return __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
+SX_DEV u32 uniform(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// byte flags (bit 7 of each byte) of four dwords -> 16-bit mask, bit j = byte j
+SX_DEV u32 movemask16(u32 f0, u32 f1, u32 f2, u32 f3) {
+    u32 lo = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false);
+    lo = __builtin_amdgcn_udot4(f1, 0x80402010u, lo, false);
+    u32 hi = __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false);
+    hi = __builtin_amdgcn_udot4(f3, 0x80402010u, hi, false);
+    return (lo >> 7) | (hi << 1);  // each flag byte is 0x80: sums are 128 * mask
+}
+SX_DEV u32 movemask4(u32 f) { return __builtin_amdgcn_udot4(f, 0x08040201u, 0u, false) >> 7; }
+
+SX_DEV u32 rep4(u32 b) { return b * 0x01010101u; }
+
+// ------------------------------------------------------------------------------------------
+// Classifiers.  Input: the lane's 16 bytes (x), the dword that follows them (nx) and
+// `avail` = how many bytes from the lane's first byte on are inside the chunk (only looked
+// at when `near_end`, which is wave-uniform).  classify<false> returns g: bits 0..15
+// "byte j belongs to an accepted valid char", bits 16.. = bits that spill onto the first
+// bytes of the next lane.  classify<true> returns the start mask s: bit j = "byte j is the
+// first byte of such a char" (only the slow path asks for it).
+// A character counts only if ALL of its bytes are inside the chunk.
+// ------------------------------------------------------------------------------------------
+SX_DEV u32 fill_ff(u32 v, int nb) {  // keep the low nb bytes, set the others to 0xFF
+    return nb >= 4 ? v : (nb <= 0 ? 0xFFFFFFFFu : (v | (0xFFFFFFFFu << (8 * nb))));
+}
+SX_DEV u32 low_mask(u32 n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
+
+// --- single byte, accept set = [a_lo,a_hi] below 0x80, all-or-none above -----------------
+struct SingleByteRange {
+    u32 c1, c2, high;
+    SX_DEV void init(const ScanParams& p, const uint8_t*) {
+        c1 = rep4(0x80u - p.a_lo);
+        c2 = rep4(0x7Fu - p.a_hi);
+        high = p.high_all ? kM : 0u;
+    }
+    SX_DEV u32 flags(u32 x) const {
+        u32 t = x & 0x7F7F7F7Fu;
+        return ((((t + c1) & ~(t + c2)) & ~x) | (x & high)) & kM;
+    }
+    template <bool WANT_S>
+    SX_DEV u32 classify(u32x4 x, u32, u32 avail, bool near_end) const {
+        u32 g = movemask16(flags(x.x), flags(x.y), flags(x.z), flags(x.w));
+        if (near_end) g &= low_mask(avail);
+        return g;  // one byte per char: starts == good bytes
+    }
+};
+
+// --- single byte, 256-entry accept LUT in LDS (entries 0x80 / 0) ---------------------------
+struct SingleByteLut {
+    const uint8_t* lut;
+    SX_DEV void init(const ScanParams&, const uint8_t* lds) { lut = lds; }
+    SX_DEV u32 look4(u32 x) const {
+        u32 a = lut[x & 0xFF], b = lut[(x >> 8) & 0xFF], c = lut[(x >> 16) & 0xFF], d = lut[x >> 24];
+        return a | (b << 8) | (c << 16) | (d << 24);
+    }
+    template <bool WANT_S>
+    SX_DEV u32 classify(u32x4 x, u32, u32 avail, bool near_end) const {
+        u32 g = movemask16(look4(x.x), look4(x.y), look4(x.z), look4(x.w));
+        if (near_end) g &= low_mask(avail);
+        return g;
+    }
+};
+
+// --- UTF-8, af = one range, ubf = one range of 2-byte leads (C2..DF), nothing longer -----
+// A byte is good iff it is an accepted ASCII byte, or an accepted lead followed by a
+// continuation byte, or the continuation byte of such a pair.  No table, no LDS.
+struct Utf8Range2 {
+    u32 a1, a2, l1, l2;
+    SX_DEV void init(const ScanParams& p, const uint8_t*) {
+        a1 = rep4(0x80u - p.a_lo);
+        a2 = rep4(0x7Fu - p.a_hi);
+        l1 = rep4(0x80u - (p.u_lo & 0x7F));  // leads are >= 0x80: compare the low 7 bits
+        l2 = rep4(0x7Fu - (p.u_hi & 0x7F));
+    }
+    template <bool WANT_S>
+    SX_DEV u32 classify(u32x4 x, u32 nx, u32 avail, bool near_end) const {
+        u32 xs[5] = { x.x, x.y, x.z, x.w, nx };
+        if (near_end) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) xs[k] = fill_ff(xs[k], (int)avail - 4 * k);
+        }
+        u32 a[4], l[4], c[5];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 v = xs[k], t = v & 0x7F7F7F7Fu;
+            a[k] = ((t + a1) & ~(t + a2)) & ~v & kM;
+            l[k] = ((t + l1) & ~(t + l2)) & v & kM;
+            c[k] = v & ~(v << 1) & kM;
+        }
+        c[4] = xs[4] & ~(xs[4] << 1) & kM;
+        u32 p[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) p[k] = l[k] & __builtin_amdgcn_alignbyte(c[k + 1], c[k], 1);
+        if (WANT_S) return movemask16(a[0] | p[0], a[1] | p[1], a[2] | p[2], a[3] | p[3]);
+        u32 g0 = a[0] | p[0] | (p[0] << 8);
+        u32 g1 = a[1] | p[1] | __builtin_amdgcn_alignbyte(p[1], p[0], 3);
+        u32 g2 = a[2] | p[2] | __builtin_amdgcn_alignbyte(p[2], p[1], 3);
+        u32 g3 = a[3] | p[3] | __builtin_amdgcn_alignbyte(p[3], p[2], 3);
+        return movemask16(g0, g1, g2, g3) | ((p[3] >> 31) << 16);
+    }
+};
+
+// --- UTF-8, any af/ubf: class LUT (LDS, 256 B: one dword per bank -> conflict free) -------
+// class byte: bits 0-2 continuation class one-hot (80-8F, 90-9F, A0-BF);
+//             bits 3-5 (accepted starts only) which continuation classes may follow;
+//             bits 6-7 (accepted starts only) length - 1.   Everything else is 0.
+struct Utf8Lut {
+    const uint8_t* lut;
+    SX_DEV void init(const ScanParams&, const uint8_t* lds) { lut = lds; }
+    SX_DEV u32 look4(u32 x) const {
+        u32 a = lut[x & 0xFF], b = lut[(x >> 8) & 0xFF], c = lut[(x >> 16) & 0xFF], d = lut[x >> 24];
+        return a | (b << 8) | (c << 16) | (d << 24);
+    }
+    static SX_DEV u32 nz(u32 v) { return (v + 0x7F7F7F7Fu) & kM; }  // bytes <= 0x3F
+    template <bool WANT_S>
+    SX_DEV u32 classify(u32x4 x, u32 nx, u32 avail, bool near_end) const {
+        u32 xs[5] = { x.x, x.y, x.z, x.w, nx };
+        if (near_end) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) xs[k] = fill_ff(xs[k], (int)avail - 4 * k);
+        }
+        u32 c[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) c[k] = look4(xs[k]);
+        u32 v[4], len2[4], len3[4], len4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 ck = c[k];
+            u32 c1 = __builtin_amdgcn_alignbyte(c[k + 1], ck, 1);
+            u32 c2 = __builtin_amdgcn_alignbyte(c[k + 1], ck, 2);
+            u32 c3 = __builtin_amdgcn_alignbyte(c[k + 1], ck, 3);
+            u32 st = nz(ck & 0x38383838u);
+            u32 k1 = nz((ck >> 3) & c1 & 0x07070707u);
+            u32 k2 = nz(c2 & 0x07070707u);
+            u32 k3 = nz(c3 & 0x07070707u);
+            u32 lb0 = (ck << 1) & kM, lb1 = ck & kM;  // bits of (length - 1)
+            u32 need1 = lb0 | lb1, need2 = lb1, need3 = lb0 & lb1;
+            u32 ok = st & (k1 | ~need1) & (k2 | ~need2) & (k3 | ~need3);
+            v[k] = ok; len2[k] = ok & need1; len3[k] = ok & need2; len4[k] = ok & need3;
+        }
+        u32 A = movemask16(v[0], v[1], v[2], v[3]);
+        if (WANT_S) return A;
+        u32 A2 = movemask16(len2[0], len2[1], len2[2], len2[3]);
+        u32 A3 = movemask16(len3[0], len3[1], len3[2], len3[3]);
+        u32 A4 = movemask16(len4[0], len4[1], len4[2], len4[3]);
+        return A | (A2 << 1) | (A3 << 2) | (A4 << 3);  // up to bit 18
+    }
+};
+
+// --- UTF-16, af = one range, accepted non-ASCII units = one range below U+0800 -----------
+// Units sit at stream parity; every surrogate and everything outside the two ranges is a
+// break.  Both bytes of an accepted unit are good; the unit's first byte is the start.
+struct Utf16Range {
+    u32 a1, a2, u1, u2, odd, be;
+    SX_DEV void init(const ScanParams& p, const uint8_t*) {
+        a1 = (0x8000u - p.a_lo) * 0x00010001u;
+        a2 = (0x7FFFu - p.a_hi) * 0x00010001u;
+        u1 = (0x8000u - p.u_lo) * 0x00010001u;
+        u2 = (0x7FFFu - p.u_hi) * 0x00010001u;
+        odd = p.parity & 1;
+        be = p.big_endian;
+    }
+    SX_DEV u32 unit_flags(u32 v) const {  // two units per dword -> flags at bits 15 and 31
+        if (be) v = __builtin_amdgcn_perm(0u, v, 0x02030001u);
+        u32 t = v & 0x7FFF7FFFu;
+        u32 ra = (t + a1) & ~(t + a2);
+        u32 ru = (t + u1) & ~(t + u2);
+        return (ra | ru) & ~v & 0x80008000u;
+    }
+    template <bool WANT_S>
+    SX_DEV u32 classify(u32x4 x, u32 nx, u32 avail, bool near_end) const {
+        u32 d0 = x.x, d1 = x.y, d2 = x.z, d3 = x.w;
+        if (odd) {  // unit k of this lane = bytes 2k+1, 2k+2
+            d0 = __builtin_amdgcn_alignbyte(x.y, x.x, 1);
+            d1 = __builtin_amdgcn_alignbyte(x.z, x.y, 1);
+            d2 = __builtin_amdgcn_alignbyte(x.w, x.z, 1);
+            d3 = __builtin_amdgcn_alignbyte(nx, x.w, 1);
+        }
+        u32 f0 = unit_flags(d0), f1 = unit_flags(d1), f2 = unit_flags(d2), f3 = unit_flags(d3);
+        u32 s0 = f0 >> 8, s1 = f1 >> 8, s2 = f2 >> 8, s3 = f3 >> 8;  // flag on the unit's first byte
+        u32 m = WANT_S ? movemask16(s0, s1, s2, s3) : movemask16(f0 | s0, f1 | s1, f2 | s2, f3 | s3);
+        if (near_end) {  // whole units only
+            u32 nu = avail > odd ? (avail - odd) >> 1 : 0u;
+            m &= low_mask(2 * nu);
+        }
+        return m << odd;  // odd parity: everything sits one byte later (bit 16 spills)
+    }
+};
+
+// --- UTF-16, any af/ubf incl. astral: two 256-entry LUTs in LDS ---------------------------
+// lutH[hi byte]: bits 0-3 accept per (lo byte >> 6) quadrant; bit 4 "hi byte is 0: use
+// lutL[lo byte] bit 0"; bit 5 high surrogate (bits 0-3 then say whether the PAIR is
+// accepted); bit 6 low surrogate.
+struct Utf16Lut {
+    const uint8_t *lutH, *lutL;
+    u32 odd, be;
+    SX_DEV void init(const ScanParams& p, const uint8_t* lds) {
+        lutH = lds; lutL = lds + 256; odd = p.parity & 1; be = p.big_endian;
+    }
+    // one unit -> bit0 accepted BMP char, bit1 high surrogate of an accepted plane, bit2 low surrogate
+    SX_DEV u32 unit_class(u32 u) const {
+        u32 hb = u >> 8, lb = u & 0xFF;
+        u32 h = lutH[hb];
+        u32 q = (h >> (lb >> 6)) & 1;
+        u32 l = lutL[lb] & 1;
+        u32 acc = (h & 0x10) ? l : q;
+        u32 hs = (h >> 5) & 1, ls = (h >> 6) & 1;
+        return (hs | ls) ? ((hs & q) << 1) | (ls << 2) : acc;
+    }
+    template <bool WANT_S>
+    SX_DEV u32 classify(u32x4 x, u32 nx, u32 avail, bool near_end) const {
+        u32 d[5] = { x.x, x.y, x.z, x.w, nx };
+        if (odd) {
+            d[0] = __builtin_amdgcn_alignbyte(x.y, x.x, 1);
+            d[1] = __builtin_amdgcn_alignbyte(x.z, x.y, 1);
+            d[2] = __builtin_amdgcn_alignbyte(x.w, x.z, 1);
+            d[3] = __builtin_amdgcn_alignbyte(nx, x.w, 1);
+            d[4] = nx >> 8;
+        }
+        u32 nu = 9;  // whole units available (8 own + 1 look-ahead)
+        if (near_end) { nu = avail > odd ? (avail - odd) >> 1 : 0u; if (nu > 9) nu = 9; }
+        u32 bmp = 0, hs = 0, ls = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            u32 v = d[k >> 1];
+            if (be) v = __builtin_amdgcn_perm(0u, v, 0x02030001u);
+            u32 u = (k & 1) ? (v >> 16) : (v & 0xFFFF);
+            u32 cl = unit_class(u);
+            bmp |= (cl & 1) << k; hs |= ((cl >> 1) & 1) << k; ls |= ((cl >> 2) & 1) << k;
+        }
+        u32 um = low_mask(nu);
+        bmp &= um; hs &= um; ls &= um;
+        u32 pair = hs & (ls >> 1) & 0xFF;   // accepted pair whose high surrogate is own unit k
+        u32 start_u = (bmp & 0xFF) | pair;   // char starts, unit granularity
+        u32 m;
+        if (WANT_S) {
+            m = start_u;  // bit k -> bit 2k
+            m = (m | (m << 4)) & 0x0F0Fu; m = (m | (m << 2)) & 0x3333u; m = (m | (m << 1)) & 0x5555u;
+        } else {
+            m = start_u | (pair << 1);  // bit 8 = first unit of the next lane
+            m = (m | (m << 8)) & 0x00FF00FFu; m = (m | (m << 4)) & 0x0F0F0F0Fu;
+            m = (m | (m << 2)) & 0x33333333u; m = (m | (m << 1)) & 0x55555555u;
+            m |= m << 1;
+        }
+        return m << odd;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Tile-to-tile state of one wavefront.  Everything here is wave-uniform (SGPRs).
+// ------------------------------------------------------------------------------------------
+struct Carry {
+    u32 g63;      // previous tile, lane 63: final 16-bit good mask | own spill bits << 16
+    u32 s63;      // previous tile, lane 63: start mask
+    u32 tracked;  // 1: a stretch is open at the tile start and described below
+    u32 t_chars, t_flags;
+    u64 t_start;
+};
+
+struct Emitter {
+    DevRun* recs;
+    u32* counters;
+    u32 capacity;
+    // all lanes call (convergent); `want` lanes append one record each; one atomic per wave
+    SX_DEV void append(bool want, u64 start, u64 end, u32 chars, u32 flags) const {
+        u64 m = __ballot(want);
+        if (m == 0) return;
+        u32 lane = lane_id();
+        int leader = __ffsll((long long)m) - 1;
+        u32 base = 0;
+        if ((int)lane == leader) base = atomicAdd(counters, (u32)__popcll(m));
+        base = __builtin_amdgcn_readlane(base, leader);
+        if (want) {
+            u32 idx = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+            if (idx < capacity) {
+                DevRun r;
+                r.start = start;
+                r.len = (u32)(end - start);
+                r.chars_flags = (chars > kRecCharsMask ? kRecCharsMask : chars) | flags;
+                recs[idx] = r;
+            }
+        }
+    }
+};
+
+SX_DEV u32 wave_inclusive_scan(u32 v) {
+    u32 lane = lane_id();
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+        u32 o = shfl(v, lane >= d ? lane - d : lane);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+SX_DEV u32 trailing_ones16(u32 g16) {  // ones from bit 15 downwards
+    u32 inv = (~g16) & 0xFFFFu;
+    return inv ? (u32)__clz((int)inv) - 16u : 16u;
+}
+
+// Exact resolution of all stretches that END inside this tile (the one still open at the
+// tile end goes into the carry).  g: final 16-bit good mask; s: start mask; g_raw: the
+// classifier's output (for its spill bits).
+// `first_tile`: the tile starts a sub-chunk: a stretch that is open on entry is clipped to
+// the sub-chunk start and flagged kRecStartOpen (the previous wave reports the part before).
+SX_DEV void slow_path(u32 g, u32 s, u32 g_raw, u64 tile_base, u64 tile_end, Carry& c, const Emitter& em,
+                      u32 min_chars, u32 cand_bytes, bool first_tile) {
+    const u32 lane = lane_id();
+    g &= 0xFFFFu;
+    s &= 0xFFFFu;
+
+    // -- the stretch that is open when the tile begins
+    bool open = false;
+    u64 ostart = 0;
+    u32 ochars = 0, oflags = 0;
+    if (c.tracked) {
+        open = true; ostart = c.t_start; ochars = c.t_chars; oflags = c.t_flags;
+    } else if (c.g63 & 0x8000u) {
+        open = true;
+        if (first_tile) { ostart = tile_base; ochars = 0; oflags = kRecStartOpen; }
+        else {  // shorter than cand_bytes <= 17 bytes: it lies inside lane 63 of the previous tile
+            u32 suf = trailing_ones16(c.g63 & 0xFFFFu);
+            ostart = tile_base - suf;
+            ochars = (u32)__popc((c.s63 & 0xFFFFu) >> (16u - suf));
+        }
+    }
+    u32 g0 = bcast(g, 0) & 1u;
+    if (open && !g0) {  // it ended exactly at the tile boundary
+        em.append(lane == 0 && (ochars >= min_chars || oflags), ostart, tile_base, ochars, oflags);
+        open = false;
+    }
+
+    // -- per-lane summaries
+    bool all = g == 0xFFFFu;
+    u32 cnt = (u32)__popc(s);
+    u32 trail1 = trailing_ones16(g);
+    u32 trail_chars = (u32)__popc(s >> (16u - trail1));
+    u64 zmask = __ballot(!all);
+    u32 P = wave_inclusive_scan(cnt);
+    u32 Pex = P - cnt;
+
+    // -- what lies to the left of my byte 0 (used only if my bit 0 is set)
+    u64 below = zmask & ((1ull << lane) - 1ull);
+    int j = below ? 63 - __clzll((long long)below) : -1;
+    u32 jj = j < 0 ? 0u : (u32)j;
+    u32 tj = shfl(trail1, jj), tcj = shfl(trail_chars, jj), Pj = shfl(P, jj);
+    u64 left_start;
+    u32 left_chars, left_flags = 0;
+    if (j >= 0) {
+        left_start = tile_base + 16ull * jj + (16u - tj);
+        left_chars = tcj + (Pex - Pj);
+    } else {
+        left_start = open ? ostart : tile_base;
+        left_chars = (open ? ochars : 0u) + Pex;
+        left_flags = open ? oflags : 0u;
+    }
+
+    // -- walk my own stretches, lowest first
+    u32 nb0 = from_next(g & 1u, 2u);  // lane 63: the next tile is not classified yet
+    u32 rem = g;
+    u32 my_open = 0, my_och = 0, my_ofl = 0;
+    u64 my_ostart = 0;
+    while (__ballot(rem != 0)) {
+        bool has = rem != 0;
+        u32 st = has ? (u32)__builtin_ctz(rem) : 0u;
+        u32 ln = (u32)__builtin_ctz(~(rem >> st));
+        u32 en = st + ln;
+        u32 field = ((1u << ln) - 1u) << st;
+        u32 ch = (u32)__popc(s & field);
+        u64 start = tile_base + 16ull * lane + st;
+        u32 flags = 0;
+        if (st == 0) { ch += left_chars; start = left_start; flags = left_flags; }
+        bool closed = en < 16u || nb0 == 0u;
+        u64 end = tile_base + 16ull * lane + en;
+        em.append(has && closed && (ch >= min_chars || flags), start, end, ch, flags);
+        if (has && !closed && lane == 63) { my_open = 1; my_ostart = start; my_och = ch; my_ofl = flags; }
+        rem &= ~field;
+    }
+
+    // -- state for the next tile
+    c.g63 = bcast(g | (g_raw & 0xFFFF0000u), 63);
+    c.s63 = bcast(s, 63);
+    c.tracked = 0;
+    if (bcast(my_open, 63)) {
+        u64 os = ((u64)bcast((u32)(my_ostart >> 32), 63) << 32) | bcast((u32)my_ostart, 63);
+        u32 ofl = bcast(my_ofl, 63);
+        if (tile_end - os >= cand_bytes || ofl) {  // short and plain: re-derived from g63/s63 when needed
+            c.tracked = 1; c.t_start = os; c.t_chars = bcast(my_och, 63); c.t_flags = ofl;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The scan kernel: one wavefront per sub-chunk.
+// ------------------------------------------------------------------------------------------
+template <class CLS, bool NEEDS_LUT>
+__global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_lut[512];
+    if (NEEDS_LUT) {
+        lds_lut[threadIdx.x] = p.lut[threadIdx.x];
+        lds_lut[threadIdx.x + 256] = p.lut[threadIdx.x + 256];
+        __syncthreads();
+    }
+    const u32 lane = lane_id();
+    const u64 wave = (u64)blockIdx.x * 4u + uniform(threadIdx.x >> 6);
+    const u64 sub_start = wave * (u64)p.subchunk;
+    if (sub_start >= p.len) return;
+    const u64 sub_end = (sub_start + p.subchunk < p.len) ? sub_start + p.subchunk : p.len;
+
+    CLS cls;
+    cls.init(p, lds_lut);
+    Emitter em{ p.recs, p.counters, p.capacity };
+
+    // Buffer descriptor over [win_lo, win_hi): one tile of look-back (classification state
+    // at the sub-chunk start) and two of look-ahead; reads beyond it return 0.
+    const bool has_pre = sub_start >= kTileBytes;
+    const u64 win_lo = has_pre ? sub_start - kTileBytes : 0;
+    u64 win_hi = sub_end + 2 * kTileBytes;
+    if (win_hi > p.len) win_hi = p.len;
+    const uint8_t* base_ptr = p.data + win_lo;
+    const u32 base_lo = uniform((u32)(uintptr_t)base_ptr), base_hi = uniform((u32)((uintptr_t)base_ptr >> 32));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((u64)base_hi << 32) | base_lo), 0, (int)uniform((u32)(win_hi - win_lo)), 0x00020000);
+    auto load = [&](u32 off) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0); };
+
+    const int n_tiles = (int)((sub_end - sub_start + kTileBytes - 1) / kTileBytes);
+    int t = has_pre ? -1 : 0;   // -1 = the look-back tile
+    u32 voff = lane * 16u;      // byte offset of my 16 bytes of tile t inside the window
+    u32x4 cur = load(voff);
+    u32x4 nxt = load(voff + kTileBytes);
+    Carry c;
+    c.g63 = 0; c.s63 = 0; c.tracked = 0; c.t_chars = 0; c.t_flags = 0; c.t_start = 0;
+
+    for (; t < n_tiles; t++) {
+        const u32x4 nn = load(voff + 2 * kTileBytes);  // in flight while this tile is classified
+        const u64 tile_base = sub_start + (u64)((long long)t * (long long)kTileBytes);
+        const bool near_end = tile_base + kTileBytes + 16 > p.len;  // uniform
+        const u64 lane_base = tile_base + 16ull * lane;
+        u32 avail = 32;
+        if (near_end) avail = lane_base >= p.len ? 0u : (p.len - lane_base > 32 ? 32u : (u32)(p.len - lane_base));
+
+        const u32 nx = from_next(cur.x, bcast(nxt.x, 0));
+        const u32 g = cls.template classify<false>(cur, nx, avail, near_end);
+
+        const u32 pg = from_prev(g, c.g63);
+        const u32 gf = (g & 0xFFFFu) | (pg >> 16);       // final good mask of my 16 bytes
+        const u32 pgf = from_prev(gf, c.g63) & 0xFFFFu;   // final mask of the 16 bytes before mine
+
+        // does any stretch of >= cand_bytes bytes end inside my 16 bytes?
+        u32 r = (gf << 16) | pgf;
+        for (u32 have = 1; have < p.cand_bytes;) {
+            u32 sh = have < p.cand_bytes - have ? have : p.cand_bytes - have;
+            r &= r << sh;
+            have += sh;
+        }
+        const u64 cand = __ballot((r & 0xFFFF0000u) != 0);
+        const bool first_tile = t == 0;
+        const u64 tile_end = tile_base + kTileBytes < sub_end ? tile_base + kTileBytes : sub_end;
+
+        if (t < 0 || (cand == 0 && !c.tracked && !(first_tile && (c.g63 & 0x8000u)))) {
+            // fast path (and the look-back tile, of which only the classification state matters)
+            const u32 s = cls.template classify<true>(cur, nx, avail, near_end);
+            c.g63 = bcast(gf | (g & 0xFFFF0000u), 63);
+            c.s63 = bcast(s, 63);
+        } else {
+            const u32 s = cls.template classify<true>(cur, nx, avail, near_end);
+            if (lane == 0) atomicAdd(p.counters + 1, 1u);
+            slow_path(gf, s, g, tile_base, tile_end, c, em, p.min_chars, p.cand_bytes, first_tile);
+        }
+        cur = nxt; nxt = nn; voff += kTileBytes;
+    }
+
+    // the stretch that is still open where the sub-chunk ends
+    if (c.tracked || (c.g63 & 0x8000u)) {
+        u64 os; u32 och, ofl;
+        if (c.tracked) { os = c.t_start; och = c.t_chars; ofl = c.t_flags; }
+        else {
+            u32 suf = trailing_ones16(c.g63 & 0xFFFFu);
+            os = sub_start + (u64)n_tiles * kTileBytes - suf;
+            och = (u32)__popc((c.s63 & 0xFFFFu) >> (16u - suf));
+            ofl = 0;
+        }
+        em.append(lane == 0, os, sub_end, och, ofl | kRecEndOpen);
+    }
+}
+
+template <class CLS, bool LUT>
+static hipError_t launch_t(const ScanParams& p, hipStream_t stream) {
+    u64 waves = (p.len + p.subchunk - 1) / p.subchunk;
+    u64 blocks = (waves + 3) / 4;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL((scan_kernel<CLS, LUT>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t stream) {
+    switch (kind) {
+    case kClsSingleByteLut: return launch_t<SingleByteLut, true>(p, stream);
+    case kClsUtf8Lut: return launch_t<Utf8Lut, true>(p, stream);
+    case kClsUtf16Lut: return launch_t<Utf16Lut, true>(p, stream);
+    case kClsUtf8Range2: return launch_t<Utf8Range2, false>(p, stream);
+    case kClsUtf16Range: return launch_t<Utf16Range, false>(p, stream);
+    case kClsSingleByteRange: return launch_t<SingleByteRange, false>(p, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// Synthetic background, read-bandwidth probe, sparse gather
+// ------------------------------------------------------------------------------------------
+SX_DEV u64 mix64(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(uint8_t* dst, u64 first, u64 len, u64 seed) {
+    // one 8-byte word of the stream per thread iteration; `first` and `dst` need not be aligned
+    u64 w0 = first >> 3, w1 = (first + len + 7) >> 3;
+    u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 w = w0 + (u64)blockIdx.x * blockDim.x + threadIdx.x; w < w1; w += stride) {
+        u64 v = mix64(seed + (w + 1) * 0x9E3779B97F4A7C15ull);
+        u64 i0 = w << 3;
+        if (i0 >= first && i0 + 8 <= first + len && (((uintptr_t)(dst + (i0 - first))) & 7) == 0) {
+            *(u64*)(dst + (i0 - first)) = v;
+        } else {
+            for (int k = 0; k < 8; k++) {
+                u64 i = i0 + k;
+                if (i >= first && i < first + len) dst[i - first] = (uint8_t)(v >> (8 * k));
+            }
+        }
+    }
+}
+
+hipError_t launch_fill_background(uint8_t* dst, u64 first, u64 len, u64 seed, hipStream_t stream) {
+    if (len == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_kernel, dim3(256 * 16), dim3(256), 0, stream, dst, first, len, seed);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void read_sum_kernel(const u32x4* src, u64 n16, u64* out) {
+    u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 acc = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        u32x4 v = __builtin_nontemporal_load(src + i);
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) atomicAdd((unsigned long long*)out, 1ull);  // keep the loads alive
+}
+
+hipError_t launch_read_sum(const uint8_t* src, u64 len, u64* out, hipStream_t stream) {
+    hipLaunchKernelGGL(read_sum_kernel, dim3(256 * 8), dim3(256), 0, stream, (const u32x4*)src, len / 16, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const uint8_t* src, uint8_t* dst, const u64* seg_src,
+                                                     const u64* seg_dst, const u32* seg_len, u32 n) {
+    // one wavefront per segment
+    u32 wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    u32 nw = (gridDim.x * 256u) >> 6;
+    for (u32 i = wave; i < n; i += nw) {
+        const uint8_t* s = src + seg_src[i];
+        uint8_t* d = dst + seg_dst[i];
+        u32 l = seg_len[i];
+        for (u32 k = lane; k < l; k += 64) d[k] = s[k];
+    }
+}
+
+hipError_t launch_gather(const uint8_t* src, uint8_t* dst, const u64* seg_src, const u64* seg_dst,
+                         const u32* seg_len, u32 n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    u32 blocks = (n + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, seg_src, seg_dst, seg_len, n);
+    return hipGetLastError();
+}
+
+}  // namespace sx

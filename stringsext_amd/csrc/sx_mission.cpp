@@ -1,0 +1,146 @@
+// sx_mission.cpp — turns a Mission (src/mission.rs:382-421) into what the device needs:
+// which classifier kernel fits its encoding + Utf8Filter, and that kernel's constants or
+// lookup tables.  The filter acts on the UTF-8 lead byte of the decoded character
+// (src/mission.rs:333-348, src/helper.rs:276-279), so for every encoding the accept set
+// is first expressed in the encoding's own byte/unit terms.
+#include <string.h>
+
+#include "sx_host.hpp"
+
+namespace sx {
+
+const char* Mission::encoding_name() const { return sx::encoding_name(c.encoding); }
+
+static uint8_t utf8_lead_of(uint32_t cp) {
+    if (cp < 0x80) return (uint8_t)cp;
+    if (cp < 0x800) return (uint8_t)(0xC0 | (cp >> 6));
+    if (cp < 0x10000) return (uint8_t)(0xE0 | (cp >> 12));
+    return (uint8_t)(0xF0 | (cp >> 18));
+}
+
+// [lo,hi] if the set bits of `bits` (positions first..last) are one contiguous run
+static bool one_range(const bool* bits, int first, int last, int* lo, int* hi, bool* empty) {
+    int l = -1, h = -1, n = 0;
+    for (int i = first; i <= last; i++)
+        if (bits[i]) { if (l < 0) l = i; h = i; n++; }
+    *empty = n == 0;
+    if (n == 0) return true;
+    *lo = l; *hi = h;
+    return n == h - l + 1;
+}
+
+int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::string* err) {
+    m->c = in;
+    m->filter.af_lo = in.af_lo; m->filter.af_hi = in.af_hi; m->filter.ubf = in.ubf;
+    m->filter.grep_char = in.grep_char;
+    m->q = in.output_line_char_nb_max;
+    if (m->q < 6) { *err = "output_line_char_nb_max must be >= 6 (src/options.rs:33)"; return SX_E_INVALID; }
+    if (in.grep_char > 127) { *err = "grep_char must be an ASCII code < 128 (src/mission.rs:547-555)"; return SX_E_INVALID; }
+    m->window = 2 * m->q;
+    m->long_run = (uint32_t)std::min<size_t>(in.chars_min_nb, m->q);
+    if (m->long_run == 0) m->long_run = 1;
+    const int enc = in.encoding;
+    const bool known = enc == SX_ENC_X_USER_DEFINED || enc == SX_ENC_UTF8 || enc == SX_ENC_UTF16LE
+                       || enc == SX_ENC_UTF16BE || single_byte_table(enc) != nullptr;
+    if (!known) { *err = "unsupported encoding id " + std::to_string(enc); return SX_E_INVALID; }
+
+    ScanParams& p = m->proto;
+    memset(&p, 0, sizeof p);
+    p.min_chars = m->long_run;
+    const uint32_t min_bytes_per_char = m->is_utf16() ? 2 : 1;
+    p.cand_bytes = std::min<uint32_t>(m->long_run * min_bytes_per_char, 17);
+    p.big_endian = enc == SX_ENC_UTF16BE;
+    p.a_lo = 1; p.a_hi = 0; p.u_lo = 0x81; p.u_hi = 0x80;  // empty ranges
+
+    bool af[128], lead2[64] = { false };
+    for (int b = 0; b < 128; b++) af[b] = m->filter.pass_af_filter((uint8_t)b);
+    int alo = 0, ahi = 0;
+    bool aempty = false;
+    const bool af_is_range = one_range(af, 0, 127, &alo, &ahi, &aempty);
+    if (!aempty) { p.a_lo = (uint32_t)alo; p.a_hi = (uint32_t)ahi; }
+    // leads C2..DF <-> ubf bits 2..31
+    for (int i = 2; i < 32; i++) lead2[i] = ((in.ubf >> i) & 1) != 0;
+    int ulo = 0, uhi = 0;
+    bool uempty = false;
+    const bool ubf2_is_range = one_range(lead2, 2, 31, &ulo, &uhi, &uempty);
+    const bool no_long_leads = ((in.ubf >> 32) & 0x1FFFFFull) == 0;  // E0..F4 <-> bits 32..52
+
+    if (enc == SX_ENC_UTF8) {
+        if (!force_generic && af_is_range && ubf2_is_range && no_long_leads) {
+            m->kind = kClsUtf8Range2;
+            if (!uempty) { p.u_lo = 0xC0u + (uint32_t)ulo; p.u_hi = 0xC0u + (uint32_t)uhi; }
+        } else {
+            m->kind = kClsUtf8Lut;
+            for (int b = 0; b < 256; b++) {
+                uint8_t cls = 0;
+                if (b < 0x80) cls = af[b] ? 0x38 : 0;
+                else if (b < 0x90) cls = 1;
+                else if (b < 0xA0) cls = 2;
+                else if (b < 0xC0) cls = 4;
+                else if (b >= 0xC2 && b <= 0xF4 && m->filter.pass_ubf_filter((uint8_t)b)) {
+                    uint8_t allowed = 7, len1 = 1;
+                    if (b >= 0xE0) { len1 = 2; if (b == 0xE0) allowed = 4; if (b == 0xED) allowed = 3; }
+                    if (b >= 0xF0) { len1 = 3; allowed = b == 0xF0 ? 6 : (b == 0xF4 ? 1 : 7); }
+                    cls = (uint8_t)((allowed << 3) | (len1 << 6));
+                }
+                p.lut[b] = cls;
+            }
+        }
+    } else if (m->is_utf16()) {
+        const bool no_bmp3 = ((in.ubf >> 32) & 0xFFFFull) == 0;   // U+0800..U+FFFF <-> bits 32..47
+        const bool no_astral = ((in.ubf >> 48) & 0x1Full) == 0;   // bits 48..52
+        if (!force_generic && af_is_range && ubf2_is_range && no_bmp3 && no_astral) {
+            m->kind = kClsUtf16Range;
+            if (!uempty) { p.u_lo = (uint32_t)ulo << 6; p.u_hi = ((uint32_t)uhi << 6) | 0x3F; }
+            else { p.u_lo = 1; p.u_hi = 0; }
+        } else {
+            m->kind = kClsUtf16Lut;
+            uint8_t* H = p.lut;
+            uint8_t* L = p.lut + 256;
+            for (int lb = 0; lb < 256; lb++) L[lb] = m->filter.pass_lead(utf8_lead_of((uint32_t)lb)) ? 1 : 0;
+            for (int hb = 0; hb < 256; hb++) {
+                uint8_t v = 0;
+                if (hb == 0) v = 0x10;
+                else if (hb >= 0xD8 && hb <= 0xDB) {
+                    v = 0x20;
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t u = (uint32_t)(hb << 8) | (uint32_t)(q << 6);
+                        const uint32_t cp = 0x10000u + ((u & 0x3FF) << 10);  // lead depends on the high surrogate only
+                        if (m->filter.pass_ubf_filter(utf8_lead_of(cp))) v |= (uint8_t)(1 << q);
+                    }
+                } else if (hb >= 0xDC && hb <= 0xDF) v = 0x40;
+                else {
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t u = (uint32_t)(hb << 8) | (uint32_t)(q << 6);
+                        if (m->filter.pass_ubf_filter(utf8_lead_of(u))) v |= (uint8_t)(1 << q);
+                    }
+                }
+                H[hb] = v;
+            }
+        }
+    } else {  // x-user-defined and single-byte tables
+        bool acc[256];
+        const uint16_t* tab = single_byte_table(enc);
+        for (int b = 0; b < 256; b++) {
+            if (b < 0x80) acc[b] = af[b];
+            else {
+                const uint32_t cp = tab ? tab[b - 0x80] : 0xF780u + (uint32_t)(b - 0x80);
+                acc[b] = cp != 0 && m->filter.pass_lead(utf8_lead_of(cp));
+            }
+        }
+        int hl = 0, hh = 0;
+        bool hempty = false;
+        one_range(acc, 128, 255, &hl, &hh, &hempty);
+        const bool high_all = !hempty && hl == 128 && hh == 255 && [&] { for (int b = 128; b < 256; b++) if (!acc[b]) return false; return true; }();
+        if (!force_generic && af_is_range && (hempty || high_all)) {
+            m->kind = kClsSingleByteRange;
+            p.high_all = high_all ? 1 : 0;
+        } else {
+            m->kind = kClsSingleByteLut;
+            for (int b = 0; b < 256; b++) p.lut[b] = acc[b] ? 0x80 : 0;
+        }
+    }
+    return SX_OK;
+}
+
+}  // namespace sx

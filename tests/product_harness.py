@@ -1,0 +1,72 @@
+"""Test helper: drive the product (stringsext_amd C-ABI) the way the reference's main::run()
+drives FindingCollection::from — file by file, chunk by chunk — and frame the output like the
+merger thread does (src/main.rs:116,138)."""
+import stringsext_amd as sx
+import sxo_binding as sxo
+
+
+def oracle_runs_for_chunk(mdicts, chunk, stream_bytes):
+    """What stage A must report for this chunk, computed by the oracle's sequential decoder."""
+    out = []
+    for m in mdicts:
+        long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
+        out.append(sxo.runs(m, chunk, stream_parity=stream_bytes & 1, min_chars=long_run))
+    return out
+
+
+def run_cli_product(mdicts, files, radix=None, no_metadata=False, chunk_bytes=None, device=None,
+                    generic_kernels=False, subchunk_bytes=0, flush_at_eof=False, record_capacity=0):
+    """Whole CLI pass.  device=None: host-only context, runs supplied by the oracle (tests the
+    replay stage on CPU).  device=int: the real thing (HIP kernels + replay)."""
+    host_only = device is None
+    sc = sx.Scanner(mdicts, device=sx.SX_HOST_ONLY if host_only else device, generic_kernels=generic_kernels,
+                    subchunk_bytes=subchunk_bytes, record_capacity=record_capacity)
+    out = bytearray(sx.OUTPUT_BOM)
+    stream = 0
+    try:
+        for fi, data in enumerate(files):
+            data = bytes(data)
+            step = chunk_bytes or max(len(data), 1)
+            assert step % 4096 == 0 or step >= len(data)
+            off = 0
+            while off < len(data):
+                chunk = data[off:off + step]
+                last = flush_at_eof and fi == len(files) - 1 and off + len(chunk) == len(data)
+                if host_only:
+                    res = sc.replay_runs(chunk, oracle_runs_for_chunk(mdicts, chunk, stream), file_id=fi + 1,
+                                         is_last=last)
+                else:
+                    res = sc.scan(chunk, file_id=fi + 1, is_last=last)
+                out += res.printed(n_inputs=len(files), radix=radix, no_metadata=no_metadata)
+                res.free()
+                off += len(chunk)
+                stream += len(chunk)
+    finally:
+        sc.close()
+    out += b"\n"
+    return bytes(out)
+
+
+class ProductScanner:
+    """The reference's test-visible surface (ScannerState + FindingCollection::from) on top of
+    the product's replay stage, for the unit-test known answers."""
+
+    def __init__(self, mdict, device=None):
+        self.m = mdict
+        self.device = device
+        self.sc = sx.Scanner([mdict], device=sx.SX_HOST_ONLY if device is None else device)
+        self.stream = 0
+        self.first_byte_position = None
+        self.arena = b""
+
+    def scan(self, data, file_id=0, is_last=False):
+        data = bytes(data)
+        if self.device is None:
+            res = self.sc.replay_runs(data, oracle_runs_for_chunk([self.m], data, self.stream), file_id=file_id,
+                                      is_last=is_last)
+        else:
+            res = self.sc.scan(data, file_id=file_id, is_last=is_last)
+        self.stream += len(data)
+        f = res.findings()
+        res.free()
+        return f

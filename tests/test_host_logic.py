@@ -1,0 +1,180 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol of
+include/stringsext_amd.h, refuses to run without a GPU, and its replay stage (fed with the
+run records the ORACLE's sequential decoder computes) reproduces the reference's golden
+outputs, unit-test known answers and the oracle's full scan on adversarial inputs."""
+import ctypes
+import os
+import random
+import re
+
+import pytest
+
+import refconfig as rc
+import stringsext_amd as sx
+import sxo_binding as sxo
+from golden import unit_kats as K
+from product_harness import ProductScanner, run_cli_product
+from test_oracle_golden import CLI_CASES, rd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "stringsext_amd.h")).read()
+    declared = set(re.findall(r"\b(sx_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"sx_scan_device"} - set(sx.EXPORTS)  # nothing to subtract; keeps intent explicit
+    L = sx.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert set(sx.EXPORTS) == declared
+    assert L.sx_abi_version() == 1
+
+
+def test_no_gpu_means_no_scan():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(sx.SxError) as e:
+        sx.Scanner([rc.mission()], device=0)
+    assert e.value.code == sx.SX_E_NO_DEVICE
+    sc = sx.Scanner([rc.mission()], device=sx.SX_HOST_ONLY)
+    with pytest.raises(sx.SxError) as e:
+        sc.scan(b"no device, no scan")
+    assert e.value.code == sx.SX_E_STATE
+
+
+@pytest.mark.parametrize("expected,flags,inputs", CLI_CASES, ids=[c[0] for c in CLI_CASES])
+@pytest.mark.parametrize("chunk", [None, 4096, 8192])
+def test_replay_reproduces_cli_goldens(expected, flags, inputs, chunk):
+    out = run_cli_product(rc.missions(**flags), [rd(i) for i in inputs], radix="x", chunk_bytes=chunk)
+    assert out == rd(expected)
+
+
+@pytest.mark.parametrize("kat", K.SCAN_KATS, ids=[k["name"] for k in K.SCAN_KATS])
+def test_replay_scan_known_answers(kat):
+    sc = ProductScanner(kat["mission"])
+    for i, call in enumerate(kat["calls"]):
+        got = sc.scan(call["input"], file_id=0, is_last=call["is_last"])
+        slim = [dict(position=f["position"], precision=f["precision"], s=f["s"]) for f in got]
+        if "findings" in call:
+            assert slim == call["findings"], (kat["name"], i)
+        if "findings_prefix" in call:
+            assert slim[:len(call["findings_prefix"])] == call["findings_prefix"], (kat["name"], i)
+        if "n_findings_not" in call:
+            assert len(slim) != call["n_findings_not"]
+
+
+def test_replay_merger_known_answer():
+    k = K.MERGER_KAT
+    ms = rc.missions(**k["flags"])
+    sc = sx.Scanner(ms, device=sx.SX_HOST_ONLY)
+    from product_harness import oracle_runs_for_chunk
+    res = sc.replay_runs(k["input"], oracle_runs_for_chunk(ms, k["input"], 0), file_id=0, is_last=True)
+    got = [(f["s"], f["position"], f["precision"], f["mission_id"]) for f in res.findings()]
+    assert got == k["merged"]
+
+
+# ------------------------------------------------------------------------------------------
+# differential: sparse replay == the oracle's full scan
+# ------------------------------------------------------------------------------------------
+WORDS_ASCII = [b"/usr/lib/x86_64-linux-gnu/libfoo.so.1", b"C:\\Windows\\System32\\drivers\\etc\\hosts", b"hello world",
+               b"The quick brown fox jumps over the lazy dog. " * 5, b"A" * 64, b"B" * 63, b"C" * 65, b"D" * 128,
+               b"x" * 300, b"key=value; path=/;", b"abc", b"abcd", b"0123456789"]
+WORDS_UNI = ["Բարեւ աշխարհ ողջույն", "שלום עולם מה שלומך היום", "مرحبا بالعالم كيف حالك", "Привет, мир! Как дела?",
+             "Καλημέρα κόσμε", "žluťoučký kůň úpěl ďábelské ódy", "日本語のテキスト文字列", "𝔘𝔫𝔦𝔠𝔬𝔡𝔢 𝔱𝔢𝔵𝔱 😀😀😀",
+             "ÄÖÜäöüß" * 12, "ՀայերենՀայերենՀայերեն" * 4]
+
+
+def synth(rng, size, density, encodings=("utf-8", "utf-16le", "utf-16be", "latin")):
+    """Random bytes with planted strings in several encodings, some at slice/window edges."""
+    buf = bytearray(rng.randbytes(size))
+    pos = 0
+    while pos < size:
+        pos += int(rng.expovariate(density)) + 1
+        if rng.random() < 0.25:  # snap near a 4096 / 128 boundary
+            g = rng.choice([4096, 128, 1024])
+            pos = (pos // g + 1) * g - rng.randrange(0, 24)
+        w = rng.choice(WORDS_ASCII) if rng.random() < 0.5 else rng.choice(WORDS_UNI).encode("utf-8")
+        enc = rng.choice(encodings)
+        if enc == "utf-16le":
+            w = w.decode("utf-8").encode("utf-16-le")
+        elif enc == "utf-16be":
+            w = w.decode("utf-8").encode("utf-16-be")
+        elif enc == "latin":
+            w = w.decode("utf-8").encode("koi8-r", "replace")
+        if pos < 0 or pos + len(w) > size:
+            continue
+        buf[pos:pos + len(w)] = w
+        pos += len(w)
+    return bytes(buf)
+
+
+def soup(rng, size):
+    """Adversarial byte soup: leads, boundary continuations, surrogate halves, short ASCII."""
+    alphabet = [0x41, 0x42, 0x20, 0x7E, 0x7F, 0x00, 0x0A, 0x80, 0x8F, 0x90, 0x9F, 0xA0, 0xBF, 0xC0, 0xC1, 0xC2,
+                0xD5, 0xDF, 0xE0, 0xE1, 0xED, 0xEE, 0xF0, 0xF1, 0xF4, 0xF5, 0xFF, 0xD8, 0xDB, 0xDC, 0xDD, 0x05, 0x06]
+    return bytes(rng.choice(alphabet) for _ in range(size))
+
+
+OPTION_SETS = [
+    dict(chars_min="4"),
+    dict(chars_min="10", unicode_block_filter="African"),
+    dict(chars_min="5", output_line_len="10"),
+    dict(chars_min="3", output_line_len="6", grep_char="47"),
+    dict(chars_min="12", output_line_len="8"),
+    dict(chars_min="4", same_unicode_block=True, unicode_block_filter="All"),
+    dict(chars_min="6", output_line_len="30", ascii_filter="All-Ctrl+Wsp", unicode_block_filter="All"),
+    dict(chars_min="2", ascii_filter="0x7ffffffe000000007ffffffe00000000", unicode_block_filter="Latin"),
+    dict(chars_min="1", output_line_len="7", unicode_block_filter="Cyrillic"),
+    dict(chars_min="8", unicode_block_filter="Uncommon", ascii_filter="None"),
+]
+ENC_SETS = [["utf-8"], ["ascii"], ["utf-16le"], ["utf-16be"], ["koi8-r"], ["utf-8", "utf-16le", "utf-16be"],
+            ["ascii", "utf-8", "koi8-r"], ["utf-8,3,All,All", "utf-16le,,,Asian", "ascii,5"]]
+
+
+def _cases():
+    rng = random.Random(20240928)
+    cases = []
+    for i, opts in enumerate(OPTION_SETS):
+        for j, encs in enumerate(ENC_SETS):
+            if (i + j) % 3 == 0:  # a third of the grid keeps the CPU suite short
+                cases.append((opts, encs, rng.randrange(1 << 30)))
+    return cases
+
+
+@pytest.mark.parametrize("opts,encs,seed", _cases(), ids=lambda v: str(v)[:40])
+def test_sparse_replay_equals_full_scan(opts, encs, seed):
+    rng = random.Random(seed)
+    ms = rc.missions(encodings=encs, **opts)
+    kind = rng.choice(["synth_dense", "synth_sparse", "soup", "odd_files", "text"])
+    if kind == "synth_dense":
+        files = [synth(rng, 40000, 1 / 200)]
+    elif kind == "synth_sparse":
+        files = [synth(rng, 120000, 1 / 3000)]
+    elif kind == "soup":
+        files = [soup(rng, 30000)]
+    elif kind == "odd_files":  # odd lengths shift the UTF-16 unit parity and restart the slice grid
+        files = [synth(rng, 4096 * 2 + 1, 1 / 150), synth(rng, 8193 + 4096, 1 / 150), soup(rng, 777), b"",
+                 synth(rng, 20001, 1 / 300)]
+    else:
+        files = [rd("input1"), rd("input2")[:30001]]
+    want = sxo.run_cli(ms, files, radix="x")
+    for chunk in (None, 4096, 12288):
+        got = run_cli_product(ms, files, radix="x", chunk_bytes=chunk)
+        assert got == want, (kind, chunk)
+
+
+def test_flush_at_eof_path():
+    ms = rc.missions(encodings=["utf-8", "utf-16le"], chars_min="4", output_line_len="8")
+    rng = random.Random(5)
+    for _ in range(10):
+        f = synth(rng, rng.randrange(1, 9000), 1 / 100)
+        assert run_cli_product(ms, [f], radix="d", flush_at_eof=True) == sxo.run_cli(ms, [f], radix="d", flush_at_eof=True)
+
+
+def test_print_variants():
+    ms = rc.missions(encodings=["ascii", "utf-8"], chars_min="5")
+    f = [rd("input1")]
+    for radix in (None, "x", "d", "o"):
+        for nometa in (False, True):
+            assert run_cli_product(ms, f, radix=radix, no_metadata=nometa) == sxo.run_cli(ms, f, radix=radix, no_metadata=nometa)
