@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py — GiB/s scanned on BASELINE.json's headline workload (C3(i): 64 GiB synthetic
+background, `-e utf-8 -e utf-16le -e utf-16be -n 10 -u African`, three concurrent mission
+streams), one process per GPU.
+
+A step = one pass of the hot path (sx_scan_device: three HIP scan kernels on three streams
++ exact host replay -> findings in reference order) over the rank's HBM-resident shard.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
+(HIP-event kernel time vs the 8 TB/s HBM peak) and `cpu_baseline` (the oracle, the only
+runnable restatement of the reference, on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+SEED = 0x5EED5EED5EED5EED
+
+WORKLOADS = {
+    # BASELINE.json configs[2]: the configuration the metric is quoted on
+    "c3": dict(flags=dict(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10",
+                          unicode_block_filter="African"), gib=64.0,
+               name="C3(i): -e utf-8 -e utf-16le -e utf-16be -n 10 -u African -t x, synthetic background"),
+    # BASELINE.json configs[1]
+    "c2": dict(flags=dict(encodings=["utf-8"], chars_min="10"), gib=4.0,
+               name="C2: -e utf-8 -n 10 -t x, synthetic background"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--gib", type=float, default=None, help="bytes per GPU in GiB (default: the workload's size)")
+    ap.add_argument("--subchunk-kib", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mib", type=int, default=512)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import refconfig as rc
+    import stringsext_amd as sx
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the scan has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    wl = WORKLOADS[args.workload]
+    missions = rc.missions(**wl["flags"])
+    nbytes = int((args.gib if args.gib is not None else wl["gib"]) * (1 << 30)) // 4096 * 4096
+    sc = sx.Scanner(missions, device=local_rank, subchunk_bytes=args.subchunk_kib * 1024)
+
+    # weak scaling: rank r holds bytes [r*nbytes, (r+1)*nbytes) of one N*nbytes image
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
+    import ctypes
+    dptr = ctypes.c_void_p(buf.data_ptr())
+    sc.fill_background(dptr, rank * nbytes, nbytes, SEED)
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        sc.reset()
+        res = sc.scan_device(dptr, nbytes, file_id=1)
+        n = len(res)
+        st = sc.stats()
+        res.free()
+        return n, st
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = [0.0] * len(missions)
+    device_ms = replay_ms = d2h_ms = 0.0
+    findings = records = replay_bytes = 0
+    for _ in range(args.steps):
+        n, st = step()
+        findings = n
+        records = st.run_records
+        replay_bytes = st.replay_bytes
+        for k in range(len(missions)):
+            kernel_ms[k] += st.kernel_ms[k]
+        device_ms += st.device_ms
+        replay_ms += st.replay_ms
+        d2h_ms += st.d2h_ms
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    K = max(args.steps, 1)
+    kernel_ms = [x / K for x in kernel_ms]
+    device_ms /= K
+    out = None
+    if rank == 0:
+        total_bytes = world * nbytes * K
+        value = total_bytes / dt / (1 << 30)
+        # Dominant kernel = the scan kernels, one launch per mission per step, each reading the
+        # whole shard once (algorithmic bytes per launch = nbytes, SURVEY.md §8d: 1 byte per
+        # input byte x Mission pass; writes ~0).  They run concurrently on three streams and
+        # share the HBM, so the roofline figure is the aggregate: (missions x nbytes) over the
+        # span from the first launch to the last completion, HIP events on the mission streams.
+        span_ms = max(kernel_ms)  # concurrent streams: the longest kernel spans the group
+        agg_gbs = len(missions) * nbytes / (span_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "sx::scan_kernel<*> x%d concurrent streams" % len(missions),
+            "algorithmic_bytes_per_launch": nbytes,
+            "per_kernel_ms": [round(x, 3) for x in kernel_ms],
+            "per_kernel_gbs": [round(nbytes / (x * 1e-3) / 1e9, 1) if x > 0 else None for x in kernel_ms],
+        }
+        out = {
+            "metric": "GiB/s scanned", "value": round(value, 2), "unit": "GiB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": wl["name"], "bytes_per_gpu": nbytes, "missions": len(missions),
+                       "parallelism": f"byte-range shards x{world}", "passes": len(missions)},
+            "roofline": roofline,
+            "breakdown_ms_per_step": {"device_scan": round(device_ms, 3), "sparse_download": round(d2h_ms / K, 3),
+                                      "host_replay": round(replay_ms / K, 3)},
+            "findings_per_step_rank0": findings, "run_records_rank0": records,
+            "replay_fraction": round(replay_bytes / (len(missions) * nbytes), 5),
+            "kernel_only_gib_s": round(world * nbytes / (device_ms * 1e-3) / (1 << 30), 1) if device_ms > 0 else None,
+        }
+        if not args.no_cpu_baseline:
+            import sxo_binding as sxo
+            sample = min(args.cpu_sample_mib << 20, nbytes)
+            host = sxo.background(0, sample, SEED)
+            t1 = time.perf_counter()
+            n_ref, _ = sxo.run_count(missions, [host])
+            cdt = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": round(sample / cdt / (1 << 30), 4), "unit": "GiB/s", "cores": 1, "kind": "port",
+                "sample": f"first {sample >> 20} MiB of the same background, same {len(missions)} missions, "
+                          f"oracle/libsxo.so (C restatement, -O3), sequential missions on one core; "
+                          f"{n_ref} findings",
+            }
+        print(json.dumps(out), flush=True)
+    sc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

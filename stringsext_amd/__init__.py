@@ -173,11 +173,12 @@ class Result:
 class Scanner:
     """One sx_ctx: N missions bound to one HIP device (device=SX_HOST_ONLY: replay stage only)."""
 
-    def __init__(self, mission_dicts, device=0, subchunk_bytes=0, record_capacity=0, generic_kernels=False):
+    def __init__(self, mission_dicts, device=0, subchunk_bytes=0, record_capacity=0, generic_kernels=False,
+                 replay_threads=0):
         L = lib()
         self.n = len(mission_dicts)
         self._ms = (Mission * self.n)(*[Mission.from_dict(d) for d in mission_dicts])
-        opt = Options(subchunk_bytes, record_capacity, 0, SX_OPT_GENERIC_KERNELS if generic_kernels else 0)
+        opt = Options(subchunk_bytes, record_capacity, replay_threads, SX_OPT_GENERIC_KERNELS if generic_kernels else 0)
         self.h = C.c_void_p()
         rc = L.sx_create(C.byref(self.h), self._ms, self.n, device, C.byref(opt))
         if rc != SX_OK:

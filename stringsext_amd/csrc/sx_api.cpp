@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <deque>
 #include <mutex>
@@ -165,23 +166,61 @@ int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_byt
     return SX_OK;
 }
 
+unsigned replay_threads(const sx_ctx* ctx) {
+    unsigned n = ctx->opt.replay_threads ? ctx->opt.replay_threads : std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    return n > 256 ? 256 : n;
+}
+
+// Stage B for all missions: every (mission, part) pair is one task for a small thread pool;
+// part 0 of a mission starts from its exact carried state, the others speculate, and the
+// per-mission stitch verifies/repairs them serially.
 int replay_all(sx_ctx* ctx, ByteView& bytes, uint64_t len, int file_id, bool is_last,
                const std::vector<std::vector<sx_run>>& runs, sx_result** out) {
     const double t0 = now_ms();
     const size_t nm = ctx->missions.size();
-    std::vector<MissionFindings> per(nm);
-    auto work = [&](size_t k) {
-        replay_chunk(ctx->missions[k], ctx->states[k], bytes, len, file_id, is_last, runs[k].data(), runs[k].size(),
-                     &per[k]);
+    const unsigned nthreads = replay_threads(ctx);
+    std::vector<uint64_t> bounds;
+    replay_plan(len, nthreads, &bounds);
+    const size_t np = bounds.size() - 1;
+    std::vector<std::vector<ReplayPart>> parts(nm, std::vector<ReplayPart>(np));
+    std::vector<uint64_t> consumed0(nm), stream0(nm);
+    for (size_t k = 0; k < nm; k++) { consumed0[k] = ctx->states[k].consumed_bytes; stream0[k] = ctx->states[k].stream_bytes; }
+    std::atomic<size_t> next{ 0 };
+    auto worker = [&]() {
+        for (;;) {
+            const size_t t = next.fetch_add(1);
+            if (t >= nm * np) break;
+            const size_t k = t / np, p = t % np;
+            replay_part(ctx->missions[k], ctx->states[k], consumed0[k], stream0[k], bytes, len, file_id, is_last,
+                        runs[k].data(), runs[k].size(), bounds[p], bounds[p + 1], p == 0, &parts[k][p]);
+        }
     };
-    if (nm == 1) work(0);
+    const size_t nw = std::min<size_t>(nthreads, nm * np);
+    if (nw <= 1) worker();
     else {
         std::vector<std::thread> th;
-        for (size_t k = 0; k < nm; k++) th.emplace_back(work, k);
+        for (size_t i = 0; i < nw; i++) th.emplace_back(worker);
         for (auto& t : th) t.join();
     }
+    const double t_parts = now_ms();
+    std::vector<MissionFindings> per(nm);
+    auto stitch = [&](size_t k) {
+        replay_stitch(ctx->missions[k], ctx->states[k], consumed0[k], stream0[k], bytes, len, file_id, is_last,
+                      runs[k].data(), runs[k].size(), parts[k], &per[k]);
+    };
+    if (nm == 1) stitch(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < nm; k++) th.emplace_back(stitch, k);
+        for (auto& t : th) t.join();
+    }
+    const double t_stitch = now_ms();
     sx_result* r = new sx_result();
     merge_findings(per, &r->r);
+    if (getenv("SX_TIMING"))
+        fprintf(stderr, "[sx] replay: plan+parts %.2f ms (%zu tasks, %zu workers), stitch %.2f ms, merge %.2f ms\n",
+                t_parts - t0, nm * np, nw, t_stitch - t_parts, now_ms() - t_stitch);
     for (auto& mf : per) ctx->stats.replay_bytes += mf.replay_bytes;
     ctx->stats.findings += r->r.findings.size();
     ctx->stats.replay_ms += now_ms() - t0;
@@ -292,7 +331,8 @@ static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_
         // download only what the replay will look at
         const double t0 = now_ms();
         std::vector<std::pair<uint64_t, uint64_t>> rg;
-        for (size_t k = 0; k < nm; k++) replay_ranges(ctx->missions[k], ctx->states[k], len, runs[k].data(), runs[k].size(), &rg);
+        for (size_t k = 0; k < nm; k++)
+            replay_ranges(ctx->missions[k], ctx->states[k], len, runs[k].data(), runs[k].size(), replay_threads(ctx), &rg);
         std::sort(rg.begin(), rg.end());
         std::vector<std::pair<uint64_t, uint64_t>> mg;
         for (auto& r : rg) {
@@ -364,6 +404,7 @@ int sx_scan_device(sx_ctx* ctx, const void* device_bytes, uint64_t len, int inpu
     if (!ctx || !out || (!device_bytes && len)) return SX_E_INVALID;
     begin_call(ctx);
     if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
+    if ((uintptr_t)device_bytes & 15) { ctx->err = "device_bytes must be 16-byte aligned"; return SX_E_INVALID; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return scan_common(ctx, nullptr, (const uint8_t*)device_bytes, len, input_file_id, is_last_input_buffer, out);
 }
@@ -373,6 +414,7 @@ int sx_device_runs(sx_ctx* ctx, int mission_index, const void* device_bytes, uin
     if (!ctx || !runs || !n_runs || mission_index < 0 || (size_t)mission_index >= ctx->missions.size()) return SX_E_INVALID;
     begin_call(ctx);
     if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
+    if ((uintptr_t)device_bytes & 15) { ctx->err = "device_bytes must be 16-byte aligned"; return SX_E_INVALID; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::vector<std::vector<sx_run>> out;
     int rc = device_runs(ctx, { mission_index }, (const uint8_t*)device_bytes, len, { (uint32_t)(stream_parity & 1) },

@@ -167,10 +167,28 @@ struct MissionFindings {
 void replay_chunk(const Mission& m, ScannerState& st, ByteView& bytes, uint64_t len, int input_file_id,
                   bool is_last_input_buffer, const sx_run* runs, uint64_t n_runs, MissionFindings* out);
 
-// Byte ranges of the chunk that replay_chunk() will (very likely) touch, for sparse
-// download of device-resident input.  Appends [lo,hi) pairs (unsorted, may overlap).
+// The same, split into parts that can run on different threads: part 0 starts from the exact
+// carried state, the others speculate that nothing is carried where they start;
+// replay_stitch() verifies that against the exact part before and repairs where it was wrong.
+struct ReplayPart {
+    MissionFindings findings;
+    struct Region { uint64_t start, end; size_t f0, f1; };
+    std::vector<Region> regions;
+    uint64_t end_pos = 0;
+    ScannerState state;
+};
+void replay_plan(uint64_t len, unsigned max_parts, std::vector<uint64_t>* bounds);  // bounds[k]..bounds[k+1]
+void replay_part(const Mission& m, const ScannerState& entry, uint64_t consumed0, uint64_t stream0, ByteView& bytes,
+                 uint64_t len, int file_id, bool is_last, const sx_run* runs, uint64_t n_runs, uint64_t lo, uint64_t hi,
+                 bool entry_exact, ReplayPart* part);
+void replay_stitch(const Mission& m, ScannerState& st, uint64_t consumed0, uint64_t stream0, ByteView& bytes,
+                   uint64_t len, int file_id, bool is_last, const sx_run* runs, uint64_t n_runs,
+                   std::vector<ReplayPart>& parts, MissionFindings* out);
+
+// Byte ranges of the chunk that the replay will (very likely) touch, for sparse download of
+// device-resident input.  Appends [lo,hi) pairs (unsorted, may overlap).
 void replay_ranges(const Mission& m, const ScannerState& st, uint64_t len, const sx_run* runs, uint64_t n_runs,
-                   std::vector<std::pair<uint64_t, uint64_t>>* ranges);
+                   unsigned parts, std::vector<std::pair<uint64_t, uint64_t>>* ranges);
 
 // Turn raw device records (any order, sub-chunk pieces flagged open) into maximal runs
 // with >= min_chars characters, sorted by start.

@@ -465,8 +465,11 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
     if (win_hi > p.len) win_hi = p.len;
     const uint8_t* base_ptr = p.data + win_lo;
     const u32 base_lo = uniform((u32)(uintptr_t)base_ptr), base_hi = uniform((u32)((uintptr_t)base_ptr >> 32));
+    // The range check is per dword: a dword that straddles the end would read as 0, so the
+    // size is rounded up to the 16-byte block (same page: `data` is 16-byte aligned); bytes
+    // past the chunk end are masked by the classifiers (`avail`), never trusted.
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(((u64)base_hi << 32) | base_lo), 0, (int)uniform((u32)(win_hi - win_lo)), 0x00020000);
+        (void*)(((u64)base_hi << 32) | base_lo), 0, (int)uniform(((u32)(win_hi - win_lo) + 15u) & ~15u), 0x00020000);
     auto load = [&](u32 off) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0); };
 
     const int n_tiles = (int)((sub_end - sub_start + kTileBytes - 1) / kTileBytes);

@@ -8,12 +8,21 @@
 //   * between long runs the carried state is only ever a short `leftover`
 //     (src/finding_collection.rs:269-285) that dies with the run it belongs to.
 // So we run FindingCollection::from (src/finding_collection.rs:84-342) verbatim, but only
-// over windows from three windows before a long run until the carried state is clean
-// again (leftover empty, `maybe_cut` false).  Three windows = 6q bytes > 4(q-1) bytes, the
-// longest a run of < q chars can be, so whatever short leftover existed where we start has
-// ended before the first window that can print.  The decoder's private state at the start
-// is re-derived from the 8 bytes before it.  The chunk's first windows (exact carried
-// state) and last windows (exact state for the next chunk) are always replayed.
+// from the window in which a long run begins until the run is over and no cut string is
+// pending (`maybe_cut` false).  What the reference carries into that first window is
+// re-derived from the few bytes before it:
+//   * the decoder's private state (UTF-8: <= 3 bytes; UTF-16: stream parity + last unit);
+//   * whether a `leftover` exists.  Between long runs a leftover is a run of < min(n,q)
+//     accepted chars hanging over the window edge; it can never be printed or reach q, and
+//     its only observable effect is `Precision::Before` on the first string of the next
+//     decoder call (src/finding_collection.rs:214-221).  So its content is irrelevant: we
+//     carry the last accepted char before the edge if there is one, nothing otherwise.
+//     (If it joined a run of >= min(n,q) chars, that run would begin before the edge and
+//     the device would have reported it from there.)
+// The chunk's first windows start from the exact carried ScannerState and are followed
+// strictly (until leftover AND maybe_cut are clear: a run split over two chunks is seen by
+// neither chunk's device scan); the last window is always replayed so that the state
+// handed to the next chunk is exact.
 #include <stdio.h>
 #include <string.h>
 
@@ -95,75 +104,112 @@ static inline uint64_t window_end(uint64_t p, size_t W, uint64_t len) {  // end 
     if (e > s + kInputBufLen) e = s + kInputBufLen;
     return e < len ? e : len;
 }
-constexpr int kLeadWindows = 3;
+constexpr int kLeadWindows = 3;  // sparse-download margin only (see replay_ranges)
 
 namespace {
 
-class ChunkReplay {
+struct RegionLog {
+    uint64_t start, end;  // window starts: replayed [start, end)
+    size_t f0, f1;        // findings [f0, f1) of the worker's list
+};
+
+// One worker: replays the regions that begin in [lo, hi) of the chunk.
+class RangeReplay {
 public:
-    ChunkReplay(const Mission& m, ScannerState& st, ByteView& bytes, uint64_t len, int file_id, bool is_last,
-                const sx_run* runs, uint64_t n_runs, MissionFindings* out)
-        : m_(m), st_(st), bytes_(bytes), len_(len), file_id_(file_id), is_last_(is_last), runs_(runs),
-          n_runs_(n_runs), out_(out), W_(m.window), consumed0_(st.consumed_bytes), stream0_(st.stream_bytes) {
-        size_t cap = 0x9192;  // OUTPUT_BUF_LEN, src/finding.rs:23
+    RangeReplay(const Mission& m, ByteView& bytes, uint64_t len, int file_id, bool is_last, const sx_run* runs,
+                uint64_t n_runs, uint64_t consumed0, uint64_t stream0)
+        : m_(m), bytes_(bytes), len_(len), file_id_(file_id), is_last_(is_last), runs_(runs), n_runs_(n_runs),
+          W_(m.window), consumed0_(consumed0), stream0_(stream0) {
+        const size_t cap = 0x9192;  // OUTPUT_BUF_LEN, src/finding.rs:23
         const size_t need = 4 * m.q + 3 * kInputBufLen + 64;
         ob_.resize(cap < need ? need : cap);
-        tail_start_ = len ? back_windows(len - 1, W_, kLeadWindows) : 0;
     }
 
-    void run() {
-        uint64_t pos = 0;
+    // `st` describes position `lo`: the exact carried state (entry_exact) or "nothing carried"
+    // (then the decoder is re-derived from the bytes before lo).  Regions that begin in
+    // [lo, hi) are replayed, the last one to its own end.  owns_tail: also bring the state to
+    // the chunk end exactly.  Returns the position up to which the state is known clean/exact.
+    uint64_t run(ScannerState& st, uint64_t lo, uint64_t hi, bool entry_exact, bool owns_tail,
+                 MissionFindings* out, std::vector<RegionLog>* log) {
+        st_ = &st; out_ = out; hi_ = hi; owns_tail_ = owns_tail;
+        ri_ = 0;
+        while (ri_ < n_runs_ && runs_[ri_].end <= lo) ri_++;
+        strict_ = entry_exact && !st.clean();  // exact carried state: follow it until it is clean
+        if (!entry_exact) derive_state(lo, lo, st.decoder);
+        uint64_t pos = lo;
         while (pos < len_) {
-            if (st_.clean()) {
-                const uint64_t t = next_trigger(pos);
-                if (t > pos) { prime(pos, t); pos = t; continue; }
+            if (!strict_ && !st.last_run_str_was_printed_and_is_maybe_cut_str) {
+                const uint64_t r = next_region_start(pos);
+                if (r >= len_) { pos = len_; break; }
+                if (r >= hi_ && !owns_tail_) { pos = std::max(pos, hi_); break; }
+                pos = r;
             }
+            RegionLog rg{ pos, 0, out->v.size(), 0 };
             pos = scan_from(pos);
+            strict_ = false;
+            rg.end = pos; rg.f1 = out->v.size();
+            if (log) log->push_back(rg);
         }
-        st_.consumed_bytes = consumed0_ + len_;
-        st_.stream_bytes = stream0_ + len_;
+        st.consumed_bytes = consumed0_ + pos;
+        st.stream_bytes = stream0_ + pos;
+        return pos;
     }
 
 private:
-    // first window start at or after which the replay must be running
-    uint64_t next_trigger(uint64_t pos) {
-        while (ri_ < n_runs_ && runs_[ri_].end <= pos) ri_++;
-        uint64_t t = tail_start_;
-        if (ri_ < n_runs_) {
-            const uint64_t r = back_windows(runs_[ri_].start, W_, kLeadWindows);
-            if (r < t) t = r;
-        }
-        return t;
-    }
-
-    // Bring the decoder from its exact state at `from` to its exact state at `to` without
-    // looking at what it decodes.  Far jumps restart it 8 bytes (whole units) before `to`:
-    // UTF-8 state depends on <= 3 bytes, UTF-16 on the last unit and the stream parity.
-    void prime(uint64_t from, uint64_t to) {
-        uint64_t p = from;
-        if (to - from > 16) {
-            p = to - 8;
-            if (m_.is_utf16() && ((stream0_ + p) & 1)) p -= 1;
-            st_.decoder.reset(m_.c.encoding);
-        }
-        uint8_t sink[96];
-        while (p < to) {
-            const size_t n = (size_t)std::min<uint64_t>(to - p, 16);
+    // Re-derive what the reference carries into window start B: run a decoder over the few
+    // bytes before B (from `pos` with its exact decoder `d_pos` if that is nearer than 8
+    // bytes).  Sets st_->decoder to the decoder state at B and st_->leftover to the last
+    // accepted character if it is the last thing delivered before B (see file comment).
+    void derive_state(uint64_t B, uint64_t pos, const Decoder& d_pos) {
+        Decoder d(m_.c.encoding);
+        uint64_t p = B >= 8 ? B - 8 : 0;
+        if (m_.is_utf16() && ((stream0_ + p) & 1)) p = p ? p - 1 : p + 1;
+        if (p <= pos && pos <= B) { p = pos; d = d_pos; }
+        if (p > B) p = B;
+        uint8_t sink[96], last[4];
+        size_t last_len = 0;
+        if (p < B) {
+            const size_t n = (size_t)(B - p);
             const uint8_t* s = bytes_.span(p, n);
             size_t i = 0;
             for (;;) {
-                const DecodeStep r = st_.decoder.decode_to_str_without_replacement(s + i, n - i, sink, sizeof sink, false);
+                const DecodeStep r = d.decode_to_str_without_replacement(s + i, n - i, sink, sizeof sink, false);
                 i += r.read;
+                for (size_t w = 0; w < r.written;) {
+                    const uint8_t lead = sink[w];
+                    const size_t cl = lead < 0x80 ? 1 : lead < 0xE0 ? 2 : lead < 0xF0 ? 3 : 4;
+                    if (m_.filter.pass_lead(lead)) { memcpy(last, sink + w, cl); last_len = cl; }
+                    else last_len = 0;
+                    w += cl;
+                }
                 if (r.result == DecoderResult::InputEmpty) break;
+                if (r.result == DecoderResult::Malformed) last_len = 0;
             }
-            p += n;
         }
+        st_->decoder = d;
+        st_->last_scan_run_leftover.assign((const char*)last, last_len);
+        st_->last_run_str_was_printed_and_is_maybe_cut_str = false;
+    }
+
+    // First window start >= pos at which the replay must be running (len_ if there is none).
+    // No cut string is pending at pos and the decoder state at pos is exact.
+    uint64_t next_region_start(uint64_t pos) {
+        while (ri_ < n_runs_ && runs_[ri_].end <= pos) ri_++;
+        uint64_t want = len_;
+        if (ri_ < n_runs_) want = window_start(runs_[ri_].start, W_);
+        if (owns_tail_ && len_) want = std::min(want, window_start(len_ - 1, W_));
+        if (want >= len_) return len_;
+        if (want <= pos) return pos;                   // state at pos is exact: just go on
+        if (want >= hi_ && !owns_tail_) return want;  // somebody else's
+        derive_state(want, pos, st_->decoder);
+        return want;
     }
 
     // FindingCollection::from over consecutive windows beginning at window start `pos`;
-    // returns the first window start at which the carried state is clean and nothing
-    // nearby needs replaying (or len).
+    // returns the first window start at which the carried state is clean and the next
+    // region does not begin right there (or len).
     uint64_t scan_from(uint64_t pos) {
+        ScannerState& st = *st_;
         uint8_t* ob = ob_.data();
         const size_t cap = ob_.size();
         while (pos < len_) {
@@ -176,13 +222,13 @@ private:
             size_t din = (size_t)(pos - soff), dend = 0, dout = 0;
 
             size_t leftover_len = 0;  // :101-114
-            if (!st_.last_scan_run_leftover.empty()) {
-                leftover_len = st_.last_scan_run_leftover.size();
-                memcpy(ob, st_.last_scan_run_leftover.data(), leftover_len);
-                st_.last_scan_run_leftover.clear();
+            if (!st.last_scan_run_leftover.empty()) {
+                leftover_len = st.last_scan_run_leftover.size();
+                memcpy(ob, st.last_scan_run_leftover.data(), leftover_len);
+                st.last_scan_run_leftover.clear();
                 dout = leftover_len;
             }
-            bool maybe_cut = st_.last_run_str_was_printed_and_is_maybe_cut_str;  // :115
+            bool maybe_cut = st.last_run_str_was_printed_and_is_maybe_cut_str;  // :115
             bool extra_round = false, is_last_window = false, stopped = false;
 
             while (din < slen) {  // :124
@@ -193,12 +239,12 @@ private:
                 out_->replay_bytes += dend - wbase;
 
                 for (;;) {  // 'decoder, :134
-                    const DecodeStep r = st_.decoder.decode_to_str_without_replacement(
+                    const DecodeStep r = st.decoder.decode_to_str_without_replacement(
                         wp + (din - wbase), dend - din, ob + dout, cap - dout, extra_round);
                     uint8_t precision = SX_PRECISION_EXACT;  // :146
 
                     if (r.written > 0 && din == 0 && (ob[dout] & 0x80)) {  // :153,176
-                        Decoder fresh = st_.decoder.new_decoder_without_bom_handling();
+                        Decoder fresh = st.decoder.new_decoder_without_bom_handling();
                         uint8_t probe[8] = { 0 }, have[8] = { 0 };
                         const size_t pn = std::min<size_t>(slen, 32);
                         const DecodeStep pr = fresh.decode_to_str_without_replacement(bytes_.span(soff, pn), pn, probe,
@@ -217,30 +263,37 @@ private:
                     const bool continue_str_if_possible = maybe_cut;  // :240-241
                     maybe_cut = false;
 
-                    SplitStr it(ob + split_start, split_end - split_start, m_.c.chars_min_nb,
-                                m_.c.require_same_unicode_block != 0, continue_str_if_possible, invalid_bytes_after,
-                                m_.filter, m_.q);
-                    SplitStrResult ch;
-                    while (it.next(&ch)) {  // :246
-                        if (!ch.s_is_to_be_filtered_again) {
-                            sx_finding f{};
-                            f.position = consumed + din;  // :260
-                            f.str_off = (uint32_t)out_->arena.size();
-                            f.str_len = (uint32_t)ch.len;
-                            f.precision = precision;
-                            f.completes_previous = ch.s_completes_previous_s;
-                            f.mission_id = m_.c.mission_id;
-                            f.input_file_id = (int16_t)file_id_;
-                            f.slice_index = slice_index;
-                            out_->arena.append((const char*)ch.s, ch.len);
-                            out_->v.push_back(f);
-                            leftover_len = 0;
-                            maybe_cut = ch.s_is_maybe_cut;  // :268
-                        } else {
-                            leftover_len = ch.len;  // :281
-                            maybe_cut = false;
+                    // A chunk is only ever returned if it continues a cut string, may be carried
+                    // over the window edge, or has >= chars_min_nb chars (helper.rs:410-415):
+                    // a few bytes in front of a malformed sequence cannot be any of these.
+                    const bool may_yield = continue_str_if_possible || !invalid_bytes_after
+                                           || split_end - split_start >= m_.c.chars_min_nb;
+                    if (split_end > split_start && may_yield) {
+                        SplitStr it(ob + split_start, split_end - split_start, m_.c.chars_min_nb,
+                                    m_.c.require_same_unicode_block != 0, continue_str_if_possible, invalid_bytes_after,
+                                    m_.filter, m_.q);
+                        SplitStrResult ch;
+                        while (it.next(&ch)) {  // :246
+                            if (!ch.s_is_to_be_filtered_again) {
+                                sx_finding f{};
+                                f.position = consumed + din;  // :260
+                                f.str_off = (uint32_t)out_->arena.size();
+                                f.str_len = (uint32_t)ch.len;
+                                f.precision = precision;
+                                f.completes_previous = ch.s_completes_previous_s;
+                                f.mission_id = m_.c.mission_id;
+                                f.input_file_id = (int16_t)file_id_;
+                                f.slice_index = slice_index;
+                                out_->arena.append((const char*)ch.s, ch.len);
+                                out_->v.push_back(f);
+                                leftover_len = 0;
+                                maybe_cut = ch.s_is_maybe_cut;  // :268
+                            } else {
+                                leftover_len = ch.len;  // :281
+                                maybe_cut = false;
+                            }
+                            precision = SX_PRECISION_AFTER;  // :289
                         }
-                        precision = SX_PRECISION_AFTER;  // :289
                     }
                     dout += r.written;  // :292
                     din += r.read;      // :294
@@ -254,46 +307,142 @@ private:
                     }
                 }
                 // a window boundary inside the slice: may we stop here?
-                if (din < slen && leftover_len == 0 && !maybe_cut && next_trigger(soff + din) > soff + din) {
+                if (din < slen && !maybe_cut && may_drop(ob + dout - leftover_len, leftover_len)
+                    && region_over(soff + din)) {
                     stopped = true;
                     break;
                 }
             }
             // :330-338
-            st_.last_scan_run_leftover.assign((const char*)ob + dout - leftover_len, leftover_len);
-            st_.last_run_str_was_printed_and_is_maybe_cut_str = maybe_cut;
+            st.last_scan_run_leftover.assign((const char*)ob + dout - leftover_len, leftover_len);
+            st.last_run_str_was_printed_and_is_maybe_cut_str = maybe_cut;
             pos = soff + din;
             if (stopped) return pos;
-            if (st_.clean() && next_trigger(pos) > pos) return pos;
+            if (!maybe_cut && may_drop(ob + dout - leftover_len, leftover_len) && region_over(pos)) return pos;
         }
         return pos;
     }
 
+    // May the replay stop although this leftover is carried?  Only a leftover of fewer than
+    // min(n,q) chars is inert (file comment).  A longer one is a long run that reached the
+    // window edge (possibly followed by an incomplete character) and is still waiting to be
+    // printed by the next decoder call (src/helper.rs:389-392).
+    bool may_drop(const uint8_t* lo, size_t n) const {
+        if (n == 0) return true;
+        if (strict_) return false;
+        if (n < m_.long_run) return true;
+        size_t chars = 0;
+        for (size_t i = 0; i < n; i++) chars += (lo[i] & 0xC0) != 0x80;
+        return chars < m_.long_run;
+    }
+
+    // no cut string pending at window start p: is there nothing that forces the replay to continue right here?
+    bool region_over(uint64_t p) {
+        while (ri_ < n_runs_ && runs_[ri_].end <= p) ri_++;
+        if (ri_ < n_runs_ && window_start(runs_[ri_].start, W_) <= p) return false;
+        if (owns_tail_ && len_ && window_start(len_ - 1, W_) <= p) return false;
+        return true;
+    }
+
     const Mission& m_;
-    ScannerState& st_;
     ByteView& bytes_;
     const uint64_t len_;
     const int file_id_;
     const bool is_last_;
     const sx_run* runs_;
     const uint64_t n_runs_;
-    MissionFindings* out_;
     const size_t W_;
     const uint64_t consumed0_, stream0_;
     std::vector<uint8_t> ob_;
-    uint64_t tail_start_ = 0;
-    uint64_t ri_ = 0;
+    ScannerState* st_ = nullptr;
+    MissionFindings* out_ = nullptr;
+    uint64_t hi_ = 0, ri_ = 0;
+    bool owns_tail_ = false, strict_ = false;
 };
 
 }  // namespace
 
+void replay_plan(uint64_t len, unsigned max_parts, std::vector<uint64_t>* bounds) {
+    // partition boundaries on the slice grid; a partition is worth a thread from ~4 MiB on
+    bounds->clear();
+    uint64_t parts = std::min<uint64_t>(max_parts ? max_parts : 1, len / (4u << 20));
+    if (parts < 1) parts = 1;
+    const uint64_t per = (len / parts + kInputBufLen - 1) / kInputBufLen * kInputBufLen;
+    for (uint64_t k = 0; k < parts; k++) bounds->push_back(std::min(len, k * per));
+    bounds->push_back(len);
+}
+
+void replay_part(const Mission& m, const ScannerState& entry, uint64_t consumed0, uint64_t stream0, ByteView& bytes,
+                 uint64_t len, int file_id, bool is_last, const sx_run* runs, uint64_t n_runs, uint64_t lo, uint64_t hi,
+                 bool entry_exact, ReplayPart* part) {
+    part->state = entry;
+    if (!entry_exact) part->state.decoder.reset(m.c.encoding);
+    RangeReplay rr(m, bytes, len, file_id, is_last, runs, n_runs, consumed0, stream0);
+    std::vector<RegionLog> log;
+    part->end_pos = rr.run(part->state, lo, hi, entry_exact, hi >= len, &part->findings, &log);
+    part->regions.clear();
+    for (const RegionLog& r : log) part->regions.push_back({ r.start, r.end, r.f0, r.f1 });
+}
+
+// Serial verification of speculative parts (part k assumed "nothing carried" at its start):
+// keep a part's regions only from where the exact replay before it is clean and idle;
+// where a speculative region straddles that point, replay exactly from there (rare).
+void replay_stitch(const Mission& m, ScannerState& st, uint64_t consumed0, uint64_t stream0, ByteView& bytes,
+                   uint64_t len, int file_id, bool is_last, const sx_run* runs, uint64_t n_runs,
+                   std::vector<ReplayPart>& parts, MissionFindings* out) {
+    auto take = [&](const MissionFindings& src, size_t f0, size_t f1) {
+        for (size_t i = f0; i < f1; i++) {
+            sx_finding f = src.v[i];
+            const uint32_t off = (uint32_t)out->arena.size();
+            out->arena.append(src.arena, f.str_off, f.str_len);
+            f.str_off = off;
+            out->v.push_back(f);
+        }
+    };
+    uint64_t E = 0;
+    ScannerState cur = st;
+    for (size_t k = 0; k < parts.size(); k++) {
+        ReplayPart& p = parts[k];
+        out->replay_bytes += p.findings.replay_bytes;
+        size_t i = 0;
+        if (k > 0) {
+            for (;;) {
+                while (i < p.regions.size() && p.regions[i].start < E) i++;
+                if (i == 0 || p.regions[i - 1].end <= E) break;
+                // region i-1 began under a wrong assumption and reaches beyond E: redo it exactly
+                ReplayPart fix;
+                replay_part(m, cur, consumed0, stream0, bytes, len, file_id, is_last, runs, n_runs, E,
+                            std::min(len, p.regions[i - 1].end), false, &fix);
+                take(fix.findings, 0, fix.findings.v.size());
+                out->replay_bytes += fix.findings.replay_bytes;
+                E = std::max(E, fix.end_pos);
+                cur = fix.state;
+            }
+        }
+        bool kept = false;
+        for (; i < p.regions.size(); i++) { take(p.findings, p.regions[i].f0, p.regions[i].f1); kept = true; }
+        if (k == 0 || kept || p.end_pos > E) {
+            if (k == 0 || kept) cur = p.state;
+            E = std::max(E, p.end_pos);
+        }
+    }
+    // the state handed to the next chunk
+    cur.consumed_bytes = consumed0 + len;
+    cur.stream_bytes = stream0 + len;
+    st = cur;
+}
+
 void replay_chunk(const Mission& m, ScannerState& st, ByteView& bytes, uint64_t len, int input_file_id,
                   bool is_last_input_buffer, const sx_run* runs, uint64_t n_runs, MissionFindings* out) {
-    ChunkReplay(m, st, bytes, len, input_file_id, is_last_input_buffer, runs, n_runs, out).run();
+    const uint64_t consumed0 = st.consumed_bytes, stream0 = st.stream_bytes;
+    std::vector<ReplayPart> parts(1);
+    replay_part(m, st, consumed0, stream0, bytes, len, input_file_id, is_last_input_buffer, runs, n_runs, 0, len, true,
+                &parts[0]);
+    replay_stitch(m, st, consumed0, stream0, bytes, len, input_file_id, is_last_input_buffer, runs, n_runs, parts, out);
 }
 
 void replay_ranges(const Mission& m, const ScannerState& st, uint64_t len, const sx_run* runs, uint64_t n_runs,
-                   std::vector<std::pair<uint64_t, uint64_t>>* ranges) {
+                   unsigned parts, std::vector<std::pair<uint64_t, uint64_t>>* ranges) {
     if (len == 0) return;
     const size_t W = m.window;
     auto add = [&](uint64_t lo, uint64_t hi) {
@@ -308,6 +457,9 @@ void replay_ranges(const Mission& m, const ScannerState& st, uint64_t len, const
         add(lo, window_end(last < len ? last : len - 1, W, len) + 4 * W);
     }
     add(back_windows(len - 1, W, kLeadWindows), len);
+    std::vector<uint64_t> bounds;
+    replay_plan(len, parts, &bounds);
+    for (size_t k = 1; k + 1 < bounds.size(); k++) add(bounds[k], bounds[k] + 1);  // decoder priming at part starts
 }
 
 void merge_device_runs(const DevRun* recs, size_t n, uint64_t min_chars, std::vector<sx_run>* out) {

@@ -1,0 +1,185 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C-ABI
+(libstringsext_amd.so); the oracle is only the checker."""
+import os
+import random
+
+import pytest
+
+import refconfig as rc
+import stringsext_amd as sx
+import sxo_binding as sxo
+from golden import unit_kats as K
+from product_harness import ProductScanner, run_cli_product
+from test_host_logic import ENC_SETS, OPTION_SETS, soup, synth
+from test_oracle_golden import CLI_CASES, rd
+
+pytestmark = pytest.mark.gpu
+
+
+def device_runs(mdict, data, parity=0, min_chars=None, generic=False, subchunk=0, capacity=0):
+    sc = sx.Scanner([mdict], device=0, generic_kernels=generic, subchunk_bytes=subchunk, record_capacity=capacity)
+    try:
+        d = sc.alloc(len(data))
+        sc.upload(d, data)
+        mc = min_chars if min_chars is not None else max(1, min(mdict["chars_min_nb"], mdict["output_line_char_nb_max"]))
+        got = sc.device_runs(0, d, len(data), stream_parity=parity, min_chars=mc)
+        sc.free(d)
+        return got, mc
+    finally:
+        sc.close()
+
+
+RUN_MISSIONS = {
+    "ascii": dict(encodings=["ascii"], chars_min="4"),
+    "ascii_all": dict(encodings=["ascii"], chars_min="3", unicode_block_filter="All"),
+    "utf8_common": dict(encodings=["utf-8"], chars_min="10"),
+    "utf8_african": dict(encodings=["utf-8"], chars_min="10", unicode_block_filter="African"),
+    "utf8_all": dict(encodings=["utf-8"], chars_min="5", unicode_block_filter="All", ascii_filter="All-Ctrl+Wsp"),
+    "utf8_cjk": dict(encodings=["utf-8"], chars_min="3", unicode_block_filter="Cjk"),
+    "utf8_uncommon": dict(encodings=["utf-8"], chars_min="2", unicode_block_filter="Uncommon", ascii_filter="None"),
+    "utf16le_african": dict(encodings=["utf-16le"], chars_min="10", unicode_block_filter="African"),
+    "utf16be_common": dict(encodings=["utf-16be"], chars_min="4"),
+    "utf16le_all": dict(encodings=["utf-16le"], chars_min="3", unicode_block_filter="All"),
+    "utf16be_uncommon": dict(encodings=["utf-16be"], chars_min="2", unicode_block_filter="Uncommon"),
+    "koi8r": dict(encodings=["koi8-r"], chars_min="4", unicode_block_filter="Cyrillic"),
+    "win1251_all": dict(encodings=["windows-1251"], chars_min="6", unicode_block_filter="All"),
+    "odd_af": dict(encodings=["utf-8"], chars_min="4", ascii_filter="0x7ffffffe000000007ffffffe00000000"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(RUN_MISSIONS))
+@pytest.mark.parametrize("generic", [False, True], ids=["fast", "generic"])
+def test_device_runs_equal_oracle_runs(name, generic):
+    """Stage A: the run records of the HIP kernels == the oracle's sequential decoder."""
+    m = rc.missions(**RUN_MISSIONS[name])[0]
+    rng = random.Random(hash(name) & 0xFFFF)
+    datas = [
+        synth(rng, 200_000, 1 / 400),
+        soup(rng, 70_001),
+        rng.randbytes(1 << 20),
+        b"A" * 5000 + rng.randbytes(3000) + "Ж".encode() * 4000 + b"\x00" * 100 + b"zz" * 3000,
+        synth(rng, 1023, 1 / 50), synth(rng, 1025, 1 / 50), synth(rng, 17, 1 / 5), b"abcdefghijkl", b"",
+        ("Բարեւ" * 2000).encode("utf-16-le") + b"\x41" + ("שלום" * 2000).encode("utf-16-be"),
+        "𝔘𝔫𝔦𝔠𝔬𝔡𝔢😀".encode("utf-8") * 500 + "𝔘𝔫𝔦𝔠𝔬𝔡𝔢😀".encode("utf-16-le") * 500 + "𝔘𝔫𝔦😀".encode("utf-16-be") * 500,
+    ]
+    for di, data in enumerate(datas):
+        for parity in (0, 1):
+            for sub in (1024, 4096, 65536):
+                if sub != 65536 and len(data) > 300_000:
+                    continue
+                got, mc = device_runs(m, data, parity=parity, generic=generic, subchunk=sub)
+                want = sxo.runs(m, data, stream_parity=parity, min_chars=mc)
+                assert got == want, (name, di, parity, sub, len(got), len(want))
+
+
+def test_device_runs_min_chars_sweep_and_overflow():
+    m = rc.missions(encodings=["ascii"], chars_min="4")[0]
+    data = random.Random(3).randbytes(1 << 20)
+    for mc in (1, 2, 3, 9, 16, 17, 18, 40, 255):
+        got, _ = device_runs(m, data, min_chars=mc, capacity=1024)  # forces the grow-and-rerun path for small mc
+        assert got == sxo.runs(m, data, min_chars=mc), mc
+
+
+@pytest.mark.parametrize("expected,flags,inputs", CLI_CASES, ids=[c[0] for c in CLI_CASES])
+@pytest.mark.parametrize("chunk", [None, 8192])
+@pytest.mark.parametrize("generic", [False, True], ids=["fast", "generic"])
+def test_cli_golden_outputs_on_gpu(expected, flags, inputs, chunk, generic):
+    out = run_cli_product(rc.missions(**flags), [rd(i) for i in inputs], radix="x", chunk_bytes=chunk, device=0,
+                          generic_kernels=generic)
+    assert out == rd(expected)
+
+
+@pytest.mark.parametrize("kat", K.SCAN_KATS, ids=[k["name"] for k in K.SCAN_KATS])
+def test_scan_known_answers_on_gpu(kat):
+    sc = ProductScanner(kat["mission"], device=0)
+    for i, call in enumerate(kat["calls"]):
+        got = sc.scan(call["input"], file_id=0, is_last=call["is_last"])
+        slim = [dict(position=f["position"], precision=f["precision"], s=f["s"]) for f in got]
+        if "findings" in call:
+            assert slim == call["findings"], (kat["name"], i)
+        if "findings_prefix" in call:
+            assert slim[:len(call["findings_prefix"])] == call["findings_prefix"], (kat["name"], i)
+
+
+def _cases():
+    rng = random.Random(77)
+    out = []
+    for i, opts in enumerate(OPTION_SETS):
+        for j, encs in enumerate(ENC_SETS):
+            if (i + 2 * j) % 4 == 0:
+                out.append((opts, encs, rng.randrange(1 << 30)))
+    return out
+
+
+@pytest.mark.parametrize("opts,encs,seed", _cases(), ids=lambda v: str(v)[:40])
+def test_end_to_end_equals_oracle(opts, encs, seed):
+    """HIP kernels + host replay == the oracle's full scan, byte for byte."""
+    rng = random.Random(seed)
+    ms = rc.missions(encodings=encs, **opts)
+    files = [synth(rng, 150_000, 1 / 300), soup(rng, 20_001), synth(rng, 4096 * 3 + 1, 1 / 100), b"",
+             synth(rng, 50_000, 1 / 2000)]
+    want = sxo.run_cli(ms, files, radix="x")
+    for chunk, sub in ((None, 0), (16384, 1024)):
+        got = run_cli_product(ms, files, radix="x", chunk_bytes=chunk, device=0, subchunk_bytes=sub)
+        assert got == want, (chunk, sub)
+
+
+def test_device_resident_input_and_background_generator():
+    """sx_scan_device on HBM-resident synthetic background (BASELINE.md §3 generator on the
+    device) == the oracle on the same bytes generated on the host."""
+    ms = rc.missions(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African")
+    n = (8 << 20) + 4096 * 3 + 17
+    sc = sx.Scanner(ms, device=0)
+    d = sc.alloc(n)
+    sc.fill_background(d, 12345, n)
+    host = sxo.background(12345, n)
+    assert sc.download(d, n) == host
+    res = sc.scan_device(d, n, file_id=1)
+    got = sx.OUTPUT_BOM + res.printed(n_inputs=1, radix="x") + b"\n"
+    st = sc.stats()
+    assert got == sxo.run_cli(ms, [host], radix="x")
+    assert st.bytes_scanned == 3 * n and st.replay_bytes < 0.1 * 3 * n
+    # C2: default UBF, one mission
+    ms2 = rc.missions(encodings=["utf-8"], chars_min="10")
+    sc2 = sx.Scanner(ms2, device=0)
+    res2 = sc2.scan_device(d, n, file_id=1)  # pointer from another context on the same device
+    assert sx.OUTPUT_BOM + res2.printed(n_inputs=1, radix="x") + b"\n" == sxo.run_cli(ms2, [host], radix="x")
+    sc.free(d)
+    sc.close(); sc2.close()
+
+
+def test_large_input_properties():
+    """At a size the oracle cannot cover in seconds: invariances the path must have."""
+    ms = rc.missions(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African")
+    n = 1 << 30
+    sc = sx.Scanner(ms, device=0)
+    d = sc.alloc(n)
+    sc.fill_background(d, 0, n)
+    r1 = sc.scan_device(d, n, file_id=1)
+    a = r1.findings()
+    sc.reset()
+    # sub-chunk size must not matter; neither must scanning the same bytes again
+    sc_b = sx.Scanner(ms, device=0, subchunk_bytes=1 << 20)
+    b = sc_b.scan_device(d, n, file_id=1).findings()
+    assert a == b
+    # two chunks with carried state == one chunk
+    half = n // 2
+    import ctypes
+    c1 = sc.scan_device(d, half, file_id=1).findings()
+    c2 = sc.scan_device(ctypes.c_void_p(d.value + half), n - half, file_id=1).findings()
+    for f in c2:
+        f["slice_index"] += half // 4096
+    assert c1 + c2 == a
+    # oracle on a 64 MiB prefix
+    pre = 64 << 20
+    host = sxo.background(0, pre)
+    want = sxo.run_cli(ms, [host], radix="x")
+    sc.reset()
+    got = sx.OUTPUT_BOM + sc.scan_device(d, pre, file_id=1).printed(radix="x") + b"\n"
+    assert got == want
+    # positions sorted within a mission, all inside the input
+    for mid in range(3):
+        pos = [f["position"] for f in a if f["mission_id"] == mid]
+        assert pos == sorted(pos) and (not pos or pos[-1] < n)
+    sc.free(d)
+    sc.close(); sc_b.close()

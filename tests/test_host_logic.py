@@ -178,3 +178,69 @@ def test_print_variants():
     for radix in (None, "x", "d", "o"):
         for nometa in (False, True):
             assert run_cli_product(ms, f, radix=radix, no_metadata=nometa) == sxo.run_cli(ms, f, radix=radix, no_metadata=nometa)
+
+
+def test_parallel_parts_and_stitch():
+    """Inputs large enough for several replay parts (4 MiB each), with strings planted across
+    the part boundaries so that the speculative parts must be verified and repaired."""
+    rng = random.Random(99)
+    n = 17 << 20
+    base = bytearray(sxo.background(0, n))
+    part = (n // 4 + 4095) // 4096 * 4096  # replay_plan: 4 parts for 17 MiB
+    long_ascii = bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz /._-") for _ in range(9000))
+    heb = ("שלום עולם " * 700).encode("utf-8")
+    heb16 = ("שלום עולם " * 300).encode("utf-16-le")
+    for k in range(1, 8):
+        b = k * (n // 8) // 4096 * 4096
+        for off, blob in ((-4000, long_ascii), (2 << 20, heb), (-100, heb16), (3 << 20, long_ascii[:63]),
+                          ((1 << 20) - 64, long_ascii[:64]), ((1 << 20) + 128 - 10, long_ascii[:20])):
+            p = b + off + rng.randrange(0, 3)
+            if 0 <= p and p + len(blob) < n:
+                base[p:p + len(blob)] = blob
+    for k in (1, 2, 3):  # exactly at the real part boundaries
+        p = k * part - 5000
+        base[p:p + len(long_ascii)] = long_ascii
+    data = bytes(base)
+    for flags in (dict(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African"),
+                  dict(encodings=["ascii"], chars_min="12", output_line_len="20"),
+                  dict(encodings=["utf-8"], chars_min="70", output_line_len="64"),
+                  dict(encodings=["utf-8"], chars_min="6", output_line_len="32", grep_char="47")):
+        ms = rc.missions(**flags)
+        assert run_cli_product(ms, [data], radix="x") == sxo.run_cli(ms, [data], radix="x"), flags
+
+
+def test_fuzz_sparse_replay():
+    """Many small adversarial inputs x random option combinations: the sparse replay must
+    equal the oracle's full scan byte for byte."""
+    rng = random.Random(424242)
+    enc_pool = ["utf-8", "ascii", "utf-16le", "utf-16be", "koi8-r", "windows-1252"]
+    ubf_pool = [None, "African", "All", "Common", "Latin", "Cyrillic", "None", "Arabic", "0x0010400000000000"]
+    af_pool = [None, "All", "All-Ctrl+Wsp", "None", "Wsp"]
+    alphabet_hi = list(range(0x20, 0x7F)) * 3 + [0xC3, 0xA9, 0xD7, 0x90, 0xD5, 0xB1, 0xE2, 0x82, 0xAC, 0xF0, 0x9F,
+                                                 0x98, 0x80, 0x00, 0x0A, 0xFF, 0xC0, 0xED, 0xA0, 0xD8, 0x00, 0xDC]
+    for it in range(160):
+        n = rng.choice([1, 2, 3, 4, 5, 7, 10, 16, 33, 64, 70])
+        q = rng.choice([6, 7, 8, 10, 16, 32, 64])
+        encs = rng.sample(enc_pool, rng.choice([1, 1, 2, 3]))
+        flags = dict(encodings=encs, chars_min=str(n), output_line_len=str(q),
+                     unicode_block_filter=rng.choice(ubf_pool), ascii_filter=rng.choice(af_pool),
+                     same_unicode_block=rng.random() < 0.2,
+                     grep_char=rng.choice([None, None, None, "47", "32", "101"]))
+        ms = rc.missions(**flags)
+        files = []
+        for _ in range(rng.choice([1, 1, 2, 3])):
+            size = rng.choice([0, 1, 5, 127, 128, 129, 4095, 4096, 4097, 9000, 20000])
+            kind = rng.random()
+            if kind < 0.3:
+                d = bytes(rng.choice(alphabet_hi) for _ in range(size))
+            elif kind < 0.6:
+                d = synth(rng, size, 1 / 60) if size else b""
+            elif kind < 0.8:
+                d = soup(rng, size)
+            else:  # long text-like stretches, cut by rare breaks
+                d = bytes((rng.choice(b"abcdefghij klmnop/") if rng.random() > 0.01 else rng.choice([0, 0xFF, 0xC3]))
+                          for _ in range(size))
+            files.append(d)
+        want = sxo.run_cli(ms, files, radix="x")
+        got = run_cli_product(ms, files, radix="x", chunk_bytes=rng.choice([None, 4096, 8192]))
+        assert got == want, (it, flags, [len(f) for f in files])
