@@ -104,7 +104,7 @@ static inline uint64_t window_end(uint64_t p, size_t W, uint64_t len) {  // end 
     if (e > s + kInputBufLen) e = s + kInputBufLen;
     return e < len ? e : len;
 }
-constexpr int kLeadWindows = 3;  // sparse-download margin only (see replay_ranges)
+constexpr int kLeadWindows = 3;
 
 namespace {
 
@@ -197,7 +197,7 @@ private:
         while (ri_ < n_runs_ && runs_[ri_].end <= pos) ri_++;
         uint64_t want = len_;
         if (ri_ < n_runs_) want = window_start(runs_[ri_].start, W_);
-        if (owns_tail_ && len_) want = std::min(want, window_start(len_ - 1, W_));
+        if (owns_tail_ && len_) want = std::min(want, tail_start());
         if (want >= len_) return len_;
         if (want <= pos) return pos;                   // state at pos is exact: just go on
         if (want >= hi_ && !owns_tail_) return want;  // somebody else's
@@ -340,9 +340,15 @@ private:
     bool region_over(uint64_t p) {
         while (ri_ < n_runs_ && runs_[ri_].end <= p) ri_++;
         if (ri_ < n_runs_ && window_start(runs_[ri_].start, W_) <= p) return false;
-        if (owns_tail_ && len_ && window_start(len_ - 1, W_) <= p) return false;
+        if (owns_tail_ && len_ && tail_start() <= p) return false;
         return true;
     }
+
+    // The state handed to the next chunk must be exact, leftover content included (the next
+    // chunk may complete it to a long run that neither chunk's device scan sees as one).  A
+    // leftover not covered by a long run is < min(n,q) chars <= 4(q-1) bytes < 2 windows, so
+    // starting three windows early makes it exact whatever was derived at the start.
+    uint64_t tail_start() const { return back_windows(len_ - 1, W_, kLeadWindows); }
 
     const Mission& m_;
     ByteView& bytes_;

@@ -244,3 +244,25 @@ def test_fuzz_sparse_replay():
         want = sxo.run_cli(ms, files, radix="x")
         got = run_cli_product(ms, files, radix="x", chunk_bytes=rng.choice([None, 4096, 8192]))
         assert got == want, (it, flags, [len(f) for f in files])
+
+
+def test_carried_state_across_many_small_files():
+    """Text-heavy streams cut into many small files (every cut restarts the slice grid and
+    hands a leftover / cut-string flag / partial character to the next file)."""
+    rng = random.Random(31337)
+    words = [w.decode("utf-8", "ignore") for w in WORDS_ASCII] + WORDS_UNI
+    for it in range(40):
+        enc = rng.choice(["utf-8", "utf-16le", "utf-16be"])
+        text = "".join(rng.choice(words) + rng.choice(["\x00", "\x01\x02", "", " ", "\n"]) for _ in range(60))
+        blob = text.encode({"utf-8": "utf-8", "utf-16le": "utf-16-le", "utf-16be": "utf-16-be"}[enc])
+        blob = bytearray(blob)
+        for _ in range(len(blob) // 200):  # sprinkle breaks
+            blob[rng.randrange(len(blob))] = rng.choice([0xFF, 0xC0, 0x00, 0xD8, 0xDC])
+        blob = bytes(blob)
+        cuts = sorted(rng.sample(range(1, len(blob)), min(len(blob) - 1, rng.choice([3, 10, 25]))))
+        files = [blob[a:b] for a, b in zip([0] + cuts, cuts + [len(blob)])]
+        ms = rc.missions(encodings=[enc, "ascii"], chars_min=str(rng.choice([3, 5, 9, 14])),
+                         output_line_len=str(rng.choice([6, 9, 16, 64])),
+                         unicode_block_filter=rng.choice(["All", "Common", "African"]),
+                         same_unicode_block=rng.random() < 0.2)
+        assert run_cli_product(ms, files, radix="x") == sxo.run_cli(ms, files, radix="x"), (it, enc, len(files))
