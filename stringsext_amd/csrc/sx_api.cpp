@@ -130,6 +130,14 @@ int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_byt
             p.min_chars = (uint32_t)std::min<uint64_t>(min_chars[k], kRecCharsMask);
             if (p.min_chars == 0) p.min_chars = 1;
             p.cand_bytes = std::min<uint32_t>(p.min_chars * (m.is_utf16() ? 2u : 1u), 17u);
+            {   // r &= r << sh, doubling the proven run length until it reaches cand_bytes
+                uint32_t have = 1;
+                for (int i = 0; i < 5; i++) {
+                    const uint32_t sh = have < p.cand_bytes ? std::min(have, p.cand_bytes - have) : 0;
+                    p.cand_sh[i] = sh;
+                    have += sh;
+                }
+            }
             p.capacity = d.capacity; p.recs = d.d_recs; p.counters = d.d_counters;
             HIP_TRY(ctx, hipMemsetAsync(d.d_counters, 0, 4 * sizeof(uint32_t), d.stream));
             HIP_TRY(ctx, hipEventRecord(d.ev0, d.stream));
@@ -154,6 +162,15 @@ int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_byt
             std::vector<DevRun> recs(counters[0]);
             if (counters[0])
                 HIP_TRY(ctx, hipMemcpy(recs.data(), d.d_recs, (size_t)counters[0] * sizeof(DevRun), hipMemcpyDeviceToHost));
+            if (getenv("SX_DEBUG_RECS")) {
+                std::vector<DevRun> srt(recs);
+                std::sort(srt.begin(), srt.end(), [](const DevRun& a, const DevRun& b) { return a.start < b.start; });
+                for (const DevRun& r : srt)
+                    fprintf(stderr, "[sx] rec start=%llu len=%u chars=%u flags=%s%s\n", (unsigned long long)r.start, r.len,
+                            r.chars_flags & kRecCharsMask, (r.chars_flags & kRecStartOpen) ? "S" : "-",
+                            (r.chars_flags & kRecEndOpen) ? "E" : "-");
+                fprintf(stderr, "[sx] slow tiles %u\n", counters[1]);
+            }
             merge_device_runs(recs.data(), recs.size(), min_chars[k], &(*out)[k]);
             ctx->stats.run_records += (*out)[k].size();
             ctx->stats.bytes_scanned += len;

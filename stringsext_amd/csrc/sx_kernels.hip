@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "sx_device.hpp"
 
 namespace sx {
@@ -297,7 +299,6 @@ struct Utf16Lut {
 // ------------------------------------------------------------------------------------------
 struct Carry {
     u32 g63;      // previous tile, lane 63: final 16-bit good mask | own spill bits << 16
-    u32 s63;      // previous tile, lane 63: start mask
     u32 tracked;  // 1: a stretch is open at the tile start and described below
     u32 t_chars, t_flags;
     u64 t_start;
@@ -344,13 +345,43 @@ SX_DEV u32 trailing_ones16(u32 g16) {  // ones from bit 15 downwards
     return inv ? (u32)__clz((int)inv) - 16u : 16u;
 }
 
-// Exact resolution of all stretches that END inside this tile (the one still open at the
-// tile end goes into the carry).  g: final 16-bit good mask; s: start mask; g_raw: the
-// classifier's output (for its spill bits).
+// Light path: every stretch of >= cand_bytes bytes that ENDS in this tile lies inside the
+// 32-bit window (previous lane | own lane) of the lane it ends in, and nothing long is
+// open at either tile edge.  Each such lane resolves its stretch with a few bit operations.
+// Returns false (nothing emitted) if the tile needs the general path instead.
+//   w  = own good mask << 16 | previous lane's good mask;  sw = the same for start masks
+//   r  = bit p set iff bits p-cand_bytes+1..p of w are all set
+SX_DEV bool light_path(u32 w, u32 sw, u32 r, u64 lane_base, const Emitter& em, u32 min_chars) {
+    const u32 lane = lane_id();
+    const u32 gf = w >> 16;
+    const u32 n0 = from_next(gf & 1u, 1u);  // lane 63: the next tile is unknown -> "goes on"
+    const u32 ends = gf & ~((gf >> 1) | (n0 << 15));
+    u32 cand = ends & (r >> 16);
+    const bool open_long = lane == 63 && (r >> 31);  // >= cand_bytes already and still open at the tile end
+    const u32 e0 = 16u + (cand ? (u32)__builtin_ctz(cand) : 0u);
+    const bool unresolved = cand && ((~w) & ((1u << e0) - 1u)) == 0u;  // reaches beyond the window
+    if (__ballot(open_long || unresolved)) return false;
+    while (__ballot(cand != 0)) {
+        const bool has = cand != 0;
+        const u32 e = 16u + (has ? (u32)__builtin_ctz(cand) : 0u);
+        const u32 below = (~w) & ((1u << e) - 1u);            // has a set bit whenever `has`
+        const u32 st = below ? 32u - (u32)__clz((int)below) : 0u;
+        const u32 field = (e >= 31u ? 0xFFFFFFFFu : ((1u << (e + 1u)) - 1u)) & ~((1u << st) - 1u);
+        const u32 ch = (u32)__popc(sw & field);
+        em.append(has && ch >= min_chars, lane_base - 16 + st, lane_base - 16 + e + 1, ch, 0u);
+        cand &= cand - 1u;
+    }
+    return true;
+}
+
+// General path: exact resolution of all stretches that END inside this tile (the one still
+// open at the tile end goes into the carry).  g: final 16-bit good mask; s: start mask;
+// g_raw: the classifier's output (for its spill bits); s63: start mask of the previous
+// tile's lane 63 (only read if an untracked stretch is open on entry).
 // `first_tile`: the tile starts a sub-chunk: a stretch that is open on entry is clipped to
 // the sub-chunk start and flagged kRecStartOpen (the previous wave reports the part before).
-SX_DEV void slow_path(u32 g, u32 s, u32 g_raw, u64 tile_base, u64 tile_end, Carry& c, const Emitter& em,
-                      u32 min_chars, u32 cand_bytes, bool first_tile) {
+SX_DEV void heavy_path(u32 g, u32 s, u32 g_raw, u32 g63_in, u32 s63, u64 tile_base, u64 tile_end, Carry& c,
+                       const Emitter& em, u32 min_chars, u32 cand_bytes, bool first_tile) {
     const u32 lane = lane_id();
     g &= 0xFFFFu;
     s &= 0xFFFFu;
@@ -361,13 +392,13 @@ SX_DEV void slow_path(u32 g, u32 s, u32 g_raw, u64 tile_base, u64 tile_end, Carr
     u32 ochars = 0, oflags = 0;
     if (c.tracked) {
         open = true; ostart = c.t_start; ochars = c.t_chars; oflags = c.t_flags;
-    } else if (c.g63 & 0x8000u) {
+    } else if (g63_in & 0x8000u) {
         open = true;
         if (first_tile) { ostart = tile_base; ochars = 0; oflags = kRecStartOpen; }
         else {  // shorter than cand_bytes <= 17 bytes: it lies inside lane 63 of the previous tile
-            u32 suf = trailing_ones16(c.g63 & 0xFFFFu);
+            u32 suf = trailing_ones16(g63_in & 0xFFFFu);
             ostart = tile_base - suf;
-            ochars = (u32)__popc((c.s63 & 0xFFFFu) >> (16u - suf));
+            ochars = (u32)__popc((s63 & 0xFFFFu) >> (16u - suf));
         }
     }
     u32 g0 = bcast(g, 0) & 1u;
@@ -425,12 +456,11 @@ SX_DEV void slow_path(u32 g, u32 s, u32 g_raw, u64 tile_base, u64 tile_end, Carr
 
     // -- state for the next tile
     c.g63 = bcast(g | (g_raw & 0xFFFF0000u), 63);
-    c.s63 = bcast(s, 63);
     c.tracked = 0;
     if (bcast(my_open, 63)) {
         u64 os = ((u64)bcast((u32)(my_ostart >> 32), 63) << 32) | bcast((u32)my_ostart, 63);
         u32 ofl = bcast(my_ofl, 63);
-        if (tile_end - os >= cand_bytes || ofl) {  // short and plain: re-derived from g63/s63 when needed
+        if (tile_end - os >= cand_bytes || ofl) {  // short and plain: re-derived from g63 when needed
             c.tracked = 1; c.t_start = os; c.t_chars = bcast(my_och, 63); c.t_flags = ofl;
         }
     }
@@ -455,7 +485,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
 
     CLS cls;
     cls.init(p, lds_lut);
-    Emitter em{ p.recs, p.counters, p.capacity };
+    const Emitter em{ p.recs, p.counters, p.capacity };
 
     // Buffer descriptor over [win_lo, win_hi): one tile of look-back (classification state
     // at the sub-chunk start) and two of look-ahead; reads beyond it return 0.
@@ -473,60 +503,87 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
     auto load = [&](u32 off) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0); };
 
     const int n_tiles = (int)((sub_end - sub_start + kTileBytes - 1) / kTileBytes);
-    int t = has_pre ? -1 : 0;   // -1 = the look-back tile
-    u32 voff = lane * 16u;      // byte offset of my 16 bytes of tile t inside the window
-    u32x4 cur = load(voff);
-    u32x4 nxt = load(voff + kTileBytes);
-    Carry c;
-    c.g63 = 0; c.s63 = 0; c.tracked = 0; c.t_chars = 0; c.t_flags = 0; c.t_start = 0;
+    // tiles whose 1 KiB + look-ahead lie fully inside the chunk need no end-of-input care
+    int n_safe = n_tiles;
+    while (n_safe > 0 && sub_start + (u64)n_safe * kTileBytes + 16 > p.len) n_safe--;
 
-    for (; t < n_tiles; t++) {
-        const u32x4 nn = load(voff + 2 * kTileBytes);  // in flight while this tile is classified
+    int t = has_pre ? -1 : 0;  // -1 = the look-back tile
+    u32 toff = 0;              // byte offset of tile t inside the window
+    u32x4 cur = load(lane * 16u);
+    u32x4 nxt = load(lane * 16u + kTileBytes);
+    Carry c;
+    c.g63 = 0; c.tracked = 0; c.t_chars = 0; c.t_flags = 0; c.t_start = 0;
+
+    // start mask of the 16 bytes right before the tile at window offset `off` (= lane 63 of
+    // the previous tile), recomputed on demand: every lane reads the same 20 bytes
+    auto starts_before = [&](u32 off, u64 tile_base, auto near_tag) -> u32 {
+        constexpr bool NE = decltype(near_tag)::value;
+        if (off < 16u) return 0u;
+        const u32x4 x = load(off - 16u);
+        const u32 nx = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0);
+        u32 avail = 32;
+        if (NE) { const u64 b = tile_base - 16; avail = b >= p.len ? 0u : (p.len - b > 32 ? 32u : (u32)(p.len - b)); }
+        return uniform(cls.template classify<true>(x, nx, avail, NE));
+    };
+
+    auto body = [&](auto near_tag) {
+        constexpr bool NE = decltype(near_tag)::value;
+        const u32x4 nn = load(toff + lane * 16u + 2 * kTileBytes);  // in flight while this tile is classified
         const u64 tile_base = sub_start + (u64)((long long)t * (long long)kTileBytes);
-        const bool near_end = tile_base + kTileBytes + 16 > p.len;  // uniform
         const u64 lane_base = tile_base + 16ull * lane;
         u32 avail = 32;
-        if (near_end) avail = lane_base >= p.len ? 0u : (p.len - lane_base > 32 ? 32u : (u32)(p.len - lane_base));
+        if (NE) avail = lane_base >= p.len ? 0u : (p.len - lane_base > 32 ? 32u : (u32)(p.len - lane_base));
 
+        const u32 g63_in = c.g63;  // previous tile's lane 63 (by value: c is rewritten below)
+        const bool tracked_in = c.tracked != 0;
         const u32 nx = from_next(cur.x, bcast(nxt.x, 0));
-        const u32 g = cls.template classify<false>(cur, nx, avail, near_end);
-
-        const u32 pg = from_prev(g, c.g63);
+        const u32 g = cls.template classify<false>(cur, nx, avail, NE);
+        const u32 pg = from_prev(g, g63_in);
         const u32 gf = (g & 0xFFFFu) | (pg >> 16);       // final good mask of my 16 bytes
-        const u32 pgf = from_prev(gf, c.g63) & 0xFFFFu;   // final mask of the 16 bytes before mine
+        const u32 pgf = from_prev(gf, g63_in) & 0xFFFFu;  // final mask of the 16 bytes before mine
+        const u32 g63_out = bcast(gf | (g & 0xFFFF0000u), 63);
 
-        // does any stretch of >= cand_bytes bytes end inside my 16 bytes?
-        u32 r = (gf << 16) | pgf;
-        for (u32 have = 1; have < p.cand_bytes;) {
-            u32 sh = have < p.cand_bytes - have ? have : p.cand_bytes - have;
-            r &= r << sh;
-            have += sh;
-        }
-        const u64 cand = __ballot((r & 0xFFFF0000u) != 0);
+        // r: bit q set iff bits q-cand_bytes+1 .. q of the window are all set
+        const u32 w = (gf << 16) | pgf;
+        u32 r = w;
+        r &= r << p.cand_sh[0]; r &= r << p.cand_sh[1]; r &= r << p.cand_sh[2];
+        r &= r << p.cand_sh[3]; r &= r << p.cand_sh[4];
+        const bool any_cand = __ballot((r & 0xFFFF0000u) != 0) != 0;
         const bool first_tile = t == 0;
-        const u64 tile_end = tile_base + kTileBytes < sub_end ? tile_base + kTileBytes : sub_end;
+        const bool first_open = first_tile && (g63_in & 0x8000u);
 
-        if (t < 0 || (cand == 0 && !c.tracked && !(first_tile && (c.g63 & 0x8000u)))) {
+        if (t < 0 || (!any_cand && !tracked_in && !first_open)) {
             // fast path (and the look-back tile, of which only the classification state matters)
-            const u32 s = cls.template classify<true>(cur, nx, avail, near_end);
-            c.g63 = bcast(gf | (g & 0xFFFF0000u), 63);
-            c.s63 = bcast(s, 63);
+            c.g63 = g63_out;
         } else {
-            const u32 s = cls.template classify<true>(cur, nx, avail, near_end);
-            if (lane == 0) atomicAdd(p.counters + 1, 1u);
-            slow_path(gf, s, g, tile_base, tile_end, c, em, p.min_chars, p.cand_bytes, first_tile);
+            const u32 s = cls.template classify<true>(cur, nx, avail, NE);
+            const u32 s63 = (g63_in & 0x8000u) ? starts_before(toff, tile_base, near_tag) : 0u;
+            const u32 sw = (s << 16) | (from_prev(s, s63) & 0xFFFFu);
+            bool done = false;
+            if (!tracked_in && !first_open) done = light_path(w, sw, r, lane_base, em, p.min_chars);
+            if (done) c.g63 = g63_out;
+            else {
+                if (lane == 0) atomicAdd(p.counters + 1, 1u);
+                const u64 tile_end = tile_base + kTileBytes < sub_end ? tile_base + kTileBytes : sub_end;
+                heavy_path(gf, s, g, g63_in, s63, tile_base, tile_end, c, em, p.min_chars, p.cand_bytes, first_tile);
+            }
         }
-        cur = nxt; nxt = nn; voff += kTileBytes;
-    }
+        cur = nxt; nxt = nn; toff += kTileBytes; t++;
+    };
+
+    while (t < n_safe) body(std::false_type{});
+    while (t < n_tiles) body(std::true_type{});
 
     // the stretch that is still open where the sub-chunk ends
     if (c.tracked || (c.g63 & 0x8000u)) {
         u64 os; u32 och, ofl;
         if (c.tracked) { os = c.t_start; och = c.t_chars; ofl = c.t_flags; }
         else {
-            u32 suf = trailing_ones16(c.g63 & 0xFFFFu);
-            os = sub_start + (u64)n_tiles * kTileBytes - suf;
-            och = (u32)__popc((c.s63 & 0xFFFFu) >> (16u - suf));
+            const u32 suf = trailing_ones16(c.g63 & 0xFFFFu);
+            const u64 after = sub_start + (u64)n_tiles * kTileBytes;
+            const u32 s63 = starts_before(toff, after, std::true_type{});
+            os = after - suf;
+            och = (u32)__popc((s63 & 0xFFFFu) >> (16u - suf));
             ofl = 0;
         }
         em.append(lane == 0, os, sub_end, och, ofl | kRecEndOpen);
