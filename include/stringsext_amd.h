@@ -101,6 +101,7 @@ typedef struct sx_stats {
     double   kernel_ms[16];              /* per mission: device scan kernel, HIP events on its stream */
     double   device_ms;                  /* all mission streams, first launch -> last completion */
     double   h2d_ms, d2h_ms, replay_ms, total_ms;
+    uint64_t heavy_tiles;                /* 1 KiB tiles that needed the general cross-lane path (all missions) */
 } sx_stats;
 
 typedef struct sx_ctx sx_ctx;

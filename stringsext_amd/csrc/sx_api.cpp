@@ -114,7 +114,7 @@ int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_byt
                 std::vector<std::vector<sx_run>>* out) {
     out->assign(which.size(), {});
     if (len == 0) return SX_OK;
-    uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 64u * 1024u;
+    uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 256u * 1024u;
     sub = std::max<uint32_t>(kTileBytes, sub / kTileBytes * kTileBytes);
     const double t0 = now_ms();
     std::vector<bool> pending(which.size(), true);
@@ -174,6 +174,7 @@ int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_byt
             merge_device_runs(recs.data(), recs.size(), min_chars[k], &(*out)[k]);
             ctx->stats.run_records += (*out)[k].size();
             ctx->stats.bytes_scanned += len;
+            ctx->stats.heavy_tiles += counters[1];
             pending[k] = false;
         }
     }

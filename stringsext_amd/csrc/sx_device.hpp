@@ -25,6 +25,8 @@ struct DevRun {
 constexpr uint32_t kRecStartOpen = 0x80000000u;  // stretch begins at a sub-chunk start (may continue a previous one)
 constexpr uint32_t kRecEndOpen = 0x40000000u;    // stretch reaches the sub-chunk end (may be continued)
 constexpr uint32_t kRecCharsMask = 0x3FFFFFFFu;
+// a reserved slot that was never filled (see Emitter in sx_kernels.hip)
+constexpr uint32_t kRecInvalidLen = 0xFFFFFFFFu, kRecInvalidFlags = 0xFFFFFFFFu;
 
 enum ClassifierKind : uint32_t {
     kClsSingleByteLut = 0,  // x-user-defined and WHATWG single-byte tables: 256-entry accept LUT

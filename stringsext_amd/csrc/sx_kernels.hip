@@ -304,19 +304,39 @@ struct Carry {
     u64 t_start;
 };
 
+// Record output.  One global atomic word sustains only ~90 returning atomics per
+// microsecond on this chip (MI355X_MICROARCH.md, row "dequeue"), which is less than the
+// record rate of a text-rich input.  So a wavefront reserves record slots in blocks: one
+// atomic per kRecBlock records.  Slots of a block that stay unused are marked invalid
+// (kRecInvalid) so that the host can skip them.  All fields are wave-uniform (SGPRs).
+constexpr u32 kRecBlock = 16;
 struct Emitter {
     DevRun* recs;
     u32* counters;
     u32 capacity;
-    // all lanes call (convergent); `want` lanes append one record each; one atomic per wave
-    SX_DEV void append(bool want, u64 start, u64 end, u32 chars, u32 flags) const {
+    u32 base, left;  // my current block: slots [base, base+left) are still free
+
+    SX_DEV void invalidate_rest() {
+        u32 lane = lane_id();
+        if (lane < left && base + lane < capacity) {
+            DevRun r; r.start = 0; r.len = kRecInvalidLen; r.chars_flags = kRecInvalidFlags;
+            recs[base + lane] = r;
+        }
+        left = 0;
+    }
+    // all lanes call (convergent); `want` lanes append one record each
+    SX_DEV void append(bool want, u64 start, u64 end, u32 chars, u32 flags) {
         u64 m = __ballot(want);
         if (m == 0) return;
         u32 lane = lane_id();
-        int leader = __ffsll((long long)m) - 1;
-        u32 base = 0;
-        if ((int)lane == leader) base = atomicAdd(counters, (u32)__popcll(m));
-        base = __builtin_amdgcn_readlane(base, leader);
+        u32 n = (u32)__popcll(m);
+        if (n > left) {
+            invalidate_rest();
+            u32 grab = n > kRecBlock ? n : kRecBlock, b = 0;
+            if (lane == 0) b = atomicAdd(counters, grab);
+            base = __builtin_amdgcn_readfirstlane(b);
+            left = grab;
+        }
         if (want) {
             u32 idx = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
             if (idx < capacity) {
@@ -327,6 +347,7 @@ struct Emitter {
                 recs[idx] = r;
             }
         }
+        base += n; left -= n;
     }
 };
 
@@ -351,7 +372,7 @@ SX_DEV u32 trailing_ones16(u32 g16) {  // ones from bit 15 downwards
 // Returns false (nothing emitted) if the tile needs the general path instead.
 //   w  = own good mask << 16 | previous lane's good mask;  sw = the same for start masks
 //   r  = bit p set iff bits p-cand_bytes+1..p of w are all set
-SX_DEV bool light_path(u32 w, u32 sw, u32 r, u64 lane_base, const Emitter& em, u32 min_chars) {
+SX_DEV bool light_path(u32 w, u32 sw, u32 r, u64 lane_base, Emitter& em, u32 min_chars) {
     const u32 lane = lane_id();
     const u32 gf = w >> 16;
     const u32 n0 = from_next(gf & 1u, 1u);  // lane 63: the next tile is unknown -> "goes on"
@@ -381,7 +402,7 @@ SX_DEV bool light_path(u32 w, u32 sw, u32 r, u64 lane_base, const Emitter& em, u
 // `first_tile`: the tile starts a sub-chunk: a stretch that is open on entry is clipped to
 // the sub-chunk start and flagged kRecStartOpen (the previous wave reports the part before).
 SX_DEV void heavy_path(u32 g, u32 s, u32 g_raw, u32 g63_in, u32 s63, u64 tile_base, u64 tile_end, Carry& c,
-                       const Emitter& em, u32 min_chars, u32 cand_bytes, bool first_tile) {
+                       Emitter& em, u32 min_chars, u32 cand_bytes, bool first_tile) {
     const u32 lane = lane_id();
     g &= 0xFFFFu;
     s &= 0xFFFFu;
@@ -485,7 +506,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
 
     CLS cls;
     cls.init(p, lds_lut);
-    const Emitter em{ p.recs, p.counters, p.capacity };
+    Emitter em{ p.recs, p.counters, p.capacity, 0u, 0u };
 
     // Buffer descriptor over [win_lo, win_hi): one tile of look-back (classification state
     // at the sub-chunk start) and two of look-ahead; reads beyond it return 0.
@@ -519,6 +540,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
     auto starts_before = [&](u32 off, u64 tile_base, auto near_tag) -> u32 {
         constexpr bool NE = decltype(near_tag)::value;
         if (off < 16u) return 0u;
+        asm volatile("" : "+s"(off));  // do not speculate these loads into the per-tile fast path
         const u32x4 x = load(off - 16u);
         const u32 nx = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0);
         u32 avail = 32;
@@ -588,6 +610,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
         }
         em.append(lane == 0, os, sub_end, och, ofl | kRecEndOpen);
     }
+    em.invalidate_rest();
 }
 
 template <class CLS, bool LUT>

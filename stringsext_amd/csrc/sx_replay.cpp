@@ -469,7 +469,10 @@ void replay_ranges(const Mission& m, const ScannerState& st, uint64_t len, const
 }
 
 void merge_device_runs(const DevRun* recs, size_t n, uint64_t min_chars, std::vector<sx_run>* out) {
-    std::vector<DevRun> v(recs, recs + n);
+    std::vector<DevRun> v;
+    v.reserve(n);
+    for (size_t i = 0; i < n; i++)
+        if (!(recs[i].len == kRecInvalidLen && recs[i].chars_flags == kRecInvalidFlags)) v.push_back(recs[i]);
     std::sort(v.begin(), v.end(), [](const DevRun& a, const DevRun& b) { return a.start < b.start; });
     out->clear();
     for (size_t i = 0; i < v.size();) {

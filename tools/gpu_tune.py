@@ -22,6 +22,9 @@ solo = {"utf8_african": [c3[0]], "utf16le_african": [dict(c3[1], mission_id=0)],
 base = sx.Scanner(c3, device=0)
 d = base.alloc(n)
 base.fill_background(d, 0, n)
+MINC = {"utf8_african_T17": 64, "utf8_common_T17": 64}
+solo["utf8_african_T17"] = solo["utf8_african"]
+solo["utf8_common_T17"] = solo["utf8_common_n10"]
 print(f"buffer {GIB} GiB; read-only streaming probe: {base.read_bandwidth(d, n, 5):.0f} GB/s")
 base.close()
 
@@ -33,10 +36,11 @@ for name, ms in solo.items():
             sc = sx.Scanner(ms, device=0, subchunk_bytes=s * 1024, generic_kernels=generic, record_capacity=1 << 22)
             best = 1e9
             for _ in range(3):
-                sc.device_runs(0, d, n, 0, max(1, min(ms[0]["chars_min_nb"], 64)))
-                best = min(best, sc.stats().kernel_ms[0])
+                sc.device_runs(0, d, n, 0, MINC.get(name, max(1, min(ms[0]["chars_min_nb"], 64))))
+                st = sc.stats()
+                best = min(best, st.kernel_ms[0])
             sc.close()
-            row.append(f"{best:6.2f}|{n / best / 1e6:5.0f}")
+            row.append(f"{best:6.2f}|{n / best / 1e6:5.0f}|h{st.heavy_tiles}")
         print(f"{name:18s} {str(generic):7s} " + " ".join(row))
 
 print("three concurrent streams (C3):")
