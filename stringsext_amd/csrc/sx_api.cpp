@@ -54,6 +54,9 @@ struct sx_ctx {
     uint8_t* d_input = nullptr;  // staging for host input
     uint64_t d_input_cap = 0;
     uint64_t ondemand_fetches = 0;
+    // grow-only scratch reused by every call (pinned host memory: D2H at full PCIe rate)
+    uint8_t* h_pin = nullptr;   uint64_t h_pin_cap = 0;
+    uint8_t* d_scratch = nullptr; uint64_t d_scratch_cap = 0;
 };
 
 #define HIP_TRY(ctx, expr)                                                                     \
@@ -97,6 +100,25 @@ private:
     std::deque<std::vector<uint8_t>> extra_;
     std::mutex mu_;
 };
+
+int ensure_pinned(sx_ctx* ctx, uint64_t bytes) {
+    if (ctx->h_pin_cap >= bytes) return SX_OK;
+    if (ctx->h_pin) HIP_TRY(ctx, hipHostFree(ctx->h_pin));
+    ctx->h_pin = nullptr; ctx->h_pin_cap = 0;
+    bytes += bytes / 4 + (1u << 20);
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_pin, bytes, hipHostMallocDefault));
+    ctx->h_pin_cap = bytes;
+    return SX_OK;
+}
+int ensure_scratch(sx_ctx* ctx, uint64_t bytes) {
+    if (ctx->d_scratch_cap >= bytes) return SX_OK;
+    if (ctx->d_scratch) HIP_TRY(ctx, hipFree(ctx->d_scratch));
+    ctx->d_scratch = nullptr; ctx->d_scratch_cap = 0;
+    bytes += bytes / 4 + (1u << 20);
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_scratch, bytes));
+    ctx->d_scratch_cap = bytes;
+    return SX_OK;
+}
 
 int ensure_capacity(sx_ctx* ctx, MissionDev& d, uint32_t cap) {
     if (d.capacity >= cap) return SX_OK;
@@ -159,11 +181,17 @@ int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_byt
                 if (rc != SX_OK) return rc;
                 continue;
             }
-            std::vector<DevRun> recs(counters[0]);
+            const double tc0 = now_ms();
+            {
+                int rc = ensure_pinned(ctx, (uint64_t)counters[0] * sizeof(DevRun) + 16);
+                if (rc != SX_OK) return rc;
+            }
+            DevRun* recs_p = (DevRun*)ctx->h_pin;
             if (counters[0])
-                HIP_TRY(ctx, hipMemcpy(recs.data(), d.d_recs, (size_t)counters[0] * sizeof(DevRun), hipMemcpyDeviceToHost));
+                HIP_TRY(ctx, hipMemcpy(recs_p, d.d_recs, (size_t)counters[0] * sizeof(DevRun), hipMemcpyDeviceToHost));
+            const double tc1 = now_ms();
             if (getenv("SX_DEBUG_RECS")) {
-                std::vector<DevRun> srt(recs);
+                std::vector<DevRun> srt(recs_p, recs_p + counters[0]);
                 std::sort(srt.begin(), srt.end(), [](const DevRun& a, const DevRun& b) { return a.start < b.start; });
                 for (const DevRun& r : srt)
                     fprintf(stderr, "[sx] rec start=%llu len=%u chars=%u flags=%s%s\n", (unsigned long long)r.start, r.len,
@@ -171,7 +199,10 @@ int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_byt
                             (r.chars_flags & kRecEndOpen) ? "E" : "-");
                 fprintf(stderr, "[sx] slow tiles %u\n", counters[1]);
             }
-            merge_device_runs(recs.data(), recs.size(), min_chars[k], &(*out)[k]);
+            merge_device_runs(recs_p, counters[0], min_chars[k], sub, &(*out)[k]);
+            if (getenv("SX_TIMING"))
+                fprintf(stderr, "[sx] mission %d: %u record slots, d2h %.2f ms, merge/sort %.2f ms -> %zu runs\n", which[k],
+                        counters[0], tc1 - tc0, now_ms() - tc1, (*out)[k].size());
             ctx->stats.run_records += (*out)[k].size();
             ctx->stats.bytes_scanned += len;
             ctx->stats.heavy_tiles += counters[1];
@@ -225,7 +256,7 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, uint64_t len, int file_id, bool is_
     std::vector<MissionFindings> per(nm);
     auto stitch = [&](size_t k) {
         replay_stitch(ctx->missions[k], ctx->states[k], consumed0[k], stream0[k], bytes, len, file_id, is_last,
-                      runs[k].data(), runs[k].size(), parts[k], &per[k]);
+                      runs[k].data(), runs[k].size(), parts[k], &per[k], nthreads);
     };
     if (nm == 1) stitch(0);
     else {
@@ -237,8 +268,8 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, uint64_t len, int file_id, bool is_
     sx_result* r = new sx_result();
     merge_findings(per, &r->r);
     if (getenv("SX_TIMING"))
-        fprintf(stderr, "[sx] replay: plan+parts %.2f ms (%zu tasks, %zu workers), stitch %.2f ms, merge %.2f ms\n",
-                t_parts - t0, nm * np, nw, t_stitch - t_parts, now_ms() - t_stitch);
+        fprintf(stderr, "[sx] replay: plan+parts %.2f ms (%zu tasks, %zu workers), stitch %.2f ms, merge %.2f ms, on-demand fetches so far %llu\n",
+                t_parts - t0, nm * np, nw, t_stitch - t_parts, now_ms() - t_stitch, (unsigned long long)ctx->ondemand_fetches);
     for (auto& mf : per) ctx->stats.replay_bytes += mf.replay_bytes;
     ctx->stats.findings += r->r.findings.size();
     ctx->stats.replay_ms += now_ms() - t0;
@@ -314,6 +345,8 @@ void sx_destroy(sx_ctx* ctx) {
             if (d.stream) (void)hipStreamDestroy(d.stream);
         }
         if (ctx->d_input) (void)hipFree(ctx->d_input);
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     }
     delete ctx;
 }
@@ -349,10 +382,16 @@ static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_
         // download only what the replay will look at
         const double t0 = now_ms();
         std::vector<std::pair<uint64_t, uint64_t>> rg;
-        for (size_t k = 0; k < nm; k++)
+        for (size_t k = 0; k < nm; k++) {
+            const size_t before = rg.size();
             replay_ranges(ctx->missions[k], ctx->states[k], len, runs[k].data(), runs[k].size(), replay_threads(ctx), &rg);
-        std::sort(rg.begin(), rg.end());
+            // a mission's ranges come out almost sorted (runs are); fix up, then merge the sorted lists
+            if (!std::is_sorted(rg.begin() + before, rg.end())) std::sort(rg.begin() + before, rg.end());
+            std::inplace_merge(rg.begin(), rg.begin() + before, rg.end());
+        }
+        const double t_rg = now_ms();
         std::vector<std::pair<uint64_t, uint64_t>> mg;
+        mg.reserve(rg.size());
         for (auto& r : rg) {
             if (!mg.empty() && r.first <= mg.back().second) mg.back().second = std::max(mg.back().second, r.second);
             else mg.push_back(r);
@@ -367,29 +406,33 @@ static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_
                 seg_src.push_back(a); seg_dst.push_back(total); seg_len.push_back((uint32_t)n);
                 total += n;
             }
-        std::vector<uint8_t> host(total ? total : 1);
+        const double t_seg = now_ms();
         SparseDeviceBytes view(ctx, d_bytes);
         if (total) {
             hipStream_t s = ctx->dev[0].stream;
-            uint8_t* d_out = nullptr;
-            uint64_t *d_src = nullptr, *d_dst = nullptr;
-            uint32_t* d_len = nullptr;
             const size_t ns = seg_src.size();
-            HIP_TRY(ctx, hipMalloc((void**)&d_out, total));
-            HIP_TRY(ctx, hipMalloc((void**)&d_src, ns * 8));
-            HIP_TRY(ctx, hipMalloc((void**)&d_dst, ns * 8));
-            HIP_TRY(ctx, hipMalloc((void**)&d_len, ns * 4));
+            const uint64_t seg_bytes = ns * (8 + 8 + 4) + 64;
+            int rc2 = ensure_pinned(ctx, total + 64);
+            if (rc2 != SX_OK) return rc2;
+            rc2 = ensure_scratch(ctx, total + seg_bytes + 256);
+            if (rc2 != SX_OK) return rc2;
+            uint8_t* d_out = ctx->d_scratch;
+            uint64_t* d_src = (uint64_t*)(ctx->d_scratch + ((total + 255) & ~255ull));
+            uint64_t* d_dst = d_src + ns;
+            uint32_t* d_len = (uint32_t*)(d_dst + ns);
             HIP_TRY(ctx, hipMemcpyAsync(d_src, seg_src.data(), ns * 8, hipMemcpyHostToDevice, s));
             HIP_TRY(ctx, hipMemcpyAsync(d_dst, seg_dst.data(), ns * 8, hipMemcpyHostToDevice, s));
             HIP_TRY(ctx, hipMemcpyAsync(d_len, seg_len.data(), ns * 4, hipMemcpyHostToDevice, s));
             HIP_TRY(ctx, launch_gather(d_bytes, d_out, d_src, d_dst, d_len, (uint32_t)ns, s));
-            HIP_TRY(ctx, hipMemcpyAsync(host.data(), d_out, total, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin, d_out, total, hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));
-            (void)hipFree(d_out); (void)hipFree(d_src); (void)hipFree(d_dst); (void)hipFree(d_len);
             uint64_t off = 0;
-            for (auto& r : mg) { view.add(r.first, r.second, host.data() + off); off += r.second - r.first; }
+            for (auto& r : mg) { view.add(r.first, r.second, ctx->h_pin + off); off += r.second - r.first; }
         }
         ctx->stats.d2h_ms += now_ms() - t0;
+        if (getenv("SX_TIMING"))
+            fprintf(stderr, "[sx] sparse download: ranges %.2f ms, sort+merge+segments %.2f ms (%zu ranges, %zu segs), gather+d2h %.2f ms (%.1f MB)\n",
+                    t_rg - t0, t_seg - t_rg, mg.size(), seg_src.size(), now_ms() - t_seg, total / 1e6);
         rc = replay_all(ctx, view, len, file_id, is_last != 0, runs, out);
     }
     ctx->stats.total_ms = now_ms() - t_begin;

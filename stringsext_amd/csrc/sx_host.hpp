@@ -183,7 +183,7 @@ void replay_part(const Mission& m, const ScannerState& entry, uint64_t consumed0
                  bool entry_exact, ReplayPart* part);
 void replay_stitch(const Mission& m, ScannerState& st, uint64_t consumed0, uint64_t stream0, ByteView& bytes,
                    uint64_t len, int file_id, bool is_last, const sx_run* runs, uint64_t n_runs,
-                   std::vector<ReplayPart>& parts, MissionFindings* out);
+                   std::vector<ReplayPart>& parts, MissionFindings* out, unsigned copy_threads);
 
 // Byte ranges of the chunk that the replay will (very likely) touch, for sparse download of
 // device-resident input.  Appends [lo,hi) pairs (unsorted, may overlap).
@@ -192,7 +192,7 @@ void replay_ranges(const Mission& m, const ScannerState& st, uint64_t len, const
 
 // Turn raw device records (any order, sub-chunk pieces flagged open) into maximal runs
 // with >= min_chars characters, sorted by start.
-void merge_device_runs(const DevRun* recs, size_t n, uint64_t min_chars, std::vector<sx_run>* out);
+void merge_device_runs(const DevRun* recs, size_t n, uint64_t min_chars, uint64_t subchunk, std::vector<sx_run>* out);
 
 // k-way merge in the reference's order: slice by slice, then (position, mission_id)
 // — src/main.rs:118-136, src/finding.rs:92-109.

@@ -27,6 +27,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <deque>
+#include <thread>
 
 #include "sx_host.hpp"
 
@@ -395,16 +398,11 @@ void replay_part(const Mission& m, const ScannerState& entry, uint64_t consumed0
 // where a speculative region straddles that point, replay exactly from there (rare).
 void replay_stitch(const Mission& m, ScannerState& st, uint64_t consumed0, uint64_t stream0, ByteView& bytes,
                    uint64_t len, int file_id, bool is_last, const sx_run* runs, uint64_t n_runs,
-                   std::vector<ReplayPart>& parts, MissionFindings* out) {
-    auto take = [&](const MissionFindings& src, size_t f0, size_t f1) {
-        for (size_t i = f0; i < f1; i++) {
-            sx_finding f = src.v[i];
-            const uint32_t off = (uint32_t)out->arena.size();
-            out->arena.append(src.arena, f.str_off, f.str_len);
-            f.str_off = off;
-            out->v.push_back(f);
-        }
-    };
+                   std::vector<ReplayPart>& parts, MissionFindings* out, unsigned copy_threads) {
+    // 1. decide (serially, cheap) which finding ranges survive, repairing where needed
+    struct Seg { const MissionFindings* src; size_t f0, f1; };
+    std::vector<Seg> segs;
+    std::deque<ReplayPart> fixes;
     uint64_t E = 0;
     ScannerState cur = st;
     for (size_t k = 0; k < parts.size(); k++) {
@@ -416,26 +414,62 @@ void replay_stitch(const Mission& m, ScannerState& st, uint64_t consumed0, uint6
                 while (i < p.regions.size() && p.regions[i].start < E) i++;
                 if (i == 0 || p.regions[i - 1].end <= E) break;
                 // region i-1 began under a wrong assumption and reaches beyond E: redo it exactly
-                ReplayPart fix;
+                fixes.emplace_back();
+                ReplayPart& fix = fixes.back();
                 replay_part(m, cur, consumed0, stream0, bytes, len, file_id, is_last, runs, n_runs, E,
                             std::min(len, p.regions[i - 1].end), false, &fix);
-                take(fix.findings, 0, fix.findings.v.size());
+                segs.push_back({ &fix.findings, 0, fix.findings.v.size() });
                 out->replay_bytes += fix.findings.replay_bytes;
                 E = std::max(E, fix.end_pos);
                 cur = fix.state;
             }
         }
-        bool kept = false;
-        for (; i < p.regions.size(); i++) { take(p.findings, p.regions[i].f0, p.regions[i].f1); kept = true; }
+        const bool kept = i < p.regions.size();
+        if (kept) segs.push_back({ &p.findings, p.regions[i].f0, p.regions.back().f1 });
         if (k == 0 || kept || p.end_pos > E) {
             if (k == 0 || kept) cur = p.state;
             E = std::max(E, p.end_pos);
         }
     }
-    // the state handed to the next chunk
     cur.consumed_bytes = consumed0 + len;
     cur.stream_bytes = stream0 + len;
     st = cur;
+
+    // 2. copy the surviving findings and their strings (parallel: the bulk of the work)
+    std::vector<size_t> fbase(segs.size() + 1, 0), abase(segs.size() + 1, 0);
+    for (size_t i = 0; i < segs.size(); i++) {
+        const Seg& g = segs[i];
+        size_t ab = 0;
+        if (g.f1 > g.f0) {
+            const sx_finding& a = g.src->v[g.f0];
+            const sx_finding& b = g.src->v[g.f1 - 1];
+            ab = (size_t)(b.str_off + b.str_len) - a.str_off;  // a worker appends strings in finding order
+        }
+        fbase[i + 1] = fbase[i] + (g.f1 - g.f0);
+        abase[i + 1] = abase[i] + ab;
+    }
+    out->v.resize(fbase.back());
+    out->arena.resize(abase.back());
+    auto copy_seg = [&](size_t i) {
+        const Seg& g = segs[i];
+        if (g.f1 <= g.f0) return;
+        const uint32_t src0 = g.src->v[g.f0].str_off;
+        memcpy(&out->arena[abase[i]], g.src->arena.data() + src0, abase[i + 1] - abase[i]);
+        for (size_t j = g.f0; j < g.f1; j++) {
+            sx_finding f = g.src->v[j];
+            f.str_off = (uint32_t)(abase[i] + (f.str_off - src0));
+            out->v[fbase[i] + (j - g.f0)] = f;
+        }
+    };
+    const size_t nt = std::min<size_t>(copy_threads ? copy_threads : 1, segs.size());
+    if (nt <= 1 || fbase.back() < 50000) { for (size_t i = 0; i < segs.size(); i++) copy_seg(i); }
+    else {
+        std::atomic<size_t> next{ 0 };
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; t++)
+            th.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < segs.size();) copy_seg(i); });
+        for (auto& t : th) t.join();
+    }
 }
 
 void replay_chunk(const Mission& m, ScannerState& st, ByteView& bytes, uint64_t len, int input_file_id,
@@ -444,37 +478,60 @@ void replay_chunk(const Mission& m, ScannerState& st, ByteView& bytes, uint64_t 
     std::vector<ReplayPart> parts(1);
     replay_part(m, st, consumed0, stream0, bytes, len, input_file_id, is_last_input_buffer, runs, n_runs, 0, len, true,
                 &parts[0]);
-    replay_stitch(m, st, consumed0, stream0, bytes, len, input_file_id, is_last_input_buffer, runs, n_runs, parts, out);
+    replay_stitch(m, st, consumed0, stream0, bytes, len, input_file_id, is_last_input_buffer, runs, n_runs, parts, out, 1);
 }
 
 void replay_ranges(const Mission& m, const ScannerState& st, uint64_t len, const sx_run* runs, uint64_t n_runs,
                    unsigned parts, std::vector<std::pair<uint64_t, uint64_t>>* ranges) {
     if (len == 0) return;
     const size_t W = m.window;
+    const size_t first = ranges->size();
     auto add = [&](uint64_t lo, uint64_t hi) {
         lo = lo > 16 ? lo - 16 : 0;  // decoder priming
         if (hi > len) hi = len;
         if (lo < hi) ranges->emplace_back(lo, hi);
     };
-    if (!st.clean()) add(0, 4 * W);
     for (uint64_t i = 0; i < n_runs; i++) {
-        const uint64_t lo = back_windows(runs[i].start, W, kLeadWindows);
+        // a region starts in the window of the run's first byte and usually ends with the
+        // window of its last byte; anything beyond is fetched on demand
         const uint64_t last = runs[i].end ? runs[i].end - 1 : 0;
-        add(lo, window_end(last < len ? last : len - 1, W, len) + 4 * W);
+        add(window_start(runs[i].start, W), window_end(last < len ? last : len - 1, W, len) + W);
     }
-    add(back_windows(len - 1, W, kLeadWindows), len);
+    // a handful of extras: carried state at the chunk start, exact tail, decoder priming at part starts
+    const size_t mid = ranges->size();
+    if (!st.clean()) add(0, 4 * W);
     std::vector<uint64_t> bounds;
     replay_plan(len, parts, &bounds);
-    for (size_t k = 1; k + 1 < bounds.size(); k++) add(bounds[k], bounds[k] + 1);  // decoder priming at part starts
+    for (size_t k = 1; k + 1 < bounds.size(); k++) add(bounds[k], bounds[k] + 1);
+    add(back_windows(len - 1, W, kLeadWindows), len);
+    std::inplace_merge(ranges->begin() + first, ranges->begin() + mid, ranges->end());
 }
 
-void merge_device_runs(const DevRun* recs, size_t n, uint64_t min_chars, std::vector<sx_run>* out) {
-    std::vector<DevRun> v;
-    v.reserve(n);
+void merge_device_runs(const DevRun* recs, size_t n, uint64_t min_chars, uint64_t subchunk, std::vector<sx_run>* out) {
+    // A record starts inside the sub-chunk of the wavefront that wrote it, and a wavefront
+    // writes in (almost) ascending order: bucket by sub-chunk, then order each small bucket.
+    auto valid = [](const DevRun& r) { return !(r.len == kRecInvalidLen && r.chars_flags == kRecInvalidFlags); };
+    if (subchunk == 0) subchunk = 1;
+    size_t m = 0;
+    uint64_t max_b = 0;
     for (size_t i = 0; i < n; i++)
-        if (!(recs[i].len == kRecInvalidLen && recs[i].chars_flags == kRecInvalidFlags)) v.push_back(recs[i]);
-    std::sort(v.begin(), v.end(), [](const DevRun& a, const DevRun& b) { return a.start < b.start; });
+        if (valid(recs[i])) { max_b = std::max(max_b, recs[i].start / subchunk); m++; }
+    std::vector<uint32_t> head(max_b + 2, 0);
+    for (size_t i = 0; i < n; i++)
+        if (valid(recs[i])) head[recs[i].start / subchunk + 1]++;
+    for (size_t b = 1; b < head.size(); b++) head[b] += head[b - 1];
+    std::vector<DevRun> v(m);
+    {
+        std::vector<uint32_t> cur(head.begin(), head.end() - 1);
+        for (size_t i = 0; i < n; i++)
+            if (valid(recs[i])) v[cur[recs[i].start / subchunk]++] = recs[i];
+    }
+    auto less = [](const DevRun& a, const DevRun& b) { return a.start < b.start || (a.start == b.start && a.len < b.len); };
+    for (size_t b = 0; b + 1 < head.size(); b++)
+        if (head[b + 1] - head[b] > 1 && !std::is_sorted(v.begin() + head[b], v.begin() + head[b + 1], less))
+            std::sort(v.begin() + head[b], v.begin() + head[b + 1], less);
     out->clear();
+    out->reserve(m);
     for (size_t i = 0; i < v.size();) {
         sx_run r{ v[i].start, v[i].start + v[i].len, v[i].chars_flags & kRecCharsMask };
         bool open_end = (v[i].chars_flags & kRecEndOpen) != 0;
@@ -493,6 +550,14 @@ void merge_device_runs(const DevRun* recs, size_t n, uint64_t min_chars, std::ve
 void merge_findings(std::vector<MissionFindings>& per, Result* out) {
     out->findings.clear();
     out->arena.clear();
+    size_t nonempty = 0, which = 0;
+    for (size_t k = 0; k < per.size(); k++) if (!per[k].v.empty()) { nonempty++; which = k; }
+    if (nonempty == 0) return;
+    if (nonempty == 1) {  // nothing to interleave
+        out->findings = std::move(per[which].v);
+        out->arena = std::move(per[which].arena);
+        return;
+    }
     size_t total = 0, bytes = 0;
     for (auto& mf : per) { total += mf.v.size(); bytes += mf.arena.size(); }
     out->findings.reserve(total);
