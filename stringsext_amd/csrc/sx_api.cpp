@@ -75,14 +75,21 @@ class SparseDeviceBytes : public ByteView {
 public:
     SparseDeviceBytes(sx_ctx* ctx, const uint8_t* d_base) : ctx_(ctx), d_base_(d_base) {}
     void add(uint64_t lo, uint64_t hi, const uint8_t* p) { segs_.push_back({ lo, hi, p }); }
-    const uint8_t* span(uint64_t off, size_t n) override {
-        // segments are sorted and disjoint
-        size_t a = 0, b = segs_.size();
-        while (a < b) {
-            size_t mid = (a + b) / 2;
-            if (segs_[mid].hi <= off) a = mid + 1; else b = mid;
+    const uint8_t* span(uint64_t off, size_t n, size_t* hint) override {
+        // segments are sorted and disjoint; the caller moves forward, so look near its cursor first
+        size_t a = *hint < segs_.size() ? *hint : 0;
+        if (!(a < segs_.size() && segs_[a].lo <= off)) a = 0;
+        size_t steps = 0;
+        while (a < segs_.size() && segs_[a].hi <= off && steps < 8) { a++; steps++; }
+        if (!(a < segs_.size() && segs_[a].lo <= off && off < segs_[a].hi)) {
+            size_t lo = 0, hi = segs_.size();
+            while (lo < hi) {
+                size_t mid = (lo + hi) / 2;
+                if (segs_[mid].hi <= off) lo = mid + 1; else hi = mid;
+            }
+            a = lo;
         }
-        if (a < segs_.size() && segs_[a].lo <= off && off + n <= segs_[a].hi) return segs_[a].p + (off - segs_[a].lo);
+        if (a < segs_.size() && segs_[a].lo <= off && off + n <= segs_[a].hi) { *hint = a; return segs_[a].p + (off - segs_[a].lo); }
         // rare: the replay ran further than planned — fetch exactly what is asked for
         std::lock_guard<std::mutex> g(mu_);
         extra_.emplace_back(n);
@@ -106,7 +113,9 @@ int ensure_pinned(sx_ctx* ctx, uint64_t bytes) {
     if (ctx->h_pin) HIP_TRY(ctx, hipHostFree(ctx->h_pin));
     ctx->h_pin = nullptr; ctx->h_pin_cap = 0;
     bytes += bytes / 4 + (1u << 20);
-    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_pin, bytes, hipHostMallocDefault));
+    unsigned flags = hipHostMallocNonCoherent;  // CPU-cached: it is only read by the host after a stream sync
+    if (const char* e = getenv("SX_PIN_FLAGS")) flags = (unsigned)strtoul(e, nullptr, 0);
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_pin, bytes, flags));
     ctx->h_pin_cap = bytes;
     return SX_OK;
 }
@@ -215,8 +224,28 @@ int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_byt
     return SX_OK;
 }
 
+// CPUs this process may really use: the cgroup quota can be far below the visible cores.
+unsigned usable_cpus() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char a[64] = { 0 };
+        unsigned long long period = 0;
+        if (fscanf(f, "%63s %llu", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0) {
+            const unsigned long long quota = strtoull(a, nullptr, 10);
+            const unsigned q = (unsigned)((quota + period - 1) / period);
+            if (q >= 1 && q < n) n = q;
+        }
+        fclose(f);
+    }
+    return n;
+}
+
 unsigned replay_threads(const sx_ctx* ctx) {
-    unsigned n = ctx->opt.replay_threads ? ctx->opt.replay_threads : std::thread::hardware_concurrency();
+    // a few threads per usable CPU smooth out the quota's time slicing (measured: 4x is best)
+    unsigned n = ctx->opt.replay_threads ? ctx->opt.replay_threads
+                                         : std::min(std::thread::hardware_concurrency(), 4 * usable_cpus());
+    if (const char* e = getenv("SX_REPLAY_THREADS")) n = (unsigned)atoi(e);
     if (n < 1) n = 1;
     return n > 256 ? 256 : n;
 }
@@ -236,13 +265,16 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, uint64_t len, int file_id, bool is_
     std::vector<uint64_t> consumed0(nm), stream0(nm);
     for (size_t k = 0; k < nm; k++) { consumed0[k] = ctx->states[k].consumed_bytes; stream0[k] = ctx->states[k].stream_bytes; }
     std::atomic<size_t> next{ 0 };
+    std::vector<double> task_ms(nm * np, 0.0);
     auto worker = [&]() {
         for (;;) {
             const size_t t = next.fetch_add(1);
             if (t >= nm * np) break;
             const size_t k = t / np, p = t % np;
+            const double tt0 = now_ms();
             replay_part(ctx->missions[k], ctx->states[k], consumed0[k], stream0[k], bytes, len, file_id, is_last,
                         runs[k].data(), runs[k].size(), bounds[p], bounds[p + 1], p == 0, &parts[k][p]);
+            task_ms[t] = now_ms() - tt0;
         }
     };
     const size_t nw = std::min<size_t>(nthreads, nm * np);
@@ -267,6 +299,11 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, uint64_t len, int file_id, bool is_
     const double t_stitch = now_ms();
     sx_result* r = new sx_result();
     merge_findings(per, &r->r);
+    if (getenv("SX_TIMING")) {
+        double mx = 0, sum = 0; size_t arg = 0;
+        for (size_t i = 0; i < task_ms.size(); i++) { sum += task_ms[i]; if (task_ms[i] > mx) { mx = task_ms[i]; arg = i; } }
+        fprintf(stderr, "[sx] replay tasks: sum %.1f ms, max %.1f ms (task %zu), avg %.2f ms\n", sum, mx, arg, sum / task_ms.size());
+    }
     if (getenv("SX_TIMING"))
         fprintf(stderr, "[sx] replay: plan+parts %.2f ms (%zu tasks, %zu workers), stitch %.2f ms, merge %.2f ms, on-demand fetches so far %llu\n",
                 t_parts - t0, nm * np, nw, t_stitch - t_parts, now_ms() - t_stitch, (unsigned long long)ctx->ondemand_fetches);

@@ -141,14 +141,14 @@ struct ScannerState {
 class ByteView {
 public:
     virtual ~ByteView() {}
-    // pointer to bytes [off, off+n) of the chunk; n <= 4096; the pointer stays valid until
-    // the next call from the same thread
-    virtual const uint8_t* span(uint64_t off, size_t n) = 0;
+    // pointer to bytes [off, off+n) of the chunk; n <= 4096; stays valid for the lifetime of
+    // the view.  `hint` is a caller-owned cursor (callers walk the chunk in ascending order).
+    virtual const uint8_t* span(uint64_t off, size_t n, size_t* hint) = 0;
 };
 class HostBytes : public ByteView {
 public:
     explicit HostBytes(const uint8_t* p) : p_(p) {}
-    const uint8_t* span(uint64_t off, size_t) override { return p_ + off; }
+    const uint8_t* span(uint64_t off, size_t, size_t*) override { return p_ + off; }
 private:
     const uint8_t* p_;
 };

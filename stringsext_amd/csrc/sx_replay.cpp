@@ -173,7 +173,7 @@ private:
         size_t last_len = 0;
         if (p < B) {
             const size_t n = (size_t)(B - p);
-            const uint8_t* s = bytes_.span(p, n);
+            const uint8_t* s = bytes_.span(p, n, &hint_);
             size_t i = 0;
             for (;;) {
                 const DecodeStep r = d.decode_to_str_without_replacement(s + i, n - i, sink, sizeof sink, false);
@@ -238,7 +238,7 @@ private:
                 if (din + W_ < slen) dend = din + W_;
                 else { is_last_window = true; dend = slen; }
                 const size_t wbase = din;
-                const uint8_t* wp = bytes_.span(soff + wbase, dend - wbase);
+                const uint8_t* wp = bytes_.span(soff + wbase, dend - wbase, &hint_);
                 out_->replay_bytes += dend - wbase;
 
                 for (;;) {  // 'decoder, :134
@@ -250,7 +250,7 @@ private:
                         Decoder fresh = st.decoder.new_decoder_without_bom_handling();
                         uint8_t probe[8] = { 0 }, have[8] = { 0 };
                         const size_t pn = std::min<size_t>(slen, 32);
-                        const DecodeStep pr = fresh.decode_to_str_without_replacement(bytes_.span(soff, pn), pn, probe,
+                        const DecodeStep pr = fresh.decode_to_str_without_replacement(bytes_.span(soff, pn, &hint_), pn, probe,
                                                                                      sizeof probe, true);
                         const size_t filled = std::min<size_t>(8, dout + r.written);
                         memcpy(have, ob, filled);  // beyond what was written the arena is zero, :55
@@ -366,6 +366,7 @@ private:
     ScannerState* st_ = nullptr;
     MissionFindings* out_ = nullptr;
     uint64_t hi_ = 0, ri_ = 0;
+    size_t hint_ = 0;
     bool owns_tail_ = false, strict_ = false;
 };
 
