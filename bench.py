@@ -69,12 +69,25 @@ def main():
     nbytes = int((args.gib if args.gib is not None else wl["gib"]) * (1 << 30)) // 4096 * 4096
     sc = sx.Scanner(missions, device=local_rank, subchunk_bytes=args.subchunk_kib * 1024)
 
-    # weak scaling: rank r holds bytes [r*nbytes, (r+1)*nbytes) of one N*nbytes image
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
+    # weak scaling: rank r owns bytes [r*nbytes, (r+1)*nbytes) of ONE world*nbytes image; for
+    # N > 1 its buffer also holds a halo on both sides (runs that cross a shard boundary)
     import ctypes
-    dptr = ctypes.c_void_p(buf.data_ptr())
-    sc.fill_background(dptr, rank * nbytes, nbytes, SEED)
-    torch.cuda.synchronize()
+    from stringsext_amd import sharded
+    file_len = world * nbytes
+    halo = sharded.HALO_DEFAULT if world > 1 else 0
+    own_lo, own_hi = rank * nbytes, (rank + 1) * nbytes
+    state = {}
+
+    def get_buffer(lo, hi):
+        if state.get("range") != (lo, hi):
+            state["buf"] = None
+            state["buf"] = torch.empty(hi - lo, dtype=torch.uint8, device=f"cuda:{local_rank}")
+            sc.fill_background(ctypes.c_void_p(state["buf"].data_ptr()), lo, hi - lo, SEED)
+            torch.cuda.synchronize()
+            state["range"] = (lo, hi)
+        return ctypes.c_void_p(state["buf"].data_ptr())
+
+    dptr = get_buffer(max(0, own_lo - halo) // 4096 * 4096, min(file_len, own_hi + halo))
 
     def barrier():
         torch.cuda.synchronize()
@@ -84,8 +97,14 @@ def main():
 
     def step():
         sc.reset()
-        res = sc.scan_device(dptr, nbytes, file_id=1)
-        n = len(res)
+        if world == 1:
+            res = sc.scan_device(dptr, nbytes, file_id=1)
+            n = len(res)
+        else:
+            # shard scan + "where did you stop" chain + RCCL gather of the Finding buffers to rank 0
+            gathered, res = sharded.scan_sharded(sc, get_buffer, file_len, file_id=1, halo=halo,
+                                                 device=f"cuda:{local_rank}")
+            n = sum(len(fb) // ctypes.sizeof(sx.Finding) for fb, _ in gathered) if rank == 0 else len(res)
         st = sc.stats()
         res.free()
         return n, st
@@ -145,7 +164,7 @@ def main():
             "roofline": roofline,
             "breakdown_ms_per_step": {"device_scan": round(device_ms, 3), "sparse_download": round(d2h_ms / K, 3),
                                       "host_replay": round(replay_ms / K, 3)},
-            "findings_per_step_rank0": findings, "run_records_rank0": records,
+            "findings_per_step": findings, "run_records_rank0": records,
             "replay_fraction": round(replay_bytes / (len(missions) * nbytes), 5),
             "kernel_only_gib_s": round(world * nbytes / (device_ms * 1e-3) / (1 << 30), 1) if device_ms > 0 else None,
         }

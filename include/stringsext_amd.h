@@ -157,6 +157,36 @@ int sx_replay_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_fi
                    int is_last_input_buffer, const sx_run* const* runs, const uint64_t* n_runs,
                    sx_result** out);
 
+/* Byte-range sharding of ONE input file over several contexts — one process per GPU
+ * (multi-GPU row of the scope table).  The buffer holds file bytes
+ * [buf_off, buf_off+buf_len), buf_off a multiple of 4096 (the slice grid is the file's);
+ * it should reach `halo` bytes beyond [own_lo, own_hi) on both sides where the file does.
+ * The call returns the findings of every replay region that BEGINS in
+ * [max(own_lo, start_at[m]), own_hi) for mission m, following the last such region to its
+ * own end even beyond own_hi, and reports in end_pos[m] (file offset) where mission m's
+ * replay stopped: the next rank's start_at[m].  start_at == NULL means own_lo for every
+ * mission (first attempt; a rank must repeat the call with reuse_runs=1 if the previous
+ * rank's end_pos turns out to lie beyond own_lo).  If end_pos[m] == buf_off+buf_len although
+ * the file goes on, the buffer was too short for a run that crosses it: repeat with a
+ * larger halo.  Positions are counter_offset + file_stream_off + file offset.  The context's
+ * carried state is used only by the shard that starts the file (buf_off == own_lo == 0) and
+ * updated only by the shard whose own_hi is the buffer end.
+ *   sx_scan_shard_device: bytes resident in HBM;  sx_scan_shard: host bytes (uploaded);
+ *   sx_replay_shard_runs: stage B only, run records (buffer relative) supplied by the caller. */
+int sx_scan_shard_device(sx_ctx* ctx, const void* device_bytes, uint64_t buf_off, uint64_t buf_len,
+                         uint64_t own_lo, uint64_t own_hi, const uint64_t* start_at,
+                         uint64_t file_stream_off, int input_file_id, int reuse_runs,
+                         sx_result** out, uint64_t* end_pos);
+int sx_scan_shard(sx_ctx* ctx, const uint8_t* bytes, uint64_t buf_off, uint64_t buf_len,
+                  uint64_t own_lo, uint64_t own_hi, const uint64_t* start_at,
+                  uint64_t file_stream_off, int input_file_id, int reuse_runs,
+                  sx_result** out, uint64_t* end_pos);
+int sx_replay_shard_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t buf_off, uint64_t buf_len,
+                         uint64_t own_lo, uint64_t own_hi, const uint64_t* start_at,
+                         uint64_t file_stream_off, int input_file_id,
+                         const sx_run* const* runs, const uint64_t* n_runs,
+                         sx_result** out, uint64_t* end_pos);
+
 uint64_t          sx_result_count(const sx_result* r);
 const sx_finding* sx_result_findings(const sx_result* r);
 const uint8_t*    sx_result_arena(const sx_result* r, uint64_t* len);

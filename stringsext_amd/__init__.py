@@ -22,7 +22,8 @@ PRECISION = {0: "Before", 1: "Exact", 2: "After"}
 
 # every symbol include/stringsext_amd.h declares
 EXPORTS = ["sx_abi_version", "sx_create", "sx_destroy", "sx_last_error", "sx_scan", "sx_scan_device", "sx_reset",
-           "sx_device_runs", "sx_replay_runs", "sx_result_count", "sx_result_findings", "sx_result_arena",
+           "sx_device_runs", "sx_replay_runs", "sx_scan_shard_device", "sx_scan_shard", "sx_replay_shard_runs",
+           "sx_result_count", "sx_result_findings", "sx_result_arena",
            "sx_result_free", "sx_print_findings", "sx_get_stats", "sx_free", "sx_fill_background_device",
            "sx_device_alloc", "sx_device_free", "sx_device_upload", "sx_device_download",
            "sx_device_read_bandwidth"]
@@ -106,6 +107,11 @@ def lib():
     L.sx_device_runs.argtypes = [vp, C.c_int, vp, u64, C.c_int, u64, C.POINTER(C.POINTER(Run)), C.POINTER(u64)]
     L.sx_replay_runs.argtypes = [vp, cp, u64, C.c_int, C.c_int, C.POINTER(C.POINTER(Run)), C.POINTER(u64),
                                  C.POINTER(vp)]
+    pu64 = C.POINTER(u64)
+    L.sx_scan_shard_device.argtypes = [vp, vp, u64, u64, u64, u64, pu64, u64, C.c_int, C.c_int, C.POINTER(vp), pu64]
+    L.sx_scan_shard.argtypes = [vp, cp, u64, u64, u64, u64, pu64, u64, C.c_int, C.c_int, C.POINTER(vp), pu64]
+    L.sx_replay_shard_runs.argtypes = [vp, cp, u64, u64, u64, u64, pu64, u64, C.c_int, C.POINTER(C.POINTER(Run)), pu64,
+                                       C.POINTER(vp), pu64]
     L.sx_result_count.restype = u64
     L.sx_result_count.argtypes = [vp]
     L.sx_result_findings.restype = C.POINTER(Finding)
@@ -135,6 +141,15 @@ class Result:
 
     def __len__(self):
         return lib().sx_result_count(self.h)
+
+    def raw(self):
+        """(findings array bytes, arena bytes): the buffers a gather moves between ranks."""
+        L = lib()
+        n = L.sx_result_count(self.h)
+        alen = C.c_uint64()
+        ap = L.sx_result_arena(self.h, C.byref(alen))
+        fb = C.string_at(L.sx_result_findings(self.h), n * C.sizeof(Finding)) if n else b""
+        return fb, (C.string_at(ap, alen.value) if alen.value else b"")
 
     def findings(self):
         L = lib()
@@ -210,6 +225,30 @@ class Scanner:
         r = C.c_void_p()
         self._chk(lib().sx_replay_runs(self.h, data, len(data), file_id, int(is_last), ptrs, ns, C.byref(r)))
         return Result(self, r)
+
+    def scan_shard(self, buf, buf_off, own_lo, own_hi, start_at=None, file_stream_off=0, file_id=-1, reuse_runs=False,
+                   runs_per_mission=None, buf_len=None):
+        """One rank of a byte-range-sharded scan (sx_scan_shard / _device / sx_replay_shard_runs).
+        buf: bytes (host) or a ctypes.c_void_p device pointer (then buf_len is required).
+        Returns (Result, end_pos per mission)."""
+        sa = (C.c_uint64 * self.n)(*start_at) if start_at is not None else None
+        ends = (C.c_uint64 * self.n)()
+        r = C.c_void_p()
+        if isinstance(buf, C.c_void_p):
+            self._chk(lib().sx_scan_shard_device(self.h, buf, buf_off, buf_len, own_lo, own_hi, sa, file_stream_off, file_id,
+                                                 int(reuse_runs), C.byref(r), ends))
+        else:
+            buf = bytes(buf)
+            if runs_per_mission is not None:
+                arrs = [(Run * max(1, len(rs)))(*[Run(*t) for t in rs]) for rs in runs_per_mission]
+                ptrs = (C.POINTER(Run) * self.n)(*[C.cast(a, C.POINTER(Run)) for a in arrs])
+                ns = (C.c_uint64 * self.n)(*[len(rs) for rs in runs_per_mission])
+                self._chk(lib().sx_replay_shard_runs(self.h, buf, buf_off, len(buf), own_lo, own_hi, sa, file_stream_off,
+                                                     file_id, ptrs, ns, C.byref(r), ends))
+            else:
+                self._chk(lib().sx_scan_shard(self.h, buf, buf_off, len(buf), own_lo, own_hi, sa, file_stream_off, file_id,
+                                              int(reuse_runs), C.byref(r), ends))
+        return Result(self, r), list(ends)
 
     def device_runs(self, mission_index, dptr, length, stream_parity=0, min_chars=1):
         runs = C.POINTER(Run)()

@@ -55,6 +55,8 @@ struct sx_ctx {
     uint64_t d_input_cap = 0;
     uint64_t ondemand_fetches = 0;
     // grow-only scratch reused by every call (pinned host memory: D2H at full PCIe rate)
+    std::vector<std::vector<sx_run>> shard_runs;  // device runs of the last sx_scan_shard* buffer (reuse_runs)
+    bool shard_runs_valid = false;
     uint8_t* h_pin = nullptr;   uint64_t h_pin_cap = 0;
     uint8_t* d_scratch = nullptr; uint64_t d_scratch_cap = 0;
 };
@@ -250,34 +252,50 @@ unsigned replay_threads(const sx_ctx* ctx) {
     return n > 256 ? 256 : n;
 }
 
+// What stage B is asked to do for one buffer ("chunk" of sx_scan, or a shard's buffer).
+struct ReplayJob {
+    uint64_t len = 0;                   // buffer bytes (its byte 0 lies on the slice grid)
+    int file_id = -1;
+    bool is_last = false;
+    std::vector<uint64_t> lo;           // per mission: replay regions that begin in [lo, hi)
+    uint64_t hi = 0;
+    std::vector<char> entry_exact;      // per mission: ctx->states[m] is the exact state at lo
+    std::vector<uint64_t> consumed0, stream0;  // per mission: ScannerState counters at buffer byte 0
+    bool commit_state = true;           // store the final state in the context
+    uint32_t slice_base = 0;            // added to slice_index of the findings
+};
+
 // Stage B for all missions: every (mission, part) pair is one task for a small thread pool;
-// part 0 of a mission starts from its exact carried state, the others speculate, and the
-// per-mission stitch verifies/repairs them serially.
-int replay_all(sx_ctx* ctx, ByteView& bytes, uint64_t len, int file_id, bool is_last,
-               const std::vector<std::vector<sx_run>>& runs, sx_result** out) {
+// part 0 of a mission starts from its entry state, the others speculate, and the per-mission
+// stitch verifies/repairs them serially.
+int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::vector<std::vector<sx_run>>& runs,
+               sx_result** out, uint64_t* end_pos) {
     const double t0 = now_ms();
     const size_t nm = ctx->missions.size();
     const unsigned nthreads = replay_threads(ctx);
-    std::vector<uint64_t> bounds;
-    replay_plan(len, nthreads, &bounds);
-    const size_t np = bounds.size() - 1;
-    std::vector<std::vector<ReplayPart>> parts(nm, std::vector<ReplayPart>(np));
-    std::vector<uint64_t> consumed0(nm), stream0(nm);
-    for (size_t k = 0; k < nm; k++) { consumed0[k] = ctx->states[k].consumed_bytes; stream0[k] = ctx->states[k].stream_bytes; }
+    std::vector<std::vector<uint64_t>> bounds(nm);
+    std::vector<std::vector<ReplayPart>> parts(nm);
+    std::vector<std::pair<size_t, size_t>> tasks;
+    for (size_t k = 0; k < nm; k++) {
+        replay_plan_range(std::min(job.lo[k], job.hi), job.hi, nthreads, &bounds[k]);
+        parts[k].resize(bounds[k].size() - 1);
+        for (size_t p = 0; p + 1 < bounds[k].size(); p++) tasks.emplace_back(k, p);
+    }
     std::atomic<size_t> next{ 0 };
-    std::vector<double> task_ms(nm * np, 0.0);
+    std::vector<double> task_ms(tasks.size(), 0.0);
     auto worker = [&]() {
         for (;;) {
             const size_t t = next.fetch_add(1);
-            if (t >= nm * np) break;
-            const size_t k = t / np, p = t % np;
+            if (t >= tasks.size()) break;
+            const size_t k = tasks[t].first, p = tasks[t].second;
             const double tt0 = now_ms();
-            replay_part(ctx->missions[k], ctx->states[k], consumed0[k], stream0[k], bytes, len, file_id, is_last,
-                        runs[k].data(), runs[k].size(), bounds[p], bounds[p + 1], p == 0, &parts[k][p]);
+            replay_part(ctx->missions[k], ctx->states[k], job.consumed0[k], job.stream0[k], bytes, job.len, job.file_id,
+                        job.is_last, runs[k].data(), runs[k].size(), bounds[k][p], bounds[k][p + 1],
+                        p == 0 && job.entry_exact[k], &parts[k][p]);
             task_ms[t] = now_ms() - tt0;
         }
     };
-    const size_t nw = std::min<size_t>(nthreads, nm * np);
+    const size_t nw = std::min<size_t>(nthreads, tasks.size());
     if (nw <= 1) worker();
     else {
         std::vector<std::thread> th;
@@ -286,9 +304,13 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, uint64_t len, int file_id, bool is_
     }
     const double t_parts = now_ms();
     std::vector<MissionFindings> per(nm);
+    std::vector<uint64_t> ends(nm, 0);
     auto stitch = [&](size_t k) {
-        replay_stitch(ctx->missions[k], ctx->states[k], consumed0[k], stream0[k], bytes, len, file_id, is_last,
-                      runs[k].data(), runs[k].size(), parts[k], &per[k], nthreads);
+        ScannerState st = ctx->states[k];
+        replay_stitch(ctx->missions[k], st, job.consumed0[k], job.stream0[k], bytes, job.len, job.file_id, job.is_last,
+                      runs[k].data(), runs[k].size(), parts[k], &per[k], nthreads, &ends[k]);
+        if (job.commit_state) ctx->states[k] = st;
+        if (job.slice_base) for (auto& f : per[k].v) f.slice_index += job.slice_base;
     };
     if (nm == 1) stitch(0);
     else {
@@ -296,22 +318,31 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, uint64_t len, int file_id, bool is_
         for (size_t k = 0; k < nm; k++) th.emplace_back(stitch, k);
         for (auto& t : th) t.join();
     }
+    if (end_pos) for (size_t k = 0; k < nm; k++) end_pos[k] = ends[k];
     const double t_stitch = now_ms();
     sx_result* r = new sx_result();
     merge_findings(per, &r->r);
     if (getenv("SX_TIMING")) {
-        double mx = 0, sum = 0; size_t arg = 0;
-        for (size_t i = 0; i < task_ms.size(); i++) { sum += task_ms[i]; if (task_ms[i] > mx) { mx = task_ms[i]; arg = i; } }
-        fprintf(stderr, "[sx] replay tasks: sum %.1f ms, max %.1f ms (task %zu), avg %.2f ms\n", sum, mx, arg, sum / task_ms.size());
+        double mx = 0, sum = 0;
+        for (double v : task_ms) { sum += v; mx = std::max(mx, v); }
+        fprintf(stderr, "[sx] replay: parts %.2f ms (%zu tasks, %zu workers; task sum %.1f max %.1f ms), stitch %.2f ms, merge %.2f ms, "
+                        "on-demand fetches so far %llu\n", t_parts - t0, tasks.size(), nw, sum, mx, t_stitch - t_parts,
+                now_ms() - t_stitch, (unsigned long long)ctx->ondemand_fetches);
     }
-    if (getenv("SX_TIMING"))
-        fprintf(stderr, "[sx] replay: plan+parts %.2f ms (%zu tasks, %zu workers), stitch %.2f ms, merge %.2f ms, on-demand fetches so far %llu\n",
-                t_parts - t0, nm * np, nw, t_stitch - t_parts, now_ms() - t_stitch, (unsigned long long)ctx->ondemand_fetches);
     for (auto& mf : per) ctx->stats.replay_bytes += mf.replay_bytes;
     ctx->stats.findings += r->r.findings.size();
     ctx->stats.replay_ms += now_ms() - t0;
     *out = r;
     return SX_OK;
+}
+
+ReplayJob whole_chunk_job(sx_ctx* ctx, uint64_t len, int file_id, bool is_last) {
+    ReplayJob j;
+    const size_t nm = ctx->missions.size();
+    j.len = len; j.file_id = file_id; j.is_last = is_last; j.hi = len;
+    j.lo.assign(nm, 0); j.entry_exact.assign(nm, 1);
+    for (size_t k = 0; k < nm; k++) { j.consumed0.push_back(ctx->states[k].consumed_bytes); j.stream0.push_back(ctx->states[k].stream_bytes); }
+    return j;
 }
 
 void begin_call(sx_ctx* ctx) {
@@ -393,30 +424,14 @@ const char* sx_last_error(const sx_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 int sx_reset(sx_ctx* ctx) {
     if (!ctx) return SX_E_INVALID;
     for (size_t k = 0; k < ctx->missions.size(); k++) ctx->states[k].reset(ctx->missions[k]);
+    ctx->shard_runs_valid = false;
     return SX_OK;
 }
 
-static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len, int file_id,
-                       int is_last, sx_result** out) {
-    const double t_begin = now_ms();
+// Device-resident input: download only the byte ranges the replay will look at.
+static int download_for_replay(sx_ctx* ctx, const uint8_t* d_bytes, uint64_t len,
+                               const std::vector<std::vector<sx_run>>& runs, SparseDeviceBytes* view) {
     const size_t nm = ctx->missions.size();
-    std::vector<int> which(nm);
-    std::vector<uint32_t> parity(nm);
-    std::vector<uint64_t> minc(nm);
-    for (size_t k = 0; k < nm; k++) {
-        which[k] = (int)k;
-        parity[k] = (uint32_t)(ctx->states[k].stream_bytes & 1);
-        minc[k] = ctx->missions[k].long_run;
-    }
-    std::vector<std::vector<sx_run>> runs;
-    int rc = device_runs(ctx, which, d_bytes, len, parity, minc, &runs);
-    if (rc != SX_OK) return rc;
-
-    if (host_bytes) {
-        HostBytes view(host_bytes);
-        rc = replay_all(ctx, view, len, file_id, is_last != 0, runs, out);
-    } else {
-        // download only what the replay will look at
         const double t0 = now_ms();
         std::vector<std::pair<uint64_t, uint64_t>> rg;
         for (size_t k = 0; k < nm; k++) {
@@ -444,7 +459,6 @@ static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_
                 total += n;
             }
         const double t_seg = now_ms();
-        SparseDeviceBytes view(ctx, d_bytes);
         if (total) {
             hipStream_t s = ctx->dev[0].stream;
             const size_t ns = seg_src.size();
@@ -464,13 +478,39 @@ static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_
             HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin, d_out, total, hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));
             uint64_t off = 0;
-            for (auto& r : mg) { view.add(r.first, r.second, ctx->h_pin + off); off += r.second - r.first; }
+            for (auto& r : mg) { view->add(r.first, r.second, ctx->h_pin + off); off += r.second - r.first; }
         }
         ctx->stats.d2h_ms += now_ms() - t0;
         if (getenv("SX_TIMING"))
             fprintf(stderr, "[sx] sparse download: ranges %.2f ms, sort+merge+segments %.2f ms (%zu ranges, %zu segs), gather+d2h %.2f ms (%.1f MB)\n",
                     t_rg - t0, t_seg - t_rg, mg.size(), seg_src.size(), now_ms() - t_seg, total / 1e6);
-        rc = replay_all(ctx, view, len, file_id, is_last != 0, runs, out);
+    return SX_OK;
+}
+
+static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len, int file_id,
+                       int is_last, sx_result** out) {
+    const double t_begin = now_ms();
+    const size_t nm = ctx->missions.size();
+    std::vector<int> which(nm);
+    std::vector<uint32_t> parity(nm);
+    std::vector<uint64_t> minc(nm);
+    for (size_t k = 0; k < nm; k++) {
+        which[k] = (int)k;
+        parity[k] = (uint32_t)(ctx->states[k].stream_bytes & 1);
+        minc[k] = ctx->missions[k].long_run;
+    }
+    std::vector<std::vector<sx_run>> runs;
+    int rc = device_runs(ctx, which, d_bytes, len, parity, minc, &runs);
+    if (rc != SX_OK) return rc;
+
+    if (host_bytes) {
+        HostBytes view(host_bytes);
+        rc = replay_all(ctx, view, whole_chunk_job(ctx, len, file_id, is_last != 0), runs, out, nullptr);
+    } else {
+        SparseDeviceBytes view(ctx, d_bytes);
+        rc = download_for_replay(ctx, d_bytes, len, runs, &view);
+        if (rc != SX_OK) return rc;
+        rc = replay_all(ctx, view, whole_chunk_job(ctx, len, file_id, is_last != 0), runs, out, nullptr);
     }
     ctx->stats.total_ms = now_ms() - t_begin;
     return rc;
@@ -532,7 +572,100 @@ int sx_replay_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_fi
     std::vector<std::vector<sx_run>> r(ctx->missions.size());
     for (size_t k = 0; k < r.size(); k++) r[k].assign(runs[k], runs[k] + n_runs[k]);
     HostBytes view(bytes ? bytes : (const uint8_t*)"");
-    return replay_all(ctx, view, len, input_file_id, is_last_input_buffer != 0, r, out);
+    return replay_all(ctx, view, whole_chunk_job(ctx, len, input_file_id, is_last_input_buffer != 0), r, out, nullptr);
+}
+
+static int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
+                        const sx_run* const* given_runs, const uint64_t* given_n, uint64_t buf_off, uint64_t buf_len,
+                        uint64_t own_lo, uint64_t own_hi, const uint64_t* start_at, uint64_t file_stream_off, int file_id,
+                        int reuse_runs, sx_result** out, uint64_t* end_pos) {
+    if (!out || !end_pos || (buf_off % kInputBufLen) != 0 || own_lo < buf_off || own_hi < own_lo || own_hi > buf_off + buf_len) {
+        ctx->err = "bad shard geometry"; return SX_E_INVALID;
+    }
+    const size_t nm = ctx->missions.size();
+    const double t_begin = now_ms();
+    if (given_runs) {
+        ctx->shard_runs.assign(nm, {});
+        for (size_t k = 0; k < nm; k++) ctx->shard_runs[k].assign(given_runs[k], given_runs[k] + given_n[k]);
+    } else if (!(reuse_runs && ctx->shard_runs_valid)) {
+        std::vector<int> which(nm);
+        std::vector<uint32_t> parity(nm, (uint32_t)((file_stream_off + buf_off) & 1));
+        std::vector<uint64_t> minc(nm);
+        for (size_t k = 0; k < nm; k++) { which[k] = (int)k; minc[k] = ctx->missions[k].long_run; }
+        int rc = device_runs(ctx, which, d_bytes, buf_len, parity, minc, &ctx->shard_runs);
+        if (rc != SX_OK) return rc;
+    }
+    ctx->shard_runs_valid = true;
+
+    ReplayJob job;
+    job.len = buf_len; job.file_id = file_id; job.is_last = false;
+    job.hi = own_hi - buf_off;
+    job.commit_state = job.hi >= buf_len;
+    job.slice_base = (uint32_t)(buf_off / kInputBufLen);
+    for (size_t k = 0; k < nm; k++) {
+        uint64_t lo = own_lo;
+        if (start_at && start_at[k] > lo) lo = start_at[k];
+        if (lo > own_hi) lo = own_hi;
+        job.lo.push_back(lo - buf_off);
+        job.entry_exact.push_back(buf_off == 0 && lo == 0);
+        job.consumed0.push_back(ctx->missions[k].c.counter_offset + file_stream_off + buf_off);
+        job.stream0.push_back(file_stream_off + buf_off);
+    }
+    int rc;
+    std::vector<uint64_t> ends(nm, 0);
+    if (host_bytes) {
+        HostBytes view(host_bytes);
+        rc = replay_all(ctx, view, job, ctx->shard_runs, out, ends.data());
+    } else {
+        SparseDeviceBytes view(ctx, d_bytes);
+        rc = download_for_replay(ctx, d_bytes, buf_len, ctx->shard_runs, &view);
+        if (rc != SX_OK) return rc;
+        rc = replay_all(ctx, view, job, ctx->shard_runs, out, ends.data());
+    }
+    for (size_t k = 0; k < nm; k++) end_pos[k] = buf_off + ends[k];
+    ctx->stats.total_ms = now_ms() - t_begin;
+    return rc;
+}
+
+int sx_scan_shard_device(sx_ctx* ctx, const void* device_bytes, uint64_t buf_off, uint64_t buf_len, uint64_t own_lo,
+                         uint64_t own_hi, const uint64_t* start_at, uint64_t file_stream_off, int input_file_id,
+                         int reuse_runs, sx_result** out, uint64_t* end_pos) {
+    if (!ctx || (!device_bytes && buf_len)) return SX_E_INVALID;
+    begin_call(ctx);
+    if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
+    if ((uintptr_t)device_bytes & 15) { ctx->err = "device_bytes must be 16-byte aligned"; return SX_E_INVALID; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return shard_common(ctx, nullptr, (const uint8_t*)device_bytes, nullptr, nullptr, buf_off, buf_len, own_lo, own_hi, start_at,
+                        file_stream_off, input_file_id, reuse_runs, out, end_pos);
+}
+
+int sx_scan_shard(sx_ctx* ctx, const uint8_t* bytes, uint64_t buf_off, uint64_t buf_len, uint64_t own_lo, uint64_t own_hi,
+                  const uint64_t* start_at, uint64_t file_stream_off, int input_file_id, int reuse_runs, sx_result** out,
+                  uint64_t* end_pos) {
+    if (!ctx || (!bytes && buf_len)) return SX_E_INVALID;
+    begin_call(ctx);
+    if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!(reuse_runs && ctx->shard_runs_valid)) {
+        if (buf_len > ctx->d_input_cap) {
+            if (ctx->d_input) HIP_TRY(ctx, hipFree(ctx->d_input));
+            ctx->d_input = nullptr; ctx->d_input_cap = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_input, buf_len));
+            ctx->d_input_cap = buf_len;
+        }
+        if (buf_len) HIP_TRY(ctx, hipMemcpy(ctx->d_input, bytes, buf_len, hipMemcpyHostToDevice));
+    }
+    return shard_common(ctx, bytes ? bytes : (const uint8_t*)"", ctx->d_input, nullptr, nullptr, buf_off, buf_len, own_lo, own_hi,
+                        start_at, file_stream_off, input_file_id, reuse_runs, out, end_pos);
+}
+
+int sx_replay_shard_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t buf_off, uint64_t buf_len, uint64_t own_lo,
+                         uint64_t own_hi, const uint64_t* start_at, uint64_t file_stream_off, int input_file_id,
+                         const sx_run* const* runs, const uint64_t* n_runs, sx_result** out, uint64_t* end_pos) {
+    if (!ctx || (!bytes && buf_len) || !runs || !n_runs) return SX_E_INVALID;
+    begin_call(ctx);
+    return shard_common(ctx, bytes ? bytes : (const uint8_t*)"", nullptr, runs, n_runs, buf_off, buf_len, own_lo, own_hi, start_at,
+                        file_stream_off, input_file_id, 0, out, end_pos);
 }
 
 uint64_t sx_result_count(const sx_result* r) { return r ? r->r.findings.size() : 0; }

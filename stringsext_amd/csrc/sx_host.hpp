@@ -178,12 +178,14 @@ struct ReplayPart {
     ScannerState state;
 };
 void replay_plan(uint64_t len, unsigned max_parts, std::vector<uint64_t>* bounds);  // bounds[k]..bounds[k+1]
+void replay_plan_range(uint64_t lo, uint64_t hi, unsigned max_parts, std::vector<uint64_t>* bounds);
 void replay_part(const Mission& m, const ScannerState& entry, uint64_t consumed0, uint64_t stream0, ByteView& bytes,
                  uint64_t len, int file_id, bool is_last, const sx_run* runs, uint64_t n_runs, uint64_t lo, uint64_t hi,
                  bool entry_exact, ReplayPart* part);
 void replay_stitch(const Mission& m, ScannerState& st, uint64_t consumed0, uint64_t stream0, ByteView& bytes,
                    uint64_t len, int file_id, bool is_last, const sx_run* runs, uint64_t n_runs,
-                   std::vector<ReplayPart>& parts, MissionFindings* out, unsigned copy_threads);
+                   std::vector<ReplayPart>& parts, MissionFindings* out, unsigned copy_threads,
+                   uint64_t* end_pos);
 
 // Byte ranges of the chunk that the replay will (very likely) touch, for sparse download of
 // device-resident input.  Appends [lo,hi) pairs (unsorted, may overlap).

@@ -372,15 +372,17 @@ private:
 
 }  // namespace
 
-void replay_plan(uint64_t len, unsigned max_parts, std::vector<uint64_t>* bounds) {
+void replay_plan_range(uint64_t lo, uint64_t hi, unsigned max_parts, std::vector<uint64_t>* bounds) {
     // partition boundaries on the slice grid; a partition is worth a thread from ~4 MiB on
     bounds->clear();
+    const uint64_t len = hi > lo ? hi - lo : 0;
     uint64_t parts = std::min<uint64_t>(max_parts ? max_parts : 1, len / (4u << 20));
     if (parts < 1) parts = 1;
     const uint64_t per = (len / parts + kInputBufLen - 1) / kInputBufLen * kInputBufLen;
-    for (uint64_t k = 0; k < parts; k++) bounds->push_back(std::min(len, k * per));
-    bounds->push_back(len);
+    for (uint64_t k = 0; k < parts; k++) bounds->push_back(std::min(hi, lo + k * per));
+    bounds->push_back(hi);
 }
+void replay_plan(uint64_t len, unsigned max_parts, std::vector<uint64_t>* bounds) { replay_plan_range(0, len, max_parts, bounds); }
 
 void replay_part(const Mission& m, const ScannerState& entry, uint64_t consumed0, uint64_t stream0, ByteView& bytes,
                  uint64_t len, int file_id, bool is_last, const sx_run* runs, uint64_t n_runs, uint64_t lo, uint64_t hi,
@@ -399,7 +401,7 @@ void replay_part(const Mission& m, const ScannerState& entry, uint64_t consumed0
 // where a speculative region straddles that point, replay exactly from there (rare).
 void replay_stitch(const Mission& m, ScannerState& st, uint64_t consumed0, uint64_t stream0, ByteView& bytes,
                    uint64_t len, int file_id, bool is_last, const sx_run* runs, uint64_t n_runs,
-                   std::vector<ReplayPart>& parts, MissionFindings* out, unsigned copy_threads) {
+                   std::vector<ReplayPart>& parts, MissionFindings* out, unsigned copy_threads, uint64_t* end_pos) {
     // 1. decide (serially, cheap) which finding ranges survive, repairing where needed
     struct Seg { const MissionFindings* src; size_t f0, f1; };
     std::vector<Seg> segs;
@@ -432,9 +434,10 @@ void replay_stitch(const Mission& m, ScannerState& st, uint64_t consumed0, uint6
             E = std::max(E, p.end_pos);
         }
     }
-    cur.consumed_bytes = consumed0 + len;
-    cur.stream_bytes = stream0 + len;
+    cur.consumed_bytes = consumed0 + E;
+    cur.stream_bytes = stream0 + E;
     st = cur;
+    if (end_pos) *end_pos = E;
 
     // 2. copy the surviving findings and their strings (parallel: the bulk of the work)
     std::vector<size_t> fbase(segs.size() + 1, 0), abase(segs.size() + 1, 0);
@@ -479,7 +482,7 @@ void replay_chunk(const Mission& m, ScannerState& st, ByteView& bytes, uint64_t 
     std::vector<ReplayPart> parts(1);
     replay_part(m, st, consumed0, stream0, bytes, len, input_file_id, is_last_input_buffer, runs, n_runs, 0, len, true,
                 &parts[0]);
-    replay_stitch(m, st, consumed0, stream0, bytes, len, input_file_id, is_last_input_buffer, runs, n_runs, parts, out, 1);
+    replay_stitch(m, st, consumed0, stream0, bytes, len, input_file_id, is_last_input_buffer, runs, n_runs, parts, out, 1, nullptr);
 }
 
 void replay_ranges(const Mission& m, const ScannerState& st, uint64_t len, const sx_run* runs, uint64_t n_runs,

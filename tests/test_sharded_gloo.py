@@ -1,0 +1,106 @@
+"""Multi-process (gloo, CPU) tests of the byte-range sharding splice: N ranks, each replaying
+its own byte range of one file with a halo, chained "where did you stop" exchange, gather of
+the Finding buffers to rank 0 — the result must equal the oracle's single sequential scan.
+Stage A is replaced by the oracle's run finder here (no GPU); the GPU run uses the kernels."""
+import os
+import random
+import socket
+
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import refconfig as rc
+import sxo_binding as sxo
+
+
+def oracle_findings(mdicts, data):
+    """Findings of the reference loop (4 KiB slices, k-merge per slice)."""
+    scs = [sxo.Scanner(m) for m in mdicts]
+    out = []
+    for si, off in enumerate(range(0, len(data), 4096)):
+        per = []
+        for mi, sc in enumerate(scs):
+            per += [(f["position"], mi, i, f) for i, f in enumerate(sc.scan(data[off:off + 4096], file_id=1))]
+        per.sort(key=lambda t: (t[0], t[1], t[2]))
+        out += [(f["position"], f["precision"], f["s"], f["completes"], mi, si) for _, mi, _, f in per]
+    return out
+
+
+def make_data(kind, seed):
+    from test_host_logic import synth
+    rng = random.Random(seed)
+    n = 3 * (1 << 20) + 4096 * 5 + 123
+    if kind == "planted":
+        d = bytearray(synth(rng, n, 1 / 400))
+        for w in (2, 3):
+            for r in range(1, w):
+                b = (n // w + 4095) // 4096 * 4096 * r
+                d[b - 20:b + 30] = b"crossing-the-shard-boundary-" + b"x" * 22
+                d[b + 4096 - 3:b + 4096 + 9] = "שלום עולם"[:6].encode("utf-8")[:12]
+        return bytes(d)
+    if kind == "giant":  # one run far longer than the halo, across every boundary
+        d = bytearray(synth(rng, n, 1 / 2000))
+        text = bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz ") for _ in range(2 * (1 << 20)))
+        d[300_000:300_000 + len(text)] = text
+        return bytes(d)
+    raise ValueError(kind)
+
+
+def _worker(rank, world, port, kind, flags, halo, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import stringsext_amd as sx
+        from stringsext_amd import sharded
+        from product_harness import oracle_runs_for_chunk
+        data = make_data(kind, 1234)
+        ms = rc.missions(**flags)
+        sc = sx.Scanner(ms, device=sx.SX_HOST_ONLY)
+        gathered, _ = sharded.scan_sharded(
+            sc, lambda lo, hi: data[lo:hi], len(data), file_id=1, halo=halo, device="cpu",
+            runs_for_buffer=lambda buf, off: oracle_runs_for_chunk(ms, buf, off))
+        if rank == 0:
+            got = []
+            for fb, ab in gathered:
+                got += [(f["position"], f["precision"], f["s"], f["completes"], f["mission_id"], f["slice_index"])
+                        for f in sharded.decode_findings(fb, ab)]
+            want = oracle_findings(ms, data)
+            q.put(("ok", got == want, len(got), len(want),
+                   next(((a, b) for a, b in zip(got, want) if a != b), None)))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+CASES = [
+    (2, "planted", dict(encodings=["utf-8", "utf-16le"], chars_min="6", unicode_block_filter="African"), 1 << 16),
+    (3, "planted", dict(encodings=["ascii", "utf-8"], chars_min="10", output_line_len="16"), 1 << 14),
+    (2, "giant", dict(encodings=["utf-8"], chars_min="10"), 1 << 14),
+    (3, "giant", dict(encodings=["ascii"], chars_min="4", output_line_len="20"), 1 << 12),
+]
+
+
+@pytest.mark.parametrize("world,kind,flags,halo", CASES, ids=[f"{c[0]}ranks-{c[1]}-{i}" for i, c in enumerate(CASES)])
+def test_sharded_scan_equals_sequential(world, kind, flags, halo):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, flags, halo, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+    assert res[0] == "ok", res[1]
+    assert res[1], f"sharded != sequential: {res[2]} vs {res[3]} findings, first diff {res[4]}"
