@@ -114,7 +114,11 @@ typedef struct sx_options {
     uint32_t replay_threads;             /* host threads for the exact replay */
     uint32_t flags;                      /* SX_OPT_* */
 } sx_options;
-enum { SX_OPT_GENERIC_KERNELS = 1u  /* force the table-driven classifiers (testing) */ };
+enum {
+    SX_OPT_GENERIC_KERNELS = 1u,  /* force the table-driven classifiers (testing) */
+    SX_OPT_DEVICE_REPLAY = 2u,    /* run the exact replay (stage B) on the device even for small inputs */
+    SX_OPT_HOST_REPLAY = 4u       /* never run stage B on the device */
+};
 
 int  sx_abi_version(void);
 

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libstringsext_amd.so")
 
 SX_OK, SX_E_INVALID, SX_E_NO_DEVICE, SX_E_HIP, SX_E_NOMEM, SX_E_STATE = 0, -1, -2, -3, -4, -5
 SX_HOST_ONLY = -1
-SX_OPT_GENERIC_KERNELS = 1
+SX_OPT_GENERIC_KERNELS, SX_OPT_DEVICE_REPLAY, SX_OPT_HOST_REPLAY = 1, 2, 4
 ENC = {"x-user-defined": 0, "utf-8": 1, "utf-16le": 2, "utf-16be": 3, "koi8-r": 16, "ibm866": 17,
        "iso-8859-2": 18, "iso-8859-5": 19, "iso-8859-15": 20, "windows-1251": 21, "windows-1252": 22}
 PRECISION = {0: "Before", 1: "Exact", 2: "After"}
@@ -189,11 +189,16 @@ class Scanner:
     """One sx_ctx: N missions bound to one HIP device (device=SX_HOST_ONLY: replay stage only)."""
 
     def __init__(self, mission_dicts, device=0, subchunk_bytes=0, record_capacity=0, generic_kernels=False,
-                 replay_threads=0):
+                 replay_threads=0, device_replay=None):
         L = lib()
         self.n = len(mission_dicts)
         self._ms = (Mission * self.n)(*[Mission.from_dict(d) for d in mission_dicts])
-        opt = Options(subchunk_bytes, record_capacity, replay_threads, SX_OPT_GENERIC_KERNELS if generic_kernels else 0)
+        flags = SX_OPT_GENERIC_KERNELS if generic_kernels else 0
+        if device_replay is True:
+            flags |= SX_OPT_DEVICE_REPLAY   # stage B on the device even for small inputs
+        elif device_replay is False:
+            flags |= SX_OPT_HOST_REPLAY
+        opt = Options(subchunk_bytes, record_capacity, replay_threads, flags)
         self.h = C.c_void_p()
         rc = L.sx_create(C.byref(self.h), self._ms, self.n, device, C.byref(opt))
         if rc != SX_OK:

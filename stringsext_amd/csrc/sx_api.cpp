@@ -34,6 +34,10 @@ struct MissionDev {
     DevRun* d_recs = nullptr;
     uint32_t* d_counters = nullptr;
     uint32_t capacity = 0;
+    // stage B on the device: grow-only buffers
+    uint16_t* d_table = nullptr;                        // single-byte decoder table
+    void* d_rp[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
+    uint64_t d_rp_cap[6] = { 0, 0, 0, 0, 0, 0 };
 };
 
 }  // namespace
@@ -263,7 +267,176 @@ struct ReplayJob {
     std::vector<uint64_t> consumed0, stream0;  // per mission: ScannerState counters at buffer byte 0
     bool commit_state = true;           // store the final state in the context
     uint32_t slice_base = 0;            // added to slice_index of the findings
+    const uint8_t* d_bytes = nullptr;   // the buffer in HBM, if stage B may run on the device
 };
+
+
+int ensure_rp(sx_ctx* ctx, MissionDev& d, int slot, uint64_t bytes) {
+    if (d.d_rp_cap[slot] >= bytes) return SX_OK;
+    if (d.d_rp[slot]) HIP_TRY(ctx, hipFree(d.d_rp[slot]));
+    d.d_rp[slot] = nullptr; d.d_rp_cap[slot] = 0;
+    bytes += bytes / 4 + 4096;
+    HIP_TRY(ctx, hipMalloc(&d.d_rp[slot], bytes));
+    d.d_rp_cap[slot] = bytes;
+    return SX_OK;
+}
+
+static inline uint64_t win_start_h(uint64_t p, size_t W) {
+    const uint64_t s0 = p / kInputBufLen * kInputBufLen;
+    return s0 + (p - s0) / W * W;
+}
+
+bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs) {
+    if (!job.d_bytes || ctx->host_only || job.is_last) return false;
+    if (ctx->opt.flags & SX_OPT_HOST_REPLAY) return false;
+    if (ctx->missions[k].q > 64) return false;
+    if (getenv("SX_HOST_REPLAY")) return false;
+    return (ctx->opt.flags & SX_OPT_DEVICE_REPLAY) || getenv("SX_DEVICE_REPLAY") || n_runs >= 4096;
+}
+
+// Stage B of one mission on the device (sx_replay_dev.hip) + the little the host keeps:
+// the chunk's strict entry region, regions the device gave back, the exact exit state.
+int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, const std::vector<sx_run>& runs,
+                          MissionFindings* out, uint64_t* end_pos) {
+    const Mission& m = ctx->missions[k];
+    MissionDev& d = ctx->dev[k];
+    const size_t n = runs.size();
+    const size_t W = m.window;
+    const double t0 = now_ms();
+
+    // ---- pass 1 on the device: every region's extent and output size
+    ReplayParams P{};
+    std::vector<ReplayRegionOut> ro(n);
+    if (n) {
+        int rc = ensure_rp(ctx, d, 0, n * sizeof(sx_run)); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 1, n * sizeof(ReplayRegionOut)); if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[0], runs.data(), n * sizeof(sx_run), hipMemcpyHostToDevice, d.stream));
+        P.data = job.d_bytes; P.len = job.len; P.runs = (const sx_run*)d.d_rp[0]; P.n_runs = n;
+        P.lo = job.lo[k]; P.hi = job.hi; P.consumed0 = job.consumed0[k]; P.stream0 = job.stream0[k];
+        P.slice_base = job.slice_base; P.encoding = m.c.encoding; P.table = d.d_table;
+        P.chars_min_nb = m.c.chars_min_nb; P.same_block = m.c.require_same_unicode_block; P.q = (uint32_t)m.q;
+        P.W = (uint32_t)W; P.long_run = m.long_run; P.grep_char = m.c.grep_char; P.mission_id = m.c.mission_id;
+        P.file_id = job.file_id; P.af_lo = m.c.af_lo; P.af_hi = m.c.af_hi; P.ubf = m.c.ubf;
+        HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], d.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ro.data(), d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream));
+    }
+
+    // ---- meanwhile on the host: the strict entry region (exact carried state), if any
+    std::deque<ReplayPart> host_parts;
+    struct Seg { int host_part; size_t v0, v1; };  // host_part >= 0, or device regions [v0, v1) of `valid`
+    std::vector<Seg> segs;
+    uint64_t E = std::min(job.lo[k], job.hi);
+    uint64_t last_start = E;   // start of the last region of any kind (for the exit state)
+    bool last_is_entry = false;
+    if (job.entry_exact[k]) {
+        // The chunk's first window belongs to the host: only it has the exact carried state
+        // (leftover, cut flag, and the decoder's pending bytes, which cannot be re-derived here).
+        host_parts.emplace_back();
+        replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(), n,
+                    job.lo[k], job.lo[k] + 1, true, &host_parts.back());
+        if (host_parts.back().regions.empty()) host_parts.pop_back();
+        else { segs.push_back({ (int)host_parts.size() - 1, 0, 0 }); last_is_entry = true; E = std::max(E, host_parts.back().end_pos); }
+        E = std::max(E, job.lo[k] + 1);
+    }
+    if (n) HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    const double t1 = now_ms();
+
+    // ---- which regions stand: a region is void if an earlier one ran over its start
+    std::vector<uint64_t> valid, fbase, abase;
+    valid.reserve(n); fbase.reserve(n + 1); abase.reserve(n + 1);
+    uint64_t nf = 0, nb = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t st = ro[i].status;
+        if (st == kRegionChained || st == kRegionNotMine) continue;
+        const uint64_t want = win_start_h(runs[i].start, W);
+        if (want >= job.hi) break;
+        if (want < E) continue;
+        if (st == kRegionTooLong) {  // given back: the host replays it (and whatever it runs into)
+            host_parts.emplace_back();
+            replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(),
+                        n, want, want + 1, false, &host_parts.back());
+            segs.push_back({ (int)host_parts.size() - 1, 0, 0 });
+            E = std::max(E, host_parts.back().end_pos);
+        } else {
+            if (segs.empty() || segs.back().host_part >= 0) segs.push_back({ -1, valid.size(), valid.size() });
+            valid.push_back(i); fbase.push_back(nf); abase.push_back(nb);
+            segs.back().v1 = valid.size();
+            nf += ro[i].n_find; nb += ro[i].n_bytes;
+            E = std::max(E, ro[i].end);
+        }
+        last_start = want; last_is_entry = false;
+    }
+    fbase.push_back(nf); abase.push_back(nb);
+    if (nb > 0xFFFFFFFFull) { ctx->err = "more than 4 GiB of strings in one chunk"; return SX_E_NOMEM; }
+    const double t2 = now_ms();
+
+    // ---- pass 2: the standing regions write findings and strings, in order
+    std::vector<sx_finding> dev_f(nf);
+    std::string dev_a(nb, '\0');
+    if (!valid.empty()) {
+        const size_t nv = valid.size();
+        int rc = ensure_rp(ctx, d, 2, nv * 8); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 3, (nv + 1) * 8); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 4, (nv + 1) * 8); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 5, nf * sizeof(sx_finding) + nb + 64); if (rc) return rc;
+        sx_finding* d_f = (sx_finding*)d.d_rp[5];
+        uint8_t* d_a = (uint8_t*)d.d_rp[5] + nf * sizeof(sx_finding);
+        HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[2], valid.data(), nv * 8, hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[3], fbase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[4], abase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(ctx, launch_replay_write(P, (const uint64_t*)d.d_rp[2], (const uint64_t*)d.d_rp[3], (const uint64_t*)d.d_rp[4],
+                                         nv, d_f, d_a, d.stream));
+        if (nf) HIP_TRY(ctx, hipMemcpyAsync(dev_f.data(), d_f, nf * sizeof(sx_finding), hipMemcpyDeviceToHost, d.stream));
+        if (nb) HIP_TRY(ctx, hipMemcpyAsync(&dev_a[0], d_a, nb, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    }
+    const double t3 = now_ms();
+
+    // ---- splice (almost always: device findings only)
+    if (host_parts.empty()) {
+        out->v = std::move(dev_f);
+        out->arena = std::move(dev_a);
+    } else {
+        for (const Seg& g : segs) {
+            if (g.host_part >= 0) {
+                const MissionFindings& hf = host_parts[(size_t)g.host_part].findings;
+                const uint32_t base = (uint32_t)out->arena.size();
+                out->arena += hf.arena;
+                for (sx_finding f : hf.v) { f.str_off += base; f.slice_index += job.slice_base; out->v.push_back(f); }
+                out->replay_bytes += hf.replay_bytes;
+            } else if (g.v1 > g.v0) {
+                const uint64_t f0 = fbase[g.v0], f1 = fbase[g.v1], a0 = abase[g.v0], a1 = abase[g.v1];
+                const uint32_t base = (uint32_t)out->arena.size();
+                out->arena.append(dev_a, a0, a1 - a0);
+                for (uint64_t j = f0; j < f1; j++) { sx_finding f = dev_f[j]; f.str_off = f.str_off - (uint32_t)a0 + base; out->v.push_back(f); }
+            }
+        }
+    }
+    for (uint64_t v : valid) out->replay_bytes += ro[v].end - win_start_h(runs[v].start, W);
+
+    // ---- the state handed to the next chunk: replay the last region and the tail once more
+    // on the host, only for its final state (RangeReplay's tail rule makes it exact)
+    if (job.commit_state) {
+        const uint64_t tail = job.len ? job.len - 1 : 0;
+        uint64_t ts = win_start_h(tail, W);
+        for (int t = 0; t < 3 && ts > 0; t++) ts = win_start_h(ts - 1, W);
+        uint64_t from = last_is_entry ? job.lo[k] : (E > ts ? last_start : ts);
+        if (from < job.lo[k]) from = job.lo[k];
+        ReplayPart fin;
+        replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(), n,
+                    from, job.len, job.entry_exact[k] && from == job.lo[k], &fin);
+        ctx->states[k] = fin.state;
+        ctx->states[k].consumed_bytes = job.consumed0[k] + job.len;
+        ctx->states[k].stream_bytes = job.stream0[k] + job.len;
+        E = job.len;
+    }
+    if (end_pos) *end_pos = std::max(E, std::min(job.hi, job.len));
+    if (getenv("SX_TIMING"))
+        fprintf(stderr, "[sx] device replay mission %zu: %zu runs, pass1+entry %.2f ms, validity %.2f ms (%zu standing, %zu host parts), "
+                        "pass2+d2h %.2f ms (%llu findings), splice+state %.2f ms\n", k, n, t1 - t0, t2 - t1, valid.size(),
+                host_parts.size(), t3 - t2, (unsigned long long)nf, now_ms() - t3);
+    return SX_OK;
+}
 
 // Stage B for all missions: every (mission, part) pair is one task for a small thread pool;
 // part 0 of a mission starts from its entry state, the others speculate, and the per-mission
@@ -276,7 +449,10 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
     std::vector<std::vector<uint64_t>> bounds(nm);
     std::vector<std::vector<ReplayPart>> parts(nm);
     std::vector<std::pair<size_t, size_t>> tasks;
+    std::vector<char> on_device(nm, 0);
+    for (size_t k = 0; k < nm; k++) on_device[k] = device_replay_wanted(ctx, job, k, runs[k].size());
     for (size_t k = 0; k < nm; k++) {
+        if (on_device[k]) continue;
         replay_plan_range(std::min(job.lo[k], job.hi), job.hi, nthreads, &bounds[k]);
         parts[k].resize(bounds[k].size() - 1);
         for (size_t p = 0; p + 1 < bounds[k].size(); p++) tasks.emplace_back(k, p);
@@ -305,7 +481,13 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
     const double t_parts = now_ms();
     std::vector<MissionFindings> per(nm);
     std::vector<uint64_t> ends(nm, 0);
+    for (size_t k = 0; k < nm; k++)
+        if (on_device[k]) {
+            int rc = device_replay_mission(ctx, k, bytes, job, runs[k], &per[k], &ends[k]);
+            if (rc != SX_OK) return rc;
+        }
     auto stitch = [&](size_t k) {
+        if (on_device[k]) return;
         ScannerState st = ctx->states[k];
         replay_stitch(ctx->missions[k], st, job.consumed0[k], job.stream0[k], bytes, job.len, job.file_id, job.is_last,
                       runs[k].data(), runs[k].size(), parts[k], &per[k], nthreads, &ends[k]);
@@ -396,6 +578,11 @@ int sx_create(sx_ctx** out, const sx_mission* missions, int n_missions, int hip_
         if ((e = hipMalloc((void**)&d.d_recs, (size_t)cap * sizeof(DevRun))) != hipSuccess) return fail("hipMalloc", e);
         d.capacity = cap;
     }
+    for (size_t k = 0; k < ctx->dev.size(); k++)
+        if (const uint16_t* t = single_byte_table(ctx->missions[k].c.encoding)) {
+            if ((e = hipMalloc((void**)&ctx->dev[k].d_table, 256)) != hipSuccess) return fail("hipMalloc", e);
+            if ((e = hipMemcpy(ctx->dev[k].d_table, t, 256, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+        }
     *out = ctx;
     return SX_OK;
 }
@@ -408,6 +595,8 @@ void sx_destroy(sx_ctx* ctx) {
             if (d.stream) (void)hipStreamSynchronize(d.stream);
             if (d.d_recs) (void)hipFree(d.d_recs);
             if (d.d_counters) (void)hipFree(d.d_counters);
+            if (d.d_table) (void)hipFree(d.d_table);
+            for (void* q : d.d_rp) if (q) (void)hipFree(q);
             if (d.ev0) (void)hipEventDestroy(d.ev0);
             if (d.ev1) (void)hipEventDestroy(d.ev1);
             if (d.stream) (void)hipStreamDestroy(d.stream);
@@ -430,11 +619,16 @@ int sx_reset(sx_ctx* ctx) {
 
 // Device-resident input: download only the byte ranges the replay will look at.
 static int download_for_replay(sx_ctx* ctx, const uint8_t* d_bytes, uint64_t len,
-                               const std::vector<std::vector<sx_run>>& runs, SparseDeviceBytes* view) {
+                               const std::vector<std::vector<sx_run>>& runs, SparseDeviceBytes* view,
+                               const ReplayJob& job) {
     const size_t nm = ctx->missions.size();
         const double t0 = now_ms();
         std::vector<std::pair<uint64_t, uint64_t>> rg;
+        // what the host always looks at: the chunk's first windows and its tail
+        rg.emplace_back(0, std::min<uint64_t>(len, 64 * 1024));
+        if (len > 64 * 1024) rg.emplace_back(len - 64 * 1024, len);
         for (size_t k = 0; k < nm; k++) {
+            if (device_replay_wanted(ctx, job, k, runs[k].size())) continue;  // stage B of this mission runs on the device
             const size_t before = rg.size();
             replay_ranges(ctx->missions[k], ctx->states[k], len, runs[k].data(), runs[k].size(), replay_threads(ctx), &rg);
             // a mission's ranges come out almost sorted (runs are); fix up, then merge the sorted lists
@@ -505,12 +699,16 @@ static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_
 
     if (host_bytes) {
         HostBytes view(host_bytes);
-        rc = replay_all(ctx, view, whole_chunk_job(ctx, len, file_id, is_last != 0), runs, out, nullptr);
+        ReplayJob job = whole_chunk_job(ctx, len, file_id, is_last != 0);
+        job.d_bytes = d_bytes;
+        rc = replay_all(ctx, view, job, runs, out, nullptr);
     } else {
         SparseDeviceBytes view(ctx, d_bytes);
-        rc = download_for_replay(ctx, d_bytes, len, runs, &view);
+        ReplayJob job = whole_chunk_job(ctx, len, file_id, is_last != 0);
+        job.d_bytes = d_bytes;
+        rc = download_for_replay(ctx, d_bytes, len, runs, &view, job);
         if (rc != SX_OK) return rc;
-        rc = replay_all(ctx, view, whole_chunk_job(ctx, len, file_id, is_last != 0), runs, out, nullptr);
+        rc = replay_all(ctx, view, job, runs, out, nullptr);
     }
     ctx->stats.total_ms = now_ms() - t_begin;
     return rc;
@@ -611,6 +809,7 @@ static int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d
         job.consumed0.push_back(ctx->missions[k].c.counter_offset + file_stream_off + buf_off);
         job.stream0.push_back(file_stream_off + buf_off);
     }
+    job.d_bytes = d_bytes;
     int rc;
     std::vector<uint64_t> ends(nm, 0);
     if (host_bytes) {
@@ -618,7 +817,7 @@ static int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d
         rc = replay_all(ctx, view, job, ctx->shard_runs, out, ends.data());
     } else {
         SparseDeviceBytes view(ctx, d_bytes);
-        rc = download_for_replay(ctx, d_bytes, buf_len, ctx->shard_runs, &view);
+        rc = download_for_replay(ctx, d_bytes, buf_len, ctx->shard_runs, &view, job);
         if (rc != SX_OK) return rc;
         rc = replay_all(ctx, view, job, ctx->shard_runs, out, ends.data());
     }
@@ -731,17 +930,20 @@ int sx_device_download(sx_ctx* ctx, void* host_dst, const void* device_src, uint
 }
 
 int sx_device_read_bandwidth(sx_ctx* ctx, const void* device_bytes, uint64_t len, int repeats, double* gbytes_per_s) {
-    if (!ctx || ctx->host_only || !gbytes_per_s || repeats <= 0) return SX_E_STATE;
+    if (!ctx || ctx->host_only || !gbytes_per_s || repeats == 0) return SX_E_STATE;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     MissionDev& d = ctx->dev[0];
     uint64_t* d_out = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&d_out, 8));
     HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 8, d.stream));
-    HIP_TRY(ctx, launch_read_sum((const uint8_t*)device_bytes, len, d_out, d.stream));  // warm-up
+    // repeats < 0: probe with the scan kernels' traversal (private sub-chunk per wavefront) instead of grid-stride
+    const uint32_t sub = repeats < 0 ? (ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 256u * 1024u) : 0u;
+    if (repeats < 0) repeats = -repeats;
+    HIP_TRY(ctx, launch_read_sum((const uint8_t*)device_bytes, len, d_out, d.stream, sub));  // warm-up
     float best = 1e30f;
     for (int i = 0; i < repeats; i++) {
         HIP_TRY(ctx, hipEventRecord(d.ev0, d.stream));
-        HIP_TRY(ctx, launch_read_sum((const uint8_t*)device_bytes, len, d_out, d.stream));
+        HIP_TRY(ctx, launch_read_sum((const uint8_t*)device_bytes, len, d_out, d.stream, sub));
         HIP_TRY(ctx, hipEventRecord(d.ev1, d.stream));
         HIP_TRY(ctx, hipStreamSynchronize(d.stream));
         float ms = 0;

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include "../../include/stringsext_amd.h"
+
 namespace sx {
 
 // One wavefront streams `subchunk` consecutive bytes in 1 KiB tiles.
@@ -57,10 +59,36 @@ struct ScanParams {
     uint8_t lut[512];
 };
 
+// ---- stage B on the device (sx_replay_dev.hip) ----
+constexpr uint32_t kMaxRegionWindows = 64;  // longer regions go back to the host
+enum : uint32_t { kRegionOk = 0, kRegionChained = 1, kRegionNotMine = 2, kRegionTooLong = 3 };
+struct ReplayParams {
+    const uint8_t* data;      // device: buffer byte 0 (on the slice grid)
+    uint64_t len;
+    const sx_run* runs;       // device: sorted long runs of this mission (buffer relative)
+    uint64_t n_runs;
+    uint64_t lo, hi;          // only regions that begin in [lo, hi)
+    uint64_t consumed0, stream0;
+    uint32_t slice_base;
+    uint32_t encoding;        // SX_ENC_*
+    const uint16_t* table;    // device: 128-entry single-byte table or nullptr
+    uint32_t chars_min_nb, same_block, q, W, long_run;
+    int32_t grep_char, mission_id, file_id;
+    uint64_t af_lo, af_hi, ubf;
+};
+struct ReplayRegionOut {
+    uint64_t end;             // where the region's replay stopped (a window start, buffer relative)
+    uint32_t n_find, n_bytes, status, pad;
+};
+hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, hipStream_t stream);
+hipError_t launch_replay_write(const ReplayParams& P, const uint64_t* region_index, const uint64_t* fbase,
+                               const uint64_t* abase, uint64_t n_regions, sx_finding* findings, uint8_t* arena,
+                               hipStream_t stream);
+
 hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t stream);
 hipError_t launch_fill_background(uint8_t* dst, uint64_t first_index, uint64_t len, uint64_t seed,
                                   hipStream_t stream);
-hipError_t launch_read_sum(const uint8_t* src, uint64_t len, uint64_t* out, hipStream_t stream);
+hipError_t launch_read_sum(const uint8_t* src, uint64_t len, uint64_t* out, hipStream_t stream, uint32_t subchunk = 0);
 // dst[seg_dst[i] .. ] = src[seg_src[i] .. seg_src[i]+seg_len[i]) for i < n
 hipError_t launch_gather(const uint8_t* src, uint8_t* dst, const uint64_t* seg_src, const uint64_t* seg_dst,
                          const uint32_t* seg_len, uint32_t n, hipStream_t stream);

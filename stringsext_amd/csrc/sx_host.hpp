@@ -15,7 +15,6 @@
 #include <string>
 #include <vector>
 
-#include "../../include/stringsext_amd.h"
 #include "sx_device.hpp"
 
 namespace sx {

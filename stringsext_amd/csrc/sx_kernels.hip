@@ -677,8 +677,37 @@ __global__ __launch_bounds__(256) void read_sum_kernel(const u32x4* src, u64 n16
     if (acc == 0x12345678u) atomicAdd((unsigned long long*)out, 1ull);  // keep the loads alive
 }
 
-hipError_t launch_read_sum(const uint8_t* src, u64 len, u64* out, hipStream_t stream) {
-    hipLaunchKernelGGL(read_sum_kernel, dim3(256 * 8), dim3(256), 0, stream, (const u32x4*)src, len / 16, out);
+// same traversal as scan_kernel (one wavefront streams a private sub-chunk in 1 KiB tiles, two
+// tiles in flight) but no classification: the bandwidth this access pattern can reach at all
+__global__ __launch_bounds__(256) void read_subchunk_kernel(const uint8_t* data, u64 len, u32 subchunk, u64* out) {
+    const u32 lane = lane_id();
+    const u64 wave = (u64)blockIdx.x * 4u + uniform(threadIdx.x >> 6);
+    const u64 sub_start = wave * (u64)subchunk;
+    if (sub_start >= len) return;
+    const u64 sub_end = sub_start + subchunk < len ? sub_start + subchunk : len;
+    const uint8_t* base_ptr = data + sub_start;
+    const u32 base_lo = uniform((u32)(uintptr_t)base_ptr), base_hi = uniform((u32)((uintptr_t)base_ptr >> 32));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((u64)base_hi << 32) | base_lo), 0, (int)uniform((u32)(sub_end - sub_start)), 0x00020000);
+    const int n_tiles = (int)((sub_end - sub_start) / kTileBytes);
+    u32x4 cur = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u), 0, 0);
+    u32x4 nxt = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + kTileBytes), 0, 0);
+    u32 acc = 0, off = lane * 16u;
+    for (int t = 0; t < n_tiles; t++) {
+        u32x4 nn = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 2 * kTileBytes), 0, 0);
+        acc += cur.x ^ cur.y ^ cur.z ^ cur.w;
+        cur = nxt; nxt = nn; off += kTileBytes;
+    }
+    if (acc == 0x12345678u) atomicAdd((unsigned long long*)out, 1ull);
+}
+
+hipError_t launch_read_sum(const uint8_t* src, u64 len, u64* out, hipStream_t stream, uint32_t subchunk) {
+    if (subchunk) {
+        u64 waves = (len + subchunk - 1) / subchunk;
+        hipLaunchKernelGGL(read_subchunk_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, src, len, subchunk, out);
+    } else {
+        hipLaunchKernelGGL(read_sum_kernel, dim3(256 * 8), dim3(256), 0, stream, (const u32x4*)src, len / 16, out);
+    }
     return hipGetLastError();
 }
 

@@ -138,7 +138,8 @@ public:
         ri_ = 0;
         while (ri_ < n_runs_ && runs_[ri_].end <= lo) ri_++;
         strict_ = entry_exact && !st.clean();  // exact carried state: follow it until it is clean
-        if (!entry_exact) derive_state(lo, lo, st.decoder);
+        // no exact state here: re-derive decoder state AND leftover presence from the bytes before lo
+        if (!entry_exact) derive_state(lo, lo >= 9 ? lo - 9 : 0, st.decoder);
         uint64_t pos = lo;
         while (pos < len_) {
             if (!strict_ && !st.last_run_str_was_printed_and_is_maybe_cut_str) {

@@ -1,0 +1,367 @@
+// sx_replay_core.hpp — the body of the device-side exact replay (stage B).  Included by
+// sx_replay_dev.hip with SXD = `__device__ __forceinline__`; the test-only harness
+// tests/native/replay_core_host.cpp includes it with SXD = `inline` so that the very same
+// code can be compared region by region with the host replayer on a machine without GPU.
+#pragma once
+#include <stdint.h>
+
+#include "sx_device.hpp"
+
+namespace sx {
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+
+constexpr u32 kSliceLen = 4096;  // INPUT_BUF_LEN, src/input.rs:22
+
+enum { RES_INPUT_EMPTY = 0, RES_OUTPUT_FULL = 1, RES_MALFORMED = 2 };
+
+struct DStep { int result; u32 read, written; };
+
+// ------------------------------------------------------------------------------------------
+// Decoders (twin of sx_decoder.cpp)
+// ------------------------------------------------------------------------------------------
+struct DDecoder {
+    int enc;
+    u32 cp; u8 seen, needed, lower, upper;          // UTF-8
+    int lead_byte; u32 lead_surrogate; bool pending_bmp;  // UTF-16
+    const uint16_t* table;                            // single byte (0 = x-user-defined)
+};
+
+SXD void ddec_reset(DDecoder& d, int enc, const uint16_t* table) {
+    d.enc = enc; d.cp = 0; d.seen = d.needed = 0; d.lower = 0x80; d.upper = 0xBF;
+    d.lead_byte = -1; d.lead_surrogate = 0; d.pending_bmp = false; d.table = table;
+}
+
+SXD u32 dput_cp(u8* d, u32 c) {
+    if (c < 0x80) { d[0] = (u8)c; return 1; }
+    if (c < 0x800) { d[0] = (u8)(0xC0 | (c >> 6)); d[1] = (u8)(0x80 | (c & 0x3F)); return 2; }
+    if (c < 0x10000) {
+        d[0] = (u8)(0xE0 | (c >> 12)); d[1] = (u8)(0x80 | ((c >> 6) & 0x3F)); d[2] = (u8)(0x80 | (c & 0x3F));
+        return 3;
+    }
+    d[0] = (u8)(0xF0 | (c >> 18)); d[1] = (u8)(0x80 | ((c >> 12) & 0x3F));
+    d[2] = (u8)(0x80 | ((c >> 6) & 0x3F)); d[3] = (u8)(0x80 | (c & 0x3F));
+    return 4;
+}
+
+SXD DStep ddec_utf8(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {
+    u32 i = 0, w = 0;
+    for (;;) {
+        if (i >= n) {
+            if (last && d.needed != 0) {
+                d.cp = 0; d.needed = d.seen = 0; d.lower = 0x80; d.upper = 0xBF;
+                return { RES_MALFORMED, i, w };
+            }
+            return { RES_INPUT_EMPTY, i, w };
+        }
+        if (cap - w < 4) return { RES_OUTPUT_FULL, i, w };
+        const u8 b = src[i++];
+        if (d.needed == 0) {
+            if (b < 0x80) { dst[w++] = b; continue; }
+            if (b >= 0xC2 && b <= 0xDF) { d.needed = 1; d.cp = b & 0x1F; continue; }
+            if (b >= 0xE0 && b <= 0xEF) {
+                if (b == 0xE0) d.lower = 0xA0;
+                if (b == 0xED) d.upper = 0x9F;
+                d.needed = 2; d.cp = b & 0x0F; continue;
+            }
+            if (b >= 0xF0 && b <= 0xF4) {
+                if (b == 0xF0) d.lower = 0x90;
+                if (b == 0xF4) d.upper = 0x8F;
+                d.needed = 3; d.cp = b & 0x07; continue;
+            }
+            return { RES_MALFORMED, i, w };
+        }
+        if (b < d.lower || b > d.upper) {
+            d.cp = 0; d.needed = d.seen = 0; d.lower = 0x80; d.upper = 0xBF;
+            return { RES_MALFORMED, i - 1, w };  // un-read
+        }
+        d.lower = 0x80; d.upper = 0xBF;
+        d.cp = (d.cp << 6) | (b & 0x3F);
+        if (++d.seen != d.needed) continue;
+        w += dput_cp(dst + w, d.cp);
+        d.cp = 0; d.needed = d.seen = 0;
+    }
+}
+
+SXD DStep ddec_utf16(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {
+    const bool be = d.enc == 3;
+    u32 i = 0, w = 0;
+    if (d.pending_bmp) {
+        if (cap - w < 3) return { RES_OUTPUT_FULL, 0, 0 };
+        w += dput_cp(dst + w, d.lead_surrogate);
+        d.pending_bmp = false; d.lead_surrogate = 0;
+    }
+    for (;;) {
+        if (d.lead_byte < 0 && d.lead_surrogate == 0) {
+            while (n - i >= 2 && cap - w >= 4) {
+                const u32 u = be ? ((u32)src[i] << 8) | src[i + 1] : ((u32)src[i + 1] << 8) | src[i];
+                if ((u & 0xF800) != 0xD800) { w += dput_cp(dst + w, u); i += 2; continue; }
+                if ((u & 0xFC00) == 0xDC00) { i += 2; return { RES_MALFORMED, i, w }; }
+                if (n - i < 4) break;
+                const u32 v = be ? ((u32)src[i + 2] << 8) | src[i + 3] : ((u32)src[i + 3] << 8) | src[i + 2];
+                if ((v & 0xFC00) != 0xDC00) { i += 2; return { RES_MALFORMED, i, w }; }
+                w += dput_cp(dst + w, 0x10000u + ((u & 0x3FF) << 10) + (v & 0x3FF));
+                i += 4;
+            }
+        }
+        if (i >= n) {
+            if (last && (d.lead_surrogate != 0 || d.lead_byte >= 0)) {
+                d.lead_surrogate = 0; d.lead_byte = -1;
+                return { RES_MALFORMED, i, w };
+            }
+            return { RES_INPUT_EMPTY, i, w };
+        }
+        if (cap - w < 4) return { RES_OUTPUT_FULL, i, w };
+        const u8 b = src[i++];
+        if (d.lead_byte < 0) { d.lead_byte = b; continue; }
+        const u32 u = be ? ((u32)d.lead_byte << 8) | b : ((u32)b << 8) | (u32)d.lead_byte;
+        d.lead_byte = -1;
+        if ((u & 0xFC00) == 0xD800) {
+            if (d.lead_surrogate != 0) { d.lead_surrogate = u; return { RES_MALFORMED, i, w }; }
+            d.lead_surrogate = u;
+            continue;
+        }
+        if ((u & 0xFC00) == 0xDC00) {
+            if (d.lead_surrogate == 0) return { RES_MALFORMED, i, w };
+            w += dput_cp(dst + w, 0x10000u + ((d.lead_surrogate & 0x3FF) << 10) + (u & 0x3FF));
+            d.lead_surrogate = 0;
+            continue;
+        }
+        if (d.lead_surrogate != 0) { d.lead_surrogate = u; d.pending_bmp = true; return { RES_MALFORMED, i, w }; }
+        w += dput_cp(dst + w, u);
+    }
+}
+
+SXD DStep ddec_single(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap) {
+    u32 i = 0, w = 0;
+    for (;;) {
+        if (i >= n) return { RES_INPUT_EMPTY, i, w };
+        if (cap - w < 3) return { RES_OUTPUT_FULL, i, w };
+        const u8 b = src[i++];
+        if (b < 0x80) { dst[w++] = b; continue; }
+        const u32 c = d.table ? d.table[b - 0x80] : 0xF780u + (b - 0x80u);
+        if (c == 0) return { RES_MALFORMED, i, w };
+        w += dput_cp(dst + w, c);
+    }
+}
+
+SXD DStep ddecode(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {
+    if (d.enc == 1) return ddec_utf8(d, src, n, dst, cap, last);
+    if (d.enc == 2 || d.enc == 3) return ddec_utf16(d, src, n, dst, cap, last);
+    return ddec_single(d, src, n, dst, cap);
+}
+
+// ------------------------------------------------------------------------------------------
+// Filter + SplitStr (twin of sx_replay.cpp SplitStr::next, reference src/helper.rs:206-433)
+// ------------------------------------------------------------------------------------------
+SXD bool pass_af(const ReplayParams& p, u8 b) { b &= 127; return ((b < 64 ? p.af_lo >> b : p.af_hi >> (b - 64)) & 1) != 0; }
+SXD bool pass_ubf(const ReplayParams& p, u8 b) { return ((p.ubf >> (b & 0x3F)) & 1) != 0; }
+SXD bool pass_lead(const ReplayParams& p, u8 lead) { return (lead & 0x80) ? pass_ubf(p, lead) : pass_af(p, lead); }
+
+struct DSplit {
+    const u8 *inp_start, *inp_end, *p;
+    bool last_cut, invalid_after;
+};
+struct DChunk { const u8* s; u32 len; bool completes, maybe_cut, again; };
+
+SXD bool dsplit_next(const ReplayParams& m, DSplit& it, DChunk& out) {
+    const bool grep_needed = m.grep_char >= 0;
+    bool grep_ok = !grep_needed;
+    const u8* ok_p = it.p;
+    u32 ok_len = 0, ok_n = 0;
+    u8 last_mb = 0;
+    while (it.p < it.inp_end && ok_n < m.q) {
+        const u8 lead = *it.p;
+        u32 cl = 1;
+        if ((lead & 0x80) == 0) { if (!grep_ok && m.grep_char == (int)lead) grep_ok = true; }
+        else if ((lead & 0xE0) == 0xC0) cl = 2;
+        else if ((lead & 0xF0) == 0xE0) cl = 3;
+        else if ((lead & 0xF8) == 0xF0) cl = 4;
+        bool ok, advance = true;
+        if (cl == 1) ok = pass_af(m, lead);
+        else if (pass_ubf(m, lead)) {
+            ok = !m.same_block || lead == last_mb || last_mb == 0;
+            if (!ok) advance = false;
+            last_mb = lead;
+        } else { ok = false; last_mb = 0; }
+        if (ok) { ok_len += cl; ok_n++; it.p += cl; continue; }
+        if (advance) it.p += cl;
+        const bool exit3 = it.last_cut && ok_n > 0 && ok_p == it.inp_start;
+        const bool exit4 = ok_n >= m.chars_min_nb && grep_ok;
+        if (exit3 || exit4) break;
+        ok_len = 0; ok_n = 0; ok_p = it.p; grep_ok = !grep_needed;
+    }
+    if (ok_len == 0) return false;
+    const bool touches_left = ok_p == it.inp_start;
+    const bool touches_right = ok_p + ok_len >= it.inp_end;
+    const bool maybe_cut = ok_n >= m.q || (touches_right && !it.invalid_after);
+    const bool completes = touches_left && it.last_cut;
+    const bool again = !completes && touches_right && !it.invalid_after && (ok_n < m.q || !grep_ok);
+    const bool min_rule = ok_n >= m.chars_min_nb;
+    if (!completes && !again && (!grep_ok || !min_rule)) return false;
+    if (ok_n >= m.q) it.inp_start = it.p;
+    it.last_cut = maybe_cut;
+    out.s = ok_p; out.len = ok_len; out.completes = completes; out.maybe_cut = maybe_cut; out.again = again;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// Window grid (twin of sx_replay.cpp)
+// ------------------------------------------------------------------------------------------
+SXD u64 win_start(u64 p, u32 W) { const u64 s = p / kSliceLen * kSliceLen; return s + (p - s) / W * W; }
+
+constexpr u32 kObCap = 4 * 64 + 3 * 128 + 16;  // leftover (<= 4q bytes) + one window's output; q <= 64
+
+// One region.  WRITE=false: count only.  Returns through `o`.
+template <bool WRITE>
+SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_finding* fout, u8* aout, u64 abase) {
+    const u8* bytes = P.data;
+    const u64 len = P.len;
+    const u32 W = P.W;
+    const u64 want = win_start(P.runs[i].start, W);
+    u8 ob[kObCap];
+    DDecoder dec;
+
+    // ---- derive the state the reference would carry into `want` (RangeReplay::derive_state)
+    u32 leftover_len = 0;
+    {
+        ddec_reset(dec, P.encoding, P.table);
+        u64 p = want >= 8 ? want - 8 : 0;
+        if ((P.encoding == 2 || P.encoding == 3) && ((P.stream0 + p) & 1)) p = p ? p - 1 : p + 1;
+        if (p > want) p = want;
+        u8 sink[40], last[4];
+        u32 last_len = 0;
+        if (p < want) {
+            const u32 n = (u32)(want - p);
+            u32 k = 0;
+            for (;;) {
+                const DStep r = ddecode(dec, bytes + p + k, n - k, sink, sizeof sink, false);
+                k += r.read;
+                for (u32 w = 0; w < r.written;) {
+                    const u8 lead = sink[w];
+                    const u32 cl = lead < 0x80 ? 1 : lead < 0xE0 ? 2 : lead < 0xF0 ? 3 : 4;
+                    if (pass_lead(P, lead)) { for (u32 t = 0; t < cl; t++) last[t] = sink[w + t]; last_len = cl; }
+                    else last_len = 0;
+                    w += cl;
+                }
+                if (r.result == RES_INPUT_EMPTY) break;
+                if (r.result == RES_MALFORMED) last_len = 0;
+            }
+        }
+        for (u32 t = 0; t < last_len; t++) ob[t] = last[t];
+        leftover_len = last_len;
+    }
+    bool maybe_cut = false;
+
+    u64 ri = i;  // first run not yet behind us
+    u32 n_find = 0, n_bytes = 0, windows = 0;
+    u32 status = kRegionOk;
+    u64 pos = want;
+
+    // region_over(p): nothing forces the replay to go on at window start p
+    auto region_over = [&](u64 p) -> bool {
+        while (ri < P.n_runs && P.runs[ri].end <= p) ri++;
+        if (ri < P.n_runs && win_start(P.runs[ri].start, W) <= p) return false;
+        return true;
+    };
+    auto may_drop = [&](const u8* lo, u32 n) -> bool {
+        if (n == 0) return true;
+        if (n < P.long_run) return true;
+        u32 chars = 0;
+        for (u32 k = 0; k < n; k++) chars += (lo[k] & 0xC0) != 0x80;
+        return chars < P.long_run;
+    };
+
+    bool done = false;
+    while (!done && pos < len) {
+        const u64 soff = pos / kSliceLen * kSliceLen;
+        const u32 slen = (u32)(len - soff < kSliceLen ? len - soff : kSliceLen);
+        const u64 consumed = P.consumed0 + soff;
+        const u32 slice_index = (u32)(soff / kSliceLen) + P.slice_base;
+        u32 din = (u32)(pos - soff);
+        bool is_last_window = false;
+        // the leftover sits at the front of ob (the reference copies it there per slice, :101-114;
+        // here it is moved there per window — strings are copied out at once, so only ob[0..] matters)
+        while (din < slen) {
+            u32 dend;
+            if (din + W < slen) dend = din + W; else { is_last_window = true; dend = slen; }
+            if (++windows > kMaxRegionWindows) { status = kRegionTooLong; done = true; break; }
+            u32 dout = leftover_len;
+            for (;;) {  // 'decoder
+                const DStep r = ddecode(dec, bytes + soff + din, dend - din, ob + dout, kObCap - dout, false);
+                if (r.result == RES_OUTPUT_FULL) { status = kRegionTooLong; done = true; break; }
+                u8 precision = SX_PRECISION_EXACT;
+                if (r.written > 0 && din == 0 && (ob[dout] & 0x80)) {  // slice-start probe, :176-207
+                    DDecoder fresh;
+                    ddec_reset(fresh, P.encoding, P.table);
+                    u8 probe[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+                    const u32 pn = slen < 32 ? slen : 32;
+                    const DStep pr = ddecode(fresh, bytes + soff, pn, probe, 8, true);
+                    const u32 filled = dout + r.written < 8 ? dout + r.written : 8;
+                    bool same = pr.written != 0;
+                    for (u32 t = 0; t < pr.written && same; t++) same = (t < filled ? ob[t] : 0) == probe[t];
+                    if (!same) precision = SX_PRECISION_BEFORE;
+                }
+                u32 split_start = dout;
+                const u32 split_end = dout + r.written;
+                if (leftover_len > 0) { split_start -= leftover_len; leftover_len = 0; precision = SX_PRECISION_BEFORE; }
+                const bool invalid_after = r.result == RES_MALFORMED;  // is_last_input_buffer is never set here
+                const bool continue_str = maybe_cut;
+                maybe_cut = false;
+                const bool may_yield = continue_str || !invalid_after || split_end - split_start >= P.chars_min_nb;
+                if (split_end > split_start && may_yield) {
+                    DSplit it{ ob + split_start, ob + split_end, ob + split_start, continue_str, invalid_after };
+                    DChunk ch;
+                    while (dsplit_next(P, it, ch)) {
+                        if (!ch.again) {
+                            if (WRITE) {
+                                sx_finding f;
+                                f.position = consumed + din;
+                                f.str_off = (u32)(abase + n_bytes);
+                                f.str_len = ch.len;
+                                f.precision = precision;
+                                f.completes_previous = ch.completes ? 1 : 0;
+                                f.mission_id = (u8)P.mission_id;
+                                f.reserved = 0;
+                                f.input_file_id = (int16_t)P.file_id;
+                                f.reserved2 = 0;
+                                f.slice_index = slice_index;
+                                fout[n_find] = f;
+                                for (u32 t = 0; t < ch.len; t++) aout[n_bytes + t] = ch.s[t];
+                            }
+                            n_find++; n_bytes += ch.len;
+                            leftover_len = 0;
+                            maybe_cut = ch.maybe_cut;
+                        } else {
+                            leftover_len = ch.len;
+                            maybe_cut = false;
+                        }
+                        precision = SX_PRECISION_AFTER;
+                    }
+                }
+                dout += r.written;
+                din += r.read;
+                if (r.result == RES_INPUT_EMPTY) break;
+            }
+            if (done) break;
+            // move the leftover to the front for the next window / slice
+            if (leftover_len) {
+                const u32 from = dout - leftover_len;
+                if (from) for (u32 t = 0; t < leftover_len; t++) ob[t] = ob[from + t];
+            }
+            if (!maybe_cut && may_drop(ob, leftover_len) && region_over(soff + din)) { done = true; break; }
+        }
+        pos = soff + din;
+        (void)is_last_window;
+    }
+    o.end = pos;
+    o.n_find = n_find;
+    o.n_bytes = n_bytes;
+    o.status = status;
+}
+
+
+}  // namespace sx

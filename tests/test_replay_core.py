@@ -1,0 +1,120 @@
+"""The device-side exact replay (stringsext_amd/csrc/sx_replay_core.hpp), compiled as plain
+host C++ by a test-only harness, must agree region by region with the product's host replayer
+(sx_replay_shard_runs restricted to one region): same end position, same findings."""
+import ctypes as C
+import importlib.util
+import os
+import random
+import subprocess
+
+import pytest
+
+import refconfig as rc
+import stringsext_amd as sx
+import sxo_binding as sxo
+from test_host_logic import soup, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NATIVE = os.path.join(ROOT, "tests", "native")
+
+
+class ReplayParams(C.Structure):
+    _fields_ = [("data", C.c_char_p), ("len", C.c_uint64), ("runs", C.POINTER(sx.Run)), ("n_runs", C.c_uint64),
+                ("lo", C.c_uint64), ("hi", C.c_uint64), ("consumed0", C.c_uint64), ("stream0", C.c_uint64),
+                ("slice_base", C.c_uint32), ("encoding", C.c_uint32), ("table", C.POINTER(C.c_uint16)),
+                ("chars_min_nb", C.c_uint32), ("same_block", C.c_uint32), ("q", C.c_uint32), ("W", C.c_uint32),
+                ("long_run", C.c_uint32), ("grep_char", C.c_int32), ("mission_id", C.c_int32), ("file_id", C.c_int32),
+                ("af_lo", C.c_uint64), ("af_hi", C.c_uint64), ("ubf", C.c_uint64)]
+
+
+class RegionOut(C.Structure):
+    _fields_ = [("end", C.c_uint64), ("n_find", C.c_uint32), ("n_bytes", C.c_uint32), ("status", C.c_uint32),
+                ("pad", C.c_uint32)]
+
+
+@pytest.fixture(scope="module")
+def core():
+    so = os.path.join(NATIVE, "libreplay_core_host.so")
+    src = os.path.join(NATIVE, "replay_core_host.cpp")
+    hdr = os.path.join(ROOT, "stringsext_amd", "csrc", "sx_replay_core.hpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
+                               "-I/opt/rocm/include", "-o", so, src])
+    L = C.CDLL(so)
+    L.sxd_replay_region_host.argtypes = [C.POINTER(ReplayParams), C.c_uint64, C.POINTER(RegionOut), C.POINTER(sx.Finding),
+                                         C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]
+    return L
+
+
+def sb_table(enc_id):
+    spec = importlib.util.spec_from_file_location("gen_tables", os.path.join(ROOT, "oracle", "gen_tables.py"))
+    gt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gt)
+    name, codec, fill = gt.TABLES[enc_id - 16]
+    return (C.c_uint16 * 128)(*gt.table(codec, fill))
+
+
+def ws(p, W):
+    s = p // 4096 * 4096
+    return s + (p - s) // W * W
+
+
+CONFIGS = [
+    dict(encodings=["utf-8"], chars_min="10", unicode_block_filter="African"),
+    dict(encodings=["utf-8"], chars_min="4"),
+    dict(encodings=["koi8-r"], chars_min="4"),
+    dict(encodings=["ascii"], chars_min="5", output_line_len="10"),
+    dict(encodings=["utf-16le"], chars_min="3", unicode_block_filter="All"),
+    dict(encodings=["utf-16be"], chars_min="6", output_line_len="30", unicode_block_filter="Common"),
+    dict(encodings=["utf-8"], chars_min="3", output_line_len="6", grep_char="47", unicode_block_filter="All"),
+    dict(encodings=["utf-8"], chars_min="4", same_unicode_block=True, unicode_block_filter="All"),
+    dict(encodings=["windows-1252"], chars_min="8", unicode_block_filter="Latin"),
+    dict(encodings=["utf-8"], chars_min="70", output_line_len="64"),
+]
+
+
+@pytest.mark.parametrize("flags", CONFIGS, ids=lambda f: "-".join(f["encodings"]) + "-n" + f["chars_min"])
+@pytest.mark.parametrize("parity", [0, 1])
+def test_device_replay_core_equals_host_replayer(core, flags, parity):
+    rng = random.Random(hash(str(flags)) & 0xFFFF)
+    m = rc.missions(**flags)[0]
+    if m["output_line_char_nb_max"] > 64:
+        pytest.skip("device replay covers q <= 64")
+    W = 2 * m["output_line_char_nb_max"]
+    long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
+    table = sb_table(m["encoding"]) if m["encoding"] >= 16 else None
+    for data in (synth(rng, 60_000, 1 / 150), soup(rng, 30_001), synth(rng, 20_000, 1 / 2000),
+                 bytes(rng.choice(b"abcdefgh \x00") for _ in range(9_000))):
+        stream0 = parity  # odd stream offset of buffer byte 0 shifts the UTF-16 unit grid
+        runs = sxo.runs(m, data, stream_parity=stream0 & 1, min_chars=long_run)
+        arr = (sx.Run * max(1, len(runs)))(*[sx.Run(*t) for t in runs])
+        P = ReplayParams(data, len(data), arr, len(runs), 0, len(data), m["counter_offset"] + stream0, stream0, 0,
+                         m["encoding"], table, m["chars_min_nb"], int(m["require_same_unicode_block"]),
+                         m["output_line_char_nb_max"], W, long_run, -1 if m["grep_char"] is None else m["grep_char"],
+                         0, 1, m["af"] & (2**64 - 1), m["af"] >> 64, m["ubf"])
+        sc = sx.Scanner([m], device=sx.SX_HOST_ONLY)
+        fbuf = (sx.Finding * 4096)()
+        abuf = (C.c_uint8 * (1 << 20))()
+        checked = 0
+        for i, r in enumerate(runs):
+            want = ws(r[0], W)
+            if want == 0 or (i > 0 and want <= ws(runs[i - 1][1] - 1, W)):
+                continue  # first window: host only; chained: handled by the region before it
+            o = RegionOut()
+            rc_ = core.sxd_replay_region_host(C.byref(P), i, C.byref(o), fbuf, abuf, 4096, 1 << 20)
+            assert rc_ == 0
+            res, ends = sc.scan_shard(data, 0, 0, want + 1, start_at=[want], file_stream_off=stream0, file_id=1,
+                                      runs_per_mission=[runs])
+            host = [(f["position"], f["precision"], f["s"], f["completes"], f["slice_index"]) for f in res.findings()]
+            res.free()
+            arena = bytes(abuf[:o.n_bytes])
+            dev = [(fbuf[k].position, sx.PRECISION[fbuf[k].precision],
+                    arena[fbuf[k].str_off:fbuf[k].str_off + fbuf[k].str_len].decode("utf-8"),
+                    bool(fbuf[k].completes_previous), fbuf[k].slice_index) for k in range(o.n_find)]
+            if o.status == 3:
+                continue  # too long for the device: given back to the host by design
+            assert dev == host, (i, r, want)
+            # the host reports len when no further region exists; otherwise the stop position must agree
+            assert o.end == ends[0] or ends[0] == len(data), (i, r, want, o.end, ends[0])
+            checked += 1
+        assert checked > 0 or not runs
