@@ -62,6 +62,7 @@ struct sx_ctx {
     std::vector<std::vector<sx_run>> shard_runs;  // device runs of the last sx_scan_shard* buffer (reuse_runs)
     bool shard_runs_valid = false;
     uint8_t* h_pin = nullptr;   uint64_t h_pin_cap = 0;
+    uint8_t* h_pin2 = nullptr;  uint64_t h_pin2_cap = 0;   // device replay traffic (h_pin may back a live byte view)
     uint8_t* d_scratch = nullptr; uint64_t d_scratch_cap = 0;
 };
 
@@ -123,6 +124,15 @@ int ensure_pinned(sx_ctx* ctx, uint64_t bytes) {
     if (const char* e = getenv("SX_PIN_FLAGS")) flags = (unsigned)strtoul(e, nullptr, 0);
     HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_pin, bytes, flags));
     ctx->h_pin_cap = bytes;
+    return SX_OK;
+}
+int ensure_pinned2(sx_ctx* ctx, uint64_t bytes) {
+    if (ctx->h_pin2_cap >= bytes) return SX_OK;
+    if (ctx->h_pin2) HIP_TRY(ctx, hipHostFree(ctx->h_pin2));
+    ctx->h_pin2 = nullptr; ctx->h_pin2_cap = 0;
+    bytes += bytes / 4 + (1u << 20);
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_pin2, bytes, hipHostMallocNonCoherent));
+    ctx->h_pin2_cap = bytes;
     return SX_OK;
 }
 int ensure_scratch(sx_ctx* ctx, uint64_t bytes) {
@@ -202,7 +212,15 @@ int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_byt
                 if (rc != SX_OK) return rc;
             }
             DevRun* recs_p = (DevRun*)ctx->h_pin;
-            if (counters[0])
+            const bool dev_sorted = counters[0] >= 65536;  // worth three small kernels
+            if (dev_sorted) {
+                const size_t sb = sort_scratch_bytes(counters[0]);
+                int rc = ensure_scratch(ctx, sb);
+                if (rc != SX_OK) return rc;
+                HIP_TRY(ctx, sort_records(d.d_recs, counters[0], ctx->d_scratch, ctx->d_scratch_cap, d.stream));
+                HIP_TRY(ctx, hipMemcpyAsync(recs_p, d.d_recs, (size_t)counters[0] * sizeof(DevRun), hipMemcpyDeviceToHost, d.stream));
+                HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+            } else if (counters[0])
                 HIP_TRY(ctx, hipMemcpy(recs_p, d.d_recs, (size_t)counters[0] * sizeof(DevRun), hipMemcpyDeviceToHost));
             const double tc1 = now_ms();
             if (getenv("SX_DEBUG_RECS")) {
@@ -214,7 +232,8 @@ int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_byt
                             (r.chars_flags & kRecEndOpen) ? "E" : "-");
                 fprintf(stderr, "[sx] slow tiles %u\n", counters[1]);
             }
-            merge_device_runs(recs_p, counters[0], min_chars[k], sub, &(*out)[k]);
+            if (dev_sorted) merge_sorted_device_runs(recs_p, counters[0], min_chars[k], &(*out)[k]);
+            else merge_device_runs(recs_p, counters[0], min_chars[k], sub, &(*out)[k]);
             if (getenv("SX_TIMING"))
                 fprintf(stderr, "[sx] mission %d: %u record slots, d2h %.2f ms, merge/sort %.2f ms -> %zu runs\n", which[k],
                         counters[0], tc1 - tc0, now_ms() - tc1, (*out)[k].size());
@@ -306,7 +325,11 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
 
     // ---- pass 1 on the device: every region's extent and output size
     ReplayParams P{};
-    std::vector<ReplayRegionOut> ro(n);
+    {
+        int rc = ensure_pinned2(ctx, n * sizeof(ReplayRegionOut) + 64);
+        if (rc != SX_OK) return rc;
+    }
+    ReplayRegionOut* ro = (ReplayRegionOut*)ctx->h_pin2;
     if (n) {
         int rc = ensure_rp(ctx, d, 0, n * sizeof(sx_run)); if (rc) return rc;
         rc = ensure_rp(ctx, d, 1, n * sizeof(ReplayRegionOut)); if (rc) return rc;
@@ -318,7 +341,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         P.W = (uint32_t)W; P.long_run = m.long_run; P.grep_char = m.c.grep_char; P.mission_id = m.c.mission_id;
         P.file_id = job.file_id; P.af_lo = m.c.af_lo; P.af_hi = m.c.af_hi; P.ubf = m.c.ubf;
         HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], d.stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ro.data(), d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ro, d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream));
     }
 
     // ---- meanwhile on the host: the strict entry region (exact carried state), if any
@@ -386,9 +409,27 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[4], abase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream));
         HIP_TRY(ctx, launch_replay_write(P, (const uint64_t*)d.d_rp[2], (const uint64_t*)d.d_rp[3], (const uint64_t*)d.d_rp[4],
                                          nv, d_f, d_a, d.stream));
-        if (nf) HIP_TRY(ctx, hipMemcpyAsync(dev_f.data(), d_f, nf * sizeof(sx_finding), hipMemcpyDeviceToHost, d.stream));
-        if (nb) HIP_TRY(ctx, hipMemcpyAsync(&dev_a[0], d_a, nb, hipMemcpyDeviceToHost, d.stream));
+        // D2H through pinned memory (the region table in h_pin2 is no longer needed), then a
+        // threaded copy into the result storage
+        std::vector<uint64_t> ends_keep;  // `ro` is about to be overwritten: keep what the bookkeeping below reads
+        ends_keep.reserve(nv);
+        for (uint64_t v : valid) ends_keep.push_back(ro[v].end);
+        rc = ensure_pinned2(ctx, nf * sizeof(sx_finding) + nb + 64); if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin2, d_f, nf * sizeof(sx_finding) + nb, hipMemcpyDeviceToHost, d.stream));
         HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+        const uint8_t* src_f = ctx->h_pin2;
+        const uint8_t* src_a = ctx->h_pin2 + nf * sizeof(sx_finding);
+        const size_t fb = nf * sizeof(sx_finding);
+        const unsigned ct = std::max(1u, std::min(8u, usable_cpus()));
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < ct; t++)
+            th.emplace_back([&, t]() {
+                const size_t f0 = fb * t / ct, f1 = fb * (t + 1) / ct, a0 = nb * t / ct, a1 = nb * (t + 1) / ct;
+                if (f1 > f0) memcpy((uint8_t*)dev_f.data() + f0, src_f + f0, f1 - f0);
+                if (a1 > a0) memcpy(&dev_a[a0], src_a + a0, a1 - a0);
+            });
+        for (auto& x : th) x.join();
+        for (size_t j = 0; j < nv; j++) out->replay_bytes += ends_keep[j] - win_start_h(runs[valid[j]].start, W);
     }
     const double t3 = now_ms();
 
@@ -412,7 +453,6 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
             }
         }
     }
-    for (uint64_t v : valid) out->replay_bytes += ro[v].end - win_start_h(runs[v].start, W);
 
     // ---- the state handed to the next chunk: replay the last region and the tail once more
     // on the host, only for its final state (RangeReplay's tail rule makes it exact)
@@ -604,6 +644,7 @@ void sx_destroy(sx_ctx* ctx) {
         if (ctx->d_input) (void)hipFree(ctx->d_input);
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
         if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+        if (ctx->h_pin2) (void)hipHostFree(ctx->h_pin2);
     }
     delete ctx;
 }

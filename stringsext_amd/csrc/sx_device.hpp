@@ -85,6 +85,10 @@ hipError_t launch_replay_write(const ReplayParams& P, const uint64_t* region_ind
                                const uint64_t* abase, uint64_t n_regions, sx_finding* findings, uint8_t* arena,
                                hipStream_t stream);
 
+// order run records by start on the device (sx_sort.hip); unused slots end up last with start = ~0
+size_t sort_scratch_bytes(uint32_t n);
+hipError_t sort_records(DevRun* recs, uint32_t n, void* scratch, size_t scratch_bytes, hipStream_t stream);
+
 hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t stream);
 hipError_t launch_fill_background(uint8_t* dst, uint64_t first_index, uint64_t len, uint64_t seed,
                                   hipStream_t stream);

@@ -194,6 +194,8 @@ void replay_ranges(const Mission& m, const ScannerState& st, uint64_t len, const
 // Turn raw device records (any order, sub-chunk pieces flagged open) into maximal runs
 // with >= min_chars characters, sorted by start.
 void merge_device_runs(const DevRun* recs, size_t n, uint64_t min_chars, uint64_t subchunk, std::vector<sx_run>* out);
+// the same for records already sorted by start (unused slots last, start == ~0)
+void merge_sorted_device_runs(const DevRun* recs, size_t n, uint64_t min_chars, std::vector<sx_run>* out);
 
 // k-way merge in the reference's order: slice by slice, then (position, mission_id)
 // — src/main.rs:118-136, src/finding.rs:92-109.

@@ -552,6 +552,24 @@ void merge_device_runs(const DevRun* recs, size_t n, uint64_t min_chars, uint64_
     }
 }
 
+void merge_sorted_device_runs(const DevRun* v, size_t n, uint64_t min_chars, std::vector<sx_run>* out) {
+    out->clear();
+    out->reserve(n / 2);
+    for (size_t i = 0; i < n && v[i].start != ~0ull;) {
+        sx_run r{ v[i].start, v[i].start + v[i].len, v[i].chars_flags & kRecCharsMask };
+        bool open_end = (v[i].chars_flags & kRecEndOpen) != 0;
+        size_t k = i + 1;
+        while (open_end && k < n && v[k].start != ~0ull && (v[k].chars_flags & kRecStartOpen) && v[k].start == r.end) {
+            r.end = v[k].start + v[k].len;
+            r.chars += v[k].chars_flags & kRecCharsMask;
+            open_end = (v[k].chars_flags & kRecEndOpen) != 0;
+            k++;
+        }
+        if (r.chars >= min_chars) out->push_back(r);
+        i = k;
+    }
+}
+
 void merge_findings(std::vector<MissionFindings>& per, Result* out) {
     out->findings.clear();
     out->arena.clear();
