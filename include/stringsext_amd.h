@@ -117,7 +117,9 @@ typedef struct sx_options {
 enum {
     SX_OPT_GENERIC_KERNELS = 1u,  /* force the table-driven classifiers (testing) */
     SX_OPT_DEVICE_REPLAY = 2u,    /* run the exact replay (stage B) on the device even for small inputs */
-    SX_OPT_HOST_REPLAY = 4u       /* never run stage B on the device */
+    SX_OPT_HOST_REPLAY = 4u,      /* never run stage B on the device */
+    SX_OPT_TILE_TRAVERSAL = 8u    /* scan kernels: independent overlapping tiles visited grid-stride (experimental;
+                                     measured slower than the default: one private sub-chunk per wavefront) */
 };
 
 int  sx_abi_version(void);

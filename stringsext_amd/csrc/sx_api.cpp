@@ -186,6 +186,8 @@ int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_byt
                 }
             }
             p.capacity = d.capacity; p.recs = d.d_recs; p.counters = d.d_counters;
+            p.traversal = (ctx->opt.flags & SX_OPT_TILE_TRAVERSAL) ? 1u : 0u;
+            if (const char* e = getenv("SX_TRAVERSAL")) p.traversal = (uint32_t)atoi(e);
             HIP_TRY(ctx, hipMemsetAsync(d.d_counters, 0, 4 * sizeof(uint32_t), d.stream));
             HIP_TRY(ctx, hipEventRecord(d.ev0, d.stream));
             HIP_TRY(ctx, launch_scan(m.kind, p, d.stream));
@@ -233,7 +235,7 @@ int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_byt
                 fprintf(stderr, "[sx] slow tiles %u\n", counters[1]);
             }
             if (dev_sorted) merge_sorted_device_runs(recs_p, counters[0], min_chars[k], &(*out)[k]);
-            else merge_device_runs(recs_p, counters[0], min_chars[k], sub, &(*out)[k]);
+            else merge_device_runs(recs_p, counters[0], min_chars[k], 64 * 1024, &(*out)[k]);
             if (getenv("SX_TIMING"))
                 fprintf(stderr, "[sx] mission %d: %u record slots, d2h %.2f ms, merge/sort %.2f ms -> %zu runs\n", which[k],
                         counters[0], tc1 - tc0, now_ms() - tc1, (*out)[k].size());

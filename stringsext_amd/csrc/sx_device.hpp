@@ -49,6 +49,7 @@ struct ScanParams {
     uint32_t parity;       // UTF-16: (stream offset of byte 0) & 1
     uint32_t big_endian;   // UTF-16BE
     uint32_t capacity;     // record slots
+    uint32_t traversal;    // 0: one sub-chunk per wavefront (carry in SGPRs); 1: independent overlapping tiles, grid-stride
     DevRun* recs;
     uint32_t* counters;    // [0] records appended (may exceed capacity = overflow), [1] slow-path tiles
     // range classifiers

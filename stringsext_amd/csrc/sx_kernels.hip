@@ -613,6 +613,191 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
     em.invalidate_rest();
 }
 
+// ------------------------------------------------------------------------------------------
+// scan_kernel_v2: tile-independent, grid-stride.
+//
+// A wavefront loads 1 KiB = bytes [tb-32, tb+992) where tb = 976*t: lanes 0-1 are look-back
+// context (the last 32 bytes the previous tile owns), lanes 2-62 are OWNED (976 bytes), lane 63
+// is look-ahead (its byte 0 tells whether a stretch goes on; its first dword is lane 62's
+// look-ahead for multi-byte characters).  Nothing is carried from tile to tile, so tiles are
+// visited grid-stride: at any moment the resident wavefronts read one compact, advancing
+// window of the buffer — the DRAM-friendly pattern of a plain streaming read.
+//
+// Who reports a stretch: the tile that owns its END.  If the stretch began before what that
+// tile can see (its lanes 0 and 1 are all ones) it reports only the part from tb on, flagged
+// kRecStartOpen; the tile before reports the part up to tb flagged kRecEndOpen — it applies
+// the same test to the same 32 bytes (its lanes 61 and 62).  The host joins the flagged
+// parts.  A stretch that begins inside those 32 bytes belongs wholly to the next tile.
+// ------------------------------------------------------------------------------------------
+constexpr u32 kOwnedBytes = 976;  // 61 lanes x 16 bytes
+
+// Exact resolution of every stretch that ends in an owned lane, and of the one that runs over
+// the owned end.  g, s: final good / start masks (16 bits); tb: first owned byte.
+SX_DEV void heavy_path_v2(u32 g, u32 s, u64 tb, Emitter& em, u32 min_chars) {
+    const u32 lane = lane_id();
+    g &= 0xFFFFu; s &= 0xFFFFu;
+    // Lane 0 cannot know whether its first three bytes continue a character that began before
+    // the loaded window (the tile before knows).  Both tiles therefore leave these three bits
+    // out of the "can the next tile see the start" test: here they count as ones.
+    if (lane == 0) g |= 7u;
+    const bool all = g == 0xFFFFu;
+    const u32 cnt = (u32)__popc(s);
+    const u32 trail1 = trailing_ones16(g);
+    const u32 trail_chars = (u32)__popc(s >> (16u - trail1));
+    const u64 zmask = __ballot(!all);
+    const u32 P = wave_inclusive_scan(cnt);
+    const u32 Pex = P - cnt;
+    const u32 ctx_chars = bcast(P, 1);  // starts inside the two context lanes
+
+    const u64 below = zmask & ((1ull << lane) - 1ull);
+    const int j = below ? 63 - __clzll((long long)below) : -1;
+    const u32 jj = j < 0 ? 0u : (u32)j;
+    const u32 tj = shfl(trail1, jj), tcj = shfl(trail_chars, jj), Pj = shfl(P, jj);
+    const u64 tile0 = tb - 32;  // byte 0 of lane 0
+    u64 left_start;
+    u32 left_chars, left_flags = 0;
+    if (j >= 0) { left_start = tile0 + 16ull * jj + (16u - tj); left_chars = tcj + (Pex - Pj); }
+    else { left_start = tb; left_chars = Pex - ctx_chars; left_flags = kRecStartOpen; }  // began before lane 0
+
+    const u32 nb0 = from_next(g & 1u, 0u);
+    const bool owned = lane >= 2 && lane <= 62;
+    const u32 pg = from_prev(g, 0u);
+    u32 rem = owned ? g : 0u;
+    while (__ballot(rem != 0)) {
+        const bool has = rem != 0;
+        const u32 st = has ? (u32)__builtin_ctz(rem) : 0u;
+        const u32 ln = (u32)__builtin_ctz(~(rem >> st));
+        const u32 en = st + ln;
+        const u32 field = ((1u << ln) - 1u) << st;
+        u32 ch = (u32)__popc(s & field);
+        u64 start = tile0 + 16ull * lane + st;
+        u32 flags = 0;
+        if (st == 0) { ch += left_chars; start = left_start; flags = left_flags; }
+        const bool closed = en < 16u || nb0 == 0u;
+        u64 end = tile0 + 16ull * lane + en;
+        bool emit = has && closed && (ch >= min_chars || flags);
+        if (has && !closed && lane == 62) {
+            // runs over the owned end: mine to report (up to there) only if the next tile cannot see its start
+            const bool next_blind = g == 0xFFFFu && (pg | 7u) == 0xFFFFu;  // lane 61's bits 0..2: see above
+            if (next_blind) { emit = true; flags |= kRecEndOpen; }
+        }
+        em.append(emit, start, end, ch, flags);
+        rem &= ~field;
+    }
+}
+
+// lane-local resolution (see light_path); owned lanes only.  false: the tile needs heavy_path_v2.
+SX_DEV bool light_path_v2(u32 w, u32 sw, u32 r, u64 lane_base, Emitter& em, u32 min_chars) {
+    const u32 lane = lane_id();
+    const bool owned = lane >= 2 && lane <= 62;
+    const u32 gf = w >> 16;
+    const u32 n0 = from_next(gf & 1u, 0u);
+    const u32 ends = gf & ~((gf >> 1) | (n0 << 15));
+    u32 cand = owned ? (ends & (r >> 16)) : 0u;
+    // a stretch that runs over the owned end and that the next tile cannot resolve
+    const bool over_end = lane == 62 && (gf & 0x8000u) && n0 && (w | 7u) == 0xFFFFFFFFu;
+    const u32 e0 = 16u + (cand ? (u32)__builtin_ctz(cand) : 0u);
+    const bool unresolved = cand && ((~w) & ((1u << e0) - 1u)) == 0u;
+    if (__ballot(over_end || unresolved)) return false;
+    while (__ballot(cand != 0)) {
+        const bool has = cand != 0;
+        const u32 e = 16u + (has ? (u32)__builtin_ctz(cand) : 0u);
+        const u32 below = (~w) & ((1u << e) - 1u);
+        const u32 st = below ? 32u - (u32)__clz((int)below) : 0u;
+        const u32 field = (e >= 31u ? 0xFFFFFFFFu : ((1u << (e + 1u)) - 1u)) & ~((1u << st) - 1u);
+        const u32 ch = (u32)__popc(sw & field);
+        em.append(has && ch >= min_chars, lane_base - 16 + st, lane_base - 16 + e + 1, ch, 0u);
+        cand &= cand - 1u;
+    }
+    return true;
+}
+
+template <class CLS, bool NEEDS_LUT>
+__global__ __launch_bounds__(256) void scan_kernel_v2(const ScanParams p) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_lut[512];
+    if (NEEDS_LUT) {
+        lds_lut[threadIdx.x] = p.lut[threadIdx.x];
+        lds_lut[threadIdx.x + 256] = p.lut[threadIdx.x + 256];
+        __syncthreads();
+    }
+    const u32 lane = lane_id();
+    const u64 n_tiles = (p.len + kOwnedBytes - 1) / kOwnedBytes;
+    const u64 n_waves = (u64)gridDim.x * 4u;
+    u64 t = (u64)blockIdx.x * 4u + uniform(threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+
+    CLS cls;
+    cls.init(p, lds_lut);
+    Emitter em{ p.recs, p.counters, p.capacity, 0u, 0u };
+
+    // the tile's 1 KiB through a descriptor of its own (64-bit base in SGPRs, 32-bit offsets)
+    auto load_tile = [&](u64 tile) -> u32x4 {
+        const long long first = (long long)(tile * kOwnedBytes) - 32;  // may be -32 for tile 0
+        const u64 lo = first < 0 ? 0ull : (u64)first;
+        const uint8_t* bp = p.data + lo;
+        u64 avail = p.len > lo ? p.len - lo : 0;
+        if (avail > kTileBytes + 16) avail = kTileBytes + 16;
+        const u32 b_lo = uniform((u32)(uintptr_t)bp), b_hi = uniform((u32)((uintptr_t)bp >> 32));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((u64)b_hi << 32) | b_lo), 0, (int)uniform(((u32)avail + 15u) & ~15u), 0x00020000);
+        // lanes 0,1 of tile 0 lie before the chunk: unsigned wrap puts them out of range -> 0
+        const u32 off = lane * 16u - (first < 0 ? 32u : 0u);
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+    };
+
+    u32x4 cur = load_tile(t);
+    u32x4 nxt = t + n_waves < n_tiles ? load_tile(t + n_waves) : cur;
+
+    auto body = [&](auto near_tag) {
+        constexpr bool NE = decltype(near_tag)::value;
+        const u32x4 nn = t + 2 * n_waves < n_tiles ? load_tile(t + 2 * n_waves) : nxt;
+        const u64 tb = t * kOwnedBytes;
+        const long long lb = (long long)tb - 32 + 16ll * lane;  // my first byte (negative: before the chunk)
+        u32 avail = 32;
+        if (NE) avail = lb < 0 ? 32u : ((u64)lb >= p.len ? 0u : (p.len - (u64)lb > 32 ? 32u : (u32)(p.len - (u64)lb)));
+        u32x4 x = cur;
+        if (t == 0 && lane < 2) { x.x = 0xFFFFFFFFu; x.y = 0xFFFFFFFFu; x.z = 0xFFFFFFFFu; x.w = 0xFFFFFFFFu; }  // nothing before the chunk
+        const u32 nx = from_next(x.x, 0u);  // lane 63's own look-ahead is never used
+        u32 g = cls.template classify<false>(x, nx, avail, NE);
+        if (t == 0 && lane < 2) g = 0;
+        const u32 pg = from_prev(g, 0u);
+        const u32 gf = (g & 0xFFFFu) | (pg >> 16);
+        const u32 pgf = from_prev(gf, 0u) & 0xFFFFu;
+        const u32 w = (gf << 16) | pgf;
+        u32 r = w;
+        r &= r << p.cand_sh[0]; r &= r << p.cand_sh[1]; r &= r << p.cand_sh[2];
+        r &= r << p.cand_sh[3]; r &= r << p.cand_sh[4];
+        const bool owned = lane >= 2 && lane <= 62;
+        const u32 n0 = from_next(gf & 1u, 0u);
+        const bool over_end = lane == 62 && (gf & 0x8000u) && n0 && (w | 7u) == 0xFFFFFFFFu;
+        if (__ballot((owned && (r & 0xFFFF0000u) != 0) || over_end)) {
+            u32 s = cls.template classify<true>(x, nx, avail, NE);
+            if (t == 0 && lane < 2) s = 0;
+            const u32 sw = (s << 16) | (from_prev(s, 0u) & 0xFFFFu);
+            const u64 lane_base = (u64)(lb < 0 ? 0 : lb);
+            if (!light_path_v2(w, sw, r, lane_base, em, p.min_chars)) {
+                if (lane == 0) atomicAdd(p.counters + 1, 1u);
+                heavy_path_v2(gf, s, tb, em, p.min_chars);
+            }
+        }
+        cur = nxt; nxt = nn; t += n_waves;
+    };
+    // tiles whose 1 KiB (+16) lies fully inside the chunk need no end-of-input care
+    while (t < n_tiles && t * kOwnedBytes + kTileBytes + 16 <= p.len) body(std::false_type{});
+    while (t < n_tiles) body(std::true_type{});
+    em.invalidate_rest();
+}
+
+template <class CLS, bool LUT>
+static hipError_t launch_v2(const ScanParams& p, hipStream_t stream) {
+    const u64 n_tiles = (p.len + kOwnedBytes - 1) / kOwnedBytes;
+    u64 blocks = (n_tiles + 3) / 4;
+    if (blocks > 256u * 8u) blocks = 256u * 8u;  // 8 blocks of 4 waves per CU, grid-stride beyond
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL((scan_kernel_v2<CLS, LUT>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 template <class CLS, bool LUT>
 static hipError_t launch_t(const ScanParams& p, hipStream_t stream) {
     u64 waves = (p.len + p.subchunk - 1) / p.subchunk;
@@ -623,6 +808,16 @@ static hipError_t launch_t(const ScanParams& p, hipStream_t stream) {
 }
 
 hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t stream) {
+    if (p.traversal == 1) {
+        switch (kind) {
+        case kClsSingleByteLut: return launch_v2<SingleByteLut, true>(p, stream);
+        case kClsUtf8Lut: return launch_v2<Utf8Lut, true>(p, stream);
+        case kClsUtf16Lut: return launch_v2<Utf16Lut, true>(p, stream);
+        case kClsUtf8Range2: return launch_v2<Utf8Range2, false>(p, stream);
+        case kClsUtf16Range: return launch_v2<Utf16Range, false>(p, stream);
+        case kClsSingleByteRange: return launch_v2<SingleByteRange, false>(p, stream);
+        }
+    }
     switch (kind) {
     case kClsSingleByteLut: return launch_t<SingleByteLut, true>(p, stream);
     case kClsUtf8Lut: return launch_t<Utf8Lut, true>(p, stream);

@@ -72,6 +72,20 @@ def test_device_runs_equal_oracle_runs(name, generic):
                 assert got == want, (name, di, parity, sub, len(got), len(want))
 
 
+def test_tile_traversal_kernels_equal_oracle_runs(monkeypatch):
+    """The experimental tile-independent grid-stride kernels (SX_TRAVERSAL=1) report the same runs."""
+    monkeypatch.setenv("SX_TRAVERSAL", "1")
+    rng = random.Random(11)
+    for name in ("ascii", "utf8_common", "utf8_all", "utf16le_all", "utf16be_uncommon", "koi8r"):
+        m = rc.missions(**RUN_MISSIONS[name])[0]
+        for data in (synth(rng, 300_000, 1 / 300), soup(rng, 50_001), b"A" * 70000 + rng.randbytes(977) + b"B" * 3000,
+                     synth(rng, 975, 1 / 40), synth(rng, 977, 1 / 40), synth(rng, 2000, 1 / 40)):
+            for parity in (0, 1):
+                for generic in (False, True):
+                    got, mc = device_runs(m, data, parity=parity, generic=generic)
+                    assert got == sxo.runs(m, data, stream_parity=parity, min_chars=mc), (name, len(data), parity, generic)
+
+
 def test_device_runs_min_chars_sweep_and_overflow():
     m = rc.missions(encodings=["ascii"], chars_min="4")[0]
     data = random.Random(3).randbytes(1 << 20)
