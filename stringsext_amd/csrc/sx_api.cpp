@@ -19,6 +19,31 @@
 
 using namespace sx;
 
+namespace sx {
+PinnedPool::Block PinnedPool::take(size_t bytes) {
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < free_blocks.size(); i++)
+            if (free_blocks[i].cap >= bytes) { Block b = free_blocks[i]; free_blocks.erase(free_blocks.begin() + (long)i); return b; }
+        // too small ones are dropped: the pool holds at most a couple of blocks
+        for (Block& b : free_blocks) (void)hipHostFree(b.p);
+        free_blocks.clear();
+    }
+    Block b;
+    const size_t cap = bytes + bytes / 8 + (1u << 20);
+    if (hipHostMalloc(&b.p, cap, hipHostMallocNonCoherent) != hipSuccess) { b.p = nullptr; return b; }
+    b.cap = cap;
+    return b;
+}
+void PinnedPool::give(Block b) {
+    if (!b.p) return;
+    std::lock_guard<std::mutex> g(mu);
+    if (free_blocks.size() >= 2) { (void)hipHostFree(b.p); return; }
+    free_blocks.push_back(b);
+}
+PinnedPool::~PinnedPool() { for (Block& b : free_blocks) (void)hipHostFree(b.p); }
+}  // namespace sx
+
 namespace {
 
 std::string g_create_error;
@@ -47,6 +72,7 @@ struct sx_result {
 };
 
 struct sx_ctx {
+    std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
     std::vector<Mission> missions;
     std::vector<ScannerState> states;
     std::vector<MissionDev> dev;
@@ -395,9 +421,9 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     if (nb > 0xFFFFFFFFull) { ctx->err = "more than 4 GiB of strings in one chunk"; return SX_E_NOMEM; }
     const double t2 = now_ms();
 
-    // ---- pass 2: the standing regions write findings and strings, in order
-    std::vector<sx_finding> dev_f(nf);
-    std::string dev_a(nb, '\0');
+    // ---- pass 2: the standing regions write findings and strings, in order; the D2H lands in a
+    // pinned block that becomes the result's storage (no copy) unless host parts must be spliced in
+    PinnedPool::Block blk{};
     if (!valid.empty()) {
         const size_t nv = valid.size();
         int rc = ensure_rp(ctx, d, 2, nv * 8); if (rc) return rc;
@@ -406,40 +432,25 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         rc = ensure_rp(ctx, d, 5, nf * sizeof(sx_finding) + nb + 64); if (rc) return rc;
         sx_finding* d_f = (sx_finding*)d.d_rp[5];
         uint8_t* d_a = (uint8_t*)d.d_rp[5] + nf * sizeof(sx_finding);
+        for (uint64_t v : valid) out->replay_bytes += ro[v].end - win_start_h(runs[v].start, W);
         HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[2], valid.data(), nv * 8, hipMemcpyHostToDevice, d.stream));
         HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[3], fbase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream));
         HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[4], abase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream));
         HIP_TRY(ctx, launch_replay_write(P, (const uint64_t*)d.d_rp[2], (const uint64_t*)d.d_rp[3], (const uint64_t*)d.d_rp[4],
                                          nv, d_f, d_a, d.stream));
-        // D2H through pinned memory (the region table in h_pin2 is no longer needed), then a
-        // threaded copy into the result storage
-        std::vector<uint64_t> ends_keep;  // `ro` is about to be overwritten: keep what the bookkeeping below reads
-        ends_keep.reserve(nv);
-        for (uint64_t v : valid) ends_keep.push_back(ro[v].end);
-        rc = ensure_pinned2(ctx, nf * sizeof(sx_finding) + nb + 64); if (rc) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin2, d_f, nf * sizeof(sx_finding) + nb, hipMemcpyDeviceToHost, d.stream));
+        blk = ctx->pool->take(nf * sizeof(sx_finding) + nb + 64);
+        if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
+        HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_f, nf * sizeof(sx_finding) + nb, hipMemcpyDeviceToHost, d.stream));
         HIP_TRY(ctx, hipStreamSynchronize(d.stream));
-        const uint8_t* src_f = ctx->h_pin2;
-        const uint8_t* src_a = ctx->h_pin2 + nf * sizeof(sx_finding);
-        const size_t fb = nf * sizeof(sx_finding);
-        const unsigned ct = std::max(1u, std::min(8u, usable_cpus()));
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < ct; t++)
-            th.emplace_back([&, t]() {
-                const size_t f0 = fb * t / ct, f1 = fb * (t + 1) / ct, a0 = nb * t / ct, a1 = nb * (t + 1) / ct;
-                if (f1 > f0) memcpy((uint8_t*)dev_f.data() + f0, src_f + f0, f1 - f0);
-                if (a1 > a0) memcpy(&dev_a[a0], src_a + a0, a1 - a0);
-            });
-        for (auto& x : th) x.join();
-        for (size_t j = 0; j < nv; j++) out->replay_bytes += ends_keep[j] - win_start_h(runs[valid[j]].start, W);
     }
     const double t3 = now_ms();
 
     // ---- splice (almost always: device findings only)
     if (host_parts.empty()) {
-        out->v = std::move(dev_f);
-        out->arena = std::move(dev_a);
+        if (blk.p) { out->ext = blk; out->ext_nf = nf; out->ext_na = nb; }
     } else {
+        const sx_finding* dev_f = (const sx_finding*)blk.p;
+        const char* dev_a = blk.p ? (const char*)blk.p + nf * sizeof(sx_finding) : nullptr;
         for (const Seg& g : segs) {
             if (g.host_part >= 0) {
                 const MissionFindings& hf = host_parts[(size_t)g.host_part].findings;
@@ -450,10 +461,11 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
             } else if (g.v1 > g.v0) {
                 const uint64_t f0 = fbase[g.v0], f1 = fbase[g.v1], a0 = abase[g.v0], a1 = abase[g.v1];
                 const uint32_t base = (uint32_t)out->arena.size();
-                out->arena.append(dev_a, a0, a1 - a0);
+                out->arena.append(dev_a + a0, a1 - a0);
                 for (uint64_t j = f0; j < f1; j++) { sx_finding f = dev_f[j]; f.str_off = f.str_off - (uint32_t)a0 + base; out->v.push_back(f); }
             }
         }
+        ctx->pool->give(blk);
     }
 
     // ---- the state handed to the next chunk: replay the last region and the tail once more
@@ -545,7 +557,7 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
     if (end_pos) for (size_t k = 0; k < nm; k++) end_pos[k] = ends[k];
     const double t_stitch = now_ms();
     sx_result* r = new sx_result();
-    merge_findings(per, &r->r);
+    merge_findings(per, ctx->pool, &r->r);
     if (getenv("SX_TIMING")) {
         double mx = 0, sum = 0;
         for (double v : task_ms) { sum += v; mx = std::max(mx, v); }
@@ -554,7 +566,7 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
                 now_ms() - t_stitch, (unsigned long long)ctx->ondemand_fetches);
     }
     for (auto& mf : per) ctx->stats.replay_bytes += mf.replay_bytes;
-    ctx->stats.findings += r->r.findings.size();
+    ctx->stats.findings += r->r.count();
     ctx->stats.replay_ms += now_ms() - t0;
     *out = r;
     return SX_OK;
@@ -910,12 +922,12 @@ int sx_replay_shard_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t buf_off, ui
                         file_stream_off, input_file_id, 0, out, end_pos);
 }
 
-uint64_t sx_result_count(const sx_result* r) { return r ? r->r.findings.size() : 0; }
-const sx_finding* sx_result_findings(const sx_result* r) { return r ? r->r.findings.data() : nullptr; }
+uint64_t sx_result_count(const sx_result* r) { return r ? r->r.count() : 0; }
+const sx_finding* sx_result_findings(const sx_result* r) { return r ? r->r.data() : nullptr; }
 const uint8_t* sx_result_arena(const sx_result* r, uint64_t* len) {
     if (!r) return nullptr;
-    if (len) *len = r->r.arena.size();
-    return (const uint8_t*)r->r.arena.data();
+    if (len) *len = r->r.strings_len();
+    return (const uint8_t*)r->r.strings();
 }
 void sx_result_free(sx_result* r) { delete r; }
 

@@ -12,6 +12,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -155,10 +157,29 @@ private:
 // ---------------------------------------------------------------------------------------
 // Findings of one mission for one chunk
 // ---------------------------------------------------------------------------------------
+// Pinned host blocks that travel from the context (D2H target) to a result (zero copy) and
+// back when the result is freed.  Shared so that a result may outlive its context.
+struct PinnedPool {
+    struct Block { void* p = nullptr; size_t cap = 0; };
+    std::mutex mu;
+    std::vector<Block> free_blocks;
+    Block take(size_t bytes);   // a pooled block of >= bytes, or a new allocation (sx_api.cpp: hipHostMalloc)
+    void give(Block b);
+    ~PinnedPool();
+};
+
 struct MissionFindings {
     std::vector<sx_finding> v;  // str_off relative to `arena`
     std::string arena;
     uint64_t replay_bytes = 0;
+    // alternatively the findings live in a pinned block (device replay output, no copy):
+    // [ext_nf x sx_finding][ext_na bytes of strings]
+    PinnedPool::Block ext{};
+    size_t ext_nf = 0, ext_na = 0;
+    size_t count() const { return ext.p ? ext_nf : v.size(); }
+    const sx_finding* data() const { return ext.p ? (const sx_finding*)ext.p : v.data(); }
+    const char* strings() const { return ext.p ? (const char*)ext.p + ext_nf * sizeof(sx_finding) : arena.data(); }
+    size_t strings_len() const { return ext.p ? ext_na : arena.size(); }
 };
 
 // Exact replay of FindingCollection::from over the windows that matter.
@@ -200,10 +221,15 @@ void merge_sorted_device_runs(const DevRun* recs, size_t n, uint64_t min_chars, 
 // k-way merge in the reference's order: slice by slice, then (position, mission_id)
 // — src/main.rs:118-136, src/finding.rs:92-109.
 struct Result {
-    std::vector<sx_finding> findings;
-    std::string arena;
+    MissionFindings m;                 // the merged findings (vectors, or a pinned block taken over)
+    std::shared_ptr<PinnedPool> pool;  // where m.ext goes back to
+    ~Result() { if (m.ext.p && pool) pool->give(m.ext); }
+    size_t count() const { return m.count(); }
+    const sx_finding* data() const { return m.data(); }
+    const char* strings() const { return m.strings(); }
+    size_t strings_len() const { return m.strings_len(); }
 };
-void merge_findings(std::vector<MissionFindings>& per_mission, Result* out);
+void merge_findings(std::vector<MissionFindings>& per_mission, const std::shared_ptr<PinnedPool>& pool, Result* out);
 
 // Finding::print — src/finding.rs:112-155
 void print_findings(const std::vector<Mission>& missions, const Result& r, int n_inputs, int radix, bool no_metadata,

@@ -570,43 +570,44 @@ void merge_sorted_device_runs(const DevRun* v, size_t n, uint64_t min_chars, std
     }
 }
 
-void merge_findings(std::vector<MissionFindings>& per, Result* out) {
-    out->findings.clear();
-    out->arena.clear();
+void merge_findings(std::vector<MissionFindings>& per, const std::shared_ptr<PinnedPool>& pool, Result* out) {
+    out->pool = pool;
     size_t nonempty = 0, which = 0;
-    for (size_t k = 0; k < per.size(); k++) if (!per[k].v.empty()) { nonempty++; which = k; }
-    if (nonempty == 0) return;
-    if (nonempty == 1) {  // nothing to interleave
-        out->findings = std::move(per[which].v);
-        out->arena = std::move(per[which].arena);
+    for (size_t k = 0; k < per.size(); k++) if (per[k].count()) { nonempty++; which = k; }
+    auto release = [&](MissionFindings& mf) { if (mf.ext.p && pool) pool->give(mf.ext); mf.ext = {}; };
+    if (nonempty <= 1) {  // nothing to interleave: hand the storage over as it is
+        for (size_t k = 0; k < per.size(); k++) if (!(nonempty == 1 && k == which)) release(per[k]);
+        if (nonempty == 1) { out->m = std::move(per[which]); per[which].ext = {}; }
         return;
     }
     size_t total = 0, bytes = 0;
-    for (auto& mf : per) { total += mf.v.size(); bytes += mf.arena.size(); }
-    out->findings.reserve(total);
-    out->arena.reserve(bytes);
+    for (auto& mf : per) { total += mf.count(); bytes += mf.strings_len(); }
+    out->m.v.reserve(total);
+    out->m.arena.reserve(bytes);
     std::vector<size_t> idx(per.size(), 0), base(per.size(), 0);
-    for (size_t k = 0; k < per.size(); k++) { base[k] = out->arena.size(); out->arena += per[k].arena; }
+    for (size_t k = 0; k < per.size(); k++) { base[k] = out->m.arena.size(); out->m.arena.append(per[k].strings(), per[k].strings_len()); }
     for (;;) {
         int best = -1;
         for (size_t k = 0; k < per.size(); k++) {
-            if (idx[k] >= per[k].v.size()) continue;
+            if (idx[k] >= per[k].count()) continue;
             if (best < 0) { best = (int)k; continue; }
-            const sx_finding& a = per[k].v[idx[k]];
-            const sx_finding& b = per[best].v[idx[best]];
+            const sx_finding& a = per[k].data()[idx[k]];
+            const sx_finding& b = per[best].data()[idx[best]];
             if (a.slice_index < b.slice_index || (a.slice_index == b.slice_index && a.position < b.position)) best = (int)k;
         }
         if (best < 0) break;
-        sx_finding f = per[best].v[idx[best]++];
+        sx_finding f = per[best].data()[idx[best]++];
         f.str_off += (uint32_t)base[best];
-        out->findings.push_back(f);
+        out->m.v.push_back(f);
     }
+    for (auto& mf : per) release(mf);
 }
 
 void print_findings(const std::vector<Mission>& missions, const Result& r, int n_inputs, int radix, bool no_metadata,
                     std::string* out) {
     char num[40];
-    for (const sx_finding& f : r.findings) {
+    for (size_t fi = 0; fi < r.count(); fi++) {
+        const sx_finding& f = r.data()[fi];
         const Mission* m = nullptr;
         for (const Mission& c : missions) if (c.c.mission_id == f.mission_id) { m = &c; break; }
         out->push_back('\n');  // src/finding.rs:113
@@ -629,7 +630,7 @@ void print_findings(const std::vector<Mission>& missions, const Result& r, int n
                 out->append(")\t");
             }
         }
-        out->append(r.arena.data() + f.str_off, f.str_len);
+        out->append(r.strings() + f.str_off, f.str_len);
     }
 }
 
