@@ -53,6 +53,20 @@ double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+// The long runs of one mission over one buffer: owned (host merge, caller-supplied) or a view
+// of the mission's pinned download buffer; `on_device` says MissionDev::d_rp[0] holds the same list.
+struct RunList {
+    std::vector<sx_run> own;
+    const sx_run* p = nullptr;
+    size_t n = 0;
+    bool on_device = false;
+    void use_own() { p = own.data(); n = own.size(); on_device = false; }
+    void assign(const sx_run* b, const sx_run* e) { own.assign(b, e); use_own(); }
+    const sx_run* data() const { return p; }
+    size_t size() const { return n; }
+    const sx_run& operator[](size_t i) const { return p[i]; }
+};
+
 struct MissionDev {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -61,6 +75,7 @@ struct MissionDev {
     uint32_t capacity = 0;
     // stage B on the device: grow-only buffers
     uint16_t* d_table = nullptr;                        // single-byte decoder table
+    sx_run* h_runs = nullptr; uint64_t h_runs_cap = 0;   // pinned: runs joined on the device
     void* d_rp[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
     uint64_t d_rp_cap[6] = { 0, 0, 0, 0, 0, 0 };
 };
@@ -85,7 +100,7 @@ struct sx_ctx {
     uint64_t d_input_cap = 0;
     uint64_t ondemand_fetches = 0;
     // grow-only scratch reused by every call (pinned host memory: D2H at full PCIe rate)
-    std::vector<std::vector<sx_run>> shard_runs;  // device runs of the last sx_scan_shard* buffer (reuse_runs)
+    std::vector<RunList> shard_runs;  // device runs of the last sx_scan_shard* buffer (reuse_runs)
     bool shard_runs_valid = false;
     uint8_t* h_pin = nullptr;   uint64_t h_pin_cap = 0;
     uint8_t* h_pin2 = nullptr;  uint64_t h_pin2_cap = 0;   // device replay traffic (h_pin may back a live byte view)
@@ -182,10 +197,20 @@ int ensure_capacity(sx_ctx* ctx, MissionDev& d, uint32_t cap) {
 
 // Stage A for a set of missions: launch every mission's kernel on its own stream, then
 // collect, growing a record buffer and re-running that mission if it overflowed.
+int ensure_rp(sx_ctx* ctx, MissionDev& d, int slot, uint64_t bytes) {
+    if (d.d_rp_cap[slot] >= bytes) return SX_OK;
+    if (d.d_rp[slot]) HIP_TRY(ctx, hipFree(d.d_rp[slot]));
+    d.d_rp[slot] = nullptr; d.d_rp_cap[slot] = 0;
+    bytes += bytes / 4 + 4096;
+    HIP_TRY(ctx, hipMalloc(&d.d_rp[slot], bytes));
+    d.d_rp_cap[slot] = bytes;
+    return SX_OK;
+}
+
 int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
                 const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars,
-                std::vector<std::vector<sx_run>>* out) {
-    out->assign(which.size(), {});
+                std::vector<RunList>* out) {
+    out->assign(which.size(), RunList{});
     if (len == 0) return SX_OK;
     uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 256u * 1024u;
     sub = std::max<uint32_t>(kTileBytes, sub / kTileBytes * kTileBytes);
@@ -235,36 +260,54 @@ int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_byt
                 continue;
             }
             const double tc0 = now_ms();
-            {
-                int rc = ensure_pinned(ctx, (uint64_t)counters[0] * sizeof(DevRun) + 16);
-                if (rc != SX_OK) return rc;
-            }
-            DevRun* recs_p = (DevRun*)ctx->h_pin;
-            const bool dev_sorted = counters[0] >= 65536;  // worth three small kernels
+            const uint32_t nrec = counters[0];
+            const uint32_t join_min = getenv("SX_DEVICE_JOIN_MIN") ? (uint32_t)atoi(getenv("SX_DEVICE_JOIN_MIN")) : 65536u;
+            const bool dev_sorted = nrec >= join_min && nrec > 0;  // worth a handful of small kernels
+            double tc1 = tc0;
+            RunList& rl = (*out)[k];
             if (dev_sorted) {
-                const size_t sb = sort_scratch_bytes(counters[0]);
-                int rc = ensure_scratch(ctx, sb);
-                if (rc != SX_OK) return rc;
-                HIP_TRY(ctx, sort_records(d.d_recs, counters[0], ctx->d_scratch, ctx->d_scratch_cap, d.stream));
-                HIP_TRY(ctx, hipMemcpyAsync(recs_p, d.d_recs, (size_t)counters[0] * sizeof(DevRun), hipMemcpyDeviceToHost, d.stream));
+                // sort the records and join them into runs on the device; only the runs travel
+                const size_t sb = std::max(sort_scratch_bytes(nrec), merge_scratch_bytes(nrec));
+                int rc = ensure_scratch(ctx, sb); if (rc != SX_OK) return rc;
+                rc = ensure_rp(ctx, d, 0, (uint64_t)nrec * sizeof(sx_run)); if (rc != SX_OK) return rc;
+                HIP_TRY(ctx, sort_records(d.d_recs, nrec, ctx->d_scratch, ctx->d_scratch_cap, d.stream));
+                HIP_TRY(ctx, merge_sorted_records(d.d_recs, nrec, min_chars[k], ctx->d_scratch, ctx->d_scratch_cap,
+                                                  (sx_run*)d.d_rp[0], d.d_counters + 2, d.stream));
+                uint32_t nruns = 0;
+                HIP_TRY(ctx, hipMemcpyAsync(&nruns, d.d_counters + 2, 4, hipMemcpyDeviceToHost, d.stream));
                 HIP_TRY(ctx, hipStreamSynchronize(d.stream));
-            } else if (counters[0])
-                HIP_TRY(ctx, hipMemcpy(recs_p, d.d_recs, (size_t)counters[0] * sizeof(DevRun), hipMemcpyDeviceToHost));
-            const double tc1 = now_ms();
-            if (getenv("SX_DEBUG_RECS")) {
-                std::vector<DevRun> srt(recs_p, recs_p + counters[0]);
-                std::sort(srt.begin(), srt.end(), [](const DevRun& a, const DevRun& b) { return a.start < b.start; });
-                for (const DevRun& r : srt)
-                    fprintf(stderr, "[sx] rec start=%llu len=%u chars=%u flags=%s%s\n", (unsigned long long)r.start, r.len,
-                            r.chars_flags & kRecCharsMask, (r.chars_flags & kRecStartOpen) ? "S" : "-",
-                            (r.chars_flags & kRecEndOpen) ? "E" : "-");
-                fprintf(stderr, "[sx] slow tiles %u\n", counters[1]);
+                tc1 = now_ms();
+                if ((uint64_t)nruns * sizeof(sx_run) > d.h_runs_cap) {
+                    if (d.h_runs) HIP_TRY(ctx, hipHostFree(d.h_runs));
+                    d.h_runs = nullptr; d.h_runs_cap = 0;
+                    const uint64_t cap = (uint64_t)nruns * sizeof(sx_run) * 5 / 4 + 4096;
+                    HIP_TRY(ctx, hipHostMalloc((void**)&d.h_runs, cap, hipHostMallocNonCoherent));
+                    d.h_runs_cap = cap;
+                }
+                if (nruns) HIP_TRY(ctx, hipMemcpy(d.h_runs, d.d_rp[0], (size_t)nruns * sizeof(sx_run), hipMemcpyDeviceToHost));
+                rl.p = d.h_runs; rl.n = nruns; rl.on_device = true;
+            } else {
+                int rc = ensure_pinned(ctx, (uint64_t)nrec * sizeof(DevRun) + 16);
+                if (rc != SX_OK) return rc;
+                DevRun* recs_p = (DevRun*)ctx->h_pin;
+                if (nrec) HIP_TRY(ctx, hipMemcpy(recs_p, d.d_recs, (size_t)nrec * sizeof(DevRun), hipMemcpyDeviceToHost));
+                tc1 = now_ms();
+                if (getenv("SX_DEBUG_RECS")) {
+                    std::vector<DevRun> srt(recs_p, recs_p + nrec);
+                    std::sort(srt.begin(), srt.end(), [](const DevRun& a, const DevRun& b) { return a.start < b.start; });
+                    for (const DevRun& r : srt)
+                        fprintf(stderr, "[sx] rec start=%llu len=%u chars=%u flags=%s%s\n", (unsigned long long)r.start, r.len,
+                                r.chars_flags & kRecCharsMask, (r.chars_flags & kRecStartOpen) ? "S" : "-",
+                                (r.chars_flags & kRecEndOpen) ? "E" : "-");
+                    fprintf(stderr, "[sx] slow tiles %u\n", counters[1]);
+                }
+                merge_device_runs(recs_p, nrec, min_chars[k], 64 * 1024, &rl.own);
+                rl.use_own();
             }
-            if (dev_sorted) merge_sorted_device_runs(recs_p, counters[0], min_chars[k], &(*out)[k]);
-            else merge_device_runs(recs_p, counters[0], min_chars[k], 64 * 1024, &(*out)[k]);
             if (getenv("SX_TIMING"))
-                fprintf(stderr, "[sx] mission %d: %u record slots, d2h %.2f ms, merge/sort %.2f ms -> %zu runs\n", which[k],
-                        counters[0], tc1 - tc0, now_ms() - tc1, (*out)[k].size());
+                fprintf(stderr, "[sx] mission %d: %u record slots, %s %.2f ms, %s %.2f ms -> %zu runs\n", which[k], nrec,
+                        dev_sorted ? "device sort+join" : "d2h", tc1 - tc0, dev_sorted ? "d2h runs" : "host join", now_ms() - tc1,
+                        rl.size());
             ctx->stats.run_records += (*out)[k].size();
             ctx->stats.bytes_scanned += len;
             ctx->stats.heavy_tiles += counters[1];
@@ -318,15 +361,6 @@ struct ReplayJob {
 };
 
 
-int ensure_rp(sx_ctx* ctx, MissionDev& d, int slot, uint64_t bytes) {
-    if (d.d_rp_cap[slot] >= bytes) return SX_OK;
-    if (d.d_rp[slot]) HIP_TRY(ctx, hipFree(d.d_rp[slot]));
-    d.d_rp[slot] = nullptr; d.d_rp_cap[slot] = 0;
-    bytes += bytes / 4 + 4096;
-    HIP_TRY(ctx, hipMalloc(&d.d_rp[slot], bytes));
-    d.d_rp_cap[slot] = bytes;
-    return SX_OK;
-}
 
 static inline uint64_t win_start_h(uint64_t p, size_t W) {
     const uint64_t s0 = p / kInputBufLen * kInputBufLen;
@@ -343,7 +377,7 @@ bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, siz
 
 // Stage B of one mission on the device (sx_replay_dev.hip) + the little the host keeps:
 // the chunk's strict entry region, regions the device gave back, the exact exit state.
-int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, const std::vector<sx_run>& runs,
+int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, const RunList& runs,
                           MissionFindings* out, uint64_t* end_pos) {
     const Mission& m = ctx->missions[k];
     MissionDev& d = ctx->dev[k];
@@ -361,7 +395,8 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     if (n) {
         int rc = ensure_rp(ctx, d, 0, n * sizeof(sx_run)); if (rc) return rc;
         rc = ensure_rp(ctx, d, 1, n * sizeof(ReplayRegionOut)); if (rc) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[0], runs.data(), n * sizeof(sx_run), hipMemcpyHostToDevice, d.stream));
+        if (!runs.on_device)
+            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[0], runs.data(), n * sizeof(sx_run), hipMemcpyHostToDevice, d.stream));
         P.data = job.d_bytes; P.len = job.len; P.runs = (const sx_run*)d.d_rp[0]; P.n_runs = n;
         P.lo = job.lo[k]; P.hi = job.hi; P.consumed0 = job.consumed0[k]; P.stream0 = job.stream0[k];
         P.slice_base = job.slice_base; P.encoding = m.c.encoding; P.table = d.d_table;
@@ -495,7 +530,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
 // Stage B for all missions: every (mission, part) pair is one task for a small thread pool;
 // part 0 of a mission starts from its entry state, the others speculate, and the per-mission
 // stitch verifies/repairs them serially.
-int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::vector<std::vector<sx_run>>& runs,
+int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::vector<RunList>& runs,
                sx_result** out, uint64_t* end_pos) {
     const double t0 = now_ms();
     const size_t nm = ctx->missions.size();
@@ -651,6 +686,7 @@ void sx_destroy(sx_ctx* ctx) {
             if (d.d_counters) (void)hipFree(d.d_counters);
             if (d.d_table) (void)hipFree(d.d_table);
             for (void* q : d.d_rp) if (q) (void)hipFree(q);
+            if (d.h_runs) (void)hipHostFree(d.h_runs);
             if (d.ev0) (void)hipEventDestroy(d.ev0);
             if (d.ev1) (void)hipEventDestroy(d.ev1);
             if (d.stream) (void)hipStreamDestroy(d.stream);
@@ -674,7 +710,7 @@ int sx_reset(sx_ctx* ctx) {
 
 // Device-resident input: download only the byte ranges the replay will look at.
 static int download_for_replay(sx_ctx* ctx, const uint8_t* d_bytes, uint64_t len,
-                               const std::vector<std::vector<sx_run>>& runs, SparseDeviceBytes* view,
+                               const std::vector<RunList>& runs, SparseDeviceBytes* view,
                                const ReplayJob& job) {
     const size_t nm = ctx->missions.size();
         const double t0 = now_ms();
@@ -748,7 +784,7 @@ static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_
         parity[k] = (uint32_t)(ctx->states[k].stream_bytes & 1);
         minc[k] = ctx->missions[k].long_run;
     }
-    std::vector<std::vector<sx_run>> runs;
+    std::vector<RunList> runs;
     int rc = device_runs(ctx, which, d_bytes, len, parity, minc, &runs);
     if (rc != SX_OK) return rc;
 
@@ -807,7 +843,8 @@ int sx_device_runs(sx_ctx* ctx, int mission_index, const void* device_bytes, uin
     if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
     if ((uintptr_t)device_bytes & 15) { ctx->err = "device_bytes must be 16-byte aligned"; return SX_E_INVALID; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    std::vector<std::vector<sx_run>> out;
+    std::vector<RunList> out;
+    ctx->shard_runs_valid = false;  // the mission's device-side run list is about to be replaced
     int rc = device_runs(ctx, { mission_index }, (const uint8_t*)device_bytes, len, { (uint32_t)(stream_parity & 1) },
                          { min_chars }, &out);
     if (rc != SX_OK) return rc;
@@ -822,7 +859,7 @@ int sx_replay_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_fi
                    const sx_run* const* runs, const uint64_t* n_runs, sx_result** out) {
     if (!ctx || !out || (!bytes && len) || !runs || !n_runs) return SX_E_INVALID;
     begin_call(ctx);
-    std::vector<std::vector<sx_run>> r(ctx->missions.size());
+    std::vector<RunList> r(ctx->missions.size());
     for (size_t k = 0; k < r.size(); k++) r[k].assign(runs[k], runs[k] + n_runs[k]);
     HostBytes view(bytes ? bytes : (const uint8_t*)"");
     return replay_all(ctx, view, whole_chunk_job(ctx, len, input_file_id, is_last_input_buffer != 0), r, out, nullptr);
@@ -838,7 +875,7 @@ static int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d
     const size_t nm = ctx->missions.size();
     const double t_begin = now_ms();
     if (given_runs) {
-        ctx->shard_runs.assign(nm, {});
+        ctx->shard_runs.assign(nm, RunList{});
         for (size_t k = 0; k < nm; k++) ctx->shard_runs[k].assign(given_runs[k], given_runs[k] + given_n[k]);
     } else if (!(reuse_runs && ctx->shard_runs_valid)) {
         std::vector<int> which(nm);

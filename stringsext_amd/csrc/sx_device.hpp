@@ -90,6 +90,11 @@ hipError_t launch_replay_write(const ReplayParams& P, const uint64_t* region_ind
 size_t sort_scratch_bytes(uint32_t n);
 hipError_t sort_records(DevRun* recs, uint32_t n, void* scratch, size_t scratch_bytes, hipStream_t stream);
 
+// join sorted records into runs (>= min_chars chars) on the device; out holds up to n runs
+size_t merge_scratch_bytes(uint32_t n);
+hipError_t merge_sorted_records(const DevRun* recs, uint32_t n, uint64_t min_chars, void* scratch, size_t scratch_bytes,
+                                sx_run* out, uint32_t* out_count, hipStream_t stream);
+
 hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t stream);
 hipError_t launch_fill_background(uint8_t* dst, uint64_t first_index, uint64_t len, uint64_t seed,
                                   hipStream_t stream);

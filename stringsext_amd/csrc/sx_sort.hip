@@ -4,6 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "sx_device.hpp"
 
@@ -39,13 +43,82 @@ hipError_t sort_records(DevRun* recs, uint32_t n, void* scratch, size_t scratch_
     uint64_t* v0 = k0 + n;
     uint64_t* k1 = v0 + n;
     uint64_t* v1 = k1 + n;
-    void* tmp = (void*)(v1 + n);
-    size_t tmp_bytes = scratch_bytes - (size_t)n * 32;
+    uint8_t* tmp = (uint8_t*)(((uintptr_t)(v1 + n) + 255) & ~(uintptr_t)255);  // rocPRIM wants its storage aligned
+    size_t tmp_bytes = scratch_bytes - (size_t)(tmp - (uint8_t*)scratch);
     const unsigned blocks = (n + 255) / 256;
     hipLaunchKernelGGL(split_records_kernel, dim3(blocks), dim3(256), 0, stream, recs, n, k0, v0);
     hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, (size_t)n, 0, 64, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(join_records_kernel, dim3(blocks), dim3(256), 0, stream, k1, v1, n, recs);
+    return hipGetLastError();
+}
+
+
+// ---- join the sorted records into runs on the device -------------------------------------
+// Same rule as merge_sorted_device_runs (sx_replay.cpp): a record continues its predecessor if
+// that one reaches its sub-chunk end, this one begins at a sub-chunk start, and they touch.
+// Runs with fewer than min_chars characters cannot produce a Finding and are dropped.
+struct RecIsHead {
+    const DevRun* v;
+    __device__ uint32_t operator()(uint32_t i) const {
+        const DevRun r = v[i];
+        if (r.start == ~0ull) return 0u;
+        if (i == 0 || !(r.chars_flags & kRecStartOpen)) return 1u;
+        const DevRun p = v[i - 1];
+        return ((p.chars_flags & kRecEndOpen) && p.start + p.len == r.start) ? 0u : 1u;
+    }
+};
+struct RunIsLong {
+    uint64_t min_chars;
+    __device__ bool operator()(const sx_run& r) const { return r.chars >= min_chars; }
+};
+__global__ __launch_bounds__(256) void accumulate_runs_kernel(const DevRun* v, uint32_t n, const uint32_t* rid, sx_run* tmp) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const DevRun r = v[i];
+    if (r.start == ~0ull) return;
+    const uint32_t id = rid[i] - 1u;
+    const bool head = i == 0 || rid[i - 1] != rid[i];
+    const bool tail = i + 1 >= n || rid[i + 1] != rid[i] || v[i + 1].start == ~0ull;
+    const unsigned long long chars = r.chars_flags & kRecCharsMask, end = r.start + r.len;
+    if (head && tail) { sx_run o; o.start = r.start; o.end = end; o.chars = chars; tmp[id] = o; return; }  // the usual case
+    if (head) tmp[id].start = r.start;
+    atomicAdd((unsigned long long*)&tmp[id].chars, chars);
+    atomicMax((unsigned long long*)&tmp[id].end, end);
+}
+
+static size_t merge_tmp_bytes(uint32_t n) {
+    size_t a = 0, b = 0;
+    auto heads = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), RecIsHead{ nullptr });
+    (void)rocprim::inclusive_scan(nullptr, a, heads, (uint32_t*)nullptr, (size_t)n, rocprim::plus<uint32_t>(), (hipStream_t)0);
+    (void)rocprim::select(nullptr, b, (sx_run*)nullptr, (sx_run*)nullptr, (uint32_t*)nullptr, (size_t)n, RunIsLong{ 1 },
+                          (hipStream_t)0);
+    return (a > b ? a : b) + 256;
+}
+size_t merge_scratch_bytes(uint32_t n) {
+    return ((size_t)n * 4 + 255) / 256 * 256 + ((size_t)n * sizeof(sx_run) + 511) / 256 * 256 + merge_tmp_bytes(n);
+}
+
+// recs: sorted (sort_records); out: room for n runs; out_count: device u32
+hipError_t merge_sorted_records(const DevRun* recs, uint32_t n, uint64_t min_chars, void* scratch, size_t scratch_bytes,
+                                sx_run* out, uint32_t* out_count, hipStream_t stream) {
+    if (n == 0) return hipMemsetAsync(out_count, 0, 4, stream);
+    uint8_t* base = (uint8_t*)scratch;
+    uint32_t* rid = (uint32_t*)base;
+    const size_t rid_bytes = ((size_t)n * 4 + 255) / 256 * 256;
+    sx_run* tmp = (sx_run*)(base + rid_bytes);
+    const size_t run_bytes = ((size_t)n * sizeof(sx_run) + 511) / 256 * 256;  // rocPRIM wants its storage aligned
+    void* rp_tmp = base + rid_bytes + run_bytes;
+    size_t rp_bytes = scratch_bytes - rid_bytes - run_bytes;
+    auto heads = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), RecIsHead{ recs });
+    hipError_t e = rocprim::inclusive_scan(rp_tmp, rp_bytes, heads, rid, (size_t)n, rocprim::plus<uint32_t>(), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(tmp, 0, (size_t)n * sizeof(sx_run), stream);  // unused entries: chars 0 -> dropped below
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(accumulate_runs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, recs, n, rid, tmp);
+    rp_bytes = scratch_bytes - rid_bytes - run_bytes;
+    e = rocprim::select(rp_tmp, rp_bytes, tmp, out, out_count, (size_t)n, RunIsLong{ min_chars ? min_chars : 1 }, stream);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 

@@ -197,3 +197,20 @@ def test_large_input_properties():
         assert pos == sorted(pos) and (not pos or pos[-1] < n)
     sc.free(d)
     sc.close(); sc_b.close()
+
+
+@pytest.mark.parametrize("name", ["ascii", "utf8_common", "utf16le_african", "koi8r"])
+def test_device_join_equals_oracle_runs(name, monkeypatch):
+    """Records sorted and joined into runs on the device (rocPRIM sort/scan/select, the path large
+    buffers take) == the oracle's runs; forced here for small buffers, with tiny sub-chunks so
+    that runs are chained across many records."""
+    monkeypatch.setenv("SX_DEVICE_JOIN_MIN", "1")
+    m = rc.missions(**RUN_MISSIONS[name])[0]
+    rng = random.Random(77)
+    datas = [rng.randbytes(3 << 20), b"A" * 300_000 + rng.randbytes(5000) + b"B" * 70_000,
+             synth(rng, 500_000, 1 / 300), ("ab" * 100_000).encode("utf-16-le"), b"x"]
+    for data in datas:
+        for sub in (1024, 65536):
+            got, mc = device_runs(m, data, parity=0, subchunk=sub)
+            want = sxo.runs(m, data, stream_parity=0, min_chars=mc)
+            assert got == want, (name, len(data), sub, len(got), len(want))
