@@ -76,8 +76,8 @@ struct MissionDev {
     // stage B on the device: grow-only buffers
     uint16_t* d_table = nullptr;                        // single-byte decoder table
     sx_run* h_runs = nullptr; uint64_t h_runs_cap = 0;   // pinned: runs joined on the device
-    void* d_rp[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
-    uint64_t d_rp_cap[6] = { 0, 0, 0, 0, 0, 0 };
+    void* d_rp[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
+    uint64_t d_rp_cap[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };  // + stitch blocks, totals
 };
 
 }  // namespace
@@ -385,16 +385,28 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     const size_t W = m.window;
     const double t0 = now_ms();
 
-    // ---- pass 1 on the device: every region's extent and output size
+    // ---- pass 1 on the device: every region's extent and output size; then (still on the
+    // device) which regions stand and where each writes.  The host keeps its own version of
+    // that step for buffers with regions the device gave back (kRegionTooLong).
     ReplayParams P{};
+    bool dev_stitch = n > 0 && !getenv("SX_HOST_STITCH");
+    uint64_t* h_tot = nullptr;
+    ReplayRegionOut* ro = nullptr;
     {
-        int rc = ensure_pinned2(ctx, n * sizeof(ReplayRegionOut) + 64);
+        int rc = ensure_pinned2(ctx, n * sizeof(ReplayRegionOut) + 256);
         if (rc != SX_OK) return rc;
+        h_tot = (uint64_t*)ctx->h_pin2;
+        ro = (ReplayRegionOut*)(ctx->h_pin2 + 128);
     }
-    ReplayRegionOut* ro = (ReplayRegionOut*)ctx->h_pin2;
     if (n) {
         int rc = ensure_rp(ctx, d, 0, n * sizeof(sx_run)); if (rc) return rc;
         rc = ensure_rp(ctx, d, 1, n * sizeof(ReplayRegionOut)); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 2, n * 8); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 3, (n + 1) * 8); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 4, (n + 1) * 8); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 6, stitch_blocks_bytes(n)); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 7, kTotCount * 8); if (rc) return rc;
+        rc = ensure_scratch(ctx, stitch_scratch_bytes(n)); if (rc) return rc;
         if (!runs.on_device)
             HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[0], runs.data(), n * sizeof(sx_run), hipMemcpyHostToDevice, d.stream));
         P.data = job.d_bytes; P.len = job.len; P.runs = (const sx_run*)d.d_rp[0]; P.n_runs = n;
@@ -404,7 +416,12 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         P.W = (uint32_t)W; P.long_run = m.long_run; P.grep_char = m.c.grep_char; P.mission_id = m.c.mission_id;
         P.file_id = job.file_id; P.af_lo = m.c.af_lo; P.af_hi = m.c.af_hi; P.ubf = m.c.ubf;
         HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], d.stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ro, d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream));
+        if (dev_stitch) {
+            HIP_TRY(ctx, hipMemsetAsync(d.d_rp[7], 0, kTotCount * 8, d.stream));
+            HIP_TRY(ctx, launch_stitch_blocks(P, (const ReplayRegionOut*)d.d_rp[1], (uint8_t*)d.d_rp[2], d.d_rp[6],
+                                              (uint64_t*)d.d_rp[7], d.stream));
+        } else
+            HIP_TRY(ctx, hipMemcpyAsync(ro, d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream));
     }
 
     // ---- meanwhile on the host: the strict entry region (exact carried state), if any
@@ -424,55 +441,79 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         else { segs.push_back({ (int)host_parts.size() - 1, 0, 0 }); last_is_entry = true; E = std::max(E, host_parts.back().end_pos); }
         E = std::max(E, job.lo[k] + 1);
     }
+    if (dev_stitch) {
+        HIP_TRY(ctx, launch_stitch_finish(P, (const ReplayRegionOut*)d.d_rp[1], (uint8_t*)d.d_rp[2], d.d_rp[6], E,
+                                          (uint64_t*)d.d_rp[3], (uint64_t*)d.d_rp[4], (uint64_t*)d.d_rp[7], ctx->d_scratch,
+                                          ctx->d_scratch_cap, d.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(h_tot, d.d_rp[7], kTotCount * 8, hipMemcpyDeviceToHost, d.stream));
+    }
     if (n) HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    if (dev_stitch && h_tot[kTotTooLong]) {  // regions for the host: it also decides what stands
+        dev_stitch = false;
+        HIP_TRY(ctx, hipMemcpyAsync(ro, d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    }
     const double t1 = now_ms();
 
-    // ---- which regions stand: a region is void if an earlier one ran over its start
     std::vector<uint64_t> valid, fbase, abase;
-    valid.reserve(n); fbase.reserve(n + 1); abase.reserve(n + 1);
-    uint64_t nf = 0, nb = 0;
-    for (size_t i = 0; i < n; i++) {
-        const uint32_t st = ro[i].status;
-        if (st == kRegionChained || st == kRegionNotMine) continue;
-        const uint64_t want = win_start_h(runs[i].start, W);
-        if (want >= job.hi) break;
-        if (want < E) continue;
-        if (st == kRegionTooLong) {  // given back: the host replays it (and whatever it runs into)
-            host_parts.emplace_back();
-            replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(),
-                        n, want, want + 1, false, &host_parts.back());
-            segs.push_back({ (int)host_parts.size() - 1, 0, 0 });
-            E = std::max(E, host_parts.back().end_pos);
-        } else {
-            if (segs.empty() || segs.back().host_part >= 0) segs.push_back({ -1, valid.size(), valid.size() });
-            valid.push_back(i); fbase.push_back(nf); abase.push_back(nb);
-            segs.back().v1 = valid.size();
-            nf += ro[i].n_find; nb += ro[i].n_bytes;
-            E = std::max(E, ro[i].end);
+    uint64_t nf = 0, nb = 0, n_standing = 0;
+    if (dev_stitch) {
+        nf = h_tot[kTotFindings]; nb = h_tot[kTotBytes]; n_standing = h_tot[kTotStanding];
+        out->replay_bytes += h_tot[kTotReplayBytes];
+        if (h_tot[kTotLast] != ~0ull) {
+            E = std::max(E, h_tot[kTotEnd]);
+            last_start = win_start_h(runs[(size_t)h_tot[kTotLast]].start, W);
+            last_is_entry = false;
         }
-        last_start = want; last_is_entry = false;
+    } else {
+        // ---- which regions stand: a region is void if an earlier one ran over its start
+        valid.reserve(n); fbase.reserve(n + 1); abase.reserve(n + 1);
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t st = ro[i].status;
+            if (st == kRegionChained || st == kRegionNotMine) continue;
+            const uint64_t want = win_start_h(runs[i].start, W);
+            if (want >= job.hi) break;
+            if (want < E) continue;
+            if (st == kRegionTooLong) {  // given back: the host replays it (and whatever it runs into)
+                host_parts.emplace_back();
+                replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(),
+                            n, want, want + 1, false, &host_parts.back());
+                segs.push_back({ (int)host_parts.size() - 1, 0, 0 });
+                E = std::max(E, host_parts.back().end_pos);
+            } else {
+                if (segs.empty() || segs.back().host_part >= 0) segs.push_back({ -1, valid.size(), valid.size() });
+                valid.push_back(i); fbase.push_back(nf); abase.push_back(nb);
+                segs.back().v1 = valid.size();
+                nf += ro[i].n_find; nb += ro[i].n_bytes;
+                E = std::max(E, ro[i].end);
+            }
+            last_start = want; last_is_entry = false;
+        }
+        fbase.push_back(nf); abase.push_back(nb);
+        n_standing = valid.size();
+        for (uint64_t v : valid) out->replay_bytes += ro[v].end - win_start_h(runs[v].start, W);
     }
-    fbase.push_back(nf); abase.push_back(nb);
     if (nb > 0xFFFFFFFFull) { ctx->err = "more than 4 GiB of strings in one chunk"; return SX_E_NOMEM; }
     const double t2 = now_ms();
 
     // ---- pass 2: the standing regions write findings and strings, in order; the D2H lands in a
     // pinned block that becomes the result's storage (no copy) unless host parts must be spliced in
     PinnedPool::Block blk{};
-    if (!valid.empty()) {
-        const size_t nv = valid.size();
-        int rc = ensure_rp(ctx, d, 2, nv * 8); if (rc) return rc;
-        rc = ensure_rp(ctx, d, 3, (nv + 1) * 8); if (rc) return rc;
-        rc = ensure_rp(ctx, d, 4, (nv + 1) * 8); if (rc) return rc;
-        rc = ensure_rp(ctx, d, 5, nf * sizeof(sx_finding) + nb + 64); if (rc) return rc;
+    if (n_standing) {
+        int rc = ensure_rp(ctx, d, 5, nf * sizeof(sx_finding) + nb + 64); if (rc) return rc;
         sx_finding* d_f = (sx_finding*)d.d_rp[5];
         uint8_t* d_a = (uint8_t*)d.d_rp[5] + nf * sizeof(sx_finding);
-        for (uint64_t v : valid) out->replay_bytes += ro[v].end - win_start_h(runs[v].start, W);
-        HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[2], valid.data(), nv * 8, hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[3], fbase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[4], abase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(ctx, launch_replay_write(P, (const uint64_t*)d.d_rp[2], (const uint64_t*)d.d_rp[3], (const uint64_t*)d.d_rp[4],
-                                         nv, d_f, d_a, d.stream));
+        if (dev_stitch) {
+            HIP_TRY(ctx, launch_replay_write_flagged(P, (const uint8_t*)d.d_rp[2], (const uint64_t*)d.d_rp[3],
+                                                     (const uint64_t*)d.d_rp[4], d_f, d_a, d.stream));
+        } else {
+            const size_t nv = valid.size();
+            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[2], valid.data(), nv * 8, hipMemcpyHostToDevice, d.stream));
+            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[3], fbase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream));
+            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[4], abase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream));
+            HIP_TRY(ctx, launch_replay_write(P, (const uint64_t*)d.d_rp[2], (const uint64_t*)d.d_rp[3],
+                                             (const uint64_t*)d.d_rp[4], nv, d_f, d_a, d.stream));
+        }
         blk = ctx->pool->take(nf * sizeof(sx_finding) + nb + 64);
         if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
         HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_f, nf * sizeof(sx_finding) + nb, hipMemcpyDeviceToHost, d.stream));
@@ -486,6 +527,10 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     } else {
         const sx_finding* dev_f = (const sx_finding*)blk.p;
         const char* dev_a = blk.p ? (const char*)blk.p + nf * sizeof(sx_finding) : nullptr;
+        if (dev_stitch) {  // only the entry part can be here; everything the device wrote follows it
+            fbase.assign({ 0, nf }); abase.assign({ 0, nb });
+            if (n_standing) segs.push_back({ -1, 0, 1 });
+        }
         for (const Seg& g : segs) {
             if (g.host_part >= 0) {
                 const MissionFindings& hf = host_parts[(size_t)g.host_part].findings;
@@ -522,7 +567,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     if (end_pos) *end_pos = std::max(E, std::min(job.hi, job.len));
     if (getenv("SX_TIMING"))
         fprintf(stderr, "[sx] device replay mission %zu: %zu runs, pass1+entry %.2f ms, validity %.2f ms (%zu standing, %zu host parts), "
-                        "pass2+d2h %.2f ms (%llu findings), splice+state %.2f ms\n", k, n, t1 - t0, t2 - t1, valid.size(),
+                        "pass2+d2h %.2f ms (%llu findings), splice+state %.2f ms\n", k, n, t1 - t0, t2 - t1, (size_t)n_standing,
                 host_parts.size(), t3 - t2, (unsigned long long)nf, now_ms() - t3);
     return SX_OK;
 }

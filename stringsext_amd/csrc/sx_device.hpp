@@ -86,6 +86,19 @@ hipError_t launch_replay_write(const ReplayParams& P, const uint64_t* region_ind
                                const uint64_t* abase, uint64_t n_regions, sx_finding* findings, uint8_t* arena,
                                hipStream_t stream);
 
+// "which regions stand" + output offsets on the device (sx_replay_dev.hip)
+constexpr uint32_t kStitchBlock = 128;     // runs resolved per lane in the first stage
+enum : uint32_t { kTotEnd = 0, kTotLast, kTotFindings, kTotBytes, kTotStanding, kTotReplayBytes, kTotTooLong, kTotCount };
+size_t stitch_scratch_bytes(uint64_t n_runs);
+size_t stitch_blocks_bytes(uint64_t n_runs);
+hipError_t launch_stitch_blocks(const ReplayParams& P, const ReplayRegionOut* ro, uint8_t* stands, void* blocks,
+                                uint64_t* totals, hipStream_t stream);
+hipError_t launch_stitch_finish(const ReplayParams& P, const ReplayRegionOut* ro, uint8_t* stands, const void* blocks,
+                                uint64_t E0, uint64_t* fpos, uint64_t* apos, uint64_t* totals, void* scratch,
+                                size_t scratch_bytes, hipStream_t stream);
+hipError_t launch_replay_write_flagged(const ReplayParams& P, const uint8_t* stands, const uint64_t* fpos, const uint64_t* apos,
+                                       sx_finding* findings, uint8_t* arena, hipStream_t stream);
+
 // order run records by start on the device (sx_sort.hip); unused slots end up last with start = ~0
 size_t sort_scratch_bytes(uint32_t n);
 hipError_t sort_records(DevRun* recs, uint32_t n, void* scratch, size_t scratch_bytes, hipStream_t stream);

@@ -17,6 +17,10 @@
 // reported with a status and replayed by the host.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "sx_device.hpp"
 
@@ -48,6 +52,146 @@ __global__ __launch_bounds__(64) void replay_write_kernel(const ReplayParams P, 
     if (k >= n_regions) return;
     ReplayRegionOut o;
     replay_region<true>(P, region_index[k], o, findings + fbase[k], arena + abase[k], abase[k]);
+}
+
+// Pass 2, flagged form: one lane per run; the standing regions (stitch below) write at the
+// offsets the device scans assigned.
+__global__ __launch_bounds__(64) void replay_write_flagged_kernel(const ReplayParams P, const u8* stands, const u64* fpos,
+                                                                  const u64* apos, sx_finding* findings, u8* arena) {
+    const u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
+    if (i >= P.n_runs || !stands[i]) return;
+    ReplayRegionOut o;
+    replay_region<true>(P, i, o, findings + fpos[i], arena + apos[i], apos[i]);
+}
+
+// ---- which regions stand, on the device ---------------------------------------------------
+// The rule is sequential (a region is void if an earlier standing one ran over its start:
+// E = end of the last standing region; region i stands iff want_i >= E), but regions rarely
+// reach their successor, so: every block of kStitchBlock runs is resolved on its own as if
+// nothing reached into it (its first candidate stands); then one wavefront walks the block
+// summaries in order and repairs the few blocks whose entry was overrun, following the true
+// chain only until it meets the block's own chain again.
+struct StitchBlock { u64 first_want, end; u64 last; };  // first candidate's window, E after the block, last standing run
+
+__global__ __launch_bounds__(64) void stitch_blocks_kernel(const ReplayParams P, const ReplayRegionOut* ro, u8* stands,
+                                                           StitchBlock* blocks, u64 n_blocks, u64* totals) {
+    const u64 b = (u64)blockIdx.x * 64 + threadIdx.x;
+    if (b >= n_blocks) return;
+    const u64 i0 = b * kStitchBlock, i1 = i0 + kStitchBlock < P.n_runs ? i0 + kStitchBlock : P.n_runs;
+    StitchBlock sb; sb.first_want = ~0ull; sb.end = 0; sb.last = ~0ull;
+    u32 too_long = 0;
+    for (u64 i = i0; i < i1; i++) {
+        const u32 st = ro[i].status;
+        u8 f = 0;
+        if (st == kRegionTooLong) too_long++;
+        if (st == kRegionOk) {
+            const u64 w = win_start(P.runs[i].start, P.W);
+            if (sb.first_want == ~0ull) sb.first_want = w;
+            if (w >= sb.end) { f = 1; sb.end = ro[i].end; sb.last = i; }
+        }
+        stands[i] = f;
+    }
+    blocks[b] = sb;
+    if (too_long) atomicAdd((unsigned long long*)&totals[kTotTooLong], (unsigned long long)too_long);
+}
+
+__global__ __launch_bounds__(64) void stitch_chain_kernel(const ReplayParams P, const ReplayRegionOut* ro, u8* stands,
+                                                          const StitchBlock* blocks, u64 n_blocks, u64 E0, u64* totals) {
+    const u32 lane = threadIdx.x;
+    u64 E = E0, last = ~0ull;
+    for (u64 base = 0; base < n_blocks; base += 64) {
+        StitchBlock mine; mine.first_want = ~0ull; mine.end = 0; mine.last = ~0ull;
+        if (base + lane < n_blocks) mine = blocks[base + lane];
+        const u32 cnt = n_blocks - base < 64 ? (u32)(n_blocks - base) : 64u;
+        for (u32 l = 0; l < cnt; l++) {
+            const u64 fw = __shfl(mine.first_want, (int)l), be = __shfl(mine.end, (int)l), bl = __shfl(mine.last, (int)l);
+            if (fw == ~0ull) continue;                 // no candidate in this block
+            if (E <= fw) { E = be; last = bl; continue; }  // nothing reached into it: its own chain stands
+            // repair (rare; every lane does the same work on the same data: stores are idempotent)
+            const u64 b = base + l, i0 = b * kStitchBlock, i1 = i0 + kStitchBlock < P.n_runs ? i0 + kStitchBlock : P.n_runs;
+            for (u64 i = i0; i < i1; i++) {
+                if (ro[i].status != kRegionOk) continue;
+                const u64 w = win_start(P.runs[i].start, P.W);
+                if (w < E) { if (lane == 0) stands[i] = 0; continue; }
+                if (stands[i]) { E = be; last = bl; break; }  // back on the block's own chain
+                // note: lanes read stands[i] before lane 0 may set it; all see the same old value per iteration
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) stands[i] = 1;
+                E = ro[i].end; last = i;
+            }
+        }
+    }
+    if (lane == 0) { totals[kTotEnd] = E; totals[kTotLast] = last; }
+}
+
+struct StandingFindings {
+    const u8* stands; const ReplayRegionOut* ro;
+    __device__ u64 operator()(u64 i) const { return stands[i] ? (u64)ro[i].n_find : 0ull; }
+};
+struct StandingBytes {
+    const u8* stands; const ReplayRegionOut* ro;
+    __device__ u64 operator()(u64 i) const { return stands[i] ? (u64)ro[i].n_bytes : 0ull; }
+};
+__global__ __launch_bounds__(256) void stitch_totals_kernel(const ReplayParams P, const ReplayRegionOut* ro, const u8* stands,
+                                                            const u64* fpos, const u64* apos, u64* totals) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    u64 cnt = 0, rb = 0;
+    if (i < P.n_runs && stands[i]) { cnt = 1; rb = ro[i].end - win_start(P.runs[i].start, P.W); }
+    for (int o = 32; o; o >>= 1) { cnt += __shfl_down(cnt, o); rb += __shfl_down(rb, o); }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicAdd((unsigned long long*)&totals[kTotStanding], (unsigned long long)cnt);
+        atomicAdd((unsigned long long*)&totals[kTotReplayBytes], (unsigned long long)rb);
+    }
+    if (i + 1 == P.n_runs) {
+        totals[kTotFindings] = fpos[i] + (stands[i] ? ro[i].n_find : 0);
+        totals[kTotBytes] = apos[i] + (stands[i] ? ro[i].n_bytes : 0);
+    }
+}
+
+size_t stitch_scratch_bytes(uint64_t n_runs) {
+    size_t a = 0;
+    auto it = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), StandingFindings{ nullptr, nullptr });
+    (void)rocprim::exclusive_scan(nullptr, a, it, (u64*)nullptr, (u64)0, (size_t)n_runs, rocprim::plus<u64>(), (hipStream_t)0);
+    return a + 512;
+}
+uint64_t stitch_block_count(uint64_t n_runs) { return (n_runs + kStitchBlock - 1) / kStitchBlock; }
+size_t stitch_blocks_bytes(uint64_t n_runs) { return stitch_block_count(n_runs) * sizeof(StitchBlock) + 64; }
+
+// stage 1 (no dependency on the entry region): the blocks' own chains.  totals must be zeroed.
+hipError_t launch_stitch_blocks(const ReplayParams& P, const ReplayRegionOut* ro, uint8_t* stands, void* blocks,
+                                uint64_t* totals, hipStream_t stream) {
+    if (P.n_runs == 0) return hipSuccess;
+    const u64 nb = stitch_block_count(P.n_runs);
+    hipLaunchKernelGGL(stitch_blocks_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, stream, P, ro, stands,
+                       (StitchBlock*)blocks, nb, totals);
+    return hipGetLastError();
+}
+// stage 2: chain the blocks from E0 (end of the host's entry region), assign output offsets, totals
+hipError_t launch_stitch_finish(const ReplayParams& P, const ReplayRegionOut* ro, uint8_t* stands, const void* blocks,
+                                uint64_t E0, uint64_t* fpos, uint64_t* apos, uint64_t* totals, void* scratch,
+                                size_t scratch_bytes, hipStream_t stream) {
+    if (P.n_runs == 0) return hipSuccess;
+    const u64 nb = stitch_block_count(P.n_runs);
+    hipLaunchKernelGGL(stitch_chain_kernel, dim3(1), dim3(64), 0, stream, P, ro, stands, (const StitchBlock*)blocks, nb, E0, totals);
+    void* tmp = (void*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    size_t tmp_bytes = scratch_bytes - (size_t)((uint8_t*)tmp - (uint8_t*)scratch);
+    auto itf = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), StandingFindings{ stands, ro });
+    hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, itf, fpos, (u64)0, (size_t)P.n_runs, rocprim::plus<u64>(), stream);
+    if (e != hipSuccess) return e;
+    tmp_bytes = scratch_bytes - (size_t)((uint8_t*)tmp - (uint8_t*)scratch);
+    auto itb = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), StandingBytes{ stands, ro });
+    e = rocprim::exclusive_scan(tmp, tmp_bytes, itb, apos, (u64)0, (size_t)P.n_runs, rocprim::plus<u64>(), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(stitch_totals_kernel, dim3((unsigned)((P.n_runs + 255) / 256)), dim3(256), 0, stream, P, ro, stands, fpos,
+                       apos, totals);
+    return hipGetLastError();
+}
+hipError_t launch_replay_write_flagged(const ReplayParams& P, const uint8_t* stands, const uint64_t* fpos, const uint64_t* apos,
+                                       sx_finding* findings, uint8_t* arena, hipStream_t stream) {
+    if (P.n_runs == 0) return hipSuccess;
+    hipLaunchKernelGGL(replay_write_flagged_kernel, dim3((unsigned)((P.n_runs + 63) / 64)), dim3(64), 0, stream, P, stands, fpos,
+                       apos, findings, arena);
+    return hipGetLastError();
 }
 
 hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, hipStream_t stream) {
