@@ -95,30 +95,56 @@ __global__ __launch_bounds__(64) void stitch_blocks_kernel(const ReplayParams P,
     if (too_long) atomicAdd((unsigned long long*)&totals[kTotTooLong], (unsigned long long)too_long);
 }
 
+SXD u64 wave_prefix_max_excl(u64 x, u32 lane) {  // max over lanes below `lane` (0 for lane 0)
+    u64 v = x;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u64 t = __shfl_up(v, o);
+        if ((int)lane >= o && t > v) v = t;
+    }
+    const u64 up = __shfl_up(v, 1);
+    return lane ? up : 0ull;
+}
+
 __global__ __launch_bounds__(64) void stitch_chain_kernel(const ReplayParams P, const ReplayRegionOut* ro, u8* stands,
                                                           const StitchBlock* blocks, u64 n_blocks, u64 E0, u64* totals) {
     const u32 lane = threadIdx.x;
-    u64 E = E0, last = ~0ull;
+    u64 E = E0, last = ~0ull;  // wave-uniform
     for (u64 base = 0; base < n_blocks; base += 64) {
         StitchBlock mine; mine.first_want = ~0ull; mine.end = 0; mine.last = ~0ull;
         if (base + lane < n_blocks) mine = blocks[base + lane];
-        const u32 cnt = n_blocks - base < 64 ? (u32)(n_blocks - base) : 64u;
-        for (u32 l = 0; l < cnt; l++) {
-            const u64 fw = __shfl(mine.first_want, (int)l), be = __shfl(mine.end, (int)l), bl = __shfl(mine.last, (int)l);
-            if (fw == ~0ull) continue;                 // no candidate in this block
-            if (E <= fw) { E = be; last = bl; continue; }  // nothing reached into it: its own chain stands
-            // repair (rare; every lane does the same work on the same data: stores are idempotent)
-            const u64 b = base + l, i0 = b * kStitchBlock, i1 = i0 + kStitchBlock < P.n_runs ? i0 + kStitchBlock : P.n_runs;
+        const bool has = mine.first_want != ~0ull;
+        u32 cur = 0;  // lanes below cur are settled
+        while (cur < 64) {
+            // As long as nothing reaches into a block, the ends of the blocks' own chains grow
+            // with the block index, so E at lane l = max(E, ends of the lanes in [cur, l)).
+            const u64 contrib = (has && lane >= cur) ? mine.end : 0ull;
+            u64 e_in = wave_prefix_max_excl(contrib, lane);
+            if (e_in < E) e_in = E;
+            const bool bad = has && lane >= cur && e_in > mine.first_want;
+            const unsigned long long badmask = __ballot(bad);
+            const u32 v = badmask ? (u32)__ffsll((long long)badmask) - 1u : 64u;  // first overrun block
+            // settle lanes [cur, v): their own chains stand
+            const unsigned long long okmask = __ballot(has && lane >= cur && lane < v);
+            if (okmask) {
+                const int top = 63 - __clzll((long long)okmask);
+                E = __shfl(mine.end, top);
+                last = __shfl(mine.last, top);
+            }
+            if (v >= 64) break;
+            // repair block v: follow the true chain until it meets the block's own chain again
+            // (every lane does the same work on the same data; lane 0 stores)
+            const u64 be = __shfl(mine.end, (int)v), bl = __shfl(mine.last, (int)v);
+            const u64 b = base + v, i0 = b * kStitchBlock, i1 = i0 + kStitchBlock < P.n_runs ? i0 + kStitchBlock : P.n_runs;
             for (u64 i = i0; i < i1; i++) {
                 if (ro[i].status != kRegionOk) continue;
                 const u64 w = win_start(P.runs[i].start, P.W);
-                if (w < E) { if (lane == 0) stands[i] = 0; continue; }
-                if (stands[i]) { E = be; last = bl; break; }  // back on the block's own chain
-                // note: lanes read stands[i] before lane 0 may set it; all see the same old value per iteration
-                __builtin_amdgcn_wave_barrier();
+                const u8 was = stands[i];
+                if (w < E) { if (lane == 0 && was) stands[i] = 0; continue; }
+                if (was) { E = be; last = bl; break; }
                 if (lane == 0) stands[i] = 1;
                 E = ro[i].end; last = i;
             }
+            cur = v + 1;
         }
     }
     if (lane == 0) { totals[kTotEnd] = E; totals[kTotLast] = last; }
@@ -132,15 +158,22 @@ struct StandingBytes {
     const u8* stands; const ReplayRegionOut* ro;
     __device__ u64 operator()(u64 i) const { return stands[i] ? (u64)ro[i].n_bytes : 0ull; }
 };
-__global__ __launch_bounds__(256) void stitch_totals_kernel(const ReplayParams P, const ReplayRegionOut* ro, const u8* stands,
-                                                            const u64* fpos, const u64* apos, u64* totals) {
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(1024) void stitch_totals_kernel(const ReplayParams P, const ReplayRegionOut* ro, const u8* stands,
+                                                             const u64* fpos, const u64* apos, u64* totals) {
+    __shared__ u64 s_cnt[16], s_rb[16];
+    const u64 i = (u64)blockIdx.x * 1024 + threadIdx.x;
     u64 cnt = 0, rb = 0;
     if (i < P.n_runs && stands[i]) { cnt = 1; rb = ro[i].end - win_start(P.runs[i].start, P.W); }
     for (int o = 32; o; o >>= 1) { cnt += __shfl_down(cnt, o); rb += __shfl_down(rb, o); }
-    if ((threadIdx.x & 63) == 0 && cnt) {
-        atomicAdd((unsigned long long*)&totals[kTotStanding], (unsigned long long)cnt);
-        atomicAdd((unsigned long long*)&totals[kTotReplayBytes], (unsigned long long)rb);
+    if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6] = cnt; s_rb[threadIdx.x >> 6] = rb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 c = 0, r = 0;
+        for (int w = 0; w < 16; w++) { c += s_cnt[w]; r += s_rb[w]; }
+        if (c) {
+            atomicAdd((unsigned long long*)&totals[kTotStanding], (unsigned long long)c);
+            atomicAdd((unsigned long long*)&totals[kTotReplayBytes], (unsigned long long)r);
+        }
     }
     if (i + 1 == P.n_runs) {
         totals[kTotFindings] = fpos[i] + (stands[i] ? ro[i].n_find : 0);
@@ -182,7 +215,7 @@ hipError_t launch_stitch_finish(const ReplayParams& P, const ReplayRegionOut* ro
     auto itb = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), StandingBytes{ stands, ro });
     e = rocprim::exclusive_scan(tmp, tmp_bytes, itb, apos, (u64)0, (size_t)P.n_runs, rocprim::plus<u64>(), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(stitch_totals_kernel, dim3((unsigned)((P.n_runs + 255) / 256)), dim3(256), 0, stream, P, ro, stands, fpos,
+    hipLaunchKernelGGL(stitch_totals_kernel, dim3((unsigned)((P.n_runs + 1023) / 1024)), dim3(1024), 0, stream, P, ro, stands, fpos,
                        apos, totals);
     return hipGetLastError();
 }

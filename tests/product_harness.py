@@ -15,12 +15,12 @@ def oracle_runs_for_chunk(mdicts, chunk, stream_bytes):
 
 
 def run_cli_product(mdicts, files, radix=None, no_metadata=False, chunk_bytes=None, device=None,
-                    generic_kernels=False, subchunk_bytes=0, flush_at_eof=False, record_capacity=0):
+                    generic_kernels=False, subchunk_bytes=0, flush_at_eof=False, record_capacity=0, device_replay=None):
     """Whole CLI pass.  device=None: host-only context, runs supplied by the oracle (tests the
     replay stage on CPU).  device=int: the real thing (HIP kernels + replay)."""
     host_only = device is None
     sc = sx.Scanner(mdicts, device=sx.SX_HOST_ONLY if host_only else device, generic_kernels=generic_kernels,
-                    subchunk_bytes=subchunk_bytes, record_capacity=record_capacity)
+                    subchunk_bytes=subchunk_bytes, record_capacity=record_capacity, device_replay=device_replay)
     out = bytearray(sx.OUTPUT_BOM)
     stream = 0
     try:

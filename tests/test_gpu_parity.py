@@ -214,3 +214,32 @@ def test_device_join_equals_oracle_runs(name, monkeypatch):
             got, mc = device_runs(m, data, parity=0, subchunk=sub)
             want = sxo.runs(m, data, stream_parity=0, min_chars=mc)
             assert got == want, (name, len(data), sub, len(got), len(want))
+
+
+def dense(rng, n, max_gap, alphabet):
+    """Strings of 3..70 chars packed with short gaps: replay regions run into each other all the time."""
+    out = bytearray()
+    while len(out) < n:
+        k = rng.randrange(3, 70 if rng.random() < 0.9 else 400)
+        out += "".join(rng.choice(alphabet) for _ in range(k)).encode("utf-8")
+        out += bytes(rng.choice(b"\x00\x01\x7f\xff\xc0\x80") for _ in range(rng.randrange(1, max_gap)))
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("max_gap", [3, 40, 200, 1500])
+@pytest.mark.parametrize("opts", [dict(chars_min="4"), dict(chars_min="12", output_line_len="32"),
+                                  dict(chars_min="5", unicode_block_filter="Cyrillic", ascii_filter="None")],
+                         ids=["n4", "n12q32", "cyr"])
+def test_dense_strings_device_replay_and_stitch(max_gap, opts, monkeypatch):
+    """Stage B on the device (regions, which of them stand, output offsets, entry part splice)
+    == the oracle, on inputs where regions chain and overrun each other constantly."""
+    rng = random.Random(max_gap * 7 + len(opts))
+    alphabet = "abcdefghij XYZ019_-éжЖдяבשλ€"
+    data = dense(rng, 3_000_000 + rng.randrange(5000), max_gap, alphabet)
+    ms = rc.missions(encodings=["utf-8"], **opts)
+    want = sxo.run_cli(ms, [data], radix="x")
+    for chunk in (None, 1 << 20):
+        got = run_cli_product(ms, [data], radix="x", chunk_bytes=chunk, device=0, device_replay=True)
+        assert got == want, (max_gap, chunk)
+    monkeypatch.setenv("SX_HOST_STITCH", "1")
+    assert run_cli_product(ms, [data], radix="x", device=0, device_replay=True) == want
