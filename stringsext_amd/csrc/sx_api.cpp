@@ -76,8 +76,8 @@ struct MissionDev {
     // stage B on the device: grow-only buffers
     uint16_t* d_table = nullptr;                        // single-byte decoder table
     sx_run* h_runs = nullptr; uint64_t h_runs_cap = 0;   // pinned: runs joined on the device
-    void* d_rp[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
-    uint64_t d_rp_cap[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };  // + stitch blocks, totals
+    void* d_rp[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
+    uint64_t d_rp_cap[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // + stitch blocks, totals, pass-1 output cache
 };
 
 }  // namespace
@@ -392,6 +392,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     bool dev_stitch = n > 0 && !getenv("SX_HOST_STITCH");
     uint64_t* h_tot = nullptr;
     ReplayRegionOut* ro = nullptr;
+    void* cache_used = nullptr;
     {
         int rc = ensure_pinned2(ctx, n * sizeof(ReplayRegionOut) + 256);
         if (rc != SX_OK) return rc;
@@ -415,7 +416,13 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         P.chars_min_nb = m.c.chars_min_nb; P.same_block = m.c.require_same_unicode_block; P.q = (uint32_t)m.q;
         P.W = (uint32_t)W; P.long_run = m.long_run; P.grep_char = m.c.grep_char; P.mission_id = m.c.mission_id;
         P.file_id = job.file_id; P.af_lo = m.c.af_lo; P.af_hi = m.c.af_hi; P.ubf = m.c.ubf;
-        HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], d.stream));
+        void* cache = nullptr;
+        if (dev_stitch && n <= (32u << 20) && !getenv("SX_NO_REPLAY_CACHE")) {
+            rc = ensure_rp(ctx, d, 8, replay_cache_bytes(n)); if (rc) return rc;
+            cache = d.d_rp[8];
+        }
+        cache_used = cache;
+        HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], cache, d.stream));
         if (dev_stitch) {
             HIP_TRY(ctx, hipMemsetAsync(d.d_rp[7], 0, kTotCount * 8, d.stream));
             HIP_TRY(ctx, launch_stitch_blocks(P, (const ReplayRegionOut*)d.d_rp[1], (uint8_t*)d.d_rp[2], d.d_rp[6],
@@ -504,8 +511,9 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         sx_finding* d_f = (sx_finding*)d.d_rp[5];
         uint8_t* d_a = (uint8_t*)d.d_rp[5] + nf * sizeof(sx_finding);
         if (dev_stitch) {
-            HIP_TRY(ctx, launch_replay_write_flagged(P, (const uint8_t*)d.d_rp[2], (const uint64_t*)d.d_rp[3],
-                                                     (const uint64_t*)d.d_rp[4], d_f, d_a, d.stream));
+            HIP_TRY(ctx, launch_replay_write_flagged(P, (const ReplayRegionOut*)d.d_rp[1], (const uint8_t*)d.d_rp[2],
+                                                     (const uint64_t*)d.d_rp[3], (const uint64_t*)d.d_rp[4], cache_used, d_f,
+                                                     d_a, d.stream));
         } else {
             const size_t nv = valid.size();
             HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[2], valid.data(), nv * 8, hipMemcpyHostToDevice, d.stream));

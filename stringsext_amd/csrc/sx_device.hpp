@@ -79,9 +79,10 @@ struct ReplayParams {
 };
 struct ReplayRegionOut {
     uint64_t end;             // where the region's replay stopped (a window start, buffer relative)
-    uint32_t n_find, n_bytes, status, pad;
+    uint32_t n_find, n_bytes, status, pad;  // pad: 1 = pass 1 kept the whole output in the region's cache slot
 };
-hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, hipStream_t stream);
+size_t replay_cache_bytes(uint64_t n_runs);
+hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, void* cache, hipStream_t stream);
 hipError_t launch_replay_write(const ReplayParams& P, const uint64_t* region_index, const uint64_t* fbase,
                                const uint64_t* abase, uint64_t n_regions, sx_finding* findings, uint8_t* arena,
                                hipStream_t stream);
@@ -96,8 +97,9 @@ hipError_t launch_stitch_blocks(const ReplayParams& P, const ReplayRegionOut* ro
 hipError_t launch_stitch_finish(const ReplayParams& P, const ReplayRegionOut* ro, uint8_t* stands, const void* blocks,
                                 uint64_t E0, uint64_t* fpos, uint64_t* apos, uint64_t* totals, void* scratch,
                                 size_t scratch_bytes, hipStream_t stream);
-hipError_t launch_replay_write_flagged(const ReplayParams& P, const uint8_t* stands, const uint64_t* fpos, const uint64_t* apos,
-                                       sx_finding* findings, uint8_t* arena, hipStream_t stream);
+hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegionOut* ro, const uint8_t* stands,
+                                       const uint64_t* fpos, const uint64_t* apos, const void* cache, sx_finding* findings,
+                                       uint8_t* arena, hipStream_t stream);
 
 // order run records by start on the device (sx_sort.hip); unused slots end up last with start = ~0
 size_t sort_scratch_bytes(uint32_t n);

@@ -215,8 +215,11 @@ SXD u64 win_start(u64 p, u32 W) { const u64 s = p / kSliceLen * kSliceLen; retur
 
 constexpr u32 kObCap = 4 * 64 + 3 * 128 + 16;  // leftover (<= 4q bytes) + one window's output; q <= 64
 
-// One region.  WRITE=false: count only.  Returns through `o`.
-template <bool WRITE>
+// One region.  MODE 0: count only; 1: write findings and strings at fout/aout; 2: count, and
+// keep the output in the region's small cache slot (fout/aout) as long as it fits — o.pad says
+// whether it did, so that the second pass is a copy for almost every region.
+constexpr u32 kCacheFindings = 2, kCacheBytes = 96;
+template <int MODE>
 SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_finding* fout, u8* aout, u64 abase) {
     const u8* bytes = P.data;
     const u64 len = P.len;
@@ -260,6 +263,7 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
     u32 n_find = 0, n_bytes = 0, windows = 0;
     u32 status = kRegionOk;
     u64 pos = want;
+    bool cached = MODE == 2;
 
     // region_over(p): nothing forces the replay to go on at window start p
     auto region_over = [&](u64 p) -> bool {
@@ -317,7 +321,9 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
                     DChunk ch;
                     while (dsplit_next(P, it, ch)) {
                         if (!ch.again) {
-                            if (WRITE) {
+                            bool put = MODE != 0;
+                            if (MODE == 2) { put = n_find < kCacheFindings && n_bytes + ch.len <= kCacheBytes; cached = cached && put; }
+                            if (put) {
                                 sx_finding f;
                                 f.position = consumed + din;
                                 f.str_off = (u32)(abase + n_bytes);
@@ -361,6 +367,7 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
     o.n_find = n_find;
     o.n_bytes = n_bytes;
     o.status = status;
+    o.pad = cached ? 1u : 0u;
 }
 
 

@@ -33,15 +33,17 @@ namespace sx {
 
 // Pass 1: one lane per run; a run whose window is certainly inside the region of the run
 // before it is marked kRegionChained right away (the earlier region follows it).
-__global__ __launch_bounds__(64) void replay_count_kernel(const ReplayParams P, ReplayRegionOut* out) {
+__global__ __launch_bounds__(64) void replay_count_kernel(const ReplayParams P, ReplayRegionOut* out, sx_finding* cache_f,
+                                                          u8* cache_s) {
     const u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
     if (i >= P.n_runs) return;
     ReplayRegionOut o;
-    o.end = 0; o.n_find = 0; o.n_bytes = 0; o.status = kRegionOk;
+    o.end = 0; o.n_find = 0; o.n_bytes = 0; o.status = kRegionOk; o.pad = 0;
     const u64 want = win_start(P.runs[i].start, P.W);
     if (want < P.lo || want >= P.hi) o.status = kRegionNotMine;
     else if (i > 0 && want <= win_start(P.runs[i - 1].end - 1, P.W)) o.status = kRegionChained;
-    else replay_region<false>(P, i, o, nullptr, nullptr, 0);
+    else if (cache_f) replay_region<2>(P, i, o, cache_f + i * kCacheFindings, cache_s + i * kCacheBytes, 0);
+    else replay_region<0>(P, i, o, nullptr, nullptr, 0);
     out[i] = o;
 }
 
@@ -51,17 +53,31 @@ __global__ __launch_bounds__(64) void replay_write_kernel(const ReplayParams P, 
     const u64 k = (u64)blockIdx.x * 64 + threadIdx.x;
     if (k >= n_regions) return;
     ReplayRegionOut o;
-    replay_region<true>(P, region_index[k], o, findings + fbase[k], arena + abase[k], abase[k]);
+    replay_region<1>(P, region_index[k], o, findings + fbase[k], arena + abase[k], abase[k]);
 }
 
 // Pass 2, flagged form: one lane per run; the standing regions (stitch below) write at the
 // offsets the device scans assigned.
-__global__ __launch_bounds__(64) void replay_write_flagged_kernel(const ReplayParams P, const u8* stands, const u64* fpos,
-                                                                  const u64* apos, sx_finding* findings, u8* arena) {
+__global__ __launch_bounds__(64) void replay_write_flagged_kernel(const ReplayParams P, const ReplayRegionOut* ro,
+                                                                  const u8* stands, const u64* fpos, const u64* apos,
+                                                                  const sx_finding* cache_f, const u8* cache_s,
+                                                                  sx_finding* findings, u8* arena) {
     const u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
     if (i >= P.n_runs || !stands[i]) return;
+    const u64 fp = fpos[i], ap = apos[i];
+    if (cache_f && ro[i].pad) {  // pass 1 kept the region's output: copy it into place
+        const u32 nf = ro[i].n_find, nb = ro[i].n_bytes;
+        for (u32 j = 0; j < nf; j++) {
+            sx_finding f = cache_f[i * kCacheFindings + j];
+            f.str_off += (u32)ap;
+            findings[fp + j] = f;
+        }
+        const u8* src = cache_s + i * kCacheBytes;
+        for (u32 t = 0; t < nb; t++) arena[ap + t] = src[t];
+        return;
+    }
     ReplayRegionOut o;
-    replay_region<true>(P, i, o, findings + fpos[i], arena + apos[i], apos[i]);
+    replay_region<1>(P, i, o, findings + fp, arena + ap, ap);
 }
 
 // ---- which regions stand, on the device ---------------------------------------------------
@@ -219,17 +235,24 @@ hipError_t launch_stitch_finish(const ReplayParams& P, const ReplayRegionOut* ro
                        apos, totals);
     return hipGetLastError();
 }
-hipError_t launch_replay_write_flagged(const ReplayParams& P, const uint8_t* stands, const uint64_t* fpos, const uint64_t* apos,
-                                       sx_finding* findings, uint8_t* arena, hipStream_t stream) {
+hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegionOut* ro, const uint8_t* stands,
+                                       const uint64_t* fpos, const uint64_t* apos, const void* cache, sx_finding* findings,
+                                       uint8_t* arena, hipStream_t stream) {
     if (P.n_runs == 0) return hipSuccess;
-    hipLaunchKernelGGL(replay_write_flagged_kernel, dim3((unsigned)((P.n_runs + 63) / 64)), dim3(64), 0, stream, P, stands, fpos,
-                       apos, findings, arena);
+    const sx_finding* cf = (const sx_finding*)cache;
+    const u8* cs = cache ? (const u8*)cache + P.n_runs * kCacheFindings * sizeof(sx_finding) : nullptr;
+    hipLaunchKernelGGL(replay_write_flagged_kernel, dim3((unsigned)((P.n_runs + 63) / 64)), dim3(64), 0, stream, P, ro, stands,
+                       fpos, apos, cf, cs, findings, arena);
     return hipGetLastError();
 }
 
-hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, hipStream_t stream) {
+size_t replay_cache_bytes(uint64_t n_runs) { return n_runs * (kCacheFindings * sizeof(sx_finding) + kCacheBytes) + 64; }
+// cache: nullptr, or replay_cache_bytes(P.n_runs) bytes that pass 1 fills and launch_replay_write_flagged reads
+hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, void* cache, hipStream_t stream) {
     if (P.n_runs == 0) return hipSuccess;
-    hipLaunchKernelGGL(replay_count_kernel, dim3((unsigned)((P.n_runs + 63) / 64)), dim3(64), 0, stream, P, out);
+    sx_finding* cf = (sx_finding*)cache;
+    u8* cs = cache ? (u8*)cache + P.n_runs * kCacheFindings * sizeof(sx_finding) : nullptr;
+    hipLaunchKernelGGL(replay_count_kernel, dim3((unsigned)((P.n_runs + 63) / 64)), dim3(64), 0, stream, P, out, cf, cs);
     return hipGetLastError();
 }
 hipError_t launch_replay_write(const ReplayParams& P, const u64* region_index, const u64* fbase, const u64* abase,
