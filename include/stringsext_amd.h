@@ -118,8 +118,9 @@ enum {
     SX_OPT_GENERIC_KERNELS = 1u,  /* force the table-driven classifiers (testing) */
     SX_OPT_DEVICE_REPLAY = 2u,    /* run the exact replay (stage B) on the device even for small inputs */
     SX_OPT_HOST_REPLAY = 4u,      /* never run stage B on the device */
-    SX_OPT_TILE_TRAVERSAL = 8u    /* scan kernels: independent overlapping tiles visited grid-stride (experimental;
+    SX_OPT_TILE_TRAVERSAL = 8u,   /* scan kernels: independent overlapping tiles visited grid-stride (experimental;
                                      measured slower than the default: one private sub-chunk per wavefront) */
+    SX_OPT_MISSION_STREAMS = 16u  /* a scan stream per mission (default: one scan stream + one for everything else) */
 };
 
 int  sx_abi_version(void);
@@ -194,6 +195,15 @@ int sx_replay_shard_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t buf_off, ui
                          sx_result** out, uint64_t* end_pos);
 
 uint64_t          sx_result_count(const sx_result* r);
+/* The findings come in one or more segments, in print order (a large device-resident
+ * buffer is scanned piece by piece and every piece adds a segment; the segments'
+ * memory is pinned host memory the device wrote directly).  Each segment has its own
+ * arena: sx_finding.str_off is relative to it. */
+uint64_t          sx_result_segments(const sx_result* r);
+int               sx_result_segment(const sx_result* r, uint64_t index, const sx_finding** findings,
+                                    uint64_t* n_findings, const uint8_t** arena, uint64_t* arena_len);
+/* Contiguous view of all segments (joined by a copy on first use if there are several;
+ * NULL if the strings exceed 4 GiB — use the segments then). */
 const sx_finding* sx_result_findings(const sx_result* r);
 const uint8_t*    sx_result_arena(const sx_result* r, uint64_t* len);
 void              sx_result_free(sx_result* r);

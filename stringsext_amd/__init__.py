@@ -23,7 +23,7 @@ PRECISION = {0: "Before", 1: "Exact", 2: "After"}
 # every symbol include/stringsext_amd.h declares
 EXPORTS = ["sx_abi_version", "sx_create", "sx_destroy", "sx_last_error", "sx_scan", "sx_scan_device", "sx_reset",
            "sx_device_runs", "sx_replay_runs", "sx_scan_shard_device", "sx_scan_shard", "sx_replay_shard_runs",
-           "sx_result_count", "sx_result_findings", "sx_result_arena",
+           "sx_result_count", "sx_result_segments", "sx_result_segment", "sx_result_findings", "sx_result_arena",
            "sx_result_free", "sx_print_findings", "sx_get_stats", "sx_free", "sx_fill_background_device",
            "sx_device_alloc", "sx_device_free", "sx_device_upload", "sx_device_download",
            "sx_device_read_bandwidth"]
@@ -119,6 +119,10 @@ def lib():
     L.sx_result_arena.restype = C.POINTER(C.c_uint8)
     L.sx_result_arena.argtypes = [vp, C.POINTER(u64)]
     L.sx_result_free.argtypes = [vp]
+    L.sx_result_segments.restype = u64
+    L.sx_result_segments.argtypes = [vp]
+    L.sx_result_segment.argtypes = [vp, u64, C.POINTER(C.POINTER(Finding)), C.POINTER(u64),
+                                    C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(u64)]
     L.sx_print_findings.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
                                     C.POINTER(u64)]
     L.sx_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -151,17 +155,24 @@ class Result:
         fb = C.string_at(L.sx_result_findings(self.h), n * C.sizeof(Finding)) if n else b""
         return fb, (C.string_at(ap, alen.value) if alen.value else b"")
 
-    def findings(self):
+    def segments(self):
+        """[(Finding array, n, arena bytes)]: the result as the library holds it (no copy on the C side)."""
         L = lib()
-        n = L.sx_result_count(self.h)
-        v = L.sx_result_findings(self.h)
-        alen = C.c_uint64()
-        ap = L.sx_result_arena(self.h, C.byref(alen))
-        arena = C.string_at(ap, alen.value) if alen.value else b""
-        return [dict(position=v[i].position, precision=PRECISION[v[i].precision],
-                     s=arena[v[i].str_off:v[i].str_off + v[i].str_len].decode("utf-8"),
-                     completes=bool(v[i].completes_previous), mission_id=v[i].mission_id,
-                     file_id=v[i].input_file_id, slice_index=v[i].slice_index) for i in range(n)]
+        out = []
+        for i in range(L.sx_result_segments(self.h)):
+            fp, n, ap, alen = C.POINTER(Finding)(), C.c_uint64(), C.POINTER(C.c_uint8)(), C.c_uint64()
+            self._s._chk(L.sx_result_segment(self.h, i, C.byref(fp), C.byref(n), C.byref(ap), C.byref(alen)))
+            out.append((fp, n.value, C.string_at(ap, alen.value) if alen.value else b""))
+        return out
+
+    def findings(self):
+        out = []
+        for v, n, arena in self.segments():
+            out += [dict(position=v[i].position, precision=PRECISION[v[i].precision],
+                         s=arena[v[i].str_off:v[i].str_off + v[i].str_len].decode("utf-8"),
+                         completes=bool(v[i].completes_previous), mission_id=v[i].mission_id,
+                         file_id=v[i].input_file_id, slice_index=v[i].slice_index) for i in range(n)]
+        return out
 
     def printed(self, n_inputs=1, radix=None, no_metadata=False):
         """Finding::print of every finding (src/finding.rs:112-155), without BOM / final newline."""

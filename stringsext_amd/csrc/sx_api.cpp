@@ -23,11 +23,14 @@ namespace sx {
 PinnedPool::Block PinnedPool::take(size_t bytes) {
     {
         std::lock_guard<std::mutex> g(mu);
+        size_t best = free_blocks.size();
         for (size_t i = 0; i < free_blocks.size(); i++)
-            if (free_blocks[i].cap >= bytes) { Block b = free_blocks[i]; free_blocks.erase(free_blocks.begin() + (long)i); return b; }
-        // too small ones are dropped: the pool holds at most a couple of blocks
-        for (Block& b : free_blocks) (void)hipHostFree(b.p);
-        free_blocks.clear();
+            if (free_blocks[i].cap >= bytes && (best == free_blocks.size() || free_blocks[i].cap < free_blocks[best].cap)) best = i;
+        if (best < free_blocks.size() && free_blocks[best].cap <= 4 * bytes + (4u << 20)) {
+            Block b = free_blocks[best];
+            free_blocks.erase(free_blocks.begin() + (long)best);
+            return b;
+        }
     }
     Block b;
     const size_t cap = bytes + bytes / 8 + (1u << 20);
@@ -38,8 +41,13 @@ PinnedPool::Block PinnedPool::take(size_t bytes) {
 void PinnedPool::give(Block b) {
     if (!b.p) return;
     std::lock_guard<std::mutex> g(mu);
-    if (free_blocks.size() >= 2) { (void)hipHostFree(b.p); return; }
     free_blocks.push_back(b);
+    if (free_blocks.size() > 40) {  // a result of a large buffer holds one block per piece; beyond that, drop the smallest
+        size_t m = 0;
+        for (size_t i = 1; i < free_blocks.size(); i++) if (free_blocks[i].cap < free_blocks[m].cap) m = i;
+        (void)hipHostFree(free_blocks[m].p);
+        free_blocks.erase(free_blocks.begin() + (long)m);
+    }
 }
 PinnedPool::~PinnedPool() { for (Block& b : free_blocks) (void)hipHostFree(b.p); }
 }  // namespace sx
@@ -67,12 +75,20 @@ struct RunList {
     const sx_run& operator[](size_t i) const { return p[i]; }
 };
 
-struct MissionDev {
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+// Stage A writes its run records into one of two slots, so that the kernel of the next piece
+// of a large buffer can run while the previous piece's records are sorted, joined and replayed.
+struct ScanSlot {
     DevRun* d_recs = nullptr;
-    uint32_t* d_counters = nullptr;
     uint32_t capacity = 0;
+    uint32_t* d_counters = nullptr;   // 4 x u32: records, heavy tiles, joined runs, -
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the scan kernel
+    hipEvent_t ev_free = nullptr;     // the slot's records have been consumed (recorded on stream_b)
+    bool free_pending = false;
+};
+struct MissionDev {
+    hipStream_t stream = nullptr;     // scan kernels only
+    hipStream_t stream_b = nullptr;   // everything after them (sort/join, stage B, copies); higher priority
+    ScanSlot slot[2];
     // stage B on the device: grow-only buffers
     uint16_t* d_table = nullptr;                        // single-byte decoder table
     sx_run* h_runs = nullptr; uint64_t h_runs_cap = 0;   // pinned: runs joined on the device
@@ -96,6 +112,7 @@ struct sx_ctx {
     sx_options opt{};
     std::string err;
     sx_stats stats{};
+    hipStream_t scan_stream = nullptr, post_stream = nullptr;
     uint8_t* d_input = nullptr;  // staging for host input
     uint64_t d_input_cap = 0;
     uint64_t ondemand_fetches = 0;
@@ -186,12 +203,12 @@ int ensure_scratch(sx_ctx* ctx, uint64_t bytes) {
     return SX_OK;
 }
 
-int ensure_capacity(sx_ctx* ctx, MissionDev& d, uint32_t cap) {
-    if (d.capacity >= cap) return SX_OK;
-    if (d.d_recs) HIP_TRY(ctx, hipFree(d.d_recs));
-    d.d_recs = nullptr; d.capacity = 0;
-    HIP_TRY(ctx, hipMalloc((void**)&d.d_recs, (size_t)cap * sizeof(DevRun)));
-    d.capacity = cap;
+int ensure_capacity(sx_ctx* ctx, ScanSlot& s, uint32_t cap) {
+    if (s.capacity >= cap) return SX_OK;
+    if (s.d_recs) HIP_TRY(ctx, hipFree(s.d_recs));
+    s.d_recs = nullptr; s.capacity = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&s.d_recs, (size_t)cap * sizeof(DevRun)));
+    s.capacity = cap;
     return SX_OK;
 }
 
@@ -207,117 +224,149 @@ int ensure_rp(sx_ctx* ctx, MissionDev& d, int slot, uint64_t bytes) {
     return SX_OK;
 }
 
+ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const uint8_t* d_bytes, uint64_t len,
+                       uint32_t parity, uint64_t min_chars) {
+    const Mission& m = ctx->missions[(size_t)mission];
+    uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 256u * 1024u;
+    sub = std::max<uint32_t>(kTileBytes, sub / kTileBytes * kTileBytes);
+    ScanParams p = m.proto;
+    p.data = d_bytes; p.len = len; p.subchunk = sub; p.parity = parity;
+    p.min_chars = (uint32_t)std::min<uint64_t>(min_chars, kRecCharsMask);
+    if (p.min_chars == 0) p.min_chars = 1;
+    p.cand_bytes = std::min<uint32_t>(p.min_chars * (m.is_utf16() ? 2u : 1u), 17u);
+    {   // r &= r << sh, doubling the proven run length until it reaches cand_bytes
+        uint32_t have = 1;
+        for (int i = 0; i < 5; i++) {
+            const uint32_t sh = have < p.cand_bytes ? std::min(have, p.cand_bytes - have) : 0;
+            p.cand_sh[i] = sh;
+            have += sh;
+        }
+    }
+    p.capacity = s.capacity; p.recs = s.d_recs; p.counters = s.d_counters;
+    p.traversal = (ctx->opt.flags & SX_OPT_TILE_TRAVERSAL) ? 1u : 0u;
+    if (const char* e = getenv("SX_TRAVERSAL")) p.traversal = (uint32_t)atoi(e);
+    return p;
+}
+
+// Stage A, first half: enqueue every mission's scan kernel over [d_bytes, d_bytes+len) on its
+// scan stream, writing into record slot `si`.  Returns at once.
+int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
+                   const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si) {
+    if (len == 0) return SX_OK;
+    for (size_t k = 0; k < which.size(); k++) {
+        MissionDev& d = ctx->dev[(size_t)which[k]];
+        ScanSlot& s = d.slot[si];
+        if (s.free_pending) { HIP_TRY(ctx, hipStreamWaitEvent(d.stream, s.ev_free, 0)); s.free_pending = false; }
+        const ScanParams p = scan_params(ctx, which[k], s, d_bytes, len, parity[k], min_chars[k]);
+        HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream));
+        HIP_TRY(ctx, hipEventRecord(s.ev0, d.stream));
+        HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream));
+        HIP_TRY(ctx, hipEventRecord(s.ev1, d.stream));
+    }
+    return SX_OK;
+}
+
+// Stage A, second half: wait for slot `si`, re-run a mission whose record buffer overflowed,
+// and turn the records into the mission's sorted long runs (joined on the device when there
+// are many).  Only stream_b is used from here on: the scan streams may already hold the next piece.
+int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
+                   const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si,
+                   std::vector<RunList>* out) {
+    out->assign(which.size(), RunList{});
+    if (len == 0) return SX_OK;
+    const double t0 = now_ms();
+    for (size_t k = 0; k < which.size(); k++) {
+        MissionDev& d = ctx->dev[(size_t)which[k]];
+        ScanSlot& s = d.slot[si];
+        HIP_TRY(ctx, hipEventSynchronize(s.ev1));
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, s.ev0, s.ev1));
+        if (which[k] < 16) ctx->stats.kernel_ms[which[k]] += ms;
+        uint32_t counters[4] = { 0, 0, 0, 0 };
+        for (int round = 0;; round++) {
+            HIP_TRY(ctx, hipMemcpyAsync(counters, s.d_counters, sizeof counters, hipMemcpyDeviceToHost, d.stream_b));
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            if (counters[0] <= s.capacity) break;
+            if (round >= 8) { ctx->err = "device run-record buffer kept overflowing"; return SX_E_NOMEM; }
+            // overflow: grow the slot and scan this piece again for this mission
+            int rc = ensure_capacity(ctx, s, counters[0] + counters[0] / 8 + 1024);
+            if (rc != SX_OK) return rc;
+            const ScanParams p = scan_params(ctx, which[k], s, d_bytes, len, parity[k], min_chars[k]);
+            HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream_b));
+            HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream_b));
+        }
+        const double tc0 = now_ms();
+        const uint32_t nrec = counters[0];
+        const uint32_t join_min = getenv("SX_DEVICE_JOIN_MIN") ? (uint32_t)atoi(getenv("SX_DEVICE_JOIN_MIN")) : 65536u;
+        const bool dev_sorted = nrec >= join_min && nrec > 0;  // worth a handful of small kernels
+        double tc1 = tc0;
+        RunList& rl = (*out)[k];
+        if (dev_sorted) {
+            // sort the records and join them into runs on the device; only the runs travel
+            const size_t sb = std::max(sort_scratch_bytes(nrec), merge_scratch_bytes(nrec));
+            int rc = ensure_scratch(ctx, sb); if (rc != SX_OK) return rc;
+            rc = ensure_rp(ctx, d, 0, (uint64_t)nrec * sizeof(sx_run)); if (rc != SX_OK) return rc;
+            HIP_TRY(ctx, sort_records(s.d_recs, nrec, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
+            HIP_TRY(ctx, merge_sorted_records(s.d_recs, nrec, min_chars[k], ctx->d_scratch, ctx->d_scratch_cap,
+                                              (sx_run*)d.d_rp[0], s.d_counters + 2, d.stream_b));
+            HIP_TRY(ctx, hipEventRecord(s.ev_free, d.stream_b));
+            s.free_pending = true;
+            uint32_t nruns = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&nruns, s.d_counters + 2, 4, hipMemcpyDeviceToHost, d.stream_b));
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            tc1 = now_ms();
+            if ((uint64_t)nruns * sizeof(sx_run) > d.h_runs_cap) {
+                if (d.h_runs) HIP_TRY(ctx, hipHostFree(d.h_runs));
+                d.h_runs = nullptr; d.h_runs_cap = 0;
+                const uint64_t cap = (uint64_t)nruns * sizeof(sx_run) * 5 / 4 + 4096;
+                HIP_TRY(ctx, hipHostMalloc((void**)&d.h_runs, cap, hipHostMallocNonCoherent));
+                d.h_runs_cap = cap;
+            }
+            if (nruns) {
+                HIP_TRY(ctx, hipMemcpyAsync(d.h_runs, d.d_rp[0], (size_t)nruns * sizeof(sx_run), hipMemcpyDeviceToHost, d.stream_b));
+                HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            }
+            rl.p = d.h_runs; rl.n = nruns; rl.on_device = true;
+        } else {
+            int rc = ensure_pinned(ctx, (uint64_t)nrec * sizeof(DevRun) + 16);
+            if (rc != SX_OK) return rc;
+            DevRun* recs_p = (DevRun*)ctx->h_pin;
+            if (nrec) {
+                HIP_TRY(ctx, hipMemcpyAsync(recs_p, s.d_recs, (size_t)nrec * sizeof(DevRun), hipMemcpyDeviceToHost, d.stream_b));
+                HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            }
+            tc1 = now_ms();
+            if (getenv("SX_DEBUG_RECS")) {
+                std::vector<DevRun> srt(recs_p, recs_p + nrec);
+                std::sort(srt.begin(), srt.end(), [](const DevRun& a, const DevRun& b) { return a.start < b.start; });
+                for (const DevRun& r : srt)
+                    fprintf(stderr, "[sx] rec start=%llu len=%u chars=%u flags=%s%s\n", (unsigned long long)r.start, r.len,
+                            r.chars_flags & kRecCharsMask, (r.chars_flags & kRecStartOpen) ? "S" : "-",
+                            (r.chars_flags & kRecEndOpen) ? "E" : "-");
+                fprintf(stderr, "[sx] slow tiles %u\n", counters[1]);
+            }
+            merge_device_runs(recs_p, nrec, min_chars[k], 64 * 1024, &rl.own);
+            rl.use_own();
+        }
+        if (getenv("SX_TIMING"))
+            fprintf(stderr, "[sx] mission %d: kernel %.2f ms, %u record slots, %s %.2f ms, %s %.2f ms -> %zu runs\n", which[k], ms,
+                    nrec, dev_sorted ? "device sort+join" : "d2h", tc1 - tc0, dev_sorted ? "d2h runs" : "host join",
+                    now_ms() - tc1, rl.size());
+        ctx->stats.run_records += rl.size();
+        ctx->stats.bytes_scanned += len;
+        ctx->stats.heavy_tiles += counters[1];
+    }
+    ctx->stats.device_ms += now_ms() - t0;
+    return SX_OK;
+}
+
+// Stage A over one buffer, start to end.
 int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
                 const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars,
                 std::vector<RunList>* out) {
-    out->assign(which.size(), RunList{});
-    if (len == 0) return SX_OK;
-    uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 256u * 1024u;
-    sub = std::max<uint32_t>(kTileBytes, sub / kTileBytes * kTileBytes);
-    const double t0 = now_ms();
-    std::vector<bool> pending(which.size(), true);
-    for (int round = 0; round < 8; round++) {
-        bool any = false;
-        for (size_t k = 0; k < which.size(); k++) {
-            if (!pending[k]) continue;
-            any = true;
-            const Mission& m = ctx->missions[which[k]];
-            MissionDev& d = ctx->dev[which[k]];
-            ScanParams p = m.proto;
-            p.data = d_bytes; p.len = len; p.subchunk = sub; p.parity = parity[k];
-            p.min_chars = (uint32_t)std::min<uint64_t>(min_chars[k], kRecCharsMask);
-            if (p.min_chars == 0) p.min_chars = 1;
-            p.cand_bytes = std::min<uint32_t>(p.min_chars * (m.is_utf16() ? 2u : 1u), 17u);
-            {   // r &= r << sh, doubling the proven run length until it reaches cand_bytes
-                uint32_t have = 1;
-                for (int i = 0; i < 5; i++) {
-                    const uint32_t sh = have < p.cand_bytes ? std::min(have, p.cand_bytes - have) : 0;
-                    p.cand_sh[i] = sh;
-                    have += sh;
-                }
-            }
-            p.capacity = d.capacity; p.recs = d.d_recs; p.counters = d.d_counters;
-            p.traversal = (ctx->opt.flags & SX_OPT_TILE_TRAVERSAL) ? 1u : 0u;
-            if (const char* e = getenv("SX_TRAVERSAL")) p.traversal = (uint32_t)atoi(e);
-            HIP_TRY(ctx, hipMemsetAsync(d.d_counters, 0, 4 * sizeof(uint32_t), d.stream));
-            HIP_TRY(ctx, hipEventRecord(d.ev0, d.stream));
-            HIP_TRY(ctx, launch_scan(m.kind, p, d.stream));
-            HIP_TRY(ctx, hipEventRecord(d.ev1, d.stream));
-        }
-        if (!any) break;
-        for (size_t k = 0; k < which.size(); k++) {
-            if (!pending[k]) continue;
-            MissionDev& d = ctx->dev[which[k]];
-            HIP_TRY(ctx, hipStreamSynchronize(d.stream));
-            float ms = 0;
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, d.ev0, d.ev1));
-            if (which[k] < 16) ctx->stats.kernel_ms[which[k]] = ms;
-            uint32_t counters[4] = { 0, 0, 0, 0 };
-            HIP_TRY(ctx, hipMemcpy(counters, d.d_counters, sizeof counters, hipMemcpyDeviceToHost));
-            if (counters[0] > d.capacity) {  // overflow: grow and run this mission again
-                int rc = ensure_capacity(ctx, d, counters[0] + counters[0] / 8 + 1024);
-                if (rc != SX_OK) return rc;
-                continue;
-            }
-            const double tc0 = now_ms();
-            const uint32_t nrec = counters[0];
-            const uint32_t join_min = getenv("SX_DEVICE_JOIN_MIN") ? (uint32_t)atoi(getenv("SX_DEVICE_JOIN_MIN")) : 65536u;
-            const bool dev_sorted = nrec >= join_min && nrec > 0;  // worth a handful of small kernels
-            double tc1 = tc0;
-            RunList& rl = (*out)[k];
-            if (dev_sorted) {
-                // sort the records and join them into runs on the device; only the runs travel
-                const size_t sb = std::max(sort_scratch_bytes(nrec), merge_scratch_bytes(nrec));
-                int rc = ensure_scratch(ctx, sb); if (rc != SX_OK) return rc;
-                rc = ensure_rp(ctx, d, 0, (uint64_t)nrec * sizeof(sx_run)); if (rc != SX_OK) return rc;
-                HIP_TRY(ctx, sort_records(d.d_recs, nrec, ctx->d_scratch, ctx->d_scratch_cap, d.stream));
-                HIP_TRY(ctx, merge_sorted_records(d.d_recs, nrec, min_chars[k], ctx->d_scratch, ctx->d_scratch_cap,
-                                                  (sx_run*)d.d_rp[0], d.d_counters + 2, d.stream));
-                uint32_t nruns = 0;
-                HIP_TRY(ctx, hipMemcpyAsync(&nruns, d.d_counters + 2, 4, hipMemcpyDeviceToHost, d.stream));
-                HIP_TRY(ctx, hipStreamSynchronize(d.stream));
-                tc1 = now_ms();
-                if ((uint64_t)nruns * sizeof(sx_run) > d.h_runs_cap) {
-                    if (d.h_runs) HIP_TRY(ctx, hipHostFree(d.h_runs));
-                    d.h_runs = nullptr; d.h_runs_cap = 0;
-                    const uint64_t cap = (uint64_t)nruns * sizeof(sx_run) * 5 / 4 + 4096;
-                    HIP_TRY(ctx, hipHostMalloc((void**)&d.h_runs, cap, hipHostMallocNonCoherent));
-                    d.h_runs_cap = cap;
-                }
-                if (nruns) HIP_TRY(ctx, hipMemcpy(d.h_runs, d.d_rp[0], (size_t)nruns * sizeof(sx_run), hipMemcpyDeviceToHost));
-                rl.p = d.h_runs; rl.n = nruns; rl.on_device = true;
-            } else {
-                int rc = ensure_pinned(ctx, (uint64_t)nrec * sizeof(DevRun) + 16);
-                if (rc != SX_OK) return rc;
-                DevRun* recs_p = (DevRun*)ctx->h_pin;
-                if (nrec) HIP_TRY(ctx, hipMemcpy(recs_p, d.d_recs, (size_t)nrec * sizeof(DevRun), hipMemcpyDeviceToHost));
-                tc1 = now_ms();
-                if (getenv("SX_DEBUG_RECS")) {
-                    std::vector<DevRun> srt(recs_p, recs_p + nrec);
-                    std::sort(srt.begin(), srt.end(), [](const DevRun& a, const DevRun& b) { return a.start < b.start; });
-                    for (const DevRun& r : srt)
-                        fprintf(stderr, "[sx] rec start=%llu len=%u chars=%u flags=%s%s\n", (unsigned long long)r.start, r.len,
-                                r.chars_flags & kRecCharsMask, (r.chars_flags & kRecStartOpen) ? "S" : "-",
-                                (r.chars_flags & kRecEndOpen) ? "E" : "-");
-                    fprintf(stderr, "[sx] slow tiles %u\n", counters[1]);
-                }
-                merge_device_runs(recs_p, nrec, min_chars[k], 64 * 1024, &rl.own);
-                rl.use_own();
-            }
-            if (getenv("SX_TIMING"))
-                fprintf(stderr, "[sx] mission %d: %u record slots, %s %.2f ms, %s %.2f ms -> %zu runs\n", which[k], nrec,
-                        dev_sorted ? "device sort+join" : "d2h", tc1 - tc0, dev_sorted ? "d2h runs" : "host join", now_ms() - tc1,
-                        rl.size());
-            ctx->stats.run_records += (*out)[k].size();
-            ctx->stats.bytes_scanned += len;
-            ctx->stats.heavy_tiles += counters[1];
-            pending[k] = false;
-        }
-    }
-    for (size_t k = 0; k < which.size(); k++)
-        if (pending[k]) { ctx->err = "device run-record buffer kept overflowing"; return SX_E_NOMEM; }
-    ctx->stats.device_ms += now_ms() - t0;
-    return SX_OK;
+    int rc = stage_a_launch(ctx, which, d_bytes, len, parity, min_chars, 0);
+    if (rc != SX_OK) return rc;
+    return stage_a_finish(ctx, which, d_bytes, len, parity, min_chars, 0, out);
 }
 
 // CPUs this process may really use: the cgroup quota can be far below the visible cores.
@@ -409,7 +458,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         rc = ensure_rp(ctx, d, 7, kTotCount * 8); if (rc) return rc;
         rc = ensure_scratch(ctx, stitch_scratch_bytes(n)); if (rc) return rc;
         if (!runs.on_device)
-            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[0], runs.data(), n * sizeof(sx_run), hipMemcpyHostToDevice, d.stream));
+            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[0], runs.data(), n * sizeof(sx_run), hipMemcpyHostToDevice, d.stream_b));
         P.data = job.d_bytes; P.len = job.len; P.runs = (const sx_run*)d.d_rp[0]; P.n_runs = n;
         P.lo = job.lo[k]; P.hi = job.hi; P.consumed0 = job.consumed0[k]; P.stream0 = job.stream0[k];
         P.slice_base = job.slice_base; P.encoding = m.c.encoding; P.table = d.d_table;
@@ -422,13 +471,13 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
             cache = d.d_rp[8];
         }
         cache_used = cache;
-        HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], cache, d.stream));
+        HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], cache, d.stream_b));
         if (dev_stitch) {
-            HIP_TRY(ctx, hipMemsetAsync(d.d_rp[7], 0, kTotCount * 8, d.stream));
+            HIP_TRY(ctx, hipMemsetAsync(d.d_rp[7], 0, kTotCount * 8, d.stream_b));
             HIP_TRY(ctx, launch_stitch_blocks(P, (const ReplayRegionOut*)d.d_rp[1], (uint8_t*)d.d_rp[2], d.d_rp[6],
-                                              (uint64_t*)d.d_rp[7], d.stream));
+                                              (uint64_t*)d.d_rp[7], d.stream_b));
         } else
-            HIP_TRY(ctx, hipMemcpyAsync(ro, d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream));
+            HIP_TRY(ctx, hipMemcpyAsync(ro, d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream_b));
     }
 
     // ---- meanwhile on the host: the strict entry region (exact carried state), if any
@@ -451,14 +500,14 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     if (dev_stitch) {
         HIP_TRY(ctx, launch_stitch_finish(P, (const ReplayRegionOut*)d.d_rp[1], (uint8_t*)d.d_rp[2], d.d_rp[6], E,
                                           (uint64_t*)d.d_rp[3], (uint64_t*)d.d_rp[4], (uint64_t*)d.d_rp[7], ctx->d_scratch,
-                                          ctx->d_scratch_cap, d.stream));
-        HIP_TRY(ctx, hipMemcpyAsync(h_tot, d.d_rp[7], kTotCount * 8, hipMemcpyDeviceToHost, d.stream));
+                                          ctx->d_scratch_cap, d.stream_b));
+        HIP_TRY(ctx, hipMemcpyAsync(h_tot, d.d_rp[7], kTotCount * 8, hipMemcpyDeviceToHost, d.stream_b));
     }
-    if (n) HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    if (n) HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
     if (dev_stitch && h_tot[kTotTooLong]) {  // regions for the host: it also decides what stands
         dev_stitch = false;
-        HIP_TRY(ctx, hipMemcpyAsync(ro, d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream));
-        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ro, d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream_b));
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
     }
     const double t1 = now_ms();
 
@@ -513,19 +562,19 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         if (dev_stitch) {
             HIP_TRY(ctx, launch_replay_write_flagged(P, (const ReplayRegionOut*)d.d_rp[1], (const uint8_t*)d.d_rp[2],
                                                      (const uint64_t*)d.d_rp[3], (const uint64_t*)d.d_rp[4], cache_used, d_f,
-                                                     d_a, d.stream));
+                                                     d_a, d.stream_b));
         } else {
             const size_t nv = valid.size();
-            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[2], valid.data(), nv * 8, hipMemcpyHostToDevice, d.stream));
-            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[3], fbase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream));
-            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[4], abase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream));
+            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[2], valid.data(), nv * 8, hipMemcpyHostToDevice, d.stream_b));
+            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[3], fbase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream_b));
+            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[4], abase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream_b));
             HIP_TRY(ctx, launch_replay_write(P, (const uint64_t*)d.d_rp[2], (const uint64_t*)d.d_rp[3],
-                                             (const uint64_t*)d.d_rp[4], nv, d_f, d_a, d.stream));
+                                             (const uint64_t*)d.d_rp[4], nv, d_f, d_a, d.stream_b));
         }
         blk = ctx->pool->take(nf * sizeof(sx_finding) + nb + 64);
         if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
-        HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_f, nf * sizeof(sx_finding) + nb, hipMemcpyDeviceToHost, d.stream));
-        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_f, nf * sizeof(sx_finding) + nb, hipMemcpyDeviceToHost, d.stream_b));
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
     }
     const double t3 = now_ms();
 
@@ -584,7 +633,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
 // part 0 of a mission starts from its entry state, the others speculate, and the per-mission
 // stitch verifies/repairs them serially.
 int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::vector<RunList>& runs,
-               sx_result** out, uint64_t* end_pos) {
+               Result* into, uint64_t* end_pos) {
     const double t0 = now_ms();
     const size_t nm = ctx->missions.size();
     const unsigned nthreads = replay_threads(ctx);
@@ -592,10 +641,14 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
     std::vector<std::vector<ReplayPart>> parts(nm);
     std::vector<std::pair<size_t, size_t>> tasks;
     std::vector<char> on_device(nm, 0);
+    uint64_t host_runs = 0;
     for (size_t k = 0; k < nm; k++) on_device[k] = device_replay_wanted(ctx, job, k, runs[k].size());
     for (size_t k = 0; k < nm; k++) {
         if (on_device[k]) continue;
-        replay_plan_range(std::min(job.lo[k], job.hi), job.hi, nthreads, &bounds[k]);
+        // parts are speculative restarts: worth a thread each only if they hold real work
+        const unsigned want_parts = (unsigned)std::min<uint64_t>(nthreads, std::max<uint64_t>(1, runs[k].size() / 512));
+        host_runs += runs[k].size();
+        replay_plan_range(std::min(job.lo[k], job.hi), job.hi, want_parts, &bounds[k]);
         parts[k].resize(bounds[k].size() - 1);
         for (size_t p = 0; p + 1 < bounds[k].size(); p++) tasks.emplace_back(k, p);
     }
@@ -613,7 +666,7 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
             task_ms[t] = now_ms() - tt0;
         }
     };
-    const size_t nw = std::min<size_t>(nthreads, tasks.size());
+    const size_t nw = host_runs < 2048 ? 1 : std::min<size_t>(nthreads, tasks.size());
     if (nw <= 1) worker();
     else {
         std::vector<std::thread> th;
@@ -644,8 +697,8 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
     }
     if (end_pos) for (size_t k = 0; k < nm; k++) end_pos[k] = ends[k];
     const double t_stitch = now_ms();
-    sx_result* r = new sx_result();
-    merge_findings(per, ctx->pool, &r->r);
+    const size_t count_before = into->count();
+    merge_findings(per, ctx->pool, into);
     if (getenv("SX_TIMING")) {
         double mx = 0, sum = 0;
         for (double v : task_ms) { sum += v; mx = std::max(mx, v); }
@@ -654,9 +707,8 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
                 now_ms() - t_stitch, (unsigned long long)ctx->ondemand_fetches);
     }
     for (auto& mf : per) ctx->stats.replay_bytes += mf.replay_bytes;
-    ctx->stats.findings += r->r.count();
+    ctx->stats.findings += into->count() - count_before;
     ctx->stats.replay_ms += now_ms() - t0;
-    *out = r;
     return SX_OK;
 }
 
@@ -712,13 +764,29 @@ int sx_create(sx_ctx** out, const sx_mission* missions, int n_missions, int hip_
     if ((e = hipSetDevice(hip_device)) != hipSuccess) return fail("hipSetDevice", e);
     ctx->dev.resize((size_t)n_missions);
     const uint32_t cap = ctx->opt.record_capacity ? ctx->opt.record_capacity : (1u << 20);
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = higher priority
+    // Two streams for the whole context: the scan kernels of all missions queue up in one (a
+    // kernel alone already fills the device, and HIP multiplexes streams onto few hardware
+    // queues: more streams only alias), everything else runs in a second, higher-priority one
+    // so that it overlaps the scans of the next piece.  SX_OPT_MISSION_STREAMS: a scan stream per mission.
+    const bool per_mission = (ctx->opt.flags & SX_OPT_MISSION_STREAMS) || getenv("SX_MISSION_STREAMS");
+    if ((e = hipStreamCreateWithPriority(&ctx->post_stream, hipStreamNonBlocking, prio_hi)) != hipSuccess) return fail("hipStreamCreate", e);
+    if (!per_mission && (e = hipStreamCreateWithPriority(&ctx->scan_stream, hipStreamNonBlocking, prio_lo)) != hipSuccess)
+        return fail("hipStreamCreate", e);
     for (auto& d : ctx->dev) {
-        if ((e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
-        if ((e = hipEventCreate(&d.ev0)) != hipSuccess) return fail("hipEventCreate", e);
-        if ((e = hipEventCreate(&d.ev1)) != hipSuccess) return fail("hipEventCreate", e);
-        if ((e = hipMalloc((void**)&d.d_counters, 4 * sizeof(uint32_t))) != hipSuccess) return fail("hipMalloc", e);
-        if ((e = hipMalloc((void**)&d.d_recs, (size_t)cap * sizeof(DevRun))) != hipSuccess) return fail("hipMalloc", e);
-        d.capacity = cap;
+        d.stream_b = ctx->post_stream;
+        if (per_mission) {
+            if ((e = hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, prio_lo)) != hipSuccess) return fail("hipStreamCreate", e);
+        } else d.stream = ctx->scan_stream;
+        for (ScanSlot& s : d.slot) {
+            if ((e = hipEventCreate(&s.ev0)) != hipSuccess) return fail("hipEventCreate", e);
+            if ((e = hipEventCreate(&s.ev1)) != hipSuccess) return fail("hipEventCreate", e);
+            if ((e = hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+            if ((e = hipMalloc((void**)&s.d_counters, 4 * sizeof(uint32_t))) != hipSuccess) return fail("hipMalloc", e);
+            if ((e = hipMalloc((void**)&s.d_recs, (size_t)cap * sizeof(DevRun))) != hipSuccess) return fail("hipMalloc", e);
+            s.capacity = cap;
+        }
     }
     for (size_t k = 0; k < ctx->dev.size(); k++)
         if (const uint16_t* t = single_byte_table(ctx->missions[k].c.encoding)) {
@@ -735,15 +803,21 @@ void sx_destroy(sx_ctx* ctx) {
         (void)hipSetDevice(ctx->device);
         for (auto& d : ctx->dev) {
             if (d.stream) (void)hipStreamSynchronize(d.stream);
-            if (d.d_recs) (void)hipFree(d.d_recs);
-            if (d.d_counters) (void)hipFree(d.d_counters);
+            if (d.stream_b) (void)hipStreamSynchronize(d.stream_b);
+            for (ScanSlot& s : d.slot) {
+                if (s.d_recs) (void)hipFree(s.d_recs);
+                if (s.d_counters) (void)hipFree(s.d_counters);
+                if (s.ev0) (void)hipEventDestroy(s.ev0);
+                if (s.ev1) (void)hipEventDestroy(s.ev1);
+                if (s.ev_free) (void)hipEventDestroy(s.ev_free);
+            }
             if (d.d_table) (void)hipFree(d.d_table);
             for (void* q : d.d_rp) if (q) (void)hipFree(q);
             if (d.h_runs) (void)hipHostFree(d.h_runs);
-            if (d.ev0) (void)hipEventDestroy(d.ev0);
-            if (d.ev1) (void)hipEventDestroy(d.ev1);
-            if (d.stream) (void)hipStreamDestroy(d.stream);
+            if (d.stream && d.stream != ctx->scan_stream) (void)hipStreamDestroy(d.stream);
         }
+        if (ctx->scan_stream) (void)hipStreamDestroy(ctx->scan_stream);
+        if (ctx->post_stream) (void)hipStreamDestroy(ctx->post_stream);
         if (ctx->d_input) (void)hipFree(ctx->d_input);
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
         if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -798,7 +872,7 @@ static int download_for_replay(sx_ctx* ctx, const uint8_t* d_bytes, uint64_t len
             }
         const double t_seg = now_ms();
         if (total) {
-            hipStream_t s = ctx->dev[0].stream;
+            hipStream_t s = ctx->dev[0].stream_b;
             const size_t ns = seg_src.size();
             const uint64_t seg_bytes = ns * (8 + 8 + 4) + 64;
             int rc2 = ensure_pinned(ctx, total + 64);
@@ -825,37 +899,82 @@ static int download_for_replay(sx_ctx* ctx, const uint8_t* d_bytes, uint64_t len
     return SX_OK;
 }
 
+namespace {
+struct ResultHolder {
+    sx_result* r = new sx_result();
+    ~ResultHolder() { delete r; }
+    sx_result* release() { sx_result* x = r; r = nullptr; return x; }
+};
+
+// Bytes per piece of a large buffer (a multiple of the slice length), or `len` if the buffer is
+// scanned in one go.  With pieces, stage A of piece p+1 and p+2 is queued while piece p is
+// sorted, joined and replayed.  Measured on MI355X (C3(i), 64 GiB): no gain — the replay
+// kernels are latency-bound and run ~3x slower next to a scan kernel that saturates HBM, and
+// the host waits on them six times per piece — so the default is one piece; SX_PIECE_MIB
+// turns the pipeline on (tests do, to keep it correct for an asynchronous stage B later).
+uint64_t piece_bytes(const sx_ctx* ctx, uint64_t len) {
+    uint64_t piece = 0;
+    if (const char* e = getenv("SX_PIECE_MIB")) piece = (uint64_t)atoll(e) << 20;
+    if (piece == 0 || len < 2 * piece) return len;
+    return piece / kInputBufLen * kInputBufLen;
+}
+}  // namespace
+
+// One buffer, start to end: stage A on the device, stage B on device and host, the findings in
+// print order.  A large buffer is cut into pieces that behave exactly like consecutive
+// sx_scan calls (ScannerState carried from piece to piece), but their scan kernels are queued
+// two deep, so the device keeps scanning while the host finishes the piece before.
 static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len, int file_id,
                        int is_last, sx_result** out) {
     const double t_begin = now_ms();
     const size_t nm = ctx->missions.size();
     std::vector<int> which(nm);
-    std::vector<uint32_t> parity(nm);
-    std::vector<uint64_t> minc(nm);
+    std::vector<uint64_t> minc(nm), stream0(nm);
     for (size_t k = 0; k < nm; k++) {
         which[k] = (int)k;
-        parity[k] = (uint32_t)(ctx->states[k].stream_bytes & 1);
+        stream0[k] = ctx->states[k].stream_bytes;
         minc[k] = ctx->missions[k].long_run;
     }
-    std::vector<RunList> runs;
-    int rc = device_runs(ctx, which, d_bytes, len, parity, minc, &runs);
-    if (rc != SX_OK) return rc;
-
-    if (host_bytes) {
-        HostBytes view(host_bytes);
-        ReplayJob job = whole_chunk_job(ctx, len, file_id, is_last != 0);
-        job.d_bytes = d_bytes;
-        rc = replay_all(ctx, view, job, runs, out, nullptr);
-    } else {
-        SparseDeviceBytes view(ctx, d_bytes);
-        ReplayJob job = whole_chunk_job(ctx, len, file_id, is_last != 0);
-        job.d_bytes = d_bytes;
-        rc = download_for_replay(ctx, d_bytes, len, runs, &view, job);
-        if (rc != SX_OK) return rc;
-        rc = replay_all(ctx, view, job, runs, out, nullptr);
+    const uint64_t piece = piece_bytes(ctx, len);
+    const uint64_t n_pieces = len ? (len + piece - 1) / piece : 1;
+    auto piece_off = [&](uint64_t p) { return p * piece; };
+    auto piece_len = [&](uint64_t p) { return std::min(piece, len - piece_off(p)); };
+    auto launch = [&](uint64_t p) -> int {
+        std::vector<uint32_t> parity(nm);
+        for (size_t k = 0; k < nm; k++) parity[k] = (uint32_t)((stream0[k] + piece_off(p)) & 1);
+        return stage_a_launch(ctx, which, d_bytes + piece_off(p), piece_len(p), parity, minc, (int)(p & 1));
+    };
+    ResultHolder res;
+    int rc = SX_OK;
+    uint64_t launched = 0;
+    for (; launched < std::min<uint64_t>(2, n_pieces) && rc == SX_OK; launched++) rc = launch(launched);
+    for (uint64_t p = 0; p < n_pieces && rc == SX_OK; p++) {
+        const uint64_t off = piece_off(p), plen = piece_len(p);
+        std::vector<uint32_t> parity(nm);
+        for (size_t k = 0; k < nm; k++) parity[k] = (uint32_t)((stream0[k] + off) & 1);
+        std::vector<RunList> runs;
+        rc = stage_a_finish(ctx, which, d_bytes + off, plen, parity, minc, (int)(p & 1), &runs);
+        if (rc != SX_OK) break;
+        if (launched < n_pieces) { rc = launch(launched++); if (rc != SX_OK) break; }  // slot p&1 is free again (ev_free)
+        ReplayJob job = whole_chunk_job(ctx, plen, file_id, is_last != 0 && p + 1 == n_pieces);
+        job.d_bytes = d_bytes + off;
+        job.slice_base = (uint32_t)(off / kInputBufLen);
+        if (host_bytes) {
+            HostBytes view(host_bytes + off);
+            rc = replay_all(ctx, view, job, runs, &res.r->r, nullptr);
+        } else {
+            SparseDeviceBytes view(ctx, d_bytes + off);
+            rc = download_for_replay(ctx, d_bytes + off, plen, runs, &view, job);
+            if (rc == SX_OK) rc = replay_all(ctx, view, job, runs, &res.r->r, nullptr);
+        }
+    }
+    if (rc != SX_OK) {  // do not leave kernels running on the caller's buffer
+        for (auto& d : ctx->dev) { (void)hipStreamSynchronize(d.stream); (void)hipStreamSynchronize(d.stream_b); }
+        return rc;
     }
     ctx->stats.total_ms = now_ms() - t_begin;
-    return rc;
+    *out = res.release();
+    return SX_OK;
 }
 
 int sx_scan(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_file_id, int is_last_input_buffer,
@@ -915,7 +1034,10 @@ int sx_replay_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_fi
     std::vector<RunList> r(ctx->missions.size());
     for (size_t k = 0; k < r.size(); k++) r[k].assign(runs[k], runs[k] + n_runs[k]);
     HostBytes view(bytes ? bytes : (const uint8_t*)"");
-    return replay_all(ctx, view, whole_chunk_job(ctx, len, input_file_id, is_last_input_buffer != 0), r, out, nullptr);
+    ResultHolder res;
+    int rc = replay_all(ctx, view, whole_chunk_job(ctx, len, input_file_id, is_last_input_buffer != 0), r, &res.r->r, nullptr);
+    if (rc == SX_OK) *out = res.release();
+    return rc;
 }
 
 static int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
@@ -956,16 +1078,18 @@ static int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d
     }
     job.d_bytes = d_bytes;
     int rc;
+    ResultHolder res;
     std::vector<uint64_t> ends(nm, 0);
     if (host_bytes) {
         HostBytes view(host_bytes);
-        rc = replay_all(ctx, view, job, ctx->shard_runs, out, ends.data());
+        rc = replay_all(ctx, view, job, ctx->shard_runs, &res.r->r, ends.data());
     } else {
         SparseDeviceBytes view(ctx, d_bytes);
         rc = download_for_replay(ctx, d_bytes, buf_len, ctx->shard_runs, &view, job);
         if (rc != SX_OK) return rc;
-        rc = replay_all(ctx, view, job, ctx->shard_runs, out, ends.data());
+        rc = replay_all(ctx, view, job, ctx->shard_runs, &res.r->r, ends.data());
     }
+    if (rc == SX_OK) *out = res.release();
     for (size_t k = 0; k < nm; k++) end_pos[k] = buf_off + ends[k];
     ctx->stats.total_ms = now_ms() - t_begin;
     return rc;
@@ -1013,11 +1137,27 @@ int sx_replay_shard_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t buf_off, ui
 }
 
 uint64_t sx_result_count(const sx_result* r) { return r ? r->r.count() : 0; }
-const sx_finding* sx_result_findings(const sx_result* r) { return r ? r->r.data() : nullptr; }
+uint64_t sx_result_segments(const sx_result* r) { return r ? r->r.segs.size() : 0; }
+int sx_result_segment(const sx_result* r, uint64_t i, const sx_finding** findings, uint64_t* n_findings,
+                      const uint8_t** arena, uint64_t* arena_len) {
+    if (!r || i >= r->r.segs.size()) return SX_E_INVALID;
+    const MissionFindings& s = r->r.segs[(size_t)i];
+    if (findings) *findings = s.data();
+    if (n_findings) *n_findings = s.count();
+    if (arena) *arena = (const uint8_t*)s.strings();
+    if (arena_len) *arena_len = s.strings_len();
+    return SX_OK;
+}
+// The contiguous view: joins the segments on first use (a copy; none if there is one segment).
+const sx_finding* sx_result_findings(const sx_result* r) {
+    if (!r || !const_cast<sx_result*>(r)->r.flatten(nullptr) || r->r.segs.empty()) return nullptr;
+    return r->r.segs[0].data();
+}
 const uint8_t* sx_result_arena(const sx_result* r, uint64_t* len) {
-    if (!r) return nullptr;
-    if (len) *len = r->r.strings_len();
-    return (const uint8_t*)r->r.strings();
+    if (len) *len = 0;
+    if (!r || !const_cast<sx_result*>(r)->r.flatten(nullptr) || r->r.segs.empty()) return nullptr;
+    if (len) *len = r->r.segs[0].strings_len();
+    return (const uint8_t*)r->r.segs[0].strings();
 }
 void sx_result_free(sx_result* r) { delete r; }
 
@@ -1045,8 +1185,8 @@ void sx_free(void* p) { free(p); }
 int sx_fill_background_device(sx_ctx* ctx, void* device_bytes, uint64_t first_byte_index, uint64_t len, uint64_t seed) {
     if (!ctx || ctx->host_only) return SX_E_STATE;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_fill_background((uint8_t*)device_bytes, first_byte_index, len, seed, ctx->dev[0].stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->dev[0].stream));
+    HIP_TRY(ctx, launch_fill_background((uint8_t*)device_bytes, first_byte_index, len, seed, ctx->dev[0].stream_b));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->dev[0].stream_b));
     return SX_OK;
 }
 
@@ -1087,12 +1227,12 @@ int sx_device_read_bandwidth(sx_ctx* ctx, const void* device_bytes, uint64_t len
     HIP_TRY(ctx, launch_read_sum((const uint8_t*)device_bytes, len, d_out, d.stream, sub));  // warm-up
     float best = 1e30f;
     for (int i = 0; i < repeats; i++) {
-        HIP_TRY(ctx, hipEventRecord(d.ev0, d.stream));
+        HIP_TRY(ctx, hipEventRecord(d.slot[0].ev0, d.stream));
         HIP_TRY(ctx, launch_read_sum((const uint8_t*)device_bytes, len, d_out, d.stream, sub));
-        HIP_TRY(ctx, hipEventRecord(d.ev1, d.stream));
+        HIP_TRY(ctx, hipEventRecord(d.slot[0].ev1, d.stream));
         HIP_TRY(ctx, hipStreamSynchronize(d.stream));
         float ms = 0;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, d.ev0, d.ev1));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, d.slot[0].ev0, d.slot[0].ev1));
         if (ms < best) best = ms;
     }
     (void)hipFree(d_out);

@@ -220,14 +220,16 @@ void merge_sorted_device_runs(const DevRun* recs, size_t n, uint64_t min_chars, 
 
 // k-way merge in the reference's order: slice by slice, then (position, mission_id)
 // — src/main.rs:118-136, src/finding.rs:92-109.
+// What one call returns: the findings in the reference's print order, as one or more segments
+// (a large device-resident buffer is scanned piece by piece; every piece adds a segment).
 struct Result {
-    MissionFindings m;                 // the merged findings (vectors, or a pinned block taken over)
-    std::shared_ptr<PinnedPool> pool;  // where m.ext goes back to
-    ~Result() { if (m.ext.p && pool) pool->give(m.ext); }
-    size_t count() const { return m.count(); }
-    const sx_finding* data() const { return m.data(); }
-    const char* strings() const { return m.strings(); }
-    size_t strings_len() const { return m.strings_len(); }
+    std::vector<MissionFindings> segs;
+    std::shared_ptr<PinnedPool> pool;  // where the segments' pinned blocks go back to
+    ~Result() { release(); }
+    void release() { for (auto& s : segs) if (s.ext.p && pool) { pool->give(s.ext); s.ext = {}; } }
+    size_t count() const { size_t n = 0; for (auto& s : segs) n += s.count(); return n; }
+    // one contiguous findings array + arena (copies if there are several segments)
+    bool flatten(std::string* err);
 };
 void merge_findings(std::vector<MissionFindings>& per_mission, const std::shared_ptr<PinnedPool>& pool, Result* out);
 

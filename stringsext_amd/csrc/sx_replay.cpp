@@ -570,6 +570,8 @@ void merge_sorted_device_runs(const DevRun* v, size_t n, uint64_t min_chars, std
     }
 }
 
+// Interleave the missions' findings of one buffer (src/main.rs k-merge order: slice by slice,
+// position, then mission) and append them to `out` as one more segment.
 void merge_findings(std::vector<MissionFindings>& per, const std::shared_ptr<PinnedPool>& pool, Result* out) {
     out->pool = pool;
     size_t nonempty = 0, which = 0;
@@ -577,15 +579,17 @@ void merge_findings(std::vector<MissionFindings>& per, const std::shared_ptr<Pin
     auto release = [&](MissionFindings& mf) { if (mf.ext.p && pool) pool->give(mf.ext); mf.ext = {}; };
     if (nonempty <= 1) {  // nothing to interleave: hand the storage over as it is
         for (size_t k = 0; k < per.size(); k++) if (!(nonempty == 1 && k == which)) release(per[k]);
-        if (nonempty == 1) { out->m = std::move(per[which]); per[which].ext = {}; }
+        if (nonempty == 1) { out->segs.push_back(std::move(per[which])); per[which].ext = {}; }
         return;
     }
+    out->segs.emplace_back();
+    MissionFindings& m = out->segs.back();
     size_t total = 0, bytes = 0;
     for (auto& mf : per) { total += mf.count(); bytes += mf.strings_len(); }
-    out->m.v.reserve(total);
-    out->m.arena.reserve(bytes);
+    m.v.reserve(total);
+    m.arena.reserve(bytes);
     std::vector<size_t> idx(per.size(), 0), base(per.size(), 0);
-    for (size_t k = 0; k < per.size(); k++) { base[k] = out->m.arena.size(); out->m.arena.append(per[k].strings(), per[k].strings_len()); }
+    for (size_t k = 0; k < per.size(); k++) { base[k] = m.arena.size(); m.arena.append(per[k].strings(), per[k].strings_len()); }
     for (;;) {
         int best = -1;
         for (size_t k = 0; k < per.size(); k++) {
@@ -598,16 +602,37 @@ void merge_findings(std::vector<MissionFindings>& per, const std::shared_ptr<Pin
         if (best < 0) break;
         sx_finding f = per[best].data()[idx[best]++];
         f.str_off += (uint32_t)base[best];
-        out->m.v.push_back(f);
+        m.v.push_back(f);
     }
     for (auto& mf : per) release(mf);
+}
+
+bool Result::flatten(std::string* err) {
+    if (segs.size() <= 1) return true;
+    size_t total = 0, bytes = 0;
+    for (auto& s : segs) { total += s.count(); bytes += s.strings_len(); }
+    if (bytes > 0xFFFFFFFFull) { if (err) *err = "more than 4 GiB of strings: read the result segment by segment"; return false; }
+    MissionFindings m;
+    m.v.reserve(total);
+    m.arena.reserve(bytes);
+    for (auto& s : segs) {
+        const uint32_t base = (uint32_t)m.arena.size();
+        m.arena.append(s.strings(), s.strings_len());
+        const sx_finding* f = s.data();
+        for (size_t i = 0, n = s.count(); i < n; i++) { m.v.push_back(f[i]); m.v.back().str_off += base; }
+    }
+    release();
+    segs.clear();
+    segs.push_back(std::move(m));
+    return true;
 }
 
 void print_findings(const std::vector<Mission>& missions, const Result& r, int n_inputs, int radix, bool no_metadata,
                     std::string* out) {
     char num[40];
-    for (size_t fi = 0; fi < r.count(); fi++) {
-        const sx_finding& f = r.data()[fi];
+    for (const MissionFindings& seg : r.segs)
+    for (size_t fi = 0; fi < seg.count(); fi++) {
+        const sx_finding& f = seg.data()[fi];
         const Mission* m = nullptr;
         for (const Mission& c : missions) if (c.c.mission_id == f.mission_id) { m = &c; break; }
         out->push_back('\n');  // src/finding.rs:113
@@ -630,7 +655,7 @@ void print_findings(const std::vector<Mission>& missions, const Result& r, int n
                 out->append(")\t");
             }
         }
-        out->append(r.strings() + f.str_off, f.str_len);
+        out->append(seg.strings() + f.str_off, f.str_len);
     }
 }
 

@@ -172,6 +172,16 @@ def test_large_input_properties():
     r1 = sc.scan_device(d, n, file_id=1)
     a = r1.findings()
     sc.reset()
+    # pieces (scan kernels queued two deep) must not matter
+    import os
+    os.environ["SX_PIECE_MIB"] = "96"
+    try:
+        rp = sc.scan_device(d, n, file_id=1)
+        assert len(rp.segments()) > 1 and rp.findings() == a
+        rp.free()
+    finally:
+        del os.environ["SX_PIECE_MIB"]
+    sc.reset()
     # sub-chunk size must not matter; neither must scanning the same bytes again
     sc_b = sx.Scanner(ms, device=0, subchunk_bytes=1 << 20)
     b = sc_b.scan_device(d, n, file_id=1).findings()
@@ -243,3 +253,30 @@ def test_dense_strings_device_replay_and_stitch(max_gap, opts, monkeypatch):
         assert got == want, (max_gap, chunk)
     monkeypatch.setenv("SX_HOST_STITCH", "1")
     assert run_cli_product(ms, [data], radix="x", device=0, device_replay=True) == want
+
+
+@pytest.mark.parametrize("device_replay", [None, True, False])
+def test_pieces_pipeline_equals_oracle(device_replay, monkeypatch):
+    """A large buffer is scanned piece by piece with the scan kernels queued two deep
+    (scan_common); forced here with 1 MiB pieces.  Host-resident and device-resident input,
+    several missions with findings (k-merge per piece), strings crossing piece edges."""
+    monkeypatch.setenv("SX_PIECE_MIB", "1")
+    rng = random.Random(4242)
+    ms = rc.missions(encodings=["utf-8", "utf-16le", "ascii"], chars_min="5")
+    data = bytearray(synth(rng, (9 << 20) + 4096 * 5 + 123, 1 / 700))
+    for edge in range(1 << 20, len(data), 1 << 20):   # strings over the piece edges
+        data[edge - 40:edge + 40] = ("edge%08d-" % edge).encode() * 6 + b"01234567"
+        data[edge + 4096 - 3:edge + 4096 + 9] = "żółw-żółw".encode("utf-16-le")[:12]
+    data = bytes(data)
+    want = sxo.run_cli(ms, [data], radix="x")
+    got = run_cli_product(ms, [data], radix="x", device=0, device_replay=device_replay)
+    assert got == want
+    sc = sx.Scanner(ms, device=0, device_replay=device_replay)
+    d = sc.alloc(len(data)); sc.upload(d, data)
+    res = sc.scan_device(d, len(data), file_id=1)
+    assert len(res.segments()) > 1
+    assert sx.OUTPUT_BOM + res.printed(n_inputs=1, radix="x") + b"\n" == want
+    seg_view = res.findings()
+    fb, arena = res.raw()           # joins the segments
+    assert len(res.segments()) == 1 and res.findings() == seg_view and len(fb) == len(seg_view) * 32
+    sc.free(d); sc.close()
