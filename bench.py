@@ -3,8 +3,9 @@
 background, `-e utf-8 -e utf-16le -e utf-16be -n 10 -u African`, three concurrent mission
 streams), one process per GPU.
 
-A step = one pass of the hot path (sx_scan_device: three HIP scan kernels on three streams
-+ exact host replay -> findings in reference order) over the rank's HBM-resident shard.
+A step = one pass of the hot path (sx_scan_device: one HIP scan kernel per mission, records sorted
+and joined on the device, exact replay of the regions around long runs on the device -> findings in
+reference order in pinned host memory) over the rank's HBM-resident shard.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
 (HIP-event kernel time vs the 8 TB/s HBM peak) and `cpu_baseline` (the oracle, the only
 runnable restatement of the reference, on a bounded sample).
@@ -142,15 +143,15 @@ def main():
         value = total_bytes / dt / (1 << 30)
         # Dominant kernel = the scan kernels, one launch per mission per step, each reading the
         # whole shard once (algorithmic bytes per launch = nbytes, SURVEY.md §8d: 1 byte per
-        # input byte x Mission pass; writes ~0).  They run concurrently on three streams and
-        # share the HBM, so the roofline figure is the aggregate: (missions x nbytes) over the
-        # span from the first launch to the last completion, HIP events on the mission streams.
-        span_ms = max(kernel_ms)  # concurrent streams: the longest kernel spans the group
-        agg_gbs = len(missions) * nbytes / (span_ms * 1e-3) / 1e9
+        # input byte x Mission pass; writes ~0).  The library queues them in ONE stream, so the
+        # roofline figure is the average over the launches: (missions x nbytes) / sum of the
+        # launch durations, HIP events around every launch on the scan stream.  (With
+        # SX_MISSION_STREAMS=1 they overlap on a stream each and the span is the longest one.)
+        span_ms = max(kernel_ms) if os.environ.get("SX_MISSION_STREAMS") else sum(kernel_ms)
         roofline = {
             "bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "sx::scan_kernel<*> x%d concurrent streams" % len(missions),
+            "kernel": "sx::scan_kernel<Utf8Range2|Utf16Range>, %d launches per step, average" % len(missions),
             "algorithmic_bytes_per_launch": nbytes,
             "per_kernel_ms": [round(x, 3) for x in kernel_ms],
             "per_kernel_gbs": [round(nbytes / (x * 1e-3) / 1e9, 1) if x > 0 else None for x in kernel_ms],

@@ -463,7 +463,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         P.lo = job.lo[k]; P.hi = job.hi; P.consumed0 = job.consumed0[k]; P.stream0 = job.stream0[k];
         P.slice_base = job.slice_base; P.encoding = m.c.encoding; P.table = d.d_table;
         P.chars_min_nb = m.c.chars_min_nb; P.same_block = m.c.require_same_unicode_block; P.q = (uint32_t)m.q;
-        P.W = (uint32_t)W; P.long_run = m.long_run; P.grep_char = m.c.grep_char; P.mission_id = m.c.mission_id;
+        P.W = (uint32_t)W; P.long_run = m.long_run; P.skip = getenv("SX_NO_REPLAY_SKIP") ? 0u : 1u; P.grep_char = m.c.grep_char; P.mission_id = m.c.mission_id;
         P.file_id = job.file_id; P.af_lo = m.c.af_lo; P.af_hi = m.c.af_hi; P.ubf = m.c.ubf;
         void* cache = nullptr;
         if (dev_stitch && n <= (32u << 20) && !getenv("SX_NO_REPLAY_CACHE")) {

@@ -74,6 +74,7 @@ struct ReplayParams {
     uint32_t encoding;        // SX_ENC_*
     const uint16_t* table;    // device: 128-entry single-byte table or nullptr
     uint32_t chars_min_nb, same_block, q, W, long_run;
+    uint32_t skip;            // 1: take the shortcuts of sx_replay_core.hpp (0: decode every byte, for comparison)
     int32_t grep_char, mission_id, file_id;
     uint64_t af_lo, af_hi, ubf;
 };

@@ -135,8 +135,8 @@ public:
     uint64_t run(ScannerState& st, uint64_t lo, uint64_t hi, bool entry_exact, bool owns_tail,
                  MissionFindings* out, std::vector<RegionLog>* log) {
         st_ = &st; out_ = out; hi_ = hi; owns_tail_ = owns_tail;
-        ri_ = 0;
-        while (ri_ < n_runs_ && runs_[ri_].end <= lo) ri_++;
+        // first run that ends after lo (runs are disjoint and sorted: so are their ends)
+        ri_ = (uint64_t)(std::partition_point(runs_, runs_ + n_runs_, [lo](const sx_run& r) { return r.end <= lo; }) - runs_);
         strict_ = entry_exact && !st.clean();  // exact carried state: follow it until it is clean
         // no exact state here: re-derive decoder state AND leftover presence from the bytes before lo
         if (!entry_exact) derive_state(lo, lo >= 9 ? lo - 9 : 0, st.decoder);

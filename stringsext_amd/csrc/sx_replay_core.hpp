@@ -213,6 +213,122 @@ SXD bool dsplit_next(const ReplayParams& m, DSplit& it, DChunk& out) {
 // ------------------------------------------------------------------------------------------
 SXD u64 win_start(u64 p, u32 W) { const u64 s = p / kSliceLen * kSliceLen; return s + (p - s) / W * W; }
 
+// ------------------------------------------------------------------------------------------
+// Shortcuts through bytes that cannot matter (device replay only; the host replayer decodes
+// everything, and the two must agree — tests/test_replay_core.py, tests/test_gpu_parity.py).
+//
+// Between decoder calls the reference's loop state is "clean" when nothing is carried:
+// no leftover, no pending cut, decoder idle.  From a clean call start p:
+//  (A) if the next long run starts at rs > p inside this window, every decoder call that ends
+//      before the run's own call yields nothing and leaves the state clean again (a call that
+//      yields needs >= min(chars_min_nb, q) accepted chars in a row = a long run, and stage A
+//      reported none there), so the replay may jump to the start of the run's call: the first
+//      byte vs such that [vs, rs) decodes without error — found by walking BACK from rs;
+//  (B) if no long run starts in the rest of this window, nothing is emitted up to its end and
+//      the state there is what a region start derives (derive_at), so the replay jumps there.
+// ------------------------------------------------------------------------------------------
+SXD bool ddec_idle(const DDecoder& d) {
+    if (d.enc == 1) return d.needed == 0;
+    if (d.enc == 2 || d.enc == 3) return d.lead_byte < 0 && d.lead_surrogate == 0 && !d.pending_bmp;
+    return true;
+}
+
+// Start of the decoder call that contains the char boundary rs, not before the call start p.
+// Returns p if everything in [p, rs) is valid (the call at p is the one).
+SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs) {
+    const u8* bytes = P.data;
+    u64 b = rs;
+    if (P.encoding == 1) {
+        while (b > p) {
+            const u8 x = bytes[b - 1];
+            if (x < 0x80) { b--; continue; }
+            if (x >= 0xC0) break;  // a lead right before a boundary: truncated sequence
+            // continuation bytes: find the lead
+            u32 k = 1;
+            u64 j = b - 1;
+            bool found = false;
+            while (j > p && k <= 3) {
+                j--;
+                const u8 y = bytes[j];
+                if ((y & 0xC0) == 0x80) { k++; continue; }
+                found = true;
+                break;
+            }
+            if (!found) break;  // ran into p (or too many continuation bytes): stray continuation bytes after p
+            const u8 lead = bytes[j];
+            u32 need = 0;
+            u8 lo = 0x80, hi = 0xBF;
+            if (lead >= 0xC2 && lead <= 0xDF) need = 1;
+            else if (lead >= 0xE0 && lead <= 0xEF) { need = 2; if (lead == 0xE0) lo = 0xA0; if (lead == 0xED) hi = 0x9F; }
+            else if (lead >= 0xF0 && lead <= 0xF4) { need = 3; if (lead == 0xF0) lo = 0x90; if (lead == 0xF4) hi = 0x8F; }
+            if (need != k) break;
+            const u8 second = bytes[j + 1];
+            if (second < lo || second > hi) break;
+            b = j;
+        }
+        return b;
+    }
+    if (P.encoding == 2 || P.encoding == 3) {
+        const bool be = P.encoding == 3;
+        if ((rs - p) & 1) return p;  // not on the unit grid of the call at p: no shortcut
+        while (b >= p + 2) {
+            const u32 u = be ? ((u32)bytes[b - 2] << 8) | bytes[b - 1] : ((u32)bytes[b - 1] << 8) | bytes[b - 2];
+            if ((u & 0xF800) != 0xD800) { b -= 2; continue; }
+            if ((u & 0xFC00) == 0xDC00) {  // low surrogate: valid only right after a high one
+                if (b >= p + 4) {
+                    const u32 h = be ? ((u32)bytes[b - 4] << 8) | bytes[b - 3] : ((u32)bytes[b - 3] << 8) | bytes[b - 4];
+                    if ((h & 0xFC00) == 0xD800) { b -= 4; continue; }
+                }
+                break;
+            }
+            // an unpaired high surrogate: the decoder reads on into the unit after it before it
+            // reports the error, so the replay starts at the surrogate itself
+            b -= 2;
+            break;
+        }
+        return b;
+    }
+    while (b > p) {
+        const u8 x = bytes[b - 1];
+        if (x >= 0x80 && P.table && P.table[x - 0x80] == 0) break;
+        b--;
+    }
+    return b;
+}
+
+// The state the reference carries into the window that starts at `at`, when nothing long
+// crosses `at` (RangeReplay::derive_state): the decoder's pending bytes, and one accepted char
+// as leftover if it is the last thing delivered before `at`.  Decodes from max(at - 8, floor).
+SXD u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& dec, u8* ob) {
+    const u8* bytes = P.data;
+    ddec_reset(dec, P.encoding, P.table);
+    u64 p = at >= 8 ? at - 8 : 0;
+    if ((P.encoding == 2 || P.encoding == 3) && ((P.stream0 + p) & 1)) p = p ? p - 1 : p + 1;
+    if (p < floor) p = floor;
+    if (p > at) p = at;
+    u8 sink[40], last[4];
+    u32 last_len = 0;
+    if (p < at) {
+        const u32 n = (u32)(at - p);
+        u32 k = 0;
+        for (;;) {
+            const DStep r = ddecode(dec, bytes + p + k, n - k, sink, sizeof sink, false);
+            k += r.read;
+            for (u32 w = 0; w < r.written;) {
+                const u8 lead = sink[w];
+                const u32 cl = lead < 0x80 ? 1 : lead < 0xE0 ? 2 : lead < 0xF0 ? 3 : 4;
+                if (pass_lead(P, lead)) { for (u32 t = 0; t < cl; t++) last[t] = sink[w + t]; last_len = cl; }
+                else last_len = 0;
+                w += cl;
+            }
+            if (r.result == RES_INPUT_EMPTY) break;
+            if (r.result == RES_MALFORMED) last_len = 0;
+        }
+    }
+    for (u32 t = 0; t < last_len; t++) ob[t] = last[t];
+    return last_len;
+}
+
 constexpr u32 kObCap = 4 * 64 + 3 * 128 + 16;  // leftover (<= 4q bytes) + one window's output; q <= 64
 
 // One region.  MODE 0: count only; 1: write findings and strings at fout/aout; 2: count, and
@@ -229,34 +345,7 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
     DDecoder dec;
 
     // ---- derive the state the reference would carry into `want` (RangeReplay::derive_state)
-    u32 leftover_len = 0;
-    {
-        ddec_reset(dec, P.encoding, P.table);
-        u64 p = want >= 8 ? want - 8 : 0;
-        if ((P.encoding == 2 || P.encoding == 3) && ((P.stream0 + p) & 1)) p = p ? p - 1 : p + 1;
-        if (p > want) p = want;
-        u8 sink[40], last[4];
-        u32 last_len = 0;
-        if (p < want) {
-            const u32 n = (u32)(want - p);
-            u32 k = 0;
-            for (;;) {
-                const DStep r = ddecode(dec, bytes + p + k, n - k, sink, sizeof sink, false);
-                k += r.read;
-                for (u32 w = 0; w < r.written;) {
-                    const u8 lead = sink[w];
-                    const u32 cl = lead < 0x80 ? 1 : lead < 0xE0 ? 2 : lead < 0xF0 ? 3 : 4;
-                    if (pass_lead(P, lead)) { for (u32 t = 0; t < cl; t++) last[t] = sink[w + t]; last_len = cl; }
-                    else last_len = 0;
-                    w += cl;
-                }
-                if (r.result == RES_INPUT_EMPTY) break;
-                if (r.result == RES_MALFORMED) last_len = 0;
-            }
-        }
-        for (u32 t = 0; t < last_len; t++) ob[t] = last[t];
-        leftover_len = last_len;
-    }
+    u32 leftover_len = derive_at(P, want, 0, dec, ob);
     bool maybe_cut = false;
 
     u64 ri = i;  // first run not yet behind us
@@ -295,6 +384,21 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
             if (++windows > kMaxRegionWindows) { status = kRegionTooLong; done = true; break; }
             u32 dout = leftover_len;
             for (;;) {  // 'decoder
+                if (P.skip && leftover_len == 0 && !maybe_cut && din < dend && ddec_idle(dec)) {
+                    const u64 p = soff + din, wend = soff + dend;
+                    while (ri < P.n_runs && P.runs[ri].end <= p) ri++;
+                    const u64 rs = ri < P.n_runs ? P.runs[ri].start : ~0ull;
+                    if (rs >= wend) {  // (B) nothing long starts in the rest of this window
+                        leftover_len = derive_at(P, wend, p, dec, ob);
+                        dout = leftover_len;
+                        din = dend;
+                        break;
+                    }
+                    if (rs > p) {      // (A) jump to the call that holds the next long run
+                        const u64 vs = call_start_before(P, p, rs);
+                        if (vs > p) din = (u32)(vs - soff);
+                    }
+                }
                 const DStep r = ddecode(dec, bytes + soff + din, dend - din, ob + dout, kObCap - dout, false);
                 if (r.result == RES_OUTPUT_FULL) { status = kRegionTooLong; done = true; break; }
                 u8 precision = SX_PRECISION_EXACT;

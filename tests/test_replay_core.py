@@ -23,7 +23,7 @@ class ReplayParams(C.Structure):
                 ("lo", C.c_uint64), ("hi", C.c_uint64), ("consumed0", C.c_uint64), ("stream0", C.c_uint64),
                 ("slice_base", C.c_uint32), ("encoding", C.c_uint32), ("table", C.POINTER(C.c_uint16)),
                 ("chars_min_nb", C.c_uint32), ("same_block", C.c_uint32), ("q", C.c_uint32), ("W", C.c_uint32),
-                ("long_run", C.c_uint32), ("grep_char", C.c_int32), ("mission_id", C.c_int32), ("file_id", C.c_int32),
+                ("long_run", C.c_uint32), ("skip", C.c_uint32), ("grep_char", C.c_int32), ("mission_id", C.c_int32), ("file_id", C.c_int32),
                 ("af_lo", C.c_uint64), ("af_hi", C.c_uint64), ("ubf", C.c_uint64)]
 
 
@@ -59,6 +59,33 @@ def ws(p, W):
     return s + (p - s) // W * W
 
 
+def tricky(rng, n):
+    """Strings framed by the byte patterns the shortcuts must get right: truncated and overlong
+    UTF-8, stray continuation bytes, unpaired surrogates in front of BMP units, valid-but-
+    rejected chars inside a decoder call, runs at window and slice edges."""
+    frames = [b"\xe2\x82", b"\xf0\x9f\x98", b"\x80\x80", b"\xc0\xaf", b"\xed\xa0\x80", b"\xf4\x90", b"\x00\xd8", b"\xd8\x00",
+              b"\x3d\xd8", b"\xd8\x3d", b"\x00\xdc", b"\x01\x02\x03", b"\t\x0b", b"\xc2\x85", b"\xe2\x80\xa8", b"\xff", b"\xfe\xff", b""]
+    words = ["hello world!", "Ünïcödé-ßtring", "доброе утро", "a", "ab", "0123456789" * 8, "שלום עולם", "x" * 63, "y" * 64, "z" * 65,
+             "mixed Ω≈ç√∫ text", "😀😀 astral 𝔘𝔫𝔦"]
+    out = bytearray()
+    while len(out) < n:
+        w = rng.choice(words)
+        enc = rng.choice(["utf-8", "utf-8", "utf-16-le", "utf-16-be", "koi8-r", "cp1252"])
+        try:
+            b = w.encode(enc)
+        except UnicodeEncodeError:
+            b = w.encode("utf-8")
+        out += rng.choice(frames) + b + rng.choice(frames)
+        r = rng.random()
+        if r < 0.3:
+            out += rng.randbytes(rng.randrange(1, 40))
+        elif r < 0.4:
+            out += b"\x00" * (-len(out) % 128)          # next string starts a window
+        elif r < 0.45:
+            out += b"\xff" * ((-len(out) - 5) % 4096)   # next string straddles a slice edge
+    return bytes(out[:n])
+
+
 CONFIGS = [
     dict(encodings=["utf-8"], chars_min="10", unicode_block_filter="African"),
     dict(encodings=["utf-8"], chars_min="4"),
@@ -75,7 +102,8 @@ CONFIGS = [
 
 @pytest.mark.parametrize("flags", CONFIGS, ids=lambda f: "-".join(f["encodings"]) + "-n" + f["chars_min"])
 @pytest.mark.parametrize("parity", [0, 1])
-def test_device_replay_core_equals_host_replayer(core, flags, parity):
+@pytest.mark.parametrize("skip", [1, 0], ids=["shortcuts", "every-byte"])
+def test_device_replay_core_equals_host_replayer(core, flags, parity, skip):
     rng = random.Random(hash(str(flags)) & 0xFFFF)
     m = rc.missions(**flags)[0]
     if m["output_line_char_nb_max"] > 64:
@@ -84,13 +112,13 @@ def test_device_replay_core_equals_host_replayer(core, flags, parity):
     long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
     table = sb_table(m["encoding"]) if m["encoding"] >= 16 else None
     for data in (synth(rng, 60_000, 1 / 150), soup(rng, 30_001), synth(rng, 20_000, 1 / 2000),
-                 bytes(rng.choice(b"abcdefgh \x00") for _ in range(9_000))):
+                 bytes(rng.choice(b"abcdefgh \x00") for _ in range(9_000)), tricky(rng, 40_000)):
         stream0 = parity  # odd stream offset of buffer byte 0 shifts the UTF-16 unit grid
         runs = sxo.runs(m, data, stream_parity=stream0 & 1, min_chars=long_run)
         arr = (sx.Run * max(1, len(runs)))(*[sx.Run(*t) for t in runs])
         P = ReplayParams(data, len(data), arr, len(runs), 0, len(data), m["counter_offset"] + stream0, stream0, 0,
                          m["encoding"], table, m["chars_min_nb"], int(m["require_same_unicode_block"]),
-                         m["output_line_char_nb_max"], W, long_run, -1 if m["grep_char"] is None else m["grep_char"],
+                         m["output_line_char_nb_max"], W, long_run, skip, -1 if m["grep_char"] is None else m["grep_char"],
                          0, 1, m["af"] & (2**64 - 1), m["af"] >> 64, m["ubf"])
         sc = sx.Scanner([m], device=sx.SX_HOST_ONLY)
         fbuf = (sx.Finding * 4096)()
