@@ -148,6 +148,7 @@ def main():
         # launch durations, HIP events around every launch on the scan stream.  (With
         # SX_MISSION_STREAMS=1 they overlap on a stream each and the span is the longest one.)
         span_ms = max(kernel_ms) if os.environ.get("SX_MISSION_STREAMS") else sum(kernel_ms)
+        agg_gbs = len(missions) * nbytes / (span_ms * 1e-3) / 1e9
         roofline = {
             "bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "traffic": None,

@@ -113,10 +113,12 @@ struct sx_ctx {
     std::string err;
     sx_stats stats{};
     hipStream_t scan_stream = nullptr, post_stream = nullptr;
+    unsigned n_cus = 256, scan_blocks_per_cu = 8;
     uint8_t* d_input = nullptr;  // staging for host input
     uint64_t d_input_cap = 0;
     uint64_t ondemand_fetches = 0;
     // grow-only scratch reused by every call (pinned host memory: D2H at full PCIe rate)
+    std::vector<uint64_t> last_runs;  // long runs per mission of the last scanned buffer: busiest mission scans first
     std::vector<RunList> shard_runs;  // device runs of the last sx_scan_shard* buffer (reuse_runs)
     bool shard_runs_valid = false;
     uint8_t* h_pin = nullptr;   uint64_t h_pin_cap = 0;
@@ -140,6 +142,12 @@ class SparseDeviceBytes : public ByteView {
 public:
     SparseDeviceBytes(sx_ctx* ctx, const uint8_t* d_base) : ctx_(ctx), d_base_(d_base) {}
     void add(uint64_t lo, uint64_t hi, const uint8_t* p) { segs_.push_back({ lo, hi, p }); }
+    // same, but the bytes are copied (the caller's buffer may be reused while the view lives)
+    void add_copy(uint64_t lo, uint64_t hi, const uint8_t* p) {
+        owned_.emplace_back(p, p + (hi - lo));
+        segs_.push_back({ lo, hi, owned_.back().data() });
+    }
+    bool empty() const { return segs_.empty(); }
     const uint8_t* span(uint64_t off, size_t n, size_t* hint) override {
         // segments are sorted and disjoint; the caller moves forward, so look near its cursor first
         size_t a = *hint < segs_.size() ? *hint : 0;
@@ -169,7 +177,7 @@ private:
     sx_ctx* ctx_;
     const uint8_t* d_base_;
     std::vector<Seg> segs_;
-    std::deque<std::vector<uint8_t>> extra_;
+    std::deque<std::vector<uint8_t>> extra_, owned_;
     std::mutex mu_;
 };
 
@@ -245,6 +253,11 @@ ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const 
     p.capacity = s.capacity; p.recs = s.d_recs; p.counters = s.d_counters;
     p.traversal = (ctx->opt.flags & SX_OPT_TILE_TRAVERSAL) ? 1u : 0u;
     if (const char* e = getenv("SX_TRAVERSAL")) p.traversal = (uint32_t)atoi(e);
+    // Blocks (of 4 wavefronts) per CU the scan kernel occupies.  8 fills every wave slot; with
+    // fewer the kernel runs as a persistent grid and leaves the rest to the second stream
+    // (sort/join and stage B of a mission that is already scanned).
+    unsigned occ = ctx->scan_blocks_per_cu;
+    p.persistent = (occ >= 1 && occ < 8) ? occ * ctx->n_cus : 0u;
     return p;
 }
 
@@ -279,6 +292,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         MissionDev& d = ctx->dev[(size_t)which[k]];
         ScanSlot& s = d.slot[si];
         HIP_TRY(ctx, hipEventSynchronize(s.ev1));
+        const double t_ev = now_ms();
         float ms = 0;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, s.ev0, s.ev1));
         if (which[k] < 16) ctx->stats.kernel_ms[which[k]] += ms;
@@ -296,6 +310,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream_b));
         }
         const double tc0 = now_ms();
+        if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   mission %d: kernel done at +%.2f ms, counters at +%.2f ms\n", which[k], t_ev - t0, tc0 - t0);
         const uint32_t nrec = counters[0];
         const uint32_t join_min = getenv("SX_DEVICE_JOIN_MIN") ? (uint32_t)atoi(getenv("SX_DEVICE_JOIN_MIN")) : 65536u;
         const bool dev_sorted = nrec >= join_min && nrec > 0;  // worth a handful of small kernels
@@ -307,10 +322,12 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             int rc = ensure_scratch(ctx, sb); if (rc != SX_OK) return rc;
             rc = ensure_rp(ctx, d, 0, (uint64_t)nrec * sizeof(sx_run)); if (rc != SX_OK) return rc;
             HIP_TRY(ctx, sort_records(s.d_recs, nrec, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
+            if (getenv("SX_TIMING2")) { HIP_TRY(ctx, hipStreamSynchronize(d.stream_b)); fprintf(stderr, "[sx]   sort done +%.2f ms\n", now_ms() - tc0); }
             HIP_TRY(ctx, merge_sorted_records(s.d_recs, nrec, min_chars[k], ctx->d_scratch, ctx->d_scratch_cap,
                                               (sx_run*)d.d_rp[0], s.d_counters + 2, d.stream_b));
             HIP_TRY(ctx, hipEventRecord(s.ev_free, d.stream_b));
             s.free_pending = true;
+            if (getenv("SX_TIMING2")) { HIP_TRY(ctx, hipStreamSynchronize(d.stream_b)); fprintf(stderr, "[sx]   join done +%.2f ms\n", now_ms() - tc0); }
             uint32_t nruns = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&nruns, s.d_counters + 2, 4, hipMemcpyDeviceToHost, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
@@ -632,8 +649,16 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
 // Stage B for all missions: every (mission, part) pair is one task for a small thread pool;
 // part 0 of a mission starts from its entry state, the others speculate, and the per-mission
 // stitch verifies/repairs them serially.
+// Missions whose stage B already ran (on the device, while later missions were still being scanned).
+struct PreReplayed {
+    std::vector<char> done;
+    std::vector<MissionFindings> per;
+    std::vector<uint64_t> ends;
+    explicit PreReplayed(size_t nm) : done(nm, 0), per(nm), ends(nm, 0) {}
+};
+
 int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::vector<RunList>& runs,
-               Result* into, uint64_t* end_pos) {
+               Result* into, uint64_t* end_pos, PreReplayed* pre = nullptr) {
     const double t0 = now_ms();
     const size_t nm = ctx->missions.size();
     const unsigned nthreads = replay_threads(ctx);
@@ -642,7 +667,8 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
     std::vector<std::pair<size_t, size_t>> tasks;
     std::vector<char> on_device(nm, 0);
     uint64_t host_runs = 0;
-    for (size_t k = 0; k < nm; k++) on_device[k] = device_replay_wanted(ctx, job, k, runs[k].size());
+    for (size_t k = 0; k < nm; k++)
+        on_device[k] = (pre && pre->done[k]) ? 2 : (device_replay_wanted(ctx, job, k, runs[k].size()) ? 1 : 0);
     for (size_t k = 0; k < nm; k++) {
         if (on_device[k]) continue;
         // parts are speculative restarts: worth a thread each only if they hold real work
@@ -676,11 +702,13 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
     const double t_parts = now_ms();
     std::vector<MissionFindings> per(nm);
     std::vector<uint64_t> ends(nm, 0);
-    for (size_t k = 0; k < nm; k++)
-        if (on_device[k]) {
+    for (size_t k = 0; k < nm; k++) {
+        if (on_device[k] == 2) { per[k] = std::move(pre->per[k]); pre->per[k].ext = {}; ends[k] = pre->ends[k]; }
+        else if (on_device[k]) {
             int rc = device_replay_mission(ctx, k, bytes, job, runs[k], &per[k], &ends[k]);
             if (rc != SX_OK) return rc;
         }
+    }
     auto stitch = [&](size_t k) {
         if (on_device[k]) return;
         ScannerState st = ctx->states[k];
@@ -764,8 +792,15 @@ int sx_create(sx_ctx** out, const sx_mission* missions, int n_missions, int hip_
     if ((e = hipSetDevice(hip_device)) != hipSuccess) return fail("hipSetDevice", e);
     ctx->dev.resize((size_t)n_missions);
     const uint32_t cap = ctx->opt.record_capacity ? ctx->opt.record_capacity : (1u << 20);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hip_device) == hipSuccess && cus > 0) ctx->n_cus = (unsigned)cus;
+        if (const char* e2 = getenv("SX_SCAN_BLOCKS_PER_CU")) ctx->scan_blocks_per_cu = (unsigned)atoi(e2);
+        if (const char* e2 = getenv("SX_SCAN_CUS")) ctx->n_cus = (unsigned)std::max(1, atoi(e2));  // tests: persistent grid on small inputs
+    }
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = higher priority
+    if (const char* e = getenv("SX_PRIO")) { (void)sscanf(e, "%d,%d", &prio_lo, &prio_hi); fprintf(stderr, "[sx] stream priorities: scan %d, post %d\n", prio_lo, prio_hi); }
     // Two streams for the whole context: the scan kernels of all missions queue up in one (a
     // kernel alone already fills the device, and HIP multiplexes streams onto few hardware
     // queues: more streams only alias), everything else runs in a second, higher-priority one
@@ -836,19 +871,30 @@ int sx_reset(sx_ctx* ctx) {
 }
 
 // Device-resident input: download only the byte ranges the replay will look at.
+// Downloads what the host part of stage B reads: the buffer's first and last 64 KiB ("base",
+// entry and exit of every mission) and the replay ranges of the missions the host replays.
+// runs == nullptr: the base only, copied into the view.  skip: missions not to plan for; if the
+// plan then holds nothing beyond the base and `base_view` already has it, nothing is done and
+// *used_base is set.
 static int download_for_replay(sx_ctx* ctx, const uint8_t* d_bytes, uint64_t len,
-                               const std::vector<RunList>& runs, SparseDeviceBytes* view,
-                               const ReplayJob& job) {
-    const size_t nm = ctx->missions.size();
+                               const std::vector<RunList>* runs_opt, SparseDeviceBytes* view,
+                               const ReplayJob& job, const std::vector<char>* skip = nullptr,
+                               bool* used_base = nullptr) {
+    const size_t nm = runs_opt ? ctx->missions.size() : 0;
+    static const std::vector<RunList> no_runs;
+    const std::vector<RunList>& runs = runs_opt ? *runs_opt : no_runs;
+    if (used_base) *used_base = false;
         const double t0 = now_ms();
         std::vector<std::pair<uint64_t, uint64_t>> rg;
         // what the host always looks at: the chunk's first windows and its tail
         rg.emplace_back(0, std::min<uint64_t>(len, 64 * 1024));
         if (len > 64 * 1024) rg.emplace_back(len - 64 * 1024, len);
         for (size_t k = 0; k < nm; k++) {
-            if (device_replay_wanted(ctx, job, k, runs[k].size())) continue;  // stage B of this mission runs on the device
+            if ((skip && (*skip)[k]) || device_replay_wanted(ctx, job, k, runs[k].size())) continue;  // stage B of this mission runs on the device
             const size_t before = rg.size();
-            replay_ranges(ctx->missions[k], ctx->states[k], len, runs[k].data(), runs[k].size(), replay_threads(ctx), &rg);
+            // same partition count as replay_all will use
+            const unsigned want_parts = (unsigned)std::min<uint64_t>(replay_threads(ctx), std::max<uint64_t>(1, runs[k].size() / 512));
+            replay_ranges(ctx->missions[k], ctx->states[k], len, runs[k].data(), runs[k].size(), want_parts, &rg);
             // a mission's ranges come out almost sorted (runs are); fix up, then merge the sorted lists
             if (!std::is_sorted(rg.begin() + before, rg.end())) std::sort(rg.begin() + before, rg.end());
             std::inplace_merge(rg.begin(), rg.begin() + before, rg.end());
@@ -859,6 +905,12 @@ static int download_for_replay(sx_ctx* ctx, const uint8_t* d_bytes, uint64_t len
         for (auto& r : rg) {
             if (!mg.empty() && r.first <= mg.back().second) mg.back().second = std::max(mg.back().second, r.second);
             else mg.push_back(r);
+        }
+        if (used_base) {  // nothing beyond the base (already in the caller's view)?
+            bool inside = true;
+            for (auto& r : mg)
+                inside = inside && (r.second <= std::min<uint64_t>(len, 64 * 1024) || (len > 64 * 1024 && r.first >= len - 64 * 1024));
+            if (inside) { *used_base = true; return SX_OK; }
         }
         // split long ranges so that one gather wavefront never copies more than 64 KiB
         std::vector<uint64_t> seg_src, seg_dst;
@@ -890,7 +942,11 @@ static int download_for_replay(sx_ctx* ctx, const uint8_t* d_bytes, uint64_t len
             HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin, d_out, total, hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));
             uint64_t off = 0;
-            for (auto& r : mg) { view->add(r.first, r.second, ctx->h_pin + off); off += r.second - r.first; }
+            for (auto& r : mg) {
+                if (runs_opt) view->add(r.first, r.second, ctx->h_pin + off);
+                else view->add_copy(r.first, r.second, ctx->h_pin + off);
+                off += r.second - r.first;
+            }
         }
         ctx->stats.d2h_ms += now_ms() - t0;
         if (getenv("SX_TIMING"))
@@ -921,56 +977,114 @@ uint64_t piece_bytes(const sx_ctx* ctx, uint64_t len) {
 }  // namespace
 
 // One buffer, start to end: stage A on the device, stage B on device and host, the findings in
-// print order.  A large buffer is cut into pieces that behave exactly like consecutive
-// sx_scan calls (ScannerState carried from piece to piece), but their scan kernels are queued
-// two deep, so the device keeps scanning while the host finishes the piece before.
+// print order.
+//  * The missions' scan kernels queue up in one stream, busiest mission (of the last buffer)
+//    first; as soon as a mission's kernel is done its records are sorted and joined and — if its
+//    stage B runs on the device — replayed, in the second stream, while the kernels of the
+//    remaining missions still scan.  What the host replays follows when all kernels are done.
+//  * A large buffer can be cut into pieces (SX_PIECE_MIB) that behave exactly like consecutive
+//    sx_scan calls (ScannerState carried from piece to piece) with their kernels queued two deep.
 static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len, int file_id,
                        int is_last, sx_result** out) {
     const double t_begin = now_ms();
     const size_t nm = ctx->missions.size();
-    std::vector<int> which(nm);
+    std::vector<int> order(nm);
     std::vector<uint64_t> minc(nm), stream0(nm);
     for (size_t k = 0; k < nm; k++) {
-        which[k] = (int)k;
+        order[k] = (int)k;
         stream0[k] = ctx->states[k].stream_bytes;
         minc[k] = ctx->missions[k].long_run;
     }
+    if (ctx->last_runs.size() == nm)
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ctx->last_runs[(size_t)x] > ctx->last_runs[(size_t)y]; });
+    ctx->last_runs.assign(nm, 0);
     const uint64_t piece = piece_bytes(ctx, len);
     const uint64_t n_pieces = len ? (len + piece - 1) / piece : 1;
     auto piece_off = [&](uint64_t p) { return p * piece; };
     auto piece_len = [&](uint64_t p) { return std::min(piece, len - piece_off(p)); };
+    auto parity_of = [&](int k, uint64_t off) { return std::vector<uint32_t>{ (uint32_t)((stream0[(size_t)k] + off) & 1) }; };
     auto launch = [&](uint64_t p) -> int {
-        std::vector<uint32_t> parity(nm);
-        for (size_t k = 0; k < nm; k++) parity[k] = (uint32_t)((stream0[k] + piece_off(p)) & 1);
-        return stage_a_launch(ctx, which, d_bytes + piece_off(p), piece_len(p), parity, minc, (int)(p & 1));
+        for (int k : order) {
+            int rc = stage_a_launch(ctx, { k }, d_bytes + piece_off(p), piece_len(p), parity_of(k, piece_off(p)),
+                                    { minc[(size_t)k] }, (int)(p & 1));
+            if (rc != SX_OK) return rc;
+        }
+        return SX_OK;
+    };
+    auto fail = [&](int rc) {  // do not leave kernels running on the caller's buffer
+        for (auto& d : ctx->dev) { (void)hipStreamSynchronize(d.stream); (void)hipStreamSynchronize(d.stream_b); }
+        return rc;
     };
     ResultHolder res;
     int rc = SX_OK;
+    // what the host reads of piece 0 whatever the runs are (entry and exit of every mission):
+    // fetched before the kernels start, so that the copy does not queue behind them
+    std::unique_ptr<SparseDeviceBytes> base_view;
+    auto make_base = [&](uint64_t p) -> int {
+        base_view.reset();
+        if (host_bytes) return SX_OK;
+        base_view.reset(new SparseDeviceBytes(ctx, d_bytes + piece_off(p)));
+        ReplayJob none;
+        return download_for_replay(ctx, d_bytes + piece_off(p), piece_len(p), nullptr, base_view.get(), none);
+    };
+    if ((rc = make_base(0)) != SX_OK) return rc;
     uint64_t launched = 0;
     for (; launched < std::min<uint64_t>(2, n_pieces) && rc == SX_OK; launched++) rc = launch(launched);
-    for (uint64_t p = 0; p < n_pieces && rc == SX_OK; p++) {
+    if (rc != SX_OK) return fail(rc);
+    if (getenv("SX_PROBE") && ctx->d_scratch_cap >= 8192 && ctx->h_pin_cap >= 8192) {
+        // how long do small things in the second stream take while the scan kernels run?
+        hipStream_t sb = ctx->post_stream;
+        uint32_t pageable[16];
+        for (int i = 0; i < 4; i++) {
+            struct timespec ts = { 0, 2000000 }; nanosleep(&ts, nullptr);
+            double t0 = now_ms();
+            (void)launch_fill_background(ctx->d_scratch, 0, 4096, 1, sb); (void)hipStreamSynchronize(sb);
+            double t1 = now_ms();
+            (void)hipMemcpyAsync(ctx->h_pin, ctx->d_scratch, 4096, hipMemcpyDeviceToHost, sb); (void)hipStreamSynchronize(sb);
+            double t2 = now_ms();
+            (void)hipMemcpyAsync(pageable, ctx->d_scratch, sizeof pageable, hipMemcpyDeviceToHost, sb); (void)hipStreamSynchronize(sb);
+            double t3 = now_ms();
+            (void)hipMemsetAsync(ctx->d_scratch, 0, 4096, sb); (void)hipStreamSynchronize(sb);
+            double t4 = now_ms();
+            fprintf(stderr, "[sx] probe %d at +%.1f ms: tiny kernel %.3f ms, pinned d2h %.3f ms, pageable d2h %.3f ms, memset %.3f ms\n", i,
+                    t0 - t_begin, t1 - t0, t2 - t1, t3 - t2, t4 - t3);
+        }
+    }
+    for (uint64_t p = 0; p < n_pieces; p++) {
         const uint64_t off = piece_off(p), plen = piece_len(p);
-        std::vector<uint32_t> parity(nm);
-        for (size_t k = 0; k < nm; k++) parity[k] = (uint32_t)((stream0[k] + off) & 1);
-        std::vector<RunList> runs;
-        rc = stage_a_finish(ctx, which, d_bytes + off, plen, parity, minc, (int)(p & 1), &runs);
-        if (rc != SX_OK) break;
-        if (launched < n_pieces) { rc = launch(launched++); if (rc != SX_OK) break; }  // slot p&1 is free again (ev_free)
+        if (p > 0 && (rc = make_base(p)) != SX_OK) return fail(rc);
         ReplayJob job = whole_chunk_job(ctx, plen, file_id, is_last != 0 && p + 1 == n_pieces);
         job.d_bytes = d_bytes + off;
         job.slice_base = (uint32_t)(off / kInputBufLen);
-        if (host_bytes) {
-            HostBytes view(host_bytes + off);
-            rc = replay_all(ctx, view, job, runs, &res.r->r, nullptr);
-        } else {
-            SparseDeviceBytes view(ctx, d_bytes + off);
-            rc = download_for_replay(ctx, d_bytes + off, plen, runs, &view, job);
-            if (rc == SX_OK) rc = replay_all(ctx, view, job, runs, &res.r->r, nullptr);
+        HostBytes host_view(host_bytes ? host_bytes + off : (const uint8_t*)"");
+        ByteView& early_view = host_bytes ? (ByteView&)host_view : (ByteView&)*base_view;
+        std::vector<RunList> runs(nm);
+        PreReplayed pre(nm);
+        for (size_t oi = 0; oi < nm; oi++) {
+            const int k = order[oi];
+            std::vector<RunList> one;
+            rc = stage_a_finish(ctx, { k }, d_bytes + off, plen, parity_of(k, off), { minc[(size_t)k] }, (int)(p & 1), &one);
+            if (rc != SX_OK) return fail(rc);
+            runs[(size_t)k] = std::move(one[0]);
+            if (!runs[(size_t)k].own.empty()) runs[(size_t)k].use_own();  // the vector moved: point at it again
+            ctx->last_runs[(size_t)k] += runs[(size_t)k].size();
+            if (oi + 1 == nm && launched < n_pieces) {  // record slot p&1 is free again (ev_free): queue piece p+2
+                if ((rc = launch(launched++)) != SX_OK) return fail(rc);
+            }
+            if (device_replay_wanted(ctx, job, (size_t)k, runs[(size_t)k].size())) {
+                rc = device_replay_mission(ctx, (size_t)k, early_view, job, runs[(size_t)k], &pre.per[(size_t)k], &pre.ends[(size_t)k]);
+                if (rc != SX_OK) return fail(rc);
+                pre.done[(size_t)k] = 1;
+            }
         }
-    }
-    if (rc != SX_OK) {  // do not leave kernels running on the caller's buffer
-        for (auto& d : ctx->dev) { (void)hipStreamSynchronize(d.stream); (void)hipStreamSynchronize(d.stream_b); }
-        return rc;
+        if (host_bytes) rc = replay_all(ctx, host_view, job, runs, &res.r->r, nullptr, &pre);
+        else {
+            SparseDeviceBytes view(ctx, d_bytes + off);
+            bool base_is_enough = false;
+            rc = download_for_replay(ctx, d_bytes + off, plen, &runs, &view, job, &pre.done, &base_is_enough);
+            if (rc == SX_OK) rc = replay_all(ctx, base_is_enough ? (ByteView&)*base_view : (ByteView&)view, job, runs, &res.r->r, nullptr, &pre);
+        }
+        if (rc != SX_OK) return fail(rc);
     }
     ctx->stats.total_ms = now_ms() - t_begin;
     *out = res.release();
@@ -1085,7 +1199,7 @@ static int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d
         rc = replay_all(ctx, view, job, ctx->shard_runs, &res.r->r, ends.data());
     } else {
         SparseDeviceBytes view(ctx, d_bytes);
-        rc = download_for_replay(ctx, d_bytes, buf_len, ctx->shard_runs, &view, job);
+        rc = download_for_replay(ctx, d_bytes, buf_len, &ctx->shard_runs, &view, job);
         if (rc != SX_OK) return rc;
         rc = replay_all(ctx, view, job, ctx->shard_runs, &res.r->r, ends.data());
     }

@@ -49,9 +49,10 @@ struct ScanParams {
     uint32_t parity;       // UTF-16: (stream offset of byte 0) & 1
     uint32_t big_endian;   // UTF-16BE
     uint32_t capacity;     // record slots
+    uint32_t persistent;   // 0: one wavefront per sub-chunk; else: this many blocks, sub-chunks handed out by counters[3]
     uint32_t traversal;    // 0: one sub-chunk per wavefront (carry in SGPRs); 1: independent overlapping tiles, grid-stride
     DevRun* recs;
-    uint32_t* counters;    // [0] records appended (may exceed capacity = overflow), [1] slow-path tiles
+    uint32_t* counters;    // [0] records appended (may exceed capacity = overflow), [1] slow-path tiles, [3] next sub-chunk (persistent grid)
     // range classifiers
     uint32_t a_lo, a_hi;   // accepted ASCII / single-unit range (inclusive)
     uint32_t u_lo, u_hi;   // UTF-8: accepted 2-byte lead range; UTF-16: accepted unit range [u_lo,u_hi]

@@ -499,14 +499,26 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
         __syncthreads();
     }
     const u32 lane = lane_id();
-    const u64 wave = (u64)blockIdx.x * 4u + uniform(threadIdx.x >> 6);
-    const u64 sub_start = wave * (u64)p.subchunk;
-    if (sub_start >= p.len) return;
-    const u64 sub_end = (sub_start + p.subchunk < p.len) ? sub_start + p.subchunk : p.len;
-
     CLS cls;
     cls.init(p, lds_lut);
     Emitter em{ p.recs, p.counters, p.capacity, 0u, 0u };
+
+    // Classic grid: wavefront w owns sub-chunk w.  Persistent grid (p.persistent): fewer
+    // wavefronts than sub-chunks, each takes the next free sub-chunk from a device counter
+    // until none is left — the grid then leaves wave slots (and all LDS) to other streams.
+    for (bool first_round = true;; first_round = false) {
+    u64 wave;
+    if (p.persistent) {
+        u32 w = 0;
+        if (lane == 0) w = atomicAdd(p.counters + 3, 1u);
+        wave = uniform(w);
+    } else {
+        if (!first_round) break;
+        wave = (u64)blockIdx.x * 4u + uniform(threadIdx.x >> 6);
+    }
+    const u64 sub_start = wave * (u64)p.subchunk;
+    if (sub_start >= p.len) break;
+    const u64 sub_end = (sub_start + p.subchunk < p.len) ? sub_start + p.subchunk : p.len;
 
     // Buffer descriptor over [win_lo, win_hi): one tile of look-back (classification state
     // at the sub-chunk start) and two of look-ahead; reads beyond it return 0.
@@ -610,6 +622,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
         }
         em.append(lane == 0, os, sub_end, och, ofl | kRecEndOpen);
     }
+    }  // next sub-chunk
     em.invalidate_rest();
 }
 
@@ -803,7 +816,9 @@ static hipError_t launch_t(const ScanParams& p, hipStream_t stream) {
     u64 waves = (p.len + p.subchunk - 1) / p.subchunk;
     u64 blocks = (waves + 3) / 4;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((scan_kernel<CLS, LUT>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    ScanParams q = p;
+    if (q.persistent && blocks > q.persistent) blocks = q.persistent; else q.persistent = 0;
+    hipLaunchKernelGGL((scan_kernel<CLS, LUT>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
     return hipGetLastError();
 }
 

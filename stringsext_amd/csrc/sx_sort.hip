@@ -3,6 +3,9 @@
 // `start` (u64), the payload the other 8 bytes.
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_select.hpp>
@@ -46,9 +49,19 @@ hipError_t sort_records(DevRun* recs, uint32_t n, void* scratch, size_t scratch_
     uint8_t* tmp = (uint8_t*)(((uintptr_t)(v1 + n) + 255) & ~(uintptr_t)255);  // rocPRIM wants its storage aligned
     size_t tmp_bytes = scratch_bytes - (size_t)(tmp - (uint8_t*)scratch);
     const unsigned blocks = (n + 255) / 256;
+    static const bool dbg = getenv("SX_TIMING2") != nullptr;
+    auto stamp = [&](const char* what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(stream);
+        timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+        fprintf(stderr, "[sx]     %s at %.3f ms\n", what, ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6);
+    };
+    stamp("sort: begin");
     hipLaunchKernelGGL(split_records_kernel, dim3(blocks), dim3(256), 0, stream, recs, n, k0, v0);
+    stamp("sort: split done");
     hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, (size_t)n, 0, 64, stream);
     if (e != hipSuccess) return e;
+    stamp("sort: radix done");
     hipLaunchKernelGGL(join_records_kernel, dim3(blocks), dim3(256), 0, stream, k1, v1, n, recs);
     return hipGetLastError();
 }
