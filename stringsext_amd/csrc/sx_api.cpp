@@ -84,6 +84,11 @@ struct ScanSlot {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the scan kernel
     hipEvent_t ev_free = nullptr;     // the slot's records have been consumed (recorded on stream_b)
     bool free_pending = false;
+    // region mode (ScanParams::region_cap): per-sub-chunk counts and the packed, ordered records
+    uint32_t* d_cnt = nullptr;  uint64_t cnt_cap = 0;
+    DevRun* d_packed = nullptr; uint64_t packed_cap = 0;
+    uint32_t region_cap = 0;    // of the launch in flight (0: shared pool)
+    uint64_t n_regions = 0;
 };
 struct MissionDev {
     hipStream_t stream = nullptr;     // scan kernels only
@@ -114,6 +119,8 @@ struct sx_ctx {
     sx_stats stats{};
     hipStream_t scan_stream = nullptr, post_stream = nullptr;
     unsigned n_cus = 256, scan_blocks_per_cu = 8;
+    uint32_t region_cap = 32;         // record slots per sub-chunk in region mode (0: never use it)
+    std::vector<char> dense;          // per mission: the last buffer overflowed its regions -> shared pool + sort
     uint8_t* d_input = nullptr;  // staging for host input
     uint64_t d_input_cap = 0;
     uint64_t ondemand_fetches = 0;
@@ -251,6 +258,7 @@ ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const 
         }
     }
     p.capacity = s.capacity; p.recs = s.d_recs; p.counters = s.d_counters;
+    p.region_cap = s.region_cap; p.region_counts = s.d_cnt;
     p.traversal = (ctx->opt.flags & SX_OPT_TILE_TRAVERSAL) ? 1u : 0u;
     if (const char* e = getenv("SX_TRAVERSAL")) p.traversal = (uint32_t)atoi(e);
     // Blocks (of 4 wavefronts) per CU the scan kernel occupies.  8 fills every wave slot; with
@@ -270,6 +278,25 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         MissionDev& d = ctx->dev[(size_t)which[k]];
         ScanSlot& s = d.slot[si];
         if (s.free_pending) { HIP_TRY(ctx, hipStreamWaitEvent(d.stream, s.ev_free, 0)); s.free_pending = false; }
+        {   // region mode unless the mission's last buffer was too dense for it (or the options rule it out)
+            uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 256u * 1024u;
+            sub = std::max<uint32_t>(kTileBytes, sub / kTileBytes * kTileBytes);
+            const uint64_t n_regions = (len + sub - 1) / sub;
+            const bool tile_traversal = (ctx->opt.flags & SX_OPT_TILE_TRAVERSAL) || (getenv("SX_TRAVERSAL") && atoi(getenv("SX_TRAVERSAL")));
+            if (ctx->dense.size() != ctx->missions.size()) ctx->dense.assign(ctx->missions.size(), 0);
+            s.region_cap = 0; s.n_regions = n_regions;
+            if (ctx->region_cap && !ctx->dense[(size_t)which[k]] && !tile_traversal && n_regions * ctx->region_cap < (1ull << 28)) {
+                s.region_cap = ctx->region_cap;
+                int rc = ensure_capacity(ctx, s, (uint32_t)(n_regions * s.region_cap));
+                if (rc != SX_OK) return rc;
+                if (s.cnt_cap < n_regions) {
+                    if (s.d_cnt) HIP_TRY(ctx, hipFree(s.d_cnt));
+                    s.d_cnt = nullptr; s.cnt_cap = 0;
+                    HIP_TRY(ctx, hipMalloc((void**)&s.d_cnt, (n_regions + n_regions / 4 + 64) * 4));
+                    s.cnt_cap = n_regions + n_regions / 4 + 64;
+                }
+            }
+        }
         const ScanParams p = scan_params(ctx, which[k], s, d_bytes, len, parity[k], min_chars[k]);
         HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream));
         HIP_TRY(ctx, hipEventRecord(s.ev0, d.stream));
@@ -300,18 +327,44 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         for (int round = 0;; round++) {
             HIP_TRY(ctx, hipMemcpyAsync(counters, s.d_counters, sizeof counters, hipMemcpyDeviceToHost, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
-            if (counters[0] <= s.capacity) break;
-            if (round >= 8) { ctx->err = "device run-record buffer kept overflowing"; return SX_E_NOMEM; }
-            // overflow: grow the slot and scan this piece again for this mission
-            int rc = ensure_capacity(ctx, s, counters[0] + counters[0] / 8 + 1024);
-            if (rc != SX_OK) return rc;
+            if (s.region_cap) {
+                if (counters[0] == 0) break;  // every sub-chunk's records fit its region
+                // too dense for regions: this mission uses the shared pool (and a sort) from now on
+                ctx->dense[(size_t)which[k]] = 1;
+                s.region_cap = 0;
+            } else {
+                if (counters[0] <= s.capacity) break;
+                if (round >= 8) { ctx->err = "device run-record buffer kept overflowing"; return SX_E_NOMEM; }
+                // overflow: grow the slot and scan this piece again for this mission
+                int rc = ensure_capacity(ctx, s, counters[0] + counters[0] / 8 + 1024);
+                if (rc != SX_OK) return rc;
+            }
             const ScanParams p = scan_params(ctx, which[k], s, d_bytes, len, parity[k], min_chars[k]);
             HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream_b));
             HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream_b));
         }
         const double tc0 = now_ms();
         if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   mission %d: kernel done at +%.2f ms, counters at +%.2f ms\n", which[k], t_ev - t0, tc0 - t0);
-        const uint32_t nrec = counters[0];
+        uint32_t nrec = counters[0];
+        const DevRun* d_records = s.d_recs;   // sorted already in region mode
+        const bool regions = s.region_cap != 0;
+        if (regions) {
+            // pack the regions: the records come out ordered by position, no sort needed
+            const uint64_t slots = s.n_regions * s.region_cap;
+            if (s.packed_cap < slots) {
+                if (s.d_packed) HIP_TRY(ctx, hipFree(s.d_packed));
+                s.d_packed = nullptr; s.packed_cap = 0;
+                HIP_TRY(ctx, hipMalloc((void**)&s.d_packed, (slots + slots / 8 + 64) * sizeof(DevRun)));
+                s.packed_cap = slots + slots / 8 + 64;
+            }
+            int rc = ensure_scratch(ctx, compact_scratch_bytes(s.n_regions)); if (rc != SX_OK) return rc;
+            HIP_TRY(ctx, compact_regions(s.d_recs, s.d_cnt, s.n_regions, s.region_cap, s.d_packed, s.d_counters + 1, ctx->d_scratch,
+                                         ctx->d_scratch_cap, d.stream_b));
+            HIP_TRY(ctx, hipMemcpyAsync(&nrec, s.d_counters + 1, 4, hipMemcpyDeviceToHost, d.stream_b));
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            d_records = s.d_packed;
+        } else if (ctx->region_cap && nrec < s.n_regions * ctx->region_cap / 4)
+            ctx->dense[(size_t)which[k]] = 0;  // sparse again: regions next time
         const uint32_t join_min = getenv("SX_DEVICE_JOIN_MIN") ? (uint32_t)atoi(getenv("SX_DEVICE_JOIN_MIN")) : 65536u;
         const bool dev_sorted = nrec >= join_min && nrec > 0;  // worth a handful of small kernels
         double tc1 = tc0;
@@ -321,9 +374,9 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             const size_t sb = std::max(sort_scratch_bytes(nrec), merge_scratch_bytes(nrec));
             int rc = ensure_scratch(ctx, sb); if (rc != SX_OK) return rc;
             rc = ensure_rp(ctx, d, 0, (uint64_t)nrec * sizeof(sx_run)); if (rc != SX_OK) return rc;
-            HIP_TRY(ctx, sort_records(s.d_recs, nrec, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
+            if (!regions) HIP_TRY(ctx, sort_records(s.d_recs, nrec, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
             if (getenv("SX_TIMING2")) { HIP_TRY(ctx, hipStreamSynchronize(d.stream_b)); fprintf(stderr, "[sx]   sort done +%.2f ms\n", now_ms() - tc0); }
-            HIP_TRY(ctx, merge_sorted_records(s.d_recs, nrec, min_chars[k], ctx->d_scratch, ctx->d_scratch_cap,
+            HIP_TRY(ctx, merge_sorted_records(d_records, nrec, min_chars[k], ctx->d_scratch, ctx->d_scratch_cap,
                                               (sx_run*)d.d_rp[0], s.d_counters + 2, d.stream_b));
             HIP_TRY(ctx, hipEventRecord(s.ev_free, d.stream_b));
             s.free_pending = true;
@@ -349,7 +402,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             if (rc != SX_OK) return rc;
             DevRun* recs_p = (DevRun*)ctx->h_pin;
             if (nrec) {
-                HIP_TRY(ctx, hipMemcpyAsync(recs_p, s.d_recs, (size_t)nrec * sizeof(DevRun), hipMemcpyDeviceToHost, d.stream_b));
+                HIP_TRY(ctx, hipMemcpyAsync(recs_p, d_records, (size_t)nrec * sizeof(DevRun), hipMemcpyDeviceToHost, d.stream_b));
                 HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
             }
             tc1 = now_ms();
@@ -362,13 +415,14 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                             (r.chars_flags & kRecEndOpen) ? "E" : "-");
                 fprintf(stderr, "[sx] slow tiles %u\n", counters[1]);
             }
-            merge_device_runs(recs_p, nrec, min_chars[k], 64 * 1024, &rl.own);
+            if (regions) merge_sorted_device_runs(recs_p, nrec, min_chars[k], &rl.own);
+            else merge_device_runs(recs_p, nrec, min_chars[k], 64 * 1024, &rl.own);
             rl.use_own();
         }
         if (getenv("SX_TIMING"))
-            fprintf(stderr, "[sx] mission %d: kernel %.2f ms, %u record slots, %s %.2f ms, %s %.2f ms -> %zu runs\n", which[k], ms,
-                    nrec, dev_sorted ? "device sort+join" : "d2h", tc1 - tc0, dev_sorted ? "d2h runs" : "host join",
-                    now_ms() - tc1, rl.size());
+            fprintf(stderr, "[sx] mission %d: kernel %.2f ms, %u %s, %s %.2f ms, %s %.2f ms -> %zu runs\n", which[k], ms, nrec,
+                    regions ? "records (regions)" : "record slots (pool)", dev_sorted ? (regions ? "device pack+join" : "device sort+join") : "d2h",
+                    tc1 - tc0, dev_sorted ? "d2h runs" : "host join", now_ms() - tc1, rl.size());
         ctx->stats.run_records += rl.size();
         ctx->stats.bytes_scanned += len;
         ctx->stats.heavy_tiles += counters[1];
@@ -796,6 +850,7 @@ int sx_create(sx_ctx** out, const sx_mission* missions, int n_missions, int hip_
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hip_device) == hipSuccess && cus > 0) ctx->n_cus = (unsigned)cus;
         if (const char* e2 = getenv("SX_SCAN_BLOCKS_PER_CU")) ctx->scan_blocks_per_cu = (unsigned)atoi(e2);
+        if (const char* e2 = getenv("SX_REGION_CAP")) ctx->region_cap = (uint32_t)atoi(e2);
         if (const char* e2 = getenv("SX_SCAN_CUS")) ctx->n_cus = (unsigned)std::max(1, atoi(e2));  // tests: persistent grid on small inputs
     }
     int prio_lo = 0, prio_hi = 0;
@@ -841,6 +896,8 @@ void sx_destroy(sx_ctx* ctx) {
             if (d.stream_b) (void)hipStreamSynchronize(d.stream_b);
             for (ScanSlot& s : d.slot) {
                 if (s.d_recs) (void)hipFree(s.d_recs);
+                if (s.d_cnt) (void)hipFree(s.d_cnt);
+                if (s.d_packed) (void)hipFree(s.d_packed);
                 if (s.d_counters) (void)hipFree(s.d_counters);
                 if (s.ev0) (void)hipEventDestroy(s.ev0);
                 if (s.ev1) (void)hipEventDestroy(s.ev1);

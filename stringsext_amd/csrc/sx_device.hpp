@@ -52,6 +52,8 @@ struct ScanParams {
     uint32_t persistent;   // 0: one wavefront per sub-chunk; else: this many blocks, sub-chunks handed out by counters[3]
     uint32_t traversal;    // 0: one sub-chunk per wavefront (carry in SGPRs); 1: independent overlapping tiles, grid-stride
     DevRun* recs;
+    uint32_t region_cap;   // 0: shared record pool; else: slots per sub-chunk (region mode, see Emitter)
+    uint32_t* region_counts; // region mode: records of sub-chunk w
     uint32_t* counters;    // [0] records appended (may exceed capacity = overflow), [1] slow-path tiles, [3] next sub-chunk (persistent grid)
     // range classifiers
     uint32_t a_lo, a_hi;   // accepted ASCII / single-unit range (inclusive)
@@ -106,6 +108,11 @@ hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegion
 // order run records by start on the device (sx_sort.hip); unused slots end up last with start = ~0
 size_t sort_scratch_bytes(uint32_t n);
 hipError_t sort_records(DevRun* recs, uint32_t n, void* scratch, size_t scratch_bytes, hipStream_t stream);
+
+// region mode: records of all sub-chunks, in order, packed into `out`; *total = their number
+size_t compact_scratch_bytes(uint64_t n_regions);
+hipError_t compact_regions(const DevRun* recs, const uint32_t* counts, uint64_t n_regions, uint32_t region_cap, DevRun* out,
+                           uint32_t* total, void* scratch, size_t scratch_bytes, hipStream_t stream);
 
 // join sorted records into runs (>= min_chars chars) on the device; out holds up to n runs
 size_t merge_scratch_bytes(uint32_t n);

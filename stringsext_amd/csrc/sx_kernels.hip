@@ -310,13 +310,27 @@ struct Carry {
 // atomic per kRecBlock records.  Slots of a block that stay unused are marked invalid
 // (kRecInvalid) so that the host can skip them.  All fields are wave-uniform (SGPRs).
 constexpr u32 kRecBlock = 16;
+// Region mode (region_cap > 0): no shared pool and no atomics — the records of sub-chunk w go
+// to slots [w*region_cap, (w+1)*region_cap) in the order they are found, and their number to
+// region_counts[w]; a compaction pass (sx_sort.hip) then yields the records sorted by position
+// without sorting.  Records beyond region_cap are only counted (counters[0]): the host then
+// repeats the launch with the shared pool.
 struct Emitter {
     DevRun* recs;
     u32* counters;
     u32 capacity;
     u32 base, left;  // my current block: slots [base, base+left) are still free
+    u32 region_cap, rcount;
+    u32* region_counts;
 
+    SX_DEV void begin_region(u64 wave) {
+        if (region_cap) { base = (u32)wave * region_cap; rcount = 0; }
+    }
+    SX_DEV void end_region(u64 wave) {
+        if (region_cap && lane_id() == 0) region_counts[wave] = rcount < region_cap ? rcount : region_cap;
+    }
     SX_DEV void invalidate_rest() {
+        if (region_cap) return;
         u32 lane = lane_id();
         if (lane < left && base + lane < capacity) {
             DevRun r; r.start = 0; r.len = kRecInvalidLen; r.chars_flags = kRecInvalidFlags;
@@ -330,24 +344,34 @@ struct Emitter {
         if (m == 0) return;
         u32 lane = lane_id();
         u32 n = (u32)__popcll(m);
-        if (n > left) {
-            invalidate_rest();
-            u32 grab = n > kRecBlock ? n : kRecBlock, b = 0;
-            if (lane == 0) b = atomicAdd(counters, grab);
-            base = __builtin_amdgcn_readfirstlane(b);
-            left = grab;
-        }
-        if (want) {
-            u32 idx = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
-            if (idx < capacity) {
-                DevRun r;
-                r.start = start;
-                r.len = (u32)(end - start);
-                r.chars_flags = (chars > kRecCharsMask ? kRecCharsMask : chars) | flags;
-                recs[idx] = r;
+        u32 idx;
+        bool room;
+        if (region_cap) {
+            const u32 k = rcount + (u32)__popcll(m & ((1ull << lane) - 1ull));
+            idx = base + k;
+            room = k < region_cap;
+            if (rcount + n > region_cap && lane == 0)
+                atomicAdd(counters, rcount + n - (rcount > region_cap ? rcount : region_cap));
+            rcount += n;
+        } else {
+            if (n > left) {
+                invalidate_rest();
+                u32 grab = n > kRecBlock ? n : kRecBlock, b = 0;
+                if (lane == 0) b = atomicAdd(counters, grab);
+                base = __builtin_amdgcn_readfirstlane(b);
+                left = grab;
             }
+            idx = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+            room = idx < capacity;
+            base += n; left -= n;
         }
-        base += n; left -= n;
+        if (want && room) {
+            DevRun r;
+            r.start = start;
+            r.len = (u32)(end - start);
+            r.chars_flags = (chars > kRecCharsMask ? kRecCharsMask : chars) | flags;
+            recs[idx] = r;
+        }
     }
 };
 
@@ -501,7 +525,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
     const u32 lane = lane_id();
     CLS cls;
     cls.init(p, lds_lut);
-    Emitter em{ p.recs, p.counters, p.capacity, 0u, 0u };
+    Emitter em{ p.recs, p.counters, p.capacity, 0u, 0u, p.region_cap, 0u, p.region_counts };
 
     // Classic grid: wavefront w owns sub-chunk w.  Persistent grid (p.persistent): fewer
     // wavefronts than sub-chunks, each takes the next free sub-chunk from a device counter
@@ -519,6 +543,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
     const u64 sub_start = wave * (u64)p.subchunk;
     if (sub_start >= p.len) break;
     const u64 sub_end = (sub_start + p.subchunk < p.len) ? sub_start + p.subchunk : p.len;
+    em.begin_region(wave);
 
     // Buffer descriptor over [win_lo, win_hi): one tile of look-back (classification state
     // at the sub-chunk start) and two of look-ahead; reads beyond it return 0.
@@ -622,6 +647,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
         }
         em.append(lane == 0, os, sub_end, och, ofl | kRecEndOpen);
     }
+    em.end_region(wave);
     }  // next sub-chunk
     em.invalidate_rest();
 }
@@ -741,7 +767,7 @@ __global__ __launch_bounds__(256) void scan_kernel_v2(const ScanParams p) {
 
     CLS cls;
     cls.init(p, lds_lut);
-    Emitter em{ p.recs, p.counters, p.capacity, 0u, 0u };
+    Emitter em{ p.recs, p.counters, p.capacity, 0u, 0u, 0u, 0u, nullptr };  // shared pool only
 
     // the tile's 1 KiB through a descriptor of its own (64-bit base in SGPRs, 32-bit offsets)
     auto load_tile = [&](u64 tile) -> u32x4 {

@@ -67,6 +67,85 @@ hipError_t sort_records(DevRun* recs, uint32_t n, void* scratch, size_t scratch_
 }
 
 
+// ---- region mode: pack the per-sub-chunk record regions ------------------------------------
+// Small blocks, a few hundred bytes of LDS: these kernels must find room next to a scan kernel
+// that fills the device (a rocPRIM radix sort does not: its large blocks starve).
+constexpr uint32_t kScanPerBlock = 1024;  // 256 threads x 4 counts
+__global__ __launch_bounds__(256) void region_block_scan_kernel(const uint32_t* counts, uint64_t n, uint32_t* local_off,
+                                                                uint32_t* block_sum) {
+    __shared__ uint32_t wsum[4];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    uint32_t c[4], t = 0;
+    for (int j = 0; j < 4; j++) { c[j] = i0 + j < n ? counts[i0 + j] : 0u; t += c[j]; }
+    uint32_t inc = t;
+    const uint32_t lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
+    if (lane == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wsum[w];
+    uint32_t run = before + inc - t;
+    for (int j = 0; j < 4; j++) { if (i0 + j < n) local_off[i0 + j] = run; run += c[j]; }
+    if (threadIdx.x == 255) block_sum[blockIdx.x] = before + inc;
+}
+__global__ __launch_bounds__(256) void region_sum_scan_kernel(uint32_t* block_sum, uint32_t n_blocks, uint32_t* total) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_blocks; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_blocks ? block_sum[i] : 0u;
+        uint32_t inc = v;
+        const uint32_t lane = threadIdx.x & 63;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if ((int)lane >= o) inc += u; }
+        if (lane == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wsum[w];
+        if (i < n_blocks) block_sum[i] = before + inc - v;  // exclusive
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+// A region holds its sub-chunk's records almost in order (tile by tile; inside a tile the lanes
+// emit their first stretches, then their second ones, ...), so every record is placed by its
+// rank among the region's records (<= region_cap of them: a handful of cached loads).
+__global__ __launch_bounds__(256) void region_pack_kernel(const DevRun* recs, const uint32_t* counts, const uint32_t* local_off,
+                                                          const uint32_t* block_off, uint64_t n_regions, uint32_t region_cap,
+                                                          DevRun* out) {
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // slot
+    const uint64_t w = s / region_cap;
+    const uint32_t j = (uint32_t)(s - w * region_cap);
+    if (w >= n_regions) return;
+    const uint32_t n = counts[w];
+    if (j >= n) return;
+    const DevRun r = recs[s];
+    const DevRun* reg = recs + w * region_cap;
+    uint32_t rank = 0;
+    for (uint32_t i = 0; i < n; i++) rank += reg[i].start < r.start ? 1u : 0u;
+    out[(uint64_t)block_off[w / kScanPerBlock] + local_off[w] + rank] = r;
+}
+size_t compact_scratch_bytes(uint64_t n_regions) {
+    return n_regions * 4 + ((n_regions + kScanPerBlock - 1) / kScanPerBlock) * 4 + 1024;
+}
+hipError_t compact_regions(const DevRun* recs, const uint32_t* counts, uint64_t n_regions, uint32_t region_cap, DevRun* out,
+                           uint32_t* total, void* scratch, size_t scratch_bytes, hipStream_t stream) {
+    if (n_regions == 0) return hipMemsetAsync(total, 0, 4, stream);
+    const uint32_t n_blocks = (uint32_t)((n_regions + kScanPerBlock - 1) / kScanPerBlock);
+    if (scratch_bytes < compact_scratch_bytes(n_regions)) return hipErrorInvalidValue;
+    uint32_t* local_off = (uint32_t*)scratch;
+    uint32_t* block_sum = local_off + n_regions;
+    hipLaunchKernelGGL(region_block_scan_kernel, dim3(n_blocks), dim3(256), 0, stream, counts, n_regions, local_off, block_sum);
+    hipLaunchKernelGGL(region_sum_scan_kernel, dim3(1), dim3(256), 0, stream, block_sum, n_blocks, total);
+    const uint64_t slots = n_regions * region_cap;
+    hipLaunchKernelGGL(region_pack_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, recs, counts, local_off,
+                       block_sum, n_regions, region_cap, out);
+    return hipGetLastError();
+}
+
 // ---- join the sorted records into runs on the device -------------------------------------
 // Same rule as merge_sorted_device_runs (sx_replay.cpp): a record continues its predecessor if
 // that one reaches its sub-chunk end, this one begins at a sub-chunk start, and they touch.
