@@ -86,8 +86,9 @@ SXD DStep ddec_utf8(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool la
     }
 }
 
+template <bool BE>
 SXD DStep ddec_utf16(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {
-    const bool be = d.enc == 3;
+    constexpr bool be = BE;
     u32 i = 0, w = 0;
     if (d.pending_bmp) {
         if (cap - w < 3) return { RES_OUTPUT_FULL, 0, 0 };
@@ -148,9 +149,15 @@ SXD DStep ddec_single(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap) {
     }
 }
 
+// ENC: 1 UTF-8, 2 UTF-16LE, 3 UTF-16BE, 0 any single-byte encoding (SX_ENC_* >= 16, ASCII,
+// x-user-defined).  A template parameter: the replay is compiled once per encoding family,
+// which keeps each kernel's code and register footprint small.
+constexpr int enc_family(u32 encoding) { return encoding == 1 ? 1 : encoding == 2 ? 2 : encoding == 3 ? 3 : 0; }
+template <int ENC>
 SXD DStep ddecode(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {
-    if (d.enc == 1) return ddec_utf8(d, src, n, dst, cap, last);
-    if (d.enc == 2 || d.enc == 3) return ddec_utf16(d, src, n, dst, cap, last);
+    if (ENC == 1) return ddec_utf8(d, src, n, dst, cap, last);
+    if (ENC == 2) return ddec_utf16<false>(d, src, n, dst, cap, last);
+    if (ENC == 3) return ddec_utf16<true>(d, src, n, dst, cap, last);
     return ddec_single(d, src, n, dst, cap);
 }
 
@@ -227,18 +234,20 @@ SXD u64 win_start(u64 p, u32 W) { const u64 s = p / kSliceLen * kSliceLen; retur
 //  (B) if no long run starts in the rest of this window, nothing is emitted up to its end and
 //      the state there is what a region start derives (derive_at), so the replay jumps there.
 // ------------------------------------------------------------------------------------------
+template <int ENC>
 SXD bool ddec_idle(const DDecoder& d) {
-    if (d.enc == 1) return d.needed == 0;
-    if (d.enc == 2 || d.enc == 3) return d.lead_byte < 0 && d.lead_surrogate == 0 && !d.pending_bmp;
+    if (ENC == 1) return d.needed == 0;
+    if (ENC == 2 || ENC == 3) return d.lead_byte < 0 && d.lead_surrogate == 0 && !d.pending_bmp;
     return true;
 }
 
 // Start of the decoder call that contains the char boundary rs, not before the call start p.
 // Returns p if everything in [p, rs) is valid (the call at p is the one).
+template <int ENC>
 SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs) {
     const u8* bytes = P.data;
     u64 b = rs;
-    if (P.encoding == 1) {
+    if (ENC == 1) {
         while (b > p) {
             const u8 x = bytes[b - 1];
             if (x < 0x80) { b--; continue; }
@@ -268,8 +277,8 @@ SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs) {
         }
         return b;
     }
-    if (P.encoding == 2 || P.encoding == 3) {
-        const bool be = P.encoding == 3;
+    if (ENC == 2 || ENC == 3) {
+        constexpr bool be = ENC == 3;
         if ((rs - p) & 1) return p;  // not on the unit grid of the call at p: no shortcut
         while (b >= p + 2) {
             const u32 u = be ? ((u32)bytes[b - 2] << 8) | bytes[b - 1] : ((u32)bytes[b - 1] << 8) | bytes[b - 2];
@@ -299,11 +308,12 @@ SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs) {
 // The state the reference carries into the window that starts at `at`, when nothing long
 // crosses `at` (RangeReplay::derive_state): the decoder's pending bytes, and one accepted char
 // as leftover if it is the last thing delivered before `at`.  Decodes from max(at - 8, floor).
+template <int ENC>
 SXD u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& dec, u8* ob) {
     const u8* bytes = P.data;
-    ddec_reset(dec, P.encoding, P.table);
+    ddec_reset(dec, (int)P.encoding, P.table);
     u64 p = at >= 8 ? at - 8 : 0;
-    if ((P.encoding == 2 || P.encoding == 3) && ((P.stream0 + p) & 1)) p = p ? p - 1 : p + 1;
+    if ((ENC == 2 || ENC == 3) && ((P.stream0 + p) & 1)) p = p ? p - 1 : p + 1;
     if (p < floor) p = floor;
     if (p > at) p = at;
     u8 sink[40], last[4];
@@ -312,7 +322,7 @@ SXD u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& dec, u8* o
         const u32 n = (u32)(at - p);
         u32 k = 0;
         for (;;) {
-            const DStep r = ddecode(dec, bytes + p + k, n - k, sink, sizeof sink, false);
+            const DStep r = ddecode<ENC>(dec, bytes + p + k, n - k, sink, sizeof sink, false);
             k += r.read;
             for (u32 w = 0; w < r.written;) {
                 const u8 lead = sink[w];
@@ -335,7 +345,7 @@ constexpr u32 kObCap = 4 * 64 + 3 * 128 + 16;  // leftover (<= 4q bytes) + one w
 // keep the output in the region's small cache slot (fout/aout) as long as it fits — o.pad says
 // whether it did, so that the second pass is a copy for almost every region.
 constexpr u32 kCacheFindings = 2, kCacheBytes = 96;
-template <int MODE>
+template <int MODE, int ENC>
 SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_finding* fout, u8* aout, u64 abase) {
     const u8* bytes = P.data;
     const u64 len = P.len;
@@ -345,7 +355,7 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
     DDecoder dec;
 
     // ---- derive the state the reference would carry into `want` (RangeReplay::derive_state)
-    u32 leftover_len = derive_at(P, want, 0, dec, ob);
+    u32 leftover_len = derive_at<ENC>(P, want, 0, dec, ob);
     bool maybe_cut = false;
 
     u64 ri = i;  // first run not yet behind us
@@ -384,30 +394,30 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
             if (++windows > kMaxRegionWindows) { status = kRegionTooLong; done = true; break; }
             u32 dout = leftover_len;
             for (;;) {  // 'decoder
-                if (P.skip && leftover_len == 0 && !maybe_cut && din < dend && ddec_idle(dec)) {
+                if (P.skip && leftover_len == 0 && !maybe_cut && din < dend && ddec_idle<ENC>(dec)) {
                     const u64 p = soff + din, wend = soff + dend;
                     while (ri < P.n_runs && P.runs[ri].end <= p) ri++;
                     const u64 rs = ri < P.n_runs ? P.runs[ri].start : ~0ull;
                     if (rs >= wend) {  // (B) nothing long starts in the rest of this window
-                        leftover_len = derive_at(P, wend, p, dec, ob);
+                        leftover_len = derive_at<ENC>(P, wend, p, dec, ob);
                         dout = leftover_len;
                         din = dend;
                         break;
                     }
                     if (rs > p) {      // (A) jump to the call that holds the next long run
-                        const u64 vs = call_start_before(P, p, rs);
+                        const u64 vs = call_start_before<ENC>(P, p, rs);
                         if (vs > p) din = (u32)(vs - soff);
                     }
                 }
-                const DStep r = ddecode(dec, bytes + soff + din, dend - din, ob + dout, kObCap - dout, false);
+                const DStep r = ddecode<ENC>(dec, bytes + soff + din, dend - din, ob + dout, kObCap - dout, false);
                 if (r.result == RES_OUTPUT_FULL) { status = kRegionTooLong; done = true; break; }
                 u8 precision = SX_PRECISION_EXACT;
                 if (r.written > 0 && din == 0 && (ob[dout] & 0x80)) {  // slice-start probe, :176-207
                     DDecoder fresh;
-                    ddec_reset(fresh, P.encoding, P.table);
+                    ddec_reset(fresh, (int)P.encoding, P.table);
                     u8 probe[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
                     const u32 pn = slen < 32 ? slen : 32;
-                    const DStep pr = ddecode(fresh, bytes + soff, pn, probe, 8, true);
+                    const DStep pr = ddecode<ENC>(fresh, bytes + soff, pn, probe, 8, true);
                     const u32 filled = dout + r.written < 8 ? dout + r.written : 8;
                     bool same = pr.written != 0;
                     for (u32 t = 0; t < pr.written && same; t++) same = (t < filled ? ob[t] : 0) == probe[t];
@@ -472,6 +482,17 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
     o.n_bytes = n_bytes;
     o.status = status;
     o.pad = cached ? 1u : 0u;
+}
+
+// the encoding family picked at run time (host-side test harness)
+template <int MODE>
+SXD void replay_region_any(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_finding* fout, u8* aout, u64 abase) {
+    switch (enc_family(P.encoding)) {
+        case 1: replay_region<MODE, 1>(P, i, o, fout, aout, abase); break;
+        case 2: replay_region<MODE, 2>(P, i, o, fout, aout, abase); break;
+        case 3: replay_region<MODE, 3>(P, i, o, fout, aout, abase); break;
+        default: replay_region<MODE, 0>(P, i, o, fout, aout, abase); break;
+    }
 }
 
 

@@ -33,8 +33,9 @@ namespace sx {
 
 // Pass 1: one lane per run; a run whose window is certainly inside the region of the run
 // before it is marked kRegionChained right away (the earlier region follows it).
-__global__ __launch_bounds__(64) void replay_count_kernel(const ReplayParams P, ReplayRegionOut* out, sx_finding* cache_f,
-                                                          u8* cache_s) {
+template <int ENC, bool CACHED>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void replay_count_kernel(
+    const ReplayParams P, ReplayRegionOut* out, sx_finding* cache_f, u8* cache_s) {
     const u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
     if (i >= P.n_runs) return;
     ReplayRegionOut o;
@@ -42,22 +43,24 @@ __global__ __launch_bounds__(64) void replay_count_kernel(const ReplayParams P, 
     const u64 want = win_start(P.runs[i].start, P.W);
     if (want < P.lo || want >= P.hi) o.status = kRegionNotMine;
     else if (i > 0 && want <= win_start(P.runs[i - 1].end - 1, P.W)) o.status = kRegionChained;
-    else if (cache_f) replay_region<2>(P, i, o, cache_f + i * kCacheFindings, cache_s + i * kCacheBytes, 0);
-    else replay_region<0>(P, i, o, nullptr, nullptr, 0);
+    else if (CACHED) replay_region<2, ENC>(P, i, o, cache_f + i * kCacheFindings, cache_s + i * kCacheBytes, 0);
+    else replay_region<0, ENC>(P, i, o, nullptr, nullptr, 0);
     out[i] = o;
 }
 
 // Pass 2: the standing regions write their findings and strings at the offsets the host assigned.
+template <int ENC>
 __global__ __launch_bounds__(64) void replay_write_kernel(const ReplayParams P, const u64* region_index, const u64* fbase,
                                                           const u64* abase, u64 n_regions, sx_finding* findings, u8* arena) {
     const u64 k = (u64)blockIdx.x * 64 + threadIdx.x;
     if (k >= n_regions) return;
     ReplayRegionOut o;
-    replay_region<1>(P, region_index[k], o, findings + fbase[k], arena + abase[k], abase[k]);
+    replay_region<1, ENC>(P, region_index[k], o, findings + fbase[k], arena + abase[k], abase[k]);
 }
 
 // Pass 2, flagged form: one lane per run; the standing regions (stitch below) write at the
 // offsets the device scans assigned.
+template <int ENC>
 __global__ __launch_bounds__(64) void replay_write_flagged_kernel(const ReplayParams P, const ReplayRegionOut* ro,
                                                                   const u8* stands, const u64* fpos, const u64* apos,
                                                                   const sx_finding* cache_f, const u8* cache_s,
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(64) void replay_write_flagged_kernel(const ReplayPa
         return;
     }
     ReplayRegionOut o;
-    replay_region<1>(P, i, o, findings + fp, arena + ap, ap);
+    replay_region<1, ENC>(P, i, o, findings + fp, arena + ap, ap);
 }
 
 // ---- which regions stand, on the device ---------------------------------------------------
@@ -241,8 +244,13 @@ hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegion
     if (P.n_runs == 0) return hipSuccess;
     const sx_finding* cf = (const sx_finding*)cache;
     const u8* cs = cache ? (const u8*)cache + P.n_runs * kCacheFindings * sizeof(sx_finding) : nullptr;
-    hipLaunchKernelGGL(replay_write_flagged_kernel, dim3((unsigned)((P.n_runs + 63) / 64)), dim3(64), 0, stream, P, ro, stands,
-                       fpos, apos, cf, cs, findings, arena);
+    const dim3 grid((unsigned)((P.n_runs + 63) / 64));
+    switch (enc_family(P.encoding)) {
+        case 1: hipLaunchKernelGGL(replay_write_flagged_kernel<1>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, cf, cs, findings, arena); break;
+        case 2: hipLaunchKernelGGL(replay_write_flagged_kernel<2>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, cf, cs, findings, arena); break;
+        case 3: hipLaunchKernelGGL(replay_write_flagged_kernel<3>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, cf, cs, findings, arena); break;
+        default: hipLaunchKernelGGL(replay_write_flagged_kernel<0>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, cf, cs, findings, arena); break;
+    }
     return hipGetLastError();
 }
 
@@ -252,14 +260,31 @@ hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, void
     if (P.n_runs == 0) return hipSuccess;
     sx_finding* cf = (sx_finding*)cache;
     u8* cs = cache ? (u8*)cache + P.n_runs * kCacheFindings * sizeof(sx_finding) : nullptr;
-    hipLaunchKernelGGL(replay_count_kernel, dim3((unsigned)((P.n_runs + 63) / 64)), dim3(64), 0, stream, P, out, cf, cs);
+    const dim3 grid((unsigned)((P.n_runs + 63) / 64));
+#define SX_LAUNCH_COUNT(E)                                                                                         \
+    do {                                                                                                           \
+        if (cache) hipLaunchKernelGGL((replay_count_kernel<E, true>), grid, dim3(64), 0, stream, P, out, cf, cs);   \
+        else hipLaunchKernelGGL((replay_count_kernel<E, false>), grid, dim3(64), 0, stream, P, out, cf, cs);        \
+    } while (0)
+    switch (enc_family(P.encoding)) {
+        case 1: SX_LAUNCH_COUNT(1); break;
+        case 2: SX_LAUNCH_COUNT(2); break;
+        case 3: SX_LAUNCH_COUNT(3); break;
+        default: SX_LAUNCH_COUNT(0); break;
+    }
+#undef SX_LAUNCH_COUNT
     return hipGetLastError();
 }
 hipError_t launch_replay_write(const ReplayParams& P, const u64* region_index, const u64* fbase, const u64* abase,
                                u64 n_regions, sx_finding* findings, u8* arena, hipStream_t stream) {
     if (n_regions == 0) return hipSuccess;
-    hipLaunchKernelGGL(replay_write_kernel, dim3((unsigned)((n_regions + 63) / 64)), dim3(64), 0, stream, P, region_index,
-                       fbase, abase, n_regions, findings, arena);
+    const dim3 grid((unsigned)((n_regions + 63) / 64));
+    switch (enc_family(P.encoding)) {
+        case 1: hipLaunchKernelGGL(replay_write_kernel<1>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
+        case 2: hipLaunchKernelGGL(replay_write_kernel<2>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
+        case 3: hipLaunchKernelGGL(replay_write_kernel<3>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
+        default: hipLaunchKernelGGL(replay_write_kernel<0>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
+    }
     return hipGetLastError();
 }
 

@@ -7,18 +7,18 @@
 extern "C" int sxd_replay_region_host(const sx::ReplayParams* P, uint64_t i, sx::ReplayRegionOut* o, sx_finding* fout,
                                       uint8_t* aout, uint32_t fcap, uint32_t acap) {
     sx::ReplayRegionOut c;
-    sx::replay_region<0>(*P, i, c, nullptr, nullptr, 0);
+    sx::replay_region_any<0>(*P, i, c, nullptr, nullptr, 0);
     *o = c;
     if (c.n_find > fcap || c.n_bytes > acap) return -1;
     sx::ReplayRegionOut w;
-    sx::replay_region<1>(*P, i, w, fout, aout, 0);
+    sx::replay_region_any<1>(*P, i, w, fout, aout, 0);
     if (!(w.end == c.end && w.n_find == c.n_find && w.n_bytes == c.n_bytes)) return -2;
     // pass 1 with the output cache: same counts; if it says "kept", the slot holds exactly pass 2's output
     sx_finding cf[sx::kCacheFindings];
     uint8_t cs[sx::kCacheBytes];
     memset(cf, 0, sizeof cf); memset(cs, 0, sizeof cs);
     sx::ReplayRegionOut k;
-    sx::replay_region<2>(*P, i, k, cf, cs, 0);
+    sx::replay_region_any<2>(*P, i, k, cf, cs, 0);
     if (!(k.end == c.end && k.n_find == c.n_find && k.n_bytes == c.n_bytes && k.status == c.status)) return -3;
     if (k.status == sx::kRegionOk) {
         const bool fits = c.n_find <= sx::kCacheFindings && c.n_bytes <= sx::kCacheBytes;
