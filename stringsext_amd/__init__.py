@@ -266,12 +266,13 @@ class Scanner:
                                               int(reuse_runs), C.byref(r), ends))
         return Result(self, r), list(ends)
 
-    def device_runs(self, mission_index, dptr, length, stream_parity=0, min_chars=1):
+    def device_runs(self, mission_index, dptr, length, stream_parity=0, min_chars=1, count_only=False):
+        """Stage A alone: the long runs of one mission over a device buffer (count_only: just their number)."""
         runs = C.POINTER(Run)()
         n = C.c_uint64()
         self._chk(lib().sx_device_runs(self.h, mission_index, dptr, length, stream_parity, min_chars,
                                        C.byref(runs), C.byref(n)))
-        out = [(runs[i].start, runs[i].end, runs[i].chars) for i in range(n.value)]
+        out = n.value if count_only else [(runs[i].start, runs[i].end, runs[i].chars) for i in range(n.value)]
         lib().sx_free(runs)
         return out
 

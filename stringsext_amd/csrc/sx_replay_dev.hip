@@ -177,26 +177,30 @@ struct StandingBytes {
     const u8* stands; const ReplayRegionOut* ro;
     __device__ u64 operator()(u64 i) const { return stands[i] ? (u64)ro[i].n_bytes : 0ull; }
 };
-__global__ __launch_bounds__(1024) void stitch_totals_kernel(const ReplayParams P, const ReplayRegionOut* ro, const u8* stands,
-                                                             const u64* fpos, const u64* apos, u64* totals) {
-    __shared__ u64 s_cnt[16], s_rb[16];
-    const u64 i = (u64)blockIdx.x * 1024 + threadIdx.x;
+// (256-thread blocks: anything larger starves next to a scan kernel that keeps refilling the CUs)
+__global__ __launch_bounds__(256) void stitch_totals_kernel(const ReplayParams P, const ReplayRegionOut* ro, const u8* stands,
+                                                            const u64* fpos, const u64* apos, u64* totals) {
+    __shared__ u64 s_cnt[4], s_rb[4];
+    // four runs per thread: 1024 runs per block, one pair of atomics per block
+    const u64 i0 = ((u64)blockIdx.x * 256 + threadIdx.x) * 4;
     u64 cnt = 0, rb = 0;
-    if (i < P.n_runs && stands[i]) { cnt = 1; rb = ro[i].end - win_start(P.runs[i].start, P.W); }
+    for (u32 j = 0; j < 4; j++) {
+        const u64 i = i0 + j;
+        if (i < P.n_runs && stands[i]) { cnt++; rb += ro[i].end - win_start(P.runs[i].start, P.W); }
+        if (i + 1 == P.n_runs) {
+            totals[kTotFindings] = fpos[i] + (stands[i] ? ro[i].n_find : 0);
+            totals[kTotBytes] = apos[i] + (stands[i] ? ro[i].n_bytes : 0);
+        }
+    }
     for (int o = 32; o; o >>= 1) { cnt += __shfl_down(cnt, o); rb += __shfl_down(rb, o); }
     if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6] = cnt; s_rb[threadIdx.x >> 6] = rb; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        u64 c = 0, r = 0;
-        for (int w = 0; w < 16; w++) { c += s_cnt[w]; r += s_rb[w]; }
+        const u64 c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3], r = s_rb[0] + s_rb[1] + s_rb[2] + s_rb[3];
         if (c) {
             atomicAdd((unsigned long long*)&totals[kTotStanding], (unsigned long long)c);
             atomicAdd((unsigned long long*)&totals[kTotReplayBytes], (unsigned long long)r);
         }
-    }
-    if (i + 1 == P.n_runs) {
-        totals[kTotFindings] = fpos[i] + (stands[i] ? ro[i].n_find : 0);
-        totals[kTotBytes] = apos[i] + (stands[i] ? ro[i].n_bytes : 0);
     }
 }
 
@@ -234,7 +238,7 @@ hipError_t launch_stitch_finish(const ReplayParams& P, const ReplayRegionOut* ro
     auto itb = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), StandingBytes{ stands, ro });
     e = rocprim::exclusive_scan(tmp, tmp_bytes, itb, apos, (u64)0, (size_t)P.n_runs, rocprim::plus<u64>(), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(stitch_totals_kernel, dim3((unsigned)((P.n_runs + 1023) / 1024)), dim3(1024), 0, stream, P, ro, stands, fpos,
+    hipLaunchKernelGGL(stitch_totals_kernel, dim3((unsigned)((P.n_runs + 1023) / 1024)), dim3(256), 0, stream, P, ro, stands, fpos,
                        apos, totals);
     return hipGetLastError();
 }
