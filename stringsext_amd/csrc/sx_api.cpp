@@ -10,6 +10,7 @@
 #include <atomic>
 #include <chrono>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1033,10 +1034,90 @@ uint64_t piece_bytes(const sx_ctx* ctx, uint64_t len) {
 }
 }  // namespace
 
+namespace {
+// Missions in the order their kernels are queued: busiest of the previous buffer first, so that
+// its stage B (the longest) overlaps the scans of the others.
+std::vector<int> mission_order(sx_ctx* ctx) {
+    const size_t nm = ctx->missions.size();
+    std::vector<int> order(nm);
+    for (size_t k = 0; k < nm; k++) order[k] = (int)k;
+    if (ctx->last_runs.size() == nm)
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ctx->last_runs[(size_t)x] > ctx->last_runs[(size_t)y]; });
+    return order;
+}
+
+int sync_streams_and_return(sx_ctx* ctx, int rc) {  // do not leave kernels running on the caller's buffer
+    for (auto& d : ctx->dev) { (void)hipStreamSynchronize(d.stream); (void)hipStreamSynchronize(d.stream_b); }
+    return rc;
+}
+
+struct BufferScan {
+    const uint8_t* host_bytes = nullptr;  // the same bytes on the host, or nullptr (device-resident input)
+    const uint8_t* d_bytes = nullptr;
+    uint64_t len = 0;
+    std::vector<int> order;
+    std::vector<uint32_t> parity;         // per mission: stream offset of byte 0, & 1
+    std::vector<uint64_t> minc;           // per mission: long-run threshold
+    int slot = 0;
+    std::unique_ptr<SparseDeviceBytes> base_view;  // entry/exit bytes of a device-resident buffer
+
+    // what the host reads whatever the runs are (entry and exit of every mission): fetched
+    // before the kernels start, so that the copy does not queue behind them
+    int fetch_base(sx_ctx* ctx) {
+        base_view.reset();
+        if (host_bytes) return SX_OK;
+        base_view.reset(new SparseDeviceBytes(ctx, d_bytes));
+        ReplayJob none;
+        return download_for_replay(ctx, d_bytes, len, nullptr, base_view.get(), none);
+    }
+    int launch(sx_ctx* ctx) {
+        for (int k : order) {
+            int rc = stage_a_launch(ctx, { k }, d_bytes, len, { parity[(size_t)k] }, { minc[(size_t)k] }, slot);
+            if (rc != SX_OK) return rc;
+        }
+        return SX_OK;
+    }
+    // Collect stage A mission by mission (in launch order); a mission whose stage B runs on the
+    // device is replayed at once, while the kernels of the missions behind it still scan; the
+    // host's share of stage B follows when all kernels are done.  `after_last_finish` runs when
+    // the record slot is free again (piece pipeline: queue the next piece).
+    int finish_and_replay(sx_ctx* ctx, const ReplayJob& job, const std::function<int()>& after_last_finish,
+                          std::vector<RunList>* runs, Result* into, uint64_t* ends) {
+        const size_t nm = ctx->missions.size();
+        runs->assign(nm, RunList{});
+        HostBytes host_view(host_bytes ? host_bytes : (const uint8_t*)"");
+        ByteView& early_view = host_bytes ? (ByteView&)host_view : (ByteView&)*base_view;
+        PreReplayed pre(nm);
+        if (ctx->last_runs.size() != nm) ctx->last_runs.assign(nm, 0);
+        for (size_t oi = 0; oi < nm; oi++) {
+            const size_t k = (size_t)order[oi];
+            std::vector<RunList> one;
+            int rc = stage_a_finish(ctx, { (int)k }, d_bytes, len, { parity[k] }, { minc[k] }, slot, &one);
+            if (rc != SX_OK) return rc;
+            (*runs)[k] = std::move(one[0]);
+            if (!(*runs)[k].own.empty()) (*runs)[k].use_own();  // the vector moved: point at it again
+            ctx->last_runs[k] = (*runs)[k].size();
+            if (oi + 1 == nm && after_last_finish && (rc = after_last_finish()) != SX_OK) return rc;
+            if (device_replay_wanted(ctx, job, k, (*runs)[k].size())) {
+                rc = device_replay_mission(ctx, k, early_view, job, (*runs)[k], &pre.per[k], &pre.ends[k]);
+                if (rc != SX_OK) return rc;
+                pre.done[k] = 1;
+            }
+        }
+        if (host_bytes) return replay_all(ctx, host_view, job, *runs, into, ends, &pre);
+        SparseDeviceBytes view(ctx, d_bytes);
+        bool base_is_enough = false;
+        int rc = download_for_replay(ctx, d_bytes, len, runs, &view, job, &pre.done, &base_is_enough);
+        if (rc != SX_OK) return rc;
+        return replay_all(ctx, base_is_enough ? (ByteView&)*base_view : (ByteView&)view, job, *runs, into, ends, &pre);
+    }
+};
+}  // namespace
+
 // One buffer, start to end: stage A on the device, stage B on device and host, the findings in
 // print order.
 //  * The missions' scan kernels queue up in one stream, busiest mission (of the last buffer)
-//    first; as soon as a mission's kernel is done its records are sorted and joined and — if its
+//    first; as soon as a mission's kernel is done its records are packed and joined and — if its
 //    stage B runs on the device — replayed, in the second stream, while the kernels of the
 //    remaining missions still scan.  What the host replays follows when all kernels are done.
 //  * A large buffer can be cut into pieces (SX_PIECE_MIB) that behave exactly like consecutive
@@ -1045,103 +1126,44 @@ static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_
                        int is_last, sx_result** out) {
     const double t_begin = now_ms();
     const size_t nm = ctx->missions.size();
-    std::vector<int> order(nm);
-    std::vector<uint64_t> minc(nm), stream0(nm);
-    for (size_t k = 0; k < nm; k++) {
-        order[k] = (int)k;
-        stream0[k] = ctx->states[k].stream_bytes;
-        minc[k] = ctx->missions[k].long_run;
-    }
-    if (ctx->last_runs.size() == nm)
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ctx->last_runs[(size_t)x] > ctx->last_runs[(size_t)y]; });
-    ctx->last_runs.assign(nm, 0);
+    std::vector<uint64_t> stream0(nm);
+    for (size_t k = 0; k < nm; k++) stream0[k] = ctx->states[k].stream_bytes;
+    const std::vector<int> order = mission_order(ctx);
     const uint64_t piece = piece_bytes(ctx, len);
     const uint64_t n_pieces = len ? (len + piece - 1) / piece : 1;
-    auto piece_off = [&](uint64_t p) { return p * piece; };
-    auto piece_len = [&](uint64_t p) { return std::min(piece, len - piece_off(p)); };
-    auto parity_of = [&](int k, uint64_t off) { return std::vector<uint32_t>{ (uint32_t)((stream0[(size_t)k] + off) & 1) }; };
-    auto launch = [&](uint64_t p) -> int {
-        for (int k : order) {
-            int rc = stage_a_launch(ctx, { k }, d_bytes + piece_off(p), piece_len(p), parity_of(k, piece_off(p)),
-                                    { minc[(size_t)k] }, (int)(p & 1));
-            if (rc != SX_OK) return rc;
+    auto make = [&](uint64_t p) {
+        BufferScan b;
+        const uint64_t off = p * piece;
+        b.host_bytes = host_bytes ? host_bytes + off : nullptr;
+        b.d_bytes = d_bytes + off;
+        b.len = std::min(piece, len - off);
+        b.order = order;
+        b.slot = (int)(p & 1);
+        for (size_t k = 0; k < nm; k++) {
+            b.parity.push_back((uint32_t)((stream0[k] + off) & 1));
+            b.minc.push_back(ctx->missions[k].long_run);
         }
-        return SX_OK;
-    };
-    auto fail = [&](int rc) {  // do not leave kernels running on the caller's buffer
-        for (auto& d : ctx->dev) { (void)hipStreamSynchronize(d.stream); (void)hipStreamSynchronize(d.stream_b); }
-        return rc;
+        return b;
     };
     ResultHolder res;
-    int rc = SX_OK;
-    // what the host reads of piece 0 whatever the runs are (entry and exit of every mission):
-    // fetched before the kernels start, so that the copy does not queue behind them
-    std::unique_ptr<SparseDeviceBytes> base_view;
-    auto make_base = [&](uint64_t p) -> int {
-        base_view.reset();
-        if (host_bytes) return SX_OK;
-        base_view.reset(new SparseDeviceBytes(ctx, d_bytes + piece_off(p)));
-        ReplayJob none;
-        return download_for_replay(ctx, d_bytes + piece_off(p), piece_len(p), nullptr, base_view.get(), none);
-    };
-    if ((rc = make_base(0)) != SX_OK) return rc;
+    std::vector<BufferScan> pieces;
+    for (uint64_t p = 0; p < n_pieces; p++) pieces.push_back(make(p));
+    int rc = pieces[0].fetch_base(ctx);
+    if (rc != SX_OK) return rc;
     uint64_t launched = 0;
-    for (; launched < std::min<uint64_t>(2, n_pieces) && rc == SX_OK; launched++) rc = launch(launched);
-    if (rc != SX_OK) return fail(rc);
-    if (getenv("SX_PROBE") && ctx->d_scratch_cap >= 8192 && ctx->h_pin_cap >= 8192) {
-        // how long do small things in the second stream take while the scan kernels run?
-        hipStream_t sb = ctx->post_stream;
-        uint32_t pageable[16];
-        for (int i = 0; i < 4; i++) {
-            struct timespec ts = { 0, 2000000 }; nanosleep(&ts, nullptr);
-            double t0 = now_ms();
-            (void)launch_fill_background(ctx->d_scratch, 0, 4096, 1, sb); (void)hipStreamSynchronize(sb);
-            double t1 = now_ms();
-            (void)hipMemcpyAsync(ctx->h_pin, ctx->d_scratch, 4096, hipMemcpyDeviceToHost, sb); (void)hipStreamSynchronize(sb);
-            double t2 = now_ms();
-            (void)hipMemcpyAsync(pageable, ctx->d_scratch, sizeof pageable, hipMemcpyDeviceToHost, sb); (void)hipStreamSynchronize(sb);
-            double t3 = now_ms();
-            (void)hipMemsetAsync(ctx->d_scratch, 0, 4096, sb); (void)hipStreamSynchronize(sb);
-            double t4 = now_ms();
-            fprintf(stderr, "[sx] probe %d at +%.1f ms: tiny kernel %.3f ms, pinned d2h %.3f ms, pageable d2h %.3f ms, memset %.3f ms\n", i,
-                    t0 - t_begin, t1 - t0, t2 - t1, t3 - t2, t4 - t3);
-        }
-    }
+    for (; launched < std::min<uint64_t>(2, n_pieces); launched++)
+        if ((rc = pieces[launched].launch(ctx)) != SX_OK) return sync_streams_and_return(ctx, rc);
     for (uint64_t p = 0; p < n_pieces; p++) {
-        const uint64_t off = piece_off(p), plen = piece_len(p);
-        if (p > 0 && (rc = make_base(p)) != SX_OK) return fail(rc);
-        ReplayJob job = whole_chunk_job(ctx, plen, file_id, is_last != 0 && p + 1 == n_pieces);
-        job.d_bytes = d_bytes + off;
-        job.slice_base = (uint32_t)(off / kInputBufLen);
-        HostBytes host_view(host_bytes ? host_bytes + off : (const uint8_t*)"");
-        ByteView& early_view = host_bytes ? (ByteView&)host_view : (ByteView&)*base_view;
-        std::vector<RunList> runs(nm);
-        PreReplayed pre(nm);
-        for (size_t oi = 0; oi < nm; oi++) {
-            const int k = order[oi];
-            std::vector<RunList> one;
-            rc = stage_a_finish(ctx, { k }, d_bytes + off, plen, parity_of(k, off), { minc[(size_t)k] }, (int)(p & 1), &one);
-            if (rc != SX_OK) return fail(rc);
-            runs[(size_t)k] = std::move(one[0]);
-            if (!runs[(size_t)k].own.empty()) runs[(size_t)k].use_own();  // the vector moved: point at it again
-            ctx->last_runs[(size_t)k] += runs[(size_t)k].size();
-            if (oi + 1 == nm && launched < n_pieces) {  // record slot p&1 is free again (ev_free): queue piece p+2
-                if ((rc = launch(launched++)) != SX_OK) return fail(rc);
-            }
-            if (device_replay_wanted(ctx, job, (size_t)k, runs[(size_t)k].size())) {
-                rc = device_replay_mission(ctx, (size_t)k, early_view, job, runs[(size_t)k], &pre.per[(size_t)k], &pre.ends[(size_t)k]);
-                if (rc != SX_OK) return fail(rc);
-                pre.done[(size_t)k] = 1;
-            }
-        }
-        if (host_bytes) rc = replay_all(ctx, host_view, job, runs, &res.r->r, nullptr, &pre);
-        else {
-            SparseDeviceBytes view(ctx, d_bytes + off);
-            bool base_is_enough = false;
-            rc = download_for_replay(ctx, d_bytes + off, plen, &runs, &view, job, &pre.done, &base_is_enough);
-            if (rc == SX_OK) rc = replay_all(ctx, base_is_enough ? (ByteView&)*base_view : (ByteView&)view, job, runs, &res.r->r, nullptr, &pre);
-        }
-        if (rc != SX_OK) return fail(rc);
+        BufferScan& b = pieces[p];
+        if (p > 0 && (rc = b.fetch_base(ctx)) != SX_OK) return sync_streams_and_return(ctx, rc);
+        ReplayJob job = whole_chunk_job(ctx, b.len, file_id, is_last != 0 && p + 1 == n_pieces);
+        job.d_bytes = b.d_bytes;
+        job.slice_base = (uint32_t)(p * piece / kInputBufLen);
+        std::vector<RunList> runs;
+        rc = b.finish_and_replay(ctx, job,
+                                 [&]() -> int { return launched < n_pieces ? pieces[launched++].launch(ctx) : SX_OK; },  // slot p&1 is free again
+                                 &runs, &res.r->r, nullptr);
+        if (rc != SX_OK) return sync_streams_and_return(ctx, rc);
     }
     ctx->stats.total_ms = now_ms() - t_begin;
     *out = res.release();
@@ -1223,15 +1245,17 @@ static int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d
     if (given_runs) {
         ctx->shard_runs.assign(nm, RunList{});
         for (size_t k = 0; k < nm; k++) ctx->shard_runs[k].assign(given_runs[k], given_runs[k] + given_n[k]);
-    } else if (!(reuse_runs && ctx->shard_runs_valid)) {
-        std::vector<int> which(nm);
-        std::vector<uint32_t> parity(nm, (uint32_t)((file_stream_off + buf_off) & 1));
-        std::vector<uint64_t> minc(nm);
-        for (size_t k = 0; k < nm; k++) { which[k] = (int)k; minc[k] = ctx->missions[k].long_run; }
-        int rc = device_runs(ctx, which, d_bytes, buf_len, parity, minc, &ctx->shard_runs);
-        if (rc != SX_OK) return rc;
     }
-    ctx->shard_runs_valid = true;
+    const bool scan_now = !given_runs && !(reuse_runs && ctx->shard_runs_valid);
+    BufferScan b;
+    if (scan_now) {
+        b.host_bytes = host_bytes; b.d_bytes = d_bytes; b.len = buf_len; b.order = mission_order(ctx); b.slot = 0;
+        b.parity.assign(nm, (uint32_t)((file_stream_off + buf_off) & 1));
+        for (size_t k = 0; k < nm; k++) b.minc.push_back(ctx->missions[k].long_run);
+        int rc = b.fetch_base(ctx);
+        if (rc == SX_OK) rc = b.launch(ctx);
+        if (rc != SX_OK) return sync_streams_and_return(ctx, rc);
+    }
 
     ReplayJob job;
     job.len = buf_len; job.file_id = file_id; job.is_last = false;
@@ -1251,10 +1275,17 @@ static int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d
     int rc;
     ResultHolder res;
     std::vector<uint64_t> ends(nm, 0);
-    if (host_bytes) {
+    if (scan_now) {
+        ctx->shard_runs_valid = false;
+        rc = b.finish_and_replay(ctx, job, nullptr, &ctx->shard_runs, &res.r->r, ends.data());
+        if (rc != SX_OK) return sync_streams_and_return(ctx, rc);
+        ctx->shard_runs_valid = true;
+    } else if (host_bytes) {
+        ctx->shard_runs_valid = true;
         HostBytes view(host_bytes);
         rc = replay_all(ctx, view, job, ctx->shard_runs, &res.r->r, ends.data());
     } else {
+        ctx->shard_runs_valid = true;
         SparseDeviceBytes view(ctx, d_bytes);
         rc = download_for_replay(ctx, d_bytes, buf_len, &ctx->shard_runs, &view, job);
         if (rc != SX_OK) return rc;
