@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--subchunk-kib", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
+    ap.add_argument("--backend", default="nccl", help="process-group backend (testing the N>1 path on one GPU: gloo)")
+    ap.add_argument("--single-device", action="store_true", help="testing: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -60,9 +62,15 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the scan has no CPU path")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    xdev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"   # where the exchanged tensors live
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     wl = WORKLOADS[args.workload]
@@ -102,10 +110,11 @@ def main():
             res = sc.scan_device(dptr, nbytes, file_id=1)
             n = len(res)
         else:
-            # shard scan + "where did you stop" chain + RCCL gather of the Finding buffers to rank 0
-            gathered, res = sharded.scan_sharded(sc, get_buffer, file_len, file_id=1, halo=halo,
-                                                 device=f"cuda:{local_rank}")
-            n = sum(len(fb) // ctypes.sizeof(sx.Finding) for fb, _ in gathered) if rank == 0 else len(res)
+            # shard scan + one all_gather over RCCL ("where did everybody start and stop", finding counts);
+            # the findings stay on the rank that found them: rank k holds segment k, in order
+            counts, res = sharded.scan_sharded(sc, get_buffer, file_len, file_id=1, halo=halo,
+                                               device=xdev, gather=False)
+            n = sum(counts)
         st = sc.stats()
         res.free()
         return n, st
@@ -130,7 +139,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

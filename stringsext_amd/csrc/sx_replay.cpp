@@ -144,7 +144,9 @@ public:
         while (pos < len_) {
             if (!strict_ && !st.last_run_str_was_printed_and_is_maybe_cut_str) {
                 const uint64_t r = next_region_start(pos);
-                if (r >= len_) { pos = len_; break; }
+                // nothing more to replay: the tail's owner brings the state to the buffer end,
+                // anybody else stops at the end of its own range (the halo behind it is not its business)
+                if (r >= len_) { pos = owns_tail_ ? len_ : std::max(pos, std::min(hi_, len_)); break; }
                 if (r >= hi_ && !owns_tail_) { pos = std::max(pos, hi_); break; }
                 pos = r;
             }

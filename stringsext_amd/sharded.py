@@ -1,9 +1,11 @@
 """Byte-range sharding of one input file over the GPUs of a node: one process per GPU,
 `torch.distributed` for the two tiny exchanges the path really has —
 
-  1. where each rank's replay stopped (one u64 per mission, chained rank by rank: a rank
-     whose predecessor ran past the shard boundary repeats its replay from there), and
-  2. the gather of the Finding buffers to rank 0 (RCCL over xGMI with backend "nccl").
+  1. where each rank's replay started and stopped (two u64 per mission + a count, one
+     all_gather; a rank whose predecessor ran past the point it started from repeats its replay
+     from there — rare — and the table is exchanged again), and
+  2. optionally the gather of the Finding buffers to rank 0 (RCCL over xGMI with backend
+     "nccl"); by default the findings stay distributed, rank k holding segment k.
 
 There is no collective on the data path: every rank scans its own byte range (plus a halo)
 with the same kernels as the single-GPU path.  The reference has nothing comparable (one
@@ -11,7 +13,10 @@ thread per Mission, src/main.rs:97-151); the splice reproduces what its single s
 stream would have printed.
 """
 import ctypes
+import os
 import struct
+import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -42,8 +47,10 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
 
     get_buffer(lo, hi) -> bytes | ctypes.c_void_p : the file bytes [lo, hi) on this rank.
     runs_for_buffer(buf_bytes, buf_off) -> runs per mission (tests on CPU: stage B only).
-    Returns on rank 0 (gather=True): list of (findings_bytes, arena_bytes) per rank, in rank order;
-    on other ranks None.  Every rank also gets its own Result as second value.
+    gather=True: rank 0 gets the list of (findings_bytes, arena_bytes) per rank, in rank order (a
+    gather over the process group), the other ranks None.  gather=False: the findings stay where
+    they are — rank k's Result is segment k of the file's findings, in order — and every rank
+    gets the list of per-rank finding counts.  The rank's own Result is the second value.
     """
     world, rank = dist.get_world_size(), dist.get_rank()
     own_lo, own_hi = shard_bounds(file_len, world, rank)
@@ -64,33 +71,46 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
         return res, ends, truncated, buf_hi
 
     # first attempt: everybody assumes the previous rank stops at the shard boundary
+    t_begin = time.perf_counter()
     h = halo
+    start = [own_lo] * nm
     res, ends, truncated, _ = attempt(None, h, False)
     while truncated:  # a run crosses the whole halo: look further
         h *= 8
         res.free()
         res, ends, truncated, _ = attempt(None, h, False)
 
-    # chain: rank k learns where rank k-1 really stopped; almost always that is own_lo
-    prev_end = [own_lo] * nm
-    for k in range(1, world):
-        src_ends = ends if rank == k - 1 else [0] * nm
-        t = torch.tensor(src_ends, dtype=torch.int64, device=device)
-        dist.broadcast(t, src=k - 1)
-        if rank == k:
-            prev_end = [int(x) for x in t.tolist()]
-            if any(p > own_lo for p in prev_end):
-                start = [max(own_lo, p) for p in prev_end]
+    # Where did everybody stop?  One all_gather of (start used, end reached) per mission + the
+    # finding count; rank k must repeat its replay if rank k-1 ran past the point rank k started
+    # from (rare: a region crossing the shard boundary).  Every rank evaluates the same table,
+    # so all agree on who repeats; a repeat can move that rank's own end, hence the loop.
+    t_scan = time.perf_counter()
+    while True:
+        table = _all_gather_u64(start + ends + [len(res)], device)
+        redo = [False] * world
+        for k in range(1, world):
+            prev_end, my_start = table[k - 1][nm:2 * nm], table[k][:nm]
+            k_lo = shard_bounds(file_len, world, k)[0]
+            redo[k] = any(max(k_lo, p) > s0 for p, s0 in zip(prev_end, my_start))
+        if not any(redo):
+            break
+        if redo[rank]:
+            prev_end = table[rank - 1][nm:2 * nm]
+            start = [max(own_lo, p, s0) for p, s0 in zip(prev_end, start)]
+            res.free()
+            res, ends, truncated, _ = attempt(start, h, True)
+            while truncated:
+                h *= 8
                 res.free()
-                res, ends, truncated, _ = attempt(start, h, True)
-                while truncated:
-                    h *= 8
-                    res.free()
-                    res, ends, truncated, _ = attempt(start, h, False)
-                ends = [max(e, p) for e, p in zip(ends, prev_end)]
+                res, ends, truncated, _ = attempt(start, h, False)
+            ends = [max(e, p) for e, p in zip(ends, prev_end)]
+    counts = [row[2 * nm] for row in table]
+    if os.environ.get("SX_TIMING") and rank == 0:
+        print(f"[sx] sharded: scan {1e3 * (t_scan - t_begin):.2f} ms, exchange {1e3 * (time.perf_counter() - t_scan):.2f} ms",
+              file=sys.stderr)
 
     if not gather:
-        return None, res
+        return counts, res
     fb, ab = res.raw()
     blob = struct.pack("<QQ", len(fb), len(ab)) + fb + ab
     sizes = _all_gather_u64([len(blob)], device)

@@ -47,7 +47,7 @@ def make_data(kind, seed):
     raise ValueError(kind)
 
 
-def _worker(rank, world, port, kind, flags, halo, q):
+def _worker(rank, world, port, kind, flags, halo, q, gather=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -57,14 +57,22 @@ def _worker(rank, world, port, kind, flags, halo, q):
         data = make_data(kind, 1234)
         ms = rc.missions(**flags)
         sc = sx.Scanner(ms, device=sx.SX_HOST_ONLY)
-        gathered, _ = sharded.scan_sharded(
+        gathered, res = sharded.scan_sharded(
             sc, lambda lo, hi: data[lo:hi], len(data), file_id=1, halo=halo, device="cpu",
-            runs_for_buffer=lambda buf, off: oracle_runs_for_chunk(ms, buf, off))
+            runs_for_buffer=lambda buf, off: oracle_runs_for_chunk(ms, buf, off), gather=gather)
+        key = lambda f: (f["position"], f["precision"], f["s"], f["completes"], f["mission_id"], f["slice_index"])
+        if not gather:  # the findings stay distributed: rank k holds segment k; `gathered` = counts per rank
+            assert gathered[rank] == len(res) and len(gathered) == world
+            parts = [None] * world
+            dist.gather_object([key(f) for f in res.findings()], parts if rank == 0 else None, dst=0)
         if rank == 0:
             got = []
-            for fb, ab in gathered:
-                got += [(f["position"], f["precision"], f["s"], f["completes"], f["mission_id"], f["slice_index"])
-                        for f in sharded.decode_findings(fb, ab)]
+            if gather:
+                for fb, ab in gathered:
+                    got += [key(f) for f in sharded.decode_findings(fb, ab)]
+            else:
+                for part in parts:
+                    got += part
             want = oracle_findings(ms, data)
             q.put(("ok", got == want, len(got), len(want),
                    next(((a, b) for a, b in zip(got, want) if a != b), None)))
@@ -91,12 +99,13 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("gather", [True, False], ids=["gathered", "distributed"])
 @pytest.mark.parametrize("world,kind,flags,halo", CASES, ids=[f"{c[0]}ranks-{c[1]}-{i}" for i, c in enumerate(CASES)])
-def test_sharded_scan_equals_sequential(world, kind, flags, halo):
+def test_sharded_scan_equals_sequential(world, kind, flags, halo, gather):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, flags, halo, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, flags, halo, q, gather)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=600)
