@@ -19,6 +19,7 @@
 // a short fast path; the slow path resolves stretches across lanes with a ballot-guided
 // look-back and appends records with one atomic per wave.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include <type_traits>
@@ -937,10 +938,56 @@ __global__ __launch_bounds__(256) void read_subchunk_kernel(const uint8_t* data,
     if (acc == 0x12345678u) atomicAdd((unsigned long long*)out, 1ull);
 }
 
+// Access-pattern probe (tools/gpu_probe5.py): LOADS x 1 KiB per iteration and wavefront, two
+// iterations in flight.  MODE 0: a private sub-chunk per wavefront (the scan kernels' traversal);
+// MODE 1: the four wavefronts of a block share a sub-chunk of 4 x subchunk and take its tiles in turn.
+// Measured on MI355X, 32 GiB: grid-stride 6.97 TB/s; sub-chunk 16 KiB 6.74, 64 KiB-1 MiB 6.1-6.3 TB/s
+// whatever LOADS and MODE: the traversal itself caps a scan kernel at ~6.2 TB/s.
+template <int LOADS, int MODE>
+__global__ __launch_bounds__(256) void read_pattern_kernel(const uint8_t* data, u64 len, u32 subchunk, u64* out) {
+    const u32 lane = lane_id();
+    const u32 wib = uniform(threadIdx.x >> 6);
+    u64 sub_start, span;
+    u32 first, step;
+    if (MODE == 0) { sub_start = ((u64)blockIdx.x * 4u + wib) * subchunk; span = subchunk; first = 0; step = LOADS * kTileBytes; }
+    else { sub_start = (u64)blockIdx.x * 4u * subchunk; span = 4ull * subchunk; first = wib * LOADS * kTileBytes; step = 4u * LOADS * kTileBytes; }
+    if (sub_start >= len) return;
+    const u64 sub_end = sub_start + span < len ? sub_start + span : len;
+    const uint8_t* base_ptr = data + sub_start;
+    const u32 base_lo = uniform((u32)(uintptr_t)base_ptr), base_hi = uniform((u32)((uintptr_t)base_ptr >> 32));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((u64)base_hi << 32) | base_lo), 0, (int)uniform((u32)(sub_end - sub_start)), 0x00020000);
+    u32x4 cur[LOADS], nxt[LOADS];
+    u32 off = first + lane * 16u;
+#pragma unroll
+    for (int k = 0; k < LOADS; k++) {
+        cur[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + k * kTileBytes), 0, 0);
+        nxt[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + step + k * kTileBytes), 0, 0);
+    }
+    u32 acc = 0;
+    for (u32 o = first; o < (u32)(sub_end - sub_start); o += step) {
+        u32x4 nn[LOADS];
+#pragma unroll
+        for (int k = 0; k < LOADS; k++) nn[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 2 * step + k * kTileBytes), 0, 0);
+#pragma unroll
+        for (int k = 0; k < LOADS; k++) { acc += cur[k].x ^ cur[k].y ^ cur[k].z ^ cur[k].w; cur[k] = nxt[k]; nxt[k] = nn[k]; }
+        off += step;
+    }
+    if (acc == 0x12345678u) atomicAdd((unsigned long long*)out, 1ull);
+}
+
 hipError_t launch_read_sum(const uint8_t* src, u64 len, u64* out, hipStream_t stream, uint32_t subchunk) {
     if (subchunk) {
+        const int loads = getenv("SX_PROBE_LOADS") ? atoi(getenv("SX_PROBE_LOADS")) : 0;
+        const int mode = getenv("SX_PROBE_MODE") ? atoi(getenv("SX_PROBE_MODE")) : 0;
         u64 waves = (len + subchunk - 1) / subchunk;
-        hipLaunchKernelGGL(read_subchunk_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, src, len, subchunk, out);
+        const dim3 grid((unsigned)((waves + 3) / 4));
+        if (loads == 0 && mode == 0)
+            hipLaunchKernelGGL(read_subchunk_kernel, grid, dim3(256), 0, stream, src, len, subchunk, out);
+#define SX_RP(L, M) else if (loads == L && mode == M) hipLaunchKernelGGL((read_pattern_kernel<L, M>), grid, dim3(256), 0, stream, src, len, subchunk, out)
+        SX_RP(1, 0); SX_RP(2, 0); SX_RP(4, 0); SX_RP(1, 1); SX_RP(2, 1); SX_RP(4, 1);
+#undef SX_RP
+        else return hipErrorInvalidValue;
     } else {
         hipLaunchKernelGGL(read_sum_kernel, dim3(256 * 8), dim3(256), 0, stream, (const u32x4*)src, len / 16, out);
     }
