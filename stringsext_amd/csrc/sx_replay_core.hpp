@@ -399,6 +399,13 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
                     while (ri < P.n_runs && P.runs[ri].end <= p) ri++;
                     const u64 rs = ri < P.n_runs ? P.runs[ri].start : ~0ull;
                     if (rs >= wend) {  // (B) nothing long starts in the rest of this window
+                        // If the region ends there anyway (no run begins in the next window, and the
+                        // leftover — at most one derived char — is droppable) the state is never read.
+                        if (P.long_run > 1 && (ri >= P.n_runs || win_start(rs, W) > wend)) {
+                            leftover_len = 0; dout = 0; din = dend;
+                            ddec_reset(dec, (int)P.encoding, P.table);
+                            break;
+                        }
                         leftover_len = derive_at<ENC>(P, wend, p, dec, ob);
                         dout = leftover_len;
                         din = dend;
