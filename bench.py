@@ -28,6 +28,9 @@ WORKLOADS = {
     "c3": dict(flags=dict(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10",
                           unicode_block_filter="African"), gib=64.0,
                name="C3(i): -e utf-8 -e utf-16le -e utf-16be -n 10 -u African -t x, synthetic background"),
+    # BASELINE.json configs[0] at a GPU-sized length (the text-dense extreme: ~11.8 k findings per MiB)
+    "c1": dict(flags=dict(encodings=["ascii"], chars_min="4"), gib=1.0,
+               name="C1-like: -e ascii -n 4 -t x, synthetic background (dense: every 85th byte starts a finding)"),
     # BASELINE.json configs[1]
     "c2": dict(flags=dict(encodings=["utf-8"], chars_min="10"), gib=4.0,
                name="C2: -e utf-8 -n 10 -t x, synthetic background"),

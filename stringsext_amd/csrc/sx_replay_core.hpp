@@ -219,6 +219,11 @@ SXD bool dsplit_next(const ReplayParams& m, DSplit& it, DChunk& out) {
 // Window grid (twin of sx_replay.cpp)
 // ------------------------------------------------------------------------------------------
 SXD u64 win_start(u64 p, u32 W) { const u64 s = p / kSliceLen * kSliceLen; return s + (p - s) / W * W; }
+SXD u64 next_win_start(u64 p, u32 W) {  // start of the window after the one that holds p
+    const u64 s = p / kSliceLen * kSliceLen;
+    const u64 e = s + (p - s) / W * W + W;
+    return e < s + kSliceLen ? e : s + kSliceLen;
+}
 
 // ------------------------------------------------------------------------------------------
 // Shortcuts through bytes that cannot matter (device replay only; the host replayer decodes

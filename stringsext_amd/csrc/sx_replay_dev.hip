@@ -31,8 +31,10 @@ namespace sx {
 #include "sx_replay_core.hpp"
 namespace sx {
 
-// Pass 1: one lane per run; a run whose window is certainly inside the region of the run
-// before it is marked kRegionChained right away (the earlier region follows it).
+// Pass 1: one lane per run.  A run that begins in the window where the run before it ends, or in
+// the very next one, is certainly inside the region that holds that run (the replay only stops
+// at a window end after which no run begins at once): it is marked kRegionChained right away.
+// On string-dense input this keeps nearly every lane from replaying what another one covers.
 template <int ENC, bool CACHED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void replay_count_kernel(
     const ReplayParams P, ReplayRegionOut* out, sx_finding* cache_f, u8* cache_s) {
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void re
     o.end = 0; o.n_find = 0; o.n_bytes = 0; o.status = kRegionOk; o.pad = 0;
     const u64 want = win_start(P.runs[i].start, P.W);
     if (want < P.lo || want >= P.hi) o.status = kRegionNotMine;
-    else if (i > 0 && want <= win_start(P.runs[i - 1].end - 1, P.W)) o.status = kRegionChained;
+    else if (i > 0 && want <= next_win_start(P.runs[i - 1].end - 1, P.W)) o.status = kRegionChained;
     else if (CACHED) replay_region<2, ENC>(P, i, o, cache_f + i * kCacheFindings, cache_s + i * kCacheBytes, 0);
     else replay_region<0, ENC>(P, i, o, nullptr, nullptr, 0);
     out[i] = o;
