@@ -123,6 +123,33 @@ enum {
     SX_OPT_MISSION_STREAMS = 16u  /* a scan stream per mission (default: one scan stream + one for everything else) */
 };
 
+/* ---- Mission front end (src/mission.rs:448-749, src/options.rs:12-33) ------------------------------
+ * From the reference's option strings to sx_mission[]: per-encoding overrides
+ * (`-e ENC[,MIN[,AF[,UBF[,GREP]]]]`), global flags, defaults, alias prefix matching, WHATWG encoding
+ * labels, the reference's error texts.  Pointers may be NULL (= flag not given). */
+typedef struct sx_cli_flags {
+    const char* counter_offset;          /* -s */
+    const char* const* encodings;        /* -e, in command-line order */
+    int n_encodings;
+    const char* chars_min;               /* -n */
+    int same_unicode_block;              /* -r */
+    const char* ascii_filter;            /* -a */
+    const char* unicode_block_filter;    /* -u */
+    const char* grep_char;               /* -g */
+    const char* output_line_len;         /* -q */
+} sx_cli_flags;
+typedef struct sx_enc_opt {              /* Missions::parse_enc_opt's tuple of Options */
+    int has_name; char name[64];
+    int has_chars_min; uint8_t chars_min;
+    int has_af; uint64_t af_lo, af_hi;
+    int has_ubf; uint64_t ubf;
+    int has_grep_char; uint8_t grep_char;
+} sx_enc_opt;
+int sx_missions_from_flags(const sx_cli_flags* flags, sx_mission* out, int cap, int* n_out, char* err, size_t err_cap);
+int sx_parse_enc_opt(const char* enc_opt, sx_enc_opt* out, char* err, size_t err_cap);
+int sx_encoding_for_label(const char* label);      /* SX_ENC_*; -1 not a label; -2 a label of an encoding not built in */
+const char* sx_encoding_name(uint32_t encoding);   /* Encoding::name(), e.g. "UTF-16LE" */
+
 int  sx_abi_version(void);
 
 /* hip_device >= 0: bind to that device.  hip_device == SX_HOST_ONLY: a context

@@ -23,6 +23,7 @@ PRECISION = {0: "Before", 1: "Exact", 2: "After"}
 # every symbol include/stringsext_amd.h declares
 EXPORTS = ["sx_abi_version", "sx_create", "sx_destroy", "sx_last_error", "sx_scan", "sx_scan_device", "sx_reset",
            "sx_device_runs", "sx_replay_runs", "sx_scan_shard_device", "sx_scan_shard", "sx_replay_shard_runs",
+           "sx_missions_from_flags", "sx_parse_enc_opt", "sx_encoding_for_label", "sx_encoding_name",
            "sx_result_count", "sx_result_segments", "sx_result_segment", "sx_result_findings", "sx_result_arena",
            "sx_result_free", "sx_print_findings", "sx_get_stats", "sx_free", "sx_fill_background_device",
            "sx_device_alloc", "sx_device_free", "sx_device_upload", "sx_device_download",
@@ -52,6 +53,61 @@ class Mission(C.Structure):
         m.ubf = d["ubf"]
         m.counter_offset = d["counter_offset"]
         return m
+
+    def to_dict(self):
+        return dict(mission_id=self.mission_id, encoding=self.encoding, chars_min_nb=self.chars_min_nb,
+                    require_same_unicode_block=bool(self.require_same_unicode_block),
+                    grep_char=None if self.grep_char < 0 else self.grep_char,
+                    af=(self.af_hi << 64) | self.af_lo, ubf=self.ubf,
+                    output_line_char_nb_max=self.output_line_char_nb_max, counter_offset=self.counter_offset,
+                    print_encoding_as_ascii=bool(self.print_encoding_as_ascii))
+
+
+class CliFlags(C.Structure):
+    """sx_cli_flags — the option strings of the reference's command line (src/options.rs:46-90)."""
+    _fields_ = [("counter_offset", C.c_char_p), ("encodings", C.POINTER(C.c_char_p)), ("n_encodings", C.c_int),
+                ("chars_min", C.c_char_p), ("same_unicode_block", C.c_int), ("ascii_filter", C.c_char_p),
+                ("unicode_block_filter", C.c_char_p), ("grep_char", C.c_char_p), ("output_line_len", C.c_char_p)]
+
+
+class EncOpt(C.Structure):
+    _fields_ = [("has_name", C.c_int), ("name", C.c_char * 64), ("has_chars_min", C.c_int), ("chars_min", C.c_uint8),
+                ("has_af", C.c_int), ("af_lo", C.c_uint64), ("af_hi", C.c_uint64), ("has_ubf", C.c_int), ("ubf", C.c_uint64),
+                ("has_grep_char", C.c_int), ("grep_char", C.c_uint8)]
+
+
+def missions_from_flags(encodings=(), chars_min=None, same_unicode_block=False, ascii_filter=None,
+                        unicode_block_filter=None, grep_char=None, output_line_len=None, counter_offset=None):
+    """Missions::new (src/mission.rs:514-703) through the C-ABI: option strings -> mission dicts.
+    Raises SxError with the reference's message on a bad option."""
+    enc = [e.encode() for e in encodings]
+    arr = (C.c_char_p * max(1, len(enc)))(*enc)
+    b = lambda v: None if v is None else str(v).encode()
+    f = CliFlags(b(counter_offset), arr, len(enc), b(chars_min), int(bool(same_unicode_block)), b(ascii_filter),
+                 b(unicode_block_filter), b(grep_char), b(output_line_len))
+    out = (Mission * 32)()
+    n = C.c_int()
+    err = C.create_string_buffer(512)
+    L = lib()
+    L.sx_missions_from_flags.argtypes = [C.POINTER(CliFlags), C.POINTER(Mission), C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+    rc = L.sx_missions_from_flags(C.byref(f), out, 32, C.byref(n), err, 512)
+    if rc != SX_OK:
+        raise SxError(rc, err.value.decode())
+    return [out[i].to_dict() for i in range(n.value)]
+
+
+def parse_enc_opt(text):
+    """Missions::parse_enc_opt (src/mission.rs:713-749): (name, chars_min, af, ubf, grep_char), None where absent."""
+    o = EncOpt()
+    err = C.create_string_buffer(512)
+    L = lib()
+    L.sx_parse_enc_opt.argtypes = [C.c_char_p, C.POINTER(EncOpt), C.c_char_p, C.c_size_t]
+    rc = L.sx_parse_enc_opt(text.encode(), C.byref(o), err, 512)
+    if rc != SX_OK:
+        raise SxError(rc, err.value.decode())
+    return (o.name.decode() if o.has_name else None, o.chars_min if o.has_chars_min else None,
+            ((o.af_hi << 64) | o.af_lo) if o.has_af else None, o.ubf if o.has_ubf else None,
+            o.grep_char if o.has_grep_char else None)
 
 
 class Finding(C.Structure):

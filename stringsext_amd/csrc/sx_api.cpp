@@ -1037,13 +1037,13 @@ uint64_t piece_bytes(const sx_ctx* ctx, uint64_t len) {
 namespace {
 // Missions in the order their kernels are queued: busiest of the previous buffer first, so that
 // its stage B (the longest) overlaps the scans of the others.
-std::vector<int> mission_order(sx_ctx* ctx) {
+void mission_order(sx_ctx* ctx, std::vector<int>* out) {
     const size_t nm = ctx->missions.size();
-    std::vector<int> order(nm);
+    std::vector<int>& order = *out;
+    order.resize(nm);
     for (size_t k = 0; k < nm; k++) order[k] = (int)k;
     if (ctx->last_runs.size() == nm)
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ctx->last_runs[(size_t)x] > ctx->last_runs[(size_t)y]; });
-    return order;
 }
 
 int sync_streams_and_return(sx_ctx* ctx, int rc) {  // do not leave kernels running on the caller's buffer
@@ -1128,7 +1128,8 @@ static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_
     const size_t nm = ctx->missions.size();
     std::vector<uint64_t> stream0(nm);
     for (size_t k = 0; k < nm; k++) stream0[k] = ctx->states[k].stream_bytes;
-    const std::vector<int> order = mission_order(ctx);
+    std::vector<int> order;
+    mission_order(ctx, &order);
     const uint64_t piece = piece_bytes(ctx, len);
     const uint64_t n_pieces = len ? (len + piece - 1) / piece : 1;
     auto make = [&](uint64_t p) {
@@ -1249,7 +1250,7 @@ static int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d
     const bool scan_now = !given_runs && !(reuse_runs && ctx->shard_runs_valid);
     BufferScan b;
     if (scan_now) {
-        b.host_bytes = host_bytes; b.d_bytes = d_bytes; b.len = buf_len; b.order = mission_order(ctx); b.slot = 0;
+        b.host_bytes = host_bytes; b.d_bytes = d_bytes; b.len = buf_len; mission_order(ctx, &b.order); b.slot = 0;
         b.parity.assign(nm, (uint32_t)((file_stream_off + buf_off) & 1));
         for (size_t k = 0; k < nm; k++) b.minc.push_back(ctx->missions[k].long_run);
         int rc = b.fetch_base(ctx);
