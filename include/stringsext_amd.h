@@ -174,6 +174,19 @@ int sx_scan(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_file_id,
 int sx_scan_device(sx_ctx* ctx, const void* device_bytes, uint64_t len, int input_file_id,
                    int is_last_input_buffer, sx_result** out);
 
+/* Ingest pipeline (the Slicer's job, src/input.rs:57-167, for chunks instead of 4 KiB slices):
+ * a reader thread fills pinned buffers from `read` (returns bytes read, 0 at the end of the
+ * input, < 0 on error; short reads are fine) and copies them to HBM while the chunk before is
+ * scanned.  Every chunk of `chunk_bytes` (rounded to the 4096-byte grid; 0 = 256 MiB) gives
+ * one result, handed to `sink` in input order; the sink owns it (sx_result_free) and returns
+ * 0 to go on.  sx_scan_file reads a file with read(2) ("-" = stdin). */
+typedef int64_t (*sx_read_fn)(void* user, uint8_t* dst, uint64_t max_bytes);
+typedef int (*sx_result_fn)(void* user, sx_result* result);
+int sx_scan_stream(sx_ctx* ctx, sx_read_fn read, void* read_user, uint64_t chunk_bytes, int input_file_id,
+                   sx_result_fn sink, void* sink_user);
+int sx_scan_file(sx_ctx* ctx, const char* path, uint64_t chunk_bytes, int input_file_id,
+                 sx_result_fn sink, void* sink_user);
+
 /* Reset the carried ScannerState of every mission (scanner.rs:73-88). */
 int sx_reset(sx_ctx* ctx);
 

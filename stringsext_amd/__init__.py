@@ -23,7 +23,7 @@ PRECISION = {0: "Before", 1: "Exact", 2: "After"}
 # every symbol include/stringsext_amd.h declares
 EXPORTS = ["sx_abi_version", "sx_create", "sx_destroy", "sx_last_error", "sx_scan", "sx_scan_device", "sx_reset",
            "sx_device_runs", "sx_replay_runs", "sx_scan_shard_device", "sx_scan_shard", "sx_replay_shard_runs",
-           "sx_missions_from_flags", "sx_parse_enc_opt", "sx_encoding_for_label", "sx_encoding_name",
+           "sx_scan_stream", "sx_scan_file", "sx_missions_from_flags", "sx_parse_enc_opt", "sx_encoding_for_label", "sx_encoding_name",
            "sx_result_count", "sx_result_segments", "sx_result_segment", "sx_result_findings", "sx_result_arena",
            "sx_result_free", "sx_print_findings", "sx_get_stats", "sx_free", "sx_fill_background_device",
            "sx_device_alloc", "sx_device_free", "sx_device_upload", "sx_device_download",
@@ -331,6 +331,43 @@ class Scanner:
         out = n.value if count_only else [(runs[i].start, runs[i].end, runs[i].chars) for i in range(n.value)]
         lib().sx_free(runs)
         return out
+
+    def scan_file(self, path, chunk_bytes=0, file_id=1):
+        """Ingest pipeline (sx_scan_file): the file is read, copied to HBM and scanned chunk by chunk,
+        overlapped; returns the chunks' Results in input order."""
+        results = []
+        SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+        def sink(_user, handle):
+            results.append(Result(self, C.c_void_p(handle)))
+            return 0
+        cb = SINK(sink)
+        L = lib()
+        L.sx_scan_file.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int, SINK, C.c_void_p]
+        self._chk(L.sx_scan_file(self.h, os.fsencode(path), chunk_bytes, file_id, cb, None))
+        return results
+
+    def scan_stream(self, readinto, chunk_bytes=0, file_id=1):
+        """sx_scan_stream with a Python reader: readinto(memoryview) -> bytes written (0 at the end)."""
+        results = []
+        SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+        READ = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64)
+
+        def sink(_user, handle):
+            results.append(Result(self, C.c_void_p(handle)))
+            return 0
+
+        def read(_user, dst, max_bytes):
+            try:
+                view = memoryview((C.c_uint8 * max_bytes).from_address(C.addressof(dst.contents))).cast("B")
+                return int(readinto(view) or 0)
+            except Exception:
+                return -1
+        cb, rd = SINK(sink), READ(read)
+        L = lib()
+        L.sx_scan_stream.argtypes = [C.c_void_p, READ, C.c_void_p, C.c_uint64, C.c_int, SINK, C.c_void_p]
+        self._chk(L.sx_scan_stream(self.h, rd, None, chunk_bytes, file_id, cb, None))
+        return results
 
     def reset(self):
         self._chk(lib().sx_reset(self.h))

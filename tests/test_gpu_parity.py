@@ -280,3 +280,33 @@ def test_pieces_pipeline_equals_oracle(device_replay, monkeypatch):
     fb, arena = res.raw()           # joins the segments
     assert len(res.segments()) == 1 and res.findings() == seg_view and len(fb) == len(seg_view) * 32
     sc.free(d); sc.close()
+
+
+def test_ingest_pipeline_file_and_stream(tmp_path):
+    """sx_scan_file / sx_scan_stream: reader thread + pinned double buffer + H2D overlapped with the
+    scan; every chunk is one sx_scan call with carried state, so the printed text equals the oracle's."""
+    rng = random.Random(31)
+    ms = rc.missions(encodings=["utf-8", "utf-16le", "ascii"], chars_min="6")
+    data = synth(rng, (5 << 20) + 4096 * 3 + 77, 1 / 500)
+    want = sxo.run_cli(ms, [data], radix="x")
+    path = tmp_path / "image.bin"
+    path.write_bytes(data)
+    for chunk in (1 << 20, 64 << 10, 0):
+        sc = sx.Scanner(ms, device=0)
+        parts = sc.scan_file(str(path), chunk_bytes=chunk, file_id=1)
+        got = sx.OUTPUT_BOM + b"".join(r.printed(n_inputs=1, radix="x") for r in parts) + b"\n"
+        assert got == want, chunk
+        assert len(parts) == (1 if chunk == 0 else -(-len(data) // chunk))
+        sc.close()
+    # a Python reader that returns short reads
+    sc = sx.Scanner(ms, device=0)
+    pos = [0]
+
+    def readinto(view):
+        n = min(len(view), rng.randrange(1, 300_000), len(data) - pos[0])
+        view[:n] = data[pos[0]:pos[0] + n]
+        pos[0] += n
+        return n
+    parts = sc.scan_stream(readinto, chunk_bytes=2 << 20, file_id=1)
+    assert sx.OUTPUT_BOM + b"".join(r.printed(n_inputs=1, radix="x") for r in parts) + b"\n" == want
+    sc.close()
