@@ -174,9 +174,19 @@ def main():
         # SX_MISSION_STREAMS=1 they overlap on a stream each and the span is the longest one.)
         span_ms = max(kernel_ms) if os.environ.get("SX_MISSION_STREAMS") else sum(kernel_ms)
         agg_gbs = len(missions) * nbytes / (span_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters: they cannot be read inside this process, so the
+        # value comes from the committed counter passes of this very command line (profiles/traffic.json
+        # says how); null for any other workload or size
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj["workload"] == args.workload and tj["bytes_per_gpu"] == nbytes:
+                traffic = tj["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {
             "bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernel": "sx::scan_kernel<Utf8Range2|Utf16Range>, %d launches per step, average" % len(missions),
             "algorithmic_bytes_per_launch": nbytes,
             "per_kernel_ms": [round(x, 3) for x in kernel_ms],
