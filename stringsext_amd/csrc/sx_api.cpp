@@ -662,7 +662,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
 
     // ---- splice (almost always: device findings only)
     if (host_parts.empty()) {
-        if (blk.p) { out->ext = blk; out->ext_nf = nf; out->ext_na = nb; }
+        if (blk.p) { out->ext = blk; out->ext_nf = nf; out->ext_na = nb; out->dev_copy = d.d_rp[5]; }
     } else {
         const sx_finding* dev_f = (const sx_finding*)blk.p;
         const char* dev_a = blk.p ? (const char*)blk.p + nf * sizeof(sx_finding) : nullptr;
@@ -791,6 +791,45 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
     if (end_pos) for (size_t k = 0; k < nm; k++) end_pos[k] = ends[k];
     const double t_stitch = now_ms();
     const size_t count_before = into->count();
+    {   // several missions with findings that are all still on the device: interleave them there
+        // (a stable radix sort by position) instead of finding by finding on the host
+        size_t with = 0, on_dev = 0, total = 0, bytes = 0;
+        bool same_origin = true;
+        for (size_t k = 0; k < nm; k++) {
+            if (!per[k].count()) continue;
+            with++;
+            if (per[k].ext.p && per[k].dev_copy) on_dev++;
+            total += per[k].count(); bytes += per[k].strings_len();
+            same_origin = same_origin && ctx->missions[k].c.counter_offset == ctx->missions[0].c.counter_offset;
+        }
+        if (with >= 2 && on_dev == with && same_origin && bytes <= 0xFFFFFFFFull && total >= 4096 && !getenv("SX_HOST_MERGE")) {
+            const double tm0 = now_ms();
+            std::vector<const void*> srcs(nm, nullptr);
+            std::vector<uint64_t> nfs(nm, 0), nbs(nm, 0);
+            for (size_t k = 0; k < nm; k++)
+                if (per[k].count()) { srcs[k] = per[k].dev_copy; nfs[k] = per[k].ext_nf; nbs[k] = per[k].ext_na; }
+            int rc = ensure_scratch(ctx, merge_findings_scratch_bytes(total) + total * sizeof(sx_finding) + bytes + 512);
+            if (rc != SX_OK) return rc;
+            uint8_t* d_out = ctx->d_scratch;
+            const size_t out_bytes = total * sizeof(sx_finding) + bytes;
+            uint8_t* d_tmp = d_out + ((out_bytes + 255) & ~(size_t)255);
+            hipStream_t s = ctx->post_stream;
+            HIP_TRY(ctx, merge_findings_device(srcs.data(), nfs.data(), nbs.data(), (int)nm, d_out, d_tmp,
+                                               ctx->d_scratch_cap - (size_t)(d_tmp - ctx->d_scratch), s));
+            PinnedPool::Block blk = ctx->pool->take(out_bytes + 64);
+            if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
+            HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            uint64_t rb = 0;
+            for (size_t k = 0; k < nm; k++) {
+                rb += per[k].replay_bytes;
+                if (per[k].ext.p) ctx->pool->give(per[k].ext);
+                per[k] = MissionFindings{};
+            }
+            per[0].ext = blk; per[0].ext_nf = total; per[0].ext_na = bytes; per[0].replay_bytes = rb;
+            if (getenv("SX_TIMING")) fprintf(stderr, "[sx] device merge of %zu missions: %zu findings, %.2f ms\n", with, total, now_ms() - tm0);
+        }
+    }
     merge_findings(per, ctx->pool, into);
     if (getenv("SX_TIMING")) {
         double mx = 0, sum = 0;

@@ -105,6 +105,11 @@ hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegion
                                        const uint64_t* fpos, const uint64_t* apos, const void* cache, sx_finding* findings,
                                        uint8_t* arena, hipStream_t stream);
 
+// interleave several missions' findings on the device (sx_sort.hip); every src and out = [findings][string bytes]
+size_t merge_findings_scratch_bytes(uint64_t n_findings);
+hipError_t merge_findings_device(const void* const* srcs, const uint64_t* nf, const uint64_t* nb, int n_missions, void* out,
+                                 void* scratch, size_t scratch_bytes, hipStream_t stream);
+
 // order run records by start on the device (sx_sort.hip); unused slots end up last with start = ~0
 size_t sort_scratch_bytes(uint32_t n);
 hipError_t sort_records(DevRun* recs, uint32_t n, void* scratch, size_t scratch_bytes, hipStream_t stream);

@@ -176,6 +176,9 @@ struct MissionFindings {
     // [ext_nf x sx_finding][ext_na bytes of strings]
     PinnedPool::Block ext{};
     size_t ext_nf = 0, ext_na = 0;
+    // ... and, until the next scan of the mission, also still on the device (same layout):
+    // several missions' findings are interleaved there instead of on the host
+    const void* dev_copy = nullptr;
     size_t count() const { return ext.p ? ext_nf : v.size(); }
     const sx_finding* data() const { return ext.p ? (const sx_finding*)ext.p : v.data(); }
     const char* strings() const { return ext.p ? (const char*)ext.p + ext_nf * sizeof(sx_finding) : arena.data(); }

@@ -214,4 +214,64 @@ hipError_t merge_sorted_records(const DevRun* recs, uint32_t n, uint64_t min_cha
     return hipGetLastError();
 }
 
+
+// ---- interleave the findings of several missions (src/main.rs:118-136: the merger) ---------
+// Every mission's findings are ordered by position; across missions the merger orders by position
+// and, on ties, by mission.  All missions of a call count bytes from the same origin, so the key is
+// the position alone: a stable radix sort over the concatenation (mission 0's findings first, then
+// mission 1's, ...) yields exactly the merger's order.
+__global__ __launch_bounds__(256) void merge_gather_in_kernel(const sx_finding* src, uint64_t n, uint32_t arena_base, uint64_t out_base,
+                                                              sx_finding* all, uint64_t* keys, uint64_t* vals) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    sx_finding f = src[i];
+    f.str_off += arena_base;
+    all[out_base + i] = f;
+    keys[out_base + i] = f.position;
+    vals[out_base + i] = out_base + i;
+}
+__global__ __launch_bounds__(256) void merge_gather_out_kernel(const sx_finding* all, const uint64_t* order, uint64_t n, sx_finding* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = all[order[i]];
+}
+size_t merge_findings_scratch_bytes(uint64_t n) {
+    size_t tmp = 0;
+    uint64_t* nul = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, nul, nul, nul, nul, (size_t)n, 0, 64, (hipStream_t)0);
+    return n * sizeof(sx_finding) + 4 * n * 8 + tmp + 2048;
+}
+// srcs[m] = mission m's [nf[m] findings][nb[m] string bytes] on the device; out = [sum nf findings][sum nb bytes]
+hipError_t merge_findings_device(const void* const* srcs, const uint64_t* nf, const uint64_t* nb, int n_missions, void* out,
+                                 void* scratch, size_t scratch_bytes, hipStream_t stream) {
+    uint64_t n = 0;
+    for (int m = 0; m < n_missions; m++) n += nf[m];
+    if (n == 0) return hipSuccess;
+    if (scratch_bytes < merge_findings_scratch_bytes(n)) return hipErrorInvalidValue;
+    uint8_t* base = (uint8_t*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    sx_finding* all = (sx_finding*)base;
+    uint64_t* k0 = (uint64_t*)(base + ((n * sizeof(sx_finding) + 255) & ~(size_t)255));
+    uint64_t* v0 = k0 + n;
+    uint64_t* k1 = v0 + n;
+    uint64_t* v1 = k1 + n;
+    uint8_t* tmp = (uint8_t*)(((uintptr_t)(v1 + n) + 255) & ~(uintptr_t)255);
+    size_t tmp_bytes = scratch_bytes - (size_t)(tmp - (uint8_t*)scratch);
+    sx_finding* out_f = (sx_finding*)out;
+    uint8_t* out_a = (uint8_t*)out + n * sizeof(sx_finding);
+    uint64_t fb = 0, ab = 0;
+    for (int m = 0; m < n_missions; m++) {
+        if (nf[m]) {
+            const sx_finding* sf = (const sx_finding*)srcs[m];
+            hipLaunchKernelGGL(merge_gather_in_kernel, dim3((unsigned)((nf[m] + 255) / 256)), dim3(256), 0, stream, sf, nf[m], (uint32_t)ab,
+                               fb, all, k0, v0);
+            hipError_t e = hipMemcpyAsync(out_a + ab, (const uint8_t*)srcs[m] + nf[m] * sizeof(sx_finding), nb[m], hipMemcpyDeviceToDevice, stream);
+            if (e != hipSuccess) return e;
+        }
+        fb += nf[m]; ab += nb[m];
+    }
+    hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, (size_t)n, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(merge_gather_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, all, v1, n, out_f);
+    return hipGetLastError();
+}
+
 }  // namespace sx
