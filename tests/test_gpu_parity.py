@@ -310,3 +310,32 @@ def test_ingest_pipeline_file_and_stream(tmp_path):
     parts = sc.scan_stream(readinto, chunk_bytes=2 << 20, file_id=1)
     assert sx.OUTPUT_BOM + b"".join(r.printed(n_inputs=1, radix="x") for r in parts) + b"\n" == want
     sc.close()
+
+
+SWITCHES = [
+    {}, {"SX_REGION_CAP": "2"}, {"SX_REGION_CAP": "0"}, {"SX_HOST_STITCH": "1"}, {"SX_NO_REPLAY_SKIP": "1"},
+    {"SX_NO_REPLAY_CACHE": "1"}, {"SX_HOST_MERGE": "1"}, {"SX_MISSION_STREAMS": "1"}, {"SX_DEVICE_JOIN_MIN": "1"},
+    {"SX_SCAN_BLOCKS_PER_CU": "3", "SX_SCAN_CUS": "2"}, {"SX_PIECE_MIB": "2", "SX_REGION_CAP": "4"},
+]
+
+
+@pytest.mark.parametrize("env", SWITCHES, ids=lambda e: "+".join(f"{k[3:]}={v}" for k, v in e.items()) or "default")
+def test_every_switch_gives_the_same_text(env, monkeypatch):
+    """Each alternative path behind an environment switch — record pool vs regions and
+    the overflow fallback between them, host vs device for the join, the stitch and the merge, replay
+    with and without shortcuts / output cache, stream layout, persistent grid, pieces — must print
+    what the oracle prints, on a planted image where all three missions have findings."""
+    from test_gpu_baseline_configs import planted_image
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ms = rc.missions(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African")
+    img = planted_image(12 << 20, 11, every=8192)[:12 << 20]
+    want = sxo.run_cli(ms, [img], radix="x")
+    sc = sx.Scanner(ms, device=0, device_replay=True)
+    d = sc.alloc(len(img)); sc.upload(d, img)
+    for _ in range(2):      # twice: the second call starts from what the first learnt (mission order, dense flags)
+        sc.reset()
+        res = sc.scan_device(d, len(img), file_id=1)
+        assert sx.OUTPUT_BOM + res.printed(n_inputs=1, radix="x") + b"\n" == want
+        res.free()
+    sc.free(d); sc.close()
