@@ -7,6 +7,7 @@
 #include <string.h>
 #include <errno.h>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -129,7 +130,7 @@ struct sx_ctx {
     hipStream_t copy_stream = nullptr;
     uint8_t* ing_pin[2] = { nullptr, nullptr };
     uint8_t* ing_dev[2] = { nullptr, nullptr };
-    uint64_t ing_cap = 0;
+    uint64_t ing_cap = 0, ing_dev_cap = 0;
     uint32_t region_cap = 32;         // record slots per sub-chunk in region mode (0: never use it)
     std::vector<char> dense;          // per mission: the last buffer overflowed its regions -> shared pool + sort
     uint8_t* d_input = nullptr;  // staging for host input
@@ -1177,7 +1178,7 @@ struct BufferScan {
 //  * A large buffer can be cut into pieces (SX_PIECE_MIB) that behave exactly like consecutive
 //    sx_scan calls (ScannerState carried from piece to piece) with their kernels queued two deep.
 static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len, int file_id,
-                       int is_last, sx_result** out) {
+                       int is_last, sx_result** out, uint32_t slice_base0 = 0, sx_result* append_to = nullptr) {
     const double t_begin = now_ms();
     const size_t nm = ctx->missions.size();
     std::vector<uint64_t> stream0(nm);
@@ -1215,17 +1216,43 @@ static int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_
         if (p > 0 && (rc = b.fetch_base(ctx)) != SX_OK) return sync_streams_and_return(ctx, rc);
         ReplayJob job = whole_chunk_job(ctx, b.len, file_id, is_last != 0 && p + 1 == n_pieces);
         job.d_bytes = b.d_bytes;
-        job.slice_base = (uint32_t)(p * piece / kInputBufLen);
+        job.slice_base = slice_base0 + (uint32_t)(p * piece / kInputBufLen);
         std::vector<RunList> runs;
         rc = b.finish_and_replay(ctx, job,
                                  [&]() -> int { return launched < n_pieces ? pieces[launched++].launch(ctx) : SX_OK; },  // slot p&1 is free again
-                                 &runs, &res.r->r, nullptr);
+                                 &runs, append_to ? &append_to->r : &res.r->r, nullptr);
         if (rc != SX_OK) return sync_streams_and_return(ctx, rc);
     }
     ctx->stats.total_ms = now_ms() - t_begin;
-    *out = res.release();
+    if (!append_to) *out = res.release();
     return SX_OK;
 }
+
+static int stream_core(sx_ctx* ctx, sx_read_fn read, void* read_user, uint64_t chunk_bytes, int input_file_id,
+                       sx_result_fn sink, void* sink_user, sx_result* accumulate, int is_last_at_eof,
+                       const uint8_t* direct = nullptr, uint64_t direct_len = 0);
+namespace {
+struct MemReader { const uint8_t* p; uint64_t len, off; unsigned threads; };
+// several threads: one memcpy into pinned memory moves ~10 GB/s, PCIe takes five times that
+int64_t read_mem(void* user, uint8_t* dst, uint64_t max_bytes) {
+    MemReader& mr = *(MemReader*)user;
+    const uint64_t want = std::min<uint64_t>(max_bytes, mr.len - mr.off);
+    if (want == 0) return 0;
+    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(mr.threads, want / (4u << 20)));
+    if (nt == 1) memcpy(dst, mr.p + mr.off, want);
+    else {
+        const uint64_t per = (want / nt + 4095) / 4096 * 4096;
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) {
+            const uint64_t a0 = std::min<uint64_t>(want, (uint64_t)t * per), b0 = std::min<uint64_t>(want, a0 + per);
+            th.emplace_back([=, &mr]() { memcpy(dst + a0, mr.p + mr.off + a0, b0 - a0); });
+        }
+        for (auto& t : th) t.join();
+    }
+    mr.off += want;
+    return (int64_t)want;
+}
+}  // namespace
 
 int sx_scan(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_file_id, int is_last_input_buffer,
             sx_result** out) {
@@ -1233,6 +1260,18 @@ int sx_scan(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_file_id, 
     begin_call(ctx);
     if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // Measured (4 GiB, MI355X box): one hipMemcpy from pageable memory + one scan moves 50 GiB/s, the
+    // chunked pipeline below 34 GiB/s (its staging memcpy is the bottleneck) — so it is opt-in.
+    const uint64_t stream_from = getenv("SX_SCAN_STREAM_MIB") ? (uint64_t)atoll(getenv("SX_SCAN_STREAM_MIB")) << 20 : 0;
+    if (stream_from >= kInputBufLen && len >= 2 * stream_from) {
+        // the ingest pipeline: pinned staging, the copy of one chunk overlapped with the scan of
+        // the chunk before; one result with a segment per chunk
+        MemReader mr{ bytes, len, 0, std::max(1u, std::min(8u, usable_cpus() / 2)) };
+        ResultHolder res;
+        int rc = stream_core(ctx, read_mem, &mr, stream_from, input_file_id, nullptr, nullptr, res.r, is_last_input_buffer);
+        if (rc == SX_OK) *out = res.release();
+        return rc;
+    }
     const double t0 = now_ms();
     if (len > ctx->d_input_cap) {
         if (ctx->d_input) HIP_TRY(ctx, hipFree(ctx->d_input));
@@ -1263,35 +1302,46 @@ int sx_scan_device(sx_ctx* ctx, const void* device_bytes, uint64_t len, int inpu
 // it to HBM on its own stream while the main thread scans the buffer before; every chunk
 // behaves exactly like one sx_scan call (ScannerState carried), its result goes to `sink`,
 // which owns it (sx_result_free).  Throughput is what the slowest of read / PCIe / scan allows.
-int sx_scan_stream(sx_ctx* ctx, sx_read_fn read, void* read_user, uint64_t chunk_bytes, int input_file_id,
-                   sx_result_fn sink, void* sink_user) {
-    if (!ctx || !read || !sink) return SX_E_INVALID;
-    begin_call(ctx);
-    if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+// `accumulate`: instead of handing every chunk's result to the sink, append them all to this one
+// (slice indices running on), the last chunk with `is_last_at_eof` — that is sx_scan for a large
+// host buffer.
+// `direct`: the whole input is addressable host memory (a mapped file): no staging buffer, the
+// chunks are copied to HBM straight from there (HIP's pageable-memory path) and the host part of
+// stage B reads them in place.
+static int stream_core(sx_ctx* ctx, sx_read_fn read, void* read_user, uint64_t chunk_bytes, int input_file_id,
+                       sx_result_fn sink, void* sink_user, sx_result* accumulate, int is_last_at_eof,
+                       const uint8_t* direct, uint64_t direct_len) {
     const double t_begin = now_ms();
     if (chunk_bytes == 0) chunk_bytes = 256ull << 20;
     chunk_bytes = std::max<uint64_t>(kInputBufLen, chunk_bytes / kInputBufLen * kInputBufLen);
     if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    if (ctx->ing_cap < chunk_bytes) {
+    if (ctx->ing_dev_cap < chunk_bytes) {
+        for (int i = 0; i < 2; i++) {
+            if (ctx->ing_dev[i]) HIP_TRY(ctx, hipFree(ctx->ing_dev[i]));
+            ctx->ing_dev[i] = nullptr;
+        }
+        ctx->ing_dev_cap = 0;
+        for (int i = 0; i < 2; i++) HIP_TRY(ctx, hipMalloc((void**)&ctx->ing_dev[i], chunk_bytes));
+        ctx->ing_dev_cap = chunk_bytes;
+    }
+    if (!direct && ctx->ing_cap < chunk_bytes) {
         for (int i = 0; i < 2; i++) {
             if (ctx->ing_pin[i]) HIP_TRY(ctx, hipHostFree(ctx->ing_pin[i]));
-            if (ctx->ing_dev[i]) HIP_TRY(ctx, hipFree(ctx->ing_dev[i]));
-            ctx->ing_pin[i] = nullptr; ctx->ing_dev[i] = nullptr;
+            ctx->ing_pin[i] = nullptr;
         }
         ctx->ing_cap = 0;
-        for (int i = 0; i < 2; i++) {
-            HIP_TRY(ctx, hipHostMalloc((void**)&ctx->ing_pin[i], chunk_bytes, hipHostMallocDefault));
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->ing_dev[i], chunk_bytes));
-        }
+        for (int i = 0; i < 2; i++) HIP_TRY(ctx, hipHostMalloc((void**)&ctx->ing_pin[i], chunk_bytes, hipHostMallocDefault));
         ctx->ing_cap = chunk_bytes;
     }
-    struct Slot { uint64_t n = 0; bool ready = false, eof = false; int error = 0; };
+    struct Slot { uint64_t n = 0; bool ready = false, eof = false; int error = 0; const uint8_t* host = nullptr; };
+    uint64_t direct_off = 0;
     Slot slots[2];
     std::mutex mu;
     std::condition_variable cv;
     bool stop = false;
     std::string reader_err;
+    uint8_t carry = 0;
+    bool carry_valid = false;
     std::thread reader([&]() {
         (void)hipSetDevice(ctx->device);
         for (uint64_t k = 0;; k++) {
@@ -1304,26 +1354,42 @@ int sx_scan_stream(sx_ctx* ctx, sx_read_fn read, void* read_user, uint64_t chunk
             uint64_t n = 0;
             bool eof = false;
             int error = 0;
+            const uint8_t* host = ctx->ing_pin[k & 1];
+            if (direct) {
+                host = direct + direct_off;
+                n = std::min<uint64_t>(chunk_bytes, direct_len - direct_off);
+                direct_off += n;
+                eof = direct_off >= direct_len;
+            } else {
+            if (carry_valid) { ctx->ing_pin[k & 1][0] = carry; n = 1; carry_valid = false; }
             while (n < chunk_bytes) {
                 const int64_t got = read(read_user, ctx->ing_pin[k & 1] + n, chunk_bytes - n);
                 if (got < 0) { error = (int)got; break; }
                 if (got == 0) { eof = true; break; }
                 n += (uint64_t)got;
             }
+            if (!error && !eof && accumulate) {  // is this the last chunk?  (only then may it carry is_last)
+                const int64_t got = read(read_user, &carry, 1);
+                if (got < 0) error = (int)got;
+                else if (got == 0) eof = true;
+                else carry_valid = true;
+            }
+            }
             if (!error && n) {
-                hipError_t e = hipMemcpyAsync(ctx->ing_dev[k & 1], ctx->ing_pin[k & 1], n, hipMemcpyHostToDevice, ctx->copy_stream);
+                hipError_t e = hipMemcpyAsync(ctx->ing_dev[k & 1], host, n, hipMemcpyHostToDevice, ctx->copy_stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
                 if (e != hipSuccess) { error = SX_E_HIP; reader_err = std::string("H2D copy: ") + hipGetErrorString(e); }
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
-                s.n = n; s.eof = eof || error; s.error = error; s.ready = true;
+                s.n = n; s.eof = eof || error; s.error = error; s.host = host; s.ready = true;
             }
             cv.notify_all();
             if (eof || error) return;
         }
     });
     int rc = SX_OK;
+    uint64_t done_bytes = 0;
     for (uint64_t k = 0;; k++) {
         Slot& s = slots[k & 1];
         {
@@ -1331,13 +1397,20 @@ int sx_scan_stream(sx_ctx* ctx, sx_read_fn read, void* read_user, uint64_t chunk
             cv.wait(lk, [&] { return s.ready; });
         }
         if (s.error) { rc = s.error < 0 && s.error >= SX_E_STATE ? s.error : SX_E_INVALID; ctx->err = reader_err.empty() ? "read function failed" : reader_err; break; }
-        if (s.n) {
+        if (accumulate) {
+            if (s.n || (s.eof && is_last_at_eof)) {
+                rc = scan_common(ctx, s.host, ctx->ing_dev[k & 1], s.n, input_file_id, s.eof ? is_last_at_eof : 0, nullptr,
+                                 (uint32_t)(done_bytes / kInputBufLen), accumulate);
+                if (rc != SX_OK) break;
+            }
+        } else if (s.n) {
             sx_result* r = nullptr;
-            rc = scan_common(ctx, ctx->ing_pin[k & 1], ctx->ing_dev[k & 1], s.n, input_file_id, 0, &r);
+            rc = scan_common(ctx, s.host, ctx->ing_dev[k & 1], s.n, input_file_id, 0, &r);
             if (rc != SX_OK) break;
             const int src = sink(sink_user, r);
             if (src != 0) { rc = SX_E_INVALID; ctx->err = "the result sink asked to stop"; break; }
         }
+        done_bytes += s.n;
         const bool last = s.eof;
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -1354,6 +1427,15 @@ int sx_scan_stream(sx_ctx* ctx, sx_read_fn read, void* read_user, uint64_t chunk
     reader.join();
     ctx->stats.total_ms = now_ms() - t_begin;
     return rc;
+}
+
+int sx_scan_stream(sx_ctx* ctx, sx_read_fn read, void* read_user, uint64_t chunk_bytes, int input_file_id,
+                   sx_result_fn sink, void* sink_user) {
+    if (!ctx || !read || !sink) return SX_E_INVALID;
+    begin_call(ctx);
+    if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return stream_core(ctx, read, read_user, chunk_bytes, input_file_id, sink, sink_user, nullptr, 0);
 }
 
 namespace {
@@ -1408,6 +1490,23 @@ int sx_scan_file(sx_ctx* ctx, const char* path, uint64_t chunk_bytes, int input_
     if (fr.fd < 0) { ctx->err = std::string("cannot open `") + path + "`: " + strerror(errno); return SX_E_INVALID; }
     struct stat st;
     if (fr.fd > 0 && fstat(fr.fd, &st) == 0 && S_ISREG(st.st_mode)) { fr.seekable = true; fr.size = (uint64_t)st.st_size; }
+    if (fr.seekable && fr.size > 0 && getenv("SX_INGEST_MMAP")) {
+        // opt-in: map the file and copy to HBM straight from the page cache.  Measured slower than the
+        // pread threads + pinned staging (19 vs 27 GiB/s on 16 GiB): the page faults of the mapping cost more
+        // than the staging copy.
+        void* map = mmap(nullptr, fr.size, PROT_READ, MAP_PRIVATE, fr.fd, 0);
+        if (map != MAP_FAILED) {
+            (void)madvise(map, fr.size, MADV_SEQUENTIAL);
+            begin_call(ctx);
+            int rc = SX_E_STATE;
+            if (ctx->host_only) ctx->err = "host-only context: no device scan";
+            else if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; rc = SX_E_HIP; }
+            else rc = stream_core(ctx, nullptr, nullptr, chunk_bytes, input_file_id, sink, sink_user, nullptr, 0, (const uint8_t*)map, fr.size);
+            munmap(map, fr.size);
+            ::close(fr.fd);
+            return rc;
+        }
+    }
     const int rc = sx_scan_stream(ctx, read_fd, &fr, chunk_bytes, input_file_id, sink, sink_user);
     if (fr.fd > 0) ::close(fr.fd);
     return rc;

@@ -282,7 +282,7 @@ def test_pieces_pipeline_equals_oracle(device_replay, monkeypatch):
     sc.free(d); sc.close()
 
 
-def test_ingest_pipeline_file_and_stream(tmp_path):
+def test_ingest_pipeline_file_and_stream(tmp_path, monkeypatch):
     """sx_scan_file / sx_scan_stream: reader thread + pinned double buffer + H2D overlapped with the
     scan; every chunk is one sx_scan call with carried state, so the printed text equals the oracle's."""
     rng = random.Random(31)
@@ -291,7 +291,9 @@ def test_ingest_pipeline_file_and_stream(tmp_path):
     want = sxo.run_cli(ms, [data], radix="x")
     path = tmp_path / "image.bin"
     path.write_bytes(data)
-    for chunk in (1 << 20, 64 << 10, 0):
+    for chunk, mapped in ((1 << 20, False), (64 << 10, False), (0, False), (1 << 20, True)):
+        if mapped:
+            monkeypatch.setenv("SX_INGEST_MMAP", "1")
         sc = sx.Scanner(ms, device=0)
         parts = sc.scan_file(str(path), chunk_bytes=chunk, file_id=1)
         got = sx.OUTPUT_BOM + b"".join(r.printed(n_inputs=1, radix="x") for r in parts) + b"\n"
@@ -339,3 +341,24 @@ def test_every_switch_gives_the_same_text(env, monkeypatch):
         assert sx.OUTPUT_BOM + res.printed(n_inputs=1, radix="x") + b"\n" == want
         res.free()
     sc.free(d); sc.close()
+
+
+@pytest.mark.parametrize("flush", [False, True])
+def test_large_host_buffers_take_the_ingest_pipeline(flush, monkeypatch):
+    """sx_scan of a large host buffer = pinned staging + chunks copied while the chunk before is
+    scanned, ONE result with a segment per chunk (slice indices running on); forced here from 2 MiB
+    on.  Buffer sizes around the chunk grid, and the is_last flush on the final chunk."""
+    monkeypatch.setenv("SX_SCAN_STREAM_MIB", "1")
+    rng = random.Random(8)
+    ms = rc.missions(encodings=["utf-8", "utf-16be", "ascii"], chars_min="5")
+    for n in ((5 << 20) + 4096 * 2 + 33, 4 << 20, (4 << 20) + 1, (3 << 20) - 1):
+        data = synth(rng, n, 1 / 300) [:n - 20] + b"tail string without end"[:20]
+        want = sxo.run_cli(ms, [data], radix="x", flush_at_eof=flush)
+        got = run_cli_product(ms, [data], radix="x", device=0, flush_at_eof=flush)
+        assert got == want, (n, flush)
+    sc = sx.Scanner(ms, device=0)
+    res = sc.scan(data, file_id=1)
+    assert len(res.segments()) >= 2
+    idx = [f["slice_index"] for f in res.findings()]
+    assert idx == sorted(idx) and idx[-1] == (len(data) - 1) // 4096 or idx[-1] <= (len(data) - 1) // 4096
+    sc.close()
