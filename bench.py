@@ -235,6 +235,8 @@ def main():
                           f"(src/main.rs:97-151); {sum(counts)} findings",
             }
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()   # rank 0 measures the kernels alone and the CPU baseline after the timed region: wait for it
     sc.close()
     if world > 1:
         dist.destroy_process_group()
