@@ -31,12 +31,16 @@ namespace sx {
 #include "sx_replay_core.hpp"
 namespace sx {
 
+#ifndef SX_REPLAY_WAVES
+#define SX_REPLAY_WAVES 8   // the replay lives on occupancy: 64 VGPRs and a few spilled registers beat 128 VGPRs at 4 waves (measured)
+#endif
+
 // Pass 1: one lane per run.  A run that begins in the window where the run before it ends, or in
 // the very next one, is certainly inside the region that holds that run (the replay only stops
 // at a window end after which no run begins at once): it is marked kRegionChained right away.
 // On string-dense input this keeps nearly every lane from replaying what another one covers.
 template <int ENC, bool CACHED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void replay_count_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WAVES))) void replay_count_kernel(
     const ReplayParams P, ReplayRegionOut* out, sx_finding* cache_f, u8* cache_s) {
     const u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
     if (i >= P.n_runs) return;
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void re
 
 // Pass 2: the standing regions write their findings and strings at the offsets the host assigned.
 template <int ENC>
-__global__ __launch_bounds__(64) void replay_write_kernel(const ReplayParams P, const u64* region_index, const u64* fbase,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WAVES))) void replay_write_kernel(const ReplayParams P, const u64* region_index, const u64* fbase,
                                                           const u64* abase, u64 n_regions, sx_finding* findings, u8* arena) {
     const u64 k = (u64)blockIdx.x * 64 + threadIdx.x;
     if (k >= n_regions) return;
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(64) void replay_write_kernel(const ReplayParams P, 
 // Pass 2, flagged form: one lane per run; the standing regions (stitch below) write at the
 // offsets the device scans assigned.
 template <int ENC>
-__global__ __launch_bounds__(64) void replay_write_flagged_kernel(const ReplayParams P, const ReplayRegionOut* ro,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WAVES))) void replay_write_flagged_kernel(const ReplayParams P, const ReplayRegionOut* ro,
                                                                   const u8* stands, const u64* fpos, const u64* apos,
                                                                   const sx_finding* cache_f, const u8* cache_s,
                                                                   sx_finding* findings, u8* arena) {
