@@ -1,0 +1,243 @@
+// sx_ctx.hpp — what the translation units behind the C-ABI share: the context (HIP resources,
+// carried ScannerStates, grow-only buffers), the per-mission device state, and the internal
+// interfaces of stage A (sx_stage_a.cpp), stage B (sx_stage_b.cpp), the schedule that ties them
+// together (sx_schedule.cpp) and the ingest pipeline (sx_ingest.cpp).  Nothing here is public.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "sx_host.hpp"
+
+namespace sx {
+
+double now_ms();
+
+// The long runs of one mission over one buffer: owned (host merge, caller-supplied) or a view
+// of the mission's pinned download buffer; `on_device` says MissionDev::d_rp[0] holds the same list.
+struct RunList {
+    std::vector<sx_run> own;
+    const sx_run* p = nullptr;
+    size_t n = 0;
+    bool on_device = false;
+    void use_own() { p = own.data(); n = own.size(); on_device = false; }
+    void assign(const sx_run* b, const sx_run* e) { own.assign(b, e); use_own(); }
+    const sx_run* data() const { return p; }
+    size_t size() const { return n; }
+    const sx_run& operator[](size_t i) const { return p[i]; }
+};
+
+// Stage A writes its run records into one of two slots, so that the kernel of the next piece
+// of a large buffer can run while the previous piece's records are sorted, joined and replayed.
+struct ScanSlot {
+    DevRun* d_recs = nullptr;
+    uint32_t capacity = 0;
+    uint32_t* d_counters = nullptr;   // 4 x u32: records, heavy tiles, joined runs, -
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the scan kernel
+    hipEvent_t ev_free = nullptr;     // the slot's records have been consumed (recorded on stream_b)
+    bool free_pending = false;
+    // region mode (ScanParams::region_cap): per-sub-chunk counts and the packed, ordered records
+    uint32_t* d_cnt = nullptr;  uint64_t cnt_cap = 0;
+    DevRun* d_packed = nullptr; uint64_t packed_cap = 0;
+    uint32_t region_cap = 0;    // of the launch in flight (0: shared pool)
+    uint64_t n_regions = 0;
+};
+struct MissionDev {
+    hipStream_t stream = nullptr;     // scan kernels only
+    hipStream_t stream_b = nullptr;   // everything after them (sort/join, stage B, copies); higher priority
+    ScanSlot slot[2];
+    // stage B on the device: grow-only buffers
+    uint16_t* d_table = nullptr;                        // single-byte decoder table
+    sx_run* h_runs = nullptr; uint64_t h_runs_cap = 0;   // pinned: runs joined on the device
+    void* d_rp[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
+    uint64_t d_rp_cap[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // + stitch blocks, totals, pass-1 output cache
+};
+
+
+}  // namespace sx
+
+struct sx_result {
+    sx::Result r;
+};
+
+struct sx_ctx {
+    std::shared_ptr<sx::PinnedPool> pool = std::make_shared<sx::PinnedPool>();
+    std::vector<sx::Mission> missions;
+    std::vector<sx::ScannerState> states;
+    std::vector<sx::MissionDev> dev;
+    bool host_only = false;
+    int device = -1;
+    sx_options opt{};
+    std::string err;
+    sx_stats stats{};
+    hipStream_t scan_stream = nullptr, post_stream = nullptr;
+    unsigned n_cus = 256, scan_blocks_per_cu = 8;
+    // sx_scan_stream: two pinned host buffers and two device buffers, filled by a reader thread
+    hipStream_t copy_stream = nullptr;
+    uint8_t* ing_pin[2] = { nullptr, nullptr };
+    uint8_t* ing_dev[2] = { nullptr, nullptr };
+    uint64_t ing_cap = 0, ing_dev_cap = 0;
+    uint32_t region_cap = 32;         // record slots per sub-chunk in region mode (0: never use it)
+    std::vector<char> dense;          // per mission: the last buffer overflowed its regions -> shared pool + sort
+    uint8_t* d_input = nullptr;  // staging for host input
+    uint64_t d_input_cap = 0;
+    uint64_t ondemand_fetches = 0;
+    // grow-only scratch reused by every call (pinned host memory: D2H at full PCIe rate)
+    std::vector<uint64_t> last_runs;  // long runs per mission of the last scanned buffer: busiest mission scans first
+    std::vector<sx::RunList> shard_runs;  // device runs of the last sx_scan_shard* buffer (reuse_runs)
+    bool shard_runs_valid = false;
+    uint8_t* h_pin = nullptr;   uint64_t h_pin_cap = 0;
+    uint8_t* h_pin2 = nullptr;  uint64_t h_pin2_cap = 0;   // device replay traffic (h_pin may back a live byte view)
+    uint8_t* d_scratch = nullptr; uint64_t d_scratch_cap = 0;
+};
+
+#define HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            return SX_E_HIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+namespace sx {
+
+// Device-resident chunk of which only some byte ranges were downloaded.
+class SparseDeviceBytes : public ByteView {
+public:
+    SparseDeviceBytes(sx_ctx* ctx, const uint8_t* d_base) : ctx_(ctx), d_base_(d_base) {}
+    void add(uint64_t lo, uint64_t hi, const uint8_t* p) { segs_.push_back({ lo, hi, p }); }
+    // same, but the bytes are copied (the caller's buffer may be reused while the view lives)
+    void add_copy(uint64_t lo, uint64_t hi, const uint8_t* p) {
+        owned_.emplace_back(p, p + (hi - lo));
+        segs_.push_back({ lo, hi, owned_.back().data() });
+    }
+    bool empty() const { return segs_.empty(); }
+    const uint8_t* span(uint64_t off, size_t n, size_t* hint) override {
+        // segments are sorted and disjoint; the caller moves forward, so look near its cursor first
+        size_t a = *hint < segs_.size() ? *hint : 0;
+        if (!(a < segs_.size() && segs_[a].lo <= off)) a = 0;
+        size_t steps = 0;
+        while (a < segs_.size() && segs_[a].hi <= off && steps < 8) { a++; steps++; }
+        if (!(a < segs_.size() && segs_[a].lo <= off && off < segs_[a].hi)) {
+            size_t lo = 0, hi = segs_.size();
+            while (lo < hi) {
+                size_t mid = (lo + hi) / 2;
+                if (segs_[mid].hi <= off) lo = mid + 1; else hi = mid;
+            }
+            a = lo;
+        }
+        if (a < segs_.size() && segs_[a].lo <= off && off + n <= segs_[a].hi) { *hint = a; return segs_[a].p + (off - segs_[a].lo); }
+        // rare: the replay ran further than planned — fetch exactly what is asked for
+        std::lock_guard<std::mutex> g(mu_);
+        extra_.emplace_back(n);
+        if (hipMemcpy(extra_.back().data(), d_base_ + off, n, hipMemcpyDeviceToHost) != hipSuccess)
+            memset(extra_.back().data(), 0, n);
+        ctx_->ondemand_fetches++;
+        return extra_.back().data();
+    }
+
+private:
+    struct Seg { uint64_t lo, hi; const uint8_t* p; };
+    sx_ctx* ctx_;
+    const uint8_t* d_base_;
+    std::vector<Seg> segs_;
+    std::deque<std::vector<uint8_t>> extra_, owned_;
+    std::mutex mu_;
+};
+
+// grow-only buffers of the context (sx_api.cpp)
+int ensure_pinned(sx_ctx* ctx, uint64_t bytes);
+int ensure_pinned2(sx_ctx* ctx, uint64_t bytes);
+int ensure_scratch(sx_ctx* ctx, uint64_t bytes);
+int ensure_capacity(sx_ctx* ctx, ScanSlot& s, uint32_t cap);
+int ensure_rp(sx_ctx* ctx, MissionDev& d, int slot, uint64_t bytes);
+unsigned usable_cpus();
+unsigned replay_threads(const sx_ctx* ctx);
+void begin_call(sx_ctx* ctx);
+
+// ---- stage A (sx_stage_a.cpp)
+ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const uint8_t* d_bytes, uint64_t len,
+                       uint32_t parity, uint64_t min_chars);
+int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
+                   const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si);
+int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
+                   const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si,
+                   std::vector<RunList>* out);
+int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
+                const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars,
+                std::vector<RunList>* out);
+
+// ---- stage B (sx_stage_b.cpp)
+// What stage B is asked to do for one buffer ("chunk" of sx_scan, or a shard's buffer).
+struct ReplayJob {
+    uint64_t len = 0;                   // buffer bytes (its byte 0 lies on the slice grid)
+    int file_id = -1;
+    bool is_last = false;
+    std::vector<uint64_t> lo;           // per mission: replay regions that begin in [lo, hi)
+    uint64_t hi = 0;
+    std::vector<char> entry_exact;      // per mission: ctx->states[m] is the exact state at lo
+    std::vector<uint64_t> consumed0, stream0;  // per mission: ScannerState counters at buffer byte 0
+    bool commit_state = true;           // store the final state in the context
+    uint32_t slice_base = 0;            // added to slice_index of the findings
+    const uint8_t* d_bytes = nullptr;   // the buffer in HBM, if stage B may run on the device
+};
+
+
+
+
+// Missions whose stage B already ran (on the device, while later missions were still being scanned).
+struct PreReplayed {
+    std::vector<char> done;
+    std::vector<MissionFindings> per;
+    std::vector<uint64_t> ends;
+    explicit PreReplayed(size_t nm) : done(nm, 0), per(nm), ends(nm, 0) {}
+};
+
+
+bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs);
+int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, const RunList& runs,
+                          MissionFindings* out, uint64_t* end_pos);
+int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::vector<RunList>& runs,
+               Result* into, uint64_t* end_pos, PreReplayed* pre = nullptr);
+ReplayJob whole_chunk_job(sx_ctx* ctx, uint64_t len, int file_id, bool is_last);
+int download_for_replay(sx_ctx* ctx, const uint8_t* d_bytes, uint64_t len,
+                        const std::vector<RunList>* runs_opt, SparseDeviceBytes* view,
+                        const ReplayJob& job, const std::vector<char>* skip = nullptr,
+                        bool* used_base = nullptr);
+
+// ---- schedule (sx_schedule.cpp) and ingest (sx_ingest.cpp)
+struct ResultHolder {
+    sx_result* r = new sx_result();
+    ~ResultHolder() { delete r; }
+    sx_result* release() { sx_result* x = r; r = nullptr; return x; }
+};
+
+int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len, int file_id,
+                int is_last, sx_result** out, uint32_t slice_base0 = 0, sx_result* append_to = nullptr);
+int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
+                 const sx_run* const* given_runs, const uint64_t* given_n, uint64_t buf_off, uint64_t buf_len,
+                 uint64_t own_lo, uint64_t own_hi, const uint64_t* start_at, uint64_t file_stream_off, int file_id,
+                 int reuse_runs, sx_result** out, uint64_t* end_pos);
+int stream_core(sx_ctx* ctx, sx_read_fn read, void* read_user, uint64_t chunk_bytes, int input_file_id,
+                sx_result_fn sink, void* sink_user, sx_result* accumulate, int is_last_at_eof,
+                const uint8_t* direct = nullptr, uint64_t direct_len = 0);
+
+}  // namespace sx

@@ -1,0 +1,226 @@
+// sx_schedule.cpp — one buffer from stage A to the findings: mission order, overlap of a finished
+// mission's stage B with the scans still running, pieces of a large buffer, one shard of a
+// sharded scan.
+#include "sx_ctx.hpp"
+
+using namespace sx;
+
+namespace sx {
+
+// Bytes per piece of a large buffer (a multiple of the slice length), or `len` if the buffer is
+// scanned in one go.  With pieces, stage A of piece p+1 and p+2 is queued while piece p is
+// sorted, joined and replayed.  Measured on MI355X (C3(i), 64 GiB): no gain — the replay
+// kernels are latency-bound and run ~3x slower next to a scan kernel that saturates HBM, and
+// the host waits on them six times per piece — so the default is one piece; SX_PIECE_MIB
+// turns the pipeline on (tests do, to keep it correct for an asynchronous stage B later).
+uint64_t piece_bytes(const sx_ctx* ctx, uint64_t len) {
+    uint64_t piece = 0;
+    if (const char* e = getenv("SX_PIECE_MIB")) piece = (uint64_t)atoll(e) << 20;
+    if (piece == 0 || len < 2 * piece) return len;
+    return piece / kInputBufLen * kInputBufLen;
+}
+
+// Missions in the order their kernels are queued: busiest of the previous buffer first, so that
+// its stage B (the longest) overlaps the scans of the others.
+void mission_order(sx_ctx* ctx, std::vector<int>* out) {
+    const size_t nm = ctx->missions.size();
+    std::vector<int>& order = *out;
+    order.resize(nm);
+    for (size_t k = 0; k < nm; k++) order[k] = (int)k;
+    if (ctx->last_runs.size() == nm)
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ctx->last_runs[(size_t)x] > ctx->last_runs[(size_t)y]; });
+}
+
+int sync_streams_and_return(sx_ctx* ctx, int rc) {  // do not leave kernels running on the caller's buffer
+    for (auto& d : ctx->dev) { (void)hipStreamSynchronize(d.stream); (void)hipStreamSynchronize(d.stream_b); }
+    return rc;
+}
+
+struct BufferScan {
+    const uint8_t* host_bytes = nullptr;  // the same bytes on the host, or nullptr (device-resident input)
+    const uint8_t* d_bytes = nullptr;
+    uint64_t len = 0;
+    std::vector<int> order;
+    std::vector<uint32_t> parity;         // per mission: stream offset of byte 0, & 1
+    std::vector<uint64_t> minc;           // per mission: long-run threshold
+    int slot = 0;
+    std::unique_ptr<SparseDeviceBytes> base_view;  // entry/exit bytes of a device-resident buffer
+
+    // what the host reads whatever the runs are (entry and exit of every mission): fetched
+    // before the kernels start, so that the copy does not queue behind them
+    int fetch_base(sx_ctx* ctx) {
+        base_view.reset();
+        if (host_bytes) return SX_OK;
+        base_view.reset(new SparseDeviceBytes(ctx, d_bytes));
+        ReplayJob none;
+        return download_for_replay(ctx, d_bytes, len, nullptr, base_view.get(), none);
+    }
+    int launch(sx_ctx* ctx) {
+        for (int k : order) {
+            int rc = stage_a_launch(ctx, { k }, d_bytes, len, { parity[(size_t)k] }, { minc[(size_t)k] }, slot);
+            if (rc != SX_OK) return rc;
+        }
+        return SX_OK;
+    }
+    // Collect stage A mission by mission (in launch order); a mission whose stage B runs on the
+    // device is replayed at once, while the kernels of the missions behind it still scan; the
+    // host's share of stage B follows when all kernels are done.  `after_last_finish` runs when
+    // the record slot is free again (piece pipeline: queue the next piece).
+    int finish_and_replay(sx_ctx* ctx, const ReplayJob& job, const std::function<int()>& after_last_finish,
+                          std::vector<RunList>* runs, Result* into, uint64_t* ends) {
+        const size_t nm = ctx->missions.size();
+        runs->assign(nm, RunList{});
+        HostBytes host_view(host_bytes ? host_bytes : (const uint8_t*)"");
+        ByteView& early_view = host_bytes ? (ByteView&)host_view : (ByteView&)*base_view;
+        PreReplayed pre(nm);
+        if (ctx->last_runs.size() != nm) ctx->last_runs.assign(nm, 0);
+        for (size_t oi = 0; oi < nm; oi++) {
+            const size_t k = (size_t)order[oi];
+            std::vector<RunList> one;
+            int rc = stage_a_finish(ctx, { (int)k }, d_bytes, len, { parity[k] }, { minc[k] }, slot, &one);
+            if (rc != SX_OK) return rc;
+            (*runs)[k] = std::move(one[0]);
+            if (!(*runs)[k].own.empty()) (*runs)[k].use_own();  // the vector moved: point at it again
+            ctx->last_runs[k] = (*runs)[k].size();
+            if (oi + 1 == nm && after_last_finish && (rc = after_last_finish()) != SX_OK) return rc;
+            if (device_replay_wanted(ctx, job, k, (*runs)[k].size())) {
+                rc = device_replay_mission(ctx, k, early_view, job, (*runs)[k], &pre.per[k], &pre.ends[k]);
+                if (rc != SX_OK) return rc;
+                pre.done[k] = 1;
+            }
+        }
+        if (host_bytes) return replay_all(ctx, host_view, job, *runs, into, ends, &pre);
+        SparseDeviceBytes view(ctx, d_bytes);
+        bool base_is_enough = false;
+        int rc = download_for_replay(ctx, d_bytes, len, runs, &view, job, &pre.done, &base_is_enough);
+        if (rc != SX_OK) return rc;
+        return replay_all(ctx, base_is_enough ? (ByteView&)*base_view : (ByteView&)view, job, *runs, into, ends, &pre);
+    }
+};
+
+// One buffer, start to end: stage A on the device, stage B on device and host, the findings in
+// print order.
+//  * The missions' scan kernels queue up in one stream, busiest mission (of the last buffer)
+//    first; as soon as a mission's kernel is done its records are packed and joined and — if its
+//    stage B runs on the device — replayed, in the second stream, while the kernels of the
+//    remaining missions still scan.  What the host replays follows when all kernels are done.
+//  * A large buffer can be cut into pieces (SX_PIECE_MIB) that behave exactly like consecutive
+//    sx_scan calls (ScannerState carried from piece to piece) with their kernels queued two deep.
+int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len, int file_id,
+                       int is_last, sx_result** out, uint32_t slice_base0, sx_result* append_to) {
+    const double t_begin = now_ms();
+    const size_t nm = ctx->missions.size();
+    std::vector<uint64_t> stream0(nm);
+    for (size_t k = 0; k < nm; k++) stream0[k] = ctx->states[k].stream_bytes;
+    std::vector<int> order;
+    mission_order(ctx, &order);
+    const uint64_t piece = piece_bytes(ctx, len);
+    const uint64_t n_pieces = len ? (len + piece - 1) / piece : 1;
+    auto make = [&](uint64_t p) {
+        BufferScan b;
+        const uint64_t off = p * piece;
+        b.host_bytes = host_bytes ? host_bytes + off : nullptr;
+        b.d_bytes = d_bytes + off;
+        b.len = std::min(piece, len - off);
+        b.order = order;
+        b.slot = (int)(p & 1);
+        for (size_t k = 0; k < nm; k++) {
+            b.parity.push_back((uint32_t)((stream0[k] + off) & 1));
+            b.minc.push_back(ctx->missions[k].long_run);
+        }
+        return b;
+    };
+    ResultHolder res;
+    std::vector<BufferScan> pieces;
+    for (uint64_t p = 0; p < n_pieces; p++) pieces.push_back(make(p));
+    int rc = SX_OK;
+    uint64_t launched = 0;
+    for (; launched < std::min<uint64_t>(2, n_pieces); launched++)
+        if ((rc = pieces[launched].launch(ctx)) != SX_OK) return sync_streams_and_return(ctx, rc);
+    // the few bytes the host always reads: a tiny gather in the second stream, it finds room
+    // next to the scan kernels within ~0.1 ms
+    if ((rc = pieces[0].fetch_base(ctx)) != SX_OK) return sync_streams_and_return(ctx, rc);
+    for (uint64_t p = 0; p < n_pieces; p++) {
+        BufferScan& b = pieces[p];
+        if (p > 0 && (rc = b.fetch_base(ctx)) != SX_OK) return sync_streams_and_return(ctx, rc);
+        ReplayJob job = whole_chunk_job(ctx, b.len, file_id, is_last != 0 && p + 1 == n_pieces);
+        job.d_bytes = b.d_bytes;
+        job.slice_base = slice_base0 + (uint32_t)(p * piece / kInputBufLen);
+        std::vector<RunList> runs;
+        rc = b.finish_and_replay(ctx, job,
+                                 [&]() -> int { return launched < n_pieces ? pieces[launched++].launch(ctx) : SX_OK; },  // slot p&1 is free again
+                                 &runs, append_to ? &append_to->r : &res.r->r, nullptr);
+        if (rc != SX_OK) return sync_streams_and_return(ctx, rc);
+    }
+    ctx->stats.total_ms = now_ms() - t_begin;
+    if (!append_to) *out = res.release();
+    return SX_OK;
+}
+
+
+int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
+                        const sx_run* const* given_runs, const uint64_t* given_n, uint64_t buf_off, uint64_t buf_len,
+                        uint64_t own_lo, uint64_t own_hi, const uint64_t* start_at, uint64_t file_stream_off, int file_id,
+                        int reuse_runs, sx_result** out, uint64_t* end_pos) {
+    if (!out || !end_pos || (buf_off % kInputBufLen) != 0 || own_lo < buf_off || own_hi < own_lo || own_hi > buf_off + buf_len) {
+        ctx->err = "bad shard geometry"; return SX_E_INVALID;
+    }
+    const size_t nm = ctx->missions.size();
+    const double t_begin = now_ms();
+    if (given_runs) {
+        ctx->shard_runs.assign(nm, RunList{});
+        for (size_t k = 0; k < nm; k++) ctx->shard_runs[k].assign(given_runs[k], given_runs[k] + given_n[k]);
+    }
+    const bool scan_now = !given_runs && !(reuse_runs && ctx->shard_runs_valid);
+    BufferScan b;
+    if (scan_now) {
+        b.host_bytes = host_bytes; b.d_bytes = d_bytes; b.len = buf_len; mission_order(ctx, &b.order); b.slot = 0;
+        b.parity.assign(nm, (uint32_t)((file_stream_off + buf_off) & 1));
+        for (size_t k = 0; k < nm; k++) b.minc.push_back(ctx->missions[k].long_run);
+        int rc = b.launch(ctx);
+        if (rc == SX_OK) rc = b.fetch_base(ctx);
+        if (rc != SX_OK) return sync_streams_and_return(ctx, rc);
+    }
+
+    ReplayJob job;
+    job.len = buf_len; job.file_id = file_id; job.is_last = false;
+    job.hi = own_hi - buf_off;
+    job.commit_state = job.hi >= buf_len;
+    job.slice_base = (uint32_t)(buf_off / kInputBufLen);
+    for (size_t k = 0; k < nm; k++) {
+        uint64_t lo = own_lo;
+        if (start_at && start_at[k] > lo) lo = start_at[k];
+        if (lo > own_hi) lo = own_hi;
+        job.lo.push_back(lo - buf_off);
+        job.entry_exact.push_back(buf_off == 0 && lo == 0);
+        job.consumed0.push_back(ctx->missions[k].c.counter_offset + file_stream_off + buf_off);
+        job.stream0.push_back(file_stream_off + buf_off);
+    }
+    job.d_bytes = d_bytes;
+    int rc;
+    ResultHolder res;
+    std::vector<uint64_t> ends(nm, 0);
+    if (scan_now) {
+        ctx->shard_runs_valid = false;
+        rc = b.finish_and_replay(ctx, job, nullptr, &ctx->shard_runs, &res.r->r, ends.data());
+        if (rc != SX_OK) return sync_streams_and_return(ctx, rc);
+        ctx->shard_runs_valid = true;
+    } else if (host_bytes) {
+        ctx->shard_runs_valid = true;
+        HostBytes view(host_bytes);
+        rc = replay_all(ctx, view, job, ctx->shard_runs, &res.r->r, ends.data());
+    } else {
+        ctx->shard_runs_valid = true;
+        SparseDeviceBytes view(ctx, d_bytes);
+        rc = download_for_replay(ctx, d_bytes, buf_len, &ctx->shard_runs, &view, job);
+        if (rc != SX_OK) return rc;
+        rc = replay_all(ctx, view, job, ctx->shard_runs, &res.r->r, ends.data());
+    }
+    if (rc == SX_OK) *out = res.release();
+    for (size_t k = 0; k < nm; k++) end_pos[k] = buf_off + ends[k];
+    ctx->stats.total_ms = now_ms() - t_begin;
+    return rc;
+}
+
+
+}  // namespace sx

@@ -1,0 +1,211 @@
+// sx_stage_a.cpp — stage A on the host side: launch every mission's scan kernel, collect the run
+// records (region mode or shared pool), order and join them into long runs on the device.
+#include "sx_ctx.hpp"
+
+using namespace sx;
+
+namespace sx {
+
+ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const uint8_t* d_bytes, uint64_t len,
+                       uint32_t parity, uint64_t min_chars) {
+    const Mission& m = ctx->missions[(size_t)mission];
+    uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 256u * 1024u;
+    sub = std::max<uint32_t>(kTileBytes, sub / kTileBytes * kTileBytes);
+    ScanParams p = m.proto;
+    p.data = d_bytes; p.len = len; p.subchunk = sub; p.parity = parity;
+    p.min_chars = (uint32_t)std::min<uint64_t>(min_chars, kRecCharsMask);
+    if (p.min_chars == 0) p.min_chars = 1;
+    p.cand_bytes = std::min<uint32_t>(p.min_chars * (m.is_utf16() ? 2u : 1u), 17u);
+    {   // r &= r << sh, doubling the proven run length until it reaches cand_bytes
+        uint32_t have = 1;
+        for (int i = 0; i < 5; i++) {
+            const uint32_t sh = have < p.cand_bytes ? std::min(have, p.cand_bytes - have) : 0;
+            p.cand_sh[i] = sh;
+            have += sh;
+        }
+    }
+    p.capacity = s.capacity; p.recs = s.d_recs; p.counters = s.d_counters;
+    p.region_cap = s.region_cap; p.region_counts = s.d_cnt;
+    p.traversal = (ctx->opt.flags & SX_OPT_TILE_TRAVERSAL) ? 1u : 0u;
+    if (const char* e = getenv("SX_TRAVERSAL")) p.traversal = (uint32_t)atoi(e);
+    // Blocks (of 4 wavefronts) per CU the scan kernel occupies.  8 fills every wave slot; with
+    // fewer the kernel runs as a persistent grid and leaves the rest to the second stream
+    // (sort/join and stage B of a mission that is already scanned).
+    unsigned occ = ctx->scan_blocks_per_cu;
+    p.persistent = (occ >= 1 && occ < 8) ? occ * ctx->n_cus : 0u;
+    return p;
+}
+
+// Stage A, first half: enqueue every mission's scan kernel over [d_bytes, d_bytes+len) on its
+// scan stream, writing into record slot `si`.  Returns at once.
+int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
+                   const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si) {
+    if (len == 0) return SX_OK;
+    for (size_t k = 0; k < which.size(); k++) {
+        MissionDev& d = ctx->dev[(size_t)which[k]];
+        ScanSlot& s = d.slot[si];
+        if (s.free_pending) { HIP_TRY(ctx, hipStreamWaitEvent(d.stream, s.ev_free, 0)); s.free_pending = false; }
+        {   // region mode unless the mission's last buffer was too dense for it (or the options rule it out)
+            uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 256u * 1024u;
+            sub = std::max<uint32_t>(kTileBytes, sub / kTileBytes * kTileBytes);
+            const uint64_t n_regions = (len + sub - 1) / sub;
+            const bool tile_traversal = (ctx->opt.flags & SX_OPT_TILE_TRAVERSAL) || (getenv("SX_TRAVERSAL") && atoi(getenv("SX_TRAVERSAL")));
+            if (ctx->dense.size() != ctx->missions.size()) ctx->dense.assign(ctx->missions.size(), 0);
+            s.region_cap = 0; s.n_regions = n_regions;
+            if (ctx->region_cap && !ctx->dense[(size_t)which[k]] && !tile_traversal && n_regions * ctx->region_cap < (1ull << 28)) {
+                s.region_cap = ctx->region_cap;
+                int rc = ensure_capacity(ctx, s, (uint32_t)(n_regions * s.region_cap));
+                if (rc != SX_OK) return rc;
+                if (s.cnt_cap < n_regions) {
+                    if (s.d_cnt) HIP_TRY(ctx, hipFree(s.d_cnt));
+                    s.d_cnt = nullptr; s.cnt_cap = 0;
+                    HIP_TRY(ctx, hipMalloc((void**)&s.d_cnt, (n_regions + n_regions / 4 + 64) * 4));
+                    s.cnt_cap = n_regions + n_regions / 4 + 64;
+                }
+            }
+        }
+        const ScanParams p = scan_params(ctx, which[k], s, d_bytes, len, parity[k], min_chars[k]);
+        HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream));
+        HIP_TRY(ctx, hipEventRecord(s.ev0, d.stream));
+        HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream));
+        HIP_TRY(ctx, hipEventRecord(s.ev1, d.stream));
+    }
+    return SX_OK;
+}
+
+// Stage A, second half: wait for slot `si`, re-run a mission whose record buffer overflowed,
+// and turn the records into the mission's sorted long runs (joined on the device when there
+// are many).  Only stream_b is used from here on: the scan streams may already hold the next piece.
+int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
+                   const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si,
+                   std::vector<RunList>* out) {
+    out->assign(which.size(), RunList{});
+    if (len == 0) return SX_OK;
+    const double t0 = now_ms();
+    for (size_t k = 0; k < which.size(); k++) {
+        MissionDev& d = ctx->dev[(size_t)which[k]];
+        ScanSlot& s = d.slot[si];
+        HIP_TRY(ctx, hipEventSynchronize(s.ev1));
+        const double t_ev = now_ms();
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, s.ev0, s.ev1));
+        if (which[k] < 16) ctx->stats.kernel_ms[which[k]] += ms;
+        uint32_t counters[4] = { 0, 0, 0, 0 };
+        for (int round = 0;; round++) {
+            HIP_TRY(ctx, hipMemcpyAsync(counters, s.d_counters, sizeof counters, hipMemcpyDeviceToHost, d.stream_b));
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            if (s.region_cap) {
+                if (counters[0] == 0) break;  // every sub-chunk's records fit its region
+                // too dense for regions: this mission uses the shared pool (and a sort) from now on
+                ctx->dense[(size_t)which[k]] = 1;
+                s.region_cap = 0;
+            } else {
+                if (counters[0] <= s.capacity) break;
+                if (round >= 8) { ctx->err = "device run-record buffer kept overflowing"; return SX_E_NOMEM; }
+                // overflow: grow the slot and scan this piece again for this mission
+                int rc = ensure_capacity(ctx, s, counters[0] + counters[0] / 8 + 1024);
+                if (rc != SX_OK) return rc;
+            }
+            const ScanParams p = scan_params(ctx, which[k], s, d_bytes, len, parity[k], min_chars[k]);
+            HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream_b));
+            HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream_b));
+        }
+        const double tc0 = now_ms();
+        if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   mission %d: kernel done at +%.2f ms, counters at +%.2f ms\n", which[k], t_ev - t0, tc0 - t0);
+        uint32_t nrec = counters[0];
+        const DevRun* d_records = s.d_recs;   // sorted already in region mode
+        const bool regions = s.region_cap != 0;
+        if (regions) {
+            // pack the regions: the records come out ordered by position, no sort needed
+            const uint64_t slots = s.n_regions * s.region_cap;
+            if (s.packed_cap < slots) {
+                if (s.d_packed) HIP_TRY(ctx, hipFree(s.d_packed));
+                s.d_packed = nullptr; s.packed_cap = 0;
+                HIP_TRY(ctx, hipMalloc((void**)&s.d_packed, (slots + slots / 8 + 64) * sizeof(DevRun)));
+                s.packed_cap = slots + slots / 8 + 64;
+            }
+            int rc = ensure_scratch(ctx, compact_scratch_bytes(s.n_regions)); if (rc != SX_OK) return rc;
+            HIP_TRY(ctx, compact_regions(s.d_recs, s.d_cnt, s.n_regions, s.region_cap, s.d_packed, s.d_counters + 1, ctx->d_scratch,
+                                         ctx->d_scratch_cap, d.stream_b));
+            HIP_TRY(ctx, hipMemcpyAsync(&nrec, s.d_counters + 1, 4, hipMemcpyDeviceToHost, d.stream_b));
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            d_records = s.d_packed;
+        } else if (ctx->region_cap && nrec < s.n_regions * ctx->region_cap / 4)
+            ctx->dense[(size_t)which[k]] = 0;  // sparse again: regions next time
+        const uint32_t join_min = getenv("SX_DEVICE_JOIN_MIN") ? (uint32_t)atoi(getenv("SX_DEVICE_JOIN_MIN")) : 65536u;
+        const bool dev_sorted = nrec >= join_min && nrec > 0;  // worth a handful of small kernels
+        double tc1 = tc0;
+        RunList& rl = (*out)[k];
+        if (dev_sorted) {
+            // sort the records and join them into runs on the device; only the runs travel
+            const size_t sb = std::max(sort_scratch_bytes(nrec), merge_scratch_bytes(nrec));
+            int rc = ensure_scratch(ctx, sb); if (rc != SX_OK) return rc;
+            rc = ensure_rp(ctx, d, 0, (uint64_t)nrec * sizeof(sx_run)); if (rc != SX_OK) return rc;
+            if (!regions) HIP_TRY(ctx, sort_records(s.d_recs, nrec, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
+            if (getenv("SX_TIMING2")) { HIP_TRY(ctx, hipStreamSynchronize(d.stream_b)); fprintf(stderr, "[sx]   sort done +%.2f ms\n", now_ms() - tc0); }
+            HIP_TRY(ctx, merge_sorted_records(d_records, nrec, min_chars[k], ctx->d_scratch, ctx->d_scratch_cap,
+                                              (sx_run*)d.d_rp[0], s.d_counters + 2, d.stream_b));
+            HIP_TRY(ctx, hipEventRecord(s.ev_free, d.stream_b));
+            s.free_pending = true;
+            if (getenv("SX_TIMING2")) { HIP_TRY(ctx, hipStreamSynchronize(d.stream_b)); fprintf(stderr, "[sx]   join done +%.2f ms\n", now_ms() - tc0); }
+            uint32_t nruns = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&nruns, s.d_counters + 2, 4, hipMemcpyDeviceToHost, d.stream_b));
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            tc1 = now_ms();
+            if ((uint64_t)nruns * sizeof(sx_run) > d.h_runs_cap) {
+                if (d.h_runs) HIP_TRY(ctx, hipHostFree(d.h_runs));
+                d.h_runs = nullptr; d.h_runs_cap = 0;
+                const uint64_t cap = (uint64_t)nruns * sizeof(sx_run) * 5 / 4 + 4096;
+                HIP_TRY(ctx, hipHostMalloc((void**)&d.h_runs, cap, hipHostMallocNonCoherent));
+                d.h_runs_cap = cap;
+            }
+            if (nruns) {
+                HIP_TRY(ctx, hipMemcpyAsync(d.h_runs, d.d_rp[0], (size_t)nruns * sizeof(sx_run), hipMemcpyDeviceToHost, d.stream_b));
+                HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            }
+            rl.p = d.h_runs; rl.n = nruns; rl.on_device = true;
+        } else {
+            int rc = ensure_pinned(ctx, (uint64_t)nrec * sizeof(DevRun) + 16);
+            if (rc != SX_OK) return rc;
+            DevRun* recs_p = (DevRun*)ctx->h_pin;
+            if (nrec) {
+                HIP_TRY(ctx, hipMemcpyAsync(recs_p, d_records, (size_t)nrec * sizeof(DevRun), hipMemcpyDeviceToHost, d.stream_b));
+                HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            }
+            tc1 = now_ms();
+            if (getenv("SX_DEBUG_RECS")) {
+                std::vector<DevRun> srt(recs_p, recs_p + nrec);
+                std::sort(srt.begin(), srt.end(), [](const DevRun& a, const DevRun& b) { return a.start < b.start; });
+                for (const DevRun& r : srt)
+                    fprintf(stderr, "[sx] rec start=%llu len=%u chars=%u flags=%s%s\n", (unsigned long long)r.start, r.len,
+                            r.chars_flags & kRecCharsMask, (r.chars_flags & kRecStartOpen) ? "S" : "-",
+                            (r.chars_flags & kRecEndOpen) ? "E" : "-");
+                fprintf(stderr, "[sx] slow tiles %u\n", counters[1]);
+            }
+            if (regions) merge_sorted_device_runs(recs_p, nrec, min_chars[k], &rl.own);
+            else merge_device_runs(recs_p, nrec, min_chars[k], 64 * 1024, &rl.own);
+            rl.use_own();
+        }
+        if (getenv("SX_TIMING"))
+            fprintf(stderr, "[sx] mission %d: kernel %.2f ms, %u %s, %s %.2f ms, %s %.2f ms -> %zu runs\n", which[k], ms, nrec,
+                    regions ? "records (regions)" : "record slots (pool)", dev_sorted ? (regions ? "device pack+join" : "device sort+join") : "d2h",
+                    tc1 - tc0, dev_sorted ? "d2h runs" : "host join", now_ms() - tc1, rl.size());
+        ctx->stats.run_records += rl.size();
+        ctx->stats.bytes_scanned += len;
+        ctx->stats.heavy_tiles += counters[1];
+    }
+    ctx->stats.device_ms += now_ms() - t0;
+    return SX_OK;
+}
+
+// Stage A over one buffer, start to end.
+int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
+                const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars,
+                std::vector<RunList>* out) {
+    int rc = stage_a_launch(ctx, which, d_bytes, len, parity, min_chars, 0);
+    if (rc != SX_OK) return rc;
+    return stage_a_finish(ctx, which, d_bytes, len, parity, min_chars, 0, out);
+}
+
+
+}  // namespace sx

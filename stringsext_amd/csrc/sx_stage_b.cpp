@@ -1,0 +1,446 @@
+// sx_stage_b.cpp — stage B: the exact replay of FindingCollection::from around long runs, on the
+// device (regions, which of them stand, output offsets, interleaving of missions) and on the host
+// (entry/exit of every buffer, missions with few runs, regions the device gives back).
+#include "sx_ctx.hpp"
+
+using namespace sx;
+
+namespace sx {
+
+static inline uint64_t win_start_h(uint64_t p, size_t W) {
+    const uint64_t s0 = p / kInputBufLen * kInputBufLen;
+    return s0 + (p - s0) / W * W;
+}
+
+bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs) {
+    if (!job.d_bytes || ctx->host_only || job.is_last) return false;
+    if (ctx->opt.flags & SX_OPT_HOST_REPLAY) return false;
+    if (ctx->missions[k].q > 64) return false;
+    if (getenv("SX_HOST_REPLAY")) return false;
+    return (ctx->opt.flags & SX_OPT_DEVICE_REPLAY) || getenv("SX_DEVICE_REPLAY") || n_runs >= 4096;
+}
+
+// Stage B of one mission on the device (sx_replay_dev.hip) + the little the host keeps:
+// the chunk's strict entry region, regions the device gave back, the exact exit state.
+int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, const RunList& runs,
+                          MissionFindings* out, uint64_t* end_pos) {
+    const Mission& m = ctx->missions[k];
+    MissionDev& d = ctx->dev[k];
+    const size_t n = runs.size();
+    const size_t W = m.window;
+    const double t0 = now_ms();
+
+    // ---- pass 1 on the device: every region's extent and output size; then (still on the
+    // device) which regions stand and where each writes.  The host keeps its own version of
+    // that step for buffers with regions the device gave back (kRegionTooLong).
+    ReplayParams P{};
+    bool dev_stitch = n > 0 && !getenv("SX_HOST_STITCH");
+    uint64_t* h_tot = nullptr;
+    ReplayRegionOut* ro = nullptr;
+    void* cache_used = nullptr;
+    {
+        int rc = ensure_pinned2(ctx, n * sizeof(ReplayRegionOut) + 256);
+        if (rc != SX_OK) return rc;
+        h_tot = (uint64_t*)ctx->h_pin2;
+        ro = (ReplayRegionOut*)(ctx->h_pin2 + 128);
+    }
+    if (n) {
+        int rc = ensure_rp(ctx, d, 0, n * sizeof(sx_run)); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 1, n * sizeof(ReplayRegionOut)); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 2, n * 8); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 3, (n + 1) * 8); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 4, (n + 1) * 8); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 6, stitch_blocks_bytes(n)); if (rc) return rc;
+        rc = ensure_rp(ctx, d, 7, kTotCount * 8); if (rc) return rc;
+        rc = ensure_scratch(ctx, stitch_scratch_bytes(n)); if (rc) return rc;
+        if (!runs.on_device)
+            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[0], runs.data(), n * sizeof(sx_run), hipMemcpyHostToDevice, d.stream_b));
+        P.data = job.d_bytes; P.len = job.len; P.runs = (const sx_run*)d.d_rp[0]; P.n_runs = n;
+        P.lo = job.lo[k]; P.hi = job.hi; P.consumed0 = job.consumed0[k]; P.stream0 = job.stream0[k];
+        P.slice_base = job.slice_base; P.encoding = m.c.encoding; P.table = d.d_table;
+        P.chars_min_nb = m.c.chars_min_nb; P.same_block = m.c.require_same_unicode_block; P.q = (uint32_t)m.q;
+        P.W = (uint32_t)W; P.long_run = m.long_run; P.skip = getenv("SX_NO_REPLAY_SKIP") ? 0u : 1u; P.grep_char = m.c.grep_char; P.mission_id = m.c.mission_id;
+        P.file_id = job.file_id; P.af_lo = m.c.af_lo; P.af_hi = m.c.af_hi; P.ubf = m.c.ubf;
+        void* cache = nullptr;
+        if (dev_stitch && n <= (32u << 20) && !getenv("SX_NO_REPLAY_CACHE")) {
+            rc = ensure_rp(ctx, d, 8, replay_cache_bytes(n)); if (rc) return rc;
+            cache = d.d_rp[8];
+        }
+        cache_used = cache;
+        HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], cache, d.stream_b));
+        if (dev_stitch) {
+            HIP_TRY(ctx, hipMemsetAsync(d.d_rp[7], 0, kTotCount * 8, d.stream_b));
+            HIP_TRY(ctx, launch_stitch_blocks(P, (const ReplayRegionOut*)d.d_rp[1], (uint8_t*)d.d_rp[2], d.d_rp[6],
+                                              (uint64_t*)d.d_rp[7], d.stream_b));
+        } else
+            HIP_TRY(ctx, hipMemcpyAsync(ro, d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream_b));
+    }
+
+    // ---- meanwhile on the host: the strict entry region (exact carried state), if any
+    std::deque<ReplayPart> host_parts;
+    struct Seg { int host_part; size_t v0, v1; };  // host_part >= 0, or device regions [v0, v1) of `valid`
+    std::vector<Seg> segs;
+    uint64_t E = std::min(job.lo[k], job.hi);
+    uint64_t last_start = E;   // start of the last region of any kind (for the exit state)
+    bool last_is_entry = false;
+    if (job.entry_exact[k]) {
+        // The chunk's first window belongs to the host: only it has the exact carried state
+        // (leftover, cut flag, and the decoder's pending bytes, which cannot be re-derived here).
+        host_parts.emplace_back();
+        replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(), n,
+                    job.lo[k], job.lo[k] + 1, true, &host_parts.back());
+        if (host_parts.back().regions.empty()) host_parts.pop_back();
+        else { segs.push_back({ (int)host_parts.size() - 1, 0, 0 }); last_is_entry = true; E = std::max(E, host_parts.back().end_pos); }
+        E = std::max(E, job.lo[k] + 1);
+    }
+    if (dev_stitch) {
+        HIP_TRY(ctx, launch_stitch_finish(P, (const ReplayRegionOut*)d.d_rp[1], (uint8_t*)d.d_rp[2], d.d_rp[6], E,
+                                          (uint64_t*)d.d_rp[3], (uint64_t*)d.d_rp[4], (uint64_t*)d.d_rp[7], ctx->d_scratch,
+                                          ctx->d_scratch_cap, d.stream_b));
+        HIP_TRY(ctx, hipMemcpyAsync(h_tot, d.d_rp[7], kTotCount * 8, hipMemcpyDeviceToHost, d.stream_b));
+    }
+    if (n) HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+    if (dev_stitch && h_tot[kTotTooLong]) {  // regions for the host: it also decides what stands
+        dev_stitch = false;
+        HIP_TRY(ctx, hipMemcpyAsync(ro, d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream_b));
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+    }
+    const double t1 = now_ms();
+
+    std::vector<uint64_t> valid, fbase, abase;
+    uint64_t nf = 0, nb = 0, n_standing = 0;
+    if (dev_stitch) {
+        nf = h_tot[kTotFindings]; nb = h_tot[kTotBytes]; n_standing = h_tot[kTotStanding];
+        out->replay_bytes += h_tot[kTotReplayBytes];
+        if (h_tot[kTotLast] != ~0ull) {
+            E = std::max(E, h_tot[kTotEnd]);
+            last_start = win_start_h(runs[(size_t)h_tot[kTotLast]].start, W);
+            last_is_entry = false;
+        }
+    } else {
+        // ---- which regions stand: a region is void if an earlier one ran over its start
+        valid.reserve(n); fbase.reserve(n + 1); abase.reserve(n + 1);
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t st = ro[i].status;
+            if (st == kRegionChained || st == kRegionNotMine) continue;
+            const uint64_t want = win_start_h(runs[i].start, W);
+            if (want >= job.hi) break;
+            if (want < E) continue;
+            if (st == kRegionTooLong) {  // given back: the host replays it (and whatever it runs into)
+                host_parts.emplace_back();
+                replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(),
+                            n, want, want + 1, false, &host_parts.back());
+                segs.push_back({ (int)host_parts.size() - 1, 0, 0 });
+                E = std::max(E, host_parts.back().end_pos);
+            } else {
+                if (segs.empty() || segs.back().host_part >= 0) segs.push_back({ -1, valid.size(), valid.size() });
+                valid.push_back(i); fbase.push_back(nf); abase.push_back(nb);
+                segs.back().v1 = valid.size();
+                nf += ro[i].n_find; nb += ro[i].n_bytes;
+                E = std::max(E, ro[i].end);
+            }
+            last_start = want; last_is_entry = false;
+        }
+        fbase.push_back(nf); abase.push_back(nb);
+        n_standing = valid.size();
+        for (uint64_t v : valid) out->replay_bytes += ro[v].end - win_start_h(runs[v].start, W);
+    }
+    if (nb > 0xFFFFFFFFull) { ctx->err = "more than 4 GiB of strings in one chunk"; return SX_E_NOMEM; }
+    const double t2 = now_ms();
+
+    // ---- pass 2: the standing regions write findings and strings, in order; the D2H lands in a
+    // pinned block that becomes the result's storage (no copy) unless host parts must be spliced in
+    PinnedPool::Block blk{};
+    if (n_standing) {
+        int rc = ensure_rp(ctx, d, 5, nf * sizeof(sx_finding) + nb + 64); if (rc) return rc;
+        sx_finding* d_f = (sx_finding*)d.d_rp[5];
+        uint8_t* d_a = (uint8_t*)d.d_rp[5] + nf * sizeof(sx_finding);
+        if (dev_stitch) {
+            HIP_TRY(ctx, launch_replay_write_flagged(P, (const ReplayRegionOut*)d.d_rp[1], (const uint8_t*)d.d_rp[2],
+                                                     (const uint64_t*)d.d_rp[3], (const uint64_t*)d.d_rp[4], cache_used, d_f,
+                                                     d_a, d.stream_b));
+        } else {
+            const size_t nv = valid.size();
+            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[2], valid.data(), nv * 8, hipMemcpyHostToDevice, d.stream_b));
+            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[3], fbase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream_b));
+            HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[4], abase.data(), (nv + 1) * 8, hipMemcpyHostToDevice, d.stream_b));
+            HIP_TRY(ctx, launch_replay_write(P, (const uint64_t*)d.d_rp[2], (const uint64_t*)d.d_rp[3],
+                                             (const uint64_t*)d.d_rp[4], nv, d_f, d_a, d.stream_b));
+        }
+        blk = ctx->pool->take(nf * sizeof(sx_finding) + nb + 64);
+        if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
+        HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_f, nf * sizeof(sx_finding) + nb, hipMemcpyDeviceToHost, d.stream_b));
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+    }
+    const double t3 = now_ms();
+
+    // ---- splice (almost always: device findings only)
+    if (host_parts.empty()) {
+        if (blk.p) { out->ext = blk; out->ext_nf = nf; out->ext_na = nb; out->dev_copy = d.d_rp[5]; }
+    } else {
+        const sx_finding* dev_f = (const sx_finding*)blk.p;
+        const char* dev_a = blk.p ? (const char*)blk.p + nf * sizeof(sx_finding) : nullptr;
+        if (dev_stitch) {  // only the entry part can be here; everything the device wrote follows it
+            fbase.assign({ 0, nf }); abase.assign({ 0, nb });
+            if (n_standing) segs.push_back({ -1, 0, 1 });
+        }
+        for (const Seg& g : segs) {
+            if (g.host_part >= 0) {
+                const MissionFindings& hf = host_parts[(size_t)g.host_part].findings;
+                const uint32_t base = (uint32_t)out->arena.size();
+                out->arena += hf.arena;
+                for (sx_finding f : hf.v) { f.str_off += base; f.slice_index += job.slice_base; out->v.push_back(f); }
+                out->replay_bytes += hf.replay_bytes;
+            } else if (g.v1 > g.v0) {
+                const uint64_t f0 = fbase[g.v0], f1 = fbase[g.v1], a0 = abase[g.v0], a1 = abase[g.v1];
+                const uint32_t base = (uint32_t)out->arena.size();
+                out->arena.append(dev_a + a0, a1 - a0);
+                for (uint64_t j = f0; j < f1; j++) { sx_finding f = dev_f[j]; f.str_off = f.str_off - (uint32_t)a0 + base; out->v.push_back(f); }
+            }
+        }
+        ctx->pool->give(blk);
+    }
+
+    // ---- the state handed to the next chunk: replay the last region and the tail once more
+    // on the host, only for its final state (RangeReplay's tail rule makes it exact)
+    if (job.commit_state) {
+        const uint64_t tail = job.len ? job.len - 1 : 0;
+        uint64_t ts = win_start_h(tail, W);
+        for (int t = 0; t < 3 && ts > 0; t++) ts = win_start_h(ts - 1, W);
+        uint64_t from = last_is_entry ? job.lo[k] : (E > ts ? last_start : ts);
+        if (from < job.lo[k]) from = job.lo[k];
+        ReplayPart fin;
+        replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(), n,
+                    from, job.len, job.entry_exact[k] && from == job.lo[k], &fin);
+        ctx->states[k] = fin.state;
+        ctx->states[k].consumed_bytes = job.consumed0[k] + job.len;
+        ctx->states[k].stream_bytes = job.stream0[k] + job.len;
+        E = job.len;
+    }
+    if (end_pos) *end_pos = std::max(E, std::min(job.hi, job.len));
+    if (getenv("SX_TIMING"))
+        fprintf(stderr, "[sx] device replay mission %zu: %zu runs, pass1+entry %.2f ms, validity %.2f ms (%zu standing, %zu host parts), "
+                        "pass2+d2h %.2f ms (%llu findings), splice+state %.2f ms\n", k, n, t1 - t0, t2 - t1, (size_t)n_standing,
+                host_parts.size(), t3 - t2, (unsigned long long)nf, now_ms() - t3);
+    return SX_OK;
+}
+
+// Stage B for all missions: every (mission, part) pair is one task for a small thread pool;
+// part 0 of a mission starts from its entry state, the others speculate, and the per-mission
+// stitch verifies/repairs them serially.
+int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::vector<RunList>& runs,
+               Result* into, uint64_t* end_pos, PreReplayed* pre) {
+    const double t0 = now_ms();
+    const size_t nm = ctx->missions.size();
+    const unsigned nthreads = replay_threads(ctx);
+    std::vector<std::vector<uint64_t>> bounds(nm);
+    std::vector<std::vector<ReplayPart>> parts(nm);
+    std::vector<std::pair<size_t, size_t>> tasks;
+    std::vector<char> on_device(nm, 0);
+    uint64_t host_runs = 0;
+    for (size_t k = 0; k < nm; k++)
+        on_device[k] = (pre && pre->done[k]) ? 2 : (device_replay_wanted(ctx, job, k, runs[k].size()) ? 1 : 0);
+    for (size_t k = 0; k < nm; k++) {
+        if (on_device[k]) continue;
+        // parts are speculative restarts: worth a thread each only if they hold real work
+        const unsigned want_parts = (unsigned)std::min<uint64_t>(nthreads, std::max<uint64_t>(1, runs[k].size() / 512));
+        host_runs += runs[k].size();
+        replay_plan_range(std::min(job.lo[k], job.hi), job.hi, want_parts, &bounds[k]);
+        parts[k].resize(bounds[k].size() - 1);
+        for (size_t p = 0; p + 1 < bounds[k].size(); p++) tasks.emplace_back(k, p);
+    }
+    std::atomic<size_t> next{ 0 };
+    std::vector<double> task_ms(tasks.size(), 0.0);
+    auto worker = [&]() {
+        for (;;) {
+            const size_t t = next.fetch_add(1);
+            if (t >= tasks.size()) break;
+            const size_t k = tasks[t].first, p = tasks[t].second;
+            const double tt0 = now_ms();
+            replay_part(ctx->missions[k], ctx->states[k], job.consumed0[k], job.stream0[k], bytes, job.len, job.file_id,
+                        job.is_last, runs[k].data(), runs[k].size(), bounds[k][p], bounds[k][p + 1],
+                        p == 0 && job.entry_exact[k], &parts[k][p]);
+            task_ms[t] = now_ms() - tt0;
+        }
+    };
+    const size_t nw = host_runs < 2048 ? 1 : std::min<size_t>(nthreads, tasks.size());
+    if (nw <= 1) worker();
+    else {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < nw; i++) th.emplace_back(worker);
+        for (auto& t : th) t.join();
+    }
+    const double t_parts = now_ms();
+    std::vector<MissionFindings> per(nm);
+    std::vector<uint64_t> ends(nm, 0);
+    for (size_t k = 0; k < nm; k++) {
+        if (on_device[k] == 2) { per[k] = std::move(pre->per[k]); pre->per[k].ext = {}; ends[k] = pre->ends[k]; }
+        else if (on_device[k]) {
+            int rc = device_replay_mission(ctx, k, bytes, job, runs[k], &per[k], &ends[k]);
+            if (rc != SX_OK) return rc;
+        }
+    }
+    auto stitch = [&](size_t k) {
+        if (on_device[k]) return;
+        ScannerState st = ctx->states[k];
+        replay_stitch(ctx->missions[k], st, job.consumed0[k], job.stream0[k], bytes, job.len, job.file_id, job.is_last,
+                      runs[k].data(), runs[k].size(), parts[k], &per[k], nthreads, &ends[k]);
+        if (job.commit_state) ctx->states[k] = st;
+        if (job.slice_base) for (auto& f : per[k].v) f.slice_index += job.slice_base;
+    };
+    if (nm == 1) stitch(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < nm; k++) th.emplace_back(stitch, k);
+        for (auto& t : th) t.join();
+    }
+    if (end_pos) for (size_t k = 0; k < nm; k++) end_pos[k] = ends[k];
+    const double t_stitch = now_ms();
+    const size_t count_before = into->count();
+    {   // several missions with findings that are all still on the device: interleave them there
+        // (a stable radix sort by position) instead of finding by finding on the host
+        size_t with = 0, on_dev = 0, total = 0, bytes = 0;
+        bool same_origin = true;
+        for (size_t k = 0; k < nm; k++) {
+            if (!per[k].count()) continue;
+            with++;
+            if (per[k].ext.p && per[k].dev_copy) on_dev++;
+            total += per[k].count(); bytes += per[k].strings_len();
+            same_origin = same_origin && ctx->missions[k].c.counter_offset == ctx->missions[0].c.counter_offset;
+        }
+        if (with >= 2 && on_dev == with && same_origin && bytes <= 0xFFFFFFFFull && total >= 4096 && !getenv("SX_HOST_MERGE")) {
+            const double tm0 = now_ms();
+            std::vector<const void*> srcs(nm, nullptr);
+            std::vector<uint64_t> nfs(nm, 0), nbs(nm, 0);
+            for (size_t k = 0; k < nm; k++)
+                if (per[k].count()) { srcs[k] = per[k].dev_copy; nfs[k] = per[k].ext_nf; nbs[k] = per[k].ext_na; }
+            int rc = ensure_scratch(ctx, merge_findings_scratch_bytes(total) + total * sizeof(sx_finding) + bytes + 512);
+            if (rc != SX_OK) return rc;
+            uint8_t* d_out = ctx->d_scratch;
+            const size_t out_bytes = total * sizeof(sx_finding) + bytes;
+            uint8_t* d_tmp = d_out + ((out_bytes + 255) & ~(size_t)255);
+            hipStream_t s = ctx->post_stream;
+            HIP_TRY(ctx, merge_findings_device(srcs.data(), nfs.data(), nbs.data(), (int)nm, d_out, d_tmp,
+                                               ctx->d_scratch_cap - (size_t)(d_tmp - ctx->d_scratch), s));
+            PinnedPool::Block blk = ctx->pool->take(out_bytes + 64);
+            if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
+            HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            uint64_t rb = 0;
+            for (size_t k = 0; k < nm; k++) {
+                rb += per[k].replay_bytes;
+                if (per[k].ext.p) ctx->pool->give(per[k].ext);
+                per[k] = MissionFindings{};
+            }
+            per[0].ext = blk; per[0].ext_nf = total; per[0].ext_na = bytes; per[0].replay_bytes = rb;
+            if (getenv("SX_TIMING")) fprintf(stderr, "[sx] device merge of %zu missions: %zu findings, %.2f ms\n", with, total, now_ms() - tm0);
+        }
+    }
+    merge_findings(per, ctx->pool, into);
+    if (getenv("SX_TIMING")) {
+        double mx = 0, sum = 0;
+        for (double v : task_ms) { sum += v; mx = std::max(mx, v); }
+        fprintf(stderr, "[sx] replay: parts %.2f ms (%zu tasks, %zu workers; task sum %.1f max %.1f ms), stitch %.2f ms, merge %.2f ms, "
+                        "on-demand fetches so far %llu\n", t_parts - t0, tasks.size(), nw, sum, mx, t_stitch - t_parts,
+                now_ms() - t_stitch, (unsigned long long)ctx->ondemand_fetches);
+    }
+    for (auto& mf : per) ctx->stats.replay_bytes += mf.replay_bytes;
+    ctx->stats.findings += into->count() - count_before;
+    ctx->stats.replay_ms += now_ms() - t0;
+    return SX_OK;
+}
+
+ReplayJob whole_chunk_job(sx_ctx* ctx, uint64_t len, int file_id, bool is_last) {
+    ReplayJob j;
+    const size_t nm = ctx->missions.size();
+    j.len = len; j.file_id = file_id; j.is_last = is_last; j.hi = len;
+    j.lo.assign(nm, 0); j.entry_exact.assign(nm, 1);
+    for (size_t k = 0; k < nm; k++) { j.consumed0.push_back(ctx->states[k].consumed_bytes); j.stream0.push_back(ctx->states[k].stream_bytes); }
+    return j;
+}
+
+
+// Downloads what the host part of stage B reads: the buffer's first and last 64 KiB ("base",
+// entry and exit of every mission) and the replay ranges of the missions the host replays.
+// runs == nullptr: the base only, copied into the view.  skip: missions not to plan for; if the
+// plan then holds nothing beyond the base and `base_view` already has it, nothing is done and
+// *used_base is set.
+int download_for_replay(sx_ctx* ctx, const uint8_t* d_bytes, uint64_t len,
+                               const std::vector<RunList>* runs_opt, SparseDeviceBytes* view,
+                               const ReplayJob& job, const std::vector<char>* skip, bool* used_base) {
+    const size_t nm = runs_opt ? ctx->missions.size() : 0;
+    static const std::vector<RunList> no_runs;
+    const std::vector<RunList>& runs = runs_opt ? *runs_opt : no_runs;
+    if (used_base) *used_base = false;
+        const double t0 = now_ms();
+        std::vector<std::pair<uint64_t, uint64_t>> rg;
+        // what the host always looks at: the chunk's first windows and its tail
+        rg.emplace_back(0, std::min<uint64_t>(len, 64 * 1024));
+        if (len > 64 * 1024) rg.emplace_back(len - 64 * 1024, len);
+        for (size_t k = 0; k < nm; k++) {
+            if ((skip && (*skip)[k]) || device_replay_wanted(ctx, job, k, runs[k].size())) continue;  // stage B of this mission runs on the device
+            const size_t before = rg.size();
+            // same partition count as replay_all will use
+            const unsigned want_parts = (unsigned)std::min<uint64_t>(replay_threads(ctx), std::max<uint64_t>(1, runs[k].size() / 512));
+            replay_ranges(ctx->missions[k], ctx->states[k], len, runs[k].data(), runs[k].size(), want_parts, &rg);
+            // a mission's ranges come out almost sorted (runs are); fix up, then merge the sorted lists
+            if (!std::is_sorted(rg.begin() + before, rg.end())) std::sort(rg.begin() + before, rg.end());
+            std::inplace_merge(rg.begin(), rg.begin() + before, rg.end());
+        }
+        const double t_rg = now_ms();
+        std::vector<std::pair<uint64_t, uint64_t>> mg;
+        mg.reserve(rg.size());
+        for (auto& r : rg) {
+            if (!mg.empty() && r.first <= mg.back().second) mg.back().second = std::max(mg.back().second, r.second);
+            else mg.push_back(r);
+        }
+        if (used_base) {  // nothing beyond the base (already in the caller's view)?
+            bool inside = true;
+            for (auto& r : mg)
+                inside = inside && (r.second <= std::min<uint64_t>(len, 64 * 1024) || (len > 64 * 1024 && r.first >= len - 64 * 1024));
+            if (inside) { *used_base = true; return SX_OK; }
+        }
+        // split long ranges so that one gather wavefront never copies more than 64 KiB
+        std::vector<uint64_t> seg_src, seg_dst;
+        std::vector<uint32_t> seg_len;
+        uint64_t total = 0;
+        for (auto& r : mg)
+            for (uint64_t a = r.first; a < r.second; a += 65536) {
+                const uint64_t n = std::min<uint64_t>(65536, r.second - a);
+                seg_src.push_back(a); seg_dst.push_back(total); seg_len.push_back((uint32_t)n);
+                total += n;
+            }
+        const double t_seg = now_ms();
+        if (total) {
+            hipStream_t s = ctx->dev[0].stream_b;
+            const size_t ns = seg_src.size();
+            const uint64_t seg_bytes = ns * (8 + 8 + 4) + 64;
+            int rc2 = ensure_pinned(ctx, total + 64);
+            if (rc2 != SX_OK) return rc2;
+            rc2 = ensure_scratch(ctx, total + seg_bytes + 256);
+            if (rc2 != SX_OK) return rc2;
+            uint8_t* d_out = ctx->d_scratch;
+            uint64_t* d_src = (uint64_t*)(ctx->d_scratch + ((total + 255) & ~255ull));
+            uint64_t* d_dst = d_src + ns;
+            uint32_t* d_len = (uint32_t*)(d_dst + ns);
+            HIP_TRY(ctx, hipMemcpyAsync(d_src, seg_src.data(), ns * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync(d_dst, seg_dst.data(), ns * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync(d_len, seg_len.data(), ns * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, launch_gather(d_bytes, d_out, d_src, d_dst, d_len, (uint32_t)ns, s));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin, d_out, total, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            uint64_t off = 0;
+            for (auto& r : mg) {
+                if (runs_opt) view->add(r.first, r.second, ctx->h_pin + off);
+                else view->add_copy(r.first, r.second, ctx->h_pin + off);
+                off += r.second - r.first;
+            }
+        }
+        ctx->stats.d2h_ms += now_ms() - t0;
+        if (getenv("SX_TIMING"))
+            fprintf(stderr, "[sx] sparse download: ranges %.2f ms, sort+merge+segments %.2f ms (%zu ranges, %zu segs), gather+d2h %.2f ms (%.1f MB)\n",
+                    t_rg - t0, t_seg - t_rg, mg.size(), seg_src.size(), now_ms() - t_seg, total / 1e6);
+    return SX_OK;
+}
+
+}  // namespace sx
