@@ -80,13 +80,22 @@ struct ReplayParams {
     uint32_t skip;            // 1: take the shortcuts of sx_replay_core.hpp (0: decode every byte, for comparison)
     int32_t grep_char, mission_id, file_id;
     uint64_t af_lo, af_hi, ubf;
+    // pass-1 output cache (all nullptr/0: no cache): slot_of[i] = slot of run i if it replays,
+    // *n_heads = how many runs replay; the slot geometry follows from arena_bytes / *n_heads
+    const uint32_t* slot_of;
+    const uint32_t* n_heads;
+    uint8_t* cache_arena;
+    uint64_t arena_bytes;
 };
 struct ReplayRegionOut {
     uint64_t end;             // where the region's replay stopped (a window start, buffer relative)
     uint32_t n_find, n_bytes, status, pad;  // pad: 1 = pass 1 kept the whole output in the region's cache slot
 };
-size_t replay_cache_bytes(uint64_t n_runs);
-hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, void* cache, hipStream_t stream);
+// Fills slot_of / n_heads (device arrays of n_runs + 1 u32) for the cache: which runs replay at all.
+size_t replay_heads_scratch_bytes(uint64_t n_runs);
+hipError_t launch_replay_heads(const ReplayParams& P, uint32_t* slot_of, uint32_t* n_heads, void* scratch, size_t scratch_bytes,
+                               hipStream_t stream);
+hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, hipStream_t stream);
 hipError_t launch_replay_write(const ReplayParams& P, const uint64_t* region_index, const uint64_t* fbase,
                                const uint64_t* abase, uint64_t n_regions, sx_finding* findings, uint8_t* arena,
                                hipStream_t stream);
@@ -102,7 +111,7 @@ hipError_t launch_stitch_finish(const ReplayParams& P, const ReplayRegionOut* ro
                                 uint64_t E0, uint64_t* fpos, uint64_t* apos, uint64_t* totals, void* scratch,
                                 size_t scratch_bytes, hipStream_t stream);
 hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegionOut* ro, const uint8_t* stands,
-                                       const uint64_t* fpos, const uint64_t* apos, const void* cache, sx_finding* findings,
+                                       const uint64_t* fpos, const uint64_t* apos, sx_finding* findings,
                                        uint8_t* arena, hipStream_t stream);
 
 // interleave several missions' findings on the device (sx_sort.hip); every src and out = [findings][string bytes]

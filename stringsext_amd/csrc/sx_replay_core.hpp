@@ -349,9 +349,26 @@ constexpr u32 kObCap = 4 * 64 + 3 * 128 + 16;  // leftover (<= 4q bytes) + one w
 // One region.  MODE 0: count only; 1: write findings and strings at fout/aout; 2: count, and
 // keep the output in the region's small cache slot (fout/aout) as long as it fits — o.pad says
 // whether it did, so that the second pass is a copy for almost every region.
-constexpr u32 kCacheFindings = 2, kCacheBytes = 96;
+// The cache slot of a region: [cap_f findings][cap_b string bytes].  All replaying regions share one
+// arena; the slot size is the arena divided by their number (between 160 bytes and 4 KiB), so that
+// sparse input gets by with little memory and string-dense input (long regions, many findings
+// each) still finds room for nearly every region's output.
+struct CacheGeom { u32 slot_bytes, cap_f, cap_b; };
+SXD CacheGeom cache_geom(u64 arena_bytes, u64 n_heads) {
+    u64 sb = n_heads ? arena_bytes / n_heads : 4096;
+    if (sb > 4096) sb = 4096;
+    if (sb < 160) sb = 160;
+    sb &= ~15ull;
+    CacheGeom g;
+    g.slot_bytes = (u32)sb;
+    g.cap_f = (u32)(sb / 96);
+    if (g.cap_f < 2) g.cap_f = 2;
+    g.cap_b = g.slot_bytes - g.cap_f * (u32)sizeof(sx_finding);
+    return g;
+}
 template <int MODE, int ENC>
-SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_finding* fout, u8* aout, u64 abase) {
+SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_finding* fout, u8* aout, u64 abase,
+                       u32 cap_f = 0, u32 cap_b = 0) {
     const u8* bytes = P.data;
     const u64 len = P.len;
     const u32 W = P.W;
@@ -448,7 +465,7 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
                     while (dsplit_next(P, it, ch)) {
                         if (!ch.again) {
                             bool put = MODE != 0;
-                            if (MODE == 2) { put = n_find < kCacheFindings && n_bytes + ch.len <= kCacheBytes; cached = cached && put; }
+                            if (MODE == 2) { put = n_find < cap_f && n_bytes + ch.len <= cap_b; cached = cached && put; }
                             if (put) {
                                 sx_finding f;
                                 f.position = consumed + din;
@@ -498,12 +515,13 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
 
 // the encoding family picked at run time (host-side test harness)
 template <int MODE>
-SXD void replay_region_any(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_finding* fout, u8* aout, u64 abase) {
+SXD void replay_region_any(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_finding* fout, u8* aout, u64 abase,
+                           u32 cap_f = 0, u32 cap_b = 0) {
     switch (enc_family(P.encoding)) {
-        case 1: replay_region<MODE, 1>(P, i, o, fout, aout, abase); break;
-        case 2: replay_region<MODE, 2>(P, i, o, fout, aout, abase); break;
-        case 3: replay_region<MODE, 3>(P, i, o, fout, aout, abase); break;
-        default: replay_region<MODE, 0>(P, i, o, fout, aout, abase); break;
+        case 1: replay_region<MODE, 1>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
+        case 2: replay_region<MODE, 2>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
+        case 3: replay_region<MODE, 3>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
+        default: replay_region<MODE, 0>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
     }
 }
 

@@ -39,18 +39,33 @@ namespace sx {
 // the very next one, is certainly inside the region that holds that run (the replay only stops
 // at a window end after which no run begins at once): it is marked kRegionChained right away.
 // On string-dense input this keeps nearly every lane from replaying what another one covers.
+SXD bool region_is_chained(const ReplayParams& P, u64 i, u64 want) {
+    return i > 0 && want <= next_win_start(P.runs[i - 1].end - 1, P.W);
+}
+// which runs replay at all (for the cache slots): neither somebody else's nor chained
+__global__ __launch_bounds__(256) void replay_heads_kernel(const ReplayParams P, u32* head) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.n_runs) return;
+    const u64 want = win_start(P.runs[i].start, P.W);
+    head[i] = (want < P.lo || want >= P.hi || region_is_chained(P, i, want)) ? 0u : 1u;
+}
+__global__ void replay_heads_total_kernel(const u32* head_last, const u32* slot_last, u32* n_heads) { *n_heads = *slot_last + *head_last; }
+
 template <int ENC, bool CACHED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WAVES))) void replay_count_kernel(
-    const ReplayParams P, ReplayRegionOut* out, sx_finding* cache_f, u8* cache_s) {
+    const ReplayParams P, ReplayRegionOut* out) {
     const u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
     if (i >= P.n_runs) return;
     ReplayRegionOut o;
     o.end = 0; o.n_find = 0; o.n_bytes = 0; o.status = kRegionOk; o.pad = 0;
     const u64 want = win_start(P.runs[i].start, P.W);
     if (want < P.lo || want >= P.hi) o.status = kRegionNotMine;
-    else if (i > 0 && want <= next_win_start(P.runs[i - 1].end - 1, P.W)) o.status = kRegionChained;
-    else if (CACHED) replay_region<2, ENC>(P, i, o, cache_f + i * kCacheFindings, cache_s + i * kCacheBytes, 0);
-    else replay_region<0, ENC>(P, i, o, nullptr, nullptr, 0);
+    else if (region_is_chained(P, i, want)) o.status = kRegionChained;
+    else if (CACHED) {
+        const CacheGeom g = cache_geom(P.arena_bytes, *P.n_heads);
+        u8* slot = P.cache_arena + (u64)P.slot_of[i] * g.slot_bytes;
+        replay_region<2, ENC>(P, i, o, (sx_finding*)slot, slot + g.cap_f * sizeof(sx_finding), 0, g.cap_f, g.cap_b);
+    } else replay_region<0, ENC>(P, i, o, nullptr, nullptr, 0);
     out[i] = o;
 }
 
@@ -67,21 +82,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WA
 // Pass 2, flagged form: one lane per run; the standing regions (stitch below) write at the
 // offsets the device scans assigned.
 template <int ENC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WAVES))) void replay_write_flagged_kernel(const ReplayParams P, const ReplayRegionOut* ro,
-                                                                  const u8* stands, const u64* fpos, const u64* apos,
-                                                                  const sx_finding* cache_f, const u8* cache_s,
-                                                                  sx_finding* findings, u8* arena) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WAVES))) void replay_write_flagged_kernel(
+    const ReplayParams P, const ReplayRegionOut* ro, const u8* stands, const u64* fpos, const u64* apos, sx_finding* findings,
+    u8* arena) {
     const u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
     if (i >= P.n_runs || !stands[i]) return;
     const u64 fp = fpos[i], ap = apos[i];
-    if (cache_f && ro[i].pad) {  // pass 1 kept the region's output: copy it into place
+    if (P.cache_arena && ro[i].pad) {  // pass 1 kept the region's output: copy it into place
+        const CacheGeom g = cache_geom(P.arena_bytes, *P.n_heads);
+        const u8* slot = P.cache_arena + (u64)P.slot_of[i] * g.slot_bytes;
+        const sx_finding* cf = (const sx_finding*)slot;
         const u32 nf = ro[i].n_find, nb = ro[i].n_bytes;
         for (u32 j = 0; j < nf; j++) {
-            sx_finding f = cache_f[i * kCacheFindings + j];
+            sx_finding f = cf[j];
             f.str_off += (u32)ap;
             findings[fp + j] = f;
         }
-        const u8* src = cache_s + i * kCacheBytes;
+        const u8* src = slot + g.cap_f * sizeof(sx_finding);
         for (u32 t = 0; t < nb; t++) arena[ap + t] = src[t];
         return;
     }
@@ -249,32 +266,45 @@ hipError_t launch_stitch_finish(const ReplayParams& P, const ReplayRegionOut* ro
     return hipGetLastError();
 }
 hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegionOut* ro, const uint8_t* stands,
-                                       const uint64_t* fpos, const uint64_t* apos, const void* cache, sx_finding* findings,
+                                       const uint64_t* fpos, const uint64_t* apos, sx_finding* findings,
                                        uint8_t* arena, hipStream_t stream) {
     if (P.n_runs == 0) return hipSuccess;
-    const sx_finding* cf = (const sx_finding*)cache;
-    const u8* cs = cache ? (const u8*)cache + P.n_runs * kCacheFindings * sizeof(sx_finding) : nullptr;
     const dim3 grid((unsigned)((P.n_runs + 63) / 64));
     switch (enc_family(P.encoding)) {
-        case 1: hipLaunchKernelGGL(replay_write_flagged_kernel<1>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, cf, cs, findings, arena); break;
-        case 2: hipLaunchKernelGGL(replay_write_flagged_kernel<2>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, cf, cs, findings, arena); break;
-        case 3: hipLaunchKernelGGL(replay_write_flagged_kernel<3>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, cf, cs, findings, arena); break;
-        default: hipLaunchKernelGGL(replay_write_flagged_kernel<0>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, cf, cs, findings, arena); break;
+        case 1: hipLaunchKernelGGL(replay_write_flagged_kernel<1>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
+        case 2: hipLaunchKernelGGL(replay_write_flagged_kernel<2>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
+        case 3: hipLaunchKernelGGL(replay_write_flagged_kernel<3>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
+        default: hipLaunchKernelGGL(replay_write_flagged_kernel<0>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
     }
     return hipGetLastError();
 }
 
-size_t replay_cache_bytes(uint64_t n_runs) { return n_runs * (kCacheFindings * sizeof(sx_finding) + kCacheBytes) + 64; }
-// cache: nullptr, or replay_cache_bytes(P.n_runs) bytes that pass 1 fills and launch_replay_write_flagged reads
-hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, void* cache, hipStream_t stream) {
+size_t replay_heads_scratch_bytes(uint64_t n_runs) {
+    size_t a = 0;
+    (void)rocprim::exclusive_scan(nullptr, a, (u32*)nullptr, (u32*)nullptr, 0u, (size_t)n_runs, rocprim::plus<u32>(), (hipStream_t)0);
+    return n_runs * 4 + a + 1024;
+}
+hipError_t launch_replay_heads(const ReplayParams& P, uint32_t* slot_of, uint32_t* n_heads, void* scratch, size_t scratch_bytes,
+                               hipStream_t stream) {
+    if (P.n_runs == 0) return hipMemsetAsync(n_heads, 0, 4, stream);
+    if (scratch_bytes < replay_heads_scratch_bytes(P.n_runs)) return hipErrorInvalidValue;
+    u32* head = (u32*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    void* tmp = (void*)(((uintptr_t)(head + P.n_runs) + 255) & ~(uintptr_t)255);
+    size_t tmp_bytes = scratch_bytes - (size_t)((u8*)tmp - (u8*)scratch);
+    hipLaunchKernelGGL(replay_heads_kernel, dim3((unsigned)((P.n_runs + 255) / 256)), dim3(256), 0, stream, P, head);
+    hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, head, slot_of, 0u, (size_t)P.n_runs, rocprim::plus<u32>(), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(replay_heads_total_kernel, dim3(1), dim3(1), 0, stream, head + (P.n_runs - 1), slot_of + (P.n_runs - 1), n_heads);
+    return hipGetLastError();
+}
+hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, hipStream_t stream) {
     if (P.n_runs == 0) return hipSuccess;
-    sx_finding* cf = (sx_finding*)cache;
-    u8* cs = cache ? (u8*)cache + P.n_runs * kCacheFindings * sizeof(sx_finding) : nullptr;
     const dim3 grid((unsigned)((P.n_runs + 63) / 64));
-#define SX_LAUNCH_COUNT(E)                                                                                         \
-    do {                                                                                                           \
-        if (cache) hipLaunchKernelGGL((replay_count_kernel<E, true>), grid, dim3(64), 0, stream, P, out, cf, cs);   \
-        else hipLaunchKernelGGL((replay_count_kernel<E, false>), grid, dim3(64), 0, stream, P, out, cf, cs);        \
+    const bool cache = P.cache_arena != nullptr;
+#define SX_LAUNCH_COUNT(E)                                                                                 \
+    do {                                                                                                   \
+        if (cache) hipLaunchKernelGGL((replay_count_kernel<E, true>), grid, dim3(64), 0, stream, P, out);   \
+        else hipLaunchKernelGGL((replay_count_kernel<E, false>), grid, dim3(64), 0, stream, P, out);        \
     } while (0)
     switch (enc_family(P.encoding)) {
         case 1: SX_LAUNCH_COUNT(1); break;

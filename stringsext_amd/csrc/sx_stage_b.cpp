@@ -37,7 +37,6 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     bool dev_stitch = n > 0 && !getenv("SX_HOST_STITCH");
     uint64_t* h_tot = nullptr;
     ReplayRegionOut* ro = nullptr;
-    void* cache_used = nullptr;
     {
         int rc = ensure_pinned2(ctx, n * sizeof(ReplayRegionOut) + 256);
         if (rc != SX_OK) return rc;
@@ -61,13 +60,20 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         P.chars_min_nb = m.c.chars_min_nb; P.same_block = m.c.require_same_unicode_block; P.q = (uint32_t)m.q;
         P.W = (uint32_t)W; P.long_run = m.long_run; P.skip = getenv("SX_NO_REPLAY_SKIP") ? 0u : 1u; P.grep_char = m.c.grep_char; P.mission_id = m.c.mission_id;
         P.file_id = job.file_id; P.af_lo = m.c.af_lo; P.af_hi = m.c.af_hi; P.ubf = m.c.ubf;
-        void* cache = nullptr;
-        if (dev_stitch && n <= (32u << 20) && !getenv("SX_NO_REPLAY_CACHE")) {
-            rc = ensure_rp(ctx, d, 8, replay_cache_bytes(n)); if (rc) return rc;
-            cache = d.d_rp[8];
+        // pass-1 output cache: one arena for all replaying regions (slot = arena / their number, on the device)
+        if (dev_stitch && !getenv("SX_NO_REPLAY_CACHE")) {
+            uint64_t budget = 8192ull << 20;   // of 288 GB; the arena is at most 1 KiB per run
+            if (const char* e = getenv("SX_REPLAY_CACHE_MIB")) budget = (uint64_t)atoll(e) << 20;
+            const uint64_t arena = std::max<uint64_t>(4096, std::min<uint64_t>(budget, (uint64_t)n * 1024));
+            rc = ensure_rp(ctx, d, 8, arena + (uint64_t)(n + 2) * 4 + 512); if (rc) return rc;
+            rc = ensure_scratch(ctx, std::max(stitch_scratch_bytes(n), replay_heads_scratch_bytes(n))); if (rc) return rc;
+            uint8_t* base = (uint8_t*)d.d_rp[8];
+            P.cache_arena = base; P.arena_bytes = arena & ~255ull;
+            uint32_t* slot_of = (uint32_t*)(base + ((arena + 255) & ~255ull));
+            P.slot_of = slot_of; P.n_heads = slot_of + n + 1;
+            HIP_TRY(ctx, launch_replay_heads(P, slot_of, slot_of + n + 1, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
         }
-        cache_used = cache;
-        HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], cache, d.stream_b));
+        HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], d.stream_b));
         if (dev_stitch) {
             HIP_TRY(ctx, hipMemsetAsync(d.d_rp[7], 0, kTotCount * 8, d.stream_b));
             HIP_TRY(ctx, launch_stitch_blocks(P, (const ReplayRegionOut*)d.d_rp[1], (uint8_t*)d.d_rp[2], d.d_rp[6],
@@ -157,8 +163,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         uint8_t* d_a = (uint8_t*)d.d_rp[5] + nf * sizeof(sx_finding);
         if (dev_stitch) {
             HIP_TRY(ctx, launch_replay_write_flagged(P, (const ReplayRegionOut*)d.d_rp[1], (const uint8_t*)d.d_rp[2],
-                                                     (const uint64_t*)d.d_rp[3], (const uint64_t*)d.d_rp[4], cache_used, d_f,
-                                                     d_a, d.stream_b));
+                                                     (const uint64_t*)d.d_rp[3], (const uint64_t*)d.d_rp[4], d_f, d_a, d.stream_b));
         } else {
             const size_t nv = valid.size();
             HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[2], valid.data(), nv * 8, hipMemcpyHostToDevice, d.stream_b));

@@ -14,16 +14,21 @@ extern "C" int sxd_replay_region_host(const sx::ReplayParams* P, uint64_t i, sx:
     sx::replay_region_any<1>(*P, i, w, fout, aout, 0);
     if (!(w.end == c.end && w.n_find == c.n_find && w.n_bytes == c.n_bytes)) return -2;
     // pass 1 with the output cache: same counts; if it says "kept", the slot holds exactly pass 2's output
-    sx_finding cf[sx::kCacheFindings];
-    uint8_t cs[sx::kCacheBytes];
+    // two geometries: the smallest slot and a roomy one
+    for (uint64_t heads : { (uint64_t)1 << 40, (uint64_t)1 }) {
+    const sx::CacheGeom g = sx::cache_geom(1 << 20, heads);
+    sx_finding cf[64];
+    uint8_t cs[4096];
     memset(cf, 0, sizeof cf); memset(cs, 0, sizeof cs);
     sx::ReplayRegionOut k;
-    sx::replay_region_any<2>(*P, i, k, cf, cs, 0);
+    sx::replay_region_any<2>(*P, i, k, cf, cs, 0, g.cap_f, g.cap_b);
     if (!(k.end == c.end && k.n_find == c.n_find && k.n_bytes == c.n_bytes && k.status == c.status)) return -3;
     if (k.status == sx::kRegionOk) {
-        const bool fits = c.n_find <= sx::kCacheFindings && c.n_bytes <= sx::kCacheBytes;
+        const bool fits = c.n_find <= g.cap_f && c.n_bytes <= g.cap_b;
         if (k.pad && !fits) return -4;
         if (k.pad && (memcmp(cf, fout, c.n_find * sizeof(sx_finding)) != 0 || memcmp(cs, aout, c.n_bytes) != 0)) return -5;
+        if (fits && !k.pad) return -6;
+    }
     }
     return 0;
 }
