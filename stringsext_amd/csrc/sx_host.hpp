@@ -72,6 +72,8 @@ public:
     int encoding() const { return enc_; }
     Decoder new_decoder_without_bom_handling() const { return Decoder(enc_); }
     DecodeStep decode_to_str_without_replacement(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, bool last);
+    // nothing pending: no partial UTF-8 sequence, no half UTF-16 unit, no surrogate waiting for its pair
+    bool idle() const { return needed_ == 0 && lead_byte_ < 0 && lead_surrogate_ == 0 && !pending_bmp_; }
 
 private:
     DecodeStep utf8(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, bool last);
@@ -133,7 +135,13 @@ struct ScannerState {
         consumed_bytes = m.c.counter_offset;
         stream_bytes = 0;
     }
-    bool clean() const { return last_scan_run_leftover.empty() && !last_run_str_was_printed_and_is_maybe_cut_str; }
+    // Nothing carried that a later window could need: no leftover, no pending cut — and no bytes
+    // pending in the decoder: a character that straddles the chunk boundary belongs to a run
+    // that the device scan of neither chunk sees whole, so the next chunk's first windows must
+    // be replayed from this exact state (found by tools/gpu_fuzz.py).
+    bool clean() const {
+        return last_scan_run_leftover.empty() && !last_run_str_was_printed_and_is_maybe_cut_str && decoder.idle();
+    }
 };
 
 // ---------------------------------------------------------------------------------------

@@ -266,3 +266,22 @@ def test_carried_state_across_many_small_files():
                          unicode_block_filter=rng.choice(["All", "Common", "African"]),
                          same_unicode_block=rng.random() < 0.2)
         assert run_cli_product(ms, files, radix="x") == sxo.run_cli(ms, files, radix="x"), (it, enc, len(files))
+
+
+def test_character_straddling_a_chunk_boundary_starts_a_minimal_string():
+    """A run of exactly chars_min chars whose first character straddles the chunk boundary: neither
+    chunk's run finder sees a long run (the first chunk cannot count the incomplete character, the
+    second sees chars_min - 1), so only the exact carried state — here: the decoder's pending byte —
+    can make the next chunk's first windows be replayed (found by tools/gpu_fuzz.py)."""
+    ms = rc.missions(encodings=["utf-8"], output_line_len="8", ascii_filter="Wsp", unicode_block_filter="0x001ffffffffffffc")
+    for lead_in in (1, 2, 3):
+        for word in ("Ждя ", "€дя ", "😀дя "):
+            w = word.encode("utf-8")
+            first = len(word[0].encode("utf-8"))
+            if lead_in >= first:
+                continue
+            data = b"\xff" * (4096 * 3 - lead_in) + w + b"\x00" + b"0Zc" * 40 + b"\xff" * 5000
+            want = sxo.run_cli(ms, [data], radix="x")
+            assert word.strip().encode("utf-8") in want
+            for chunk in (4096, 8192, None):
+                assert run_cli_product(ms, [data], radix="x", chunk_bytes=chunk) == want, (lead_in, word, chunk)
