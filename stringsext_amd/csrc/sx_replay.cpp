@@ -168,32 +168,46 @@ private:
     // accepted character if it is the last thing delivered before B (see file comment).
     void derive_state(uint64_t B, uint64_t pos, const Decoder& d_pos) {
         Decoder d(m_.c.encoding);
-        uint64_t p = B >= 8 ? B - 8 : 0;
+        // With --same-unicode-block (-r) the leftover's content matters after all: SplitStr re-scans it
+        // and remembers the lead byte of its last multi-byte char, which decides where the NEXT stretch
+        // is cut (src/helper.rs:279-292).  The stretch is < min(n,q) chars, so look back that far.
+        const uint64_t back = m_.c.require_same_unicode_block ? 4ull * m_.long_run + 8 : 8;
+        uint64_t p = B >= back ? B - back : 0;
         if (m_.is_utf16() && ((stream0_ + p) & 1)) p = p ? p - 1 : p + 1;
         if (p <= pos && pos <= B) { p = pos; d = d_pos; }
         if (p > B) p = B;
-        uint8_t sink[96], last[4];
-        size_t last_len = 0;
+        uint8_t sink[96], last[4], mb[4];
+        size_t last_len = 0, mb_len = 0;   // last accepted char; last accepted multi-byte char of the same stretch
         if (p < B) {
-            const size_t n = (size_t)(B - p);
-            const uint8_t* s = bytes_.span(p, n, &hint_);
-            size_t i = 0;
-            for (;;) {
-                const DecodeStep r = d.decode_to_str_without_replacement(s + i, n - i, sink, sizeof sink, false);
-                i += r.read;
-                for (size_t w = 0; w < r.written;) {
-                    const uint8_t lead = sink[w];
-                    const size_t cl = lead < 0x80 ? 1 : lead < 0xE0 ? 2 : lead < 0xF0 ? 3 : 4;
-                    if (m_.filter.pass_lead(lead)) { memcpy(last, sink + w, cl); last_len = cl; }
-                    else last_len = 0;
-                    w += cl;
+            uint64_t at = p;
+            while (at < B) {  // in pieces: the sink is small
+                const size_t n = (size_t)std::min<uint64_t>(B - at, 24);
+                const uint8_t* s = bytes_.span(at, n, &hint_);
+                size_t i = 0;
+                for (;;) {
+                    const DecodeStep r = d.decode_to_str_without_replacement(s + i, n - i, sink, sizeof sink, false);
+                    i += r.read;
+                    for (size_t w = 0; w < r.written;) {
+                        const uint8_t lead = sink[w];
+                        const size_t cl = lead < 0x80 ? 1 : lead < 0xE0 ? 2 : lead < 0xF0 ? 3 : 4;
+                        if (m_.filter.pass_lead(lead)) {
+                            memcpy(last, sink + w, cl); last_len = cl;
+                            if (cl > 1) { memcpy(mb, sink + w, cl); mb_len = cl; }
+                        } else { last_len = 0; mb_len = 0; }
+                        w += cl;
+                    }
+                    if (r.result == DecoderResult::InputEmpty) break;
+                    if (r.result == DecoderResult::Malformed) { last_len = 0; mb_len = 0; }
                 }
-                if (r.result == DecoderResult::InputEmpty) break;
-                if (r.result == DecoderResult::Malformed) last_len = 0;
+                at += n;
             }
         }
         st_->decoder = d;
-        st_->last_scan_run_leftover.assign((const char*)last, last_len);
+        st_->last_scan_run_leftover.clear();
+        if (last_len) {
+            if (m_.c.require_same_unicode_block && mb_len && last_len == 1) st_->last_scan_run_leftover.assign((const char*)mb, mb_len);
+            st_->last_scan_run_leftover.append((const char*)last, last_len);
+        }
         st_->last_run_str_was_printed_and_is_maybe_cut_str = false;
     }
 

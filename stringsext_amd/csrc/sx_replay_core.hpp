@@ -317,14 +317,16 @@ template <int ENC>
 SXD u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& dec, u8* ob) {
     const u8* bytes = P.data;
     ddec_reset(dec, (int)P.encoding, P.table);
-    u64 p = at >= 8 ? at - 8 : 0;
+    // with -r the lead byte of the leftover's last multi-byte char matters (see RangeReplay::derive_state)
+    const u64 back = P.same_block ? 4ull * P.long_run + 8 : 8;
+    u64 p = at >= back ? at - back : 0;
     if ((ENC == 2 || ENC == 3) && ((P.stream0 + p) & 1)) p = p ? p - 1 : p + 1;
     if (p < floor) p = floor;
     if (p > at) p = at;
-    u8 sink[40], last[4];
-    u32 last_len = 0;
-    if (p < at) {
-        const u32 n = (u32)(at - p);
+    u8 sink[40], last[4], mb[4];
+    u32 last_len = 0, mb_len = 0;
+    while (p < at) {   // in pieces: the sink is small
+        const u32 n = (u32)(at - p < 12 ? at - p : 12);
         u32 k = 0;
         for (;;) {
             const DStep r = ddecode<ENC>(dec, bytes + p + k, n - k, sink, sizeof sink, false);
@@ -332,16 +334,24 @@ SXD u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& dec, u8* o
             for (u32 w = 0; w < r.written;) {
                 const u8 lead = sink[w];
                 const u32 cl = lead < 0x80 ? 1 : lead < 0xE0 ? 2 : lead < 0xF0 ? 3 : 4;
-                if (pass_lead(P, lead)) { for (u32 t = 0; t < cl; t++) last[t] = sink[w + t]; last_len = cl; }
-                else last_len = 0;
+                if (pass_lead(P, lead)) {
+                    for (u32 t = 0; t < cl; t++) last[t] = sink[w + t];
+                    last_len = cl;
+                    if (cl > 1) { for (u32 t = 0; t < cl; t++) mb[t] = sink[w + t]; mb_len = cl; }
+                } else { last_len = 0; mb_len = 0; }
                 w += cl;
             }
             if (r.result == RES_INPUT_EMPTY) break;
-            if (r.result == RES_MALFORMED) last_len = 0;
+            if (r.result == RES_MALFORMED) { last_len = 0; mb_len = 0; }
         }
+        p += n;
     }
-    for (u32 t = 0; t < last_len; t++) ob[t] = last[t];
-    return last_len;
+    u32 out = 0;
+    if (last_len) {
+        if (P.same_block && mb_len && last_len == 1) { for (u32 t = 0; t < mb_len; t++) ob[out++] = mb[t]; }
+        for (u32 t = 0; t < last_len; t++) ob[out++] = last[t];
+    }
+    return out;
 }
 
 constexpr u32 kObCap = 4 * 64 + 3 * 128 + 16;  // leftover (<= 4q bytes) + one window's output; q <= 64

@@ -285,3 +285,21 @@ def test_character_straddling_a_chunk_boundary_starts_a_minimal_string():
             assert word.strip().encode("utf-8") in want
             for chunk in (4096, 8192, None):
                 assert run_cli_product(ms, [data], radix="x", chunk_bytes=chunk) == want, (lead_in, word, chunk)
+
+
+def test_same_unicode_block_remembers_the_leftovers_last_multibyte_lead():
+    """-r: SplitStr re-scans the leftover and keeps the lead byte of its last multi-byte char; that decides
+    where the next stretch of the same decoder call is cut (src/helper.rs:279-292).  A replay region that
+    begins right after such a leftover must re-derive it, not just "some accepted char" (found by
+    tools/gpu_fuzz.py: a 2-char leftover 'Ѕ/' in front of '+ASy' + U+009B in ISO-8859-5)."""
+    ms = rc.missions(encodings=["iso-8859-5"], chars_min="4", output_line_len="6", ascii_filter="All-Ctrl",
+                     unicode_block_filter="Common", same_unicode_block=True)
+    W = 12
+    for pad in range(0, 3):
+        body = b"\xa5/" + b"\x1a+ASy\x9b\r\xaa\x91X\x88\xcf" + b"\x00" * 40
+        for k in (5, 40, 339):
+            data = b"\x00" * (W * k - 2 - pad) + b"/" * pad + body + b"\x01" * 3000
+            want = sxo.run_cli(ms, [data], radix="x")
+            assert b"+ASy" in want
+            assert run_cli_product(ms, [data], radix="x") == want, (pad, k)
+            assert run_cli_product(ms, [data], radix="x", chunk_bytes=4096) == want, (pad, k)
