@@ -139,7 +139,7 @@ public:
         ri_ = (uint64_t)(std::partition_point(runs_, runs_ + n_runs_, [lo](const sx_run& r) { return r.end <= lo; }) - runs_);
         strict_ = entry_exact && !st.clean();  // exact carried state: follow it until it is clean
         // no exact state here: re-derive decoder state AND leftover presence from the bytes before lo
-        if (!entry_exact) derive_state(lo, lo >= 9 ? lo - 9 : 0, st.decoder);
+        if (!entry_exact) derive_state(lo, ~0ull, st.decoder);  // no exact state anywhere near: pos out of reach
         uint64_t pos = lo;
         while (pos < len_) {
             if (!strict_ && !st.last_run_str_was_printed_and_is_maybe_cut_str) {

@@ -303,3 +303,32 @@ def test_same_unicode_block_remembers_the_leftovers_last_multibyte_lead():
             assert b"+ASy" in want
             assert run_cli_product(ms, [data], radix="x") == want, (pad, k)
             assert run_cli_product(ms, [data], radix="x", chunk_bytes=4096) == want, (pad, k)
+
+
+def test_same_unicode_block_region_entry_without_exact_state_keeps_the_unit_grid():
+    """-r looks further back when it re-derives a region's entry state; the replay parts behind the first
+    one (and the regions behind the device's) have no exact state to start from, and must not take the
+    "no state known" marker for one: UTF-16 was decoded one byte off the unit grid (found by
+    tools/gpu_fuzz.py: utf-16be -n 4 -q 30 -r -u Asian, strings of U+4200 that are not there)."""
+    n = 17 << 20
+    part = (n // 4 + 4095) // 4096 * 4096  # replay_plan: 4 parts for 17 MiB
+    base = bytearray(sxo.background(0, n))
+    text = "一丁七万丈三上下不与" * 4  # one lead byte (E4): one "unicode block" for -r
+    for k in (1, 2, 3):
+        for delta, enc in ((10, "utf-16-be"), (4096 + 20, "utf-16-le")):
+            blob = text.encode(enc)
+            base[k * part + delta:k * part + delta + len(blob)] = blob
+    # enough long runs elsewhere for the replay to be split at all (>= 512 per part)
+    rng = random.Random(5)
+    for _ in range(4000):
+        p = rng.randrange(0, n - 200) // 2 * 2
+        if all(abs(p - k * part) > 20000 for k in (1, 2, 3)):
+            base[p:p + 40] = "丐丑丒专且丕".encode("utf-16-be") * 3 + b"\xff\xff\xff\xff"
+    data = bytes(base)
+    for flags in (dict(encodings=["utf-16be"], chars_min="4", output_line_len="30", unicode_block_filter="Asian",
+                       same_unicode_block=True),
+                  dict(encodings=["utf-16le"], chars_min="4", unicode_block_filter="Asian", same_unicode_block=True)):
+        ms = rc.missions(**flags)
+        want = sxo.run_cli(ms, [data], radix="x")
+        assert text[:8].encode("utf-8") in want
+        assert run_cli_product(ms, [data], radix="x") == want, flags

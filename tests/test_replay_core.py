@@ -4,6 +4,7 @@ host C++ by a test-only harness, must agree region by region with the product's 
 import ctypes as C
 import importlib.util
 import os
+import zlib
 import random
 import subprocess
 
@@ -98,6 +99,11 @@ CONFIGS = [
     dict(encodings=["utf-8"], chars_min="4", same_unicode_block=True, unicode_block_filter="All"),
     dict(encodings=["windows-1252"], chars_min="8", unicode_block_filter="Latin"),
     dict(encodings=["utf-8"], chars_min="70", output_line_len="64"),
+    dict(encodings=["utf-16be"], chars_min="4", output_line_len="30", same_unicode_block=True, unicode_block_filter="Asian",
+         ascii_filter="0x7ffffffe000000007ffffffe00000000"),
+    dict(encodings=["utf-16le"], chars_min="3", same_unicode_block=True, unicode_block_filter="All"),
+    dict(encodings=["iso-8859-5"], chars_min="4", output_line_len="6", same_unicode_block=True, ascii_filter="All-Ctrl",
+         unicode_block_filter="Common"),
 ]
 
 
@@ -105,13 +111,14 @@ CONFIGS = [
 @pytest.mark.parametrize("parity", [0, 1])
 @pytest.mark.parametrize("skip", [1, 0], ids=["shortcuts", "every-byte"])
 def test_device_replay_core_equals_host_replayer(core, flags, parity, skip):
-    rng = random.Random(hash(str(flags)) & 0xFFFF)
+    rng = random.Random(zlib.crc32(repr(sorted(flags.items())).encode()) & 0xFFFF)
     m = rc.missions(**flags)[0]
     if m["output_line_char_nb_max"] > 64:
         pytest.skip("device replay covers q <= 64")
     W = 2 * m["output_line_char_nb_max"]
     long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
     table = sb_table(m["encoding"]) if m["encoding"] >= 16 else None
+    checked = 0
     for data in (synth(rng, 60_000, 1 / 150), soup(rng, 30_001), synth(rng, 20_000, 1 / 2000),
                  bytes(rng.choice(b"abcdefgh \x00") for _ in range(9_000)), tricky(rng, 40_000)):
         stream0 = parity  # odd stream offset of buffer byte 0 shifts the UTF-16 unit grid
@@ -124,7 +131,6 @@ def test_device_replay_core_equals_host_replayer(core, flags, parity, skip):
         sc = sx.Scanner([m], device=sx.SX_HOST_ONLY)
         fbuf = (sx.Finding * 4096)()
         abuf = (C.c_uint8 * (1 << 20))()
-        checked = 0
         for i, r in enumerate(runs):
             want = ws(r[0], W)
             if want == 0 or (i > 0 and want <= ws(runs[i - 1][1] - 1, W)):
@@ -146,4 +152,4 @@ def test_device_replay_core_equals_host_replayer(core, flags, parity, skip):
             # the host reports len when no further region exists; otherwise the stop position must agree
             assert o.end == ends[0] or ends[0] == len(data), (i, r, want, o.end, ends[0])
             checked += 1
-        assert checked > 0 or not runs
+    assert checked > 0
