@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstringsext_amd.so")
+LIB_PATH = os.environ.get("SX_LIB") or os.path.join(_HERE, "libstringsext_amd.so")  # SX_LIB: debugging builds
 
 SX_OK, SX_E_INVALID, SX_E_NO_DEVICE, SX_E_HIP, SX_E_NOMEM, SX_E_STATE = 0, -1, -2, -3, -4, -5
 SX_HOST_ONLY = -1

@@ -313,8 +313,11 @@ SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs) {
 // The state the reference carries into the window that starts at `at`, when nothing long
 // crosses `at` (RangeReplay::derive_state): the decoder's pending bytes, and one accepted char
 // as leftover if it is the last thing delivered before `at`.  Decodes from max(at - 8, floor).
+// Not inlined: it runs once or twice per region, and as a call it keeps the replay loop's register
+// pressure down.  (Inlined twice into the 64-VGPR replay kernels, one variant — UTF-16BE, count only —
+// came out of the compiler wrong: results changed with the occupancy attribute alone.  See DESIGN.md §9.)
 template <int ENC>
-SXD u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& dec, u8* ob) {
+SXD_NOINLINE u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& dec, u8* ob) {
     const u8* bytes = P.data;
     ddec_reset(dec, (int)P.encoding, P.table);
     // with -r the lead byte of the leftover's last multi-byte char matters (see RangeReplay::derive_state)

@@ -27,6 +27,7 @@
 namespace sx {
 
 #define SXD __device__ __forceinline__
+#define SXD_NOINLINE __device__ __attribute__((noinline))
 }  // namespace sx
 #include "sx_replay_core.hpp"
 namespace sx {
@@ -62,9 +63,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WA
     if (want < P.lo || want >= P.hi) o.status = kRegionNotMine;
     else if (region_is_chained(P, i, want)) o.status = kRegionChained;
     else if (CACHED) {
+        // slots have a minimum size: with more replaying regions than the arena has room for, the ones
+        // behind its end go without (cap 0: nothing fits, o.pad stays 0, pass 2 replays them)
         const CacheGeom g = cache_geom(P.arena_bytes, *P.n_heads);
-        u8* slot = P.cache_arena + (u64)P.slot_of[i] * g.slot_bytes;
-        replay_region<2, ENC>(P, i, o, (sx_finding*)slot, slot + g.cap_f * sizeof(sx_finding), 0, g.cap_f, g.cap_b);
+        const u64 off = (u64)P.slot_of[i] * g.slot_bytes;
+        const bool room = off + g.slot_bytes <= P.arena_bytes;
+        u8* slot = P.cache_arena + (room ? off : 0);
+        replay_region<2, ENC>(P, i, o, (sx_finding*)slot, slot + g.cap_f * sizeof(sx_finding), 0, room ? g.cap_f : 0u, room ? g.cap_b : 0u);
     } else replay_region<0, ENC>(P, i, o, nullptr, nullptr, 0);
     out[i] = o;
 }

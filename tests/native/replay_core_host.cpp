@@ -2,6 +2,7 @@
 #include <stdint.h>
 #include <string.h>
 #define SXD inline
+#define SXD_NOINLINE inline
 #include "../../stringsext_amd/csrc/sx_replay_core.hpp"
 
 extern "C" int sxd_replay_region_host(const sx::ReplayParams* P, uint64_t i, sx::ReplayRegionOut* o, sx_finding* fout,

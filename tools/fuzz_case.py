@@ -1,0 +1,56 @@
+"""One randomized parity case from a seed (shared by gpu_fuzz.py and gpu_repro.py)."""
+import os, random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import refconfig as rc
+from test_host_logic import soup, synth
+from test_gpu_parity import dense
+
+ENCS = ["utf-8", "ascii", "utf-16le", "utf-16be", "koi8-r", "ibm866", "windows-1252", "iso-8859-5", "x-user-defined"]
+AFS = [None, "All", "All-Ctrl", "All-Ctrl+Wsp", "None", "Wsp", "0x7ffffffe000000007ffffffe00000000"]
+UBFS = [None, "African", "All", "Common", "Cyrillic", "Latin", "Asian", "Uncommon", "None", "Hebrew", "Cjk"]
+# alternative paths behind environment switches, read by the library at call time
+SWITCH_SETS = [{}, {}, {}, {"SX_NO_REPLAY_CACHE": "1"}, {"SX_HOST_STITCH": "1"}, {"SX_NO_REPLAY_SKIP": "1"}, {"SX_REPLAY_CACHE_MIB": "0"},
+               {"SX_REGION_CAP": "2"}, {"SX_REGION_CAP": "0"}, {"SX_DEVICE_JOIN_MIN": "1"}, {"SX_HOST_MERGE": "1"},
+               {"SX_NO_REPLAY_CACHE": "1", "SX_NO_REPLAY_SKIP": "1"}, {"SX_HOST_STITCH": "1", "SX_DEVICE_JOIN_MIN": "1"}]
+ALL_SWITCHES = sorted({k for s in SWITCH_SETS for k in s})
+
+
+def make(case_seed):
+    r = random.Random(case_seed)
+    encs = []
+    for _ in range(r.randrange(1, 4)):
+        e = r.choice(ENCS)
+        if r.random() < 0.3:
+            e += "," + r.choice(["", "2", "5", "12"]) + "," + (r.choice(AFS) or "") + "," + (r.choice(UBFS) or "")
+        encs.append(e)
+    kw = dict(encodings=encs, chars_min=r.choice([None, "1", "2", "4", "7", "10", "20", "70"]),
+              output_line_len=r.choice([None, None, "6", "8", "10", "30", "64", "100"]),
+              ascii_filter=r.choice(AFS), unicode_block_filter=r.choice(UBFS),
+              grep_char=r.choice([None, None, None, "47", "0x65", "32"]), same_unicode_block=r.random() < 0.2,
+              counter_offset=r.choice([None, None, "1000", "0x10"]))
+    ms = rc.missions(**kw)
+    kind = r.choice(["synth", "synth_dense", "soup", "dense", "text", "multi"])
+    size = r.choice([5000, 70_000, 300_000, 1_200_000])
+    if kind == "synth": files = [synth(r, size, 1 / 500)]
+    elif kind == "synth_dense": files = [synth(r, size, 1 / 60)]
+    elif kind == "soup": files = [soup(r, min(size, 200_000))]
+    elif kind == "dense": files = [dense(r, size, r.choice([2, 20, 200]), "abcdefgh XYZ019_-éжЖдяבשλ€😀")]
+    elif kind == "text": files = [("The quick brown fox — Ünïcödé ßtring, доброе утро, שלום עולם. " * (size // 60 + 1)).encode(r.choice(["utf-8", "utf-16-le", "koi8-r"]), errors="replace")[:size]]
+    else: files = [synth(r, r.randrange(1, 20000), 1 / 100) for _ in range(r.randrange(2, 6))] + [b""]
+    case = dict(kw=kw, missions=ms, kind=kind, size=size, files=files, chunk=r.choice([None, None, 4096, 16384, 65536]),
+                flush=r.random() < 0.3, sub=r.choice([0, 0, 1024, 4096]), replay=r.choice([None, None, True, False]),
+                generic=r.random() < 0.2)
+    case["switches"] = r.choice(SWITCH_SETS)
+    return case
+
+
+def set_switches(sw):
+    for k in ALL_SWITCHES:
+        os.environ.pop(k, None)
+    os.environ.update(sw)
+
+
+def describe(c):
+    return (f"kind={c['kind']} size={c['size']} chunk={c['chunk']} flush={c['flush']} sub={c['sub']} replay={c['replay']} "
+            f"generic={c['generic']} switches={c['switches']}\n  flags={c['kw']}")

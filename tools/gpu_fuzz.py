@@ -1,62 +1,36 @@
 """Long-running randomized parity check on the GPU (or, with SX_FUZZ_HOST=1, of the host replay stage alone,
 fed with the oracle's runs — no GPU needed): random missions (encodings, -n, -q, filters,
--g, -r), random inputs (planted strings, adversarial soup, dense strings, text), random chunking and
-stage-B placement, each compared byte for byte with the oracle's CLI output.
+-g, -r), random inputs (planted strings, adversarial soup, dense strings, text), random chunking,
+stage-B placement and alternative code paths (the environment switches of DESIGN.md §9), each compared
+byte for byte with the oracle's CLI output.  A failing case is replayed with tools/gpu_repro.py CASE_SEED.
 usage: tools/gpu_fuzz.py SECONDS [SEED]"""
 import os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import refconfig as rc, stringsext_amd as sx, sxo_binding as sxo
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fuzz_case
+import stringsext_amd as sx, sxo_binding as sxo
 from product_harness import run_cli_product
-from test_host_logic import soup, synth
-from test_gpu_parity import dense
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
 rng = random.Random(seed)
-ENCS = ["utf-8", "ascii", "utf-16le", "utf-16be", "koi8-r", "ibm866", "windows-1252", "iso-8859-5", "x-user-defined"]
-AFS = [None, "All", "All-Ctrl", "All-Ctrl+Wsp", "None", "Wsp", "0x7ffffffe000000007ffffffe00000000"]
-UBFS = [None, "African", "All", "Common", "Cyrillic", "Latin", "Asian", "Uncommon", "None", "Hebrew", "Cjk"]
+host_only = bool(os.environ.get("SX_FUZZ_HOST"))
 t0 = time.time(); n = 0
 while time.time() - t0 < budget:
     n += 1
     case_seed = rng.randrange(1 << 31)
-    r = random.Random(case_seed)
-    encs = []
-    for _ in range(r.randrange(1, 4)):
-        e = r.choice(ENCS)
-        if r.random() < 0.3:
-            e += "," + r.choice(["", "2", "5", "12"]) + "," + (r.choice(AFS) or "") + "," + (r.choice(UBFS) or "")
-        encs.append(e)
-    kw = dict(encodings=encs, chars_min=r.choice([None, "1", "2", "4", "7", "10", "20", "70"]),
-              output_line_len=r.choice([None, None, "6", "8", "10", "30", "64", "100"]),
-              ascii_filter=r.choice(AFS), unicode_block_filter=r.choice(UBFS),
-              grep_char=r.choice([None, None, None, "47", "0x65", "32"]), same_unicode_block=r.random() < 0.2,
-              counter_offset=r.choice([None, None, "1000", "0x10"]))
-    ms = rc.missions(**kw)
-    kind = r.choice(["synth", "synth_dense", "soup", "dense", "text", "multi"])
-    size = r.choice([5000, 70_000, 300_000, 1_200_000])
-    if kind == "synth": files = [synth(r, size, 1 / 500)]
-    elif kind == "synth_dense": files = [synth(r, size, 1 / 60)]
-    elif kind == "soup": files = [soup(r, min(size, 200_000))]
-    elif kind == "dense": files = [dense(r, size, r.choice([2, 20, 200]), "abcdefgh XYZ019_-éжЖдяבשλ€😀")]
-    elif kind == "text": files = [("The quick brown fox — Ünïcödé ßtring, доброе утро, שלום עולם. " * (size // 60 + 1)).encode(r.choice(["utf-8", "utf-16-le", "koi8-r"]), errors="replace")[:size]]
-    else: files = [synth(r, r.randrange(1, 20000), 1 / 100) for _ in range(r.randrange(2, 6))] + [b""]
-    chunk = r.choice([None, None, 4096, 16384, 65536])
-    flush = r.random() < 0.3
-    sub = r.choice([0, 0, 1024, 4096])
-    replay = r.choice([None, None, True, False])
-    want = sxo.run_cli(ms, files, radix="x", flush_at_eof=flush)
+    c = fuzz_case.make(case_seed)
+    want = sxo.run_cli(c["missions"], c["files"], radix="x", flush_at_eof=c["flush"])
+    fuzz_case.set_switches({} if host_only else c["switches"])
     try:
-        if os.environ.get("SX_FUZZ_HOST"):
-            got = run_cli_product(ms, files, radix="x", chunk_bytes=chunk, device=None, flush_at_eof=flush)
+        if host_only:
+            got = run_cli_product(c["missions"], c["files"], radix="x", chunk_bytes=c["chunk"], device=None, flush_at_eof=c["flush"])
         else:
-            got = run_cli_product(ms, files, radix="x", chunk_bytes=chunk, device=0, subchunk_bytes=sub, flush_at_eof=flush,
-                                  device_replay=replay, generic_kernels=r.random() < 0.2)
+            got = run_cli_product(c["missions"], c["files"], radix="x", chunk_bytes=c["chunk"], device=0, subchunk_bytes=c["sub"],
+                                  flush_at_eof=c["flush"], device_replay=c["replay"], generic_kernels=c["generic"])
     except sx.SxError as e:
         got = ("error: %s" % e).encode()
     if got != want:
-        print(f"MISMATCH fuzz seed {seed} case {n} case_seed {case_seed}: kind={kind} size={size} chunk={chunk} flush={flush} sub={sub} replay={replay}\n  flags={kw}")
+        print(f"MISMATCH fuzz seed {seed} case {n} case_seed {case_seed}: {fuzz_case.describe(c)}")
         gl, wl = got.split(b"\n"), want.split(b"\n")
         for i, (a, b) in enumerate(zip(gl, wl)):
             if a != b:
