@@ -359,7 +359,9 @@ private:
     // no cut string pending at window start p: is there nothing that forces the replay to continue right here?
     bool region_over(uint64_t p) {
         while (ri_ < n_runs_ && runs_[ri_].end <= p) ri_++;
-        if (ri_ < n_runs_ && window_start(runs_[ri_].start, W_) <= p) return false;
+        // only a long run across p keeps the region going; one that begins at or behind p starts its own
+        // (with -g also one that begins in the window at p: sx_replay_core.hpp regions_may_touch)
+        if (ri_ < n_runs_ && (m_.c.grep_char < 0 ? runs_[ri_].start < p : window_start(runs_[ri_].start, W_) <= p)) return false;
         if (owns_tail_ && len_ && tail_start() <= p) return false;
         return true;
     }

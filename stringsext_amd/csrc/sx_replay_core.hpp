@@ -225,6 +225,14 @@ SXD u64 next_win_start(u64 p, u32 W) {  // start of the window after the one tha
     return e < s + kSliceLen ? e : s + kSliceLen;
 }
 
+// May a region end at a window start where a run begins, and the next one start right there?
+SXD bool regions_may_touch(const ReplayParams& P) { return P.grep_char < 0; }
+// A run whose window start lies inside or in front of the run before it is inside that run's region.
+SXD bool run_is_chained(const ReplayParams& P, u64 i, u64 want) {
+    if (i == 0) return false;
+    return regions_may_touch(P) ? want < P.runs[i - 1].end : want <= next_win_start(P.runs[i - 1].end - 1, P.W);
+}
+
 // ------------------------------------------------------------------------------------------
 // Shortcuts through bytes that cannot matter (device replay only; the host replayer decodes
 // everything, and the two must agree — tests/test_replay_core.py, tests/test_gpu_parity.py).
@@ -400,9 +408,14 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
     bool cached = MODE == 2;
 
     // region_over(p): nothing forces the replay to go on at window start p
+    // A run that begins at or behind p is the business of the region that starts there: with nothing
+    // pending at p, that region derives exactly this state — only a long run ACROSS p keeps this one
+    // going.  Not with -g: a stretch of q chars without the grep char ends SplitStr's iteration for the
+    // whole decoder call (helper.rs:410-415), so what follows it in the window is never carried, which
+    // the bytes in front of p cannot tell; there a region only ends in front of a window without runs.
     auto region_over = [&](u64 p) -> bool {
         while (ri < P.n_runs && P.runs[ri].end <= p) ri++;
-        if (ri < P.n_runs && win_start(P.runs[ri].start, W) <= p) return false;
+        if (ri < P.n_runs && (regions_may_touch(P) ? P.runs[ri].start < p : win_start(P.runs[ri].start, W) <= p)) return false;
         return true;
     };
     auto may_drop = [&](const u8* lo, u32 n) -> bool {
@@ -434,9 +447,10 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
                     while (ri < P.n_runs && P.runs[ri].end <= p) ri++;
                     const u64 rs = ri < P.n_runs ? P.runs[ri].start : ~0ull;
                     if (rs >= wend) {  // (B) nothing long starts in the rest of this window
-                        // If the region ends there anyway (no run begins in the next window, and the
-                        // leftover — at most one derived char — is droppable) the state is never read.
-                        if (P.long_run > 1 && (ri >= P.n_runs || win_start(rs, W) > wend)) {
+                        // Nothing is pending there and no long run lies across wend (it would begin before
+                        // wend): the region ends at wend, the state is never read.  (With -g only if no run
+                        // begins in the next window either, and the derived leftover — one char — is droppable.)
+                        if (regions_may_touch(P) || (P.long_run > 1 && (ri >= P.n_runs || win_start(rs, W) > wend))) {
                             leftover_len = 0; dout = 0; din = dend;
                             ddec_reset(dec, (int)P.encoding, P.table);
                             break;

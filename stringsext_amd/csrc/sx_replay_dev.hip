@@ -36,13 +36,14 @@ namespace sx {
 #define SX_REPLAY_WAVES 8   // the replay lives on occupancy: 64 VGPRs and a few spilled registers beat 128 VGPRs at 4 waves (measured)
 #endif
 
-// Pass 1: one lane per run.  A run that begins in the window where the run before it ends, or in
-// the very next one, is certainly inside the region that holds that run (the replay only stops
-// at a window end after which no run begins at once): it is marked kRegionChained right away.
-// On string-dense input this keeps nearly every lane from replaying what another one covers.
-SXD bool region_is_chained(const ReplayParams& P, u64 i, u64 want) {
-    return i > 0 && want <= next_win_start(P.runs[i - 1].end - 1, P.W);
-}
+// Pass 1: one lane per run.  A run that begins in the window where the run before it ends is
+// certainly inside the region that holds that run (its window start lies inside or in front of that
+// run): it is marked kRegionChained right away.  A run that begins in a later window starts a region
+// of its own — the region before it stops at that window start if nothing is pending there
+// (replay_region's region_over), else it runs on and the stitch voids this one.  On string-dense
+// input (a run in nearly every window) this gives one short region per window instead of chains.
+// (With -g the next window still belongs to the region: sx_replay_core.hpp regions_may_touch.)
+SXD bool region_is_chained(const ReplayParams& P, u64 i, u64 want) { return run_is_chained(P, i, want); }
 // which runs replay at all (for the cache slots): neither somebody else's nor chained
 __global__ __launch_bounds__(256) void replay_heads_kernel(const ReplayParams P, u32* head) {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;

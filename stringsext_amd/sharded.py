@@ -50,7 +50,9 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
     gather=True: rank 0 gets the list of (findings_bytes, arena_bytes) per rank, in rank order (a
     gather over the process group), the other ranks None.  gather=False: the findings stay where
     they are — rank k's Result is segment k of the file's findings, in order — and every rank
-    gets the list of per-rank finding counts.  The rank's own Result is the second value.
+    gets the per-rank finding counts (ShardCounts).  The rank's own Result is the second value.
+    Segment k may end with a few findings that lie behind rank k's range end (a region across the
+    boundary; ShardCounts.overflow[k] of them); splice_order() merges them into segment k+1's head.
     """
     world, rank = dist.get_world_size(), dist.get_rank()
     own_lo, own_hi = shard_bounds(file_len, world, rank)
@@ -104,7 +106,13 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
                 res.free()
                 res, ends, truncated, _ = attempt(start, h, False)
             ends = [max(e, p) for e, p in zip(ends, prev_end)]
-    counts = [row[2 * nm] for row in table]
+    # A region that crosses the shard boundary is finished by the rank it began on, so the tail of rank
+    # k's findings can lie in slices that belong to rank k+1 and interleaves there with other Missions'
+    # findings of rank k+1 (the reference prints slice by slice, src/main.rs:153-168).  How many such
+    # findings each rank holds goes along with the counts; splice_order() puts them in place.
+    over = _overflow(res, own_hi // 4096) if rank + 1 < world else 0
+    counts = ShardCounts(row[2 * nm] for row in table)
+    counts.overflow = [row[0] for row in _all_gather_u64([over], device)]
     if os.environ.get("SX_TIMING") and rank == 0:
         print(f"[sx] sharded: scan {1e3 * (t_scan - t_begin):.2f} ms, exchange {1e3 * (time.perf_counter() - t_scan):.2f} ms",
               file=sys.stderr)
@@ -128,6 +136,56 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
         return out, res
     dist.gather(mine, None, dst=0)
     return None, res
+
+
+class ShardCounts(list):
+    """Findings per rank; .overflow[k] = how many of rank k's last findings lie behind its range end."""
+    overflow = None
+
+
+def _overflow(res, boundary_slice):
+    n = 0
+    for v, cnt, _ in reversed(res.segments()):
+        i = cnt
+        while i > 0 and v[i - 1].slice_index >= boundary_slice:
+            i -= 1
+        n += cnt - i
+        if i > 0:
+            break
+    return n
+
+
+def splice_order(parts, file_len, key=lambda f: (f["slice_index"], f["position"])):
+    """parts[k] = rank k's findings (decoded, in that rank's order) -> one list in the reference's order:
+    rank k's findings behind its range end are merged into the head of rank k+1's (same rule as the
+    library's Mission merge: slice, position, then Mission order; both sides are already sorted)."""
+    world = len(parts)
+    out = []
+    carry = []  # findings of earlier ranks that lie in slices of the current one
+    for k, part in enumerate(parts):
+        b = shard_bounds(file_len, world, k)[1] // 4096
+        cut = len(part)
+        while k + 1 < world and cut > 0 and part[cut - 1]["slice_index"] >= b:
+            cut -= 1
+        own, nxt = part[:cut], part[cut:]
+        if carry:  # two sorted lists; ties: lower Mission first, and within a Mission the earlier rank
+            merged, i, j = [], 0, 0
+            while i < len(carry) and j < len(own):
+                a, c = carry[i], own[j]
+                if (key(a), a["mission_id"]) <= (key(c), c["mission_id"]):
+                    merged.append(a); i += 1
+                else:
+                    merged.append(c); j += 1
+            own = merged + carry[i:] + own[j:]
+            # what was carried may itself lie behind this rank's end (a region across a whole shard)
+            cut2 = len(own)
+            while k + 1 < world and cut2 > 0 and own[cut2 - 1]["slice_index"] >= b:
+                cut2 -= 1
+            nxt = sorted(own[cut2:] + nxt, key=lambda f: (key(f), f["mission_id"]))
+            own = own[:cut2]
+        out += own
+        carry = nxt
+    return out + carry
 
 
 def decode_findings(findings_bytes, arena_bytes):

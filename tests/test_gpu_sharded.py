@@ -36,10 +36,9 @@ def _worker(rank, world, port, kind, flags, halo, q):
 
         gathered, _ = sharded.scan_sharded(sc, get_buffer, len(data), file_id=1, halo=halo, device="cpu")
         if rank == 0:
-            got = []
-            for fb, ab in gathered:
-                got += [(f["position"], f["precision"], f["s"], f["completes"], f["mission_id"], f["slice_index"])
-                        for f in sharded.decode_findings(fb, ab)]
+            parts = [sharded.decode_findings(fb, ab) for fb, ab in gathered]
+            got = [(f["position"], f["precision"], f["s"], f["completes"], f["mission_id"], f["slice_index"])
+                   for f in sharded.splice_order(parts, len(data))]
             want = oracle_findings(ms, data)
             q.put(("ok", got == want, len(got), len(want), next(((a, b) for a, b in zip(got, want) if a != b), None)))
     except Exception:  # pragma: no cover

@@ -36,6 +36,10 @@ class RegionOut(C.Structure):
 
 @pytest.fixture(scope="module")
 def core():
+    return load_core()
+
+
+def load_core():
     so = os.path.join(NATIVE, "libreplay_core_host.so")
     src = os.path.join(NATIVE, "replay_core_host.cpp")
     hdr = os.path.join(ROOT, "stringsext_amd", "csrc", "sx_replay_core.hpp")
@@ -153,3 +157,80 @@ def test_device_replay_core_equals_host_replayer(core, flags, parity, skip):
             assert o.end == ends[0] or ends[0] == len(data), (i, r, want, o.end, ends[0])
             checked += 1
     assert checked > 0
+
+
+def make_params(m, data, runs, stream0=0, skip=1):
+    W = 2 * m["output_line_char_nb_max"]
+    long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
+    table = sb_table(m["encoding"]) if m["encoding"] >= 16 else None
+    arr = (sx.Run * max(1, len(runs)))(*[sx.Run(*t) for t in runs])
+    P = ReplayParams(data, len(data), arr, len(runs), 0, len(data), m["counter_offset"] + stream0, stream0, 0,
+                     m["encoding"], table, m["chars_min_nb"], int(m["require_same_unicode_block"]),
+                     m["output_line_char_nb_max"], W, long_run, skip, -1 if m["grep_char"] is None else m["grep_char"],
+                     m["mission_id"], 1, m["af"] & (2**64 - 1), m["af"] >> 64, m["ubf"], None, None, None, 0)
+    P._keep = (arr, table)
+    return P, W, long_run
+
+
+def emulate_device_stage_b(core, m, data, runs, skip=1):
+    """What the device does with one Mission's runs, on the CPU: every head run (sx_replay_dev.hip
+    region_is_chained) replays its region from derived state with the device core, then the sequential
+    stitch rule (a region stands iff it begins at or behind the end of the last standing one).  The first
+    region derives from the stream start, which is the true initial state.  Returns None if a region is
+    given back to the host (too long)."""
+    P, W, _ = make_params(m, data, runs, skip=skip)
+    fbuf = (sx.Finding * 8192)()
+    abuf = (C.c_uint8 * (1 << 21))()
+    out, E = [], 0
+    for i, r in enumerate(runs):
+        want = ws(r[0], W)
+        if i > 0 and (want < runs[i - 1][1] if m["grep_char"] is None else want <= ws(runs[i - 1][1] - 1, W) + W):
+            continue  # chained (sx_replay_core.hpp run_is_chained; the slice-end case of the -g form is covered by the stitch)
+        if want < E:
+            continue  # void: an earlier region ran over its start
+        o = RegionOut()
+        assert core.sxd_replay_region_host(C.byref(P), i, C.byref(o), fbuf, abuf, 8192, 1 << 21) == 0
+        if o.status == 3:
+            return None
+        arena = bytes(abuf[:o.n_bytes])
+        out += [(fbuf[k].position, sx.PRECISION[fbuf[k].precision],
+                 arena[fbuf[k].str_off:fbuf[k].str_off + fbuf[k].str_len].decode("utf-8"),
+                 bool(fbuf[k].completes_previous), fbuf[k].slice_index) for k in range(o.n_find)]
+        E = o.end
+    return out
+
+
+EMU_CONFIGS = CONFIGS + [
+    dict(encodings=["ascii"], chars_min="1", ascii_filter="All-Ctrl+Wsp", unicode_block_filter="Common", grep_char="32",
+         counter_offset="1000"),  # -g: a q-long stretch without the grep char ends the call's iteration (found by tools/gpu_fuzz.py)
+    dict(encodings=["utf-8"], chars_min="1", output_line_len="8", grep_char="101"),
+    dict(encodings=["ascii"], chars_min="4"),
+    dict(encodings=["ascii"], chars_min="2", output_line_len="6", grep_char="32"),
+    dict(encodings=["utf-8"], chars_min="1", output_line_len="8", unicode_block_filter="All"),
+    dict(encodings=["utf-16le"], chars_min="1", unicode_block_filter="African", grep_char="0x65"),
+]
+
+
+@pytest.mark.parametrize("flags", EMU_CONFIGS, ids=lambda f: "-".join(f["encodings"]) + "-n" + f["chars_min"])
+def test_device_pipeline_emulated_on_cpu_equals_the_oracle(core, flags):
+    """Heads, derived entry states, region ends and the stitch together must give exactly the oracle's
+    findings — this is where the premises of the region rules are checked (a region may end at a window
+    start where nothing is pending although a run begins there: the next region derives that very state)."""
+    from test_sharded_gloo import oracle_findings
+    from test_gpu_parity import dense
+    rng = random.Random(zlib.crc32(repr(sorted(flags.items())).encode()) & 0xFFFF)
+    m = rc.missions(**flags)[0]
+    if m["output_line_char_nb_max"] > 64:
+        pytest.skip("device replay covers q <= 64")
+    long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
+    done = 0
+    for data in (synth(rng, 40_000, 1 / 150), soup(rng, 20_001), synth(rng, 30_000, 1 / 40), tricky(rng, 30_000),
+                 dense(rng, 30_000, 20, "abcdefgh XYZ019_-éжЖдяבשλ€😀"), bytes(rng.randrange(256) for _ in range(30_000))):
+        runs = sxo.runs(m, data, stream_parity=0, min_chars=long_run)
+        got = emulate_device_stage_b(core, m, data, runs)
+        if got is None:
+            continue
+        want = [(p, pr, s, c, si) for p, pr, s, c, _, si in oracle_findings([m], data)]
+        assert got == want, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want)))
+        done += 1
+    assert done > 0

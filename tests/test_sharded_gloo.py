@@ -64,15 +64,13 @@ def _worker(rank, world, port, kind, flags, halo, q, gather=True):
         if not gather:  # the findings stay distributed: rank k holds segment k; `gathered` = counts per rank
             assert gathered[rank] == len(res) and len(gathered) == world
             parts = [None] * world
-            dist.gather_object([key(f) for f in res.findings()], parts if rank == 0 else None, dst=0)
+            dist.gather_object(res.findings(), parts if rank == 0 else None, dst=0)
         if rank == 0:
-            got = []
             if gather:
-                for fb, ab in gathered:
-                    got += [key(f) for f in sharded.decode_findings(fb, ab)]
+                parts = [sharded.decode_findings(fb, ab) for fb, ab in gathered]
             else:
-                for part in parts:
-                    got += part
+                assert [sum(1 for f in p_[-o:] if o) for p_, o in zip(parts, gathered.overflow)] == gathered.overflow
+            got = [key(f) for f in sharded.splice_order(parts, len(data))]
             want = oracle_findings(ms, data)
             q.put(("ok", got == want, len(got), len(want),
                    next(((a, b) for a, b in zip(got, want) if a != b), None)))
