@@ -86,6 +86,7 @@ struct ReplayParams {
     const uint32_t* n_heads;
     uint8_t* cache_arena;
     uint64_t arena_bytes;
+    const uint32_t* head_list;   // head_list[slot] = run index: the replay kernels take one lane per REPLAYING run
 };
 struct ReplayRegionOut {
     uint64_t end;             // where the region's replay stopped (a window start, buffer relative)
@@ -93,7 +94,8 @@ struct ReplayRegionOut {
 };
 // Fills slot_of / n_heads (device arrays of n_runs + 1 u32) for the cache: which runs replay at all.
 size_t replay_heads_scratch_bytes(uint64_t n_runs);
-hipError_t launch_replay_heads(const ReplayParams& P, uint32_t* slot_of, uint32_t* n_heads, void* scratch, size_t scratch_bytes,
+hipError_t launch_replay_heads(const ReplayParams& P, uint32_t* slot_of, uint32_t* n_heads, uint32_t* head_list, ReplayRegionOut* ro,
+                               void* scratch, size_t scratch_bytes,
                                hipStream_t stream);
 hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, hipStream_t stream);
 hipError_t launch_replay_write(const ReplayParams& P, const uint64_t* region_index, const uint64_t* fbase,

@@ -366,6 +366,19 @@ SXD_NOINLINE u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& d
 }
 
 constexpr u32 kObCap = 4 * 64 + 3 * 128 + 16;  // leftover (<= 4q bytes) + one window's output; q <= 64
+constexpr u32 kMaxWindow = 128;                 // W = 2q
+
+// Copy of one window into private memory: 16 bytes per load where the source is aligned (it is, in the
+// default geometry: buffers are 256-byte aligned and W = 128), bytes otherwise.
+SXD void stage_window(const u8* src, u32 n, u8* win) {
+    u32 k = 0;
+    if (((uintptr_t)src & 15) == 0) {
+        for (; k + 16 <= n; k += 16) *(uint4*)(win + k) = *(const uint4*)(src + k);
+    } else if (((uintptr_t)src & 3) == 0) {
+        for (; k + 4 <= n; k += 4) *(u32*)(win + k) = *(const u32*)(src + k);
+    }
+    for (; k < n; k++) win[k] = src[k];
+}
 
 // One region.  MODE 0: count only; 1: write findings and strings at fout/aout; 2: count, and
 // keep the output in the region's small cache slot (fout/aout) as long as it fits — o.pad says
@@ -395,6 +408,8 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
     const u32 W = P.W;
     const u64 want = win_start(P.runs[i].start, W);
     u8 ob[kObCap];
+    alignas(16) u8 win[kMaxWindow];
+    u64 staged = ~0ull;
     DDecoder dec;
 
     // ---- derive the state the reference would carry into `want` (RangeReplay::derive_state)
@@ -440,6 +455,7 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
             u32 dend;
             if (din + W < slen) dend = din + W; else { is_last_window = true; dend = slen; }
             if (++windows > kMaxRegionWindows) { status = kRegionTooLong; done = true; break; }
+            const u32 wb = din;  // window start (din moves on inside the window)
             u32 dout = leftover_len;
             for (;;) {  // 'decoder
                 if (P.skip && leftover_len == 0 && !maybe_cut && din < dend && ddec_idle<ENC>(dec)) {
@@ -465,7 +481,13 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
                         if (vs > p) din = (u32)(vs - soff);
                     }
                 }
-                const DStep r = ddecode<ENC>(dec, bytes + soff + din, dend - din, ob + dout, kObCap - dout, false);
+                // the window's bytes go through a private copy made with 16-byte loads: the decoders read byte
+                // by byte, and a byte load per lane from 64 different cache lines is the slowest way to read
+                if (staged != soff + wb) {
+                    stage_window(bytes + soff + wb, dend - wb, win);
+                    staged = soff + wb;
+                }
+                const DStep r = ddecode<ENC>(dec, win + (din - wb), dend - din, ob + dout, kObCap - dout, false);
                 if (r.result == RES_OUTPUT_FULL) { status = kRegionTooLong; done = true; break; }
                 u8 precision = SX_PRECISION_EXACT;
                 if (r.written > 0 && din == 0 && (ob[dout] & 0x80)) {  // slice-start probe, :176-207

@@ -45,25 +45,38 @@ namespace sx {
 // (With -g the next window still belongs to the region: sx_replay_core.hpp regions_may_touch.)
 SXD bool region_is_chained(const ReplayParams& P, u64 i, u64 want) { return run_is_chained(P, i, want); }
 // which runs replay at all (for the cache slots): neither somebody else's nor chained
-__global__ __launch_bounds__(256) void replay_heads_kernel(const ReplayParams P, u32* head) {
+// (the runs that do not replay get their pass-1 record here: the count kernel only visits the others)
+__global__ __launch_bounds__(256) void replay_heads_kernel(const ReplayParams P, u32* head, ReplayRegionOut* ro) {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i >= P.n_runs) return;
     const u64 want = win_start(P.runs[i].start, P.W);
-    head[i] = (want < P.lo || want >= P.hi || region_is_chained(P, i, want)) ? 0u : 1u;
+    const bool not_mine = want < P.lo || want >= P.hi;
+    const bool h = !not_mine && !region_is_chained(P, i, want);
+    head[i] = h ? 1u : 0u;
+    if (!h) {
+        ReplayRegionOut o;
+        o.end = 0; o.n_find = 0; o.n_bytes = 0; o.status = not_mine ? kRegionNotMine : kRegionChained; o.pad = 0;
+        ro[i] = o;
+    }
+}
+__global__ __launch_bounds__(256) void replay_heads_list_kernel(const ReplayParams P, const u32* head, const u32* slot_of, u32* head_list) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < P.n_runs && head[i]) head_list[slot_of[i]] = (u32)i;
 }
 __global__ void replay_heads_total_kernel(const u32* head_last, const u32* slot_last, u32* n_heads) { *n_heads = *slot_last + *head_last; }
 
 template <int ENC, bool CACHED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WAVES))) void replay_count_kernel(
     const ReplayParams P, ReplayRegionOut* out) {
-    const u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
-    if (i >= P.n_runs) return;
+    u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
+    if (CACHED) {  // one lane per replaying run (on dense input half of the runs are chained: no idle lanes)
+        if (i >= *P.n_heads) return;
+        i = P.head_list[i];
+    } else if (i >= P.n_runs) return;
     ReplayRegionOut o;
     o.end = 0; o.n_find = 0; o.n_bytes = 0; o.status = kRegionOk; o.pad = 0;
     const u64 want = win_start(P.runs[i].start, P.W);
-    if (want < P.lo || want >= P.hi) o.status = kRegionNotMine;
-    else if (region_is_chained(P, i, want)) o.status = kRegionChained;
-    else if (CACHED) {
+    if (CACHED) {
         // slots have a minimum size: with more replaying regions than the arena has room for, the ones
         // behind its end go without (cap 0: nothing fits, o.pad stays 0, pass 2 replays them)
         const CacheGeom g = cache_geom(P.arena_bytes, *P.n_heads);
@@ -71,7 +84,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WA
         const bool room = off + g.slot_bytes <= P.arena_bytes;
         u8* slot = P.cache_arena + (room ? off : 0);
         replay_region<2, ENC>(P, i, o, (sx_finding*)slot, slot + g.cap_f * sizeof(sx_finding), 0, room ? g.cap_f : 0u, room ? g.cap_b : 0u);
-    } else replay_region<0, ENC>(P, i, o, nullptr, nullptr, 0);
+    } else if (want < P.lo || want >= P.hi) o.status = kRegionNotMine;
+    else if (region_is_chained(P, i, want)) o.status = kRegionChained;
+    else replay_region<0, ENC>(P, i, o, nullptr, nullptr, 0);
     out[i] = o;
 }
 
@@ -91,8 +106,12 @@ template <int ENC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WAVES))) void replay_write_flagged_kernel(
     const ReplayParams P, const ReplayRegionOut* ro, const u8* stands, const u64* fpos, const u64* apos, sx_finding* findings,
     u8* arena) {
-    const u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
-    if (i >= P.n_runs || !stands[i]) return;
+    u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
+    if (P.head_list) {  // only a replaying run can stand
+        if (i >= *P.n_heads) return;
+        i = P.head_list[i];
+    } else if (i >= P.n_runs) return;
+    if (!stands[i]) return;
     const u64 fp = fpos[i], ap = apos[i];
     if (P.cache_arena && ro[i].pad) {  // pass 1 kept the region's output: copy it into place
         const CacheGeom g = cache_geom(P.arena_bytes, *P.n_heads);
@@ -157,9 +176,14 @@ __global__ __launch_bounds__(64) void stitch_chain_kernel(const ReplayParams P, 
                                                           const StitchBlock* blocks, u64 n_blocks, u64 E0, u64* totals) {
     const u32 lane = threadIdx.x;
     u64 E = E0, last = ~0ull;  // wave-uniform
+    StitchBlock next; next.first_want = ~0ull; next.end = 0; next.last = ~0ull;
+    if (lane < n_blocks) next = blocks[lane];
     for (u64 base = 0; base < n_blocks; base += 64) {
-        StitchBlock mine; mine.first_want = ~0ull; mine.end = 0; mine.last = ~0ull;
-        if (base + lane < n_blocks) mine = blocks[base + lane];
+        const StitchBlock mine = next;
+        // the summaries of the next 64 blocks are on their way while these are chained (the loop is a
+        // chain of dependent steps: without this every step waits for a DRAM round trip)
+        next.first_want = ~0ull; next.end = 0; next.last = ~0ull;
+        if (base + 64 + lane < n_blocks) next = blocks[base + 64 + lane];
         const bool has = mine.first_want != ~0ull;
         u32 cur = 0;  // lanes below cur are settled
         while (cur < 64) {
@@ -290,16 +314,17 @@ size_t replay_heads_scratch_bytes(uint64_t n_runs) {
     (void)rocprim::exclusive_scan(nullptr, a, (u32*)nullptr, (u32*)nullptr, 0u, (size_t)n_runs, rocprim::plus<u32>(), (hipStream_t)0);
     return n_runs * 4 + a + 1024;
 }
-hipError_t launch_replay_heads(const ReplayParams& P, uint32_t* slot_of, uint32_t* n_heads, void* scratch, size_t scratch_bytes,
-                               hipStream_t stream) {
+hipError_t launch_replay_heads(const ReplayParams& P, uint32_t* slot_of, uint32_t* n_heads, uint32_t* head_list, ReplayRegionOut* ro,
+                               void* scratch, size_t scratch_bytes, hipStream_t stream) {
     if (P.n_runs == 0) return hipMemsetAsync(n_heads, 0, 4, stream);
     if (scratch_bytes < replay_heads_scratch_bytes(P.n_runs)) return hipErrorInvalidValue;
     u32* head = (u32*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
     void* tmp = (void*)(((uintptr_t)(head + P.n_runs) + 255) & ~(uintptr_t)255);
     size_t tmp_bytes = scratch_bytes - (size_t)((u8*)tmp - (u8*)scratch);
-    hipLaunchKernelGGL(replay_heads_kernel, dim3((unsigned)((P.n_runs + 255) / 256)), dim3(256), 0, stream, P, head);
+    hipLaunchKernelGGL(replay_heads_kernel, dim3((unsigned)((P.n_runs + 255) / 256)), dim3(256), 0, stream, P, head, ro);
     hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, head, slot_of, 0u, (size_t)P.n_runs, rocprim::plus<u32>(), stream);
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(replay_heads_list_kernel, dim3((unsigned)((P.n_runs + 255) / 256)), dim3(256), 0, stream, P, head, slot_of, head_list);
     hipLaunchKernelGGL(replay_heads_total_kernel, dim3(1), dim3(1), 0, stream, head + (P.n_runs - 1), slot_of + (P.n_runs - 1), n_heads);
     return hipGetLastError();
 }

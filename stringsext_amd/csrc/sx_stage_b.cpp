@@ -65,13 +65,14 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
             uint64_t budget = 8192ull << 20;   // of 288 GB; the arena is at most 1 KiB per run
             if (const char* e = getenv("SX_REPLAY_CACHE_MIB")) budget = (uint64_t)atoll(e) << 20;
             const uint64_t arena = std::max<uint64_t>(4096, std::min<uint64_t>(budget, (uint64_t)n * 1024));
-            rc = ensure_rp(ctx, d, 8, arena + (uint64_t)(n + 2) * 4 + 512); if (rc) return rc;
+            rc = ensure_rp(ctx, d, 8, arena + (uint64_t)(2 * n + 4) * 4 + 512); if (rc) return rc;
             rc = ensure_scratch(ctx, std::max(stitch_scratch_bytes(n), replay_heads_scratch_bytes(n))); if (rc) return rc;
             uint8_t* base = (uint8_t*)d.d_rp[8];
             P.cache_arena = base; P.arena_bytes = arena & ~255ull;
             uint32_t* slot_of = (uint32_t*)(base + ((arena + 255) & ~255ull));
-            P.slot_of = slot_of; P.n_heads = slot_of + n + 1;
-            HIP_TRY(ctx, launch_replay_heads(P, slot_of, slot_of + n + 1, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
+            P.slot_of = slot_of; P.n_heads = slot_of + n + 1; P.head_list = slot_of + n + 2;
+            HIP_TRY(ctx, launch_replay_heads(P, slot_of, slot_of + n + 1, slot_of + n + 2, (ReplayRegionOut*)d.d_rp[1], ctx->d_scratch,
+                                             ctx->d_scratch_cap, d.stream_b));
         }
         HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], d.stream_b));
         if (dev_stitch) {
