@@ -50,7 +50,15 @@ enum {
 enum {
     SX_ENC_X_USER_DEFINED = 0, SX_ENC_UTF8 = 1, SX_ENC_UTF16LE = 2, SX_ENC_UTF16BE = 3,
     SX_ENC_KOI8_R = 16, SX_ENC_IBM866 = 17, SX_ENC_ISO_8859_2 = 18, SX_ENC_ISO_8859_5 = 19,
-    SX_ENC_ISO_8859_15 = 20, SX_ENC_WINDOWS_1251 = 21, SX_ENC_WINDOWS_1252 = 22
+    SX_ENC_ISO_8859_15 = 20, SX_ENC_WINDOWS_1251 = 21, SX_ENC_WINDOWS_1252 = 22,
+    /* the rest of the WHATWG single-byte set (tables: csrc/gen_tables.py; parity unpinned) */
+    SX_ENC_ISO_8859_3 = 23, SX_ENC_ISO_8859_4 = 24, SX_ENC_ISO_8859_6 = 25, SX_ENC_ISO_8859_7 = 26,
+    SX_ENC_ISO_8859_8 = 27, SX_ENC_ISO_8859_8_I = 28, SX_ENC_ISO_8859_10 = 29,
+    SX_ENC_ISO_8859_13 = 30, SX_ENC_ISO_8859_14 = 31, SX_ENC_ISO_8859_16 = 32, SX_ENC_KOI8_U = 33,
+    SX_ENC_MACINTOSH = 34, SX_ENC_WINDOWS_874 = 35, SX_ENC_WINDOWS_1250 = 36,
+    SX_ENC_WINDOWS_1253 = 37, SX_ENC_WINDOWS_1254 = 38, SX_ENC_WINDOWS_1255 = 39,
+    SX_ENC_WINDOWS_1256 = 40, SX_ENC_WINDOWS_1257 = 41, SX_ENC_WINDOWS_1258 = 42,
+    SX_ENC_X_MAC_CYRILLIC = 43
 };
 
 /* `Precision` — src/finding.rs:34-46 */

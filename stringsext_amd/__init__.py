@@ -17,7 +17,12 @@ SX_OK, SX_E_INVALID, SX_E_NO_DEVICE, SX_E_HIP, SX_E_NOMEM, SX_E_STATE = 0, -1, -
 SX_HOST_ONLY = -1
 SX_OPT_GENERIC_KERNELS, SX_OPT_DEVICE_REPLAY, SX_OPT_HOST_REPLAY = 1, 2, 4
 ENC = {"x-user-defined": 0, "utf-8": 1, "utf-16le": 2, "utf-16be": 3, "koi8-r": 16, "ibm866": 17,
-       "iso-8859-2": 18, "iso-8859-5": 19, "iso-8859-15": 20, "windows-1251": 21, "windows-1252": 22}
+       "iso-8859-2": 18, "iso-8859-5": 19, "iso-8859-15": 20, "windows-1251": 21, "windows-1252": 22,
+       "iso-8859-3": 23, "iso-8859-4": 24, "iso-8859-6": 25, "iso-8859-7": 26, "iso-8859-8": 27,
+       "iso-8859-8-i": 28, "iso-8859-10": 29, "iso-8859-13": 30, "iso-8859-14": 31, "iso-8859-16": 32,
+       "koi8-u": 33, "macintosh": 34, "windows-874": 35, "windows-1250": 36, "windows-1253": 37,
+       "windows-1254": 38, "windows-1255": 39, "windows-1256": 40, "windows-1257": 41, "windows-1258": 42,
+       "x-mac-cyrillic": 43}
 PRECISION = {0: "Before", 1: "Exact", 2: "After"}
 
 # every symbol include/stringsext_amd.h declares
@@ -94,6 +99,21 @@ def missions_from_flags(encodings=(), chars_min=None, same_unicode_block=False, 
     if rc != SX_OK:
         raise SxError(rc, err.value.decode())
     return [out[i].to_dict() for i in range(n.value)]
+
+
+def encoding_name(enc):
+    """Encoding::name() of an SX_ENC_* id (None if unknown)."""
+    L = lib()
+    L.sx_encoding_name.argtypes, L.sx_encoding_name.restype = [C.c_uint32], C.c_char_p
+    s = L.sx_encoding_name(enc)
+    return s.decode() if s else None
+
+
+def encoding_for_label(label):
+    """Encoding::for_label: SX_ENC_* id; -1 not a label; -2 a label of an encoding that is not built in."""
+    L = lib()
+    L.sx_encoding_for_label.argtypes, L.sx_encoding_for_label.restype = [C.c_char_p], C.c_int
+    return L.sx_encoding_for_label(label.encode())
 
 
 def parse_enc_opt(text):

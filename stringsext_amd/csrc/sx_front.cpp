@@ -176,19 +176,56 @@ const Label kLabels[] = {
     { "iso88591", SX_ENC_WINDOWS_1252 }, { "iso_8859-1", SX_ENC_WINDOWS_1252 }, { "iso_8859-1:1987", SX_ENC_WINDOWS_1252 },
     { "l1", SX_ENC_WINDOWS_1252 }, { "latin1", SX_ENC_WINDOWS_1252 }, { "us-ascii", SX_ENC_WINDOWS_1252 },
     { "windows-1252", SX_ENC_WINDOWS_1252 }, { "x-cp1252", SX_ENC_WINDOWS_1252 },
+    { "csisolatin3", SX_ENC_ISO_8859_3 }, { "iso-8859-3", SX_ENC_ISO_8859_3 }, { "iso-ir-109", SX_ENC_ISO_8859_3 },
+    { "iso8859-3", SX_ENC_ISO_8859_3 }, { "iso88593", SX_ENC_ISO_8859_3 }, { "iso_8859-3", SX_ENC_ISO_8859_3 },
+    { "iso_8859-3:1988", SX_ENC_ISO_8859_3 }, { "l3", SX_ENC_ISO_8859_3 }, { "latin3", SX_ENC_ISO_8859_3 },
+    { "csisolatin4", SX_ENC_ISO_8859_4 }, { "iso-8859-4", SX_ENC_ISO_8859_4 }, { "iso-ir-110", SX_ENC_ISO_8859_4 },
+    { "iso8859-4", SX_ENC_ISO_8859_4 }, { "iso88594", SX_ENC_ISO_8859_4 }, { "iso_8859-4", SX_ENC_ISO_8859_4 },
+    { "iso_8859-4:1988", SX_ENC_ISO_8859_4 }, { "l4", SX_ENC_ISO_8859_4 }, { "latin4", SX_ENC_ISO_8859_4 },
+    { "arabic", SX_ENC_ISO_8859_6 }, { "asmo-708", SX_ENC_ISO_8859_6 }, { "csiso88596e", SX_ENC_ISO_8859_6 },
+    { "csiso88596i", SX_ENC_ISO_8859_6 }, { "csisolatinarabic", SX_ENC_ISO_8859_6 }, { "ecma-114", SX_ENC_ISO_8859_6 },
+    { "iso-8859-6", SX_ENC_ISO_8859_6 }, { "iso-8859-6-e", SX_ENC_ISO_8859_6 }, { "iso-8859-6-i", SX_ENC_ISO_8859_6 },
+    { "iso-ir-127", SX_ENC_ISO_8859_6 }, { "iso8859-6", SX_ENC_ISO_8859_6 }, { "iso88596", SX_ENC_ISO_8859_6 },
+    { "iso_8859-6", SX_ENC_ISO_8859_6 }, { "iso_8859-6:1987", SX_ENC_ISO_8859_6 },
+    { "csisolatingreek", SX_ENC_ISO_8859_7 }, { "ecma-118", SX_ENC_ISO_8859_7 }, { "elot_928", SX_ENC_ISO_8859_7 },
+    { "greek", SX_ENC_ISO_8859_7 }, { "greek8", SX_ENC_ISO_8859_7 }, { "iso-8859-7", SX_ENC_ISO_8859_7 },
+    { "iso-ir-126", SX_ENC_ISO_8859_7 }, { "iso8859-7", SX_ENC_ISO_8859_7 }, { "iso88597", SX_ENC_ISO_8859_7 },
+    { "iso_8859-7", SX_ENC_ISO_8859_7 }, { "iso_8859-7:1987", SX_ENC_ISO_8859_7 }, { "sun_eu_greek", SX_ENC_ISO_8859_7 },
+    { "csiso88598e", SX_ENC_ISO_8859_8 }, { "csisolatinhebrew", SX_ENC_ISO_8859_8 }, { "hebrew", SX_ENC_ISO_8859_8 },
+    { "iso-8859-8", SX_ENC_ISO_8859_8 }, { "iso-8859-8-e", SX_ENC_ISO_8859_8 }, { "iso-ir-138", SX_ENC_ISO_8859_8 },
+    { "iso8859-8", SX_ENC_ISO_8859_8 }, { "iso88598", SX_ENC_ISO_8859_8 }, { "iso_8859-8", SX_ENC_ISO_8859_8 },
+    { "iso_8859-8:1988", SX_ENC_ISO_8859_8 }, { "visual", SX_ENC_ISO_8859_8 },
+    { "csiso88598i", SX_ENC_ISO_8859_8_I }, { "iso-8859-8-i", SX_ENC_ISO_8859_8_I }, { "logical", SX_ENC_ISO_8859_8_I },
+    { "csisolatin6", SX_ENC_ISO_8859_10 }, { "iso-8859-10", SX_ENC_ISO_8859_10 }, { "iso-ir-157", SX_ENC_ISO_8859_10 },
+    { "iso8859-10", SX_ENC_ISO_8859_10 }, { "iso885910", SX_ENC_ISO_8859_10 }, { "l6", SX_ENC_ISO_8859_10 },
+    { "latin6", SX_ENC_ISO_8859_10 },
+    { "iso-8859-13", SX_ENC_ISO_8859_13 }, { "iso8859-13", SX_ENC_ISO_8859_13 }, { "iso885913", SX_ENC_ISO_8859_13 },
+    { "iso-8859-14", SX_ENC_ISO_8859_14 }, { "iso8859-14", SX_ENC_ISO_8859_14 }, { "iso885914", SX_ENC_ISO_8859_14 },
+    { "iso-8859-16", SX_ENC_ISO_8859_16 },
+    { "koi8-ru", SX_ENC_KOI8_U }, { "koi8-u", SX_ENC_KOI8_U },
+    { "csmacintosh", SX_ENC_MACINTOSH }, { "mac", SX_ENC_MACINTOSH }, { "macintosh", SX_ENC_MACINTOSH },
+    { "x-mac-roman", SX_ENC_MACINTOSH },
+    { "dos-874", SX_ENC_WINDOWS_874 }, { "iso-8859-11", SX_ENC_WINDOWS_874 }, { "iso8859-11", SX_ENC_WINDOWS_874 },
+    { "iso885911", SX_ENC_WINDOWS_874 }, { "tis-620", SX_ENC_WINDOWS_874 }, { "windows-874", SX_ENC_WINDOWS_874 },
+    { "cp1250", SX_ENC_WINDOWS_1250 }, { "windows-1250", SX_ENC_WINDOWS_1250 }, { "x-cp1250", SX_ENC_WINDOWS_1250 },
+    { "cp1253", SX_ENC_WINDOWS_1253 }, { "windows-1253", SX_ENC_WINDOWS_1253 }, { "x-cp1253", SX_ENC_WINDOWS_1253 },
+    { "cp1254", SX_ENC_WINDOWS_1254 }, { "csisolatin5", SX_ENC_WINDOWS_1254 }, { "iso-8859-9", SX_ENC_WINDOWS_1254 },
+    { "iso-ir-148", SX_ENC_WINDOWS_1254 }, { "iso8859-9", SX_ENC_WINDOWS_1254 }, { "iso88599", SX_ENC_WINDOWS_1254 },
+    { "iso_8859-9", SX_ENC_WINDOWS_1254 }, { "iso_8859-9:1989", SX_ENC_WINDOWS_1254 }, { "l5", SX_ENC_WINDOWS_1254 },
+    { "latin5", SX_ENC_WINDOWS_1254 }, { "windows-1254", SX_ENC_WINDOWS_1254 }, { "x-cp1254", SX_ENC_WINDOWS_1254 },
+    { "cp1255", SX_ENC_WINDOWS_1255 }, { "windows-1255", SX_ENC_WINDOWS_1255 }, { "x-cp1255", SX_ENC_WINDOWS_1255 },
+    { "cp1256", SX_ENC_WINDOWS_1256 }, { "windows-1256", SX_ENC_WINDOWS_1256 }, { "x-cp1256", SX_ENC_WINDOWS_1256 },
+    { "cp1257", SX_ENC_WINDOWS_1257 }, { "windows-1257", SX_ENC_WINDOWS_1257 }, { "x-cp1257", SX_ENC_WINDOWS_1257 },
+    { "cp1258", SX_ENC_WINDOWS_1258 }, { "windows-1258", SX_ENC_WINDOWS_1258 }, { "x-cp1258", SX_ENC_WINDOWS_1258 },
+    { "x-mac-cyrillic", SX_ENC_X_MAC_CYRILLIC }, { "x-mac-ukrainian", SX_ENC_X_MAC_CYRILLIC },
 };
 // labels of the encodings encoding_rs has and this library does not (help.rs:54-96 lists their names)
 const char* const kOtherLabels[] = {
-    "big5", "big5-hkscs", "cn-big5", "csbig5", "x-x-big5", "euc-jp", "cseucpkdfmtjapanese", "x-euc-jp", "shift_jis", "sjis", "ms_kanji",
-    "shift-jis", "windows-31j", "x-sjis", "csshiftjis", "ms932", "iso-2022-jp", "csiso2022jp", "euc-kr", "cseuckr", "korean", "windows-949",
-    "ks_c_5601-1987", "ksc5601", "ksc_5601", "iso-ir-149", "ks_c_5601-1989", "csksc56011987", "gbk", "gb2312", "chinese", "csgb2312",
-    "csiso58gb231280", "gb_2312", "gb_2312-80", "iso-ir-58", "x-gbk", "gb18030", "koi8-u", "koi8-ru", "macintosh", "mac", "csmacintosh",
-    "x-mac-roman", "x-mac-cyrillic", "x-mac-ukrainian", "windows-874", "dos-874", "iso-8859-11", "iso8859-11", "iso885911", "tis-620",
-    "windows-1250", "cp1250", "x-cp1250", "windows-1253", "cp1253", "x-cp1253", "windows-1254", "cp1254", "x-cp1254", "iso-8859-9",
-    "latin5", "l5", "windows-1255", "cp1255", "x-cp1255", "windows-1256", "cp1256", "x-cp1256", "windows-1257", "cp1257", "x-cp1257",
-    "windows-1258", "cp1258", "x-cp1258", "iso-8859-3", "latin3", "l3", "iso-8859-4", "latin4", "l4", "iso-8859-6", "arabic", "iso-8859-7",
-    "greek", "greek8", "iso-8859-8", "hebrew", "visual", "iso-8859-8-i", "logical", "iso-8859-10", "latin6", "l6", "iso-8859-13",
-    "iso-8859-14", "iso-8859-16", "replacement", "hz-gb-2312", "iso-2022-kr", "iso-2022-cn", "iso-2022-cn-ext",
+    "big5", "big5-hkscs", "cn-big5", "csbig5", "x-x-big5", "euc-jp", "cseucpkdfmtjapanese", "x-euc-jp", "shift_jis", "sjis",
+    "ms_kanji", "shift-jis", "windows-31j", "x-sjis", "csshiftjis", "ms932", "iso-2022-jp", "csiso2022jp", "euc-kr", "cseuckr",
+    "korean", "windows-949", "ks_c_5601-1987", "ksc5601", "ksc_5601", "iso-ir-149", "ks_c_5601-1989", "csksc56011987", "gbk",
+    "gb2312", "chinese", "csgb2312", "csiso58gb231280", "gb_2312", "gb_2312-80", "iso-ir-58", "x-gbk", "gb18030", "replacement",
+    "hz-gb-2312", "iso-2022-kr", "iso-2022-cn", "iso-2022-cn-ext",
 };
 int for_label(const std::string& raw) {
     size_t a = 0, b = raw.size();
@@ -223,6 +260,27 @@ const char* sx_encoding_name(uint32_t encoding) {  // Encoding::name()
         case SX_ENC_ISO_8859_15: return "ISO-8859-15";
         case SX_ENC_WINDOWS_1251: return "windows-1251";
         case SX_ENC_WINDOWS_1252: return "windows-1252";
+        case SX_ENC_ISO_8859_3: return "ISO-8859-3";
+        case SX_ENC_ISO_8859_4: return "ISO-8859-4";
+        case SX_ENC_ISO_8859_6: return "ISO-8859-6";
+        case SX_ENC_ISO_8859_7: return "ISO-8859-7";
+        case SX_ENC_ISO_8859_8: return "ISO-8859-8";
+        case SX_ENC_ISO_8859_8_I: return "ISO-8859-8-I";
+        case SX_ENC_ISO_8859_10: return "ISO-8859-10";
+        case SX_ENC_ISO_8859_13: return "ISO-8859-13";
+        case SX_ENC_ISO_8859_14: return "ISO-8859-14";
+        case SX_ENC_ISO_8859_16: return "ISO-8859-16";
+        case SX_ENC_KOI8_U: return "KOI8-U";
+        case SX_ENC_MACINTOSH: return "macintosh";
+        case SX_ENC_WINDOWS_874: return "windows-874";
+        case SX_ENC_WINDOWS_1250: return "windows-1250";
+        case SX_ENC_WINDOWS_1253: return "windows-1253";
+        case SX_ENC_WINDOWS_1254: return "windows-1254";
+        case SX_ENC_WINDOWS_1255: return "windows-1255";
+        case SX_ENC_WINDOWS_1256: return "windows-1256";
+        case SX_ENC_WINDOWS_1257: return "windows-1257";
+        case SX_ENC_WINDOWS_1258: return "windows-1258";
+        case SX_ENC_X_MAC_CYRILLIC: return "x-mac-cyrillic";
         default: return nullptr;
     }
 }

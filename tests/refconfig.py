@@ -49,7 +49,12 @@ AF_ALIASES = [
 ]
 
 ENC_IDS = {"x-user-defined": 0, "utf-8": 1, "utf-16le": 2, "utf-16be": 3, "koi8-r": 16, "ibm866": 17,
-           "iso-8859-2": 18, "iso-8859-5": 19, "iso-8859-15": 20, "windows-1251": 21, "windows-1252": 22}
+           "iso-8859-2": 18, "iso-8859-5": 19, "iso-8859-15": 20, "windows-1251": 21, "windows-1252": 22,
+           "iso-8859-3": 23, "iso-8859-4": 24, "iso-8859-6": 25, "iso-8859-7": 26, "iso-8859-8": 27,
+           "iso-8859-8-i": 28, "iso-8859-10": 29, "iso-8859-13": 30, "iso-8859-14": 31, "iso-8859-16": 32,
+           "koi8-u": 33, "macintosh": 34, "windows-874": 35, "windows-1250": 36, "windows-1253": 37,
+           "windows-1254": 38, "windows-1255": 39, "windows-1256": 40, "windows-1257": 41, "windows-1258": 42,
+           "x-mac-cyrillic": 43}
 
 
 def _parse_int(s):

@@ -1,6 +1,7 @@
 """The Mission front end behind the C-ABI (sx_missions_from_flags, sx_parse_enc_opt — SURVEY §8 f-2)
 against the reference's own unit-test vectors (src/mission.rs:776-868, transcribed as data) and
 against the Python restatement the other tests use (tests/refconfig.py).  No GPU needed."""
+import os
 import random
 
 import pytest
@@ -8,6 +9,7 @@ import pytest
 import refconfig as rc
 import stringsext_amd as sx
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 AF_DEFAULT, UBF_LATIN_ACC = rc.AF_DEFAULT, rc.UBF_LATIN | rc.UBF_ACCENTS
 
 # src/mission.rs test_enc_opt_parser: (input, expected tuple) and the inputs that must fail
@@ -56,6 +58,15 @@ def test_alias_prefix_quirks_and_labels():
     for label, enc in [("UTF8", 1), (" utf-16 ", 2), ("unicodeFFFE", 3), ("latin1", 22), ("KOI8_R", 16), ("866", 17), ("cyrillic", 19),
                        ("l9", 20), ("x-user-defined", 0), ("windows-1251", 21), ("latin2", 18)]:
         assert sx.missions_from_flags(encodings=[label])[0]["encoding"] == enc, label
+    # the rest of the WHATWG single-byte set, by some of their labels
+    for label, name in [("latin3", "ISO-8859-3"), ("l4", "ISO-8859-4"), ("arabic", "ISO-8859-6"), ("ELOT_928", "ISO-8859-7"),
+                        ("visual", "ISO-8859-8"), ("logical", "ISO-8859-8-I"), ("latin6", "ISO-8859-10"), ("iso885913", "ISO-8859-13"),
+                        ("iso8859-14", "ISO-8859-14"), ("iso-8859-16", "ISO-8859-16"), ("koi8-ru", "KOI8-U"), ("mac", "macintosh"),
+                        ("tis-620", "windows-874"), ("iso-8859-11", "windows-874"), ("cp1250", "windows-1250"), ("x-cp1253", "windows-1253"),
+                        ("latin5", "windows-1254"), ("iso-8859-9", "windows-1254"), ("cp1255", "windows-1255"), ("windows-1256", "windows-1256"),
+                        ("cp1257", "windows-1257"), ("x-cp1258", "windows-1258"), ("x-mac-ukrainian", "x-mac-cyrillic")]:
+        enc = sx.missions_from_flags(encodings=[label])[0]["encoding"]
+        assert sx.encoding_name(enc) == name and rc.ENC_IDS[name.lower()] == enc, label
     with pytest.raises(sx.SxError, match="invalid input encoding name"):
         sx.missions_from_flags(encodings=["utf-9"])
     with pytest.raises(sx.SxError, match="not built into this library"):
@@ -71,7 +82,7 @@ def test_alias_prefix_quirks_and_labels():
 def test_random_flag_sets_agree_with_the_python_restatement():
     rng = random.Random(99)
     encs = ["ascii", "utf-8", "UTF-16LE", "utf-16be", "koi8-r", "ibm866", "iso-8859-2", "iso-8859-5", "iso-8859-15",
-            "windows-1251", "windows-1252", "x-user-defined", ""]
+            "windows-1251", "windows-1252", "x-user-defined", "", "iso-8859-7", "windows-1255", "koi8-u", "macintosh", "windows-874"]
     afs = [None, "", "All", "All-Ctrl", "All-Ctrl+Wsp", "Default", "None", "Wsp", "W", "0x7f", " 0xFFFF "]
     ubfs = [None, "", "African", "All-Asian", "All", "Arabic", "Armenian", "Asian", "Cjk", "Common", "Cyrillic", "Default", "Greek",
             "Hangul", "Hebrew", "Kana", "Latin", "None", "Private", "Uncommon", "C", "H", "0xfffc", "0x0"]
@@ -89,3 +100,27 @@ def test_random_flag_sets_agree_with_the_python_restatement():
             pass
         got = sx.missions_from_flags(**kw)
         assert got == want, (kw, got, want)
+
+
+def test_single_byte_tables_cover_the_whatwg_set_and_agree_between_oracle_and_product():
+    """28 single-byte encodings (WHATWG) = 7 first built + 21; oracle and product are generated from
+    identical tables; every id has a name and its lower-cased name is one of its labels."""
+    import importlib.util
+    tabs = []
+    for path in ("oracle/gen_tables.py", "stringsext_amd/csrc/gen_tables.py"):
+        spec = importlib.util.spec_from_file_location("gt", os.path.join(ROOT, path))
+        gt = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gt)
+        tabs.append([(n, gt.table(c, f, n)) for n, c, f in gt.TABLES])
+    assert tabs[0] == tabs[1] and len(tabs[0]) == 28  # the WHATWG single-byte set (x-user-defined has no table)
+    for k, (name, tab) in enumerate(tabs[0]):
+        assert sx.encoding_name(16 + k) == name
+        assert sx.encoding_for_label(name.lower()) == 16 + k
+        assert len(tab) == 128 and all(0 <= v < 0x10000 for v in tab)
+    assert sx.encoding_name(16 + 28) is None
+    # the patched places (oracle/gen_tables.py header)
+    t = dict(tabs[0])
+    assert t["windows-1255"][0xCA - 0x80] == 0x05BA and t["windows-1255"][0xD9 - 0x80] == 0
+    assert t["KOI8-U"][0xAE - 0x80] == 0x045E and t["x-mac-cyrillic"][0xFF - 0x80] == 0x20AC
+    assert t["windows-874"][0x81 - 0x80] == 0x81 and t["windows-874"][0xDB - 0x80] == 0
+    assert t["windows-1253"][0xAA - 0x80] == 0 and t["ISO-8859-8-I"] == t["ISO-8859-8"]

@@ -332,3 +332,44 @@ def test_same_unicode_block_region_entry_without_exact_state_keeps_the_unit_grid
         want = sxo.run_cli(ms, [data], radix="x")
         assert text[:8].encode("utf-8") in want
         assert run_cli_product(ms, [data], radix="x") == want, flags
+
+
+NEW_SINGLE_BYTE = ["iso-8859-3", "iso-8859-4", "iso-8859-6", "iso-8859-7", "iso-8859-8", "iso-8859-8-i", "iso-8859-10", "iso-8859-13",
+                   "iso-8859-14", "iso-8859-16", "koi8-u", "macintosh", "windows-874", "windows-1250", "windows-1253", "windows-1254",
+                   "windows-1255", "windows-1256", "windows-1257", "windows-1258", "x-mac-cyrillic"]
+
+
+@pytest.mark.parametrize("enc", NEW_SINGLE_BYTE)
+def test_remaining_single_byte_encodings_replay_equals_full_scan(enc):
+    """the other WHATWG single-byte decoders go through the same table-driven path; text in the
+    encoding itself (every defined high byte), undefined bytes as breaks, and random bytes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gt", os.path.join(ROOT, "oracle", "gen_tables.py"))
+    gt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gt)
+    name, codec, fill = next(t for t in gt.TABLES if t[0].lower() == enc)
+    tab = gt.table(codec, fill, name)
+    defined = [0x80 + i for i, v in enumerate(tab) if v and v >= 0xA0]
+    undefined = [0x80 + i for i, v in enumerate(tab) if not v] or [0x00]
+    rng = random.Random(zlib_seed(enc))
+    words = [bytes(rng.choice(defined) for _ in range(rng.randrange(1, 30))) for _ in range(60)] + [b"plain ascii", b" ", b"x"]
+    text = bytearray()
+    while len(text) < 60_000:
+        text += rng.choice(words)
+        r = rng.random()
+        if r < 0.3: text += bytes([rng.choice(undefined)])
+        elif r < 0.5: text += b"\x00" * rng.randrange(1, 200)
+        elif r < 0.6: text += rng.randbytes(rng.randrange(1, 64))
+    data = bytes(text) + rng.randbytes(20_000)
+    for flags in (dict(encodings=[enc], chars_min="4", unicode_block_filter="All"),
+                  dict(encodings=[enc, "utf-8"], chars_min="3", output_line_len="16", unicode_block_filter="All-Asian", same_unicode_block=True)):
+        ms = rc.missions(**flags)
+        want = sxo.run_cli(ms, [data], radix="x")
+        assert len(want) > 2000
+        assert run_cli_product(ms, [data], radix="x") == want, flags
+        assert run_cli_product(ms, [data], radix="x", chunk_bytes=8192) == want, flags
+
+
+def zlib_seed(s):
+    import zlib
+    return zlib.crc32(s.encode())

@@ -58,7 +58,7 @@ def sb_table(enc_id):
     gt = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gt)
     name, codec, fill = gt.TABLES[enc_id - 16]
-    return (C.c_uint16 * 128)(*gt.table(codec, fill))
+    return (C.c_uint16 * 128)(*gt.table(codec, fill, name))
 
 
 def ws(p, W):

@@ -7,6 +7,7 @@ from test_host_logic import soup, synth
 from test_gpu_parity import dense
 
 ENCS = ["utf-8", "ascii", "utf-16le", "utf-16be", "koi8-r", "ibm866", "windows-1252", "iso-8859-5", "x-user-defined"]
+ENCS_MORE = ["iso-8859-7", "windows-1255", "windows-874", "koi8-u", "macintosh", "iso-8859-6", "windows-1257", "x-mac-cyrillic"]
 AFS = [None, "All", "All-Ctrl", "All-Ctrl+Wsp", "None", "Wsp", "0x7ffffffe000000007ffffffe00000000"]
 UBFS = [None, "African", "All", "Common", "Cyrillic", "Latin", "Asian", "Uncommon", "None", "Hebrew", "Cjk"]
 # alternative paths behind environment switches, read by the library at call time
@@ -42,6 +43,9 @@ def make(case_seed):
                 flush=r.random() < 0.3, sub=r.choice([0, 0, 1024, 4096]), replay=r.choice([None, None, True, False]),
                 generic=r.random() < 0.2)
     case["switches"] = r.choice(SWITCH_SETS)
+    if r.random() < 0.15:  # one of the other WHATWG single-byte tables instead of the first mission's encoding
+        kw["encodings"][0] = r.choice(ENCS_MORE) + kw["encodings"][0][len(kw["encodings"][0].split(",")[0]):]
+        case["missions"] = rc.missions(**kw)
     return case
 
 
