@@ -43,9 +43,9 @@ RUN_MISSIONS = {
     "utf16be_uncommon": dict(encodings=["utf-16be"], chars_min="2", unicode_block_filter="Uncommon"),
     "koi8r": dict(encodings=["koi8-r"], chars_min="4", unicode_block_filter="Cyrillic"),
     "win1251_all": dict(encodings=["windows-1251"], chars_min="6", unicode_block_filter="All"),
-    "iso8859_7_greek": dict(encodings=["greek"], chars_min="4", unicode_block_filter="Greek"),
+    "iso8859_7_greek": dict(encodings=["iso-8859-7"], chars_min="4", unicode_block_filter="Greek"),
     "win1255_hebrew": dict(encodings=["windows-1255"], chars_min="3", unicode_block_filter="Hebrew"),
-    "win874_all": dict(encodings=["tis-620"], chars_min="4", unicode_block_filter="All"),
+    "win874_all": dict(encodings=["windows-874"], chars_min="4", unicode_block_filter="All"),
     "xmaccyr": dict(encodings=["x-mac-cyrillic"], chars_min="5", unicode_block_filter="Cyrillic"),
     "odd_af": dict(encodings=["utf-8"], chars_min="4", ascii_filter="0x7ffffffe000000007ffffffe00000000"),
 }
