@@ -29,10 +29,10 @@ WORKLOADS = {
                           unicode_block_filter="African"), gib=64.0,
                name="C3(i): -e utf-8 -e utf-16le -e utf-16be -n 10 -u African -t x, synthetic background"),
     # BASELINE.json configs[0] at a GPU-sized length (the text-dense extreme: ~11.8 k findings per MiB)
-    "c1": dict(flags=dict(encodings=["ascii"], chars_min="4"), gib=1.0,
+    "c1": dict(flags=dict(encodings=["ascii"], chars_min="4"), gib=1.0, kernels="SingleByteRange",
                name="C1-like: -e ascii -n 4 -t x, synthetic background (dense: every 85th byte starts a finding)"),
     # BASELINE.json configs[1]
-    "c2": dict(flags=dict(encodings=["utf-8"], chars_min="10"), gib=4.0,
+    "c2": dict(flags=dict(encodings=["utf-8"], chars_min="10"), gib=4.0, kernels="Utf8Range2",
                name="C2: -e utf-8 -n 10 -t x, synthetic background"),
 }
 
@@ -187,7 +187,7 @@ def main():
         roofline = {
             "bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "sx::scan_kernel<Utf8Range2|Utf16Range>, %d launches per step, average" % len(missions),
+            "kernel": "sx::scan_kernel<%s>, %d launches per step, average" % (wl.get("kernels", "Utf8Range2|Utf16Range"), len(missions)),
             "algorithmic_bytes_per_launch": nbytes,
             "per_kernel_ms": [round(x, 3) for x in kernel_ms],
             "per_kernel_gbs": [round(nbytes / (x * 1e-3) / 1e9, 1) if x > 0 else None for x in kernel_ms],

@@ -231,6 +231,16 @@ class Result:
         fb = C.string_at(L.sx_result_findings(self.h), n * C.sizeof(Finding)) if n else b""
         return fb, (C.string_at(ap, alen.value) if alen.value else b"")
 
+    def finding_arrays(self):
+        """[(Finding pointer, n)] per segment — no copies (the strings stay where they are)."""
+        L = lib()
+        out = []
+        for i in range(L.sx_result_segments(self.h)):
+            fp, n, ap, alen = C.POINTER(Finding)(), C.c_uint64(), C.POINTER(C.c_uint8)(), C.c_uint64()
+            self._s._chk(L.sx_result_segment(self.h, i, C.byref(fp), C.byref(n), C.byref(ap), C.byref(alen)))
+            out.append((fp, n.value))
+        return out
+
     def segments(self):
         """[(Finding array, n, arena bytes)]: the result as the library holds it (no copy on the C side)."""
         L = lib()

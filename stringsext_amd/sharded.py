@@ -145,7 +145,7 @@ class ShardCounts(list):
 
 def _overflow(res, boundary_slice):
     n = 0
-    for v, cnt, _ in reversed(res.segments()):
+    for v, cnt in reversed(res.finding_arrays()):
         i = cnt
         while i > 0 and v[i - 1].slice_index >= boundary_slice:
             i -= 1
