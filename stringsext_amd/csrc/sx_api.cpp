@@ -232,6 +232,7 @@ void sx_destroy(sx_ctx* ctx) {
             if (d.d_table) (void)hipFree(d.d_table);
             for (void* q : d.d_rp) if (q) (void)hipFree(q);
             if (d.h_runs) (void)hipHostFree(d.h_runs);
+            if (d.ev_runs) (void)hipEventDestroy(d.ev_runs);
             if (d.stream && d.stream != ctx->scan_stream) (void)hipStreamDestroy(d.stream);
         }
         for (int i = 0; i < 2; i++) {
@@ -239,6 +240,7 @@ void sx_destroy(sx_ctx* ctx) {
             if (ctx->ing_dev[i]) (void)hipFree(ctx->ing_dev[i]);
         }
         if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+        if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
         if (ctx->scan_stream) (void)hipStreamDestroy(ctx->scan_stream);
         if (ctx->post_stream) (void)hipStreamDestroy(ctx->post_stream);
         if (ctx->d_input) (void)hipFree(ctx->d_input);
@@ -272,6 +274,7 @@ int sx_device_runs(sx_ctx* ctx, int mission_index, const void* device_bytes, uin
     int rc = device_runs(ctx, { mission_index }, (const uint8_t*)device_bytes, len, { (uint32_t)(stream_parity & 1) },
                          { min_chars }, &out);
     if (rc != SX_OK) return rc;
+    out[0].wait();
     *n_runs = out[0].size();
     *runs = (sx_run*)malloc(sizeof(sx_run) * (out[0].size() ? out[0].size() : 1));
     if (!*runs) return SX_E_NOMEM;

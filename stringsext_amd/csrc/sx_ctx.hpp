@@ -37,7 +37,10 @@ struct RunList {
     const sx_run* p = nullptr;
     size_t n = 0;
     bool on_device = false;
-    void use_own() { p = own.data(); n = own.size(); on_device = false; }
+    hipEvent_t ready = nullptr;  // set while the copy of a device-joined list into p[] may still be in flight
+    // the list's contents are on the host from here on (its size always is)
+    void wait() const { if (ready) (void)hipEventSynchronize(ready); }
+    void use_own() { p = own.data(); n = own.size(); on_device = false; ready = nullptr; }
     void assign(const sx_run* b, const sx_run* e) { own.assign(b, e); use_own(); }
     const sx_run* data() const { return p; }
     size_t size() const { return n; }
@@ -66,6 +69,7 @@ struct MissionDev {
     // stage B on the device: grow-only buffers
     uint16_t* d_table = nullptr;                        // single-byte decoder table
     sx_run* h_runs = nullptr; uint64_t h_runs_cap = 0;   // pinned: runs joined on the device
+    hipEvent_t ev_runs = nullptr;                         // their copy (on sx_ctx::d2h_stream) is done
     void* d_rp[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
     uint64_t d_rp_cap[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // + stitch blocks, totals, pass-1 output cache
 };
@@ -91,6 +95,7 @@ struct sx_ctx {
     unsigned n_cus = 256, scan_blocks_per_cu = 8;
     // sx_scan_stream: two pinned host buffers and two device buffers, filled by a reader thread
     hipStream_t copy_stream = nullptr;
+    hipStream_t d2h_stream = nullptr;   // run lists travel to the host while stage B's first pass runs
     uint8_t* ing_pin[2] = { nullptr, nullptr };
     uint8_t* ing_dev[2] = { nullptr, nullptr };
     uint64_t ing_cap = 0, ing_dev_cap = 0;

@@ -140,6 +140,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             // sort the records and join them into runs on the device; only the runs travel
             const size_t sb = std::max(sort_scratch_bytes(nrec), merge_scratch_bytes(nrec));
             int rc = ensure_scratch(ctx, sb); if (rc != SX_OK) return rc;
+            if (d.ev_runs) HIP_TRY(ctx, hipEventSynchronize(d.ev_runs));  // the previous list's copy (normally long done)
             rc = ensure_rp(ctx, d, 0, (uint64_t)nrec * sizeof(sx_run)); if (rc != SX_OK) return rc;
             if (!regions) HIP_TRY(ctx, sort_records(s.d_recs, nrec, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
             if (getenv("SX_TIMING2")) { HIP_TRY(ctx, hipStreamSynchronize(d.stream_b)); fprintf(stderr, "[sx]   sort done +%.2f ms\n", now_ms() - tc0); }
@@ -159,11 +160,17 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                 HIP_TRY(ctx, hipHostMalloc((void**)&d.h_runs, cap, hipHostMallocNonCoherent));
                 d.h_runs_cap = cap;
             }
-            if (nruns) {
-                HIP_TRY(ctx, hipMemcpyAsync(d.h_runs, d.d_rp[0], (size_t)nruns * sizeof(sx_run), hipMemcpyDeviceToHost, d.stream_b));
-                HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
-            }
             rl.p = d.h_runs; rl.n = nruns; rl.on_device = true;
+            if (nruns) {
+                // The list is complete on the device (the count was just read).  Its copy for the host's
+                // part of stage B runs on a stream of its own: whoever reads rl.p[] calls rl.wait() first,
+                // and the device replay does so only after its first pass is under way.
+                if (!ctx->d2h_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+                if (!d.ev_runs) HIP_TRY(ctx, hipEventCreateWithFlags(&d.ev_runs, hipEventDisableTiming));
+                HIP_TRY(ctx, hipMemcpyAsync(d.h_runs, d.d_rp[0], (size_t)nruns * sizeof(sx_run), hipMemcpyDeviceToHost, ctx->d2h_stream));
+                HIP_TRY(ctx, hipEventRecord(d.ev_runs, ctx->d2h_stream));
+                rl.ready = d.ev_runs;
+            }
         } else {
             int rc = ensure_pinned(ctx, (uint64_t)nrec * sizeof(DevRun) + 16);
             if (rc != SX_OK) return rc;
