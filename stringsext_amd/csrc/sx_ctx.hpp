@@ -100,7 +100,9 @@ struct sx_ctx {
     uint8_t* ing_dev[2] = { nullptr, nullptr };
     uint64_t ing_cap = 0, ing_dev_cap = 0;
     uint32_t region_cap = 32;         // record slots per sub-chunk in region mode (0: never use it)
-    std::vector<char> dense;          // per mission: the last buffer overflowed its regions -> shared pool + sort
+    // per mission, from the last buffer: 0 = few records (small regions, packed in order); 1 = shared pool + sort;
+    // > 1 = string-dense: regions of this many slots (no atomics in the scan kernel), sorted like the pool
+    std::vector<uint32_t> dense;
     uint8_t* d_input = nullptr;  // staging for host input
     uint64_t d_input_cap = 0;
     uint64_t ondemand_fetches = 0;

@@ -127,6 +127,7 @@ hipError_t sort_records(DevRun* recs, uint32_t n, void* scratch, size_t scratch_
 
 // region mode: records of all sub-chunks, in order, packed into `out`; *total = their number
 size_t compact_scratch_bytes(uint64_t n_regions);
+hipError_t invalidate_region_slack(DevRun* recs, const uint32_t* counts, uint64_t n_regions, uint32_t region_cap, hipStream_t stream);
 hipError_t compact_regions(const DevRun* recs, const uint32_t* counts, uint64_t n_regions, uint32_t region_cap, DevRun* out,
                            uint32_t* total, void* scratch, size_t scratch_bytes, hipStream_t stream);
 

@@ -328,7 +328,10 @@ struct Emitter {
         if (region_cap) { base = (u32)wave * region_cap; rcount = 0; }
     }
     SX_DEV void end_region(u64 wave) {
-        if (region_cap && lane_id() == 0) region_counts[wave] = rcount < region_cap ? rcount : region_cap;
+        if (region_cap && lane_id() == 0) {
+            region_counts[wave] = rcount < region_cap ? rcount : region_cap;
+            if (rcount > region_cap) atomicMax(counters + 3, rcount);  // how much room the fullest sub-chunk needs
+        }
     }
     SX_DEV void invalidate_rest() {
         if (region_cap) return;

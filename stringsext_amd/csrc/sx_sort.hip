@@ -128,6 +128,25 @@ __global__ __launch_bounds__(256) void region_pack_kernel(const DevRun* recs, co
     for (uint32_t i = 0; i < n; i++) rank += reg[i].start < r.start ? 1u : 0u;
     out[(uint64_t)block_off[w / kScanPerBlock] + local_off[w] + rank] = r;
 }
+// Large regions (string-dense input): instead of packing, the unused slots are marked like the pool's
+// unused slots and the whole array goes through the radix sort.
+__global__ __launch_bounds__(256) void region_invalidate_kernel(DevRun* recs, const uint32_t* counts, uint64_t n_regions,
+                                                                uint32_t region_cap) {
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t w = s / region_cap;
+    if (w >= n_regions) return;
+    if ((uint32_t)(s - w * region_cap) >= counts[w]) {
+        DevRun r; r.start = 0; r.len = kRecInvalidLen; r.chars_flags = kRecInvalidFlags;
+        recs[s] = r;
+    }
+}
+hipError_t invalidate_region_slack(DevRun* recs, const uint32_t* counts, uint64_t n_regions, uint32_t region_cap, hipStream_t stream) {
+    const uint64_t slots = n_regions * region_cap;
+    if (slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(region_invalidate_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, recs, counts, n_regions,
+                       region_cap);
+    return hipGetLastError();
+}
 size_t compact_scratch_bytes(uint64_t n_regions) {
     return n_regions * 4 + ((n_regions + kScanPerBlock - 1) / kScanPerBlock) * 4 + 1024;
 }

@@ -6,6 +6,12 @@ using namespace sx;
 
 namespace sx {
 
+// Regions large enough for string-dense input cost memory: at most half the input's size (and 32-bit slot numbers).
+static bool large_regions_fit(uint64_t len, uint64_t n_regions, uint32_t cap) {
+    const uint64_t slots = n_regions * cap;
+    return slots < (1ull << 31) && slots * sizeof(DevRun) <= std::max<uint64_t>(256ull << 20, len / 2);
+}
+
 ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const uint8_t* d_bytes, uint64_t len,
                        uint32_t parity, uint64_t min_chars) {
     const Mission& m = ctx->missions[(size_t)mission];
@@ -52,8 +58,11 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             const bool tile_traversal = (ctx->opt.flags & SX_OPT_TILE_TRAVERSAL) || (getenv("SX_TRAVERSAL") && atoi(getenv("SX_TRAVERSAL")));
             if (ctx->dense.size() != ctx->missions.size()) ctx->dense.assign(ctx->missions.size(), 0);
             s.region_cap = 0; s.n_regions = n_regions;
-            if (ctx->region_cap && !ctx->dense[(size_t)which[k]] && !tile_traversal && n_regions * ctx->region_cap < (1ull << 28)) {
-                s.region_cap = ctx->region_cap;
+            const uint32_t dn = ctx->dense[(size_t)which[k]];
+            const uint32_t want_cap = dn > 1 ? dn : (dn == 0 ? ctx->region_cap : 0u);
+            if (ctx->region_cap && want_cap && !tile_traversal &&
+                (dn > 1 ? large_regions_fit(len, n_regions, want_cap) : n_regions * want_cap < (1ull << 28))) {
+                s.region_cap = want_cap;
                 int rc = ensure_capacity(ctx, s, (uint32_t)(n_regions * s.region_cap));
                 if (rc != SX_OK) return rc;
                 if (s.cnt_cap < n_regions) {
@@ -96,9 +105,19 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
             if (s.region_cap) {
                 if (counters[0] == 0) break;  // every sub-chunk's records fit its region
-                // too dense for regions: this mission uses the shared pool (and a sort) from now on
-                ctx->dense[(size_t)which[k]] = 1;
-                s.region_cap = 0;
+                // Too dense for these regions.  If the fullest sub-chunk's records (+25 %) fit regions that
+                // the memory allows, scan again with those — the kernel then appends without atomics, which
+                // on string-dense input is 20x faster than the shared pool — else use the pool from now on.
+                const uint32_t big = (counters[3] + counters[3] / 4 + 127) / 64 * 64;
+                if (s.region_cap == ctx->region_cap && counters[3] && large_regions_fit(len, s.n_regions, big) && !getenv("SX_NO_LARGE_REGIONS")) {
+                    ctx->dense[(size_t)which[k]] = big;
+                    s.region_cap = big;
+                    int rc = ensure_capacity(ctx, s, (uint32_t)(s.n_regions * big));
+                    if (rc != SX_OK) return rc;
+                } else {
+                    ctx->dense[(size_t)which[k]] = 1;
+                    s.region_cap = 0;
+                }
             } else {
                 if (counters[0] <= s.capacity) break;
                 if (round >= 8) { ctx->err = "device run-record buffer kept overflowing"; return SX_E_NOMEM; }
@@ -114,7 +133,13 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   mission %d: kernel done at +%.2f ms, counters at +%.2f ms\n", which[k], t_ev - t0, tc0 - t0);
         uint32_t nrec = counters[0];
         const DevRun* d_records = s.d_recs;   // sorted already in region mode
-        const bool regions = s.region_cap != 0;
+        const bool large_regions = s.region_cap > ctx->region_cap && ctx->region_cap;
+        const bool regions = s.region_cap != 0 && !large_regions;
+        if (large_regions) {
+            // the slot array is treated like the pool: unused slots marked, everything sorted below
+            HIP_TRY(ctx, invalidate_region_slack(s.d_recs, s.d_cnt, s.n_regions, s.region_cap, d.stream_b));
+            nrec = (uint32_t)(s.n_regions * s.region_cap);
+        }
         if (regions) {
             // pack the regions: the records come out ordered by position, no sort needed
             const uint64_t slots = s.n_regions * s.region_cap;
@@ -130,7 +155,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             HIP_TRY(ctx, hipMemcpyAsync(&nrec, s.d_counters + 1, 4, hipMemcpyDeviceToHost, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
             d_records = s.d_packed;
-        } else if (ctx->region_cap && nrec < s.n_regions * ctx->region_cap / 4)
+        } else if (ctx->region_cap && !large_regions && nrec < s.n_regions * ctx->region_cap / 4)
             ctx->dense[(size_t)which[k]] = 0;  // sparse again: regions next time
         const uint32_t join_min = getenv("SX_DEVICE_JOIN_MIN") ? (uint32_t)atoi(getenv("SX_DEVICE_JOIN_MIN")) : 65536u;
         const bool dev_sorted = nrec >= join_min && nrec > 0;  // worth a handful of small kernels
@@ -161,6 +186,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                 d.h_runs_cap = cap;
             }
             rl.p = d.h_runs; rl.n = nruns; rl.on_device = true;
+            if (large_regions && nruns < s.n_regions * ctx->region_cap / 4) ctx->dense[(size_t)which[k]] = 0;  // sparse again
             if (nruns) {
                 // The list is complete on the device (the count was just read).  Its copy for the host's
                 // part of stage B runs on a stream of its own: whoever reads rl.p[] calls rl.wait() first,
@@ -195,7 +221,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         }
         if (getenv("SX_TIMING"))
             fprintf(stderr, "[sx] mission %d: kernel %.2f ms, %u %s, %s %.2f ms, %s %.2f ms -> %zu runs\n", which[k], ms, nrec,
-                    regions ? "records (regions)" : "record slots (pool)", dev_sorted ? (regions ? "device pack+join" : "device sort+join") : "d2h",
+                    regions ? "records (regions)" : (large_regions ? "record slots (large regions)" : "record slots (pool)"), dev_sorted ? (regions ? "device pack+join" : "device sort+join") : "d2h",
                     tc1 - tc0, dev_sorted ? "d2h runs" : "host join", now_ms() - tc1, rl.size());
         ctx->stats.run_records += rl.size();
         ctx->stats.bytes_scanned += len;
