@@ -310,9 +310,10 @@ SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs) {
         }
         return b;
     }
+    if (!P.table) return p;  // x-user-defined: every byte is a character, the call at p is the one
     while (b > p) {
         const u8 x = bytes[b - 1];
-        if (x >= 0x80 && P.table && P.table[x - 0x80] == 0) break;
+        if (x >= 0x80 && P.table[x - 0x80] == 0) break;
         b--;
     }
     return b;
