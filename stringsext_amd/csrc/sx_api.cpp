@@ -274,7 +274,7 @@ int sx_device_runs(sx_ctx* ctx, int mission_index, const void* device_bytes, uin
     int rc = device_runs(ctx, { mission_index }, (const uint8_t*)device_bytes, len, { (uint32_t)(stream_parity & 1) },
                          { min_chars }, &out);
     if (rc != SX_OK) return rc;
-    out[0].wait();
+    HIP_TRY(ctx, out[0].wait());
     *n_runs = out[0].size();
     *runs = (sx_run*)malloc(sizeof(sx_run) * (out[0].size() ? out[0].size() : 1));
     if (!*runs) return SX_E_NOMEM;

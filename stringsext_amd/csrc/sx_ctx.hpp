@@ -37,10 +37,26 @@ struct RunList {
     const sx_run* p = nullptr;
     size_t n = 0;
     bool on_device = false;
-    hipEvent_t ready = nullptr;  // set while the copy of a device-joined list into p[] may still be in flight
+    // A list joined on the device: p[] (pinned) is filled by a copy that is only started when somebody
+    // asks for it — the device replay asks after its first pass is launched, so that the copy (a blit
+    // kernel on this stack) does not run next to the short kernels in front of that pass.
+    const void* dev_src = nullptr; size_t copy_bytes = 0;
+    hipStream_t copy_stream = nullptr; hipEvent_t ready = nullptr;
+    mutable bool issued = false;
+    hipError_t start_copy() const {
+        if (!dev_src || issued || !copy_bytes) return hipSuccess;
+        hipError_t e = hipMemcpyAsync(const_cast<sx_run*>(p), dev_src, copy_bytes, hipMemcpyDeviceToHost, copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(ready, copy_stream);
+        issued = true;
+        return e;
+    }
     // the list's contents are on the host from here on (its size always is)
-    void wait() const { if (ready) (void)hipEventSynchronize(ready); }
-    void use_own() { p = own.data(); n = own.size(); on_device = false; ready = nullptr; }
+    hipError_t wait() const {
+        hipError_t e = start_copy();
+        if (e == hipSuccess && dev_src && copy_bytes) e = hipEventSynchronize(ready);
+        return e;
+    }
+    void use_own() { p = own.data(); n = own.size(); on_device = false; dev_src = nullptr; copy_bytes = 0; }
     void assign(const sx_run* b, const sx_run* e) { own.assign(b, e); use_own(); }
     const sx_run* data() const { return p; }
     size_t size() const { return n; }

@@ -189,13 +189,12 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             if (large_regions && nruns < s.n_regions * ctx->region_cap / 4) ctx->dense[(size_t)which[k]] = 0;  // sparse again
             if (nruns) {
                 // The list is complete on the device (the count was just read).  Its copy for the host's
-                // part of stage B runs on a stream of its own: whoever reads rl.p[] calls rl.wait() first,
-                // and the device replay does so only after its first pass is under way.
+                // part of stage B runs on a stream of its own, started on demand: whoever reads rl.p[] calls
+                // rl.wait() first; the device replay starts it once its first pass is under way.
                 if (!ctx->d2h_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
                 if (!d.ev_runs) HIP_TRY(ctx, hipEventCreateWithFlags(&d.ev_runs, hipEventDisableTiming));
-                HIP_TRY(ctx, hipMemcpyAsync(d.h_runs, d.d_rp[0], (size_t)nruns * sizeof(sx_run), hipMemcpyDeviceToHost, ctx->d2h_stream));
-                HIP_TRY(ctx, hipEventRecord(d.ev_runs, ctx->d2h_stream));
-                rl.ready = d.ev_runs;
+                rl.dev_src = d.d_rp[0]; rl.copy_bytes = (size_t)nruns * sizeof(sx_run);
+                rl.copy_stream = ctx->d2h_stream; rl.ready = d.ev_runs; rl.issued = false;
             }
         } else {
             int rc = ensure_pinned(ctx, (uint64_t)nrec * sizeof(DevRun) + 16);

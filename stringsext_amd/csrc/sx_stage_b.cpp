@@ -75,6 +75,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
                                              ctx->d_scratch_cap, d.stream_b));
         }
         HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], d.stream_b));
+        HIP_TRY(ctx, runs.start_copy());  // the host's copy of a device-joined run list travels while pass 1 runs
         if (dev_stitch) {
             HIP_TRY(ctx, hipMemsetAsync(d.d_rp[7], 0, kTotCount * 8, d.stream_b));
             HIP_TRY(ctx, launch_stitch_blocks(P, (const ReplayRegionOut*)d.d_rp[1], (uint8_t*)d.d_rp[2], d.d_rp[6],
@@ -84,7 +85,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     }
 
     // ---- meanwhile on the host: the strict entry region (exact carried state), if any
-    runs.wait();  // (a device-joined list: its copy for the host has been travelling since stage A)
+    HIP_TRY(ctx, runs.wait());
     std::deque<ReplayPart> host_parts;
     struct Seg { int host_part; size_t v0, v1; };  // host_part >= 0, or device regions [v0, v1) of `valid`
     std::vector<Seg> segs;
@@ -249,7 +250,7 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
         on_device[k] = (pre && pre->done[k]) ? 2 : (device_replay_wanted(ctx, job, k, runs[k].size()) ? 1 : 0);
     for (size_t k = 0; k < nm; k++) {
         if (on_device[k]) continue;
-        runs[k].wait();
+        HIP_TRY(ctx, runs[k].wait());
         // parts are speculative restarts: worth a thread each only if they hold real work
         const unsigned want_parts = (unsigned)std::min<uint64_t>(nthreads, std::max<uint64_t>(1, runs[k].size() / 512));
         host_runs += runs[k].size();
@@ -387,7 +388,7 @@ int download_for_replay(sx_ctx* ctx, const uint8_t* d_bytes, uint64_t len,
         if (len > 64 * 1024) rg.emplace_back(len - 64 * 1024, len);
         for (size_t k = 0; k < nm; k++) {
             if ((skip && (*skip)[k]) || device_replay_wanted(ctx, job, k, runs[k].size())) continue;  // stage B of this mission runs on the device
-            runs[k].wait();
+            HIP_TRY(ctx, runs[k].wait());
             const size_t before = rg.size();
             // same partition count as replay_all will use
             const unsigned want_parts = (unsigned)std::min<uint64_t>(replay_threads(ctx), std::max<uint64_t>(1, runs[k].size() / 512));
