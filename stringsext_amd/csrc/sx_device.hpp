@@ -8,6 +8,7 @@
 // to be able to produce a Finding (reference src/helper.rs:315-322: a string
 // needs >= chars_min_nb chars, or output_line_char_nb_max to be cut).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
@@ -103,7 +104,12 @@ hipError_t launch_replay_write(const ReplayParams& P, const uint64_t* region_ind
                                hipStream_t stream);
 
 // "which regions stand" + output offsets on the device (sx_replay_dev.hip)
-constexpr uint32_t kStitchBlock = 128;     // runs resolved per lane in the first stage
+// runs resolved per lane in the first stage of the stitch: the second stage is one wavefront walking the block
+// summaries, so with many runs (string-dense input) larger blocks keep that walk short
+inline uint32_t stitch_block_runs(uint64_t n_runs) {
+    if (const char* e = getenv("SX_STITCH_BLOCK")) { const int v = atoi(e); if (v > 0) return (uint32_t)v; }  // tests
+    return n_runs > (4ull << 20) ? 512u : 128u;
+}
 enum : uint32_t { kTotEnd = 0, kTotLast, kTotFindings, kTotBytes, kTotStanding, kTotReplayBytes, kTotTooLong, kTotCount };
 size_t stitch_scratch_bytes(uint64_t n_runs);
 size_t stitch_blocks_bytes(uint64_t n_runs);

@@ -134,17 +134,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WA
 // ---- which regions stand, on the device ---------------------------------------------------
 // The rule is sequential (a region is void if an earlier standing one ran over its start:
 // E = end of the last standing region; region i stands iff want_i >= E), but regions rarely
-// reach their successor, so: every block of kStitchBlock runs is resolved on its own as if
+// reach their successor, so: every block of stitch_block_runs() runs is resolved on its own as if
 // nothing reached into it (its first candidate stands); then one wavefront walks the block
 // summaries in order and repairs the few blocks whose entry was overrun, following the true
 // chain only until it meets the block's own chain again.
 struct StitchBlock { u64 first_want, end; u64 last; };  // first candidate's window, E after the block, last standing run
 
 __global__ __launch_bounds__(64) void stitch_blocks_kernel(const ReplayParams P, const ReplayRegionOut* ro, u8* stands,
-                                                           StitchBlock* blocks, u64 n_blocks, u64* totals) {
+                                                           StitchBlock* blocks, u64 n_blocks, u32 per_block, u64* totals) {
     const u64 b = (u64)blockIdx.x * 64 + threadIdx.x;
     if (b >= n_blocks) return;
-    const u64 i0 = b * kStitchBlock, i1 = i0 + kStitchBlock < P.n_runs ? i0 + kStitchBlock : P.n_runs;
+    const u64 i0 = b * per_block, i1 = i0 + per_block < P.n_runs ? i0 + per_block : P.n_runs;
     StitchBlock sb; sb.first_want = ~0ull; sb.end = 0; sb.last = ~0ull;
     u32 too_long = 0;
     for (u64 i = i0; i < i1; i++) {
@@ -173,7 +173,7 @@ SXD u64 wave_prefix_max_excl(u64 x, u32 lane) {  // max over lanes below `lane` 
 }
 
 __global__ __launch_bounds__(64) void stitch_chain_kernel(const ReplayParams P, const ReplayRegionOut* ro, u8* stands,
-                                                          const StitchBlock* blocks, u64 n_blocks, u64 E0, u64* totals) {
+                                                          const StitchBlock* blocks, u64 n_blocks, u32 per_block, u64 E0, u64* totals) {
     const u32 lane = threadIdx.x;
     u64 E = E0, last = ~0ull;  // wave-uniform
     StitchBlock next; next.first_want = ~0ull; next.end = 0; next.last = ~0ull;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void stitch_chain_kernel(const ReplayParams P, 
             // repair block v: follow the true chain until it meets the block's own chain again
             // (every lane does the same work on the same data; lane 0 stores)
             const u64 be = __shfl(mine.end, (int)v), bl = __shfl(mine.last, (int)v);
-            const u64 b = base + v, i0 = b * kStitchBlock, i1 = i0 + kStitchBlock < P.n_runs ? i0 + kStitchBlock : P.n_runs;
+            const u64 b = base + v, i0 = b * per_block, i1 = i0 + per_block < P.n_runs ? i0 + per_block : P.n_runs;
             for (u64 i = i0; i < i1; i++) {
                 if (ro[i].status != kRegionOk) continue;
                 const u64 w = win_start(P.runs[i].start, P.W);
@@ -263,7 +263,7 @@ size_t stitch_scratch_bytes(uint64_t n_runs) {
     (void)rocprim::exclusive_scan(nullptr, a, it, (u64*)nullptr, (u64)0, (size_t)n_runs, rocprim::plus<u64>(), (hipStream_t)0);
     return a + 512;
 }
-uint64_t stitch_block_count(uint64_t n_runs) { return (n_runs + kStitchBlock - 1) / kStitchBlock; }
+uint64_t stitch_block_count(uint64_t n_runs) { const uint64_t k = stitch_block_runs(n_runs); return (n_runs + k - 1) / k; }
 size_t stitch_blocks_bytes(uint64_t n_runs) { return stitch_block_count(n_runs) * sizeof(StitchBlock) + 64; }
 
 // stage 1 (no dependency on the entry region): the blocks' own chains.  totals must be zeroed.
@@ -272,7 +272,7 @@ hipError_t launch_stitch_blocks(const ReplayParams& P, const ReplayRegionOut* ro
     if (P.n_runs == 0) return hipSuccess;
     const u64 nb = stitch_block_count(P.n_runs);
     hipLaunchKernelGGL(stitch_blocks_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, stream, P, ro, stands,
-                       (StitchBlock*)blocks, nb, totals);
+                       (StitchBlock*)blocks, nb, stitch_block_runs(P.n_runs), totals);
     return hipGetLastError();
 }
 // stage 2: chain the blocks from E0 (end of the host's entry region), assign output offsets, totals
@@ -281,7 +281,7 @@ hipError_t launch_stitch_finish(const ReplayParams& P, const ReplayRegionOut* ro
                                 size_t scratch_bytes, hipStream_t stream) {
     if (P.n_runs == 0) return hipSuccess;
     const u64 nb = stitch_block_count(P.n_runs);
-    hipLaunchKernelGGL(stitch_chain_kernel, dim3(1), dim3(64), 0, stream, P, ro, stands, (const StitchBlock*)blocks, nb, E0, totals);
+    hipLaunchKernelGGL(stitch_chain_kernel, dim3(1), dim3(64), 0, stream, P, ro, stands, (const StitchBlock*)blocks, nb, stitch_block_runs(P.n_runs), E0, totals);
     void* tmp = (void*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
     size_t tmp_bytes = scratch_bytes - (size_t)((uint8_t*)tmp - (uint8_t*)scratch);
     auto itf = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), StandingFindings{ stands, ro });
