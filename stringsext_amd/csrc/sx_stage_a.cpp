@@ -64,7 +64,14 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                 (dn > 1 ? large_regions_fit(len, n_regions, want_cap) : n_regions * want_cap < (1ull << 28))) {
                 s.region_cap = want_cap;
                 int rc = ensure_capacity(ctx, s, (uint32_t)(n_regions * s.region_cap));
+                if (rc != SX_OK && dn > 1) {  // no room for large regions in this buffer: the pool
+                    (void)hipGetLastError();
+                    ctx->dense[(size_t)which[k]] = 1;
+                    s.region_cap = 0;
+                    rc = SX_OK;
+                }
                 if (rc != SX_OK) return rc;
+                if (s.region_cap == 0) goto launch;
                 if (s.cnt_cap < n_regions) {
                     if (s.d_cnt) HIP_TRY(ctx, hipFree(s.d_cnt));
                     s.d_cnt = nullptr; s.cnt_cap = 0;
@@ -73,6 +80,7 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                 }
             }
         }
+    launch:
         const ScanParams p = scan_params(ctx, which[k], s, d_bytes, len, parity[k], min_chars[k]);
         HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream));
         HIP_TRY(ctx, hipEventRecord(s.ev0, d.stream));
@@ -112,8 +120,11 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                 if (s.region_cap == ctx->region_cap && counters[3] && large_regions_fit(len, s.n_regions, big) && !getenv("SX_NO_LARGE_REGIONS")) {
                     ctx->dense[(size_t)which[k]] = big;
                     s.region_cap = big;
-                    int rc = ensure_capacity(ctx, s, (uint32_t)(s.n_regions * big));
-                    if (rc != SX_OK) return rc;
+                    if (ensure_capacity(ctx, s, (uint32_t)(s.n_regions * big)) != SX_OK) {  // no room after all: the pool
+                        (void)hipGetLastError();
+                        ctx->dense[(size_t)which[k]] = 1;
+                        s.region_cap = 0;
+                    }
                 } else {
                     ctx->dense[(size_t)which[k]] = 1;
                     s.region_cap = 0;
