@@ -65,7 +65,10 @@ struct ScanParams {
 };
 
 // ---- stage B on the device (sx_replay_dev.hip) ----
-constexpr uint32_t kMaxRegionWindows = 64;  // longer regions go back to the host
+// Regions longer than ReplayParams::max_windows go back to the host.  Text-like input (lines of a few dozen
+// chars) chains regions over ~60 windows on average, and giving thousands of them back costs far more than the
+// lanes that work through them, hence the generous default.
+constexpr uint32_t kMaxRegionWindowsDefault = 512;
 enum : uint32_t { kRegionOk = 0, kRegionChained = 1, kRegionNotMine = 2, kRegionTooLong = 3 };
 struct ReplayParams {
     const uint8_t* data;      // device: buffer byte 0 (on the slice grid)
@@ -88,6 +91,7 @@ struct ReplayParams {
     uint8_t* cache_arena;
     uint64_t arena_bytes;
     const uint32_t* head_list;   // head_list[slot] = run index: the replay kernels take one lane per REPLAYING run
+    uint32_t max_windows;        // a region that needs more windows is given back (kRegionTooLong)
 };
 struct ReplayRegionOut {
     uint64_t end;             // where the region's replay stopped (a window start, buffer relative)

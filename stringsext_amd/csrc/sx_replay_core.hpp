@@ -455,7 +455,7 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
         while (din < slen) {
             u32 dend;
             if (din + W < slen) dend = din + W; else { is_last_window = true; dend = slen; }
-            if (++windows > kMaxRegionWindows) { status = kRegionTooLong; done = true; break; }
+            if (++windows > P.max_windows) { status = kRegionTooLong; done = true; break; }
             const u32 wb = din;  // window start (din moves on inside the window)
             u32 dout = leftover_len;
             for (;;) {  // 'decoder

@@ -323,6 +323,7 @@ SWITCHES = [
     {"SX_NO_REPLAY_CACHE": "1"}, {"SX_REPLAY_CACHE_MIB": "0"}, {"SX_HOST_MERGE": "1"}, {"SX_MISSION_STREAMS": "1"}, {"SX_DEVICE_JOIN_MIN": "1"},
     {"SX_SCAN_BLOCKS_PER_CU": "3", "SX_SCAN_CUS": "2"}, {"SX_PIECE_MIB": "2", "SX_REGION_CAP": "4"},
     {"SX_REGION_CAP": "1"}, {"SX_REGION_CAP": "2", "SX_NO_LARGE_REGIONS": "1"}, {"SX_STITCH_BLOCK": "512"}, {"SX_STITCH_BLOCK": "5"},
+    {"SX_MAX_REGION_WINDOWS": "2"},
 ]
 
 

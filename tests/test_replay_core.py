@@ -27,7 +27,7 @@ class ReplayParams(C.Structure):
                 ("long_run", C.c_uint32), ("skip", C.c_uint32), ("grep_char", C.c_int32), ("mission_id", C.c_int32), ("file_id", C.c_int32),
                 ("af_lo", C.c_uint64), ("af_hi", C.c_uint64), ("ubf", C.c_uint64),
                 ("slot_of", C.c_void_p), ("n_heads", C.c_void_p), ("cache_arena", C.c_void_p), ("arena_bytes", C.c_uint64),
-                ("head_list", C.c_void_p)]
+                ("head_list", C.c_void_p), ("max_windows", C.c_uint32)]
 
 
 class RegionOut(C.Structure):
@@ -132,7 +132,7 @@ def test_device_replay_core_equals_host_replayer(core, flags, parity, skip):
         P = ReplayParams(data, len(data), arr, len(runs), 0, len(data), m["counter_offset"] + stream0, stream0, 0,
                          m["encoding"], table, m["chars_min_nb"], int(m["require_same_unicode_block"]),
                          m["output_line_char_nb_max"], W, long_run, skip, -1 if m["grep_char"] is None else m["grep_char"],
-                         0, 1, m["af"] & (2**64 - 1), m["af"] >> 64, m["ubf"], None, None, None, 0, None)
+                         0, 1, m["af"] & (2**64 - 1), m["af"] >> 64, m["ubf"], None, None, None, 0, None, 64)
         sc = sx.Scanner([m], device=sx.SX_HOST_ONLY)
         fbuf = (sx.Finding * 4096)()
         abuf = (C.c_uint8 * (1 << 20))()
@@ -168,7 +168,7 @@ def make_params(m, data, runs, stream0=0, skip=1):
     P = ReplayParams(data, len(data), arr, len(runs), 0, len(data), m["counter_offset"] + stream0, stream0, 0,
                      m["encoding"], table, m["chars_min_nb"], int(m["require_same_unicode_block"]),
                      m["output_line_char_nb_max"], W, long_run, skip, -1 if m["grep_char"] is None else m["grep_char"],
-                     m["mission_id"], 1, m["af"] & (2**64 - 1), m["af"] >> 64, m["ubf"], None, None, None, 0, None)
+                     m["mission_id"], 1, m["af"] & (2**64 - 1), m["af"] >> 64, m["ubf"], None, None, None, 0, None, 64)
     P._keep = (arr, table)
     return P, W, long_run
 

@@ -1,0 +1,25 @@
+"""Text-like input (lines of 10-120 printable chars ended by \\n): how the whole path behaves when nearly every
+window start is crossed by a run.  usage: tools/gpu_text.py [MIB]"""
+import os, random, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import refconfig as rc, stringsext_amd as sx
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+rng = random.Random(1)
+words = [bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyzABCDEFGH0123456789_-./:=") for _ in range(rng.randrange(2, 12))) for _ in range(500)]
+lines = []
+for _ in range(20000):
+    n = rng.randrange(10, 120); l = bytearray()
+    while len(l) < n: l += rng.choice(words) + b" "
+    lines.append(bytes(l[:n]) + b"\n")
+blob = b"".join(lines)
+data = (blob * (mib * (1 << 20) // len(blob) + 1))[:mib << 20]
+for flags in (dict(encodings=["ascii"], chars_min="4"), dict(encodings=["utf-8"], chars_min="10")):
+    ms = rc.missions(**flags)
+    sc = sx.Scanner(ms, device=0)
+    d = sc.alloc(len(data)); sc.upload(d, data)
+    for it in range(3):
+        sc.reset(); t0 = time.perf_counter()
+        res = sc.scan_device(d, len(data), file_id=1)
+        dt = time.perf_counter() - t0; n = len(res); res.free()
+    print(flags["encodings"], f"{mib} MiB text: {dt*1e3:.1f} ms = {mib/1024/dt:.2f} GiB/s, {n} findings")
+    sc.free(d); sc.close()
