@@ -58,7 +58,9 @@ enum {
     SX_ENC_MACINTOSH = 34, SX_ENC_WINDOWS_874 = 35, SX_ENC_WINDOWS_1250 = 36,
     SX_ENC_WINDOWS_1253 = 37, SX_ENC_WINDOWS_1254 = 38, SX_ENC_WINDOWS_1255 = 39,
     SX_ENC_WINDOWS_1256 = 40, SX_ENC_WINDOWS_1257 = 41, SX_ENC_WINDOWS_1258 = 42,
-    SX_ENC_X_MAC_CYRILLIC = 43
+    SX_ENC_X_MAC_CYRILLIC = 43,
+    /* legacy multi-byte (tables: csrc/gen_tables.py; parity unpinned): a pending lead byte is the decoder state */
+    SX_ENC_BIG5 = 64, SX_ENC_EUC_JP = 65
 };
 
 /* `Precision` — src/finding.rs:34-46 */
@@ -157,6 +159,9 @@ int sx_missions_from_flags(const sx_cli_flags* flags, sx_mission* out, int cap, 
 int sx_parse_enc_opt(const char* enc_opt, sx_enc_opt* out, char* err, size_t err_cap);
 int sx_encoding_for_label(const char* label);      /* SX_ENC_*; -1 not a label; -2 a label of an encoding not built in */
 const char* sx_encoding_name(uint32_t encoding);   /* Encoding::name(), e.g. "UTF-16LE" */
+/* The decoder table of a legacy encoding as uint16_t words (single byte: 128 code points for 0x80..0xFF;
+ * Big5 / EUC-JP: the index blob, layout in csrc/sx_codec_core.hpp); NULL, *n_words = 0 if the encoding has none. */
+const uint16_t* sx_decoder_table(uint32_t encoding, uint64_t* n_words);
 
 int  sx_abi_version(void);
 

@@ -1,95 +1,143 @@
 #!/usr/bin/env python3
-"""ORACLE helper (test infrastructure): generate sxo_tables.inc — the 128-entry
-high-half tables of the WHATWG single-byte decoders the oracle supports.
+"""ORACLE tables (test infrastructure): generates oracle/sxo_tables.inc from the ICU dumps in
+oracle/tables/ (made by oracle/tables/dump_icu.js with node's TextDecoder), NOT from CPython's codecs —
+the product's tables (stringsext_amd/csrc/gen_tables.py) come from CPython, so that the two sides of every
+parity test decode with tables of different origin.  tests/test_tables.py compares the two results cell by
+cell and keeps the list of raw disagreements (tests/golden/table_sources_report.txt).
 
-encoding_rs 0.8.34 is not vendored in /root/reference and there is no network,
-so the WHATWG index files are not available.  The tables are taken from CPython's
-codecs, with the places where the WHATWG indexes are known to differ patched in:
-  * bytes 0x80..0x9F that CPython leaves undefined in the windows-125x / windows-874
-    code pages map to the C1 control of the same value (WHATWG fills them; e.g.
-    index-windows-1252: 0x81,0x8D,0x8F,0x90,0x9D; index-windows-1251: 0x98); undefined
-    bytes from 0xA0 up stay undefined (malformed) in both;
-  * windows-1255 0xCA = U+05BA; KOI8-U 0xAE = U+045E, 0xBE = U+040E (the WHATWG index is
-    KOI8-RU's); x-mac-cyrillic 0xA2 = U+0490, 0xB6 = U+0491 (the WHATWG index is
-    x-mac-ukrainian's); ISO-8859-8-I shares ISO-8859-8's index.
-Parity of these tables is UNPINNED (no reference test covers any single-byte legacy
-encoding); the patches above are from memory of the standard.
+encoding_rs 0.8.34 (Cargo.toml:19) is not vendored in /root/reference and there is no network: the WHATWG
+index files themselves are not available.  ICU differs from them in known places, patched here:
+  single byte  KOI8-U 0xAE/0xBE = U+045E/U+040E (the WHATWG index is KOI8-RU's; ICU has real KOI8-U);
+               windows-874 0xDB..DE, 0xFC..FF unmapped (ICU: private use); windows-1253 0xAA unmapped
+               (ICU: U+00AA); windows-1255 0xCA = U+05BA (ICU: unmapped); ISO-8859-16 is unknown to this ICU
+               (row from oracle/tables/cpython_supplement.txt: single source).
+  Big5         ICU maps HKSCS and ETEN's C6A1..C8FE to the private use area; the WHATWG index has the HKSCS-2008
+               code points there -> those 4906 cells come from cpython_supplement.txt (single source).  The four
+               pointers that decode to two code points (1133, 1135, 1164, 1166) are handled by the decoder.
+  EUC-JP       jis0208: ICU's user-defined rows (private use) dropped; 8E E0..E2 (an ICU extension) dropped;
+               jis0212: the IBM extension rows 0xF3/0xF4 (ICU's eucJP-ms flavour) dropped — the WHATWG index is
+               JIS X 0212-1990 — and 0xA2B7 = U+FF5E as in ICU.
+Parity of all legacy tables is UNPINNED: no reference test decodes any of them.
 
-Order defines the encoding id (16 + index) and must only ever be appended to; names are
-Encoding::name().
-"""
+Order of the single-byte tables defines the encoding id (16 + index); names are Encoding::name()."""
+import os
 import sys
 
-TABLES = [
-    ("KOI8-R", "koi8_r", False),
-    ("IBM866", "cp866", False),
-    ("ISO-8859-2", "iso8859_2", False),
-    ("ISO-8859-5", "iso8859_5", False),
-    ("ISO-8859-15", "iso8859_15", False),
-    ("windows-1251", "cp1251", True),
-    ("windows-1252", "cp1252", True),
-    # --- the rest of the WHATWG single-byte set
-    ("ISO-8859-3", "iso8859_3", False),
-    ("ISO-8859-4", "iso8859_4", False),
-    ("ISO-8859-6", "iso8859_6", False),
-    ("ISO-8859-7", "iso8859_7", False),
-    ("ISO-8859-8", "iso8859_8", False),
-    ("ISO-8859-8-I", "iso8859_8", False),
-    ("ISO-8859-10", "iso8859_10", False),
-    ("ISO-8859-13", "iso8859_13", False),
-    ("ISO-8859-14", "iso8859_14", False),
-    ("ISO-8859-16", "iso8859_16", False),
-    ("KOI8-U", "koi8_u", False),
-    ("macintosh", "mac_roman", False),
-    ("windows-874", "cp874", True),
-    ("windows-1250", "cp1250", True),
-    ("windows-1253", "cp1253", True),
-    ("windows-1254", "cp1254", True),
-    ("windows-1255", "cp1255", True),
-    ("windows-1256", "cp1256", True),
-    ("windows-1257", "cp1257", True),
-    ("windows-1258", "cp1258", True),
-    ("x-mac-cyrillic", "mac_cyrillic", False),
-]
+HERE = os.path.dirname(os.path.abspath(__file__))
+TAB = os.path.join(HERE, "tables")
 
-PATCHES = {
-    "windows-1255": {0xCA: 0x05BA},
+SB_NAMES = ["KOI8-R", "IBM866", "ISO-8859-2", "ISO-8859-5", "ISO-8859-15", "windows-1251", "windows-1252",
+            "ISO-8859-3", "ISO-8859-4", "ISO-8859-6", "ISO-8859-7", "ISO-8859-8", "ISO-8859-8-I", "ISO-8859-10",
+            "ISO-8859-13", "ISO-8859-14", "ISO-8859-16", "KOI8-U", "macintosh", "windows-874", "windows-1250",
+            "windows-1253", "windows-1254", "windows-1255", "windows-1256", "windows-1257", "windows-1258",
+            "x-mac-cyrillic"]
+SB_PATCH = {
     "KOI8-U": {0xAE: 0x045E, 0xBE: 0x040E},
-    "x-mac-cyrillic": {0xA2: 0x0490, 0xB6: 0x0491},
+    "windows-874": {b: 0 for b in (0xDB, 0xDC, 0xDD, 0xDE, 0xFC, 0xFD, 0xFE, 0xFF)},
+    "windows-1253": {0xAA: 0},
+    "windows-1255": {0xCA: 0x05BA},
 }
+BIG5_N = 126 * 157
+JIS_N = 94 * 94
 
 
-def table(codec, c1_fill, name=None):
+def is_pua(cp):
+    return 0xE000 <= cp <= 0xF8FF
+
+
+def single_byte():
+    rows = {}
+    for line in open(os.path.join(TAB, "icu_single_byte.txt")):
+        p = line.split()
+        if p[1] != "UNSUPPORTED":
+            rows[p[0]] = [int(x, 16) for x in p[1:]]
+    for line in open(os.path.join(TAB, "cpython_supplement.txt")):
+        p = line.split()
+        if p[0] != "big5" and p[0] not in rows:
+            rows[p[0]] = [int(x, 16) for x in p[1:]]
     out = []
-    for b in range(0x80, 0x100):
-        try:
-            cp = ord(bytes([b]).decode(codec))
-        except UnicodeDecodeError:
-            cp = b if (c1_fill and b < 0xA0) else 0
-        cp = PATCHES.get(name, {}).get(b, cp)
-        out.append(cp)
+    for name in SB_NAMES:
+        r = list(rows[name.lower()])
+        for b, v in SB_PATCH.get(name, {}).items():
+            r[b - 0x80] = v
+        out.append(r)
     return out
 
 
-def emit(prefix, fh):
-    fh.write("/* GENERATED by gen_tables.py — do not edit. */\n")
-    fh.write(f"#define {prefix.upper()}_N_SB_TABLES {len(TABLES)}\n")
-    fh.write(f"static const char* const {prefix}_sb_names[{len(TABLES)}] = {{\n")
-    for name, _, _ in TABLES:
-        fh.write(f'    "{name}",\n')
+def big5_pointer(lead, trail):
+    return (lead - 0x81) * 157 + (trail - (0x40 if trail < 0x7F else 0x62))
+
+
+def big5():
+    t = [0] * BIG5_N
+    for line in open(os.path.join(TAB, "icu_big5.txt")):
+        k, v = line.split()
+        key = int(k, 16)
+        cps = [int(x, 16) for x in v.split("+")]
+        if len(cps) == 1 and not is_pua(cps[0]):
+            t[big5_pointer(key >> 8, key & 0xFF)] = cps[0]
+    for line in open(os.path.join(TAB, "cpython_supplement.txt")):
+        p = line.split()
+        if p[0] != "big5":
+            continue
+        key = int(p[1], 16)
+        cps = [int(x, 16) for x in p[2].split("+")]
+        ptr = big5_pointer(key >> 8, key & 0xFF)
+        if len(cps) == 1:
+            t[ptr] = cps[0]
+        else:
+            assert ptr in (1133, 1135, 1164, 1166), hex(key)
+    return t
+
+
+def euc_jp():
+    j208, j212 = [0] * JIS_N, [0] * JIS_N
+    for line in open(os.path.join(TAB, "icu_euc_jp.txt")):
+        k, v = line.split()
+        cps = [int(x, 16) for x in v.split("+")]
+        if len(cps) != 1 or is_pua(cps[0]):
+            continue
+        if len(k) == 4:
+            a, b = int(k[:2], 16), int(k[2:], 16)
+            if a >= 0xA1:
+                j208[(a - 0xA1) * 94 + (b - 0xA1)] = cps[0]
+        else:
+            a, b = int(k[2:4], 16), int(k[4:], 16)
+            if a not in (0xF3, 0xF4):
+                j212[(a - 0xA1) * 94 + (b - 0xA1)] = cps[0]
+    return j208, j212
+
+
+def emit_array(fh, ctype, name, values, per_line, width):
+    fh.write(f"static const {ctype} {name}[{len(values)}] = {{\n")
+    for i in range(0, len(values), per_line):
+        fh.write(" " + ",".join(f"0x{v:0{width}X}" for v in values[i:i + per_line]) + ",\n")
     fh.write("};\n")
-    fh.write(f"static const uint16_t {prefix}_sb_tables[{len(TABLES)}][128] = {{\n")
-    for name, codec, fill in TABLES:
-        t = table(codec, fill, name)
-        fh.write(f"    /* {name} */ {{\n")
-        for i in range(0, 128, 8):
-            fh.write("        " + ", ".join(f"0x{v:04X}" for v in t[i:i + 8]) + ",\n")
-        fh.write("    },\n")
-    fh.write("};\n")
+
+
+def emit(path):
+    sb = single_byte()
+    b5 = big5()
+    j208, j212 = euc_jp()
+    with open(path, "w") as fh:
+        fh.write("/* GENERATED by oracle/gen_tables.py from oracle/tables/ (ICU dumps) - do not edit. */\n")
+        fh.write(f"#define SXO_N_SB_TABLES {len(SB_NAMES)}\n")
+        fh.write(f"static const char* const sxo_sb_names[{len(SB_NAMES)}] = {{\n")
+        for name in SB_NAMES:
+            fh.write(f'    "{name}",\n')
+        fh.write("};\n")
+        fh.write(f"static const uint16_t sxo_sb_tables[{len(SB_NAMES)}][128] = {{\n")
+        for name, r in zip(SB_NAMES, sb):
+            fh.write(f"    /* {name} */ {{\n")
+            for i in range(0, 128, 8):
+                fh.write("        " + ", ".join(f"0x{v:04X}" for v in r[i:i + 8]) + ",\n")
+            fh.write("    },\n")
+        fh.write("};\n")
+        fh.write(f"#define SXO_BIG5_N {BIG5_N}\n#define SXO_JIS_N {JIS_N}\n")
+        emit_array(fh, "uint32_t", "sxo_big5", b5, 12, 5)
+        emit_array(fh, "uint16_t", "sxo_jis0208", j208, 16, 4)
+        emit_array(fh, "uint16_t", "sxo_jis0212", j212, 16, 4)
 
 
 if __name__ == "__main__":
-    prefix = sys.argv[1] if len(sys.argv) > 1 else "sxo"
-    path = sys.argv[2] if len(sys.argv) > 2 else "sxo_tables.inc"
-    with open(path, "w") as fh:
-        emit(prefix, fh)
+    emit(sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "sxo_tables.inc"))

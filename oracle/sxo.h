@@ -17,14 +17,15 @@
  * Third-party arithmetic restated from its published algorithm (the crate is
  * NOT in /root/reference): encoding_rs 0.8.34 (Cargo.toml:19,
  * Cargo.lock:147-150) — WHATWG Encoding Standard decoders for UTF-8,
- * UTF-16LE/BE, x-user-defined and single-byte tables, with the crate's
+ * UTF-16LE/BE, x-user-defined, single-byte tables, Big5 and EUC-JP, with the crate's
  * `decode_to_str_without_replacement` (read, written, Malformed) contract.
  *
  * Pin status: pinned against tests/functional/expected_output1/2/3 and the
  * in-file unit-test known answers of scanner.rs, finding_collection.rs,
  * helper.rs, main.rs (see tests/test_oracle_*.py).  UTF-16 surrogate
  * accounting, UTF-16BE output and the UTF-8 "un-read" rule have no golden
- * vector in the reference: those parts are "parity unpinned" (DESIGN.md §3).
+ * vector in the reference: those parts are "parity unpinned" (DESIGN.md §3),
+ * and so is every legacy encoding (tables from ICU dumps, oracle/gen_tables.py).
  */
 #ifndef SXO_H
 #define SXO_H
@@ -36,7 +37,8 @@ extern "C" {
 #endif
 
 enum { SXO_ENC_X_USER_DEFINED = 0, SXO_ENC_UTF8 = 1, SXO_ENC_UTF16LE = 2, SXO_ENC_UTF16BE = 3,
-       SXO_ENC_SINGLE_BYTE_BASE = 16 /* + table index, see sxo_single_byte_name */ };
+       SXO_ENC_SINGLE_BYTE_BASE = 16 /* + table index, see sxo_single_byte_name */,
+       SXO_ENC_BIG5 = 64, SXO_ENC_EUC_JP = 65 };
 
 enum { SXO_BEFORE = 0, SXO_EXACT = 1, SXO_AFTER = 2 };
 

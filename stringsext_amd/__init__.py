@@ -22,13 +22,14 @@ ENC = {"x-user-defined": 0, "utf-8": 1, "utf-16le": 2, "utf-16be": 3, "koi8-r": 
        "iso-8859-8-i": 28, "iso-8859-10": 29, "iso-8859-13": 30, "iso-8859-14": 31, "iso-8859-16": 32,
        "koi8-u": 33, "macintosh": 34, "windows-874": 35, "windows-1250": 36, "windows-1253": 37,
        "windows-1254": 38, "windows-1255": 39, "windows-1256": 40, "windows-1257": 41, "windows-1258": 42,
-       "x-mac-cyrillic": 43}
+       "x-mac-cyrillic": 43, "big5": 64, "euc-jp": 65}
 PRECISION = {0: "Before", 1: "Exact", 2: "After"}
 
 # every symbol include/stringsext_amd.h declares
 EXPORTS = ["sx_abi_version", "sx_create", "sx_destroy", "sx_last_error", "sx_scan", "sx_scan_device", "sx_reset",
            "sx_device_runs", "sx_replay_runs", "sx_scan_shard_device", "sx_scan_shard", "sx_replay_shard_runs",
            "sx_scan_stream", "sx_scan_file", "sx_missions_from_flags", "sx_parse_enc_opt", "sx_encoding_for_label", "sx_encoding_name",
+           "sx_decoder_table",
            "sx_result_count", "sx_result_segments", "sx_result_segment", "sx_result_findings", "sx_result_arena",
            "sx_result_free", "sx_print_findings", "sx_get_stats", "sx_free", "sx_fill_background_device",
            "sx_device_alloc", "sx_device_free", "sx_device_upload", "sx_device_download",
@@ -107,6 +108,15 @@ def encoding_name(enc):
     L.sx_encoding_name.argtypes, L.sx_encoding_name.restype = [C.c_uint32], C.c_char_p
     s = L.sx_encoding_name(enc)
     return s.decode() if s else None
+
+
+def decoder_table(enc):
+    """The decoder table of a legacy encoding as a ctypes uint16 array view (None if it has none)."""
+    L = lib()
+    L.sx_decoder_table.argtypes, L.sx_decoder_table.restype = [C.c_uint32, C.POINTER(C.c_uint64)], C.POINTER(C.c_uint16)
+    n = C.c_uint64()
+    t = L.sx_decoder_table(enc, C.byref(n))
+    return (t, n.value) if n.value else None
 
 
 def encoding_for_label(label):

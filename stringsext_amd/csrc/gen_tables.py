@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
-"""Generate sx_tables.inc — the 128-entry
-high-half tables of the WHATWG single-byte decoders the product supports.
+"""Generate sx_tables.inc — the PRODUCT's decoder tables, from CPython's codecs (the oracle's tables come from
+ICU dumps instead, oracle/gen_tables.py; tests/test_tables.py compares the two cell by cell).
 
-encoding_rs 0.8.34 is not vendored in /root/reference and there is no network,
-so the WHATWG index files are not available.  The tables are taken from CPython's
-codecs, with the places where the WHATWG indexes are known to differ patched in:
-  * bytes 0x80..0x9F that CPython leaves undefined in the windows-125x / windows-874
-    code pages map to the C1 control of the same value (WHATWG fills them; e.g.
-    index-windows-1252: 0x81,0x8D,0x8F,0x90,0x9D; index-windows-1251: 0x98); undefined
-    bytes from 0xA0 up stay undefined (malformed) in both;
-  * windows-1255 0xCA = U+05BA; KOI8-U 0xAE = U+045E, 0xBE = U+040E (the WHATWG index is
-    KOI8-RU's); x-mac-cyrillic 0xA2 = U+0490, 0xB6 = U+0491 (the WHATWG index is
-    x-mac-ukrainian's); ISO-8859-8-I shares ISO-8859-8's index.
-Parity of these tables is UNPINNED (no reference test covers any single-byte legacy
-encoding); the patches above are from memory of the standard.
+encoding_rs 0.8.34 is not vendored in /root/reference and there is no network, so the WHATWG index files are
+not available.  CPython differs from them in known places, patched here:
+  single byte
+  * bytes 0x80..0x9F that CPython leaves undefined in the windows-125x / windows-874 code pages map to the C1
+    control of the same value (WHATWG fills them); undefined bytes from 0xA0 up stay undefined in both;
+  * windows-1255 0xCA = U+05BA; KOI8-U 0xAE = U+045E, 0xBE = U+040E (the WHATWG index is KOI8-RU's);
+    x-mac-cyrillic 0xA2 = U+0490, 0xB6 = U+0491 (the WHATWG index is x-mac-ukrainian's); ISO-8859-8-I shares
+    ISO-8859-8's index.
+  Big5 (index-big5: Big5 + HKSCS-2008, Microsoft flavour in the standard rows)
+  * `big5hkscs` everywhere, except that a cell `cp950` maps outside ETEN's block C6A1..C8FE takes cp950's value
+    (12 symbols in rows A1/A2 and F9FE differ; A3E1 = U+20AC only cp950 has), and inside that block the six cells
+    only cp950 has (C6CF, C6D3, C6D5, C6D7, C6DE, C6DF) are kept;
+  * pointers 1133, 1135, 1164, 1166 (two code points each) are left 0: the decoder handles them.
+  EUC-JP (index-jis0208 is Windows-31J's table: NEC row 13 and the IBM extension rows 89..92 included)
+  * jis0208 from `cp932` through the Shift_JIS pointer arithmetic; jis0212 from `euc_jp`'s three-byte form with
+    0xA2B7 = U+FF5E (CPython: U+007E).
+Parity of all legacy tables is UNPINNED (no reference test decodes any of them).
 
-Order defines the encoding id (16 + index) and must only ever be appended to; names are
+Order of the single-byte tables defines the encoding id (16 + index) and must only ever be appended to; names are
 Encoding::name().
 """
 import sys
@@ -71,6 +76,62 @@ def table(codec, c1_fill, name=None):
     return out
 
 
+BIG5_N = 126 * 157
+JIS_N = 94 * 94
+
+
+def cps(codec, bs):
+    try:
+        return [ord(c) for c in bytes(bs).decode(codec)]
+    except UnicodeDecodeError:
+        return None
+
+
+def big5_table():
+    """pointer -> code point (0 = unmapped)"""
+    t = [0] * BIG5_N
+    for lead in range(0x81, 0xFF):
+        for trail in list(range(0x40, 0x7F)) + list(range(0xA1, 0xFF)):
+            ptr = (lead - 0x81) * 157 + (trail - (0x40 if trail < 0x7F else 0x62))
+            in_eten_block = (lead == 0xC6 and trail >= 0xA1) or lead in (0xC7, 0xC8)
+            ms = cps("cp950", [lead, trail])
+            hk = cps("big5hkscs", [lead, trail])
+            v = ms if (ms and not in_eten_block) else (hk or ms)
+            if v and len(v) == 1:
+                t[ptr] = v[0]
+    return t
+
+
+def jis0208_table():
+    t = [0] * JIS_N
+    for p in range(JIS_N):  # the index is shared with Shift_JIS: pointer -> Shift_JIS bytes -> cp932
+        lead, trail = divmod(p, 188)
+        b0 = lead + (0x81 if lead < 0x1F else 0xC1)
+        b1 = trail + (0x40 if trail < 0x3F else 0x41)
+        v = cps("cp932", [b0, b1])
+        if v and len(v) == 1:
+            t[p] = v[0]
+    return t
+
+
+def jis0212_table():
+    t = [0] * JIS_N
+    for a in range(0xA1, 0xFF):
+        for b in range(0xA1, 0xFF):
+            v = cps("euc_jp", [0x8F, a, b])
+            if v and len(v) == 1:
+                t[(a - 0xA1) * 94 + (b - 0xA1)] = v[0]
+    t[(0xA2 - 0xA1) * 94 + (0xB7 - 0xA1)] = 0xFF5E
+    return t
+
+
+def emit_array(fh, ctype, name, values, per_line, width):
+    fh.write(f"static const {ctype} {name}[{len(values)}] = {{\n")
+    for i in range(0, len(values), per_line):
+        fh.write(" " + ",".join(f"0x{v:0{width}X}" for v in values[i:i + per_line]) + ",\n")
+    fh.write("};\n")
+
+
 def emit(prefix, fh):
     fh.write("/* GENERATED by gen_tables.py — do not edit. */\n")
     fh.write(f"#define {prefix.upper()}_N_SB_TABLES {len(TABLES)}\n")
@@ -86,10 +147,24 @@ def emit(prefix, fh):
             fh.write("        " + ", ".join(f"0x{v:04X}" for v in t[i:i + 8]) + ",\n")
         fh.write("    },\n")
     fh.write("};\n")
+    # double-byte: Big5 as the low 16 bits + a bitmap of the cells in plane 2 (every astral Big5 character is)
+    b5 = big5_table()
+    assert all(v < 0x10000 or (v >> 16) == 2 for v in b5)
+    plane2 = [0] * ((BIG5_N + 15) // 16)
+    for p, v in enumerate(b5):
+        if v >> 16:
+            plane2[p >> 4] |= 1 << (p & 15)
+    # one blob of uint16_t per encoding (it goes to the device as it is):
+    #   Big5:   [BIG5_N low halves][BIG5_P2_WORDS bitmap words: pointer p is in plane 2 iff bit p&15 of word p>>4]
+    #   EUC-JP: [JIS_N jis0208][JIS_N jis0212]
+    fh.write(f"#define {prefix.upper()}_BIG5_N {BIG5_N}\n#define {prefix.upper()}_BIG5_P2_WORDS {len(plane2)}\n"
+             f"#define {prefix.upper()}_JIS_N {JIS_N}\n")
+    emit_array(fh, "uint16_t", f"{prefix}_big5", [v & 0xFFFF for v in b5] + plane2, 16, 4)
+    emit_array(fh, "uint16_t", f"{prefix}_eucjp", jis0208_table() + jis0212_table(), 16, 4)
 
 
 if __name__ == "__main__":
-    prefix = sys.argv[1] if len(sys.argv) > 1 else "sxo"
-    path = sys.argv[2] if len(sys.argv) > 2 else "sxo_tables.inc"
+    prefix = sys.argv[1] if len(sys.argv) > 1 else "sx"
+    path = sys.argv[2] if len(sys.argv) > 2 else "sx_tables.inc"
     with open(path, "w") as fh:
         emit(prefix, fh)

@@ -140,6 +140,13 @@ extern "C" {
 
 int sx_abi_version(void) { return SX_ABI_VERSION; }
 
+const uint16_t* sx_decoder_table(uint32_t encoding, uint64_t* n_words) {
+    size_t n = 0;
+    const uint16_t* t = decoder_table((int)encoding, &n);
+    if (n_words) *n_words = n;
+    return t;
+}
+
 int sx_create(sx_ctx** out, const sx_mission* missions, int n_missions, int hip_device, const sx_options* opt) {
     if (!out || !missions || n_missions <= 0 || n_missions > 26) { g_create_error = "bad arguments"; return SX_E_INVALID; }
     sx_ctx* ctx = new sx_ctx();

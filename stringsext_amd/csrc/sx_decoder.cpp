@@ -1,10 +1,7 @@
-// sx_decoder.cpp — the decoders the scan needs, with the call contract of encoding_rs
-// 0.8.34 `Decoder::decode_to_str_without_replacement` (the crate is a Cargo dependency of
-// the reference, Cargo.toml:19; call sites src/finding_collection.rs:138-143,180-194).
-// Algorithms: WHATWG Encoding Standard "utf-8 decoder", "utf-16 decoder" (with the
-// crate's streaming treatment of unpaired surrogates), "x-user-defined decoder",
-// "single-byte decoder".  What matters to the caller is (result, read, written):
-// a malformed sequence ends the call; `read` says where the next call starts.
+// sx_decoder.cpp — the host-side `Decoder` and `SplitStr` classes of sx_host.hpp (the reference's
+// operator interface: encoding_rs `Decoder` as used at src/finding_collection.rs:138-143,180-194,
+// `SplitStr` src/helper.rs:58-433) as thin wrappers around the product's ONE implementation,
+// sx_codec_core.hpp — the same source the device replay kernels are compiled from.
 #include <string.h>
 
 #include "sx_host.hpp"
@@ -13,9 +10,27 @@ namespace sx {
 
 #include "sx_tables.inc"
 
+static_assert(SX_BIG5_N == kBig5N && SX_BIG5_P2_WORDS == kBig5P2Words && SX_JIS_N == kJisN, "table layout");
+static_assert(SX_ENC_BIG5 == kEncBig5 && SX_ENC_EUC_JP == kEncEucJp, "encoding ids");
+
 const uint16_t* single_byte_table(int enc) {
     if (enc >= SX_ENC_KOI8_R && enc < SX_ENC_KOI8_R + SX_N_SB_TABLES) return sx_sb_tables[enc - SX_ENC_KOI8_R];
     return nullptr;
+}
+
+const uint16_t* decoder_table(int enc, size_t* n_words) {
+    size_t n = 0;
+    const uint16_t* t = nullptr;
+    if (enc == SX_ENC_BIG5) { t = sx_big5; n = sizeof sx_big5 / sizeof sx_big5[0]; }
+    else if (enc == SX_ENC_EUC_JP) { t = sx_eucjp; n = sizeof sx_eucjp / sizeof sx_eucjp[0]; }
+    else if ((t = single_byte_table(enc)) != nullptr) n = 128;
+    if (n_words) *n_words = n;
+    return t;
+}
+
+bool encoding_is_known(int enc) {
+    return enc == SX_ENC_X_USER_DEFINED || enc == SX_ENC_UTF8 || enc == SX_ENC_UTF16LE || enc == SX_ENC_UTF16BE
+           || decoder_table(enc, nullptr) != nullptr;
 }
 
 const char* encoding_name(int enc) {
@@ -24,153 +39,43 @@ const char* encoding_name(int enc) {
     case SX_ENC_UTF8: return "UTF-8";
     case SX_ENC_UTF16LE: return "UTF-16LE";
     case SX_ENC_UTF16BE: return "UTF-16BE";
+    case SX_ENC_BIG5: return "Big5";
+    case SX_ENC_EUC_JP: return "EUC-JP";
     default:
         if (enc >= SX_ENC_KOI8_R && enc < SX_ENC_KOI8_R + SX_N_SB_TABLES) return sx_sb_names[enc - SX_ENC_KOI8_R];
         return "?";
     }
 }
 
-void Decoder::reset(int encoding) {
-    enc_ = encoding;
-    cp_ = 0; seen_ = needed_ = 0; lower_ = 0x80; upper_ = 0xBF;
-    lead_byte_ = -1; lead_surrogate_ = 0; pending_bmp_ = false;
-    table_ = single_byte_table(encoding);
-}
-
-static inline size_t encode_utf8(uint8_t* d, uint32_t c) {
-    if (c < 0x80) { d[0] = (uint8_t)c; return 1; }
-    if (c < 0x800) { d[0] = (uint8_t)(0xC0 | (c >> 6)); d[1] = (uint8_t)(0x80 | (c & 0x3F)); return 2; }
-    if (c < 0x10000) {
-        d[0] = (uint8_t)(0xE0 | (c >> 12)); d[1] = (uint8_t)(0x80 | ((c >> 6) & 0x3F));
-        d[2] = (uint8_t)(0x80 | (c & 0x3F));
-        return 3;
-    }
-    d[0] = (uint8_t)(0xF0 | (c >> 18)); d[1] = (uint8_t)(0x80 | ((c >> 12) & 0x3F));
-    d[2] = (uint8_t)(0x80 | ((c >> 6) & 0x3F)); d[3] = (uint8_t)(0x80 | (c & 0x3F));
-    return 4;
-}
+void Decoder::reset(int encoding) { ddec_reset(d_, encoding, decoder_table(encoding, nullptr)); }
 
 DecodeStep Decoder::decode_to_str_without_replacement(const uint8_t* src, size_t n, uint8_t* dst, size_t cap,
                                                       bool last) {
-    switch (enc_) {
-    case SX_ENC_UTF8: return utf8(src, n, dst, cap, last);
-    case SX_ENC_UTF16LE:
-    case SX_ENC_UTF16BE: return utf16(src, n, dst, cap, last);
-    default: return single(src, n, dst, cap);
+    const DStep r = ddecode_any(d_, src, (u32)n, dst, (u32)(cap > 0xFFFFFFFFu ? 0xFFFFFFFFu : cap), last);
+    return { r.result == RES_INPUT_EMPTY ? DecoderResult::InputEmpty
+                                         : r.result == RES_MALFORMED ? DecoderResult::Malformed : DecoderResult::OutputFull,
+             r.read, r.written };
+}
+
+bool Decoder::idle() const { return ddec_idle_any(d_); }
+
+uint32_t Decoder::entry_skip(const uint8_t* s, uint64_t avail) const {
+    switch (enc_family((u32)d_.enc)) {
+    case 4: return dbcs_entry_skip<4>(d_, s, avail);
+    case 5: return dbcs_entry_skip<5>(d_, s, avail);
+    default: return 0;
     }
 }
 
-// UTF-8.  A byte outside the expected continuation range ends the call as Malformed and
-// is NOT consumed (the next call starts at it); a bad lead byte is consumed.
-DecodeStep Decoder::utf8(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, bool last) {
-    size_t i = 0, w = 0;
-    auto clear = [this]() { cp_ = 0; needed_ = seen_ = 0; lower_ = 0x80; upper_ = 0xBF; };
-    while (true) {
-        if (needed_ == 0) {  // bulk ASCII
-            while (i < n && src[i] < 0x80 && cap - w >= 4) dst[w++] = src[i++];
-        }
-        if (i >= n) {
-            if (last && needed_ != 0) { clear(); return { DecoderResult::Malformed, i, w }; }
-            return { DecoderResult::InputEmpty, i, w };
-        }
-        if (cap - w < 4) return { DecoderResult::OutputFull, i, w };
-        const uint8_t b = src[i++];
-        if (needed_ == 0) {
-            if (b < 0x80) { dst[w++] = b; continue; }
-            if (b >= 0xC2 && b <= 0xDF) { needed_ = 1; cp_ = b & 0x1F; continue; }
-            if (b >= 0xE0 && b <= 0xEF) {
-                if (b == 0xE0) lower_ = 0xA0;
-                if (b == 0xED) upper_ = 0x9F;
-                needed_ = 2; cp_ = b & 0x0F; continue;
-            }
-            if (b >= 0xF0 && b <= 0xF4) {
-                if (b == 0xF0) lower_ = 0x90;
-                if (b == 0xF4) upper_ = 0x8F;
-                needed_ = 3; cp_ = b & 0x07; continue;
-            }
-            return { DecoderResult::Malformed, i, w };
-        }
-        if (b < lower_ || b > upper_) { clear(); return { DecoderResult::Malformed, i - 1, w }; }
-        lower_ = 0x80; upper_ = 0xBF;
-        cp_ = (cp_ << 6) | (b & 0x3F);
-        if (++seen_ != needed_) continue;
-        w += encode_utf8(dst + w, cp_);
-        cp_ = 0; needed_ = seen_ = 0;
-    }
-}
-
-// UTF-16.  Whole units are converted in bulk while nothing is pending; an unpaired
-// surrogate met there ends the call right after that unit.  A high surrogate that is the
-// last whole unit of the input becomes pending; if the following call then sees a BMP
-// unit (or another high surrogate) the call ends Malformed with that unit consumed too —
-// a BMP unit is remembered and written first thing by the next call.
-DecodeStep Decoder::utf16(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, bool last) {
-    const bool be = enc_ == SX_ENC_UTF16BE;
-    auto unit_at = [&](size_t k) -> uint16_t {
-        return be ? (uint16_t)((src[k] << 8) | src[k + 1]) : (uint16_t)((src[k + 1] << 8) | src[k]);
-    };
-    size_t i = 0, w = 0;
-    if (pending_bmp_) {
-        if (cap - w < 3) return { DecoderResult::OutputFull, 0, 0 };
-        w += encode_utf8(dst + w, lead_surrogate_);
-        pending_bmp_ = false; lead_surrogate_ = 0;
-    }
-    while (true) {
-        if (lead_byte_ < 0 && lead_surrogate_ == 0) {
-            while (n - i >= 2 && cap - w >= 4) {
-                const uint16_t u = unit_at(i);
-                if ((u & 0xF800) != 0xD800) { w += encode_utf8(dst + w, u); i += 2; continue; }
-                if ((u & 0xFC00) == 0xDC00) { i += 2; return { DecoderResult::Malformed, i, w }; }
-                if (n - i < 4) break;  // high surrogate, last whole unit: goes pending below
-                const uint16_t v = unit_at(i + 2);
-                if ((v & 0xFC00) != 0xDC00) { i += 2; return { DecoderResult::Malformed, i, w }; }
-                w += encode_utf8(dst + w, 0x10000u + (((uint32_t)u & 0x3FF) << 10) + (v & 0x3FF));
-                i += 4;
-            }
-        }
-        if (i >= n) {
-            if (last && (lead_surrogate_ != 0 || lead_byte_ >= 0)) {
-                lead_surrogate_ = 0; lead_byte_ = -1;
-                return { DecoderResult::Malformed, i, w };
-            }
-            return { DecoderResult::InputEmpty, i, w };
-        }
-        if (cap - w < 4) return { DecoderResult::OutputFull, i, w };
-        const uint8_t b = src[i++];
-        if (lead_byte_ < 0) { lead_byte_ = b; continue; }
-        const uint16_t u = be ? (uint16_t)((lead_byte_ << 8) | b) : (uint16_t)((b << 8) | lead_byte_);
-        lead_byte_ = -1;
-        if ((u & 0xFC00) == 0xD800) {
-            if (lead_surrogate_ != 0) { lead_surrogate_ = u; return { DecoderResult::Malformed, i, w }; }
-            lead_surrogate_ = u;
-            continue;
-        }
-        if ((u & 0xFC00) == 0xDC00) {
-            if (lead_surrogate_ == 0) return { DecoderResult::Malformed, i, w };
-            w += encode_utf8(dst + w, 0x10000u + (((uint32_t)lead_surrogate_ & 0x3FF) << 10) + (u & 0x3FF));
-            lead_surrogate_ = 0;
-            continue;
-        }
-        if (lead_surrogate_ != 0) {
-            lead_surrogate_ = u; pending_bmp_ = true;
-            return { DecoderResult::Malformed, i, w };
-        }
-        w += encode_utf8(dst + w, u);
-    }
-}
-
-// x-user-defined (0x80..0xFF -> U+F780..U+F7FF) and table-driven single-byte encodings.
-DecodeStep Decoder::single(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
-    size_t i = 0, w = 0;
-    while (true) {
-        if (i >= n) return { DecoderResult::InputEmpty, i, w };
-        if (cap - w < 3) return { DecoderResult::OutputFull, i, w };
-        const uint8_t b = src[i++];
-        if (b < 0x80) { dst[w++] = b; continue; }
-        const uint32_t c = table_ ? table_[b - 0x80] : 0xF780u + (b - 0x80u);
-        if (c == 0) return { DecoderResult::Malformed, i, w };
-        w += encode_utf8(dst + w, c);
-    }
+// SplitStr::next — src/helper.rs:206-433
+bool SplitStr::next(SplitStrResult* out) {
+    DChunk ch;
+    if (!dsplit_next(pm_, it_, ch)) return false;
+    out->s = ch.s; out->len = ch.len;
+    out->s_completes_previous_s = ch.completes; out->s_is_maybe_cut = ch.maybe_cut;
+    out->s_is_to_be_filtered_again = ch.again; out->s_satisfies_min_char_rule = ch.min_ok;
+    out->s_satisfies_grep_char_rule = ch.grep_ok;
+    return true;
 }
 
 }  // namespace sx

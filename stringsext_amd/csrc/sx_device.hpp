@@ -79,7 +79,7 @@ struct ReplayParams {
     uint64_t consumed0, stream0;
     uint32_t slice_base;
     uint32_t encoding;        // SX_ENC_*
-    const uint16_t* table;    // device: 128-entry single-byte table or nullptr
+    const uint16_t* table;    // device: 128-entry single-byte table, Big5 / EUC-JP blob (sx_codec_core.hpp), or nullptr
     uint32_t chars_min_nb, same_block, q, W, long_run;
     uint32_t skip;            // 1: take the shortcuts of sx_replay_core.hpp (0: decode every byte, for comparison)
     int32_t grep_char, mission_id, file_id;
@@ -92,6 +92,7 @@ struct ReplayParams {
     uint64_t arena_bytes;
     const uint32_t* head_list;   // head_list[slot] = run index: the replay kernels take one lane per REPLAYING run
     uint32_t max_windows;        // a region that needs more windows is given back (kRegionTooLong)
+    uint32_t entry_skip;         // double-byte encodings: bytes at the buffer start that finish the token pending on entry
 };
 struct ReplayRegionOut {
     uint64_t end;             // where the region's replay stopped (a window start, buffer relative)

@@ -218,10 +218,13 @@ const Label kLabels[] = {
     { "cp1257", SX_ENC_WINDOWS_1257 }, { "windows-1257", SX_ENC_WINDOWS_1257 }, { "x-cp1257", SX_ENC_WINDOWS_1257 },
     { "cp1258", SX_ENC_WINDOWS_1258 }, { "windows-1258", SX_ENC_WINDOWS_1258 }, { "x-cp1258", SX_ENC_WINDOWS_1258 },
     { "x-mac-cyrillic", SX_ENC_X_MAC_CYRILLIC }, { "x-mac-ukrainian", SX_ENC_X_MAC_CYRILLIC },
+    { "big5", SX_ENC_BIG5 }, { "big5-hkscs", SX_ENC_BIG5 }, { "cn-big5", SX_ENC_BIG5 }, { "csbig5", SX_ENC_BIG5 },
+    { "x-x-big5", SX_ENC_BIG5 },
+    { "cseucpkdfmtjapanese", SX_ENC_EUC_JP }, { "euc-jp", SX_ENC_EUC_JP }, { "x-euc-jp", SX_ENC_EUC_JP },
 };
 // labels of the encodings encoding_rs has and this library does not (help.rs:54-96 lists their names)
 const char* const kOtherLabels[] = {
-    "big5", "big5-hkscs", "cn-big5", "csbig5", "x-x-big5", "euc-jp", "cseucpkdfmtjapanese", "x-euc-jp", "shift_jis", "sjis",
+    "shift_jis", "sjis",
     "ms_kanji", "shift-jis", "windows-31j", "x-sjis", "csshiftjis", "ms932", "iso-2022-jp", "csiso2022jp", "euc-kr", "cseuckr",
     "korean", "windows-949", "ks_c_5601-1987", "ksc5601", "ksc_5601", "iso-ir-149", "ks_c_5601-1989", "csksc56011987", "gbk",
     "gb2312", "chinese", "csgb2312", "csiso58gb231280", "gb_2312", "gb_2312-80", "iso-ir-58", "x-gbk", "gb18030", "replacement",
@@ -280,6 +283,8 @@ const char* sx_encoding_name(uint32_t encoding) {  // Encoding::name()
         case SX_ENC_WINDOWS_1256: return "windows-1256";
         case SX_ENC_WINDOWS_1257: return "windows-1257";
         case SX_ENC_WINDOWS_1258: return "windows-1258";
+        case SX_ENC_BIG5: return "Big5";
+        case SX_ENC_EUC_JP: return "EUC-JP";
         case SX_ENC_X_MAC_CYRILLIC: return "x-mac-cyrillic";
         default: return nullptr;
     }
@@ -360,7 +365,7 @@ int sx_missions_from_flags(const sx_cli_flags* f, sx_mission* out, int cap, int*
         }
         if (enc == -2) {
             e.fail(scanner + "encoding `" + name + "` is known to the reference but not built into this library "
-                             "(UTF-8, UTF-16LE/BE, ascii, x-user-defined and 7 single-byte encodings are).");
+                             "(UTF-8, UTF-16LE/BE, ascii, x-user-defined, the 28 single-byte encodings, Big5 and EUC-JP are).");
             return bail(SX_E_INVALID);
         }
         m.encoding = (uint8_t)enc;

@@ -18,6 +18,11 @@
 #include <vector>
 
 #include "sx_device.hpp"
+#ifndef SXD
+#define SXD inline
+#define SXD_NOINLINE inline
+#endif
+#include "sx_codec_core.hpp"
 
 namespace sx {
 
@@ -69,28 +74,21 @@ class Decoder {
 public:
     explicit Decoder(int encoding = SX_ENC_UTF8) { reset(encoding); }
     void reset(int encoding);
-    int encoding() const { return enc_; }
-    Decoder new_decoder_without_bom_handling() const { return Decoder(enc_); }
+    int encoding() const { return d_.enc; }
+    Decoder new_decoder_without_bom_handling() const { return Decoder(d_.enc); }
     DecodeStep decode_to_str_without_replacement(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, bool last);
-    // nothing pending: no partial UTF-8 sequence, no half UTF-16 unit, no surrogate waiting for its pair
-    bool idle() const { return needed_ == 0 && lead_byte_ < 0 && lead_surrogate_ == 0 && !pending_bmp_; }
+    // nothing pending: no partial UTF-8 sequence, no half UTF-16 unit, no surrogate waiting for its pair, no lead byte
+    bool idle() const;
+    // double-byte encodings: how many of the next bytes finish the token that is pending now (0: none pending,
+    // or its last byte will be given back) — where the token grid of what follows begins
+    uint32_t entry_skip(const uint8_t* next_bytes, uint64_t avail) const;
 
 private:
-    DecodeStep utf8(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, bool last);
-    DecodeStep utf16(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, bool last);
-    DecodeStep single(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
-    int enc_ = SX_ENC_UTF8;
-    // UTF-8
-    uint32_t cp_ = 0;
-    uint8_t seen_ = 0, needed_ = 0, lower_ = 0x80, upper_ = 0xBF;
-    // UTF-16
-    int lead_byte_ = -1;
-    uint16_t lead_surrogate_ = 0;
-    bool pending_bmp_ = false;
-    // single byte
-    const uint16_t* table_ = nullptr;
+    DDecoder d_;  // the one decoder implementation, sx_codec_core.hpp
 };
 const uint16_t* single_byte_table(int encoding);  // nullptr for x-user-defined / non-table encodings
+const uint16_t* decoder_table(int encoding, size_t* n_words);  // single-byte table or Big5 / EUC-JP blob (sx_codec_core.hpp)
+bool encoding_is_known(int encoding);
 const char* encoding_name(int encoding);
 
 // ---------------------------------------------------------------------------------------
@@ -106,17 +104,13 @@ class SplitStr {
 public:
     SplitStr(const uint8_t* inp, size_t len, uint8_t chars_min_nb, bool require_same_unicode_block,
              bool last_s_was_maybe_cut, bool invalid_bytes_after_inp, const Utf8Filter& f, size_t s_char_nb_max)
-        : inp_start_(inp), inp_end_(inp + len), p_(inp), chars_min_nb_(chars_min_nb),
-          same_block_(require_same_unicode_block), last_cut_(last_s_was_maybe_cut),
-          invalid_after_(invalid_bytes_after_inp), f_(f), max_(s_char_nb_max) {}
+        : pm_{ f.af_lo, f.af_hi, f.ubf, f.grep_char, (uint32_t)s_char_nb_max, chars_min_nb, require_same_unicode_block ? 1u : 0u },
+          it_{ inp, inp + len, inp, last_s_was_maybe_cut, invalid_bytes_after_inp } {}
     bool next(SplitStrResult* out);
 
 private:
-    const uint8_t *inp_start_, *inp_end_, *p_;
-    uint8_t chars_min_nb_;
-    bool same_block_, last_cut_, invalid_after_;
-    Utf8Filter f_;
-    size_t max_;
+    SplitParams pm_;
+    DSplit it_;  // the one SplitStr implementation, sx_codec_core.hpp
 };
 
 // ---------------------------------------------------------------------------------------

@@ -36,59 +36,6 @@
 namespace sx {
 
 // ---------------------------------------------------------------------------------------
-// SplitStr::next — src/helper.rs:206-433
-// ---------------------------------------------------------------------------------------
-bool SplitStr::next(SplitStrResult* out) {
-    const bool grep_needed = f_.grep_char >= 0;
-    bool grep_char_ok = !grep_needed;
-    const uint8_t* ok_s_p = p_;
-    size_t ok_s_len = 0, ok_char_nb = 0;
-    uint8_t last_multi_char_leading_byte = 0;
-
-    while (p_ < inp_end_ && ok_char_nb < max_) {  // exits 1 and 2, :237
-        const uint8_t lead = *p_;
-        size_t char_len = 1;
-        if ((lead & 0x80) == 0) {
-            if (!grep_char_ok && f_.grep_char == lead) grep_char_ok = true;  // :252
-        } else if ((lead & 0xE0) == 0xC0) char_len = 2;
-        else if ((lead & 0xF0) == 0xE0) char_len = 3;
-        else if ((lead & 0xF8) == 0xF0) char_len = 4;
-
-        bool char_is_ok, goto_next_char = true;
-        if (char_len == 1) char_is_ok = f_.pass_af_filter(lead);  // :276
-        else if (f_.pass_ubf_filter(lead)) {                     // :279
-            char_is_ok = !same_block_ || lead == last_multi_char_leading_byte || last_multi_char_leading_byte == 0;
-            if (!char_is_ok) goto_next_char = false;  // same char is scanned again as a string start, :289-291
-            last_multi_char_leading_byte = lead;
-        } else { char_is_ok = false; last_multi_char_leading_byte = 0; }
-
-        if (char_is_ok) { ok_s_len += char_len; ok_char_nb++; p_ += char_len; continue; }
-        if (goto_next_char) p_ += char_len;
-        const bool exit3 = last_cut_ && ok_char_nb > 0 && ok_s_p == inp_start_;  // :315
-        const bool exit4 = ok_char_nb >= chars_min_nb_ && grep_char_ok;          // :317
-        if (exit3 || exit4) break;
-        ok_s_len = 0; ok_char_nb = 0; ok_s_p = p_; grep_char_ok = !grep_needed;  // :327-330
-    }
-    if (ok_s_len == 0) return false;  // :343
-
-    const bool touches_left = ok_s_p == inp_start_;
-    const bool touches_right = ok_s_p + ok_s_len >= inp_end_;
-    const bool is_maybe_cut = ok_char_nb >= max_ || (touches_right && !invalid_after_);
-    const bool completes = touches_left && last_cut_;
-    const bool again = !completes && touches_right && !invalid_after_ && (ok_char_nb < max_ || !grep_char_ok);
-    const bool min_rule = ok_char_nb >= chars_min_nb_;
-    if (!completes && !again && (!grep_char_ok || !min_rule)) return false;  // :410-415
-    if (ok_char_nb >= max_) inp_start_ = p_;                                  // :418-420
-    last_cut_ = is_maybe_cut;                                                 // :421
-
-    out->s = ok_s_p; out->len = ok_s_len;
-    out->s_completes_previous_s = completes; out->s_is_maybe_cut = is_maybe_cut;
-    out->s_is_to_be_filtered_again = again; out->s_satisfies_min_char_rule = min_rule;
-    out->s_satisfies_grep_char_rule = grep_char_ok;
-    return true;
-}
-
-// ---------------------------------------------------------------------------------------
 // The window grid: slices of 4096 bytes from the chunk start (src/input.rs:22,121-123),
 // windows of 2q bytes inside a slice (src/finding_collection.rs:120,124-131).
 // ---------------------------------------------------------------------------------------

@@ -1,4 +1,5 @@
-// sx_replay_core.hpp — the body of the device-side exact replay (stage B).  Included by
+// sx_replay_core.hpp — the body of the device-side exact replay (stage B); decoders and SplitStr
+// come from sx_codec_core.hpp.  Included by
 // sx_replay_dev.hip with SXD = `__device__ __forceinline__`; the test-only harness
 // tests/native/replay_core_host.cpp includes it with SXD = `inline` so that the very same
 // code can be compared region by region with the host replayer on a machine without GPU.
@@ -6,214 +7,12 @@
 #include <stdint.h>
 
 #include "sx_device.hpp"
+#include "sx_codec_core.hpp"
 
 namespace sx {
 
-typedef uint8_t u8;
-typedef uint32_t u32;
-typedef uint64_t u64;
-
 
 constexpr u32 kSliceLen = 4096;  // INPUT_BUF_LEN, src/input.rs:22
-
-enum { RES_INPUT_EMPTY = 0, RES_OUTPUT_FULL = 1, RES_MALFORMED = 2 };
-
-struct DStep { int result; u32 read, written; };
-
-// ------------------------------------------------------------------------------------------
-// Decoders (twin of sx_decoder.cpp)
-// ------------------------------------------------------------------------------------------
-struct DDecoder {
-    int enc;
-    u32 cp; u8 seen, needed, lower, upper;          // UTF-8
-    int lead_byte; u32 lead_surrogate; bool pending_bmp;  // UTF-16
-    const uint16_t* table;                            // single byte (0 = x-user-defined)
-};
-
-SXD void ddec_reset(DDecoder& d, int enc, const uint16_t* table) {
-    d.enc = enc; d.cp = 0; d.seen = d.needed = 0; d.lower = 0x80; d.upper = 0xBF;
-    d.lead_byte = -1; d.lead_surrogate = 0; d.pending_bmp = false; d.table = table;
-}
-
-SXD u32 dput_cp(u8* d, u32 c) {
-    if (c < 0x80) { d[0] = (u8)c; return 1; }
-    if (c < 0x800) { d[0] = (u8)(0xC0 | (c >> 6)); d[1] = (u8)(0x80 | (c & 0x3F)); return 2; }
-    if (c < 0x10000) {
-        d[0] = (u8)(0xE0 | (c >> 12)); d[1] = (u8)(0x80 | ((c >> 6) & 0x3F)); d[2] = (u8)(0x80 | (c & 0x3F));
-        return 3;
-    }
-    d[0] = (u8)(0xF0 | (c >> 18)); d[1] = (u8)(0x80 | ((c >> 12) & 0x3F));
-    d[2] = (u8)(0x80 | ((c >> 6) & 0x3F)); d[3] = (u8)(0x80 | (c & 0x3F));
-    return 4;
-}
-
-SXD DStep ddec_utf8(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {
-    u32 i = 0, w = 0;
-    for (;;) {
-        if (i >= n) {
-            if (last && d.needed != 0) {
-                d.cp = 0; d.needed = d.seen = 0; d.lower = 0x80; d.upper = 0xBF;
-                return { RES_MALFORMED, i, w };
-            }
-            return { RES_INPUT_EMPTY, i, w };
-        }
-        if (cap - w < 4) return { RES_OUTPUT_FULL, i, w };
-        const u8 b = src[i++];
-        if (d.needed == 0) {
-            if (b < 0x80) { dst[w++] = b; continue; }
-            if (b >= 0xC2 && b <= 0xDF) { d.needed = 1; d.cp = b & 0x1F; continue; }
-            if (b >= 0xE0 && b <= 0xEF) {
-                if (b == 0xE0) d.lower = 0xA0;
-                if (b == 0xED) d.upper = 0x9F;
-                d.needed = 2; d.cp = b & 0x0F; continue;
-            }
-            if (b >= 0xF0 && b <= 0xF4) {
-                if (b == 0xF0) d.lower = 0x90;
-                if (b == 0xF4) d.upper = 0x8F;
-                d.needed = 3; d.cp = b & 0x07; continue;
-            }
-            return { RES_MALFORMED, i, w };
-        }
-        if (b < d.lower || b > d.upper) {
-            d.cp = 0; d.needed = d.seen = 0; d.lower = 0x80; d.upper = 0xBF;
-            return { RES_MALFORMED, i - 1, w };  // un-read
-        }
-        d.lower = 0x80; d.upper = 0xBF;
-        d.cp = (d.cp << 6) | (b & 0x3F);
-        if (++d.seen != d.needed) continue;
-        w += dput_cp(dst + w, d.cp);
-        d.cp = 0; d.needed = d.seen = 0;
-    }
-}
-
-template <bool BE>
-SXD DStep ddec_utf16(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {
-    constexpr bool be = BE;
-    u32 i = 0, w = 0;
-    if (d.pending_bmp) {
-        if (cap - w < 3) return { RES_OUTPUT_FULL, 0, 0 };
-        w += dput_cp(dst + w, d.lead_surrogate);
-        d.pending_bmp = false; d.lead_surrogate = 0;
-    }
-    for (;;) {
-        if (d.lead_byte < 0 && d.lead_surrogate == 0) {
-            while (n - i >= 2 && cap - w >= 4) {
-                const u32 u = be ? ((u32)src[i] << 8) | src[i + 1] : ((u32)src[i + 1] << 8) | src[i];
-                if ((u & 0xF800) != 0xD800) { w += dput_cp(dst + w, u); i += 2; continue; }
-                if ((u & 0xFC00) == 0xDC00) { i += 2; return { RES_MALFORMED, i, w }; }
-                if (n - i < 4) break;
-                const u32 v = be ? ((u32)src[i + 2] << 8) | src[i + 3] : ((u32)src[i + 3] << 8) | src[i + 2];
-                if ((v & 0xFC00) != 0xDC00) { i += 2; return { RES_MALFORMED, i, w }; }
-                w += dput_cp(dst + w, 0x10000u + ((u & 0x3FF) << 10) + (v & 0x3FF));
-                i += 4;
-            }
-        }
-        if (i >= n) {
-            if (last && (d.lead_surrogate != 0 || d.lead_byte >= 0)) {
-                d.lead_surrogate = 0; d.lead_byte = -1;
-                return { RES_MALFORMED, i, w };
-            }
-            return { RES_INPUT_EMPTY, i, w };
-        }
-        if (cap - w < 4) return { RES_OUTPUT_FULL, i, w };
-        const u8 b = src[i++];
-        if (d.lead_byte < 0) { d.lead_byte = b; continue; }
-        const u32 u = be ? ((u32)d.lead_byte << 8) | b : ((u32)b << 8) | (u32)d.lead_byte;
-        d.lead_byte = -1;
-        if ((u & 0xFC00) == 0xD800) {
-            if (d.lead_surrogate != 0) { d.lead_surrogate = u; return { RES_MALFORMED, i, w }; }
-            d.lead_surrogate = u;
-            continue;
-        }
-        if ((u & 0xFC00) == 0xDC00) {
-            if (d.lead_surrogate == 0) return { RES_MALFORMED, i, w };
-            w += dput_cp(dst + w, 0x10000u + ((d.lead_surrogate & 0x3FF) << 10) + (u & 0x3FF));
-            d.lead_surrogate = 0;
-            continue;
-        }
-        if (d.lead_surrogate != 0) { d.lead_surrogate = u; d.pending_bmp = true; return { RES_MALFORMED, i, w }; }
-        w += dput_cp(dst + w, u);
-    }
-}
-
-SXD DStep ddec_single(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap) {
-    u32 i = 0, w = 0;
-    for (;;) {
-        if (i >= n) return { RES_INPUT_EMPTY, i, w };
-        if (cap - w < 3) return { RES_OUTPUT_FULL, i, w };
-        const u8 b = src[i++];
-        if (b < 0x80) { dst[w++] = b; continue; }
-        const u32 c = d.table ? d.table[b - 0x80] : 0xF780u + (b - 0x80u);
-        if (c == 0) return { RES_MALFORMED, i, w };
-        w += dput_cp(dst + w, c);
-    }
-}
-
-// ENC: 1 UTF-8, 2 UTF-16LE, 3 UTF-16BE, 0 any single-byte encoding (SX_ENC_* >= 16, ASCII,
-// x-user-defined).  A template parameter: the replay is compiled once per encoding family,
-// which keeps each kernel's code and register footprint small.
-constexpr int enc_family(u32 encoding) { return encoding == 1 ? 1 : encoding == 2 ? 2 : encoding == 3 ? 3 : 0; }
-template <int ENC>
-SXD DStep ddecode(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {
-    if (ENC == 1) return ddec_utf8(d, src, n, dst, cap, last);
-    if (ENC == 2) return ddec_utf16<false>(d, src, n, dst, cap, last);
-    if (ENC == 3) return ddec_utf16<true>(d, src, n, dst, cap, last);
-    return ddec_single(d, src, n, dst, cap);
-}
-
-// ------------------------------------------------------------------------------------------
-// Filter + SplitStr (twin of sx_replay.cpp SplitStr::next, reference src/helper.rs:206-433)
-// ------------------------------------------------------------------------------------------
-SXD bool pass_af(const ReplayParams& p, u8 b) { b &= 127; return ((b < 64 ? p.af_lo >> b : p.af_hi >> (b - 64)) & 1) != 0; }
-SXD bool pass_ubf(const ReplayParams& p, u8 b) { return ((p.ubf >> (b & 0x3F)) & 1) != 0; }
-SXD bool pass_lead(const ReplayParams& p, u8 lead) { return (lead & 0x80) ? pass_ubf(p, lead) : pass_af(p, lead); }
-
-struct DSplit {
-    const u8 *inp_start, *inp_end, *p;
-    bool last_cut, invalid_after;
-};
-struct DChunk { const u8* s; u32 len; bool completes, maybe_cut, again; };
-
-SXD bool dsplit_next(const ReplayParams& m, DSplit& it, DChunk& out) {
-    const bool grep_needed = m.grep_char >= 0;
-    bool grep_ok = !grep_needed;
-    const u8* ok_p = it.p;
-    u32 ok_len = 0, ok_n = 0;
-    u8 last_mb = 0;
-    while (it.p < it.inp_end && ok_n < m.q) {
-        const u8 lead = *it.p;
-        u32 cl = 1;
-        if ((lead & 0x80) == 0) { if (!grep_ok && m.grep_char == (int)lead) grep_ok = true; }
-        else if ((lead & 0xE0) == 0xC0) cl = 2;
-        else if ((lead & 0xF0) == 0xE0) cl = 3;
-        else if ((lead & 0xF8) == 0xF0) cl = 4;
-        bool ok, advance = true;
-        if (cl == 1) ok = pass_af(m, lead);
-        else if (pass_ubf(m, lead)) {
-            ok = !m.same_block || lead == last_mb || last_mb == 0;
-            if (!ok) advance = false;
-            last_mb = lead;
-        } else { ok = false; last_mb = 0; }
-        if (ok) { ok_len += cl; ok_n++; it.p += cl; continue; }
-        if (advance) it.p += cl;
-        const bool exit3 = it.last_cut && ok_n > 0 && ok_p == it.inp_start;
-        const bool exit4 = ok_n >= m.chars_min_nb && grep_ok;
-        if (exit3 || exit4) break;
-        ok_len = 0; ok_n = 0; ok_p = it.p; grep_ok = !grep_needed;
-    }
-    if (ok_len == 0) return false;
-    const bool touches_left = ok_p == it.inp_start;
-    const bool touches_right = ok_p + ok_len >= it.inp_end;
-    const bool maybe_cut = ok_n >= m.q || (touches_right && !it.invalid_after);
-    const bool completes = touches_left && it.last_cut;
-    const bool again = !completes && touches_right && !it.invalid_after && (ok_n < m.q || !grep_ok);
-    const bool min_rule = ok_n >= m.chars_min_nb;
-    if (!completes && !again && (!grep_ok || !min_rule)) return false;
-    if (ok_n >= m.q) it.inp_start = it.p;
-    it.last_cut = maybe_cut;
-    out.s = ok_p; out.len = ok_len; out.completes = completes; out.maybe_cut = maybe_cut; out.again = again;
-    return true;
-}
 
 // ------------------------------------------------------------------------------------------
 // Window grid (twin of sx_replay.cpp)
@@ -247,13 +46,6 @@ SXD bool run_is_chained(const ReplayParams& P, u64 i, u64 want) {
 //  (B) if no long run starts in the rest of this window, nothing is emitted up to its end and
 //      the state there is what a region start derives (derive_at), so the replay jumps there.
 // ------------------------------------------------------------------------------------------
-template <int ENC>
-SXD bool ddec_idle(const DDecoder& d) {
-    if (ENC == 1) return d.needed == 0;
-    if (ENC == 2 || ENC == 3) return d.lead_byte < 0 && d.lead_surrogate == 0 && !d.pending_bmp;
-    return true;
-}
-
 // Start of the decoder call that contains the char boundary rs, not before the call start p.
 // Returns p if everything in [p, rs) is valid (the call at p is the one).
 template <int ENC>
@@ -310,6 +102,26 @@ SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs) {
         }
         return b;
     }
+    if (ENC == 4 || ENC == 5) {
+        // double-byte: tokens cannot be told apart walking backwards; p is a clean call start (decoder
+        // neutral), so walk forward and remember where the last malformed token ended
+        DDecoder dd;
+        ddec_reset(dd, (int)P.encoding, P.table);
+        u8 sink[48];
+        u64 at = p, vs = p;
+        while (at < rs) {
+            const u32 n = (u32)(rs - at < 12 ? rs - at : 12);
+            u32 k = 0;
+            for (;;) {
+                const DStep r = ddecode<ENC>(dd, bytes + at + k, n - k, sink, sizeof sink, false);
+                k += r.read;
+                if (r.result == RES_INPUT_EMPTY) break;
+                if (r.result == RES_MALFORMED) vs = at + k;
+            }
+            at += n;
+        }
+        return vs;
+    }
     if (!P.table) return p;  // x-user-defined: every byte is a character, the call at p is the one
     while (b > p) {
         const u8 x = bytes[b - 1];
@@ -317,6 +129,19 @@ SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs) {
         b--;
     }
     return b;
+}
+
+// Double-byte encodings: a token boundary b with lim <= b <= at (b may exceed lim by a token), found from the
+// nearest byte outside the lead range in front of `at` — the decoder is neutral right after such a byte —
+// or from `floor`, where it is neutral too (a clean call start; at the buffer start after `skip0` bytes that
+// finish the token pending on entry).  The walk back is as long as the stretch of lead-range bytes.
+template <int ENC>
+SXD u64 dbcs_sync_before(const u8* bytes, u64 len, u64 at, u64 floor, u32 skip0, u64 lim) {
+    u64 r = at;
+    while (r > floor && dbcs_is_lead_range<ENC>(bytes[r - 1])) r--;
+    if (r == floor) r += skip0;
+    while (r < lim) r += dbcs_token_len<ENC>(bytes + r, len - r);
+    return r < at ? r : at;
 }
 
 // The state the reference carries into the window that starts at `at`, when nothing long
@@ -335,6 +160,7 @@ SXD_NOINLINE u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& d
     if ((ENC == 2 || ENC == 3) && ((P.stream0 + p) & 1)) p = p ? p - 1 : p + 1;
     if (p < floor) p = floor;
     if (p > at) p = at;
+    if (ENC == 4 || ENC == 5) p = dbcs_sync_before<ENC>(bytes, P.len, at, floor, floor == 0 ? P.entry_skip : 0u, p);
     u8 sink[40], last[4], mb[4];
     u32 last_len = 0, mb_len = 0;
     while (p < at) {   // in pieces: the sink is small
@@ -571,6 +397,8 @@ SXD void replay_region_any(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_
         case 1: replay_region<MODE, 1>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
         case 2: replay_region<MODE, 2>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
         case 3: replay_region<MODE, 3>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
+        case 4: replay_region<MODE, 4>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
+        case 5: replay_region<MODE, 5>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
         default: replay_region<MODE, 0>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
     }
 }

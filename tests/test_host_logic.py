@@ -343,12 +343,8 @@ NEW_SINGLE_BYTE = ["iso-8859-3", "iso-8859-4", "iso-8859-6", "iso-8859-7", "iso-
 def test_remaining_single_byte_encodings_replay_equals_full_scan(enc):
     """the other WHATWG single-byte decoders go through the same table-driven path; text in the
     encoding itself (every defined high byte), undefined bytes as breaks, and random bytes."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("gt", os.path.join(ROOT, "oracle", "gen_tables.py"))
-    gt = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(gt)
-    name, codec, fill = next(t for t in gt.TABLES if t[0].lower() == enc)
-    tab = gt.table(codec, fill, name)
+    t, n = sx.decoder_table(rc.ENC_IDS[enc])
+    tab = [t[i] for i in range(n)]
     defined = [0x80 + i for i, v in enumerate(tab) if v and v >= 0xA0]
     undefined = [0x80 + i for i, v in enumerate(tab) if not v] or [0x00]
     rng = random.Random(zlib_seed(enc))

@@ -27,7 +27,7 @@ class ReplayParams(C.Structure):
                 ("long_run", C.c_uint32), ("skip", C.c_uint32), ("grep_char", C.c_int32), ("mission_id", C.c_int32), ("file_id", C.c_int32),
                 ("af_lo", C.c_uint64), ("af_hi", C.c_uint64), ("ubf", C.c_uint64),
                 ("slot_of", C.c_void_p), ("n_heads", C.c_void_p), ("cache_arena", C.c_void_p), ("arena_bytes", C.c_uint64),
-                ("head_list", C.c_void_p), ("max_windows", C.c_uint32)]
+                ("head_list", C.c_void_p), ("max_windows", C.c_uint32), ("entry_skip", C.c_uint32)]
 
 
 class RegionOut(C.Structure):
@@ -43,8 +43,8 @@ def core():
 def load_core():
     so = os.path.join(NATIVE, "libreplay_core_host.so")
     src = os.path.join(NATIVE, "replay_core_host.cpp")
-    hdr = os.path.join(ROOT, "stringsext_amd", "csrc", "sx_replay_core.hpp")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(ROOT, "stringsext_amd", "csrc", h) for h in ("sx_replay_core.hpp", "sx_codec_core.hpp", "sx_device.hpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
                                "-I/opt/rocm/include", "-o", so, src])
     L = C.CDLL(so)
@@ -54,11 +54,9 @@ def load_core():
 
 
 def sb_table(enc_id):
-    spec = importlib.util.spec_from_file_location("gen_tables", os.path.join(ROOT, "oracle", "gen_tables.py"))
-    gt = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(gt)
-    name, codec, fill = gt.TABLES[enc_id - 16]
-    return (C.c_uint16 * 128)(*gt.table(codec, fill, name))
+    """the product's decoder table (single byte: 128 entries; Big5 / EUC-JP: the blob)"""
+    t = sx.decoder_table(enc_id)
+    return t[0] if t else None
 
 
 def ws(p, W):
@@ -168,7 +166,7 @@ def make_params(m, data, runs, stream0=0, skip=1):
     P = ReplayParams(data, len(data), arr, len(runs), 0, len(data), m["counter_offset"] + stream0, stream0, 0,
                      m["encoding"], table, m["chars_min_nb"], int(m["require_same_unicode_block"]),
                      m["output_line_char_nb_max"], W, long_run, skip, -1 if m["grep_char"] is None else m["grep_char"],
-                     m["mission_id"], 1, m["af"] & (2**64 - 1), m["af"] >> 64, m["ubf"], None, None, None, 0, None, 64)
+                     m["mission_id"], 1, m["af"] & (2**64 - 1), m["af"] >> 64, m["ubf"], None, None, None, 0, None, 64, 0)
     P._keep = (arr, table)
     return P, W, long_run
 

@@ -1,0 +1,173 @@
+"""The decoder tables of the oracle and of the product come from DIFFERENT sources (the oracle's from ICU dumps,
+oracle/gen_tables.py + oracle/tables/; the product's from CPython's codecs, stringsext_amd/csrc/gen_tables.py),
+each patched towards the WHATWG indexes where its source is known to differ.  The results must be equal cell by
+cell — otherwise every parity test over a legacy encoding would compare a table with itself — and the raw
+disagreements between the two sources are kept as a report (tests/golden/table_sources_report.txt)."""
+import importlib.util
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _arrays(path):
+    s = open(os.path.join(ROOT, path)).read()
+    out = {}
+    for m in re.finditer(r"static const uint(?:16|32)_t (\w+)\[(\d+)\] = \{(.*?)\};", s, re.S):
+        out[m.group(1)] = [int(x, 16) for x in re.findall(r"0x[0-9A-Fa-f]+", m.group(3))]
+    m = re.search(r"_sb_tables\[(\d+)\]\[128\] = \{(.*?)\n\};", s, re.S)
+    v = [int(x, 16) for x in re.findall(r"0x[0-9A-Fa-f]+", m.group(2))]
+    out["sb"] = [v[i:i + 128] for i in range(0, len(v), 128)]
+    out["names"] = re.findall(r'^    "([^"]+)",$', s, re.M)
+    return out
+
+
+def _big5_cell(ptr):
+    lead, t = divmod(ptr, 157)
+    return "%02X%02X" % (lead + 0x81, t + (0x40 if t < 0x3F else 0x62))
+
+
+def _jis_cell(ptr):
+    a, b = divmod(ptr, 94)
+    return "%02X%02X" % (a + 0xA1, b + 0xA1)
+
+
+def test_committed_tables_are_what_the_generators_produce(tmp_path):
+    o = _load("oracle/gen_tables.py", "gt_oracle")
+    p = _load("stringsext_amd/csrc/gen_tables.py", "gt_product")
+    a = tmp_path / "o.inc"
+    o.emit(str(a))
+    assert a.read_text() == open(os.path.join(ROOT, "oracle/sxo_tables.inc")).read()
+    b = tmp_path / "p.inc"
+    with open(b, "w") as fh:
+        p.emit("sx", fh)
+    assert b.read_text() == open(os.path.join(ROOT, "stringsext_amd/csrc/sx_tables.inc")).read()
+
+
+def test_oracle_and_product_tables_agree_cell_by_cell():
+    o = _arrays("oracle/sxo_tables.inc")
+    p = _arrays("stringsext_amd/csrc/sx_tables.inc")
+    assert o["names"] == p["names"] and len(o["names"]) == 28  # the WHATWG single-byte set (x-user-defined has no table)
+    diffs = []
+    for name, ro, rp in zip(o["names"], o["sb"], p["sb"]):
+        diffs += [f"{name} 0x{0x80 + i:02X}: oracle U+{a:04X} product U+{b:04X}" for i, (a, b) in enumerate(zip(ro, rp)) if a != b]
+    n = 126 * 157
+    pb5 = [lo | (0x20000 if (p["sx_big5"][n + (i >> 4)] >> (i & 15)) & 1 else 0) for i, lo in enumerate(p["sx_big5"][:n])]
+    assert len(o["sxo_big5"]) == n and len(p["sx_big5"]) == n + (n + 15) // 16
+    diffs += [f"Big5 {_big5_cell(i)}: oracle U+{a:04X} product U+{b:04X}" for i, (a, b) in enumerate(zip(o["sxo_big5"], pb5)) if a != b]
+    j = 94 * 94
+    for k, (oa, pa) in enumerate(((o["sxo_jis0208"], p["sx_eucjp"][:j]), (o["sxo_jis0212"], p["sx_eucjp"][j:]))):
+        assert len(oa) == j and len(pa) == j
+        diffs += [f"jis02{'08' if k == 0 else '12'} {_jis_cell(i)}: oracle U+{a:04X} product U+{b:04X}" for i, (a, b) in enumerate(zip(oa, pa)) if a != b]
+    assert not diffs, "\n".join(diffs[:50])
+    # sizes of what is mapped, and a few cells whose value is a decision (see the generators' headers)
+    assert sum(1 for v in pb5 if v) == 18405 and sum(1 for v in o["sxo_jis0208"] if v) == 7336 and sum(1 for v in o["sxo_jis0212"] if v) == 6067
+    big5 = lambda lead, trail: pb5[(lead - 0x81) * 157 + (trail - (0x40 if trail < 0x7F else 0x62))]
+    assert big5(0xA1, 0x45) == 0x2027 and big5(0xA3, 0xE1) == 0x20AC and big5(0xF9, 0xFE) == 0x2593
+    assert big5(0xC6, 0xA1) == 0x2460 and big5(0x87, 0x40) == 0x43F0 and big5(0xA4, 0x40) == 0x4E00
+    assert [pb5[x] for x in (1133, 1135, 1164, 1166)] == [0, 0, 0, 0]      # two code points each: in the decoder
+    assert all(big5(lead, 0x40) == 0 for lead in range(0x81, 0x87))         # nothing below 0x8740
+    jis = lambda tab, a, b: tab[(a - 0xA1) * 94 + (b - 0xA1)]
+    assert jis(o["sxo_jis0208"], 0xA1, 0xC0) == 0xFF3C and jis(o["sxo_jis0208"], 0xAD, 0xA1) == 0x2460
+    assert jis(o["sxo_jis0208"], 0xF9, 0xA1) == 0x7E8A and jis(o["sxo_jis0212"], 0xA2, 0xB7) == 0xFF5E
+    t = dict(zip(p["names"], p["sb"]))
+    assert t["windows-1255"][0xCA - 0x80] == 0x05BA and t["windows-1255"][0xD9 - 0x80] == 0
+    assert t["KOI8-U"][0xAE - 0x80] == 0x045E and t["x-mac-cyrillic"][0xFF - 0x80] == 0x20AC
+    assert t["windows-874"][0x81 - 0x80] == 0x81 and t["windows-874"][0xDB - 0x80] == 0
+    assert t["windows-1253"][0xAA - 0x80] == 0 and t["ISO-8859-8-I"] == t["ISO-8859-8"]
+
+
+def _raw_report():
+    """Where the two RAW sources (ICU dump vs CPython codec, before any patch) disagree, and what was taken."""
+    o = _load("oracle/gen_tables.py", "gt_oracle")
+    p = _load("stringsext_amd/csrc/gen_tables.py", "gt_product")
+    fin = _arrays("stringsext_amd/csrc/sx_tables.inc")
+    lines = ["# raw source disagreements: <table> <cell>: ICU <value> | CPython <value> -> taken <value>",
+             "# (ICU = node 12 TextDecoder, ICU 70.1, oracle/tables/icu_*.txt; CPython = the codec named in",
+             "#  stringsext_amd/csrc/gen_tables.py; 'none' = the source does not decode the cell; PUA = private use)"]
+    tab = os.path.join(ROOT, "oracle", "tables")
+    fmt = lambda v: "none" if not v else "+".join("U+%04X" % x for x in v)
+    # single byte
+    icu_rows = {}
+    for line in open(os.path.join(tab, "icu_single_byte.txt")):
+        q = line.split()
+        icu_rows[q[0]] = None if q[1] == "UNSUPPORTED" else [int(x, 16) for x in q[1:]]
+    for (name, codec, fill), final in zip(p.TABLES, fin["sb"]):
+        icu = icu_rows.get(name.lower())
+        if icu is None:
+            lines.append(f"{name}: unknown to ICU here: single source (CPython {codec})")
+            continue
+        for i in range(128):
+            try:
+                cp = ord(bytes([0x80 + i]).decode(codec))
+            except UnicodeDecodeError:
+                cp = 0
+            if cp != icu[i]:
+                lines.append(f"{name} 0x{0x80 + i:02X}: ICU {fmt([icu[i]] if icu[i] else None)} | CPython {fmt([cp] if cp else None)} -> taken {fmt([final[i]] if final[i] else None)}")
+    # Big5
+    icu = {}
+    for line in open(os.path.join(tab, "icu_big5.txt")):
+        k, v = line.split()
+        icu[int(k, 16)] = [int(x, 16) for x in v.split("+")]
+    n = 126 * 157
+    pb5 = [lo | (0x20000 if (fin["sx_big5"][n + (i >> 4)] >> (i & 15)) & 1 else 0) for i, lo in enumerate(fin["sx_big5"][:n])]
+    pua = single = 0
+    for lead in range(0x81, 0xFF):
+        for trail in list(range(0x40, 0x7F)) + list(range(0xA1, 0xFF)):
+            ptr = (lead - 0x81) * 157 + (trail - (0x40 if trail < 0x7F else 0x62))
+            a = icu.get(lead << 8 | trail)
+            hk, ms = p.cps("big5hkscs", [lead, trail]), p.cps("cp950", [lead, trail])
+            if a and 0xE000 <= a[0] <= 0xF8FF:
+                pua += 1
+                single += 1 if (hk or ms) else 0
+                continue  # counted below, not listed one by one
+            for codec, b in (("big5hkscs", hk), ("cp950", ms)):
+                if b and a != b:
+                    taken = [pb5[ptr]] if pb5[ptr] else None
+                    lines.append(f"Big5 {lead:02X}{trail:02X}: ICU {fmt(a)} | CPython {codec} {fmt(b)} -> taken {fmt(taken)}")
+    lines.append(f"Big5: {pua} cells ICU maps to the private use area (HKSCS, ETEN C6A1..C8FE): {single} of them taken from CPython "
+                 "big5hkscs/cp950 alone (single source), the others unmapped in both")
+    # EUC-JP
+    j208, j212 = fin["sx_eucjp"][:94 * 94], fin["sx_eucjp"][94 * 94:]
+    raw208, raw212 = p.jis0208_table(), [0] * (94 * 94)
+    for a in range(0xA1, 0xFF):
+        for b in range(0xA1, 0xFF):
+            v = p.cps("euc_jp", [0x8F, a, b])
+            if v:
+                raw212[(a - 0xA1) * 94 + (b - 0xA1)] = v[0]
+    dropped = 0
+    for line in open(os.path.join(tab, "icu_euc_jp.txt")):
+        k, v = line.split()
+        cps = [int(x, 16) for x in v.split("+")]
+        if len(k) == 4:
+            a, b = int(k[:2], 16), int(k[2:], 16)
+            if a < 0xA1:
+                if not (0xA1 <= b <= 0xDF and cps == [0xFF61 - 0xA1 + b]):
+                    lines.append(f"EUC-JP {k.upper()}: ICU {fmt(cps)} | WHATWG: 8E takes A1..DF only -> taken none")
+                continue
+            idx, raw, final, tag = (a - 0xA1) * 94 + (b - 0xA1), raw208, j208, "jis0208"
+        else:
+            a, b = int(k[2:4], 16), int(k[4:], 16)
+            idx, raw, final, tag = (a - 0xA1) * 94 + (b - 0xA1), raw212, j212, "jis0212"
+        if 0xE000 <= cps[0] <= 0xF8FF and not raw[idx]:
+            dropped += 1
+            continue
+        if cps != ([raw[idx]] if raw[idx] else None):
+            lines.append(f"{tag} {k[-4:].upper()}: ICU {fmt(cps)} | CPython {fmt([raw[idx]] if raw[idx] else None)} -> taken {fmt([final[idx]] if final[idx] else None)}")
+    lines.append(f"EUC-JP: {dropped} user-defined cells ICU maps to the private use area, unmapped in CPython and in the tables")
+    return "\n".join(lines) + "\n"
+
+
+def test_report_of_raw_source_disagreements_is_current():
+    path = os.path.join(ROOT, "tests", "golden", "table_sources_report.txt")
+    text = _raw_report()
+    if os.environ.get("SX_WRITE_TABLE_REPORT"):
+        open(path, "w").write(text)
+    assert open(path).read() == text, "regenerate with SX_WRITE_TABLE_REPORT=1"
