@@ -211,11 +211,18 @@ int sx_create(sx_ctx** out, const sx_mission* missions, int n_missions, int hip_
             s.capacity = cap;
         }
     }
-    for (size_t k = 0; k < ctx->dev.size(); k++)
-        if (const uint16_t* t = single_byte_table(ctx->missions[k].c.encoding)) {
-            if ((e = hipMalloc((void**)&ctx->dev[k].d_table, 256)) != hipSuccess) return fail("hipMalloc", e);
-            if ((e = hipMemcpy(ctx->dev[k].d_table, t, 256, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+    for (size_t k = 0; k < ctx->dev.size(); k++) {
+        size_t n_words = 0;
+        if (const uint16_t* t = decoder_table(ctx->missions[k].c.encoding, &n_words)) {
+            if ((e = hipMalloc((void**)&ctx->dev[k].d_table, n_words * 2)) != hipSuccess) return fail("hipMalloc", e);
+            if ((e = hipMemcpy(ctx->dev[k].d_table, t, n_words * 2, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
         }
+        const std::vector<uint32_t>& pl = ctx->missions[k].pair_lut;
+        if (!pl.empty()) {
+            if ((e = hipMalloc((void**)&ctx->dev[k].d_pair_lut, pl.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
+            if ((e = hipMemcpy(ctx->dev[k].d_pair_lut, pl.data(), pl.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+        }
+    }
     *out = ctx;
     return SX_OK;
 }
@@ -237,6 +244,7 @@ void sx_destroy(sx_ctx* ctx) {
                 if (s.ev_free) (void)hipEventDestroy(s.ev_free);
             }
             if (d.d_table) (void)hipFree(d.d_table);
+            if (d.d_pair_lut) (void)hipFree(d.d_pair_lut);
             for (void* q : d.d_rp) if (q) (void)hipFree(q);
             if (d.h_runs) (void)hipHostFree(d.h_runs);
             if (d.ev_runs) (void)hipEventDestroy(d.ev_runs);
@@ -297,7 +305,10 @@ int sx_replay_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_fi
     for (size_t k = 0; k < r.size(); k++) r[k].assign(runs[k], runs[k] + n_runs[k]);
     HostBytes view(bytes ? bytes : (const uint8_t*)"");
     ResultHolder res;
-    int rc = replay_all(ctx, view, whole_chunk_job(ctx, len, input_file_id, is_last_input_buffer != 0), r, &res.r->r, nullptr);
+    std::vector<uint32_t> entry;
+    int rc = set_entry_params(ctx, true, bytes, nullptr, len, 0, &entry);
+    if (rc != SX_OK) return rc;
+    rc = replay_all(ctx, view, whole_chunk_job(ctx, len, input_file_id, is_last_input_buffer != 0), r, &res.r->r, nullptr);
     if (rc == SX_OK) *out = res.release();
     return rc;
 }

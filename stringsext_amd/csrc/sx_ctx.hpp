@@ -83,7 +83,8 @@ struct MissionDev {
     hipStream_t stream_b = nullptr;   // everything after them (sort/join, stage B, copies); higher priority
     ScanSlot slot[2];
     // stage B on the device: grow-only buffers
-    uint16_t* d_table = nullptr;                        // single-byte decoder table
+    uint16_t* d_table = nullptr;                        // decoder table: single byte (128 entries) or the Big5 / EUC-JP blob
+    uint32_t* d_pair_lut = nullptr;                     // Big5 / EUC-JP: Mission::pair_lut for the scan kernel
     sx_run* h_runs = nullptr; uint64_t h_runs_cap = 0;   // pinned: runs joined on the device
     hipEvent_t ev_runs = nullptr;                         // their copy (on sx_ctx::d2h_stream) is done
     void* d_rp[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
@@ -253,6 +254,8 @@ struct ResultHolder {
     sx_result* release() { sx_result* x = r; r = nullptr; return x; }
 };
 
+int set_entry_params(sx_ctx* ctx, bool carried_state_is_entry, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len,
+                     uint64_t stream_off, std::vector<uint32_t>* parity);
 int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len, int file_id,
                 int is_last, sx_result** out, uint32_t slice_base0 = 0, sx_result* append_to = nullptr);
 int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,

@@ -37,7 +37,9 @@ enum ClassifierKind : uint32_t {
     kClsUtf16Lut = 2,       // UTF-16LE/BE, any af/ubf: two 256-entry LUTs (high byte / low byte)
     kClsUtf8Range2 = 3,     // UTF-8, af = one range, ubf = one range of 2-byte leads: pure SWAR, no LUT
     kClsUtf16Range = 4,     // UTF-16, af = one range, ubf = one range below U+0800, no astral: pure SWAR
-    kClsSingleByteRange = 5 // single byte, accept set = one range of bytes < 0x80 (+ all/none of >= 0x80)
+    kClsSingleByteRange = 5,// single byte, accept set = one range of bytes < 0x80 (+ all/none of >= 0x80)
+    kClsBig5 = 6,           // Big5: token classifier, 2-bit pair table (16 KB) in LDS
+    kClsEucJp = 7           // EUC-JP: the same with three-byte tokens and two pair tables (32 KB)
 };
 
 struct ScanParams {
@@ -47,7 +49,7 @@ struct ScanParams {
     uint32_t min_chars;    // report stretches with >= min_chars characters
     uint32_t cand_bytes;   // a stretch shorter than this many bytes can never qualify (1..17)
     uint32_t cand_sh[5];   // shift amounts of the "cand_bytes consecutive ones" test (0 = unused step)
-    uint32_t parity;       // UTF-16: (stream offset of byte 0) & 1
+    uint32_t parity;       // UTF-16: (stream offset of byte 0) & 1; Big5 / EUC-JP: bytes at the chunk start that finish the token pending on entry
     uint32_t big_endian;   // UTF-16BE
     uint32_t capacity;     // record slots
     uint32_t persistent;   // 0: one wavefront per sub-chunk; else: this many blocks, sub-chunks handed out by counters[3]
@@ -60,6 +62,9 @@ struct ScanParams {
     uint32_t a_lo, a_hi;   // accepted ASCII / single-unit range (inclusive)
     uint32_t u_lo, u_hi;   // UTF-8: accepted 2-byte lead range; UTF-16: accepted unit range [u_lo,u_hi]
     uint32_t high_all;     // single-byte range: every byte >= 0x80 accepted
+    uint32_t af_is_range;  // Big5 / EUC-JP: the accepted ASCII bytes are [a_lo,a_hi] (else lut[0..255] holds them: 0x80 / 0)
+    const uint32_t* pair_lut;  // Big5 / EUC-JP: device, 2 bits per byte pair (index = the pair as a little-endian u16; EUC-JP: + 65536
+                               // for the last two bytes of 8F xx xx): 0 unmapped, 1 mapped, 3 accepted, 2 accepted and two characters
     // table classifiers
     uint8_t lut[512];
 };

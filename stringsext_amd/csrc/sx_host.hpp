@@ -53,11 +53,16 @@ struct Mission {
     size_t window = 128;    // decoder_input_window = 2*q, src/finding_collection.rs:120
     uint32_t long_run = 4;  // min(chars_min_nb, q): fewer chars can never yield a Finding
     bool is_utf16() const { return c.encoding == SX_ENC_UTF16LE || c.encoding == SX_ENC_UTF16BE; }
+    bool is_dbcs() const { return c.encoding == SX_ENC_BIG5 || c.encoding == SX_ENC_EUC_JP; }
     const char* encoding_name() const;
 
     // device classifier for this mission
     ClassifierKind kind = kClsSingleByteLut;
     ScanParams proto{};  // a_lo.., lut filled in; data/len/recs set per launch
+    std::vector<uint32_t> pair_lut;  // Big5 / EUC-JP: the pair codes the kernel keeps in LDS (ScanParams::pair_lut)
+    // Big5 / EUC-JP, per buffer (set by the schedule before stage A/B of a buffer; the replay only reads it):
+    // how many bytes at the buffer start finish the token that was pending on entry — where its token grid begins
+    mutable uint32_t buf_entry_skip = 0;
     static int from_c(const sx_mission& in, bool force_generic, Mission* out, std::string* err);
 };
 

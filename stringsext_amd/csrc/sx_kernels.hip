@@ -28,6 +28,7 @@
 
 namespace sx {
 
+typedef uint8_t u8;
 typedef uint32_t u32;
 typedef uint64_t u64;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
@@ -831,6 +832,281 @@ __global__ __launch_bounds__(256) void scan_kernel_v2(const ScanParams p) {
     em.invalidate_rest();
 }
 
+// ------------------------------------------------------------------------------------------
+// Double-byte legacy encodings (Big5, EUC-JP): table-driven token classifier with the index in LDS.
+//
+// WHATWG decoders of this family consume the input in TOKENS: one byte outside the lead range, or a
+// lead byte with the byte after it (EUC-JP: 8F + A1..FE + one more byte).  After a lead, any byte
+// returns the decoder to neutral, and a byte outside the lead range never becomes pending — so the
+// byte after every such byte starts a token, and inside a stretch of lead-range bytes the token
+// starts follow from the first one by jumping token lengths (2, or 3 after 8F + A1..FE).  Per lane:
+//   1. SWAR byte classes -> 16-bit masks (lead range, ASCII accepted, 8F, A1..FE);
+//   2. token starts = the orbit of the known starts under "jump by token length", computed for every
+//      possible number of bytes (0..NS-1) that the previous lane's last token hangs over: NS orbits
+//      advance together by bit operations until none changes (wave-uniform loop);
+//   3. the lane's transfer function "hang-over in -> hang-over out" is constant when the lane holds a
+//      byte outside the lead range (binary data: always); then the previous lane's value arrives with one
+//      DPP move, else the functions are composed by a wave prefix scan (text without ASCII);
+//   4. one LDS lookup per token: a 2-bit code per byte pair (unmapped / mapped / accepted / accepted,
+//      two characters), index = the pair as a little-endian u16 — tokens never start at adjacent bytes,
+//      so 8 (+1) lookups cover the 16 bytes;
+//   5. good/start masks: all bytes of an accepted token; a malformed token's last byte, if ASCII, is
+//      given back by the decoder and is a character of its own.
+// The masks then take the same light/heavy paths as every other classifier.
+// ------------------------------------------------------------------------------------------
+template <int ENC>
+struct DbcsTraits {
+    static constexpr int NS = ENC == 4 ? 2 : 3;            // possible hang-overs: 0..NS-1 bytes
+    static constexpr u32 kTableWords = ENC == 4 ? 4096u : 8192u;  // 2 bits x 65536 pairs (EUC-JP: jis0208+8E, then jis0212)
+};
+
+// byte flags (bit 7 of every byte)
+SX_DEV u32 swar_range(u32 v7, u32 c1, u32 c2) { return (v7 + c1) & ~(v7 + c2); }  // low 7 bits in [lo,hi]: c1 = 0x80-lo, c2 = 0x7F-hi
+SX_DEV u32 swar_eq(u32 v, u32 pat) {  // bytes equal to pat's bytes
+    const u32 y = v ^ pat;
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y);
+}
+
+template <int ENC, bool AF_RANGE>
+__global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds_tab[];
+    using TR = DbcsTraits<ENC>;
+    constexpr int NS = TR::NS;
+    {
+        const u32x4* src = (const u32x4*)p.pair_lut;
+        u32x4* dst = (u32x4*)lds_tab;
+        for (u32 i = threadIdx.x; i < TR::kTableWords / 4; i += 256) dst[i] = src[i];
+        if (!AF_RANGE) ((u8*)(lds_tab + TR::kTableWords))[threadIdx.x] = p.lut[threadIdx.x];
+        __syncthreads();
+    }
+    const u8* aflut = (const u8*)(lds_tab + TR::kTableWords);
+    const u32 lane = lane_id();
+    const u32 a1 = rep4(0x80u - p.a_lo), a2 = rep4(0x7Fu - p.a_hi);
+    Emitter em{ p.recs, p.counters, p.capacity, 0u, 0u, p.region_cap, 0u, p.region_counts };
+
+    const u64 wave = (u64)blockIdx.x * 4u + uniform(threadIdx.x >> 6);
+    const u64 sub_start = wave * (u64)p.subchunk;
+    if (sub_start >= p.len) return;
+    const u64 sub_end = (sub_start + p.subchunk < p.len) ? sub_start + p.subchunk : p.len;
+    em.begin_region(wave);
+
+    // byte classes of one dword: flags at bit 7 of every byte
+    auto cls_lr = [&](u32 v) -> u32 {
+        const u32 t = v & 0x7F7F7F7Fu;
+        if (ENC == 4) return v & (t + 0x7F7F7F7Fu) & ~(t + 0x01010101u) & kM;              // 81..FE
+        return ((swar_range(t, rep4(0x80u - 0x21u), rep4(0x7Fu - 0x7Eu)) & v) | swar_eq(v & 0xFEFEFEFEu, 0x8E8E8E8Eu)) & kM;  // A1..FE, 8E, 8F
+    };
+
+    // Look-back: the classification state at the sub-chunk start.  One tile normally; further back while
+    // the tile holds no byte outside the lead range (the token grid cannot be told without one).
+    int pre = 0;
+    u32 cov = 0;  // bytes at the start of the next tile that belong to a token begun before it
+    {
+        u64 lo = sub_start;
+        while (lo > 0) {
+            lo -= kTileBytes;
+            pre++;
+            const u32x4 x = *(const u32x4*)(p.data + lo + 16u * lane);
+            const u32 all = cls_lr(x.x) & cls_lr(x.y) & cls_lr(x.z) & cls_lr(x.w);
+            if (__ballot(all != kM)) break;
+        }
+        if (lo == 0) cov = p.parity;  // the chunk start: the token pending on entry takes this many bytes
+    }
+    const u64 win_lo = sub_start - (u64)pre * kTileBytes;
+    u64 win_hi = sub_end + 2 * kTileBytes;
+    if (win_hi > p.len) win_hi = p.len;
+    const uint8_t* base_ptr = p.data + win_lo;
+    const u32 base_lo = uniform((u32)(uintptr_t)base_ptr), base_hi = uniform((u32)((uintptr_t)base_ptr >> 32));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((u64)base_hi << 32) | base_lo), 0, (int)uniform(((u32)(win_hi - win_lo) + 15u) & ~15u), 0x00020000);
+    auto load = [&](u32 off) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0); };
+
+    const int n_tiles = (int)((sub_end - sub_start + kTileBytes - 1) / kTileBytes);
+    int n_safe = n_tiles;
+    while (n_safe > 0 && sub_start + (u64)n_safe * kTileBytes + 16 > p.len) n_safe--;
+
+    int t = -pre;
+    u32 toff = 0;
+    u32x4 cur = load(lane * 16u);
+    u32x4 nxt = load(lane * 16u + kTileBytes);
+    Carry c;
+    c.g63 = 0; c.tracked = 0; c.t_chars = 0; c.t_flags = 0; c.t_start = 0;
+    u32 s63c = 0;  // lane 63 of the previous tile: final start mask | own spill bits << 16
+
+    auto body = [&](auto near_tag) {
+        constexpr bool NE = decltype(near_tag)::value;
+        const u32x4 nn = load(toff + lane * 16u + 2 * kTileBytes);
+        const u64 tile_base = sub_start + (u64)((long long)t * (long long)kTileBytes);
+        const u64 lane_base = tile_base + 16ull * lane;
+        u32 avail = 32;
+        if (NE) avail = lane_base >= p.len ? 0u : (p.len - lane_base > 32 ? 32u : (u32)(p.len - lane_base));
+        const u32 valid = NE ? low_mask(avail) : 0xFFFFFFFFu;
+        const u32 nx = from_next(cur.x, bcast(nxt.x, 0));
+        const u32 xs[5] = { cur.x, cur.y, cur.z, cur.w, nx };
+
+        // ---- 1. byte classes (bits 0..15 own bytes, 16..19 the next lane's first four)
+        u32 fl[5], fa[5], fh[5], f8[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const u32 v = xs[k], t7 = v & 0x7F7F7F7Fu;
+            fl[k] = cls_lr(v);
+            if (AF_RANGE) fa[k] = swar_range(t7, a1, a2) & ~v & kM;
+            else fa[k] = (aflut[v & 0xFF] | (aflut[(v >> 8) & 0xFF] << 8) | (aflut[(v >> 16) & 0xFF] << 16) | (aflut[v >> 24] << 24)) & kM;
+            if (ENC == 5) {
+                fh[k] = swar_range(t7, rep4(0x80u - 0x21u), rep4(0x7Fu - 0x7Eu)) & v & kM;
+                f8[k] = swar_eq(v, 0x8F8F8F8Fu) & kM;
+            }
+        }
+        const u32 LR = (movemask16(fl[0], fl[1], fl[2], fl[3]) | (movemask4(fl[4]) << 16)) & valid;
+        const u32 asc = (movemask16(fa[0], fa[1], fa[2], fa[3]) | (movemask4(fa[4]) << 16)) & valid;
+        u32 L3 = 0;
+        if (ENC == 5) {
+            const u32 H = movemask16(fh[0], fh[1], fh[2], fh[3]) | (movemask4(fh[4]) << 16);
+            const u32 F8 = movemask16(f8[0], f8[1], f8[2], f8[3]);
+            L3 = F8 & (H >> 1) & 0xFFFFu;   // 8F followed by A1..FE: a three-byte token if it starts one
+        }
+        const u32 L2 = LR & ~L3 & 0xFFFFu;
+        const u32 known = ((~LR) & 0xFFFFu) << 1;  // the byte after a byte outside the lead range starts a token
+
+        // ---- 2. token starts for every possible hang-over
+        u32 St[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) St[s] = known | (1u << s);
+        for (;;) {
+            bool changed = false;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const u32 nw = St[s] | ((St[s] & L2) << 2) | ((St[s] & L3) << 3);
+                changed |= nw != St[s];
+                St[s] = nw;
+            }
+            if (!__ballot(changed)) break;
+        }
+        // ---- 3. the hang-over this lane starts with
+        u32 T = 0;  // T(s) at bits 2s..2s+1
+#pragma unroll
+        for (int s = 0; s < NS; s++) T |= (u32)__builtin_ctz(St[s] >> 16) << (2 * s);
+        u32 cov_in;
+        const bool has_reset = (LR & 0xFFFFu) != 0xFFFFu;
+        if (!__ballot(!has_reset)) {
+            cov_in = from_prev(T & 3u, cov);  // T is constant in every lane
+            cov = bcast(T & 3u, 63);
+        } else {
+            // inclusive prefix composition F_i = T_i o ... o T_0 (Hillis-Steele over the wavefront)
+            u32 F = T;
+#pragma unroll
+            for (u32 d = 1; d < 64; d <<= 1) {
+                const u32 G = shfl(F, lane >= d ? lane - d : lane);
+                u32 r = 0;
+#pragma unroll
+                for (int s = 0; s < NS; s++) r |= ((F >> (2 * ((G >> (2 * s)) & 3u))) & 3u) << (2 * s);
+                if (lane >= d) F = r;
+            }
+            const u32 Fc = (F >> (2 * cov)) & 3u;  // hang-over after my lane, given the tile's
+            cov_in = from_prev(Fc, cov);
+            cov = bcast(Fc, 63);
+        }
+        u32 S0 = NS == 2 ? (cov_in ? St[1] : St[0]) : (cov_in == 0 ? St[0] : (cov_in == 1 ? St[1] : St[NS - 1]));
+        S0 &= ~((1u << cov_in) - 1u);   // the hang-over bytes are not starts (a `known` bit may sit there)
+        S0 &= 0xFFFFu;
+
+        // ---- 4. one lookup per multi-byte token
+        u32 M3 = S0 & L3, P0 = S0 & L2, P1 = M3 << 1;  // lookup positions: table 0 at the token start, table 1 one byte later
+        if (NE) { P0 &= valid >> 1; M3 &= valid >> 2; P1 = M3 << 1; }
+        const u32 P = P0 | P1;
+        u32 A = 0, Mp = 0, Dbl = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32 w0 = xs[k >> 1], w1 = xs[(k >> 1) + 1];
+            const u32 u_even = (k & 1) ? (w0 >> 16) : (w0 & 0xFFFFu);
+            const u32 u_odd = (k & 1) ? (__builtin_amdgcn_alignbyte(w1, w0, 3) & 0xFFFFu) : ((w0 >> 8) & 0xFFFFu);
+            const u32 odd = (P >> (2 * k + 1)) & 1u;
+            u32 idx = odd ? u_odd : u_even;
+            if (ENC == 5) idx |= ((P1 >> (2 * k)) & 3u) ? 0x10000u : 0u;
+            const u32 word = lds_tab[idx >> 4];
+            const u32 code = (word >> ((idx & 15u) << 1)) & 3u;
+            const u32 sh = 2 * k + odd;
+            A |= (code >> 1) << sh; Mp |= ((code | (code >> 1)) & 1u) << sh; Dbl |= ((code == 2u) ? 1u : 0u) << sh;
+        }
+        if (ENC == 5) {  // a three-byte token that starts at byte 15: its lookup position is 16
+            const u32 idx = (nx & 0xFFFFu) | 0x10000u;
+            const u32 word = lds_tab[idx >> 4];
+            const u32 code = (word >> ((idx & 15u) << 1)) & 3u;
+            A |= (code >> 1) << 16; Mp |= ((code | (code >> 1)) & 1u) << 16;
+        }
+        A &= P; Mp &= P; Dbl &= P0;
+        const u32 A0 = A & P0, A1 = A & P1;
+        const u32 bad_last = (((P0 & ~Mp) << 1) | ((P1 & ~Mp) << 1)) & asc;  // malformed token, last byte ASCII: its own character
+        const u32 S1 = S0 & ~LR & asc;                                         // one-byte tokens
+        // ---- 5. good / start masks (bits 16.. spill onto the next lane's first bytes)
+        const u32 g = S1 | A0 | (A0 << 1) | (A1 >> 1) | A1 | (A1 << 1) | bad_last;
+        const u32 s = S1 | A0 | ((Dbl & A0) << 1) | (A1 >> 1) | bad_last;
+
+        const u32 g63_in = c.g63;
+        const bool tracked_in = c.tracked != 0;
+        const u32 pg = from_prev(g, g63_in);
+        const u32 gf = (g & 0xFFFFu) | (pg >> 16);
+        const u32 pgf = from_prev(gf, g63_in) & 0xFFFFu;
+        const u32 g63_out = bcast(gf | (g & 0xFFFF0000u), 63);
+        const u32 ps = from_prev(s, s63c);
+        const u32 sf = (s & 0xFFFFu) | (ps >> 16);
+        const u32 s63_in = s63c & 0xFFFFu;
+        s63c = bcast(sf | (s & 0xFFFF0000u), 63);
+
+        const u32 w = (gf << 16) | pgf;
+        u32 r = w;
+        r &= r << p.cand_sh[0]; r &= r << p.cand_sh[1]; r &= r << p.cand_sh[2];
+        r &= r << p.cand_sh[3]; r &= r << p.cand_sh[4];
+        const bool any_cand = __ballot((r & 0xFFFF0000u) != 0) != 0;
+        const bool first_tile = t == 0;
+        const bool first_open = first_tile && (g63_in & 0x8000u);
+        if (t < 0 || (!any_cand && !tracked_in && !first_open)) c.g63 = g63_out;
+        else {
+            const u32 sw = (sf << 16) | (from_prev(sf, s63_in) & 0xFFFFu);
+            bool done = false;
+            if (!tracked_in && !first_open) done = light_path(w, sw, r, lane_base, em, p.min_chars);
+            if (done) c.g63 = g63_out;
+            else {
+                if (lane == 0) atomicAdd(p.counters + 1, 1u);
+                const u64 tile_end = tile_base + kTileBytes < sub_end ? tile_base + kTileBytes : sub_end;
+                heavy_path(gf, sf, g, g63_in, s63_in, tile_base, tile_end, c, em, p.min_chars, p.cand_bytes, first_tile);
+            }
+        }
+        cur = nxt; nxt = nn; toff += kTileBytes; t++;
+    };
+
+    while (t < n_safe) body(std::false_type{});
+    while (t < n_tiles) body(std::true_type{});
+
+    if (c.tracked || (c.g63 & 0x8000u)) {
+        u64 os; u32 och, ofl;
+        if (c.tracked) { os = c.t_start; och = c.t_chars; ofl = c.t_flags; }
+        else {
+            const u32 suf = trailing_ones16(c.g63 & 0xFFFFu);
+            const u64 after = sub_start + (u64)n_tiles * kTileBytes;
+            os = after - suf;
+            och = (u32)__popc((s63c & 0xFFFFu) >> (16u - suf));
+            ofl = 0;
+        }
+        em.append(lane == 0, os, sub_end, och, ofl | kRecEndOpen);
+    }
+    em.end_region(wave);
+    em.invalidate_rest();
+}
+
+template <int ENC>
+static hipError_t launch_dbcs(const ScanParams& p, hipStream_t stream) {
+    u64 waves = (p.len + p.subchunk - 1) / p.subchunk;
+    u64 blocks = (waves + 3) / 4;
+    if (blocks == 0) return hipSuccess;
+    ScanParams q = p;
+    q.persistent = 0;
+    const size_t lds = DbcsTraits<ENC>::kTableWords * 4 + 256;
+    if (p.af_is_range) hipLaunchKernelGGL((scan_kernel_dbcs<ENC, true>), dim3((unsigned)blocks), dim3(256), lds, stream, q);
+    else hipLaunchKernelGGL((scan_kernel_dbcs<ENC, false>), dim3((unsigned)blocks), dim3(256), lds, stream, q);
+    return hipGetLastError();
+}
+
 template <class CLS, bool LUT>
 static hipError_t launch_v2(const ScanParams& p, hipStream_t stream) {
     const u64 n_tiles = (p.len + kOwnedBytes - 1) / kOwnedBytes;
@@ -853,6 +1129,8 @@ static hipError_t launch_t(const ScanParams& p, hipStream_t stream) {
 }
 
 hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t stream) {
+    if (kind == kClsBig5) return launch_dbcs<4>(p, stream);
+    if (kind == kClsEucJp) return launch_dbcs<5>(p, stream);
     if (p.traversal == 1) {
         switch (kind) {
         case kClsSingleByteLut: return launch_v2<SingleByteLut, true>(p, stream);
@@ -861,6 +1139,7 @@ hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t str
         case kClsUtf8Range2: return launch_v2<Utf8Range2, false>(p, stream);
         case kClsUtf16Range: return launch_v2<Utf16Range, false>(p, stream);
         case kClsSingleByteRange: return launch_v2<SingleByteRange, false>(p, stream);
+        default: break;
         }
     }
     switch (kind) {
@@ -870,6 +1149,7 @@ hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t str
     case kClsUtf8Range2: return launch_t<Utf8Range2, false>(p, stream);
     case kClsUtf16Range: return launch_t<Utf16Range, false>(p, stream);
     case kClsSingleByteRange: return launch_t<SingleByteRange, false>(p, stream);
+    default: break;
     }
     return hipErrorInvalidValue;
 }

@@ -40,9 +40,7 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
     m->long_run = (uint32_t)std::min<size_t>(in.chars_min_nb, m->q);
     if (m->long_run == 0) m->long_run = 1;
     const int enc = in.encoding;
-    const bool known = enc == SX_ENC_X_USER_DEFINED || enc == SX_ENC_UTF8 || enc == SX_ENC_UTF16LE
-                       || enc == SX_ENC_UTF16BE || single_byte_table(enc) != nullptr;
-    if (!known) { *err = "unsupported encoding id " + std::to_string(enc); return SX_E_INVALID; }
+    if (!encoding_is_known(enc)) { *err = "unsupported encoding id " + std::to_string(enc); return SX_E_INVALID; }
 
     ScanParams& p = m->proto;
     memset(&p, 0, sizeof p);
@@ -118,6 +116,39 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
                 H[hb] = v;
             }
         }
+    } else if (m->is_dbcs()) {
+        // Token classifier: accepted ASCII as a range (or a 256-entry LUT), and per byte pair a 2-bit code
+        // (sx_device.hpp ScanParams::pair_lut) from the decoder's own lookup + the filter on the UTF-8 lead byte.
+        m->kind = enc == SX_ENC_BIG5 ? kClsBig5 : kClsEucJp;
+        p.af_is_range = (!force_generic && af_is_range) ? 1u : 0u;
+        for (int b = 0; b < 128; b++) p.lut[b] = af[b] ? 0x80 : 0;
+        const uint16_t* t = decoder_table(enc, nullptr);
+        const size_t n_tables = enc == SX_ENC_BIG5 ? 1 : 2;
+        m->pair_lut.assign(n_tables * 4096, 0u);
+        auto put = [&](size_t table, uint32_t b0, uint32_t b1, uint32_t code) {
+            const uint32_t idx = b0 | (b1 << 8);
+            m->pair_lut[table * 4096 + (idx >> 4)] |= code << ((idx & 15u) * 2);
+        };
+        for (uint32_t b0 = 0x81; b0 <= 0xFE; b0++)
+            for (uint32_t b1 = 0; b1 < 256; b1++) {
+                if (enc == SX_ENC_BIG5) {
+                    uint32_t second = 0;
+                    const uint32_t cp = big5_lookup(t, b0, b1, &second);
+                    if (!cp) continue;
+                    // two characters (pointers 1133..1166): a break between them cannot be expressed per byte, so the
+                    // pair counts as accepted when either passes — a superset of the true runs (stage B is exact)
+                    const bool ok = m->filter.pass_lead(utf8_lead_of(cp)) || (second && m->filter.pass_lead(utf8_lead_of(second)));
+                    put(0, b0, b1, ok ? (second ? 2u : 3u) : 1u);
+                } else {
+                    if (b1 < 0xA1 || b1 > 0xFE) continue;
+                    if (b0 == 0x8E) { if (b1 <= 0xDF) put(0, b0, b1, m->filter.pass_lead(utf8_lead_of(0xFF61u - 0xA1u + b1)) ? 3u : 1u); continue; }
+                    if (b0 < 0xA1) continue;
+                    for (size_t tb = 0; tb < 2; tb++) {
+                        const uint32_t cp = t[tb * kJisN + (b0 - 0xA1) * 94 + (b1 - 0xA1)];
+                        if (cp) put(tb, b0, b1, m->filter.pass_lead(utf8_lead_of(cp)) ? 3u : 1u);
+                    }
+                }
+            }
     } else {  // x-user-defined and single-byte tables
         bool acc[256];
         const uint16_t* tab = single_byte_table(enc);

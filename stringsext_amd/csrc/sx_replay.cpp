@@ -122,6 +122,7 @@ private:
         uint64_t p = B >= back ? B - back : 0;
         if (m_.is_utf16() && ((stream0_ + p) & 1)) p = p ? p - 1 : p + 1;
         if (p <= pos && pos <= B) { p = pos; d = d_pos; }
+        else if (m_.is_dbcs()) p = dbcs_sync(B, p);
         if (p > B) p = B;
         uint8_t sink[96], last[4], mb[4];
         size_t last_len = 0, mb_len = 0;   // last accepted char; last accepted multi-byte char of the same stretch
@@ -156,6 +157,30 @@ private:
             st_->last_scan_run_leftover.append((const char*)last, last_len);
         }
         st_->last_run_str_was_printed_and_is_maybe_cut_str = false;
+    }
+
+    // Double-byte encodings: a token boundary in [lim, lim + 2], not beyond B (sx_replay_core.hpp dbcs_sync_before,
+    // over a ByteView): from the nearest byte outside the lead range in front of lim — the decoder is neutral right
+    // after it — or from the buffer start, where the token pending on entry ends after Mission::buf_entry_skip bytes.
+    uint64_t dbcs_sync(uint64_t B, uint64_t lim) {
+        const bool big5 = m_.c.encoding == SX_ENC_BIG5;
+        auto lead_range = [&](uint8_t b) { return big5 ? dbcs_is_lead_range<4>(b) : dbcs_is_lead_range<5>(b); };
+        uint64_t r = lim;
+        while (r > 0) {
+            const size_t n = (size_t)std::min<uint64_t>(r, 64);
+            const uint8_t* s = bytes_.span(r - n, n, &hint_);
+            size_t k = n;
+            while (k > 0 && lead_range(s[k - 1])) k--;
+            r = r - n + k;
+            if (k > 0) break;
+        }
+        if (r == 0) r = m_.buf_entry_skip;
+        while (r < lim) {
+            const size_t n = (size_t)std::min<uint64_t>(len_ - r, 3);
+            const uint8_t* s = bytes_.span(r, n, &hint_);
+            r += big5 ? dbcs_token_len<4>(s, n) : dbcs_token_len<5>(s, n);
+        }
+        return r < B ? r : B;
     }
 
     // First window start >= pos at which the replay must be running (len_ if there is none).
@@ -456,8 +481,9 @@ void replay_ranges(const Mission& m, const ScannerState& st, uint64_t len, const
     if (len == 0) return;
     const size_t W = m.window;
     const size_t first = ranges->size();
+    const uint64_t prime = m.is_dbcs() ? 96 : 16;  // double-byte: back to a byte outside the lead range (longer: fetched on demand)
     auto add = [&](uint64_t lo, uint64_t hi) {
-        lo = lo > 16 ? lo - 16 : 0;  // decoder priming
+        lo = lo > prime ? lo - prime : 0;  // decoder priming
         if (hi > len) hi = len;
         if (lo < hi) ranges->emplace_back(lo, hi);
     };

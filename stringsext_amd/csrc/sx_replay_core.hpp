@@ -131,13 +131,14 @@ SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs) {
     return b;
 }
 
-// Double-byte encodings: a token boundary b with lim <= b <= at (b may exceed lim by a token), found from the
-// nearest byte outside the lead range in front of `at` — the decoder is neutral right after such a byte —
-// or from `floor`, where it is neutral too (a clean call start; at the buffer start after `skip0` bytes that
-// finish the token pending on entry).  The walk back is as long as the stretch of lead-range bytes.
+// Double-byte encodings: a token boundary in [lim, lim + 2] (never beyond `at`), so that decoding from it sees
+// everything from lim on.  Found from the nearest byte outside the lead range in front of lim — the decoder
+// is neutral right after such a byte — or from `floor`, where it is neutral too (a clean call start; at the
+// buffer start after `skip0` bytes that finish the token pending on entry), jumping token by token from there.
+// The walk back is as long as the stretch of lead-range bytes in front of lim.
 template <int ENC>
 SXD u64 dbcs_sync_before(const u8* bytes, u64 len, u64 at, u64 floor, u32 skip0, u64 lim) {
-    u64 r = at;
+    u64 r = lim;
     while (r > floor && dbcs_is_lead_range<ENC>(bytes[r - 1])) r--;
     if (r == floor) r += skip0;
     while (r < lim) r += dbcs_token_len<ENC>(bytes + r, len - r);

@@ -17,7 +17,40 @@ uint64_t piece_bytes(const sx_ctx* ctx, uint64_t len) {
     uint64_t piece = 0;
     if (const char* e = getenv("SX_PIECE_MIB")) piece = (uint64_t)atoll(e) << 20;
     if (piece == 0 || len < 2 * piece) return len;
+    // a double-byte mission's token grid at a piece start follows from the bytes in front of it, which the
+    // kernels of a piece queued ahead cannot be told: such buffers are scanned in one go
+    for (const Mission& m : ctx->missions) if (m.is_dbcs()) return len;
     return piece / kInputBufLen * kInputBufLen;
+}
+
+// What the scan kernel needs to know about the state at buffer byte 0: UTF-16 the unit parity of the stream
+// offset; Big5 / EUC-JP how many bytes finish the token pending in the carried decoder (0 without a state).
+static int entry_param(sx_ctx* ctx, size_t k, const Decoder* carried, const uint8_t* host_bytes, const uint8_t* d_bytes,
+                       uint64_t len, uint64_t stream_off, uint32_t* out) {
+    const Mission& m = ctx->missions[k];
+    *out = (uint32_t)(stream_off & 1);
+    if (!m.is_dbcs()) return SX_OK;
+    *out = 0;
+    if (!carried || carried->idle() || len == 0) return SX_OK;
+    uint8_t first[2] = { 0, 0 };
+    const uint64_t n = std::min<uint64_t>(2, len);
+    if (host_bytes) memcpy(first, host_bytes, n);
+    else HIP_TRY(ctx, hipMemcpy(first, d_bytes, n, hipMemcpyDeviceToHost));
+    *out = carried->entry_skip(first, n);
+    return SX_OK;
+}
+int set_entry_params(sx_ctx* ctx, bool carried_state_is_entry, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len,
+                     uint64_t stream_off, std::vector<uint32_t>* parity) {
+    parity->clear();
+    for (size_t k = 0; k < ctx->missions.size(); k++) {
+        uint32_t ep = 0;
+        int rc = entry_param(ctx, k, carried_state_is_entry ? &ctx->states[k].decoder : nullptr, host_bytes, d_bytes, len,
+                             stream_off, &ep);
+        if (rc != SX_OK) return rc;
+        parity->push_back(ep);
+        ctx->missions[k].buf_entry_skip = ctx->missions[k].is_dbcs() ? ep : 0u;
+    }
+    return SX_OK;
 }
 
 // Missions in the order their kernels are queued: busiest of the previous buffer first, so that
@@ -125,7 +158,12 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
         b.order = order;
         b.slot = (int)(p & 1);
         for (size_t k = 0; k < nm; k++) {
-            b.parity.push_back((uint32_t)((stream0[k] + off) & 1));
+            uint32_t ep = (uint32_t)((stream0[k] + off) & 1);
+            if (ctx->missions[k].is_dbcs()) {  // one piece only (piece_bytes): the carried decoder describes byte 0
+                (void)entry_param(ctx, k, &ctx->states[k].decoder, b.host_bytes, b.d_bytes, b.len, 0, &ep);
+                ctx->missions[k].buf_entry_skip = ep;
+            }
+            b.parity.push_back(ep);
             b.minc.push_back(ctx->missions[k].long_run);
         }
         return b;
@@ -173,9 +211,12 @@ int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
     }
     const bool scan_now = !given_runs && !(reuse_runs && ctx->shard_runs_valid);
     BufferScan b;
+    {   // only the shard that starts the file knows the state at its byte 0 (the context's carried state)
+        int rc = set_entry_params(ctx, buf_off == 0, host_bytes, d_bytes, buf_len, file_stream_off + buf_off, &b.parity);
+        if (rc != SX_OK) return rc;
+    }
     if (scan_now) {
         b.host_bytes = host_bytes; b.d_bytes = d_bytes; b.len = buf_len; mission_order(ctx, &b.order); b.slot = 0;
-        b.parity.assign(nm, (uint32_t)((file_stream_off + buf_off) & 1));
         for (size_t k = 0; k < nm; k++) b.minc.push_back(ctx->missions[k].long_run);
         int rc = b.launch(ctx);
         if (rc == SX_OK) rc = b.fetch_base(ctx);

@@ -61,6 +61,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         P.W = (uint32_t)W; P.long_run = m.long_run; P.skip = getenv("SX_NO_REPLAY_SKIP") ? 0u : 1u; P.grep_char = m.c.grep_char; P.mission_id = m.c.mission_id;
         P.file_id = job.file_id; P.af_lo = m.c.af_lo; P.af_hi = m.c.af_hi; P.ubf = m.c.ubf;
         P.max_windows = kMaxRegionWindowsDefault;
+        P.entry_skip = m.buf_entry_skip;
         if (const char* e = getenv("SX_MAX_REGION_WINDOWS")) P.max_windows = (uint32_t)std::max(1, atoi(e));
         // pass-1 output cache: one arena for all replaying regions (slot = arena / their number, on the device)
         if (dev_stitch && !getenv("SX_NO_REPLAY_CACHE")) {

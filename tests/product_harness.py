@@ -5,12 +5,48 @@ import stringsext_amd as sx
 import sxo_binding as sxo
 
 
-def oracle_runs_for_chunk(mdicts, chunk, stream_bytes):
+def dbcs_hangover(enc, before, chunk):
+    """Double-byte encodings (64 Big5, 65 EUC-JP): how many bytes at the start of `chunk` finish a token that began
+    in `before` (the bytes of the stream in front of it) — what the product derives from its carried decoder."""
+    lead = (lambda b: 0x81 <= b <= 0xFE) if enc == 64 else (lambda b: b in (0x8E, 0x8F) or 0xA1 <= b <= 0xFE)
+    data = before + chunk[:3]
+    r = len(before)
+    while r > 0 and lead(data[r - 1]):
+        r -= 1
+    while r < len(before):
+        n = 1
+        if lead(data[r]):
+            n = 3 if (enc == 65 and data[r] == 0x8F and r + 1 < len(data) and 0xA1 <= data[r + 1] <= 0xFE) else 2
+        if r + n > len(before):
+            over = r + n - len(before)
+            # a malformed token gives its last byte back if that byte is ASCII: it is then not part of the hang-over
+            last = data[r + n - 1] if r + n - 1 < len(data) else 0x80
+            if last < 0x80 and not _dbcs_valid(enc, data[r:r + n]):
+                over -= 1
+            return over
+        r += n
+    return 0
+
+
+def _dbcs_valid(enc, tok):
+    codec = "big5hkscs" if enc == 64 else "euc_jp"
+    try:
+        bytes(tok).decode(codec)
+        return True
+    except UnicodeDecodeError:
+        return False
+
+
+def oracle_runs_for_chunk(mdicts, chunk, stream_bytes, before=b""):
     """What stage A must report for this chunk, computed by the oracle's sequential decoder."""
     out = []
     for m in mdicts:
         long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
-        out.append(sxo.runs(m, chunk, stream_parity=stream_bytes & 1, min_chars=long_run))
+        if m["encoding"] in (64, 65):
+            skip = dbcs_hangover(m["encoding"], before, chunk)
+            out.append([(a + skip, b + skip, c) for a, b, c in sxo.runs(m, chunk[skip:], min_chars=long_run)])
+        else:
+            out.append(sxo.runs(m, chunk, stream_parity=stream_bytes & 1, min_chars=long_run))
     return out
 
 
@@ -23,6 +59,7 @@ def run_cli_product(mdicts, files, radix=None, no_metadata=False, chunk_bytes=No
                     subchunk_bytes=subchunk_bytes, record_capacity=record_capacity, device_replay=device_replay)
     out = bytearray(sx.OUTPUT_BOM)
     stream = 0
+    before = b""   # the stream in front of the current chunk (decoders persist across files)
     try:
         for fi, data in enumerate(files):
             data = bytes(data)
@@ -33,7 +70,7 @@ def run_cli_product(mdicts, files, radix=None, no_metadata=False, chunk_bytes=No
                 chunk = data[off:off + step]
                 last = flush_at_eof and fi == len(files) - 1 and off + len(chunk) == len(data)
                 if host_only:
-                    res = sc.replay_runs(chunk, oracle_runs_for_chunk(mdicts, chunk, stream), file_id=fi + 1,
+                    res = sc.replay_runs(chunk, oracle_runs_for_chunk(mdicts, chunk, stream, before[-4096:]), file_id=fi + 1,
                                          is_last=last)
                 else:
                     res = sc.scan(chunk, file_id=fi + 1, is_last=last)
@@ -41,6 +78,7 @@ def run_cli_product(mdicts, files, radix=None, no_metadata=False, chunk_bytes=No
                 res.free()
                 off += len(chunk)
                 stream += len(chunk)
+                before = (before + chunk)[-8192:]
     finally:
         sc.close()
     out += b"\n"

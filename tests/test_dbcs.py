@@ -1,0 +1,188 @@
+"""Big5 and EUC-JP (BASELINE config 5; reference: help.rs:56-57 lists them, mission.rs:681 resolves them through
+Encoding::for_label, the decoders are encoding_rs').  No reference test decodes a legacy multi-byte encoding
+(parity unpinned), so the oracle's decoders are pinned here on two second sources —
+CPython's codecs and hand-derived vectors of the WHATWG "Big5 decoder" / "EUC-JP decoder" algorithms — and the
+product's host side (same code as the device's: sx_codec_core.hpp, sx_replay_core.hpp) is compared with the
+oracle on text, binary soups and chunk boundaries."""
+import random
+import zlib
+
+import pytest
+
+import refconfig as rc
+import stringsext_amd as sx
+import sxo_binding as sxo
+from product_harness import run_cli_product
+
+ZH = ("這是一個測試字串，用來檢查大五碼解碼器。香港增補字符集：𠄌𠝹 Ê̄ê̌ 結束。"
+      "天地玄黃宇宙洪荒日月盈昃辰宿列張寒來暑往秋收冬藏閏餘成歲律呂調陽")
+JA = ("これは日本語のテスト文字列です。ﾊﾝｶｸｶﾅ ① 丂丄 漢字かな交じり文。"
+      "いろはにほへとちりぬるをわかよたれそつねならむうゐのおくやまけふこえてあさきゆめみしゑひもせす")
+CODEC = {"big5": "big5hkscs", "euc-jp": "euc_jp"}
+TEXT = {"big5": ZH, "euc-jp": JA}
+ALL = "0xffffffffffffffff"
+
+
+def one(enc, data, **kw):
+    """all strings the oracle finds, as (position, precision, completes, text)"""
+    kw.setdefault("chars_min", "1")
+    ms = rc.missions(encodings=[enc], unicode_block_filter=ALL, ascii_filter="0xffffffffffffffffffffffffffffffff", **kw)
+    sc = sxo.Scanner(ms[0])
+    return [(f["position"], f["precision"], f["completes"], f["s"]) for f in sc.scan(data, is_last=True)]
+
+
+# ---- the oracle's decoders against second sources -------------------------------------------------------------------
+
+@pytest.mark.parametrize("enc", ["big5", "euc-jp"])
+def test_oracle_decodes_valid_text_like_cpython(enc):
+    """Every mapped two-byte (and, EUC-JP, three-byte) sequence on its own, framed by NULs: the oracle prints what
+    CPython's codec decodes, wherever the two sources of the tables agree (tests/test_tables.py)."""
+    codec = CODEC[enc]
+    checked = 0
+    seqs = []
+    for a in range(0x81, 0xFF):
+        for b in list(range(0x40, 0x7F)) + list(range(0xA1, 0xFF)):
+            seqs.append(bytes([a, b]))
+    if enc == "euc-jp":
+        seqs += [bytes([0x8F, a, b]) for a in range(0xA1, 0xFF, 3) for b in range(0xA1, 0xFF)]
+    for i in range(0, len(seqs), 400):
+        blob = b"".join(s + b"\n" for s in seqs[i:i + 400])
+        got = sxo.run_cli(rc.missions(encodings=[enc], chars_min="1", unicode_block_filter=ALL), [blob], no_metadata=True)
+        lines = got[3:].decode("utf-8").split("\n")
+        found = {l for l in lines if l}
+        for s in seqs[i:i + 400]:
+            try:
+                want = s.decode(codec)
+            except UnicodeDecodeError:
+                continue
+            if any(ord(c) < 0x80 for c in want):
+                continue  # cp/hkscs decodes lead + ASCII as two chars where WHATWG has an error + ASCII
+            if want in found:
+                checked += 1
+    assert checked > (13000 if enc == "big5" else 8000)  # the bulk of the index (patched cells differ by design)
+
+
+def test_oracle_big5_follows_the_whatwg_algorithm_on_hand_derived_vectors():
+    # (bytes, expected strings with the position of the decoder call that printed them)
+    A = b"AB"
+    # valid pair, trail in 40..7E and in A1..FE
+    assert one("big5", b"\xa4\x40\xa4\xa1")[0][3] == "一丑"
+    # lead + ASCII trail that does not map (0x81 0x41: below the index): error, the ASCII byte is read again
+    assert [x[3] for x in one("big5", b"\x81AB")] == ["AB"]
+    assert one("big5", b"\x81AB")[0][0] == 1          # the call after the error starts AT the 'A'
+    # lead + non-ASCII invalid trail (0x80): both consumed, next call starts behind them
+    assert one("big5", b"\xa4\x80AB")[0][0] == 2
+    # lead + 0xFF: both consumed
+    assert one("big5", b"\xa4\xffAB")[0][0] == 2
+    # 0x80 and 0xFF alone are one-byte errors
+    assert one("big5", b"\x80" + A)[0][0] == 1 and one("big5", b"\xff" + A)[0][0] == 1
+    # after a lead ANY byte returns to neutral: a4 a4 40 = (a4 a4)(40) not (a4)(a4 40)
+    assert [x[3] for x in one("big5", b"\xa4\xa4\x40")] == [b"\xa4\xa4".decode("big5") + "@"]
+    # the four pointers with two code points
+    assert one("big5", b"\x88\x62\x88\x64\x88\xa3\x88\xa5")[0][3] == "Ê̄Ê̌ê̄ê̌"
+    # a lead at the very end with is_last: error, nothing printed after it
+    assert [x[3] for x in one("big5", b"AB\xa4")] == ["AB"]
+    # astral (HKSCS): one four-byte UTF-8 char
+    assert one("big5", "𠄌".encode("big5hkscs"))[0][3] == "𠄌"
+
+
+def test_oracle_euc_jp_follows_the_whatwg_algorithm_on_hand_derived_vectors():
+    assert one("euc-jp", b"\xa4\xa2\xa4\xa4")[0][3] == "あい"
+    assert one("euc-jp", b"\x8e\xb1\x8e\xdf")[0][3] == "ｱﾟ"            # 8E + A1..DF: half-width katakana
+    assert one("euc-jp", b"\x8e\xe0AB")[0][0] == 2                      # 8E + E0: error, both consumed
+    assert one("euc-jp", b"\x8eAB")[0] [0] == 1 and one("euc-jp", b"\x8eAB")[0][3] == "AB"  # ASCII trail read again
+    assert one("euc-jp", b"\x8f\xb0\xa1")[0][3] == "丂"                  # three bytes: jis0212
+    assert one("euc-jp", b"\x8f\xb0AB")[0][0] == 2 and one("euc-jp", b"\x8f\xb0AB")[0][3] == "AB"  # 3rd byte ASCII: read again
+    assert one("euc-jp", b"\x8f\xb0\x80AB")[0][0] == 3                  # 3rd byte invalid, not ASCII: consumed
+    assert one("euc-jp", b"\x8f\x8eAB")[0][0] == 2                      # 8F + non-A1..FE: error, both consumed
+    assert one("euc-jp", b"\x8fAB")[0][0] == 1
+    assert one("euc-jp", b"\xa4\x8eAB")[0][0] == 2                      # lead + invalid trail: consumed
+    assert one("euc-jp", b"\x90AB")[0][0] == 1 and one("euc-jp", b"\xa0AB")[0][0] == 1 and one("euc-jp", b"\xffAB")[0][0] == 1
+    assert one("euc-jp", b"\xad\xa1")[0][3] == "①" and one("euc-jp", b"\xf9\xa1")[0][3] == "纊"   # NEC row 13, IBM extension
+    assert one("euc-jp", b"\xa1\xc0")[0][3] == "＼"                     # FF3C (Windows-31J flavour), not 005C
+    assert [x[3] for x in one("euc-jp", b"AB\x8f\xb0")] == ["AB"]       # pending at the end with is_last
+
+
+# ---- the product's host side against the oracle ---------------------------------------------------------------------
+
+def soup(enc, rng, n):
+    txt, codec = TEXT[enc], CODEC[enc]
+    nasty = [0x8E, 0x8F, 0xA1, 0xFE, 0x81, 0x80, 0xFF, 0x40, 0x7E, 0xA4, 0x88, 0x62, 0xA5, 0x0A, 0x20, 0xB0]
+    out = bytearray()
+    while len(out) < n:
+        r = rng.random()
+        if r < 0.3: out += txt[rng.randrange(len(txt)):][:rng.randrange(1, 40)].encode(codec, "ignore")
+        elif r < 0.5: out += rng.randbytes(rng.randrange(1, 100))
+        elif r < 0.6: out += b"plain ascii text %d " % rng.randrange(1000)
+        elif r < 0.72: out += bytes(rng.choice(nasty) for _ in range(rng.randrange(1, 30)))
+        elif r < 0.8: out += b"\x00" * rng.randrange(1, 300)
+        elif r < 0.85: out += txt.encode(codec, "ignore")[rng.randrange(2):] * rng.randrange(1, 12)   # long stretches without any ASCII
+        else: out += txt.encode(codec, "ignore") * rng.randrange(1, 4)
+    return bytes(out[:n])
+
+
+DBCS_FLAGS = [
+    dict(chars_min="4", unicode_block_filter=ALL),
+    dict(chars_min="3", output_line_len="16", unicode_block_filter="Cjk"),
+    dict(chars_min="2", unicode_block_filter="Asian", same_unicode_block=True),
+    dict(chars_min="5", grep_char="0x20", unicode_block_filter=ALL),
+    dict(chars_min="10", unicode_block_filter="Kana"),
+    dict(chars_min="1", output_line_len="6", unicode_block_filter="0x1008", ascii_filter="None"),   # C3 (Latin-1) yes, CC (combining) no: the Big5 pairs
+    dict(chars_min="4", unicode_block_filter="Common"),  # no CJK at all: only ASCII and what maps below U+0800
+]
+
+
+@pytest.mark.parametrize("enc", ["big5", "euc-jp"])
+@pytest.mark.parametrize("flags", DBCS_FLAGS, ids=lambda f: "n" + f["chars_min"] + "-" + f["unicode_block_filter"])
+def test_host_replay_equals_oracle(enc, flags):
+    rng = random.Random(zlib.crc32((enc + repr(sorted(flags.items()))).encode()))
+    data = soup(enc, rng, 150_000)
+    ms = rc.missions(encodings=[enc, "utf-8"], **flags)
+    want = sxo.run_cli(ms, [data], radix="x")
+    assert len(want) > 1000
+    assert run_cli_product(ms, [data], radix="x") == want
+    for chunk in (4096, 8192, 65536):
+        assert run_cli_product(ms, [data], radix="x", chunk_bytes=chunk) == want, chunk
+
+
+@pytest.mark.parametrize("enc", ["big5", "euc-jp"])
+def test_tokens_across_chunk_and_file_boundaries(enc):
+    """A token cut by a chunk boundary (lead | trail, 8F | xx | xx) is finished from the carried decoder; the token
+    grid of the next chunk starts behind it; the state is carried over file boundaries as in the reference."""
+    codec = CODEC[enc]
+    word = TEXT[enc][:24].encode(codec, "ignore")
+    ms = rc.missions(encodings=[enc], chars_min="3", unicode_block_filter=ALL)
+    for shift in range(0, 7):
+        for extra in (b"", b"\x8f\xb0\xa1\x8f\xb0\xa1" if enc == "euc-jp" else b"\x88\x62\x88\xa5"):
+            data = b"\x00" * (4096 - 5 - shift) + extra + word * 3 + b"\x00" * 100
+            data += b"\xa4" * (8192 - len(data) % 8192 - 1 - shift) + word + b"\n" * 50   # a long stretch of lead-range bytes over a boundary
+            want = sxo.run_cli(ms, [data], radix="x")
+            assert run_cli_product(ms, [data], radix="x", chunk_bytes=4096) == want, (shift, extra)
+            # two files: the pending lead byte survives the end of the first one
+            cut = 4096 + 1
+            want2 = sxo.run_cli(ms, [data[:cut], data[cut:]], radix="x")
+            assert run_cli_product(ms, [data[:cut], data[cut:]], radix="x") == want2, (shift, extra)
+
+
+@pytest.mark.parametrize("enc", ["big5", "euc-jp"])
+@pytest.mark.parametrize("flags", DBCS_FLAGS[:5], ids=lambda f: "n" + f["chars_min"] + "-" + f["unicode_block_filter"])
+def test_device_replay_core_emulated_on_cpu_equals_oracle(enc, flags):
+    """The device's stage B (sx_replay_core.hpp compiled for the host, driven like the kernels drive it: one
+    region per head run from derived state, with and without the shortcuts) for the double-byte decoders."""
+    import test_replay_core as trc
+    from test_sharded_gloo import oracle_findings
+    core = trc.load_core()
+    rng = random.Random(zlib.crc32((enc + "emu" + repr(sorted(flags.items()))).encode()))
+    m = rc.missions(encodings=[enc], **flags)[0]
+    long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
+    done = 0
+    for data in (soup(enc, rng, 60_000), soup(enc, rng, 30_001), rng.randbytes(40_000)):
+        runs = sxo.runs(m, data, min_chars=long_run)
+        want = [(p, pr, s, c, si) for p, pr, s, c, _, si in oracle_findings([m], data)]
+        for skip in (1, 0):
+            got = trc.emulate_device_stage_b(core, m, data, runs, skip=skip)
+            if got is None:
+                continue
+            assert got == want, (skip, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
+            done += 1
+    assert done > 0

@@ -1,0 +1,86 @@
+"""GPU parity for the double-byte encodings (Big5, EUC-JP; BASELINE config 5): stage A's token classifier
+(csrc/sx_kernels.hip scan_kernel_dbcs) against the oracle's sequential decoder, and the whole path —
+kernels, device and host replay — against the oracle's full scan.  Through the C-ABI."""
+import random
+import zlib
+
+import pytest
+
+import refconfig as rc
+import sxo_binding as sxo
+from product_harness import run_cli_product
+from test_dbcs import ALL, CODEC, DBCS_FLAGS, TEXT, soup
+from test_gpu_parity import device_runs
+
+pytestmark = pytest.mark.gpu
+
+RUNS = {
+    "all": dict(chars_min="4", unicode_block_filter=ALL),
+    "cjk": dict(chars_min="3", unicode_block_filter="Cjk"),
+    "asian_n10": dict(chars_min="10", unicode_block_filter="Asian"),
+    "kana_noascii": dict(chars_min="2", unicode_block_filter="Kana", ascii_filter="None"),
+    "common": dict(chars_min="5", unicode_block_filter="Common"),
+    "odd_af": dict(chars_min="4", unicode_block_filter="Cjk", ascii_filter="0x7ffffffe000000007ffffffe00000000"),
+}
+
+
+@pytest.mark.parametrize("enc", ["big5", "euc-jp"])
+@pytest.mark.parametrize("name", sorted(RUNS))
+def test_device_runs_equal_oracle_runs(enc, name):
+    m = rc.missions(encodings=[enc], **RUNS[name])[0]
+    rng = random.Random(zlib.crc32((enc + name).encode()))
+    txt = TEXT[enc].encode(CODEC[enc], "ignore")
+    datas = [
+        soup(enc, rng, 300_000),
+        rng.randbytes(1 << 20),
+        txt * 300,                                        # no byte outside the lead range for kilobytes
+        b"\xa4" * 5000 + b"A" + b"\xa4" * 5001 + b"\n" + txt * 40,   # long stretches of one lead-range byte, both parities
+        b"\x8f\xb0\xa1" * 3000 + b"\x8f" * 3001 + txt * 10 + b"\x8e\xb1" * 2000,
+        txt[:1023], txt[:1025], txt[1:18], b"abcdefghijkl", b"", b"\xa4", b"\xa4\x40",
+        b"A" * 5000 + rng.randbytes(3000) + txt * 7 + b"\x00" * 100 + b"zz" * 3000,
+    ]
+    for di, data in enumerate(datas):
+        for sub in (1024, 4096, 65536):
+            if sub != 65536 and len(data) > 400_000:
+                continue
+            got, mc = device_runs(m, data, subchunk=sub)
+            want = sxo.runs(m, data, min_chars=mc)
+            assert got == want, (enc, name, di, sub, len(got), len(want),
+                                 next(((a, b) for a, b in zip(got, want) if a != b), None))
+
+
+@pytest.mark.parametrize("enc", ["big5", "euc-jp"])
+@pytest.mark.parametrize("flags", DBCS_FLAGS, ids=lambda f: "n" + f["chars_min"] + "-" + f["unicode_block_filter"])
+def test_end_to_end_equals_oracle(enc, flags):
+    rng = random.Random(zlib.crc32((enc + "gpu" + repr(sorted(flags.items()))).encode()))
+    files = [soup(enc, rng, 400_000), soup(enc, rng, 20_001), b"", TEXT[enc].encode(CODEC[enc], "ignore") * 200]
+    ms = rc.missions(encodings=[enc, "utf-8", "utf-16le"], **flags)
+    want = sxo.run_cli(ms, files, radix="x")
+    for chunk, sub, dev_replay in ((None, 0, None), (16384, 1024, None), (None, 0, True), (65536, 4096, True)):
+        got = run_cli_product(ms, files, radix="x", chunk_bytes=chunk, device=0, subchunk_bytes=sub, device_replay=dev_replay)
+        assert got == want, (chunk, sub, dev_replay)
+
+
+def test_c5_six_missions_on_a_planted_image():
+    """BASELINE config 5 with the per-encoding filters SURVEY 8(a) recommends, missions built by the product's
+    front end from the literal flag strings."""
+    import stringsext_amd as sx
+    flags = dict(encodings=["utf-8,,,African", "utf-16le,,,African", "utf-16be,,,African", "big5,,,Cjk", "euc-jp,,,Asian",
+                            "koi8-r,,,Cyrillic"], chars_min="10")
+    ms = sx.missions_from_flags(**flags)
+    assert ms == rc.missions(**flags)
+    rng = random.Random(5)
+    data = bytearray(sxo.background(0, 8 << 20))
+    texts = [("Բարեւ աշխարհ — שלום עולם — مرحبا بالعالم /usr/share/doc", ["utf-8", "utf-16-le", "utf-16-be"]),
+             (TEXT["big5"], ["big5hkscs"]), (TEXT["euc-jp"], ["euc_jp"]), ("Привет, мир! Доброе утро, страна.", ["koi8-r"])]
+    pos = 3000
+    while pos + 2000 < len(data):
+        t, codecs = rng.choice(texts)
+        b = t.encode(rng.choice(codecs), "ignore")
+        data[pos:pos + len(b)] = b
+        pos += rng.choice([4096 - 40, 65536 - 17, 128 * 3 + 5, 20000])
+    data = bytes(data)
+    want = sxo.run_cli(ms, [data], radix="x")
+    assert want.count(b"(d Big5)") > 50 and want.count(b"(e EUC-JP)") > 50 and want.count(b"(f KOI8-R)") > 20
+    for dev_replay in (None, True):
+        assert run_cli_product(ms, [data], radix="x", device=0, device_replay=dev_replay) == want
