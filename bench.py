@@ -34,7 +34,24 @@ WORKLOADS = {
     # BASELINE.json configs[1]
     "c2": dict(flags=dict(encodings=["utf-8"], chars_min="10"), gib=4.0, kernels="Utf8Range2",
                name="C2: -e utf-8 -n 10 -t x, synthetic background"),
+    # BASELINE.json configs[4]: six missions, the legacy ones with the per-encoding filters SURVEY.md 8(a) recommends
+    # (with a global -u African no CJK or Cyrillic character could ever pass and the tables would never matter)
+    "c5": dict(flags=dict(encodings=["utf-8,,,African", "utf-16le,,,African", "utf-16be,,,African", "big5,,,Cjk",
+                                     "euc-jp,,,Asian", "koi8-r,,,Cyrillic"], chars_min="10"), gib=64.0,
+               kernels="Utf8Range2|Utf16Range x2|scan_kernel_dbcs<4> (Big5)|scan_kernel_dbcs<5> (EUC-JP)|SingleByteLut (KOI8-R)",
+               name="C5: -e utf-8,,,African -e utf-16le,,,African -e utf-16be,,,African -e big5,,,Cjk -e euc-jp,,,Asian "
+                    "-e koi8-r,,,Cyrillic -n 10 -t x, synthetic background"),
 }
+
+
+def scan_kernel_source_hash():
+    """What roofline.traffic was measured for: the PMC passes are separate runs (profiles/traffic.json), valid only
+    as long as the scan kernels' source is the one they ran."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("sx_kernels.hip", "sx_device.hpp"):
+        h.update(open(os.path.join(ROOT, "stringsext_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -77,7 +94,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     wl = WORKLOADS[args.workload]
-    missions = rc.missions(**wl["flags"])
+    missions = sx.missions_from_flags(**wl["flags"])   # the product's front end, from the literal flag strings
+    assert missions == rc.missions(**wl["flags"])      # (the reference's rules restated in tests/refconfig.py: the checker)
     nbytes = int((args.gib if args.gib is not None else wl["gib"]) * (1 << 30)) // 4096 * 4096
     sc = sx.Scanner(missions, device=local_rank, subchunk_bytes=args.subchunk_kib * 1024)
 
@@ -107,17 +125,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    timings = {}
+
     def step():
         sc.reset()
         if world == 1:
             res = sc.scan_device(dptr, nbytes, file_id=1)
             n = len(res)
         else:
-            # shard scan + one all_gather over RCCL ("where did everybody start and stop", finding counts);
-            # the findings stay on the rank that found them: rank k holds segment k, in order
-            counts, res = sharded.scan_sharded(sc, get_buffer, file_len, file_id=1, halo=halo,
-                                               device=xdev, gather=False)
-            n = sum(counts)
+            # shard scan + one all_gather over RCCL ("where did everybody start and stop", finding counts), then the
+            # gather of the Finding buffers to rank 0 (BASELINE config 4) — all inside the timed region
+            gathered, res = sharded.scan_sharded(sc, get_buffer, file_len, file_id=1, halo=halo,
+                                                 device=xdev, gather=True, timings=timings)
+            n = sum(len(fb) // 32 for fb, _ in gathered) if rank == 0 else 0
         st = sc.stats()
         res.free()
         return n, st
@@ -180,8 +200,8 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj["workload"] == args.workload and tj["bytes_per_gpu"] == nbytes:
-                traffic = tj["traffic_bytes_per_launch"]
+            if tj["workload"] == args.workload and tj["bytes_per_gpu"] == nbytes and tj.get("scan_kernel_source") == scan_kernel_source_hash():
+                traffic = tj["traffic_bytes_per_launch"]   # else null: the counters were taken with other kernels
         except (OSError, KeyError, ValueError):
             pass
         roofline = {
@@ -206,6 +226,8 @@ def main():
                                       "host_waits_for_stage_a": round(device_ms, 3),
                                       "sparse_download_for_host_replay": round(d2h_ms / K, 3),
                                       "host_part_of_stage_b": round(replay_ms / K, 3)},
+            "gather_ms_per_step": round(timings.get("gather_ms", 0.0), 3) if world > 1 else None,
+            "exchange_ms_per_step": round(timings.get("exchange_ms", 0.0), 3) if world > 1 else None,
             "findings_per_step": findings, "run_records_rank0": records,
             "replay_fraction": round(replay_bytes / (len(missions) * nbytes), 5),
             "kernels_only_gib_s": round(world * nbytes / (sum(kernel_ms) * 1e-3) / (1 << 30), 1) if sum(kernel_ms) > 0 else None,

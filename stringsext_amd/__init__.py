@@ -233,13 +233,27 @@ class Result:
         return lib().sx_result_count(self.h)
 
     def raw(self):
-        """(findings array bytes, arena bytes): the buffers a gather moves between ranks."""
+        """(findings array bytes, arena bytes) of the whole result as one pair (joined by a copy if it has
+        several segments; raises if their strings exceed 4 GiB — read segments() then)."""
         L = lib()
         n = L.sx_result_count(self.h)
         alen = C.c_uint64()
         ap = L.sx_result_arena(self.h, C.byref(alen))
-        fb = C.string_at(L.sx_result_findings(self.h), n * C.sizeof(Finding)) if n else b""
-        return fb, (C.string_at(ap, alen.value) if alen.value else b"")
+        fp = L.sx_result_findings(self.h)
+        if n and not fp:   # flatten failed (sx_result_findings returns NULL): > 4 GiB of strings
+            raise SxError(SX_E_INVALID, lib().sx_last_error(self._s.h).decode() or "result too large for one arena: use segments()")
+        fb = C.string_at(fp, n * C.sizeof(Finding)) if n else b""
+        return fb, (C.string_at(ap, alen.value) if alen.value and ap else b"")
+
+    def segment_pointers(self):
+        """[(Finding pointer, n findings, arena pointer, arena bytes)] per segment — no copies."""
+        L = lib()
+        out = []
+        for i in range(L.sx_result_segments(self.h)):
+            fp, n, ap, alen = C.POINTER(Finding)(), C.c_uint64(), C.POINTER(C.c_uint8)(), C.c_uint64()
+            self._s._chk(L.sx_result_segment(self.h, i, C.byref(fp), C.byref(n), C.byref(ap), C.byref(alen)))
+            out.append((fp, n.value, ap, alen.value))
+        return out
 
     def finding_arrays(self):
         """[(Finding pointer, n)] per segment — no copies (the strings stay where they are)."""

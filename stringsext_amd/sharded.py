@@ -41,8 +41,33 @@ def _all_gather_u64(values, device):
     return [[int(x) for x in o.tolist()] for o in out]
 
 
+def _payload(res):
+    """The rank's findings as ONE (findings bytes, arena bytes) pair without going through Python bytes: numpy views
+    of the result's segments (pinned host memory the device wrote), str_off rebased where there are several."""
+    import numpy as np
+    fdt = np.dtype({"names": ["position", "str_off", "str_len", "slice_index"], "formats": ["<u8", "<u4", "<u4", "<u4"],
+                    "offsets": [0, 8, 12, 24], "itemsize": ctypes.sizeof(Finding)})
+    assert fdt.itemsize == ctypes.sizeof(Finding)
+    fs, ars, base = [], [], 0
+    for fp, n, ap, alen in res.segment_pointers():
+        if n:
+            f = np.ctypeslib.as_array(ctypes.cast(fp, ctypes.POINTER(ctypes.c_uint8)), shape=(n * fdt.itemsize,)).view(fdt)
+            if base:
+                f = f.copy()
+                f["str_off"] += base
+            fs.append(f)
+        if alen:
+            ars.append(np.ctypeslib.as_array(ap, shape=(alen,)))
+        base += alen
+    if base > 0xFFFFFFFF:
+        raise ValueError("more than 4 GiB of strings in one rank's result: gather segment by segment")
+    f = fs[0] if len(fs) == 1 else (np.concatenate(fs) if fs else np.zeros(0, fdt))
+    a = ars[0] if len(ars) == 1 else (np.concatenate(ars) if ars else np.zeros(0, np.uint8))
+    return f.view(np.uint8), a
+
+
 def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, halo=HALO_DEFAULT, device="cpu",
-                 runs_for_buffer=None, gather=True):
+                 runs_for_buffer=None, gather=True, timings=None):
     """Scan one file of `file_len` bytes sharded over the process group.
 
     get_buffer(lo, hi) -> bytes | ctypes.c_void_p : the file bytes [lo, hi) on this rank.
@@ -117,25 +142,37 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
         print(f"[sx] sharded: scan {1e3 * (t_scan - t_begin):.2f} ms, exchange {1e3 * (time.perf_counter() - t_scan):.2f} ms",
               file=sys.stderr)
 
+    t_exchanged = time.perf_counter()
+    if timings is not None:
+        timings["scan_ms"] = 1e3 * (t_scan - t_begin)
+        timings["exchange_ms"] = 1e3 * (t_exchanged - t_scan)
+        timings["gather_ms"] = 0.0
     if not gather:
         return counts, res
-    fb, ab = res.raw()
-    blob = struct.pack("<QQ", len(fb), len(ab)) + fb + ab
-    sizes = _all_gather_u64([len(blob)], device)
-    mx = max(s[0] for s in sizes)
-    mine = torch.zeros(mx, dtype=torch.uint8, device=device)
-    mine[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    # The gather of the Finding buffers to rank 0 (backend "nccl" = RCCL over xGMI): sizes first, then one
+    # gather of buffers padded to the largest.  The payload goes from the result's pinned memory straight into
+    # the exchange tensor (no Python-level copy).
+    fb, ab = _payload(res)
+    sizes = _all_gather_u64([len(fb), len(ab)], device)
+    mx = max(s[0] + s[1] for s in sizes)
+    mine = torch.empty(max(mx, 1), dtype=torch.uint8, device=device)
+    if len(fb):
+        mine[:len(fb)].copy_(torch.from_numpy(fb), non_blocking=True)
+    if len(ab):
+        mine[len(fb):len(fb) + len(ab)].copy_(torch.from_numpy(ab), non_blocking=True)
+    out = None
     if rank == 0:
-        bufs = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world)]
+        bufs = [torch.empty(max(mx, 1), dtype=torch.uint8, device=device) for _ in range(world)]
         dist.gather(mine, bufs, dst=0)
         out = []
-        for b, s in zip(bufs, sizes):
-            raw = bytes(b[:s[0]].cpu().numpy().tobytes())
-            nf, na = struct.unpack("<QQ", raw[:16])
-            out.append((raw[16:16 + nf], raw[16 + nf:16 + nf + na]))
-        return out, res
-    dist.gather(mine, None, dst=0)
-    return None, res
+        for b, (nf, na) in zip(bufs, sizes):
+            raw = b[:nf + na].cpu().numpy()
+            out.append((raw[:nf].tobytes(), raw[nf:nf + na].tobytes()))
+    else:
+        dist.gather(mine, None, dst=0)
+    if timings is not None:
+        timings["gather_ms"] = 1e3 * (time.perf_counter() - t_exchanged)
+    return out, res
 
 
 class ShardCounts(list):
