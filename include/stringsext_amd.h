@@ -41,7 +41,9 @@ enum {
     SX_E_NO_DEVICE = -2,   /* no usable HIP device: the product never runs on the CPU */
     SX_E_HIP = -3,         /* a HIP call failed */
     SX_E_NOMEM = -4,
-    SX_E_STATE = -5        /* call not valid for this context (e.g. device scan on a host-only ctx) */
+    SX_E_STATE = -5,       /* call not valid for this context (e.g. device scan on a host-only ctx) */
+    SX_E_HALO = -6         /* sx_scan_shard*: the buffer must begin further in front of own_lo (Big5 / EUC-JP: no byte outside
+                              the lead range lies between the buffer start and own_lo, so its token grid is unknown) */
 };
 
 /* Encoding ids == `Encoding::name()` of encoding_rs as used at src/mission.rs:681,
@@ -228,7 +230,9 @@ int sx_replay_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_fi
  * mission (first attempt; a rank must repeat the call with reuse_runs=1 if the previous
  * rank's end_pos turns out to lie beyond own_lo).  If end_pos[m] == buf_off+buf_len although
  * the file goes on, the buffer was too short for a run that crosses it: repeat with a
- * larger halo.  Positions are counter_offset + file_stream_off + file offset.  The context's
+ * larger halo.  A Big5 / EUC-JP mission needs a byte outside the lead range between the buffer start and own_lo
+ * (buf_off > 0): without one the call fails with SX_E_HALO — repeat with a larger halo in front.  A mission with
+ * chars_min_nb 0 cannot be sharded (SX_E_INVALID).  Positions are counter_offset + file_stream_off + file offset.  The context's
  * carried state is used only by the shard that starts the file (buf_off == own_lo == 0) and
  * updated only by the shard whose own_hi is the buffer end.
  *   sx_scan_shard_device: bytes resident in HBM;  sx_scan_shard: host bytes (uploaded);

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SX_LIB") or os.path.join(_HERE, "libstringsext_amd.so")  # SX_LIB: debugging builds
 
-SX_OK, SX_E_INVALID, SX_E_NO_DEVICE, SX_E_HIP, SX_E_NOMEM, SX_E_STATE = 0, -1, -2, -3, -4, -5
+SX_OK, SX_E_INVALID, SX_E_NO_DEVICE, SX_E_HIP, SX_E_NOMEM, SX_E_STATE, SX_E_HALO = 0, -1, -2, -3, -4, -5, -6
 SX_HOST_ONLY = -1
 SX_OPT_GENERIC_KERNELS, SX_OPT_DEVICE_REPLAY, SX_OPT_HOST_REPLAY = 1, 2, 4
 ENC = {"x-user-defined": 0, "utf-8": 1, "utf-16le": 2, "utf-16be": 3, "koi8-r": 16, "ibm866": 17,

@@ -205,6 +205,42 @@ int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
     }
     const size_t nm = ctx->missions.size();
     const double t_begin = now_ms();
+    for (const Mission& m : ctx->missions)
+        if (m.c.chars_min_nb == 0 && buf_off != 0) {
+            ctx->err = "a mission with chars_min_nb 0 cannot be sharded: its state at a shard start cannot be derived from the bytes "
+                       "in front of it (stage B runs as one sequential pass for it)";
+            return SX_E_INVALID;
+        }
+    // Big5 / EUC-JP in a buffer that does not start the file: the token grid is known from the first byte outside the
+    // lead range on (scan kernel and replay assume a token starts at byte 0, which only holds by then)
+    if (buf_off > 0) {
+        bool any = false;
+        for (const Mission& m : ctx->missions) any = any || m.is_dbcs();
+        if (any) {
+            const uint64_t front = own_lo - buf_off;
+            bool found[2] = { false, false };  // Big5, EUC-JP
+            std::vector<uint8_t> tmp;
+            for (uint64_t at = 0; at < front && !(found[0] && found[1]); at += 65536) {
+                const uint64_t n = std::min<uint64_t>(65536, front - at);
+                const uint8_t* s = host_bytes ? host_bytes + at : nullptr;
+                if (!s) {
+                    tmp.resize(n);
+                    HIP_TRY(ctx, hipMemcpy(tmp.data(), d_bytes + at, n, hipMemcpyDeviceToHost));
+                    s = tmp.data();
+                }
+                for (uint64_t i = 0; i < n && !(found[0] && found[1]); i++) {
+                    if (!dbcs_is_lead_range<4>(s[i])) found[0] = true;
+                    if (!dbcs_is_lead_range<5>(s[i])) found[1] = true;
+                }
+            }
+            for (const Mission& m : ctx->missions)
+                if (m.is_dbcs() && !found[m.c.encoding == SX_ENC_BIG5 ? 0 : 1]) {
+                    ctx->err = "no byte outside the lead range between the buffer start and own_lo: the token grid of a Big5 / EUC-JP "
+                               "mission is unknown there; repeat with a larger halo in front";
+                    return SX_E_HALO;
+                }
+        }
+    }
     if (given_runs) {
         ctx->shard_runs.assign(nm, RunList{});
         for (size_t k = 0; k < nm; k++) ctx->shard_runs[k].assign(given_runs[k], given_runs[k] + given_n[k]);

@@ -16,6 +16,11 @@ bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, siz
     if (!job.d_bytes || ctx->host_only || job.is_last) return false;
     if (ctx->opt.flags & SX_OPT_HOST_REPLAY) return false;
     if (ctx->missions[k].q > 64) return false;
+    // -n 0: SplitStr's exit 4 (helper.rs:317) then fires on a rejected char with nothing collected, which ends the
+    // iteration for the whole decoder call (helper.rs:343) — accepted chars behind it are never carried, so the
+    // rule "the last accepted char in front of a window start is the leftover" (derive_at) does not hold.  Such a
+    // mission is replayed by ONE exact sequential pass on the host: no derived states, no speculation.
+    if (ctx->missions[k].c.chars_min_nb == 0) return false;
     if (getenv("SX_HOST_REPLAY")) return false;
     return (ctx->opt.flags & SX_OPT_DEVICE_REPLAY) || getenv("SX_DEVICE_REPLAY") || n_runs >= 4096;
 }
@@ -255,7 +260,8 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
         if (on_device[k]) continue;
         HIP_TRY(ctx, runs[k].wait());
         // parts are speculative restarts: worth a thread each only if they hold real work
-        const unsigned want_parts = (unsigned)std::min<uint64_t>(nthreads, std::max<uint64_t>(1, runs[k].size() / 512));
+        unsigned want_parts = (unsigned)std::min<uint64_t>(nthreads, std::max<uint64_t>(1, runs[k].size() / 512));
+        if (ctx->missions[k].c.chars_min_nb == 0) want_parts = 1;  // no speculative restarts (see device_replay_wanted)
         host_runs += runs[k].size();
         replay_plan_range(std::min(job.lo[k], job.hi), job.hi, want_parts, &bounds[k]);
         parts[k].resize(bounds[k].size() - 1);
@@ -394,7 +400,8 @@ int download_for_replay(sx_ctx* ctx, const uint8_t* d_bytes, uint64_t len,
             HIP_TRY(ctx, runs[k].wait());
             const size_t before = rg.size();
             // same partition count as replay_all will use
-            const unsigned want_parts = (unsigned)std::min<uint64_t>(replay_threads(ctx), std::max<uint64_t>(1, runs[k].size() / 512));
+            unsigned want_parts = (unsigned)std::min<uint64_t>(replay_threads(ctx), std::max<uint64_t>(1, runs[k].size() / 512));
+            if (ctx->missions[k].c.chars_min_nb == 0) want_parts = 1;
             replay_ranges(ctx->missions[k], ctx->states[k], len, runs[k].data(), runs[k].size(), want_parts, &rg);
             // a mission's ranges come out almost sorted (runs are); fix up, then merge the sorted lists
             if (!std::is_sorted(rg.begin() + before, rg.end())) std::sort(rg.begin() + before, rg.end());

@@ -21,7 +21,12 @@ import time
 import torch
 import torch.distributed as dist
 
-from . import Finding, PRECISION
+from . import Finding, PRECISION, SxError, SX_E_HALO
+
+
+class _NoResult:
+    def free(self):
+        pass
 
 HALO_DEFAULT = 1 << 20
 
@@ -92,8 +97,13 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
             kw["runs_per_mission"] = runs_for_buffer(buf, buf_lo)
         if isinstance(buf, ctypes.c_void_p):
             kw["buf_len"] = buf_hi - buf_lo
-        res, ends = scanner.scan_shard(buf, buf_lo, own_lo, own_hi, start_at=start_at, file_stream_off=file_stream_off,
-                                       file_id=file_id, reuse_runs=reuse, **kw)
+        try:
+            res, ends = scanner.scan_shard(buf, buf_lo, own_lo, own_hi, start_at=start_at, file_stream_off=file_stream_off,
+                                           file_id=file_id, reuse_runs=reuse, **kw)
+        except SxError as e:
+            if e.code != SX_E_HALO or buf_lo == 0:
+                raise
+            return _NoResult(), [own_hi] * nm, True, buf_hi   # the halo in front is too short (Big5 / EUC-JP): look further
         truncated = any(e >= buf_hi for e in ends) and buf_hi < file_len
         return res, ends, truncated, buf_hi
 

@@ -14,6 +14,15 @@ import sxo_binding as sxo
 pytestmark = pytest.mark.gpu
 SEED = 0x5EED5EED5EED5EED
 
+
+def product_missions(**flags):
+    """Missions as the PRODUCT's front end builds them from the literal BASELINE flag strings
+    (sx_missions_from_flags, csrc/sx_front.cpp); tests/refconfig.py only checks them."""
+    ms = sx.missions_from_flags(**flags)
+    assert ms == rc.missions(**flags)
+    return ms
+
+
 CORPUS = [
     "/usr/lib/x86_64-linux-gnu/libc.so.6", "C:\\Windows\\System32\\drivers\\etc\\hosts", "GET /index.html HTTP/1.1",
     "Բարեւ Ձեզ, ինչպես եք այսօր", "Հայաստանի Հանրապետություն", "שלום עולם, זוהי בדיקה של מחרוזות", "ירושלים של זהב",
@@ -40,7 +49,7 @@ def planted_image(n, seed, encodings=("utf-8", "utf-16-le", "utf-16-be"), every=
         try:
             rec = text.encode(enc)
         except UnicodeEncodeError:
-            rec = text.encode("utf-8")
+            rec = text.encode(enc, "ignore") if enc in ("big5hkscs", "euc_jp") else text.encode("utf-8")
         mode = k % 5
         if mode == 0:
             off = base - len(rec) // 2            # straddles a 64 KiB (hence 4096 / 128 / every 4th a 256 KiB) edge
@@ -69,7 +78,7 @@ def scan_text(ms, data, **kw):
 
 
 def test_c1_ascii_1mib_full_text_diff():
-    ms = rc.missions(encodings=["ascii"], chars_min="4")
+    ms = product_missions(encodings=["ascii"], chars_min="4")
     host = sxo.background(0, 1 << 20, SEED)
     got, n = scan_text(ms, host)
     assert got == sxo.run_cli(ms, [host], radix="x")
@@ -77,7 +86,7 @@ def test_c1_ascii_1mib_full_text_diff():
 
 
 def test_c2_utf8_slice_text_diff_and_whole_size_invariants():
-    ms = rc.missions(encodings=["utf-8"], chars_min="10")
+    ms = product_missions(encodings=["utf-8"], chars_min="10")
     pre = 64 << 20
     host = sxo.background(0, pre, SEED)
     got, n = scan_text(ms, host)
@@ -100,7 +109,7 @@ def test_c2_utf8_slice_text_diff_and_whole_size_invariants():
 
 
 def test_c3_run_records_equal_oracle_on_1gib_prefix():
-    ms = rc.missions(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African")
+    ms = product_missions(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African")
     n = 1 << 30
     host = sxo.background(0, n, SEED)
     sc = sx.Scanner(ms, device=0)
@@ -114,7 +123,7 @@ def test_c3_run_records_equal_oracle_on_1gib_prefix():
 
 @pytest.mark.parametrize("device_replay", [None, False])
 def test_c3ii_disk_image_256mib_full_text_diff(device_replay):
-    ms = rc.missions(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African")
+    ms = product_missions(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African")
     img = planted_image(256 << 20, 3)
     got, n = scan_text(ms, img, device_replay=device_replay)
     want = sxo.run_cli(ms, [img], radix="x")
@@ -122,11 +131,18 @@ def test_c3ii_disk_image_256mib_full_text_diff(device_replay):
     assert n > 4000                   # every planted record that passes the filters is there
 
 
-def test_c5_koi8r_records_next_to_the_utf_missions():
-    """BASELINE config 5 as far as it can be built offline (Big5/EUC-JP index tables are not in the
-    image): per-encoding filters in the reference's own syntax (SURVEY §8a, C5 note)."""
-    ms = rc.missions(encodings=["utf-8,,,African", "utf-16le,,,African", "utf-16be,,,African", "koi8-r,,,Cyrillic"], chars_min="10")
-    img = planted_image(64 << 20, 5, encodings=("utf-8", "utf-16-le", "utf-16-be", "koi8-r"))
-    got, n = scan_text(ms, img)
+@pytest.mark.parametrize("device_replay", [None, False])
+def test_c5_six_missions_disk_image_full_text_diff(device_replay):
+    """BASELINE config 5: all six missions, per-encoding filters in the reference's own syntax (SURVEY 8a, C5
+    note), on a planted image with Big5 (HKSCS), EUC-JP and KOI8-R records next to the UTF ones."""
+    ms = product_missions(encodings=["utf-8,,,African", "utf-16le,,,African", "utf-16be,,,African", "big5,,,Cjk",
+                                     "euc-jp,,,Asian", "koi8-r,,,Cyrillic"], chars_min="10")
+    from test_dbcs import TEXT
+    CORPUS.extend([TEXT["big5"][:40], TEXT["euc-jp"][:40], TEXT["big5"][20:45], TEXT["euc-jp"][30:70]])
+    try:
+        img = planted_image(32 << 20, 5, encodings=("utf-8", "utf-16-le", "utf-16-be", "koi8-r", "big5hkscs", "euc_jp"))
+    finally:
+        del CORPUS[-4:]
+    got, n = scan_text(ms, img, device_replay=device_replay)
     assert got == sxo.run_cli(ms, [img], radix="x")
-    assert b"(d KOI8-R)" in got and n > 1000
+    assert b"(f KOI8-R)" in got and b"(d Big5)" in got and b"(e EUC-JP)" in got and n > 1000

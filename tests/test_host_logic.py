@@ -127,6 +127,8 @@ OPTION_SETS = [
     dict(chars_min="2", ascii_filter="0x7ffffffe000000007ffffffe00000000", unicode_block_filter="Latin"),
     dict(chars_min="1", output_line_len="7", unicode_block_filter="Cyrillic"),
     dict(chars_min="8", unicode_block_filter="Uncommon", ascii_filter="None"),
+    dict(chars_min="0", output_line_len="9"),   # -n 0: two rejected chars in a row end a decoder call's iteration (helper.rs:317,343)
+    dict(chars_min="0", unicode_block_filter="All", grep_char="0x65"),
 ]
 ENC_SETS = [["utf-8"], ["ascii"], ["utf-16le"], ["utf-16be"], ["koi8-r"], ["utf-8", "utf-16le", "utf-16be"],
             ["ascii", "utf-8", "koi8-r"], ["utf-8,3,All,All", "utf-16le,,,Asian", "ascii,5"]]

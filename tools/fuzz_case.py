@@ -6,7 +6,7 @@ import refconfig as rc
 from test_host_logic import soup, synth
 from test_gpu_parity import dense
 
-ENCS = ["utf-8", "ascii", "utf-16le", "utf-16be", "koi8-r", "ibm866", "windows-1252", "iso-8859-5", "x-user-defined"]
+ENCS = ["utf-8", "ascii", "utf-16le", "utf-16be", "koi8-r", "ibm866", "windows-1252", "iso-8859-5", "x-user-defined", "big5", "euc-jp"]
 ENCS_MORE = ["iso-8859-7", "windows-1255", "windows-874", "koi8-u", "macintosh", "iso-8859-6", "windows-1257", "x-mac-cyrillic"]
 AFS = [None, "All", "All-Ctrl", "All-Ctrl+Wsp", "None", "Wsp", "0x7ffffffe000000007ffffffe00000000"]
 UBFS = [None, "African", "All", "Common", "Cyrillic", "Latin", "Asian", "Uncommon", "None", "Hebrew", "Cjk"]
@@ -27,19 +27,22 @@ def make(case_seed):
         if r.random() < 0.3:
             e += "," + r.choice(["", "2", "5", "12"]) + "," + (r.choice(AFS) or "") + "," + (r.choice(UBFS) or "")
         encs.append(e)
-    kw = dict(encodings=encs, chars_min=r.choice([None, "1", "2", "4", "7", "10", "20", "70"]),
+    kw = dict(encodings=encs, chars_min=r.choice([None, "0", "1", "2", "4", "7", "10", "20", "70"]),
               output_line_len=r.choice([None, None, "6", "8", "10", "30", "64", "100"]),
               ascii_filter=r.choice(AFS), unicode_block_filter=r.choice(UBFS),
               grep_char=r.choice([None, None, None, "47", "0x65", "32"]), same_unicode_block=r.random() < 0.2,
               counter_offset=r.choice([None, None, "1000", "0x10"]))
     ms = rc.missions(**kw)
-    kind = r.choice(["synth", "synth_dense", "soup", "dense", "text", "multi"])
+    kind = r.choice(["synth", "synth_dense", "soup", "dense", "text", "multi", "cjk"])
     size = r.choice([5000, 70_000, 300_000, 1_200_000])
     if kind == "synth": files = [synth(r, size, 1 / 500)]
     elif kind == "synth_dense": files = [synth(r, size, 1 / 60)]
     elif kind == "soup": files = [soup(r, min(size, 200_000))]
     elif kind == "dense": files = [dense(r, size, r.choice([2, 20, 200]), "abcdefgh XYZ019_-éжЖдяבשλ€😀")]
     elif kind == "text": files = [("The quick brown fox — Ünïcödé ßtring, доброе утро, שלום עולם. " * (size // 60 + 1)).encode(r.choice(["utf-8", "utf-16-le", "koi8-r"]), errors="replace")[:size]]
+    elif kind == "cjk":
+        from test_dbcs import soup as dbcs_soup
+        files = [dbcs_soup(r.choice(["big5", "euc-jp"]), r, min(size, 300_000))]
     else: files = [synth(r, r.randrange(1, 20000), 1 / 100) for _ in range(r.randrange(2, 6))] + [b""]
     case = dict(kw=kw, missions=ms, kind=kind, size=size, files=files, chunk=r.choice([None, None, 4096, 16384, 65536]),
                 flush=r.random() < 0.3, sub=r.choice([0, 0, 1024, 4096]), replay=r.choice([None, None, True, False]),

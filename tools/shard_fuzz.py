@@ -22,8 +22,10 @@ while time.time() - t0 < budget:
     data = c["files"][0][:400_000]
     if len(data) < 3 * 4096:
         continue
-    n += 1
     ms = c["missions"]
+    if any(m["chars_min_nb"] == 0 for m in ms):
+        continue   # refused by sx_scan_shard* (its stage B is one sequential pass)
+    n += 1
     world = rng.choice([2, 3, 5])
     halo0 = rng.choice([4096, 8192, 65536])
     parts, prev_end = [], None
@@ -36,8 +38,14 @@ while time.time() - t0 < budget:
             buf_lo = max(0, own_lo - h) // 4096 * 4096
             buf_hi = min(len(data), own_hi + h)
             buf = data[buf_lo:buf_hi]
-            res, ends = sc.scan_shard(buf, buf_lo, own_lo, own_hi, start_at=start, file_id=1,
-                                      runs_per_mission=oracle_runs_for_chunk(ms, buf, buf_lo))
+            try:
+                res, ends = sc.scan_shard(buf, buf_lo, own_lo, own_hi, start_at=start, file_id=1,
+                                          runs_per_mission=oracle_runs_for_chunk(ms, buf, buf_lo))
+            except sx.SxError as e:
+                if e.code != sx.SX_E_HALO or buf_lo == 0:
+                    raise
+                h *= 8
+                continue
             if any(e >= buf_hi for e in ends) and buf_hi < len(data):
                 res.free(); h *= 8
                 continue
