@@ -37,6 +37,7 @@ struct RunList {
     const sx_run* p = nullptr;
     size_t n = 0;
     bool on_device = false;
+    const sx_run* dev_ptr = nullptr;   // where the list lies on the device (on_device)
     // A list joined on the device: p[] (pinned) is filled by a copy that is only started when somebody
     // asks for it — the device replay asks after its first pass is launched, so that the copy (a blit
     // kernel on this stack) does not run next to the short kernels in front of that pass.
@@ -87,8 +88,8 @@ struct MissionDev {
     uint32_t* d_pair_lut = nullptr;                     // Big5 / EUC-JP: Mission::pair_lut for the scan kernel
     sx_run* h_runs = nullptr; uint64_t h_runs_cap = 0;   // pinned: runs joined on the device
     hipEvent_t ev_runs = nullptr;                         // their copy (on sx_ctx::d2h_stream) is done
-    void* d_rp[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
-    uint64_t d_rp_cap[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // + stitch blocks, totals, pass-1 output cache
+    void* d_rp[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
+    uint64_t d_rp_cap[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // + stitch blocks, totals, pass-1 output cache, runs cut into pieces
 };
 
 
@@ -204,7 +205,7 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                    const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si);
 int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
                    const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si,
-                   std::vector<RunList>* out);
+                   std::vector<RunList>* out, bool cut_into_pieces = false);
 int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
                 const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars,
                 std::vector<RunList>* out);

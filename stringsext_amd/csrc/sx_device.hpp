@@ -113,6 +113,11 @@ hipError_t launch_replay_write(const ReplayParams& P, const uint64_t* region_ind
                                const uint64_t* abase, uint64_t n_regions, sx_finding* findings, uint8_t* arena,
                                hipStream_t stream);
 
+// long runs cut into pieces at the window starts they cross (sx_replay_core.hpp kPieceCont): P.runs = the joined runs
+size_t split_scratch_bytes(uint64_t n_runs);
+hipError_t launch_split_count(const ReplayParams& P, void* scratch, size_t scratch_bytes, uint64_t* d_total, hipStream_t stream);
+hipError_t launch_split_write(const ReplayParams& P, const void* scratch, uint64_t n_pieces, sx_run* out, hipStream_t stream);
+
 // "which regions stand" + output offsets on the device (sx_replay_dev.hip)
 // runs resolved per lane in the first stage of the stitch: the second stage is one wavefront walking the block
 // summaries, so with many runs (string-dense input) larger blocks keep that walk short

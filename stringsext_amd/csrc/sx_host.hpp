@@ -87,6 +87,7 @@ public:
     // double-byte encodings: how many of the next bytes finish the token that is pending now (0: none pending,
     // or its last byte will be given back) — where the token grid of what follows begins
     uint32_t entry_skip(const uint8_t* next_bytes, uint64_t avail) const;
+    DDecoder& raw() { return d_; }
 
 private:
     DDecoder d_;  // the one decoder implementation, sx_codec_core.hpp

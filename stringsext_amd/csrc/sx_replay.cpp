@@ -32,6 +32,7 @@
 #include <thread>
 
 #include "sx_host.hpp"
+#include "sx_replay_core.hpp"   // the rules shared with the device replay: pieces of long runs (kPieceCont), derive_in_run
 
 namespace sx {
 
@@ -114,6 +115,40 @@ private:
     // bytes).  Sets st_->decoder to the decoder state at B and st_->leftover to the last
     // accepted character if it is the last thing delivered before B (see file comment).
     void derive_state(uint64_t B, uint64_t pos, const Decoder& d_pos) {
+        // B is where a continuation piece of a long run begins (sx_replay_core.hpp kPieceCont): the state there is a
+        // function of the run — unless the exact state is at hand anyway
+        if (!(pos == B)) {
+            const sx_run* pc = std::lower_bound(runs_, runs_ + n_runs_, B, [](const sx_run& r, uint64_t b) { return r.start < b; });
+            if (pc != runs_ + n_runs_ && pc->start == B && (pc->chars & kPieceCont)) {
+                const uint64_t delta = pc->chars & ~kPieceCont;
+                if (delta < 4ull * m_.q) {
+                    uint8_t ob[kObCap];
+                    bool cut = false;
+                    const uint8_t* from = bytes_.span(B - delta, (size_t)delta, &hint_);
+                    DDecoder& dd = st_->decoder.raw();
+                    const uint16_t* table = decoder_table(m_.c.encoding, nullptr);
+                    uint32_t n = 0;
+                    switch (enc_family(m_.c.encoding)) {
+                    case 1: n = derive_in_run<1>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCap, &cut); break;
+                    case 2: n = derive_in_run<2>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCap, &cut); break;
+                    case 3: n = derive_in_run<3>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCap, &cut); break;
+                    case 4: n = derive_in_run<4>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCap, &cut); break;
+                    case 5: n = derive_in_run<5>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCap, &cut); break;
+                    default: n = derive_in_run<0>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCap, &cut); break;
+                    }
+                    st_->last_scan_run_leftover.assign((const char*)ob, n);
+                    st_->last_run_str_was_printed_and_is_maybe_cut_str = cut;
+                    return;
+                }
+                derive_plain(B, pos, d_pos);   // the decoder's pending bytes
+                st_->last_scan_run_leftover.clear();
+                st_->last_run_str_was_printed_and_is_maybe_cut_str = true;
+                return;
+            }
+        }
+        derive_plain(B, pos, d_pos);
+    }
+    void derive_plain(uint64_t B, uint64_t pos, const Decoder& d_pos) {
         Decoder d(m_.c.encoding);
         // With --same-unicode-block (-r) the leftover's content matters after all: SplitStr re-scans it
         // and remembers the lead byte of its last multi-byte char, which decides where the NEXT stretch
@@ -334,6 +369,7 @@ private:
         // only a long run across p keeps the region going; one that begins at or behind p starts its own
         // (with -g also one that begins in the window at p: sx_replay_core.hpp regions_may_touch)
         if (ri_ < n_runs_ && (m_.c.grep_char < 0 ? runs_[ri_].start < p : window_start(runs_[ri_].start, W_) <= p)) return false;
+        if (ri_ < n_runs_ && runs_[ri_].start == p && (runs_[ri_].chars & kPieceCont)) return false;  // a piece of the run that lies across p
         if (owns_tail_ && len_ && tail_start() <= p) return false;
         return true;
     }

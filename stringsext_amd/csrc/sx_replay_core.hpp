@@ -131,6 +131,132 @@ SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs) {
     return b;
 }
 
+// ------------------------------------------------------------------------------------------
+// Long runs are cut at the window starts they cross.
+//
+// Inside a stretch of accepted characters the reference's state at a window start B is a function of the
+// stretch alone, PROVIDED its first character follows a rejected (valid) character decoded in the same window
+// (then SplitStr has just reset: ok_s_p != inp_start_p, so nothing "completes" a previous string,
+// helper.rs:327-330,353-355) and the Mission has no -g, no -r and n <= q:
+//   * the chars of the run accumulate as leftover from window to window (helper.rs:389-392: a stretch that
+//     touches the right edge and is shorter than q goes back to be filtered again) until a decoder call's
+//     text reaches q chars; there the first piece is cut (maybe_cut), and every later piece of the call
+//     touches inp_start_p with last_s_was_maybe_cut set, so it "completes" and is printed whatever its length
+//     (helper.rs:349-421): from that window on the state at every window start is (no leftover, maybe_cut);
+//   * so with C = chars of the run that complete in front of B:  C < q -> leftover = those C chars, no cut
+//     pending;  C >= q -> no leftover, cut pending.  (A char is at most 4 bytes: B - run start >= 4q bytes
+//     means C >= q without looking.)  The decoder's pending bytes at B follow from the bytes in front of B as ever.
+// A run with this property is cut into PIECES at the window starts inside it; a piece that begins at such a
+// window start carries kPieceCont | (its start - the run's start) in sx_run::chars.  Every piece is a region of
+// its own (one window), so a long line of text no longer chains its windows into one serial replay.
+// tests/test_replay_core.py checks the rule against the oracle on the CPU (pieces driven like the device drives them).
+// ------------------------------------------------------------------------------------------
+constexpr u64 kPieceCont = 1ull << 63;
+
+SXD bool mission_splittable(const ReplayParams& P) {
+    return P.grep_char < 0 && !P.same_block && P.chars_min_nb >= 1 && P.chars_min_nb <= P.q;
+}
+// window starts s with s < x, and the position of window start number idx (slices of 4096 bytes, windows of W inside)
+SXD u64 win_starts_below(u64 x, u32 W) { const u64 wps = (kSliceLen + W - 1) / W; return x / kSliceLen * wps + (x % kSliceLen + W - 1) / W; }
+SXD u64 win_start_no(u64 idx, u32 W) { const u64 wps = (kSliceLen + W - 1) / W; return idx / wps * kSliceLen + idx % wps * W; }
+
+// Do the bytes right in front of rs form a valid character (rejected, or it would belong to the run)?
+template <int ENC>
+SXD bool valid_char_before(const ReplayParams& P, u64 rs) {
+    const u8* bytes = P.data;
+    if (rs == 0) return false;
+    const u8 x = bytes[rs - 1];
+    if (ENC == 1) {
+        if (x < 0x80) return true;
+        if (x >= 0xC0) return false;
+        u32 k = 1;
+        u64 j = rs - 1;
+        bool found = false;
+        while (j > 0 && k <= 3) {
+            j--;
+            if ((bytes[j] & 0xC0) == 0x80) { k++; continue; }
+            found = true;
+            break;
+        }
+        if (!found) return false;
+        const u8 lead = bytes[j];
+        u32 need = 0;
+        u8 lo = 0x80, hi = 0xBF;
+        if (lead >= 0xC2 && lead <= 0xDF) need = 1;
+        else if (lead >= 0xE0 && lead <= 0xEF) { need = 2; if (lead == 0xE0) lo = 0xA0; if (lead == 0xED) hi = 0x9F; }
+        else if (lead >= 0xF0 && lead <= 0xF4) { need = 3; if (lead == 0xF0) lo = 0x90; if (lead == 0xF4) hi = 0x8F; }
+        if (need != k) return false;
+        const u8 second = bytes[j + 1];
+        return second >= lo && second <= hi;
+    }
+    if (ENC == 2 || ENC == 3) {
+        constexpr bool be = ENC == 3;
+        if (rs < 2) return false;
+        const u32 u = be ? ((u32)bytes[rs - 2] << 8) | bytes[rs - 1] : ((u32)bytes[rs - 1] << 8) | bytes[rs - 2];
+        if ((u & 0xF800) != 0xD800) return true;
+        if ((u & 0xFC00) != 0xDC00 || rs < 4) return false;
+        const u32 h = be ? ((u32)bytes[rs - 4] << 8) | bytes[rs - 3] : ((u32)bytes[rs - 3] << 8) | bytes[rs - 4];
+        return (h & 0xFC00) == 0xD800;
+    }
+    if (ENC == 4 || ENC == 5) return x < 0x80;   // an ASCII byte is a character whatever stands in front of it (own, trail, or given back)
+    return x < 0x80 || !P.table || P.table[x - 0x80] != 0;
+}
+
+// bytes of the character that starts at rs (a valid one: the first of a run)
+template <int ENC>
+SXD u32 char_len_at(const ReplayParams& P, u64 rs) {
+    const u8* b = P.data + rs;
+    if (ENC == 1) return b[0] < 0x80 ? 1u : b[0] < 0xE0 ? 2u : b[0] < 0xF0 ? 3u : 4u;
+    if (ENC == 2) return (b[1] & 0xFC) == 0xD8 ? 4u : 2u;
+    if (ENC == 3) return (b[0] & 0xFC) == 0xD8 ? 4u : 2u;
+    if (ENC == 4 || ENC == 5) return dbcs_token_len<(ENC == 4 || ENC == 5) ? ENC : 4>(b, P.len - rs);
+    return 1;
+}
+
+// How many pieces run i of the UNSPLIT list P.runs is cut into (1: not cut).  The run's first character must be
+// delivered in the same window as the rejected character in front of it (a character belongs to the window that
+// holds its LAST byte): no window start in [rs, last byte of the first character].
+template <int ENC>
+SXD u64 split_count(const ReplayParams& P, u64 i) {
+    if (!mission_splittable(P)) return 1;
+    const u64 rs = P.runs[i].start, re = P.runs[i].end;
+    const u64 inside = win_starts_below(re, P.W) - win_starts_below(rs + 1, P.W);   // window starts in (rs, re)
+    if (inside == 0) return 1;
+    const u64 fe = rs + char_len_at<ENC>(P, rs) - 1;
+    if (fe >= re || win_start(fe, P.W) >= rs) return 1;
+    return valid_char_before<ENC>(P, rs) ? inside + 1 : 1;
+}
+// piece k (0 .. count-1) of run i
+SXD sx_run split_piece(const ReplayParams& P, u64 i, u64 k, u64 count) {
+    const sx_run r = P.runs[i];
+    if (count <= 1) return r;
+    const u64 first = win_starts_below(r.start + 1, P.W);   // number of the first window start behind the run's start
+    sx_run o;
+    o.start = k == 0 ? r.start : win_start_no(first + k - 1, P.W);
+    o.end = k + 1 == count ? r.end : win_start_no(first + k, P.W);
+    o.chars = k == 0 ? r.chars : (kPieceCont | (o.start - r.start));
+    return o;
+}
+template <int ENC> SXD bool run_is_piece(const sx_run& r) { return (r.chars & kPieceCont) != 0; }
+
+// The state at the start of a continuation piece (see above).  `from` = the bytes from the run's start up to the
+// window start (delta bytes, delta < 4q: the caller handles the other case).  Returns the leftover's length in ob.
+template <int ENC>
+SXD u32 derive_in_run(u32 q, u32 encoding, const uint16_t* table, const u8* from, u32 delta, DDecoder& dec, u8* ob, u32 ob_cap,
+                      bool* cut_pending) {
+    ddec_reset(dec, (int)encoding, table);
+    u32 w = 0, k = 0;
+    while (k < delta) {   // no error can occur: the run is made of valid characters
+        const DStep r = ddecode<ENC>(dec, from + k, delta - k, ob + w, ob_cap - w, false);
+        k += r.read; w += r.written;
+        if (r.result != RES_MALFORMED) break;
+    }
+    u32 chars = 0;
+    for (u32 t = 0; t < w; t++) chars += (ob[t] & 0xC0) != 0x80;
+    *cut_pending = chars >= q;
+    return chars >= q ? 0u : w;
+}
+
 // Double-byte encodings: a token boundary in [lim, lim + 2] (never beyond `at`), so that decoding from it sees
 // everything from lim on.  Found from the nearest byte outside the lead range in front of lim — the decoder
 // is neutral right after such a byte — or from `floor`, where it is neutral too (a clean call start; at the
@@ -241,8 +367,13 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
     DDecoder dec;
 
     // ---- derive the state the reference would carry into `want` (RangeReplay::derive_state)
-    u32 leftover_len = derive_at<ENC>(P, want, 0, dec, ob);
+    u32 leftover_len;
     bool maybe_cut = false;
+    if (P.runs[i].chars & kPieceCont) {   // a window start inside a run: the state is a function of the run (see kPieceCont)
+        const u64 delta = P.runs[i].chars & ~kPieceCont;
+        if (delta < 4ull * P.q) leftover_len = derive_in_run<ENC>(P.q, P.encoding, P.table, bytes + (want - delta), (u32)delta, dec, ob, kObCap, &maybe_cut);
+        else { (void)derive_at<ENC>(P, want, 0, dec, ob); leftover_len = 0; maybe_cut = true; }
+    } else leftover_len = derive_at<ENC>(P, want, 0, dec, ob);
 
     u64 ri = i;  // first run not yet behind us
     u32 n_find = 0, n_bytes = 0, windows = 0;
@@ -256,6 +387,11 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
     // going.  Not with -g: a stretch of q chars without the grep char ends SplitStr's iteration for the
     // whole decoder call (helper.rs:410-415), so what follows it in the window is never carried, which
     // the bytes in front of p cannot tell; there a region only ends in front of a window without runs.
+    // a continuation piece begins at p: the region that starts there derives the very state this one has reached
+    auto piece_at = [&](u64 p) -> bool {
+        while (ri < P.n_runs && P.runs[ri].end <= p) ri++;
+        return ri < P.n_runs && P.runs[ri].start == p && (P.runs[ri].chars & kPieceCont);
+    };
     auto region_over = [&](u64 p) -> bool {
         while (ri < P.n_runs && P.runs[ri].end <= p) ri++;
         if (ri < P.n_runs && (regions_may_touch(P) ? P.runs[ri].start < p : win_start(P.runs[ri].start, W) <= p)) return false;
@@ -378,7 +514,7 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
                 const u32 from = dout - leftover_len;
                 if (from) for (u32 t = 0; t < leftover_len; t++) ob[t] = ob[from + t];
             }
-            if (!maybe_cut && may_drop(ob, leftover_len) && region_over(soff + din)) { done = true; break; }
+            if (piece_at(soff + din) || (!maybe_cut && may_drop(ob, leftover_len) && region_over(soff + din))) { done = true; break; }
         }
         pos = soff + din;
         (void)is_last_window;

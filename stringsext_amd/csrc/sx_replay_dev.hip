@@ -131,6 +131,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WA
     replay_region<1, ENC>(P, i, o, findings + fp, arena + ap, ap);
 }
 
+// ---- long runs cut into pieces at the window starts they cross (sx_replay_core.hpp kPieceCont) ----------
+// P.runs = the joined runs; counts -> exclusive scan -> one thread per piece writes it.
+template <int ENC>
+__global__ __launch_bounds__(256) void split_count_kernel(const ReplayParams P, u64* counts) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < P.n_runs) counts[i] = split_count<ENC>(P, i);
+}
+__global__ void split_total_kernel(const u64* counts, const u64* offsets, u64 n, u64* total) { *total = offsets[n - 1] + counts[n - 1]; }
+__global__ __launch_bounds__(256) void split_write_kernel(const ReplayParams P, const u64* offsets, u64 n_pieces, sx_run* out) {
+    const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_pieces) return;
+    u64 lo = 0, hi = P.n_runs;   // the last run whose first piece is at or before j
+    while (hi - lo > 1) {
+        const u64 mid = (lo + hi) / 2;
+        if (offsets[mid] <= j) lo = mid; else hi = mid;
+    }
+    const u64 count = (lo + 1 < P.n_runs ? offsets[lo + 1] : n_pieces) - offsets[lo];
+    out[j] = split_piece(P, lo, j - offsets[lo], count);
+}
+size_t split_scratch_bytes(uint64_t n_runs) {
+    size_t a = 0;
+    (void)rocprim::exclusive_scan(nullptr, a, (const u64*)nullptr, (u64*)nullptr, (u64)0, (size_t)n_runs, rocprim::plus<u64>(), (hipStream_t)0);
+    return a + 2 * n_runs * 8 + 1024;
+}
+// scratch: [counts n][offsets n][rocprim]; *d_total (device) = number of pieces
+hipError_t launch_split_count(const ReplayParams& P, void* scratch, size_t scratch_bytes, uint64_t* d_total, hipStream_t stream) {
+    if (P.n_runs == 0) return hipSuccess;
+    u64* counts = (u64*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    u64* offsets = counts + P.n_runs;
+    void* tmp = (void*)(((uintptr_t)(offsets + P.n_runs) + 255) & ~(uintptr_t)255);
+    size_t tmp_bytes = scratch_bytes - (size_t)((uint8_t*)tmp - (uint8_t*)scratch);
+    const dim3 grid((unsigned)((P.n_runs + 255) / 256));
+    switch (enc_family(P.encoding)) {
+        case 1: hipLaunchKernelGGL(split_count_kernel<1>, grid, dim3(256), 0, stream, P, counts); break;
+        case 2: hipLaunchKernelGGL(split_count_kernel<2>, grid, dim3(256), 0, stream, P, counts); break;
+        case 3: hipLaunchKernelGGL(split_count_kernel<3>, grid, dim3(256), 0, stream, P, counts); break;
+        case 4: hipLaunchKernelGGL(split_count_kernel<4>, grid, dim3(256), 0, stream, P, counts); break;
+        case 5: hipLaunchKernelGGL(split_count_kernel<5>, grid, dim3(256), 0, stream, P, counts); break;
+        default: hipLaunchKernelGGL(split_count_kernel<0>, grid, dim3(256), 0, stream, P, counts); break;
+    }
+    hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, (const u64*)counts, offsets, (u64)0, (size_t)P.n_runs, rocprim::plus<u64>(), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(split_total_kernel, dim3(1), dim3(1), 0, stream, counts, offsets, P.n_runs, d_total);
+    return hipGetLastError();
+}
+hipError_t launch_split_write(const ReplayParams& P, const void* scratch, uint64_t n_pieces, sx_run* out, hipStream_t stream) {
+    if (n_pieces == 0) return hipSuccess;
+    const u64* counts = (const u64*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    hipLaunchKernelGGL(split_write_kernel, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, stream, P, counts + P.n_runs, n_pieces, out);
+    return hipGetLastError();
+}
+
 // ---- which regions stand, on the device ---------------------------------------------------
 // The rule is sequential (a region is void if an earlier standing one ran over its start:
 // E = end of the last standing region; region i stands iff want_i >= E), but regions rarely

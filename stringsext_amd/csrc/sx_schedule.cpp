@@ -110,7 +110,7 @@ struct BufferScan {
         for (size_t oi = 0; oi < nm; oi++) {
             const size_t k = (size_t)order[oi];
             std::vector<RunList> one;
-            int rc = stage_a_finish(ctx, { (int)k }, d_bytes, len, { parity[k] }, { minc[k] }, slot, &one);
+            int rc = stage_a_finish(ctx, { (int)k }, d_bytes, len, { parity[k] }, { minc[k] }, slot, &one, true);
             if (rc != SX_OK) return rc;
             (*runs)[k] = std::move(one[0]);
             if (!(*runs)[k].own.empty()) (*runs)[k].use_own();  // the vector moved: point at it again

@@ -96,7 +96,7 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
 // are many).  Only stream_b is used from here on: the scan streams may already hold the next piece.
 int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
                    const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si,
-                   std::vector<RunList>* out) {
+                   std::vector<RunList>* out, bool cut_into_pieces) {
     out->assign(which.size(), RunList{});
     if (len == 0) return SX_OK;
     const double t0 = now_ms();
@@ -186,9 +186,32 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             HIP_TRY(ctx, hipEventRecord(s.ev_free, d.stream_b));
             s.free_pending = true;
             if (getenv("SX_TIMING2")) { HIP_TRY(ctx, hipStreamSynchronize(d.stream_b)); fprintf(stderr, "[sx]   join done +%.2f ms\n", now_ms() - tc0); }
-            uint32_t nruns = 0;
-            HIP_TRY(ctx, hipMemcpyAsync(&nruns, s.d_counters + 2, 4, hipMemcpyDeviceToHost, d.stream_b));
+            uint32_t nruns32 = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&nruns32, s.d_counters + 2, 4, hipMemcpyDeviceToHost, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            uint64_t nruns = nruns32;
+            const sx_run* d_list = (const sx_run*)d.d_rp[0];
+            // Runs that cross window starts are cut into one piece per window where the state at those window
+            // starts follows from the run alone (sx_replay_core.hpp kPieceCont): stage B then gets a region per
+            // window instead of one serial replay per run (text: a run per line, most of them cross a window start).
+            const Mission& mm = ctx->missions[(size_t)which[k]];
+            if (cut_into_pieces && nruns && !getenv("SX_NO_PIECES") && mm.c.grep_char < 0 && !mm.c.require_same_unicode_block
+                && mm.c.chars_min_nb >= 1 && mm.c.chars_min_nb <= mm.q && mm.q <= 64) {
+                ReplayParams SP{};
+                SP.data = d_bytes; SP.len = len; SP.runs = d_list; SP.n_runs = nruns; SP.encoding = mm.c.encoding; SP.table = d.d_table;
+                SP.chars_min_nb = mm.c.chars_min_nb; SP.same_block = 0; SP.q = (uint32_t)mm.q; SP.W = (uint32_t)mm.window; SP.grep_char = -1;
+                rc = ensure_scratch(ctx, split_scratch_bytes(nruns) + 64); if (rc != SX_OK) return rc;
+                uint64_t* d_total = (uint64_t*)ctx->d_scratch;   // the first 64 bytes; the rest is the split's scratch
+                HIP_TRY(ctx, launch_split_count(SP, ctx->d_scratch + 64, ctx->d_scratch_cap - 64, d_total, d.stream_b));
+                uint64_t total = 0;
+                HIP_TRY(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, d.stream_b));
+                HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+                if (total > nruns && total < (1ull << 32) && ensure_rp(ctx, d, 9, total * sizeof(sx_run)) == SX_OK) {
+                    HIP_TRY(ctx, launch_split_write(SP, ctx->d_scratch + 64, total, (sx_run*)d.d_rp[9], d.stream_b));
+                    d_list = (const sx_run*)d.d_rp[9];
+                    nruns = total;
+                } else (void)hipGetLastError();
+            }
             tc1 = now_ms();
             if ((uint64_t)nruns * sizeof(sx_run) > d.h_runs_cap) {
                 if (d.h_runs) HIP_TRY(ctx, hipHostFree(d.h_runs));
@@ -197,7 +220,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                 HIP_TRY(ctx, hipHostMalloc((void**)&d.h_runs, cap, hipHostMallocNonCoherent));
                 d.h_runs_cap = cap;
             }
-            rl.p = d.h_runs; rl.n = nruns; rl.on_device = true;
+            rl.p = d.h_runs; rl.n = nruns; rl.on_device = true; rl.dev_ptr = d_list;
             if (large_regions && nruns < s.n_regions * ctx->region_cap / 4) ctx->dense[(size_t)which[k]] = 0;  // sparse again
             if (nruns) {
                 // The list is complete on the device (the count was just read).  Its copy for the host's
@@ -205,7 +228,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                 // rl.wait() first; the device replay starts it once its first pass is under way.
                 if (!ctx->d2h_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
                 if (!d.ev_runs) HIP_TRY(ctx, hipEventCreateWithFlags(&d.ev_runs, hipEventDisableTiming));
-                rl.dev_src = d.d_rp[0]; rl.copy_bytes = (size_t)nruns * sizeof(sx_run);
+                rl.dev_src = d_list; rl.copy_bytes = (size_t)nruns * sizeof(sx_run);
                 rl.copy_stream = ctx->d2h_stream; rl.ready = d.ev_runs; rl.issued = false;
             }
         } else {

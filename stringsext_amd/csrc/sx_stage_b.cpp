@@ -59,7 +59,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         rc = ensure_scratch(ctx, stitch_scratch_bytes(n)); if (rc) return rc;
         if (!runs.on_device)
             HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[0], runs.data(), n * sizeof(sx_run), hipMemcpyHostToDevice, d.stream_b));
-        P.data = job.d_bytes; P.len = job.len; P.runs = (const sx_run*)d.d_rp[0]; P.n_runs = n;
+        P.data = job.d_bytes; P.len = job.len; P.runs = runs.on_device ? runs.dev_ptr : (const sx_run*)d.d_rp[0]; P.n_runs = n;
         P.lo = job.lo[k]; P.hi = job.hi; P.consumed0 = job.consumed0[k]; P.stream0 = job.stream0[k];
         P.slice_base = job.slice_base; P.encoding = m.c.encoding; P.table = d.d_table;
         P.chars_min_nb = m.c.chars_min_nb; P.same_block = m.c.require_same_unicode_block; P.q = (uint32_t)m.q;

@@ -33,3 +33,21 @@ extern "C" int sxd_replay_region_host(const sx::ReplayParams* P, uint64_t i, sx:
     }
     return 0;
 }
+
+// Runs cut into pieces at the window starts they cross, exactly as the device does it (split_count / split_piece).
+extern "C" uint64_t sxd_split_runs_host(const sx::ReplayParams* P, sx_run* out, uint64_t cap) {
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < P->n_runs; i++) {
+        uint64_t c;
+        switch (sx::enc_family(P->encoding)) {
+            case 1: c = sx::split_count<1>(*P, i); break;
+            case 2: c = sx::split_count<2>(*P, i); break;
+            case 3: c = sx::split_count<3>(*P, i); break;
+            case 4: c = sx::split_count<4>(*P, i); break;
+            case 5: c = sx::split_count<5>(*P, i); break;
+            default: c = sx::split_count<0>(*P, i); break;
+        }
+        for (uint64_t k = 0; k < c; k++) { if (n < cap) out[n] = sx::split_piece(*P, i, k, c); n++; }
+    }
+    return n;
+}

@@ -50,13 +50,23 @@ def oracle_runs_for_chunk(mdicts, chunk, stream_bytes, before=b""):
     return out
 
 
+def cut_into_pieces(mdicts, chunk, runs_per_mission):
+    """the runs as the device hands them to stage B: cut at the window starts they cross (sx_replay_core.hpp kPieceCont)"""
+    import test_replay_core as trc
+    core = trc.load_core()
+    return [trc.split_runs(core, m, chunk, runs) if m["output_line_char_nb_max"] <= 64 else runs
+            for m, runs in zip(mdicts, runs_per_mission)]
+
+
 def run_cli_product(mdicts, files, radix=None, no_metadata=False, chunk_bytes=None, device=None,
-                    generic_kernels=False, subchunk_bytes=0, flush_at_eof=False, record_capacity=0, device_replay=None):
+                    generic_kernels=False, subchunk_bytes=0, flush_at_eof=False, record_capacity=0, device_replay=None,
+                    pieces=False, replay_threads=0):
     """Whole CLI pass.  device=None: host-only context, runs supplied by the oracle (tests the
     replay stage on CPU).  device=int: the real thing (HIP kernels + replay)."""
     host_only = device is None
     sc = sx.Scanner(mdicts, device=sx.SX_HOST_ONLY if host_only else device, generic_kernels=generic_kernels,
-                    subchunk_bytes=subchunk_bytes, record_capacity=record_capacity, device_replay=device_replay)
+                    subchunk_bytes=subchunk_bytes, record_capacity=record_capacity, device_replay=device_replay,
+                    replay_threads=replay_threads)
     out = bytearray(sx.OUTPUT_BOM)
     stream = 0
     before = b""   # the stream in front of the current chunk (decoders persist across files)
@@ -70,8 +80,10 @@ def run_cli_product(mdicts, files, radix=None, no_metadata=False, chunk_bytes=No
                 chunk = data[off:off + step]
                 last = flush_at_eof and fi == len(files) - 1 and off + len(chunk) == len(data)
                 if host_only:
-                    res = sc.replay_runs(chunk, oracle_runs_for_chunk(mdicts, chunk, stream, before[-4096:]), file_id=fi + 1,
-                                         is_last=last)
+                    runs = oracle_runs_for_chunk(mdicts, chunk, stream, before[-4096:])
+                    if pieces:
+                        runs = cut_into_pieces(mdicts, chunk, runs)
+                    res = sc.replay_runs(chunk, runs, file_id=fi + 1, is_last=last)
                 else:
                     res = sc.scan(chunk, file_id=fi + 1, is_last=last)
                 out += res.printed(n_inputs=len(files), radix=radix, no_metadata=no_metadata)

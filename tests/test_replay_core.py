@@ -50,7 +50,21 @@ def load_core():
     L = C.CDLL(so)
     L.sxd_replay_region_host.argtypes = [C.POINTER(ReplayParams), C.c_uint64, C.POINTER(RegionOut), C.POINTER(sx.Finding),
                                          C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]
+    L.sxd_split_runs_host.restype = C.c_uint64
+    L.sxd_split_runs_host.argtypes = [C.POINTER(ReplayParams), C.POINTER(sx.Run), C.c_uint64]
     return L
+
+
+def split_runs(core, m, data, runs, stream0=0):
+    """the runs cut into pieces at the window starts they cross, as the device cuts them (sx_replay_core.hpp kPieceCont)"""
+    if not runs:
+        return []
+    P, _, _ = make_params(m, data, runs, stream0=stream0)
+    cap = len(runs) + sum((b - a) // 12 + 2 for a, b, _ in runs)
+    out = (sx.Run * cap)()
+    n = core.sxd_split_runs_host(C.byref(P), out, cap)
+    assert n <= cap
+    return [(out[i].start, out[i].end, out[i].chars) for i in range(n)]
 
 
 def sb_table(enc_id):
@@ -171,12 +185,14 @@ def make_params(m, data, runs, stream0=0, skip=1):
     return P, W, long_run
 
 
-def emulate_device_stage_b(core, m, data, runs, skip=1):
+def emulate_device_stage_b(core, m, data, runs, skip=1, pieces=True):
     """What the device does with one Mission's runs, on the CPU: every head run (sx_replay_dev.hip
     region_is_chained) replays its region from derived state with the device core, then the sequential
     stitch rule (a region stands iff it begins at or behind the end of the last standing one).  The first
     region derives from the stream start, which is the true initial state.  Returns None if a region is
     given back to the host (too long)."""
+    if pieces:
+        runs = split_runs(core, m, data, runs)
     P, W, _ = make_params(m, data, runs, skip=skip)
     fbuf = (sx.Finding * 8192)()
     abuf = (C.c_uint8 * (1 << 21))()
@@ -233,3 +249,27 @@ def test_device_pipeline_emulated_on_cpu_equals_the_oracle(core, flags):
         assert got == want, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want)))
         done += 1
     assert done > 0
+
+
+def test_host_replay_understands_pieces_of_long_runs():
+    """The run lists the device joins reach the host cut into pieces (kPieceCont): its sequential replay must not end a
+    region at a piece boundary, and where it STARTS at one (a speculative part, a region the device gave back, the
+    exit state) it derives the state from the run.  Text whose lines cross most window starts, several host parts."""
+    from product_harness import run_cli_product
+    rng = random.Random(99)
+    words = [bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyzABCDEFGH0123456789_-./:=") for _ in range(rng.randrange(2, 12))) for _ in range(300)]
+    uni = ["Ünïcödé", "доброе утро", "שלום", "λόγος", "€uro"]
+    out = bytearray()
+    while len(out) < 9 * (1 << 20) + 12345:
+        n = rng.choice([10, 30, 70, 127, 128, 129, 200, 400, 5000]); l = bytearray()
+        while len(l) < n:
+            l += (rng.choice(uni).encode() if rng.random() < 0.1 else rng.choice(words)) + b" "
+        out += l[:n] + rng.choice([b"\n", b"\r\n", b"\x00", b"\xff", b"\n\n"])
+    data = bytes(out)
+    for flags in (dict(encodings=["utf-8"], chars_min="10"), dict(encodings=["ascii", "utf-8"], chars_min="4", output_line_len="20"),
+                  dict(encodings=["utf-8"], chars_min="3", unicode_block_filter="All", output_line_len="7")):
+        ms = rc.missions(**flags)
+        want = sxo.run_cli(ms, [data], radix="x")
+        for threads in (1, 4):
+            assert run_cli_product(ms, [data], radix="x", pieces=True, replay_threads=threads) == want, (flags, threads)
+        assert run_cli_product(ms, [data], radix="x", pieces=True, chunk_bytes=1 << 20) == want, flags
