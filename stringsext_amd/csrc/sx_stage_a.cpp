@@ -208,6 +208,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                 HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
                 if (total > nruns && total < (1ull << 32) && ensure_rp(ctx, d, 9, total * sizeof(sx_run)) == SX_OK) {
                     HIP_TRY(ctx, launch_split_write(SP, ctx->d_scratch + 64, total, (sx_run*)d.d_rp[9], d.stream_b));
+                    HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));   // the list's copy for the host runs on another stream: complete first
                     d_list = (const sx_run*)d.d_rp[9];
                     nruns = total;
                 } else (void)hipGetLastError();
