@@ -97,6 +97,7 @@ struct ReplayParams {
     uint64_t arena_bytes;
     const uint32_t* head_list;   // head_list[slot] = run index: the replay kernels take one lane per REPLAYING run
     uint32_t max_windows;        // a region that needs more windows is given back (kRegionTooLong)
+    uint32_t str_off_base;       // pass 2 (flagged form): added to every str_off (strings of the host's entry part come first)
     uint32_t entry_skip;         // double-byte encodings: bytes at the buffer start that finish the token pending on entry
 };
 struct ReplayRegionOut {

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WA
         const u32 nf = ro[i].n_find, nb = ro[i].n_bytes;
         for (u32 j = 0; j < nf; j++) {
             sx_finding f = cf[j];
-            f.str_off += (u32)ap;
+            f.str_off += (u32)ap + P.str_off_base;
             findings[fp + j] = f;
         }
         const u8* src = slot + g.cap_f * sizeof(sx_finding);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WA
         return;
     }
     ReplayRegionOut o;
-    replay_region<1, ENC>(P, i, o, findings + fp, arena + ap, ap);
+    replay_region<1, ENC>(P, i, o, findings + fp, arena + ap, ap + P.str_off_base);
 }
 
 // ---- long runs cut into pieces at the window starts they cross (sx_replay_core.hpp kPieceCont) ----------

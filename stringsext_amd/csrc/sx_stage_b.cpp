@@ -166,13 +166,21 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     const double t2 = now_ms();
 
     // ---- pass 2: the standing regions write findings and strings, in order; the D2H lands in a
-    // pinned block that becomes the result's storage (no copy) unless host parts must be spliced in
+    // pinned block that becomes the result's storage (no copy).  The host's entry part (the chunk's first
+    // region, replayed from the exact carried state) goes in front of it in the same block: the device writes
+    // its str_off already shifted by that part's strings.  Only regions the device gave back to the host
+    // (somewhere in the middle) need the finding-by-finding splice.
     PinnedPool::Block blk{};
+    const bool entry_only = dev_stitch && host_parts.size() == 1 && true;
+    const MissionFindings* hf0 = entry_only ? &host_parts[0].findings : nullptr;
+    const uint64_t nfh = hf0 ? hf0->v.size() : 0, nbh = hf0 ? hf0->arena.size() : 0;
+    if (nb + nbh > 0xFFFFFFFFull) { ctx->err = "more than 4 GiB of strings in one chunk"; return SX_E_NOMEM; }
     if (n_standing) {
         int rc = ensure_rp(ctx, d, 5, nf * sizeof(sx_finding) + nb + 64); if (rc) return rc;
         sx_finding* d_f = (sx_finding*)d.d_rp[5];
         uint8_t* d_a = (uint8_t*)d.d_rp[5] + nf * sizeof(sx_finding);
         if (dev_stitch) {
+            P.str_off_base = (uint32_t)nbh;
             HIP_TRY(ctx, launch_replay_write_flagged(P, (const ReplayRegionOut*)d.d_rp[1], (const uint8_t*)d.d_rp[2],
                                                      (const uint64_t*)d.d_rp[3], (const uint64_t*)d.d_rp[4], d_f, d_a, d.stream_b));
         } else {
@@ -183,16 +191,29 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
             HIP_TRY(ctx, launch_replay_write(P, (const uint64_t*)d.d_rp[2], (const uint64_t*)d.d_rp[3],
                                              (const uint64_t*)d.d_rp[4], nv, d_f, d_a, d.stream_b));
         }
-        blk = ctx->pool->take(nf * sizeof(sx_finding) + nb + 64);
+        blk = ctx->pool->take((nfh + nf) * sizeof(sx_finding) + nbh + nb + 64);
         if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
-        HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_f, nf * sizeof(sx_finding) + nb, hipMemcpyDeviceToHost, d.stream_b));
+        uint8_t* bp = (uint8_t*)blk.p;
+        if (nfh == 0 && nbh == 0)
+            HIP_TRY(ctx, hipMemcpyAsync(bp, d_f, nf * sizeof(sx_finding) + nb, hipMemcpyDeviceToHost, d.stream_b));
+        else {
+            HIP_TRY(ctx, hipMemcpyAsync(bp + nfh * sizeof(sx_finding), d_f, nf * sizeof(sx_finding), hipMemcpyDeviceToHost, d.stream_b));
+            if (nb) HIP_TRY(ctx, hipMemcpyAsync(bp + (nfh + nf) * sizeof(sx_finding) + nbh, d_a, nb, hipMemcpyDeviceToHost, d.stream_b));
+        }
         HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
     }
     const double t3 = now_ms();
 
-    // ---- splice (almost always: device findings only)
+    // ---- splice (almost always: device findings only, or the entry part in front of them)
     if (host_parts.empty()) {
         if (blk.p) { out->ext = blk; out->ext_nf = nf; out->ext_na = nb; out->dev_copy = d.d_rp[5]; }
+    } else if (entry_only && blk.p) {
+        uint8_t* bp = (uint8_t*)blk.p;
+        sx_finding* hf = (sx_finding*)bp;
+        for (uint64_t j = 0; j < nfh; j++) { hf[j] = hf0->v[j]; hf[j].slice_index += job.slice_base; }
+        memcpy(bp + (nfh + nf) * sizeof(sx_finding), hf0->arena.data(), nbh);
+        out->ext = blk; out->ext_nf = nfh + nf; out->ext_na = nbh + nb;   // (no dev_copy: the device holds only its own part)
+        out->replay_bytes += hf0->replay_bytes;
     } else {
         const sx_finding* dev_f = (const sx_finding*)blk.p;
         const char* dev_a = blk.p ? (const char*)blk.p + nf * sizeof(sx_finding) : nullptr;
