@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--subchunk-kib", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
+    ap.add_argument("--background", default="random", choices=["random", "zero"],
+                    help="zero: a constant-byte buffer instead of the synthetic background (counter passes: same instructions, other data)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (testing the N>1 path on one GPU: gloo)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses cuda:0")
     args = ap.parse_args()
@@ -112,7 +114,10 @@ def main():
         if state.get("range") != (lo, hi):
             state["buf"] = None
             state["buf"] = torch.empty(hi - lo, dtype=torch.uint8, device=f"cuda:{local_rank}")
-            sc.fill_background(ctypes.c_void_p(state["buf"].data_ptr()), lo, hi - lo, SEED)
+            if args.background == "zero":
+                state["buf"].zero_()
+            else:
+                sc.fill_background(ctypes.c_void_p(state["buf"].data_ptr()), lo, hi - lo, SEED)
             torch.cuda.synchronize()
             state["range"] = (lo, hi)
         return ctypes.c_void_p(state["buf"].data_ptr())
@@ -218,7 +223,7 @@ def main():
         out = {
             "metric": "GiB/s scanned", "value": round(value, 2), "unit": "GiB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic" if args.background == "random" else "constant bytes (counter pass)",
             "config": {"workload": wl["name"], "bytes_per_gpu": nbytes, "missions": len(missions),
                        "parallelism": f"byte-range shards x{world}", "passes": len(missions)},
             "roofline": roofline,

@@ -62,6 +62,7 @@ struct ScanParams {
     uint32_t a_lo, a_hi;   // accepted ASCII / single-unit range (inclusive)
     uint32_t u_lo, u_hi;   // UTF-8: accepted 2-byte lead range; UTF-16: accepted unit range [u_lo,u_hi]
     uint32_t high_all;     // single-byte range: every byte >= 0x80 accepted
+    uint32_t wave_prio;    // 1: the scan wavefronts raise their issue priority (s_setprio)
     uint32_t af_is_range;  // Big5 / EUC-JP: the accepted ASCII bytes are [a_lo,a_hi] (else lut[0..255] holds them: 0x80 / 0)
     const uint32_t* pair_lut;  // Big5 / EUC-JP: device, 2 bits per byte pair (index = the pair as a little-endian u16; EUC-JP: + 65536
                                // for the last two bytes of 8F xx xx): 0 unmapped, 1 mapped, 3 accepted, 2 accepted and two characters

@@ -200,18 +200,23 @@ struct Utf8Lut {
 // --- UTF-16, af = one range, accepted non-ASCII units = one range below U+0800 -----------
 // Units sit at stream parity; every surrogate and everything outside the two ranges is a
 // break.  Both bytes of an accepted unit are good; the unit's first byte is the start.
-struct Utf16Range {
-    u32 a1, a2, u1, u2, odd, be;
+// BE_T / ODD_T: byte order and unit parity as compile-time constants (-1: read from the parameters) — the
+// kernels are bound by VALU issue, and a run-time byte order costs a v_perm + v_cndmask per dword.
+template <int BE_T, int ODD_T>
+struct Utf16RangeT {
+    u32 a1, a2, u1, u2, odd_rt, be_rt;
     SX_DEV void init(const ScanParams& p, const uint8_t*) {
         a1 = (0x8000u - p.a_lo) * 0x00010001u;
         a2 = (0x7FFFu - p.a_hi) * 0x00010001u;
         u1 = (0x8000u - p.u_lo) * 0x00010001u;
         u2 = (0x7FFFu - p.u_hi) * 0x00010001u;
-        odd = p.parity & 1;
-        be = p.big_endian;
+        odd_rt = p.parity & 1;
+        be_rt = p.big_endian;
     }
+    SX_DEV u32 odd() const { return ODD_T < 0 ? odd_rt : (u32)ODD_T; }
+    SX_DEV bool be() const { return BE_T < 0 ? be_rt != 0 : BE_T != 0; }
     SX_DEV u32 unit_flags(u32 v) const {  // two units per dword -> flags at bits 15 and 31
-        if (be) v = __builtin_amdgcn_perm(0u, v, 0x02030001u);
+        if (be()) v = __builtin_amdgcn_perm(0u, v, 0x02030001u);
         u32 t = v & 0x7FFF7FFFu;
         u32 ra = (t + a1) & ~(t + a2);
         u32 ru = (t + u1) & ~(t + u2);
@@ -220,7 +225,7 @@ struct Utf16Range {
     template <bool WANT_S>
     SX_DEV u32 classify(u32x4 x, u32 nx, u32 avail, bool near_end) const {
         u32 d0 = x.x, d1 = x.y, d2 = x.z, d3 = x.w;
-        if (odd) {  // unit k of this lane = bytes 2k+1, 2k+2
+        if (odd()) {  // unit k of this lane = bytes 2k+1, 2k+2
             d0 = __builtin_amdgcn_alignbyte(x.y, x.x, 1);
             d1 = __builtin_amdgcn_alignbyte(x.z, x.y, 1);
             d2 = __builtin_amdgcn_alignbyte(x.w, x.z, 1);
@@ -230,12 +235,13 @@ struct Utf16Range {
         u32 s0 = f0 >> 8, s1 = f1 >> 8, s2 = f2 >> 8, s3 = f3 >> 8;  // flag on the unit's first byte
         u32 m = WANT_S ? movemask16(s0, s1, s2, s3) : movemask16(f0 | s0, f1 | s1, f2 | s2, f3 | s3);
         if (near_end) {  // whole units only
-            u32 nu = avail > odd ? (avail - odd) >> 1 : 0u;
+            u32 nu = avail > odd() ? (avail - odd()) >> 1 : 0u;
             m &= low_mask(2 * nu);
         }
-        return m << odd;  // odd parity: everything sits one byte later (bit 16 spills)
+        return m << odd();  // odd parity: everything sits one byte later (bit 16 spills)
     }
 };
+using Utf16Range = Utf16RangeT<-1, -1>;
 
 // --- UTF-16, any af/ubf incl. astral: two 256-entry LUTs in LDS ---------------------------
 // lutH[hi byte]: bits 0-3 accept per (lo byte >> 6) quadrant; bit 4 "hi byte is 0: use
@@ -528,6 +534,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
         __syncthreads();
     }
     const u32 lane = lane_id();
+    if (p.wave_prio) __builtin_amdgcn_s_setprio(3);   // scan waves issue before another stream's waves on the same SIMD (stage B)
     CLS cls;
     cls.init(p, lds_lut);
     Emitter em{ p.recs, p.counters, p.capacity, 0u, 0u, p.region_cap, 0u, p.region_counts };
@@ -1147,7 +1154,13 @@ hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t str
     case kClsUtf8Lut: return launch_t<Utf8Lut, true>(p, stream);
     case kClsUtf16Lut: return launch_t<Utf16Lut, true>(p, stream);
     case kClsUtf8Range2: return launch_t<Utf8Range2, false>(p, stream);
-    case kClsUtf16Range: return launch_t<Utf16Range, false>(p, stream);
+    case kClsUtf16Range:
+        switch ((p.big_endian ? 2 : 0) | (p.parity & 1)) {
+        case 0: return launch_t<Utf16RangeT<0, 0>, false>(p, stream);
+        case 1: return launch_t<Utf16RangeT<0, 1>, false>(p, stream);
+        case 2: return launch_t<Utf16RangeT<1, 0>, false>(p, stream);
+        default: return launch_t<Utf16RangeT<1, 1>, false>(p, stream);
+        }
     case kClsSingleByteRange: return launch_t<SingleByteRange, false>(p, stream);
     default: break;
     }

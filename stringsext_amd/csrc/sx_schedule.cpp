@@ -53,15 +53,24 @@ int set_entry_params(sx_ctx* ctx, bool carried_state_is_entry, const uint8_t* ho
     return SX_OK;
 }
 
-// Missions in the order their kernels are queued: busiest of the previous buffer first, so that
-// its stage B (the longest) overlaps the scans of the others.
+// Missions in the order their kernels are queued (by their number of long runs in the previous buffer).
+// The scan kernels are bound by VALU issue (profiles/r02b_pmc_*: 88-100 % of the SIMDs' issue slots), so a stage B
+// that runs next to them takes its instructions out of their time: with a few million runs (a stage B of a few
+// milliseconds) the busiest Mission is scanned LAST and its stage B runs when the scans are done — the scan
+// launches then run at the speed they have alone.  With tens of millions of runs stage B is longer than the
+// scans: the busiest Mission goes FIRST and the others' scans hide behind its stage B.
 void mission_order(sx_ctx* ctx, std::vector<int>* out) {
     const size_t nm = ctx->missions.size();
     std::vector<int>& order = *out;
     order.resize(nm);
     for (size_t k = 0; k < nm; k++) order[k] = (int)k;
-    if (ctx->last_runs.size() == nm)
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ctx->last_runs[(size_t)x] > ctx->last_runs[(size_t)y]; });
+    if (ctx->last_runs.size() != nm) return;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ctx->last_runs[(size_t)x] > ctx->last_runs[(size_t)y]; });
+    uint64_t most = 0;
+    for (uint64_t r : ctx->last_runs) most = std::max(most, r);
+    bool busiest_last = most < (16ull << 20);
+    if (const char* e = getenv("SX_BUSIEST_LAST")) busiest_last = atoi(e) != 0;
+    if (busiest_last) std::reverse(order.begin(), order.end());
 }
 
 int sync_streams_and_return(sx_ctx* ctx, int rc) {  // do not leave kernels running on the caller's buffer

@@ -20,6 +20,7 @@ ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const 
     ScanParams p = m.proto;
     p.data = d_bytes; p.len = len; p.subchunk = sub; p.parity = parity;
     p.pair_lut = ctx->dev[(size_t)mission].d_pair_lut;
+    p.wave_prio = getenv("SX_SCAN_PRIO") ? (uint32_t)atoi(getenv("SX_SCAN_PRIO")) : 0u;
     p.min_chars = (uint32_t)std::min<uint64_t>(min_chars, kRecCharsMask);
     if (p.min_chars == 0) p.min_chars = 1;
     p.cand_bytes = std::min<uint32_t>(p.min_chars * (m.is_utf16() ? 2u : 1u), 17u);
