@@ -251,6 +251,29 @@ int sx_replay_shard_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t buf_off, ui
                          const sx_run* const* runs, const uint64_t* n_runs,
                          sx_result** out, uint64_t* end_pos);
 
+/* The whole sharded scan of one file for one rank of a job of `world` ranks (one process per GPU): own range + halo
+ * (sx_shard_bounds), the "where did everybody stop" exchange, the repeat when the previous rank ran past this rank's
+ * start, wider halos where a run (or, Big5 / EUC-JP, a stretch without token boundary) crosses them.  The transport is
+ * the caller's: `allgather` must deliver every rank's `bytes` bytes to all ranks, in rank order (RCCL, MPI, ...), and
+ * return 0.  `get_buffer` returns the file bytes [lo, hi) — in HBM of the context's device (*is_device = 1, 16-byte
+ * aligned) or in host memory — valid until its next call.  `get_runs` is normally NULL; if given, stage A is skipped
+ * and the runs of the buffer come from the caller (host bytes; CPU tests, runs from elsewhere).
+ * *out = this rank's findings (segment `rank` of the file's findings, in order); counts[k] / overflow[k] (arrays of
+ * `world`, may be NULL) = findings of rank k / how many of its last findings lie behind its range end.  Gathering the
+ * Finding buffers is the caller's (e.g. one gather over RCCL); sx_shard_splice() puts gathered buffers in order. */
+typedef int (*sx_allgather_fn)(void* user, const void* send, uint64_t bytes, void* recv);
+typedef int (*sx_shard_buffer_fn)(void* user, uint64_t lo, uint64_t hi, const void** ptr, int* is_device);
+typedef int (*sx_shard_runs_fn)(void* user, const uint8_t* bytes, uint64_t buf_off, uint64_t buf_len,
+                                const sx_run* const** runs, const uint64_t** n_runs);
+void sx_shard_bounds(uint64_t file_len, int world, int rank, uint64_t* own_lo, uint64_t* own_hi);
+int sx_scan_sharded(sx_ctx* ctx, int rank, int world, uint64_t file_len, uint64_t file_stream_off, int input_file_id,
+                    uint64_t halo, sx_shard_buffer_fn get_buffer, void* buffer_user, sx_shard_runs_fn get_runs, void* runs_user,
+                    sx_allgather_fn allgather, void* allgather_user, sx_result** out, uint64_t* counts, uint64_t* overflow);
+/* The ranks' finding buffers -> ONE result in the reference's print order (rank k's findings behind its range end
+ * merged into the head of rank k+1's: slice, position, Mission).  str_off of findings[k] is relative to arenas[k]. */
+int sx_shard_splice(const sx_finding* const* findings, const uint64_t* n_findings, const uint8_t* const* arenas,
+                    const uint64_t* arena_lens, int world, uint64_t file_len, sx_result** out);
+
 uint64_t          sx_result_count(const sx_result* r);
 /* The findings come in one or more segments, in print order (a large device-resident
  * buffer is scanned piece by piece and every piece adds a segment; the segments'

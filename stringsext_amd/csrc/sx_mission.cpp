@@ -163,9 +163,26 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
         bool hempty = false;
         one_range(acc, 128, 255, &hl, &hh, &hempty);
         const bool high_all = !hempty && hl == 128 && hh == 255 && [&] { for (int b = 128; b < 256; b++) if (!acc[b]) return false; return true; }();
+        // maximal ranges of accepted bytes, cut at 0x80
+        std::vector<std::pair<int, int>> ranges;
+        for (int b = 0; b < 256; b++)
+            if (acc[b]) {
+                if (!ranges.empty() && ranges.back().second == b - 1 && b != 0x80) ranges.back().second = b;
+                else ranges.emplace_back(b, b);
+            }
         if (!force_generic && af_is_range && (hempty || high_all)) {
             m->kind = kClsSingleByteRange;
             p.high_all = high_all ? 1 : 0;
+        } else if (!force_generic && ranges.size() <= 6) {
+            m->kind = kClsSingleByteRanges;
+            p.n_ranges = (uint32_t)ranges.size();
+            for (size_t k = 0; k < 6; k++) {
+                uint32_t lo = 1, hi = 0, high = 0;   // empty
+                if (k < ranges.size()) { lo = (uint32_t)ranges[k].first & 0x7F; hi = (uint32_t)ranges[k].second & 0x7F; high = ranges[k].first >= 0x80; }
+                p.rng_c1[k] = (0x80u - lo) * 0x01010101u;
+                p.rng_c2[k] = (0x7Fu - hi) * 0x01010101u;
+                p.rng_hi[k] = high ? 0u : 0xFFFFFFFFu;
+            }
         } else {
             m->kind = kClsSingleByteLut;
             for (int b = 0; b < 256; b++) p.lut[b] = acc[b] ? 0x80 : 0;

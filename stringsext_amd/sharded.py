@@ -21,22 +21,37 @@ import time
 import torch
 import torch.distributed as dist
 
-from . import Finding, PRECISION, SxError, SX_E_HALO
-
-
-class _NoResult:
-    def free(self):
-        pass
+from . import Finding, PRECISION, Result, Run, lib
 
 HALO_DEFAULT = 1 << 20
 
 
 def shard_bounds(file_len, world, rank):
-    """[own_lo, own_hi): contiguous, on the 4096-byte slice grid (src/input.rs:22)."""
-    per = (file_len // world + 4095) // 4096 * 4096
-    lo = min(file_len, rank * per)
-    hi = file_len if rank == world - 1 else min(file_len, (rank + 1) * per)
-    return lo, hi
+    """[own_lo, own_hi): contiguous, on the 4096-byte slice grid (src/input.rs:22) — sx_shard_bounds."""
+    L = lib()
+    L.sx_shard_bounds.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    L.sx_shard_bounds.restype = None
+    lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
+    L.sx_shard_bounds(file_len, world, rank, ctypes.byref(lo), ctypes.byref(hi))
+    return lo.value, hi.value
+
+
+def splice(scanner, gathered, file_len):
+    """gathered = [(findings_bytes, arena_bytes)] per rank (what scan_sharded(gather=True) returns on rank 0) -> one
+    Result in the reference's print order (sx_shard_splice)."""
+    L = lib()
+    world = len(gathered)
+    keep = [(ctypes.create_string_buffer(fb, len(fb)), ctypes.create_string_buffer(ab, len(ab))) for fb, ab in gathered]
+    fptr = (ctypes.POINTER(Finding) * world)(*[ctypes.cast(f, ctypes.POINTER(Finding)) for f, _ in keep])
+    aptr = (ctypes.POINTER(ctypes.c_uint8) * world)(*[ctypes.cast(a, ctypes.POINTER(ctypes.c_uint8)) for _, a in keep])
+    nf = (ctypes.c_uint64 * world)(*[len(fb) // ctypes.sizeof(Finding) for fb, _ in gathered])
+    na = (ctypes.c_uint64 * world)(*[len(ab) for _, ab in gathered])
+    L.sx_shard_splice.argtypes = [ctypes.POINTER(ctypes.POINTER(Finding)), ctypes.POINTER(ctypes.c_uint64),
+                                  ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), ctypes.POINTER(ctypes.c_uint64), ctypes.c_int,
+                                  ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+    r = ctypes.c_void_p()
+    scanner._chk(L.sx_shard_splice(fptr, nf, aptr, na, world, file_len, ctypes.byref(r)))
+    return Result(scanner, r)
 
 
 def _all_gather_u64(values, device):
@@ -71,90 +86,94 @@ def _payload(res):
     return f.view(np.uint8), a
 
 
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p)
+BUFFER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p),
+                             ctypes.POINTER(ctypes.c_int))
+RUNS_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                           ctypes.POINTER(ctypes.POINTER(ctypes.POINTER(Run))), ctypes.POINTER(ctypes.POINTER(ctypes.c_uint64)))
+
+
 def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, halo=HALO_DEFAULT, device="cpu",
                  runs_for_buffer=None, gather=True, timings=None):
-    """Scan one file of `file_len` bytes sharded over the process group.
+    """Scan one file of `file_len` bytes sharded over the process group.  The protocol (own range + halo, the "where
+    did everybody stop" exchange, repeats, wider halos) is the library's — sx_scan_sharded behind the C-ABI; this
+    function only supplies the transport (torch.distributed all_gather; backend "nccl" = RCCL over xGMI) and the buffers.
 
-    get_buffer(lo, hi) -> bytes | ctypes.c_void_p : the file bytes [lo, hi) on this rank.
+    get_buffer(lo, hi) -> bytes | ctypes.c_void_p : the file bytes [lo, hi) on this rank (c_void_p: in HBM).
     runs_for_buffer(buf_bytes, buf_off) -> runs per mission (tests on CPU: stage B only).
-    gather=True: rank 0 gets the list of (findings_bytes, arena_bytes) per rank, in rank order (a
-    gather over the process group), the other ranks None.  gather=False: the findings stay where
-    they are — rank k's Result is segment k of the file's findings, in order — and every rank
-    gets the per-rank finding counts (ShardCounts).  The rank's own Result is the second value.
-    Segment k may end with a few findings that lie behind rank k's range end (a region across the
-    boundary; ShardCounts.overflow[k] of them); splice_order() merges them into segment k+1's head.
+    gather=True: rank 0 gets the list of (findings_bytes, arena_bytes) per rank, in rank order (one gather over the
+    process group), the other ranks None.  gather=False: the findings stay where they are — rank k's Result is
+    segment k of the file's findings, in order — and every rank gets the per-rank finding counts (ShardCounts).
+    The rank's own Result is the second value.  Segment k may end with a few findings that lie behind rank k's range
+    end (a region across the boundary; ShardCounts.overflow[k] of them); splice() / splice_order() merge them into
+    segment k+1's head.
     """
     world, rank = dist.get_world_size(), dist.get_rank()
-    own_lo, own_hi = shard_bounds(file_len, world, rank)
-    nm = scanner.n
+    L = lib()
+    keep = {}
+    errors = []
 
-    def attempt(start_at, h, reuse):
-        buf_lo = max(0, own_lo - h) // 4096 * 4096
-        buf_hi = min(file_len, own_hi + h)
-        buf = get_buffer(buf_lo, buf_hi)
-        kw = {}
-        if runs_for_buffer is not None:
-            kw["runs_per_mission"] = runs_for_buffer(buf, buf_lo)
-        if isinstance(buf, ctypes.c_void_p):
-            kw["buf_len"] = buf_hi - buf_lo
+    def _allgather(user, send, nbytes, recv):
         try:
-            res, ends = scanner.scan_shard(buf, buf_lo, own_lo, own_hi, start_at=start_at, file_stream_off=file_stream_off,
-                                           file_id=file_id, reuse_runs=reuse, **kw)
-        except SxError as e:
-            if e.code != SX_E_HALO or buf_lo == 0:
-                raise
-            return _NoResult(), [own_hi] * nm, True, buf_hi   # the halo in front is too short (Big5 / EUC-JP): look further
-        truncated = any(e >= buf_hi for e in ends) and buf_hi < file_len
-        return res, ends, truncated, buf_hi
+            t = torch.frombuffer(bytearray(ctypes.string_at(send, nbytes)), dtype=torch.uint8).to(device)
+            outs = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(outs, t)
+            blob = torch.cat(outs).cpu().numpy().tobytes()
+            ctypes.memmove(recv, blob, len(blob))
+            return 0
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            return 1
 
-    # first attempt: everybody assumes the previous rank stops at the shard boundary
+    def _buffer(user, lo, hi, ptr, is_device):
+        try:
+            buf = get_buffer(lo, hi)
+            if isinstance(buf, ctypes.c_void_p):
+                ptr[0] = buf.value
+                is_device[0] = 1
+            else:
+                keep["buf"] = ctypes.create_string_buffer(bytes(buf), hi - lo)
+                ptr[0] = ctypes.cast(keep["buf"], ctypes.c_void_p).value
+                is_device[0] = 0
+            return 0
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            return 1
+
+    def _runs(user, bytes_ptr, buf_off, buf_len, runs_out, n_out):
+        try:
+            per = runs_for_buffer(ctypes.string_at(bytes_ptr, buf_len), buf_off)
+            arrs = [(Run * max(1, len(rs)))(*[Run(*t) for t in rs]) for rs in per]
+            keep["runs"] = (arrs, (ctypes.POINTER(Run) * len(per))(*[ctypes.cast(a, ctypes.POINTER(Run)) for a in arrs]),
+                            (ctypes.c_uint64 * len(per))(*[len(rs) for rs in per]))
+            runs_out[0] = ctypes.cast(keep["runs"][1], ctypes.POINTER(ctypes.POINTER(Run)))
+            n_out[0] = ctypes.cast(keep["runs"][2], ctypes.POINTER(ctypes.c_uint64))
+            return 0
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            return 1
+
+    cb_gather, cb_buffer = ALLGATHER_FN(_allgather), BUFFER_FN(_buffer)
+    cb_runs = RUNS_FN(_runs) if runs_for_buffer is not None else ctypes.cast(None, RUNS_FN)
+    L.sx_scan_sharded.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int,
+                                  ctypes.c_uint64, BUFFER_FN, ctypes.c_void_p, RUNS_FN, ctypes.c_void_p, ALLGATHER_FN, ctypes.c_void_p,
+                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     t_begin = time.perf_counter()
-    h = halo
-    start = [own_lo] * nm
-    res, ends, truncated, _ = attempt(None, h, False)
-    while truncated:  # a run crosses the whole halo: look further
-        h *= 8
-        res.free()
-        res, ends, truncated, _ = attempt(None, h, False)
-
-    # Where did everybody stop?  One all_gather of (start used, end reached) per mission + the
-    # finding count; rank k must repeat its replay if rank k-1 ran past the point rank k started
-    # from (rare: a region crossing the shard boundary).  Every rank evaluates the same table,
-    # so all agree on who repeats; a repeat can move that rank's own end, hence the loop.
-    t_scan = time.perf_counter()
-    while True:
-        table = _all_gather_u64(start + ends + [len(res)], device)
-        redo = [False] * world
-        for k in range(1, world):
-            prev_end, my_start = table[k - 1][nm:2 * nm], table[k][:nm]
-            k_lo = shard_bounds(file_len, world, k)[0]
-            redo[k] = any(max(k_lo, p) > s0 for p, s0 in zip(prev_end, my_start))
-        if not any(redo):
-            break
-        if redo[rank]:
-            prev_end = table[rank - 1][nm:2 * nm]
-            start = [max(own_lo, p, s0) for p, s0 in zip(prev_end, start)]
-            res.free()
-            res, ends, truncated, _ = attempt(start, h, True)
-            while truncated:
-                h *= 8
-                res.free()
-                res, ends, truncated, _ = attempt(start, h, False)
-            ends = [max(e, p) for e, p in zip(ends, prev_end)]
-    # A region that crosses the shard boundary is finished by the rank it began on, so the tail of rank
-    # k's findings can lie in slices that belong to rank k+1 and interleaves there with other Missions'
-    # findings of rank k+1 (the reference prints slice by slice, src/main.rs:153-168).  How many such
-    # findings each rank holds goes along with the counts; splice_order() puts them in place.
-    over = _overflow(res, own_hi // 4096) if rank + 1 < world else 0
-    counts = ShardCounts(row[2 * nm] for row in table)
-    counts.overflow = [row[0] for row in _all_gather_u64([over], device)]
-    if os.environ.get("SX_TIMING") and rank == 0:
-        print(f"[sx] sharded: scan {1e3 * (t_scan - t_begin):.2f} ms, exchange {1e3 * (time.perf_counter() - t_scan):.2f} ms",
-              file=sys.stderr)
+    r = ctypes.c_void_p()
+    cnt, over = (ctypes.c_uint64 * world)(), (ctypes.c_uint64 * world)()
+    rc = L.sx_scan_sharded(scanner.h, rank, world, file_len, file_stream_off, file_id, halo, cb_buffer, None, cb_runs, None,
+                           cb_gather, None, ctypes.byref(r), cnt, over)
+    if errors:
+        raise errors[0]
+    scanner._chk(rc)
+    res = Result(scanner, r)
+    counts = ShardCounts(cnt)
+    counts.overflow = list(over)
+    t_scan = time.perf_counter()   # (the exchange is inside the library call: two small all-gathers)
 
     t_exchanged = time.perf_counter()
     if timings is not None:
-        timings["scan_ms"] = 1e3 * (t_scan - t_begin)
+        timings["scan_ms"] = 1e3 * (t_scan - t_begin)     # incl. the two small all-gathers inside sx_scan_sharded
         timings["exchange_ms"] = 1e3 * (t_exchanged - t_scan)
         timings["gather_ms"] = 0.0
     if not gather:
@@ -188,18 +207,6 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
 class ShardCounts(list):
     """Findings per rank; .overflow[k] = how many of rank k's last findings lie behind its range end."""
     overflow = None
-
-
-def _overflow(res, boundary_slice):
-    n = 0
-    for v, cnt in reversed(res.finding_arrays()):
-        i = cnt
-        while i > 0 and v[i - 1].slice_index >= boundary_slice:
-            i -= 1
-        n += cnt - i
-        if i > 0:
-            break
-    return n
 
 
 def splice_order(parts, file_len, key=lambda f: (f["slice_index"], f["position"])):

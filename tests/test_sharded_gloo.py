@@ -39,6 +39,28 @@ def make_data(kind, seed):
                 d[b - 20:b + 30] = b"crossing-the-shard-boundary-" + b"x" * 22
                 d[b + 4096 - 3:b + 4096 + 9] = "שלום עולם"[:6].encode("utf-8")[:12]
         return bytes(d)
+    if kind == "c4":  # BASELINE config 4's image in small: records of the three encodings across EVERY shard edge (2 and 4 ranks)
+        from test_gpu_baseline_configs import CORPUS
+        d = bytearray(synth(rng, n, 1 / 3000))
+        k = 0
+        for w in (2, 4):
+            for r in range(1, w):
+                b = (n // w + 4095) // 4096 * 4096 * r
+                for enc, at in (("utf-8", b - 30), ("utf-16-le", b + 4096 - 24), ("utf-16-be", b - 4096 - 10), ("utf-8", b + 128 * 3 - 7)):
+                    text = (CORPUS[(k * 3 + 3) % len(CORPUS)] + " " + CORPUS[(k + 5) % len(CORPUS)])[:rng.choice([30, 64, 65, 100])]
+                    rec = b"\x00\x00" + text.encode(enc) + b"\x00\x00"
+                    at &= ~1
+                    d[at:at + len(rec)] = rec
+                    k += 1
+        return bytes(d)
+    if kind == "cjk":   # Big5 / EUC-JP: the token grid at a shard start needs a byte outside the lead range in the halo
+        from test_dbcs import soup as dbcs_soup
+        d = bytearray(dbcs_soup("big5", rng, n // 2) + dbcs_soup("euc-jp", rng, n - n // 2))
+        for r in (1, 2):
+            b = (n // 3 + 4095) // 4096 * 4096 * r
+            d[b - 30000:b + 500] = b"\xa4" * 30500          # no token boundary for 30 KB in front of the shard start: wider halo
+            d[b + 500:b + 540] = "天地玄黃宇宙洪荒日月盈昃辰宿列張".encode("big5")[:40]
+        return bytes(d)
     if kind == "giant":  # one run far longer than the halo, across every boundary
         d = bytearray(synth(rng, n, 1 / 2000))
         text = bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz ") for _ in range(2 * (1 << 20)))
@@ -68,6 +90,10 @@ def _worker(rank, world, port, kind, flags, halo, q, gather=True):
         if rank == 0:
             if gather:
                 parts = [sharded.decode_findings(fb, ab) for fb, ab in gathered]
+                # the library's own splice (sx_shard_splice) == the Python restatement of it below
+                spliced = sharded.splice(sc, gathered, len(data))
+                assert [key(f) for f in spliced.findings()] == [key(f) for f in sharded.splice_order(parts, len(data))]
+                spliced.free()
             else:
                 assert [sum(1 for f in p_[-o:] if o) for p_, o in zip(parts, gathered.overflow)] == gathered.overflow
             got = [key(f) for f in sharded.splice_order(parts, len(data))]
@@ -94,6 +120,11 @@ CASES = [
     (3, "planted", dict(encodings=["ascii", "utf-8"], chars_min="10", output_line_len="16"), 1 << 14),
     (2, "giant", dict(encodings=["utf-8"], chars_min="10"), 1 << 14),
     (3, "giant", dict(encodings=["ascii"], chars_min="4", output_line_len="20"), 1 << 12),
+    # BASELINE config 4: the three-encoding -u African scan, byte-range sharded
+    (2, "c4", dict(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African"), 1 << 16),
+    (4, "c4", dict(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African"), 1 << 14),
+    (4, "giant", dict(encodings=["utf-8", "utf-16le"], chars_min="10"), 1 << 13),
+    (3, "cjk", dict(encodings=["big5", "euc-jp", "utf-8"], chars_min="4", unicode_block_filter="Asian"), 1 << 12),
 ]
 
 
