@@ -125,6 +125,12 @@ size_t sxo_runs(const sxo_mission* m, const uint8_t* buf, size_t len, int stream
 
 const char* sxo_encoding_name(int encoding);
 
+/* One decoder on its own: decode_to_str_without_replacement(src, dst, last) -> result (0 InputEmpty, 1 OutputFull,
+ * 2 Malformed), bytes read, bytes written.  State persists between steps like encoding_rs' Decoder. */
+void* sxo_decoder_new(int encoding);
+int   sxo_decoder_step(void* d, const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int last, size_t* read, size_t* written);
+void  sxo_decoder_free(void* d);
+
 /* Deterministic synthetic background. */
 void sxo_fill_background(uint8_t* dst, uint64_t first_byte_index, size_t len, uint64_t seed);
 

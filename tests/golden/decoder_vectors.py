@@ -1,0 +1,76 @@
+"""Hand-derived known answers for `Decoder::decode_to_str_without_replacement` where the reference's own tests pin
+nothing ("parity unpinned"): the UTF-16 surrogate accounting and the UTF-8 un-read rule.
+
+Source: the WHATWG Encoding Standard's "utf-16 decoder" / "utf-8 decoder" algorithms, and for what a streaming
+decoder must do differently the crate's documented contract as restated in SURVEY.md 3.3:
+  * a low surrogate without a high one: Malformed, the unit consumed;
+  * a high surrogate followed IN THE SAME CALL by a whole unit that is not a low surrogate: Malformed, only the high
+    surrogate consumed (the following unit is decoded by the next call);
+  * a high surrogate that is the LAST whole unit of a call stays pending; the next call's first unit decides:
+    low -> the pair; high -> Malformed, that unit consumed, the new high surrogate pending; anything else ->
+    Malformed, that unit consumed too, and its character is the FIRST OUTPUT of the call after that (pending_bmp);
+  * an odd byte at the end of a call stays pending (the unit grid is the stream's, not the call's);
+  * UTF-8: a byte that cannot continue the sequence is NOT consumed by the Malformed call (it starts the next
+    call); E0 / ED / F0 / F4 narrow the range of the second byte; C0, C1, F5..FF and stray continuation bytes are
+    one-byte errors.
+Each vector was written down from these rules BEFORE it was run against any implementation; it is checked against the
+oracle's decoders (oracle/sxo.c) and the product's (sx_codec_core.hpp compiled for the host — the device kernels are
+compiled from the same source) in tests/test_decoder_vectors.py, and end to end on the GPU through finding positions.
+
+Format: (name, encoding, [call, ...]); call = (input bytes as hex, last flag, [(result, read, written), ...]) — the
+steps the loop `loop { r = decode(rest); rest = rest[read..]; if r is InputEmpty { break } }` goes through
+(src/finding_collection.rs:134-143,292-325: after Malformed the decoder is called again, even on empty input).
+result: E = InputEmpty, M = Malformed."""
+
+H, H2, L, A, B = "3dd8", "3cd8", "00de", "4100", "4200"      # UTF-16LE units: U+D83D, U+D83C (high), U+DE00 (low), 'A', 'B'
+
+
+def be(hexunits):
+    """the same units, big endian"""
+    return "".join(hexunits[i + 2:i + 4] + hexunits[i:i + 2] for i in range(0, len(hexunits), 4))
+
+
+UTF16LE = [
+    ("bmp", [(A + B, False, [("E", 4, 2)])]),
+    ("pair", [(H + L, False, [("E", 4, 4)])]),
+    ("lone low", [(L + A, False, [("M", 2, 0), ("E", 2, 1)])]),
+    ("high then bmp in one call", [(H + A, False, [("M", 2, 0), ("E", 2, 1)])]),
+    ("high high low in one call", [(H + H2 + L, False, [("M", 2, 0), ("E", 4, 4)])]),
+    ("high as last unit stays pending, low completes it", [(H, False, [("E", 2, 0)]), (L, False, [("E", 2, 4)])]),
+    ("pending high then bmp: both consumed, the bmp char opens the call after", [
+        (H, False, [("E", 2, 0)]), (A + B, False, [("M", 2, 0), ("E", 2, 2)])]),
+    ("pending high then bmp at the very end: an empty call delivers it", [
+        (H, False, [("E", 2, 0)]), (A, False, [("M", 2, 0), ("E", 0, 1)])]),
+    ("pending high then high then low", [(H, False, [("E", 2, 0)]), (H2 + L, False, [("M", 2, 0), ("E", 2, 4)])]),
+    ("pending high then lone low is the pair even across three calls", [
+        (A + H, False, [("E", 4, 1)]), (L + B, False, [("E", 4, 5)])]),
+    ("odd byte pending", [("41", False, [("E", 1, 0)]), ("00" + B, False, [("E", 3, 2)])]),
+    ("high + half a unit", [(H + "41", False, [("E", 3, 0)]), ("00", False, [("M", 1, 0), ("E", 0, 1)])]),
+    ("pending high at the end of the input", [(A + H, True, [("M", 4, 1), ("E", 0, 0)])]),
+    ("pending odd byte at the end of the input", [(A + "41", True, [("M", 3, 1), ("E", 0, 0)])]),
+    ("low low", [(L + L, False, [("M", 2, 0), ("M", 2, 0), ("E", 0, 0)])]),
+]
+
+UTF8 = [
+    ("ascii", [("4142", False, [("E", 2, 2)])]),
+    ("c0 is a one-byte error", [("c0af41", False, [("M", 1, 0), ("M", 1, 0), ("E", 1, 1)])]),
+    ("lead + ascii: the ascii byte is not consumed", [("c241", False, [("M", 1, 0), ("E", 1, 1)])]),
+    ("e0 narrows the second byte to a0..bf", [("e09f80", False, [("M", 1, 0), ("M", 1, 0), ("M", 1, 0), ("E", 0, 0)])]),
+    ("e0 a0 80 is U+0800", [("e0a080", False, [("E", 3, 3)])]),
+    ("ed narrows to 80..9f (no surrogates)", [("eda080", False, [("M", 1, 0), ("M", 1, 0), ("M", 1, 0), ("E", 0, 0)])]),
+    ("f0 narrows to 90..bf", [("f08f8080", False, [("M", 1, 0), ("M", 1, 0), ("M", 1, 0), ("M", 1, 0), ("E", 0, 0)])]),
+    ("f4 narrows to 80..8f", [("f4908080", False, [("M", 1, 0), ("M", 1, 0), ("M", 1, 0), ("M", 1, 0), ("E", 0, 0)])]),
+    ("f5 and ff", [("f5ff41", False, [("M", 1, 0), ("M", 1, 0), ("E", 1, 1)])]),
+    ("two good bytes then a bad third: three bytes malformed, the bad byte stays", [("e282" + "41", False, [("M", 2, 0), ("E", 1, 1)])]),
+    ("three good bytes of four then ascii", [("f09f98" + "41", False, [("M", 3, 0), ("E", 1, 1)])]),
+    ("a sequence split over two calls", [("e2", False, [("E", 1, 0)]), ("82ac41", False, [("E", 3, 4)])]),
+    ("a bad continuation as the FIRST byte of a call: nothing read, nothing written", [
+        ("e2", False, [("E", 1, 0)]), ("41", False, [("M", 0, 0), ("E", 1, 1)])]),
+    ("truncated at the end of the input", [("41e282", True, [("M", 3, 1), ("E", 0, 0)])]),
+    ("stray continuation bytes", [("80bf41", False, [("M", 1, 0), ("M", 1, 0), ("E", 1, 1)])]),
+]
+
+VECTORS = ([(n, "utf-16le", c) for n, c in UTF16LE]
+           + [(n, "utf-16be", [(be(x) if len(x) % 4 == 0 else None, last, steps) for x, last, steps in c]) for n, c in UTF16LE
+              if all(len(x) % 4 == 0 for x, _, _ in c)]
+           + [(n, "utf-8", c) for n, c in UTF8])

@@ -51,3 +51,16 @@ extern "C" uint64_t sxd_split_runs_host(const sx::ReplayParams* P, sx_run* out, 
     }
     return n;
 }
+
+// The product's decoder (sx_codec_core.hpp: the source the device kernels are compiled from) on its own.
+extern "C" void* sxd_decoder_new(int enc, const uint16_t* table) {
+    sx::DDecoder* d = new sx::DDecoder;
+    sx::ddec_reset(*d, enc, table);
+    return d;
+}
+extern "C" int sxd_decoder_step(void* d, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, int last, uint32_t* rd, uint32_t* wr) {
+    const sx::DStep r = sx::ddecode_any(*(sx::DDecoder*)d, src, n, dst, cap, last != 0);
+    *rd = r.read; *wr = r.written;
+    return r.result;
+}
+extern "C" void sxd_decoder_free(void* d) { delete (sx::DDecoder*)d; }
