@@ -62,7 +62,9 @@ enum {
     SX_ENC_WINDOWS_1256 = 40, SX_ENC_WINDOWS_1257 = 41, SX_ENC_WINDOWS_1258 = 42,
     SX_ENC_X_MAC_CYRILLIC = 43,
     /* legacy multi-byte (tables: csrc/gen_tables.py; parity unpinned): a pending lead byte is the decoder state */
-    SX_ENC_BIG5 = 64, SX_ENC_EUC_JP = 65
+    SX_ENC_BIG5 = 64, SX_ENC_EUC_JP = 65, SX_ENC_SHIFT_JIS = 66, SX_ENC_EUC_KR = 67,
+    /* the "replacement" encoding (ISO-2022-KR, ISO-2022-CN, HZ-GB-2312): its decoder reports one error and nothing else */
+    SX_ENC_REPLACEMENT = 70
 };
 
 /* `Precision` — src/finding.rs:34-46 */

@@ -17,6 +17,10 @@ index files themselves are not available.  ICU differs from them in known places
   EUC-JP       jis0208: ICU's user-defined rows (private use) dropped; 8E E0..E2 (an ICU extension) dropped;
                jis0212: the IBM extension rows 0xF3/0xF4 (ICU's eucJP-ms flavour) dropped — the WHATWG index is
                JIS X 0212-1990 — and 0xA2B7 = U+FF5E as in ICU.
+  Shift_JIS    ICU and CPython's cp932 agree on every two-byte cell; the single byte 0x80 is U+0080 in the WHATWG decoder
+               (an error in ICU) — that is in the decoder, not in this table.
+  EUC-KR       ICU has KS X 1001 only; the UHC extension (the WHATWG index is windows-949) comes from cpython_supplement.txt
+               (single source).
 Parity of all legacy tables is UNPINNED: no reference test decodes any of them.
 
 Order of the single-byte tables defines the encoding id (16 + index); names are Encoding::name()."""
@@ -39,6 +43,8 @@ SB_PATCH = {
 }
 BIG5_N = 126 * 157
 JIS_N = 94 * 94
+SJIS_N = 11280      # pointers of the Shift_JIS decoder: (lead - offset) * 188 + trail - offset, lead up to 0xFC
+EUCKR_N = 126 * 190
 
 
 def is_pua(cp):
@@ -108,6 +114,34 @@ def euc_jp():
     return j208, j212
 
 
+def shift_jis():
+    """index jis0208 as the Shift_JIS decoder addresses it (the user-defined pointers 8836..10715 stay 0: a rule)"""
+    t = [0] * SJIS_N
+    for line in open(os.path.join(TAB, "icu_shift_jis.txt")):
+        k, v = line.split()
+        key = int(k, 16)
+        cps = [int(x, 16) for x in v.split("+")]
+        lead, trail = key >> 8, key & 0xFF
+        ptr = (lead - (0x81 if lead < 0xA0 else 0xC1)) * 188 + (trail - (0x40 if trail < 0x7F else 0x41))
+        if len(cps) == 1 and not 8836 <= ptr <= 10715:
+            t[ptr] = cps[0]
+    return t
+
+
+def euc_kr():
+    t = [0] * EUCKR_N
+    for path, pick in (("icu_euc_kr.txt", lambda p: (p[0], p[1])), ("cpython_supplement.txt", lambda p: (p[1], p[2]) if p[0] == "euc-kr" else None)):
+        for line in open(os.path.join(TAB, path)):
+            kv = pick(line.split())
+            if not kv:
+                continue
+            key, cp = int(kv[0], 16), int(kv[1].split("+")[0], 16)
+            if "+" in kv[1] or is_pua(cp):   # ICU's user-defined rows C9xx / FExx (private use) are not in the WHATWG index
+                continue
+            t[((key >> 8) - 0x81) * 190 + ((key & 0xFF) - 0x41)] = cp
+    return t
+
+
 def emit_array(fh, ctype, name, values, per_line, width):
     fh.write(f"static const {ctype} {name}[{len(values)}] = {{\n")
     for i in range(0, len(values), per_line):
@@ -137,6 +171,9 @@ def emit(path):
         emit_array(fh, "uint32_t", "sxo_big5", b5, 12, 5)
         emit_array(fh, "uint16_t", "sxo_jis0208", j208, 16, 4)
         emit_array(fh, "uint16_t", "sxo_jis0212", j212, 16, 4)
+        fh.write(f"#define SXO_SJIS_N {SJIS_N}\n#define SXO_EUCKR_N {EUCKR_N}\n")
+        emit_array(fh, "uint16_t", "sxo_sjis", shift_jis(), 16, 4)
+        emit_array(fh, "uint16_t", "sxo_euckr", euc_kr(), 16, 4)
 
 
 if __name__ == "__main__":

@@ -49,4 +49,6 @@ const ej = two('euc-jp', null, [0x8E].concat(range(0xA1, 0xFE)), range(0xA1, 0xF
   }
 }
 write('icu_euc_jp.txt', ej);
+write('icu_shift_jis.txt', two('shift_jis', null, range(0x81, 0x9F).concat(range(0xE0, 0xFC)), range(0x40, 0x7E).concat(range(0x80, 0xFC))));
+write('icu_euc_kr.txt', two('euc-kr', null, range(0x81, 0xFE), range(0x41, 0xFE)).filter(l => l.indexOf('+') < 0));
 console.log('ICU', process.versions.icu, 'Unicode', process.versions.unicode);

@@ -18,6 +18,8 @@ not available.  CPython differs from them in known places, patched here:
   EUC-JP (index-jis0208 is Windows-31J's table: NEC row 13 and the IBM extension rows 89..92 included)
   * jis0208 from `cp932` through the Shift_JIS pointer arithmetic; jis0212 from `euc_jp`'s three-byte form with
     0xA2B7 = U+FF5E (CPython: U+007E).
+  Shift_JIS: index jis0208 from `cp932` by Shift_JIS pointer (ICU agrees on every cell); EUC-KR: `cp949` (= windows-949,
+  the WHATWG index; ICU has only the KS X 1001 part).
 Parity of all legacy tables is UNPINNED (no reference test decodes any of them).
 
 Order of the single-byte tables defines the encoding id (16 + index) and must only ever be appended to; names are
@@ -125,6 +127,34 @@ def jis0212_table():
     return t
 
 
+SJIS_N = 11280
+EUCKR_N = 126 * 190
+
+
+def shift_jis_table():
+    """index jis0208 by Shift_JIS pointer, from cp932 (the user-defined pointers 8836..10715 stay 0: a rule in the decoder)"""
+    t = [0] * SJIS_N
+    for p in range(SJIS_N):
+        if 8836 <= p <= 10715:
+            continue
+        lead, trail = divmod(p, 188)
+        v = cps("cp932", [lead + (0x81 if lead < 0x1F else 0xC1), trail + (0x40 if trail < 0x3F else 0x41)])
+        if v and len(v) == 1:
+            t[p] = v[0]
+    return t
+
+
+def euc_kr_table():
+    """the WHATWG euc-kr index is windows-949's: cp949"""
+    t = [0] * EUCKR_N
+    for lead in range(0x81, 0xFF):
+        for trail in range(0x41, 0xFF):
+            v = cps("cp949", [lead, trail])
+            if v and len(v) == 1 and v[0] >= 0x80:
+                t[(lead - 0x81) * 190 + (trail - 0x41)] = v[0]
+    return t
+
+
 def emit_array(fh, ctype, name, values, per_line, width):
     fh.write(f"static const {ctype} {name}[{len(values)}] = {{\n")
     for i in range(0, len(values), per_line):
@@ -161,6 +191,9 @@ def emit(prefix, fh):
              f"#define {prefix.upper()}_JIS_N {JIS_N}\n")
     emit_array(fh, "uint16_t", f"{prefix}_big5", [v & 0xFFFF for v in b5] + plane2, 16, 4)
     emit_array(fh, "uint16_t", f"{prefix}_eucjp", jis0208_table() + jis0212_table(), 16, 4)
+    fh.write(f"#define {prefix.upper()}_SJIS_N {SJIS_N}\n#define {prefix.upper()}_EUCKR_N {EUCKR_N}\n")
+    emit_array(fh, "uint16_t", f"{prefix}_sjis", shift_jis_table(), 16, 4)
+    emit_array(fh, "uint16_t", f"{prefix}_euckr", euc_kr_table(), 16, 4)
 
 
 if __name__ == "__main__":

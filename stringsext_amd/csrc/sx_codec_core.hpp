@@ -27,12 +27,17 @@ struct DStep { int result; u32 read, written; };
 
 // Encoding families the code is compiled for (template parameter ENC): 1 UTF-8, 2 UTF-16LE,
 // 3 UTF-16BE, 4 Big5, 5 EUC-JP, 0 every single-byte encoding (SX_ENC_* 16.., x-user-defined).
-constexpr int kEncBig5 = 64, kEncEucJp = 65;  // == SX_ENC_BIG5 / SX_ENC_EUC_JP (include/stringsext_amd.h)
+// Family 4 = the two-byte encodings (Big5, Shift_JIS, EUC-KR: a lead byte and one more; which one is a run-time
+// value), family 5 = EUC-JP (three-byte tokens too).
+constexpr int kEncBig5 = 64, kEncEucJp = 65, kEncShiftJis = 66, kEncEucKr = 67;  // == SX_ENC_* (include/stringsext_amd.h)
 constexpr int enc_family(u32 encoding) {
-    return encoding == 1 ? 1 : encoding == 2 ? 2 : encoding == 3 ? 3 : encoding == (u32)kEncBig5 ? 4 : encoding == (u32)kEncEucJp ? 5 : 0;
+    return encoding == 1 ? 1 : encoding == 2 ? 2 : encoding == 3 ? 3
+         : (encoding == (u32)kEncBig5 || encoding == (u32)kEncShiftJis || encoding == (u32)kEncEucKr) ? 4 : encoding == (u32)kEncEucJp ? 5 : 0;
 }
 // Layout of the double-byte tables (csrc/gen_tables.py): one uint16_t blob per encoding.
-constexpr u32 kBig5N = 126 * 157, kBig5P2Words = (kBig5N + 15) / 16, kJisN = 94 * 94;
+//   Big5: [kBig5N low halves][kBig5P2Words plane-2 bitmap];  EUC-JP: [kJisN jis0208][kJisN jis0212];
+//   Shift_JIS: [kSjisN: index jis0208 up to the IBM extension rows];  EUC-KR: [kEucKrN].
+constexpr u32 kBig5N = 126 * 157, kBig5P2Words = (kBig5N + 15) / 16, kJisN = 94 * 94, kSjisN = 11280, kEucKrN = 126 * 190;
 
 struct DDecoder {
     int enc;
@@ -148,7 +153,11 @@ SXD DStep ddec_utf16(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool l
     }
 }
 
+constexpr int kEncReplacement = 70;   // == SX_ENC_REPLACEMENT
 SXD DStep ddec_single(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap) {
+    // WHATWG "replacement decoder": one error for the whole input and no character ever — nothing of it is observable
+    // in the scan (no output, hence no finding, and no position anybody reads), so the input is just consumed
+    if (d.enc == kEncReplacement) return { RES_INPUT_EMPTY, n, 0 };
     u32 i = 0, w = 0;
     for (;;) {
         if (i >= n) return { RES_INPUT_EMPTY, i, w };
@@ -178,7 +187,35 @@ SXD u32 big5_lookup(const uint16_t* t, u32 lead, u32 trail, u32* second) {
     return lo | (p2 << 17);
 }
 
-SXD DStep ddec_big5(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {
+// Shift_JIS (WHATWG "Shift_JIS decoder"): pointer -> index jis0208, or the user-defined range 8836..10715 -> U+E000..
+SXD u32 sjis_lookup(const uint16_t* t, u32 lead, u32 trail) {
+    if (!((trail >= 0x40 && trail <= 0x7E) || (trail >= 0x80 && trail <= 0xFC))) return 0;
+    const u32 ptr = (lead - (lead < 0xA0 ? 0x81u : 0xC1u)) * 188 + (trail - (trail < 0x7F ? 0x40u : 0x41u));
+    if (ptr >= 8836 && ptr <= 10715) return 0xE000u - 8836u + ptr;
+    return ptr < kSjisN ? t[ptr] : 0u;
+}
+// EUC-KR (WHATWG "EUC-KR decoder"): lead 81..FE, trail 41..FE
+SXD u32 euckr_lookup(const uint16_t* t, u32 lead, u32 trail) {
+    if (trail < 0x41 || trail > 0xFE) return 0;
+    return t[(lead - 0x81) * 190 + (trail - 0x41)];
+}
+// the two-byte family: is b a lead byte / which character is (lead, trail) / which character is a single byte >= 0x80
+SXD bool two_byte_lead(int enc, u8 b) {
+    if (enc == kEncShiftJis) return (b >= 0x81 && b <= 0x9F) || (b >= 0xE0 && b <= 0xFC);
+    return b >= 0x81 && b <= 0xFE;
+}
+SXD u32 two_byte_lookup(int enc, const uint16_t* t, u32 lead, u32 trail, u32* second) {
+    *second = 0;
+    if (enc == kEncShiftJis) return sjis_lookup(t, lead, trail);
+    if (enc == kEncEucKr) return euckr_lookup(t, lead, trail);
+    return big5_lookup(t, lead, trail, second);
+}
+SXD u32 two_byte_single(int enc, u8 b) {   // b >= 0x80 and not a lead byte: its character, 0 = malformed
+    if (enc == kEncShiftJis) return b == 0x80 ? 0x80u : (b >= 0xA1 && b <= 0xDF) ? 0xFF61u - 0xA1u + b : 0u;
+    return 0;
+}
+
+SXD DStep ddec_big5(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {   // Big5, Shift_JIS, EUC-KR
     u32 i = 0, w = 0;
     for (;;) {
         if (i >= n) {
@@ -190,12 +227,14 @@ SXD DStep ddec_big5(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool la
         if (d.dlead == 0) {
             i++;
             if (b < 0x80) { dst[w++] = b; continue; }
-            if (b == 0x80 || b == 0xFF) return { RES_MALFORMED, i, w };
-            d.dlead = b;
+            if (two_byte_lead(d.enc, b)) { d.dlead = b; continue; }
+            const u32 c1 = two_byte_single(d.enc, b);
+            if (c1 == 0) return { RES_MALFORMED, i, w };
+            w += dput_cp(dst + w, c1);
             continue;
         }
         u32 second;
-        const u32 cp = big5_lookup(d.table, d.dlead, b, &second);
+        const u32 cp = two_byte_lookup(d.enc, d.table, d.dlead, b, &second);
         d.dlead = 0;
         if (cp) {
             i++;
@@ -272,15 +311,15 @@ SXD bool ddec_idle_any(const DDecoder& d) {
 // the byte after a byte outside the lead range always starts a token (WHATWG decoders: after a lead, any
 // byte returns to neutral; a byte outside the lead range never becomes pending).
 template <int ENC>
-SXD bool dbcs_is_lead_range(u8 b) {
-    if (ENC == 4) return b >= 0x81 && b <= 0xFE;
+SXD bool dbcs_is_lead_range(u8 b, int enc) {
+    if (ENC == 4) return two_byte_lead(enc, b);
     return b == 0x8E || b == 0x8F || (b >= 0xA1 && b <= 0xFE);
 }
 // length of the token that starts at s[0] when the decoder is neutral there (`avail` bytes are readable;
 // a token cut short by the end of the input reports the full length it would have)
 template <int ENC>
-SXD u32 dbcs_token_len(const u8* s, u64 avail) {
-    if (!dbcs_is_lead_range<ENC>(s[0])) return 1;
+SXD u32 dbcs_token_len(const u8* s, u64 avail, int enc) {
+    if (!dbcs_is_lead_range<ENC>(s[0], enc)) return 1;
     if (ENC == 5 && s[0] == 0x8F && avail >= 2 && s[1] >= 0xA1 && s[1] <= 0xFE) return 3;
     return 2;
 }
@@ -293,7 +332,7 @@ SXD u32 dbcs_entry_skip(const DDecoder& d, const u8* s, u64 avail) {
     const u8 b = s[0];
     if (ENC == 4) {
         u32 second;
-        return (big5_lookup(d.table, d.dlead, b, &second) || b >= 0x80) ? 1u : 0u;
+        return (two_byte_lookup(d.enc, d.table, d.dlead, b, &second) || b >= 0x80) ? 1u : 0u;
     }
     if (b < 0x80) return 0;  // EUC-JP trails are >= 0xA1: the token is malformed, the ASCII byte is given back
     if (d.dlead == 0x8F && !d.dflag && b >= 0xA1 && b <= 0xFE) return (avail >= 2 && s[1] >= 0x80) ? 2u : 1u;

@@ -11,7 +11,9 @@ namespace sx {
 #include "sx_tables.inc"
 
 static_assert(SX_BIG5_N == kBig5N && SX_BIG5_P2_WORDS == kBig5P2Words && SX_JIS_N == kJisN, "table layout");
-static_assert(SX_ENC_BIG5 == kEncBig5 && SX_ENC_EUC_JP == kEncEucJp, "encoding ids");
+static_assert(SX_ENC_BIG5 == kEncBig5 && SX_ENC_EUC_JP == kEncEucJp && SX_ENC_SHIFT_JIS == kEncShiftJis && SX_ENC_EUC_KR == kEncEucKr, "encoding ids");
+static_assert(SX_ENC_REPLACEMENT == kEncReplacement, "encoding ids");
+static_assert(SX_SJIS_N == kSjisN && SX_EUCKR_N == kEucKrN, "table layout");
 
 const uint16_t* single_byte_table(int enc) {
     if (enc >= SX_ENC_KOI8_R && enc < SX_ENC_KOI8_R + SX_N_SB_TABLES) return sx_sb_tables[enc - SX_ENC_KOI8_R];
@@ -23,6 +25,8 @@ const uint16_t* decoder_table(int enc, size_t* n_words) {
     const uint16_t* t = nullptr;
     if (enc == SX_ENC_BIG5) { t = sx_big5; n = sizeof sx_big5 / sizeof sx_big5[0]; }
     else if (enc == SX_ENC_EUC_JP) { t = sx_eucjp; n = sizeof sx_eucjp / sizeof sx_eucjp[0]; }
+    else if (enc == SX_ENC_SHIFT_JIS) { t = sx_sjis; n = sizeof sx_sjis / sizeof sx_sjis[0]; }
+    else if (enc == SX_ENC_EUC_KR) { t = sx_euckr; n = sizeof sx_euckr / sizeof sx_euckr[0]; }
     else if ((t = single_byte_table(enc)) != nullptr) n = 128;
     if (n_words) *n_words = n;
     return t;
@@ -30,7 +34,7 @@ const uint16_t* decoder_table(int enc, size_t* n_words) {
 
 bool encoding_is_known(int enc) {
     return enc == SX_ENC_X_USER_DEFINED || enc == SX_ENC_UTF8 || enc == SX_ENC_UTF16LE || enc == SX_ENC_UTF16BE
-           || decoder_table(enc, nullptr) != nullptr;
+           || enc == SX_ENC_REPLACEMENT || decoder_table(enc, nullptr) != nullptr;
 }
 
 const char* encoding_name(int enc) {
@@ -41,6 +45,9 @@ const char* encoding_name(int enc) {
     case SX_ENC_UTF16BE: return "UTF-16BE";
     case SX_ENC_BIG5: return "Big5";
     case SX_ENC_EUC_JP: return "EUC-JP";
+    case SX_ENC_SHIFT_JIS: return "Shift_JIS";
+    case SX_ENC_EUC_KR: return "EUC-KR";
+    case SX_ENC_REPLACEMENT: return "replacement";
     default:
         if (enc >= SX_ENC_KOI8_R && enc < SX_ENC_KOI8_R + SX_N_SB_TABLES) return sx_sb_names[enc - SX_ENC_KOI8_R];
         return "?";

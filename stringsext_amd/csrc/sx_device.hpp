@@ -38,7 +38,7 @@ enum ClassifierKind : uint32_t {
     kClsUtf8Range2 = 3,     // UTF-8, af = one range, ubf = one range of 2-byte leads: pure SWAR, no LUT
     kClsUtf16Range = 4,     // UTF-16, af = one range, ubf = one range below U+0800, no astral: pure SWAR
     kClsSingleByteRange = 5,// single byte, accept set = one range of bytes < 0x80 (+ all/none of >= 0x80)
-    kClsBig5 = 6,           // Big5: token classifier, 2-bit pair table (16 KB) in LDS
+    kClsBig5 = 6,           // Big5, Shift_JIS, EUC-KR: token classifier, 2-bit pair table (16 KB) in LDS
     kClsEucJp = 7,          // EUC-JP: the same with three-byte tokens and two pair tables (32 KB)
     kClsSingleByteRanges = 8 // single byte, accept set = up to 6 byte ranges: SWAR, no LUT
 };
@@ -66,6 +66,8 @@ struct ScanParams {
     uint32_t n_ranges;     // kClsSingleByteRanges: ranges in use (the others are empty); per range, replicated over the four bytes:
     uint32_t rng_c1[6], rng_c2[6], rng_hi[6];  // 0x80 - lo7, 0x7F - hi7, and 0 for a range of bytes >= 0x80 / ~0 for one below
     uint32_t wave_prio;    // 1: the scan wavefronts raise their issue priority (s_setprio)
+    uint32_t lr_c1[2], lr_c2[2];  // Big5 / Shift_JIS / EUC-KR: the lead byte ranges (low 7 bits; 0x80 - lo, 0x7F - hi, replicated)
+    uint32_t high1;        // Shift_JIS: bytes >= 0x80 outside the lead ranges can be characters (0x80, A1..DF): lut[] holds all 256
     uint32_t af_is_range;  // Big5 / EUC-JP: the accepted ASCII bytes are [a_lo,a_hi] (else lut[0..255] holds them: 0x80 / 0)
     const uint32_t* pair_lut;  // Big5 / EUC-JP: device, 2 bits per byte pair (index = the pair as a little-endian u16; EUC-JP: + 65536
                                // for the last two bytes of 8F xx xx): 0 unmapped, 1 mapped, 3 accepted, 2 accepted and two characters

@@ -221,14 +221,18 @@ const Label kLabels[] = {
     { "big5", SX_ENC_BIG5 }, { "big5-hkscs", SX_ENC_BIG5 }, { "cn-big5", SX_ENC_BIG5 }, { "csbig5", SX_ENC_BIG5 },
     { "x-x-big5", SX_ENC_BIG5 },
     { "cseucpkdfmtjapanese", SX_ENC_EUC_JP }, { "euc-jp", SX_ENC_EUC_JP }, { "x-euc-jp", SX_ENC_EUC_JP },
+    { "csshiftjis", SX_ENC_SHIFT_JIS }, { "ms932", SX_ENC_SHIFT_JIS }, { "ms_kanji", SX_ENC_SHIFT_JIS }, { "shift-jis", SX_ENC_SHIFT_JIS },
+    { "shift_jis", SX_ENC_SHIFT_JIS }, { "sjis", SX_ENC_SHIFT_JIS }, { "windows-31j", SX_ENC_SHIFT_JIS }, { "x-sjis", SX_ENC_SHIFT_JIS },
+    { "cseuckr", SX_ENC_EUC_KR }, { "csksc56011987", SX_ENC_EUC_KR }, { "euc-kr", SX_ENC_EUC_KR }, { "iso-ir-149", SX_ENC_EUC_KR },
+    { "korean", SX_ENC_EUC_KR }, { "ks_c_5601-1987", SX_ENC_EUC_KR }, { "ks_c_5601-1989", SX_ENC_EUC_KR }, { "ksc5601", SX_ENC_EUC_KR },
+    { "ksc_5601", SX_ENC_EUC_KR }, { "windows-949", SX_ENC_EUC_KR },
+    { "csiso2022kr", SX_ENC_REPLACEMENT }, { "hz-gb-2312", SX_ENC_REPLACEMENT }, { "iso-2022-cn", SX_ENC_REPLACEMENT },
+    { "iso-2022-cn-ext", SX_ENC_REPLACEMENT }, { "iso-2022-kr", SX_ENC_REPLACEMENT }, { "replacement", SX_ENC_REPLACEMENT },
 };
 // labels of the encodings encoding_rs has and this library does not (help.rs:54-96 lists their names)
 const char* const kOtherLabels[] = {
-    "shift_jis", "sjis",
-    "ms_kanji", "shift-jis", "windows-31j", "x-sjis", "csshiftjis", "ms932", "iso-2022-jp", "csiso2022jp", "euc-kr", "cseuckr",
-    "korean", "windows-949", "ks_c_5601-1987", "ksc5601", "ksc_5601", "iso-ir-149", "ks_c_5601-1989", "csksc56011987", "gbk",
-    "gb2312", "chinese", "csgb2312", "csiso58gb231280", "gb_2312", "gb_2312-80", "iso-ir-58", "x-gbk", "gb18030", "replacement",
-    "hz-gb-2312", "iso-2022-kr", "iso-2022-cn", "iso-2022-cn-ext",
+    "iso-2022-jp", "csiso2022jp", "gbk", "gb2312", "chinese", "csgb2312", "csiso58gb231280", "gb_2312", "gb_2312-80", "iso-ir-58",
+    "x-gbk", "gb18030",
 };
 int for_label(const std::string& raw) {
     size_t a = 0, b = raw.size();
@@ -285,6 +289,9 @@ const char* sx_encoding_name(uint32_t encoding) {  // Encoding::name()
         case SX_ENC_WINDOWS_1258: return "windows-1258";
         case SX_ENC_BIG5: return "Big5";
         case SX_ENC_EUC_JP: return "EUC-JP";
+        case SX_ENC_SHIFT_JIS: return "Shift_JIS";
+        case SX_ENC_EUC_KR: return "EUC-KR";
+        case SX_ENC_REPLACEMENT: return "replacement";
         case SX_ENC_X_MAC_CYRILLIC: return "x-mac-cyrillic";
         default: return nullptr;
     }
@@ -365,7 +372,8 @@ int sx_missions_from_flags(const sx_cli_flags* f, sx_mission* out, int cap, int*
         }
         if (enc == -2) {
             e.fail(scanner + "encoding `" + name + "` is known to the reference but not built into this library "
-                             "(UTF-8, UTF-16LE/BE, ascii, x-user-defined, the 28 single-byte encodings, Big5 and EUC-JP are).");
+                             "(UTF-8, UTF-16LE/BE, ascii, x-user-defined, the 28 single-byte encodings, Big5, EUC-JP, Shift_JIS, EUC-KR and replacement are; "
+                             "gb18030 / GBK and ISO-2022-JP are not).");
             return bail(SX_E_INVALID);
         }
         m.encoding = (uint8_t)enc;

@@ -53,7 +53,7 @@ struct Mission {
     size_t window = 128;    // decoder_input_window = 2*q, src/finding_collection.rs:120
     uint32_t long_run = 4;  // min(chars_min_nb, q): fewer chars can never yield a Finding
     bool is_utf16() const { return c.encoding == SX_ENC_UTF16LE || c.encoding == SX_ENC_UTF16BE; }
-    bool is_dbcs() const { return c.encoding == SX_ENC_BIG5 || c.encoding == SX_ENC_EUC_JP; }
+    bool is_dbcs() const { return c.encoding >= SX_ENC_BIG5 && c.encoding <= SX_ENC_EUC_KR; }   // a pending lead byte is the decoder state
     const char* encoding_name() const;
 
     // device classifier for this mission

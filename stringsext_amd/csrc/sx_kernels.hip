@@ -899,7 +899,10 @@ SX_DEV u32 swar_eq(u32 v, u32 pat) {  // bytes equal to pat's bytes
     return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y);
 }
 
-template <int ENC, bool AF_RANGE>
+// ENC 4: the two-byte encodings (Big5, Shift_JIS, EUC-KR: lead ranges and pair table are parameters), 5: EUC-JP.
+// AF_RANGE: the accepted ASCII bytes are one range (else a 256-entry LUT in LDS).  HIGH1: bytes >= 0x80 outside the
+// lead range can be characters too (Shift_JIS: 0x80, A1..DF) — they come from the LUT.
+template <int ENC, bool AF_RANGE, bool HIGH1 = false>
 __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) u32 lds_tab[];
     using TR = DbcsTraits<ENC>;
@@ -909,6 +912,7 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
         u32x4* dst = (u32x4*)lds_tab;
         for (u32 i = threadIdx.x; i < TR::kTableWords / 4; i += 256) dst[i] = src[i];
         if (!AF_RANGE) ((u8*)(lds_tab + TR::kTableWords))[threadIdx.x] = p.lut[threadIdx.x];
+        static_assert(!HIGH1 || !AF_RANGE, "single bytes >= 0x80 are looked up");
         __syncthreads();
     }
     const u8* aflut = (const u8*)(lds_tab + TR::kTableWords);
@@ -923,9 +927,10 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
     em.begin_region(wave);
 
     // byte classes of one dword: flags at bit 7 of every byte
+    const u32 lr1a = p.lr_c1[0], lr2a = p.lr_c2[0], lr1b = p.lr_c1[1], lr2b = p.lr_c2[1];
     auto cls_lr = [&](u32 v) -> u32 {
         const u32 t = v & 0x7F7F7F7Fu;
-        if (ENC == 4) return v & (t + 0x7F7F7F7Fu) & ~(t + 0x01010101u) & kM;              // 81..FE
+        if (ENC == 4) return (swar_range(t, lr1a, lr2a) | swar_range(t, lr1b, lr2b)) & v & kM;   // Big5 / EUC-KR 81..FE; Shift_JIS 81..9F, E0..FC
         return ((swar_range(t, rep4(0x80u - 0x21u), rep4(0x7Fu - 0x7Eu)) & v) | swar_eq(v & 0xFEFEFEFEu, 0x8E8E8E8Eu)) & kM;  // A1..FE, 8E, 8F
     };
 
@@ -977,20 +982,22 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
         const u32 xs[5] = { cur.x, cur.y, cur.z, cur.w, nx };
 
         // ---- 1. byte classes (bits 0..15 own bytes, 16..19 the next lane's first four)
-        u32 fl[5], fa[5], fh[5], f8[5];
+        u32 fl[5], fa[5], fh[5], f8[5], fx[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const u32 v = xs[k], t7 = v & 0x7F7F7F7Fu;
             fl[k] = cls_lr(v);
             if (AF_RANGE) fa[k] = swar_range(t7, a1, a2) & ~v & kM;
             else fa[k] = (aflut[v & 0xFF] | (aflut[(v >> 8) & 0xFF] << 8) | (aflut[(v >> 16) & 0xFF] << 16) | (aflut[v >> 24] << 24)) & kM;
+            if (HIGH1) fx[k] = fa[k] & ~v;   // the ASCII ones among them
             if (ENC == 5) {
                 fh[k] = swar_range(t7, rep4(0x80u - 0x21u), rep4(0x7Fu - 0x7Eu)) & v & kM;
                 f8[k] = swar_eq(v, 0x8F8F8F8Fu) & kM;
             }
         }
         const u32 LR = (movemask16(fl[0], fl[1], fl[2], fl[3]) | (movemask4(fl[4]) << 16)) & valid;
-        const u32 asc = (movemask16(fa[0], fa[1], fa[2], fa[3]) | (movemask4(fa[4]) << 16)) & valid;
+        const u32 asc = (movemask16(fa[0], fa[1], fa[2], fa[3]) | (movemask4(fa[4]) << 16)) & valid;   // accepted one-byte characters
+        const u32 asc7 = HIGH1 ? (movemask16(fx[0], fx[1], fx[2], fx[3]) | (movemask4(fx[4]) << 16)) & valid : asc;   // ... that are ASCII
         u32 L3 = 0;
         if (ENC == 5) {
             const u32 H = movemask16(fh[0], fh[1], fh[2], fh[3]) | (movemask4(fh[4]) << 16);
@@ -1068,7 +1075,7 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
         }
         A &= P; Mp &= P; Dbl &= P0;
         const u32 A0 = A & P0, A1 = A & P1;
-        const u32 bad_last = (((P0 & ~Mp) << 1) | ((P1 & ~Mp) << 1)) & asc;  // malformed token, last byte ASCII: its own character
+        const u32 bad_last = (((P0 & ~Mp) << 1) | ((P1 & ~Mp) << 1)) & asc7;  // malformed token, last byte ASCII: its own character
         const u32 S1 = S0 & ~LR & asc;                                         // one-byte tokens
         // ---- 5. good / start masks (bits 16.. spill onto the next lane's first bytes)
         const u32 g = S1 | A0 | (A0 << 1) | (A1 >> 1) | A1 | (A1 << 1) | bad_last;
@@ -1134,7 +1141,8 @@ static hipError_t launch_dbcs(const ScanParams& p, hipStream_t stream) {
     ScanParams q = p;
     q.persistent = 0;
     const size_t lds = DbcsTraits<ENC>::kTableWords * 4 + 256;
-    if (p.af_is_range) hipLaunchKernelGGL((scan_kernel_dbcs<ENC, true>), dim3((unsigned)blocks), dim3(256), lds, stream, q);
+    if (ENC == 4 && p.high1) hipLaunchKernelGGL((scan_kernel_dbcs<ENC == 4 ? 4 : ENC, false, ENC == 4>), dim3((unsigned)blocks), dim3(256), lds, stream, q);
+    else if (p.af_is_range) hipLaunchKernelGGL((scan_kernel_dbcs<ENC, true>), dim3((unsigned)blocks), dim3(256), lds, stream, q);
     else hipLaunchKernelGGL((scan_kernel_dbcs<ENC, false>), dim3((unsigned)blocks), dim3(256), lds, stream, q);
     return hipGetLastError();
 }

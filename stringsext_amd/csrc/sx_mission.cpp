@@ -116,14 +116,35 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
                 H[hb] = v;
             }
         }
+    } else if (enc == SX_ENC_REPLACEMENT) {
+        // the replacement decoder emits nothing but one error: no byte is ever part of a character
+        m->kind = kClsSingleByteRange;
+        p.a_lo = 1; p.a_hi = 0; p.high_all = 0;
     } else if (m->is_dbcs()) {
         // Token classifier: accepted ASCII as a range (or a 256-entry LUT), and per byte pair a 2-bit code
         // (sx_device.hpp ScanParams::pair_lut) from the decoder's own lookup + the filter on the UTF-8 lead byte.
-        m->kind = enc == SX_ENC_BIG5 ? kClsBig5 : kClsEucJp;
-        p.af_is_range = (!force_generic && af_is_range) ? 1u : 0u;
+        const bool two_byte = enc_family((uint32_t)enc) == 4;
+        m->kind = two_byte ? kClsBig5 : kClsEucJp;
+        for (int b = 0; b < 256; b++) p.lut[b] = 0;
         for (int b = 0; b < 128; b++) p.lut[b] = af[b] ? 0x80 : 0;
+        // lead byte ranges (two-byte family) and the single bytes >= 0x80 that are characters (Shift_JIS)
+        const uint32_t lr[2][2] = { { enc == SX_ENC_SHIFT_JIS ? 0x81u : 0x81u, enc == SX_ENC_SHIFT_JIS ? 0x9Fu : 0xFEu },
+                                    { enc == SX_ENC_SHIFT_JIS ? 0xE0u : 1u, enc == SX_ENC_SHIFT_JIS ? 0xFCu : 0u } };
+        for (int r = 0; r < 2; r++) {
+            const bool empty = lr[r][0] > lr[r][1];
+            p.lr_c1[r] = (0x80u - (empty ? 1u : (lr[r][0] & 0x7F))) * 0x01010101u;
+            p.lr_c2[r] = (0x7Fu - (empty ? 0u : (lr[r][1] & 0x7F))) * 0x01010101u;
+        }
+        p.high1 = 0;
+        if (two_byte)
+            for (int b = 0x80; b < 256; b++) {
+                if (two_byte_lead(enc, (uint8_t)b)) continue;
+                const uint32_t cp = two_byte_single(enc, (uint8_t)b);
+                if (cp) { p.high1 = 1; if (m->filter.pass_lead(utf8_lead_of(cp))) p.lut[b] = 0x80; }
+            }
+        p.af_is_range = (!force_generic && af_is_range && !p.high1) ? 1u : 0u;
         const uint16_t* t = decoder_table(enc, nullptr);
-        const size_t n_tables = enc == SX_ENC_BIG5 ? 1 : 2;
+        const size_t n_tables = two_byte ? 1 : 2;
         m->pair_lut.assign(n_tables * 4096, 0u);
         auto put = [&](size_t table, uint32_t b0, uint32_t b1, uint32_t code) {
             const uint32_t idx = b0 | (b1 << 8);
@@ -131,11 +152,12 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
         };
         for (uint32_t b0 = 0x81; b0 <= 0xFE; b0++)
             for (uint32_t b1 = 0; b1 < 256; b1++) {
-                if (enc == SX_ENC_BIG5) {
+                if (two_byte) {
+                    if (!two_byte_lead(enc, (uint8_t)b0)) continue;
                     uint32_t second = 0;
-                    const uint32_t cp = big5_lookup(t, b0, b1, &second);
+                    const uint32_t cp = two_byte_lookup(enc, t, b0, b1, &second);
                     if (!cp) continue;
-                    // two characters (pointers 1133..1166): a break between them cannot be expressed per byte, so the
+                    // two characters (Big5 pointers 1133..1166): a break between them cannot be expressed per byte, so the
                     // pair counts as accepted when either passes — a superset of the true runs (stage B is exact)
                     const bool ok = m->filter.pass_lead(utf8_lead_of(cp)) || (second && m->filter.pass_lead(utf8_lead_of(second)));
                     put(0, b0, b1, ok ? (second ? 2u : 3u) : 1u);

@@ -198,8 +198,9 @@ private:
     // over a ByteView): from the nearest byte outside the lead range in front of lim — the decoder is neutral right
     // after it — or from the buffer start, where the token pending on entry ends after Mission::buf_entry_skip bytes.
     uint64_t dbcs_sync(uint64_t B, uint64_t lim) {
-        const bool big5 = m_.c.encoding == SX_ENC_BIG5;
-        auto lead_range = [&](uint8_t b) { return big5 ? dbcs_is_lead_range<4>(b) : dbcs_is_lead_range<5>(b); };
+        const int enc = m_.c.encoding;
+        const bool big5 = enc_family((uint32_t)enc) == 4;   // the two-byte family
+        auto lead_range = [&](uint8_t b) { return big5 ? dbcs_is_lead_range<4>(b, enc) : dbcs_is_lead_range<5>(b, enc); };
         uint64_t r = lim;
         while (r > 0) {
             const size_t n = (size_t)std::min<uint64_t>(r, 64);
@@ -213,7 +214,7 @@ private:
         while (r < lim) {
             const size_t n = (size_t)std::min<uint64_t>(len_ - r, 3);
             const uint8_t* s = bytes_.span(r, n, &hint_);
-            r += big5 ? dbcs_token_len<4>(s, n) : dbcs_token_len<5>(s, n);
+            r += big5 ? dbcs_token_len<4>(s, n, enc) : dbcs_token_len<5>(s, n, enc);
         }
         return r < B ? r : B;
     }

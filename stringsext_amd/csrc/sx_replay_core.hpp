@@ -209,7 +209,7 @@ SXD u32 char_len_at(const ReplayParams& P, u64 rs) {
     if (ENC == 1) return b[0] < 0x80 ? 1u : b[0] < 0xE0 ? 2u : b[0] < 0xF0 ? 3u : 4u;
     if (ENC == 2) return (b[1] & 0xFC) == 0xD8 ? 4u : 2u;
     if (ENC == 3) return (b[0] & 0xFC) == 0xD8 ? 4u : 2u;
-    if (ENC == 4 || ENC == 5) return dbcs_token_len<(ENC == 4 || ENC == 5) ? ENC : 4>(b, P.len - rs);
+    if (ENC == 4 || ENC == 5) return dbcs_token_len<(ENC == 4 || ENC == 5) ? ENC : 4>(b, P.len - rs, (int)P.encoding);
     return 1;
 }
 
@@ -263,11 +263,11 @@ SXD u32 derive_in_run(u32 q, u32 encoding, const uint16_t* table, const u8* from
 // buffer start after `skip0` bytes that finish the token pending on entry), jumping token by token from there.
 // The walk back is as long as the stretch of lead-range bytes in front of lim.
 template <int ENC>
-SXD u64 dbcs_sync_before(const u8* bytes, u64 len, u64 at, u64 floor, u32 skip0, u64 lim) {
+SXD u64 dbcs_sync_before(const u8* bytes, u64 len, u64 at, u64 floor, u32 skip0, u64 lim, int enc) {
     u64 r = lim;
-    while (r > floor && dbcs_is_lead_range<ENC>(bytes[r - 1])) r--;
+    while (r > floor && dbcs_is_lead_range<ENC>(bytes[r - 1], enc)) r--;
     if (r == floor) r += skip0;
-    while (r < lim) r += dbcs_token_len<ENC>(bytes + r, len - r);
+    while (r < lim) r += dbcs_token_len<ENC>(bytes + r, len - r, enc);
     return r < at ? r : at;
 }
 
@@ -287,7 +287,7 @@ SXD_NOINLINE u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& d
     if ((ENC == 2 || ENC == 3) && ((P.stream0 + p) & 1)) p = p ? p - 1 : p + 1;
     if (p < floor) p = floor;
     if (p > at) p = at;
-    if (ENC == 4 || ENC == 5) p = dbcs_sync_before<ENC>(bytes, P.len, at, floor, floor == 0 ? P.entry_skip : 0u, p);
+    if (ENC == 4 || ENC == 5) p = dbcs_sync_before<ENC>(bytes, P.len, at, floor, floor == 0 ? P.entry_skip : 0u, p, (int)P.encoding);
     u8 sink[40], last[4], mb[4];
     u32 last_len = 0, mb_len = 0;
     while (p < at) {   // in pieces: the sink is small

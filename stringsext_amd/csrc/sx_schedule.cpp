@@ -227,9 +227,10 @@ int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
         for (const Mission& m : ctx->missions) any = any || m.is_dbcs();
         if (any) {
             const uint64_t front = own_lo - buf_off;
-            bool found[2] = { false, false };  // Big5, EUC-JP
+            std::vector<char> found(nm, 0);   // per mission: a byte outside ITS lead range seen
             std::vector<uint8_t> tmp;
-            for (uint64_t at = 0; at < front && !(found[0] && found[1]); at += 65536) {
+            auto all_found = [&]() { for (size_t k = 0; k < nm; k++) if (ctx->missions[k].is_dbcs() && !found[k]) return false; return true; };
+            for (uint64_t at = 0; at < front && !all_found(); at += 65536) {
                 const uint64_t n = std::min<uint64_t>(65536, front - at);
                 const uint8_t* s = host_bytes ? host_bytes + at : nullptr;
                 if (!s) {
@@ -237,17 +238,20 @@ int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
                     HIP_TRY(ctx, hipMemcpy(tmp.data(), d_bytes + at, n, hipMemcpyDeviceToHost));
                     s = tmp.data();
                 }
-                for (uint64_t i = 0; i < n && !(found[0] && found[1]); i++) {
-                    if (!dbcs_is_lead_range<4>(s[i])) found[0] = true;
-                    if (!dbcs_is_lead_range<5>(s[i])) found[1] = true;
+                for (size_t k = 0; k < nm; k++) {
+                    const Mission& m = ctx->missions[k];
+                    if (!m.is_dbcs() || found[k]) continue;
+                    const int enc = m.c.encoding;
+                    const bool two = enc_family((uint32_t)enc) == 4;
+                    for (uint64_t i = 0; i < n; i++)
+                        if (!(two ? dbcs_is_lead_range<4>(s[i], enc) : dbcs_is_lead_range<5>(s[i], enc))) { found[k] = 1; break; }
                 }
             }
-            for (const Mission& m : ctx->missions)
-                if (m.is_dbcs() && !found[m.c.encoding == SX_ENC_BIG5 ? 0 : 1]) {
-                    ctx->err = "no byte outside the lead range between the buffer start and own_lo: the token grid of a Big5 / EUC-JP "
-                               "mission is unknown there; repeat with a larger halo in front";
-                    return SX_E_HALO;
-                }
+            if (!all_found()) {
+                ctx->err = "no byte outside the lead range between the buffer start and own_lo: the token grid of a double-byte "
+                           "mission is unknown there; repeat with a larger halo in front";
+                return SX_E_HALO;
+            }
         }
     }
     if (given_runs) {

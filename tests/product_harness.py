@@ -8,7 +8,8 @@ import sxo_binding as sxo
 def dbcs_hangover(enc, before, chunk):
     """Double-byte encodings (64 Big5, 65 EUC-JP): how many bytes at the start of `chunk` finish a token that began
     in `before` (the bytes of the stream in front of it) — what the product derives from its carried decoder."""
-    lead = (lambda b: 0x81 <= b <= 0xFE) if enc == 64 else (lambda b: b in (0x8E, 0x8F) or 0xA1 <= b <= 0xFE)
+    lead = {64: lambda b: 0x81 <= b <= 0xFE, 65: lambda b: b in (0x8E, 0x8F) or 0xA1 <= b <= 0xFE,
+            66: lambda b: 0x81 <= b <= 0x9F or 0xE0 <= b <= 0xFC, 67: lambda b: 0x81 <= b <= 0xFE}[enc]
     data = before + chunk[:3]
     r = len(before)
     while r > 0 and lead(data[r - 1]):
@@ -29,7 +30,7 @@ def dbcs_hangover(enc, before, chunk):
 
 
 def _dbcs_valid(enc, tok):
-    codec = "big5hkscs" if enc == 64 else "euc_jp"
+    codec = {64: "big5hkscs", 65: "euc_jp", 66: "cp932", 67: "cp949"}[enc]
     try:
         bytes(tok).decode(codec)
         return True
@@ -42,7 +43,7 @@ def oracle_runs_for_chunk(mdicts, chunk, stream_bytes, before=b""):
     out = []
     for m in mdicts:
         long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
-        if m["encoding"] in (64, 65):
+        if m["encoding"] in (64, 65, 66, 67):
             skip = dbcs_hangover(m["encoding"], before, chunk)
             out.append([(a + skip, b + skip, c) for a, b, c in sxo.runs(m, chunk[skip:], min_chars=long_run)])
         else:

@@ -9,7 +9,7 @@ import pytest
 import refconfig as rc
 import sxo_binding as sxo
 from product_harness import run_cli_product
-from test_dbcs import ALL, CODEC, DBCS_FLAGS, TEXT, soup
+from test_dbcs import ALL, CODEC, DBCS_FLAGS, ENCS, TEXT, soup
 from test_gpu_parity import device_runs
 
 pytestmark = pytest.mark.gpu
@@ -24,7 +24,7 @@ RUNS = {
 }
 
 
-@pytest.mark.parametrize("enc", ["big5", "euc-jp"])
+@pytest.mark.parametrize("enc", ENCS)
 @pytest.mark.parametrize("name", sorted(RUNS))
 def test_device_runs_equal_oracle_runs(enc, name):
     m = rc.missions(encodings=[enc], **RUNS[name])[0]
@@ -34,7 +34,8 @@ def test_device_runs_equal_oracle_runs(enc, name):
         soup(enc, rng, 300_000),
         rng.randbytes(1 << 20),
         txt * 300,                                        # no byte outside the lead range for kilobytes
-        b"\xa4" * 5000 + b"A" + b"\xa4" * 5001 + b"\n" + txt * 40,   # long stretches of one lead-range byte, both parities
+        (b"\x88" if enc == "shift_jis" else b"\xa4") * 5000 + b"A" + (b"\x88" if enc == "shift_jis" else b"\xa4") * 5001 + b"\n" + txt * 40,   # long stretches of one lead byte, both parities
+        b"\xb1\xdf\x80" * 3000 + b"\xa0\xfd" * 100 + txt * 5,        # Shift_JIS: one-byte characters >= 0x80
         b"\x8f\xb0\xa1" * 3000 + b"\x8f" * 3001 + txt * 10 + b"\x8e\xb1" * 2000,
         txt[:1023], txt[:1025], txt[1:18], b"abcdefghijkl", b"", b"\xa4", b"\xa4\x40",
         b"A" * 5000 + rng.randbytes(3000) + txt * 7 + b"\x00" * 100 + b"zz" * 3000,
@@ -49,7 +50,7 @@ def test_device_runs_equal_oracle_runs(enc, name):
                                  next(((a, b) for a, b in zip(got, want) if a != b), None))
 
 
-@pytest.mark.parametrize("enc", ["big5", "euc-jp"])
+@pytest.mark.parametrize("enc", ENCS)
 @pytest.mark.parametrize("flags", DBCS_FLAGS, ids=lambda f: "n" + f["chars_min"] + "-" + f["unicode_block_filter"])
 def test_end_to_end_equals_oracle(enc, flags):
     rng = random.Random(zlib.crc32((enc + "gpu" + repr(sorted(flags.items()))).encode()))

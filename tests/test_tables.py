@@ -66,7 +66,12 @@ def test_oracle_and_product_tables_agree_cell_by_cell():
     for k, (oa, pa) in enumerate(((o["sxo_jis0208"], p["sx_eucjp"][:j]), (o["sxo_jis0212"], p["sx_eucjp"][j:]))):
         assert len(oa) == j and len(pa) == j
         diffs += [f"jis02{'08' if k == 0 else '12'} {_jis_cell(i)}: oracle U+{a:04X} product U+{b:04X}" for i, (a, b) in enumerate(zip(oa, pa)) if a != b]
+    for name, oa, pa in (("Shift_JIS pointer", o["sxo_sjis"], p["sx_sjis"]), ("EUC-KR pointer", o["sxo_euckr"], p["sx_euckr"])):
+        assert len(oa) == len(pa)
+        diffs += [f"{name} {i}: oracle U+{a:04X} product U+{b:04X}" for i, (a, b) in enumerate(zip(oa, pa)) if a != b]
     assert not diffs, "\n".join(diffs[:50])
+    assert sum(1 for v in p["sx_sjis"] if v) == 7724 and sum(1 for v in p["sx_euckr"] if v) == 17048
+    assert all(v == 0 for v in p["sx_sjis"][8836:10716])       # the user-defined range is a rule of the decoder, not table data
     # sizes of what is mapped, and a few cells whose value is a decision (see the generators' headers)
     assert sum(1 for v in pb5 if v) == 18405 and sum(1 for v in o["sxo_jis0208"] if v) == 7336 and sum(1 for v in o["sxo_jis0212"] if v) == 6067
     big5 = lambda lead, trail: pb5[(lead - 0x81) * 157 + (trail - (0x40 if trail < 0x7F else 0x62))]
@@ -162,6 +167,39 @@ def _raw_report():
         if cps != ([raw[idx]] if raw[idx] else None):
             lines.append(f"{tag} {k[-4:].upper()}: ICU {fmt(cps)} | CPython {fmt([raw[idx]] if raw[idx] else None)} -> taken {fmt([final[idx]] if final[idx] else None)}")
     lines.append(f"EUC-JP: {dropped} user-defined cells ICU maps to the private use area, unmapped in CPython and in the tables")
+    # Shift_JIS: two-byte cells
+    n_diff = 0
+    for line in open(os.path.join(tab, "icu_shift_jis.txt")):
+        k, v = line.split()
+        key = int(k, 16)
+        if p.cps("cp932", [key >> 8, key & 0xFF]) != [int(x, 16) for x in v.split("+")]:
+            n_diff += 1
+            lines.append(f"Shift_JIS {k.upper()}: ICU {v} | CPython cp932 {fmt(p.cps('cp932', [key >> 8, key & 0xFF]))}")
+    lines.append(f"Shift_JIS: {n_diff} two-byte cells differ between ICU and CPython cp932; the single byte 0x80 is an error in ICU and U+0080 in "
+                 "CPython and in the WHATWG decoder (taken: U+0080, in the decoders)")
+    # EUC-KR
+    icu_kr = {}
+    for line in open(os.path.join(tab, "icu_euc_kr.txt")):
+        k, v = line.split()
+        icu_kr[int(k, 16)] = int(v, 16)
+    pua = sum(1 for v in icu_kr.values() if 0xE000 <= v <= 0xF8FF)
+    both = differ = single = 0
+    for lead in range(0x81, 0xFF):
+        for trail in range(0x41, 0xFF):
+            key = lead << 8 | trail
+            c = p.cps("cp949", [lead, trail])
+            c = c[0] if c and len(c) == 1 and c[0] >= 0x80 else 0
+            a = icu_kr.get(key, 0)
+            a = 0 if 0xE000 <= a <= 0xF8FF else a
+            if a and c:
+                both += 1
+                if a != c:
+                    differ += 1
+                    lines.append(f"EUC-KR {key:04X}: ICU U+{a:04X} | CPython cp949 U+{c:04X} -> taken U+{fin['sx_euckr'][(lead - 0x81) * 190 + trail - 0x41]:04X}")
+            elif c:
+                single += 1
+    lines.append(f"EUC-KR: {both} cells in both sources ({differ} differ), {single} cells only CPython cp949 has (the UHC extension: single "
+                 f"source), {pua} user-defined cells ICU maps to the private use area (not in the tables)")
     return "\n".join(lines) + "\n"
 
 
