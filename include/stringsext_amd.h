@@ -19,10 +19,12 @@
  * Conventions: plain pointers and sizes only; every function returns 0 on
  * success or a negative SX_E_* code, with text from sx_last_error(); the
  * caller owns inputs, the library owns sx_result until sx_result_free(); a
- * context is bound to ONE HIP device and is not thread-safe; internally one
- * HIP stream per Mission (the reference's one thread per Mission,
- * src/main.rs:97,151).  There is no CPU fallback: without a HIP device
- * sx_create() fails with SX_E_NO_DEVICE.
+ * context is bound to ONE HIP device and is not thread-safe; internally the
+ * Missions' scan kernels queue up in one HIP stream and everything after them
+ * (records -> runs, the exact replay, copies) runs in a second one
+ * (SX_OPT_MISSION_STREAMS: a scan stream per Mission, the reference's one
+ * thread per Mission, src/main.rs:97,151).  There is no CPU fallback: without
+ * a HIP device sx_create() fails with SX_E_NO_DEVICE.
  */
 #ifndef STRINGSEXT_AMD_H
 #define STRINGSEXT_AMD_H
@@ -100,7 +102,10 @@ typedef struct sx_finding {
 } sx_finding;
 
 /* Device run record: one maximal stretch of bytes belonging to valid,
- * filter-accepted characters (ignoring -g / -r), with its character count. */
+ * filter-accepted characters (ignoring -g / -r), with its character count.
+ * (Inside the library a run that crosses window starts may travel as several pieces, one per window: a piece
+ * that begins at a window start has bit 63 of `chars` set and, in the low bits, its distance from the run's start.
+ * sx_device_runs never returns pieces; sx_replay_runs accepts them.) */
 typedef struct sx_run {
     uint64_t start;                      /* byte offset of the first byte, chunk relative */
     uint64_t end;                        /* one past the last byte */
