@@ -333,7 +333,9 @@ int sx_scan_shard(sx_ctx* ctx, const uint8_t* bytes, uint64_t buf_off, uint64_t 
     begin_call(ctx);
     if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!(reuse_runs && ctx->shard_runs_valid)) {
+    // (sx_scan_shard uploads into the context's own staging buffer: the runs of the previous call belong to the same
+    //  host bytes only if offset, length and pointer agree — shard_common checks that again on its side)
+    if (!(reuse_runs && ctx->shard_runs_valid && ctx->shard_runs_off == buf_off && ctx->shard_runs_len == buf_len && ctx->shard_runs_ptr == (const void*)ctx->d_input)) {
         if (buf_len > ctx->d_input_cap) {
             if (ctx->d_input) HIP_TRY(ctx, hipFree(ctx->d_input));
             ctx->d_input = nullptr; ctx->d_input_cap = 0;

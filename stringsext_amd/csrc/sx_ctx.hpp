@@ -128,6 +128,9 @@ struct sx_ctx {
     std::vector<uint64_t> last_runs;  // long runs per mission of the last scanned buffer: busiest mission scans first
     std::vector<sx::RunList> shard_runs;  // device runs of the last sx_scan_shard* buffer (reuse_runs)
     bool shard_runs_valid = false;
+    // ... of which buffer: reuse_runs only counts for the very same one (ADVICE, round 1)
+    uint64_t shard_runs_off = 0, shard_runs_len = 0;
+    const void* shard_runs_ptr = nullptr;
     uint8_t* h_pin = nullptr;   uint64_t h_pin_cap = 0;
     uint8_t* h_pin2 = nullptr;  uint64_t h_pin2_cap = 0;   // device replay traffic (h_pin may back a live byte view)
     uint8_t* d_scratch = nullptr; uint64_t d_scratch_cap = 0;

@@ -610,27 +610,58 @@ void merge_findings(std::vector<MissionFindings>& per, const std::shared_ptr<Pin
         if (nonempty == 1) { out->segs.push_back(std::move(per[which])); per[which].ext = {}; }
         return;
     }
-    out->segs.emplace_back();
-    MissionFindings& m = out->segs.back();
+    // One segment normally.  str_off is 32 bits: when the Missions' strings together exceed 4 GiB the findings go out as
+    // several segments (in print order, each with its own arena), cut where the running string size would pass 4 GiB
+    // (ADVICE, round 1: the offsets used to wrap silently).
     size_t total = 0, bytes = 0;
     for (auto& mf : per) { total += mf.count(); bytes += mf.strings_len(); }
-    m.v.reserve(total);
-    m.arena.reserve(bytes);
-    std::vector<size_t> idx(per.size(), 0), base(per.size(), 0);
-    for (size_t k = 0; k < per.size(); k++) { base[k] = m.arena.size(); m.arena.append(per[k].strings(), per[k].strings_len()); }
-    for (;;) {
-        int best = -1;
-        for (size_t k = 0; k < per.size(); k++) {
-            if (idx[k] >= per[k].count()) continue;
-            if (best < 0) { best = (int)k; continue; }
-            const sx_finding& a = per[k].data()[idx[k]];
-            const sx_finding& b = per[best].data()[idx[best]];
-            if (a.slice_index < b.slice_index || (a.slice_index == b.slice_index && a.position < b.position)) best = (int)k;
+    std::vector<size_t> idx(per.size(), 0);
+    if (bytes <= 0xFFFFFFF0ull) {   // the usual case: the arenas are copied whole, the offsets rebased
+        out->segs.emplace_back();
+        MissionFindings& m = out->segs.back();
+        m.v.reserve(total);
+        m.arena.reserve(bytes);
+        std::vector<size_t> base(per.size(), 0);
+        for (size_t k = 0; k < per.size(); k++) { base[k] = m.arena.size(); m.arena.append(per[k].strings(), per[k].strings_len()); }
+        for (;;) {
+            int best = -1;
+            for (size_t k = 0; k < per.size(); k++) {
+                if (idx[k] >= per[k].count()) continue;
+                if (best < 0) { best = (int)k; continue; }
+                const sx_finding& a = per[k].data()[idx[k]];
+                const sx_finding& b = per[best].data()[idx[best]];
+                if (a.slice_index < b.slice_index || (a.slice_index == b.slice_index && a.position < b.position)) best = (int)k;
+            }
+            if (best < 0) break;
+            sx_finding f = per[best].data()[idx[best]++];
+            f.str_off += (uint32_t)base[best];
+            m.v.push_back(f);
         }
-        if (best < 0) break;
-        sx_finding f = per[best].data()[idx[best]++];
-        f.str_off += (uint32_t)base[best];
-        m.v.push_back(f);
+        total = 0;   // done
+    }
+    size_t done = 0;
+    while (done < total) {
+        out->segs.emplace_back();
+        MissionFindings& m = out->segs.back();
+        m.v.reserve(std::min<size_t>(total - done, 1u << 24));
+        for (;;) {
+            int best = -1;
+            for (size_t k = 0; k < per.size(); k++) {
+                if (idx[k] >= per[k].count()) continue;
+                if (best < 0) { best = (int)k; continue; }
+                const sx_finding& a = per[k].data()[idx[k]];
+                const sx_finding& b = per[best].data()[idx[best]];
+                if (a.slice_index < b.slice_index || (a.slice_index == b.slice_index && a.position < b.position)) best = (int)k;
+            }
+            if (best < 0) break;
+            const sx_finding& src = per[best].data()[idx[best]];
+            if (m.arena.size() + src.str_len > 0xFFFFFFF0ull) break;   // next segment
+            sx_finding f = src;
+            f.str_off = (uint32_t)m.arena.size();
+            m.arena.append(per[best].strings() + src.str_off, src.str_len);
+            m.v.push_back(f);
+            idx[best]++; done++;
+        }
     }
     for (auto& mf : per) release(mf);
 }

@@ -152,6 +152,7 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
                        int is_last, sx_result** out, uint32_t slice_base0, sx_result* append_to) {
     const double t_begin = now_ms();
     const size_t nm = ctx->missions.size();
+    ctx->shard_runs_valid = false;   // the run lists a shard call left behind are about to be overwritten
     std::vector<uint64_t> stream0(nm);
     for (size_t k = 0; k < nm; k++) stream0[k] = ctx->states[k].stream_bytes;
     std::vector<int> order;
@@ -258,7 +259,11 @@ int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
         ctx->shard_runs.assign(nm, RunList{});
         for (size_t k = 0; k < nm; k++) ctx->shard_runs[k].assign(given_runs[k], given_runs[k] + given_n[k]);
     }
-    const bool scan_now = !given_runs && !(reuse_runs && ctx->shard_runs_valid);
+    // the runs of the last shard call may be reused for the same buffer only; runs the caller supplied are never "scanned" ones
+    const void* buf_id = d_bytes ? (const void*)d_bytes : (const void*)host_bytes;
+    const bool same_buffer = ctx->shard_runs_valid && ctx->shard_runs_off == buf_off && ctx->shard_runs_len == buf_len && ctx->shard_runs_ptr == buf_id;
+    const bool scan_now = !given_runs && !(reuse_runs && same_buffer);
+    if (given_runs || scan_now) ctx->shard_runs_valid = false;
     BufferScan b;
     {   // only the shard that starts the file knows the state at its byte 0 (the context's carried state)
         int rc = set_entry_params(ctx, buf_off == 0, host_bytes, d_bytes, buf_len, file_stream_off + buf_off, &b.parity);
@@ -294,13 +299,11 @@ int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
         ctx->shard_runs_valid = false;
         rc = b.finish_and_replay(ctx, job, nullptr, &ctx->shard_runs, &res.r->r, ends.data());
         if (rc != SX_OK) return sync_streams_and_return(ctx, rc);
-        ctx->shard_runs_valid = true;
+        ctx->shard_runs_valid = true; ctx->shard_runs_off = buf_off; ctx->shard_runs_len = buf_len; ctx->shard_runs_ptr = buf_id;
     } else if (host_bytes) {
-        ctx->shard_runs_valid = true;
         HostBytes view(host_bytes);
         rc = replay_all(ctx, view, job, ctx->shard_runs, &res.r->r, ends.data());
     } else {
-        ctx->shard_runs_valid = true;
         SparseDeviceBytes view(ctx, d_bytes);
         rc = download_for_replay(ctx, d_bytes, buf_len, &ctx->shard_runs, &view, job);
         if (rc != SX_OK) return rc;
