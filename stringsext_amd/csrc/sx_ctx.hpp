@@ -51,13 +51,28 @@ struct RunList {
         issued = true;
         return e;
     }
+    // Only the first and last `edge` runs (what the host's share of a device replay reads: the buffer's entry region
+    // and its exit state) — the middle of p[] stays unwritten.  full() says whether everything is there.
+    mutable bool complete = false;
+    bool full() const { return !dev_src || !copy_bytes || complete; }
+    hipError_t fetch_edges(size_t edge) const {
+        if (full() || issued) return wait();
+        if (n <= 2 * edge) return wait();
+        hipError_t e = hipMemcpyAsync(const_cast<sx_run*>(p), dev_src, edge * sizeof(sx_run), hipMemcpyDeviceToHost, copy_stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(const_cast<sx_run*>(p) + (n - edge), (const sx_run*)dev_src + (n - edge), edge * sizeof(sx_run),
+                               hipMemcpyDeviceToHost, copy_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(copy_stream);
+        return e;
+    }
     // the list's contents are on the host from here on (its size always is)
     hipError_t wait() const {
         hipError_t e = start_copy();
         if (e == hipSuccess && dev_src && copy_bytes) e = hipEventSynchronize(ready);
+        if (e == hipSuccess) complete = true;
         return e;
     }
-    void use_own() { p = own.data(); n = own.size(); on_device = false; dev_src = nullptr; copy_bytes = 0; }
+    void use_own() { p = own.data(); n = own.size(); on_device = false; dev_src = nullptr; copy_bytes = 0; complete = true; }
     void assign(const sx_run* b, const sx_run* e) { own.assign(b, e); use_own(); }
     const sx_run* data() const { return p; }
     size_t size() const { return n; }
@@ -110,6 +125,8 @@ struct sx_ctx {
     std::string err;
     sx_stats stats{};
     hipStream_t scan_stream = nullptr, post_stream = nullptr;
+    hipStream_t merge_copy_stream = nullptr;   // device_merge: the copy of one part next to the sort of the following one
+    hipEvent_t merge_ev[3] = { nullptr, nullptr, nullptr };
     unsigned n_cus = 256, scan_blocks_per_cu = 8;
     // sx_scan_stream: two pinned host buffers and two device buffers, filled by a reader thread
     hipStream_t copy_stream = nullptr;
@@ -242,7 +259,7 @@ struct PreReplayed {
 
 bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs);
 int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, const RunList& runs,
-                          MissionFindings* out, uint64_t* end_pos);
+                          MissionFindings* out, uint64_t* end_pos, uint64_t defer_min_bytes);
 int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::vector<RunList>& runs,
                Result* into, uint64_t* end_pos, PreReplayed* pre = nullptr);
 ReplayJob whole_chunk_job(sx_ctx* ctx, uint64_t len, int file_id, bool is_last);

@@ -132,7 +132,7 @@ inline uint32_t stitch_block_runs(uint64_t n_runs) {
     if (const char* e = getenv("SX_STITCH_BLOCK")) { const int v = atoi(e); if (v > 0) return (uint32_t)v; }  // tests
     return n_runs > (4ull << 20) ? 512u : 128u;
 }
-enum : uint32_t { kTotEnd = 0, kTotLast, kTotFindings, kTotBytes, kTotStanding, kTotReplayBytes, kTotTooLong, kTotCount };
+enum : uint32_t { kTotEnd = 0, kTotLast, kTotFindings, kTotBytes, kTotStanding, kTotReplayBytes, kTotTooLong, kTotLastStart, kTotCount };
 size_t stitch_scratch_bytes(uint64_t n_runs);
 size_t stitch_blocks_bytes(uint64_t n_runs);
 hipError_t launch_stitch_blocks(const ReplayParams& P, const ReplayRegionOut* ro, uint8_t* stands, void* blocks,
@@ -142,9 +142,14 @@ hipError_t launch_stitch_finish(const ReplayParams& P, const ReplayRegionOut* ro
                                 size_t scratch_bytes, hipStream_t stream);
 hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegionOut* ro, const uint8_t* stands,
                                        const uint64_t* fpos, const uint64_t* apos, sx_finding* findings,
-                                       uint8_t* arena, hipStream_t stream);
+                                       uint8_t* arena, uint64_t avg_out_bytes, hipStream_t stream);
 
 // interleave several missions' findings on the device (sx_sort.hip); every src and out = [findings][string bytes]
+hipError_t merge_findings_device_part(const sx_finding* const* f, const uint8_t* const* a, const uint64_t* nf, const uint64_t* nb,
+                                      const uint32_t* off0, int n_missions, void* out, void* scratch, size_t scratch_bytes,
+                                      hipStream_t stream);
+hipError_t launch_merge_cuts(const sx_finding* f, uint64_t n, uint64_t nb, const uint64_t* cuts, uint32_t n_cuts, uint64_t* idx,
+                             uint64_t* off, hipStream_t stream);
 size_t merge_findings_scratch_bytes(uint64_t n_findings);
 hipError_t merge_findings_device(const void* const* srcs, const uint64_t* nf, const uint64_t* nb, int n_missions, void* out,
                                  void* scratch, size_t scratch_bytes, hipStream_t stream);

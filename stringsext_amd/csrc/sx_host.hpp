@@ -187,10 +187,13 @@ struct MissionFindings {
     // ... and, until the next scan of the mission, also still on the device (same layout):
     // several missions' findings are interleaved there instead of on the host
     const void* dev_copy = nullptr;
-    size_t count() const { return ext.p ? ext_nf : v.size(); }
+    // dev_only: the copy to the host was put off (several missions are interleaved on the device first); ext_nf / ext_na
+    // count what dev_copy holds, data() / strings() are not valid until it is fetched
+    bool dev_only = false;
+    size_t count() const { return (ext.p || dev_only) ? ext_nf : v.size(); }
     const sx_finding* data() const { return ext.p ? (const sx_finding*)ext.p : v.data(); }
     const char* strings() const { return ext.p ? (const char*)ext.p + ext_nf * sizeof(sx_finding) : arena.data(); }
-    size_t strings_len() const { return ext.p ? ext_na : arena.size(); }
+    size_t strings_len() const { return (ext.p || dev_only) ? ext_na : arena.size(); }
 };
 
 // Exact replay of FindingCollection::from over the windows that matter.

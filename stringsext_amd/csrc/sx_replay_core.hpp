@@ -334,6 +334,21 @@ SXD void stage_window(const u8* src, u32 n, u8* win) {
     for (; k < n; k++) win[k] = src[k];
 }
 
+// the same for a destination that is only 4-aligned (an LDS row, sx_replay_dev.hip win_row_bytes)
+SXD void stage_window_words(const u8* src, u32 n, u8* win) {
+    u32 k = 0;
+    if (((uintptr_t)src & 15) == 0) {
+        for (; k + 16 <= n; k += 16) {
+            const uint4 v = *(const uint4*)(src + k);
+            u32* w = (u32*)(win + k);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        }
+    } else if (((uintptr_t)src & 3) == 0) {
+        for (; k + 4 <= n; k += 4) *(u32*)(win + k) = *(const u32*)(src + k);
+    }
+    for (; k < n; k++) win[k] = src[k];
+}
+
 // One region.  MODE 0: count only; 1: write findings and strings at fout/aout; 2: count, and
 // keep the output in the region's small cache slot (fout/aout) as long as it fits — o.pad says
 // whether it did, so that the second pass is a copy for almost every region.
@@ -354,15 +369,18 @@ SXD CacheGeom cache_geom(u64 arena_bytes, u64 n_heads) {
     g.cap_b = g.slot_bytes - g.cap_f * (u32)sizeof(sx_finding);
     return g;
 }
-template <int MODE, int ENC>
+// EXT_WIN: the window's staging copy lies where the caller says (the kernels: a row in LDS) instead of
+// in a private array.
+template <int MODE, int ENC, bool EXT_WIN = false>
 SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_finding* fout, u8* aout, u64 abase,
-                       u32 cap_f = 0, u32 cap_b = 0) {
+                       u32 cap_f = 0, u32 cap_b = 0, u8* win_ext = nullptr) {
     const u8* bytes = P.data;
     const u64 len = P.len;
     const u32 W = P.W;
     const u64 want = win_start(P.runs[i].start, W);
     u8 ob[kObCap];
-    alignas(16) u8 win[kMaxWindow];
+    alignas(16) u8 win_own[EXT_WIN ? 16 : kMaxWindow];
+    u8* const win = EXT_WIN ? win_ext : win_own;
     u64 staged = ~0ull;
     DDecoder dec;
 
@@ -448,7 +466,8 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
                 // the window's bytes go through a private copy made with 16-byte loads: the decoders read byte
                 // by byte, and a byte load per lane from 64 different cache lines is the slowest way to read
                 if (staged != soff + wb) {
-                    stage_window(bytes + soff + wb, dend - wb, win);
+                    if (EXT_WIN) stage_window_words(bytes + soff + wb, dend - wb, win);
+                    else stage_window(bytes + soff + wb, dend - wb, win);
                     staged = soff + wb;
                 }
                 const DStep r = ddecode<ENC>(dec, win + (din - wb), dend - din, ob + dout, kObCap - dout, false);

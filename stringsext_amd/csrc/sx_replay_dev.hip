@@ -65,28 +65,40 @@ __global__ __launch_bounds__(256) void replay_heads_list_kernel(const ReplayPara
 }
 __global__ void replay_heads_total_kernel(const u32* head_last, const u32* slot_last, u32* n_heads) { *n_heads = *slot_last + *head_last; }
 
-template <int ENC, bool CACHED>
+template <int ENC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WAVES))) void replay_count_kernel(
     const ReplayParams P, ReplayRegionOut* out) {
-    u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
-    if (CACHED) {  // one lane per replaying run (on dense input half of the runs are chained: no idle lanes)
-        if (i >= *P.n_heads) return;
-        i = P.head_list[i];
-    } else if (i >= P.n_runs) return;
+    const u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
+    if (i >= P.n_runs) return;
     ReplayRegionOut o;
     o.end = 0; o.n_find = 0; o.n_bytes = 0; o.status = kRegionOk; o.pad = 0;
     const u64 want = win_start(P.runs[i].start, P.W);
-    if (CACHED) {
-        // slots have a minimum size: with more replaying regions than the arena has room for, the ones
-        // behind its end go without (cap 0: nothing fits, o.pad stays 0, pass 2 replays them)
-        const CacheGeom g = cache_geom(P.arena_bytes, *P.n_heads);
-        const u64 off = (u64)P.slot_of[i] * g.slot_bytes;
-        const bool room = off + g.slot_bytes <= P.arena_bytes;
-        u8* slot = P.cache_arena + (room ? off : 0);
-        replay_region<2, ENC>(P, i, o, (sx_finding*)slot, slot + g.cap_f * sizeof(sx_finding), 0, room ? g.cap_f : 0u, room ? g.cap_b : 0u);
-    } else if (want < P.lo || want >= P.hi) o.status = kRegionNotMine;
+    if (want < P.lo || want >= P.hi) o.status = kRegionNotMine;
     else if (region_is_chained(P, i, want)) o.status = kRegionChained;
     else replay_region<0, ENC>(P, i, o, nullptr, nullptr, 0);
+    out[i] = o;
+}
+// Pass 1 with the output cache: one lane per replaying run (on dense input half of the runs are chained: no idle lanes).
+// The window's staging copy lies in LDS, one row per lane (win_row_bytes: an odd number of dwords, the rows start in
+// different banks) — as a private array it is scratch memory, and the scratch of all resident waves is far larger than L2.
+__host__ __device__ inline u32 win_row_bytes(u32 W) { return (((W + 3) / 4) | 1u) * 4; }
+template <int ENC, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void replay_count_cached_kernel(
+    const ReplayParams P, ReplayRegionOut* out) {
+    extern __shared__ __align__(16) u8 lds_win[];
+    u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
+    if (i >= *P.n_heads) return;
+    i = P.head_list[i];
+    ReplayRegionOut o;
+    o.end = 0; o.n_find = 0; o.n_bytes = 0; o.status = kRegionOk; o.pad = 0;
+    // slots have a minimum size: with more replaying regions than the arena has room for, the ones
+    // behind its end go without (cap 0: nothing fits, o.pad stays 0, pass 2 replays them)
+    const CacheGeom g = cache_geom(P.arena_bytes, *P.n_heads);
+    const u64 off = (u64)P.slot_of[i] * g.slot_bytes;
+    const bool room = off + g.slot_bytes <= P.arena_bytes;
+    u8* slot = P.cache_arena + (room ? off : 0);
+    replay_region<2, ENC, true>(P, i, o, (sx_finding*)slot, slot + g.cap_f * sizeof(sx_finding), 0, room ? g.cap_f : 0u, room ? g.cap_b : 0u,
+                                lds_win + threadIdx.x * win_row_bytes(P.W));
     out[i] = o;
 }
 
@@ -101,7 +113,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WA
 }
 
 // Pass 2, flagged form: one lane per run; the standing regions (stitch below) write at the
-// offsets the device scans assigned.
+// offsets the device scans assigned.  A region whose output pass 1 kept in its cache slot is left to
+// replay_copy_cached_kernel below; the others are replayed once more by their lane.
 template <int ENC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WAVES))) void replay_write_flagged_kernel(
     const ReplayParams P, const ReplayRegionOut* ro, const u8* stands, const u64* fpos, const u64* apos, sx_finding* findings,
@@ -112,23 +125,95 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WA
         i = P.head_list[i];
     } else if (i >= P.n_runs) return;
     if (!stands[i]) return;
+    if (P.cache_arena && ro[i].pad) return;
     const u64 fp = fpos[i], ap = apos[i];
-    if (P.cache_arena && ro[i].pad) {  // pass 1 kept the region's output: copy it into place
-        const CacheGeom g = cache_geom(P.arena_bytes, *P.n_heads);
-        const u8* slot = P.cache_arena + (u64)P.slot_of[i] * g.slot_bytes;
-        const sx_finding* cf = (const sx_finding*)slot;
-        const u32 nf = ro[i].n_find, nb = ro[i].n_bytes;
-        for (u32 j = 0; j < nf; j++) {
-            sx_finding f = cf[j];
-            f.str_off += (u32)ap + P.str_off_base;
-            findings[fp + j] = f;
-        }
-        const u8* src = slot + g.cap_f * sizeof(sx_finding);
-        for (u32 t = 0; t < nb; t++) arena[ap + t] = src[t];
-        return;
-    }
     ReplayRegionOut o;
     replay_region<1, ENC>(P, i, o, findings + fp, arena + ap, ap + P.str_off_base);
+}
+
+// The cached outputs go into place: G lanes per region (4, 16 or 64, by the average output size), 64 / G regions of a wave
+// at a time — coalesced within a region (a lane of its own would copy byte by byte into 64 different lines per
+// instruction), and no decoder in the kernel, so that many waves are resident.  A finding is two uint4 (str_off at offset 8
+// of the first); the strings go as dwords aligned to the DESTINATION, each built from two source dwords, the up to three
+// bytes on either side singly.
+template <int G, int U>
+__global__ __launch_bounds__(64) void replay_copy_cached_kernel(const ReplayParams P, const ReplayRegionOut* ro, const u8* stands,
+                                                                const u64* fpos, const u64* apos, sx_finding* findings, u8* arena) {
+    const u32 lane = threadIdx.x;
+    u64 i = (u64)blockIdx.x * 64 + lane;
+    bool mine;
+    if (P.head_list) {
+        mine = i < *P.n_heads;
+        if (mine) i = P.head_list[i];
+    } else mine = i < P.n_runs;
+    u64 fp = 0, ap = 0;
+    u32 nf = 0, nb = 0, slot_no = 0;
+    if (mine && stands[i] && ro[i].pad) { fp = fpos[i]; ap = apos[i]; nf = ro[i].n_find; nb = ro[i].n_bytes; slot_no = P.slot_of[i]; }
+    if (!__ballot(nf | nb)) return;
+    const CacheGeom g = cache_geom(P.arena_bytes, *P.n_heads);
+    const u32 bytes_at = g.cap_f * (u32)sizeof(sx_finding);
+    const u32 sub = lane % G, group = lane / G;
+#pragma unroll 1
+    for (u32 it = 0; it < G; it += U) {
+        // U regions per group at a time, all their loads first (the first G uint4 of findings and G dwords of strings
+        // of each: what most regions have), then the stores; what is left of large regions follows in plain loops
+        const u8* slot[U];
+        u64 rfp[U], rap[U];
+        u32 rnf[U], rnb[U], head[U], body[U], lo[U], hi[U];
+        uint4 fv[U];
+        u8 hb[U], tb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int r = (int)((it + u) * (64 / G) + group);   // the region this group copies: lane r's
+            rnf[u] = __shfl(nf, r); rnb[u] = __shfl(nb, r);
+            rfp[u] = __shfl(fp, r); rap[u] = __shfl(ap, r);
+            slot[u] = P.cache_arena + (u64)__shfl(slot_no, r) * g.slot_bytes;
+            fv[u] = sub < 2 * rnf[u] ? ((const uint4*)slot[u])[sub] : uint4{ 0, 0, 0, 0 };
+            const u8* src = slot[u] + bytes_at;   // 16-aligned
+            head[u] = (u32)((4 - ((uintptr_t)(arena + rap[u]) & 3)) & 3);
+            if (head[u] > rnb[u]) head[u] = rnb[u];
+            body[u] = (rnb[u] - head[u]) >> 2;
+            const u32* sw = (const u32*)src;   // the dword that holds src[head] (head < 4)
+            lo[u] = sub < body[u] ? sw[sub] : 0;
+            hi[u] = sub < body[u] && head[u] ? sw[sub + 1] : 0;   // (slots lie inside the arena: one dword on is readable)
+            hb[u] = sub < head[u] ? src[sub] : (u8)0;
+            const u32 tail = (rnb[u] - head[u]) & 3;
+            tb[u] = sub < tail ? src[head[u] + body[u] * 4 + sub] : (u8)0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u32 add = (u32)rap[u] + P.str_off_base;
+            uint4* of = (uint4*)(findings + rfp[u]);
+            u8* dst = arena + rap[u];
+            u32* d = (u32*)(dst + head[u]);
+            if (sub < 2 * rnf[u]) {
+                uint4 v = fv[u];
+                if (!(sub & 1)) v.z += add;
+                of[sub] = v;
+            }
+            if (sub < head[u]) dst[sub] = hb[u];
+            if (sub < body[u]) d[sub] = head[u] ? __builtin_amdgcn_alignbyte(hi[u], lo[u], head[u]) : lo[u];
+            const u32 tail = (rnb[u] - head[u]) & 3;
+            if (sub < tail) dst[head[u] + body[u] * 4 + sub] = tb[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u32 add = (u32)rap[u] + P.str_off_base;
+            const uint4* cf = (const uint4*)slot[u];
+            uint4* of = (uint4*)(findings + rfp[u]);
+            for (u32 t = sub + G; t < 2 * rnf[u]; t += G) {
+                uint4 v = cf[t];
+                if (!(t & 1)) v.z += add;
+                of[t] = v;
+            }
+            const u32* sw = (const u32*)(slot[u] + bytes_at);
+            u32* d = (u32*)(arena + rap[u] + head[u]);
+            for (u32 k = sub + G; k < body[u]; k += G) {
+                const u32 l = sw[k];
+                d[k] = head[u] ? __builtin_amdgcn_alignbyte(sw[k + 1], l, head[u]) : l;
+            }
+        }
+    }
 }
 
 // ---- long runs cut into pieces at the window starts they cross (sx_replay_core.hpp kPieceCont) ----------
@@ -271,7 +356,10 @@ __global__ __launch_bounds__(64) void stitch_chain_kernel(const ReplayParams P, 
             cur = v + 1;
         }
     }
-    if (lane == 0) { totals[kTotEnd] = E; totals[kTotLast] = last; }
+    if (lane == 0) {
+        totals[kTotEnd] = E; totals[kTotLast] = last;
+        totals[kTotLastStart] = last == ~0ull ? 0ull : win_start(P.runs[last].start, P.W);   // (the host need not hold the run list for it)
+    }
 }
 
 struct StandingFindings {
@@ -349,7 +437,7 @@ hipError_t launch_stitch_finish(const ReplayParams& P, const ReplayRegionOut* ro
 }
 hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegionOut* ro, const uint8_t* stands,
                                        const uint64_t* fpos, const uint64_t* apos, sx_finding* findings,
-                                       uint8_t* arena, hipStream_t stream) {
+                                       uint8_t* arena, uint64_t avg_out_bytes, hipStream_t stream) {
     if (P.n_runs == 0) return hipSuccess;
     const dim3 grid((unsigned)((P.n_runs + 63) / 64));
     switch (enc_family(P.encoding)) {
@@ -359,6 +447,11 @@ hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegion
         case 4: hipLaunchKernelGGL(replay_write_flagged_kernel<4>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
         case 5: hipLaunchKernelGGL(replay_write_flagged_kernel<5>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
         default: hipLaunchKernelGGL(replay_write_flagged_kernel<0>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
+    }
+    if (P.cache_arena) {
+        if (avg_out_bytes <= 96) hipLaunchKernelGGL((replay_copy_cached_kernel<4, 2>), grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena);
+        else if (avg_out_bytes <= 640) hipLaunchKernelGGL((replay_copy_cached_kernel<32, 4>), grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena);
+        else hipLaunchKernelGGL((replay_copy_cached_kernel<64, 4>), grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena);
     }
     return hipGetLastError();
 }
@@ -386,10 +479,14 @@ hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, hipS
     if (P.n_runs == 0) return hipSuccess;
     const dim3 grid((unsigned)((P.n_runs + 63) / 64));
     const bool cache = P.cache_arena != nullptr;
-#define SX_LAUNCH_COUNT(E)                                                                                 \
-    do {                                                                                                   \
-        if (cache) hipLaunchKernelGGL((replay_count_kernel<E, true>), grid, dim3(64), 0, stream, P, out);   \
-        else hipLaunchKernelGGL((replay_count_kernel<E, false>), grid, dim3(64), 0, stream, P, out);        \
+    const unsigned lds = 64u * win_row_bytes(P.W);
+    static const int waves = [] { const char* e = getenv("SX_COUNT_WAVES"); return e ? atoi(e) : 4; }();
+#define SX_LAUNCH_COUNT(E)                                                                                              \
+    do {                                                                                                                \
+        if (!cache) hipLaunchKernelGGL((replay_count_kernel<E>), grid, dim3(64), 0, stream, P, out);                     \
+        else if (waves >= 8) hipLaunchKernelGGL((replay_count_cached_kernel<E, 8>), grid, dim3(64), lds, stream, P, out); \
+        else if (waves >= 6) hipLaunchKernelGGL((replay_count_cached_kernel<E, 6>), grid, dim3(64), lds, stream, P, out); \
+        else hipLaunchKernelGGL((replay_count_cached_kernel<E, 4>), grid, dim3(64), lds, stream, P, out);                 \
     } while (0)
     switch (enc_family(P.encoding)) {
         case 1: SX_LAUNCH_COUNT(1); break;

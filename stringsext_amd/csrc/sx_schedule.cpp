@@ -126,7 +126,10 @@ struct BufferScan {
             ctx->last_runs[k] = (*runs)[k].size();
             if (oi + 1 == nm && after_last_finish && (rc = after_last_finish()) != SX_OK) return rc;
             if (device_replay_wanted(ctx, job, k, (*runs)[k].size())) {
-                rc = device_replay_mission(ctx, k, early_view, job, (*runs)[k], &pre.per[k], &pre.ends[k]);
+                // (with several missions a large output stays on the device: replay_all interleaves them there, one copy instead of two)
+                uint64_t defer = nm >= 2 ? (256ull << 20) : 0;
+                if (const char* e = getenv("SX_DEFER_MIN_BYTES")) defer = nm >= 2 ? (uint64_t)atoll(e) : 0;
+                rc = device_replay_mission(ctx, k, early_view, job, (*runs)[k], &pre.per[k], &pre.ends[k], defer);
                 if (rc != SX_OK) return rc;
                 pre.done[k] = 1;
             }

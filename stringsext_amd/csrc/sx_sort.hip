@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void merge_gather_in_kernel(const sx_finding* 
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     sx_finding f = src[i];
-    f.str_off += arena_base;
+    f.str_off += arena_base;   // (mod 2^32: a part's base may be "negative", see merge_findings_device_part)
     all[out_base + i] = f;
     keys[out_base + i] = f.position;
     vals[out_base + i] = out_base + i;
@@ -259,9 +259,11 @@ size_t merge_findings_scratch_bytes(uint64_t n) {
     (void)rocprim::radix_sort_pairs(nullptr, tmp, nul, nul, nul, nul, (size_t)n, 0, 64, (hipStream_t)0);
     return n * sizeof(sx_finding) + 4 * n * 8 + tmp + 2048;
 }
-// srcs[m] = mission m's [nf[m] findings][nb[m] string bytes] on the device; out = [sum nf findings][sum nb bytes]
-hipError_t merge_findings_device(const void* const* srcs, const uint64_t* nf, const uint64_t* nb, int n_missions, void* out,
-                                 void* scratch, size_t scratch_bytes, hipStream_t stream) {
+// One part of the interleave: of mission m the findings f[m][0 .. nf[m]) whose strings are a[m][0 .. nb[m]) and whose str_off
+// count from off0[m] (the part's first string); out = [sum nf findings][sum nb bytes].
+hipError_t merge_findings_device_part(const sx_finding* const* f, const uint8_t* const* a, const uint64_t* nf, const uint64_t* nb,
+                                      const uint32_t* off0, int n_missions, void* out, void* scratch, size_t scratch_bytes,
+                                      hipStream_t stream) {
     uint64_t n = 0;
     for (int m = 0; m < n_missions; m++) n += nf[m];
     if (n == 0) return hipSuccess;
@@ -279,10 +281,9 @@ hipError_t merge_findings_device(const void* const* srcs, const uint64_t* nf, co
     uint64_t fb = 0, ab = 0;
     for (int m = 0; m < n_missions; m++) {
         if (nf[m]) {
-            const sx_finding* sf = (const sx_finding*)srcs[m];
-            hipLaunchKernelGGL(merge_gather_in_kernel, dim3((unsigned)((nf[m] + 255) / 256)), dim3(256), 0, stream, sf, nf[m], (uint32_t)ab,
-                               fb, all, k0, v0);
-            hipError_t e = hipMemcpyAsync(out_a + ab, (const uint8_t*)srcs[m] + nf[m] * sizeof(sx_finding), nb[m], hipMemcpyDeviceToDevice, stream);
+            hipLaunchKernelGGL(merge_gather_in_kernel, dim3((unsigned)((nf[m] + 255) / 256)), dim3(256), 0, stream, f[m], nf[m],
+                               (uint32_t)ab - off0[m], fb, all, k0, v0);
+            hipError_t e = hipMemcpyAsync(out_a + ab, a[m], nb[m], hipMemcpyDeviceToDevice, stream);
             if (e != hipSuccess) return e;
         }
         fb += nf[m]; ab += nb[m];
@@ -290,6 +291,42 @@ hipError_t merge_findings_device(const void* const* srcs, const uint64_t* nf, co
     hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, (size_t)n, 0, 64, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_gather_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, all, v1, n, out_f);
+    return hipGetLastError();
+}
+// srcs[m] = mission m's [nf[m] findings][nb[m] string bytes] on the device; out = [sum nf findings][sum nb bytes]
+hipError_t merge_findings_device(const void* const* srcs, const uint64_t* nf, const uint64_t* nb, int n_missions, void* out,
+                                 void* scratch, size_t scratch_bytes, hipStream_t stream) {
+    const sx_finding* f[256];
+    const uint8_t* a[256];
+    uint32_t off0[256];
+    if (n_missions > 256) return hipErrorInvalidValue;
+    for (int m = 0; m < n_missions; m++) {
+        f[m] = (const sx_finding*)srcs[m];
+        a[m] = (const uint8_t*)srcs[m] + nf[m] * sizeof(sx_finding);
+        off0[m] = 0;
+    }
+    return merge_findings_device_part(f, a, nf, nb, off0, n_missions, out, scratch, scratch_bytes, stream);
+}
+
+// Where a mission's findings (ordered by position, strings laid out in the same order) are cut at the given positions:
+// idx[j] = the first finding at or behind cuts[j], off[j] = where its string begins (= the bytes of all strings before it).
+__global__ __launch_bounds__(64) void merge_cuts_kernel(const sx_finding* f, uint64_t n, uint64_t nb, const uint64_t* cuts, uint32_t n_cuts,
+                                                        uint64_t* idx, uint64_t* off) {
+    const uint32_t j = blockIdx.x * 64u + threadIdx.x;
+    if (j >= n_cuts) return;
+    const uint64_t c = cuts[j];
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (f[mid].position < c) lo = mid + 1; else hi = mid;
+    }
+    idx[j] = lo;
+    off[j] = lo < n ? f[lo].str_off : nb;
+}
+hipError_t launch_merge_cuts(const sx_finding* f, uint64_t n, uint64_t nb, const uint64_t* cuts, uint32_t n_cuts, uint64_t* idx,
+                             uint64_t* off, hipStream_t stream) {
+    if (n_cuts == 0) return hipSuccess;
+    hipLaunchKernelGGL(merge_cuts_kernel, dim3((n_cuts + 63) / 64), dim3(64), 0, stream, f, n, nb, cuts, n_cuts, idx, off);
     return hipGetLastError();
 }
 

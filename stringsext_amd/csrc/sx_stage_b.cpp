@@ -28,7 +28,7 @@ bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, siz
 // Stage B of one mission on the device (sx_replay_dev.hip) + the little the host keeps:
 // the chunk's strict entry region, regions the device gave back, the exact exit state.
 int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, const RunList& runs,
-                          MissionFindings* out, uint64_t* end_pos) {
+                          MissionFindings* out, uint64_t* end_pos, uint64_t defer_min_bytes) {
     const Mission& m = ctx->missions[k];
     MissionDev& d = ctx->dev[k];
     const size_t n = runs.size();
@@ -83,7 +83,10 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
                                              ctx->d_scratch_cap, d.stream_b));
         }
         HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], d.stream_b));
-        HIP_TRY(ctx, runs.start_copy());  // the host's copy of a device-joined run list travels while pass 1 runs
+        // The host's copy of a device-joined run list: its share of this replay (the buffer's entry region, the exit state)
+        // reads only the list's two ends — a large list is not copied whole (68 MB for the headline's 2.8 M runs, 1.2 ms on
+        // the critical path when nothing else runs); the rest follows on demand (regions the device gives back).
+        if (runs.size() * sizeof(sx_run) <= (4u << 20)) HIP_TRY(ctx, runs.start_copy());
         if (dev_stitch) {
             HIP_TRY(ctx, hipMemsetAsync(d.d_rp[7], 0, kTotCount * 8, d.stream_b));
             HIP_TRY(ctx, launch_stitch_blocks(P, (const ReplayRegionOut*)d.d_rp[1], (uint8_t*)d.d_rp[2], d.d_rp[6],
@@ -93,7 +96,10 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     }
 
     // ---- meanwhile on the host: the strict entry region (exact carried state), if any
-    HIP_TRY(ctx, runs.wait());
+    constexpr size_t kEdgeRuns = 8192;
+    if (dev_stitch) HIP_TRY(ctx, runs.fetch_edges(kEdgeRuns)); else HIP_TRY(ctx, runs.wait());   // (the host's stitch walks the whole list)
+    // the part of the list the host may read without the whole copy: [0, kEdgeRuns) and [n - kEdgeRuns, n)
+    const size_t head_n = runs.full() ? n : kEdgeRuns;
     std::deque<ReplayPart> host_parts;
     struct Seg { int host_part; size_t v0, v1; };  // host_part >= 0, or device regions [v0, v1) of `valid`
     std::vector<Seg> segs;
@@ -104,8 +110,15 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         // The chunk's first window belongs to the host: only it has the exact carried state
         // (leftover, cut flag, and the decoder's pending bytes, which cannot be re-derived here).
         host_parts.emplace_back();
-        replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(), n,
+        replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(), head_n,
                     job.lo[k], job.lo[k] + 1, true, &host_parts.back());
+        if (head_n < n && host_parts.back().end_pos >= runs[head_n - 1].start) {   // it ran into what was not copied: the whole list
+            HIP_TRY(ctx, runs.wait());
+            host_parts.pop_back();
+            host_parts.emplace_back();
+            replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(), n,
+                        job.lo[k], job.lo[k] + 1, true, &host_parts.back());
+        }
         if (host_parts.back().regions.empty()) host_parts.pop_back();
         else { segs.push_back({ (int)host_parts.size() - 1, 0, 0 }); last_is_entry = true; E = std::max(E, host_parts.back().end_pos); }
         E = std::max(E, job.lo[k] + 1);
@@ -119,6 +132,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     if (n) HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
     if (dev_stitch && h_tot[kTotTooLong]) {  // regions for the host: it also decides what stands
         dev_stitch = false;
+        HIP_TRY(ctx, runs.wait());
         HIP_TRY(ctx, hipMemcpyAsync(ro, d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream_b));
         HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
     }
@@ -131,7 +145,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         out->replay_bytes += h_tot[kTotReplayBytes];
         if (h_tot[kTotLast] != ~0ull) {
             E = std::max(E, h_tot[kTotEnd]);
-            last_start = win_start_h(runs[(size_t)h_tot[kTotLast]].start, W);
+            last_start = h_tot[kTotLastStart];
             last_is_entry = false;
         }
     } else {
@@ -171,18 +185,29 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     // its str_off already shifted by that part's strings.  Only regions the device gave back to the host
     // (somewhere in the middle) need the finding-by-finding splice.
     PinnedPool::Block blk{};
+    bool deferred = false;
+    std::vector<sx_finding> entry_f;
     const bool entry_only = dev_stitch && host_parts.size() == 1 && true;
     const MissionFindings* hf0 = entry_only ? &host_parts[0].findings : nullptr;
     const uint64_t nfh = hf0 ? hf0->v.size() : 0, nbh = hf0 ? hf0->arena.size() : 0;
     if (nb + nbh > 0xFFFFFFFFull) { ctx->err = "more than 4 GiB of strings in one chunk"; return SX_E_NOMEM; }
     if (n_standing) {
-        int rc = ensure_rp(ctx, d, 5, nf * sizeof(sx_finding) + nb + 64); if (rc) return rc;
-        sx_finding* d_f = (sx_finding*)d.d_rp[5];
-        uint8_t* d_a = (uint8_t*)d.d_rp[5] + nf * sizeof(sx_finding);
+        // the device buffer has the block's layout: [host findings][device findings][host strings][device strings]
+        int rc = ensure_rp(ctx, d, 5, (nfh + nf) * sizeof(sx_finding) + nbh + nb + 64); if (rc) return rc;
+        uint8_t* d_all = (uint8_t*)d.d_rp[5];
+        sx_finding* d_f = (sx_finding*)d_all + nfh;
+        uint8_t* d_a = d_all + (nfh + nf) * sizeof(sx_finding) + nbh;
         if (dev_stitch) {
             P.str_off_base = (uint32_t)nbh;
             HIP_TRY(ctx, launch_replay_write_flagged(P, (const ReplayRegionOut*)d.d_rp[1], (const uint8_t*)d.d_rp[2],
-                                                     (const uint64_t*)d.d_rp[3], (const uint64_t*)d.d_rp[4], d_f, d_a, d.stream_b));
+                                                     (const uint64_t*)d.d_rp[3], (const uint64_t*)d.d_rp[4], d_f, d_a,
+                                                     (nf * sizeof(sx_finding) + nb) / std::max<uint64_t>(1, n_standing), d.stream_b));
+            if (nfh) {   // the host's entry part joins it there (a few findings): the missions can be interleaved on the device
+                entry_f.assign(hf0->v.begin(), hf0->v.end());
+                for (sx_finding& f : entry_f) f.slice_index += job.slice_base;
+                HIP_TRY(ctx, hipMemcpyAsync(d_all, entry_f.data(), nfh * sizeof(sx_finding), hipMemcpyHostToDevice, d.stream_b));
+                if (nbh) HIP_TRY(ctx, hipMemcpyAsync(d_all + (nfh + nf) * sizeof(sx_finding), hf0->arena.data(), nbh, hipMemcpyHostToDevice, d.stream_b));
+            }
         } else {
             const size_t nv = valid.size();
             HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[2], valid.data(), nv * 8, hipMemcpyHostToDevice, d.stream_b));
@@ -191,29 +216,22 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
             HIP_TRY(ctx, launch_replay_write(P, (const uint64_t*)d.d_rp[2], (const uint64_t*)d.d_rp[3],
                                              (const uint64_t*)d.d_rp[4], nv, d_f, d_a, d.stream_b));
         }
-        blk = ctx->pool->take((nfh + nf) * sizeof(sx_finding) + nbh + nb + 64);
-        if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
-        uint8_t* bp = (uint8_t*)blk.p;
-        if (nfh == 0 && nbh == 0)
-            HIP_TRY(ctx, hipMemcpyAsync(bp, d_f, nf * sizeof(sx_finding) + nb, hipMemcpyDeviceToHost, d.stream_b));
-        else {
-            HIP_TRY(ctx, hipMemcpyAsync(bp + nfh * sizeof(sx_finding), d_f, nf * sizeof(sx_finding), hipMemcpyDeviceToHost, d.stream_b));
-            if (nb) HIP_TRY(ctx, hipMemcpyAsync(bp + (nfh + nf) * sizeof(sx_finding) + nbh, d_a, nb, hipMemcpyDeviceToHost, d.stream_b));
+        // a large output of one of several missions: the caller interleaves the missions on the device first, one copy instead of two
+        deferred = defer_min_bytes && nf * sizeof(sx_finding) + nb >= defer_min_bytes && dev_stitch && (host_parts.empty() || entry_only);
+        if (!deferred) {
+            blk = ctx->pool->take((nfh + nf) * sizeof(sx_finding) + nbh + nb + 64);
+            if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
+            HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, (nfh + nf) * sizeof(sx_finding) + nbh + nb, hipMemcpyDeviceToHost, d.stream_b));
         }
         HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
     }
     const double t3 = now_ms();
 
     // ---- splice (almost always: device findings only, or the entry part in front of them)
-    if (host_parts.empty()) {
-        if (blk.p) { out->ext = blk; out->ext_nf = nf; out->ext_na = nb; out->dev_copy = d.d_rp[5]; }
-    } else if (entry_only && blk.p) {
-        uint8_t* bp = (uint8_t*)blk.p;
-        sx_finding* hf = (sx_finding*)bp;
-        for (uint64_t j = 0; j < nfh; j++) { hf[j] = hf0->v[j]; hf[j].slice_index += job.slice_base; }
-        memcpy(bp + (nfh + nf) * sizeof(sx_finding), hf0->arena.data(), nbh);
-        out->ext = blk; out->ext_nf = nfh + nf; out->ext_na = nbh + nb;   // (no dev_copy: the device holds only its own part)
-        out->replay_bytes += hf0->replay_bytes;
+    if (host_parts.empty() || (entry_only && (blk.p || deferred))) {
+        if (deferred) { out->dev_only = true; out->ext_nf = nfh + nf; out->ext_na = nbh + nb; out->dev_copy = d.d_rp[5]; }
+        else if (blk.p) { out->ext = blk; out->ext_nf = nfh + nf; out->ext_na = nbh + nb; out->dev_copy = d.d_rp[5]; }
+        if (hf0) out->replay_bytes += hf0->replay_bytes;
     } else {
         const sx_finding* dev_f = (const sx_finding*)blk.p;
         const char* dev_a = blk.p ? (const char*)blk.p + nf * sizeof(sx_finding) : nullptr;
@@ -247,7 +265,13 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         uint64_t from = last_is_entry ? job.lo[k] : (E > ts ? last_start : ts);
         if (from < job.lo[k]) from = job.lo[k];
         ReplayPart fin;
-        replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(), n,
+        const sx_run* fr = runs.data();
+        size_t fn = n;
+        if (!runs.full()) {   // the list's tail is enough if it begins in front of `from`
+            if (n > kEdgeRuns && runs[n - kEdgeRuns].start <= from) { fr = runs.data() + (n - kEdgeRuns); fn = kEdgeRuns; }
+            else HIP_TRY(ctx, runs.wait());
+        }
+        replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, fr, fn,
                     from, job.len, job.entry_exact[k] && from == job.lo[k], &fin);
         ctx->states[k] = fin.state;
         ctx->states[k].consumed_bytes = job.consumed0[k] + job.len;
@@ -259,6 +283,152 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         fprintf(stderr, "[sx] device replay mission %zu: %zu runs, pass1+entry %.2f ms, validity %.2f ms (%zu standing, %zu host parts), "
                         "pass2+d2h %.2f ms (%llu findings), splice+state %.2f ms\n", k, n, t1 - t0, t2 - t1, (size_t)n_standing,
                 host_parts.size(), t3 - t2, (unsigned long long)nf, now_ms() - t3);
+    return SX_OK;
+}
+
+// A mission's findings that were left on the device (dev_only) come to the host after all.
+static int fetch_deferred(sx_ctx* ctx, MissionFindings& mf) {
+    if (!mf.dev_only) return SX_OK;
+    const size_t bytes = mf.ext_nf * sizeof(sx_finding) + mf.ext_na;
+    PinnedPool::Block blk = ctx->pool->take(bytes + 64);
+    if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
+    HIP_TRY(ctx, hipMemcpyAsync(blk.p, mf.dev_copy, bytes, hipMemcpyDeviceToHost, ctx->post_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->post_stream));
+    mf.ext = blk; mf.dev_only = false;
+    return SX_OK;
+}
+
+// The merger (src/main.rs:118-136) on the device: the missions' findings, each ordered by position and still in HBM, are
+// interleaved by a stable radix sort on the position and arrive on the host as they will be printed.  str_off has 32 bits, and
+// the sort's scratch is a multiple of its input: a large output is cut at slice boundaries into parts (each at most
+// SX_MERGE_PART_MIB of strings and SX_MERGE_PART_FINDINGS findings) that become one segment of the result each; the copy of
+// part j runs while part j+1 is sorted.  If the conditions do not hold the host merges (merge_findings).
+static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFindings>& per, Result* into) {
+    const size_t nm = per.size();
+    size_t with = 0, on_dev = 0, deferred = 0;
+    uint64_t total = 0, bytes = 0;
+    bool same_origin = true;
+    for (size_t k = 0; k < nm; k++) {
+        if (!per[k].count()) continue;
+        with++;
+        if ((per[k].ext.p || per[k].dev_only) && per[k].dev_copy) on_dev++;
+        if (per[k].dev_only) deferred++;
+        total += per[k].count(); bytes += per[k].strings_len();
+        same_origin = same_origin && job.consumed0[k] == job.consumed0[0];
+    }
+    auto give_up = [&]() -> int {
+        for (auto& mf : per) { int rc = fetch_deferred(ctx, mf); if (rc != SX_OK) return rc; }
+        return SX_OK;
+    };
+    if (!(with >= 2 && on_dev == with && same_origin && total >= 4096 && !getenv("SX_HOST_MERGE"))) return give_up();
+    const double tm0 = now_ms();
+    uint64_t part_bytes = 2048ull << 20, part_findings = 96ull << 20;
+    if (const char* e = getenv("SX_MERGE_PART_MIB")) part_bytes = std::max<uint64_t>(1, (uint64_t)atoll(e)) << 20;
+    if (const char* e = getenv("SX_MERGE_PART_FINDINGS")) part_findings = std::max<uint64_t>(1024, (uint64_t)atoll(e));
+    if (part_bytes > (3584ull << 20)) part_bytes = 3584ull << 20;
+    uint64_t K = std::max<uint64_t>(1, std::max((bytes + part_bytes - 1) / part_bytes, (total + part_findings - 1) / part_findings));
+    hipStream_t s = ctx->post_stream;
+    const uint64_t n_slices = (job.len + kInputBufLen - 1) / kInputBufLen;
+    std::vector<std::vector<uint64_t>> idx(nm), off(nm);   // per mission: K + 1 finding indices and string offsets
+    for (int attempt = 0;; attempt++) {
+        if (K > n_slices) K = std::max<uint64_t>(1, n_slices);
+        for (size_t k = 0; k < nm; k++) { idx[k].assign(K + 1, 0); off[k].assign(K + 1, 0); idx[k][K] = per[k].count(); off[k][K] = per[k].strings_len(); }
+        if (K > 1) {
+            std::vector<uint64_t> cuts(K - 1);
+            for (uint64_t j = 1; j < K; j++) cuts[j - 1] = job.consumed0[0] + (n_slices * j / K) * kInputBufLen;
+            const size_t row = (K - 1) * 8;
+            int rc = ensure_scratch(ctx, row * (1 + 2 * nm) + 256);
+            if (rc != SX_OK) return rc;
+            rc = ensure_pinned2(ctx, row * 2 * nm + 256);
+            if (rc != SX_OK) return rc;
+            uint64_t* d_cuts = (uint64_t*)ctx->d_scratch;
+            HIP_TRY(ctx, hipMemcpyAsync(d_cuts, cuts.data(), row, hipMemcpyHostToDevice, s));
+            for (size_t k = 0; k < nm; k++)
+                if (per[k].count())
+                    HIP_TRY(ctx, launch_merge_cuts((const sx_finding*)per[k].dev_copy, per[k].count(), per[k].strings_len(), d_cuts,
+                                                   (uint32_t)(K - 1), d_cuts + (K - 1) * (1 + 2 * k), d_cuts + (K - 1) * (2 + 2 * k), s));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin2, d_cuts + (K - 1), row * 2 * nm, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            const uint64_t* h = (const uint64_t*)ctx->h_pin2;
+            for (size_t k = 0; k < nm; k++)
+                if (per[k].count())
+                    for (uint64_t j = 1; j < K; j++) { idx[k][j] = h[(K - 1) * 2 * k + (j - 1)]; off[k][j] = h[(K - 1) * (2 * k + 1) + (j - 1)]; }
+                else
+                    for (uint64_t j = 1; j < K; j++) { idx[k][j] = 0; off[k][j] = 0; }
+        }
+        bool fits = true;
+        for (uint64_t j = 0; j < K && fits; j++) {
+            uint64_t pb = 0, pf = 0;
+            for (size_t k = 0; k < nm; k++) { pb += off[k][j + 1] - off[k][j]; pf += idx[k][j + 1] - idx[k][j]; }
+            fits = pb <= 0xFFFFFFF0ull && (pf <= 2 * part_findings || K >= n_slices);
+        }
+        if (fits) break;
+        if (attempt >= 8 || K >= n_slices) return give_up();   // (one slice alone with more than 4 GiB of strings cannot be)
+        K *= 2;
+    }
+    // the parts, two output buffers in turn: the copy of one runs while the next is sorted
+    uint64_t max_out = 0, max_n = 0;
+    for (uint64_t j = 0; j < K; j++) {
+        uint64_t pb = 0, pf = 0;
+        for (size_t k = 0; k < nm; k++) { pb += off[k][j + 1] - off[k][j]; pf += idx[k][j + 1] - idx[k][j]; }
+        max_out = std::max(max_out, pf * sizeof(sx_finding) + pb); max_n = std::max(max_n, pf);
+    }
+    const size_t out_room = (max_out + 511) & ~(size_t)255;
+    const size_t n_out = K > 1 ? 2 : 1;
+    int rc = ensure_scratch(ctx, n_out * out_room + merge_findings_scratch_bytes(max_n) + 512);
+    if (rc != SX_OK) return rc;
+    uint8_t* d_tmp = ctx->d_scratch + n_out * out_room;
+    const size_t tmp_bytes = ctx->d_scratch_cap - n_out * out_room;
+    if (!ctx->merge_copy_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->merge_copy_stream, hipStreamNonBlocking));
+        for (hipEvent_t& e : ctx->merge_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    hipStream_t cs = ctx->merge_copy_stream;
+    hipEvent_t ev_sorted = ctx->merge_ev[0], ev_copied[2] = { ctx->merge_ev[1], ctx->merge_ev[2] };
+    std::vector<const sx_finding*> fp(nm);
+    std::vector<const uint8_t*> ap(nm);
+    std::vector<uint64_t> pnf(nm), pnb(nm);
+    std::vector<uint32_t> off0(nm);
+    std::vector<MissionFindings> outs;
+    uint64_t rb = 0;
+    for (size_t k = 0; k < nm; k++) rb += per[k].replay_bytes;
+    bool copy_pending[2] = { false, false };
+    for (uint64_t j = 0; j < K; j++) {
+        uint64_t pb = 0, pf = 0;
+        for (size_t k = 0; k < nm; k++) {
+            const sx_finding* f0 = (const sx_finding*)per[k].dev_copy;
+            const uint8_t* a0 = (const uint8_t*)per[k].dev_copy + per[k].count() * sizeof(sx_finding);
+            fp[k] = f0 ? f0 + idx[k][j] : nullptr; ap[k] = f0 ? a0 + off[k][j] : nullptr;
+            pnf[k] = idx[k][j + 1] - idx[k][j]; pnb[k] = off[k][j + 1] - off[k][j]; off0[k] = (uint32_t)off[k][j];
+            pf += pnf[k]; pb += pnb[k];
+        }
+        if (!pf) continue;
+        uint8_t* d_out = ctx->d_scratch + (j & (n_out - 1)) * out_room;
+        if (copy_pending[j & 1]) HIP_TRY(ctx, hipStreamWaitEvent(s, ev_copied[j & 1], 0));   // the buffer is free again
+        HIP_TRY(ctx, merge_findings_device_part(fp.data(), ap.data(), pnf.data(), pnb.data(), off0.data(), (int)nm, d_out, d_tmp, tmp_bytes, s));
+        HIP_TRY(ctx, hipEventRecord(ev_sorted, s));
+        const size_t out_bytes = pf * sizeof(sx_finding) + pb;
+        PinnedPool::Block blk = ctx->pool->take(out_bytes + 64);
+        if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
+        HIP_TRY(ctx, hipStreamWaitEvent(cs, ev_sorted, 0));
+        HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_out, out_bytes, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(ctx, hipEventRecord(ev_copied[j & 1], cs));
+        copy_pending[j & 1] = true;
+        outs.emplace_back();
+        outs.back().ext = blk; outs.back().ext_nf = pf; outs.back().ext_na = pb;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipStreamSynchronize(cs));
+    for (size_t k = 0; k < nm; k++) {
+        if (per[k].ext.p) ctx->pool->give(per[k].ext);
+        per[k] = MissionFindings{};
+    }
+    if (!outs.empty()) outs[0].replay_bytes = rb; else per[0].replay_bytes = rb;
+    into->pool = ctx->pool;
+    for (auto& o : outs) { ctx->stats.replay_bytes += o.replay_bytes; into->segs.push_back(std::move(o)); o.ext = {}; }
+    if (getenv("SX_TIMING"))
+        fprintf(stderr, "[sx] device merge of %zu missions (%zu held back on the device): %llu findings, %llu parts, %.2f ms\n", with, deferred,
+                (unsigned long long)total, (unsigned long long)K, now_ms() - tm0);
     return SX_OK;
 }
 
@@ -315,7 +485,7 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
     for (size_t k = 0; k < nm; k++) {
         if (on_device[k] == 2) { per[k] = std::move(pre->per[k]); pre->per[k].ext = {}; ends[k] = pre->ends[k]; }
         else if (on_device[k]) {
-            int rc = device_replay_mission(ctx, k, bytes, job, runs[k], &per[k], &ends[k]);
+            int rc = device_replay_mission(ctx, k, bytes, job, runs[k], &per[k], &ends[k], 0);
             if (rc != SX_OK) return rc;
         }
     }
@@ -338,42 +508,8 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
     const size_t count_before = into->count();
     {   // several missions with findings that are all still on the device: interleave them there
         // (a stable radix sort by position) instead of finding by finding on the host
-        size_t with = 0, on_dev = 0, total = 0, bytes = 0;
-        bool same_origin = true;
-        for (size_t k = 0; k < nm; k++) {
-            if (!per[k].count()) continue;
-            with++;
-            if (per[k].ext.p && per[k].dev_copy) on_dev++;
-            total += per[k].count(); bytes += per[k].strings_len();
-            same_origin = same_origin && ctx->missions[k].c.counter_offset == ctx->missions[0].c.counter_offset;
-        }
-        if (with >= 2 && on_dev == with && same_origin && bytes <= 0xFFFFFFFFull && total >= 4096 && !getenv("SX_HOST_MERGE")) {
-            const double tm0 = now_ms();
-            std::vector<const void*> srcs(nm, nullptr);
-            std::vector<uint64_t> nfs(nm, 0), nbs(nm, 0);
-            for (size_t k = 0; k < nm; k++)
-                if (per[k].count()) { srcs[k] = per[k].dev_copy; nfs[k] = per[k].ext_nf; nbs[k] = per[k].ext_na; }
-            int rc = ensure_scratch(ctx, merge_findings_scratch_bytes(total) + total * sizeof(sx_finding) + bytes + 512);
-            if (rc != SX_OK) return rc;
-            uint8_t* d_out = ctx->d_scratch;
-            const size_t out_bytes = total * sizeof(sx_finding) + bytes;
-            uint8_t* d_tmp = d_out + ((out_bytes + 255) & ~(size_t)255);
-            hipStream_t s = ctx->post_stream;
-            HIP_TRY(ctx, merge_findings_device(srcs.data(), nfs.data(), nbs.data(), (int)nm, d_out, d_tmp,
-                                               ctx->d_scratch_cap - (size_t)(d_tmp - ctx->d_scratch), s));
-            PinnedPool::Block blk = ctx->pool->take(out_bytes + 64);
-            if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
-            HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_out, out_bytes, hipMemcpyDeviceToHost, s));
-            HIP_TRY(ctx, hipStreamSynchronize(s));
-            uint64_t rb = 0;
-            for (size_t k = 0; k < nm; k++) {
-                rb += per[k].replay_bytes;
-                if (per[k].ext.p) ctx->pool->give(per[k].ext);
-                per[k] = MissionFindings{};
-            }
-            per[0].ext = blk; per[0].ext_nf = total; per[0].ext_na = bytes; per[0].replay_bytes = rb;
-            if (getenv("SX_TIMING")) fprintf(stderr, "[sx] device merge of %zu missions: %zu findings, %.2f ms\n", with, total, now_ms() - tm0);
-        }
+        int rc = device_merge(ctx, job, per, into);
+        if (rc != SX_OK) return rc;
     }
     merge_findings(per, ctx->pool, into);
     if (getenv("SX_TIMING")) {

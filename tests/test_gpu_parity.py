@@ -323,7 +323,7 @@ SWITCHES = [
     {"SX_NO_REPLAY_CACHE": "1"}, {"SX_REPLAY_CACHE_MIB": "0"}, {"SX_HOST_MERGE": "1"}, {"SX_MISSION_STREAMS": "1"}, {"SX_DEVICE_JOIN_MIN": "1"},
     {"SX_SCAN_BLOCKS_PER_CU": "3", "SX_SCAN_CUS": "2"}, {"SX_PIECE_MIB": "2", "SX_REGION_CAP": "4"},
     {"SX_REGION_CAP": "1"}, {"SX_REGION_CAP": "2", "SX_NO_LARGE_REGIONS": "1"}, {"SX_STITCH_BLOCK": "512"}, {"SX_STITCH_BLOCK": "5"},
-    {"SX_MAX_REGION_WINDOWS": "2"},
+    {"SX_MAX_REGION_WINDOWS": "2"}, {"SX_DEFER_MIN_BYTES": "1"},
 ]
 
 
@@ -344,6 +344,30 @@ def test_every_switch_gives_the_same_text(env, monkeypatch):
     for _ in range(2):      # twice: the second call starts from what the first learnt (mission order, dense flags)
         sc.reset()
         res = sc.scan_device(d, len(img), file_id=1)
+        assert sx.OUTPUT_BOM + res.printed(n_inputs=1, radix="x") + b"\n" == want
+        res.free()
+    sc.free(d); sc.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"SX_DEFER_MIN_BYTES": "1"}, {"SX_MERGE_PART_FINDINGS": "20000"},
+                                 {"SX_DEFER_MIN_BYTES": "1", "SX_MERGE_PART_FINDINGS": "7000", "SX_MERGE_PART_MIB": "1"},
+                                 {"SX_DEFER_MIN_BYTES": "100000", "SX_MERGE_PART_FINDINGS": "1024"}],
+                         ids=lambda e: "+".join(f"{k[3:]}={v}" for k, v in e.items()) or "default")
+def test_device_merge_in_parts(env, monkeypatch):
+    """The merger on the device (sx_stage_b.cpp device_merge): several missions with many findings each, their output held
+    back on the device (SX_DEFER_MIN_BYTES) or already copied, interleaved in one part or in many (one result segment each)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ms = rc.missions(encodings=["ascii", "utf-8", "windows-1252", "utf-16le"], chars_min="4")
+    data = sxo.background(77, 3 << 20) + bytes(random.Random(5).choices(b"abcdefgh \x00\xc3\xa9", k=1 << 20))
+    want = sxo.run_cli(ms, [data], radix="x")
+    sc = sx.Scanner(ms, device=0, device_replay=True)
+    d = sc.alloc(len(data)); sc.upload(d, data)
+    for _ in range(2):
+        sc.reset()
+        res = sc.scan_device(d, len(data), file_id=1)
+        if env.get("SX_MERGE_PART_FINDINGS"):
+            assert len(res.segment_pointers()) > 1
         assert sx.OUTPUT_BOM + res.printed(n_inputs=1, radix="x") + b"\n" == want
         res.free()
     sc.free(d); sc.close()
