@@ -90,6 +90,15 @@ int ensure_capacity(sx_ctx* ctx, ScanSlot& s, uint32_t cap) {
 
 // Stage A for a set of missions: launch every mission's kernel on its own stream, then
 // collect, growing a record buffer and re-running that mission if it overflowed.
+// Pass 1's output cache: one for all missions (their stage B runs one after the other).
+int ensure_cache(sx_ctx* ctx, uint64_t bytes) {
+    if (ctx->d_cache_cap >= bytes) return SX_OK;
+    if (ctx->d_cache) HIP_TRY(ctx, hipFree(ctx->d_cache));
+    ctx->d_cache = nullptr; ctx->d_cache_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cache, bytes));
+    ctx->d_cache_cap = bytes;
+    return SX_OK;
+}
 int ensure_rp(sx_ctx* ctx, MissionDev& d, int slot, uint64_t bytes) {
     if (d.d_rp_cap[slot] >= bytes) return SX_OK;
     if (d.d_rp[slot]) HIP_TRY(ctx, hipFree(d.d_rp[slot]));
@@ -257,6 +266,7 @@ void sx_destroy(sx_ctx* ctx) {
         if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
         if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
         if (ctx->scan_stream) (void)hipStreamDestroy(ctx->scan_stream);
+        if (ctx->d_cache) (void)hipFree(ctx->d_cache);
         if (ctx->post_stream) (void)hipStreamDestroy(ctx->post_stream);
         if (ctx->merge_copy_stream) (void)hipStreamDestroy(ctx->merge_copy_stream);
         for (hipEvent_t e : ctx->merge_ev) if (e) (void)hipEventDestroy(e);

@@ -53,11 +53,13 @@ struct RunList {
     }
     // Only the first and last `edge` runs (what the host's share of a device replay reads: the buffer's entry region
     // and its exit state) — the middle of p[] stays unwritten.  full() says whether everything is there.
-    mutable bool complete = false;
+    mutable bool complete = false, edges_done = false;
     bool full() const { return !dev_src || !copy_bytes || complete; }
     hipError_t fetch_edges(size_t edge) const {
         if (full() || issued) return wait();
         if (n <= 2 * edge) return wait();
+        if (edges_done) return hipSuccess;
+        edges_done = true;
         hipError_t e = hipMemcpyAsync(const_cast<sx_run*>(p), dev_src, edge * sizeof(sx_run), hipMemcpyDeviceToHost, copy_stream);
         if (e == hipSuccess)
             e = hipMemcpyAsync(const_cast<sx_run*>(p) + (n - edge), (const sx_run*)dev_src + (n - edge), edge * sizeof(sx_run),
@@ -125,6 +127,8 @@ struct sx_ctx {
     std::string err;
     sx_stats stats{};
     hipStream_t scan_stream = nullptr, post_stream = nullptr;
+    uint8_t* d_cache = nullptr;   // stage B, pass 1's output cache (sx_stage_b.cpp)
+    uint64_t d_cache_cap = 0;
     hipStream_t merge_copy_stream = nullptr;   // device_merge: the copy of one part next to the sort of the following one
     hipEvent_t merge_ev[3] = { nullptr, nullptr, nullptr };
     unsigned n_cus = 256, scan_blocks_per_cu = 8;
@@ -214,6 +218,7 @@ int ensure_pinned2(sx_ctx* ctx, uint64_t bytes);
 int ensure_scratch(sx_ctx* ctx, uint64_t bytes);
 int ensure_capacity(sx_ctx* ctx, ScanSlot& s, uint32_t cap);
 int ensure_rp(sx_ctx* ctx, MissionDev& d, int slot, uint64_t bytes);
+int ensure_cache(sx_ctx* ctx, uint64_t bytes);
 unsigned usable_cpus();
 unsigned replay_threads(const sx_ctx* ctx);
 void begin_call(sx_ctx* ctx);

@@ -105,6 +105,7 @@ struct ReplayParams {
     uint32_t max_windows;        // a region that needs more windows is given back (kRegionTooLong)
     uint32_t str_off_base;       // pass 2 (flagged form): added to every str_off (strings of the host's entry part come first)
     uint32_t entry_skip;         // double-byte encodings: bytes at the buffer start that finish the token pending on entry
+    uint64_t n_look;             // runs[] may be read up to here (0: n_runs) — a slab's kernels visit n_runs of them, its regions look on
 };
 struct ReplayRegionOut {
     uint64_t end;             // where the region's replay stopped (a window start, buffer relative)
@@ -130,7 +131,7 @@ hipError_t launch_split_write(const ReplayParams& P, const void* scratch, uint64
 // summaries, so with many runs (string-dense input) larger blocks keep that walk short
 inline uint32_t stitch_block_runs(uint64_t n_runs) {
     if (const char* e = getenv("SX_STITCH_BLOCK")) { const int v = atoi(e); if (v > 0) return (uint32_t)v; }  // tests
-    return n_runs > (4ull << 20) ? 512u : 128u;
+    return n_runs > (1ull << 20) ? 512u : 128u;
 }
 enum : uint32_t { kTotEnd = 0, kTotLast, kTotFindings, kTotBytes, kTotStanding, kTotReplayBytes, kTotTooLong, kTotLastStart, kTotCount };
 size_t stitch_scratch_bytes(uint64_t n_runs);
@@ -148,6 +149,7 @@ hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegion
 hipError_t merge_findings_device_part(const sx_finding* const* f, const uint8_t* const* a, const uint64_t* nf, const uint64_t* nb,
                                       const uint32_t* off0, int n_missions, void* out, void* scratch, size_t scratch_bytes,
                                       hipStream_t stream);
+hipError_t launch_slab_cuts(const ReplayParams& P, uint32_t n_slabs, uint64_t* idx, uint64_t* hi, hipStream_t stream);
 hipError_t launch_merge_cuts(const sx_finding* f, uint64_t n, uint64_t nb, const uint64_t* cuts, uint32_t n_cuts, uint64_t* idx,
                              uint64_t* off, hipStream_t stream);
 size_t merge_findings_scratch_bytes(uint64_t n_findings);

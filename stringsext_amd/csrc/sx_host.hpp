@@ -190,6 +190,8 @@ struct MissionFindings {
     // dev_only: the copy to the host was put off (several missions are interleaved on the device first); ext_nf / ext_na
     // count what dev_copy holds, data() / strings() are not valid until it is fetched
     bool dev_only = false;
+    // further segments of the same mission, in order (a mission replayed in slabs; only with a single mission)
+    std::vector<MissionFindings> more;
     size_t count() const { return (ext.p || dev_only) ? ext_nf : v.size(); }
     const sx_finding* data() const { return ext.p ? (const sx_finding*)ext.p : v.data(); }
     const char* strings() const { return ext.p ? (const char*)ext.p + ext_nf * sizeof(sx_finding) : arena.data(); }

@@ -607,7 +607,12 @@ void merge_findings(std::vector<MissionFindings>& per, const std::shared_ptr<Pin
     auto release = [&](MissionFindings& mf) { if (mf.ext.p && pool) pool->give(mf.ext); mf.ext = {}; };
     if (nonempty <= 1) {  // nothing to interleave: hand the storage over as it is
         for (size_t k = 0; k < per.size(); k++) if (!(nonempty == 1 && k == which)) release(per[k]);
-        if (nonempty == 1) { out->segs.push_back(std::move(per[which])); per[which].ext = {}; }
+        if (nonempty == 1) {
+            std::vector<MissionFindings> more = std::move(per[which].more);
+            per[which].more.clear();
+            out->segs.push_back(std::move(per[which])); per[which].ext = {};
+            for (auto& m : more) { out->segs.push_back(std::move(m)); m.ext = {}; }
+        }
         return;
     }
     // One segment normally.  str_off is 32 bits: when the Missions' strings together exceed 4 GiB the findings go out as

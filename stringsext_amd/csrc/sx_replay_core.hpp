@@ -406,13 +406,14 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
     // whole decoder call (helper.rs:410-415), so what follows it in the window is never carried, which
     // the bytes in front of p cannot tell; there a region only ends in front of a window without runs.
     // a continuation piece begins at p: the region that starts there derives the very state this one has reached
+    const u64 n_look = P.n_look ? P.n_look : P.n_runs;
     auto piece_at = [&](u64 p) -> bool {
-        while (ri < P.n_runs && P.runs[ri].end <= p) ri++;
-        return ri < P.n_runs && P.runs[ri].start == p && (P.runs[ri].chars & kPieceCont);
+        while (ri < n_look && P.runs[ri].end <= p) ri++;
+        return ri < n_look && P.runs[ri].start == p && (P.runs[ri].chars & kPieceCont);
     };
     auto region_over = [&](u64 p) -> bool {
-        while (ri < P.n_runs && P.runs[ri].end <= p) ri++;
-        if (ri < P.n_runs && (regions_may_touch(P) ? P.runs[ri].start < p : win_start(P.runs[ri].start, W) <= p)) return false;
+        while (ri < n_look && P.runs[ri].end <= p) ri++;
+        if (ri < n_look && (regions_may_touch(P) ? P.runs[ri].start < p : win_start(P.runs[ri].start, W) <= p)) return false;
         return true;
     };
     auto may_drop = [&](const u8* lo, u32 n) -> bool {
@@ -442,13 +443,13 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
             for (;;) {  // 'decoder
                 if (P.skip && leftover_len == 0 && !maybe_cut && din < dend && ddec_idle<ENC>(dec)) {
                     const u64 p = soff + din, wend = soff + dend;
-                    while (ri < P.n_runs && P.runs[ri].end <= p) ri++;
-                    const u64 rs = ri < P.n_runs ? P.runs[ri].start : ~0ull;
+                    while (ri < n_look && P.runs[ri].end <= p) ri++;
+                    const u64 rs = ri < n_look ? P.runs[ri].start : ~0ull;
                     if (rs >= wend) {  // (B) nothing long starts in the rest of this window
                         // Nothing is pending there and no long run lies across wend (it would begin before
                         // wend): the region ends at wend, the state is never read.  (With -g only if no run
                         // begins in the next window either, and the derived leftover — one char — is droppable.)
-                        if (regions_may_touch(P) || (P.long_run > 1 && (ri >= P.n_runs || win_start(rs, W) > wend))) {
+                        if (regions_may_touch(P) || (P.long_run > 1 && (ri >= n_look || win_start(rs, W) > wend))) {
                             leftover_len = 0; dout = 0; din = dend;
                             ddec_reset(dec, (int)P.encoding, P.table);
                             break;

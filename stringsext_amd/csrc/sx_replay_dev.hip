@@ -499,6 +499,22 @@ hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, hipS
 #undef SX_LAUNCH_COUNT
     return hipGetLastError();
 }
+// Where a run list may be cut into slabs that are replayed one after the other (sx_stage_b.cpp): at a run that starts a
+// region of its own (not chained), the first one at or behind j/n_slabs of the list.  idx[j-1], hi[j-1] = that run and its
+// window start, for j = 1 .. n_slabs-1.
+__global__ void slab_cuts_kernel(const ReplayParams P, u32 n_slabs, u64* idx, u64* hi) {
+    const u32 j = threadIdx.x + 1;
+    if (j >= n_slabs) return;
+    u64 i = P.n_runs / n_slabs * j;
+    while (i < P.n_runs && run_is_chained(P, i, win_start(P.runs[i].start, P.W))) i++;
+    idx[j - 1] = i;
+    hi[j - 1] = i < P.n_runs ? win_start(P.runs[i].start, P.W) : ~0ull;
+}
+hipError_t launch_slab_cuts(const ReplayParams& P, uint32_t n_slabs, uint64_t* idx, uint64_t* hi, hipStream_t stream) {
+    if (n_slabs < 2 || n_slabs > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(slab_cuts_kernel, dim3(1), dim3(64), 0, stream, P, n_slabs, idx, hi);
+    return hipGetLastError();
+}
 hipError_t launch_replay_write(const ReplayParams& P, const u64* region_index, const u64* fbase, const u64* abase,
                                u64 n_regions, sx_finding* findings, u8* arena, hipStream_t stream) {
     if (n_regions == 0) return hipSuccess;

@@ -27,11 +27,29 @@ bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, siz
 
 // Stage B of one mission on the device (sx_replay_dev.hip) + the little the host keeps:
 // the chunk's strict entry region, regions the device gave back, the exact exit state.
-int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, const RunList& runs,
-                          MissionFindings* out, uint64_t* end_pos, uint64_t defer_min_bytes) {
+// One slab = the runs [i0, i1) of the list (all of them unless the mission is replayed in slabs, see device_replay_mission):
+// its regions begin in [job.lo, job.hi); what it writes goes to the host on the copy stream, behind `copied`.
+struct Slab {
+    size_t i0 = 0, i1 = 0;
+    bool first = true, last = true;   // first: the host's entry part belongs to it; last: the exit state
+    int out_slot = 5;                 // d_rp[] index of the output buffer (two in turn)
+    bool async_copy = false;          // leave the copy to the host running (the caller waits for `copied`)
+    hipEvent_t reuse_after = nullptr; // the output buffer is read by a copy until this event
+    hipEvent_t copied = nullptr;
+};
+struct SlabCarry {                    // from slab to slab: where the replay stands
+    uint64_t last_start = 0;
+    bool last_is_entry = false, any = false;
+};
+constexpr int SX_RETRY_WHOLE = 1000;  // (internal) a slab met something only the whole-list path handles
+
+static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, const RunList& runs, const Slab& sl,
+                              SlabCarry& carry, MissionFindings* out, uint64_t* end_pos, uint64_t defer_min_bytes) {
     const Mission& m = ctx->missions[k];
     MissionDev& d = ctx->dev[k];
-    const size_t n = runs.size();
+    const size_t n_all = runs.size();
+    const size_t n = sl.i1 - sl.i0;   // the runs this slab's kernels visit (lookups may go on to the list's end)
+    const bool slabbed = !(sl.first && sl.last);
     const size_t W = m.window;
     const double t0 = now_ms();
 
@@ -57,9 +75,10 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         rc = ensure_rp(ctx, d, 6, stitch_blocks_bytes(n)); if (rc) return rc;
         rc = ensure_rp(ctx, d, 7, kTotCount * 8); if (rc) return rc;
         rc = ensure_scratch(ctx, stitch_scratch_bytes(n)); if (rc) return rc;
-        if (!runs.on_device)
+        if (!runs.on_device)   // (never slabbed)
             HIP_TRY(ctx, hipMemcpyAsync(d.d_rp[0], runs.data(), n * sizeof(sx_run), hipMemcpyHostToDevice, d.stream_b));
-        P.data = job.d_bytes; P.len = job.len; P.runs = runs.on_device ? runs.dev_ptr : (const sx_run*)d.d_rp[0]; P.n_runs = n;
+        P.data = job.d_bytes; P.len = job.len; P.runs = (runs.on_device ? runs.dev_ptr : (const sx_run*)d.d_rp[0]) + sl.i0; P.n_runs = n;
+        P.n_look = n_all - sl.i0;
         P.lo = job.lo[k]; P.hi = job.hi; P.consumed0 = job.consumed0[k]; P.stream0 = job.stream0[k];
         P.slice_base = job.slice_base; P.encoding = m.c.encoding; P.table = d.d_table;
         P.chars_min_nb = m.c.chars_min_nb; P.same_block = m.c.require_same_unicode_block; P.q = (uint32_t)m.q;
@@ -70,12 +89,20 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         if (const char* e = getenv("SX_MAX_REGION_WINDOWS")) P.max_windows = (uint32_t)std::max(1, atoi(e));
         // pass-1 output cache: one arena for all replaying regions (slot = arena / their number, on the device)
         if (dev_stitch && !getenv("SX_NO_REPLAY_CACHE")) {
-            uint64_t budget = 8192ull << 20;   // of 288 GB; the arena is at most 1 KiB per run
+            // the arena is at most 1 KiB per run; 8 GiB of the 288 GB, and for a flood of runs (a Mission with hundreds of
+            // millions of them: slots of the minimum size, 160 bytes, for as many regions as possible — a region without slot
+            // is replayed twice) up to a third of what is free, at most 40 GiB
+            uint64_t budget = 8192ull << 20;
+            if ((uint64_t)n * 160 > budget) {
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess)
+                    budget = std::max(budget, std::min<uint64_t>(40960ull << 20, ((uint64_t)fr + ctx->d_cache_cap) / 3));
+            }
             if (const char* e = getenv("SX_REPLAY_CACHE_MIB")) budget = (uint64_t)atoll(e) << 20;
             const uint64_t arena = std::max<uint64_t>(4096, std::min<uint64_t>(budget, (uint64_t)n * 1024));
-            rc = ensure_rp(ctx, d, 8, arena + (uint64_t)(2 * n + 4) * 4 + 512); if (rc) return rc;
+            rc = ensure_cache(ctx, arena + (uint64_t)(2 * n + 4) * 4 + 512); if (rc) return rc;
             rc = ensure_scratch(ctx, std::max(stitch_scratch_bytes(n), replay_heads_scratch_bytes(n))); if (rc) return rc;
-            uint8_t* base = (uint8_t*)d.d_rp[8];
+            uint8_t* base = ctx->d_cache;
             P.cache_arena = base; P.arena_bytes = arena & ~255ull;
             uint32_t* slot_of = (uint32_t*)(base + ((arena + 255) & ~255ull));
             P.slot_of = slot_of; P.n_heads = slot_of + n + 1; P.head_list = slot_of + n + 2;
@@ -99,24 +126,24 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     constexpr size_t kEdgeRuns = 8192;
     if (dev_stitch) HIP_TRY(ctx, runs.fetch_edges(kEdgeRuns)); else HIP_TRY(ctx, runs.wait());   // (the host's stitch walks the whole list)
     // the part of the list the host may read without the whole copy: [0, kEdgeRuns) and [n - kEdgeRuns, n)
-    const size_t head_n = runs.full() ? n : kEdgeRuns;
+    const size_t head_n = runs.full() ? n_all : kEdgeRuns;
     std::deque<ReplayPart> host_parts;
     struct Seg { int host_part; size_t v0, v1; };  // host_part >= 0, or device regions [v0, v1) of `valid`
     std::vector<Seg> segs;
     uint64_t E = std::min(job.lo[k], job.hi);
-    uint64_t last_start = E;   // start of the last region of any kind (for the exit state)
-    bool last_is_entry = false;
+    uint64_t last_start = carry.any ? carry.last_start : E;   // start of the last region of any kind (for the exit state)
+    bool last_is_entry = carry.any ? carry.last_is_entry : false;
     if (job.entry_exact[k]) {
         // The chunk's first window belongs to the host: only it has the exact carried state
         // (leftover, cut flag, and the decoder's pending bytes, which cannot be re-derived here).
         host_parts.emplace_back();
         replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(), head_n,
                     job.lo[k], job.lo[k] + 1, true, &host_parts.back());
-        if (head_n < n && host_parts.back().end_pos >= runs[head_n - 1].start) {   // it ran into what was not copied: the whole list
+        if (head_n < n_all && host_parts.back().end_pos >= runs[head_n - 1].start) {   // it ran into what was not copied: the whole list
             HIP_TRY(ctx, runs.wait());
             host_parts.pop_back();
             host_parts.emplace_back();
-            replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(), n,
+            replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, runs.data(), n_all,
                         job.lo[k], job.lo[k] + 1, true, &host_parts.back());
         }
         if (host_parts.back().regions.empty()) host_parts.pop_back();
@@ -130,6 +157,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         HIP_TRY(ctx, hipMemcpyAsync(h_tot, d.d_rp[7], kTotCount * 8, hipMemcpyDeviceToHost, d.stream_b));
     }
     if (n) HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+    if (dev_stitch && h_tot[kTotTooLong] && slabbed) return SX_RETRY_WHOLE;
     if (dev_stitch && h_tot[kTotTooLong]) {  // regions for the host: it also decides what stands
         dev_stitch = false;
         HIP_TRY(ctx, runs.wait());
@@ -193,8 +221,13 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     if (nb + nbh > 0xFFFFFFFFull) { ctx->err = "more than 4 GiB of strings in one chunk"; return SX_E_NOMEM; }
     if (n_standing) {
         // the device buffer has the block's layout: [host findings][device findings][host strings][device strings]
-        int rc = ensure_rp(ctx, d, 5, (nfh + nf) * sizeof(sx_finding) + nbh + nb + 64); if (rc) return rc;
-        uint8_t* d_all = (uint8_t*)d.d_rp[5];
+        const uint64_t out_bytes = (nfh + nf) * sizeof(sx_finding) + nbh + nb;
+        if (sl.reuse_after) {   // a copy of an earlier slab may still read this buffer
+            if (d.d_rp_cap[sl.out_slot] < out_bytes + 64) HIP_TRY(ctx, hipEventSynchronize(sl.reuse_after));
+            else HIP_TRY(ctx, hipStreamWaitEvent(d.stream_b, sl.reuse_after, 0));
+        }
+        int rc = ensure_rp(ctx, d, sl.out_slot, out_bytes + 64); if (rc) return rc;
+        uint8_t* d_all = (uint8_t*)d.d_rp[sl.out_slot];
         sx_finding* d_f = (sx_finding*)d_all + nfh;
         uint8_t* d_a = d_all + (nfh + nf) * sizeof(sx_finding) + nbh;
         if (dev_stitch) {
@@ -219,18 +252,24 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         // a large output of one of several missions: the caller interleaves the missions on the device first, one copy instead of two
         deferred = defer_min_bytes && nf * sizeof(sx_finding) + nb >= defer_min_bytes && dev_stitch && (host_parts.empty() || entry_only);
         if (!deferred) {
-            blk = ctx->pool->take((nfh + nf) * sizeof(sx_finding) + nbh + nb + 64);
+            blk = ctx->pool->take(out_bytes + 64);
             if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
-            HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, (nfh + nf) * sizeof(sx_finding) + nbh + nb, hipMemcpyDeviceToHost, d.stream_b));
+            if (sl.async_copy) {   // on the copy stream: the next slab's kernels run meanwhile
+                HIP_TRY(ctx, hipEventRecord(ctx->merge_ev[0], d.stream_b));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->merge_copy_stream, ctx->merge_ev[0], 0));
+                HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, out_bytes, hipMemcpyDeviceToHost, ctx->merge_copy_stream));
+                HIP_TRY(ctx, hipEventRecord(sl.copied, ctx->merge_copy_stream));
+            } else
+                HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, out_bytes, hipMemcpyDeviceToHost, d.stream_b));
         }
-        HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+        if (!sl.async_copy || nfh) HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));   // (nfh: the entry part's upload reads host vectors)
     }
     const double t3 = now_ms();
 
     // ---- splice (almost always: device findings only, or the entry part in front of them)
     if (host_parts.empty() || (entry_only && (blk.p || deferred))) {
-        if (deferred) { out->dev_only = true; out->ext_nf = nfh + nf; out->ext_na = nbh + nb; out->dev_copy = d.d_rp[5]; }
-        else if (blk.p) { out->ext = blk; out->ext_nf = nfh + nf; out->ext_na = nbh + nb; out->dev_copy = d.d_rp[5]; }
+        if (deferred) { out->dev_only = true; out->ext_nf = nfh + nf; out->ext_na = nbh + nb; out->dev_copy = d.d_rp[sl.out_slot]; }
+        else if (blk.p) { out->ext = blk; out->ext_nf = nfh + nf; out->ext_na = nbh + nb; out->dev_copy = sl.async_copy ? nullptr : d.d_rp[sl.out_slot]; }
         if (hf0) out->replay_bytes += hf0->replay_bytes;
     } else {
         const sx_finding* dev_f = (const sx_finding*)blk.p;
@@ -266,9 +305,9 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         if (from < job.lo[k]) from = job.lo[k];
         ReplayPart fin;
         const sx_run* fr = runs.data();
-        size_t fn = n;
+        size_t fn = n_all;
         if (!runs.full()) {   // the list's tail is enough if it begins in front of `from`
-            if (n > kEdgeRuns && runs[n - kEdgeRuns].start <= from) { fr = runs.data() + (n - kEdgeRuns); fn = kEdgeRuns; }
+            if (n_all > kEdgeRuns && runs[n_all - kEdgeRuns].start <= from) { fr = runs.data() + (n_all - kEdgeRuns); fn = kEdgeRuns; }
             else HIP_TRY(ctx, runs.wait());
         }
         replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, fr, fn,
@@ -279,11 +318,94 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         E = job.len;
     }
     if (end_pos) *end_pos = std::max(E, std::min(job.hi, job.len));
+    carry.last_start = last_start; carry.last_is_entry = last_is_entry; carry.any = true;
     if (getenv("SX_TIMING"))
         fprintf(stderr, "[sx] device replay mission %zu: %zu runs, pass1+entry %.2f ms, validity %.2f ms (%zu standing, %zu host parts), "
                         "pass2+d2h %.2f ms (%llu findings), splice+state %.2f ms\n", k, n, t1 - t0, t2 - t1, (size_t)n_standing,
                 host_parts.size(), t3 - t2, (unsigned long long)nf, now_ms() - t3);
     return SX_OK;
+}
+
+static int ensure_copy_stream(sx_ctx* ctx) {
+    if (ctx->merge_copy_stream) return SX_OK;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->merge_copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t& e : ctx->merge_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return SX_OK;
+}
+
+// Stage B of one mission on the device.  A single mission with a long run list is replayed in slabs (a quarter of the
+// list each, cut where a region begins): a slab's findings travel to the host while the next slab is replayed, so that only
+// the last slab's copy is not hidden (string-dense and text-like input: the output is as large as the input).  Slab j begins
+// where slab j-1 stopped — its last region may run past the cut —, with the state derived there as at a shard start.
+int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, const RunList& runs,
+                          MissionFindings* out, uint64_t* end_pos, uint64_t defer_min_bytes) {
+    const size_t n = runs.size();
+    MissionDev& d = ctx->dev[k];
+    size_t K = 1;
+    const bool can = ctx->missions.size() == 1 && runs.on_device && !getenv("SX_HOST_STITCH") && defer_min_bytes == 0;
+    if (can && n >= (1u << 20)) K = 3;   // (measured on string-dense and text-like input: 3 beats 2, 4 and 6)
+    if (const char* e = getenv("SX_SLABS")) { K = (size_t)std::max(1, std::min(64, atoi(e))); if (!can || n < 8 * K) K = 1; }
+    std::vector<uint64_t> idx{ 0 }, his{ 0 };
+    if (K > 1) {   // where to cut
+        int rc = ensure_copy_stream(ctx); if (rc != SX_OK) return rc;
+        rc = ensure_scratch(ctx, 4096); if (rc != SX_OK) return rc;
+        rc = ensure_pinned2(ctx, 4096); if (rc != SX_OK) return rc;
+        ReplayParams P{};
+        P.runs = runs.dev_ptr; P.n_runs = n; P.W = (uint32_t)ctx->missions[k].window; P.grep_char = ctx->missions[k].c.grep_char;
+        uint64_t* d_cut = (uint64_t*)ctx->d_scratch;
+        HIP_TRY(ctx, launch_slab_cuts(P, (uint32_t)K, d_cut, d_cut + 64, d.stream_b));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin2, d_cut, 128 * 8, hipMemcpyDeviceToHost, d.stream_b));
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+        const uint64_t* h = (const uint64_t*)ctx->h_pin2;
+        for (size_t j = 1; j < K; j++)
+            if (h[j - 1] > idx.back() && h[j - 1] < n && h[64 + j - 1] < job.hi) { idx.push_back(h[j - 1]); his.push_back(h[64 + j - 1]); }
+    }
+    idx.push_back(n);
+    const size_t ns = idx.size() - 1;
+    if (ns > 1) {
+        std::vector<MissionFindings> got;
+        SlabCarry carry;
+        hipEvent_t copied[2] = { ctx->merge_ev[1], ctx->merge_ev[2] };
+        uint64_t e_prev = 0;
+        int rc = SX_OK;
+        for (size_t j = 0; j < ns && rc == SX_OK; j++) {
+            ReplayJob sj = job;
+            sj.hi = j + 1 < ns ? std::min(job.hi, his[j + 1]) : job.hi;
+            if (j > 0) { sj.lo[k] = std::max(job.lo[k], e_prev); sj.entry_exact[k] = 0; }
+            sj.commit_state = job.commit_state && j + 1 == ns;
+            Slab sl;
+            sl.i0 = idx[j]; sl.i1 = idx[j + 1]; sl.first = j == 0; sl.last = j + 1 == ns;
+            sl.out_slot = (j & 1) ? 8 : 5; sl.async_copy = true;
+            sl.reuse_after = j >= 2 ? copied[j & 1] : nullptr; sl.copied = copied[j & 1];
+            MissionFindings mf;
+            uint64_t e_now = 0;
+            rc = device_replay_slab(ctx, k, view, sj, runs, sl, carry, &mf, &e_now, 0);
+            e_prev = std::max(e_prev, e_now);
+            if (rc == SX_OK) {
+                out->replay_bytes += mf.replay_bytes; mf.replay_bytes = 0;
+                if (mf.count()) got.push_back(std::move(mf));
+            } else if (mf.ext.p) got.push_back(std::move(mf));
+        }
+        (void)hipStreamSynchronize(ctx->merge_copy_stream);
+        (void)hipStreamSynchronize(d.stream_b);
+        if (rc == SX_OK) {
+            const uint64_t rb = out->replay_bytes;
+            if (!got.empty()) {
+                *out = std::move(got[0]);
+                for (size_t j = 1; j < got.size(); j++) out->more.push_back(std::move(got[j]));
+            }
+            out->replay_bytes = rb;
+            if (end_pos) *end_pos = e_prev;
+            return SX_OK;
+        }
+        for (auto& g : got) if (g.ext.p) ctx->pool->give(g.ext);
+        out->replay_bytes = 0;
+        if (rc != SX_RETRY_WHOLE) return rc;
+    }
+    Slab sl;
+    sl.i1 = n;
+    SlabCarry carry;
+    return device_replay_slab(ctx, k, view, job, runs, sl, carry, out, end_pos, defer_min_bytes);
 }
 
 // A mission's findings that were left on the device (dev_only) come to the host after all.
@@ -379,10 +501,7 @@ static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFi
     if (rc != SX_OK) return rc;
     uint8_t* d_tmp = ctx->d_scratch + n_out * out_room;
     const size_t tmp_bytes = ctx->d_scratch_cap - n_out * out_room;
-    if (!ctx->merge_copy_stream) {
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->merge_copy_stream, hipStreamNonBlocking));
-        for (hipEvent_t& e : ctx->merge_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    { int rc = ensure_copy_stream(ctx); if (rc != SX_OK) return rc; }
     hipStream_t cs = ctx->merge_copy_stream;
     hipEvent_t ev_sorted = ctx->merge_ev[0], ev_copied[2] = { ctx->merge_ev[1], ctx->merge_ev[2] };
     std::vector<const sx_finding*> fp(nm);

@@ -255,6 +255,12 @@ def test_dense_strings_device_replay_and_stitch(max_gap, opts, monkeypatch):
     for chunk in (None, 1 << 20):
         got = run_cli_product(ms, [data], radix="x", chunk_bytes=chunk, device=0, device_replay=True)
         assert got == want, (max_gap, chunk)
+    for slabs, cap in (("3", None), ("7", None), ("16", "1"), ("4", "2")):   # the mission replayed in slabs (also with regions given back)
+        monkeypatch.setenv("SX_SLABS", slabs)
+        if cap: monkeypatch.setenv("SX_MAX_REGION_WINDOWS", cap)
+        for chunk in (None, 1 << 20):
+            assert run_cli_product(ms, [data], radix="x", chunk_bytes=chunk, device=0, device_replay=True) == want, (max_gap, slabs, chunk)
+    monkeypatch.delenv("SX_SLABS"); monkeypatch.delenv("SX_MAX_REGION_WINDOWS")
     monkeypatch.setenv("SX_HOST_STITCH", "1")
     assert run_cli_product(ms, [data], radix="x", device=0, device_replay=True) == want
 

@@ -27,7 +27,8 @@ class ReplayParams(C.Structure):
                 ("long_run", C.c_uint32), ("skip", C.c_uint32), ("grep_char", C.c_int32), ("mission_id", C.c_int32), ("file_id", C.c_int32),
                 ("af_lo", C.c_uint64), ("af_hi", C.c_uint64), ("ubf", C.c_uint64),
                 ("slot_of", C.c_void_p), ("n_heads", C.c_void_p), ("cache_arena", C.c_void_p), ("arena_bytes", C.c_uint64),
-                ("head_list", C.c_void_p), ("max_windows", C.c_uint32), ("entry_skip", C.c_uint32)]
+                ("head_list", C.c_void_p), ("max_windows", C.c_uint32), ("str_off_base", C.c_uint32), ("entry_skip", C.c_uint32),
+                ("n_look", C.c_uint64)]
 
 
 class RegionOut(C.Structure):

@@ -15,7 +15,9 @@ SWITCH_SETS = [{}, {}, {}, {"SX_NO_REPLAY_CACHE": "1"}, {"SX_HOST_STITCH": "1"},
                {"SX_REGION_CAP": "2"}, {"SX_REGION_CAP": "0"}, {"SX_DEVICE_JOIN_MIN": "1"}, {"SX_HOST_MERGE": "1"},
                {"SX_NO_REPLAY_CACHE": "1", "SX_NO_REPLAY_SKIP": "1"}, {"SX_HOST_STITCH": "1", "SX_DEVICE_JOIN_MIN": "1"},
                {"SX_REGION_CAP": "1"}, {"SX_REGION_CAP": "2", "SX_NO_LARGE_REGIONS": "1"}, {"SX_REGION_CAP": "1", "SX_DEVICE_JOIN_MIN": "1"},
-               {"SX_STITCH_BLOCK": "512"}, {"SX_STITCH_BLOCK": "3"}, {"SX_MAX_REGION_WINDOWS": "2"}, {"SX_MAX_REGION_WINDOWS": "64"}]
+               {"SX_STITCH_BLOCK": "512"}, {"SX_STITCH_BLOCK": "3"}, {"SX_MAX_REGION_WINDOWS": "2"}, {"SX_MAX_REGION_WINDOWS": "64"},
+               {"SX_SLABS": "3"}, {"SX_SLABS": "8"}, {"SX_SLABS": "5", "SX_MAX_REGION_WINDOWS": "2"}, {"SX_SLABS": "2", "SX_DEVICE_JOIN_MIN": "1"},
+               {"SX_DEFER_MIN_BYTES": "1"}, {"SX_DEFER_MIN_BYTES": "1", "SX_MERGE_PART_FINDINGS": "2000"}, {"SX_MERGE_PART_FINDINGS": "3000"}]
 ALL_SWITCHES = sorted({k for s in SWITCH_SETS for k in s})
 
 
