@@ -158,7 +158,7 @@ hipError_t merge_findings_device(const void* const* srcs, const uint64_t* nf, co
 
 // order run records by start on the device (sx_sort.hip); unused slots end up last with start = ~0
 size_t sort_scratch_bytes(uint32_t n);
-hipError_t sort_records(DevRun* recs, uint32_t n, void* scratch, size_t scratch_bytes, hipStream_t stream);
+hipError_t sort_records(DevRun* recs, uint32_t n, uint64_t max_key, void* scratch, size_t scratch_bytes, hipStream_t stream);
 
 // region mode: records of all sub-chunks, in order, packed into `out`; *total = their number
 size_t compact_scratch_bytes(uint64_t n_regions);

@@ -180,7 +180,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             int rc = ensure_scratch(ctx, sb); if (rc != SX_OK) return rc;
             if (d.ev_runs) HIP_TRY(ctx, hipEventSynchronize(d.ev_runs));  // the previous list's copy (normally long done)
             rc = ensure_rp(ctx, d, 0, (uint64_t)nrec * sizeof(sx_run)); if (rc != SX_OK) return rc;
-            if (!regions) HIP_TRY(ctx, sort_records(s.d_recs, nrec, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
+            if (!regions) HIP_TRY(ctx, sort_records(s.d_recs, nrec, len, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
             if (getenv("SX_TIMING2")) { HIP_TRY(ctx, hipStreamSynchronize(d.stream_b)); fprintf(stderr, "[sx]   sort done +%.2f ms\n", now_ms() - tc0); }
             HIP_TRY(ctx, merge_sorted_records(d_records, nrec, min_chars[k], ctx->d_scratch, ctx->d_scratch_cap,
                                               (sx_run*)d.d_rp[0], s.d_counters + 2, d.stream_b));

@@ -36,6 +36,10 @@ struct Slab {
     bool async_copy = false;          // leave the copy to the host running (the caller waits for `copied`)
     hipEvent_t reuse_after = nullptr; // the output buffer is read by a copy until this event
     hipEvent_t copied = nullptr;
+    // the mission's own start in this buffer (the job's lo / entry_exact are the slab's): the exit state is replayed from the
+    // last region's start, which may lie in an earlier slab
+    uint64_t lo0 = 0;
+    bool entry_exact0 = false;
 };
 struct SlabCarry {                    // from slab to slab: where the replay stands
     uint64_t last_start = 0;
@@ -301,8 +305,10 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
         const uint64_t tail = job.len ? job.len - 1 : 0;
         uint64_t ts = win_start_h(tail, W);
         for (int t = 0; t < 3 && ts > 0; t++) ts = win_start_h(ts - 1, W);
-        uint64_t from = last_is_entry ? job.lo[k] : (E > ts ? last_start : ts);
-        if (from < job.lo[k]) from = job.lo[k];
+        const uint64_t lo0 = slabbed ? sl.lo0 : job.lo[k];
+        const bool exact0 = slabbed ? sl.entry_exact0 : job.entry_exact[k] != 0;
+        uint64_t from = last_is_entry ? lo0 : (E > ts ? last_start : ts);
+        if (from < lo0) from = lo0;
         ReplayPart fin;
         const sx_run* fr = runs.data();
         size_t fn = n_all;
@@ -311,7 +317,7 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
             else HIP_TRY(ctx, runs.wait());
         }
         replay_part(m, ctx->states[k], job.consumed0[k], job.stream0[k], view, job.len, job.file_id, false, fr, fn,
-                    from, job.len, job.entry_exact[k] && from == job.lo[k], &fin);
+                    from, job.len, exact0 && from == lo0, &fin);
         ctx->states[k] = fin.state;
         ctx->states[k].consumed_bytes = job.consumed0[k] + job.len;
         ctx->states[k].stream_bytes = job.stream0[k] + job.len;
@@ -377,6 +383,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
             sl.i0 = idx[j]; sl.i1 = idx[j + 1]; sl.first = j == 0; sl.last = j + 1 == ns;
             sl.out_slot = (j & 1) ? 8 : 5; sl.async_copy = true;
             sl.reuse_after = j >= 2 ? copied[j & 1] : nullptr; sl.copied = copied[j & 1];
+            sl.lo0 = job.lo[k]; sl.entry_exact0 = job.entry_exact[k] != 0;
             MissionFindings mf;
             uint64_t e_now = 0;
             rc = device_replay_slab(ctx, k, view, sj, runs, sl, carry, &mf, &e_now, 0);

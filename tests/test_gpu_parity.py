@@ -260,6 +260,11 @@ def test_dense_strings_device_replay_and_stitch(max_gap, opts, monkeypatch):
         if cap: monkeypatch.setenv("SX_MAX_REGION_WINDOWS", cap)
         for chunk in (None, 1 << 20):
             assert run_cli_product(ms, [data], radix="x", chunk_bytes=chunk, device=0, device_replay=True) == want, (max_gap, slabs, chunk)
+    # small chunks: a slab's last region often runs to the chunk's end, the state handed on is the replay of THAT region
+    monkeypatch.setenv("SX_DEVICE_JOIN_MIN", "1")
+    small = data[:400_000]
+    assert run_cli_product(ms, [small], radix="x", chunk_bytes=4096, device=0, device_replay=True) == sxo.run_cli(ms, [small], radix="x")
+    monkeypatch.delenv("SX_DEVICE_JOIN_MIN")
     monkeypatch.delenv("SX_SLABS"); monkeypatch.delenv("SX_MAX_REGION_WINDOWS")
     monkeypatch.setenv("SX_HOST_STITCH", "1")
     assert run_cli_product(ms, [data], radix="x", device=0, device_replay=True) == want
