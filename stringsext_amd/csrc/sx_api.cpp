@@ -19,7 +19,8 @@ PinnedPool::Block PinnedPool::take(size_t bytes) {
     }
     Block b;
     const size_t cap = bytes + bytes / 8 + (1u << 20);
-    if (hipHostMalloc(&b.p, cap, hipHostMallocNonCoherent) != hipSuccess) { b.p = nullptr; return b; }
+    static const unsigned flags = [] { const char* e = getenv("SX_POOL_PIN_FLAGS"); return e ? (unsigned)strtoul(e, nullptr, 0) : (unsigned)hipHostMallocNonCoherent; }();
+    if (hipHostMalloc(&b.p, cap, flags) != hipSuccess) { b.p = nullptr; return b; }
     b.cap = cap;
     return b;
 }
