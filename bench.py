@@ -216,7 +216,7 @@ def main():
             "algorithmic_bytes_per_launch": nbytes,
             "per_kernel_ms": [round(x, 3) for x in kernel_ms],
             "per_kernel_gbs": [round(nbytes / (x * 1e-3) / 1e9, 1) if x > 0 else None for x in kernel_ms],
-            "note": "durations inside the timed region: the busiest mission's stage B runs next to the other missions' kernels",
+            "note": "durations inside the timed region; default schedule: the busiest mission is scanned last and its stage B follows the scans (SX_BUSIEST_LAST=0: it is scanned first and its stage B runs next to the other missions' kernels)",
             "per_kernel_ms_alone": [round(x, 3) for x in alone_ms],
             "frac_alone": round(len(missions) * nbytes / (sum(alone_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if alone_ms and sum(alone_ms) > 0 else None,
         }

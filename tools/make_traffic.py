@@ -9,7 +9,7 @@ tag = sys.argv[1]
 def per_launch(path, counter):
     out = {}
     for r in csv.DictReader(open(path)):
-        if "scan_kernel" in r["kernel"] and r["counter"] == counter:
+        if "::scan_kernel<" in r["kernel"] and r["counter"] == counter:
             out[r["kernel"].split("scan_kernel")[1]] = float(r["sum_over_dispatches"]) / float(r["dispatches"])
     return out
 fetch = per_launch(os.path.join(ROOT, "profiles", f"{tag}_fetch.csv"), "FETCH_SIZE")
