@@ -68,6 +68,8 @@ def main():
                     help="zero: a constant-byte buffer instead of the synthetic background (counter passes: same instructions, other data)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (testing the N>1 path on one GPU: gloo)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses cuda:0")
+    ap.add_argument("--generic-kernels", action="store_true",
+                    help="force the table-driven (LUT) classifiers instead of the range kernels: what a Mission with an arbitrary af / ubf costs")
     args = ap.parse_args()
 
     import torch
@@ -99,7 +101,7 @@ def main():
     missions = sx.missions_from_flags(**wl["flags"])   # the product's front end, from the literal flag strings
     assert missions == rc.missions(**wl["flags"])      # (the reference's rules restated in tests/refconfig.py: the checker)
     nbytes = int((args.gib if args.gib is not None else wl["gib"]) * (1 << 30)) // 4096 * 4096
-    sc = sx.Scanner(missions, device=local_rank, subchunk_bytes=args.subchunk_kib * 1024)
+    sc = sx.Scanner(missions, device=local_rank, subchunk_bytes=args.subchunk_kib * 1024, generic_kernels=args.generic_kernels)
 
     # weak scaling: rank r owns bytes [r*nbytes, (r+1)*nbytes) of ONE world*nbytes image; for
     # N > 1 its buffer also holds a halo on both sides (runs that cross a shard boundary)
