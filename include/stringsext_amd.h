@@ -282,10 +282,11 @@ int sx_shard_splice(const sx_finding* const* findings, const uint64_t* n_finding
                     const uint64_t* arena_lens, int world, uint64_t file_len, sx_result** out);
 
 uint64_t          sx_result_count(const sx_result* r);
-/* The findings come in one or more segments, in print order (a large device-resident
- * buffer is scanned piece by piece and every piece adds a segment; the segments'
- * memory is pinned host memory the device wrote directly).  Each segment has its own
- * arena: sx_finding.str_off is relative to it. */
+/* The findings come in one or more segments, in print order: a buffer scanned piece by piece adds a segment per
+ * piece; a single Mission with millions of runs is replayed in slabs, one segment each (a slab travels to the host while
+ * the next is replayed); several Missions with a large output are interleaved on the device in parts of at most 2 GiB of
+ * strings, one segment each (str_off has 32 bits).  The segments' memory is pinned host memory the device wrote
+ * directly.  Each segment has its own arena: str_off counts from that arena's start. */
 uint64_t          sx_result_segments(const sx_result* r);
 int               sx_result_segment(const sx_result* r, uint64_t index, const sx_finding** findings,
                                     uint64_t* n_findings, const uint8_t** arena, uint64_t* arena_len);
