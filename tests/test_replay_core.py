@@ -186,33 +186,53 @@ def make_params(m, data, runs, stream0=0, skip=1):
     return P, W, long_run
 
 
-def emulate_device_stage_b(core, m, data, runs, skip=1, pieces=True):
+def emulate_device_stage_b(core, m, data, runs, skip=1, pieces=True, slabs=1):
     """What the device does with one Mission's runs, on the CPU: every head run (sx_replay_dev.hip
     region_is_chained) replays its region from derived state with the device core, then the sequential
     stitch rule (a region stands iff it begins at or behind the end of the last standing one).  The first
     region derives from the stream start, which is the true initial state.  Returns None if a region is
-    given back to the host (too long)."""
+    given back to the host (too long).
+    slabs > 1: as sx_stage_b.cpp device_replay_mission does it — the list is cut where a region begins
+    (slab_cuts_kernel), every slab's kernels see only its runs (lookups may go on to the list's end: n_look),
+    slab j owns the regions that begin in [where slab j-1 stopped, the window start of slab j+1's first run)."""
     if pieces:
         runs = split_runs(core, m, data, runs)
-    P, W, _ = make_params(m, data, runs, skip=skip)
+    P0, W, _ = make_params(m, data, runs, skip=skip)
+    n = len(runs)
+    chained = lambda i: i > 0 and (ws(runs[i][0], W) < runs[i - 1][1] if m["grep_char"] is None
+                                   else ws(runs[i][0], W) <= ws(runs[i - 1][1] - 1, W) + W)
+    cuts = [0]
+    for j in range(1, slabs):
+        i = n // slabs * j
+        while i < n and chained(i):
+            i += 1
+        if cuts[-1] < i < n:
+            cuts.append(i)
+    cuts.append(n)
     fbuf = (sx.Finding * 8192)()
     abuf = (C.c_uint8 * (1 << 21))()
     out, E = [], 0
-    for i, r in enumerate(runs):
-        want = ws(r[0], W)
-        if i > 0 and (want < runs[i - 1][1] if m["grep_char"] is None else want <= ws(runs[i - 1][1] - 1, W) + W):
-            continue  # chained (sx_replay_core.hpp run_is_chained; the slice-end case of the -g form is covered by the stitch)
-        if want < E:
-            continue  # void: an earlier region ran over its start
-        o = RegionOut()
-        assert core.sxd_replay_region_host(C.byref(P), i, C.byref(o), fbuf, abuf, 8192, 1 << 21) == 0
-        if o.status == 3:
-            return None
-        arena = bytes(abuf[:o.n_bytes])
-        out += [(fbuf[k].position, sx.PRECISION[fbuf[k].precision],
-                 arena[fbuf[k].str_off:fbuf[k].str_off + fbuf[k].str_len].decode("utf-8"),
-                 bool(fbuf[k].completes_previous), fbuf[k].slice_index) for k in range(o.n_find)]
-        E = o.end
+    for c0, c1 in zip(cuts, cuts[1:]):
+        hi = ws(runs[c1][0], W) if c1 < n else len(data)
+        P = ReplayParams.from_buffer_copy(P0)
+        P.runs = C.cast(C.byref(P0._keep[0], c0 * C.sizeof(sx.Run)), C.POINTER(sx.Run))
+        P.n_runs, P.n_look, P.lo, P.hi = c1 - c0, n - c0, E, hi
+        for i in range(c0, c1):
+            want = ws(runs[i][0], W)
+            if i > c0 and chained(i):
+                continue  # chained (sx_replay_core.hpp run_is_chained; the slice-end case of the -g form is covered by the stitch)
+            if want < E or want >= hi:
+                continue  # void: an earlier region ran over its start / the next slab's
+            o = RegionOut()
+            assert core.sxd_replay_region_host(C.byref(P), i - c0, C.byref(o), fbuf, abuf, 8192, 1 << 21) == 0
+            if o.status == 3:
+                return None
+            arena = bytes(abuf[:o.n_bytes])
+            out += [(fbuf[k].position, sx.PRECISION[fbuf[k].precision],
+                     arena[fbuf[k].str_off:fbuf[k].str_off + fbuf[k].str_len].decode("utf-8"),
+                     bool(fbuf[k].completes_previous), fbuf[k].slice_index) for k in range(o.n_find)]
+            E = o.end
+        E = max(E, min(hi, len(data)))
     return out
 
 
@@ -248,6 +268,9 @@ def test_device_pipeline_emulated_on_cpu_equals_the_oracle(core, flags):
             continue
         want = [(p, pr, s, c, si) for p, pr, s, c, _, si in oracle_findings([m], data)]
         assert got == want, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want)))
+        for slabs in (2, 5, 16):   # the same replayed in slabs (sx_stage_b.cpp device_replay_mission)
+            got = emulate_device_stage_b(core, m, data, runs, slabs=slabs)
+            assert got == want, (slabs, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
         done += 1
     assert done > 0
 

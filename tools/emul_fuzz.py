@@ -27,12 +27,13 @@ while time.time() - t0 < budget:
         long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
         runs = sxo.runs(m, data, stream_parity=0, min_chars=long_run)
         for skip in (1, 0):
-            got = trc.emulate_device_stage_b(core, m, data, runs, skip=skip)
+            slabs = rng.choice([1, 1, 2, 3, 7, 20])   # the list replayed in slabs (sx_stage_b.cpp device_replay_mission)
+            got = trc.emulate_device_stage_b(core, m, data, runs, skip=skip, slabs=slabs)
             if got is None:
                 break
             want = [(p, pr, s, c_, si) for p, pr, s, c_, _, si in oracle_findings([dict(m, mission_id=0)], data)]
             if got != want:
-                print(f"MISMATCH emul seed {seed} case_seed {case_seed} mission {m} skip={skip}: {fuzz_case.describe(c)}")
+                print(f"MISMATCH emul seed {seed} case_seed {case_seed} mission {m} skip={skip} slabs={slabs}: {fuzz_case.describe(c)}")
                 print("  first diff", next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
                 sys.exit(1)
             checked += 1
