@@ -46,11 +46,26 @@ SXD bool run_is_chained(const ReplayParams& P, u64 i, u64 want) {
 //  (B) if no long run starts in the rest of this window, nothing is emitted up to its end and
 //      the state there is what a region start derives (derive_at), so the replay jumps there.
 // ------------------------------------------------------------------------------------------
+// A copy of the buffer bytes [lo, hi) that is cheaper to read than the buffer (the kernels: the window's staging row in
+// LDS, with the 16 bytes in front of the region's first window): the look-back walks below read single bytes, and from
+// global memory every one of them is a round trip the lane waits for.
+struct NearBytes {
+    const u8* p = nullptr;
+    u64 lo = 0, hi = 0;
+};
+struct ByteReader {
+    const u8* far;
+    NearBytes nr;
+    SXD u8 operator[](u64 pos) const { return pos - nr.lo < nr.hi - nr.lo ? nr.p[pos - nr.lo] : far[pos]; }
+    // a pointer to [pos, pos + n): the near copy if it holds all of it
+    SXD const u8* span(u64 pos, u64 n) const { return (pos >= nr.lo && pos + n <= nr.hi) ? nr.p + (pos - nr.lo) : far + pos; }
+};
+
 // Start of the decoder call that contains the char boundary rs, not before the call start p.
 // Returns p if everything in [p, rs) is valid (the call at p is the one).
 template <int ENC>
-SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs) {
-    const u8* bytes = P.data;
+SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs, NearBytes nr = NearBytes{}) {
+    const ByteReader bytes{ P.data, nr };
     u64 b = rs;
     if (ENC == 1) {
         while (b > p) {
@@ -113,7 +128,7 @@ SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs) {
             const u32 n = (u32)(rs - at < 12 ? rs - at : 12);
             u32 k = 0;
             for (;;) {
-                const DStep r = ddecode<ENC>(dd, bytes + at + k, n - k, sink, sizeof sink, false);
+                const DStep r = ddecode<ENC>(dd, P.data + at + k, n - k, sink, sizeof sink, false);
                 k += r.read;
                 if (r.result == RES_INPUT_EMPTY) break;
                 if (r.result == RES_MALFORMED) vs = at + k;
@@ -278,8 +293,9 @@ SXD u64 dbcs_sync_before(const u8* bytes, u64 len, u64 at, u64 floor, u32 skip0,
 // pressure down.  (Inlined twice into the 64-VGPR replay kernels, one variant — UTF-16BE, count only —
 // came out of the compiler wrong: results changed with the occupancy attribute alone.  See DESIGN.md §9.)
 template <int ENC>
-SXD_NOINLINE u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& dec, u8* ob) {
+SXD_NOINLINE u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& dec, u8* ob, NearBytes nr = NearBytes{}) {
     const u8* bytes = P.data;
+    const ByteReader rd{ P.data, nr };
     ddec_reset(dec, (int)P.encoding, P.table);
     // with -r the lead byte of the leftover's last multi-byte char matters (see RangeReplay::derive_state)
     const u64 back = P.same_block ? 4ull * P.long_run + 8 : 8;
@@ -292,9 +308,10 @@ SXD_NOINLINE u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& d
     u32 last_len = 0, mb_len = 0;
     while (p < at) {   // in pieces: the sink is small
         const u32 n = (u32)(at - p < 12 ? at - p : 12);
+        const u8* src = rd.span(p, n);
         u32 k = 0;
         for (;;) {
-            const DStep r = ddecode<ENC>(dec, bytes + p + k, n - k, sink, sizeof sink, false);
+            const DStep r = ddecode<ENC>(dec, src + k, n - k, sink, sizeof sink, false);
             k += r.read;
             for (u32 w = 0; w < r.written;) {
                 const u8 lead = sink[w];
@@ -321,6 +338,7 @@ SXD_NOINLINE u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& d
 
 constexpr u32 kObCap = 4 * 64 + 3 * 128 + 16;  // leftover (<= 4q bytes) + one window's output; q <= 64
 constexpr u32 kMaxWindow = 128;                 // W = 2q
+constexpr u32 kBackBytes = 16;                  // of the buffer in front of a region's first window, staged with it (derive_at looks back 8)
 
 // Copy of one window into private memory: 16 bytes per load where the source is aligned (it is, in the
 // default geometry: buffers are 256-byte aligned and W = 128), bytes otherwise.
@@ -379,19 +397,27 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
     const u32 W = P.W;
     const u64 want = win_start(P.runs[i].start, W);
     u8 ob[kObCap];
-    alignas(16) u8 win_own[EXT_WIN ? 16 : kMaxWindow];
-    u8* const win = EXT_WIN ? win_ext : win_own;
+    // the staging row: [kBackBytes in front of the region's first window][the window]
+    alignas(16) u8 win_own[EXT_WIN ? 16 : kMaxWindow + kBackBytes];
+    u8* const row = EXT_WIN ? win_ext : win_own;
+    u8* const win = row + kBackBytes;
     u64 staged = ~0ull;
+    NearBytes near;   // what of the buffer the row holds right now
     DDecoder dec;
 
     // ---- derive the state the reference would carry into `want` (RangeReplay::derive_state)
+    if (want >= kBackBytes) {   // the look-back of derive_at reads the row, not the buffer
+        if (EXT_WIN) stage_window_words(bytes + want - kBackBytes, kBackBytes, row);
+        else stage_window(bytes + want - kBackBytes, kBackBytes, row);
+        near.p = row; near.lo = want - kBackBytes; near.hi = want;
+    }
     u32 leftover_len;
     bool maybe_cut = false;
     if (P.runs[i].chars & kPieceCont) {   // a window start inside a run: the state is a function of the run (see kPieceCont)
         const u64 delta = P.runs[i].chars & ~kPieceCont;
         if (delta < 4ull * P.q) leftover_len = derive_in_run<ENC>(P.q, P.encoding, P.table, bytes + (want - delta), (u32)delta, dec, ob, kObCap, &maybe_cut);
-        else { (void)derive_at<ENC>(P, want, 0, dec, ob); leftover_len = 0; maybe_cut = true; }
-    } else leftover_len = derive_at<ENC>(P, want, 0, dec, ob);
+        else { (void)derive_at<ENC>(P, want, 0, dec, ob, near); leftover_len = 0; maybe_cut = true; }
+    } else leftover_len = derive_at<ENC>(P, want, 0, dec, ob, near);
 
     u64 ri = i;  // first run not yet behind us
     u32 n_find = 0, n_bytes = 0, windows = 0;
@@ -441,6 +467,16 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
             const u32 wb = din;  // window start (din moves on inside the window)
             u32 dout = leftover_len;
             for (;;) {  // 'decoder
+                // the window's bytes go through a copy made with 16-byte loads (the kernels: a row in LDS): the decoders
+                // and the look-back walks of the shortcuts read byte by byte, and a byte load per lane from 64 different
+                // cache lines is the slowest way to read
+                if (staged != soff + wb) {
+                    if (EXT_WIN) stage_window_words(bytes + soff + wb, dend - wb, win);
+                    else stage_window(bytes + soff + wb, dend - wb, win);
+                    staged = soff + wb;
+                    if (near.p == row && staged == want) near.hi = soff + dend;   // the first window: the row holds the bytes in front of it too
+                    else { near.p = win; near.lo = staged; near.hi = soff + dend; }
+                }
                 if (P.skip && leftover_len == 0 && !maybe_cut && din < dend && ddec_idle<ENC>(dec)) {
                     const u64 p = soff + din, wend = soff + dend;
                     while (ri < n_look && P.runs[ri].end <= p) ri++;
@@ -454,22 +490,15 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
                             ddec_reset(dec, (int)P.encoding, P.table);
                             break;
                         }
-                        leftover_len = derive_at<ENC>(P, wend, p, dec, ob);
+                        leftover_len = derive_at<ENC>(P, wend, p, dec, ob, near);
                         dout = leftover_len;
                         din = dend;
                         break;
                     }
                     if (rs > p) {      // (A) jump to the call that holds the next long run
-                        const u64 vs = call_start_before<ENC>(P, p, rs);
+                        const u64 vs = call_start_before<ENC>(P, p, rs, near);
                         if (vs > p) din = (u32)(vs - soff);
                     }
-                }
-                // the window's bytes go through a private copy made with 16-byte loads: the decoders read byte
-                // by byte, and a byte load per lane from 64 different cache lines is the slowest way to read
-                if (staged != soff + wb) {
-                    if (EXT_WIN) stage_window_words(bytes + soff + wb, dend - wb, win);
-                    else stage_window(bytes + soff + wb, dend - wb, win);
-                    staged = soff + wb;
                 }
                 const DStep r = ddecode<ENC>(dec, win + (din - wb), dend - din, ob + dout, kObCap - dout, false);
                 if (r.result == RES_OUTPUT_FULL) { status = kRegionTooLong; done = true; break; }

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WA
 // Pass 1 with the output cache: one lane per replaying run (on dense input half of the runs are chained: no idle lanes).
 // The window's staging copy lies in LDS, one row per lane (win_row_bytes: an odd number of dwords, the rows start in
 // different banks) — as a private array it is scratch memory, and the scratch of all resident waves is far larger than L2.
-__host__ __device__ inline u32 win_row_bytes(u32 W) { return (((W + 3) / 4) | 1u) * 4; }
+__host__ __device__ inline u32 win_row_bytes(u32 W) { return (((W + kBackBytes + 3) / 4) | 1u) * 4; }
 template <int ENC, int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void replay_count_cached_kernel(
     const ReplayParams P, ReplayRegionOut* out) {
