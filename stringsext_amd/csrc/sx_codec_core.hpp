@@ -222,7 +222,7 @@ SXD DStep ddec_big5(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool la
             if (last && d.dlead) { d.dlead = 0; return { RES_MALFORMED, i, w }; }
             return { RES_INPUT_EMPTY, i, w };
         }
-        if (cap - w < 8) return { RES_OUTPUT_FULL, i, w };
+        if (cap - w < 4) return { RES_OUTPUT_FULL, i, w };   // an astral character, or Big5's two code points (2 + 2 bytes): as the other two-byte decoders
         const u8 b = src[i];
         if (d.dlead == 0) {
             i++;

@@ -65,7 +65,8 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
     uint64_t* h_tot = nullptr;
     ReplayRegionOut* ro = nullptr;
     {
-        int rc = ensure_pinned2(ctx, n * sizeof(ReplayRegionOut) + 256);
+        // (the regions' records only travel to the host when it decides what stands: 24 bytes per run, 6 GB for C5's floods)
+        int rc = ensure_pinned2(ctx, (dev_stitch ? 0 : n * sizeof(ReplayRegionOut)) + 256);
         if (rc != SX_OK) return rc;
         h_tot = (uint64_t*)ctx->h_pin2;
         ro = (ReplayRegionOut*)(ctx->h_pin2 + 128);
@@ -165,6 +166,10 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
     if (dev_stitch && h_tot[kTotTooLong]) {  // regions for the host: it also decides what stands
         dev_stitch = false;
         HIP_TRY(ctx, runs.wait());
+        int rc = ensure_pinned2(ctx, n * sizeof(ReplayRegionOut) + 256);
+        if (rc != SX_OK) return rc;
+        h_tot = (uint64_t*)ctx->h_pin2;   // (its values are not read again)
+        ro = (ReplayRegionOut*)(ctx->h_pin2 + 128);
         HIP_TRY(ctx, hipMemcpyAsync(ro, d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream_b));
         HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
     }

@@ -178,6 +178,23 @@ def test_host_replay_equals_oracle(enc, flags):
 
 
 @pytest.mark.parametrize("enc", ENCS)
+def test_slice_start_probe_compares_two_characters(enc):
+    """finding_collection.rs:176-207: a slice whose first character is completed from a lead byte of the slice before is
+    marked `<` when a fresh decoder yields something else for the slice's first 8 output bytes.  The first character can
+    coincide — lead L pending, slice = L L B ...: the true tokens are (L L)(L B), a fresh decoder sees (L L)(B L) — so
+    the second one decides, and the 8-byte probe buffer must hold two characters for every decoder of this family
+    (found by tools/gpu_fuzz.py: the product's two-byte decoder wanted 8 free bytes per character, the oracle's 4)."""
+    ms = rc.missions(encodings=[enc], chars_min="2", unicode_block_filter=ALL, ascii_filter="All-Ctrl")
+    for L, B in ((0xA4, 0xED), (0xB0, 0xA1), (0x88, 0x62), (0xE0, 0x9F)):
+        body = bytes([L, L, B, L, B, L, B, L, B, L, B]) + b" and so on\n"
+        for pad in (4095, 4094):   # pad 4094: the grid falls the other way
+            data = b"x" * pad + bytes([L]) + body + b"\x00" * 64
+            want = sxo.run_cli(ms, [data], radix="x")
+            for chunk in (None, 4096):
+                assert run_cli_product(ms, [data], radix="x", chunk_bytes=chunk) == want, (hex(L), hex(B), pad, chunk)
+
+
+@pytest.mark.parametrize("enc", ENCS)
 def test_tokens_across_chunk_and_file_boundaries(enc):
     """A token cut by a chunk boundary (lead | trail, 8F | xx | xx) is finished from the carried decoder; the token
     grid of the next chunk starts behind it; the state is carried over file boundaries as in the reference."""

@@ -143,3 +143,17 @@ def test_c2_4gib_windows_equal_oracle():
     ms = product_missions(encodings=["utf-8"], chars_min="10")
     compared, total = check_windows(ms, 4 << 30, True, 6, 4)
     assert total > 200_000 and compared > 6 * 3000        # ~59 findings per MiB
+
+
+C5 = dict(encodings=["utf-8,,,African", "utf-16le,,,African", "utf-16be,,,African", "big5,,,Cjk", "euc-jp,,,Asian", "koi8-r,,,Cyrillic"],
+          chars_min="10")
+
+
+def test_c5_64gib_windows_equal_oracle():
+    """BASELINE config 5 at its full size: on the synthetic background the double-byte and KOI8-R Missions produce a flood
+    (411 M findings, 19 GB) — the scale at which the outputs stay on the device, pass 1's cache takes tens of GiB and the
+    merger runs on the device in several parts (one result segment each, str_off restarting per segment).  Windows across
+    2^32 and 2^33, at the buffer's end and at a random place must equal the oracle finding by finding."""
+    ms = product_missions(**C5)
+    compared, total = check_windows(ms, 64 << 30, False, 4, 5)
+    assert total > 300_000_000 and compared > 4 * 300_000
