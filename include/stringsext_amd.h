@@ -65,6 +65,7 @@ enum {
     SX_ENC_X_MAC_CYRILLIC = 43,
     /* legacy multi-byte (tables: csrc/gen_tables.py; parity unpinned): a pending lead byte is the decoder state */
     SX_ENC_BIG5 = 64, SX_ENC_EUC_JP = 65, SX_ENC_SHIFT_JIS = 66, SX_ENC_EUC_KR = 67,
+    SX_ENC_GB18030 = 68, SX_ENC_GBK = 69,   /* one decoder (four-byte tokens too), two names */
     /* the "replacement" encoding (ISO-2022-KR, ISO-2022-CN, HZ-GB-2312): its decoder reports one error and nothing else */
     SX_ENC_REPLACEMENT = 70
 };

@@ -142,6 +142,27 @@ def euc_kr():
     return t
 
 
+GB_N = 126 * 190
+
+
+def gb18030():
+    """index gb18030 and its ranges from the ICU dump; 0xA3A0 = U+3000 as in the WHATWG index (ICU and CPython: U+E5E5, the
+    GB18030 private-use assignment); everything else as ICU has it (0xA8BC = U+1E3F, pointer 7457 = U+E7C7: the WHATWG version)"""
+    cells = [0] * GB_N
+    for line in open(os.path.join(TAB, "icu_gb18030.txt")):
+        k, v = line.split()
+        key = int(k, 16)
+        lead, trail = key >> 8, key & 0xFF
+        cells[(lead - 0x81) * 190 + (trail - (0x40 if trail < 0x7F else 0x41))] = int(v, 16)
+    cells[(0xA3 - 0x81) * 190 + (0xA0 - 0x41)] = 0x3000
+    ptrs, starts = [], []
+    for line in open(os.path.join(TAB, "icu_gb18030_ranges.txt")):
+        a, b = line.split()
+        assert b != "-", "a four-byte pointer below 39420 without mapping"
+        ptrs.append(int(a)); starts.append(int(b, 16))
+    return cells, ptrs, starts
+
+
 def emit_array(fh, ctype, name, values, per_line, width):
     fh.write(f"static const {ctype} {name}[{len(values)}] = {{\n")
     for i in range(0, len(values), per_line):
@@ -174,6 +195,11 @@ def emit(path):
         fh.write(f"#define SXO_SJIS_N {SJIS_N}\n#define SXO_EUCKR_N {EUCKR_N}\n")
         emit_array(fh, "uint16_t", "sxo_sjis", shift_jis(), 16, 4)
         emit_array(fh, "uint16_t", "sxo_euckr", euc_kr(), 16, 4)
+        cells, ptrs, starts = gb18030()
+        fh.write(f"#define SXO_GB_N {GB_N}\n#define SXO_GB_RANGES {len(ptrs)}\n")
+        emit_array(fh, "uint16_t", "sxo_gb18030", cells, 16, 4)
+        emit_array(fh, "uint16_t", "sxo_gb_range_ptr", ptrs, 16, 4)
+        emit_array(fh, "uint16_t", "sxo_gb_range_cp", starts, 16, 4)
 
 
 if __name__ == "__main__":

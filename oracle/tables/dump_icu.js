@@ -52,3 +52,20 @@ write('icu_euc_jp.txt', ej);
 write('icu_shift_jis.txt', two('shift_jis', null, range(0x81, 0x9F).concat(range(0xE0, 0xFC)), range(0x40, 0x7E).concat(range(0x80, 0xFC))));
 write('icu_euc_kr.txt', two('euc-kr', null, range(0x81, 0xFE), range(0x41, 0xFE)).filter(l => l.indexOf('+') < 0));
 console.log('ICU', process.versions.icu, 'Unicode', process.versions.unicode);
+// gb18030 (GBK is the same decoder): the two-byte index (leads 81..FE, trails 40..7E and 80..FE) and the four-byte
+// sequences below pointer 39420 (the BMP ranges), written as breakpoints: "<pointer> <code point>" where the linear
+// run cp = cp0 + (pointer - pointer0) begins; "<pointer> -" where a stretch without mapping begins.
+{
+  write('icu_gb18030.txt', two('gb18030', null, range(0x81, 0xFE), range(0x40, 0x7E).concat(range(0x80, 0xFE))).filter(l => l.indexOf('+') < 0));
+  const d = dec('gb18030'), out = [];
+  let prev = null, prevp = -2;
+  for (let p = 0; p < 39420; p++) {
+    const b = [0x81 + Math.floor(p / 12600), 0x30 + Math.floor(p / 1260) % 10, 0x81 + Math.floor(p / 10) % 126, 0x30 + p % 10];
+    const r = cps(d, b);
+    const cp = (r && r.length == 1) ? r[0] : null;
+    if (cp === null) { if (prev !== null || p == 0) out.push(p + ' -'); }
+    else if (prev === null || cp != prev + 1 || prevp != p - 1) out.push(p + ' ' + hex(cp, 4));
+    prev = cp; prevp = p;
+  }
+  write('icu_gb18030_ranges.txt', out);
+}

@@ -155,6 +155,35 @@ def euc_kr_table():
     return t
 
 
+GB_N = 126 * 190
+GB_RANGE_LIMIT = 39420   # four-byte pointers below this are in the BMP ranges; 189000.. are U+10000..
+
+
+def gb18030_tables():
+    """index gb18030 (two-byte cells) and index gb18030 ranges as breakpoints (pointer, code point), from CPython's
+    gb18030 codec, patched to the WHATWG indexes: 0xA8BC = U+1E3F with four-byte pointer 7457 = U+E7C7 (CPython has
+    the GB18030-2000 assignment the other way round; ICU agrees with WHATWG), 0xA3A0 = U+3000 (both sources: U+E5E5)."""
+    cells = [0] * GB_N
+    for lead in range(0x81, 0xFF):
+        for trail in list(range(0x40, 0x7F)) + list(range(0x80, 0xFF)):
+            v = cps("gb18030", [lead, trail])
+            if v and len(v) == 1:
+                cells[(lead - 0x81) * 190 + (trail - (0x40 if trail < 0x7F else 0x41))] = v[0]
+    cells[(0xA8 - 0x81) * 190 + (0xBC - 0x41)] = 0x1E3F
+    cells[(0xA3 - 0x81) * 190 + (0xA0 - 0x41)] = 0x3000
+    cp4 = []
+    for p in range(GB_RANGE_LIMIT):
+        v = cps("gb18030", [0x81 + p // 12600, 0x30 + (p // 1260) % 10, 0x81 + (p // 10) % 126, 0x30 + p % 10])
+        assert v and len(v) == 1, p
+        cp4.append(v[0])
+    cp4[7457] = 0xE7C7
+    ptrs, starts = [], []
+    for p, cp in enumerate(cp4):
+        if p == 0 or cp != cp4[p - 1] + 1:
+            ptrs.append(p); starts.append(cp)
+    return cells, ptrs, starts
+
+
 def emit_array(fh, ctype, name, values, per_line, width):
     fh.write(f"static const {ctype} {name}[{len(values)}] = {{\n")
     for i in range(0, len(values), per_line):
@@ -194,6 +223,10 @@ def emit(prefix, fh):
     fh.write(f"#define {prefix.upper()}_SJIS_N {SJIS_N}\n#define {prefix.upper()}_EUCKR_N {EUCKR_N}\n")
     emit_array(fh, "uint16_t", f"{prefix}_sjis", shift_jis_table(), 16, 4)
     emit_array(fh, "uint16_t", f"{prefix}_euckr", euc_kr_table(), 16, 4)
+    # gb18030 / GBK: [GB_N two-byte cells][GB_RANGES breakpoint pointers][GB_RANGES code points]
+    cells, ptrs, starts = gb18030_tables()
+    fh.write(f"#define {prefix.upper()}_GB_N {GB_N}\n#define {prefix.upper()}_GB_RANGES {len(ptrs)}\n")
+    emit_array(fh, "uint16_t", f"{prefix}_gb18030", cells + ptrs + starts, 16, 4)
 
 
 if __name__ == "__main__":

@@ -29,27 +29,33 @@ struct DStep { int result; u32 read, written; };
 // 3 UTF-16BE, 4 Big5, 5 EUC-JP, 0 every single-byte encoding (SX_ENC_* 16.., x-user-defined).
 // Family 4 = the two-byte encodings (Big5, Shift_JIS, EUC-KR: a lead byte and one more; which one is a run-time
 // value), family 5 = EUC-JP (three-byte tokens too).
-constexpr int kEncBig5 = 64, kEncEucJp = 65, kEncShiftJis = 66, kEncEucKr = 67;  // == SX_ENC_* (include/stringsext_amd.h)
+constexpr int kEncBig5 = 64, kEncEucJp = 65, kEncShiftJis = 66, kEncEucKr = 67, kEncGb18030 = 68, kEncGbk = 69;  // == SX_ENC_* (include/stringsext_amd.h)
+constexpr bool enc_is_gb(int e) { return e == kEncGb18030 || e == kEncGbk; }   // GBK decodes as gb18030
 constexpr int enc_family(u32 encoding) {
     return encoding == 1 ? 1 : encoding == 2 ? 2 : encoding == 3 ? 3
-         : (encoding == (u32)kEncBig5 || encoding == (u32)kEncShiftJis || encoding == (u32)kEncEucKr) ? 4 : encoding == (u32)kEncEucJp ? 5 : 0;
+         : (encoding == (u32)kEncBig5 || encoding == (u32)kEncShiftJis || encoding == (u32)kEncEucKr || enc_is_gb((int)encoding)) ? 4 : encoding == (u32)kEncEucJp ? 5 : 0;
 }
 // Layout of the double-byte tables (csrc/gen_tables.py): one uint16_t blob per encoding.
 //   Big5: [kBig5N low halves][kBig5P2Words plane-2 bitmap];  EUC-JP: [kJisN jis0208][kJisN jis0212];
 //   Shift_JIS: [kSjisN: index jis0208 up to the IBM extension rows];  EUC-KR: [kEucKrN].
+//   gb18030 / GBK: [kGbN two-byte cells][kGbRanges breakpoint pointers][kGbRanges code points] (index gb18030 ranges).
 constexpr u32 kBig5N = 126 * 157, kBig5P2Words = (kBig5N + 15) / 16, kJisN = 94 * 94, kSjisN = 11280, kEucKrN = 126 * 190;
+constexpr u32 kGbN = 126 * 190, kGbRanges = 208;
 
 struct DDecoder {
     int enc;
     u32 cp; u8 seen, needed, lower, upper;               // UTF-8
     int lead_byte; u32 lead_surrogate; bool pending_bmp;  // UTF-16
     u8 dlead, dflag;                                      // Big5 / EUC-JP: pending lead byte; EUC-JP: the lead is the 2nd byte of 8F xx
+    // gb18030 (family 4 with four-byte tokens): dlead = "gb18030 first", gb2 / gb3 = second / third; rq = bytes the algorithm
+    // "prepends to the stream" that an EARLIER call consumed: they are decoded again in front of the next call's input
+    u8 gb2, gb3, rq[2], rq_n;
     const uint16_t* table;  // single byte: 128 entries (nullptr = x-user-defined); Big5 / EUC-JP: the blob
 };
 
 SXD void ddec_reset(DDecoder& d, int enc, const uint16_t* table) {
     d.enc = enc; d.cp = 0; d.seen = d.needed = 0; d.lower = 0x80; d.upper = 0xBF;
-    d.lead_byte = -1; d.lead_surrogate = 0; d.pending_bmp = false; d.dlead = 0; d.dflag = 0; d.table = table;
+    d.lead_byte = -1; d.lead_surrogate = 0; d.pending_bmp = false; d.dlead = 0; d.dflag = 0; d.gb2 = d.gb3 = 0; d.rq[0] = d.rq[1] = 0; d.rq_n = 0; d.table = table;
 }
 
 SXD u32 dput_cp(u8* d, u32 c) {
@@ -199,6 +205,91 @@ SXD u32 euckr_lookup(const uint16_t* t, u32 lead, u32 trail) {
     if (trail < 0x41 || trail > 0xFE) return 0;
     return t[(lead - 0x81) * 190 + (trail - 0x41)];
 }
+// gb18030 / GBK (WHATWG "gb18030 decoder"): two-byte cells, and the four-byte pointers through index gb18030 ranges
+SXD u32 gb_lookup(const uint16_t* t, u32 lead, u32 trail) {
+    if (trail < 0x40 || trail == 0x7F || trail > 0xFE) return 0;
+    return t[(lead - 0x81) * 190 + (trail - (trail < 0x7F ? 0x40u : 0x41u))];
+}
+SXD u32 gb_ranges_cp(const uint16_t* t, u32 pointer) {   // 0 = null
+    if ((pointer > 39419 && pointer < 189000) || pointer > 1237575) return 0;
+    if (pointer == 7457) return 0xE7C7;
+    if (pointer >= 189000) return 0x10000 + (pointer - 189000);
+    const uint16_t* ptr = t + kGbN;
+    const uint16_t* cp = ptr + kGbRanges;
+    u32 lo = 0, hi = kGbRanges;   // the last breakpoint at or below pointer
+    while (hi - lo > 1) { const u32 mid = (lo + hi) / 2; if (ptr[mid] <= pointer) lo = mid; else hi = mid; }
+    return (u32)cp[lo] + (pointer - ptr[lo]);
+}
+SXD bool gb_digit(u8 b) { return b >= 0x30 && b <= 0x39; }
+
+// The stream a call sees is [re-queued bytes..., src...] (position j < 0: in the queue).  "Prepend to the stream": what this call
+// consumed is un-read (j goes back, possibly into the queue again); what an earlier call consumed is queued for the next call.
+SXD DStep ddec_gb18030(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {
+    const int q0 = d.rq_n;
+    const u8 q[2] = { d.rq[0], d.rq[1] };
+    int j = -q0;
+    const int j0 = j;
+    u32 w = 0;
+    d.rq_n = 0;
+    // leave with result r: positions below 0 that were not consumed stay queued
+    auto leave = [&](int r) -> DStep {
+        if (j < 0) { d.rq_n = (u8)(-j); for (int t = 0; t < -j; t++) d.rq[t] = q[q0 + j + t]; j = 0; }
+        return { r, (u32)j, w };
+    };
+    // give back the last k bytes of the stream (the current byte and the pending ones before it); pre = the pending ones
+    auto prepend = [&](int k, u8 p1, u8 p2) -> bool {   // true: bytes of an earlier call were queued (then j >= 0)
+        const int c = (j - j0) < k ? (j - j0) : k;
+        j -= c;
+        if (k - c <= 0) return false;
+        const u8 pre[2] = { p1, p2 };
+        d.rq_n = (u8)(k - c);
+        for (int t = 0; t < k - c; t++) d.rq[t] = pre[(k == 3 ? 0 : 1) + t];
+        return true;
+    };
+    for (;;) {
+        if (j >= (int)n) {
+            if (last && (d.dlead || d.gb2 || d.gb3)) { d.dlead = d.gb2 = d.gb3 = 0; return leave(RES_MALFORMED); }
+            return leave(RES_INPUT_EMPTY);
+        }
+        if (cap - w < 4) return leave(RES_OUTPUT_FULL);
+        const u8 b = j < 0 ? q[q0 + j] : src[j];
+        j++;
+        if (d.gb3) {
+            if (!gb_digit(b)) {
+                const u8 b2 = d.gb2, b3 = d.gb3;
+                d.dlead = d.gb2 = d.gb3 = 0;
+                if (prepend(3, b2, b3)) return { RES_MALFORMED, (u32)j, w };
+                return leave(RES_MALFORMED);
+            }
+            const u32 pointer = (u32)(d.dlead - 0x81) * 12600u + (u32)(d.gb2 - 0x30) * 1260u + (u32)(d.gb3 - 0x81) * 10u + (b - 0x30);
+            d.dlead = d.gb2 = d.gb3 = 0;
+            const u32 cp = gb_ranges_cp(d.table, pointer);
+            if (!cp) return leave(RES_MALFORMED);
+            w += dput_cp(dst + w, cp);
+            continue;
+        }
+        if (d.gb2) {
+            if (b >= 0x81 && b <= 0xFE) { d.gb3 = b; continue; }
+            const u8 b2 = d.gb2;
+            d.dlead = d.gb2 = 0;
+            if (prepend(2, 0, b2)) return { RES_MALFORMED, (u32)j, w };
+            return leave(RES_MALFORMED);
+        }
+        if (d.dlead) {
+            if (gb_digit(b)) { d.gb2 = b; continue; }
+            const u32 cp = gb_lookup(d.table, d.dlead, b);
+            d.dlead = 0;
+            if (cp) { w += dput_cp(dst + w, cp); continue; }
+            if (b < 0x80) (void)prepend(1, 0, 0);
+            return leave(RES_MALFORMED);
+        }
+        if (b < 0x80) { dst[w++] = b; continue; }
+        if (b == 0x80) { w += dput_cp(dst + w, 0x20AC); continue; }
+        if (b <= 0xFE) { d.dlead = b; continue; }
+        return leave(RES_MALFORMED);   // 0xFF
+    }
+}
+
 // the two-byte family: is b a lead byte / which character is (lead, trail) / which character is a single byte >= 0x80
 SXD bool two_byte_lead(int enc, u8 b) {
     if (enc == kEncShiftJis) return (b >= 0x81 && b <= 0x9F) || (b >= 0xE0 && b <= 0xFC);
@@ -208,14 +299,17 @@ SXD u32 two_byte_lookup(int enc, const uint16_t* t, u32 lead, u32 trail, u32* se
     *second = 0;
     if (enc == kEncShiftJis) return sjis_lookup(t, lead, trail);
     if (enc == kEncEucKr) return euckr_lookup(t, lead, trail);
+    if (enc_is_gb(enc)) return gb_lookup(t, lead, trail);
     return big5_lookup(t, lead, trail, second);
 }
 SXD u32 two_byte_single(int enc, u8 b) {   // b >= 0x80 and not a lead byte: its character, 0 = malformed
     if (enc == kEncShiftJis) return b == 0x80 ? 0x80u : (b >= 0xA1 && b <= 0xDF) ? 0xFF61u - 0xA1u + b : 0u;
+    if (enc_is_gb(enc)) return b == 0x80 ? 0x20ACu : 0u;
     return 0;
 }
 
-SXD DStep ddec_big5(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {   // Big5, Shift_JIS, EUC-KR
+SXD DStep ddec_big5(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {   // Big5, Shift_JIS, EUC-KR (and gb18030: its own function)
+    if (enc_is_gb(d.enc)) return ddec_gb18030(d, src, n, dst, cap, last);
     u32 i = 0, w = 0;
     for (;;) {
         if (i >= n) {
@@ -300,11 +394,11 @@ template <int ENC>
 SXD bool ddec_idle(const DDecoder& d) {
     if (ENC == 1) return d.needed == 0;
     if (ENC == 2 || ENC == 3) return d.lead_byte < 0 && d.lead_surrogate == 0 && !d.pending_bmp;
-    if (ENC == 4 || ENC == 5) return d.dlead == 0;
+    if (ENC == 4 || ENC == 5) return d.dlead == 0 && d.gb2 == 0 && d.rq_n == 0;
     return true;
 }
 SXD bool ddec_idle_any(const DDecoder& d) {
-    return d.needed == 0 && d.lead_byte < 0 && d.lead_surrogate == 0 && !d.pending_bmp && d.dlead == 0;
+    return d.needed == 0 && d.lead_byte < 0 && d.lead_surrogate == 0 && !d.pending_bmp && d.dlead == 0 && d.gb2 == 0 && d.rq_n == 0;
 }
 
 // Token grammar of the double-byte encodings, used to find a character boundary without context:
@@ -317,9 +411,24 @@ SXD bool dbcs_is_lead_range(u8 b, int enc) {
 }
 // length of the token that starts at s[0] when the decoder is neutral there (`avail` bytes are readable;
 // a token cut short by the end of the input reports the full length it would have)
+// ... with one exception, gb18030: an ASCII digit after a lead byte is the second byte of a four-byte token (or the lead is
+// an error on its own and the digit is read again): the decoder is neutral after a byte that is neither in the lead range
+// nor a digit.  "Could the decoder be in the middle of a token after b?"
+template <int ENC>
+SXD bool dbcs_may_be_pending_after(u8 b, int enc) {
+    if (ENC == 4 && enc_is_gb(enc)) return two_byte_lead(enc, b) || gb_digit(b);
+    return dbcs_is_lead_range<ENC>(b, enc);
+}
 template <int ENC>
 SXD u32 dbcs_token_len(const u8* s, u64 avail, int enc) {
     if (!dbcs_is_lead_range<ENC>(s[0], enc)) return 1;
+    if (ENC == 4 && enc_is_gb(enc) && avail >= 2 && gb_digit(s[1])) {
+        // lead digit lead digit: four bytes (cut short by the end of the input: the length it would have); else the lead alone is
+        // the error and the digit is read again
+        if (avail >= 3 && !(s[2] >= 0x81 && s[2] <= 0xFE)) return 1;
+        if (avail >= 4 && !gb_digit(s[3])) return 1;
+        return 4;
+    }
     if (ENC == 5 && s[0] == 0x8F && avail >= 2 && s[1] >= 0xA1 && s[1] <= 0xFE) return 3;
     return 2;
 }
@@ -328,6 +437,20 @@ SXD u32 dbcs_token_len(const u8* s, u64 avail, int enc) {
 // will be given back because the token is malformed and that byte is ASCII).
 template <int ENC>
 SXD u32 dbcs_entry_skip(const DDecoder& d, const u8* s, u64 avail) {
+    if (ENC == 4 && enc_is_gb(d.enc)) {
+        if ((d.dlead == 0 && d.gb2 == 0 && d.rq_n == 0) || avail == 0) return 0;
+        // ask the decoder: the shortest prefix of s after which it is neutral again, or the bytes it keeps when the
+        // pending token ends in an error (what it gives back is not counted: read shrinks)
+        u8 sink[32];
+        const u32 lim = avail < 4 ? (u32)avail : 4u;
+        for (u32 m = 1; m <= lim; m++) {
+            DDecoder c = d;
+            const DStep r = ddec_gb18030(c, s, m, sink, sizeof sink, false);
+            if (r.result == RES_MALFORMED) return r.read;
+            if (c.dlead == 0 && c.gb2 == 0 && c.rq_n == 0) return m;
+        }
+        return lim;
+    }
     if (d.dlead == 0 || avail == 0) return 0;
     const u8 b = s[0];
     if (ENC == 4) {

@@ -11,7 +11,7 @@ namespace sx {
 #include "sx_tables.inc"
 
 static_assert(SX_BIG5_N == kBig5N && SX_BIG5_P2_WORDS == kBig5P2Words && SX_JIS_N == kJisN, "table layout");
-static_assert(SX_ENC_BIG5 == kEncBig5 && SX_ENC_EUC_JP == kEncEucJp && SX_ENC_SHIFT_JIS == kEncShiftJis && SX_ENC_EUC_KR == kEncEucKr, "encoding ids");
+static_assert(SX_ENC_BIG5 == kEncBig5 && SX_ENC_EUC_JP == kEncEucJp && SX_ENC_SHIFT_JIS == kEncShiftJis && SX_ENC_EUC_KR == kEncEucKr && SX_ENC_GB18030 == kEncGb18030 && SX_ENC_GBK == kEncGbk, "encoding ids");
 static_assert(SX_ENC_REPLACEMENT == kEncReplacement, "encoding ids");
 static_assert(SX_SJIS_N == kSjisN && SX_EUCKR_N == kEucKrN, "table layout");
 
@@ -27,6 +27,7 @@ const uint16_t* decoder_table(int enc, size_t* n_words) {
     else if (enc == SX_ENC_EUC_JP) { t = sx_eucjp; n = sizeof sx_eucjp / sizeof sx_eucjp[0]; }
     else if (enc == SX_ENC_SHIFT_JIS) { t = sx_sjis; n = sizeof sx_sjis / sizeof sx_sjis[0]; }
     else if (enc == SX_ENC_EUC_KR) { t = sx_euckr; n = sizeof sx_euckr / sizeof sx_euckr[0]; }
+    else if (enc == SX_ENC_GB18030 || enc == SX_ENC_GBK) { t = sx_gb18030; n = sizeof sx_gb18030 / sizeof sx_gb18030[0]; }
     else if ((t = single_byte_table(enc)) != nullptr) n = 128;
     if (n_words) *n_words = n;
     return t;
@@ -47,6 +48,8 @@ const char* encoding_name(int enc) {
     case SX_ENC_EUC_JP: return "EUC-JP";
     case SX_ENC_SHIFT_JIS: return "Shift_JIS";
     case SX_ENC_EUC_KR: return "EUC-KR";
+    case SX_ENC_GB18030: return "gb18030";
+    case SX_ENC_GBK: return "GBK";
     case SX_ENC_REPLACEMENT: return "replacement";
     default:
         if (enc >= SX_ENC_KOI8_R && enc < SX_ENC_KOI8_R + SX_N_SB_TABLES) return sx_sb_names[enc - SX_ENC_KOI8_R];
@@ -72,6 +75,19 @@ uint32_t Decoder::entry_skip(const uint8_t* s, uint64_t avail) const {
     case 5: return dbcs_entry_skip<5>(d_, s, avail);
     default: return 0;
     }
+}
+
+uint32_t Decoder::entry_skip_scan(const uint8_t* s, uint64_t avail) const {
+    if (!enc_is_gb(d_.enc)) return entry_skip(s, avail);
+    if (avail == 0) return 0;
+    // the lead byte that is pending in the kernel's grammar: the third byte of a four-byte token, a lead waiting in the queue,
+    // or a plain pending lead (lead + digit: the digit was a token of its own)
+    uint8_t x = 0;
+    if (d_.gb3) x = d_.gb3;
+    else if (d_.rq_n) x = two_byte_lead(d_.enc, d_.rq[d_.rq_n - 1]) ? d_.rq[d_.rq_n - 1] : 0;
+    else if (!d_.gb2) x = d_.dlead;
+    if (!x) return 0;
+    return (gb_lookup(d_.table, x, s[0]) || s[0] >= 0x80) ? 1u : 0u;
 }
 
 // SplitStr::next — src/helper.rs:206-433

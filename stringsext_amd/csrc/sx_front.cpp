@@ -226,13 +226,14 @@ const Label kLabels[] = {
     { "cseuckr", SX_ENC_EUC_KR }, { "csksc56011987", SX_ENC_EUC_KR }, { "euc-kr", SX_ENC_EUC_KR }, { "iso-ir-149", SX_ENC_EUC_KR },
     { "korean", SX_ENC_EUC_KR }, { "ks_c_5601-1987", SX_ENC_EUC_KR }, { "ks_c_5601-1989", SX_ENC_EUC_KR }, { "ksc5601", SX_ENC_EUC_KR },
     { "ksc_5601", SX_ENC_EUC_KR }, { "windows-949", SX_ENC_EUC_KR },
+    { "chinese", SX_ENC_GBK }, { "csgb2312", SX_ENC_GBK }, { "csiso58gb231280", SX_ENC_GBK }, { "gb2312", SX_ENC_GBK }, { "gb_2312", SX_ENC_GBK },
+    { "gb_2312-80", SX_ENC_GBK }, { "gbk", SX_ENC_GBK }, { "iso-ir-58", SX_ENC_GBK }, { "x-gbk", SX_ENC_GBK }, { "gb18030", SX_ENC_GB18030 },
     { "csiso2022kr", SX_ENC_REPLACEMENT }, { "hz-gb-2312", SX_ENC_REPLACEMENT }, { "iso-2022-cn", SX_ENC_REPLACEMENT },
     { "iso-2022-cn-ext", SX_ENC_REPLACEMENT }, { "iso-2022-kr", SX_ENC_REPLACEMENT }, { "replacement", SX_ENC_REPLACEMENT },
 };
 // labels of the encodings encoding_rs has and this library does not (help.rs:54-96 lists their names)
 const char* const kOtherLabels[] = {
-    "iso-2022-jp", "csiso2022jp", "gbk", "gb2312", "chinese", "csgb2312", "csiso58gb231280", "gb_2312", "gb_2312-80", "iso-ir-58",
-    "x-gbk", "gb18030",
+    "iso-2022-jp", "csiso2022jp",
 };
 int for_label(const std::string& raw) {
     size_t a = 0, b = raw.size();
@@ -291,6 +292,8 @@ const char* sx_encoding_name(uint32_t encoding) {  // Encoding::name()
         case SX_ENC_EUC_JP: return "EUC-JP";
         case SX_ENC_SHIFT_JIS: return "Shift_JIS";
         case SX_ENC_EUC_KR: return "EUC-KR";
+        case SX_ENC_GB18030: return "gb18030";
+        case SX_ENC_GBK: return "GBK";
         case SX_ENC_REPLACEMENT: return "replacement";
         case SX_ENC_X_MAC_CYRILLIC: return "x-mac-cyrillic";
         default: return nullptr;
@@ -372,8 +375,8 @@ int sx_missions_from_flags(const sx_cli_flags* f, sx_mission* out, int cap, int*
         }
         if (enc == -2) {
             e.fail(scanner + "encoding `" + name + "` is known to the reference but not built into this library "
-                             "(UTF-8, UTF-16LE/BE, ascii, x-user-defined, the 28 single-byte encodings, Big5, EUC-JP, Shift_JIS, EUC-KR and replacement are; "
-                             "gb18030 / GBK and ISO-2022-JP are not).");
+                             "(UTF-8, UTF-16LE/BE, ascii, x-user-defined, the 28 single-byte encodings, Big5, EUC-JP, Shift_JIS, EUC-KR, gb18030 / GBK and replacement are; "
+                             "ISO-2022-JP is not).");
             return bail(SX_E_INVALID);
         }
         m.encoding = (uint8_t)enc;

@@ -53,7 +53,7 @@ struct Mission {
     size_t window = 128;    // decoder_input_window = 2*q, src/finding_collection.rs:120
     uint32_t long_run = 4;  // min(chars_min_nb, q): fewer chars can never yield a Finding
     bool is_utf16() const { return c.encoding == SX_ENC_UTF16LE || c.encoding == SX_ENC_UTF16BE; }
-    bool is_dbcs() const { return c.encoding >= SX_ENC_BIG5 && c.encoding <= SX_ENC_EUC_KR; }   // a pending lead byte is the decoder state
+    bool is_dbcs() const { return c.encoding >= SX_ENC_BIG5 && c.encoding <= SX_ENC_GBK; }   // a pending lead byte is the decoder state
     const char* encoding_name() const;
 
     // device classifier for this mission
@@ -87,6 +87,9 @@ public:
     // double-byte encodings: how many of the next bytes finish the token that is pending now (0: none pending,
     // or its last byte will be given back) — where the token grid of what follows begins
     uint32_t entry_skip(const uint8_t* next_bytes, uint64_t avail) const;
+    // the same in the grammar of the scan kernel, which differs for gb18030 only: the kernel reads a four-byte token as
+    // lead(error) digit lead(error) digit — aligned with the true tokens, pending is only ever one lead byte
+    uint32_t entry_skip_scan(const uint8_t* next_bytes, uint64_t avail) const;
     DDecoder& raw() { return d_; }
 
 private:

@@ -1078,8 +1078,20 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
         const u32 bad_last = (((P0 & ~Mp) << 1) | ((P1 & ~Mp) << 1)) & asc7;  // malformed token, last byte ASCII: its own character
         const u32 S1 = S0 & ~LR & asc;                                         // one-byte tokens
         // ---- 5. good / start masks (bits 16.. spill onto the next lane's first bytes)
-        const u32 g = S1 | A0 | (A0 << 1) | (A1 >> 1) | A1 | (A1 << 1) | bad_last;
-        const u32 s = S1 | A0 | ((Dbl & A0) << 1) | (A1 >> 1) | bad_last;
+        u32 g = S1 | A0 | (A0 << 1) | (A1 >> 1) | A1 | (A1 << 1) | bad_last;
+        u32 s = S1 | A0 | ((Dbl & A0) << 1) | (A1 >> 1) | bad_last;
+        if (HIGH1 && p.gb4) {
+            // gb18030: lead digit lead digit = one four-byte character.  The two-byte grammar above reads it as (lead, digit) malformed,
+            // digit given back, twice — aligned with the true tokens, so only the marking is missing: all four bytes good, the first
+            // a start, wherever the pattern stands (a superset; ScanParams::gb4)
+            u32 fd[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) fd[k] = swar_range(xs[k] & 0x7F7F7F7Fu, rep4(0x80u - 0x30u), rep4(0x7Fu - 0x39u)) & ~xs[k] & kM;
+            const u32 D = (movemask16(fd[0], fd[1], fd[2], fd[3]) | (movemask4(fd[4]) << 16)) & valid;
+            const u32 Q = LR & (D >> 1) & (LR >> 2) & (D >> 3) & 0xFFFFu;
+            g |= Q | (Q << 1) | (Q << 2) | (Q << 3);
+            s |= Q;
+        }
 
         const u32 g63_in = c.g63;
         const bool tracked_in = c.tracked != 0;

@@ -142,6 +142,7 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
                 const uint32_t cp = two_byte_single(enc, (uint8_t)b);
                 if (cp) { p.high1 = 1; if (m->filter.pass_lead(utf8_lead_of(cp))) p.lut[b] = 0x80; }
             }
+        p.gb4 = (enc_is_gb(enc) && m->c.ubf != 0) ? 1u : 0u;   // some character beyond ASCII is accepted: four-byte tokens may be
         p.af_is_range = (!force_generic && af_is_range && !p.high1) ? 1u : 0u;
         const uint16_t* t = decoder_table(enc, nullptr);
         const size_t n_tables = two_byte ? 1 : 2;

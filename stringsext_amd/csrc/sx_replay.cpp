@@ -200,7 +200,7 @@ private:
     uint64_t dbcs_sync(uint64_t B, uint64_t lim) {
         const int enc = m_.c.encoding;
         const bool big5 = enc_family((uint32_t)enc) == 4;   // the two-byte family
-        auto lead_range = [&](uint8_t b) { return big5 ? dbcs_is_lead_range<4>(b, enc) : dbcs_is_lead_range<5>(b, enc); };
+        auto lead_range = [&](uint8_t b) { return big5 ? dbcs_may_be_pending_after<4>(b, enc) : dbcs_may_be_pending_after<5>(b, enc); };   // (gb18030: digits too)
         uint64_t r = lim;
         while (r > 0) {
             const size_t n = (size_t)std::min<uint64_t>(r, 64);
@@ -212,7 +212,7 @@ private:
         }
         if (r == 0) r = m_.buf_entry_skip;
         while (r < lim) {
-            const size_t n = (size_t)std::min<uint64_t>(len_ - r, 3);
+            const size_t n = (size_t)std::min<uint64_t>(len_ - r, 4);
             const uint8_t* s = bytes_.span(r, n, &hint_);
             r += big5 ? dbcs_token_len<4>(s, n, enc) : dbcs_token_len<5>(s, n, enc);
         }

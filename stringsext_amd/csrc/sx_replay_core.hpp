@@ -126,14 +126,14 @@ SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs, NearBytes nr = N
         u64 at = p, vs = p;
         while (at < rs) {
             const u32 n = (u32)(rs - at < 12 ? rs - at : 12);
-            u32 k = 0;
-            for (;;) {
-                const DStep r = ddecode<ENC>(dd, P.data + at + k, n - k, sink, sizeof sink, false);
-                k += r.read;
-                if (r.result == RES_INPUT_EMPTY) break;
-                if (r.result == RES_MALFORMED) vs = at + k;
+            const DStep r = ddecode<ENC>(dd, P.data + at, n, sink, sizeof sink, false);
+            at += r.read;
+            if (r.result == RES_MALFORMED) {
+                // (gb18030: bytes the error gave back that lie in front of this piece — the pieces are this walk's own, the
+                // reference's call ends where the reading resumes)
+                at -= dd.rq_n; dd.rq_n = 0;
+                vs = at;
             }
-            at += n;
         }
         return vs;
     }
@@ -169,7 +169,8 @@ SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs, NearBytes nr = N
 constexpr u64 kPieceCont = 1ull << 63;
 
 SXD bool mission_splittable(const ReplayParams& P) {
-    return P.grep_char < 0 && !P.same_block && P.chars_min_nb >= 1 && P.chars_min_nb <= P.q;
+    // (gb18030: stage A reports a superset of the runs there — the pieces' premise is a run of accepted characters)
+    return P.grep_char < 0 && !P.same_block && P.chars_min_nb >= 1 && P.chars_min_nb <= P.q && !enc_is_gb((int)P.encoding);
 }
 // window starts s with s < x, and the position of window start number idx (slices of 4096 bytes, windows of W inside)
 SXD u64 win_starts_below(u64 x, u32 W) { const u64 wps = (kSliceLen + W - 1) / W; return x / kSliceLen * wps + (x % kSliceLen + W - 1) / W; }
@@ -280,7 +281,7 @@ SXD u32 derive_in_run(u32 q, u32 encoding, const uint16_t* table, const u8* from
 template <int ENC>
 SXD u64 dbcs_sync_before(const u8* bytes, u64 len, u64 at, u64 floor, u32 skip0, u64 lim, int enc) {
     u64 r = lim;
-    while (r > floor && dbcs_is_lead_range<ENC>(bytes[r - 1], enc)) r--;
+    while (r > floor && dbcs_may_be_pending_after<ENC>(bytes[r - 1], enc)) r--;
     if (r == floor) r += skip0;
     while (r < lim) r += dbcs_token_len<ENC>(bytes + r, len - r, enc);
     return r < at ? r : at;

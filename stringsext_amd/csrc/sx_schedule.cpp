@@ -26,29 +26,31 @@ uint64_t piece_bytes(const sx_ctx* ctx, uint64_t len) {
 // What the scan kernel needs to know about the state at buffer byte 0: UTF-16 the unit parity of the stream
 // offset; Big5 / EUC-JP how many bytes finish the token pending in the carried decoder (0 without a state).
 static int entry_param(sx_ctx* ctx, size_t k, const Decoder* carried, const uint8_t* host_bytes, const uint8_t* d_bytes,
-                       uint64_t len, uint64_t stream_off, uint32_t* out) {
+                       uint64_t len, uint64_t stream_off, uint32_t* out, uint32_t* out_replay = nullptr) {
     const Mission& m = ctx->missions[k];
     *out = (uint32_t)(stream_off & 1);
+    if (out_replay) *out_replay = 0;
     if (!m.is_dbcs()) return SX_OK;
     *out = 0;
     if (!carried || carried->idle() || len == 0) return SX_OK;
-    uint8_t first[2] = { 0, 0 };
-    const uint64_t n = std::min<uint64_t>(2, len);
+    uint8_t first[4] = { 0, 0, 0, 0 };
+    const uint64_t n = std::min<uint64_t>(4, len);
     if (host_bytes) memcpy(first, host_bytes, n);
     else HIP_TRY(ctx, hipMemcpy(first, d_bytes, n, hipMemcpyDeviceToHost));
-    *out = carried->entry_skip(first, n);
+    *out = carried->entry_skip_scan(first, n);                     // for the scan kernel (its own grammar for gb18030)
+    if (out_replay) *out_replay = carried->entry_skip(first, n);   // for the replay: the true token grid
     return SX_OK;
 }
 int set_entry_params(sx_ctx* ctx, bool carried_state_is_entry, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len,
                      uint64_t stream_off, std::vector<uint32_t>* parity) {
     parity->clear();
     for (size_t k = 0; k < ctx->missions.size(); k++) {
-        uint32_t ep = 0;
+        uint32_t ep = 0, ep_replay = 0;
         int rc = entry_param(ctx, k, carried_state_is_entry ? &ctx->states[k].decoder : nullptr, host_bytes, d_bytes, len,
-                             stream_off, &ep);
+                             stream_off, &ep, &ep_replay);
         if (rc != SX_OK) return rc;
         parity->push_back(ep);
-        ctx->missions[k].buf_entry_skip = ctx->missions[k].is_dbcs() ? ep : 0u;
+        ctx->missions[k].buf_entry_skip = ctx->missions[k].is_dbcs() ? ep_replay : 0u;
     }
     return SX_OK;
 }
@@ -173,8 +175,9 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
         for (size_t k = 0; k < nm; k++) {
             uint32_t ep = (uint32_t)((stream0[k] + off) & 1);
             if (ctx->missions[k].is_dbcs()) {  // one piece only (piece_bytes): the carried decoder describes byte 0
-                (void)entry_param(ctx, k, &ctx->states[k].decoder, b.host_bytes, b.d_bytes, b.len, 0, &ep);
-                ctx->missions[k].buf_entry_skip = ep;
+                uint32_t ep_replay = 0;
+                (void)entry_param(ctx, k, &ctx->states[k].decoder, b.host_bytes, b.d_bytes, b.len, 0, &ep, &ep_replay);
+                ctx->missions[k].buf_entry_skip = ep_replay;
             }
             b.parity.push_back(ep);
             b.minc.push_back(ctx->missions[k].long_run);
@@ -248,7 +251,7 @@ int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
                     const int enc = m.c.encoding;
                     const bool two = enc_family((uint32_t)enc) == 4;
                     for (uint64_t i = 0; i < n; i++)
-                        if (!(two ? dbcs_is_lead_range<4>(s[i], enc) : dbcs_is_lead_range<5>(s[i], enc))) { found[k] = 1; break; }
+                        if (!(two ? dbcs_may_be_pending_after<4>(s[i], enc) : dbcs_may_be_pending_after<5>(s[i], enc))) { found[k] = 1; break; }
                 }
             }
             if (!all_found()) {

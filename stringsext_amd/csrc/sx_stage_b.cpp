@@ -104,8 +104,15 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
                     budget = std::max(budget, std::min<uint64_t>(40960ull << 20, ((uint64_t)fr + ctx->d_cache_cap) / 3));
             }
             if (const char* e = getenv("SX_REPLAY_CACHE_MIB")) budget = (uint64_t)atoll(e) << 20;
-            const uint64_t arena = std::max<uint64_t>(4096, std::min<uint64_t>(budget, (uint64_t)n * 1024));
-            rc = ensure_cache(ctx, arena + (uint64_t)(2 * n + 4) * 4 + 512); if (rc) return rc;
+            uint64_t arena = std::max<uint64_t>(4096, std::min<uint64_t>(budget, (uint64_t)n * 1024));
+            const uint64_t lists = (uint64_t)(2 * n + 4) * 4 + 512;
+            rc = ensure_cache(ctx, arena + lists);
+            while (rc != SX_OK && arena > (64ull << 20)) {   // the device is short of memory: a smaller arena (more regions are replayed twice)
+                (void)hipGetLastError();
+                arena /= 2;
+                rc = ensure_cache(ctx, arena + lists);
+            }
+            if (rc) return rc;
             rc = ensure_scratch(ctx, std::max(stitch_scratch_bytes(n), replay_heads_scratch_bytes(n))); if (rc) return rc;
             uint8_t* base = ctx->d_cache;
             P.cache_arena = base; P.arena_bytes = arena & ~255ull;

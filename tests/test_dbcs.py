@@ -20,9 +20,11 @@ JA = ("ã“ã‚Œã¯æ—¥æœ¬èªžã®ãƒ†ã‚¹ãƒˆæ–‡å­—åˆ—ã§ã™ã€‚ï¾Šï¾ï½¶ï½¸ï½¶ï¾… â‘  ä¸
       "ã„ã‚ã¯ã«ã»ã¸ã¨ã¡ã‚Šã¬ã‚‹ã‚’ã‚ã‹ã‚ˆãŸã‚Œãã¤ã­ãªã‚‰ã‚€ã†ã‚ã®ãŠãã‚„ã¾ã‘ãµã“ãˆã¦ã‚ã•ãã‚†ã‚ã¿ã—ã‚‘ã²ã‚‚ã›ã™")
 KO = ("í•œêµ­ì–´ í…ìŠ¤íŠ¸ í…ŒìŠ¤íŠ¸ ë¬¸ìžì—´ìž…ë‹ˆë‹¤. ë˜ ë°©ê°í•˜ íŽ²ì‹œì½œë¼ íž£ ABC ê°€ë‚˜ë‹¤ë¼ë§ˆë°”ì‚¬ì•„ìžì°¨ì¹´íƒ€íŒŒí•˜ "
       "ë™í•´ë¬¼ê³¼ ë°±ë‘ì‚°ì´ ë§ˆë¥´ê³  ë‹³ë„ë¡ í•˜ëŠë‹˜ì´ ë³´ìš°í•˜ì‚¬ ìš°ë¦¬ë‚˜ë¼ ë§Œì„¸")
-CODEC = {"big5": "big5hkscs", "euc-jp": "euc_jp", "shift_jis": "cp932", "euc-kr": "cp949"}
-TEXT = {"big5": ZH, "euc-jp": JA, "shift_jis": JA + " é«™ï¨‘ ", "euc-kr": KO}
-ENCS = ["big5", "euc-jp", "shift_jis", "euc-kr"]
+ZHS = ("è¿™æ˜¯ä¸€ä¸ªæµ‹è¯•å­—ç¬¦ä¸²ï¼Œç”¨æ¥æ£€æŸ¥å›½æ ‡ç è§£ç å™¨ã€‚å››å­—èŠ‚ï¼šð €€ð €ðªš¥ Ç¹ á¸¿ â‚  ãŠ£ ã€‡ â‚¬ 1234567890 ç»“æŸã€‚81308130 9 "
+       "å¤©åœ°çŽ„é»„å®‡å®™æ´ªè’æ—¥æœˆç›ˆæ˜ƒè¾°å®¿åˆ—å¼ å¯’æ¥æš‘å¾€ç§‹æ”¶å†¬è—é—°ä½™æˆå²å¾‹å•è°ƒé˜³")
+CODEC = {"big5": "big5hkscs", "euc-jp": "euc_jp", "shift_jis": "cp932", "euc-kr": "cp949", "gbk": "gb18030", "gb18030": "gb18030"}
+TEXT = {"big5": ZH, "euc-jp": JA, "shift_jis": JA + " é«™ï¨‘ ", "euc-kr": KO, "gbk": ZHS, "gb18030": ZHS + ZH}
+ENCS = ["big5", "euc-jp", "shift_jis", "euc-kr", "gbk", "gb18030"]
 ALL = "0xffffffffffffffff"
 
 
@@ -44,10 +46,13 @@ def test_oracle_decodes_valid_text_like_cpython(enc):
     checked = 0
     seqs = []
     for a in range(0x81, 0xFF):
-        for b in list(range(0x40, 0x7F)) + list(range(0x80 if enc in ("shift_jis", "euc-kr") else 0xA1, 0xFF)):
+        for b in list(range(0x40, 0x7F)) + list(range(0x80 if enc in ("shift_jis", "euc-kr", "gbk", "gb18030") else 0xA1, 0xFF)):
             seqs.append(bytes([a, b]))
     if enc == "euc-jp":
         seqs += [bytes([0x8F, a, b]) for a in range(0xA1, 0xFF, 3) for b in range(0xA1, 0xFF)]
+    if enc in ("gbk", "gb18030"):   # four-byte sequences: a sample of the BMP ranges and of the astral planes
+        seqs += [bytes([0x81 + p // 12600, 0x30 + p // 1260 % 10, 0x81 + p // 10 % 126, 0x30 + p % 10])
+                 for p in list(range(0, 39420, 7)) + list(range(189000, 1237576, 997))]
     for i in range(0, len(seqs), 400):
         blob = b"".join(s + b"\n" for s in seqs[i:i + 400])
         got = sxo.run_cli(rc.missions(encodings=[enc], chars_min="1", unicode_block_filter=ALL), [blob], no_metadata=True)
@@ -62,7 +67,7 @@ def test_oracle_decodes_valid_text_like_cpython(enc):
                 continue  # cp/hkscs decodes lead + ASCII as two chars where WHATWG has an error + ASCII
             if want in found:
                 checked += 1
-    assert checked > {"big5": 13000, "euc-jp": 8000, "shift_jis": 7000, "euc-kr": 16000}[enc]  # the bulk of the index (patched cells differ by design)
+    assert checked > {"big5": 13000, "euc-jp": 8000, "shift_jis": 7000, "euc-kr": 16000, "gbk": 29000, "gb18030": 29000}[enc]  # the bulk of the index (patched cells differ by design)
 
 
 def test_oracle_big5_follows_the_whatwg_algorithm_on_hand_derived_vectors():
@@ -140,6 +145,8 @@ def test_replacement_never_prints():
 def soup(enc, rng, n):
     txt, codec = TEXT[enc], CODEC[enc]
     nasty = [0x8E, 0x8F, 0xA1, 0xFE, 0x81, 0x80, 0xFF, 0x40, 0x7E, 0xA4, 0x88, 0x62, 0xA5, 0x0A, 0x20, 0xB0, 0x9F, 0xE0, 0xFC, 0xFD, 0xA0, 0xDF, 0x7F, 0x41]
+    if enc in ("gbk", "gb18030"):   # digits: second and fourth bytes of the four-byte tokens
+        nasty += [0x30, 0x39, 0x35, 0x81, 0x30, 0x84, 0x31, 0x90, 0x32, 0xE3, 0x39]
     out = bytearray()
     while len(out) < n:
         r = rng.random()

@@ -46,6 +46,15 @@ def test_device_runs_equal_oracle_runs(enc, name):
                 continue
             got, mc = device_runs(m, data, subchunk=sub)
             want = sxo.runs(m, data, min_chars=mc)
+            if enc in ("gbk", "gb18030"):
+                # a SUPERSET there (ScanParams::gb4: lead digit lead digit is marked good wherever it stands, the digits may
+                # count as characters of their own): every true run lies inside a reported one with at least its characters
+                j = 0
+                for a, b, ch in want:
+                    while j < len(got) and got[j][1] < b:
+                        j += 1
+                    assert j < len(got) and got[j][0] <= a and got[j][2] >= ch, (enc, name, di, sub, (a, b, ch), got[max(0, j - 1):j + 1])
+                continue
             assert got == want, (enc, name, di, sub, len(got), len(want),
                                  next(((a, b) for a, b in zip(got, want) if a != b), None))
 

@@ -69,7 +69,17 @@ def test_oracle_and_product_tables_agree_cell_by_cell():
     for name, oa, pa in (("Shift_JIS pointer", o["sxo_sjis"], p["sx_sjis"]), ("EUC-KR pointer", o["sxo_euckr"], p["sx_euckr"])):
         assert len(oa) == len(pa)
         diffs += [f"{name} {i}: oracle U+{a:04X} product U+{b:04X}" for i, (a, b) in enumerate(zip(oa, pa)) if a != b]
+    gb = 126 * 190
+    assert len(o["sxo_gb18030"]) == gb and len(p["sx_gb18030"]) == gb + 2 * len(o["sxo_gb_range_ptr"])
+    diffs += [f"gb18030 pointer {i}: oracle U+{a:04X} product U+{b:04X}" for i, (a, b) in enumerate(zip(o["sxo_gb18030"], p["sx_gb18030"][:gb])) if a != b]
+    nr = len(o["sxo_gb_range_ptr"])
+    if o["sxo_gb_range_ptr"] + o["sxo_gb_range_cp"] != p["sx_gb18030"][gb:]:
+        diffs.append("gb18030 ranges differ")
+    assert nr == 208 and o["sxo_gb_range_ptr"][0] == 0 and o["sxo_gb_range_cp"][0] == 0x80 and o["sxo_gb_range_cp"][-1] == 0xFFE6
     assert not diffs, "\n".join(diffs[:50])
+    gbc = lambda lead, trail: p["sx_gb18030"][(lead - 0x81) * 190 + (trail - (0x40 if trail < 0x7F else 0x41))]
+    assert gbc(0xA8, 0xBC) == 0x1E3F and gbc(0xA3, 0xA0) == 0x3000 and gbc(0xD6, 0xD0) == 0x4E2D and gbc(0x81, 0x40) == 0x4E02
+    assert all(v for v in p["sx_gb18030"][:gb])   # every two-byte cell is mapped (private use included)
     assert sum(1 for v in p["sx_sjis"] if v) == 7724 and sum(1 for v in p["sx_euckr"] if v) == 17048
     assert all(v == 0 for v in p["sx_sjis"][8836:10716])       # the user-defined range is a rule of the decoder, not table data
     # sizes of what is mapped, and a few cells whose value is a decision (see the generators' headers)
@@ -200,6 +210,22 @@ def _raw_report():
                 single += 1
     lines.append(f"EUC-KR: {both} cells in both sources ({differ} differ), {single} cells only CPython cp949 has (the UHC extension: single "
                  f"source), {pua} user-defined cells ICU maps to the private use area (not in the tables)")
+    # gb18030: two-byte cells and the four-byte ranges
+    n2 = 0
+    for line in open(os.path.join(tab, "icu_gb18030.txt")):
+        k, v = line.split()
+        key = int(k, 16)
+        c = p.cps("gb18030", [key >> 8, key & 0xFF])
+        if c != [int(v, 16)]:
+            n2 += 1
+            lead, trail = key >> 8, key & 0xFF
+            lines.append(f"gb18030 {k.upper()}: ICU U+{int(v, 16):04X} | CPython {fmt(c)} -> taken U+{fin['sx_gb18030'][(lead - 0x81) * 190 + (trail - (0x40 if trail < 0x7F else 0x41))]:04X}")
+    icu_r = [tuple(line.split()) for line in open(os.path.join(tab, "icu_gb18030_ranges.txt"))]
+    _, pp, pc = p.gb18030_tables()
+    lines.append(f"gb18030: {n2} two-byte cell differs between ICU and CPython (0xA8BC: GB18030-2000 has U+E7C7 there and U+1E3F at four-byte pointer "
+                 f"7457, GB18030-2005 and the WHATWG index the other way round: taken ICU's); the ranges: {len(icu_r)} breakpoints in ICU, "
+                 f"{len(pp)} after the same patch in CPython; 0xA3A0 is U+E5E5 in both sources and U+3000 in the WHATWG index (taken: U+3000); "
+                 "the 18 code points GB18030-2022 moved out of the private use area are as in both sources (2005)")
     return "\n".join(lines) + "\n"
 
 
