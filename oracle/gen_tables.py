@@ -21,6 +21,8 @@ index files themselves are not available.  ICU differs from them in known places
                (an error in ICU) — that is in the decoder, not in this table.
   EUC-KR       ICU has KS X 1001 only; the UHC extension (the WHATWG index is windows-949) comes from cpython_supplement.txt
                (single source).
+  gb18030      ICU (GB18030-2005) has the WHATWG assignment of 0xA8BC / four-byte pointer 7457; 0xA3A0 = U+3000 is patched in (both
+               sources: U+E5E5); the 18 code points GB18030-2022 moved out of the private use area are left as in both sources.
 Parity of all legacy tables is UNPINNED: no reference test decodes any of them.
 
 Order of the single-byte tables defines the encoding id (16 + index); names are Encoding::name()."""

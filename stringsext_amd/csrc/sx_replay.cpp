@@ -335,7 +335,7 @@ private:
                     }
                 }
                 // a window boundary inside the slice: may we stop here?
-                if (din < slen && !maybe_cut && may_drop(ob + dout - leftover_len, leftover_len)
+                if (din < slen && !maybe_cut && may_drop(ob + dout - leftover_len, leftover_len) && !digit_pending()
                     && region_over(soff + din)) {
                     stopped = true;
                     break;
@@ -346,10 +346,15 @@ private:
             st.last_run_str_was_printed_and_is_maybe_cut_str = maybe_cut;
             pos = soff + din;
             if (stopped) return pos;
-            if (!maybe_cut && may_drop(ob + dout - leftover_len, leftover_len) && region_over(pos)) return pos;
+            if (!maybe_cut && may_drop(ob + dout - leftover_len, leftover_len) && !digit_pending() && region_over(pos)) return pos;
         }
         return pos;
     }
+
+    // gb18030: lead + digit (+ lead) pending.  If the token ends in an error the digit is read again and is a character of
+    // the NEXT window although its byte lies in this one (its run ends at the window edge: no run crosses it) — the region
+    // goes on.  (A plain pending lead byte is different: the character it begins has its last byte in the next window.)
+    bool digit_pending() { return enc_is_gb(m_.c.encoding) && st_->decoder.raw().gb2 != 0; }
 
     // May the replay stop although this leftover is carried?  Only a leftover of fewer than
     // min(n,q) chars is inert (file comment).  A longer one is a long run that reached the

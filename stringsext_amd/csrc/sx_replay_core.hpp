@@ -564,7 +564,9 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
                 const u32 from = dout - leftover_len;
                 if (from) for (u32 t = 0; t < leftover_len; t++) ob[t] = ob[from + t];
             }
-            if (piece_at(soff + din) || (!maybe_cut && may_drop(ob, leftover_len) && region_over(soff + din))) { done = true; break; }
+            // (gb18030 with lead + digit pending: if the token ends in an error the digit is a character of the NEXT window — go on)
+            const bool digit_pending = (ENC == 4) && enc_is_gb((int)P.encoding) && dec.gb2 != 0;
+            if (piece_at(soff + din) || (!maybe_cut && !digit_pending && may_drop(ob, leftover_len) && region_over(soff + din))) { done = true; break; }
         }
         pos = soff + din;
         (void)is_last_window;

@@ -70,7 +70,28 @@ UTF8 = [
     ("stray continuation bytes", [("80bf41", False, [("M", 1, 0), ("M", 1, 0), ("E", 1, 1)])]),
 ]
 
-VECTORS = ([(n, "utf-16le", c) for n, c in UTF16LE]
+# gb18030 / GBK — the WHATWG "gb18030 decoder" (https://encoding.spec.whatwg.org/#gb18030-decoder): first / second / third,
+# "prepend ... to ioQueue" = the bytes are read again.  What a streaming decoder does with bytes it must read again but received in
+# an EARLIER call is this project's choice (encoding_rs is not vendored: unpinned): they are decoded in front of the next call's
+# input; read counts bytes of the call's own input only.
+GB = [
+    ("two bytes", [("d6d0", False, [("E", 2, 3)])]),                                     # U+4E2D
+    ("four bytes, BMP range", [("81308130", False, [("E", 4, 2)])]),                     # pointer 0 -> U+0080
+    ("four bytes, astral", [("90308130", False, [("E", 4, 4)])]),                        # pointer 189000 -> U+10000
+    ("0x80 is the euro sign", [("80", False, [("E", 1, 3)])]),
+    ("0xFF is an error of its own", [("ff41", False, [("M", 1, 0), ("E", 1, 1)])]),
+    ("lead + ASCII byte that is no trail: the byte is read again", [("a17f", False, [("M", 1, 0), ("E", 1, 1)])]),
+    ("lead + 0xFF: both consumed", [("a1ff", False, [("M", 2, 0), ("E", 0, 0)])]),
+    ("lead digit, then no lead: the digit and that byte are read again", [("81307841", False, [("M", 1, 0), ("E", 3, 3)])]),
+    ("lead digit lead, then no digit: all three are read again", [("81308178", False, [("M", 1, 0), ("E", 3, 4)])]),   # '0' + U+4E41
+    ("pointer between the BMP ranges and the astral planes: error, four bytes consumed", [("8431a530", False, [("M", 4, 0), ("E", 0, 0)])]),
+    ("the token over three calls, then the error: what earlier calls consumed is decoded in front of the next call",
+     [("81", False, [("E", 1, 0)]), ("3081", False, [("E", 2, 0)]), ("78", False, [("M", 0, 0), ("E", 1, 4)])]),
+    ("pending bytes at the end of the stream", [("8130", True, [("M", 2, 0), ("E", 0, 0)])]),
+]
+
+VECTORS = ([(n, "gb18030", c) for n, c in GB] + [(n, "gbk", c) for n, c in GB]
+           + [(n, "utf-16le", c) for n, c in UTF16LE]
            + [(n, "utf-16be", [(be(x) if len(x) % 4 == 0 else None, last, steps) for x, last, steps in c]) for n, c in UTF16LE
               if all(len(x) % 4 == 0 for x, _, _ in c)]
            + [(n, "utf-8", c) for n, c in UTF8])

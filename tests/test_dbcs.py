@@ -243,3 +243,26 @@ def test_device_replay_core_emulated_on_cpu_equals_oracle(enc, flags):
             assert got == want, (skip, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
             done += 1
     assert done > 0 or "grep_char" in flags   # (with -g a region can exceed the harness's 64 windows: given back by design)
+
+
+@pytest.mark.parametrize("enc", ["gbk", "gb18030"])
+def test_gb18030_digit_read_again_is_a_character_of_the_next_window(enc):
+    """lead + digit as the last two bytes of a window, the token ends in an error in the next one: the digit is decoded again
+    and delivered there (position = that window's start), although its byte — and so its run — lies in the window before and
+    no run crosses the edge.  The region must go on while lead + digit are pending (found by tools/gpu_fuzz.py, seed 6868)."""
+    import test_replay_core as trc
+    from test_sharded_gloo import oracle_findings
+    core = trc.load_core()
+    flags = dict(chars_min="1", output_line_len="8", ascii_filter="0x7ffffffe000000007ffffffe00000000", unicode_block_filter="Latin")
+    ms = rc.missions(encodings=[enc], **flags)
+    body = bytes.fromhex("00000000000000be49bbba3317c18aef38" "eb4ab4f6ac9cc7fde6cbf71e1dc3e3b65cb2bf3f872b17a7e8ccc4e0ba6840f6")
+    for pad in (15, 31, 4079):   # the window edge right behind the digit; the last one: a slice edge too
+        data = b"\x00" * pad + body + b"\x00" * 200
+        want = sxo.run_cli(ms, [data], radix="x")
+        assert b"\t8\n" in want
+        for chunk in (None, 4096):
+            assert run_cli_product(ms, [data], radix="x", chunk_bytes=chunk) == want, (pad, chunk)
+        runs = sxo.runs(ms[0], data, min_chars=1)
+        wantf = [(p, pr, s, c, si) for p, pr, s, c, _, si in oracle_findings([ms[0]], data)]
+        for skip in (1, 0):
+            assert trc.emulate_device_stage_b(core, ms[0], data, runs, skip=skip) == wantf, (pad, skip)

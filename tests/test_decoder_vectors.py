@@ -41,7 +41,9 @@ class ProductDecoder:
         L.sxd_decoder_step.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int,
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.sxd_decoder_free.argtypes = [C.c_void_p]
-        self.L, self.d = L, L.sxd_decoder_new(enc, None)
+        import stringsext_amd as sx
+        t = sx.decoder_table(enc)   # the product's own table (the double-byte decoders read it)
+        self.L, self.d = L, L.sxd_decoder_new(enc, C.cast(t[0], C.c_void_p) if t else None)
 
     def step(self, src, last):
         dst = C.create_string_buffer(256)
