@@ -43,7 +43,15 @@ def oracle_runs_for_chunk(mdicts, chunk, stream_bytes, before=b""):
     out = []
     for m in mdicts:
         long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
-        if m["encoding"] in (64, 65, 66, 67):
+        if m["encoding"] in (68, 69):
+            # gb18030 / GBK: decode from the last byte in `before` after which the decoder is certainly neutral (neither lead
+            # range nor digit), and keep what reaches into the chunk (clipped: stage A's runs are hints for stage B)
+            r = len(before)
+            while r > 0 and (0x81 <= before[r - 1] <= 0xFE or 0x30 <= before[r - 1] <= 0x39):
+                r -= 1
+            shift = len(before) - r
+            out.append([(max(0, a - shift), b - shift, c) for a, b, c in sxo.runs(m, before[r:] + chunk, min_chars=long_run) if b > shift])
+        elif m["encoding"] in (64, 65, 66, 67):
             skip = dbcs_hangover(m["encoding"], before, chunk)
             out.append([(a + skip, b + skip, c) for a, b, c in sxo.runs(m, chunk[skip:], min_chars=long_run)])
         else:
