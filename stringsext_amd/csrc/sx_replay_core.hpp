@@ -169,8 +169,7 @@ SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs, NearBytes nr = N
 constexpr u64 kPieceCont = 1ull << 63;
 
 SXD bool mission_splittable(const ReplayParams& P) {
-    // (gb18030: stage A reports a superset of the runs there — the pieces' premise is a run of accepted characters)
-    return P.grep_char < 0 && !P.same_block && P.chars_min_nb >= 1 && P.chars_min_nb <= P.q && !enc_is_gb((int)P.encoding);
+    return P.grep_char < 0 && !P.same_block && P.chars_min_nb >= 1 && P.chars_min_nb <= P.q;
 }
 // window starts s with s < x, and the position of window start number idx (slices of 4096 bytes, windows of W inside)
 SXD u64 win_starts_below(u64 x, u32 W) { const u64 wps = (kSliceLen + W - 1) / W; return x / kSliceLen * wps + (x % kSliceLen + W - 1) / W; }
@@ -229,6 +228,34 @@ SXD u32 char_len_at(const ReplayParams& P, u64 rs) {
     return 1;
 }
 
+// gb18030 / GBK: stage A reports a SUPERSET of the runs there (ScanParams::gb4), and the pieces' premise is a run of accepted
+// characters that begins where the decoder is neutral.  So a run is only cut if that can be seen: the byte in front of it is
+// ASCII and no digit (a character of its own, rejected or it would belong to the run; the decoder is neutral behind it), and
+// the run — at most kGbVerifyMax bytes, a lane decodes it alone — decodes without error into accepted characters only and ends
+// with the decoder neutral.  Anything else is replayed as one run, as in round 1.
+constexpr u64 kGbVerifyMax = 2048;
+SXD bool gb_run_is_exact(const ReplayParams& P, u64 rs, u64 re) {
+    if (rs == 0 || re - rs > kGbVerifyMax) return false;
+    const u8 x = P.data[rs - 1];
+    if (x >= 0x80 || gb_digit(x)) return false;
+    DDecoder d;
+    ddec_reset(d, (int)P.encoding, P.table);
+    u8 sink[48];
+    u64 at = rs;
+    while (at < re) {
+        const u32 n = (u32)(re - at < 12 ? re - at : 12);
+        const DStep r = ddec_gb18030(d, P.data + at, n, sink, sizeof sink, false);
+        if (r.result != RES_INPUT_EMPTY) return false;
+        for (u32 w = 0; w < r.written;) {
+            const u8 lead = sink[w];
+            if (!pass_lead(P, lead)) return false;
+            w += lead < 0x80 ? 1 : lead < 0xE0 ? 2 : lead < 0xF0 ? 3 : 4;
+        }
+        at += r.read;
+    }
+    return d.dlead == 0 && d.gb2 == 0 && d.rq_n == 0;
+}
+
 // How many pieces run i of the UNSPLIT list P.runs is cut into (1: not cut).  The run's first character must be
 // delivered in the same window as the rejected character in front of it (a character belongs to the window that
 // holds its LAST byte): no window start in [rs, last byte of the first character].
@@ -240,6 +267,7 @@ SXD u64 split_count(const ReplayParams& P, u64 i) {
     if (inside == 0) return 1;
     const u64 fe = rs + char_len_at<ENC>(P, rs) - 1;
     if (fe >= re || win_start(fe, P.W) >= rs) return 1;
+    if (ENC == 4 && enc_is_gb((int)P.encoding)) return gb_run_is_exact(P, rs, re) ? inside + 1 : 1;
     return valid_char_before<ENC>(P, rs) ? inside + 1 : 1;
 }
 // piece k (0 .. count-1) of run i

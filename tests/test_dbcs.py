@@ -266,3 +266,37 @@ def test_gb18030_digit_read_again_is_a_character_of_the_next_window(enc):
         wantf = [(p, pr, s, c, si) for p, pr, s, c, _, si in oracle_findings([ms[0]], data)]
         for skip in (1, 0):
             assert trc.emulate_device_stage_b(core, ms[0], data, runs, skip=skip) == wantf, (pad, skip)
+
+
+def text_lines(enc, rng, n_lines):
+    txt = TEXT[enc]
+    lines = []
+    for _ in range(n_lines):
+        a = rng.randrange(len(txt) - 5)
+        lines.append((txt[a:a + rng.randrange(3, 70)] + rng.choice(["", " 123", "abc", "9"])).encode(CODEC[enc], "ignore")
+                     + rng.choice([b"\n", b"\r\n", b"\x00", b"\n\n"]))
+    return b"".join(lines)
+
+
+@pytest.mark.parametrize("enc", ["gbk", "gb18030", "big5", "euc-kr"])
+def test_text_lines_cut_into_pieces_equal_oracle(enc):
+    """Lines of CJK text (each crosses several window starts) framed by line feeds: the runs are cut into pieces at the window
+    starts (for gb18030 / GBK only runs that verify as exact: sx_replay_core.hpp gb_run_is_exact) — host replay with the
+    pieces the device would hand over, and the host-compiled device core driven as the device drives it."""
+    import test_replay_core as trc
+    from test_sharded_gloo import oracle_findings
+    core = trc.load_core()
+    data = text_lines(enc, random.Random(zlib.crc32(enc.encode())), 400)
+    for flags in (dict(chars_min="4", unicode_block_filter=ALL), dict(chars_min="2", output_line_len="12", unicode_block_filter="Cjk")):
+        ms = rc.missions(encodings=[enc], **flags)
+        want = sxo.run_cli(ms, [data], radix="x")
+        assert want.count(b"\n") > 300
+        for chunk in (None, 4096):
+            assert run_cli_product(ms, [data], radix="x", chunk_bytes=chunk, pieces=True) == want, (flags, chunk)
+        m = ms[0]
+        runs = sxo.runs(m, data, min_chars=max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"])))
+        cut = trc.split_runs(core, m, data, runs)
+        assert len(cut) > len(runs)      # pieces were made
+        wantf = [(p, pr, s, c, si) for p, pr, s, c, _, si in oracle_findings([m], data)]
+        for skip in (1, 0):
+            assert trc.emulate_device_stage_b(core, m, data, runs, skip=skip) == wantf, (flags, skip)

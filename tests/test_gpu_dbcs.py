@@ -9,7 +9,7 @@ import pytest
 import refconfig as rc
 import sxo_binding as sxo
 from product_harness import run_cli_product
-from test_dbcs import ALL, CODEC, DBCS_FLAGS, ENCS, TEXT, soup
+from test_dbcs import ALL, CODEC, DBCS_FLAGS, ENCS, TEXT, soup, text_lines
 from test_gpu_parity import device_runs
 
 pytestmark = pytest.mark.gpu
@@ -69,6 +69,18 @@ def test_end_to_end_equals_oracle(enc, flags):
     for chunk, sub, dev_replay in ((None, 0, None), (16384, 1024, None), (None, 0, True), (65536, 4096, True)):
         got = run_cli_product(ms, files, radix="x", chunk_bytes=chunk, device=0, subchunk_bytes=sub, device_replay=dev_replay)
         assert got == want, (chunk, sub, dev_replay)
+
+
+@pytest.mark.parametrize("enc", ENCS)
+def test_text_lines_on_the_gpu(enc):
+    """Lines of CJK text, every one across several window starts: the device cuts the runs into pieces (gb18030 / GBK: those
+    that verify as exact) and replays a region per window; 120 000 lines so that stage B runs on the device."""
+    data = text_lines(enc, random.Random(zlib.crc32((enc + "lines").encode())), 120_000)
+    for flags in (dict(chars_min="4", unicode_block_filter=ALL), dict(chars_min="2", output_line_len="12", unicode_block_filter="Cjk")):
+        ms = rc.missions(encodings=[enc], **flags)
+        want = sxo.run_cli(ms, [data], radix="x")
+        for chunk, dev_replay in ((None, None), (1 << 20, True)):
+            assert run_cli_product(ms, [data], radix="x", chunk_bytes=chunk, device=0, device_replay=dev_replay) == want, (flags, chunk)
 
 
 def test_c5_six_missions_on_a_planted_image():
