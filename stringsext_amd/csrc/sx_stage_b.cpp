@@ -528,6 +528,16 @@ static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFi
     std::vector<uint64_t> pnf(nm), pnb(nm);
     std::vector<uint32_t> off0(nm);
     std::vector<MissionFindings> outs;
+    // leaving early (a HIP error, no pinned memory): no copy may still be writing into a block that goes back to the pool
+    struct Guard {
+        sx_ctx* ctx; std::vector<MissionFindings>* outs; hipStream_t a, b; bool done = false;
+        ~Guard() {
+            if (done) return;
+            (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+            for (auto& o : *outs) if (o.ext.p) ctx->pool->give(o.ext);
+            outs->clear();
+        }
+    } guard{ ctx, &outs, s, cs };
     uint64_t rb = 0;
     for (size_t k = 0; k < nm; k++) rb += per[k].replay_bytes;
     bool copy_pending[2] = { false, false };
@@ -557,6 +567,7 @@ static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFi
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     HIP_TRY(ctx, hipStreamSynchronize(cs));
+    guard.done = true;
     for (size_t k = 0; k < nm; k++) {
         if (per[k].ext.p) ctx->pool->give(per[k].ext);
         per[k] = MissionFindings{};
