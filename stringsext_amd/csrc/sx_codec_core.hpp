@@ -439,15 +439,21 @@ template <int ENC>
 SXD u32 dbcs_entry_skip(const DDecoder& d, const u8* s, u64 avail) {
     if (ENC == 4 && enc_is_gb(d.enc)) {
         if ((d.dlead == 0 && d.gb2 == 0 && d.rq_n == 0) || avail == 0) return 0;
-        // ask the decoder: the shortest prefix of s after which it is neutral again, or the bytes it keeps when the
-        // pending token ends in an error (what it gives back is not counted: read shrinks)
-        u8 sink[32];
-        const u32 lim = avail < 4 ? (u32)avail : 4u;
-        for (u32 m = 1; m <= lim; m++) {
+        // ask the decoder: the shortest prefix of s after which it is neutral again — driven as the reference drives it (after
+        // Malformed the decoder is called again on what was not read: an error of the pending token can queue bytes that are
+        // decoded in front of s and take s[0] as their trail byte).  The result is a token boundary of the true grammar, the
+        // first one the state on entry allows to name; the token grid of the buffer is counted from there.
+        u8 sink[64];
+        const u32 lim = avail < 8 ? (u32)avail : 8u;
+        for (u32 m = 0; m <= lim; m++) {
             DDecoder c = d;
-            const DStep r = ddec_gb18030(c, s, m, sink, sizeof sink, false);
-            if (r.result == RES_MALFORMED) return r.read;
-            if (c.dlead == 0 && c.gb2 == 0 && c.rq_n == 0) return m;
+            u32 used = 0;
+            for (int guard = 0; guard < 8; guard++) {
+                const DStep r = ddec_gb18030(c, s + used, m - used, sink, sizeof sink, false);
+                used += r.read;
+                if (r.result != RES_MALFORMED) break;
+            }
+            if (used == m && c.dlead == 0 && c.gb2 == 0 && c.rq_n == 0) return m;
         }
         return lim;
     }

@@ -33,12 +33,13 @@ static int entry_param(sx_ctx* ctx, size_t k, const Decoder* carried, const uint
     if (!m.is_dbcs()) return SX_OK;
     *out = 0;
     if (!carried || carried->idle() || len == 0) return SX_OK;
-    uint8_t first[4] = { 0, 0, 0, 0 };
-    const uint64_t n = std::min<uint64_t>(4, len);
+    uint8_t first[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const uint64_t n = std::min<uint64_t>(8, len);
     if (host_bytes) memcpy(first, host_bytes, n);
     else HIP_TRY(ctx, hipMemcpy(first, d_bytes, n, hipMemcpyDeviceToHost));
     *out = carried->entry_skip_scan(first, n);                     // for the scan kernel (its own grammar for gb18030)
     if (out_replay) *out_replay = carried->entry_skip(first, n);   // for the replay: the true token grid
+    if (getenv("SX_DEBUG_ENTRY")) { const DDecoder& dd = const_cast<Decoder*>(carried)->raw(); fprintf(stderr, "[sx] entry mission %zu: dlead %02x gb2 %02x gb3 %02x rq_n %u first %02x %02x -> scan %u replay %u\n", k, dd.dlead, dd.gb2, dd.gb3, dd.rq_n, first[0], first[1], *out, out_replay ? *out_replay : 0u); }
     return SX_OK;
 }
 int set_entry_params(sx_ctx* ctx, bool carried_state_is_entry, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len,

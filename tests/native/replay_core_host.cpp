@@ -64,3 +64,7 @@ extern "C" int sxd_decoder_step(void* d, const uint8_t* src, uint32_t n, uint8_t
     return r.result;
 }
 extern "C" void sxd_decoder_free(void* d) { delete (sx::DDecoder*)d; }
+// how many bytes at a buffer start belong to the token pending in the decoder (two-byte family incl. gb18030)
+extern "C" uint32_t sxd_entry_skip(const void* d, const uint8_t* next, uint64_t avail) {
+    return sx::dbcs_entry_skip<4>(*(const sx::DDecoder*)d, next, avail);
+}

@@ -82,6 +82,27 @@ def test_decoder_follows_the_hand_derived_vectors(name, enc, calls, which):
     assert text.decode("utf-8")  is not None
 
 
+def test_gb18030_token_pending_at_a_buffer_start():
+    """Where the token grid of a buffer begins when the carried decoder has bytes pending (what the device replay's look-back
+    uses when it walks back to the buffer start): a token boundary of the true grammar — after an error of the pending token the
+    bytes given back are decoded in front of the buffer and can take its first byte as their trail (found by tools/gpu_fuzz.py,
+    seed 20260930: pending A9 37 C3, then 84)."""
+    cases = [("a937c3", "84c39cc3", 1),      # error; 37 and C3 are decoded again, C3 takes 84: the grid starts at 1
+             ("81", "30813041", 3),          # the four-byte token finishes after three more bytes
+             ("8130", "81304142", 2),
+             ("81", "4041", 1),              # a two-byte token
+             ("813081", "30414243", 1),
+             ("", "81304142", 0)]            # nothing pending
+    for pending, nxt, want in cases:
+        dec = ProductDecoder(rc.ENC_IDS["gb18030"])
+        if pending:
+            assert dec.step(bytes.fromhex(pending), False)[:3] == ("E", len(pending) // 2, 0)
+        dec.L.sxd_entry_skip.restype = C.c_uint32
+        dec.L.sxd_entry_skip.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+        b = bytes.fromhex(nxt)
+        assert dec.L.sxd_entry_skip(dec.d, b, len(b)) == want, (pending, nxt)
+
+
 # ---- the same rules seen through the scan: the position of a finding is where its decoder call began -------------------
 def _positions_case():
     """(data, expected findings) written down from the rules in tests/golden/decoder_vectors.py — not from a run."""
