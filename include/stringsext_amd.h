@@ -173,6 +173,13 @@ const char* sx_encoding_name(uint32_t encoding);   /* Encoding::name(), e.g. "UT
  * Big5 / EUC-JP: the index blob, layout in csrc/sx_codec_core.hpp); NULL, *n_words = 0 if the encoding has none. */
 const uint16_t* sx_decoder_table(uint32_t encoding, uint64_t* n_words);
 
+/* Lower level: does the wave-cooperative stage B (csrc/sx_wave_core.hpp) cover this Mission — no -g, no -r,
+ * 1 <= chars_min_nb <= output_line_char_nb_max <= 64, a single-byte encoding (the reference's rules it relies on:
+ * src/helper.rs:315-322, 349-421)?  Returns 1 and the class byte it keeps per input byte (bit 0 a character, bit 1
+ * its UTF-8 lead byte passes af / ubf — src/mission.rs:333-348 —, bit 2 / 3 its UTF-8 form has 2 / 3 bytes) in
+ * classes[256]; 0 if not covered; < 0 on error. */
+int sx_wave_classes(const sx_mission* mission, uint8_t* classes);
+
 int  sx_abi_version(void);
 
 /* hip_device >= 0: bind to that device.  hip_device == SX_HOST_ONLY: a context

@@ -157,6 +157,17 @@ const uint16_t* sx_decoder_table(uint32_t encoding, uint64_t* n_words) {
     return t;
 }
 
+int sx_wave_classes(const sx_mission* mission, uint8_t* classes) {
+    if (!mission || !classes) return SX_E_INVALID;
+    Mission m;
+    std::string err;
+    const int rc = Mission::from_c(*mission, false, &m, &err);
+    if (rc != SX_OK) return rc;
+    if (!m.wave_ok || m.wave_lut.size() != 256) return 0;
+    memcpy(classes, m.wave_lut.data(), 256);
+    return 1;
+}
+
 int sx_create(sx_ctx** out, const sx_mission* missions, int n_missions, int hip_device, const sx_options* opt) {
     if (!out || !missions || n_missions <= 0 || n_missions > 26) { g_create_error = "bad arguments"; return SX_E_INVALID; }
     sx_ctx* ctx = new sx_ctx();

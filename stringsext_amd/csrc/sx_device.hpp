@@ -147,6 +147,37 @@ hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegion
                                        const uint64_t* fpos, const uint64_t* apos, sx_finding* findings,
                                        uint8_t* arena, uint64_t avg_out_bytes, hipStream_t stream);
 
+// ---- stage B for string-dense Missions, wave-cooperative (sx_wave_dev.hip, sx_wave_core.hpp) ----
+// One lane per decoder-input window, 64 consecutive windows per wavefront batch; two passes (count, write).
+struct WaveParams {
+    const uint8_t* data;      // device: buffer byte 0 (on the slice grid)
+    uint64_t len;
+    uint64_t consumed0;
+    uint32_t slice_base;
+    uint32_t W, wps, q, n_min;   // window bytes, windows per slice, output_line_char_nb_max, chars_min_nb
+    uint64_t g_lo, g_hi;      // windows [g_lo, g_hi) (numbered through the buffer) are replayed here
+    uint32_t nwin;            // windows a wavefront owns
+    uint32_t inject;          // the exact state at window g_lo (wv_pack), from the host
+    int32_t mission_id, file_id;
+    const uint8_t* lut;       // device: 256 class bytes (single byte: WVC_*)
+    const uint16_t* table;    // device: the decoder table (single byte: 128 entries; nullptr = x-user-defined)
+    // pass 1 out, per wavefront: findings, string bytes, the entry state it assumed for its first window, the state after its last
+    uint32_t *wave_nf, *wave_nb, *wave_in, *wave_out;
+    // pass 2 in: exclusive sums of the above; the launch's output segment starts at (f_sub, a_sub)
+    const uint64_t *wave_fbase, *wave_abase;
+    uint64_t f_sub, a_sub;
+    sx_finding* findings;
+    uint8_t* arena;
+    uint32_t str_off_base;    // added to every str_off
+    uint64_t v0;              // first wavefront of this launch
+};
+size_t wave_scratch_bytes(uint64_t n_waves);
+// pass 1 + exclusive sums + verification; totals (device, 4 x u64): findings, string bytes, wavefronts whose assumed entry
+// state was wrong (then nothing of this replay may be used), packed state after the last window
+hipError_t launch_wave_count(const WaveParams& P, uint64_t n_waves, uint64_t* fbase, uint64_t* abase, uint64_t* totals,
+                             void* scratch, size_t scratch_bytes, hipStream_t stream);
+hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipStream_t stream);
+
 // interleave several missions' findings on the device (sx_sort.hip); every src and out = [findings][string bytes]
 hipError_t merge_findings_device_part(const sx_finding* const* f, const uint8_t* const* a, const uint64_t* nf, const uint64_t* nb,
                                       const uint32_t* off0, int n_missions, void* out, void* scratch, size_t scratch_bytes,

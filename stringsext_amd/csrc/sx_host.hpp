@@ -60,6 +60,9 @@ struct Mission {
     ClassifierKind kind = kClsSingleByteLut;
     ScanParams proto{};  // a_lo.., lut filled in; data/len/recs set per launch
     std::vector<uint32_t> pair_lut;  // Big5 / EUC-JP: the pair codes the kernel keeps in LDS (ScanParams::pair_lut)
+    // wave-cooperative stage B (sx_wave_core.hpp): the Mission is one it covers, and its class byte per input byte
+    bool wave_ok = false;
+    std::vector<uint8_t> wave_lut;
     // Big5 / EUC-JP, per buffer (set by the schedule before stage A/B of a buffer; the replay only reads it):
     // how many bytes at the buffer start finish the token that was pending on entry — where its token grid begins
     mutable uint32_t buf_entry_skip = 0;

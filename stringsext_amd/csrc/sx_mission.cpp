@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "sx_host.hpp"
+#include "sx_wave_core.hpp"
 
 namespace sx {
 
@@ -175,12 +176,18 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
     } else {  // x-user-defined and single-byte tables
         bool acc[256];
         const uint16_t* tab = single_byte_table(enc);
+        // the wave-cooperative stage B (sx_wave_dev.hip) reads a class per byte: valid / accepted / bytes of its UTF-8 form
+        m->wave_ok = wv_mission_ok(in.grep_char, in.require_same_unicode_block, in.chars_min_nb, (uint32_t)m->q);
+        m->wave_lut.assign(256, 0);
         for (int b = 0; b < 256; b++) {
+            uint32_t cp = (uint32_t)b;
             if (b < 0x80) acc[b] = af[b];
             else {
-                const uint32_t cp = tab ? tab[b - 0x80] : 0xF780u + (uint32_t)(b - 0x80);
+                cp = tab ? tab[b - 0x80] : 0xF780u + (uint32_t)(b - 0x80);
                 acc[b] = cp != 0 && m->filter.pass_lead(utf8_lead_of(cp));
             }
+            if (b < 0x80 || cp != 0)
+                m->wave_lut[(size_t)b] = (uint8_t)(WVC_VALID | (acc[b] ? WVC_ACC : 0) | (cp >= 0x800 ? WVC_O3 : cp >= 0x80 ? WVC_O2 : 0));
         }
         int hl = 0, hh = 0;
         bool hempty = false;

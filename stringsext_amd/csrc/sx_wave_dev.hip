@@ -1,0 +1,252 @@
+// sx_wave_dev.hip — stage B for string-dense Missions, wave-cooperative (gfx950, wave64).
+//
+// The lane-per-region replay (sx_replay_dev.hip) decodes byte by byte under full divergence: 0.7 % of the HBM
+// peak on the bytes it touches.  Here a wavefront takes 64 CONSECUTIVE windows (8 KiB at W = 128) together:
+//   1. it streams their bytes as stage A does (16 bytes per lane, coalesced), classifies them, and leaves
+//      the per-byte masks (valid / accepted / UTF-8 length) in LDS as bit arrays;
+//   2. lane i pulls window i's 128 bits of every mask out of LDS and runs FindingCollection::from over them
+//      as bit arithmetic (sx_wave_core.hpp: decoder calls from the "invalid" bits, SplitStr's stretches and
+//      q-char cuts from find-first-set / popcount);
+//   3. the state a window carries into the next one (leftover, cut flag) travels lane to lane with one DPP move;
+//      the lanes iterate until no lane's entry state changes (two rounds on all but contrived input: only a
+//      window's first stretch depends on what is carried in);
+//   4. findings per lane -> wave prefix sum -> (pass 2) records and strings written in order.
+// A wavefront owns `nwin` consecutive windows and walks them batch by batch (the last lane's state is the next
+// batch's entry: an SGPR); it starts kWvWarm windows early with "nothing carried" — the state is a function of
+// the three windows in front —, and wave_verify_kernel checks afterwards that every wavefront's assumed entry state is
+// what its predecessor really left (if not — input built for it — the Mission falls back to the lane-per-region path).
+// Two passes: count (per-wavefront totals -> exclusive scan), write.  No atomics; output order = position order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include "sx_device.hpp"
+
+namespace sx {
+#define SXD __device__ __forceinline__
+#define SXD_NOINLINE __device__ __attribute__((noinline))
+}  // namespace sx
+#include "sx_wave_core.hpp"
+
+namespace sx {
+
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+SXD u32 wv_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+SXD u32 wv_from_prev(u32 v, u32 edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xF, 0xF, false); }   // lane i <- lane i-1; lane 0 <- edge
+SXD u32 wv_uniform(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
+SXD u32 wv_shfl(u32 v, u32 src) { return __builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v); }
+SXD u32 wv_scan_incl(u32 v, u32 lane) {
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+        const u32 o = wv_shfl(v, lane >= d ? lane - d : lane);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+struct CountEmit {
+    u32 nf = 0, nb = 0;
+    SXD void operator()(u32, u32, bool, i32, u32, u32 out_len) { nf++; nb += out_len; }
+};
+
+// pass 2: the finding record and its string (single byte: transcoded byte by byte through the decoder table)
+struct WriteEmit {
+    const WaveParams* P;
+    sx_finding* f;        // next record of this lane
+    u8* a;                // next string byte of this lane
+    u64 a_off;            // ... its offset in the segment's string arena
+    u64 win_pos;          // buffer offset of the window
+    SXD void operator()(u32 din, u32 prec, bool completes, i32 src_rel, u32 src_len, u32 out_len) {
+        const u64 soff = win_pos / kWvSlice * kWvSlice;
+        sx_finding r;
+        r.position = P->consumed0 + win_pos + din;
+        r.str_off = (u32)(a_off + P->str_off_base);
+        r.str_len = out_len;
+        r.precision = (u8)prec;
+        r.completes_previous = completes ? 1 : 0;
+        r.mission_id = (u8)P->mission_id;
+        r.reserved = 0;
+        r.input_file_id = (int16_t)P->file_id;
+        r.reserved2 = 0;
+        r.slice_index = (u32)(soff / kWvSlice) + P->slice_base;
+        *f++ = r;
+        const u8* s = P->data + (u64)((long long)win_pos + src_rel);
+        if (out_len == src_len) {          // every char is one byte on both sides (ASCII; UTF-8 input)
+            for (u32 t = 0; t < src_len; t++) a[t] = s[t];
+        } else {
+            u32 w = 0;
+            for (u32 t = 0; t < src_len; t++) {
+                const u8 b = s[t];
+                if (b < 0x80) a[w++] = b;
+                else w += dput_cp(a + w, P->table ? (u32)P->table[b - 0x80] : 0xF780u + (b - 0x80u));
+            }
+        }
+        a += out_len; a_off += out_len;
+    }
+};
+
+// MODE 0: count; 1: write
+template <int MODE>
+__global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
+    __shared__ u32 lds_mask[4][kWvMaxTiles * 32 + 8];   // valid, accepted, O2, O3: 16 bits per lane and tile
+    __shared__ u8 lds_lut[256];
+    const u32 lane = threadIdx.x;
+    ((u32*)lds_lut)[lane] = ((const u32*)P.lut)[lane];
+    __syncthreads();
+
+    const u64 v = P.v0 + blockIdx.x;
+    const u64 own_start = P.g_lo + v * P.nwin;
+    if (own_start >= P.g_hi) return;
+    const u64 own_end = own_start + P.nwin < P.g_hi ? own_start + P.nwin : P.g_hi;
+    const u64 gw = v == 0 ? own_start : own_start - kWvWarm;
+    u32 carry = v == 0 ? P.inject : 0u;   // entry state of the batch's first window
+    u32 assumed_in = carry;
+    u32 tot_f = 0, tot_b = 0;
+    u64 fbase = 0, abase = 0;
+    if (MODE == 1) { fbase = P.wave_fbase[v] - P.f_sub; abase = P.wave_abase[v] - P.a_sub; }   // relative to this launch's output segment
+    const WvParams WP{ P.q, P.n_min };
+
+    for (u64 g0 = gw; g0 < own_end; g0 += kWvBatch) {
+        const u64 g = g0 + lane;
+        const bool active = g < own_end, owned = active && g >= own_start;
+        u64 ws = 0;
+        u32 wn = 0;
+        if (active) wv_window_at(g, P.W, P.wps, P.len, &ws, &wn);
+        const u32 n_act = own_end - g0 < kWvBatch ? (u32)(own_end - g0) : kWvBatch;
+        const u64 span_lo = ((u64)wv_uniform((u32)(ws >> 32)) << 32) | wv_uniform((u32)ws);
+        const u64 we = ws + wn;
+        const int last_lane = (int)wv_uniform(n_act - 1);
+        const u64 span_hi = ((u64)__builtin_amdgcn_readlane((u32)(we >> 32), last_lane) << 32) | __builtin_amdgcn_readlane((u32)we, last_lane);
+        const u64 tile0 = span_lo & ~15ull;
+        const u32 n_tiles = (u32)((span_hi - tile0 + kTileBytes - 1) / kTileBytes);
+
+        // ---- 1. classify the batch's bytes; masks -> LDS
+        __syncthreads();   // (the previous batch's readers are done)
+        for (u32 t = 0; t < n_tiles; t++) {
+            const u64 off = tile0 + (u64)t * kTileBytes + 16ull * lane;
+            u32x4 x = { 0, 0, 0, 0 };
+            const u32 avail = off >= P.len ? 0u : (P.len - off >= 16 ? 16u : (u32)(P.len - off));
+            if (avail == 16) x = *(const u32x4*)(P.data + off);
+            else if (avail) {   // the buffer's last bytes: never read beyond them
+                u32 xs[4] = { 0, 0, 0, 0 };
+                for (u32 k = 0; k < avail; k++) xs[k >> 2] |= (u32)P.data[off + k] << (8 * (k & 3));
+                x.x = xs[0]; x.y = xs[1]; x.z = xs[2]; x.w = xs[3];
+            }
+            const WvMasks16 m = wv_classify16_single(lds_lut, x.x, x.y, x.z, x.w, avail);
+            const u32 idx = t * 64 + lane;
+            ((uint16_t*)lds_mask[0])[idx] = (uint16_t)m.v;
+            ((uint16_t*)lds_mask[1])[idx] = (uint16_t)m.a;
+            ((uint16_t*)lds_mask[2])[idx] = (uint16_t)m.o2;
+            ((uint16_t*)lds_mask[3])[idx] = (uint16_t)m.o3;
+        }
+        __syncthreads();
+
+        // ---- 2. lane = window
+        WvWin w;
+        if (active) {
+            const u32 o = (u32)(ws - tile0);
+            w = wv_win_single(wv_extract(lds_mask[0], o, wn), wv_extract(lds_mask[1], o, wn), wv_extract(lds_mask[2], o, wn),
+                              wv_extract(lds_mask[3], o, wn), wn);
+        } else { w = wv_win_single(wm_zero(), wm_zero(), wm_zero(), wm_zero(), 0); }
+
+        // ---- 3. entry states: iterate until they are consistent along the lanes
+        u32 in = lane == 0 ? carry : 0u, out = 0;
+        const bool injected = g == P.g_lo;   // the host's exact state
+        if (injected) in = P.inject;
+        u32 nf = 0, nb = 0;
+        bool todo = true;
+        for (;;) {
+            if (todo && active) {
+                WvState st = wv_unpack(in);
+                CountEmit ce;
+                wv_window<true>(WP, w, st, ce);
+                out = wv_pack(st); nf = ce.nf; nb = ce.nb;
+            } else if (!active) out = in;
+            u32 pin = wv_from_prev(out, carry);
+            if (injected) pin = P.inject;
+            todo = active && pin != in;
+            in = pin;
+            if (!__ballot(todo)) break;
+        }
+        if (g0 == gw && v != 0) {   // the state this wavefront assumes for its first own window (lane kWvWarm of the first batch)
+            assumed_in = __builtin_amdgcn_readlane(in, (int)kWvWarm);
+        }
+        carry = __builtin_amdgcn_readlane(out, 63);
+        const u32 last_out = __builtin_amdgcn_readlane(out, last_lane);
+        if (!owned) { nf = 0; nb = 0; }
+
+        // ---- 4. counts -> offsets -> (pass 2) output
+        const u32 packed = (nf << 18) | nb;   // per batch: nb <= 64 windows x 640 bytes < 2^18, nf <= 64 x 129 < 2^14
+        const u32 incl = wv_scan_incl(packed, lane);
+        const u32 bt = __builtin_amdgcn_readlane(incl, 63);
+        if (MODE == 1 && (nf | nb)) {
+            const u32 excl = incl - packed;
+            const u64 fo = fbase + tot_f + (excl >> 18), ao = abase + tot_b + (excl & 0x3FFFFu);
+            WriteEmit we_{ &P, P.findings + fo, P.arena + ao, ao, ws };
+            WvState st = wv_unpack(in);
+            wv_window<true>(WP, w, st, we_);
+        }
+        tot_f += bt >> 18; tot_b += bt & 0x3FFFFu;
+        if (g0 + kWvBatch >= own_end && MODE == 0 && lane == 0) P.wave_out[v] = last_out;
+    }
+    if (MODE == 0 && lane == 0) { P.wave_nf[v] = tot_f; P.wave_nb[v] = tot_b; P.wave_in[v] = assumed_in; }
+}
+
+// Every wavefront after the first assumed "nothing carried" kWvWarm windows in front of its own; is the state it
+// reached for its first own window what its predecessor really left there?  totals: [0] findings, [1] string bytes,
+// [2] wavefronts whose assumption was wrong, [3] the state after the last window.
+__global__ __launch_bounds__(256) void wave_verify_kernel(const u32* wave_in, const u32* wave_out, const u32* wave_nf, const u32* wave_nb,
+                                                          const u64* fbase, const u64* abase, u64 n_waves, u64* totals) {
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_waves) return;
+    if (v > 0 && wave_in[v] != wave_out[v - 1]) atomicAdd((unsigned long long*)&totals[2], 1ull);
+    if (v + 1 == n_waves) { totals[0] = fbase[v] + wave_nf[v]; totals[1] = abase[v] + wave_nb[v]; totals[3] = wave_out[v]; }
+}
+
+struct U32ToU64 {
+    const u32* p;
+    __device__ u64 operator()(u64 i) const { return (u64)p[i]; }
+};
+
+size_t wave_scratch_bytes(uint64_t n_waves) {
+    size_t a = 0;
+    auto it = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), U32ToU64{ nullptr });
+    (void)rocprim::exclusive_scan(nullptr, a, it, (u64*)nullptr, (u64)0, (size_t)n_waves, rocprim::plus<u64>(), (hipStream_t)0);
+    return a + 512;
+}
+
+hipError_t launch_wave_count(const WaveParams& P, uint64_t n_waves, uint64_t* fbase, uint64_t* abase, uint64_t* totals,
+                             void* scratch, size_t scratch_bytes, hipStream_t stream) {
+    if (n_waves == 0) return hipSuccess;
+    WaveParams Q = P;
+    Q.v0 = 0;
+    hipLaunchKernelGGL(wave_replay_kernel<0>, dim3((unsigned)n_waves), dim3(64), 0, stream, Q);
+    void* tmp = (void*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    size_t tmp_bytes = scratch_bytes - (size_t)((uint8_t*)tmp - (uint8_t*)scratch);
+    auto itf = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), U32ToU64{ P.wave_nf });
+    hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, itf, fbase, (u64)0, (size_t)n_waves, rocprim::plus<u64>(), stream);
+    if (e != hipSuccess) return e;
+    tmp_bytes = scratch_bytes - (size_t)((uint8_t*)tmp - (uint8_t*)scratch);
+    auto itb = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), U32ToU64{ P.wave_nb });
+    e = rocprim::exclusive_scan(tmp, tmp_bytes, itb, abase, (u64)0, (size_t)n_waves, rocprim::plus<u64>(), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(totals, 0, 4 * sizeof(uint64_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wave_verify_kernel, dim3((unsigned)((n_waves + 255) / 256)), dim3(256), 0, stream, P.wave_in, P.wave_out, P.wave_nf,
+                       P.wave_nb, fbase, abase, n_waves, totals);
+    return hipGetLastError();
+}
+
+// wavefronts [v0, v1): their findings go to P.findings / P.arena at (their offset - P.f_sub / P.a_sub)
+hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipStream_t stream) {
+    if (v1 <= v0) return hipSuccess;
+    WaveParams Q = P;
+    Q.v0 = v0;
+    hipLaunchKernelGGL(wave_replay_kernel<1>, dim3((unsigned)(v1 - v0)), dim3(64), 0, stream, Q);
+    return hipGetLastError();
+}
+
+}  // namespace sx

@@ -1,0 +1,190 @@
+// Test-only harness: the wave-cooperative stage B (stringsext_amd/csrc/sx_wave_core.hpp) compiled as host code and
+// driven the way sx_wave_dev.hip drives it — wavefronts that own `nwin` windows, batches of 64 windows with one "lane"
+// each, bit masks staged in an array that stands for LDS, entry states exchanged lane to lane until they are consistent,
+// warm-up windows, the verification of the assumed entry states, count pass then write pass.  Only the wave intrinsics
+// are replaced by loops; every per-lane function is the kernels' own.
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+#define SXD inline
+#define SXD_NOINLINE inline
+#include "../../stringsext_amd/csrc/sx_device.hpp"
+#include "../../stringsext_amd/csrc/sx_wave_core.hpp"
+
+using namespace sx;
+
+namespace {
+
+struct CountEmit {
+    u32 nf = 0, nb = 0;
+    void operator()(u32, u32, bool, i32, u32, u32 out_len) { nf++; nb += out_len; }
+};
+struct WriteEmit {
+    const WaveParams* P;
+    sx_finding* f;
+    u8* a;
+    u64 a_off, win_pos;
+    void operator()(u32 din, u32 prec, bool completes, i32 src_rel, u32 src_len, u32 out_len) {
+        const u64 soff = win_pos / kWvSlice * kWvSlice;
+        sx_finding r;
+        memset(&r, 0, sizeof r);
+        r.position = P->consumed0 + win_pos + din;
+        r.str_off = (u32)(a_off + P->str_off_base);
+        r.str_len = out_len;
+        r.precision = (u8)prec;
+        r.completes_previous = completes ? 1 : 0;
+        r.mission_id = (u8)P->mission_id;
+        r.input_file_id = (int16_t)P->file_id;
+        r.slice_index = (u32)(soff / kWvSlice) + P->slice_base;
+        *f++ = r;
+        const u8* s = P->data + (u64)((long long)win_pos + src_rel);
+        if (out_len == src_len) memcpy(a, s, src_len);
+        else {
+            u32 w = 0;
+            for (u32 t = 0; t < src_len; t++) {
+                const u8 b = s[t];
+                if (b < 0x80) a[w++] = b;
+                else w += dput_cp(a + w, P->table ? (u32)P->table[b - 0x80] : 0xF780u + (b - 0x80u));
+            }
+        }
+        a += out_len; a_off += out_len;
+    }
+};
+
+// one wavefront, MODE 0 count / 1 write; returns false if an iteration did not settle (cannot happen)
+template <int MODE>
+bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
+    const u64 own_start = P.g_lo + v * P.nwin;
+    if (own_start >= P.g_hi) return true;
+    const u64 own_end = own_start + P.nwin < P.g_hi ? own_start + P.nwin : P.g_hi;
+    const u64 gw = v == 0 ? own_start : own_start - kWvWarm;
+    u32 carry = v == 0 ? P.inject : 0u, assumed_in = carry;
+    u32 tot_f = 0, tot_b = 0;
+    u64 fbase = 0, abase = 0;
+    if (MODE == 1) { fbase = P.wave_fbase[v] - P.f_sub; abase = P.wave_abase[v] - P.a_sub; }
+    const WvParams WP{ P.q, P.n_min };
+    std::vector<u32> lds[4];
+    for (auto& l : lds) l.assign(kWvMaxTiles * 32 + 8, 0xDEADBEEFu);   // stale bits must not matter
+    for (u64 g0 = gw; g0 < own_end; g0 += kWvBatch) {
+        u64 ws[64]; u32 wn[64]; bool active[64], owned[64];
+        for (u32 l = 0; l < 64; l++) {
+            const u64 g = g0 + l;
+            active[l] = g < own_end; owned[l] = active[l] && g >= own_start;
+            ws[l] = 0; wn[l] = 0;
+            if (active[l]) wv_window_at(g, P.W, P.wps, P.len, &ws[l], &wn[l]);
+        }
+        const u32 n_act = own_end - g0 < kWvBatch ? (u32)(own_end - g0) : kWvBatch;
+        const u64 span_lo = ws[0], span_hi = ws[n_act - 1] + wn[n_act - 1];
+        const u64 tile0 = span_lo & ~15ull;
+        const u32 n_tiles = (u32)((span_hi - tile0 + kTileBytes - 1) / kTileBytes);
+        if (n_tiles > kWvMaxTiles) return false;
+        for (u32 t = 0; t < n_tiles; t++)
+            for (u32 l = 0; l < 64; l++) {
+                const u64 off = tile0 + (u64)t * kTileBytes + 16ull * l;
+                u32 xs[4] = { 0, 0, 0, 0 };
+                const u32 avail = off >= P.len ? 0u : (P.len - off >= 16 ? 16u : (u32)(P.len - off));
+                for (u32 k = 0; k < avail; k++) xs[k >> 2] |= (u32)P.data[off + k] << (8 * (k & 3));
+                const WvMasks16 m = wv_classify16_single(P.lut, xs[0], xs[1], xs[2], xs[3], avail);
+                const u32 idx = t * 64 + l;
+                ((uint16_t*)lds[0].data())[idx] = (uint16_t)m.v;
+                ((uint16_t*)lds[1].data())[idx] = (uint16_t)m.a;
+                ((uint16_t*)lds[2].data())[idx] = (uint16_t)m.o2;
+                ((uint16_t*)lds[3].data())[idx] = (uint16_t)m.o3;
+            }
+        WvWin w[64];
+        for (u32 l = 0; l < 64; l++) {
+            if (active[l]) {
+                const u32 o = (u32)(ws[l] - tile0);
+                w[l] = wv_win_single(wv_extract(lds[0], o, wn[l]), wv_extract(lds[1], o, wn[l]), wv_extract(lds[2], o, wn[l]),
+                                     wv_extract(lds[3], o, wn[l]), wn[l]);
+            } else w[l] = wv_win_single(wm_zero(), wm_zero(), wm_zero(), wm_zero(), 0);
+        }
+        u32 in[64], out[64], nf[64], nb[64];
+        bool todo[64], injected[64];
+        for (u32 l = 0; l < 64; l++) {
+            injected[l] = g0 + l == P.g_lo;
+            in[l] = l == 0 ? carry : 0u;
+            if (injected[l]) in[l] = P.inject;
+            out[l] = 0; nf[l] = nb[l] = 0; todo[l] = true;
+        }
+        u32 rounds = 0;
+        for (;;) {
+            if (++rounds > 70) return false;
+            for (u32 l = 0; l < 64; l++) {
+                if (todo[l] && active[l]) {
+                    WvState st = wv_unpack(in[l]);
+                    CountEmit ce;
+                    wv_window<true>(WP, w[l], st, ce, skip_idle);
+                    out[l] = wv_pack(st); nf[l] = ce.nf; nb[l] = ce.nb;
+                } else if (!active[l]) out[l] = in[l];
+            }
+            bool any = false;
+            u32 pin[64];
+            for (u32 l = 0; l < 64; l++) pin[l] = l == 0 ? carry : out[l - 1];
+            for (u32 l = 0; l < 64; l++) {
+                if (injected[l]) pin[l] = P.inject;
+                todo[l] = active[l] && pin[l] != in[l];
+                in[l] = pin[l];
+                any = any || todo[l];
+            }
+            if (!any) break;
+        }
+        if (rounds > *rounds_max) *rounds_max = rounds;
+        if (g0 == gw && v != 0) assumed_in = in[kWvWarm];
+        carry = out[63];
+        const u32 last_out = out[n_act - 1];
+        u32 bf = 0, bb = 0;
+        for (u32 l = 0; l < 64; l++) {
+            if (!owned[l]) { nf[l] = 0; nb[l] = 0; }
+            if (MODE == 1 && (nf[l] | nb[l])) {
+                const u64 fo = fbase + tot_f + bf, ao = abase + tot_b + bb;
+                WriteEmit we{ &P, P.findings + fo, P.arena + ao, ao, ws[l] };
+                WvState st = wv_unpack(in[l]);
+                wv_window<true>(WP, w[l], st, we, skip_idle);
+                if ((u64)(we.f - (P.findings + fo)) != nf[l] || we.a_off - ao != nb[l]) return false;   // both passes must agree
+            }
+            bf += nf[l]; bb += nb[l];
+        }
+        if (bf >= (1u << 14) || bb >= (1u << 18)) return false;   // the kernels pack a batch's totals into 32 bits
+        tot_f += bf; tot_b += bb;
+        if (g0 + kWvBatch >= own_end && MODE == 0) P.wave_out[v] = last_out;
+    }
+    if (MODE == 0) { P.wave_nf[v] = tot_f; P.wave_nb[v] = tot_b; P.wave_in[v] = assumed_in; }
+    return true;
+}
+
+}  // namespace
+
+// Replays windows [g_lo, all) of the buffer from the exact state `inject` at window g_lo.  Returns 0, or -1 (a pass did not
+// settle / the passes disagree), -2 (output capacity).  *bad_waves = wavefronts whose assumed entry state was wrong.
+extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0, uint32_t slice_base, uint32_t W, uint32_t q, uint32_t n_min,
+                           uint64_t g_lo, uint32_t inject, uint32_t nwin, const uint8_t* lut, const uint16_t* table, int mission_id,
+                           int file_id, sx_finding* fout, uint64_t fcap, uint8_t* aout, uint64_t acap, uint64_t* nf, uint64_t* nb,
+                           uint32_t* final_state, uint64_t* bad_waves, int skip_idle, uint32_t* rounds_max) {
+    WaveParams P;
+    memset(&P, 0, sizeof P);
+    P.data = data; P.len = len; P.consumed0 = consumed0; P.slice_base = slice_base; P.W = W; P.wps = wv_wps(W); P.q = q; P.n_min = n_min;
+    P.g_lo = g_lo; P.g_hi = wv_window_count(len, W); P.nwin = nwin; P.inject = inject; P.mission_id = mission_id; P.file_id = file_id;
+    P.lut = lut; P.table = table;
+    *nf = *nb = 0; *bad_waves = 0; *final_state = inject; *rounds_max = 0;
+    if (P.g_hi <= P.g_lo) return 0;
+    const u64 n_waves = (P.g_hi - P.g_lo + nwin - 1) / nwin;
+    std::vector<u32> wnf(n_waves), wnb(n_waves), win(n_waves), wout(n_waves);
+    std::vector<u64> fb(n_waves), ab(n_waves);
+    P.wave_nf = wnf.data(); P.wave_nb = wnb.data(); P.wave_in = win.data(); P.wave_out = wout.data();
+    for (u64 v = 0; v < n_waves; v++) if (!wave<0>(P, v, skip_idle != 0, rounds_max)) return -1;
+    u64 f = 0, a = 0;
+    for (u64 v = 0; v < n_waves; v++) {
+        fb[v] = f; ab[v] = a; f += wnf[v]; a += wnb[v];
+        if (v > 0 && win[v] != wout[v - 1]) (*bad_waves)++;
+    }
+    *nf = f; *nb = a; *final_state = wout[n_waves - 1];
+    if (f > fcap || a > acap) return -2;
+    P.wave_fbase = fb.data(); P.wave_abase = ab.data(); P.findings = fout; P.arena = aout;
+    u32 dummy = 0;
+    for (u64 v = 0; v < n_waves; v++) if (!wave<1>(P, v, skip_idle != 0, &dummy)) return -1;
+    return 0;
+}
+
+extern "C" uint32_t sxw_pack_state(uint32_t lc, uint32_t lb, uint32_t lback, uint32_t cut) { return wv_pack(WvState{ lc, lb, lback, cut }); }

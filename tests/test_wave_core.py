@@ -1,0 +1,149 @@
+"""The wave-cooperative stage B (stringsext_amd/csrc/sx_wave_core.hpp: FindingCollection::from as bit arithmetic over
+one window's masks), compiled as plain host C++ and driven exactly as sx_wave_dev.hip drives it (tests/native/
+wave_core_host.cpp: wavefronts, batches of 64 windows, warm-up windows, entry states exchanged until consistent, count pass
+then write pass), must give the oracle's findings — position, precision, `+`, string, slice — on every kind of input."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import pytest
+
+import refconfig as rc
+import stringsext_amd as sx
+import sxo_binding as sxo
+from test_host_logic import soup, synth
+from test_sharded_gloo import oracle_findings
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NATIVE = os.path.join(ROOT, "tests", "native")
+
+
+def load_wave():
+    so = os.path.join(NATIVE, "libwave_core_host.so")
+    src = os.path.join(NATIVE, "wave_core_host.cpp")
+    hdrs = [os.path.join(ROOT, "stringsext_amd", "csrc", h) for h in ("sx_wave_core.hpp", "sx_codec_core.hpp", "sx_device.hpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                               "-Wno-unknown-pragmas", "-o", so, src])
+    L = C.CDLL(so)
+    L.sxw_emulate.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
+                              C.c_uint32, C.c_char_p, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.POINTER(sx.Finding), C.c_uint64,
+                              C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint32)]
+    L.sxw_pack_state.restype = C.c_uint32
+    L.sxw_pack_state.argtypes = [C.c_uint32] * 4
+    return L
+
+
+@pytest.fixture(scope="module")
+def wave():
+    return load_wave()
+
+
+def wave_classes(m):
+    """the product's class table for the Mission (sx_wave_classes), or None if the wave path does not cover it"""
+    L = sx.lib()
+    L.sx_wave_classes.argtypes, L.sx_wave_classes.restype = [C.POINTER(sx.Mission), C.POINTER(C.c_uint8)], C.c_int
+    cm = sx.Mission.from_dict(dict(m, mission_id=m.get("mission_id", 0)))
+    out = (C.c_uint8 * 256)()
+    r = L.sx_wave_classes(C.byref(cm), out)
+    assert r >= 0
+    return bytes(out) if r == 1 else None
+
+
+PREC = {0: "Before", 1: "Exact", 2: "After"}
+
+
+def emulate(L, m, data, nwin=508, skip_idle=1, g_lo=0, inject=0, consumed0=None):
+    lut = wave_classes(m)
+    assert lut is not None
+    t = sx.decoder_table(m["encoding"])
+    table = t[0] if t else None
+    q = m["output_line_char_nb_max"]
+    cap_f = len(data) + 64
+    cap_a = 4 * len(data) + 4096
+    fout = (sx.Finding * cap_f)()
+    aout = (C.c_uint8 * cap_a)()
+    nf, nb, bad = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    fin, rounds = C.c_uint32(), C.c_uint32()
+    rcode = L.sxw_emulate(data, len(data), m["counter_offset"] if consumed0 is None else consumed0, 0, 2 * q, q, m["chars_min_nb"], g_lo,
+                          inject, nwin, lut, table, 0, 1, fout, cap_f, aout, cap_a, C.byref(nf), C.byref(nb), C.byref(fin), C.byref(bad),
+                          skip_idle, C.byref(rounds))
+    assert rcode == 0, rcode
+    arena = bytes(aout[:nb.value])
+    got = []
+    for i in range(nf.value):
+        f = fout[i]
+        got.append((f.position, PREC[f.precision], arena[f.str_off:f.str_off + f.str_len].decode("utf-8"), bool(f.completes_previous), 0,
+                    f.slice_index))
+    return got, dict(final=fin.value, bad=bad.value, rounds=rounds.value)
+
+
+def text_lines(rng, n, lo=10, hi=120, alphabet=b"abcdefghijklmnopqrstuvwxyzABCDEFGH0123456789_-./:= "):
+    out = bytearray()
+    while len(out) < n:
+        out += bytes(rng.choice(alphabet) for _ in range(rng.randrange(lo, hi))) + b"\n"
+    return bytes(out[:n])
+
+
+def records(rng, n, rec, fill):
+    """fixed-width records on the window grid: `rec` accepted bytes, then rejected filler up to the next multiple of 64"""
+    out = bytearray()
+    while len(out) < n:
+        out += b"x" * rec
+        out += bytes([fill]) * (-len(out) % 64 or 64)
+    return bytes(out[:n])
+
+
+def inputs(rng):
+    yield "random", rng.randbytes(70_000)
+    yield "text", text_lines(rng, 90_000)
+    yield "long lines", text_lines(rng, 60_000, 100, 700)
+    yield "soup", soup(rng, 50_000)
+    yield "synth dense", synth(rng, 80_000, 1 / 60)
+    yield "all accepted", b"A" * 20_000
+    yield "records 64", records(rng, 40_000, 64, 0)
+    yield "records 60", records(rng, 40_000, 60, 0xFF)
+    yield "records 128", records(rng, 40_000, 128, 1)
+    yield "high bytes", bytes(rng.choice([0x41, 0x42, 0xC0, 0xE1, 0xFF, 0x98, 0x0A, 0x20]) for _ in range(50_000))
+    yield "short tail", text_lines(rng, 4096 * 3 + 77)
+    yield "tiny", b"hello world, this is tiny\n"
+    yield "one byte", b"a"
+
+
+MISSIONS = [
+    dict(encodings=["ascii"], chars_min="4"),
+    dict(encodings=["ascii"], chars_min="1"),
+    dict(encodings=["ascii"], chars_min="10", output_line_len="10"),
+    dict(encodings=["ascii"], chars_min="3", output_line_len="6"),
+    dict(encodings=["ascii"], chars_min="5", output_line_len="30", ascii_filter="All"),
+    dict(encodings=["x-user-defined"], chars_min="4", unicode_block_filter="All"),
+    dict(encodings=["koi8-r"], chars_min="10", unicode_block_filter="Cyrillic"),
+    dict(encodings=["koi8-r"], chars_min="4"),
+    dict(encodings=["windows-1252"], chars_min="4", unicode_block_filter="Latin"),
+    dict(encodings=["windows-1253"], chars_min="2", output_line_len="8", unicode_block_filter="All"),
+    dict(encodings=["windows-874"], chars_min="6", unicode_block_filter="All"),
+    dict(encodings=["iso-8859-7"], chars_min="64", output_line_len="64", unicode_block_filter="All"),
+    dict(encodings=["ibm866"], chars_min="7", output_line_len="32", ascii_filter="None", unicode_block_filter="All"),
+]
+
+
+@pytest.mark.parametrize("mi", range(len(MISSIONS)))
+def test_emulated_wave_pipeline_equals_the_oracle(wave, mi):
+    m = rc.missions(**MISSIONS[mi])[0]
+    rng = random.Random(1000 + mi)
+    for name, data in inputs(rng):
+        want = oracle_findings([dict(m, mission_id=0)], data)
+        for nwin, skip in ((508, 1), (60, 0), (7, 1), (123, 1)):
+            got, info = emulate(wave, m, data, nwin=nwin, skip_idle=skip)
+            assert info["bad"] == 0, (name, nwin, info)
+            assert got == want, (name, nwin, skip, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
+
+
+def test_missions_the_wave_path_does_not_cover():
+    for kw in (dict(encodings=["ascii"], chars_min="4", grep_char="47"), dict(encodings=["ascii"], chars_min="4", same_unicode_block=True),
+               dict(encodings=["ascii"], chars_min="0"), dict(encodings=["ascii"], chars_min="70"),
+               dict(encodings=["ascii"], chars_min="4", output_line_len="100"), dict(encodings=["utf-16le"], chars_min="4"),
+               dict(encodings=["big5"], chars_min="4")):
+        assert wave_classes(rc.missions(**kw)[0]) is None, kw

@@ -1,0 +1,34 @@
+"""CPU-only randomized check of the wave-cooperative stage B (no GPU): sx_wave_core.hpp compiled for the host and driven as
+sx_wave_dev.hip drives it (tests/native/wave_core_host.cpp) against the oracle, on the cases of gpu_fuzz.py whose Missions
+the wave path covers, with random wavefront sizes.  usage: tools/wave_fuzz.py SECONDS [SEED]"""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fuzz_case
+import test_wave_core as twc
+from test_sharded_gloo import oracle_findings
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+rng = random.Random(seed)
+L = twc.load_wave()
+t0 = time.time(); n = checked = 0; max_rounds = 0
+while time.time() - t0 < budget:
+    n += 1
+    case_seed = rng.randrange(1 << 31)
+    c = fuzz_case.make(case_seed)
+    data = c["files"][0][:300_000]
+    if not data:
+        continue
+    for m in c["missions"]:
+        if twc.wave_classes(m) is None:
+            continue
+        want = oracle_findings([dict(m, mission_id=0)], data)
+        nwin = rng.choice([508, 508, 60, 5, 17, 64, 1000])
+        got, info = twc.emulate(L, m, data, nwin=nwin, skip_idle=rng.choice([0, 1, 1]))
+        max_rounds = max(max_rounds, info["rounds"])
+        if got != want or info["bad"]:
+            print(f"MISMATCH wave seed {seed} case_seed {case_seed} mission {m} nwin={nwin} info={info}: {fuzz_case.describe(c)}")
+            print("  first diff", next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
+            sys.exit(1)
+        checked += 1
+print(f"wave fuzz seed {seed}: {n} cases, {checked} mission replays (most rounds to settle a batch: {max_rounds}), all equal to the oracle")
