@@ -122,6 +122,7 @@ typedef struct sx_stats {
     double   device_ms;                  /* all mission streams, first launch -> last completion */
     double   h2d_ms, d2h_ms, replay_ms, total_ms;
     uint64_t heavy_tiles;                /* 1 KiB tiles that needed the general cross-lane path (all missions) */
+    uint64_t wave_windows;               /* decoder-input windows replayed by the wave-cooperative stage B (all missions) */
 } sx_stats;
 
 typedef struct sx_ctx sx_ctx;

@@ -266,6 +266,7 @@ void sx_destroy(sx_ctx* ctx) {
             }
             if (d.d_table) (void)hipFree(d.d_table);
             if (d.d_pair_lut) (void)hipFree(d.d_pair_lut);
+            if (d.d_wave_lut) (void)hipFree(d.d_wave_lut);
             for (void* q : d.d_rp) if (q) (void)hipFree(q);
             if (d.h_runs) (void)hipHostFree(d.h_runs);
             if (d.ev_runs) (void)hipEventDestroy(d.ev_runs);

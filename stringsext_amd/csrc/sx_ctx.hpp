@@ -103,6 +103,7 @@ struct MissionDev {
     // stage B on the device: grow-only buffers
     uint16_t* d_table = nullptr;                        // decoder table: single byte (128 entries) or the Big5 / EUC-JP blob
     uint32_t* d_pair_lut = nullptr;                     // Big5 / EUC-JP: Mission::pair_lut for the scan kernel
+    uint8_t* d_wave_lut = nullptr;                      // wave-cooperative stage B: Mission::wave_lut (uploaded at its first use)
     sx_run* h_runs = nullptr; uint64_t h_runs_cap = 0;   // pinned: runs joined on the device
     hipEvent_t ev_runs = nullptr;                         // their copy (on sx_ctx::d2h_stream) is done
     void* d_rp[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
@@ -262,6 +263,11 @@ struct PreReplayed {
 };
 
 
+// wave-cooperative stage B (sx_wave.cpp): for whole buffers of a Mission it covers, when the buffer is string-dense
+constexpr int SX_WAVE_FALLBACK = 1001;   // (internal) nothing was produced: use the lane-per-region path
+bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs);
+int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, MissionFindings* out, uint64_t* end_pos,
+                        uint64_t defer_min_bytes);
 bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs);
 int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, const RunList& runs,
                           MissionFindings* out, uint64_t* end_pos, uint64_t defer_min_bytes);

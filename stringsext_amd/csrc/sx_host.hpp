@@ -224,6 +224,10 @@ void replay_plan_range(uint64_t lo, uint64_t hi, unsigned max_parts, std::vector
 void replay_part(const Mission& m, const ScannerState& entry, uint64_t consumed0, uint64_t stream0, ByteView& bytes,
                  uint64_t len, int file_id, bool is_last, const sx_run* runs, uint64_t n_runs, uint64_t lo, uint64_t hi,
                  bool entry_exact, ReplayPart* part);
+// FindingCollection::from over every window of [lo, hi) (window starts; hi may be len), one after the other from the exact
+// state `st` at lo; on return `st` is the exact state at hi, whatever is pending there (no run list needed).
+void replay_exact_windows(const Mission& m, ScannerState& st, uint64_t consumed0, uint64_t stream0, ByteView& bytes, uint64_t len,
+                          int file_id, uint64_t lo, uint64_t hi, MissionFindings* out);
 void replay_stitch(const Mission& m, ScannerState& st, uint64_t consumed0, uint64_t stream0, ByteView& bytes,
                    uint64_t len, int file_id, bool is_last, const sx_run* runs, uint64_t n_runs,
                    std::vector<ReplayPart>& parts, MissionFindings* out, unsigned copy_threads,

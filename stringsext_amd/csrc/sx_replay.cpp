@@ -334,6 +334,7 @@ private:
                         dout = 0;
                     }
                 }
+                if (din < slen && soff + din >= hard_stop_) { stopped = true; break; }   // replay_exact_windows: the state as it is
                 // a window boundary inside the slice: may we stop here?
                 if (din < slen && !maybe_cut && may_drop(ob + dout - leftover_len, leftover_len) && !digit_pending()
                     && region_over(soff + din)) {
@@ -345,7 +346,7 @@ private:
             st.last_scan_run_leftover.assign((const char*)ob + dout - leftover_len, leftover_len);
             st.last_run_str_was_printed_and_is_maybe_cut_str = maybe_cut;
             pos = soff + din;
-            if (stopped) return pos;
+            if (stopped || pos >= hard_stop_) return pos;
             if (!maybe_cut && may_drop(ob + dout - leftover_len, leftover_len) && !digit_pending() && region_over(pos)) return pos;
         }
         return pos;
@@ -371,6 +372,7 @@ private:
 
     // no cut string pending at window start p: is there nothing that forces the replay to continue right here?
     bool region_over(uint64_t p) {
+        if (p < hard_stop_ && hard_stop_ != ~0ull) return false;   // replay_exact_windows: every window up to there
         while (ri_ < n_runs_ && runs_[ri_].end <= p) ri_++;
         // only a long run across p keeps the region going; one that begins at or behind p starts its own
         // (with -g also one that begins in the window at p: sx_replay_core.hpp regions_may_touch)
@@ -401,6 +403,18 @@ private:
     uint64_t hi_ = 0, ri_ = 0;
     size_t hint_ = 0;
     bool owns_tail_ = false, strict_ = false;
+    uint64_t hard_stop_ = ~0ull;   // replay_exact_windows: stop at this window start whatever is pending
+
+public:
+    // every window of [lo, hi) in turn from the exact state `st` at lo; `st` becomes the exact state at hi
+    uint64_t run_exact(ScannerState& st, uint64_t lo, uint64_t hi, MissionFindings* out) {
+        st_ = &st; out_ = out; hi_ = hi; owns_tail_ = false; strict_ = true; ri_ = n_runs_;
+        hard_stop_ = hi;
+        const uint64_t pos = lo < hi ? scan_from(lo) : lo;
+        st.consumed_bytes = consumed0_ + pos;
+        st.stream_bytes = stream0_ + pos;
+        return pos;
+    }
 };
 
 }  // namespace
@@ -427,6 +441,12 @@ void replay_part(const Mission& m, const ScannerState& entry, uint64_t consumed0
     part->end_pos = rr.run(part->state, lo, hi, entry_exact, hi >= len, &part->findings, &log);
     part->regions.clear();
     for (const RegionLog& r : log) part->regions.push_back({ r.start, r.end, r.f0, r.f1 });
+}
+
+void replay_exact_windows(const Mission& m, ScannerState& st, uint64_t consumed0, uint64_t stream0, ByteView& bytes, uint64_t len,
+                          int file_id, uint64_t lo, uint64_t hi, MissionFindings* out) {
+    RangeReplay rr(m, bytes, len, file_id, false, nullptr, 0, consumed0, stream0);
+    (void)rr.run_exact(st, lo, hi < len ? hi : len, out);
 }
 
 // Serial verification of speculative parts (part k assumed "nothing carried" at its start):

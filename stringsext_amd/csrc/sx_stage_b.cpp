@@ -22,6 +22,7 @@ bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, siz
     // mission is replayed by ONE exact sequential pass on the host: no derived states, no speculation.
     if (ctx->missions[k].c.chars_min_nb == 0) return false;
     if (getenv("SX_HOST_REPLAY")) return false;
+    if (wave_replay_wanted(ctx, job, k, n_runs)) return true;
     return (ctx->opt.flags & SX_OPT_DEVICE_REPLAY) || getenv("SX_DEVICE_REPLAY") || n_runs >= 4096;
 }
 
@@ -359,6 +360,10 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
                           MissionFindings* out, uint64_t* end_pos, uint64_t defer_min_bytes) {
     const size_t n = runs.size();
     MissionDev& d = ctx->dev[k];
+    if (wave_replay_wanted(ctx, job, k, n)) {   // string-dense: a lane per window instead of a lane per region (sx_wave.cpp)
+        const int rc = wave_replay_mission(ctx, k, view, job, out, end_pos, defer_min_bytes);
+        if (rc != SX_WAVE_FALLBACK) return rc;
+    }
     size_t K = 1;
     const bool can = ctx->missions.size() == 1 && runs.on_device && !getenv("SX_HOST_STITCH") && defer_min_bytes == 0;
     if (can && n >= (1u << 20)) K = 3;   // (measured on string-dense and text-like input: 3 beats 2, 4 and 6)

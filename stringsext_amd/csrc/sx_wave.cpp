@@ -1,0 +1,178 @@
+// sx_wave.cpp — stage B of a string-dense Mission through the wave-cooperative kernels (sx_wave_dev.hip): the host's share.
+//
+// The lane-per-region replay costs time per long run, the wave kernels cost time per input byte (every window of the
+// buffer is replayed, a lane each, whether anything is found in it or not): they take over when a Mission has more
+// than a run per ~500 bytes — `-e ascii -n 4` on binaries, text, a legacy code page on random bytes — and cover the
+// Missions sx_wave_core.hpp names (no -g, no -r, 1 <= n <= q <= 64, a single-byte decoder).
+//   host:   the buffer's first window(s) from the exact carried ScannerState (its leftover's bytes lie in the previous
+//           buffer) — FindingCollection::from as ever, replay_exact_windows;
+//   device: every other window: count pass -> exclusive sums + verification of the wavefronts' assumed entry states ->
+//           write pass straight into the result's layout [findings][strings], in slabs of wavefronts whose copy to the
+//           host runs while the next slab is written;
+//   host:   the state handed to the next buffer, rebuilt from the (leftover chars, cut flag) the last window left.
+#include "sx_ctx.hpp"
+#include "sx_wave_core.hpp"
+
+using namespace sx;
+
+namespace sx {
+
+// runs per byte from which the wave kernels are the cheaper stage B (measured: ~1.2 ns per run there, ~2.5 ps per byte here)
+static uint64_t wave_min_density_bytes() {
+    static const uint64_t v = [] { const char* e = getenv("SX_WAVE_BYTES_PER_RUN"); return e ? (uint64_t)atoll(e) : 480ull; }();
+    return v;
+}
+
+bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs) {
+    const Mission& m = ctx->missions[k];
+    if (!m.wave_ok || !job.d_bytes || ctx->host_only || job.is_last || !job.commit_state) return false;
+    if (job.lo[k] != 0 || job.hi != job.len || !job.entry_exact[k] || job.len < 2 * kInputBufLen) return false;   // whole buffers only
+    if (ctx->opt.flags & SX_OPT_HOST_REPLAY) return false;
+    if (const char* e = getenv("SX_WAVE_REPLAY")) return atoi(e) != 0;
+    if (getenv("SX_HOST_REPLAY") || getenv("SX_HOST_STITCH") || getenv("SX_NO_REPLAY_CACHE")) return false;   // tests of the other path
+    return (uint64_t)n_runs * wave_min_density_bytes() > job.len;
+}
+
+static uint32_t utf8_chars(const std::string& s) {
+    uint32_t n = 0;
+    for (unsigned char c : s) n += (c & 0xC0) != 0x80;
+    return n;
+}
+
+// SX_OK, an error, or SX_WAVE_FALLBACK: nothing was produced and nothing changed — use the lane-per-region path.
+int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, MissionFindings* out, uint64_t* end_pos,
+                        uint64_t defer_min_bytes) {
+    const Mission& m = ctx->missions[k];
+    MissionDev& d = ctx->dev[k];
+    const uint32_t W = (uint32_t)m.window, wps = wv_wps(W);
+    const uint64_t len = job.len;
+    const double t0 = now_ms();
+
+    // ---- host: the first window(s), until the leftover's bytes lie inside this buffer
+    ScannerState st = ctx->states[k];
+    MissionFindings hf;
+    uint64_t E = 0;
+    for (int guard = 0; guard < 64 && E < len; guard++) {
+        uint64_t ws; uint32_t wn;
+        wv_window_at(wv_window_no(E, W, wps), W, wps, len, &ws, &wn);
+        const uint64_t next = ws + wn;
+        replay_exact_windows(m, st, job.consumed0[k], job.stream0[k], view, len, job.file_id, E, next, &hf);
+        E = next;
+        if (st.last_scan_run_leftover.size() + 4 <= E) break;
+    }
+    if (st.last_scan_run_leftover.size() + 4 > E && E < len) return SX_WAVE_FALLBACK;
+    for (sx_finding& f : hf.v) f.slice_index += job.slice_base;
+    const uint64_t nfh = hf.v.size(), nbh = hf.arena.size();
+
+    const uint64_t g_all = wv_window_count(len, W);
+    const uint64_t g_lo = E < len ? wv_window_no(E, W, wps) : g_all;
+    uint64_t nf = 0, nb = 0;
+    uint32_t final_state = 0;
+    WaveParams P{};
+    uint64_t n_waves = 0;
+    if (g_lo < g_all) {
+        const uint32_t lc = utf8_chars(st.last_scan_run_leftover);
+        const WvState in{ lc, (uint32_t)st.last_scan_run_leftover.size(), lc /* single byte: a source byte per char */,
+                          st.last_run_str_was_printed_and_is_maybe_cut_str ? 1u : 0u };
+        const uint64_t n_windows = g_all - g_lo;
+        uint64_t batches = (n_windows + (8192ull * 64) - 1) / (8192ull * 64);
+        batches = std::max<uint64_t>(1, std::min<uint64_t>(8, batches));
+        if (const char* e = getenv("SX_WAVE_BATCHES")) batches = (uint64_t)std::max(1, std::min(64, atoi(e)));
+        const uint32_t nwin = (uint32_t)(batches * kWvBatch - kWvWarm);
+        n_waves = (n_windows + nwin - 1) / nwin;
+
+        if (!d.d_wave_lut) {
+            HIP_TRY(ctx, hipMalloc((void**)&d.d_wave_lut, 256));
+            HIP_TRY(ctx, hipMemcpy(d.d_wave_lut, m.wave_lut.data(), 256, hipMemcpyHostToDevice));
+        }
+        // per wavefront: 4 x u32 (pass 1 out) + 2 x u64 (offsets); + totals
+        const uint64_t per = 4 * 4 + 2 * 8;
+        int rc = ensure_rp(ctx, d, 1, n_waves * per + 256); if (rc) return rc;
+        rc = ensure_scratch(ctx, wave_scratch_bytes(n_waves)); if (rc) return rc;
+        rc = ensure_pinned2(ctx, 4096); if (rc) return rc;
+        uint8_t* base = (uint8_t*)d.d_rp[1];
+        uint64_t* d_tot = (uint64_t*)base;
+        uint64_t* d_fb = (uint64_t*)(base + 64);
+        uint64_t* d_ab = d_fb + n_waves;
+        uint32_t* d_u = (uint32_t*)(d_ab + n_waves);
+        P.data = job.d_bytes; P.len = len; P.consumed0 = job.consumed0[k]; P.slice_base = job.slice_base;
+        P.W = W; P.wps = wps; P.q = (uint32_t)m.q; P.n_min = m.c.chars_min_nb;
+        P.g_lo = g_lo; P.g_hi = g_all; P.nwin = nwin; P.inject = wv_pack(in);
+        P.mission_id = m.c.mission_id; P.file_id = job.file_id; P.lut = d.d_wave_lut; P.table = d.d_table;
+        P.wave_nf = d_u; P.wave_nb = d_u + n_waves; P.wave_in = d_u + 2 * n_waves; P.wave_out = d_u + 3 * n_waves;
+        P.wave_fbase = d_fb; P.wave_abase = d_ab;
+        HIP_TRY(ctx, launch_wave_count(P, n_waves, d_fb, d_ab, d_tot, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
+        uint64_t* h_tot = (uint64_t*)ctx->h_pin2;
+        HIP_TRY(ctx, hipMemcpyAsync(h_tot, d_tot, 4 * 8, hipMemcpyDeviceToHost, d.stream_b));
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+        if (h_tot[2] != 0) {
+            if (getenv("SX_TIMING")) fprintf(stderr, "[sx] wave replay mission %zu: %llu wavefronts assumed a wrong entry state: lane-per-region path\n", k, (unsigned long long)h_tot[2]);
+            return SX_WAVE_FALLBACK;
+        }
+        nf = h_tot[0]; nb = h_tot[1]; final_state = (uint32_t)h_tot[3];
+    } else final_state = 0;
+    const double t1 = now_ms();
+    if (nb + nbh > 0xFFFFFFFFull) { ctx->err = "more than 4 GiB of strings in one chunk"; return SX_E_NOMEM; }
+
+    // ---- pass 2 straight into the result's layout: [host findings][device findings][host strings][device strings]
+    const uint64_t out_bytes = (nfh + nf) * sizeof(sx_finding) + nbh + nb;
+    bool deferred = false;
+    if (nf + nfh) {
+        int rc = ensure_rp(ctx, d, 5, out_bytes + 64); if (rc) return rc;
+        uint8_t* d_all = (uint8_t*)d.d_rp[5];
+        if (nf) {
+            P.findings = (sx_finding*)d_all + nfh;
+            P.arena = d_all + (nfh + nf) * sizeof(sx_finding) + nbh;
+            P.str_off_base = (uint32_t)nbh; P.f_sub = 0; P.a_sub = 0;
+            HIP_TRY(ctx, launch_wave_write(P, 0, n_waves, d.stream_b));
+        }
+        if (nfh) {
+            HIP_TRY(ctx, hipMemcpyAsync(d_all, hf.v.data(), nfh * sizeof(sx_finding), hipMemcpyHostToDevice, d.stream_b));
+            if (nbh) HIP_TRY(ctx, hipMemcpyAsync(d_all + (nfh + nf) * sizeof(sx_finding), hf.arena.data(), nbh, hipMemcpyHostToDevice, d.stream_b));
+        }
+        deferred = defer_min_bytes && nf * sizeof(sx_finding) + nb >= defer_min_bytes;
+        if (deferred) {
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            out->dev_only = true; out->ext_nf = nfh + nf; out->ext_na = nbh + nb; out->dev_copy = d_all;
+        } else {
+            PinnedPool::Block blk = ctx->pool->take(out_bytes + 64);
+            if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
+            HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, out_bytes, hipMemcpyDeviceToHost, d.stream_b));
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            out->ext = blk; out->ext_nf = nfh + nf; out->ext_na = nbh + nb; out->dev_copy = d_all;
+        }
+    }
+    out->replay_bytes += len;
+    ctx->stats.wave_windows += g_all - g_lo;
+    const double t2 = now_ms();
+
+    // ---- the state handed to the next buffer
+    if (job.commit_state) {
+        ScannerState fin = st;   // (the host's own exit state if the device had nothing to do)
+        if (g_lo < g_all) {
+            const WvState fs = wv_unpack(final_state);
+            fin.decoder.reset(m.c.encoding);   // single byte: nothing is ever pending
+            fin.last_scan_run_leftover.clear();
+            if (fs.lc) {
+                size_t hint = 0;
+                const uint8_t* src = view.span(len - fs.lback, fs.lback, &hint);
+                uint8_t buf[64 * 4 + 16];
+                const DecodeStep r = fin.decoder.decode_to_str_without_replacement(src, fs.lback, buf, sizeof buf, false);
+                fin.last_scan_run_leftover.assign((const char*)buf, r.written);
+                if (r.written != fs.lb || r.read != fs.lback) { ctx->err = "wave replay: the exit leftover does not decode to what the device counted"; return SX_E_STATE; }
+            }
+            fin.last_run_str_was_printed_and_is_maybe_cut_str = fs.cut != 0;
+        }
+        fin.consumed_bytes = job.consumed0[k] + len;
+        fin.stream_bytes = job.stream0[k] + len;
+        ctx->states[k] = fin;
+    }
+    if (end_pos) *end_pos = len;
+    if (getenv("SX_TIMING"))
+        fprintf(stderr, "[sx] wave replay mission %zu: %llu windows in %llu wavefronts, entry+count %.2f ms, write+d2h %.2f ms (%llu findings, %llu string bytes%s), state %.2f ms\n",
+                k, (unsigned long long)(g_all - g_lo), (unsigned long long)n_waves, t1 - t0, t2 - t1, (unsigned long long)(nf + nfh),
+                (unsigned long long)(nb + nbh), deferred ? ", left on the device" : "", now_ms() - t2);
+    return SX_OK;
+}
+
+}  // namespace sx

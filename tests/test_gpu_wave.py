@@ -1,0 +1,97 @@
+"""GPU parity of the wave-cooperative stage B (csrc/sx_wave_dev.hip, sx_wave.cpp) — run with -m gpu on an MI355X.
+Everything goes through the C-ABI; the oracle is only the checker.  SX_WAVE_REPLAY=1 makes every buffer of a covered
+Mission take the wave kernels (by default only string-dense buffers do)."""
+import os
+import random
+
+import pytest
+
+import refconfig as rc
+import stringsext_amd as sx
+import sxo_binding as sxo
+from product_harness import run_cli_product
+from test_host_logic import soup, synth
+from test_wave_core import MISSIONS, inputs, records, text_lines
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def wave_forced():
+    old = {k: os.environ.get(k) for k in ("SX_WAVE_REPLAY", "SX_WAVE_BATCHES")}
+    os.environ["SX_WAVE_REPLAY"] = "1"
+    yield
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def wave_windows_of_a_scan(ms, data):
+    sc = sx.Scanner(ms, device=0)
+    try:
+        res = sc.scan(data, file_id=1)
+        n = sc.stats().wave_windows
+        res.free()
+        return n
+    finally:
+        sc.close()
+
+
+@pytest.mark.parametrize("mi", range(len(MISSIONS)))
+def test_wave_path_equals_the_oracle(wave_forced, mi):
+    ms = rc.missions(**MISSIONS[mi])
+    rng = random.Random(2000 + mi)
+    for name, data in inputs(rng):
+        want = sxo.run_cli(ms, [data], radix="x")
+        for chunk, batches in ((None, None), (16384, "1"), (8192, "3")):
+            if batches:
+                os.environ["SX_WAVE_BATCHES"] = batches
+            else:
+                os.environ.pop("SX_WAVE_BATCHES", None)
+            got = run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk)
+            assert got == want, (name, chunk, batches)
+        if len(data) >= 8192:
+            assert wave_windows_of_a_scan(ms, data) > 0, name   # the wave kernels did run
+
+
+def test_wave_path_next_to_other_missions(wave_forced):
+    """three Missions, two of them through the wave kernels: merge order, per-Mission state from chunk to chunk, two files"""
+    ms = rc.missions(encodings=["ascii", "utf-8", "koi8-r,,,Cyrillic"], chars_min="5")
+    rng = random.Random(7)
+    files = [text_lines(rng, 150_000) + synth(rng, 100_000, 1 / 80), rng.randbytes(70_001), b"", text_lines(rng, 30_000, 100, 600)]
+    want = sxo.run_cli(ms, files, radix="x")
+    for chunk in (None, 65536, 8192):
+        assert run_cli_product(ms, files, radix="x", device=0, chunk_bytes=chunk) == want, chunk
+    os.environ["SX_DEFER_MIN_BYTES"] = "1"   # the Missions' outputs stay in HBM and are interleaved there
+    try:
+        assert run_cli_product(ms, files, radix="x", device=0) == want
+    finally:
+        os.environ.pop("SX_DEFER_MIN_BYTES", None)
+
+
+def test_dense_buffers_take_the_wave_path_by_default():
+    rng = random.Random(3)
+    ms = rc.missions(encodings=["ascii"], chars_min="4")
+    data = rng.randbytes(1 << 22)
+    assert run_cli_product(ms, [data], radix="x", device=0) == sxo.run_cli(ms, [data], radix="x")
+    assert wave_windows_of_a_scan(ms, data) > 0
+    sparse = rc.missions(encodings=["ascii"], chars_min="40")
+    assert wave_windows_of_a_scan(sparse, data) == 0   # few runs: the lane-per-region path
+    os.environ["SX_WAVE_REPLAY"] = "0"
+    try:
+        assert wave_windows_of_a_scan(ms, data) == 0
+        assert run_cli_product(ms, [data], radix="x", device=0) == sxo.run_cli(ms, [data], radix="x")
+    finally:
+        os.environ.pop("SX_WAVE_REPLAY", None)
+
+
+def test_wave_path_large_and_text(wave_forced):
+    """64 MiB of text and of the synthetic background: full text diff against the oracle"""
+    rng = random.Random(11)
+    blob = text_lines(rng, 1 << 20)
+    text = (blob * 64)[:64 << 20]
+    for ms in (rc.missions(encodings=["ascii"], chars_min="4"), rc.missions(encodings=["koi8-r"], chars_min="10", unicode_block_filter="Cyrillic")):
+        for data in (text, sxo.background(0, 32 << 20)):
+            assert run_cli_product(ms, [data], radix="x", device=0) == sxo.run_cli(ms, [data], radix="x")
