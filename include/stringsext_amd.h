@@ -175,10 +175,11 @@ const char* sx_encoding_name(uint32_t encoding);   /* Encoding::name(), e.g. "UT
 const uint16_t* sx_decoder_table(uint32_t encoding, uint64_t* n_words);
 
 /* Lower level: does the wave-cooperative stage B (csrc/sx_wave_core.hpp) cover this Mission — no -g, no -r,
- * 1 <= chars_min_nb <= output_line_char_nb_max <= 64, a single-byte encoding (the reference's rules it relies on:
- * src/helper.rs:315-322, 349-421)?  Returns 1 and the class byte it keeps per input byte (bit 0 a character, bit 1
- * its UTF-8 lead byte passes af / ubf — src/mission.rs:333-348 —, bit 2 / 3 its UTF-8 form has 2 / 3 bytes) in
- * classes[256]; 0 if not covered; < 0 on error. */
+ * 1 <= chars_min_nb <= output_line_char_nb_max <= 64, a single-byte encoding or UTF-8 (the reference's rules it
+ * relies on: src/helper.rs:315-322, 349-421)?  Returns 0 if not covered, < 0 on error, else the class byte it keeps per
+ * input byte in classes[256] and 1 for a single-byte encoding (bit 0 a character, bit 1 its UTF-8 lead byte passes
+ * af / ubf — src/mission.rs:333-348 —, bit 2 / 3 its UTF-8 form has 2 / 3 bytes), 2 for UTF-8 (bits 0-2: 0 never valid,
+ * 1 ASCII, 2 continuation byte, 3 / 4 / 5 lead byte of 2 / 3 / 4; bit 3 a character that starts with it passes). */
 int sx_wave_classes(const sx_mission* mission, uint8_t* classes);
 
 int  sx_abi_version(void);

@@ -165,7 +165,7 @@ int sx_wave_classes(const sx_mission* mission, uint8_t* classes) {
     if (rc != SX_OK) return rc;
     if (!m.wave_ok || m.wave_lut.size() != 256) return 0;
     memcpy(classes, m.wave_lut.data(), 256);
-    return 1;
+    return 1 + (int)m.wave_family;
 }
 
 int sx_create(sx_ctx** out, const sx_mission* missions, int n_missions, int hip_device, const sx_options* opt) {

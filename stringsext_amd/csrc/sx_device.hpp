@@ -159,7 +159,8 @@ struct WaveParams {
     uint32_t nwin;            // windows a wavefront owns
     uint32_t inject;          // the exact state at window g_lo (wv_pack), from the host
     int32_t mission_id, file_id;
-    const uint8_t* lut;       // device: 256 class bytes (single byte: WVC_*)
+    uint32_t family;          // 0: single-byte decoders, 1: UTF-8
+    const uint8_t* lut;       // device: 256 class bytes (single byte: WVC_*; UTF-8: WVU_*)
     const uint16_t* table;    // device: the decoder table (single byte: 128 entries; nullptr = x-user-defined)
     // pass 1 out, per wavefront: findings, string bytes, the entry state it assumed for its first window, the state after its last
     uint32_t *wave_nf, *wave_nb, *wave_in, *wave_out;

@@ -62,6 +62,7 @@ struct Mission {
     std::vector<uint32_t> pair_lut;  // Big5 / EUC-JP: the pair codes the kernel keeps in LDS (ScanParams::pair_lut)
     // wave-cooperative stage B (sx_wave_core.hpp): the Mission is one it covers, and its class byte per input byte
     bool wave_ok = false;
+    uint32_t wave_family = 0;   // 0: single-byte decoders, 1: UTF-8
     std::vector<uint8_t> wave_lut;
     // Big5 / EUC-JP, per buffer (set by the schedule before stage A/B of a buffer; the replay only reads it):
     // how many bytes at the buffer start finish the token that was pending on entry — where its token grid begins

@@ -65,6 +65,17 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
     const bool no_long_leads = ((in.ubf >> 32) & 0x1FFFFFull) == 0;  // E0..F4 <-> bits 32..52
 
     if (enc == SX_ENC_UTF8) {
+        // the wave-cooperative stage B (sx_wave_dev.hip): kind of every byte + "a character with this lead byte passes the filter"
+        m->wave_ok = wv_mission_ok(in.grep_char, in.require_same_unicode_block, in.chars_min_nb, (uint32_t)m->q);
+        m->wave_family = 1;
+        m->wave_lut.assign(256, 0);
+        for (int b = 0; b < 256; b++) {
+            uint8_t kind = WVU_BAD;
+            if (b < 0x80) kind = WVU_ASCII; else if (b < 0xC0) kind = WVU_CONT; else if (b >= 0xC2 && b <= 0xDF) kind = WVU_LEAD2;
+            else if (b >= 0xE0 && b <= 0xEF) kind = WVU_LEAD3; else if (b >= 0xF0 && b <= 0xF4) kind = WVU_LEAD4;
+            const bool acc = kind == WVU_ASCII ? af[b] : (kind >= WVU_LEAD2 && m->filter.pass_ubf_filter((uint8_t)b));
+            m->wave_lut[(size_t)b] = (uint8_t)(kind | (acc ? WVU_ACC : 0));
+        }
         if (!force_generic && af_is_range && ubf2_is_range && no_long_leads) {
             m->kind = kClsUtf8Range2;
             if (!uempty) { p.u_lo = 0xC0u + (uint32_t)ulo; p.u_hi = 0xC0u + (uint32_t)uhi; }

@@ -3,7 +3,7 @@
 // The lane-per-region replay costs time per long run, the wave kernels cost time per input byte (every window of the
 // buffer is replayed, a lane each, whether anything is found in it or not): they take over when a Mission has more
 // than a run per ~500 bytes — `-e ascii -n 4` on binaries, text, a legacy code page on random bytes — and cover the
-// Missions sx_wave_core.hpp names (no -g, no -r, 1 <= n <= q <= 64, a single-byte decoder).
+// Missions sx_wave_core.hpp names (no -g, no -r, 1 <= n <= q <= 64, a single-byte decoder or UTF-8).
 //   host:   the buffer's first window(s) from the exact carried ScannerState (its leftover's bytes lie in the previous
 //           buffer) — FindingCollection::from as ever, replay_exact_windows;
 //   device: every other window: count pass -> exclusive sums + verification of the wavefronts' assumed entry states ->
@@ -71,9 +71,11 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
     WaveParams P{};
     uint64_t n_waves = 0;
     if (g_lo < g_all) {
-        const uint32_t lc = utf8_chars(st.last_scan_run_leftover);
-        const WvState in{ lc, (uint32_t)st.last_scan_run_leftover.size(), lc /* single byte: a source byte per char */,
-                          st.last_run_str_was_printed_and_is_maybe_cut_str ? 1u : 0u };
+        const uint32_t lc = utf8_chars(st.last_scan_run_leftover), lb = (uint32_t)st.last_scan_run_leftover.size();
+        // source bytes from the leftover's first byte to E: single byte: one per char; UTF-8: its bytes + what the decoder holds of the next char
+        const DDecoder& dd = st.decoder.raw();
+        const uint32_t lback = m.wave_family == 0 ? lc : lb + (dd.needed ? dd.seen + 1u : 0u);
+        const WvState in{ lc, lb, lc ? lback : 0u, st.last_run_str_was_printed_and_is_maybe_cut_str ? 1u : 0u };
         const uint64_t n_windows = g_all - g_lo;
         uint64_t batches = (n_windows + (8192ull * 64) - 1) / (8192ull * 64);
         batches = std::max<uint64_t>(1, std::min<uint64_t>(8, batches));
@@ -98,7 +100,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         P.data = job.d_bytes; P.len = len; P.consumed0 = job.consumed0[k]; P.slice_base = job.slice_base;
         P.W = W; P.wps = wps; P.q = (uint32_t)m.q; P.n_min = m.c.chars_min_nb;
         P.g_lo = g_lo; P.g_hi = g_all; P.nwin = nwin; P.inject = wv_pack(in);
-        P.mission_id = m.c.mission_id; P.file_id = job.file_id; P.lut = d.d_wave_lut; P.table = d.d_table;
+        P.mission_id = m.c.mission_id; P.file_id = job.file_id; P.family = m.wave_family; P.lut = d.d_wave_lut; P.table = d.d_table;
         P.wave_nf = d_u; P.wave_nb = d_u + n_waves; P.wave_in = d_u + 2 * n_waves; P.wave_out = d_u + 3 * n_waves;
         P.wave_fbase = d_fb; P.wave_abase = d_ab;
         HIP_TRY(ctx, launch_wave_count(P, n_waves, d_fb, d_ab, d_tot, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
@@ -151,15 +153,24 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         ScannerState fin = st;   // (the host's own exit state if the device had nothing to do)
         if (g_lo < g_all) {
             const WvState fs = wv_unpack(final_state);
-            fin.decoder.reset(m.c.encoding);   // single byte: nothing is ever pending
+            // decode the bytes from the leftover's first one to the buffer end once more: the leftover's text and what the decoder
+            // holds of a character that is still incomplete (without leftover: the last bytes, for the decoder alone)
+            fin.decoder.reset(m.c.encoding);
             fin.last_scan_run_leftover.clear();
+            const uint64_t back = fs.lc ? fs.lback : std::min<uint64_t>(8, len);
+            size_t hint = 0;
+            const uint8_t* src = view.span(len - back, back, &hint);
+            uint8_t buf[64 * 4 + 16];
+            size_t at = 0, written = 0;
+            for (;;) {
+                const DecodeStep r = fin.decoder.decode_to_str_without_replacement(src + at, back - at, buf + written, sizeof buf - written, false);
+                at += r.read; written += r.written;
+                if (r.result != DecoderResult::Malformed) break;
+                written = 0;   // (only without leftover: the bytes of a leftover decode without error)
+            }
             if (fs.lc) {
-                size_t hint = 0;
-                const uint8_t* src = view.span(len - fs.lback, fs.lback, &hint);
-                uint8_t buf[64 * 4 + 16];
-                const DecodeStep r = fin.decoder.decode_to_str_without_replacement(src, fs.lback, buf, sizeof buf, false);
-                fin.last_scan_run_leftover.assign((const char*)buf, r.written);
-                if (r.written != fs.lb || r.read != fs.lback) { ctx->err = "wave replay: the exit leftover does not decode to what the device counted"; return SX_E_STATE; }
+                if (written != fs.lb) { ctx->err = "wave replay: the exit leftover does not decode to what the device counted"; return SX_E_STATE; }
+                fin.last_scan_run_leftover.assign((const char*)buf, written);
             }
             fin.last_run_str_was_printed_and_is_maybe_cut_str = fs.cut != 0;
         }

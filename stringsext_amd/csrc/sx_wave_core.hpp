@@ -98,6 +98,7 @@ struct WvWin {
     WvMask E, A;     // char ends delivered in this window; those whose char passes the filter
     WvMask F;        // first bytes of the characters (multi-byte encodings; single byte: unused)
     WvMask CS;       // bit i (1 <= i < n): a decoder call starts at byte i
+    WvMask LS;       // first bytes of the stretches of accepted chars that have >= n BYTES (so every stretch of >= n chars is among them)
     WvMask O2, O3;   // single byte: bytes whose UTF-8 form has 2 / 3 bytes (str_len = source bytes + popc(O2) + 2 popc(O3))
     u32 n;           // bytes in the window
     u32 pre_empty;   // an empty decoder call at byte 0 precedes the first one (UTF-8: the byte a pending sequence rejects is read again)
@@ -112,15 +113,23 @@ SXD bool wv_mission_ok(int grep_char, u32 same_block, u32 n_min, u32 q) {
     return grep_char < 0 && !same_block && n_min >= 1 && n_min <= q && q <= 64;
 }
 
-// One decoder call [din, cend) of the window: finding_collection.rs:146-290 with SplitStr::next inlined.
+// One decoder call [din, cend) of the window: finding_collection.rs:146-290 with SplitStr::next (helper.rs:206-433) restated per
+// STRETCH of accepted chars instead of per char.  With n <= q and no -g / -r, SplitStr's walk over a call's text comes to this:
+//   * the text is a row of stretches of accepted chars separated by rejected ones; a stretch is cut into lines of q chars
+//     (helper.rs:237) and a rest; every line is pushed; a rest that follows a line "completes" it (:365, :418-421) and is pushed
+//     whatever its length;
+//   * only the stretch at the very start of the text (the leftover belongs to it, finding_collection.rs:211-227) can complete a
+//     string of the call before (`cont`, :240-241); a stretch behind a rejected char never touches inp_start_p (helper.rs:327-330);
+//   * any other stretch counts if it has >= n chars (:317), or if it ends the text of a call that did not end in an error — then
+//     it is carried as the leftover (:389-392) however short; everything else is dropped without a trace (:327-330).
+// So a call costs: its first stretch, its LONG stretches (found through w.LS), its last stretch.
 // EMIT(din, precision, completes, src_rel, src_len, out_len): src_rel = first source byte relative to the window start
 // (negative: in front of it), out_len = bytes of the string.
 template <bool BYTES, class EMIT>
 SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 cend, bool invalid_after, bool first_call, EMIT& emit) {
     const bool cont = st.cut != 0;   // :240-241: consumed by this call whatever it yields
     st.cut = 0;
-    u32 lrem = st.lc;
-    const u32 lbytes = st.lb, lback = st.lback;
+    const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback;
     const bool has_left = lrem > 0;
     st.lc = 0; st.lb = 0; st.lback = 0;   // :211-227: the leftover is prepended, then gone
     const WvMask rng = wm_range(din, cend);
@@ -128,61 +137,83 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
     if (!has_left && !wm_any(Ec)) return;
     const WvMask Rc = wm_andn(Ec, w.A);   // rejected (valid) chars of this call
     u32 prec = (has_left || (first_call && w.probe_before)) ? WV_BEFORE : WV_EXACT;   // :146, 214-221, 176-207
-    bool last_cut = cont, tl = true;      // SplitStr: last_s_was_maybe_cut; "the scan position is inp_start_p"
-    u32 p = din;                          // chars whose last byte lies below p are consumed
-    for (;;) {                            // one SplitStr::next per round
-        u32 ok_n = 0, out_b = 0;
-        i32 src0 = 0;
-        u32 src_end = p;
-        bool started = false, piece_tl = tl;
-        if (lrem) { ok_n = lrem; out_b = lbytes; src0 = -(i32)lback; started = true; lrem = 0; }
-        int reason = 0;   // 0: the call's text ended, 1: a rejected char, 2: q chars collected (helper.rs:237)
-        for (;;) {
-            const u32 e = wm_next(Ec, p);
-            if (e >= 128) { reason = 0; break; }
-            if (!wm_test(w.A, e)) {
-                p = e + 1;
-                if (ok_n == 0) { piece_tl = false; tl = false; continue; }   // helper.rs:327-330: the string would start behind it
-                reason = 1;
-                break;
+
+    // One stretch: `pre` chars carried in front of it (the leftover), its accepted chars = the E bits in [a, er).
+    // comp0: its first piece completes the string before.
+    auto stretch = [&](u32 a, u32 er, u32 pre, bool comp0) {
+        const WvMask av = wm_and(Ec, wm_range(a, er));
+        const bool ends_by_rej = er < 128;          // a rejected char follows (else the call's text ends with it)
+        u32 rem = pre + wm_popc(av);
+        u32 at = a;                                  // E bit of the next char to hand out
+        i32 src = 0;                                 // first source byte of the next piece
+        if (pre) src = -(i32)lback;
+        else if (BYTES) src = (i32)a;
+        else { const i32 f = wm_prev(w.F, a); src = f < 0 ? -(i32)w.head_back : f; }
+        bool comp = comp0;
+        u32 carried = pre, carried_b = pre ? lbytes : 0u;
+        while (rem) {
+            const u32 pn = rem < P.q ? rem : P.q;
+            const bool is_q = pn == P.q;
+            rem -= pn;
+            const bool tr = rem == 0 && !ends_by_rej;                       // touches the end of the call's text
+            if (!is_q && !tr && !comp && pn < P.n_min) return;              // helper.rs:315-330: dropped
+            const bool maybe_cut = is_q || (tr && !invalid_after);          // :353-355
+            const bool again = !comp && tr && !invalid_after && !is_q;      // :389-392
+            if (!comp && !again && pn < P.n_min) return;                    // :410-415 (the text ends here anyway)
+            // the piece's chars inside the window: pn - carried of them, from E bit `at` on
+            const u32 inwin = pn - carried;
+            u32 last_e = at, out_b = carried_b;
+            // (a leftover on its own: its source bytes; UTF-8: lback also counts the bytes of a character that was pending behind it)
+            i32 src_end = src + (i32)(carried ? (BYTES ? lback : lbytes) : 0u);
+            if (inwin) {
+                last_e = BYTES ? at + inwin - 1 : wm_select(av, at, inwin);
+                src_end = (i32)last_e + 1;
+                if (BYTES) {
+                    const WvMask tr_ = wm_range(at, last_e + 1);
+                    out_b += inwin + wm_popc(wm_and(w.O2, tr_)) + 2 * wm_popc(wm_and(w.O3, tr_));
+                } else out_b = (u32)(src_end - src);    // UTF-8 in, UTF-8 out: the string is the source bytes
             }
-            const u32 er = wm_next(Rc, e);                       // accepted chars follow one another up to here
-            const WvMask av = wm_and(Ec, wm_range(e, er));
-            const u32 navail = wm_popc(av);
-            const u32 take = P.q - ok_n < navail ? P.q - ok_n : navail;
-            const u32 last = BYTES ? e + take - 1 : wm_select(av, e, take);
-            i32 c0;   // first source byte of the char that ends at e
-            if (BYTES) c0 = (i32)e;
-            else { const i32 f = wm_prev(w.F, e); c0 = f < 0 ? -(i32)w.head_back : f; }
-            if (!started) { src0 = c0; started = true; }
-            if (BYTES) {
-                const WvMask tr = wm_range(e, last + 1);
-                out_b += take + wm_popc(wm_and(w.O2, tr)) + 2 * wm_popc(wm_and(w.O3, tr));
-            } else out_b += (u32)((i32)(last + 1) - c0);
-            ok_n += take;
-            src_end = last + 1;
-            p = last + 1;
-            if (ok_n >= P.q) { reason = 2; break; }
+            if (again) { st.lc = pn; st.lb = out_b; st.lback = (u32)((i32)w.n - src); st.cut = 0; }   // finding_collection.rs:269-285
+            else {                                                                                     // :255-268
+                emit(din, prec, comp, src, (u32)(src_end - src), out_b);
+                st.lc = 0; st.lb = 0; st.lback = 0; st.cut = maybe_cut ? 1u : 0u;
+            }
+            prec = WV_AFTER;   // :289
+            comp = true;       // helper.rs:418-421: what follows a full line touches inp_start_p with the cut flag set
+            carried = 0; carried_b = 0;
+            src = src_end;
+            if (inwin) at = last_e + 1;
         }
-        if (ok_n == 0) break;   // helper.rs:343
-        if (reason == 1) {
-            const bool exit3 = last_cut && piece_tl, exit4 = ok_n >= P.n_min;   // helper.rs:315-317
-            if (!exit3 && !exit4) { tl = false; continue; }                    // :327-330
+    };
+
+    // ---- the stretch at the start of the text
+    const u32 fe = wm_next(Ec, 0);                                   // the call's first char
+    const bool first_acc = fe < 128 && wm_test(w.A, fe);
+    u32 pos = din;                                                   // stretches that begin below pos are done
+    if (has_left || first_acc) {
+        const u32 er = first_acc ? wm_next(Rc, fe) : (fe < 128 ? fe : 128u);   // leftover alone: the rejected char right behind it, or nothing
+        stretch(first_acc ? fe : (fe < 128 ? fe : cend), er, lrem, cont);
+        pos = er < 128 ? er + 1 : 128u;
+    }
+    // ---- long stretches behind it
+    const WvMask LSc = wm_and(w.LS, rng);
+    // ---- the last stretch, if the text ends with accepted chars and the call did not end in an error: carried however short
+    u32 tail_a = 128;
+    if (!invalid_after) {
+        const i32 el = wm_prev(Ec, 127);
+        if (el >= 0 && wm_test(w.A, (u32)el)) {
+            const i32 r = wm_prev(Rc, (u32)el);
+            tail_a = wm_next(Ec, r < 0 ? 0u : (u32)r + 1);
         }
-        const bool touches_right = reason == 0 || (reason == 2 && wm_next(Ec, p) >= 128);
-        const bool maybe_cut = ok_n >= P.q || (touches_right && !invalid_after);     // helper.rs:353-355
-        const bool completes = piece_tl && last_cut;                                // :365
-        const bool again = !completes && touches_right && !invalid_after && ok_n < P.q;   // :389-392
-        if (!completes && !again && ok_n < P.n_min) break;                          // :410-415
-        tl = ok_n >= P.q;         // :418-420: inp_start_p moves behind a full line; else nothing later touches it
-        last_cut = maybe_cut;     // :421
-        if (again) {              // finding_collection.rs:269-285
-            st.lc = ok_n; st.lb = out_b; st.lback = (u32)((i32)w.n - src0); st.cut = 0;
-        } else {                  // :255-268
-            emit(din, prec, completes, src0, (u32)((i32)src_end - src0), out_b);
-            st.lc = 0; st.lb = 0; st.lback = 0; st.cut = maybe_cut ? 1u : 0u;
-        }
-        prec = WV_AFTER;          // :289
+    }
+    while (pos < 128) {
+        u32 sb = wm_next(LSc, pos);                                  // first byte of the next stretch of >= n bytes
+        u32 a = sb < 128 ? (BYTES ? sb : wm_next(Ec, sb)) : 128u;     // ... its first char
+        if (tail_a >= pos && tail_a < a) a = tail_a;
+        if (a >= 128) break;
+        const u32 er = wm_next(Rc, a);
+        stretch(a, er, 0u, false);
+        pos = er < 128 ? er + 1 : 128u;
     }
 }
 
@@ -246,14 +277,113 @@ SXD WvMask wv_extract(const WORDS& words, u32 o, u32 n) {
     return wm_and(r, wm_below(n));
 }
 
+SXD WvMask wm_shr(WvMask m, u32 k) {   // 0 < k < 64
+    return WvMask{ (m.lo >> k) | (m.hi << (64 - k)), m.hi >> k };
+}
+// first bits of the runs of >= n set bits in G (n >= 1)
+SXD WvMask wv_long_starts(WvMask G, u32 n) {
+    WvMask r = G;   // bit i: bits i .. i + have - 1 are all set
+    u32 have = 1;
+    while (have < n) {
+        const u32 sh = have < n - have ? have : n - have;
+        r = wm_and(r, sh < 64 ? wm_shr(r, sh) : WvMask{ r.hi, 0 });
+        have += sh;
+    }
+    const WvMask starts = wm_andn(G, wm_shl1(G));
+    return wm_and(starts, r);
+}
+
 // the window of a single-byte Mission from its valid / accepted / length masks
-SXD WvWin wv_win_single(WvMask V, WvMask A, WvMask O2, WvMask O3, u32 n) {
+SXD WvWin wv_win_single(WvMask V, WvMask A, WvMask O2, WvMask O3, u32 n, u32 n_min) {
     WvWin w;
     w.E = V; w.A = A; w.F = V; w.O2 = O2; w.O3 = O3; w.n = n;
+    w.LS = wv_long_starts(A, n_min);
     const WvMask bad = wm_andn(wm_below(n), V);        // a byte without a character: Malformed(1, 0), the call ends behind it
     w.CS = wm_and(wm_shl1(bad), wm_below(n));
     w.tail_empty = n && wm_test(bad, n - 1) ? 1u : 0u;
     w.pre_empty = 0; w.head_back = 0; w.probe_before = 0;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------
+// Classification, UTF-8 (WHATWG "utf-8 decoder" as encoding_rs runs it, sx_codec_core.hpp ddec_utf8): per byte, from the
+// 4 bytes in front of the lane's 16 and the 4 behind them (a lane loads 24 bytes; nothing crosses lanes).
+//   * every lead byte C2..F4 starts a parse where it stands (mid-sequence it is the byte the decoder rejects and reads
+//     again); it consumes the continuation bytes that are in range (the first one narrowed for E0 / ED / F0 / F4);
+//     complete -> a character (F on its first byte, E on its last); short -> Malformed(bytes, 0) and the call ends IN FRONT
+//     of the byte that did not fit (MB on that byte);
+//   * a continuation byte nobody consumed, C0, C1, F5..FF -> Malformed(1, 0), the call ends BEHIND it (MA).
+// class byte per input byte: bits 0-2 kind (0 bad, 1 ASCII, 2 continuation, 3 / 4 / 5 lead of 2 / 3 / 4), bit 3 accepted.
+// ------------------------------------------------------------------------------------------
+enum { WVU_BAD = 0, WVU_ASCII = 1, WVU_CONT = 2, WVU_LEAD2 = 3, WVU_LEAD3 = 4, WVU_LEAD4 = 5, WVU_ACC = 8 };
+struct WvMasks16U { u32 e, a, f, g, ma, mb; };
+
+// b[0..23] = the bytes at lane offset -4 .. +19; have_lo / have_hi: which of them exist (indices [have_lo, have_hi))
+template <class LUT>
+SXD WvMasks16U wv_classify16_utf8(const LUT& lut, const u8* b, u32 have_lo, u32 have_hi) {
+    WvMasks16U m{ 0, 0, 0, 0, 0, 0 };
+    u32 covered = 0;   // bit i: byte i (0..23) is consumed by a lead in front of it
+    u32 kind[24];
+#pragma unroll
+    for (int i = 0; i < 24; i++) kind[i] = ((u32)i >= have_lo && (u32)i < have_hi) ? (u32)lut[b[i]] : 0xFFu;   // 0xFF: no such byte
+#pragma unroll
+    for (int i = 1; i < 20; i++) {   // leads at lane offsets -3 .. 15
+        const u32 k = kind[i];
+        if (k == 0xFFu || (k & 7u) < WVU_LEAD2) continue;
+        const u32 need = (k & 7u) - 2u;   // continuation bytes
+        const u8 lead = b[i];
+        u32 lo = 0x80, hi = 0xBF;
+        if (lead == 0xE0) lo = 0xA0; else if (lead == 0xED) hi = 0x9F; else if (lead == 0xF0) lo = 0x90; else if (lead == 0xF4) hi = 0x8F;
+        u32 got = 0;
+        bool open = false, stop = false;   // open: ran into the end of what exists: still pending there
+#pragma unroll
+        for (int t = 1; t <= 3; t++) {   // (constant indices: the arrays stay in registers)
+            if ((u32)t > need || stop) continue;
+            if (i + t >= 24 || kind[i + t >= 24 ? 23 : i + t] == 0xFFu) { open = true; stop = true; continue; }
+            const u8 c = b[i + t >= 24 ? 23 : i + t];
+            if (c < lo || c > hi) { stop = true; continue; }
+            lo = 0x80; hi = 0xBF;
+            got++;
+        }
+        covered |= ((1u << got) - 1u) << (i + 1);
+        const int j = i - 4;   // lane offset of the lead
+        if (got == need) {
+            const int last = j + (int)need;
+            if (j >= 0 && j < 16) m.f |= 1u << j;
+            if (last >= 0 && last < 16) { m.e |= 1u << last; if (k & WVU_ACC) m.a |= 1u << last; }
+            if (k & WVU_ACC) {   // bits j .. last, clipped to the lane's 16
+                const u32 span = ((2u << (need + 0)) - 1u);   // need + 1 ones
+                m.g |= (j >= 0 ? span << j : span >> (-j)) & 0xFFFFu;
+            }
+        } else if (!open) {
+            const int off = j + (int)got + 1;   // the byte that did not fit: the call ends in front of it
+            if (off >= 0 && off < 16) m.mb |= 1u << off;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const u32 k = kind[j + 4];
+        if (k == 0xFFu) continue;
+        if ((k & 7u) == WVU_ASCII) { m.f |= 1u << j; m.e |= 1u << j; if (k & WVU_ACC) { m.a |= 1u << j; m.g |= 1u << j; } }
+        else if ((k & 7u) == WVU_BAD || ((k & 7u) == WVU_CONT && !((covered >> (j + 4)) & 1u))) m.ma |= 1u << j;
+    }
+    return m;
+}
+
+// the window of a UTF-8 Mission.  f_back: the F bits of the three bytes in front of the window (bit 2 = the byte right before
+// it); slice_start: the window is the first of its slice (the probe of finding_collection.rs:176-207 then runs: a fresh decoder
+// cannot reproduce a first character that began in the slice before -> `Before`).
+SXD WvWin wv_win_utf8(WvMask E, WvMask A, WvMask F, WvMask G, WvMask MA, WvMask MB, u32 f_back, bool slice_start, u32 n, u32 n_min) {
+    WvWin w;
+    w.E = E; w.A = A; w.F = F; w.O2 = wm_zero(); w.O3 = wm_zero(); w.n = n;
+    w.LS = wv_long_starts(G, n_min);
+    w.CS = wm_and(wm_or(wm_shl1(MA), MB), wm_andn(wm_below(n), wm_below(1)));
+    w.tail_empty = n && wm_test(MA, n - 1) ? 1u : 0u;
+    w.pre_empty = n && wm_test(MB, 0) ? 1u : 0u;
+    w.head_back = 0;
+    const u32 e0 = wm_next(E, 0);
+    if (e0 < 128 && wm_prev(F, e0) < 0) w.head_back = (f_back & 4u) ? 1u : (f_back & 2u) ? 2u : (f_back & 1u) ? 3u : 0u;
+    w.probe_before = slice_start && w.head_back ? 1u : 0u;
     return w;
 }
 
@@ -275,6 +405,10 @@ SXD void wv_window_at(u64 g, u32 W, u32 wps, u64 len, u64* start, u32* n) {
 }
 // number of the window that starts at byte position p (a window start)
 SXD u64 wv_window_no(u64 p, u32 W, u32 wps) { return p / kWvSlice * wps + (p % kWvSlice) / W; }
+
+// first byte of the 1 KiB tiles that cover a batch whose first window starts at span_lo: 16-byte aligned and at least three
+// bytes in front of it (UTF-8: a character delivered in the first window may begin there)
+SXD u64 wv_tile0(u64 span_lo) { const u64 a = span_lo & ~15ull; return a >= 16 ? a - 16 : a; }
 
 constexpr u32 kWvWarm = 4;         // windows a wavefront replays in front of its own, only for their state
 constexpr u32 kWvBatch = 64;       // windows per batch: one per lane

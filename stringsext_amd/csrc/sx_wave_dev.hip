@@ -88,10 +88,11 @@ struct WriteEmit {
     }
 };
 
-// MODE 0: count; 1: write
-template <int MODE>
+// MODE 0: count; 1: write.  FAM 0: single-byte decoders; 1: UTF-8.
+template <int MODE, int FAM>
 __global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
-    __shared__ u32 lds_mask[4][kWvMaxTiles * 32 + 8];   // valid, accepted, O2, O3: 16 bits per lane and tile
+    // FAM 0: valid, accepted, O2, O3; FAM 1: E, A, F, MA, MB, G — 16 bits per lane and tile
+    __shared__ u32 lds_mask[FAM == 1 ? 6 : 4][kWvMaxTiles * 32 + 8];
     __shared__ u8 lds_lut[256];
     const u32 lane = threadIdx.x;
     ((u32*)lds_lut)[lane] = ((const u32*)P.lut)[lane];
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
         const u64 we = ws + wn;
         const int last_lane = (int)wv_uniform(n_act - 1);
         const u64 span_hi = ((u64)__builtin_amdgcn_readlane((u32)(we >> 32), last_lane) << 32) | __builtin_amdgcn_readlane((u32)we, last_lane);
-        const u64 tile0 = span_lo & ~15ull;
+        const u64 tile0 = wv_tile0(span_lo);
         const u32 n_tiles = (u32)((span_hi - tile0 + kTileBytes - 1) / kTileBytes);
 
         // ---- 1. classify the batch's bytes; masks -> LDS
@@ -135,22 +136,53 @@ __global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
                 for (u32 k = 0; k < avail; k++) xs[k >> 2] |= (u32)P.data[off + k] << (8 * (k & 3));
                 x.x = xs[0]; x.y = xs[1]; x.z = xs[2]; x.w = xs[3];
             }
-            const WvMasks16 m = wv_classify16_single(lds_lut, x.x, x.y, x.z, x.w, avail);
             const u32 idx = t * 64 + lane;
-            ((uint16_t*)lds_mask[0])[idx] = (uint16_t)m.v;
-            ((uint16_t*)lds_mask[1])[idx] = (uint16_t)m.a;
-            ((uint16_t*)lds_mask[2])[idx] = (uint16_t)m.o2;
-            ((uint16_t*)lds_mask[3])[idx] = (uint16_t)m.o3;
+            if (FAM == 0) {
+                const WvMasks16 m = wv_classify16_single(lds_lut, x.x, x.y, x.z, x.w, avail);
+                ((uint16_t*)lds_mask[0])[idx] = (uint16_t)m.v;
+                ((uint16_t*)lds_mask[1])[idx] = (uint16_t)m.a;
+                ((uint16_t*)lds_mask[2])[idx] = (uint16_t)m.o2;
+                ((uint16_t*)lds_mask[3])[idx] = (uint16_t)m.o3;
+            } else {
+                // the four bytes in front of the lane's 16 and the four behind them (the neighbours' bytes: cache hits)
+                u32 back = 0, ahead = 0;
+                if (off >= 4 && avail) back = *(const u32*)(P.data + off - 4);
+                u32 n_ahead = 0;
+                if (avail == 16 && off + 16 < P.len) {
+                    n_ahead = P.len - (off + 16) >= 4 ? 4u : (u32)(P.len - (off + 16));
+                    if (n_ahead == 4) ahead = *(const u32*)(P.data + off + 16);
+                    else for (u32 k = 0; k < n_ahead; k++) ahead |= (u32)P.data[off + 16 + k] << (8 * k);
+                }
+                u8 b[24];
+                const u32 ws6[6] = { back, x.x, x.y, x.z, x.w, ahead };
+#pragma unroll
+                for (int k = 0; k < 24; k++) b[k] = (u8)(ws6[k >> 2] >> (8 * (k & 3)));
+                const WvMasks16U m = wv_classify16_utf8(lds_lut, b, off >= 4 ? 0u : 4u, 4u + avail + n_ahead);
+                ((uint16_t*)lds_mask[0])[idx] = (uint16_t)m.e;
+                ((uint16_t*)lds_mask[1])[idx] = (uint16_t)m.a;
+                ((uint16_t*)lds_mask[2])[idx] = (uint16_t)m.f;
+                ((uint16_t*)lds_mask[3])[idx] = (uint16_t)m.ma;
+                ((uint16_t*)lds_mask[FAM == 1 ? 4 : 0])[idx] = (uint16_t)m.mb;
+                ((uint16_t*)lds_mask[FAM == 1 ? 5 : 0])[idx] = (uint16_t)m.g;
+            }
         }
         __syncthreads();
 
         // ---- 2. lane = window
         WvWin w;
-        if (active) {
-            const u32 o = (u32)(ws - tile0);
-            w = wv_win_single(wv_extract(lds_mask[0], o, wn), wv_extract(lds_mask[1], o, wn), wv_extract(lds_mask[2], o, wn),
-                              wv_extract(lds_mask[3], o, wn), wn);
-        } else { w = wv_win_single(wm_zero(), wm_zero(), wm_zero(), wm_zero(), 0); }
+        {
+            const u32 o = active ? (u32)(ws - tile0) : 0u;
+            const u32 n = active ? wn : 0u;
+            if (FAM == 0)
+                w = wv_win_single(wv_extract(lds_mask[0], o, n), wv_extract(lds_mask[1], o, n), wv_extract(lds_mask[2], o, n),
+                                  wv_extract(lds_mask[3], o, n), n, P.n_min);
+            else {
+                const u32 fb = o >= 3 ? (u32)wv_extract(lds_mask[2], o - 3, 3).lo : 0u;
+                w = wv_win_utf8(wv_extract(lds_mask[0], o, n), wv_extract(lds_mask[1], o, n), wv_extract(lds_mask[2], o, n),
+                                wv_extract(lds_mask[FAM == 1 ? 5 : 0], o, n), wv_extract(lds_mask[3], o, n),
+                                wv_extract(lds_mask[FAM == 1 ? 4 : 0], o, n), fb, ws % kWvSlice == 0, n, P.n_min);
+            }
+        }
 
         // ---- 3. entry states: iterate until they are consistent along the lanes
         u32 in = lane == 0 ? carry : 0u, out = 0;
@@ -162,7 +194,7 @@ __global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
             if (todo && active) {
                 WvState st = wv_unpack(in);
                 CountEmit ce;
-                wv_window<true>(WP, w, st, ce);
+                wv_window<FAM == 0>(WP, w, st, ce);
                 out = wv_pack(st); nf = ce.nf; nb = ce.nb;
             } else if (!active) out = in;
             u32 pin = wv_from_prev(out, carry);
@@ -187,7 +219,7 @@ __global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
             const u64 fo = fbase + tot_f + (excl >> 18), ao = abase + tot_b + (excl & 0x3FFFFu);
             WriteEmit we_{ &P, P.findings + fo, P.arena + ao, ao, ws };
             WvState st = wv_unpack(in);
-            wv_window<true>(WP, w, st, we_);
+            wv_window<FAM == 0>(WP, w, st, we_);
         }
         tot_f += bt >> 18; tot_b += bt & 0x3FFFFu;
         if (g0 + kWvBatch >= own_end && MODE == 0 && lane == 0) P.wave_out[v] = last_out;
@@ -223,7 +255,8 @@ hipError_t launch_wave_count(const WaveParams& P, uint64_t n_waves, uint64_t* fb
     if (n_waves == 0) return hipSuccess;
     WaveParams Q = P;
     Q.v0 = 0;
-    hipLaunchKernelGGL(wave_replay_kernel<0>, dim3((unsigned)n_waves), dim3(64), 0, stream, Q);
+    if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<0, 1>), dim3((unsigned)n_waves), dim3(64), 0, stream, Q);
+    else hipLaunchKernelGGL((wave_replay_kernel<0, 0>), dim3((unsigned)n_waves), dim3(64), 0, stream, Q);
     void* tmp = (void*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
     size_t tmp_bytes = scratch_bytes - (size_t)((uint8_t*)tmp - (uint8_t*)scratch);
     auto itf = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), U32ToU64{ P.wave_nf });
@@ -245,7 +278,8 @@ hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipS
     if (v1 <= v0) return hipSuccess;
     WaveParams Q = P;
     Q.v0 = v0;
-    hipLaunchKernelGGL(wave_replay_kernel<1>, dim3((unsigned)(v1 - v0)), dim3(64), 0, stream, Q);
+    if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<1, 1>), dim3((unsigned)(v1 - v0)), dim3(64), 0, stream, Q);
+    else hipLaunchKernelGGL((wave_replay_kernel<1, 0>), dim3((unsigned)(v1 - v0)), dim3(64), 0, stream, Q);
     return hipGetLastError();
 }
 

@@ -64,7 +64,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
     u64 fbase = 0, abase = 0;
     if (MODE == 1) { fbase = P.wave_fbase[v] - P.f_sub; abase = P.wave_abase[v] - P.a_sub; }
     const WvParams WP{ P.q, P.n_min };
-    std::vector<u32> lds[4];
+    std::vector<u32> lds[6];
     for (auto& l : lds) l.assign(kWvMaxTiles * 32 + 8, 0xDEADBEEFu);   // stale bits must not matter
     for (u64 g0 = gw; g0 < own_end; g0 += kWvBatch) {
         u64 ws[64]; u32 wn[64]; bool active[64], owned[64];
@@ -76,7 +76,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
         }
         const u32 n_act = own_end - g0 < kWvBatch ? (u32)(own_end - g0) : kWvBatch;
         const u64 span_lo = ws[0], span_hi = ws[n_act - 1] + wn[n_act - 1];
-        const u64 tile0 = span_lo & ~15ull;
+        const u64 tile0 = wv_tile0(span_lo);
         const u32 n_tiles = (u32)((span_hi - tile0 + kTileBytes - 1) / kTileBytes);
         if (n_tiles > kWvMaxTiles) return false;
         for (u32 t = 0; t < n_tiles; t++)
@@ -85,20 +85,42 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                 u32 xs[4] = { 0, 0, 0, 0 };
                 const u32 avail = off >= P.len ? 0u : (P.len - off >= 16 ? 16u : (u32)(P.len - off));
                 for (u32 k = 0; k < avail; k++) xs[k >> 2] |= (u32)P.data[off + k] << (8 * (k & 3));
-                const WvMasks16 m = wv_classify16_single(P.lut, xs[0], xs[1], xs[2], xs[3], avail);
                 const u32 idx = t * 64 + l;
-                ((uint16_t*)lds[0].data())[idx] = (uint16_t)m.v;
-                ((uint16_t*)lds[1].data())[idx] = (uint16_t)m.a;
-                ((uint16_t*)lds[2].data())[idx] = (uint16_t)m.o2;
-                ((uint16_t*)lds[3].data())[idx] = (uint16_t)m.o3;
+                if (P.family == 0) {
+                    const WvMasks16 m = wv_classify16_single(P.lut, xs[0], xs[1], xs[2], xs[3], avail);
+                    ((uint16_t*)lds[0].data())[idx] = (uint16_t)m.v;
+                    ((uint16_t*)lds[1].data())[idx] = (uint16_t)m.a;
+                    ((uint16_t*)lds[2].data())[idx] = (uint16_t)m.o2;
+                    ((uint16_t*)lds[3].data())[idx] = (uint16_t)m.o3;
+                } else {
+                    u32 back = 0, ahead = 0, n_ahead = 0;
+                    if (off >= 4 && avail) memcpy(&back, P.data + off - 4, 4);
+                    if (avail == 16 && off + 16 < P.len) {
+                        n_ahead = P.len - (off + 16) >= 4 ? 4u : (u32)(P.len - (off + 16));
+                        for (u32 k = 0; k < n_ahead; k++) ahead |= (u32)P.data[off + 16 + k] << (8 * k);
+                    }
+                    u8 b[24];
+                    const u32 ws6[6] = { back, xs[0], xs[1], xs[2], xs[3], ahead };
+                    for (int k = 0; k < 24; k++) b[k] = (u8)(ws6[k >> 2] >> (8 * (k & 3)));
+                    const WvMasks16U m = wv_classify16_utf8(P.lut, b, off >= 4 ? 0u : 4u, 4u + avail + n_ahead);
+                    ((uint16_t*)lds[0].data())[idx] = (uint16_t)m.e;
+                    ((uint16_t*)lds[1].data())[idx] = (uint16_t)m.a;
+                    ((uint16_t*)lds[2].data())[idx] = (uint16_t)m.f;
+                    ((uint16_t*)lds[3].data())[idx] = (uint16_t)m.ma;
+                    ((uint16_t*)lds[4].data())[idx] = (uint16_t)m.mb;
+                    ((uint16_t*)lds[5].data())[idx] = (uint16_t)m.g;
+                }
             }
         WvWin w[64];
         for (u32 l = 0; l < 64; l++) {
-            if (active[l]) {
-                const u32 o = (u32)(ws[l] - tile0);
-                w[l] = wv_win_single(wv_extract(lds[0], o, wn[l]), wv_extract(lds[1], o, wn[l]), wv_extract(lds[2], o, wn[l]),
-                                     wv_extract(lds[3], o, wn[l]), wn[l]);
-            } else w[l] = wv_win_single(wm_zero(), wm_zero(), wm_zero(), wm_zero(), 0);
+            const u32 o = active[l] ? (u32)(ws[l] - tile0) : 0u, n = active[l] ? wn[l] : 0u;
+            if (P.family == 0)
+                w[l] = wv_win_single(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[3], o, n), n, P.n_min);
+            else {
+                const u32 fb = o >= 3 ? (u32)wv_extract(lds[2], o - 3, 3).lo : 0u;
+                w[l] = wv_win_utf8(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[5], o, n),
+                                   wv_extract(lds[3], o, n), wv_extract(lds[4], o, n), fb, ws[l] % kWvSlice == 0, n, P.n_min);
+            }
         }
         u32 in[64], out[64], nf[64], nb[64];
         bool todo[64], injected[64];
@@ -115,7 +137,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                 if (todo[l] && active[l]) {
                     WvState st = wv_unpack(in[l]);
                     CountEmit ce;
-                    wv_window<true>(WP, w[l], st, ce, skip_idle);
+                    if (P.family == 0) wv_window<true>(WP, w[l], st, ce, skip_idle); else wv_window<false>(WP, w[l], st, ce, skip_idle);
                     out[l] = wv_pack(st); nf[l] = ce.nf; nb[l] = ce.nb;
                 } else if (!active[l]) out[l] = in[l];
             }
@@ -141,7 +163,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                 const u64 fo = fbase + tot_f + bf, ao = abase + tot_b + bb;
                 WriteEmit we{ &P, P.findings + fo, P.arena + ao, ao, ws[l] };
                 WvState st = wv_unpack(in[l]);
-                wv_window<true>(WP, w[l], st, we, skip_idle);
+                if (P.family == 0) wv_window<true>(WP, w[l], st, we, skip_idle); else wv_window<false>(WP, w[l], st, we, skip_idle);
                 if ((u64)(we.f - (P.findings + fo)) != nf[l] || we.a_off - ao != nb[l]) return false;   // both passes must agree
             }
             bf += nf[l]; bb += nb[l];
@@ -161,12 +183,12 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
 extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0, uint32_t slice_base, uint32_t W, uint32_t q, uint32_t n_min,
                            uint64_t g_lo, uint32_t inject, uint32_t nwin, const uint8_t* lut, const uint16_t* table, int mission_id,
                            int file_id, sx_finding* fout, uint64_t fcap, uint8_t* aout, uint64_t acap, uint64_t* nf, uint64_t* nb,
-                           uint32_t* final_state, uint64_t* bad_waves, int skip_idle, uint32_t* rounds_max) {
+                           uint32_t* final_state, uint64_t* bad_waves, int skip_idle, uint32_t* rounds_max, uint32_t family) {
     WaveParams P;
     memset(&P, 0, sizeof P);
     P.data = data; P.len = len; P.consumed0 = consumed0; P.slice_base = slice_base; P.W = W; P.wps = wv_wps(W); P.q = q; P.n_min = n_min;
     P.g_lo = g_lo; P.g_hi = wv_window_count(len, W); P.nwin = nwin; P.inject = inject; P.mission_id = mission_id; P.file_id = file_id;
-    P.lut = lut; P.table = table;
+    P.lut = lut; P.table = table; P.family = family;
     *nf = *nb = 0; *bad_waves = 0; *final_state = inject; *rounds_max = 0;
     if (P.g_hi <= P.g_lo) return 0;
     const u64 n_waves = (P.g_hi - P.g_lo + nwin - 1) / nwin;

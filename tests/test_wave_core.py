@@ -30,7 +30,7 @@ def load_wave():
     L.sxw_emulate.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
                               C.c_uint32, C.c_char_p, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.POINTER(sx.Finding), C.c_uint64,
                               C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
-                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint32)]
+                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint32), C.c_uint32]
     L.sxw_pack_state.restype = C.c_uint32
     L.sxw_pack_state.argtypes = [C.c_uint32] * 4
     return L
@@ -49,15 +49,14 @@ def wave_classes(m):
     out = (C.c_uint8 * 256)()
     r = L.sx_wave_classes(C.byref(cm), out)
     assert r >= 0
-    return bytes(out) if r == 1 else None
+    return (bytes(out), r - 1) if r >= 1 else None   # (class table, family: 0 single byte, 1 UTF-8)
 
 
 PREC = {0: "Before", 1: "Exact", 2: "After"}
 
 
 def emulate(L, m, data, nwin=508, skip_idle=1, g_lo=0, inject=0, consumed0=None):
-    lut = wave_classes(m)
-    assert lut is not None
+    lut, family = wave_classes(m)
     t = sx.decoder_table(m["encoding"])
     table = t[0] if t else None
     q = m["output_line_char_nb_max"]
@@ -69,7 +68,7 @@ def emulate(L, m, data, nwin=508, skip_idle=1, g_lo=0, inject=0, consumed0=None)
     fin, rounds = C.c_uint32(), C.c_uint32()
     rcode = L.sxw_emulate(data, len(data), m["counter_offset"] if consumed0 is None else consumed0, 0, 2 * q, q, m["chars_min_nb"], g_lo,
                           inject, nwin, lut, table, 0, 1, fout, cap_f, aout, cap_a, C.byref(nf), C.byref(nb), C.byref(fin), C.byref(bad),
-                          skip_idle, C.byref(rounds))
+                          skip_idle, C.byref(rounds), family)
     assert rcode == 0, rcode
     arena = bytes(aout[:nb.value])
     got = []
@@ -108,6 +107,11 @@ def inputs(rng):
     yield "records 128", records(rng, 40_000, 128, 1)
     yield "high bytes", bytes(rng.choice([0x41, 0x42, 0xC0, 0xE1, 0xFF, 0x98, 0x0A, 0x20]) for _ in range(50_000))
     yield "short tail", text_lines(rng, 4096 * 3 + 77)
+    words = ["hello world!", "Ünïcödé-ßtring", "доброе утро", "שלום עולם", "中文字符串测试", "😀😀 astral 𝔘𝔫𝔦", "Բարեւ աշխարհ", "mixed Ω≈ç√∫ text", "x" * 70]
+    yield "utf-8 text", ("".join(rng.choice(words) + rng.choice([" ", "\n", "\t", " — "]) for _ in range(6000))).encode()
+    yield "utf-8 4-byte", ("😀" * 50 + "\n" + "𝔘𝔫𝔦" * 40 + "a").encode() * 40
+    frames = [b"\xe2\x82", b"\xf0\x9f\x98", b"\x80\x80", b"\xc0\xaf", b"\xed\xa0\x80", b"\xf4\x90", b"\xff", b"\xe0\x80", b"\xc3", b"\xf0\x90\x80", b""]
+    yield "utf-8 broken", b"".join(rng.choice(frames) + rng.choice(words).encode() + rng.choice(frames) + rng.randbytes(rng.randrange(0, 6)) for _ in range(5000))
     yield "tiny", b"hello world, this is tiny\n"
     yield "one byte", b"a"
 
@@ -126,6 +130,12 @@ MISSIONS = [
     dict(encodings=["windows-874"], chars_min="6", unicode_block_filter="All"),
     dict(encodings=["iso-8859-7"], chars_min="64", output_line_len="64", unicode_block_filter="All"),
     dict(encodings=["ibm866"], chars_min="7", output_line_len="32", ascii_filter="None", unicode_block_filter="All"),
+    dict(encodings=["utf-8"], chars_min="10"),
+    dict(encodings=["utf-8"], chars_min="4", unicode_block_filter="All"),
+    dict(encodings=["utf-8"], chars_min="3", output_line_len="6", unicode_block_filter="All"),
+    dict(encodings=["utf-8"], chars_min="10", unicode_block_filter="African"),
+    dict(encodings=["utf-8"], chars_min="2", output_line_len="16", unicode_block_filter="Cjk", ascii_filter="None"),
+    dict(encodings=["utf-8"], chars_min="20", output_line_len="20", unicode_block_filter="Uncommon"),
 ]
 
 
