@@ -37,6 +37,9 @@ struct RunList {
     const sx_run* p = nullptr;
     size_t n = 0;
     bool on_device = false;
+    // the records were only counted (n = their number): the buffer is string-dense and the Mission's stage B replays every
+    // window (sx_wave.cpp) — nobody reads the runs.  If that stage B gives up, stage A is finished again, in full.
+    bool skipped = false;
     const sx_run* dev_ptr = nullptr;   // where the list lies on the device (on_device)
     // A list joined on the device: p[] (pinned) is filled by a copy that is only started when somebody
     // asks for it — the device replay asks after its first pass is launched, so that the copy (a blit
@@ -148,6 +151,7 @@ struct sx_ctx {
     uint64_t ondemand_fetches = 0;
     // grow-only scratch reused by every call (pinned host memory: D2H at full PCIe rate)
     std::vector<uint64_t> last_runs;  // long runs per mission of the last scanned buffer: busiest mission scans first
+    std::vector<char> wave_off;       // per mission, for the buffer in hand: the wave-cooperative stage B gave up on it (sx_wave.cpp)
     std::vector<sx::RunList> shard_runs;  // device runs of the last sx_scan_shard* buffer (reuse_runs)
     bool shard_runs_valid = false;
     // ... of which buffer: reuse_runs only counts for the very same one (ADVICE, round 1)
@@ -229,9 +233,10 @@ ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const 
                        uint32_t parity, uint64_t min_chars);
 int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
                    const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si);
+struct ReplayJob;
 int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
                    const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si,
-                   std::vector<RunList>* out, bool cut_into_pieces = false);
+                   std::vector<RunList>* out, bool cut_into_pieces = false, const ReplayJob* wave_job = nullptr);
 int device_runs(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
                 const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars,
                 std::vector<RunList>* out);
@@ -265,6 +270,7 @@ struct PreReplayed {
 
 // wave-cooperative stage B (sx_wave.cpp): for whole buffers of a Mission it covers, when the buffer is string-dense
 constexpr int SX_WAVE_FALLBACK = 1001;   // (internal) nothing was produced: use the lane-per-region path
+constexpr int SX_NEED_RUNS = 1002;       // (internal) ... which needs the run list that stage A skipped (RunList::skipped)
 bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs);
 int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, MissionFindings* out, uint64_t* end_pos,
                         uint64_t defer_min_bytes);

@@ -173,9 +173,9 @@ struct WaveParams {
     uint64_t v0;              // first wavefront of this launch
 };
 size_t wave_scratch_bytes(uint64_t n_waves);
-// pass 1 + exclusive sums + verification; totals (device, 4 x u64): findings, string bytes, wavefronts whose assumed entry
-// state was wrong (then nothing of this replay may be used), packed state after the last window
-hipError_t launch_wave_count(const WaveParams& P, uint64_t n_waves, uint64_t* fbase, uint64_t* abase, uint64_t* totals,
+// pass 1 of wavefronts [v0, v1) + exclusive sums from v0 on + verification; totals (device, 4 x u64): findings, string bytes,
+// wavefronts whose assumed entry state was wrong (then nothing of this replay may be used), packed state after the last window
+hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint64_t* fbase, uint64_t* abase, uint64_t* totals,
                              void* scratch, size_t scratch_bytes, hipStream_t stream);
 hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipStream_t stream);
 

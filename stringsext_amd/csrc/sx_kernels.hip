@@ -362,6 +362,7 @@ struct Emitter {
     SX_DEV void end_region(u64 wave) {
         if (region_cap && lane_id() == 0) {
             region_counts[wave] = rcount < region_cap ? rcount : region_cap;
+            if (rcount) atomicAdd(counters + 2, rcount);               // all records of the launch (stage A's host side: how dense is the input?)
             if (rcount > region_cap) atomicMax(counters + 3, rcount);  // how much room the fullest sub-chunk needs
         }
     }

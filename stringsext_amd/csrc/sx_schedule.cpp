@@ -119,10 +119,11 @@ struct BufferScan {
         ByteView& early_view = host_bytes ? (ByteView&)host_view : (ByteView&)*base_view;
         PreReplayed pre(nm);
         if (ctx->last_runs.size() != nm) ctx->last_runs.assign(nm, 0);
+        ctx->wave_off.assign(nm, 0);
         for (size_t oi = 0; oi < nm; oi++) {
             const size_t k = (size_t)order[oi];
             std::vector<RunList> one;
-            int rc = stage_a_finish(ctx, { (int)k }, d_bytes, len, { parity[k] }, { minc[k] }, slot, &one, true);
+            int rc = stage_a_finish(ctx, { (int)k }, d_bytes, len, { parity[k] }, { minc[k] }, slot, &one, true, &job);
             if (rc != SX_OK) return rc;
             (*runs)[k] = std::move(one[0]);
             if (!(*runs)[k].own.empty()) (*runs)[k].use_own();  // the vector moved: point at it again
@@ -133,6 +134,17 @@ struct BufferScan {
                 uint64_t defer = nm >= 2 ? (256ull << 20) : 0;
                 if (const char* e = getenv("SX_DEFER_MIN_BYTES")) defer = nm >= 2 ? (uint64_t)atoll(e) : 0;
                 rc = device_replay_mission(ctx, k, early_view, job, (*runs)[k], &pre.per[k], &pre.ends[k], defer);
+                if (rc == SX_NEED_RUNS) {   // the wave kernels gave up on a buffer whose runs were only counted: stage A in full, then the other stage B
+                    ctx->wave_off[k] = 1;
+                    rc = stage_a_launch(ctx, { (int)k }, d_bytes, len, { parity[k] }, { minc[k] }, slot);
+                    if (rc == SX_OK) rc = stage_a_finish(ctx, { (int)k }, d_bytes, len, { parity[k] }, { minc[k] }, slot, &one, true, nullptr);
+                    if (rc != SX_OK) return rc;
+                    (*runs)[k] = std::move(one[0]);
+                    if (!(*runs)[k].own.empty()) (*runs)[k].use_own();
+                    ctx->last_runs[k] = (*runs)[k].size();
+                    if (!device_replay_wanted(ctx, job, k, (*runs)[k].size())) continue;   // few runs after all: the host's share of stage B
+                    rc = device_replay_mission(ctx, k, early_view, job, (*runs)[k], &pre.per[k], &pre.ends[k], defer);
+                }
                 if (rc != SX_OK) return rc;
                 pre.done[k] = 1;
             }

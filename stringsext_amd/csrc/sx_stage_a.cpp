@@ -97,7 +97,7 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
 // are many).  Only stream_b is used from here on: the scan streams may already hold the next piece.
 int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
                    const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si,
-                   std::vector<RunList>* out, bool cut_into_pieces) {
+                   std::vector<RunList>* out, bool cut_into_pieces, const ReplayJob* wave_job) {
     out->assign(which.size(), RunList{});
     if (len == 0) return SX_OK;
     const double t0 = now_ms();
@@ -110,9 +110,21 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         HIP_TRY(ctx, hipEventElapsedTime(&ms, s.ev0, s.ev1));
         if (which[k] < 16) ctx->stats.kernel_ms[which[k]] += ms;
         uint32_t counters[4] = { 0, 0, 0, 0 };
+        bool skip_runs = false;
         for (int round = 0;; round++) {
             HIP_TRY(ctx, hipMemcpyAsync(counters, s.d_counters, sizeof counters, hipMemcpyDeviceToHost, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            if (round == 0 && wave_job) {
+                // String-dense input of a Mission whose stage B can replay every window (sx_wave.cpp): the records are only
+                // counted — no second scan with larger regions, no sort, no join, no pieces.
+                const uint64_t total = s.region_cap ? counters[2] : counters[0];
+                if (wave_replay_wanted(ctx, *wave_job, (size_t)which[k], total)) {
+                    RunList& rl = (*out)[k];
+                    rl.n = total; rl.p = nullptr; rl.skipped = true; rl.complete = true;
+                    skip_runs = true;
+                    break;
+                }
+            }
             if (s.region_cap) {
                 if (counters[0] == 0) break;  // every sub-chunk's records fit its region
                 // Too dense for these regions.  If the fullest sub-chunk's records (+25 %) fit regions that
@@ -144,6 +156,15 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         }
         const double tc0 = now_ms();
         if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   mission %d: kernel done at +%.2f ms, counters at +%.2f ms\n", which[k], t_ev - t0, tc0 - t0);
+        if (skip_runs) {
+            HIP_TRY(ctx, hipEventRecord(s.ev_free, d.stream_b));
+            s.free_pending = true;
+            if (getenv("SX_TIMING")) fprintf(stderr, "[sx] mission %d: kernel %.2f ms, %llu records counted: string-dense, every window is replayed\n", which[k], ms, (unsigned long long)(*out)[k].n);
+            ctx->stats.run_records += (*out)[k].n;
+            ctx->stats.bytes_scanned += len;
+            ctx->stats.heavy_tiles += counters[1];
+            continue;
+        }
         uint32_t nrec = counters[0];
         const DevRun* d_records = s.d_recs;   // sorted already in region mode
         const bool large_regions = s.region_cap > ctx->region_cap && ctx->region_cap;

@@ -363,7 +363,9 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     if (wave_replay_wanted(ctx, job, k, n)) {   // string-dense: a lane per window instead of a lane per region (sx_wave.cpp)
         const int rc = wave_replay_mission(ctx, k, view, job, out, end_pos, defer_min_bytes);
         if (rc != SX_WAVE_FALLBACK) return rc;
+        if (k < ctx->wave_off.size()) ctx->wave_off[k] = 1;
     }
+    if (runs.skipped) return SX_NEED_RUNS;
     size_t K = 1;
     const bool can = ctx->missions.size() == 1 && runs.on_device && !getenv("SX_HOST_STITCH") && defer_min_bytes == 0;
     if (can && n >= (1u << 20)) K = 3;   // (measured on string-dense and text-like input: 3 beats 2, 4 and 6)

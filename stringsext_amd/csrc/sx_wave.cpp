@@ -26,6 +26,7 @@ static uint64_t wave_min_density_bytes() {
 bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs) {
     const Mission& m = ctx->missions[k];
     if (!m.wave_ok || !job.d_bytes || ctx->host_only || job.is_last || !job.commit_state) return false;
+    if (k < ctx->wave_off.size() && ctx->wave_off[k]) return false;
     if (job.lo[k] != 0 || job.hi != job.len || !job.entry_exact[k] || job.len < 2 * kInputBufLen) return false;   // whole buffers only
     if (ctx->opt.flags & SX_OPT_HOST_REPLAY) return false;
     if (const char* e = getenv("SX_WAVE_REPLAY")) return atoi(e) != 0;
@@ -66,10 +67,17 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
 
     const uint64_t g_all = wv_window_count(len, W);
     const uint64_t g_lo = E < len ? wv_window_no(E, W, wps) : g_all;
-    uint64_t nf = 0, nb = 0;
     uint32_t final_state = 0;
-    WaveParams P{};
-    uint64_t n_waves = 0;
+    uint64_t n_waves = 0, nf_all = 0, nb_all = 0;
+    bool deferred = false;
+    std::vector<MissionFindings> segs;   // one per slab, in order
+    // leaving early: no copy may still be writing into a block that goes back to the pool
+    auto abandon = [&](int rc) -> int {
+        if (ctx->merge_copy_stream) (void)hipStreamSynchronize(ctx->merge_copy_stream);
+        (void)hipStreamSynchronize(d.stream_b);
+        for (auto& g : segs) if (g.ext.p) ctx->pool->give(g.ext);
+        return rc;
+    };
     if (g_lo < g_all) {
         const uint32_t lc = utf8_chars(st.last_scan_run_leftover), lb = (uint32_t)st.last_scan_run_leftover.size();
         // source bytes from the leftover's first byte to E: single byte: one per char; UTF-8: its bytes + what the decoder holds of the next char
@@ -82,71 +90,119 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         if (const char* e = getenv("SX_WAVE_BATCHES")) batches = (uint64_t)std::max(1, std::min(64, atoi(e)));
         const uint32_t nwin = (uint32_t)(batches * kWvBatch - kWvWarm);
         n_waves = (n_windows + nwin - 1) / nwin;
+        // Slabs of wavefronts: count -> write -> copy to the host, the copy of a slab next to the kernels of the following one.
+        // (Several Missions: one slab; their outputs stay in HBM and are interleaved there, sx_stage_b.cpp device_merge.)
+        uint64_t K = 1;
+        if (ctx->missions.size() == 1 && defer_min_bytes == 0) K = std::min<uint64_t>(8, std::max<uint64_t>(1, len >> 26));   // >= 64 MiB of input each
+        if (const char* e = getenv("SX_WAVE_SLABS")) K = (uint64_t)std::max(1, std::min(64, atoi(e)));
+        if (ctx->missions.size() != 1 || defer_min_bytes != 0) K = 1;
+        K = std::min<uint64_t>(K, n_waves);
 
         if (!d.d_wave_lut) {
             HIP_TRY(ctx, hipMalloc((void**)&d.d_wave_lut, 256));
             HIP_TRY(ctx, hipMemcpy(d.d_wave_lut, m.wave_lut.data(), 256, hipMemcpyHostToDevice));
         }
-        // per wavefront: 4 x u32 (pass 1 out) + 2 x u64 (offsets); + totals
+        // per wavefront: 4 x u32 (pass 1 out) + 2 x u64 (offsets); + totals per slab
         const uint64_t per = 4 * 4 + 2 * 8;
-        int rc = ensure_rp(ctx, d, 1, n_waves * per + 256); if (rc) return rc;
+        int rc = ensure_rp(ctx, d, 1, n_waves * per + 4096); if (rc) return rc;
         rc = ensure_scratch(ctx, wave_scratch_bytes(n_waves)); if (rc) return rc;
         rc = ensure_pinned2(ctx, 4096); if (rc) return rc;
         uint8_t* base = (uint8_t*)d.d_rp[1];
-        uint64_t* d_tot = (uint64_t*)base;
-        uint64_t* d_fb = (uint64_t*)(base + 64);
+        uint64_t* d_tot = (uint64_t*)base;            // 4 x u64 per slab
+        uint64_t* d_fb = (uint64_t*)(base + 2048);
         uint64_t* d_ab = d_fb + n_waves;
         uint32_t* d_u = (uint32_t*)(d_ab + n_waves);
+        WaveParams P{};
         P.data = job.d_bytes; P.len = len; P.consumed0 = job.consumed0[k]; P.slice_base = job.slice_base;
         P.W = W; P.wps = wps; P.q = (uint32_t)m.q; P.n_min = m.c.chars_min_nb;
         P.g_lo = g_lo; P.g_hi = g_all; P.nwin = nwin; P.inject = wv_pack(in);
         P.mission_id = m.c.mission_id; P.file_id = job.file_id; P.family = m.wave_family; P.lut = d.d_wave_lut; P.table = d.d_table;
         P.wave_nf = d_u; P.wave_nb = d_u + n_waves; P.wave_in = d_u + 2 * n_waves; P.wave_out = d_u + 3 * n_waves;
         P.wave_fbase = d_fb; P.wave_abase = d_ab;
-        HIP_TRY(ctx, launch_wave_count(P, n_waves, d_fb, d_ab, d_tot, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
+        if (K > 1) {
+            if (!ctx->merge_copy_stream) {
+                HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->merge_copy_stream, hipStreamNonBlocking));
+                for (hipEvent_t& e : ctx->merge_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+        }
         uint64_t* h_tot = (uint64_t*)ctx->h_pin2;
-        HIP_TRY(ctx, hipMemcpyAsync(h_tot, d_tot, 4 * 8, hipMemcpyDeviceToHost, d.stream_b));
-        HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
-        if (h_tot[2] != 0) {
-            if (getenv("SX_TIMING")) fprintf(stderr, "[sx] wave replay mission %zu: %llu wavefronts assumed a wrong entry state: lane-per-region path\n", k, (unsigned long long)h_tot[2]);
-            return SX_WAVE_FALLBACK;
-        }
-        nf = h_tot[0]; nb = h_tot[1]; final_state = (uint32_t)h_tot[3];
-    } else final_state = 0;
-    const double t1 = now_ms();
-    if (nb + nbh > 0xFFFFFFFFull) { ctx->err = "more than 4 GiB of strings in one chunk"; return SX_E_NOMEM; }
-
-    // ---- pass 2 straight into the result's layout: [host findings][device findings][host strings][device strings]
-    const uint64_t out_bytes = (nfh + nf) * sizeof(sx_finding) + nbh + nb;
-    bool deferred = false;
-    if (nf + nfh) {
-        int rc = ensure_rp(ctx, d, 5, out_bytes + 64); if (rc) return rc;
-        uint8_t* d_all = (uint8_t*)d.d_rp[5];
-        if (nf) {
-            P.findings = (sx_finding*)d_all + nfh;
-            P.arena = d_all + (nfh + nf) * sizeof(sx_finding) + nbh;
-            P.str_off_base = (uint32_t)nbh; P.f_sub = 0; P.a_sub = 0;
-            HIP_TRY(ctx, launch_wave_write(P, 0, n_waves, d.stream_b));
-        }
-        if (nfh) {
-            HIP_TRY(ctx, hipMemcpyAsync(d_all, hf.v.data(), nfh * sizeof(sx_finding), hipMemcpyHostToDevice, d.stream_b));
-            if (nbh) HIP_TRY(ctx, hipMemcpyAsync(d_all + (nfh + nf) * sizeof(sx_finding), hf.arena.data(), nbh, hipMemcpyHostToDevice, d.stream_b));
-        }
-        deferred = defer_min_bytes && nf * sizeof(sx_finding) + nb >= defer_min_bytes;
-        if (deferred) {
+        hipEvent_t copied[2] = { ctx->merge_ev[1], ctx->merge_ev[2] };
+        bool pending[2] = { false, false };
+        for (uint64_t j = 0; j < K; j++) {
+            const uint64_t v0 = n_waves * j / K, v1 = n_waves * (j + 1) / K;
+            HIP_TRY(ctx, launch_wave_count(P, v0, v1, d_fb, d_ab, d_tot + 4 * j, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
+            HIP_TRY(ctx, hipMemcpyAsync(h_tot + 4 * j, d_tot + 4 * j, 4 * 8, hipMemcpyDeviceToHost, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
-            out->dev_only = true; out->ext_nf = nfh + nf; out->ext_na = nbh + nb; out->dev_copy = d_all;
-        } else {
-            PinnedPool::Block blk = ctx->pool->take(out_bytes + 64);
-            if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
-            HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, out_bytes, hipMemcpyDeviceToHost, d.stream_b));
-            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
-            out->ext = blk; out->ext_nf = nfh + nf; out->ext_na = nbh + nb; out->dev_copy = d_all;
+            if (h_tot[4 * j + 2] != 0 || getenv("SX_WAVE_FAIL")) {   // (SX_WAVE_FAIL: tests of the way back)
+                if (getenv("SX_TIMING")) fprintf(stderr, "[sx] wave replay mission %zu: %llu wavefronts assumed a wrong entry state: lane-per-region path\n", k, (unsigned long long)h_tot[4 * j + 2]);
+                return abandon(SX_WAVE_FALLBACK);
+            }
+            const uint64_t nf = h_tot[4 * j], nb = h_tot[4 * j + 1];
+            final_state = (uint32_t)h_tot[4 * j + 3];
+            const uint64_t nfh_j = j == 0 ? nfh : 0, nbh_j = j == 0 ? nbh : 0;   // the host's entry windows go in front of the first slab
+            if (nb + nbh_j > 0xFFFFFFFFull) { ctx->err = "more than 4 GiB of strings in one chunk"; return abandon(SX_E_NOMEM); }
+            nf_all += nf; nb_all += nb;
+            if (nf + nfh_j == 0) continue;
+            // ---- pass 2 straight into the result's layout: [host findings][device findings][host strings][device strings]
+            const uint64_t out_bytes = (nfh_j + nf) * sizeof(sx_finding) + nbh_j + nb;
+            const int slot = (j & 1) ? 8 : 5;
+            if (pending[j & 1]) {   // the copy of slab j - 2 may still read this buffer
+                if (d.d_rp_cap[slot] < out_bytes + 64) HIP_TRY(ctx, hipEventSynchronize(copied[j & 1]));
+                else HIP_TRY(ctx, hipStreamWaitEvent(d.stream_b, copied[j & 1], 0));
+            }
+            rc = ensure_rp(ctx, d, slot, out_bytes + 64); if (rc) return abandon(rc);
+            uint8_t* d_all = (uint8_t*)d.d_rp[slot];
+            if (nf) {
+                P.findings = (sx_finding*)d_all + nfh_j;
+                P.arena = d_all + (nfh_j + nf) * sizeof(sx_finding) + nbh_j;
+                P.str_off_base = (uint32_t)nbh_j; P.f_sub = 0; P.a_sub = 0;
+                HIP_TRY(ctx, launch_wave_write(P, v0, v1, d.stream_b));
+            }
+            if (nfh_j) {
+                HIP_TRY(ctx, hipMemcpyAsync(d_all, hf.v.data(), nfh_j * sizeof(sx_finding), hipMemcpyHostToDevice, d.stream_b));
+                if (nbh_j) HIP_TRY(ctx, hipMemcpyAsync(d_all + (nfh_j + nf) * sizeof(sx_finding), hf.arena.data(), nbh_j, hipMemcpyHostToDevice, d.stream_b));
+            }
+            MissionFindings seg;
+            deferred = K == 1 && defer_min_bytes && nf * sizeof(sx_finding) + nb >= defer_min_bytes;
+            if (deferred) {
+                HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+                seg.dev_only = true; seg.ext_nf = nfh_j + nf; seg.ext_na = nbh_j + nb; seg.dev_copy = d_all;
+            } else {
+                PinnedPool::Block blk = ctx->pool->take(out_bytes + 64);
+                if (!blk.p) { ctx->err = "hipHostMalloc failed"; return abandon(SX_E_NOMEM); }
+                seg.ext = blk; seg.ext_nf = nfh_j + nf; seg.ext_na = nbh_j + nb;
+                if (K > 1) {   // on the copy stream: the next slab's kernels run meanwhile
+                    segs.push_back(std::move(seg));
+                    HIP_TRY(ctx, hipEventRecord(ctx->merge_ev[0], d.stream_b));
+                    HIP_TRY(ctx, hipStreamWaitEvent(ctx->merge_copy_stream, ctx->merge_ev[0], 0));
+                    HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, out_bytes, hipMemcpyDeviceToHost, ctx->merge_copy_stream));
+                    HIP_TRY(ctx, hipEventRecord(copied[j & 1], ctx->merge_copy_stream));
+                    pending[j & 1] = true;
+                    if (nfh_j) HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));   // (the entry part's upload reads host vectors)
+                    continue;
+                }
+                HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, out_bytes, hipMemcpyDeviceToHost, d.stream_b));
+                HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+                seg.dev_copy = d_all;
+            }
+            segs.push_back(std::move(seg));
         }
+        if (K > 1) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->merge_copy_stream));
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+        }
+    } else if (nfh) {   // the host's windows were the whole buffer
+        out->v = std::move(hf.v); out->arena = std::move(hf.arena);
     }
+    if (!segs.empty()) {
+        const uint64_t rb = out->replay_bytes;
+        *out = std::move(segs[0]);
+        for (size_t j = 1; j < segs.size(); j++) out->more.push_back(std::move(segs[j]));
+        out->replay_bytes = rb;
+    } else if (g_lo < g_all && nfh) { out->v = std::move(hf.v); out->arena = std::move(hf.arena); }
     out->replay_bytes += len;
     ctx->stats.wave_windows += g_all - g_lo;
-    const double t2 = now_ms();
+    const double t1 = now_ms();
 
     // ---- the state handed to the next buffer
     if (job.commit_state) {
@@ -180,9 +236,9 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
     }
     if (end_pos) *end_pos = len;
     if (getenv("SX_TIMING"))
-        fprintf(stderr, "[sx] wave replay mission %zu: %llu windows in %llu wavefronts, entry+count %.2f ms, write+d2h %.2f ms (%llu findings, %llu string bytes%s), state %.2f ms\n",
-                k, (unsigned long long)(g_all - g_lo), (unsigned long long)n_waves, t1 - t0, t2 - t1, (unsigned long long)(nf + nfh),
-                (unsigned long long)(nb + nbh), deferred ? ", left on the device" : "", now_ms() - t2);
+        fprintf(stderr, "[sx] wave replay mission %zu: %llu windows in %llu wavefronts, %zu slab(s): entry + count + write + d2h %.2f ms (%llu findings, %llu string bytes%s), state %.2f ms\n",
+                k, (unsigned long long)(g_all - g_lo), (unsigned long long)n_waves, segs.size(), t1 - t0, (unsigned long long)(nf_all + nfh),
+                (unsigned long long)(nb_all + nbh), deferred ? ", left on the device" : "", now_ms() - t1);
     return SX_OK;
 }
 

@@ -231,11 +231,11 @@ __global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
 // reached for its first own window what its predecessor really left there?  totals: [0] findings, [1] string bytes,
 // [2] wavefronts whose assumption was wrong, [3] the state after the last window.
 __global__ __launch_bounds__(256) void wave_verify_kernel(const u32* wave_in, const u32* wave_out, const u32* wave_nf, const u32* wave_nb,
-                                                          const u64* fbase, const u64* abase, u64 n_waves, u64* totals) {
-    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (v >= n_waves) return;
+                                                          const u64* fbase, const u64* abase, u64 v0, u64 v1, u64* totals) {
+    const u64 v = v0 + (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= v1) return;
     if (v > 0 && wave_in[v] != wave_out[v - 1]) atomicAdd((unsigned long long*)&totals[2], 1ull);
-    if (v + 1 == n_waves) { totals[0] = fbase[v] + wave_nf[v]; totals[1] = abase[v] + wave_nb[v]; totals[3] = wave_out[v]; }
+    if (v + 1 == v1) { totals[0] = fbase[v] + wave_nf[v]; totals[1] = abase[v] + wave_nb[v]; totals[3] = wave_out[v]; }
 }
 
 struct U32ToU64 {
@@ -250,26 +250,29 @@ size_t wave_scratch_bytes(uint64_t n_waves) {
     return a + 512;
 }
 
-hipError_t launch_wave_count(const WaveParams& P, uint64_t n_waves, uint64_t* fbase, uint64_t* abase, uint64_t* totals,
+// pass 1 of wavefronts [v0, v1): counts, their exclusive sums from v0 on (fbase[v], abase[v]), the verification against
+// wavefront v0 - 1 (an earlier launch on the same stream) and among themselves
+hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint64_t* fbase, uint64_t* abase, uint64_t* totals,
                              void* scratch, size_t scratch_bytes, hipStream_t stream) {
-    if (n_waves == 0) return hipSuccess;
+    if (v1 <= v0) return hipSuccess;
+    const uint64_t n = v1 - v0;
     WaveParams Q = P;
-    Q.v0 = 0;
-    if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<0, 1>), dim3((unsigned)n_waves), dim3(64), 0, stream, Q);
-    else hipLaunchKernelGGL((wave_replay_kernel<0, 0>), dim3((unsigned)n_waves), dim3(64), 0, stream, Q);
+    Q.v0 = v0;
+    if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<0, 1>), dim3((unsigned)n), dim3(64), 0, stream, Q);
+    else hipLaunchKernelGGL((wave_replay_kernel<0, 0>), dim3((unsigned)n), dim3(64), 0, stream, Q);
     void* tmp = (void*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
     size_t tmp_bytes = scratch_bytes - (size_t)((uint8_t*)tmp - (uint8_t*)scratch);
-    auto itf = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), U32ToU64{ P.wave_nf });
-    hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, itf, fbase, (u64)0, (size_t)n_waves, rocprim::plus<u64>(), stream);
+    auto itf = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), U32ToU64{ P.wave_nf + v0 });
+    hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, itf, fbase + v0, (u64)0, (size_t)n, rocprim::plus<u64>(), stream);
     if (e != hipSuccess) return e;
     tmp_bytes = scratch_bytes - (size_t)((uint8_t*)tmp - (uint8_t*)scratch);
-    auto itb = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), U32ToU64{ P.wave_nb });
-    e = rocprim::exclusive_scan(tmp, tmp_bytes, itb, abase, (u64)0, (size_t)n_waves, rocprim::plus<u64>(), stream);
+    auto itb = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), U32ToU64{ P.wave_nb + v0 });
+    e = rocprim::exclusive_scan(tmp, tmp_bytes, itb, abase + v0, (u64)0, (size_t)n, rocprim::plus<u64>(), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(totals, 0, 4 * sizeof(uint64_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(wave_verify_kernel, dim3((unsigned)((n_waves + 255) / 256)), dim3(256), 0, stream, P.wave_in, P.wave_out, P.wave_nf,
-                       P.wave_nb, fbase, abase, n_waves, totals);
+    hipLaunchKernelGGL(wave_verify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P.wave_in, P.wave_out, P.wave_nf,
+                       P.wave_nb, fbase, abase, v0, v1, totals);
     return hipGetLastError();
 }
 

@@ -95,3 +95,18 @@ def test_wave_path_large_and_text(wave_forced):
     for ms in (rc.missions(encodings=["ascii"], chars_min="4"), rc.missions(encodings=["koi8-r"], chars_min="10", unicode_block_filter="Cyrillic")):
         for data in (text, sxo.background(0, 32 << 20)):
             assert run_cli_product(ms, [data], radix="x", device=0) == sxo.run_cli(ms, [data], radix="x")
+
+
+def test_wave_path_gives_up_and_the_other_path_takes_over(wave_forced):
+    """SX_WAVE_FAIL makes the wave kernels report a wrong entry-state assumption after their count pass: stage A is finished
+    in full after all (its runs were only counted) and the lane-per-region stage B produces the findings"""
+    rng = random.Random(5)
+    ms = rc.missions(encodings=["ascii", "utf-8"], chars_min="4")
+    data = text_lines(rng, 300_000) + rng.randbytes(200_000)
+    os.environ["SX_WAVE_FAIL"] = "1"
+    try:
+        for chunk in (None, 65536):
+            assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == sxo.run_cli(ms, [data], radix="x")
+        assert wave_windows_of_a_scan(ms, data) == 0
+    finally:
+        os.environ.pop("SX_WAVE_FAIL", None)
