@@ -343,6 +343,9 @@ struct Carry {
 // atomic per kRecBlock records.  Slots of a block that stay unused are marked invalid
 // (kRecInvalid) so that the host can skip them.  All fields are wave-uniform (SGPRs).
 constexpr u32 kRecBlock = 16;
+// region_cap == kCountOnly: the records are counted (counters[2]) and not written: the host expects a string-dense buffer whose
+// stage B replays every window anyway (sx_wave.cpp) and only wants to know whether it is one
+constexpr u32 kCountOnly = kRegionCountOnly;
 // Region mode (region_cap > 0): no shared pool and no atomics — the records of sub-chunk w go
 // to slots [w*region_cap, (w+1)*region_cap) in the order they are found, and their number to
 // region_counts[w]; a compaction pass (sx_sort.hip) then yields the records sorted by position
@@ -359,11 +362,16 @@ struct Emitter {
     SX_DEV void begin_region(u64 wave) {
         if (region_cap) { base = (u32)wave * region_cap; rcount = 0; }
     }
+    // (records beyond the region's room are only counted; one atomic per sub-chunk — one per append made the scan of a
+    // string-dense buffer 30x slower: a single word takes ~90 atomics per microsecond)
     SX_DEV void end_region(u64 wave) {
         if (region_cap && lane_id() == 0) {
-            region_counts[wave] = rcount < region_cap ? rcount : region_cap;
+            if (region_cap != kCountOnly) region_counts[wave] = rcount < region_cap ? rcount : region_cap;
             if (rcount) atomicAdd(counters + 2, rcount);               // all records of the launch (stage A's host side: how dense is the input?)
-            if (rcount > region_cap) atomicMax(counters + 3, rcount);  // how much room the fullest sub-chunk needs
+            if (rcount > region_cap && region_cap != kCountOnly) {
+                atomicAdd(counters, rcount - region_cap);              // records that found no room
+                atomicMax(counters + 3, rcount);                       // how much room the fullest sub-chunk needs
+            }
         }
     }
     SX_DEV void invalidate_rest() {
@@ -386,9 +394,7 @@ struct Emitter {
         if (region_cap) {
             const u32 k = rcount + (u32)__popcll(m & ((1ull << lane) - 1ull));
             idx = base + k;
-            room = k < region_cap;
-            if (rcount + n > region_cap && lane == 0)
-                atomicAdd(counters, rcount + n - (rcount > region_cap ? rcount : region_cap));
+            room = k < region_cap && region_cap != kCountOnly;
             rcount += n;
         } else {
             if (n > left) {

@@ -90,6 +90,7 @@ struct BufferScan {
     std::vector<uint64_t> minc;           // per mission: long-run threshold
     int slot = 0;
     std::unique_ptr<SparseDeviceBytes> base_view;  // entry/exit bytes of a device-resident buffer
+    bool whole = false;                   // a whole buffer of sx_scan* (not a shard): a Mission whose last buffer was string-dense only counts its records
 
     // what the host reads whatever the runs are (entry and exit of every mission): fetched
     // before the kernels start, so that the copy does not queue behind them
@@ -102,7 +103,7 @@ struct BufferScan {
     }
     int launch(sx_ctx* ctx) {
         for (int k : order) {
-            int rc = stage_a_launch(ctx, { k }, d_bytes, len, { parity[(size_t)k] }, { minc[(size_t)k] }, slot);
+            int rc = stage_a_launch(ctx, { k }, d_bytes, len, { parity[(size_t)k] }, { minc[(size_t)k] }, slot, whole);
             if (rc != SX_OK) return rc;
         }
         return SX_OK;
@@ -120,6 +121,7 @@ struct BufferScan {
         PreReplayed pre(nm);
         if (ctx->last_runs.size() != nm) ctx->last_runs.assign(nm, 0);
         ctx->wave_off.assign(nm, 0);
+        if (ctx->wave_pred.size() != nm) ctx->wave_pred.assign(nm, 0);
         for (size_t oi = 0; oi < nm; oi++) {
             const size_t k = (size_t)order[oi];
             std::vector<RunList> one;
@@ -184,6 +186,7 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
         b.d_bytes = d_bytes + off;
         b.len = std::min(piece, len - off);
         b.order = order;
+        b.whole = true;
         b.slot = (int)(p & 1);
         for (size_t k = 0; k < nm; k++) {
             uint32_t ep = (uint32_t)((stream0[k] + off) & 1);

@@ -364,6 +364,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         const int rc = wave_replay_mission(ctx, k, view, job, out, end_pos, defer_min_bytes);
         if (rc != SX_WAVE_FALLBACK) return rc;
         if (k < ctx->wave_off.size()) ctx->wave_off[k] = 1;
+        if (k < ctx->wave_pred.size()) ctx->wave_pred[k] = 0;
     }
     if (runs.skipped) return SX_NEED_RUNS;
     size_t K = 1;

@@ -202,6 +202,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
     } else if (g_lo < g_all && nfh) { out->v = std::move(hf.v); out->arena = std::move(hf.arena); }
     out->replay_bytes += len;
     ctx->stats.wave_windows += g_all - g_lo;
+    if (k < ctx->wave_pred.size()) ctx->wave_pred[k] = 1;   // the next buffer's scan only counts (sx_stage_a.cpp)
     const double t1 = now_ms();
 
     // ---- the state handed to the next buffer

@@ -105,9 +105,16 @@ struct WvWin {
     u32 tail_empty;  // a decoder call starts exactly at the window end: one more (empty) call in this window
     u32 head_back;   // bytes of the first delivered character that lie in front of the window (0..3)
     u32 probe_before;// the slice-start probe (:176-207) marks the first call's first chunk `Before`
+    u32 slice_start; // the window is the first of its slice
 };
 
 enum { WV_BEFORE = 0, WV_EXACT = 1, WV_AFTER = 2 };   // == SX_PRECISION_*
+// A fourth value only between wv_call and the writer: "Exact unless the slice-start probe says Before", with the bytes / source
+// bytes of the leftover the window began with in bits 8.. / 17..  (finding_collection.rs:176-207 compares the first 8 bytes of the
+// slice's OUTPUT BUFFER with a fresh decoder's; after an empty first call — UTF-8: the byte a pending sequence rejects is read
+// again — the leftover that call consumed still lies at the front of that buffer.)  wv_resolve_probe settles it from the bytes.
+enum { WV_PROBE = 3 };
+SXD u32 wv_probe_pack(u32 lb, u32 lback) { return WV_PROBE | (lb << 8) | (lback << 17); }
 
 SXD bool wv_mission_ok(int grep_char, u32 same_block, u32 n_min, u32 q) {
     return grep_char < 0 && !same_block && n_min >= 1 && n_min <= q && q <= 64;
@@ -126,7 +133,8 @@ SXD bool wv_mission_ok(int grep_char, u32 same_block, u32 n_min, u32 q) {
 // EMIT(din, precision, completes, src_rel, src_len, out_len): src_rel = first source byte relative to the window start
 // (negative: in front of it), out_len = bytes of the string.
 template <bool BYTES, class EMIT>
-SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 cend, bool invalid_after, bool first_call, EMIT& emit) {
+SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 cend, bool invalid_after, bool first_call, EMIT& emit,
+                 u32 probe = 0) {
     const bool cont = st.cut != 0;   // :240-241: consumed by this call whatever it yields
     st.cut = 0;
     const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback;
@@ -137,6 +145,10 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
     if (!has_left && !wm_any(Ec)) return;
     const WvMask Rc = wm_andn(Ec, w.A);   // rejected (valid) chars of this call
     u32 prec = (has_left || (first_call && w.probe_before)) ? WV_BEFORE : WV_EXACT;   // :146, 214-221, 176-207
+    if (!BYTES && probe && !has_left) {   // a second call at byte 0 of a slice: the probe runs if its first char is not ASCII
+        const u32 fe0 = wm_next(Ec, 0);
+        if (fe0 < 128 && !wm_test(w.F, fe0)) prec = probe;
+    }
 
     // One stretch: `pre` chars carried in front of it (the leftover), its accepted chars = the E bits in [a, er).
     // comp0: its first piece completes the string before.
@@ -221,11 +233,15 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
 // meet no leftover only clear the cut flag: they are skipped in bulk.
 template <bool BYTES, class EMIT>
 SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, bool skip_idle_calls = true) {
-    if (w.pre_empty) wv_call<BYTES>(P, w, st, 0u, 0u, true, false, emit);
+    u32 probe = 0;
+    if (w.pre_empty) {
+        if (w.slice_start && st.lb) probe = wv_probe_pack(st.lb, st.lback);
+        wv_call<BYTES>(P, w, st, 0u, 0u, true, false, emit);
+    }
     u32 din = 0;
     bool first = true;
     for (;;) {
-        if (skip_idle_calls && st.lc == 0 && !(first && w.probe_before)) {
+        if (skip_idle_calls && st.lc == 0 && !(first && (w.probe_before || probe))) {
             const u32 a = wm_next(w.A, din);
             if (a >= w.n) { st.cut = 0; return; }   // (at least the call at din is still to come, and none of them yields)
             const i32 cs = wm_prev(w.CS, a);        // start of the call that delivers the next accepted char
@@ -234,7 +250,7 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, b
         u32 cend = wm_next(w.CS, din + 1);
         if (cend > w.n) cend = w.n;
         const bool last = cend >= w.n;
-        wv_call<BYTES>(P, w, st, din, cend, !last || w.tail_empty != 0, first, emit);
+        wv_call<BYTES>(P, w, st, din, cend, !last || w.tail_empty != 0, first, emit, din == 0 ? probe : 0u);
         first = false;
         if (last) break;
         din = cend;
@@ -301,7 +317,7 @@ SXD WvWin wv_win_single(WvMask V, WvMask A, WvMask O2, WvMask O3, u32 n, u32 n_m
     const WvMask bad = wm_andn(wm_below(n), V);        // a byte without a character: Malformed(1, 0), the call ends behind it
     w.CS = wm_and(wm_shl1(bad), wm_below(n));
     w.tail_empty = n && wm_test(bad, n - 1) ? 1u : 0u;
-    w.pre_empty = 0; w.head_back = 0; w.probe_before = 0;
+    w.pre_empty = 0; w.head_back = 0; w.probe_before = 0; w.slice_start = 0;
     return w;
 }
 
@@ -384,7 +400,21 @@ SXD WvWin wv_win_utf8(WvMask E, WvMask A, WvMask F, WvMask G, WvMask MA, WvMask 
     const u32 e0 = wm_next(E, 0);
     if (e0 < 128 && wm_prev(F, e0) < 0) w.head_back = (f_back & 4u) ? 1u : (f_back & 2u) ? 2u : (f_back & 1u) ? 3u : 0u;
     w.probe_before = slice_start && w.head_back ? 1u : 0u;
+    w.slice_start = slice_start ? 1u : 0u;
     return w;
+}
+
+// WV_PROBE settled (UTF-8): `slice` = the slice's first bytes (n of them, n <= 32 is enough), `left` = the lb bytes of the
+// leftover.  The fresh decoder's output (at most 8 bytes, whole chars) must equal the first bytes of [leftover][the call's output];
+// the call's output begins like the fresh decoder's (same bytes, same neutral decoder).
+SXD u32 wv_resolve_probe(const u8* slice, u32 n, const u8* left, u32 lb) {
+    DDecoder fresh;
+    ddec_reset(fresh, 1, nullptr);
+    u8 probe[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const DStep pr = ddec_utf8(fresh, slice, n < 32 ? n : 32, probe, 8, true);
+    bool same = pr.written != 0;
+    for (u32 t = 0; t < pr.written && same; t++) same = (t < lb ? left[t] : probe[t - lb]) == probe[t];
+    return same ? WV_EXACT : WV_BEFORE;
 }
 
 // ------------------------------------------------------------------------------------------

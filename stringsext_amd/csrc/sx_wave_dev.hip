@@ -65,6 +65,11 @@ struct WriteEmit {
         r.position = P->consumed0 + win_pos + din;
         r.str_off = (u32)(a_off + P->str_off_base);
         r.str_len = out_len;
+        if ((prec & 0xFFu) == WV_PROBE) {   // sx_wave_core.hpp WV_PROBE: this call starts at the slice's byte 0
+            const u32 lb = (prec >> 8) & 511u, lback = prec >> 17;
+            const u64 avail = P->len - win_pos;
+            prec = wv_resolve_probe(P->data + win_pos, avail < 32 ? (u32)avail : 32u, P->data + (win_pos - lback), lb);
+        }
         r.precision = (u8)prec;
         r.completes_previous = completes ? 1 : 0;
         r.mission_id = (u8)P->mission_id;
