@@ -123,6 +123,7 @@ typedef struct sx_stats {
     double   h2d_ms, d2h_ms, replay_ms, total_ms;
     uint64_t heavy_tiles;                /* 1 KiB tiles that needed the general cross-lane path (all missions) */
     uint64_t wave_windows;               /* decoder-input windows replayed by the wave-cooperative stage B (all missions) */
+    double   wave_count_ms, wave_write_ms; /* ... its two passes, HIP events around their launches (all missions and slabs) */
 } sx_stats;
 
 typedef struct sx_ctx sx_ctx;

@@ -155,7 +155,8 @@ class Stats(C.Structure):
     _fields_ = [("bytes_scanned", C.c_uint64), ("run_records", C.c_uint64), ("replay_bytes", C.c_uint64),
                 ("findings", C.c_uint64), ("kernel_ms", C.c_double * 16), ("device_ms", C.c_double),
                 ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("replay_ms", C.c_double),
-                ("total_ms", C.c_double), ("heavy_tiles", C.c_uint64), ("wave_windows", C.c_uint64)]
+                ("total_ms", C.c_double), ("heavy_tiles", C.c_uint64), ("wave_windows", C.c_uint64),
+                ("wave_count_ms", C.c_double), ("wave_write_ms", C.c_double)]
 
 
 class Options(C.Structure):

@@ -283,6 +283,7 @@ void sx_destroy(sx_ctx* ctx) {
         if (ctx->post_stream) (void)hipStreamDestroy(ctx->post_stream);
         if (ctx->merge_copy_stream) (void)hipStreamDestroy(ctx->merge_copy_stream);
         for (hipEvent_t e : ctx->merge_ev) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ctx->wave_ev) if (e) (void)hipEventDestroy(e);
         if (ctx->d_input) (void)hipFree(ctx->d_input);
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
         if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);

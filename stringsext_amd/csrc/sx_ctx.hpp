@@ -151,7 +151,8 @@ struct sx_ctx {
     uint64_t ondemand_fetches = 0;
     // grow-only scratch reused by every call (pinned host memory: D2H at full PCIe rate)
     std::vector<uint64_t> last_runs;  // long runs per mission of the last scanned buffer: busiest mission scans first
-    std::vector<char> wave_pred;      // per mission: its last whole buffer was string-dense and went through the wave kernels: the next scan only counts records
+    std::vector<char> wave_pred;      // per mission: its last whole buffer was string-dense and went through the wave kernels: the next one does without stage A
+    std::vector<hipEvent_t> wave_ev;  // timing events of the wave kernels (4 per slab: count begin / end, write begin / end)
     std::vector<char> wave_off;       // per mission, for the buffer in hand: the wave-cooperative stage B gave up on it (sx_wave.cpp)
     std::vector<sx::RunList> shard_runs;  // device runs of the last sx_scan_shard* buffer (reuse_runs)
     bool shard_runs_valid = false;
@@ -233,7 +234,7 @@ void begin_call(sx_ctx* ctx);
 ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const uint8_t* d_bytes, uint64_t len,
                        uint32_t parity, uint64_t min_chars);
 int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
-                   const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si, bool may_count_only = false);
+                   const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si);
 struct ReplayJob;
 int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
                    const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si,

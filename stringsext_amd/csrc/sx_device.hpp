@@ -31,8 +31,6 @@ constexpr uint32_t kRecCharsMask = 0x3FFFFFFFu;
 // a reserved slot that was never filled (see Emitter in sx_kernels.hip)
 constexpr uint32_t kRecInvalidLen = 0xFFFFFFFFu, kRecInvalidFlags = 0xFFFFFFFFu;
 
-constexpr uint32_t kRegionCountOnly = 0xFFFFFFFFu;   // ScanParams::region_cap: count the records (counters[2]), write none
-
 enum ClassifierKind : uint32_t {
     kClsSingleByteLut = 0,  // x-user-defined and WHATWG single-byte tables: 256-entry accept LUT
     kClsUtf8Lut = 1,        // UTF-8, any af/ubf: 256-entry class LUT + SWAR validity

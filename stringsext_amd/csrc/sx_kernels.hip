@@ -343,9 +343,6 @@ struct Carry {
 // atomic per kRecBlock records.  Slots of a block that stay unused are marked invalid
 // (kRecInvalid) so that the host can skip them.  All fields are wave-uniform (SGPRs).
 constexpr u32 kRecBlock = 16;
-// region_cap == kCountOnly: the records are counted (counters[2]) and not written: the host expects a string-dense buffer whose
-// stage B replays every window anyway (sx_wave.cpp) and only wants to know whether it is one
-constexpr u32 kCountOnly = kRegionCountOnly;
 // Region mode (region_cap > 0): no shared pool and no atomics — the records of sub-chunk w go
 // to slots [w*region_cap, (w+1)*region_cap) in the order they are found, and their number to
 // region_counts[w]; a compaction pass (sx_sort.hip) then yields the records sorted by position
@@ -366,9 +363,9 @@ struct Emitter {
     // string-dense buffer 30x slower: a single word takes ~90 atomics per microsecond)
     SX_DEV void end_region(u64 wave) {
         if (region_cap && lane_id() == 0) {
-            if (region_cap != kCountOnly) region_counts[wave] = rcount < region_cap ? rcount : region_cap;
+            region_counts[wave] = rcount < region_cap ? rcount : region_cap;
             if (rcount) atomicAdd(counters + 2, rcount);               // all records of the launch (stage A's host side: how dense is the input?)
-            if (rcount > region_cap && region_cap != kCountOnly) {
+            if (rcount > region_cap) {
                 atomicAdd(counters, rcount - region_cap);              // records that found no room
                 atomicMax(counters + 3, rcount);                       // how much room the fullest sub-chunk needs
             }
@@ -394,7 +391,7 @@ struct Emitter {
         if (region_cap) {
             const u32 k = rcount + (u32)__popcll(m & ((1ull << lane) - 1ull));
             idx = base + k;
-            room = k < region_cap && region_cap != kCountOnly;
+            room = k < region_cap;
             rcount += n;
         } else {
             if (n > left) {

@@ -90,7 +90,18 @@ struct BufferScan {
     std::vector<uint64_t> minc;           // per mission: long-run threshold
     int slot = 0;
     std::unique_ptr<SparseDeviceBytes> base_view;  // entry/exit bytes of a device-resident buffer
-    bool whole = false;                   // a whole buffer of sx_scan* (not a shard): a Mission whose last buffer was string-dense only counts its records
+    bool whole = false;                   // a whole buffer of sx_scan* (not a shard)
+    // A Mission whose last whole buffer was string-dense and went through the wave kernels (sx_wave.cpp) does without stage A
+    // for the next one: its stage B replays every window anyway, and says afterwards whether the buffer was dense again.
+    bool skip_scan(const sx_ctx* ctx, size_t k) const {
+        return whole && len >= 2 * kInputBufLen && k < ctx->wave_pred.size() && ctx->wave_pred[k] && ctx->missions[k].wave_ok && !getenv("SX_WAVE_KEEP_SCAN")
+               && !(getenv("SX_WAVE_REPLAY") && !atoi(getenv("SX_WAVE_REPLAY")));
+    }
+    bool none_scanned(const sx_ctx* ctx) const {
+        if (not_scanned.size() != ctx->missions.size()) return false;
+        for (char c : not_scanned) if (!c) return false;
+        return true;
+    }
 
     // what the host reads whatever the runs are (entry and exit of every mission): fetched
     // before the kernels start, so that the copy does not queue behind them
@@ -98,12 +109,16 @@ struct BufferScan {
         base_view.reset();
         if (host_bytes) return SX_OK;
         base_view.reset(new SparseDeviceBytes(ctx, d_bytes));
+        if (none_scanned(ctx)) return SX_OK;   // the wave path reads two windows' worth: fetched when asked for (SparseDeviceBytes::span)
         ReplayJob none;
         return download_for_replay(ctx, d_bytes, len, nullptr, base_view.get(), none);
     }
+    std::vector<char> not_scanned;        // per mission: launch() left its scan kernel out (skip_scan)
     int launch(sx_ctx* ctx) {
+        not_scanned.assign(ctx->missions.size(), 0);
         for (int k : order) {
-            int rc = stage_a_launch(ctx, { k }, d_bytes, len, { parity[(size_t)k] }, { minc[(size_t)k] }, slot, whole);
+            if (skip_scan(ctx, (size_t)k)) { not_scanned[(size_t)k] = 1; continue; }
+            int rc = stage_a_launch(ctx, { k }, d_bytes, len, { parity[(size_t)k] }, { minc[(size_t)k] }, slot);
             if (rc != SX_OK) return rc;
         }
         return SX_OK;
@@ -125,7 +140,20 @@ struct BufferScan {
         for (size_t oi = 0; oi < nm; oi++) {
             const size_t k = (size_t)order[oi];
             std::vector<RunList> one;
-            int rc = stage_a_finish(ctx, { (int)k }, d_bytes, len, { parity[k] }, { minc[k] }, slot, &one, true, &job);
+            int rc = SX_OK;
+            const bool unscanned = k < not_scanned.size() && not_scanned[k];
+            if (unscanned && wave_replay_wanted(ctx, job, k, len)) {   // no stage A: "as dense as the last buffer"
+                one.assign(1, RunList{});
+                one[0].n = len / 64; one[0].skipped = true; one[0].complete = true;
+                ctx->stats.bytes_scanned += len;
+            } else {
+                if (unscanned) {   // (not launched with the others, but the job is not one for the wave kernels after all)
+                    ctx->wave_pred[k] = 0;
+                    rc = stage_a_launch(ctx, { (int)k }, d_bytes, len, { parity[k] }, { minc[k] }, slot);
+                    if (rc != SX_OK) return rc;
+                }
+                rc = stage_a_finish(ctx, { (int)k }, d_bytes, len, { parity[k] }, { minc[k] }, slot, &one, true, &job);
+            }
             if (rc != SX_OK) return rc;
             (*runs)[k] = std::move(one[0]);
             if (!(*runs)[k].own.empty()) (*runs)[k].use_own();  // the vector moved: point at it again

@@ -47,23 +47,12 @@ ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const 
 // Stage A, first half: enqueue every mission's scan kernel over [d_bytes, d_bytes+len) on its
 // scan stream, writing into record slot `si`.  Returns at once.
 int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
-                   const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si, bool may_count_only) {
+                   const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si) {
     if (len == 0) return SX_OK;
     for (size_t k = 0; k < which.size(); k++) {
         MissionDev& d = ctx->dev[(size_t)which[k]];
         ScanSlot& s = d.slot[si];
         if (s.free_pending) { HIP_TRY(ctx, hipStreamWaitEvent(d.stream, s.ev_free, 0)); s.free_pending = false; }
-        if (may_count_only && (size_t)which[k] < ctx->wave_pred.size() && ctx->wave_pred[(size_t)which[k]] && ctx->missions[(size_t)which[k]].wave_ok
-            && !getenv("SX_NO_COUNT_ONLY")) {
-            // the Mission's last buffer was string-dense and replayed window by window (sx_wave.cpp): this scan only says whether
-            // this one is too — it counts its records and writes none
-            uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 256u * 1024u;
-            sub = std::max<uint32_t>(kTileBytes, sub / kTileBytes * kTileBytes);
-            s.region_cap = kRegionCountOnly; s.n_regions = (len + sub - 1) / sub;
-            int rc = ensure_capacity(ctx, s, 1024);
-            if (rc != SX_OK) return rc;
-            goto launch;
-        }
         {   // region mode unless the mission's last buffer was too dense for it (or the options rule it out)
             uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 256u * 1024u;
             sub = std::max<uint32_t>(kTileBytes, sub / kTileBytes * kTileBytes);
@@ -125,14 +114,6 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         for (int round = 0;; round++) {
             HIP_TRY(ctx, hipMemcpyAsync(counters, s.d_counters, sizeof counters, hipMemcpyDeviceToHost, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
-            if (round == 0 && s.region_cap == kRegionCountOnly && !(wave_job && wave_replay_wanted(ctx, *wave_job, (size_t)which[k], counters[2]))) {
-                // the records were only counted (the last buffer was string-dense) and this buffer is not: scan it again, records and all
-                ctx->wave_pred[(size_t)which[k]] = 0;
-                int rc = stage_a_launch(ctx, { which[k] }, d_bytes, len, { parity[k] }, { min_chars[k] }, si, false);
-                if (rc != SX_OK) return rc;
-                HIP_TRY(ctx, hipEventSynchronize(s.ev1));
-                continue;
-            }
             if (round == 0 && wave_job) {
                 // String-dense input of a Mission whose stage B can replay every window (sx_wave.cpp): the records are only
                 // counted — no second scan with larger regions, no sort, no join, no pieces.

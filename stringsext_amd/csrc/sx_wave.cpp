@@ -125,12 +125,20 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
                 for (hipEvent_t& e : ctx->merge_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             }
         }
+        while (ctx->wave_ev.size() < 4 * K) {
+            hipEvent_t e;
+            HIP_TRY(ctx, hipEventCreate(&e));
+            ctx->wave_ev.push_back(e);
+        }
+        std::vector<char> wrote(K, 0);
         uint64_t* h_tot = (uint64_t*)ctx->h_pin2;
         hipEvent_t copied[2] = { ctx->merge_ev[1], ctx->merge_ev[2] };
         bool pending[2] = { false, false };
         for (uint64_t j = 0; j < K; j++) {
             const uint64_t v0 = n_waves * j / K, v1 = n_waves * (j + 1) / K;
+            HIP_TRY(ctx, hipEventRecord(ctx->wave_ev[4 * j], d.stream_b));
             HIP_TRY(ctx, launch_wave_count(P, v0, v1, d_fb, d_ab, d_tot + 4 * j, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
+            HIP_TRY(ctx, hipEventRecord(ctx->wave_ev[4 * j + 1], d.stream_b));
             HIP_TRY(ctx, hipMemcpyAsync(h_tot + 4 * j, d_tot + 4 * j, 4 * 8, hipMemcpyDeviceToHost, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
             if (h_tot[4 * j + 2] != 0 || getenv("SX_WAVE_FAIL")) {   // (SX_WAVE_FAIL: tests of the way back)
@@ -156,7 +164,10 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
                 P.findings = (sx_finding*)d_all + nfh_j;
                 P.arena = d_all + (nfh_j + nf) * sizeof(sx_finding) + nbh_j;
                 P.str_off_base = (uint32_t)nbh_j; P.f_sub = 0; P.a_sub = 0;
+                HIP_TRY(ctx, hipEventRecord(ctx->wave_ev[4 * j + 2], d.stream_b));
                 HIP_TRY(ctx, launch_wave_write(P, v0, v1, d.stream_b));
+                HIP_TRY(ctx, hipEventRecord(ctx->wave_ev[4 * j + 3], d.stream_b));
+                wrote[j] = 1;
             }
             if (nfh_j) {
                 HIP_TRY(ctx, hipMemcpyAsync(d_all, hf.v.data(), nfh_j * sizeof(sx_finding), hipMemcpyHostToDevice, d.stream_b));
@@ -191,6 +202,12 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             HIP_TRY(ctx, hipStreamSynchronize(ctx->merge_copy_stream));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
         }
+        for (uint64_t j = 0; j < K; j++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ctx->wave_ev[4 * j], ctx->wave_ev[4 * j + 1]) == hipSuccess) ctx->stats.wave_count_ms += ms;
+            if (wrote[j] && hipEventElapsedTime(&ms, ctx->wave_ev[4 * j + 2], ctx->wave_ev[4 * j + 3]) == hipSuccess) ctx->stats.wave_write_ms += ms;
+        }
+        (void)hipGetLastError();
     } else if (nfh) {   // the host's windows were the whole buffer
         out->v = std::move(hf.v); out->arena = std::move(hf.arena);
     }
@@ -202,7 +219,8 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
     } else if (g_lo < g_all && nfh) { out->v = std::move(hf.v); out->arena = std::move(hf.arena); }
     out->replay_bytes += len;
     ctx->stats.wave_windows += g_all - g_lo;
-    if (k < ctx->wave_pred.size()) ctx->wave_pred[k] = 1;   // the next buffer's scan only counts (sx_stage_a.cpp)
+    // the next whole buffer of this Mission does without stage A (sx_schedule.cpp) as long as this one was string-dense
+    if (k < ctx->wave_pred.size()) ctx->wave_pred[k] = (nf_all + nfh) * wave_min_density_bytes() * 2 > len ? 1 : 0;
     const double t1 = now_ms();
 
     // ---- the state handed to the next buffer
