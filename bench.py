@@ -154,7 +154,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     kernel_ms = [0.0] * len(missions)
-    device_ms = replay_ms = d2h_ms = 0.0
+    device_ms = replay_ms = d2h_ms = wave_count_ms = wave_write_ms = 0.0
+    wave_windows = 0
     findings = records = replay_bytes = 0
     for _ in range(args.steps):
         n, st = step()
@@ -166,6 +167,9 @@ def main():
         device_ms += st.device_ms
         replay_ms += st.replay_ms
         d2h_ms += st.d2h_ms
+        wave_count_ms += st.wave_count_ms
+        wave_write_ms += st.wave_write_ms
+        wave_windows = st.wave_windows
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -199,8 +203,17 @@ def main():
         # roofline figure is the average over the launches: (missions x nbytes) / sum of the
         # launch durations, HIP events around every launch on the scan stream.  (With
         # SX_MISSION_STREAMS=1 they overlap on a stream each and the span is the longest one.)
+        # A Mission whose last buffer was string-dense has no scan kernel: its stage B replays every window with the
+        # wave-cooperative kernels (sx_wave_dev.hip), a count pass and a write pass that each read the shard once — they are the
+        # Mission's passes over the input and enter the average as such (their durations: HIP events around their launches).
+        n_scanned = sum(1 for x in kernel_ms if x > 0)
+        n_wave = int(round(wave_windows / (nbytes / 128.0))) if wave_windows else 0
+        wave_count_ms /= K
+        wave_write_ms /= K
         span_ms = max(kernel_ms) if os.environ.get("SX_MISSION_STREAMS") else sum(kernel_ms)
-        agg_gbs = len(missions) * nbytes / (span_ms * 1e-3) / 1e9
+        passes = n_scanned + (2 * n_wave if (n_wave and n_scanned < len(missions)) else 0)
+        span_all = span_ms + ((wave_count_ms + wave_write_ms) if n_scanned < len(missions) else 0.0)
+        agg_gbs = passes * nbytes / (span_all * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters: they cannot be read inside this process, so the
         # value comes from the committed counter passes of this very command line (profiles/traffic.json
         # says how); null for any other workload or size
@@ -214,7 +227,12 @@ def main():
         roofline = {
             "bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "sx::scan_kernel<%s>, %d launches per step, average" % (wl.get("kernels", "Utf8Range2|Utf16Range"), len(missions)),
+            "kernel": "sx::scan_kernel<%s>, %d launches per step, average" % (wl.get("kernels", "Utf8Range2|Utf16Range"), n_scanned)
+                      + (" + sx::wave_replay_kernel count and write pass of %d string-dense Mission(s) (no scan kernel: every window is replayed)" % n_wave
+                         if n_scanned < len(missions) and n_wave else ""),
+            "wave_passes_ms": {"missions": n_wave, "count": round(wave_count_ms, 3), "write": round(wave_write_ms, 3),
+                               "count_gbs": round(n_wave * nbytes / (wave_count_ms * 1e-3) / 1e9, 1) if wave_count_ms > 0 else None,
+                               "write_gbs": round(n_wave * nbytes / (wave_write_ms * 1e-3) / 1e9, 1) if wave_write_ms > 0 else None},
             "algorithmic_bytes_per_launch": nbytes,
             "per_kernel_ms": [round(x, 3) for x in kernel_ms],
             "per_kernel_gbs": [round(nbytes / (x * 1e-3) / 1e9, 1) if x > 0 else None for x in kernel_ms],
@@ -227,7 +245,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic" if args.background == "random" else "constant bytes (counter pass)",
             "config": {"workload": wl["name"], "bytes_per_gpu": nbytes, "missions": len(missions),
-                       "parallelism": f"byte-range shards x{world}", "passes": len(missions)},
+                       "parallelism": f"byte-range shards x{world}", "passes": passes},
             "roofline": roofline,
             "breakdown_ms_per_step": {"scan_kernels_sum": round(sum(kernel_ms), 3),
                                       "host_waits_for_stage_a": round(device_ms, 3),
@@ -237,7 +255,7 @@ def main():
             "exchange_ms_per_step": round(timings.get("exchange_ms", 0.0), 3) if world > 1 else None,
             "findings_per_step": findings, "run_records_rank0": records,
             "replay_fraction": round(replay_bytes / (len(missions) * nbytes), 5),
-            "kernels_only_gib_s": round(world * nbytes / (sum(kernel_ms) * 1e-3) / (1 << 30), 1) if sum(kernel_ms) > 0 else None,
+            "kernels_only_gib_s": round(world * nbytes / (span_all * 1e-3) / (1 << 30), 1) if span_all > 0 else None,
         }
         if not args.no_cpu_baseline:
             import threading
