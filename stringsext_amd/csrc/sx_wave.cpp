@@ -136,6 +136,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         bool pending[2] = { false, false };
         for (uint64_t j = 0; j < K; j++) {
             const uint64_t v0 = n_waves * j / K, v1 = n_waves * (j + 1) / K;
+            if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   wave mission %zu slab %llu: waves [%llu, %llu) of %llu, E %llu, count...\n", k, (unsigned long long)j, (unsigned long long)v0, (unsigned long long)v1, (unsigned long long)n_waves, (unsigned long long)E);
             HIP_TRY(ctx, hipEventRecord(ctx->wave_ev[4 * j], d.stream_b));
             HIP_TRY(ctx, launch_wave_count(P, v0, v1, d_fb, d_ab, d_tot + 4 * j, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
             HIP_TRY(ctx, hipEventRecord(ctx->wave_ev[4 * j + 1], d.stream_b));
@@ -146,6 +147,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
                 return abandon(SX_WAVE_FALLBACK);
             }
             const uint64_t nf = h_tot[4 * j], nb = h_tot[4 * j + 1];
+            if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   ... counted %llu findings, %llu bytes at +%.2f ms\n", (unsigned long long)nf, (unsigned long long)nb, now_ms() - t0);
             final_state = (uint32_t)h_tot[4 * j + 3];
             const uint64_t nfh_j = j == 0 ? nfh : 0, nbh_j = j == 0 ? nbh : 0;   // the host's entry windows go in front of the first slab
             if (nb + nbh_j > 0xFFFFFFFFull) { ctx->err = "more than 4 GiB of strings in one chunk"; return abandon(SX_E_NOMEM); }
@@ -177,6 +179,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             deferred = K == 1 && defer_min_bytes && nf * sizeof(sx_finding) + nb >= defer_min_bytes;
             if (deferred) {
                 HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+                if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   ... written (left on the device) at +%.2f ms\n", now_ms() - t0);
                 seg.dev_only = true; seg.ext_nf = nfh_j + nf; seg.ext_na = nbh_j + nb; seg.dev_copy = d_all;
             } else {
                 PinnedPool::Block blk = ctx->pool->take(out_bytes + 64);

@@ -125,7 +125,8 @@ __global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
         const u64 span_lo = ((u64)wv_uniform((u32)(ws >> 32)) << 32) | wv_uniform((u32)ws);
         const u64 we = ws + wn;
         const int last_lane = (int)wv_uniform(n_act - 1);
-        const u64 span_hi = ((u64)__builtin_amdgcn_readlane((u32)(we >> 32), last_lane) << 32) | __builtin_amdgcn_readlane((u32)we, last_lane);
+        // (the builtin returns int: without the casts a low half >= 2^31 sign-extends into the high one)
+        const u64 span_hi = ((u64)(u32)__builtin_amdgcn_readlane((u32)(we >> 32), last_lane) << 32) | (u64)(u32)__builtin_amdgcn_readlane((u32)we, last_lane);
         const u64 tile0 = wv_tile0(span_lo);
         const u32 n_tiles = (u32)((span_hi - tile0 + kTileBytes - 1) / kTileBytes);
 
@@ -209,16 +210,16 @@ __global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
             if (!__ballot(todo)) break;
         }
         if (g0 == gw && v != 0) {   // the state this wavefront assumes for its first own window (lane kWvWarm of the first batch)
-            assumed_in = __builtin_amdgcn_readlane(in, (int)kWvWarm);
+            assumed_in = (u32)__builtin_amdgcn_readlane(in, (int)kWvWarm);
         }
-        carry = __builtin_amdgcn_readlane(out, 63);
-        const u32 last_out = __builtin_amdgcn_readlane(out, last_lane);
+        carry = (u32)__builtin_amdgcn_readlane(out, 63);
+        const u32 last_out = (u32)__builtin_amdgcn_readlane(out, last_lane);
         if (!owned) { nf = 0; nb = 0; }
 
         // ---- 4. counts -> offsets -> (pass 2) output
         const u32 packed = (nf << 18) | nb;   // per batch: nb <= 64 windows x 640 bytes < 2^18, nf <= 64 x 129 < 2^14
         const u32 incl = wv_scan_incl(packed, lane);
-        const u32 bt = __builtin_amdgcn_readlane(incl, 63);
+        const u32 bt = (u32)__builtin_amdgcn_readlane(incl, 63);
         if (MODE == 1 && (nf | nb)) {
             const u32 excl = incl - packed;
             const u64 fo = fbase + tot_f + (excl >> 18), ao = abase + tot_b + (excl & 0x3FFFFu);

@@ -157,3 +157,29 @@ def test_c5_64gib_windows_equal_oracle():
     ms = product_missions(**C5)
     compared, total = check_windows(ms, 64 << 30, False, 4, 5)
     assert total > 300_000_000 and compared > 4 * 300_000
+
+
+def test_wave_path_6gib_windows_equal_oracle():
+    """One string-dense Mission through the wave-cooperative stage B in slabs (csrc/sx_wave.cpp): 6 GiB, so that windows,
+    slices and string offsets pass 2^31 and 2^32; the oracle's windows include both."""
+    ms = product_missions(encodings=["koi8-r,,,Cyrillic"], chars_min="10")
+    total = 6 << 30
+    sc = sx.Scanner(ms, device=0)
+    d = sc.alloc(total)
+    sc.fill_background(d, 0, total, SEED)
+    res = sc.scan_device(d, total, file_id=1)
+    try:
+        assert sc.stats().wave_windows == total // 128 - 1   # all but the buffer's first window (the host's)
+        segs = product_findings_by_slice(res)
+        assert len(segs) > 1 and sum(len(f) for f, _ in segs) == len(res) > 20_000_000
+        small = 16 << 20
+        for ws in ((1 << 31) - small // 2, (1 << 32) - small // 2, total - small, 5 * (1 << 30) + 4096 * 77):
+            host = sxo.background(ws, small, SEED)
+            want = oracle_window(ms, host, ws)
+            at_end = ws + small == total
+            lo_slice, hi_slice = (ws + MARGIN) // 4096, (ws + small - (0 if at_end else MARGIN)) // 4096
+            want = [t for t in want if lo_slice <= t[5] < hi_slice]
+            got = window_findings(segs, lo_slice, hi_slice)
+            assert got == want, (hex(ws), len(got), len(want), next(((a, b) for a, b in zip(got, want) if a != b), None))
+    finally:
+        res.free(); sc.free(d); sc.close()
