@@ -17,7 +17,12 @@ SWITCH_SETS = [{}, {}, {}, {"SX_NO_REPLAY_CACHE": "1"}, {"SX_HOST_STITCH": "1"},
                {"SX_REGION_CAP": "1"}, {"SX_REGION_CAP": "2", "SX_NO_LARGE_REGIONS": "1"}, {"SX_REGION_CAP": "1", "SX_DEVICE_JOIN_MIN": "1"},
                {"SX_STITCH_BLOCK": "512"}, {"SX_STITCH_BLOCK": "3"}, {"SX_MAX_REGION_WINDOWS": "2"}, {"SX_MAX_REGION_WINDOWS": "64"},
                {"SX_SLABS": "3"}, {"SX_SLABS": "8"}, {"SX_SLABS": "5", "SX_MAX_REGION_WINDOWS": "2"}, {"SX_SLABS": "2", "SX_DEVICE_JOIN_MIN": "1"},
-               {"SX_DEFER_MIN_BYTES": "1"}, {"SX_DEFER_MIN_BYTES": "1", "SX_MERGE_PART_FINDINGS": "2000"}, {"SX_MERGE_PART_FINDINGS": "3000"}]
+               {"SX_DEFER_MIN_BYTES": "1"}, {"SX_DEFER_MIN_BYTES": "1", "SX_MERGE_PART_FINDINGS": "2000"}, {"SX_MERGE_PART_FINDINGS": "3000"},
+               # the wave-cooperative stage B (sx_wave.cpp): forced on for every covered Mission, with odd wavefront / slab geometries,
+               # with and without stage A in front of it, with its way back to the lane-per-region path, and forced off
+               {"SX_WAVE_REPLAY": "1"}, {"SX_WAVE_REPLAY": "1"}, {"SX_WAVE_REPLAY": "1"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_BATCHES": "1"},
+               {"SX_WAVE_REPLAY": "1", "SX_WAVE_BATCHES": "2", "SX_WAVE_SLABS": "3"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_SLABS": "5", "SX_WAVE_KEEP_SCAN": "1"},
+               {"SX_WAVE_REPLAY": "1", "SX_DEFER_MIN_BYTES": "1"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_FAIL": "1"}, {"SX_WAVE_REPLAY": "0"}]
 ALL_SWITCHES = sorted({k for s in SWITCH_SETS for k in s})
 
 
