@@ -67,7 +67,10 @@ enum {
     SX_ENC_BIG5 = 64, SX_ENC_EUC_JP = 65, SX_ENC_SHIFT_JIS = 66, SX_ENC_EUC_KR = 67,
     SX_ENC_GB18030 = 68, SX_ENC_GBK = 69,   /* one decoder (four-byte tokens too), two names */
     /* the "replacement" encoding (ISO-2022-KR, ISO-2022-CN, HZ-GB-2312): its decoder reports one error and nothing else */
-    SX_ENC_REPLACEMENT = 70
+    SX_ENC_REPLACEMENT = 70,
+    /* ISO-2022-JP: escape sequences select the character set, so the meaning of a byte depends on unbounded history: a Mission
+     * with it is ONE sequential pass on the host (never on the device, never sharded) */
+    SX_ENC_ISO_2022_JP = 71
 };
 
 /* `Precision` — src/finding.rs:34-46 */

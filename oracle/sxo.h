@@ -39,7 +39,7 @@ extern "C" {
 enum { SXO_ENC_X_USER_DEFINED = 0, SXO_ENC_UTF8 = 1, SXO_ENC_UTF16LE = 2, SXO_ENC_UTF16BE = 3,
        SXO_ENC_SINGLE_BYTE_BASE = 16 /* + table index, see sxo_single_byte_name */,
        SXO_ENC_BIG5 = 64, SXO_ENC_EUC_JP = 65, SXO_ENC_SHIFT_JIS = 66, SXO_ENC_EUC_KR = 67, SXO_ENC_GB18030 = 68, SXO_ENC_GBK = 69 /* the same decoder, another name */,
-       SXO_ENC_REPLACEMENT = 70 };
+       SXO_ENC_REPLACEMENT = 70, SXO_ENC_ISO_2022_JP = 71 };
 
 enum { SXO_BEFORE = 0, SXO_EXACT = 1, SXO_AFTER = 2 };
 

@@ -309,6 +309,7 @@ int sx_device_runs(sx_ctx* ctx, int mission_index, const void* device_bytes, uin
     begin_call(ctx);
     if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
     if ((uintptr_t)device_bytes & 15) { ctx->err = "device_bytes must be 16-byte aligned"; return SX_E_INVALID; }
+    if (ctx->missions[(size_t)mission_index].host_sequential()) { ctx->err = "an ISO-2022-JP mission has no stage A (one sequential pass on the host)"; return SX_E_INVALID; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::vector<RunList> out;
     ctx->shard_runs_valid = false;  // the mission's device-side run list is about to be replaced

@@ -50,12 +50,17 @@ struct DDecoder {
     // gb18030 (family 4 with four-byte tokens): dlead = "gb18030 first", gb2 / gb3 = second / third; rq = bytes the algorithm
     // "prepends to the stream" that an EARLIER call consumed: they are decoded again in front of the next call's input
     u8 gb2, gb3, rq[2], rq_n;
+    // ISO-2022-JP: which set the bytes select (what an escape sequence changes), the set that was selected when an escape
+    // sequence began, the byte in hand, "an escape sequence and no character since", and the `$` / `(` of a broken escape
+    // sequence that the next call decodes in front of its input
+    u8 iso_set, iso_out, iso_mid, iso_b1, iso_flag, iso_pend;
     const uint16_t* table;  // single byte: 128 entries (nullptr = x-user-defined); Big5 / EUC-JP: the blob
 };
 
 SXD void ddec_reset(DDecoder& d, int enc, const uint16_t* table) {
     d.enc = enc; d.cp = 0; d.seen = d.needed = 0; d.lower = 0x80; d.upper = 0xBF;
     d.lead_byte = -1; d.lead_surrogate = 0; d.pending_bmp = false; d.dlead = 0; d.dflag = 0; d.gb2 = d.gb3 = 0; d.rq[0] = d.rq[1] = 0; d.rq_n = 0; d.table = table;
+    d.iso_set = d.iso_out = d.iso_mid = d.iso_b1 = d.iso_flag = d.iso_pend = 0;
 }
 
 SXD u32 dput_cp(u8* d, u32 c) {
@@ -160,7 +165,90 @@ SXD DStep ddec_utf16(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool l
 }
 
 constexpr int kEncReplacement = 70;   // == SX_ENC_REPLACEMENT
-SXD DStep ddec_single(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap) {
+constexpr int kEncIso2022Jp = 71;     // == SX_ENC_ISO_2022_JP
+
+// ISO-2022-JP (WHATWG "ISO-2022-JP decoder") as transitions over (selected set, where in a token we are):
+//   iso_set: 0 ASCII, 1 JIS X 0201 Roman, 2 half-width katakana, 3 JIS X 0208 (two bytes per character);
+//   iso_mid: 0 between tokens, 1 the first byte of a JIS X 0208 pair is in iso_b1, 2 ESC seen, 3 ESC and `$` / `(` (in iso_b1) seen.
+// An escape sequence that does not complete is an error of the ESC alone: the byte that broke it is read again, and a `$` / `(`
+// that was already consumed is decoded in front of the NEXT call's input (encoding_rs keeps it pending; its char then carries
+// the position of that call).  Two escape sequences without a character between them: the second one is an error (iso_flag).
+// The table is index jis0208 (the first kJisN words of the EUC-JP blob).  Never runs on the device: the set in force at a byte is
+// not derivable from a bounded look-back, so such a Mission is ONE sequential pass on the host (sx_stage_b.cpp).
+SXD DStep ddec_iso2022jp(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {
+    u32 i = 0, w = 0;
+    bool from_pend = d.iso_pend != 0;
+    for (;;) {
+        u8 b;
+        if (from_pend) { b = d.iso_pend; d.iso_pend = 0; }
+        else {
+            if (i >= n) {
+                if (!last || d.iso_mid == 0) return { RES_INPUT_EMPTY, i, w };
+                // the input ends inside a token
+                const u8 mid = d.iso_mid;
+                d.iso_mid = 0;
+                if (mid == 3) d.iso_pend = d.iso_b1;
+                if (mid >= 2) { d.iso_flag = 0; d.iso_set = d.iso_out; }
+                return { RES_MALFORMED, i, w };
+            }
+            if (cap - w < 3) return { RES_OUTPUT_FULL, i, w };
+            b = src[i++];
+        }
+        const bool was_pend = from_pend;
+        from_pend = false;
+        if (was_pend && cap - w < 3) { d.iso_pend = b; return { RES_OUTPUT_FULL, i, w }; }
+        switch (d.iso_mid) {
+        case 2:   // after ESC
+            if (b == 0x24 || b == 0x28) { d.iso_b1 = b; d.iso_mid = 3; continue; }
+            i--;  // not an escape sequence: the byte is read again as what it is in the set that was in force
+            d.iso_mid = 0; d.iso_flag = 0; d.iso_set = d.iso_out;
+            return { RES_MALFORMED, i, w };
+        case 3: { // after ESC `$` or ESC `(`
+            int set = -1;
+            if (d.iso_b1 == 0x28) set = b == 0x42 ? 0 : b == 0x4A ? 1 : b == 0x49 ? 2 : -1;
+            else if (b == 0x40 || b == 0x42) set = 3;
+            d.iso_mid = 0;
+            if (set >= 0) {
+                d.iso_set = d.iso_out = (u8)set;
+                const bool twice = d.iso_flag != 0;
+                d.iso_flag = 1;
+                if (twice) return { RES_MALFORMED, i, w };
+                continue;
+            }
+            i--;
+            d.iso_pend = d.iso_b1; d.iso_flag = 0; d.iso_set = d.iso_out;
+            return { RES_MALFORMED, i, w };
+        }
+        case 1: { // second byte of a JIS X 0208 pair
+            d.iso_mid = 0;
+            if (b == 0x1B) { d.iso_mid = 2; return { RES_MALFORMED, i, w }; }
+            u32 cp = 0;
+            if (b >= 0x21 && b <= 0x7E) cp = d.table[(u32)(d.iso_b1 - 0x21) * 94 + (b - 0x21)];
+            if (!cp) return { RES_MALFORMED, i, w };
+            w += dput_cp(dst + w, cp);
+            continue;
+        }
+        default: break;
+        }
+        if (b == 0x1B) { d.iso_mid = 2; continue; }   // (iso_out already is the set in force)
+        d.iso_flag = 0;
+        u32 cp = 0;
+        if (d.iso_set == 3) {
+            if (b >= 0x21 && b <= 0x7E) { d.iso_b1 = b; d.iso_mid = 1; continue; }
+        } else if (d.iso_set == 2) {
+            if (b >= 0x21 && b <= 0x5F) cp = 0xFF61u - 0x21u + b;
+        } else if (b < 0x80 && b != 0x0E && b != 0x0F) {
+            cp = b;
+            if (d.iso_set == 1) { if (b == 0x5C) cp = 0xA5; else if (b == 0x7E) cp = 0x203E; }
+            if (b == 0) { dst[w++] = 0; continue; }
+        }
+        if (!cp) return { RES_MALFORMED, i, w };
+        w += dput_cp(dst + w, cp);
+    }
+}
+
+SXD DStep ddec_single(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last = false) {
+    if (d.enc == kEncIso2022Jp) return ddec_iso2022jp(d, src, n, dst, cap, last);
     // WHATWG "replacement decoder": one error for the whole input and no character ever — nothing of it is observable
     // in the scan (no output, hence no finding, and no position anybody reads), so the input is just consumed
     if (d.enc == kEncReplacement) return { RES_INPUT_EMPTY, n, 0 };
@@ -376,7 +464,7 @@ SXD DStep ddecode(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last
     if (ENC == 3) return ddec_utf16<true>(d, src, n, dst, cap, last);
     if (ENC == 4) return ddec_big5(d, src, n, dst, cap, last);
     if (ENC == 5) return ddec_eucjp(d, src, n, dst, cap, last);
-    return ddec_single(d, src, n, dst, cap);
+    return ddec_single(d, src, n, dst, cap, last);
 }
 SXD DStep ddecode_any(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool last) {
     switch (enc_family((u32)d.enc)) {
@@ -398,7 +486,8 @@ SXD bool ddec_idle(const DDecoder& d) {
     return true;
 }
 SXD bool ddec_idle_any(const DDecoder& d) {
-    return d.needed == 0 && d.lead_byte < 0 && d.lead_surrogate == 0 && !d.pending_bmp && d.dlead == 0 && d.gb2 == 0 && d.rq_n == 0;
+    return d.needed == 0 && d.lead_byte < 0 && d.lead_surrogate == 0 && !d.pending_bmp && d.dlead == 0 && d.gb2 == 0 && d.rq_n == 0
+           && d.iso_mid == 0 && d.iso_pend == 0;
 }
 
 // Token grammar of the double-byte encodings, used to find a character boundary without context:

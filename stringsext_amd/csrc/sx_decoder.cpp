@@ -12,7 +12,7 @@ namespace sx {
 
 static_assert(SX_BIG5_N == kBig5N && SX_BIG5_P2_WORDS == kBig5P2Words && SX_JIS_N == kJisN, "table layout");
 static_assert(SX_ENC_BIG5 == kEncBig5 && SX_ENC_EUC_JP == kEncEucJp && SX_ENC_SHIFT_JIS == kEncShiftJis && SX_ENC_EUC_KR == kEncEucKr && SX_ENC_GB18030 == kEncGb18030 && SX_ENC_GBK == kEncGbk, "encoding ids");
-static_assert(SX_ENC_REPLACEMENT == kEncReplacement, "encoding ids");
+static_assert(SX_ENC_REPLACEMENT == kEncReplacement && SX_ENC_ISO_2022_JP == kEncIso2022Jp, "encoding ids");
 static_assert(SX_SJIS_N == kSjisN && SX_EUCKR_N == kEucKrN, "table layout");
 
 const uint16_t* single_byte_table(int enc) {
@@ -28,6 +28,7 @@ const uint16_t* decoder_table(int enc, size_t* n_words) {
     else if (enc == SX_ENC_SHIFT_JIS) { t = sx_sjis; n = sizeof sx_sjis / sizeof sx_sjis[0]; }
     else if (enc == SX_ENC_EUC_KR) { t = sx_euckr; n = sizeof sx_euckr / sizeof sx_euckr[0]; }
     else if (enc == SX_ENC_GB18030 || enc == SX_ENC_GBK) { t = sx_gb18030; n = sizeof sx_gb18030 / sizeof sx_gb18030[0]; }
+    else if (enc == SX_ENC_ISO_2022_JP) { t = sx_eucjp; n = kJisN; }   // index jis0208: the first half of the EUC-JP blob
     else if ((t = single_byte_table(enc)) != nullptr) n = 128;
     if (n_words) *n_words = n;
     return t;
@@ -51,6 +52,7 @@ const char* encoding_name(int enc) {
     case SX_ENC_GB18030: return "gb18030";
     case SX_ENC_GBK: return "GBK";
     case SX_ENC_REPLACEMENT: return "replacement";
+    case SX_ENC_ISO_2022_JP: return "ISO-2022-JP";
     default:
         if (enc >= SX_ENC_KOI8_R && enc < SX_ENC_KOI8_R + SX_N_SB_TABLES) return sx_sb_names[enc - SX_ENC_KOI8_R];
         return "?";

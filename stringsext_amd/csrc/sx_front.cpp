@@ -230,10 +230,7 @@ const Label kLabels[] = {
     { "gb_2312-80", SX_ENC_GBK }, { "gbk", SX_ENC_GBK }, { "iso-ir-58", SX_ENC_GBK }, { "x-gbk", SX_ENC_GBK }, { "gb18030", SX_ENC_GB18030 },
     { "csiso2022kr", SX_ENC_REPLACEMENT }, { "hz-gb-2312", SX_ENC_REPLACEMENT }, { "iso-2022-cn", SX_ENC_REPLACEMENT },
     { "iso-2022-cn-ext", SX_ENC_REPLACEMENT }, { "iso-2022-kr", SX_ENC_REPLACEMENT }, { "replacement", SX_ENC_REPLACEMENT },
-};
-// labels of the encodings encoding_rs has and this library does not (help.rs:54-96 lists their names)
-const char* const kOtherLabels[] = {
-    "iso-2022-jp", "csiso2022jp",
+    { "csiso2022jp", SX_ENC_ISO_2022_JP }, { "iso-2022-jp", SX_ENC_ISO_2022_JP },
 };
 int for_label(const std::string& raw) {
     size_t a = 0, b = raw.size();
@@ -243,8 +240,7 @@ int for_label(const std::string& raw) {
     std::string l = raw.substr(a, b - a);
     for (char& c : l) if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');
     for (const Label& k : kLabels) if (l == k.label) return k.enc;
-    for (const char* k : kOtherLabels) if (l == k) return -2;
-    return -1;
+    return -1;   // (every encoding of help.rs:54-96 is built in: -2, "known to the reference, not built in", no longer occurs)
 }
 
 void put_err(const Err& e, char* err, size_t cap) {
@@ -295,6 +291,7 @@ const char* sx_encoding_name(uint32_t encoding) {  // Encoding::name()
         case SX_ENC_GB18030: return "gb18030";
         case SX_ENC_GBK: return "GBK";
         case SX_ENC_REPLACEMENT: return "replacement";
+        case SX_ENC_ISO_2022_JP: return "ISO-2022-JP";
         case SX_ENC_X_MAC_CYRILLIC: return "x-mac-cyrillic";
         default: return nullptr;
     }
@@ -371,12 +368,6 @@ int sx_missions_from_flags(const sx_cli_flags* f, sx_mission* out, int cap, int*
         const int enc = for_label(name);
         if (enc == -1) {
             e.fail(scanner + "invalid input encoding name `" + name + "`, try flag `--list-encodings`.");
-            return bail(SX_E_INVALID);
-        }
-        if (enc == -2) {
-            e.fail(scanner + "encoding `" + name + "` is known to the reference but not built into this library "
-                             "(UTF-8, UTF-16LE/BE, ascii, x-user-defined, the 28 single-byte encodings, Big5, EUC-JP, Shift_JIS, EUC-KR, gb18030 / GBK and replacement are; "
-                             "ISO-2022-JP is not).");
             return bail(SX_E_INVALID);
         }
         m.encoding = (uint8_t)enc;

@@ -54,6 +54,9 @@ struct Mission {
     uint32_t long_run = 4;  // min(chars_min_nb, q): fewer chars can never yield a Finding
     bool is_utf16() const { return c.encoding == SX_ENC_UTF16LE || c.encoding == SX_ENC_UTF16BE; }
     bool is_dbcs() const { return c.encoding >= SX_ENC_BIG5 && c.encoding <= SX_ENC_GBK; }   // a pending lead byte is the decoder state
+    // the decoder's state at a byte is not derivable from the bytes near it (ISO-2022-JP: the set an escape sequence selected):
+    // no stage A, no device, no shards — FindingCollection::from over every window, in order, on the host
+    bool host_sequential() const { return c.encoding == SX_ENC_ISO_2022_JP; }
     const char* encoding_name() const;
 
     // device classifier for this mission
@@ -160,11 +163,13 @@ public:
     // pointer to bytes [off, off+n) of the chunk; n <= 4096; stays valid for the lifetime of
     // the view.  `hint` is a caller-owned cursor (callers walk the chunk in ascending order).
     virtual const uint8_t* span(uint64_t off, size_t n, size_t* hint) = 0;
+    virtual bool all_on_host() const { return false; }   // every byte is here: reading the chunk front to back costs nothing extra
 };
 class HostBytes : public ByteView {
 public:
     explicit HostBytes(const uint8_t* p) : p_(p) {}
     const uint8_t* span(uint64_t off, size_t, size_t*) override { return p_ + off; }
+    bool all_on_host() const override { return true; }
 private:
     const uint8_t* p_;
 };
@@ -228,7 +233,7 @@ void replay_part(const Mission& m, const ScannerState& entry, uint64_t consumed0
 // FindingCollection::from over every window of [lo, hi) (window starts; hi may be len), one after the other from the exact
 // state `st` at lo; on return `st` is the exact state at hi, whatever is pending there (no run list needed).
 void replay_exact_windows(const Mission& m, ScannerState& st, uint64_t consumed0, uint64_t stream0, ByteView& bytes, uint64_t len,
-                          int file_id, uint64_t lo, uint64_t hi, MissionFindings* out);
+                          int file_id, uint64_t lo, uint64_t hi, MissionFindings* out, bool is_last = false);
 void replay_stitch(const Mission& m, ScannerState& st, uint64_t consumed0, uint64_t stream0, ByteView& bytes,
                    uint64_t len, int file_id, bool is_last, const sx_run* runs, uint64_t n_runs,
                    std::vector<ReplayPart>& parts, MissionFindings* out, unsigned copy_threads,

@@ -128,7 +128,8 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
                 H[hb] = v;
             }
         }
-    } else if (enc == SX_ENC_REPLACEMENT) {
+    } else if (enc == SX_ENC_REPLACEMENT || enc == SX_ENC_ISO_2022_JP) {
+        // (ISO-2022-JP never reaches a scan kernel: Mission::host_sequential)
         // the replacement decoder emits nothing but one error: no byte is ever part of a character
         m->kind = kClsSingleByteRange;
         p.a_lo = 1; p.a_hi = 0; p.high_all = 0;

@@ -444,8 +444,8 @@ void replay_part(const Mission& m, const ScannerState& entry, uint64_t consumed0
 }
 
 void replay_exact_windows(const Mission& m, ScannerState& st, uint64_t consumed0, uint64_t stream0, ByteView& bytes, uint64_t len,
-                          int file_id, uint64_t lo, uint64_t hi, MissionFindings* out) {
-    RangeReplay rr(m, bytes, len, file_id, false, nullptr, 0, consumed0, stream0);
+                          int file_id, uint64_t lo, uint64_t hi, MissionFindings* out, bool is_last) {
+    RangeReplay rr(m, bytes, len, file_id, is_last, nullptr, 0, consumed0, stream0);
     (void)rr.run_exact(st, lo, hi < len ? hi : len, out);
 }
 

@@ -117,7 +117,7 @@ struct BufferScan {
     int launch(sx_ctx* ctx) {
         not_scanned.assign(ctx->missions.size(), 0);
         for (int k : order) {
-            if (skip_scan(ctx, (size_t)k)) { not_scanned[(size_t)k] = 1; continue; }
+            if (ctx->missions[(size_t)k].host_sequential() || skip_scan(ctx, (size_t)k)) { not_scanned[(size_t)k] = 1; continue; }
             int rc = stage_a_launch(ctx, { k }, d_bytes, len, { parity[(size_t)k] }, { minc[(size_t)k] }, slot);
             if (rc != SX_OK) return rc;
         }
@@ -142,7 +142,10 @@ struct BufferScan {
             std::vector<RunList> one;
             int rc = SX_OK;
             const bool unscanned = k < not_scanned.size() && not_scanned[k];
-            if (unscanned && wave_replay_wanted(ctx, job, k, len)) {   // no stage A: "as dense as the last buffer"
+            if (ctx->missions[k].host_sequential()) {   // no stage A at all: every window is replayed on the host (sx_stage_b.cpp)
+                one.assign(1, RunList{});
+                one[0].complete = true;
+            } else if (unscanned && wave_replay_wanted(ctx, job, k, len)) {   // no stage A: "as dense as the last buffer"
                 one.assign(1, RunList{});
                 one[0].n = len / 64; one[0].skipped = true; one[0].complete = true;
                 ctx->stats.bytes_scanned += len;
@@ -207,6 +210,7 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
     mission_order(ctx, &order);
     const uint64_t piece = piece_bytes(ctx, len);
     const uint64_t n_pieces = len ? (len + piece - 1) / piece : 1;
+    int entry_rc = SX_OK;   // (a failed read of the buffer's first bytes must not go unnoticed: the token grid would be wrong)
     auto make = [&](uint64_t p) {
         BufferScan b;
         const uint64_t off = p * piece;
@@ -220,7 +224,7 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
             uint32_t ep = (uint32_t)((stream0[k] + off) & 1);
             if (ctx->missions[k].is_dbcs()) {  // one piece only (piece_bytes): the carried decoder describes byte 0
                 uint32_t ep_replay = 0;
-                (void)entry_param(ctx, k, &ctx->states[k].decoder, b.host_bytes, b.d_bytes, b.len, 0, &ep, &ep_replay);
+                entry_rc = std::min(entry_rc, entry_param(ctx, k, &ctx->states[k].decoder, b.host_bytes, b.d_bytes, b.len, 0, &ep, &ep_replay));
                 ctx->missions[k].buf_entry_skip = ep_replay;
             }
             b.parity.push_back(ep);
@@ -231,6 +235,7 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
     ResultHolder res;
     std::vector<BufferScan> pieces;
     for (uint64_t p = 0; p < n_pieces; p++) pieces.push_back(make(p));
+    if (entry_rc != SX_OK) return entry_rc;
     int rc = SX_OK;
     uint64_t launched = 0;
     for (; launched < std::min<uint64_t>(2, n_pieces); launched++)
@@ -265,6 +270,12 @@ int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
     }
     const size_t nm = ctx->missions.size();
     const double t_begin = now_ms();
+    for (const Mission& m : ctx->missions)
+        if (m.host_sequential()) {
+            ctx->err = "an ISO-2022-JP mission cannot be sharded: the character set in force at a shard start depends on every escape "
+                       "sequence in front of it (its stage B is one sequential pass)";
+            return SX_E_INVALID;
+        }
     for (const Mission& m : ctx->missions)
         if (m.c.chars_min_nb == 0 && buf_off != 0) {
             ctx->err = "a mission with chars_min_nb 0 cannot be sharded: its state at a shard start cannot be derived from the bytes "

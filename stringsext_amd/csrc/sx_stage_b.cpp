@@ -13,7 +13,7 @@ static inline uint64_t win_start_h(uint64_t p, size_t W) {
 }
 
 bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs) {
-    if (!job.d_bytes || ctx->host_only || job.is_last) return false;
+    if (!job.d_bytes || ctx->host_only || job.is_last || ctx->missions[k].host_sequential()) return false;
     if (ctx->opt.flags & SX_OPT_HOST_REPLAY) return false;
     if (ctx->missions[k].q > 64) return false;
     // -n 0: SplitStr's exit 4 (helper.rs:317) then fires on a rejected char with nothing collected, which ends the
@@ -589,6 +589,36 @@ static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFi
     return SX_OK;
 }
 
+// A Mission whose decoder state cannot be derived from the bytes near a position (ISO-2022-JP): FindingCollection::from over every
+// window of the buffer, in order, from the carried state — no stage A, no regions.  Device-resident input comes to the host in pieces.
+static int host_sequential_mission(sx_ctx* ctx, size_t k, ByteView& bytes, const ReplayJob& job, MissionFindings* out) {
+    const Mission& m = ctx->missions[k];
+    ScannerState st = ctx->states[k];
+    if (bytes.all_on_host() || !job.d_bytes) {
+        replay_exact_windows(m, st, job.consumed0[k], job.stream0[k], bytes, job.len, job.file_id, 0, job.len, out, job.is_last);
+    } else {
+        struct Piece : ByteView {
+            std::vector<uint8_t> buf; uint64_t base = 0;
+            const uint8_t* span(uint64_t off, size_t, size_t*) override { return buf.data() + (off - base); }
+        } piece;
+        const uint64_t step = 64ull << 20;
+        for (uint64_t at = 0; at < job.len; at += step) {
+            const uint64_t n = std::min(step, job.len - at);
+            piece.buf.resize(n); piece.base = at;
+            HIP_TRY(ctx, hipMemcpy(piece.buf.data(), job.d_bytes + at, n, hipMemcpyDeviceToHost));
+            replay_exact_windows(m, st, job.consumed0[k], job.stream0[k], piece, job.len, job.file_id, at, at + n, out, job.is_last);
+        }
+    }
+    out->replay_bytes += job.len;
+    if (job.slice_base) for (auto& f : out->v) f.slice_index += job.slice_base;
+    if (job.commit_state) {
+        st.consumed_bytes = job.consumed0[k] + job.len;
+        st.stream_bytes = job.stream0[k] + job.len;
+        ctx->states[k] = st;
+    }
+    return SX_OK;
+}
+
 // Stage B for all missions: every (mission, part) pair is one task for a small thread pool;
 // part 0 of a mission starts from its entry state, the others speculate, and the per-mission
 // stitch verifies/repairs them serially.
@@ -603,7 +633,7 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
     std::vector<char> on_device(nm, 0);
     uint64_t host_runs = 0;
     for (size_t k = 0; k < nm; k++)
-        on_device[k] = (pre && pre->done[k]) ? 2 : (device_replay_wanted(ctx, job, k, runs[k].size()) ? 1 : 0);
+        on_device[k] = (pre && pre->done[k]) ? 2 : ctx->missions[k].host_sequential() ? 3 : (device_replay_wanted(ctx, job, k, runs[k].size()) ? 1 : 0);
     for (size_t k = 0; k < nm; k++) {
         if (on_device[k]) continue;
         HIP_TRY(ctx, runs[k].wait());
@@ -641,7 +671,11 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
     std::vector<uint64_t> ends(nm, 0);
     for (size_t k = 0; k < nm; k++) {
         if (on_device[k] == 2) { per[k] = std::move(pre->per[k]); pre->per[k].ext = {}; ends[k] = pre->ends[k]; }
-        else if (on_device[k]) {
+        else if (on_device[k] == 3) {
+            int rc = host_sequential_mission(ctx, k, bytes, job, &per[k]);
+            if (rc != SX_OK) return rc;
+            ends[k] = job.len;
+        } else if (on_device[k]) {
             int rc = device_replay_mission(ctx, k, bytes, job, runs[k], &per[k], &ends[k], 0);
             if (rc != SX_OK) return rc;
         }
@@ -710,7 +744,7 @@ int download_for_replay(sx_ctx* ctx, const uint8_t* d_bytes, uint64_t len,
         rg.emplace_back(0, std::min<uint64_t>(len, 64 * 1024));
         if (len > 64 * 1024) rg.emplace_back(len - 64 * 1024, len);
         for (size_t k = 0; k < nm; k++) {
-            if ((skip && (*skip)[k]) || device_replay_wanted(ctx, job, k, runs[k].size())) continue;  // stage B of this mission runs on the device
+            if ((skip && (*skip)[k]) || ctx->missions[k].host_sequential() || device_replay_wanted(ctx, job, k, runs[k].size())) continue;  // stage B of this mission runs on the device (or fetches its bytes itself)
             HIP_TRY(ctx, runs[k].wait());
             const size_t before = rg.size();
             // same partition count as replay_all will use

@@ -90,7 +90,39 @@ GB = [
     ("pending bytes at the end of the stream", [("8130", True, [("M", 2, 0), ("E", 0, 0)])]),
 ]
 
-VECTORS = ([(n, "gb18030", c) for n, c in GB] + [(n, "gbk", c) for n, c in GB]
+# ISO-2022-JP (WHATWG "ISO-2022-JP decoder"; round 3).  ESC ( B = ASCII, ESC ( J = JIS X 0201 Roman, ESC ( I = half-width katakana,
+# ESC $ @ / ESC $ B = JIS X 0208 (two bytes per character; 0x2422 = U+3042).  What a streaming decoder adds to the algorithm: a byte
+# "restored to the stream" is read again by the next call (`read` stops in front of it); the `$` / `(` of an escape sequence that
+# fails at its third byte was already consumed — its character is the FIRST OUTPUT of the call after the error (as the crate's
+# pending_prepended; like pending_bmp in UTF-16).  Unpinned like every legacy decoder.
+ISO2022JP = [
+    ("plain ASCII", [("4142", False, [("E", 2, 2)])]),
+    ("to JIS X 0208 and back", [("1b244224221b284241", False, [("E", 9, 4)])]),
+    ("Roman: 5C is the yen sign, 7E the overline", [("1b284a5c7e41", False, [("E", 6, 6)])]),
+    ("katakana", [("1b2849215f", False, [("E", 5, 6)])]),
+    ("katakana: 0x60 is an error, the set stays", [("1b28496041", False, [("M", 4, 0), ("E", 1, 3)])]),
+    ("shift out is an error in ASCII", [("0e41", False, [("M", 1, 0), ("E", 1, 1)])]),
+    ("a byte >= 0x80 is an error", [("a441", False, [("M", 1, 0), ("E", 1, 1)])]),
+    ("two escape sequences in a row: the second is the error", [("1b28421b284a7e", False, [("M", 6, 0), ("E", 1, 3)])]),
+    ("ESC and no escape sequence: the ESC is the error, the byte is read again", [("1b41", False, [("M", 1, 0), ("E", 1, 1)])]),
+    ("ESC ( and a wrong third byte: that byte is read again, the ( comes out in front of it",
+     [("1b2841", False, [("M", 2, 0), ("E", 1, 2)])]),
+    ("ESC $ and a wrong third byte", [("1b2441", False, [("M", 2, 0), ("E", 1, 2)])]),
+    ("an escape sequence over three calls", [("1b", False, [("E", 1, 0)]), ("24", False, [("E", 1, 0)]), ("42", False, [("E", 1, 0)]),
+                                             ("2422", False, [("E", 2, 3)])]),
+    ("a broken one over three calls: nothing of the last call is read, the ( belongs to the call after",
+     [("1b", False, [("E", 1, 0)]), ("28", False, [("E", 1, 0)]), ("41", False, [("M", 0, 0), ("E", 1, 2)])]),
+    ("ESC pending, then no escape sequence", [("1b", False, [("E", 1, 0)]), ("41", False, [("M", 0, 0), ("E", 1, 1)])]),
+    ("ESC instead of a second byte: the first byte is the error, the escape sequence goes on",
+     [("1b2442241b284241", False, [("M", 5, 0), ("E", 3, 1)])]),
+    ("a second byte out of range: both consumed, the set stays", [("1b2442242041", False, [("M", 5, 0), ("E", 1, 0)])]),
+    ("a character over two calls", [("1b244224", False, [("E", 4, 0)]), ("22", False, [("E", 1, 3)])]),
+    ("first byte pending at the end of the stream", [("1b244224", True, [("M", 4, 0), ("E", 0, 0)])]),
+    ("ESC ( at the end of the stream: the ( is still decoded", [("1b28", True, [("M", 2, 0), ("E", 0, 1)])]),
+    ("ESC at the end of the stream", [("1b", True, [("M", 1, 0), ("E", 0, 0)])]),
+]
+
+VECTORS = ([(n, "gb18030", c) for n, c in GB] + [(n, "iso-2022-jp", c) for n, c in ISO2022JP] + [(n, "gbk", c) for n, c in GB]
            + [(n, "utf-16le", c) for n, c in UTF16LE]
            + [(n, "utf-16be", [(be(x) if len(x) % 4 == 0 else None, last, steps) for x, last, steps in c]) for n, c in UTF16LE
               if all(len(x) % 4 == 0 for x, _, _ in c)]

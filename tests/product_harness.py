@@ -51,6 +51,8 @@ def oracle_runs_for_chunk(mdicts, chunk, stream_bytes, before=b""):
                 r -= 1
             shift = len(before) - r
             out.append([(max(0, a - shift), b - shift, c) for a, b, c in sxo.runs(m, before[r:] + chunk, min_chars=long_run) if b > shift])
+        elif m["encoding"] == 71:
+            out.append([])   # ISO-2022-JP: no stage A (one sequential pass on the host, whatever the runs say)
         elif m["encoding"] in (64, 65, 66, 67):
             skip = dbcs_hangover(m["encoding"], before, chunk)
             out.append([(a + skip, b + skip, c) for a, b, c in sxo.runs(m, chunk[skip:], min_chars=long_run)])

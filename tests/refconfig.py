@@ -54,7 +54,8 @@ ENC_IDS = {"x-user-defined": 0, "utf-8": 1, "utf-16le": 2, "utf-16be": 3, "koi8-
            "iso-8859-8-i": 28, "iso-8859-10": 29, "iso-8859-13": 30, "iso-8859-14": 31, "iso-8859-16": 32,
            "koi8-u": 33, "macintosh": 34, "windows-874": 35, "windows-1250": 36, "windows-1253": 37,
            "windows-1254": 38, "windows-1255": 39, "windows-1256": 40, "windows-1257": 41, "windows-1258": 42,
-           "x-mac-cyrillic": 43, "big5": 64, "euc-jp": 65, "shift_jis": 66, "euc-kr": 67, "gb18030": 68, "gbk": 69, "replacement": 70}
+           "x-mac-cyrillic": 43, "big5": 64, "euc-jp": 65, "shift_jis": 66, "euc-kr": 67, "gb18030": 68, "gbk": 69, "replacement": 70,
+           "iso-2022-jp": 71}
 
 
 def _parse_int(s):

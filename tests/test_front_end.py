@@ -69,12 +69,11 @@ def test_alias_prefix_quirks_and_labels():
         assert sx.encoding_name(enc) == name and rc.ENC_IDS[name.lower()] == enc, label
     with pytest.raises(sx.SxError, match="invalid input encoding name"):
         sx.missions_from_flags(encodings=["utf-9"])
-    with pytest.raises(sx.SxError, match="not built into this library"):
-        sx.missions_from_flags(encodings=["iso-2022-jp"])
     # the legacy multi-byte encodings that are built in (help.rs:56-57; mission.rs:681)
     for label, name in [("big5", "Big5"), ("Big5-HKSCS", "Big5"), ("x-x-big5", "Big5"), ("EUC-JP", "EUC-JP"), ("x-euc-jp", "EUC-JP"),
                         ("sjis", "Shift_JIS"), ("windows-31j", "Shift_JIS"), ("MS_Kanji", "Shift_JIS"), ("korean", "EUC-KR"),
                         ("windows-949", "EUC-KR"), ("ks_c_5601-1987", "EUC-KR"), ("iso-2022-kr", "replacement"), ("hz-gb-2312", "replacement"),
+                        ("iso-2022-jp", "ISO-2022-JP"), ("csISO2022JP", "ISO-2022-JP"),
                         ("gb18030", "gb18030"), ("GBK", "GBK"), ("gb2312", "GBK"), ("chinese", "GBK"), ("x-gbk", "GBK"), ("iso-ir-58", "GBK")]:
         enc = sx.missions_from_flags(encodings=[label])[0]["encoding"]
         assert sx.encoding_name(enc) == name and rc.ENC_IDS[name.lower()] == enc, label

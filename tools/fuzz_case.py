@@ -6,7 +6,7 @@ import refconfig as rc
 from test_host_logic import soup, synth
 from test_gpu_parity import dense
 
-ENCS = ["utf-8", "ascii", "utf-16le", "utf-16be", "koi8-r", "ibm866", "windows-1252", "iso-8859-5", "x-user-defined", "big5", "euc-jp", "shift_jis", "euc-kr", "gbk", "gb18030"]
+ENCS = ["utf-8", "ascii", "utf-16le", "utf-16be", "koi8-r", "ibm866", "windows-1252", "iso-8859-5", "x-user-defined", "big5", "euc-jp", "shift_jis", "euc-kr", "gbk", "gb18030", "iso-2022-jp"]
 ENCS_MORE = ["iso-8859-7", "windows-1255", "windows-874", "koi8-u", "macintosh", "iso-8859-6", "windows-1257", "x-mac-cyrillic"]
 AFS = [None, "All", "All-Ctrl", "All-Ctrl+Wsp", "None", "Wsp", "0x7ffffffe000000007ffffffe00000000"]
 UBFS = [None, "African", "All", "Common", "Cyrillic", "Latin", "Asian", "Uncommon", "None", "Hebrew", "Cjk"]
@@ -49,7 +49,9 @@ def make(case_seed):
     elif kind == "text": files = [("The quick brown fox — Ünïcödé ßtring, доброе утро, שלום עולם. " * (size // 60 + 1)).encode(r.choice(["utf-8", "utf-16-le", "koi8-r"]), errors="replace")[:size]]
     elif kind == "cjk":
         from test_dbcs import soup as dbcs_soup
-        files = [dbcs_soup(r.choice(["big5", "euc-jp", "shift_jis", "euc-kr", "gbk", "gb18030"]), r, min(size, 300_000))]
+        from test_iso2022jp import soup as iso_soup
+        which = r.choice(["big5", "euc-jp", "shift_jis", "euc-kr", "gbk", "gb18030", "iso-2022-jp"])
+        files = [iso_soup(r, min(size, 300_000)) if which == "iso-2022-jp" else dbcs_soup(which, r, min(size, 300_000))]
     else: files = [synth(r, r.randrange(1, 20000), 1 / 100) for _ in range(r.randrange(2, 6))] + [b""]
     case = dict(kw=kw, missions=ms, kind=kind, size=size, files=files, chunk=r.choice([None, None, 4096, 16384, 65536]),
                 flush=r.random() < 0.3, sub=r.choice([0, 0, 1024, 4096]), replay=r.choice([None, None, True, False]),
