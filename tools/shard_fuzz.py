@@ -23,7 +23,7 @@ while time.time() - t0 < budget:
     if len(data) < 3 * 4096:
         continue
     ms = c["missions"]
-    if any(m["chars_min_nb"] == 0 for m in ms):
+    if any(m["chars_min_nb"] == 0 or m["encoding"] == 71 for m in ms):   # (71: ISO-2022-JP)
         continue   # refused by sx_scan_shard* (its stage B is one sequential pass)
     n += 1
     world = rng.choice([2, 3, 5])
