@@ -316,7 +316,6 @@ SXD DStep ddec_gb18030(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool
     const int q0 = d.rq_n;
     const u8 q[2] = { d.rq[0], d.rq[1] };
     int j = -q0;
-    const int j0 = j;
     u32 w = 0;
     d.rq_n = 0;
     // leave with result r: positions below 0 that were not consumed stay queued
@@ -324,14 +323,15 @@ SXD DStep ddec_gb18030(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool
         if (j < 0) { d.rq_n = (u8)(-j); for (int t = 0; t < -j; t++) d.rq[t] = q[q0 + j + t]; j = 0; }
         return { r, (u32)j, w };
     };
-    // give back the last k bytes of the stream (the current byte and the pending ones before it); pre = the pending ones
-    auto prepend = [&](int k, u8 p1, u8 p2) -> bool {   // true: bytes of an earlier call were queued (then j >= 0)
-        const int c = (j - j0) < k ? (j - j0) : k;
-        j -= c;
-        if (k - c <= 0) return false;
+    // "restore the last k bytes to the stream" (the current byte and the pending ones before it; pre = the pending ones): the
+    // current byte — always one of src — is read again by the next call; the pending ones stay consumed and are queued for it,
+    // whichever call read them (encoding_rs keeps the digit / the third byte pending instead of un-reading them)
+    auto prepend = [&](int k, u8 p1, u8 p2) -> bool {   // true: bytes were queued
+        j -= 1;
+        if (k < 2) return false;
         const u8 pre[2] = { p1, p2 };
-        d.rq_n = (u8)(k - c);
-        for (int t = 0; t < k - c; t++) d.rq[t] = pre[(k == 3 ? 0 : 1) + t];
+        d.rq_n = (u8)(k - 1);
+        for (int t = 0; t < k - 1; t++) d.rq[t] = pre[(k == 3 ? 0 : 1) + t];
         return true;
     };
     for (;;) {

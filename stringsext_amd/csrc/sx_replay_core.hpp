@@ -128,12 +128,9 @@ SXD u64 call_start_before(const ReplayParams& P, u64 p, u64 rs, NearBytes nr = N
             const u32 n = (u32)(rs - at < 12 ? rs - at : 12);
             const DStep r = ddecode<ENC>(dd, P.data + at, n, sink, sizeof sink, false);
             at += r.read;
-            if (r.result == RES_MALFORMED) {
-                // (gb18030: bytes the error gave back that lie in front of this piece — the pieces are this walk's own, the
-                // reference's call ends where the reading resumes)
-                at -= dd.rq_n; dd.rq_n = 0;
-                vs = at;
-            }
+            // a call starts here with an idle decoder (gb18030: not while bytes of a broken four-byte token wait in the queue —
+            // their characters belong to the call that starts here, whose position this is: an earlier start stays the answer)
+            if (r.result == RES_MALFORMED && dd.rq_n == 0) vs = at;
         }
         return vs;
     }

@@ -24,6 +24,13 @@ int sx_scan_sharded(sx_ctx* ctx, int rank, int world, uint64_t file_len, uint64_
                     sx_allgather_fn allgather, void* allgather_user, sx_result** out, uint64_t* counts, uint64_t* overflow) {
     if (!ctx || !get_buffer || !allgather || !out || world < 1 || rank < 0 || rank >= world) return SX_E_INVALID;
     const size_t nm = ctx->missions.size();
+    // What no rank can do is refused by EVERY rank, before anybody waits for anybody (shard_common would refuse it only on the
+    // ranks whose buffer does not start the file: rank 0 would then wait in the all-gather for ever — ADVICE, round 2).
+    if (world > 1)
+        for (const Mission& m : ctx->missions) {
+            if (m.host_sequential()) { ctx->err = "an ISO-2022-JP mission cannot be sharded (its stage B is one sequential pass)"; return SX_E_INVALID; }
+            if (m.c.chars_min_nb == 0) { ctx->err = "a mission with chars_min_nb 0 cannot be sharded (its stage B is one sequential pass)"; return SX_E_INVALID; }
+        }
     uint64_t own_lo, own_hi;
     sx_shard_bounds(file_len, world, rank, &own_lo, &own_hi);
     if (halo == 0) halo = 1u << 20;
@@ -71,17 +78,27 @@ int sx_scan_sharded(sx_ctx* ctx, int rank, int world, uint64_t file_len, uint64_
     };
     // first attempt: everybody assumes the previous rank stops at the shard boundary
     int rc = attempt_until_it_fits(nullptr, 0);
-    if (rc != SX_OK) { if (res) sx_result_free(res); return rc; }
 
-    // Where did everybody stop?  One all-gather of (start used, end reached) per mission + the finding count; rank k
-    // repeats its replay if rank k-1 ran past the point rank k started from (a region across the shard boundary).
+    // Where did everybody stop?  One all-gather of (start used, end reached) per mission + the finding count + this rank's status;
+    // rank k repeats its replay if rank k-1 ran past the point rank k started from (a region across the shard boundary).
     // Every rank evaluates the same table, so all agree on who repeats; a repeat can move that rank's own end: loop.
-    const size_t row = 2 * nm + 1;
+    // A rank whose own work failed (no memory, a HIP error, its buffer callback) still joins the exchange, with its error code in
+    // the row: every rank then leaves with an error in the same round, and nobody waits for a rank that is gone.
+    const size_t row = 2 * nm + 2;
     std::vector<uint64_t> mine(row), table((size_t)world * row);
     for (;;) {
         for (size_t m = 0; m < nm; m++) { mine[m] = start[m]; mine[nm + m] = ends[m]; }
-        mine[2 * nm] = sx_result_count(res);
-        if (allgather(allgather_user, mine.data(), row * 8, table.data()) != 0) { ctx->err = "the all-gather callback failed"; sx_result_free(res); return SX_E_INVALID; }
+        mine[2 * nm] = res ? sx_result_count(res) : 0;
+        mine[2 * nm + 1] = (uint64_t)(int64_t)rc;
+        if (allgather(allgather_user, mine.data(), row * 8, table.data()) != 0) { ctx->err = "the all-gather callback failed"; if (res) sx_result_free(res); return SX_E_INVALID; }
+        for (int k = 0; k < world; k++) {
+            const int krc = (int)(int64_t)table[(size_t)k * row + 2 * nm + 1];
+            if (krc == SX_OK) continue;
+            if (res) sx_result_free(res);
+            if (rc != SX_OK) return rc;   // this rank's own failure: its message stands
+            ctx->err = "rank " + std::to_string(k) + " of the sharded scan failed (error " + std::to_string(krc) + "): nothing of this file's scan can be used";
+            return SX_E_STATE;
+        }
         std::vector<char> redo((size_t)world, 0);
         bool any = false;
         for (int k = 1; k < world; k++) {
@@ -98,9 +115,8 @@ int sx_scan_sharded(sx_ctx* ctx, int rank, int world, uint64_t file_len, uint64_
                 prev_end[m] = table[(size_t)(rank - 1) * row + nm + m];
                 start[m] = std::max(std::max(own_lo, prev_end[m]), start[m]);
             }
-            rc = attempt_until_it_fits(start.data(), 1);
-            if (rc != SX_OK) { if (res) sx_result_free(res); return rc; }
-            for (size_t m = 0; m < nm; m++) ends[m] = std::max(ends[m], prev_end[m]);
+            rc = attempt_until_it_fits(start.data(), 1);   // (a failure travels in the next round's row)
+            if (rc == SX_OK) for (size_t m = 0; m < nm; m++) ends[m] = std::max(ends[m], prev_end[m]);
         }
     }
     // A region that crosses the shard boundary is finished by the rank it began on: the tail of rank k's findings can
@@ -122,6 +138,41 @@ int sx_scan_sharded(sx_ctx* ctx, int rank, int world, uint64_t file_len, uint64_
     for (int k = 0; k < world; k++) {
         if (counts) counts[k] = table[(size_t)k * row + 2 * nm];
         if (overflow) overflow[k] = overs[(size_t)k];
+    }
+    // The state at the file's end — decoder, leftover, cut flag: what the reference carries into the next file (src/main.rs:153-168,
+    // src/input.rs:116-132: one ScannerState per Mission for the whole stream) — is known to the LAST rank only (its range ends the
+    // file: shard_common commits it).  It goes to every rank, so that the next file's first shard (rank 0, buffer offset 0) starts
+    // from it: a multi-file stream scanned file by file with sx_scan_sharded gives what one process would.
+    if (world > 1) {
+        std::vector<size_t> off(nm + 1, 0);
+        for (size_t m = 0; m < nm; m++) off[m + 1] = off[m] + ((sizeof(DDecoder) + 24 + 4 * ctx->missions[m].q + 8 + 7) & ~(size_t)7);
+        std::vector<uint8_t> blob(off[nm], 0), all((size_t)world * off[nm], 0);
+        for (size_t m = 0; m < nm; m++) {
+            uint8_t* b = blob.data() + off[m];
+            ScannerState& st = ctx->states[m];
+            DDecoder dd = st.decoder.raw();
+            dd.table = nullptr;   // (a pointer of this process: the receiver puts its own back)
+            memcpy(b, &dd, sizeof dd);
+            uint64_t head[3] = { st.last_run_str_was_printed_and_is_maybe_cut_str ? 1ull : 0ull, st.last_scan_run_leftover.size(), st.consumed_bytes };
+            memcpy(b + sizeof dd, head, sizeof head);
+            memcpy(b + sizeof dd + sizeof head, st.last_scan_run_leftover.data(), std::min<size_t>(st.last_scan_run_leftover.size(), 4 * ctx->missions[m].q + 8));
+        }
+        if (allgather(allgather_user, blob.data(), blob.size(), all.data()) != 0) { ctx->err = "the all-gather callback failed"; sx_result_free(res); return SX_E_INVALID; }
+        const uint8_t* last = all.data() + (size_t)(world - 1) * off[nm];
+        for (size_t m = 0; m < nm; m++) {
+            const uint8_t* b = last + off[m];
+            ScannerState& st = ctx->states[m];
+            DDecoder dd;
+            memcpy(&dd, b, sizeof dd);
+            dd.table = st.decoder.raw().table;
+            st.decoder.raw() = dd;
+            uint64_t head[3];
+            memcpy(head, b + sizeof dd, sizeof head);
+            st.last_run_str_was_printed_and_is_maybe_cut_str = head[0] != 0;
+            st.last_scan_run_leftover.assign((const char*)(b + sizeof dd + sizeof head), (size_t)std::min<uint64_t>(head[1], 4 * ctx->missions[m].q + 8));
+            st.consumed_bytes = head[2];
+            st.stream_bytes = file_stream_off + file_len;
+        }
     }
     *out = res;
     return SX_OK;

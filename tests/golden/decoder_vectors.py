@@ -82,8 +82,11 @@ GB = [
     ("0xFF is an error of its own", [("ff41", False, [("M", 1, 0), ("E", 1, 1)])]),
     ("lead + ASCII byte that is no trail: the byte is read again", [("a17f", False, [("M", 1, 0), ("E", 1, 1)])]),
     ("lead + 0xFF: both consumed", [("a1ff", False, [("M", 2, 0), ("E", 0, 0)])]),
-    ("lead digit, then no lead: the digit and that byte are read again", [("81307841", False, [("M", 1, 0), ("E", 3, 3)])]),
-    ("lead digit lead, then no digit: all three are read again", [("81308178", False, [("M", 1, 0), ("E", 3, 4)])]),   # '0' + U+4E41
+    # (round 3, ADVICE: the digit / the third byte stay consumed — the crate keeps them pending — and are decoded in front of
+    # the next call's input; only the byte that broke the token is read again)
+    ("lead digit, then no lead: that byte is read again, the digit comes out in front of it", [("81307841", False, [("M", 2, 0), ("E", 2, 3)])]),
+    ("lead digit lead, then no digit: that byte is read again, digit and third byte are decoded in front of it",
+     [("81308178", False, [("M", 3, 0), ("E", 1, 4)])]),   # '0' + U+4E41
     ("pointer between the BMP ranges and the astral planes: error, four bytes consumed", [("8431a530", False, [("M", 4, 0), ("E", 0, 0)])]),
     ("the token over three calls, then the error: what earlier calls consumed is decoded in front of the next call",
      [("81", False, [("E", 1, 0)]), ("3081", False, [("E", 2, 0)]), ("78", False, [("M", 0, 0), ("E", 1, 4)])]),

@@ -142,3 +142,127 @@ def test_sharded_scan_equals_sequential(world, kind, flags, halo, gather):
         p.join(timeout=120)
     assert res[0] == "ok", res[1]
     assert res[1], f"sharded != sequential: {res[2]} vs {res[3]} findings, first diff {res[4]}"
+
+
+# ---- a stream of several files, each sharded: the state at a file's end travels to the next file's first shard ----
+def oracle_findings_files(mdicts, files):
+    """the reference loop over a stream of files: one ScannerState per Mission for the whole stream (src/main.rs:150-168), the
+    4 KiB grid restarting per file (src/input.rs:121-123)"""
+    scs = [sxo.Scanner(m) for m in mdicts]
+    out = []
+    for fi, data in enumerate(files):
+        rows = []
+        for si, off in enumerate(range(0, len(data), 4096)):
+            per = []
+            for mi, sc in enumerate(scs):
+                per += [(f["position"], mi, i, f) for i, f in enumerate(sc.scan(data[off:off + 4096], file_id=fi + 1))]
+            per.sort(key=lambda t: (t[0], t[1], t[2]))
+            rows += [(f["position"], f["precision"], f["s"], f["completes"], mi, si) for _, mi, _, f in per]
+        out.append(rows)
+    return out
+
+
+def stream_files(seed):
+    from test_host_logic import synth
+    rng = random.Random(seed)
+    n = 600_000
+    a = bytearray(synth(rng, n + 1, 1 / 300))                      # odd length: the UTF-16 unit grid of the NEXT file starts at an odd byte
+    text16 = "Բարեւ աշխարհ, שלום עולם, مرحبا بالعالم".encode("utf-16-le")
+    a[-25:] = text16[:25]                                          # ... and a unit is cut by the file boundary
+    b = bytearray(synth(rng, n, 1 / 300))
+    b[:len(text16) - 25] = text16[25:]
+    line = b"a line of text that is much longer than the sixty-four chars one output line may hold, so that it is cut and continued, "
+    b[-70:] = line[:70]                                            # a string across the file boundary: its rest is a `+` line of the next file
+    c = bytearray(synth(rng, n // 2 + 77, 1 / 300))
+    c[:len(line) - 70] = line[70:]
+    return [bytes(a), bytes(b), bytes(c)]
+
+
+def _stream_worker(rank, world, port, flags, halo, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import stringsext_amd as sx
+        from stringsext_amd import sharded
+        from product_harness import oracle_runs_for_chunk
+        files = stream_files(99)
+        ms = rc.missions(**flags)
+        sc = sx.Scanner(ms, device=sx.SX_HOST_ONLY)
+        key = lambda f: (f["position"], f["precision"], f["s"], f["completes"], f["mission_id"], f["slice_index"])
+        got, stream_off = [], 0
+        for fi, data in enumerate(files):
+            def runs(buf, off, data=data, stream_off=stream_off):
+                return oracle_runs_for_chunk(ms, buf, stream_off + off, data[max(0, off - 4096):off])
+            gathered, res = sharded.scan_sharded(sc, lambda lo, hi, data=data: data[lo:hi], len(data), file_id=fi + 1,
+                                                 file_stream_off=stream_off, halo=halo, device="cpu", runs_for_buffer=runs, gather=True)
+            if rank == 0:
+                parts = [sharded.decode_findings(fb, ab) for fb, ab in gathered]
+                got.append([key(f) for f in sharded.splice_order(parts, len(data))])
+            stream_off += len(data)
+        if rank == 0:
+            want = oracle_findings_files(ms, files)
+            q.put(("ok", got == want, [len(g) for g in got], [len(w) for w in want],
+                   next(((fi, a, b) for fi, (g, w) in enumerate(zip(got, want)) for a, b in zip(g, w) if a != b), None)))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_stream_of_files_equals_sequential(world):
+    """three files; the first ends in the middle of a UTF-16 unit (and has an odd length), the second ends in the middle of a
+    line that the third continues: rank 0 of the next file must start from the LAST rank's state of the file before"""
+    flags = dict(encodings=["utf-16le", "ascii", "utf-8"], chars_min="6", unicode_block_filter="African")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, flags, 1 << 14, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+    assert res[0] == "ok", res[1]
+    assert res[1], f"sharded stream != sequential: {res[2]} vs {res[3]} findings per file, first diff {res[4]}"
+
+
+def _failing_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import stringsext_amd as sx
+        from stringsext_amd import sharded
+        data = make_data("planted", 1234)
+        ms = rc.missions(encodings=["utf-8"], chars_min="6")
+        sc = sx.Scanner(ms, device=sx.SX_HOST_ONLY)
+
+        def runs(buf, off):
+            if rank == 1:
+                raise RuntimeError("this rank's stage A fails")   # (the library sees a failed callback)
+            from product_harness import oracle_runs_for_chunk
+            return oracle_runs_for_chunk(ms, buf, off)
+        try:
+            sharded.scan_sharded(sc, lambda lo, hi: data[lo:hi], len(data), file_id=1, halo=1 << 14, device="cpu", runs_for_buffer=runs)
+            q.put((rank, "no error"))
+        except Exception as e:
+            q.put((rank, type(e).__name__ + ": " + str(e)[:120]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_fails_every_rank_instead_of_hanging_them():
+    """a rank that failed used to leave before the all-gather and the others waited for ever"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all("no error" not in v for v in got.values()), got
+    assert "rank 1" in got[0] and "rank 1" in got[2], got
