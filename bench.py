@@ -28,6 +28,12 @@ WORKLOADS = {
     "c3": dict(flags=dict(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10",
                           unicode_block_filter="African"), gib=64.0,
                name="C3(i): -e utf-8 -e utf-16le -e utf-16be -n 10 -u African -t x, synthetic background"),
+    # BASELINE.json configs[3]: the same three Missions on a 256 GiB image, byte-range sharded over 8 GPUs = 32 GiB per rank
+    # (`--gpus 8 --workload c4` is the stated configuration; with fewer ranks it is the same per-rank share of a smaller image)
+    "c4": dict(flags=dict(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10",
+                          unicode_block_filter="African"), gib=32.0,
+               name="C4: -e utf-8 -e utf-16le -e utf-16be -n 10 -u African -t x, synthetic background, 32 GiB per rank (256 GiB over 8 ranks), "
+                    "byte-range shards + halo, Finding buffers gathered to rank 0"),
     # BASELINE.json configs[0] at a GPU-sized length (the text-dense extreme: ~11.8 k findings per MiB)
     "c1": dict(flags=dict(encodings=["ascii"], chars_min="4"), gib=1.0, kernels="SingleByteRange",
                name="C1-like: -e ascii -n 4 -t x, synthetic background (dense: every 85th byte starts a finding)"),

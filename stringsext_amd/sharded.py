@@ -56,6 +56,7 @@ def splice(scanner, gathered, file_len):
 
 
 _HOST = {}
+_XCHG = {}   # (row bytes, world, device) -> the exchange's tensors
 
 
 def _host_buffer(n, device):
@@ -75,29 +76,37 @@ def _all_gather_u64(values, device):
     return [[int(x) for x in o.tolist()] for o in out]
 
 
+MAX_SEGMENTS = 16   # of one rank's result that the gather can ship separately (a segment holds up to 4 GiB of strings)
+
+
 def _payload(res):
-    """The rank's findings as ONE (findings bytes, arena bytes) pair without going through Python bytes: numpy views
-    of the result's segments (pinned host memory the device wrote), str_off rebased where there are several."""
+    """The rank's findings as (findings bytes, arena bytes) pairs without going through Python bytes: numpy views of the
+    result's segments (pinned host memory the device wrote).  ONE pair (str_off rebased where there are several segments)
+    as long as the strings fit 32-bit offsets, else one pair per segment, each with its own str_off space."""
     import numpy as np
     fdt = np.dtype({"names": ["position", "str_off", "str_len", "slice_index"], "formats": ["<u8", "<u4", "<u4", "<u4"],
                     "offsets": [0, 8, 12, 24], "itemsize": ctypes.sizeof(Finding)})
     assert fdt.itemsize == ctypes.sizeof(Finding)
-    fs, ars, base = [], [], 0
+    segs = []
     for fp, n, ap, alen in res.segment_pointers():
-        if n:
-            f = np.ctypeslib.as_array(ctypes.cast(fp, ctypes.POINTER(ctypes.c_uint8)), shape=(n * fdt.itemsize,)).view(fdt)
-            if base:
+        f = (np.ctypeslib.as_array(ctypes.cast(fp, ctypes.POINTER(ctypes.c_uint8)), shape=(n * fdt.itemsize,)).view(fdt)
+             if n else np.zeros(0, fdt))
+        a = np.ctypeslib.as_array(ap, shape=(alen,)) if alen else np.zeros(0, np.uint8)
+        if n or alen:
+            segs.append((f, a))
+    if sum(len(a) for _, a in segs) <= 0xFFFFFFFF:
+        fs, ars, base = [], [], 0
+        for f, a in segs:
+            if base and len(f):
                 f = f.copy()
                 f["str_off"] += base
-            fs.append(f)
-        if alen:
-            ars.append(np.ctypeslib.as_array(ap, shape=(alen,)))
-        base += alen
-    if base > 0xFFFFFFFF:
-        raise ValueError("more than 4 GiB of strings in one rank's result: gather segment by segment")
-    f = fs[0] if len(fs) == 1 else (np.concatenate(fs) if fs else np.zeros(0, fdt))
-    a = ars[0] if len(ars) == 1 else (np.concatenate(ars) if ars else np.zeros(0, np.uint8))
-    return f.view(np.uint8), a
+            fs.append(f); ars.append(a); base += len(a)
+        f = fs[0] if len(fs) == 1 else (np.concatenate(fs) if fs else np.zeros(0, fdt))
+        a = ars[0] if len(ars) == 1 else (np.concatenate(ars) if ars else np.zeros(0, np.uint8))
+        return [(f.view(np.uint8), a)]
+    if len(segs) > MAX_SEGMENTS:
+        raise ValueError(f"{len(segs)} result segments on one rank: more than the gather ships ({MAX_SEGMENTS})")
+    return [(f.view(np.uint8), a) for f, a in segs]
 
 
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p)
@@ -115,8 +124,9 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
 
     get_buffer(lo, hi) -> bytes | ctypes.c_void_p : the file bytes [lo, hi) on this rank (c_void_p: in HBM).
     runs_for_buffer(buf_bytes, buf_off) -> runs per mission (tests on CPU: stage B only).
-    gather=True: rank 0 gets the list of (findings_bytes, arena_bytes) per rank, in rank order (one gather over the
-    process group), the other ranks None.  gather=False: the findings stay where they are — rank k's Result is
+    gather=True: rank 0 gets the list of (findings_bytes, arena_bytes) per rank, in rank order (sizes, then transfers of
+    exactly those sizes), the other ranks None.  A rank whose strings exceed 4 GiB arrives as a LIST of such pairs, one per
+    result segment (str_off is per segment).  gather=False: the findings stay where they are — rank k's Result is
     segment k of the file's findings, in order — and every rank gets the per-rank finding counts (ShardCounts).
     The rank's own Result is the second value.  Segment k may end with a few findings that lie behind rank k's range
     end (a region across the boundary; ShardCounts.overflow[k] of them); splice() / splice_order() merge them into
@@ -127,13 +137,27 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
     keep = {}
     errors = []
 
+    on_gpu = torch.device(device).type == "cuda"
+
     def _allgather(user, send, nbytes, recv):
+        # the exchanged rows are a few hundred bytes: one pinned host tensor per direction, kept between calls (and one device
+        # tensor each for backend "nccl"), filled and read with memmove — no Python-level copies of the payload
         try:
-            t = torch.frombuffer(bytearray(ctypes.string_at(send, nbytes)), dtype=torch.uint8).to(device)
-            outs = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(outs, t)
-            blob = torch.cat(outs).cpu().numpy().tobytes()
-            ctypes.memmove(recv, blob, len(blob))
+            key = (nbytes, world, str(device))
+            t = _XCHG.get(key)
+            if t is None:
+                hs = torch.empty(nbytes, dtype=torch.uint8, pin_memory=on_gpu)
+                hr = torch.empty(nbytes * world, dtype=torch.uint8, pin_memory=on_gpu)
+                t = _XCHG[key] = (hs, hr, hs.to(device) if on_gpu else hs, hr.to(device) if on_gpu else hr)
+            hs, hr, ds, dr = t
+            ctypes.memmove(hs.data_ptr(), send, nbytes)
+            if on_gpu:
+                ds.copy_(hs, non_blocking=True)
+            dist.all_gather_into_tensor(dr, ds)
+            if on_gpu:
+                hr.copy_(dr, non_blocking=True)
+                torch.cuda.current_stream(device).synchronize()
+            ctypes.memmove(recv, hr.data_ptr(), nbytes * world)
             return 0
         except Exception as e:  # pragma: no cover
             errors.append(e)
@@ -192,33 +216,60 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
         timings["gather_ms"] = 0.0
     if not gather:
         return counts, res
-    # The gather of the Finding buffers to rank 0 (backend "nccl" = RCCL over xGMI): sizes first, then one
-    # gather of buffers padded to the largest.  The payload goes from the result's pinned memory straight into
-    # the exchange tensor (no Python-level copy).
-    fb, ab = _payload(res)
-    sizes = _all_gather_u64([len(fb), len(ab)], device)
-    mx = max(s[0] + s[1] for s in sizes)
-    mine = torch.empty(max(mx, 1), dtype=torch.uint8, device=device)
-    if len(fb):
-        mine[:len(fb)].copy_(torch.from_numpy(fb), non_blocking=True)
-    if len(ab):
-        mine[len(fb):len(fb) + len(ab)].copy_(torch.from_numpy(ab), non_blocking=True)
+    # The gather of the Finding buffers to rank 0 (backend "nccl" = RCCL over xGMI): every rank's segment sizes first (one
+    # all_gather of a small table), then point-to-point transfers of exactly those sizes — nothing is padded to the largest
+    # payload, rank 0 holds one staging buffer on the device (the largest single segment), and a rank with more than 4 GiB of
+    # strings ships its result segment by segment.  The payload goes from the result's pinned memory straight into the
+    # exchange tensor (no Python-level copy).
+    pairs = _payload(res)
+    row = [len(pairs)] + [x for fb, ab in pairs for x in (len(fb), len(ab))] + [0] * (2 * (MAX_SEGMENTS - len(pairs)))
+    sizes = _all_gather_u64(row, device)
     out = None
     if rank == 0:
-        bufs = [torch.empty(max(mx, 1), dtype=torch.uint8, device=device) for _ in range(world)]
-        dist.gather(mine, bufs, dst=0)
-        # to the host in one pinned buffer (kept between calls), asynchronously, and handed on as views of it — no
-        # per-rank .cpu() + bytes copies (a GiB of findings at 8 ranks); the views are valid until the next gather
-        host = _host_buffer(world * max(mx, 1), device)
-        for k, (b, (nf, na)) in enumerate(zip(bufs, sizes)):
-            if nf + na:
-                host[k * mx:k * mx + nf + na].copy_(b[:nf + na], non_blocking=True)
-        if torch.device(device).type == "cuda":
-            torch.cuda.current_stream(device).synchronize()
-        raw = host.numpy()
-        out = [(raw[k * mx:k * mx + nf], raw[k * mx + nf:k * mx + nf + na]) for k, (nf, na) in enumerate(sizes)]
+        total = sum(sum(r[1:1 + 2 * r[0]]) for r in sizes)
+        host = _host_buffer(max(total, 1), device)
+        stage = None
+        if on_gpu:
+            biggest = max([nf + na for r in sizes[1:] for nf, na in zip(r[1:1 + 2 * r[0]:2], r[2:2 + 2 * r[0]:2])] + [1])
+            stage = torch.empty(biggest, dtype=torch.uint8, device=device)
+        off, where = 0, []
+        for k, r in enumerate(sizes):
+            segs_k = []
+            for j in range(r[0]):
+                nf, na = r[1 + 2 * j], r[2 + 2 * j]
+                dst = host[off:off + nf + na]
+                if k == 0:
+                    fb, ab = pairs[j]
+                    if nf: dst[:nf].copy_(torch.from_numpy(fb))
+                    if na: dst[nf:].copy_(torch.from_numpy(ab))
+                elif nf + na:
+                    if on_gpu:
+                        dist.recv(stage[:nf + na], src=k)
+                        dst.copy_(stage[:nf + na], non_blocking=True)
+                        torch.cuda.current_stream(device).synchronize()   # (the staging buffer is reused by the next transfer)
+                    else:
+                        dist.recv(dst, src=k)
+                segs_k.append((off, nf, na))
+                off += nf + na
+            where.append(segs_k)
+        raw = host.numpy()   # the views are valid until the next gather
+        out = []
+        for segs_k in where:
+            views = [(raw[o:o + nf], raw[o + nf:o + nf + na]) for o, nf, na in segs_k]
+            out.append(views[0] if len(views) == 1 else (views if views else (raw[0:0], raw[0:0])))
     else:
-        dist.gather(mine, None, dst=0)
+        for fb, ab in pairs:
+            n = len(fb) + len(ab)
+            if not n:
+                continue
+            if on_gpu:
+                mine = torch.empty(n, dtype=torch.uint8, device=device)
+                if len(fb): mine[:len(fb)].copy_(torch.from_numpy(fb), non_blocking=True)
+                if len(ab): mine[len(fb):].copy_(torch.from_numpy(ab), non_blocking=True)
+            else:
+                import numpy as np
+                mine = torch.from_numpy(np.concatenate([fb, ab]) if len(ab) and len(fb) else (fb if len(fb) else ab))
+            dist.send(mine, dst=0)
     if timings is not None:
         timings["gather_ms"] = 1e3 * (time.perf_counter() - t_exchanged)
     return out, res

@@ -61,3 +61,44 @@ def test_sharded_device_scan_equals_sequential(world, kind, flags, halo):
         p.join(timeout=120)
     assert res[0] == "ok", res[1]
     assert res[1], f"sharded != sequential: {res[2]} vs {res[3]} findings, first diff {res[4]}"
+
+
+def _nccl_worker(port, q):
+    """world size 1, backend nccl (= RCCL) on cuda:0: the exchange's all_gather_into_tensor and the gather's size table run on
+    DEVICE tensors — the code the 8-GPU run takes, executed once"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import stringsext_amd as sx
+        from stringsext_amd import sharded
+        data = make_data("c4", 1234)
+        ms = rc.missions(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African")
+        sc = sx.Scanner(ms, device=0)
+        d = sc.alloc(len(data)); sc.upload(d, data)
+        timings = {}
+        gathered, res = sharded.scan_sharded(sc, lambda lo, hi: ctypes.c_void_p(d.value + lo), len(data), file_id=1, device="cuda:0",
+                                             gather=True, timings=timings)
+        parts = [sharded.decode_findings(fb, ab) for fb, ab in gathered]
+        got = [(f["position"], f["precision"], f["s"], f["completes"], f["mission_id"], f["slice_index"])
+               for f in sharded.splice_order(parts, len(data))]
+        want = oracle_findings(ms, data)
+        counts, _ = sharded.scan_sharded(sc, lambda lo, hi: ctypes.c_void_p(d.value + lo), len(data), file_id=1, device="cuda:0", gather=False)
+        q.put(("ok", got == want and list(counts) == [len(want)], len(got), len(want), timings))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_the_nccl_transport_runs_once_on_one_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert res[0] == "ok", res[1]
+    assert res[1], res
