@@ -404,7 +404,10 @@ SXD DStep ddec_big5(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool la
             if (last && d.dlead) { d.dlead = 0; return { RES_MALFORMED, i, w }; }
             return { RES_INPUT_EMPTY, i, w };
         }
-        if (cap - w < 4) return { RES_OUTPUT_FULL, i, w };   // an astral character, or Big5's two code points (2 + 2 bytes): as the other two-byte decoders
+        // room for one character before the next byte is read: Big5 may yield an astral one or two code points (2 + 2 bytes); Shift_JIS
+        // and EUC-KR only yield BMP characters (encoding_rs: check_space_astral / check_space_bmp).  Observable through the
+        // 8-byte probe of a slice start (finding_collection.rs:176-207) only.
+        if (cap - w < (d.enc == kEncBig5 ? 4u : 3u)) return { RES_OUTPUT_FULL, i, w };
         const u8 b = src[i];
         if (d.dlead == 0) {
             i++;
@@ -436,7 +439,7 @@ SXD DStep ddec_eucjp(DDecoder& d, const u8* src, u32 n, u8* dst, u32 cap, bool l
             if (last && d.dlead) { d.dlead = 0; d.dflag = 0; return { RES_MALFORMED, i, w }; }
             return { RES_INPUT_EMPTY, i, w };
         }
-        if (cap - w < 4) return { RES_OUTPUT_FULL, i, w };
+        if (cap - w < 3) return { RES_OUTPUT_FULL, i, w };   // BMP characters only
         const u8 b = src[i];
         const bool b_hi = b >= 0xA1 && b <= 0xFE;
         if (d.dlead == 0) {
