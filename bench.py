@@ -155,13 +155,24 @@ def main():
         res.free()
         return n, st
 
+    # a 16-byte fill_kernel launch right before and right after the timed region: in a rocprofv3 --kernel-trace of this command the
+    # scan launches between the two markers are the K timed steps, those before them the warm-up (with its re-scans), those after
+    # them the "alone" launches (tools/launch_rows.py splits the trace there)
+    marker_buf = torch.empty(4096, dtype=torch.uint8, device=f"cuda:{local_rank}")
+
+    def marker():
+        sc.fill_background(ctypes.c_void_p(marker_buf.data_ptr()), 0, 16, SEED)
+        torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         step()
+    marker()
     barrier()
     t0 = time.perf_counter()
     kernel_ms = [0.0] * len(missions)
     device_ms = replay_ms = d2h_ms = wave_count_ms = wave_write_ms = 0.0
-    wave_windows = 0
+    wave_windows = rescans = 0
+    rescan_ms = 0.0
     findings = records = replay_bytes = 0
     for _ in range(args.steps):
         n, st = step()
@@ -171,6 +182,8 @@ def main():
         for k in range(len(missions)):
             kernel_ms[k] += st.kernel_ms[k]
         device_ms += st.device_ms
+        rescans += st.rescans
+        rescan_ms += st.rescan_ms
         replay_ms += st.replay_ms
         d2h_ms += st.d2h_ms
         wave_count_ms += st.wave_count_ms
@@ -178,6 +191,7 @@ def main():
         wave_windows = st.wave_windows
     barrier()
     dt = time.perf_counter() - t0
+    marker()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -255,6 +269,7 @@ def main():
             "roofline": roofline,
             "breakdown_ms_per_step": {"scan_kernels_sum": round(sum(kernel_ms), 3),
                                       "host_waits_for_stage_a": round(device_ms, 3),
+                                      "scan_kernels_launched_again": {"launches": round(rescans / K, 3), "ms": round(rescan_ms / K, 3)},
                                       "sparse_download_for_host_replay": round(d2h_ms / K, 3),
                                       "host_part_of_stage_b": round(replay_ms / K, 3)},
             "gather_ms_per_step": round(timings.get("gather_ms", 0.0), 3) if world > 1 else None,

@@ -127,6 +127,8 @@ typedef struct sx_stats {
     uint64_t heavy_tiles;                /* 1 KiB tiles that needed the general cross-lane path (all missions) */
     uint64_t wave_windows;               /* decoder-input windows replayed by the wave-cooperative stage B (all missions) */
     double   wave_count_ms, wave_write_ms; /* ... its two passes, HIP events around their launches (all missions and slabs) */
+    uint64_t rescans;                    /* scan kernels launched a second time (their records overflowed the regions / the pool) */
+    double   rescan_ms;                  /* ... host time until their records were there */
 } sx_stats;
 
 typedef struct sx_ctx sx_ctx;

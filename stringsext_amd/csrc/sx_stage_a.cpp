@@ -151,8 +151,12 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                 if (rc != SX_OK) return rc;
             }
             const ScanParams p = scan_params(ctx, which[k], s, d_bytes, len, parity[k], min_chars[k]);
+            const double tr0 = now_ms();
             HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream_b));
             HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream_b));
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            ctx->stats.rescans++;
+            ctx->stats.rescan_ms += now_ms() - tr0;
         }
         const double tc0 = now_ms();
         if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   mission %d: kernel done at +%.2f ms, counters at +%.2f ms\n", which[k], t_ev - t0, tc0 - t0);
