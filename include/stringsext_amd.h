@@ -183,10 +183,15 @@ const uint16_t* sx_decoder_table(uint32_t encoding, uint64_t* n_words);
 /* Lower level: does the wave-cooperative stage B (csrc/sx_wave_core.hpp) cover this Mission — no -g, no -r,
  * 1 <= chars_min_nb <= output_line_char_nb_max <= 64, a single-byte encoding or UTF-8 (the reference's rules it
  * relies on: src/helper.rs:315-322, 349-421)?  Returns 0 if not covered, < 0 on error, else the class byte it keeps per
- * input byte in classes[256] and 1 for a single-byte encoding (bit 0 a character, bit 1 its UTF-8 lead byte passes
+ * input byte in classes[256] and 1 + family: 1 for a single-byte encoding (bit 0 a character, bit 1 its UTF-8 lead byte passes
  * af / ubf — src/mission.rs:333-348 —, bit 2 / 3 its UTF-8 form has 2 / 3 bytes), 2 for UTF-8 (bits 0-2: 0 never valid,
  * 1 ASCII, 2 continuation byte, 3 / 4 / 5 lead byte of 2 / 3 / 4; bit 3 a character that starts with it passes). */
 int sx_wave_classes(const sx_mission* mission, uint8_t* classes);
+/* ... and for the two-byte family (sx_wave_classes returns 5: Big5 — only if the Mission rejects U+00C0.. and U+0300.. —,
+ * Shift_JIS, EUC-KR; classes[]: as a single-byte encoding's for the bytes that are characters on their own, bit 4 = lead byte):
+ * 4 bits per byte pair, index lead | trail << 8, eight per word: bit 0 the index maps the pair, bit 1 its character passes the
+ * filter, bits 2-3: its UTF-8 form has 2 / 3 / 4 bytes, 3 = it yields two code points.  out8192 or NULL. */
+const uint32_t* sx_wave_pair_codes(const sx_mission* mission, uint32_t* out8192);
 
 int  sx_abi_version(void);
 

@@ -157,6 +157,15 @@ const uint16_t* sx_decoder_table(uint32_t encoding, uint64_t* n_words) {
     return t;
 }
 
+const uint32_t* sx_wave_pair_codes(const sx_mission* mission, uint32_t* out8192) {
+    if (!mission || !out8192) return nullptr;
+    Mission m;
+    std::string err;
+    if (Mission::from_c(*mission, false, &m, &err) != SX_OK || m.wave_pairs.size() != 8192) return nullptr;
+    memcpy(out8192, m.wave_pairs.data(), 8192 * 4);
+    return out8192;
+}
+
 int sx_wave_classes(const sx_mission* mission, uint8_t* classes) {
     if (!mission || !classes) return SX_E_INVALID;
     Mission m;
@@ -267,6 +276,7 @@ void sx_destroy(sx_ctx* ctx) {
             if (d.d_table) (void)hipFree(d.d_table);
             if (d.d_pair_lut) (void)hipFree(d.d_pair_lut);
             if (d.d_wave_lut) (void)hipFree(d.d_wave_lut);
+            if (d.d_wave_pairs) (void)hipFree(d.d_wave_pairs);
             for (void* q : d.d_rp) if (q) (void)hipFree(q);
             if (d.h_runs) (void)hipHostFree(d.h_runs);
             if (d.ev_runs) (void)hipEventDestroy(d.ev_runs);

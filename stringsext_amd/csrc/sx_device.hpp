@@ -159,9 +159,12 @@ struct WaveParams {
     uint32_t nwin;            // windows a wavefront owns
     uint32_t inject;          // the exact state at window g_lo (wv_pack), from the host
     int32_t mission_id, file_id;
-    uint32_t family;          // 0: single-byte decoders, 1: UTF-8
+    uint32_t family;          // 0: single-byte decoders, 1: UTF-8, 4: the two-byte family (Big5, Shift_JIS, EUC-KR)
     const uint8_t* lut;       // device: 256 class bytes (single byte: WVC_*; UTF-8: WVU_*)
-    const uint16_t* table;    // device: the decoder table (single byte: 128 entries; nullptr = x-user-defined)
+    const uint16_t* table;    // device: the decoder table (single byte: 128 entries; nullptr = x-user-defined; two-byte family: its blob)
+    const uint32_t* pairs;    // device, two-byte family: 4 bits per byte pair (lead | trail << 8), sx_wave_core.hpp wv_classify16_dbcs
+    uint32_t encoding;        // SX_ENC_* (the two-byte family's decoders are picked at run time)
+    uint32_t entry_skip;      // two-byte family: bytes at the buffer's start that finish the token pending on entry (0 / 1)
     // pass 1 out, per wavefront: findings, string bytes, the entry state it assumed for its first window, the state after its last
     uint32_t *wave_nf, *wave_nb, *wave_in, *wave_out;
     // pass 2 in: exclusive sums of the above; the launch's output segment starts at (f_sub, a_sub)
@@ -170,7 +173,7 @@ struct WaveParams {
     sx_finding* findings;
     uint8_t* arena;
     uint32_t str_off_base;    // added to every str_off
-    uint64_t v0;              // first wavefront of this launch
+    uint64_t v0, v1;          // the wavefronts of this launch: [v0, v1)
 };
 size_t wave_scratch_bytes(uint64_t n_waves);
 // pass 1 of wavefronts [v0, v1) + exclusive sums from v0 on + verification; totals (device, 4 x u64): findings, string bytes,

@@ -155,6 +155,37 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
                 const uint32_t cp = two_byte_single(enc, (uint8_t)b);
                 if (cp) { p.high1 = 1; if (m->filter.pass_lead(utf8_lead_of(cp))) p.lut[b] = 0x80; }
             }
+        if (two_byte && !enc_is_gb(enc)) {
+            // the wave-cooperative stage B (sx_wave_dev.hip): a class per byte on its own, 4 bits per byte pair.  Big5's four pointers that
+            // yield two code points (U+00CA / U+00EA + U+0304 / U+030C) stand as ONE rejected char there: only for Missions that
+            // reject both (UTF-8 lead bytes C3 and CC)
+            m->wave_ok = wv_mission_ok(in.grep_char, in.require_same_unicode_block, in.chars_min_nb, (uint32_t)m->q)
+                         && (enc != SX_ENC_BIG5 || (!m->filter.pass_ubf_filter(0xC3) && !m->filter.pass_ubf_filter(0xCC)));
+            m->wave_family = 4;
+            m->wave_lut.assign(256, 0);
+            const uint16_t* t4 = decoder_table(enc, nullptr);
+            for (int b = 0; b < 256; b++) {
+                uint8_t c = 0;
+                if (b < 0x80) c = (uint8_t)(WVC_VALID | (af[b] ? WVC_ACC : 0));
+                else if (two_byte_lead(enc, (uint8_t)b)) c = WVC_LEAD;
+                else if (const uint32_t cp = two_byte_single(enc, (uint8_t)b))
+                    c = (uint8_t)(WVC_VALID | (m->filter.pass_lead(utf8_lead_of(cp)) ? WVC_ACC : 0) | (cp >= 0x800 ? WVC_O3 : WVC_O2));
+                m->wave_lut[(size_t)b] = c;
+            }
+            m->wave_pairs.assign(8192, 0u);
+            for (uint32_t b0 = 0x81; b0 <= 0xFE; b0++) {
+                if (!two_byte_lead(enc, (uint8_t)b0)) continue;
+                for (uint32_t b1 = 0; b1 < 256; b1++) {
+                    uint32_t second = 0;
+                    const uint32_t cp = two_byte_lookup(enc, t4, b0, b1, &second);
+                    if (!cp) continue;
+                    const uint32_t len = second ? 3u : cp < 0x800 ? 0u : cp < 0x10000 ? 1u : 2u;
+                    const uint32_t code = 1u | ((!second && m->filter.pass_lead(utf8_lead_of(cp))) ? 2u : 0u) | (len << 2);
+                    const uint32_t idx = b0 | (b1 << 8);
+                    m->wave_pairs[idx >> 3] |= code << ((idx & 7u) * 4);
+                }
+            }
+        }
         p.gb4 = (enc_is_gb(enc) && m->c.ubf != 0) ? 1u : 0u;   // some character beyond ASCII is accepted: four-byte tokens may be
         p.af_is_range = (!force_generic && af_is_range && !p.high1) ? 1u : 0u;
         const uint16_t* t = decoder_table(enc, nullptr);

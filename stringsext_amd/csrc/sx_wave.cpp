@@ -3,7 +3,7 @@
 // The lane-per-region replay costs time per long run, the wave kernels cost time per input byte (every window of the
 // buffer is replayed, a lane each, whether anything is found in it or not): they take over when a Mission has more
 // than a run per ~500 bytes — `-e ascii -n 4` on binaries, text, a legacy code page on random bytes — and cover the
-// Missions sx_wave_core.hpp names (no -g, no -r, 1 <= n <= q <= 64, a single-byte decoder or UTF-8).
+// Missions sx_wave_core.hpp names (no -g, no -r, 1 <= n <= q <= 64; a single-byte decoder, UTF-8, or Big5 / Shift_JIS / EUC-KR).
 //   host:   the buffer's first window(s) from the exact carried ScannerState (its leftover's bytes lie in the previous
 //           buffer) — FindingCollection::from as ever, replay_exact_windows;
 //   device: every other window: count pass -> exclusive sums + verification of the wavefronts' assumed entry states ->
@@ -82,7 +82,23 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         const uint32_t lc = utf8_chars(st.last_scan_run_leftover), lb = (uint32_t)st.last_scan_run_leftover.size();
         // source bytes from the leftover's first byte to E: single byte: one per char; UTF-8: its bytes + what the decoder holds of the next char
         const DDecoder& dd = st.decoder.raw();
-        const uint32_t lback = m.wave_family == 0 ? lc : lb + (dd.needed ? dd.seen + 1u : 0u);
+        uint32_t lback = m.wave_family == 0 ? lc : lb + (dd.needed ? dd.seen + 1u : 0u);
+        if (m.wave_family == 4) {
+            // two-byte family: one or two source bytes per char — which, the text does not say: the bytes in front of E (less the
+            // lead byte the decoder holds) that decode to exactly the leftover
+            const uint32_t pend = dd.dlead ? 1u : 0u;
+            lback = 0;
+            for (uint32_t cand = lc; lc && cand <= 2 * lc && cand + pend <= E; cand++) {
+                size_t hint = 0;
+                const uint8_t* src = view.span(E - pend - cand, cand, &hint);
+                Decoder probe(m.c.encoding);
+                uint8_t buf[64 * 4 + 16];
+                const DecodeStep r = probe.decode_to_str_without_replacement(src, cand, buf, sizeof buf, false);
+                if (r.result == DecoderResult::InputEmpty && r.read == cand && probe.idle() && r.written == lb
+                    && memcmp(buf, st.last_scan_run_leftover.data(), lb) == 0) { lback = cand + pend; break; }
+            }
+            if (lc && !lback) return SX_WAVE_FALLBACK;
+        }
         const WvState in{ lc, lb, lc ? lback : 0u, st.last_run_str_was_printed_and_is_maybe_cut_str ? 1u : 0u };
         const uint64_t n_windows = g_all - g_lo;
         uint64_t batches = (n_windows + (8192ull * 64) - 1) / (8192ull * 64);
@@ -102,6 +118,10 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             HIP_TRY(ctx, hipMalloc((void**)&d.d_wave_lut, 256));
             HIP_TRY(ctx, hipMemcpy(d.d_wave_lut, m.wave_lut.data(), 256, hipMemcpyHostToDevice));
         }
+        if (m.wave_family == 4 && !d.d_wave_pairs) {
+            HIP_TRY(ctx, hipMalloc((void**)&d.d_wave_pairs, 8192 * 4));
+            HIP_TRY(ctx, hipMemcpy(d.d_wave_pairs, m.wave_pairs.data(), 8192 * 4, hipMemcpyHostToDevice));
+        }
         // per wavefront: 4 x u32 (pass 1 out) + 2 x u64 (offsets); + totals per slab
         const uint64_t per = 4 * 4 + 2 * 8;
         int rc = ensure_rp(ctx, d, 1, n_waves * per + 4096); if (rc) return rc;
@@ -117,6 +137,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         P.W = W; P.wps = wps; P.q = (uint32_t)m.q; P.n_min = m.c.chars_min_nb;
         P.g_lo = g_lo; P.g_hi = g_all; P.nwin = nwin; P.inject = wv_pack(in);
         P.mission_id = m.c.mission_id; P.file_id = job.file_id; P.family = m.wave_family; P.lut = d.d_wave_lut; P.table = d.d_table;
+        P.pairs = d.d_wave_pairs; P.encoding = m.c.encoding; P.entry_skip = m.buf_entry_skip;
         P.wave_nf = d_u; P.wave_nb = d_u + n_waves; P.wave_in = d_u + 2 * n_waves; P.wave_out = d_u + 3 * n_waves;
         P.wave_fbase = d_fb; P.wave_abase = d_ab;
         if (K > 1) {
@@ -235,12 +256,19 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             // holds of a character that is still incomplete (without leftover: the last bytes, for the decoder alone)
             fin.decoder.reset(m.c.encoding);
             fin.last_scan_run_leftover.clear();
-            const uint64_t back = fs.lc ? fs.lback : std::min<uint64_t>(8, len);
+            // (two-byte family without leftover: a fresh decoder cannot find the token grid in the last bytes; the device says whether
+            // the buffer ends inside a token — its last byte is then the lead byte the decoder holds)
+            const bool dbcs_tail = m.wave_family == 4 && !fs.lc;
+            if (dbcs_tail && (final_state & kWvPendBit)) {
+                size_t hint1 = 0;
+                fin.decoder.raw().dlead = *view.span(len - 1, 1, &hint1);
+            }
+            const uint64_t back = dbcs_tail ? 0 : fs.lc ? fs.lback : std::min<uint64_t>(8, len);
             size_t hint = 0;
-            const uint8_t* src = view.span(len - back, back, &hint);
+            const uint8_t* src = back ? view.span(len - back, back, &hint) : (const uint8_t*)"";
             uint8_t buf[64 * 4 + 16];
             size_t at = 0, written = 0;
-            for (;;) {
+            for (; back;) {
                 const DecodeStep r = fin.decoder.decode_to_str_without_replacement(src + at, back - at, buf + written, sizeof buf - written, false);
                 at += r.read; written += r.written;
                 if (r.result != DecoderResult::Malformed) break;

@@ -90,6 +90,7 @@ SXD u32 wm_select(WvMask m, u32 from, u32 k) {
 struct WvState { u32 lc, lb, lback, cut; };
 SXD u32 wv_pack(const WvState& s) { return s.lc | (s.lb << 7) | (s.lback << 16) | (s.cut << 26); }
 SXD WvState wv_unpack(u32 v) { return WvState{ v & 127u, (v >> 7) & 511u, (v >> 16) & 1023u, (v >> 26) & 1u }; }
+constexpr u32 kWvPendBit = 1u << 27;   // on the state after a buffer's LAST window only: it ends inside a token (double byte)
 
 struct WvParams { u32 q, n_min; };
 
@@ -100,12 +101,16 @@ struct WvWin {
     WvMask CS;       // bit i (1 <= i < n): a decoder call starts at byte i
     WvMask LS;       // first bytes of the stretches of accepted chars that have >= n BYTES (so every stretch of >= n chars is among them)
     WvMask O2, O3;   // single byte: bytes whose UTF-8 form has 2 / 3 bytes (str_len = source bytes + popc(O2) + 2 popc(O3))
+    WvMask O4;       // double byte: O2 / O3 / O4 = last bytes of the chars whose UTF-8 form has >= 2 / >= 3 / 4 bytes
     u32 n;           // bytes in the window
     u32 pre_empty;   // an empty decoder call at byte 0 precedes the first one (UTF-8: the byte a pending sequence rejects is read again)
     u32 tail_empty;  // a decoder call starts exactly at the window end: one more (empty) call in this window
     u32 head_back;   // bytes of the first delivered character that lie in front of the window (0..3)
     u32 probe_before;// the slice-start probe (:176-207) marks the first call's first chunk `Before`
     u32 slice_start; // the window is the first of its slice
+    u32 probe_hb;    // double byte, first window of a slice: bytes of the first char in front of the slice (the probe is settled by decoding)
+    u32 head_pend;   // double byte: bytes in front of the window that belong to a token still incomplete there (a pending lead byte: 0 / 1)
+    u32 tail_pend;   // double byte: the window ends inside a token (its last byte is a lead byte waiting for its trail)
 };
 
 enum { WV_BEFORE = 0, WV_EXACT = 1, WV_AFTER = 2 };   // == SX_PRECISION_*
@@ -132,22 +137,29 @@ SXD bool wv_mission_ok(int grep_char, u32 same_block, u32 n_min, u32 q) {
 // So a call costs: its first stretch, its LONG stretches (found through w.LS), its last stretch.
 // EMIT(din, precision, completes, src_rel, src_len, out_len): src_rel = first source byte relative to the window start
 // (negative: in front of it), out_len = bytes of the string.
-template <bool BYTES, class EMIT>
+// KIND 0: single-byte decoders (a char per byte; string bytes from O2 / O3); 1: UTF-8 (the string is the source bytes);
+// 2: double-byte decoders (chars from E / F; string bytes from O2 / O3 / O4 at the chars' last bytes).
+template <int KIND, class EMIT>
 SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 cend, bool invalid_after, bool first_call, EMIT& emit,
                  u32 probe = 0) {
     const bool cont = st.cut != 0;   // :240-241: consumed by this call whatever it yields
     st.cut = 0;
     const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback;
+    const u32 lsrc = KIND == 2 ? lback - (first_call || din == 0 ? w.head_pend : 0u) : lback;   // the leftover's own source bytes
     const bool has_left = lrem > 0;
     st.lc = 0; st.lb = 0; st.lback = 0;   // :211-227: the leftover is prepended, then gone
     const WvMask rng = wm_range(din, cend);
     const WvMask Ec = wm_and(w.E, rng);
     if (!has_left && !wm_any(Ec)) return;
+    constexpr bool BYTES = KIND == 0;
     const WvMask Rc = wm_andn(Ec, w.A);   // rejected (valid) chars of this call
     u32 prec = (has_left || (first_call && w.probe_before)) ? WV_BEFORE : WV_EXACT;   // :146, 214-221, 176-207
-    if (!BYTES && probe && !has_left) {   // a second call at byte 0 of a slice: the probe runs if its first char is not ASCII
+    if (!BYTES && !has_left && (probe || (first_call && w.probe_hb))) {
+        // a call at byte 0 of a slice whose first char is not ASCII: the probe runs (:176).  UTF-8 / a second call: against the
+        // leftover the empty first call consumed; double-byte, first call: against a decoder that holds the lead byte of the slice before
         const u32 fe0 = wm_next(Ec, 0);
-        if (fe0 < 128 && !wm_test(w.F, fe0)) prec = probe;
+        const bool non_ascii = fe0 < 128 && (KIND == 1 ? !wm_test(w.F, fe0) : wm_test(w.O2, fe0));
+        if (non_ascii) prec = probe ? probe : (wv_probe_pack(0, 0) | (w.probe_hb << 27));
     }
 
     // One stretch: `pre` chars carried in front of it (the leftover), its accepted chars = the E bits in [a, er).
@@ -176,13 +188,16 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
             const u32 inwin = pn - carried;
             u32 last_e = at, out_b = carried_b;
             // (a leftover on its own: its source bytes; UTF-8: lback also counts the bytes of a character that was pending behind it)
-            i32 src_end = src + (i32)(carried ? (BYTES ? lback : lbytes) : 0u);
+            i32 src_end = src + (i32)(carried ? (KIND == 1 ? lbytes : lsrc) : 0u);
             if (inwin) {
                 last_e = BYTES ? at + inwin - 1 : wm_select(av, at, inwin);
                 src_end = (i32)last_e + 1;
                 if (BYTES) {
                     const WvMask tr_ = wm_range(at, last_e + 1);
                     out_b += inwin + wm_popc(wm_and(w.O2, tr_)) + 2 * wm_popc(wm_and(w.O3, tr_));
+                } else if (KIND == 2) {
+                    const WvMask tr_ = wm_range(at, last_e + 1);   // (the length bits sit on the chars' last bytes)
+                    out_b += inwin + wm_popc(wm_and(w.O2, tr_)) + wm_popc(wm_and(w.O3, tr_)) + wm_popc(wm_and(w.O4, tr_));
                 } else out_b = (u32)(src_end - src);    // UTF-8 in, UTF-8 out: the string is the source bytes
             }
             if (again) { st.lc = pn; st.lb = out_b; st.lback = (u32)((i32)w.n - src); st.cut = 0; }   // finding_collection.rs:269-285
@@ -231,12 +246,12 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
 
 // One window: its decoder calls in order (finding_collection.rs:134-325).  Calls that hold no accepted char and
 // meet no leftover only clear the cut flag: they are skipped in bulk.
-template <bool BYTES, class EMIT>
+template <int KIND, class EMIT>
 SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, bool skip_idle_calls = true) {
     u32 probe = 0;
     if (w.pre_empty) {
         if (w.slice_start && st.lb) probe = wv_probe_pack(st.lb, st.lback);
-        wv_call<BYTES>(P, w, st, 0u, 0u, true, false, emit);
+        wv_call<KIND>(P, w, st, 0u, 0u, true, false, emit);
     }
     u32 din = 0;
     bool first = true;
@@ -250,12 +265,12 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, b
         u32 cend = wm_next(w.CS, din + 1);
         if (cend > w.n) cend = w.n;
         const bool last = cend >= w.n;
-        wv_call<BYTES>(P, w, st, din, cend, !last || w.tail_empty != 0, first, emit, din == 0 ? probe : 0u);
+        wv_call<KIND>(P, w, st, din, cend, !last || w.tail_empty != 0, first, emit, din == 0 ? probe : 0u);
         first = false;
         if (last) break;
         din = cend;
     }
-    if (w.tail_empty) wv_call<BYTES>(P, w, st, w.n, w.n, false, false, emit);
+    if (w.tail_empty) wv_call<KIND>(P, w, st, w.n, w.n, false, false, emit);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -317,7 +332,8 @@ SXD WvWin wv_win_single(WvMask V, WvMask A, WvMask O2, WvMask O3, u32 n, u32 n_m
     const WvMask bad = wm_andn(wm_below(n), V);        // a byte without a character: Malformed(1, 0), the call ends behind it
     w.CS = wm_and(wm_shl1(bad), wm_below(n));
     w.tail_empty = n && wm_test(bad, n - 1) ? 1u : 0u;
-    w.pre_empty = 0; w.head_back = 0; w.probe_before = 0; w.slice_start = 0;
+    w.pre_empty = 0; w.head_back = 0; w.probe_before = 0; w.slice_start = 0; w.probe_hb = 0; w.head_pend = 0; w.tail_pend = 0;
+    w.O4 = wm_zero();
     return w;
 }
 
@@ -401,6 +417,110 @@ SXD WvWin wv_win_utf8(WvMask E, WvMask A, WvMask F, WvMask G, WvMask MA, WvMask 
     if (e0 < 128 && wm_prev(F, e0) < 0) w.head_back = (f_back & 4u) ? 1u : (f_back & 2u) ? 2u : (f_back & 1u) ? 3u : 0u;
     w.probe_before = slice_start && w.head_back ? 1u : 0u;
     w.slice_start = slice_start ? 1u : 0u;
+    w.probe_hb = 0; w.head_pend = 0; w.tail_pend = 0; w.O4 = wm_zero();
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------
+// Classification, the two-byte family (Big5, Shift_JIS, EUC-KR; sx_codec_core.hpp ddec_big5).  The decoder consumes TOKENS: one byte
+// outside the lead range, or a lead byte with the byte behind it, whatever that is.  Where tokens start follows from where the
+// one before started (the scan kernel's token classifier, sx_kernels.hip scan_kernel_dbcs, says the same in bit operations):
+//   * per lane (16 bytes) the walk is done for both cases "my byte 0 starts a token" / "is the trail of the lane before" (wv_dbcs_walk);
+//     the lanes' in -> out functions are composed along the wavefront, which gives every lane its case;
+//   * a lead + trail that the index maps: a character (E on the trail, F on the lead); Big5's four pointers that yield TWO code
+//     points: two characters, one per byte (D marks the second); else Malformed: an ASCII trail is read again (MB on it) and is a
+//     character of its own, any other trail is consumed (MA on it);
+//   * a byte on its own: a character (ASCII; Shift_JIS 0x80, A1..DF), or Malformed(1, 0) (MA).
+// lut1[b]: WVC_* of the byte as a character on its own | WVC_LEAD; pair codes: 4 bits per (lead | trail << 8): bit 0 mapped, bit 1
+// accepted (a pair of two: its first), bits 2-3: 0 / 1 / 2 = the UTF-8 form has 2 / 3 / 4 bytes, 3 = two characters of 2 bytes each.
+// ------------------------------------------------------------------------------------------
+enum { WVC_LEAD = 16 };
+struct WvMasks16D { u32 e, a, f, g, ma, mb, o2, o3, o4; };
+
+// lead-range mask of the lane's 16 bytes (bit 16 + k: the k-th byte behind them), existing bytes only
+template <class LUT>
+SXD u32 wv_dbcs_lead_mask(const LUT& lut1, const u8* b, u32 have_hi) {
+    u32 lr = 0;
+#pragma unroll
+    for (int j = 0; j < 20; j++) if ((u32)(j + 4) < have_hi && (lut1[b[j + 4]] & WVC_LEAD)) lr |= 1u << j;
+    return lr;
+}
+// token starts among the lane's bytes 0..15 when the first token starts at byte `first` (0 or 1); *over = how far the last token
+// reaches into the next lane (0 / 1)
+SXD u32 wv_dbcs_walk(u32 lr, u32 first, u32* over) {
+    u32 s = 0, pos = first;
+    while (pos < 16) { s |= 1u << pos; pos += ((lr >> pos) & 1u) ? 2u : 1u; }
+    *over = pos - 16;
+    return s;
+}
+
+template <class LUT, class PAIRS>
+SXD WvMasks16D wv_classify16_dbcs(const LUT& lut1, const PAIRS& pairs, const u8* b, u32 have_lo, u32 have_hi, u32 lr, u32 starts, u32 cov_in) {
+    WvMasks16D m{ 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    // tokens of two bytes that start at lane offsets -1 .. 15 (their trails at 0 .. 16): never at adjacent offsets
+    const u32 two = (((starts & lr) << 1) | (cov_in ? 1u : 0u)) & 0x1FFFFu;   // bit p + 1: a two-byte token starts at p
+#pragma unroll
+    for (int k = 0; k <= 8; k++) {
+        const int p = ((two >> (2 * k)) & 1u) ? 2 * k - 1 : (((two >> (2 * k + 1)) & 1u) ? 2 * k : -2);
+        if (p < -1 || p > 15) continue;
+        if ((u32)(p + 5) >= have_hi || (u32)(p + 4) < have_lo) continue;   // the trail does not exist (yet): the token is pending (or its lead lies in front of the buffer)
+        const u32 lead = b[p + 4], trail = b[p + 5];
+        const u32 idx = lead | (trail << 8);
+        const u32 code = (pairs[idx >> 3] >> ((idx & 7u) * 4)) & 15u;
+        const u32 at_l = p >= 0 ? 1u << p : 0u, at_t = p + 1 <= 15 ? 1u << (p + 1) : 0u;
+        if (code & 1u) {
+            const u32 acc = (code >> 1) & 1u, len = code >> 2;
+            if (len == 3) {
+                // Big5's four pointers that yield TWO code points (U+00CA / U+00EA + a combining mark), both delivered when the trail
+                // is read.  The wave path only takes Missions that reject both (sx_mission.cpp): for SplitStr two rejected chars in
+                // a row are what one is — a break — so the token stands as ONE rejected char.
+                m.f |= at_l; m.e |= at_t; m.o2 |= at_t;
+            } else {
+                m.f |= at_l; m.e |= at_t; m.o2 |= at_t;
+                if (len >= 1) m.o3 |= at_t;
+                if (len == 2) m.o4 |= at_t;
+                if (acc) { m.a |= at_t; m.g |= at_l | at_t; }
+            }
+        } else if (trail < 0x80) {                          // the trail is read again: a character of its own
+            m.mb |= at_t;
+            const u32 c = lut1[trail];
+            if (c & WVC_VALID) { m.f |= at_t; m.e |= at_t; if (c & WVC_ACC) { m.a |= at_t; m.g |= at_t; } }
+            else m.ma |= at_t;
+        } else m.ma |= at_t;
+    }
+    // tokens of one byte
+    const u32 one = starts & ~lr & 0xFFFFu;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (!((one >> j) & 1u) || (u32)(j + 4) >= have_hi) continue;
+        const u32 c = lut1[b[j + 4]];
+        if (c & WVC_VALID) {
+            m.f |= 1u << j; m.e |= 1u << j;
+            if (c & (WVC_O2 | WVC_O3)) m.o2 |= 1u << j;
+            if (c & WVC_O3) m.o3 |= 1u << j;
+            if (c & WVC_ACC) { m.a |= 1u << j; m.g |= 1u << j; }
+        } else m.ma |= 1u << j;
+    }
+    return m;
+}
+
+// the window of a two-byte Mission.  back: the E | MA bits and the F bits of the byte right in front of the window.
+SXD WvWin wv_win_dbcs(WvMask E, WvMask A, WvMask F, WvMask G, WvMask MA, WvMask MB, WvMask O2, WvMask O3, WvMask O4,
+                      bool back_done, bool back_f, bool has_back, bool slice_start, u32 n, u32 n_min) {
+    WvWin w;
+    w.E = E; w.A = A; w.F = F; w.O2 = O2; w.O3 = O3; w.O4 = O4; w.n = n;
+    w.LS = wv_long_starts(G, n_min);
+    w.CS = wm_and(wm_or(wm_shl1(MA), MB), wm_andn(wm_below(n), wm_below(1)));
+    w.tail_empty = n && wm_test(MA, n - 1) ? 1u : 0u;
+    w.pre_empty = n && wm_test(MB, 0) ? 1u : 0u;
+    w.head_pend = has_back && !back_done ? 1u : 0u;       // the byte in front is a lead byte still waiting for its trail
+    w.head_back = 0;
+    const u32 e0 = wm_next(E, 0);
+    if (e0 == 0 && !wm_test(F, 0) && back_f) w.head_back = 1;   // the first char's lead byte lies in front of the window
+    w.probe_before = 0;
+    w.slice_start = slice_start ? 1u : 0u;
+    w.probe_hb = slice_start ? w.head_back : 0u;
+    w.tail_pend = n && !wm_test(E, n - 1) && !wm_test(MA, n - 1) ? 1u : 0u;
     return w;
 }
 
@@ -415,6 +535,46 @@ SXD u32 wv_resolve_probe(const u8* slice, u32 n, const u8* left, u32 lb) {
     bool same = pr.written != 0;
     for (u32 t = 0; t < pr.written && same; t++) same = (t < lb ? left[t] : probe[t - lb]) == probe[t];
     return same ? WV_EXACT : WV_BEFORE;
+}
+
+// WV_PROBE settled for the two-byte family by decoding: the call's output comes from a decoder that holds the `hb` bytes in front of
+// the slice (its pending lead byte; 0: it is neutral), the probe's from a fresh one (finding_collection.rs:176-207).  left_src: the
+// source bytes of the leftover that lies at the front of the output buffer (lsrc of them, lb bytes once decoded).
+SXD u32 wv_transcode_dbcs(int enc, const uint16_t* table, const u8* s, u32 n, u8* dst);
+SXD u32 wv_resolve_probe_dbcs(int enc, const uint16_t* table, const u8* slice, u32 n, const u8* left_src, u32 lsrc, u32 lb, u32 hb) {
+    DDecoder real, fresh;
+    ddec_reset(real, enc, table); ddec_reset(fresh, enc, table);
+    u8 sink[8], out[16], probe[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, left[64 * 4 + 8];
+    if (lb) (void)wv_transcode_dbcs(enc, table, left_src, lsrc, left);
+    if (hb) (void)ddec_big5(real, slice - hb, hb, sink, sizeof sink, false);
+    const u32 m = n < 32 ? n : 32;
+    const DStep ro = ddec_big5(real, slice, m < 12 ? m : 12, out, sizeof out, false);   // (its first 8 bytes are all that is compared)
+    const DStep pr = ddec_big5(fresh, slice, m, probe, 8, true);
+    bool same = pr.written != 0;
+    for (u32 t = 0; t < pr.written && same; t++) {
+        const u8 have = t < lb ? left[t] : (t - lb < ro.written ? out[t - lb] : (u8)0);
+        same = have == probe[t];
+    }
+    return same ? WV_EXACT : WV_BEFORE;
+}
+
+// the string of a finding of the two-byte family: its source bytes [s, s + n) token by token (it begins and ends on token
+// boundaries; tokens of two code points never occur in one: the Missions that take this path reject both)
+SXD u32 wv_transcode_dbcs(int enc, const uint16_t* table, const u8* s, u32 n, u8* dst) {
+    u32 w = 0, p = 0;
+    while (p < n) {
+        const u8 b = s[p];
+        if (b < 0x80) { dst[w++] = b; p++; continue; }
+        if (two_byte_lead(enc, b)) {
+            u32 second = 0;
+            w += dput_cp(dst + w, two_byte_lookup(enc, table, b, s[p + 1], &second));
+            p += 2;
+            continue;
+        }
+        w += dput_cp(dst + w, two_byte_single(enc, b));
+        p++;
+    }
+    return w;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -66,9 +66,12 @@ struct WriteEmit {
         r.str_off = (u32)(a_off + P->str_off_base);
         r.str_len = out_len;
         if ((prec & 0xFFu) == WV_PROBE) {   // sx_wave_core.hpp WV_PROBE: this call starts at the slice's byte 0
-            const u32 lb = (prec >> 8) & 511u, lback = prec >> 17;
+            const u32 lb = (prec >> 8) & 511u, lback = (prec >> 17) & 1023u, hb = prec >> 27;
             const u64 avail = P->len - win_pos;
-            prec = wv_resolve_probe(P->data + win_pos, avail < 32 ? (u32)avail : 32u, P->data + (win_pos - lback), lb);
+            if (P->family == 4)   // (a leftover at a second call at byte 0: the byte in front of the slice was a lead byte, not the leftover's)
+                prec = wv_resolve_probe_dbcs((int)P->encoding, P->table, P->data + win_pos, avail < 32 ? (u32)avail : 32u,
+                                             P->data + (win_pos - lback), lb ? lback - 1 : 0u, lb, hb);
+            else prec = wv_resolve_probe(P->data + win_pos, avail < 32 ? (u32)avail : 32u, P->data + (win_pos - lback), lb);
         }
         r.precision = (u8)prec;
         r.completes_previous = completes ? 1 : 0;
@@ -79,7 +82,8 @@ struct WriteEmit {
         r.slice_index = (u32)(soff / kWvSlice) + P->slice_base;
         *f++ = r;
         const u8* s = P->data + (u64)((long long)win_pos + src_rel);
-        if (out_len == src_len) {          // every char is one byte on both sides (ASCII; UTF-8 input)
+        if (P->family == 4) (void)wv_transcode_dbcs((int)P->encoding, P->table, s, src_len, a);
+        else if (out_len == src_len) {     // every char is one byte on both sides (ASCII; UTF-8 input)
             for (u32 t = 0; t < src_len; t++) a[t] = s[t];
         } else {
             u32 w = 0;
@@ -93,24 +97,38 @@ struct WriteEmit {
     }
 };
 
-// MODE 0: count; 1: write.  FAM 0: single-byte decoders; 1: UTF-8.
-template <int MODE, int FAM>
-__global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
-    // FAM 0: valid, accepted, O2, O3; FAM 1: E, A, F, MA, MB, G — 16 bits per lane and tile
-    __shared__ u32 lds_mask[FAM == 1 ? 6 : 4][kWvMaxTiles * 32 + 8];
-    __shared__ u8 lds_lut[256];
-    const u32 lane = threadIdx.x;
-    ((u32*)lds_lut)[lane] = ((const u32*)P.lut)[lane];
-    __syncthreads();
+// the lanes' LDS traffic of one wavefront in order (a block of several wavefronts shares only read-only tables: no block barrier)
+template <int WPB> SXD void wave_lds_sync() {
+    if (WPB == 1) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+}
 
-    const u64 v = P.v0 + blockIdx.x;
+constexpr int wv_n_masks(int fam) { return fam == 4 ? 9 : fam == 1 ? 6 : 4; }
+
+// MODE 0: count; 1: write.  FAM 0: single-byte decoders; 1: UTF-8; 4: the two-byte family (Big5, Shift_JIS, EUC-KR: 4 wavefronts
+// per block share the 32 KB of pair codes in LDS).
+template <int MODE, int FAM, int WPB>
+__global__ __launch_bounds__(64 * WPB) void wave_replay_kernel(const WaveParams P) {
+    // FAM 0: valid, accepted, O2, O3; FAM 1: E, A, F, MA, MB, G; FAM 4: E, A, F, MA, MB, G, O2, O3, O4 — 16 bits per lane and tile
+    __shared__ u32 lds_mask_all[WPB][wv_n_masks(FAM)][kWvMaxTiles * 32 + 8];
+    __shared__ u8 lds_lut[256];
+    __shared__ u32 lds_pairs[FAM == 4 ? 8192 : 1];
+    const u32 lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    if (threadIdx.x < 64) ((u32*)lds_lut)[threadIdx.x] = ((const u32*)P.lut)[threadIdx.x];
+    if (FAM == 4) for (u32 i = threadIdx.x; i < 8192; i += 64 * WPB) lds_pairs[i] = P.pairs[i];
+    __syncthreads();
+    u32 (*lds_mask)[kWvMaxTiles * 32 + 8] = lds_mask_all[wib];
+
+    const u64 v = P.v0 + (u64)blockIdx.x * WPB + wib;
     const u64 own_start = P.g_lo + v * P.nwin;
-    if (own_start >= P.g_hi) return;
+    if (v >= P.v1 || own_start >= P.g_hi) return;
     const u64 own_end = own_start + P.nwin < P.g_hi ? own_start + P.nwin : P.g_hi;
     const u64 gw = v == 0 ? own_start : own_start - kWvWarm;
     u32 carry = v == 0 ? P.inject : 0u;   // entry state of the batch's first window
     u32 assumed_in = carry;
     u32 tot_f = 0, tot_b = 0;
+    u32 dbcs_cov = 0;   // FAM 4: bytes at the next tile's start that belong to a token begun before it (0 / 1)
+    bool dbcs_valid = false;   // ... known for the next batch's first tile
     u64 fbase = 0, abase = 0;
     if (MODE == 1) { fbase = P.wave_fbase[v] - P.f_sub; abase = P.wave_abase[v] - P.a_sub; }   // relative to this launch's output segment
     const WvParams WP{ P.q, P.n_min };
@@ -131,18 +149,41 @@ __global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
         const u32 n_tiles = (u32)((span_hi - tile0 + kTileBytes - 1) / kTileBytes);
 
         // ---- 1. classify the batch's bytes; masks -> LDS
-        __syncthreads();   // (the previous batch's readers are done)
-        for (u32 t = 0; t < n_tiles; t++) {
-            const u64 off = tile0 + (u64)t * kTileBytes + 16ull * lane;
+        wave_lds_sync<WPB>();   // (the previous batch's readers are done)
+        // FAM 4: where tokens start at tile0 follows from the bytes in front of it: the wavefront's first batch walks back to a tile
+        // that holds a byte outside the lead range (behind such a byte a token starts whatever came before); later batches go on
+        // from the batch before.  At the buffer's byte 0 the token pending on entry ends after P.entry_skip bytes.
+        int t_first = 0;
+        const u64 next_t0 = wv_tile0(span_hi);   // the next batch's first tile (the batches' windows are contiguous)
+        bool have_next = false;
+        u32 cov_next = 0;
+        if (FAM == 4 && (g0 == gw || !dbcs_valid)) {
+            dbcs_cov = 0;
+            long long lo = (long long)tile0;
+            while (lo > 0) {
+                lo -= kTileBytes; t_first--;
+                const long long o = lo + 16ll * lane;
+                bool reset = o < 0;
+                if (!reset) {
+                    const u32x4 x = *(const u32x4*)(P.data + o);
+                    const u32 xs[4] = { x.x, x.y, x.z, x.w };
+                    for (int k = 0; k < 16; k++) reset = reset || !(lds_lut[(xs[k >> 2] >> (8 * (k & 3))) & 0xFFu] & WVC_LEAD);
+                }
+                if (__ballot(reset)) break;
+            }
+        }
+        for (int t = t_first; t < (int)n_tiles; t++) {
+            const long long soff = (long long)tile0 + (long long)t * (long long)kTileBytes + 16ll * lane;
+            const u64 off = soff < 0 ? 0ull : (u64)soff;
             u32x4 x = { 0, 0, 0, 0 };
-            const u32 avail = off >= P.len ? 0u : (P.len - off >= 16 ? 16u : (u32)(P.len - off));
+            const u32 avail = soff < 0 || off >= P.len ? 0u : (P.len - off >= 16 ? 16u : (u32)(P.len - off));
             if (avail == 16) x = *(const u32x4*)(P.data + off);
             else if (avail) {   // the buffer's last bytes: never read beyond them
                 u32 xs[4] = { 0, 0, 0, 0 };
                 for (u32 k = 0; k < avail; k++) xs[k >> 2] |= (u32)P.data[off + k] << (8 * (k & 3));
                 x.x = xs[0]; x.y = xs[1]; x.z = xs[2]; x.w = xs[3];
             }
-            const u32 idx = t * 64 + lane;
+            const u32 idx = (u32)(t < 0 ? 0 : t) * 64 + lane;
             if (FAM == 0) {
                 const WvMasks16 m = wv_classify16_single(lds_lut, x.x, x.y, x.z, x.w, avail);
                 ((uint16_t*)lds_mask[0])[idx] = (uint16_t)m.v;
@@ -163,16 +204,51 @@ __global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
                 const u32 ws6[6] = { back, x.x, x.y, x.z, x.w, ahead };
 #pragma unroll
                 for (int k = 0; k < 24; k++) b[k] = (u8)(ws6[k >> 2] >> (8 * (k & 3)));
-                const WvMasks16U m = wv_classify16_utf8(lds_lut, b, off >= 4 ? 0u : 4u, 4u + avail + n_ahead);
-                ((uint16_t*)lds_mask[0])[idx] = (uint16_t)m.e;
-                ((uint16_t*)lds_mask[1])[idx] = (uint16_t)m.a;
-                ((uint16_t*)lds_mask[2])[idx] = (uint16_t)m.f;
-                ((uint16_t*)lds_mask[3])[idx] = (uint16_t)m.ma;
-                ((uint16_t*)lds_mask[FAM == 1 ? 4 : 0])[idx] = (uint16_t)m.mb;
-                ((uint16_t*)lds_mask[FAM == 1 ? 5 : 0])[idx] = (uint16_t)m.g;
+                const u32 have_lo = off >= 4 ? 0u : 4u, have_hi = 4u + avail + n_ahead;
+                if (FAM == 1) {
+                    const WvMasks16U m = wv_classify16_utf8(lds_lut, b, have_lo, have_hi);
+                    ((uint16_t*)lds_mask[0])[idx] = (uint16_t)m.e;
+                    ((uint16_t*)lds_mask[1])[idx] = (uint16_t)m.a;
+                    ((uint16_t*)lds_mask[2])[idx] = (uint16_t)m.f;
+                    ((uint16_t*)lds_mask[3])[idx] = (uint16_t)m.ma;
+                    ((uint16_t*)lds_mask[FAM == 1 ? 4 : 0])[idx] = (uint16_t)m.mb;
+                    ((uint16_t*)lds_mask[FAM == 1 ? 5 : 0])[idx] = (uint16_t)m.g;
+                } else {
+                    // token starts: the lane's walk for both cases, the cases composed along the wavefront
+                    const u32 lr = soff < 0 ? 0u : wv_dbcs_lead_mask(lds_lut, b, have_hi);
+                    u32 o0, o1;
+                    const u32 s0 = wv_dbcs_walk(lr, 0, &o0), s1 = wv_dbcs_walk(lr, 1, &o1);
+                    u32 fn = o0 | (o1 << 1);                       // bit c: how far the lane's last token hangs over if its first byte is at c
+                    const bool at_zero = soff == 0;                // the buffer's byte 0: the token pending on entry decides
+                    if (at_zero) { const u32 o = P.entry_skip ? o1 : o0; fn = o | (o << 1); }
+#pragma unroll
+                    for (u32 d = 1; d < 64; d <<= 1) {             // inclusive composition: fn_i o ... o fn_0
+                        const u32 g = wv_shfl(fn, lane >= d ? lane - d : lane);
+                        const u32 r = ((fn >> (g & 1u)) & 1u) | (((fn >> ((g >> 1) & 1u)) & 1u) << 1);
+                        if (lane >= d) fn = r;
+                    }
+                    const u32 out_here = (fn >> dbcs_cov) & 1u;
+                    u32 cov_in = wv_from_prev(out_here, dbcs_cov);
+                    if (at_zero) cov_in = P.entry_skip ? 1u : 0u;
+                    dbcs_cov = (u32)__builtin_amdgcn_readlane(out_here, 63);
+                    if ((long long)tile0 + (long long)(t + 1) * (long long)kTileBytes == (long long)next_t0) { cov_next = dbcs_cov; have_next = true; }
+                    if (t >= 0) {
+                        const WvMasks16D m = wv_classify16_dbcs(lds_lut, lds_pairs, b, have_lo, have_hi, lr, cov_in ? s1 : s0, cov_in);
+                        ((uint16_t*)lds_mask[0])[idx] = (uint16_t)m.e;
+                        ((uint16_t*)lds_mask[1])[idx] = (uint16_t)m.a;
+                        ((uint16_t*)lds_mask[2])[idx] = (uint16_t)m.f;
+                        ((uint16_t*)lds_mask[3])[idx] = (uint16_t)m.ma;
+                        ((uint16_t*)lds_mask[FAM == 4 ? 4 : 0])[idx] = (uint16_t)m.mb;
+                        ((uint16_t*)lds_mask[FAM == 4 ? 5 : 0])[idx] = (uint16_t)m.g;
+                        ((uint16_t*)lds_mask[FAM == 4 ? 6 : 0])[idx] = (uint16_t)m.o2;
+                        ((uint16_t*)lds_mask[FAM == 4 ? 7 : 0])[idx] = (uint16_t)m.o3;
+                        ((uint16_t*)lds_mask[FAM == 4 ? 8 : 0])[idx] = (uint16_t)m.o4;
+                    }
+                }
             }
         }
-        __syncthreads();
+        wave_lds_sync<WPB>();
+        if (FAM == 4) { dbcs_valid = have_next; if (have_next) dbcs_cov = cov_next; }   // (else the next batch walks back again)
 
         // ---- 2. lane = window
         WvWin w;
@@ -182,7 +258,14 @@ __global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
             if (FAM == 0)
                 w = wv_win_single(wv_extract(lds_mask[0], o, n), wv_extract(lds_mask[1], o, n), wv_extract(lds_mask[2], o, n),
                                   wv_extract(lds_mask[3], o, n), n, P.n_min);
-            else {
+            else if (FAM == 4) {
+                const u32 eb = o >= 1 ? (u32)wv_extract(lds_mask[0], o - 1, 1).lo : 1u, mab = o >= 1 ? (u32)wv_extract(lds_mask[3], o - 1, 1).lo : 0u;
+                const u32 fb1 = o >= 1 ? (u32)wv_extract(lds_mask[2], o - 1, 1).lo : 0u;
+                w = wv_win_dbcs(wv_extract(lds_mask[0], o, n), wv_extract(lds_mask[1], o, n), wv_extract(lds_mask[2], o, n),
+                                wv_extract(lds_mask[FAM == 4 ? 5 : 0], o, n), wv_extract(lds_mask[3], o, n), wv_extract(lds_mask[FAM == 4 ? 4 : 0], o, n),
+                                wv_extract(lds_mask[FAM == 4 ? 6 : 0], o, n), wv_extract(lds_mask[FAM == 4 ? 7 : 0], o, n),
+                                wv_extract(lds_mask[FAM == 4 ? 8 : 0], o, n), (eb | mab) != 0, fb1 != 0, ws > 0, ws % kWvSlice == 0, n, P.n_min);
+            } else {
                 const u32 fb = o >= 3 ? (u32)wv_extract(lds_mask[2], o - 3, 3).lo : 0u;
                 w = wv_win_utf8(wv_extract(lds_mask[0], o, n), wv_extract(lds_mask[1], o, n), wv_extract(lds_mask[2], o, n),
                                 wv_extract(lds_mask[FAM == 1 ? 5 : 0], o, n), wv_extract(lds_mask[3], o, n),
@@ -200,7 +283,7 @@ __global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
             if (todo && active) {
                 WvState st = wv_unpack(in);
                 CountEmit ce;
-                wv_window<FAM == 0>(WP, w, st, ce);
+                wv_window<(FAM == 0 ? 0 : FAM == 1 ? 1 : 2)>(WP, w, st, ce);
                 out = wv_pack(st); nf = ce.nf; nb = ce.nb;
             } else if (!active) out = in;
             u32 pin = wv_from_prev(out, carry);
@@ -225,10 +308,14 @@ __global__ __launch_bounds__(64) void wave_replay_kernel(const WaveParams P) {
             const u64 fo = fbase + tot_f + (excl >> 18), ao = abase + tot_b + (excl & 0x3FFFFu);
             WriteEmit we_{ &P, P.findings + fo, P.arena + ao, ao, ws };
             WvState st = wv_unpack(in);
-            wv_window<FAM == 0>(WP, w, st, we_);
+            wv_window<(FAM == 0 ? 0 : FAM == 1 ? 1 : 2)>(WP, w, st, we_);
         }
         tot_f += bt >> 18; tot_b += bt & 0x3FFFFu;
-        if (g0 + kWvBatch >= own_end && MODE == 0 && lane == 0) P.wave_out[v] = last_out;
+        if (g0 + kWvBatch >= own_end && MODE == 0) {
+            // (the state after a buffer's last window also says whether it ends inside a token: the next buffer's decoder holds that byte)
+            const u32 pend = FAM == 4 ? (u32)__builtin_amdgcn_readlane(w.tail_pend, last_lane) : 0u;
+            if (lane == 0) P.wave_out[v] = last_out | (own_end == P.g_hi && pend ? kWvPendBit : 0u);
+        }
     }
     if (MODE == 0 && lane == 0) { P.wave_nf[v] = tot_f; P.wave_nb[v] = tot_b; P.wave_in[v] = assumed_in; }
 }
@@ -263,9 +350,10 @@ hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint
     if (v1 <= v0) return hipSuccess;
     const uint64_t n = v1 - v0;
     WaveParams Q = P;
-    Q.v0 = v0;
-    if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<0, 1>), dim3((unsigned)n), dim3(64), 0, stream, Q);
-    else hipLaunchKernelGGL((wave_replay_kernel<0, 0>), dim3((unsigned)n), dim3(64), 0, stream, Q);
+    Q.v0 = v0; Q.v1 = v1;
+    if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, Q);
+    else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<0, 1, 1>), dim3((unsigned)n), dim3(64), 0, stream, Q);
+    else hipLaunchKernelGGL((wave_replay_kernel<0, 0, 1>), dim3((unsigned)n), dim3(64), 0, stream, Q);
     void* tmp = (void*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
     size_t tmp_bytes = scratch_bytes - (size_t)((uint8_t*)tmp - (uint8_t*)scratch);
     auto itf = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), U32ToU64{ P.wave_nf + v0 });
@@ -286,9 +374,10 @@ hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint
 hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipStream_t stream) {
     if (v1 <= v0) return hipSuccess;
     WaveParams Q = P;
-    Q.v0 = v0;
-    if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<1, 1>), dim3((unsigned)(v1 - v0)), dim3(64), 0, stream, Q);
-    else hipLaunchKernelGGL((wave_replay_kernel<1, 0>), dim3((unsigned)(v1 - v0)), dim3(64), 0, stream, Q);
+    Q.v0 = v0; Q.v1 = v1;
+    if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), 0, stream, Q);
+    else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<1, 1, 1>), dim3((unsigned)(v1 - v0)), dim3(64), 0, stream, Q);
+    else hipLaunchKernelGGL((wave_replay_kernel<1, 0, 1>), dim3((unsigned)(v1 - v0)), dim3(64), 0, stream, Q);
     return hipGetLastError();
 }
 

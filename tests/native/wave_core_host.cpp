@@ -25,6 +25,7 @@ struct WriteEmit {
     sx_finding* f;
     u8* a;
     u64 a_off, win_pos;
+    bool bad_len = false;   // the transcoded string is not as long as the count pass said
     void operator()(u32 din, u32 prec, bool completes, i32 src_rel, u32 src_len, u32 out_len) {
         const u64 soff = win_pos / kWvSlice * kWvSlice;
         sx_finding r;
@@ -33,9 +34,12 @@ struct WriteEmit {
         r.str_off = (u32)(a_off + P->str_off_base);
         r.str_len = out_len;
         if ((prec & 0xFFu) == WV_PROBE) {   // sx_wave_core.hpp WV_PROBE: this call starts at the slice's byte 0
-            const u32 lb = (prec >> 8) & 511u, lback = prec >> 17;
+            const u32 lb = (prec >> 8) & 511u, lback = (prec >> 17) & 1023u, hb = prec >> 27;
             const u64 avail = P->len - win_pos;
-            prec = wv_resolve_probe(P->data + win_pos, avail < 32 ? (u32)avail : 32u, P->data + (win_pos - lback), lb);
+            if (P->family == 4)   // (a leftover at a second call at byte 0: the byte in front of the slice was a lead byte, not the leftover's)
+                prec = wv_resolve_probe_dbcs((int)P->encoding, P->table, P->data + win_pos, avail < 32 ? (u32)avail : 32u,
+                                             P->data + (win_pos - lback), lb ? lback - 1 : 0u, lb, hb);
+            else prec = wv_resolve_probe(P->data + win_pos, avail < 32 ? (u32)avail : 32u, P->data + (win_pos - lback), lb);
         }
         r.precision = (u8)prec;
         r.completes_previous = completes ? 1 : 0;
@@ -44,7 +48,8 @@ struct WriteEmit {
         r.slice_index = (u32)(soff / kWvSlice) + P->slice_base;
         *f++ = r;
         const u8* s = P->data + (u64)((long long)win_pos + src_rel);
-        if (out_len == src_len) memcpy(a, s, src_len);
+        if (P->family == 4) { if (wv_transcode_dbcs((int)P->encoding, P->table, s, src_len, a) != out_len) bad_len = true; }
+        else if (out_len == src_len) memcpy(a, s, src_len);
         else {
             u32 w = 0;
             for (u32 t = 0; t < src_len; t++) {
@@ -69,7 +74,9 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
     u64 fbase = 0, abase = 0;
     if (MODE == 1) { fbase = P.wave_fbase[v] - P.f_sub; abase = P.wave_abase[v] - P.a_sub; }
     const WvParams WP{ P.q, P.n_min };
-    std::vector<u32> lds[6];
+    std::vector<u32> lds[9];
+    u32 dbcs_cov = 0;
+    bool dbcs_valid = false;
     for (auto& l : lds) l.assign(kWvMaxTiles * 32 + 8, 0xDEADBEEFu);   // stale bits must not matter
     for (u64 g0 = gw; g0 < own_end; g0 += kWvBatch) {
         u64 ws[64]; u32 wn[64]; bool active[64], owned[64];
@@ -84,44 +91,91 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
         const u64 tile0 = wv_tile0(span_lo);
         const u32 n_tiles = (u32)((span_hi - tile0 + kTileBytes - 1) / kTileBytes);
         if (n_tiles > kWvMaxTiles) return false;
-        for (u32 t = 0; t < n_tiles; t++)
+        int t_first = 0;
+        const u64 next_t0 = wv_tile0(span_hi);
+        bool have_next = false;
+        u32 cov_next = 0;
+        if (P.family == 4 && (g0 == gw || !dbcs_valid)) {   // as the kernel: back to a tile that holds a byte outside the lead range
+            dbcs_cov = 0;
+            long long lo = (long long)tile0;
+            while (lo > 0) {
+                lo -= kTileBytes; t_first--;
+                bool any = false;
+                for (u32 l = 0; l < 64 && !any; l++) {
+                    const long long o = lo + 16ll * l;
+                    if (o < 0) { any = true; break; }
+                    for (int k = 0; k < 16; k++) any = any || !(P.lut[P.data[o + k]] & WVC_LEAD);
+                }
+                if (any) break;
+            }
+        }
+        for (int t = t_first; t < (int)n_tiles; t++) {
+            u32 outs[64];
             for (u32 l = 0; l < 64; l++) {
-                const u64 off = tile0 + (u64)t * kTileBytes + 16ull * l;
+                const long long soff = (long long)tile0 + (long long)t * (long long)kTileBytes + 16ll * l;
+                const u64 off = soff < 0 ? 0ull : (u64)soff;
                 u32 xs[4] = { 0, 0, 0, 0 };
-                const u32 avail = off >= P.len ? 0u : (P.len - off >= 16 ? 16u : (u32)(P.len - off));
+                const u32 avail = soff < 0 || off >= P.len ? 0u : (P.len - off >= 16 ? 16u : (u32)(P.len - off));
                 for (u32 k = 0; k < avail; k++) xs[k >> 2] |= (u32)P.data[off + k] << (8 * (k & 3));
-                const u32 idx = t * 64 + l;
+                const u32 idx = (u32)(t < 0 ? 0 : t) * 64 + l;
                 if (P.family == 0) {
                     const WvMasks16 m = wv_classify16_single(P.lut, xs[0], xs[1], xs[2], xs[3], avail);
                     ((uint16_t*)lds[0].data())[idx] = (uint16_t)m.v;
                     ((uint16_t*)lds[1].data())[idx] = (uint16_t)m.a;
                     ((uint16_t*)lds[2].data())[idx] = (uint16_t)m.o2;
                     ((uint16_t*)lds[3].data())[idx] = (uint16_t)m.o3;
-                } else {
-                    u32 back = 0, ahead = 0, n_ahead = 0;
-                    if (off >= 4 && avail) memcpy(&back, P.data + off - 4, 4);
-                    if (avail == 16 && off + 16 < P.len) {
-                        n_ahead = P.len - (off + 16) >= 4 ? 4u : (u32)(P.len - (off + 16));
-                        for (u32 k = 0; k < n_ahead; k++) ahead |= (u32)P.data[off + 16 + k] << (8 * k);
-                    }
-                    u8 b[24];
-                    const u32 ws6[6] = { back, xs[0], xs[1], xs[2], xs[3], ahead };
-                    for (int k = 0; k < 24; k++) b[k] = (u8)(ws6[k >> 2] >> (8 * (k & 3)));
-                    const WvMasks16U m = wv_classify16_utf8(P.lut, b, off >= 4 ? 0u : 4u, 4u + avail + n_ahead);
+                    continue;
+                }
+                u32 back = 0, ahead = 0, n_ahead = 0;
+                if (off >= 4 && avail) memcpy(&back, P.data + off - 4, 4);
+                if (avail == 16 && off + 16 < P.len) {
+                    n_ahead = P.len - (off + 16) >= 4 ? 4u : (u32)(P.len - (off + 16));
+                    for (u32 k = 0; k < n_ahead; k++) ahead |= (u32)P.data[off + 16 + k] << (8 * k);
+                }
+                u8 b[24];
+                const u32 ws6[6] = { back, xs[0], xs[1], xs[2], xs[3], ahead };
+                for (int k = 0; k < 24; k++) b[k] = (u8)(ws6[k >> 2] >> (8 * (k & 3)));
+                const u32 have_lo = off >= 4 ? 0u : 4u, have_hi = 4u + avail + n_ahead;
+                if (P.family == 1) {
+                    const WvMasks16U m = wv_classify16_utf8(P.lut, b, have_lo, have_hi);
                     ((uint16_t*)lds[0].data())[idx] = (uint16_t)m.e;
                     ((uint16_t*)lds[1].data())[idx] = (uint16_t)m.a;
                     ((uint16_t*)lds[2].data())[idx] = (uint16_t)m.f;
                     ((uint16_t*)lds[3].data())[idx] = (uint16_t)m.ma;
                     ((uint16_t*)lds[4].data())[idx] = (uint16_t)m.mb;
                     ((uint16_t*)lds[5].data())[idx] = (uint16_t)m.g;
+                    continue;
                 }
+                // the two-byte family: the lanes in order (the kernel composes their in -> out functions along the wavefront)
+                const u32 lr = soff < 0 ? 0u : wv_dbcs_lead_mask(P.lut, b, have_hi);
+                u32 o0, o1;
+                const u32 s0 = wv_dbcs_walk(lr, 0, &o0), s1 = wv_dbcs_walk(lr, 1, &o1);
+                u32 cov_in = l == 0 ? dbcs_cov : outs[l - 1];
+                if (soff == 0) cov_in = P.entry_skip ? 1u : 0u;
+                outs[l] = cov_in ? o1 : o0;
+                if (l == 63) {
+                    dbcs_cov = outs[63];
+                    if ((long long)tile0 + (long long)(t + 1) * (long long)kTileBytes == (long long)next_t0) { cov_next = dbcs_cov; have_next = true; }
+                }
+                if (t < 0) continue;
+                const WvMasks16D m = wv_classify16_dbcs(P.lut, P.pairs, b, have_lo, have_hi, lr, cov_in ? s1 : s0, cov_in);
+                const u32 vals[9] = { m.e, m.a, m.f, m.ma, m.mb, m.g, m.o2, m.o3, m.o4 };
+                for (int k = 0; k < 9; k++) ((uint16_t*)lds[k].data())[idx] = (uint16_t)vals[k];
             }
+        }
+        if (P.family == 4) { dbcs_valid = have_next; if (have_next) dbcs_cov = cov_next; }
         WvWin w[64];
         for (u32 l = 0; l < 64; l++) {
             const u32 o = active[l] ? (u32)(ws[l] - tile0) : 0u, n = active[l] ? wn[l] : 0u;
             if (P.family == 0)
                 w[l] = wv_win_single(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[3], o, n), n, P.n_min);
-            else {
+            else if (P.family == 4) {
+                const u32 eb = o >= 1 ? (u32)wv_extract(lds[0], o - 1, 1).lo : 1u, mab = o >= 1 ? (u32)wv_extract(lds[3], o - 1, 1).lo : 0u;
+                const u32 fb1 = o >= 1 ? (u32)wv_extract(lds[2], o - 1, 1).lo : 0u;
+                w[l] = wv_win_dbcs(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[5], o, n),
+                                   wv_extract(lds[3], o, n), wv_extract(lds[4], o, n), wv_extract(lds[6], o, n), wv_extract(lds[7], o, n),
+                                   wv_extract(lds[8], o, n), (eb | mab) != 0, fb1 != 0, ws[l] > 0, ws[l] % kWvSlice == 0, n, P.n_min);
+            } else {
                 const u32 fb = o >= 3 ? (u32)wv_extract(lds[2], o - 3, 3).lo : 0u;
                 w[l] = wv_win_utf8(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[5], o, n),
                                    wv_extract(lds[3], o, n), wv_extract(lds[4], o, n), fb, ws[l] % kWvSlice == 0, n, P.n_min);
@@ -142,7 +196,9 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                 if (todo[l] && active[l]) {
                     WvState st = wv_unpack(in[l]);
                     CountEmit ce;
-                    if (P.family == 0) wv_window<true>(WP, w[l], st, ce, skip_idle); else wv_window<false>(WP, w[l], st, ce, skip_idle);
+                    if (P.family == 0) wv_window<0>(WP, w[l], st, ce, skip_idle);
+                    else if (P.family == 1) wv_window<1>(WP, w[l], st, ce, skip_idle);
+                    else wv_window<2>(WP, w[l], st, ce, skip_idle);
                     out[l] = wv_pack(st); nf[l] = ce.nf; nb[l] = ce.nb;
                 } else if (!active[l]) out[l] = in[l];
             }
@@ -168,14 +224,17 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                 const u64 fo = fbase + tot_f + bf, ao = abase + tot_b + bb;
                 WriteEmit we{ &P, P.findings + fo, P.arena + ao, ao, ws[l] };
                 WvState st = wv_unpack(in[l]);
-                if (P.family == 0) wv_window<true>(WP, w[l], st, we, skip_idle); else wv_window<false>(WP, w[l], st, we, skip_idle);
-                if ((u64)(we.f - (P.findings + fo)) != nf[l] || we.a_off - ao != nb[l]) return false;   // both passes must agree
+                if (P.family == 0) wv_window<0>(WP, w[l], st, we, skip_idle);
+                else if (P.family == 1) wv_window<1>(WP, w[l], st, we, skip_idle);
+                else wv_window<2>(WP, w[l], st, we, skip_idle);
+                if ((u64)(we.f - (P.findings + fo)) != nf[l] || we.a_off - ao != nb[l] || we.bad_len) return false;   // both passes must agree
             }
             bf += nf[l]; bb += nb[l];
         }
         if (bf >= (1u << 14) || bb >= (1u << 18)) return false;   // the kernels pack a batch's totals into 32 bits
         tot_f += bf; tot_b += bb;
-        if (g0 + kWvBatch >= own_end && MODE == 0) P.wave_out[v] = last_out;
+        if (g0 + kWvBatch >= own_end && MODE == 0)
+            P.wave_out[v] = last_out | (P.family == 4 && own_end == P.g_hi && w[n_act - 1].tail_pend ? kWvPendBit : 0u);
     }
     if (MODE == 0) { P.wave_nf[v] = tot_f; P.wave_nb[v] = tot_b; P.wave_in[v] = assumed_in; }
     return true;
@@ -188,12 +247,14 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
 extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0, uint32_t slice_base, uint32_t W, uint32_t q, uint32_t n_min,
                            uint64_t g_lo, uint32_t inject, uint32_t nwin, const uint8_t* lut, const uint16_t* table, int mission_id,
                            int file_id, sx_finding* fout, uint64_t fcap, uint8_t* aout, uint64_t acap, uint64_t* nf, uint64_t* nb,
-                           uint32_t* final_state, uint64_t* bad_waves, int skip_idle, uint32_t* rounds_max, uint32_t family) {
+                           uint32_t* final_state, uint64_t* bad_waves, int skip_idle, uint32_t* rounds_max, uint32_t family,
+                           const uint32_t* pairs, uint32_t encoding, uint32_t entry_skip) {
     WaveParams P;
     memset(&P, 0, sizeof P);
     P.data = data; P.len = len; P.consumed0 = consumed0; P.slice_base = slice_base; P.W = W; P.wps = wv_wps(W); P.q = q; P.n_min = n_min;
+    P.v0 = 0; P.v1 = ~0ull;
     P.g_lo = g_lo; P.g_hi = wv_window_count(len, W); P.nwin = nwin; P.inject = inject; P.mission_id = mission_id; P.file_id = file_id;
-    P.lut = lut; P.table = table; P.family = family;
+    P.lut = lut; P.table = table; P.family = family; P.pairs = pairs; P.encoding = encoding; P.entry_skip = entry_skip;
     *nf = *nb = 0; *bad_waves = 0; *final_state = inject; *rounds_max = 0;
     if (P.g_hi <= P.g_lo) return 0;
     const u64 n_waves = (P.g_hi - P.g_lo + nwin - 1) / nwin;

@@ -110,3 +110,28 @@ def test_wave_path_gives_up_and_the_other_path_takes_over(wave_forced):
         assert wave_windows_of_a_scan(ms, data) == 0
     finally:
         os.environ.pop("SX_WAVE_FAIL", None)
+
+
+from test_wave_core import DBCS_MISSIONS
+
+
+@pytest.mark.parametrize("di", range(len(DBCS_MISSIONS)))
+def test_wave_path_two_byte_family(wave_forced, di):
+    """Big5 / Shift_JIS / EUC-KR through the wave kernels: token starts composed along the wavefront, pair codes in LDS, buffers that
+    begin and end inside a token (16 KiB chunks), next to a UTF-8 Mission"""
+    from test_dbcs import soup as dbcs_soup, TEXT, CODEC
+    enc, flags = DBCS_MISSIONS[di]
+    ms = rc.missions(**dict(flags, encodings=flags["encodings"] + ["utf-8"]))
+    rng = random.Random(4000 + di)
+    txt = TEXT[enc].encode(CODEC[enc], "ignore")
+    datas = [("soup", dbcs_soup(enc, rng, 300_000)), ("random", rng.randbytes(200_000)), ("text", (txt + b"\n") * (100_000 // (len(txt) + 1))),
+             ("text no ascii", txt.replace(b" ", b"").replace(b"\n", b"") * 60), ("lead bytes", b"\xa4" * 9001 + b"A" + b"\xa4\xa4" * 5000 + b"\x00" * 300)]
+    for name, data in datas:
+        want = sxo.run_cli(ms, [data], radix="x")
+        for chunk, batches in ((None, None), (16384, "1"), (8192, "2")):
+            if batches:
+                os.environ["SX_WAVE_BATCHES"] = batches
+            else:
+                os.environ.pop("SX_WAVE_BATCHES", None)
+            assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (enc, name, chunk)
+    assert wave_windows_of_a_scan(ms[:1], datas[0][1]) > 0

@@ -32,7 +32,7 @@ def load_wave():
     L.sxw_emulate.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
                               C.c_uint32, C.c_char_p, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.POINTER(sx.Finding), C.c_uint64,
                               C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
-                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint32), C.c_uint32]
+                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
     L.sxw_pack_state.restype = C.c_uint32
     L.sxw_pack_state.argtypes = [C.c_uint32] * 4
     return L
@@ -51,7 +51,15 @@ def wave_classes(m):
     out = (C.c_uint8 * 256)()
     r = L.sx_wave_classes(C.byref(cm), out)
     assert r >= 0
-    return (bytes(out), r - 1) if r >= 1 else None   # (class table, family: 0 single byte, 1 UTF-8)
+    return (bytes(out), r - 1) if r >= 1 else None   # (class table, family: 0 single byte, 1 UTF-8, 4 the two-byte family)
+
+
+def wave_pairs(m):
+    L = sx.lib()
+    L.sx_wave_pair_codes.argtypes, L.sx_wave_pair_codes.restype = [C.POINTER(sx.Mission), C.POINTER(C.c_uint32)], C.c_void_p
+    out = (C.c_uint32 * 8192)()
+    cm = sx.Mission.from_dict(dict(m, mission_id=m.get("mission_id", 0)))
+    return out if L.sx_wave_pair_codes(C.byref(cm), out) else None
 
 
 PREC = {0: "Before", 1: "Exact", 2: "After"}
@@ -70,7 +78,7 @@ def emulate(L, m, data, nwin=508, skip_idle=1, g_lo=0, inject=0, consumed0=None)
     fin, rounds = C.c_uint32(), C.c_uint32()
     rcode = L.sxw_emulate(data, len(data), m["counter_offset"] if consumed0 is None else consumed0, 0, 2 * q, q, m["chars_min_nb"], g_lo,
                           inject, nwin, lut, table, 0, 1, fout, cap_f, aout, cap_a, C.byref(nf), C.byref(nb), C.byref(fin), C.byref(bad),
-                          skip_idle, C.byref(rounds), family)
+                          skip_idle, C.byref(rounds), family, wave_pairs(m) if family == 4 else None, m["encoding"], 0)
     assert rcode == 0, rcode
     arena = bytes(aout[:nb.value])
     got = []
@@ -149,6 +157,43 @@ MISSIONS = [
 ]
 
 
+DBCS_MISSIONS = [
+    ("big5", dict(encodings=["big5"], chars_min="10", unicode_block_filter="Cjk")),
+    ("big5", dict(encodings=["big5"], chars_min="3", output_line_len="8", unicode_block_filter="Asian")),
+    ("big5", dict(encodings=["big5"], chars_min="2", output_line_len="6", unicode_block_filter="Cjk", ascii_filter="None")),
+    ("shift_jis", dict(encodings=["shift_jis"], chars_min="4", unicode_block_filter="All")),
+    ("shift_jis", dict(encodings=["shift_jis"], chars_min="10", unicode_block_filter="Kana")),
+    ("shift_jis", dict(encodings=["shift_jis"], chars_min="2", output_line_len="6", unicode_block_filter="All", ascii_filter="All")),
+    ("euc-kr", dict(encodings=["euc-kr"], chars_min="4", unicode_block_filter="All")),
+    ("euc-kr", dict(encodings=["euc-kr"], chars_min="20", output_line_len="20", unicode_block_filter="Hangul")),
+]
+
+
+@pytest.mark.parametrize("di", range(len(DBCS_MISSIONS)))
+def test_emulated_wave_pipeline_two_byte_family(wave, di):
+    """Big5, Shift_JIS, EUC-KR: token starts composed lane to lane, pair codes, pending lead bytes at window and slice starts"""
+    from test_dbcs import soup as dbcs_soup, TEXT, CODEC
+    enc, flags = DBCS_MISSIONS[di]
+    m = rc.missions(**flags)[0]
+    assert wave_classes(m)[1] == 4
+    rng = random.Random(3000 + di)
+    txt = TEXT[enc].encode(CODEC[enc], "ignore")
+    datas = [("soup", dbcs_soup(enc, rng, 120_000)), ("random", rng.randbytes(90_000)), ("text", (txt + b"\n") * (60_000 // (len(txt) + 1))),
+             ("text no ascii", txt.replace(b" ", b"").replace(b"\n", b"") * 40), ("lead bytes", b"\xa4" * 5000 + b"A" + b"\xa4\xa4" * 3000 + b"\x00" * 300),
+             ("ascii", text_lines(rng, 50_000)), ("short tail", dbcs_soup(enc, rng, 4096 * 3 + 77))]
+    for name, data in datas:
+        want = oracle_findings([dict(m, mission_id=0)], data)
+        for nwin, skip in ((508, 1), (60, 0), (7, 1)):
+            got, info = emulate(wave, m, data, nwin=nwin, skip_idle=skip)
+            assert info["bad"] == 0, (name, nwin, info)
+            assert got == want, (enc, name, nwin, skip, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
+
+
+def test_big5_missions_that_accept_the_two_code_point_tokens_stay_on_the_other_path():
+    for ubf in ("All", "Common", "Latin"):
+        assert wave_classes(rc.missions(encodings=["big5"], chars_min="4", unicode_block_filter=ubf)[0]) is None, ubf
+
+
 @pytest.mark.parametrize("mi", range(len(MISSIONS)))
 def test_emulated_wave_pipeline_equals_the_oracle(wave, mi):
     m = rc.missions(**MISSIONS[mi])[0]
@@ -165,5 +210,5 @@ def test_missions_the_wave_path_does_not_cover():
     for kw in (dict(encodings=["ascii"], chars_min="4", grep_char="47"), dict(encodings=["ascii"], chars_min="4", same_unicode_block=True),
                dict(encodings=["ascii"], chars_min="0"), dict(encodings=["ascii"], chars_min="70"),
                dict(encodings=["ascii"], chars_min="4", output_line_len="100"), dict(encodings=["utf-16le"], chars_min="4"),
-               dict(encodings=["big5"], chars_min="4")):
+               dict(encodings=["big5"], chars_min="4"), dict(encodings=["euc-jp"], chars_min="4"), dict(encodings=["gbk"], chars_min="4")):
         assert wave_classes(rc.missions(**kw)[0]) is None, kw
