@@ -147,7 +147,7 @@ struct BufferScan {
                 one[0].complete = true;
             } else if (unscanned && wave_replay_wanted(ctx, job, k, len)) {   // no stage A: "as dense as the last buffer"
                 one.assign(1, RunList{});
-                one[0].n = len / 64; one[0].skipped = true; one[0].complete = true;
+                one[0].n = len / 16; one[0].skipped = true; one[0].complete = true;
                 ctx->stats.bytes_scanned += len;
             } else {
                 if (unscanned) {   // (not launched with the others, but the job is not one for the wave kernels after all)

@@ -17,10 +17,13 @@ using namespace sx;
 
 namespace sx {
 
-// runs per byte from which the wave kernels are the cheaper stage B (measured: ~1.2 ns per run there, ~2.5 ps per byte here)
-static uint64_t wave_min_density_bytes() {
-    static const uint64_t v = [] { const char* e = getenv("SX_WAVE_BYTES_PER_RUN"); return e ? (uint64_t)atoll(e) : 480ull; }();
-    return v;
+// bytes per run below which the wave kernels are the cheaper stage B.  Measured on the MI355X: the lane-per-region path costs
+// ~1.2 ns per run (single byte, UTF-8) / ~3 ns (two-byte family), the wave kernels ~2.5 ps per input byte — ~28 ps for the two-byte
+// family, whose token walk per lane is still scalar code: Big5 on random bytes (a run per 470 bytes) stays on the other path,
+// CJK text (a run per line) comes here.
+static uint64_t wave_min_density_bytes(uint32_t family = 0) {
+    static const uint64_t v = [] { const char* e = getenv("SX_WAVE_BYTES_PER_RUN"); return e ? (uint64_t)atoll(e) : 0ull; }();
+    return v ? v : (family == 4 ? 100ull : 480ull);
 }
 
 bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs) {
@@ -31,7 +34,7 @@ bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_
     if (ctx->opt.flags & SX_OPT_HOST_REPLAY) return false;
     if (const char* e = getenv("SX_WAVE_REPLAY")) return atoi(e) != 0;
     if (getenv("SX_HOST_REPLAY") || getenv("SX_HOST_STITCH") || getenv("SX_NO_REPLAY_CACHE")) return false;   // tests of the other path
-    return (uint64_t)n_runs * wave_min_density_bytes() > job.len;
+    return (uint64_t)n_runs * wave_min_density_bytes(m.wave_family) > job.len;
 }
 
 static uint32_t utf8_chars(const std::string& s) {
@@ -244,7 +247,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
     out->replay_bytes += len;
     ctx->stats.wave_windows += g_all - g_lo;
     // the next whole buffer of this Mission does without stage A (sx_schedule.cpp) as long as this one was string-dense
-    if (k < ctx->wave_pred.size()) ctx->wave_pred[k] = (nf_all + nfh) * wave_min_density_bytes() * 2 > len ? 1 : 0;
+    if (k < ctx->wave_pred.size()) ctx->wave_pred[k] = (nf_all + nfh) * wave_min_density_bytes(m.wave_family) * 2 > len ? 1 : 0;
     const double t1 = now_ms();
 
     // ---- the state handed to the next buffer
