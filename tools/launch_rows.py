@@ -13,6 +13,10 @@ m0, m1 = fills[-2], fills[-1]
 def cls(i):
     return "warm-up" if i < m0 else "timed" if i < m1 else "alone"
 want = ("scan_kernel", "wave_replay_kernel")
+# a scan kernel launched AGAIN (its records did not fit: larger regions or the shared pool) runs on the library's second stream
+import collections
+scan_stream = collections.Counter(r.get("Stream_Id") for r in rows if "scan_kernel" in r["Kernel_Name"]).most_common(1)
+scan_stream = scan_stream[0][0] if scan_stream else None
 agg = {}
 for i, r in enumerate(rows):
     n = r["Kernel_Name"]
@@ -20,7 +24,10 @@ for i, r in enumerate(rows):
         continue
     name = n.split("(")[0].replace("void ", "").replace("sx::", "")
     ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-    agg.setdefault((name, cls(i)), []).append(ms)
+    c = cls(i)
+    if "scan_kernel" in n and r.get("Stream_Id") != scan_stream:
+        c += " (launched again)"
+    agg.setdefault((name, c), []).append(ms)
 print("kernel,class,launches,avg_ms,min_ms,max_ms,gbs_at_avg")
 tot_ms = tot_launch = 0
 for (name, c), v in sorted(agg.items()):
@@ -33,3 +40,11 @@ if tot_launch:
     frac = tot_launch * nbytes / (tot_ms * 1e-3) / 1e9 / 8000.0
     print(f'# scan launches inside the timed region: {tot_launch} launches, {tot_ms:.3f} ms -> {tot_launch * nbytes / (tot_ms * 1e-3) / 1e9:.1f} GB/s = {frac:.4f} of the 8 TB/s peak '
           f'(bench.py in the same run: {bench["roofline"]["frac"]}); a step = {tot_ms / bench["steps"]:.3f} ms of scan launches')
+# string-dense Missions: their passes over the input are the wave kernels' count pass (MODE 0) and write pass (MODE 1); a pass of a
+# single Mission is cut into slabs, i.e. several launches.  bench.py's figure for them comes from HIP events around each pass
+# (the verify kernel and the two prefix sums between count and write are inside), so it is a little above these sums.
+wave = {m: sum(sum(v) for (name, c), v in agg.items() if c == "timed" and name.startswith("wave_replay_kernel<%d," % m)) for m in (0, 1)}
+if wave[0] or wave[1]:
+    wp = bench["roofline"].get("wave_passes_ms", {})
+    print(f'# wave kernels inside the timed region, per step: count pass {wave[0] / bench["steps"]:.3f} ms, write pass {wave[1] / bench["steps"]:.3f} ms '
+          f'(bench.py in the same run, events around the passes: {wp.get("count")} / {wp.get("write")} ms for {wp.get("missions")} Mission(s))')
