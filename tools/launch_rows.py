@@ -12,29 +12,33 @@ fills = [i for i, r in enumerate(rows) if "fill_kernel" in r["Kernel_Name"]]
 m0, m1 = fills[-2], fills[-1]
 def cls(i):
     return "warm-up" if i < m0 else "timed" if i < m1 else "alone"
-want = ("scan_kernel", "wave_replay_kernel")
-# a scan kernel launched AGAIN (its records did not fit: larger regions or the shared pool) runs on the library's second stream
-import collections
-scan_stream = collections.Counter(r.get("Stream_Id") for r in rows if "scan_kernel" in r["Kernel_Name"]).most_common(1)
-scan_stream = scan_stream[0][0] if scan_stream else None
+import re
+want = re.compile(r"\bsx::(scan_kernel(_dbcs)?|wave_replay_kernel)<")
+is_scan = lambda name: name.startswith("scan_kernel")
+# Warm-up launches are listed one by one: that is where a Mission's first launch finds its record regions too small and is launched
+# AGAIN with larger ones (the library then remembers the size: bench.py's "scan_kernels_launched_again" counts them per timed step).
+# The "alone" launches too: 1 and 2 start on an idle chip (bench.py's per_kernel_ms_alone = the faster one), 3 and 4 are a pair queued
+# back to back (SX_SCAN_WARM=1), 4 being per_kernel_ms_alone_behind_an_identical_launch.
 agg = {}
+seen_warm = {}
 for i, r in enumerate(rows):
     n = r["Kernel_Name"]
-    if not any(w in n for w in want):
+    if not want.search(n):
         continue
     name = n.split("(")[0].replace("void ", "").replace("sx::", "")
     ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     c = cls(i)
-    if "scan_kernel" in n and r.get("Stream_Id") != scan_stream:
-        c += " (launched again)"
+    if c != "timed" and is_scan(name):
+        seen_warm[(name, c)] = seen_warm.get((name, c), 0) + 1
+        c = "%s launch %d" % (c, seen_warm[(name, c)])
     agg.setdefault((name, c), []).append(ms)
 print("kernel,class,launches,avg_ms,min_ms,max_ms,gbs_at_avg")
 tot_ms = tot_launch = 0
 for (name, c), v in sorted(agg.items()):
     avg = sum(v) / len(v)
-    per_launch_bytes = nbytes if "scan_kernel" in name else nbytes / max(1, len(v) / max(1, bench["steps"]) ) if c == "timed" else nbytes
+    per_launch_bytes = nbytes if is_scan(name) else nbytes / max(1, len(v) / max(1, bench["steps"]) ) if c == "timed" else nbytes
     print(f'"{name}",{c},{len(v)},{avg:.3f},{min(v):.3f},{max(v):.3f},{per_launch_bytes / (avg * 1e-3) / 1e9:.1f}')
-    if c == "timed" and "scan_kernel" in name:
+    if c == "timed" and is_scan(name):
         tot_ms += sum(v); tot_launch += len(v)
 if tot_launch:
     frac = tot_launch * nbytes / (tot_ms * 1e-3) / 1e9 / 8000.0
