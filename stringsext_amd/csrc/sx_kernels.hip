@@ -355,6 +355,7 @@ struct Emitter {
     u32 base, left;  // my current block: slots [base, base+left) are still free
     u32 region_cap, rcount;
     u32* region_counts;
+    u32 heavy_n = 0;   // tiles of this sub-chunk that took the general path (a statistic: one atomic per sub-chunk, not per tile)
 
     SX_DEV void begin_region(u64 wave) {
         if (region_cap) { base = (u32)wave * region_cap; rcount = 0; }
@@ -362,6 +363,8 @@ struct Emitter {
     // (records beyond the region's room are only counted; one atomic per sub-chunk — one per append made the scan of a
     // string-dense buffer 30x slower: a single word takes ~90 atomics per microsecond)
     SX_DEV void end_region(u64 wave) {
+        if (heavy_n && lane_id() == 0) atomicAdd(counters + 1, heavy_n);
+        heavy_n = 0;
         if (region_cap && lane_id() == 0) {
             region_counts[wave] = rcount < region_cap ? rcount : region_cap;
             if (rcount) atomicAdd(counters + 2, rcount);               // all records of the launch (stage A's host side: how dense is the input?)
@@ -465,7 +468,7 @@ SX_DEV bool light_path(u32 w, u32 sw, u32 r, u64 lane_base, Emitter& em, u32 min
 // tile's lane 63 (only read if an untracked stretch is open on entry).
 // `first_tile`: the tile starts a sub-chunk: a stretch that is open on entry is clipped to
 // the sub-chunk start and flagged kRecStartOpen (the previous wave reports the part before).
-SX_DEV void heavy_path(u32 g, u32 s, u32 g_raw, u32 g63_in, u32 s63, u64 tile_base, u64 tile_end, Carry& c,
+SX_DEV void heavy_path(u32 g, u32 s, u32 g_raw, u32 g63_in, u32 s63, u32 r16, u64 tile_base, u64 tile_end, Carry& c,
                        Emitter& em, u32 min_chars, u32 cand_bytes, bool first_tile) {
     const u32 lane = lane_id();
     g &= 0xFFFFu;
@@ -517,26 +520,36 @@ SX_DEV void heavy_path(u32 g, u32 s, u32 g_raw, u32 g63_in, u32 s63, u64 tile_ba
         left_flags = open ? oflags : 0u;
     }
 
-    // -- walk my own stretches, lowest first
-    u32 nb0 = from_next(g & 1u, 2u);  // lane 63: the next tile is not classified yet
-    u32 rem = g;
-    u32 my_open = 0, my_och = 0, my_ofl = 0;
-    u64 my_ostart = 0;
-    while (__ballot(rem != 0)) {
-        bool has = rem != 0;
-        u32 st = has ? (u32)__builtin_ctz(rem) : 0u;
-        u32 ln = (u32)__builtin_ctz(~(rem >> st));
-        u32 en = st + ln;
-        u32 field = ((1u << ln) - 1u) << st;
+    // -- my stretches that can matter (round 3; before, every stretch of the lane went through the loop: up to eight rounds of
+    //    ballot + append per tile where one or two matter).  r16: bit e set iff the cand_bytes bytes up to my byte e are all good —
+    //    a record needs min_chars characters, i.e. at least cand_bytes bytes.  So: the closed stretches whose end bit is in r16, the
+    //    closed stretch at my byte 0 that carries flags from the left (the part of a stretch cut at the sub-chunk start is reported
+    //    whatever its length), and — without a loop — the stretch still open at the tile end.
+    const u32 nb0 = from_next(g & 1u, 2u);  // lane 63: the next tile is not classified yet -> "goes on"
+    const u64 lane_base = tile_base + 16ull * lane;
+    u32 ends = g & ~(g >> 1);
+    if (nb0) ends &= 0x7FFFu;
+    u32 cand = ends & r16;
+    if ((g & 1u) && left_flags) cand |= ends & (1u << ((u32)__builtin_ctz(~g) - 1u));   // (~g has a bit above 15 at the latest)
+    while (__ballot(cand != 0)) {
+        const bool has = cand != 0;
+        const u32 e = has ? (u32)__builtin_ctz(cand) : 0u;
+        const u32 zb = ~g & ((1u << e) - 1u);
+        const u32 st = zb ? 32u - (u32)__clz((int)zb) : 0u;
+        const u32 field = ((2u << e) - 1u) & ~((1u << st) - 1u);
         u32 ch = (u32)__popc(s & field);
-        u64 start = tile_base + 16ull * lane + st;
+        u64 start = lane_base + st;
         u32 flags = 0;
         if (st == 0) { ch += left_chars; start = left_start; flags = left_flags; }
-        bool closed = en < 16u || nb0 == 0u;
-        u64 end = tile_base + 16ull * lane + en;
-        em.append(has && closed && (ch >= min_chars || flags), start, end, ch, flags);
-        if (has && !closed && lane == 63) { my_open = 1; my_ostart = start; my_och = ch; my_ofl = flags; }
-        rem &= ~field;
+        em.append(has && (ch >= min_chars || flags), start, lane_base + e + 1u, ch, flags);
+        cand &= cand - 1u;
+    }
+    u32 my_open = 0, my_och = 0, my_ofl = 0;
+    u64 my_ostart = 0;
+    if (lane == 63 && (g & 0x8000u)) {   // open at the tile end
+        my_open = 1;
+        if (all) { my_ostart = left_start; my_och = left_chars + cnt; my_ofl = left_flags; }
+        else { my_ostart = lane_base + (16u - trail1); my_och = trail_chars; }
     }
 
     // -- state for the next tile
@@ -663,9 +676,9 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
             if (!tracked_in && !first_open) done = light_path(w, sw, r, lane_base, em, p.min_chars);
             if (done) c.g63 = g63_out;
             else {
-                if (lane == 0) atomicAdd(p.counters + 1, 1u);
+                em.heavy_n++;
                 const u64 tile_end = tile_base + kTileBytes < sub_end ? tile_base + kTileBytes : sub_end;
-                heavy_path(gf, s, g, g63_in, s63, tile_base, tile_end, c, em, p.min_chars, p.cand_bytes, first_tile);
+                heavy_path(gf, s, g, g63_in, s63, r >> 16, tile_base, tile_end, c, em, p.min_chars, p.cand_bytes, first_tile);
             }
         }
         cur = nxt; nxt = nn; toff += kTileBytes; t++;
@@ -1122,9 +1135,9 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
             if (!tracked_in && !first_open) done = light_path(w, sw, r, lane_base, em, p.min_chars);
             if (done) c.g63 = g63_out;
             else {
-                if (lane == 0) atomicAdd(p.counters + 1, 1u);
+                em.heavy_n++;
                 const u64 tile_end = tile_base + kTileBytes < sub_end ? tile_base + kTileBytes : sub_end;
-                heavy_path(gf, sf, g, g63_in, s63_in, tile_base, tile_end, c, em, p.min_chars, p.cand_bytes, first_tile);
+                heavy_path(gf, sf, g, g63_in, s63_in, r >> 16, tile_base, tile_end, c, em, p.min_chars, p.cand_bytes, first_tile);
             }
         }
         cur = nxt; nxt = nn; toff += kTileBytes; t++;
