@@ -288,7 +288,15 @@ int sx_replay_shard_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t buf_off, ui
  * and the runs of the buffer come from the caller (host bytes; CPU tests, runs from elsewhere).
  * *out = this rank's findings (segment `rank` of the file's findings, in order); counts[k] / overflow[k] (arrays of
  * `world`, may be NULL) = findings of rank k / how many of its last findings lie behind its range end.  Gathering the
- * Finding buffers is the caller's (e.g. one gather over RCCL); sx_shard_splice() puts gathered buffers in order. */
+ * Finding buffers is the caller's (e.g. one gather over RCCL); sx_shard_splice() puts gathered buffers in order.
+ * Errors: what does not depend on the rank (a Mission with chars_min_nb == 0 or ISO-2022-JP and world > 1, ...) is refused on
+ * every rank before anything is exchanged; a rank whose own work fails (memory, HIP, its buffer callback) still joins the
+ * exchange with its error code in its row, and EVERY rank returns an error in that round (SX_E_STATE on the healthy ones).
+ * A stream of several files: call once per file, in order, on every rank, with file_stream_off = the bytes of the files
+ * before.  The state the reference carries from file to file (decoder, leftover, cut flag: src/main.rs:153-168, one
+ * ScannerState per Mission for the whole stream) is known to the last rank at the end of a file; it travels to all ranks in
+ * one more all-gather of the same callback (<= sizeof decoder + 4q + 40 bytes per Mission) and enters the next file's first
+ * shard, so the result is what one process scanning the files in a row gives. */
 typedef int (*sx_allgather_fn)(void* user, const void* send, uint64_t bytes, void* recv);
 typedef int (*sx_shard_buffer_fn)(void* user, uint64_t lo, uint64_t hi, const void** ptr, int* is_device);
 typedef int (*sx_shard_runs_fn)(void* user, const uint8_t* bytes, uint64_t buf_off, uint64_t buf_len,

@@ -53,7 +53,7 @@ struct CountEmit {
 };
 
 // pass 2: the finding record and its string (single byte: transcoded byte by byte through the decoder table)
-struct WriteEmit {
+template <int FAM> struct WriteEmit {   // (FAM: the family's code only — the two-byte family's probe brings 384 B of scratch with it)
     const WaveParams* P;
     sx_finding* f;        // next record of this lane
     u8* a;                // next string byte of this lane
@@ -68,10 +68,11 @@ struct WriteEmit {
         if ((prec & 0xFFu) == WV_PROBE) {   // sx_wave_core.hpp WV_PROBE: this call starts at the slice's byte 0
             const u32 lb = (prec >> 8) & 511u, lback = (prec >> 17) & 1023u, hb = prec >> 27;
             const u64 avail = P->len - win_pos;
-            if (P->family == 4)   // (a leftover at a second call at byte 0: the byte in front of the slice was a lead byte, not the leftover's)
+            if (FAM == 4)   // (a leftover at a second call at byte 0: the byte in front of the slice was a lead byte, not the leftover's)
                 prec = wv_resolve_probe_dbcs((int)P->encoding, P->table, P->data + win_pos, avail < 32 ? (u32)avail : 32u,
                                              P->data + (win_pos - lback), lb ? lback - 1 : 0u, lb, hb);
-            else prec = wv_resolve_probe(P->data + win_pos, avail < 32 ? (u32)avail : 32u, P->data + (win_pos - lback), lb);
+            else if (FAM == 1) prec = wv_resolve_probe(P->data + win_pos, avail < 32 ? (u32)avail : 32u, P->data + (win_pos - lback), lb);
+            else prec = WV_EXACT;   // (single-byte decoders never leave the probe open)
         }
         r.precision = (u8)prec;
         r.completes_previous = completes ? 1 : 0;
@@ -82,7 +83,7 @@ struct WriteEmit {
         r.slice_index = (u32)(soff / kWvSlice) + P->slice_base;
         *f++ = r;
         const u8* s = P->data + (u64)((long long)win_pos + src_rel);
-        if (P->family == 4) (void)wv_transcode_dbcs((int)P->encoding, P->table, s, src_len, a);
+        if (FAM == 4) (void)wv_transcode_dbcs((int)P->encoding, P->table, s, src_len, a);
         else if (out_len == src_len) {     // every char is one byte on both sides (ASCII; UTF-8 input)
             for (u32 t = 0; t < src_len; t++) a[t] = s[t];
         } else {
@@ -108,7 +109,7 @@ constexpr int wv_n_masks(int fam) { return fam == 4 ? 9 : fam == 1 ? 6 : 4; }
 // MODE 0: count; 1: write.  FAM 0: single-byte decoders; 1: UTF-8; 4: the two-byte family (Big5, Shift_JIS, EUC-KR: 4 wavefronts
 // per block share the 32 KB of pair codes in LDS).
 template <int MODE, int FAM, int WPB>
-__global__ __launch_bounds__(64 * WPB) void wave_replay_kernel(const WaveParams P) {
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(FAM == 4 ? 2 : 4))) void wave_replay_kernel(const WaveParams P) {
     // FAM 0: valid, accepted, O2, O3; FAM 1: E, A, F, MA, MB, G; FAM 4: E, A, F, MA, MB, G, O2, O3, O4 — 16 bits per lane and tile
     __shared__ u32 lds_mask_all[WPB][wv_n_masks(FAM)][kWvMaxTiles * 32 + 8];
     __shared__ u8 lds_lut[256];
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(64 * WPB) void wave_replay_kernel(const WaveParams 
         if (MODE == 1 && (nf | nb)) {
             const u32 excl = incl - packed;
             const u64 fo = fbase + tot_f + (excl >> 18), ao = abase + tot_b + (excl & 0x3FFFFu);
-            WriteEmit we_{ &P, P.findings + fo, P.arena + ao, ao, ws };
+            WriteEmit<FAM> we_{ &P, P.findings + fo, P.arena + ao, ao, ws };
             WvState st = wv_unpack(in);
             wv_window<(FAM == 0 ? 0 : FAM == 1 ? 1 : 2)>(WP, w, st, we_);
         }
