@@ -147,8 +147,17 @@ struct Utf8Range2 {
         l1 = rep4(0x80u - (p.u_lo & 0x7F));  // leads are >= 0x80: compare the low 7 bits
         l2 = rep4(0x7Fu - (p.u_hi & 0x7F));
     }
+    // Round 3: l[] keeps the garbage of its two additions below bit 7 — it only ever meets c[], which is clean (one AND less per dword);
+    // LA: the continuation flags behind my 16 bytes are the NEXT lane's c[0], fetched by DPP (c_edge = the flags of the dword behind
+    // lane 63's bytes, wave-uniform) instead of the next lane's raw dword classified a second time (3 VALU less per tile); not for tiles
+    // near the end of the input (`avail`), nor where all lanes hold the same bytes (starts_before).
+    static constexpr bool kLa = true;
     template <bool WANT_S>
-    SX_DEV u32 classify(u32x4 x, u32 nx, u32 avail, bool near_end) const {
+    SX_DEV u32 classify_la(u32x4 x, u32 c_edge) const { return classify_impl<WANT_S, true>(x, c_edge, 32u, false); }
+    template <bool WANT_S>
+    SX_DEV u32 classify(u32x4 x, u32 nx, u32 avail, bool near_end) const { return classify_impl<WANT_S, false>(x, nx, avail, near_end); }
+    template <bool WANT_S, bool LA>
+    SX_DEV u32 classify_impl(u32x4 x, u32 nx, u32 avail, bool near_end) const {
         u32 xs[5] = { x.x, x.y, x.z, x.w, nx };
         if (near_end) {
 #pragma unroll
@@ -159,10 +168,10 @@ struct Utf8Range2 {
         for (int k = 0; k < 4; k++) {
             u32 v = xs[k], t = v & 0x7F7F7F7Fu;
             a[k] = ((t + a1) & ~(t + a2)) & ~v & kM;
-            l[k] = ((t + l1) & ~(t + l2)) & v & kM;
+            l[k] = ((t + l1) & ~(t + l2)) & v;
             c[k] = v & ~(v << 1) & kM;
         }
-        c[4] = xs[4] & ~(xs[4] << 1) & kM;
+        c[4] = LA ? from_next(c[0], nx) : (xs[4] & ~(xs[4] << 1) & kM);
         u32 p[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) p[k] = l[k] & __builtin_amdgcn_alignbyte(c[k + 1], c[k], 1);
@@ -174,6 +183,11 @@ struct Utf8Range2 {
         return movemask16(g0, g1, g2, g3) | ((p[3] >> 31) << 16);
     }
 };
+
+template <class T, class = void> struct has_la : std::false_type {};
+template <class T> struct has_la<T, std::void_t<decltype(T::kLa)>> : std::true_type {};
+template <class C> SX_DEV std::enable_if_t<has_la<C>::value, u32> classify_la_of(const C& c, u32x4 x, u32 c_edge) { return c.template classify_la<false>(x, c_edge); }
+template <class C> SX_DEV std::enable_if_t<!has_la<C>::value, u32> classify_la_of(const C&, u32x4, u32) { return 0u; }
 
 // --- UTF-8, any af/ubf: class LUT (LDS, 256 B: one dword per bank -> conflict free) -------
 // class byte: bits 0-2 continuation class one-hot (80-8F, 90-9F, A0-BF);
@@ -483,7 +497,7 @@ SX_DEV void heavy_path(u32 g, u32 s, u32 g_raw, u32 g63_in, u32 s63, u32 r16, u6
     } else if (g63_in & 0x8000u) {
         open = true;
         if (first_tile) { ostart = tile_base; ochars = 0; oflags = kRecStartOpen; }
-        else {  // shorter than cand_bytes <= 17 bytes: it lies inside lane 63 of the previous tile
+        else {  // shorter than cand_bytes <= 16 bytes: it lies inside lane 63 of the previous tile
             u32 suf = trailing_ones16(g63_in & 0xFFFFu);
             ostart = tile_base - suf;
             ochars = (u32)__popc((s63 & 0xFFFFu) >> (16u - suf));
@@ -649,18 +663,23 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
 
         const u32 g63_in = c.g63;  // previous tile's lane 63 (by value: c is rewritten below)
         const bool tracked_in = c.tracked != 0;
-        const u32 nx = from_next(cur.x, bcast(nxt.x, 0));
-        const u32 g = cls.template classify<false>(cur, nx, avail, NE);
+        constexpr bool LA = has_la<CLS>::value && !NE;
+        u32 g;
+        if constexpr (LA) {
+            const u32 e = bcast(nxt.x, 0);                 // the dword behind lane 63's bytes: its continuation flags, on the scalar side
+            g = classify_la_of(cls, cur, e & ~(e << 1) & kM);
+        } else g = cls.template classify<false>(cur, from_next(cur.x, bcast(nxt.x, 0)), avail, NE);
         const u32 pg = from_prev(g, g63_in);
         const u32 gf = (g & 0xFFFFu) | (pg >> 16);       // final good mask of my 16 bytes
-        const u32 pgf = from_prev(gf, g63_in) & 0xFFFFu;  // final mask of the 16 bytes before mine
         const u32 g63_out = bcast(gf | (g & 0xFFFF0000u), 63);
 
-        // r: bit q set iff bits q-cand_bytes+1 .. q of the window are all set
-        const u32 w = (gf << 16) | pgf;
+        // r: bit q set iff bits q-cand_bytes+1 .. q of the window (my 16 bytes above the 16 before them) are all set.  The window's bit 0
+        // is the one bit of the previous lane that ITS predecessor's spill can set; cand_bytes is <= 16 (sx_stage_a.cpp), so no bit of r above 15 looks
+        // at it, so the candidate test takes the previous lane's mask as the first DPP delivered it (the slow paths get the exact
+        // window); four doubling steps reach 16.
+        u32 w = __builtin_amdgcn_perm(gf, pg, 0x05040100u);   // gf << 16 | pg & 0xFFFF
         u32 r = w;
-        r &= r << p.cand_sh[0]; r &= r << p.cand_sh[1]; r &= r << p.cand_sh[2];
-        r &= r << p.cand_sh[3]; r &= r << p.cand_sh[4];
+        r &= r << p.cand_sh[0]; r &= r << p.cand_sh[1]; r &= r << p.cand_sh[2]; r &= r << p.cand_sh[3];   // (1 + 1 + 2 + 4 + 8 = 16 >= cand_bytes)
         const bool any_cand = __ballot((r & 0xFFFF0000u) != 0) != 0;
         const bool first_tile = t == 0;
         const bool first_open = first_tile && (g63_in & 0x8000u);
@@ -669,7 +688,9 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
             // fast path (and the look-back tile, of which only the classification state matters)
             c.g63 = g63_out;
         } else {
+            const u32 nx = from_next(cur.x, bcast(nxt.x, 0));
             const u32 s = cls.template classify<true>(cur, nx, avail, NE);
+            w = (gf << 16) | (from_prev(gf, g63_in) & 0xFFFFu);   // the exact window
             const u32 s63 = (g63_in & 0x8000u) ? starts_before(toff, tile_base, near_tag) : 0u;
             const u32 sw = (s << 16) | (from_prev(s, s63) & 0xFFFFu);
             bool done = false;
