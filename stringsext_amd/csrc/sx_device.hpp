@@ -48,7 +48,7 @@ struct ScanParams {
     uint64_t len;          // chunk bytes
     uint32_t subchunk;     // bytes per wavefront (multiple of kTileBytes)
     uint32_t min_chars;    // report stretches with >= min_chars characters
-    uint32_t cand_bytes;   // a stretch shorter than this many bytes can never qualify (1..16)
+    uint32_t cand_bytes;   // a stretch shorter than this many bytes can never qualify (1..14)
     uint32_t cand_sh[5];   // shift amounts of the "cand_bytes consecutive ones" test (0 = unused step)
     uint32_t parity;       // UTF-16: (stream offset of byte 0) & 1; Big5 / EUC-JP: bytes at the chunk start that finish the token pending on entry
     uint32_t big_endian;   // UTF-16BE

@@ -497,7 +497,7 @@ SX_DEV void heavy_path(u32 g, u32 s, u32 g_raw, u32 g63_in, u32 s63, u32 r16, u6
     } else if (g63_in & 0x8000u) {
         open = true;
         if (first_tile) { ostart = tile_base; ochars = 0; oflags = kRecStartOpen; }
-        else {  // shorter than cand_bytes <= 16 bytes: it lies inside lane 63 of the previous tile
+        else {  // shorter than cand_bytes <= 14 bytes: it lies inside lane 63 of the previous tile
             u32 suf = trailing_ones16(g63_in & 0xFFFFu);
             ostart = tile_base - suf;
             ochars = (u32)__popc((s63 & 0xFFFFu) >> (16u - suf));
@@ -673,13 +673,14 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
         const u32 gf = (g & 0xFFFFu) | (pg >> 16);       // final good mask of my 16 bytes
         const u32 g63_out = bcast(gf | (g & 0xFFFF0000u), 63);
 
-        // r: bit q set iff bits q-cand_bytes+1 .. q of the window (my 16 bytes above the 16 before them) are all set.  The window's bit 0
-        // is the one bit of the previous lane that ITS predecessor's spill can set; cand_bytes is <= 16 (sx_stage_a.cpp), so no bit of r above 15 looks
-        // at it, so the candidate test takes the previous lane's mask as the first DPP delivered it (the slow paths get the exact
-        // window); four doubling steps reach 16.
+        // r: bit q set iff bits q-cand_bytes+1 .. q of the window (my 16 bytes above the 16 before them) are all set.  The window's
+        // lowest bits are the bits of the previous lane that ITS predecessor's spill can set (one bit for the range classifiers, up to
+        // three for the LUT ones); cand_bytes is <= 14 (sx_stage_a.cpp), so no bit of r above 15 looks below bit 3, and the candidate
+        // test takes the previous lane's mask as the first DPP delivered it (the slow paths get the exact window); four doubling
+        // steps reach 14.
         u32 w = __builtin_amdgcn_perm(gf, pg, 0x05040100u);   // gf << 16 | pg & 0xFFFF
         u32 r = w;
-        r &= r << p.cand_sh[0]; r &= r << p.cand_sh[1]; r &= r << p.cand_sh[2]; r &= r << p.cand_sh[3];   // (1 + 1 + 2 + 4 + 8 = 16 >= cand_bytes)
+        r &= r << p.cand_sh[0]; r &= r << p.cand_sh[1]; r &= r << p.cand_sh[2]; r &= r << p.cand_sh[3];   // (1 + 1 + 2 + 4 + 6 = 14 >= cand_bytes)
         const bool any_cand = __ballot((r & 0xFFFF0000u) != 0) != 0;
         const bool first_tile = t == 0;
         const bool first_open = first_tile && (g63_in & 0x8000u);

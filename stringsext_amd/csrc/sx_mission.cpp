@@ -47,7 +47,7 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
     memset(&p, 0, sizeof p);
     p.min_chars = m->long_run;
     const uint32_t min_bytes_per_char = m->is_utf16() ? 2 : 1;
-    p.cand_bytes = std::min<uint32_t>(m->long_run * min_bytes_per_char, 16);
+    p.cand_bytes = std::min<uint32_t>(m->long_run * min_bytes_per_char, 14);
     p.big_endian = enc == SX_ENC_UTF16BE;
     p.a_lo = 1; p.a_hi = 0; p.u_lo = 0x81; p.u_hi = 0x80;  // empty ranges
 

@@ -23,7 +23,9 @@ ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const 
     p.wave_prio = getenv("SX_SCAN_PRIO") ? (uint32_t)atoi(getenv("SX_SCAN_PRIO")) : 0u;
     p.min_chars = (uint32_t)std::min<uint64_t>(min_chars, kRecCharsMask);
     if (p.min_chars == 0) p.min_chars = 1;
-    p.cand_bytes = std::min<uint32_t>(p.min_chars * (m.is_utf16() ? 2u : 1u), 16u);   // (<= 16: the candidate test never looks at the window's bit 0, sx_kernels.hip)
+    // (<= 14: the scan kernel's candidate test takes the previous lane's mask without what ITS predecessor spilled into it — at most
+    // the window's bits 0..2, a three-byte continuation of the LUT classifiers —, and with 14 no bit of the test looks below bit 3)
+    p.cand_bytes = std::min<uint32_t>(p.min_chars * (m.is_utf16() ? 2u : 1u), 14u);
     {   // r &= r << sh, doubling the proven run length until it reaches cand_bytes
         uint32_t have = 1;
         for (int i = 0; i < 5; i++) {

@@ -76,6 +76,31 @@ def test_device_runs_equal_oracle_runs(name, generic):
                 assert got == want, (name, di, parity, sub, len(got), len(want))
 
 
+@pytest.mark.parametrize("n", [13, 14, 15, 16, 17, 20])
+def test_long_thresholds_with_characters_across_lane_edges(n):
+    """The candidate test of the scan kernels works on the lane's 16 bytes above the 16 before them, and takes the lower half
+    without what ITS predecessor's last character spilled into it (up to three continuation bytes): stretches of exactly
+    n .. n+2 characters of 2, 3 and 4 bytes at every phase of the 16-byte grid, for thresholds around the window's reach."""
+    rng = random.Random(100 + n)
+    words = ["Ж", "中", "字", "😀", "𝔘", "é", "א"]
+    parts = []
+    for _ in range(6000):
+        k = rng.choice([n - 1, n, n, n + 1, n + 2])
+        txt = "".join(rng.choice(words[:rng.choice([1, 3, 5, 7])]) for _ in range(k))
+        parts.append(rng.choice([b"\xff", b"\x00\x01", b"\x80", b"\xc0\xff\xfe", b"\n\n\n\n\n"]) * rng.randrange(1, 4))
+        parts.append(rng.choice([txt.encode("utf-8"), txt.encode("utf-16-le"), txt.encode("utf-16-be")]))
+    data = b"".join(parts)
+    for flags in (dict(encodings=["utf-8"], unicode_block_filter="All"), dict(encodings=["utf-16le"], unicode_block_filter="All"),
+                  dict(encodings=["utf-16be"], unicode_block_filter="All"), dict(encodings=["utf-8"], unicode_block_filter="Cyrillic")):
+        m = rc.missions(chars_min=str(n), **flags)[0]
+        for parity in (0, 1):
+            for generic in (False, True):
+                got, mc = device_runs(m, data, parity=parity, generic=generic, subchunk=4096)
+                assert got == sxo.runs(m, data, stream_parity=parity, min_chars=mc), (n, flags, parity, generic)
+        ms = rc.missions(chars_min=str(n), **flags)
+        assert run_cli_product(ms, [data], radix="x", device=0) == sxo.run_cli(ms, [data], radix="x"), (n, flags)
+
+
 def test_tile_traversal_kernels_equal_oracle_runs(monkeypatch):
     """The experimental tile-independent grid-stride kernels (SX_TRAVERSAL=1) report the same runs."""
     monkeypatch.setenv("SX_TRAVERSAL", "1")
