@@ -237,6 +237,7 @@ ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const 
 int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
                    const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si);
 struct ReplayJob;
+int ensure_copy_stream(sx_ctx* ctx);   // sx_stage_b.cpp
 int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
                    const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si,
                    std::vector<RunList>* out, bool cut_into_pieces = false, const ReplayJob* wave_job = nullptr);

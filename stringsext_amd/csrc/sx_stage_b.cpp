@@ -345,9 +345,12 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
     return SX_OK;
 }
 
-static int ensure_copy_stream(sx_ctx* ctx) {
+// The stream of the result copies (slabs, merge parts).  SX_COPY_PRIO=-1/0/1: its priority (experiments).
+int ensure_copy_stream(sx_ctx* ctx) {
     if (ctx->merge_copy_stream) return SX_OK;
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->merge_copy_stream, hipStreamNonBlocking));
+    int prio = 0;
+    if (const char* e = getenv("SX_COPY_PRIO")) prio = atoi(e);
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->merge_copy_stream, hipStreamNonBlocking, prio));
     for (hipEvent_t& e : ctx->merge_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return SX_OK;
 }

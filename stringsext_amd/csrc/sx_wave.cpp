@@ -144,10 +144,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         P.wave_nf = d_u; P.wave_nb = d_u + n_waves; P.wave_in = d_u + 2 * n_waves; P.wave_out = d_u + 3 * n_waves;
         P.wave_fbase = d_fb; P.wave_abase = d_ab;
         if (K > 1) {
-            if (!ctx->merge_copy_stream) {
-                HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->merge_copy_stream, hipStreamNonBlocking));
-                for (hipEvent_t& e : ctx->merge_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            }
+            { const int rc = ensure_copy_stream(ctx); if (rc != SX_OK) return rc; }
         }
         while (ctx->wave_ev.size() < 4 * K) {
             hipEvent_t e;
