@@ -4,9 +4,14 @@ tag=$1
 python bench.py > gpurun_out/${tag}_bench_c3_64gib.json 2> gpurun_out/${tag}_bench_c3.err < /dev/null
 tail -c 600 gpurun_out/${tag}_bench_c3_64gib.json; echo
 SX_BUSIEST_LAST=0 python bench.py --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_c3_64gib_busiest_first.json
+# (a process that held 64 GiB of HBM has just ended: for about ten seconds the driver clears that memory, and device-to-host copies
+# run at 43 instead of 53 GB/s meanwhile — C1 and the text workload, which are bound by exactly those copies, wait for it)
+sleep 20
 python bench.py --workload c1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_c1.json
-for w in c2 c4 c5; do python bench.py --workload $w --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_${w}.json; done
 python tools/gpu_text.py > gpurun_out/${tag}_text.txt 2>&1 < /dev/null
+for w in c2 c4; do python bench.py --workload $w --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_${w}.json; done
+sleep 20
+python bench.py --workload c5 --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_c5.json
 # kernel statistics + the launch rows (warm-up / timed / alone) of the same run
 for w in c3 c5; do timeout 600 tools/kernel_stats.sh ${tag}_${w} --workload $w --steps 3 --warmup 1 > /dev/null 2>&1 < /dev/null; done
 timeout 600 tools/kernel_stats.sh ${tag}_c1 --workload c1 --steps 20 --warmup 5 > /dev/null 2>&1 < /dev/null
