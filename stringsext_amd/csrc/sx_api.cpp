@@ -267,6 +267,7 @@ void sx_destroy(sx_ctx* ctx) {
             for (ScanSlot& s : d.slot) {
                 if (s.d_recs) (void)hipFree(s.d_recs);
                 if (s.d_cnt) (void)hipFree(s.d_cnt);
+                if (s.d_grid) (void)hipFree(s.d_grid);
                 if (s.d_packed) (void)hipFree(s.d_packed);
                 if (s.d_counters) (void)hipFree(s.d_counters);
                 if (s.ev0) (void)hipEventDestroy(s.ev0);

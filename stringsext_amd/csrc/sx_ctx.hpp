@@ -95,6 +95,7 @@ struct ScanSlot {
     bool free_pending = false;
     // region mode (ScanParams::region_cap): per-sub-chunk counts and the packed, ordered records
     uint32_t* d_cnt = nullptr;  uint64_t cnt_cap = 0;
+    uint32_t* d_grid = nullptr; uint64_t grid_cap = 0;   // ScanParams::grid_flags (double-byte Missions)
     DevRun* d_packed = nullptr; uint64_t packed_cap = 0;
     uint32_t region_cap = 0;    // of the launch in flight (0: shared pool)
     uint64_t n_regions = 0;

@@ -58,6 +58,7 @@ struct ScanParams {
     DevRun* recs;
     uint32_t region_cap;   // 0: shared record pool; else: slots per sub-chunk (region mode, see Emitter)
     uint32_t* region_counts; // region mode: records of sub-chunk w
+    uint32_t* grid_flags;    // double-byte kernels: per sub-chunk, bit 0 "its token grid is known", bits 1-2 the hang-over at its first byte (zeroed before every launch)
     uint32_t* counters;    // [0] records appended (may exceed capacity = overflow), [1] slow-path tiles, [3] next sub-chunk (persistent grid)
     // range classifiers
     uint32_t a_lo, a_hi;   // accepted ASCII / single-unit range (inclusive)

@@ -973,20 +973,69 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
         return ((swar_range(t, rep4(0x80u - 0x21u), rep4(0x7Fu - 0x7Eu)) & v) | swar_eq(v & 0xFEFEFEFEu, 0x8E8E8E8Eu)) & kM;  // A1..FE, 8E, 8F
     };
 
-    // Look-back: the classification state at the sub-chunk start.  One tile normally; further back while
-    // the tile holds no byte outside the lead range (the token grid cannot be told without one).
+    // Look-back: the classification state at the sub-chunk start.  One tile normally: it holds a byte outside the lead range, and the
+    // byte behind such a byte starts a token whatever came before.  A tile of lead-range bytes only says nothing about the grid; the
+    // walk then goes further back — through the sub-chunk in front at most (round 3; before, to the nearest such byte however far:
+    // a format fill of 0xF6 or 0xE5 bytes, gigabytes in a disk image, cost every wavefront in it a walk to its beginning and the
+    // classification of all of it).  In a stretch of lead-range bytes every token has two bytes (EUC-JP: unless an 8E / 8F occurs),
+    // so the hang-over at a position follows from the distance to a known position by parity:
+    //   * a byte outside the lead range found at s: tokens start at s + 1;
+    //   * none in the whole sub-chunk in front: that sub-chunk's wavefront publishes the hang-over at ITS first byte
+    //     (p.grid_flags, written as soon as it is known, i.e. before its main loop) and this one waits for it — wavefronts are
+    //     dispatched in order, so the one in front is resident or done; the chain ends at a sub-chunk that holds such a byte or at
+    //     the chunk start, where the carried decoder says how many bytes finish the pending token (p.parity).
+    // Then one look-back tile is classified (for the stretch that may be open at the sub-chunk start), entered with that hang-over.
+    // EUC-JP with an 8E / 8F among the walked bytes: token lengths differ, all walked tiles are classified as before.
     int pre = 0;
     u32 cov = 0;  // bytes at the start of the next tile that belong to a token begun before it
     {
         u64 lo = sub_start;
-        while (lo > 0) {
+        const u64 stop = sub_start >= p.subchunk ? sub_start - p.subchunk : 0;
+        bool found = false, special = false;
+        u64 known_at = 0;     // a position from which the hang-over is known_cov ...
+        u32 known_cov = 0;
+        while (lo > stop) {
             lo -= kTileBytes;
             pre++;
             const u32x4 x = *(const u32x4*)(p.data + lo + 16u * lane);
-            const u32 all = cls_lr(x.x) & cls_lr(x.y) & cls_lr(x.z) & cls_lr(x.w);
-            if (__ballot(all != kM)) break;
+            const u32 f0 = cls_lr(x.x), f1 = cls_lr(x.y), f2 = cls_lr(x.z), f3 = cls_lr(x.w);
+            if (ENC == 5) special = special || __ballot(((swar_eq(x.x & 0xFEFEFEFEu, 0x8E8E8E8Eu) | swar_eq(x.y & 0xFEFEFEFEu, 0x8E8E8E8Eu) |
+                                                          swar_eq(x.z & 0xFEFEFEFEu, 0x8E8E8E8Eu) | swar_eq(x.w & 0xFEFEFEFEu, 0x8E8E8E8Eu)) & kM) != 0) != 0;
+            const u32 out16 = movemask16(f0, f1, f2, f3) ^ 0xFFFFu;   // my bytes outside the lead range
+            const u64 bal = __ballot(out16 != 0);
+            if (bal) {
+                const int top = 63 - __clzll((long long)bal);
+                const u32 m = bcast(out16, top);
+                known_at = lo + 16ull * (u32)top + (32u - (u32)__clz((int)m));   // the byte behind the last such byte
+                known_cov = 0;
+                found = true;
+                break;
+            }
         }
-        if (lo == 0) cov = p.parity;  // the chunk start: the token pending on entry takes this many bytes
+        if (pre == 1 && found) cov = 0;                      // the usual case: the tile in front holds such a byte, its entry does not matter
+        else if (pre >= 1) {
+            if (!found) {
+                if (lo == 0) { known_at = 0; known_cov = p.parity; }   // the chunk start: the token pending on entry takes this many bytes
+                else {
+                    const u32* flag = p.grid_flags + (wave - 1);
+                    u32 v = 0;
+                    if (lane == 0) { while (((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1u) == 0) __builtin_amdgcn_s_sleep(2); }
+                    v = uniform(v);
+                    known_at = stop; known_cov = (v >> 1) & 3u;
+                }
+            }
+            if (special) cov = found ? 0u : known_cov;       // (all walked tiles are classified; the first one's entry: nothing known / the known hang-over)
+            else {
+                // tokens start at known_at + known_cov and have two bytes each up to the look-back tile
+                const u64 tile_lo = sub_start - kTileBytes, first = known_at + known_cov;
+                cov = first >= tile_lo ? (u32)(first - tile_lo) : (u32)((tile_lo - first) & 1ull);
+                pre = 1;
+                // (the hang-over at my own first byte follows the same way: the wavefront behind me need not wait for my look-back tile)
+                if (lane == 0 && first <= sub_start)
+                    __hip_atomic_store(p.grid_flags + wave, 1u | ((u32)((sub_start - first) & 1ull) << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        else cov = p.parity;  // sub-chunk 0: the chunk start
     }
     const u64 win_lo = sub_start - (u64)pre * kTileBytes;
     u64 win_hi = sub_end + 2 * kTileBytes;
@@ -1165,6 +1214,10 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
         cur = nxt; nxt = nn; toff += kTileBytes; t++;
     };
 
+    // the look-back tiles first; then the hang-over at my first byte is known: published for the wavefront behind me (its look-back may
+    // end at my sub-chunk's start) — outside the tile loop, whose code a store with release semantics would slow down
+    while (t < 0) { if (sub_start + 16 <= p.len) body(std::false_type{}); else body(std::true_type{}); }
+    if (lane == 0) __hip_atomic_store(p.grid_flags + wave, 1u | (cov << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (relaxed: the word is all there is to see — a release would write the L2 back once per sub-chunk)
     while (t < n_safe) body(std::false_type{});
     while (t < n_tiles) body(std::true_type{});
 

@@ -35,7 +35,7 @@ ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const 
         }
     }
     p.capacity = s.capacity; p.recs = s.d_recs; p.counters = s.d_counters;
-    p.region_cap = s.region_cap; p.region_counts = s.d_cnt;
+    p.region_cap = s.region_cap; p.region_counts = s.d_cnt; p.grid_flags = s.d_grid;
     p.traversal = (ctx->opt.flags & SX_OPT_TILE_TRAVERSAL) ? 1u : 0u;
     if (const char* e = getenv("SX_TRAVERSAL")) p.traversal = (uint32_t)atoi(e);
     // Blocks (of 4 wavefronts) per CU the scan kernel occupies.  8 fills every wave slot; with
@@ -85,14 +85,29 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             }
         }
     launch:
+        const bool dbcs = ctx->missions[(size_t)which[k]].is_dbcs();
+        uint64_t n_sub = 0;
+        if (dbcs) {   // a flag word per sub-chunk: where its token grid stands, for the sub-chunks behind it (sx_kernels.hip scan_kernel_dbcs)
+            uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 256u * 1024u;
+            sub = std::max<uint32_t>(kTileBytes, sub / kTileBytes * kTileBytes);
+            n_sub = (len + sub - 1) / sub;
+            if (s.grid_cap < n_sub) {
+                if (s.d_grid) HIP_TRY(ctx, hipFree(s.d_grid));
+                s.d_grid = nullptr; s.grid_cap = 0;
+                HIP_TRY(ctx, hipMalloc((void**)&s.d_grid, (n_sub + n_sub / 4 + 64) * 4));
+                s.grid_cap = n_sub + n_sub / 4 + 64;
+            }
+        }
         const ScanParams p = scan_params(ctx, which[k], s, d_bytes, len, parity[k], min_chars[k]);
         // SX_SCAN_WARM=n (measurements): the launch is preceded by n identical ones, so that the timed one starts on a busy chip
         // (bench.py's "alone" launches start from an idle one and take ~1 ms longer: DESIGN §6)
         if (const char* e = getenv("SX_SCAN_WARM"))
             for (int w = atoi(e); w > 0; w--) {
+                if (dbcs) HIP_TRY(ctx, hipMemsetAsync(s.d_grid, 0, n_sub * 4, d.stream));
                 HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream));
                 HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream));
             }
+        if (dbcs) HIP_TRY(ctx, hipMemsetAsync(s.d_grid, 0, n_sub * 4, d.stream));
         HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream));
         HIP_TRY(ctx, hipEventRecord(s.ev0, d.stream));
         HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream));
@@ -161,6 +176,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             }
             const ScanParams p = scan_params(ctx, which[k], s, d_bytes, len, parity[k], min_chars[k]);
             const double tr0 = now_ms();
+            if (p.grid_flags) HIP_TRY(ctx, hipMemsetAsync(p.grid_flags, 0, ((len + p.subchunk - 1) / p.subchunk) * 4, d.stream_b));
             HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream_b));
             HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));

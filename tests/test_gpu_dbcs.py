@@ -60,6 +60,36 @@ def test_device_runs_equal_oracle_runs(enc, name):
 
 
 @pytest.mark.parametrize("enc", ENCS)
+def test_long_fills_of_lead_range_bytes(enc):
+    """Format and deleted-entry fills of disk images (0xF6, 0xE5, ...) lie inside the lead ranges: for kilobytes no byte tells where
+    tokens start.  The scan kernel takes the grid from the sub-chunk in front (a published hang-over + parity) instead of walking
+    to the fill's beginning: fills across many sub-chunks, both parities, chunks that begin inside a fill, EUC-JP's 8E / 8F."""
+    rng = random.Random(zlib.crc32(enc.encode()) + 7)
+    txt = TEXT[enc].encode(CODEC[enc], "ignore")
+    m = rc.missions(encodings=[enc], chars_min="4", unicode_block_filter=ALL)[0]
+    ms = rc.missions(encodings=[enc, "utf-8"], chars_min="4", unicode_block_filter=ALL)
+    for fill in (0xF6, 0xE5, 0xA4, 0x81, 0xFE, 0x8F, 0x8E, 0x39):
+        for odd in (0, 1):
+            f = bytes([fill])
+            data = (soup(enc, rng, 3000) + f * (40_000 + odd) + b"A" + f * (70_001 + odd) + txt * 5 + f * (9000 + odd) + b"\x8f" + f * 5000 +
+                    b"1" + f * (12_345 + odd) + txt[:77] + b"\n")
+            for sub in (1024, 4096, 65536):
+                got, mc = device_runs(m, data, subchunk=sub)
+                want = sxo.runs(m, data, min_chars=mc)
+                if enc in ("gbk", "gb18030"):
+                    j = 0
+                    for a, b, ch in want:
+                        while j < len(got) and got[j][1] < b:
+                            j += 1
+                        assert j < len(got) and got[j][0] <= a and got[j][2] >= ch, (enc, hex(fill), odd, sub, (a, b, ch))
+                else:
+                    assert got == want, (enc, hex(fill), odd, sub, len(got), len(want), next(((a, b) for a, b in zip(got, want) if a != b), None))
+            want = sxo.run_cli(ms, [data], radix="x")
+            for chunk in (None, 8192, 4096 * 7):
+                assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (enc, hex(fill), odd, chunk)
+
+
+@pytest.mark.parametrize("enc", ENCS)
 @pytest.mark.parametrize("flags", DBCS_FLAGS, ids=lambda f: "n" + f["chars_min"] + "-" + f["unicode_block_filter"])
 def test_end_to_end_equals_oracle(enc, flags):
     rng = random.Random(zlib.crc32((enc + "gpu" + repr(sorted(flags.items()))).encode()))
