@@ -276,7 +276,7 @@ struct PreReplayed {
 // wave-cooperative stage B (sx_wave.cpp): for whole buffers of a Mission it covers, when the buffer is string-dense
 constexpr int SX_WAVE_FALLBACK = 1001;   // (internal) nothing was produced: use the lane-per-region path
 constexpr int SX_NEED_RUNS = 1002;       // (internal) ... which needs the run list that stage A skipped (RunList::skipped)
-bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs);
+bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs, uint64_t heavy_tiles = 0);
 int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, MissionFindings* out, uint64_t* end_pos,
                         uint64_t defer_min_bytes);
 bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs);

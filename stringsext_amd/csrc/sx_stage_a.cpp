@@ -142,9 +142,11 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                 // String-dense input of a Mission whose stage B can replay every window (sx_wave.cpp): the records are only
                 // counted — no second scan with larger regions, no sort, no join, no pieces.
                 const uint64_t total = s.region_cap ? counters[2] : counters[0];
-                if (wave_replay_wanted(ctx, *wave_job, (size_t)which[k], total)) {
+                if (wave_replay_wanted(ctx, *wave_job, (size_t)which[k], total, counters[1])) {
                     RunList& rl = (*out)[k];
-                    rl.n = total; rl.p = nullptr; rl.skipped = true; rl.complete = true;
+                    // (n: what stage B sees as the buffer's density; a buffer of a few GIANT runs counts as dense too)
+                    rl.n = wave_replay_wanted(ctx, *wave_job, (size_t)which[k], total) ? total : std::max<uint64_t>(total, len / 16);
+                    rl.p = nullptr; rl.skipped = true; rl.complete = true;
                     skip_runs = true;
                     break;
                 }

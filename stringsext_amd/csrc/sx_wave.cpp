@@ -26,7 +26,10 @@ static uint64_t wave_min_density_bytes(uint32_t family = 0) {
     return v ? v : (family == 4 ? 100ull : 480ull);
 }
 
-bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs) {
+// n_runs: the long runs (or records) of the buffer; heavy_tiles: 1 KiB tiles of it that took the scan kernel's general path.  Dense =
+// a run per wave_min_density_bytes or more — or hardly any runs but half of the tiles on the general path: GIANT runs (a fill of
+// printable bytes: gigabytes of spaces or '0' in a disk image), which the lane-per-region path hands to the host as one region.
+bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs, uint64_t heavy_tiles) {
     const Mission& m = ctx->missions[k];
     if (!m.wave_ok || !job.d_bytes || ctx->host_only || job.is_last || !job.commit_state) return false;
     if (k < ctx->wave_off.size() && ctx->wave_off[k]) return false;
@@ -34,7 +37,10 @@ bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_
     if (ctx->opt.flags & SX_OPT_HOST_REPLAY) return false;
     if (const char* e = getenv("SX_WAVE_REPLAY")) return atoi(e) != 0;
     if (getenv("SX_HOST_REPLAY") || getenv("SX_HOST_STITCH") || getenv("SX_NO_REPLAY_CACHE")) return false;   // tests of the other path
-    return (uint64_t)n_runs * wave_min_density_bytes(m.wave_family) > job.len;
+    if ((uint64_t)n_runs * wave_min_density_bytes(m.wave_family) > job.len) return true;
+    // (not the two-byte family: its wave kernels find the token grid by walking back to a byte outside the lead range — a fill is
+    // the one input where that walk has no end; they give up after 64 KiB and the other path takes over)
+    return m.wave_family != 4 && heavy_tiles * 2048 > job.len && (uint64_t)n_runs * 4096 < job.len;
 }
 
 static uint32_t utf8_chars(const std::string& s) {

@@ -261,6 +261,17 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, b
             if (a >= w.n) { st.cut = 0; return; }   // (at least the call at din is still to come, and none of them yields)
             const i32 cs = wm_prev(w.CS, a);        // start of the call that delivers the next accepted char
             if (cs > (i32)din) { st.cut = 0; din = (u32)cs; first = false; }
+            // Nothing carried in at all (no leftover, no cut pending): a call that holds no stretch of >= n bytes and is not the
+            // window's last one hands SplitStr a text of short stretches only — each is dropped (helper.rs:315-330), the last of
+            // them too, because the call ended in an error (finding_collection.rs:269: only a call that ran into the window end
+            // leaves a leftover).  On binary data that is nearly every call: go on at the next call that can matter.
+            if (st.cut == 0) {
+                const u32 ls = wm_next(w.LS, din);
+                if (ls >= w.n && w.tail_empty) return;           // (the last real call ends in an error as well)
+                i32 t = wm_prev(w.CS, 127);                      // the window's last call
+                if (ls < w.n) { const i32 c = wm_prev(w.CS, ls); if (c < t) t = c; }
+                if (t > (i32)din) { din = (u32)t; first = false; }
+            }
         }
         u32 cend = wm_next(w.CS, din + 1);
         if (cend > w.n) cend = w.n;
@@ -501,6 +512,105 @@ SXD WvMasks16D wv_classify16_dbcs(const LUT& lut1, const PAIRS& pairs, const u8*
             if (c & WVC_ACC) { m.a |= 1u << j; m.g |= 1u << j; }
         } else m.ma |= 1u << j;
     }
+    return m;
+}
+
+// ---- the same classification as bit arithmetic (the kernels' path; the functions above stay as its statement byte by byte and as
+// what tests/native/wave_core_host.cpp compares it with).  Masks of the lane's 16 bytes: bit j = byte j.
+struct WvDbcsPre { u32 v1, a1, o2, o3, lr, asc; };   // a character on its own / accepted / UTF-8 form of >= 2 / 3 bytes / lead range / < 0x80
+
+// flags at bit 0 of every byte of four dwords -> 16 bits
+SXD u32 wv_movemask16(u32 f0, u32 f1, u32 f2, u32 f3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 lo = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false);
+    lo = __builtin_amdgcn_udot4(f1, 0x80402010u, lo, false);
+    u32 hi = __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false);
+    hi = __builtin_amdgcn_udot4(f3, 0x80402010u, hi, false);
+    return lo | (hi << 8);
+#else
+    const u32 f[4] = { f0, f1, f2, f3 };
+    u32 m = 0;
+    for (int k = 0; k < 16; k++) m |= ((f[k >> 2] >> (8 * (k & 3))) & 1u) << k;
+    return m;
+#endif
+}
+
+// x: the lane's four dwords, avail: how many of its 16 bytes exist
+template <class LUT>
+SXD WvDbcsPre wv_dbcs_classes(const LUT& lut1, const u32* x, u32 avail) {
+    u32 cw[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        cw[k] = (u32)lut1[x[k] & 0xFFu] | ((u32)lut1[(x[k] >> 8) & 0xFFu] << 8) | ((u32)lut1[(x[k] >> 16) & 0xFFu] << 16) | ((u32)lut1[x[k] >> 24] << 24);
+    const u32 k1 = 0x01010101u, ex = avail >= 16 ? 0xFFFFu : ((1u << avail) - 1u);
+    WvDbcsPre c;
+    c.v1 = wv_movemask16(cw[0] & k1, cw[1] & k1, cw[2] & k1, cw[3] & k1) & ex;                                       // WVC_VALID
+    c.a1 = wv_movemask16((cw[0] >> 1) & k1, (cw[1] >> 1) & k1, (cw[2] >> 1) & k1, (cw[3] >> 1) & k1) & ex;           // WVC_ACC
+    c.o2 = wv_movemask16((cw[0] >> 2) & k1, (cw[1] >> 2) & k1, (cw[2] >> 2) & k1, (cw[3] >> 2) & k1) & ex;           // WVC_O2
+    c.o3 = wv_movemask16((cw[0] >> 3) & k1, (cw[1] >> 3) & k1, (cw[2] >> 3) & k1, (cw[3] >> 3) & k1) & ex;           // WVC_O3
+    c.lr = wv_movemask16((cw[0] >> 4) & k1, (cw[1] >> 4) & k1, (cw[2] >> 4) & k1, (cw[3] >> 4) & k1) & ex;           // WVC_LEAD
+    c.asc = wv_movemask16((~x[0] >> 7) & k1, (~x[1] >> 7) & k1, (~x[2] >> 7) & k1, (~x[3] >> 7) & k1) & ex;
+    return c;
+}
+
+// The token walk of wv_dbcs_walk without the walk.  Bit i of the result: byte i is the TRAIL of a two-byte token (bit 16: the lane's
+// last token reaches into the next lane); cov: byte 0 is one.  A lead byte "escapes" the byte behind it unless it is escaped itself —
+// runs of lead-range bytes alternate, and whether a run's first byte starts a token is the parity of where it stands: the carry of
+// one addition tells the runs that start on odd positions from those on even ones.
+SXD u32 wv_dbcs_trails(u32 lr, u32 cov) {
+    const u32 even = 0x55555555u;
+    const u32 b = lr & ~cov;                       // (byte 0 as a trail is no lead)
+    const u32 follows = (b << 1) | cov;            // bytes behind a lead-range byte
+    const u32 odd_starts = b & ~even & ~follows;   // runs that begin on an odd position
+    const u32 inv = (odd_starts + b) << 1;         // ... flip the parity of everything up to the byte behind their end
+    return (even ^ inv) & follows & 0x1FFFFu;
+}
+
+// ws6: the dwords at lane offset -4 .. +19; c: the classes of the lane's own bytes; tr = wv_dbcs_trails(c.lr, cov_in);
+// back_exists: the byte in front of the lane's first lies inside the buffer; n_exist: existing bytes from the lane's first on (<= 20)
+template <class PAIRS>
+SXD WvMasks16D wv_classify16_dbcs_bits(const PAIRS& pairs, const u32* ws6, const WvDbcsPre& c, u32 tr, u32 cov_in, bool back_exists,
+                                       u32 n_exist) {
+    // "shifted" masks: bit p + 1 = lane offset p, so that the token whose lead lies in front of the lane (p = -1) has a bit
+    const u32 starts_s = ((~tr & 0xFFFFu) << 1) | cov_in;
+    const u32 lr_s = (c.lr << 1) | cov_in;
+    const u32 ex_s = ((n_exist >= 20 ? 0xFFFFFu : ((1u << n_exist) - 1u)) << 1) | (back_exists ? 1u : 0u);
+    const u32 two = starts_s & lr_s & ex_s & (ex_s >> 1);   // two-byte tokens whose both bytes exist, at their leads
+    const u32 T = two << 1;                                 // ... at their trails
+    u32 Mp = 0, Ac = 0, L0 = 0, L1 = 0;                     // the pair code's bits, at the trails
+#pragma unroll
+    for (int k = 0; k <= 8; k++) {
+        // the slot's token, if any, starts at lane offset 2k - 1 (its lead is byte 2k + 3 of ws6) or 2k (byte 2k + 4)
+        const u32 has = (two >> (2 * k)) & 3u;
+        if (!has) continue;
+        const u32 odd = has >> 1;
+        const int ie = 2 * k + 3, io = 2 * k + 4;
+        const u32 u_even = (ie & 3) == 3 ? ((ws6[ie >> 2] >> 24) | ((ws6[(ie >> 2) + 1] & 0xFFu) << 8)) : ((ws6[ie >> 2] >> (8 * (ie & 3))) & 0xFFFFu);
+        const u32 u_odd = (ws6[io >> 2 > 5 ? 5 : io >> 2] >> (8 * (io & 3))) & 0xFFFFu;   // (k = 8: no token starts at offset 16)
+        const u32 idx = odd ? u_odd : u_even;               // lead | trail << 8
+        const u32 code = (pairs[idx >> 3] >> ((idx & 7u) * 4)) & 15u;
+        const u32 sh = 2 * k + 1 + odd;
+        Mp |= (code & 1u) << sh; Ac |= ((code >> 1) & 1u) << sh; L0 |= ((code >> 2) & 1u) << sh; L1 |= (code >> 3) << sh;
+    }
+    const u32 v_s = c.v1 << 1, a_s = c.a1 << 1, asc_s = c.asc << 1;
+    const u32 dbl = Mp & L0 & L1;                           // Big5's tokens of two code points: one rejected char (see above)
+    const u32 acc2 = Ac & Mp & ~dbl;
+    const u32 un = T & ~Mp;                                 // unmapped: an ASCII trail is read again as a character of its own
+    const u32 un_a = un & asc_s;
+    const u32 one = starts_s & ~lr_s & ex_s;                // tokens of one byte
+    const u32 own = (un_a | one) & v_s;                     // characters of one byte
+    u32 f = (Mp >> 1) | own;
+    u32 e = Mp | own;
+    u32 a = acc2 | (own & a_s);
+    u32 g = acc2 | (acc2 >> 1) | (own & a_s);
+    u32 ma = (un & ~asc_s) | ((un_a | one) & ~v_s);
+    u32 o2 = Mp | (one & v_s & ((c.o2 | c.o3) << 1));
+    u32 o3 = (Mp & (L0 ^ L1)) | (one & v_s & (c.o3 << 1));
+    u32 o4 = Mp & L1 & ~L0;
+    WvMasks16D m;
+    m.e = (e >> 1) & 0xFFFFu; m.a = (a >> 1) & 0xFFFFu; m.f = (f >> 1) & 0xFFFFu; m.g = (g >> 1) & 0xFFFFu;
+    m.ma = (ma >> 1) & 0xFFFFu; m.mb = (un_a >> 1) & 0xFFFFu;
+    m.o2 = (o2 >> 1) & 0xFFFFu; m.o3 = (o3 >> 1) & 0xFFFFu; m.o4 = (o4 >> 1) & 0xFFFFu;
     return m;
 }
 

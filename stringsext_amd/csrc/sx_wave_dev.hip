@@ -171,6 +171,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(FAM ==
                     for (int k = 0; k < 16; k++) reset = reset || !(lds_lut[(xs[k >> 2] >> (8 * (k & 3))) & 0xFFu] & WVC_LEAD);
                 }
                 if (__ballot(reset)) break;
+                if (t_first < -64) {   // 64 KiB of lead-range bytes and no end: a fill.  This wavefront gives up — an entry state no wavefront
+                                       // ever leaves makes the verification fail, and the lane-per-region path takes the buffer
+                    if (lane == 0) { P.wave_in[v] = 0xFFFFFFFEu; P.wave_out[v] = 0xFFFFFFFDu; P.wave_nf[v] = 0; P.wave_nb[v] = 0; }
+                    return;
+                }
             }
         }
         for (int t = t_first; t < (int)n_tiles; t++) {
@@ -201,12 +206,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(FAM ==
                     if (n_ahead == 4) ahead = *(const u32*)(P.data + off + 16);
                     else for (u32 k = 0; k < n_ahead; k++) ahead |= (u32)P.data[off + 16 + k] << (8 * k);
                 }
-                u8 b[24];
                 const u32 ws6[6] = { back, x.x, x.y, x.z, x.w, ahead };
-#pragma unroll
-                for (int k = 0; k < 24; k++) b[k] = (u8)(ws6[k >> 2] >> (8 * (k & 3)));
                 const u32 have_lo = off >= 4 ? 0u : 4u, have_hi = 4u + avail + n_ahead;
                 if (FAM == 1) {
+                    u8 b[24];
+#pragma unroll
+                    for (int k = 0; k < 24; k++) b[k] = (u8)(ws6[k >> 2] >> (8 * (k & 3)));
                     const WvMasks16U m = wv_classify16_utf8(lds_lut, b, have_lo, have_hi);
                     ((uint16_t*)lds_mask[0])[idx] = (uint16_t)m.e;
                     ((uint16_t*)lds_mask[1])[idx] = (uint16_t)m.a;
@@ -215,10 +220,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(FAM ==
                     ((uint16_t*)lds_mask[FAM == 1 ? 4 : 0])[idx] = (uint16_t)m.mb;
                     ((uint16_t*)lds_mask[FAM == 1 ? 5 : 0])[idx] = (uint16_t)m.g;
                 } else {
-                    // token starts: the lane's walk for both cases, the cases composed along the wavefront
-                    const u32 lr = soff < 0 ? 0u : wv_dbcs_lead_mask(lds_lut, b, have_hi);
-                    u32 o0, o1;
-                    const u32 s0 = wv_dbcs_walk(lr, 0, &o0), s1 = wv_dbcs_walk(lr, 1, &o1);
+                    // token starts: the lane's trails for both cases (bit arithmetic, sx_wave_core.hpp wv_dbcs_trails), the cases
+                    // composed along the wavefront
+                    const WvDbcsPre pc = wv_dbcs_classes(lds_lut, &ws6[1], avail);
+                    const u32 tr0 = wv_dbcs_trails(pc.lr, 0u), tr1 = wv_dbcs_trails(pc.lr, 1u);
+                    const u32 o0 = tr0 >> 16, o1 = tr1 >> 16;
                     u32 fn = o0 | (o1 << 1);                       // bit c: how far the lane's last token hangs over if its first byte is at c
                     const bool at_zero = soff == 0;                // the buffer's byte 0: the token pending on entry decides
                     if (at_zero) { const u32 o = P.entry_skip ? o1 : o0; fn = o | (o << 1); }
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(FAM ==
                     dbcs_cov = (u32)__builtin_amdgcn_readlane(out_here, 63);
                     if ((long long)tile0 + (long long)(t + 1) * (long long)kTileBytes == (long long)next_t0) { cov_next = dbcs_cov; have_next = true; }
                     if (t >= 0) {
-                        const WvMasks16D m = wv_classify16_dbcs(lds_lut, lds_pairs, b, have_lo, have_hi, lr, cov_in ? s1 : s0, cov_in);
+                        const WvMasks16D m = wv_classify16_dbcs_bits(lds_pairs, ws6, pc, cov_in ? tr1 : tr0, cov_in, off > 0, avail + n_ahead);
                         ((uint16_t*)lds_mask[0])[idx] = (uint16_t)m.e;
                         ((uint16_t*)lds_mask[1])[idx] = (uint16_t)m.a;
                         ((uint16_t*)lds_mask[2])[idx] = (uint16_t)m.f;

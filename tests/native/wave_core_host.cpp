@@ -158,7 +158,14 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                     if ((long long)tile0 + (long long)(t + 1) * (long long)kTileBytes == (long long)next_t0) { cov_next = dbcs_cov; have_next = true; }
                 }
                 if (t < 0) continue;
-                const WvMasks16D m = wv_classify16_dbcs(P.lut, P.pairs, b, have_lo, have_hi, lr, cov_in ? s1 : s0, cov_in);
+                const WvMasks16D m0 = wv_classify16_dbcs(P.lut, P.pairs, b, have_lo, have_hi, lr, cov_in ? s1 : s0, cov_in);
+                // the kernels' path: the same as bit arithmetic — compared with the statement byte by byte above
+                const WvDbcsPre pc = wv_dbcs_classes(P.lut, &ws6[1], avail);
+                const u32 tr0 = wv_dbcs_trails(pc.lr, 0u), tr1 = wv_dbcs_trails(pc.lr, 1u);
+                if ((tr0 >> 16) != o0 || (tr1 >> 16) != o1 || (~tr0 & 0xFFFFu) != s0 || (~tr1 & 0xFFFFu & ~1u) != (s1 & ~1u)) return false;
+                const WvMasks16D m = wv_classify16_dbcs_bits(P.pairs, ws6, pc, cov_in ? tr1 : tr0, cov_in, off > 0, avail + n_ahead);
+                if (m.e != m0.e || m.a != m0.a || m.f != m0.f || m.g != m0.g || m.ma != m0.ma || m.mb != m0.mb || m.o2 != m0.o2 ||
+                    m.o3 != m0.o3 || m.o4 != m0.o4) return false;
                 const u32 vals[9] = { m.e, m.a, m.f, m.ma, m.mb, m.g, m.o2, m.o3, m.o4 };
                 for (int k = 0; k < 9; k++) ((uint16_t*)lds[k].data())[idx] = (uint16_t)vals[k];
             }

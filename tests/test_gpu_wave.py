@@ -135,3 +135,22 @@ def test_wave_path_two_byte_family(wave_forced, di):
                 os.environ.pop("SX_WAVE_BATCHES", None)
             assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (enc, name, chunk)
     assert wave_windows_of_a_scan(ms[:1], datas[0][1]) > 0
+
+
+def test_giant_runs_take_the_wave_path():
+    """a fill of accepted bytes (megabytes of spaces, '0', 0xFF in a Latin code page, 0xF6F6 in Big5) is ONE run: few runs, but every
+    tile of it on the scan kernel's general path — the buffer counts as dense and is replayed a lane per window, not handed to the
+    host as one region; next to a second Mission, chunked and in one piece.  (Not the two-byte family: inside a fill of lead-range bytes its
+    wave kernels find no token grid; the lane-per-region path keeps such a buffer, and only the text is compared.)"""
+    rng = random.Random(21)
+    cases = [(dict(encodings=["utf-8", "utf-16le"], chars_min="4"), b"\xff" + b" " * (6 << 20) + b"\xc3"),
+             (dict(encodings=["utf-8"], chars_min="10"), rng.randbytes(5000) + b"\x80" + b"0" * (5 << 20) + rng.randbytes(3000)),
+             (dict(encodings=["windows-1252", "ascii"], chars_min="4", unicode_block_filter="Latin"), b"\x00" + b"\xff" * (4 << 20) + b"\x00abcd"),
+             (dict(encodings=["big5"], chars_min="4", unicode_block_filter="Cjk"), rng.randbytes(3000) + b"\x80" + b"\xf6" * ((4 << 20) + 1) + b"\n")]
+    for flags, data in cases:
+        ms = rc.missions(**flags)
+        want = sxo.run_cli(ms, [data], radix="x")
+        for chunk in (None, 1 << 20):
+            assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (flags, chunk)
+        if "big5" not in flags["encodings"]:
+            assert wave_windows_of_a_scan(ms[:1], data) > 0, flags
