@@ -129,6 +129,7 @@ typedef struct sx_stats {
     double   wave_count_ms, wave_write_ms; /* ... its two passes, HIP events around their launches (all missions and slabs) */
     uint64_t rescans;                    /* scan kernels launched a second time (their records overflowed the regions / the pool) */
     double   rescan_ms;                  /* ... host time until their records were there */
+    uint64_t wave_desc_overflows;        /* wave stage B: slabs written by the window-parallel writer because a wavefront found more than its descriptors hold */
 } sx_stats;
 
 typedef struct sx_ctx sx_ctx;

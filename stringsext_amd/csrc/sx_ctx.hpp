@@ -154,6 +154,7 @@ struct sx_ctx {
     // grow-only scratch reused by every call (pinned host memory: D2H at full PCIe rate)
     std::vector<uint64_t> last_runs;  // long runs per mission of the last scanned buffer: busiest mission scans first
     std::vector<char> wave_pred;      // per mission: its last whole buffer was string-dense and went through the wave kernels: the next one does without stage A
+    std::vector<double> wave_density; // per mission: findings per input byte of the last buffer that went through the wave kernels (sizes the descriptors)
     std::vector<hipEvent_t> wave_ev;  // timing events of the wave kernels (4 per slab: count begin / end, write begin / end)
     std::vector<char> wave_off;       // per mission, for the buffer in hand: the wave-cooperative stage B gave up on it (sx_wave.cpp)
     std::vector<sx::RunList> shard_runs;  // device runs of the last sx_scan_shard* buffer (reuse_runs)

@@ -175,6 +175,10 @@ struct WaveParams {
     uint8_t* arena;
     uint32_t str_off_base;    // added to every str_off
     uint64_t v0, v1;          // the wavefronts of this launch: [v0, v1)
+    // descriptors (sx_wave_core.hpp WvDesc, three words each): the count pass leaves one per finding, desc_cap per wavefront, for the
+    // writer that works a lane per finding (launch_wave_emit); nullptr: the window-parallel writer (launch_wave_write) is the only one
+    uint32_t* desc;
+    uint32_t desc_cap;
 };
 size_t wave_scratch_bytes(uint64_t n_waves);
 // pass 1 of wavefronts [v0, v1) + exclusive sums from v0 on + verification; totals (device, 4 x u64): findings, string bytes,
@@ -182,6 +186,8 @@ size_t wave_scratch_bytes(uint64_t n_waves);
 hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint64_t* fbase, uint64_t* abase, uint64_t* totals,
                              void* scratch, size_t scratch_bytes, hipStream_t stream);
 hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipStream_t stream);
+// the same output from the count pass' descriptors (P.desc; totals[2] >> 32 says how many wavefronts found more than desc_cap: then not this one)
+hipError_t launch_wave_emit(const WaveParams& P, uint64_t v0, uint64_t v1, hipStream_t stream);
 
 // interleave several missions' findings on the device (sx_sort.hip); every src and out = [findings][string bytes]
 hipError_t merge_findings_device_part(const sx_finding* const* f, const uint8_t* const* a, const uint64_t* nf, const uint64_t* nb,

@@ -18,12 +18,13 @@ using namespace sx;
 namespace sx {
 
 // bytes per run below which the wave kernels are the cheaper stage B.  Measured on the MI355X: the lane-per-region path costs
-// ~1.2 ns per run (single byte, UTF-8) / ~3 ns (two-byte family), the wave kernels ~2.5 ps per input byte — ~28 ps for the two-byte
-// family, whose token walk per lane is still scalar code: Big5 on random bytes (a run per 470 bytes) stays on the other path,
-// CJK text (a run per line) comes here.
+// ~1.2 ns per run (single byte, UTF-8) / ~3.6 ns (two-byte family: sort + join, both passes); the wave kernels, since their writer
+// works a lane per finding, 2.0 ps per input byte (single byte: 5.5 + 2.9 ms per 4 GiB with 15 M findings) / 6.3 ps (two-byte
+// family: 24.7 + 2.2 ms, Big5 on random bytes with a run per 490 bytes) / 5.5 ps (UTF-8 on random bytes, where a decoder call starts
+// every other byte; on text it is the single-byte figure).
 static uint64_t wave_min_density_bytes(uint32_t family = 0) {
     static const uint64_t v = [] { const char* e = getenv("SX_WAVE_BYTES_PER_RUN"); return e ? (uint64_t)atoll(e) : 0ull; }();
-    return v ? v : (family == 4 ? 100ull : 480ull);
+    return v ? v : (family == 4 ? 560ull : family == 1 ? 480ull : 600ull);
 }
 
 // n_runs: the long runs (or records) of the buffer; heavy_tiles: 1 KiB tiles of it that took the scan kernel's general path.  Dense =
@@ -149,6 +150,22 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         P.pairs = d.d_wave_pairs; P.encoding = m.c.encoding; P.entry_skip = m.buf_entry_skip;
         P.wave_nf = d_u; P.wave_nb = d_u + n_waves; P.wave_in = d_u + 2 * n_waves; P.wave_out = d_u + 3 * n_waves;
         P.wave_fbase = d_fb; P.wave_abase = d_ab;
+        // Descriptors for the lane-per-finding writer: room for twice the findings a wavefront is expected to hold (the last buffer's
+        // density; stage A's record count; else one per window), at most two per window and a third of the input's size in all.  A
+        // wavefront that finds more is only counted, and the launch takes the window-parallel writer.
+        P.desc = nullptr; P.desc_cap = 0;
+        if (nwin <= kWvDescMaxWin && !(getenv("SX_WAVE_DESC") && !atoi(getenv("SX_WAVE_DESC")))) {
+            if (ctx->wave_density.size() != ctx->missions.size()) ctx->wave_density.assign(ctx->missions.size(), 0.0);
+            double per_byte = ctx->wave_density[k];
+            if (per_byte <= 0 && k < ctx->last_runs.size() && ctx->last_runs[k] && ctx->last_runs[k] < len / 16) per_byte = (double)ctx->last_runs[k] / (double)len;
+            const double bytes_per_wave = (double)len / (double)n_waves;
+            uint64_t cap = per_byte > 0 ? (uint64_t)(2.0 * per_byte * bytes_per_wave) + 128 : (uint64_t)nwin + 64;
+            cap = std::min<uint64_t>(cap, 2ull * nwin + 64);
+            cap = std::min<uint64_t>(cap, std::max<uint64_t>(64, len / 3 / 12 / n_waves));
+            if (const char* e = getenv("SX_WAVE_DESC_CAP")) cap = (uint64_t)std::max(1, atoi(e));
+            if (ensure_rp(ctx, d, 2, n_waves * cap * 12 + 64) == SX_OK) { P.desc = (uint32_t*)d.d_rp[2]; P.desc_cap = (uint32_t)cap; }
+            else ctx->err.clear();   // (no room: the other writer)
+        }
         if (K > 1) {
             { const int rc = ensure_copy_stream(ctx); if (rc != SX_OK) return rc; }
         }
@@ -169,10 +186,12 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             HIP_TRY(ctx, hipEventRecord(ctx->wave_ev[4 * j + 1], d.stream_b));
             HIP_TRY(ctx, hipMemcpyAsync(h_tot + 4 * j, d_tot + 4 * j, 4 * 8, hipMemcpyDeviceToHost, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
-            if (h_tot[4 * j + 2] != 0 || getenv("SX_WAVE_FAIL")) {   // (SX_WAVE_FAIL: tests of the way back)
-                if (getenv("SX_TIMING")) fprintf(stderr, "[sx] wave replay mission %zu: %llu wavefronts assumed a wrong entry state: lane-per-region path\n", k, (unsigned long long)h_tot[4 * j + 2]);
+            if ((h_tot[4 * j + 2] & 0xFFFFFFFFull) != 0 || getenv("SX_WAVE_FAIL")) {   // (SX_WAVE_FAIL: tests of the way back)
+                if (getenv("SX_TIMING")) fprintf(stderr, "[sx] wave replay mission %zu: %llu wavefronts assumed a wrong entry state: lane-per-region path\n", k, (unsigned long long)(h_tot[4 * j + 2] & 0xFFFFFFFFull));
                 return abandon(SX_WAVE_FALLBACK);
             }
+            const bool by_desc = P.desc && (h_tot[4 * j + 2] >> 32) == 0;   // every wavefront of the slab left all its descriptors
+            if (P.desc && !by_desc) ctx->stats.wave_desc_overflows++;
             const uint64_t nf = h_tot[4 * j], nb = h_tot[4 * j + 1];
             if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   ... counted %llu findings, %llu bytes at +%.2f ms\n", (unsigned long long)nf, (unsigned long long)nb, now_ms() - t0);
             final_state = (uint32_t)h_tot[4 * j + 3];
@@ -194,7 +213,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
                 P.arena = d_all + (nfh_j + nf) * sizeof(sx_finding) + nbh_j;
                 P.str_off_base = (uint32_t)nbh_j; P.f_sub = 0; P.a_sub = 0;
                 HIP_TRY(ctx, hipEventRecord(ctx->wave_ev[4 * j + 2], d.stream_b));
-                HIP_TRY(ctx, launch_wave_write(P, v0, v1, d.stream_b));
+                HIP_TRY(ctx, by_desc ? launch_wave_emit(P, v0, v1, d.stream_b) : launch_wave_write(P, v0, v1, d.stream_b));
                 HIP_TRY(ctx, hipEventRecord(ctx->wave_ev[4 * j + 3], d.stream_b));
                 wrote[j] = 1;
             }
@@ -251,6 +270,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
     ctx->stats.wave_windows += g_all - g_lo;
     // the next whole buffer of this Mission does without stage A (sx_schedule.cpp) as long as this one was string-dense
     if (k < ctx->wave_pred.size()) ctx->wave_pred[k] = (nf_all + nfh) * wave_min_density_bytes(m.wave_family) * 2 > len ? 1 : 0;
+    if (k < ctx->wave_density.size() && len) ctx->wave_density[k] = (double)(nf_all + nfh) / (double)len;   // sizes the next buffer's descriptors
     const double t1 = now_ms();
 
     // ---- the state handed to the next buffer

@@ -710,6 +710,43 @@ SXD u64 wv_window_no(u64 p, u32 W, u32 wps) { return p / kWvSlice * wps + (p % k
 // bytes in front of it (UTF-8: a character delivered in the first window may begin there)
 SXD u64 wv_tile0(u64 span_lo) { const u64 a = span_lo & ~15ull; return a >= 16 ? a - 16 : a; }
 
+// ------------------------------------------------------------------------------------------
+// Descriptors: what the count pass leaves behind for a writer that works a LANE PER FINDING.  The window-parallel writer (the count
+// pass run again with an emitter that writes) keeps the lanes of windows without findings idle and classifies every byte a second
+// time; with descriptors the second pass reads 12 bytes per finding and nothing else of the count pass' work.
+//   w0: string offset inside the wavefront's output (19 bits) | window index among the wavefront's own (10) | precision (2) | completes (1)
+//   w1: din (8) | src_rel + 2048 (12) | src_len (12)        w2: out_len (9) | the WV_PROBE payload (lb 9, lback 10, hb 1)
+// A wavefront has room for `cap` of them; one that finds more says so through its count (wave_nf > cap) and the launch falls back to the
+// window-parallel writer.
+// ------------------------------------------------------------------------------------------
+struct WvDesc { u32 w0, w1, w2; };
+constexpr u32 kWvDescMaxWin = 800;   // windows a wavefront may own with descriptors: 800 x 640 string bytes < 2^19
+SXD WvDesc wv_desc_pack(u32 a_local, u32 widx, u32 din, u32 prec, bool completes, i32 src_rel, u32 src_len, u32 out_len) {
+    WvDesc d;
+    d.w0 = (a_local & 0x7FFFFu) | ((widx & 1023u) << 19) | ((prec & 3u) << 29) | (completes ? 0x80000000u : 0u);
+    d.w1 = (din & 255u) | (((u32)(src_rel + 2048) & 4095u) << 8) | ((src_len & 4095u) << 20);
+    d.w2 = (out_len & 511u) | ((prec >> 8) << 9);
+    return d;
+}
+SXD u32 wv_desc_a_local(const WvDesc& d) { return d.w0 & 0x7FFFFu; }
+SXD u32 wv_desc_widx(const WvDesc& d) { return (d.w0 >> 19) & 1023u; }
+SXD u32 wv_desc_prec(const WvDesc& d) { return ((d.w0 >> 29) & 3u) | ((d.w2 >> 9) << 8); }   // as wv_call handed it to the emitter
+SXD bool wv_desc_completes(const WvDesc& d) { return (d.w0 >> 31) != 0; }
+SXD u32 wv_desc_din(const WvDesc& d) { return d.w1 & 255u; }
+SXD i32 wv_desc_src_rel(const WvDesc& d) { return (i32)((d.w1 >> 8) & 4095u) - 2048; }
+SXD u32 wv_desc_src_len(const WvDesc& d) { return d.w1 >> 20; }
+SXD u32 wv_desc_out_len(const WvDesc& d) { return d.w2 & 511u; }
+
+// the count pass' second emitter: descriptors at slot[0 ..], string offsets from a_local on; `room` slots are left (beyond them: counted only)
+struct WvDescEmit {
+    WvDesc* slot;
+    u32 room, a_local, widx;
+    SXD void operator()(u32 din, u32 prec, bool completes, i32 src_rel, u32 src_len, u32 out_len) {
+        if (room) { *slot++ = wv_desc_pack(a_local, widx, din, prec, completes, src_rel, src_len, out_len); room--; }
+        a_local += out_len;
+    }
+};
+
 constexpr u32 kWvWarm = 4;         // windows a wavefront replays in front of its own, only for their state
 constexpr u32 kWvBatch = 64;       // windows per batch: one per lane
 constexpr u32 kWvMaxTiles = 10;    // 1 KiB tiles that cover a batch of 64 windows of <= 128 bytes (+ alignment slack)

@@ -18,6 +18,7 @@
 // Two passes: count (per-wavefront totals -> exclusive scan), write.  No atomics; output order = position order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -52,49 +53,58 @@ struct CountEmit {
     SXD void operator()(u32, u32, bool, i32, u32, u32 out_len) { nf++; nb += out_len; }
 };
 
-// pass 2: the finding record and its string (single byte: transcoded byte by byte through the decoder table)
-template <int FAM> struct WriteEmit {   // (FAM: the family's code only — the two-byte family's probe brings 384 B of scratch with it)
+// the finding record and its string (single byte: transcoded byte by byte through the decoder table).  FAM: the family's code only —
+// the two-byte family's probe brings 384 B of scratch with it.  f / a: where the record and the string go, a_off: the string's offset
+// in the segment's arena, win_pos: buffer offset of the window the finding belongs to.
+template <int FAM>
+SXD void wv_write_finding(const WaveParams& P, sx_finding* f, u8* a, u64 a_off, u64 win_pos, u32 din, u32 prec, bool completes, i32 src_rel,
+                          u32 src_len, u32 out_len) {
+    const u64 soff = win_pos / kWvSlice * kWvSlice;
+    sx_finding r;
+    r.position = P.consumed0 + win_pos + din;
+    r.str_off = (u32)(a_off + P.str_off_base);
+    r.str_len = out_len;
+    if ((prec & 0xFFu) == WV_PROBE) {   // sx_wave_core.hpp WV_PROBE: this call starts at the slice's byte 0
+        const u32 lb = (prec >> 8) & 511u, lback = (prec >> 17) & 1023u, hb = prec >> 27;
+        const u64 avail = P.len - win_pos;
+        if (FAM == 4)   // (a leftover at a second call at byte 0: the byte in front of the slice was a lead byte, not the leftover's)
+            prec = wv_resolve_probe_dbcs((int)P.encoding, P.table, P.data + win_pos, avail < 32 ? (u32)avail : 32u,
+                                         P.data + (win_pos - lback), lb ? lback - 1 : 0u, lb, hb);
+        else if (FAM == 1) prec = wv_resolve_probe(P.data + win_pos, avail < 32 ? (u32)avail : 32u, P.data + (win_pos - lback), lb);
+        else prec = WV_EXACT;   // (single-byte decoders never leave the probe open)
+    }
+    r.precision = (u8)prec;
+    r.completes_previous = completes ? 1 : 0;
+    r.mission_id = (u8)P.mission_id;
+    r.reserved = 0;
+    r.input_file_id = (int16_t)P.file_id;
+    r.reserved2 = 0;
+    r.slice_index = (u32)(soff / kWvSlice) + P.slice_base;
+    *f = r;
+    const u8* s = P.data + (u64)((long long)win_pos + src_rel);
+    if (FAM == 4) (void)wv_transcode_dbcs((int)P.encoding, P.table, s, src_len, a);
+    else if (out_len == src_len) {     // every char is one byte on both sides (ASCII; UTF-8 input)
+        for (u32 t = 0; t < src_len; t++) a[t] = s[t];
+    } else {
+        u32 w = 0;
+        for (u32 t = 0; t < src_len; t++) {
+            const u8 b = s[t];
+            if (b < 0x80) a[w++] = b;
+            else w += dput_cp(a + w, P.table ? (u32)P.table[b - 0x80] : 0xF780u + (b - 0x80u));
+        }
+    }
+}
+
+// the window-parallel writer's emitter (pass 2 = the count pass once more, writing)
+template <int FAM> struct WriteEmit {
     const WaveParams* P;
     sx_finding* f;        // next record of this lane
     u8* a;                // next string byte of this lane
     u64 a_off;            // ... its offset in the segment's string arena
     u64 win_pos;          // buffer offset of the window
     SXD void operator()(u32 din, u32 prec, bool completes, i32 src_rel, u32 src_len, u32 out_len) {
-        const u64 soff = win_pos / kWvSlice * kWvSlice;
-        sx_finding r;
-        r.position = P->consumed0 + win_pos + din;
-        r.str_off = (u32)(a_off + P->str_off_base);
-        r.str_len = out_len;
-        if ((prec & 0xFFu) == WV_PROBE) {   // sx_wave_core.hpp WV_PROBE: this call starts at the slice's byte 0
-            const u32 lb = (prec >> 8) & 511u, lback = (prec >> 17) & 1023u, hb = prec >> 27;
-            const u64 avail = P->len - win_pos;
-            if (FAM == 4)   // (a leftover at a second call at byte 0: the byte in front of the slice was a lead byte, not the leftover's)
-                prec = wv_resolve_probe_dbcs((int)P->encoding, P->table, P->data + win_pos, avail < 32 ? (u32)avail : 32u,
-                                             P->data + (win_pos - lback), lb ? lback - 1 : 0u, lb, hb);
-            else if (FAM == 1) prec = wv_resolve_probe(P->data + win_pos, avail < 32 ? (u32)avail : 32u, P->data + (win_pos - lback), lb);
-            else prec = WV_EXACT;   // (single-byte decoders never leave the probe open)
-        }
-        r.precision = (u8)prec;
-        r.completes_previous = completes ? 1 : 0;
-        r.mission_id = (u8)P->mission_id;
-        r.reserved = 0;
-        r.input_file_id = (int16_t)P->file_id;
-        r.reserved2 = 0;
-        r.slice_index = (u32)(soff / kWvSlice) + P->slice_base;
-        *f++ = r;
-        const u8* s = P->data + (u64)((long long)win_pos + src_rel);
-        if (FAM == 4) (void)wv_transcode_dbcs((int)P->encoding, P->table, s, src_len, a);
-        else if (out_len == src_len) {     // every char is one byte on both sides (ASCII; UTF-8 input)
-            for (u32 t = 0; t < src_len; t++) a[t] = s[t];
-        } else {
-            u32 w = 0;
-            for (u32 t = 0; t < src_len; t++) {
-                const u8 b = s[t];
-                if (b < 0x80) a[w++] = b;
-                else w += dput_cp(a + w, P->table ? (u32)P->table[b - 0x80] : 0xF780u + (b - 0x80u));
-            }
-        }
-        a += out_len; a_off += out_len;
+        wv_write_finding<FAM>(*P, f, a, a_off, win_pos, din, prec, completes, src_rel, src_len, out_len);
+        f++; a += out_len; a_off += out_len;
     }
 };
 
@@ -108,8 +118,21 @@ constexpr int wv_n_masks(int fam) { return fam == 4 ? 9 : fam == 1 ? 6 : 4; }
 
 // MODE 0: count; 1: write.  FAM 0: single-byte decoders; 1: UTF-8; 4: the two-byte family (Big5, Shift_JIS, EUC-KR: 4 wavefronts
 // per block share the 32 KB of pair codes in LDS).
+#ifndef SX_WV_OCC0
+#define SX_WV_OCC0 4   // wavefronts per SIMD the compiler is asked for, count pass: single-byte / UTF-8 / two-byte family
+#define SX_WV_OCC1 4
+#define SX_WV_OCC4 2
+#endif
+#ifndef SX_WV_OCCW0
+#define SX_WV_OCCW0 SX_WV_OCC0   // ... write pass
+#define SX_WV_OCCW1 SX_WV_OCC1
+#define SX_WV_OCCW4 SX_WV_OCC4
+#endif
+constexpr int wv_occ(int mode, int fam) {
+    return mode == 0 ? (fam == 4 ? SX_WV_OCC4 : fam == 1 ? SX_WV_OCC1 : SX_WV_OCC0) : (fam == 4 ? SX_WV_OCCW4 : fam == 1 ? SX_WV_OCCW1 : SX_WV_OCCW0);
+}
 template <int MODE, int FAM, int WPB>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(FAM == 4 ? 2 : 4))) void wave_replay_kernel(const WaveParams P) {
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ(MODE, FAM)))) void wave_replay_kernel(const WaveParams P) {
     // FAM 0: valid, accepted, O2, O3; FAM 1: E, A, F, MA, MB, G; FAM 4: E, A, F, MA, MB, G, O2, O3, O4 — 16 bits per lane and tile
     __shared__ u32 lds_mask_all[WPB][wv_n_masks(FAM)][kWvMaxTiles * 32 + 8];
     __shared__ u8 lds_lut[256];
@@ -317,6 +340,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(FAM ==
             WvState st = wv_unpack(in);
             wv_window<(FAM == 0 ? 0 : FAM == 1 ? 1 : 2)>(WP, w, st, we_);
         }
+        if (MODE == 0 && P.desc && (nf | nb)) {   // the lane-per-finding writer's input (beyond desc_cap: counted only, the launch falls back)
+            const u32 excl = incl - packed;
+            const u32 at = tot_f + (excl >> 18);
+            WvDescEmit de{ (WvDesc*)P.desc + v * (u64)P.desc_cap + at, at < P.desc_cap ? P.desc_cap - at : 0u, tot_b + (excl & 0x3FFFFu),
+                           (u32)(g - own_start) };
+            WvState st = wv_unpack(in);
+            wv_window<(FAM == 0 ? 0 : FAM == 1 ? 1 : 2)>(WP, w, st, de);
+        }
         tot_f += bt >> 18; tot_b += bt & 0x3FFFFu;
         if (g0 + kWvBatch >= own_end && MODE == 0) {
             // (the state after a buffer's last window also says whether it ends inside a token: the next buffer's decoder holds that byte)
@@ -331,11 +362,44 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(FAM ==
 // reached for its first own window what its predecessor really left there?  totals: [0] findings, [1] string bytes,
 // [2] wavefronts whose assumption was wrong, [3] the state after the last window.
 __global__ __launch_bounds__(256) void wave_verify_kernel(const u32* wave_in, const u32* wave_out, const u32* wave_nf, const u32* wave_nb,
-                                                          const u64* fbase, const u64* abase, u64 v0, u64 v1, u64* totals) {
+                                                          const u64* fbase, const u64* abase, u64 v0, u64 v1, u64* totals, u32 desc_cap) {
     const u64 v = v0 + (u64)blockIdx.x * 256 + threadIdx.x;
     if (v >= v1) return;
     if (v > 0 && wave_in[v] != wave_out[v - 1]) atomicAdd((unsigned long long*)&totals[2], 1ull);
+    if (desc_cap && wave_nf[v] > desc_cap) atomicAdd((unsigned long long*)&totals[2], 1ull << 32);   // more findings than descriptors
     if (v + 1 == v1) { totals[0] = fbase[v] + wave_nf[v]; totals[1] = abase[v] + wave_nb[v]; totals[3] = wave_out[v]; }
+}
+
+// The writer that works a lane per finding: wavefront v's descriptors -> records and strings.  No classification, no state machine, no
+// LDS; every lane has work (the window-parallel writer: a lane per window, busy only where a window holds a finding).
+template <int FAM>
+__global__ __launch_bounds__(256) void wave_emit_kernel(const WaveParams P) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 v = P.v0 + (u64)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (v >= P.v1) return;
+    const u32 nf = P.wave_nf[v];
+    const u64 own_start = P.g_lo + v * P.nwin;
+    const u64 fbase = P.wave_fbase[v] - P.f_sub, abase = P.wave_abase[v] - P.a_sub;
+    const WvDesc* d = (const WvDesc*)P.desc + v * (u64)P.desc_cap;
+    for (u32 i = lane; i < nf; i += 64) {
+        const WvDesc x = d[i];
+        u64 ws; u32 wn;
+        wv_window_at(own_start + wv_desc_widx(x), P.W, P.wps, P.len, &ws, &wn);
+        const u64 ao = abase + wv_desc_a_local(x);
+        wv_write_finding<FAM>(P, P.findings + fbase + i, P.arena + ao, ao, ws, wv_desc_din(x), wv_desc_prec(x), wv_desc_completes(x),
+                              wv_desc_src_rel(x), wv_desc_src_len(x), wv_desc_out_len(x));
+    }
+}
+
+hipError_t launch_wave_emit(const WaveParams& P, uint64_t v0, uint64_t v1, hipStream_t stream) {
+    if (v1 <= v0) return hipSuccess;
+    WaveParams Q = P;
+    Q.v0 = v0; Q.v1 = v1;
+    const dim3 grid((unsigned)((v1 - v0 + 3) / 4));
+    if (P.family == 4) hipLaunchKernelGGL((wave_emit_kernel<4>), grid, dim3(256), 0, stream, Q);
+    else if (P.family == 1) hipLaunchKernelGGL((wave_emit_kernel<1>), grid, dim3(256), 0, stream, Q);
+    else hipLaunchKernelGGL((wave_emit_kernel<0>), grid, dim3(256), 0, stream, Q);
+    return hipGetLastError();
 }
 
 struct U32ToU64 {
@@ -358,9 +422,10 @@ hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint
     const uint64_t n = v1 - v0;
     WaveParams Q = P;
     Q.v0 = v0; Q.v1 = v1;
-    if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, Q);
-    else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<0, 1, 1>), dim3((unsigned)n), dim3(64), 0, stream, Q);
-    else hipLaunchKernelGGL((wave_replay_kernel<0, 0, 1>), dim3((unsigned)n), dim3(64), 0, stream, Q);
+    const unsigned dyn = getenv("SX_WAVE_DYN_LDS") ? (unsigned)atoi(getenv("SX_WAVE_DYN_LDS")) : 0u;   // experiments: fewer wavefronts per CU
+    if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
+    else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<0, 1, 1>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
+    else hipLaunchKernelGGL((wave_replay_kernel<0, 0, 1>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
     void* tmp = (void*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
     size_t tmp_bytes = scratch_bytes - (size_t)((uint8_t*)tmp - (uint8_t*)scratch);
     auto itf = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), U32ToU64{ P.wave_nf + v0 });
@@ -373,7 +438,7 @@ hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint
     e = hipMemsetAsync(totals, 0, 4 * sizeof(uint64_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(wave_verify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P.wave_in, P.wave_out, P.wave_nf,
-                       P.wave_nb, fbase, abase, v0, v1, totals);
+                       P.wave_nb, fbase, abase, v0, v1, totals, P.desc ? P.desc_cap : 0u);
     return hipGetLastError();
 }
 
@@ -382,9 +447,10 @@ hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipS
     if (v1 <= v0) return hipSuccess;
     WaveParams Q = P;
     Q.v0 = v0; Q.v1 = v1;
-    if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), 0, stream, Q);
-    else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<1, 1, 1>), dim3((unsigned)(v1 - v0)), dim3(64), 0, stream, Q);
-    else hipLaunchKernelGGL((wave_replay_kernel<1, 0, 1>), dim3((unsigned)(v1 - v0)), dim3(64), 0, stream, Q);
+    const unsigned dyn = getenv("SX_WAVE_DYN_LDS") ? (unsigned)atoi(getenv("SX_WAVE_DYN_LDS")) : 0u;
+    if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
+    else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<1, 1, 1>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
+    else hipLaunchKernelGGL((wave_replay_kernel<1, 0, 1>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
     return hipGetLastError();
 }
 

@@ -227,6 +227,15 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
         u32 bf = 0, bb = 0;
         for (u32 l = 0; l < 64; l++) {
             if (!owned[l]) { nf[l] = 0; nb[l] = 0; }
+            if (MODE == 0 && P.desc && (nf[l] | nb[l])) {   // as the kernel: the descriptors of the lane-per-finding writer
+                const u32 at = tot_f + bf;
+                WvDescEmit de{ (WvDesc*)P.desc + v * (u64)P.desc_cap + at, at < P.desc_cap ? P.desc_cap - at : 0u, tot_b + bb, (u32)(g0 + l - own_start) };
+                WvState st = wv_unpack(in[l]);
+                if (P.family == 0) wv_window<0>(WP, w[l], st, de, skip_idle);
+                else if (P.family == 1) wv_window<1>(WP, w[l], st, de, skip_idle);
+                else wv_window<2>(WP, w[l], st, de, skip_idle);
+                if (de.a_local != tot_b + bb + nb[l]) return false;
+            }
             if (MODE == 1 && (nf[l] | nb[l])) {
                 const u64 fo = fbase + tot_f + bf, ao = abase + tot_b + bb;
                 WriteEmit we{ &P, P.findings + fo, P.arena + ao, ao, ws[l] };
@@ -268,6 +277,10 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
     std::vector<u32> wnf(n_waves), wnb(n_waves), win(n_waves), wout(n_waves);
     std::vector<u64> fb(n_waves), ab(n_waves);
     P.wave_nf = wnf.data(); P.wave_nb = wnb.data(); P.wave_in = win.data(); P.wave_out = wout.data();
+    // descriptors: two per window, or few enough that some wavefronts overflow (then only the window-parallel writer's output is checked)
+    P.desc_cap = (nwin & 3u) == 1u ? nwin / 8 + 1 : 2 * nwin + 64;
+    std::vector<u32> desc((size_t)(n_waves * P.desc_cap * 3 + 3), 0xDEADBEEFu);
+    P.desc = nwin <= kWvDescMaxWin ? desc.data() : nullptr;   // (as sx_wave.cpp: larger wavefronts do without)
     for (u64 v = 0; v < n_waves; v++) if (!wave<0>(P, v, skip_idle != 0, rounds_max)) return -1;
     u64 f = 0, a = 0;
     for (u64 v = 0; v < n_waves; v++) {
@@ -279,6 +292,28 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
     P.wave_fbase = fb.data(); P.wave_abase = ab.data(); P.findings = fout; P.arena = aout;
     u32 dummy = 0;
     for (u64 v = 0; v < n_waves; v++) if (!wave<1>(P, v, skip_idle != 0, &dummy)) return -1;
+    // the lane-per-finding writer (sx_wave_dev.hip wave_emit_kernel) from the count pass' descriptors: the same records and strings
+    bool overflow = false;
+    for (u64 v = 0; v < n_waves; v++) overflow = overflow || wnf[v] > P.desc_cap;
+    if (!overflow && P.desc) {
+        std::vector<sx_finding> f2((size_t)f + 1);
+        std::vector<u8> a2((size_t)a + 8, 0);
+        for (u64 v = 0; v < n_waves; v++) {
+            const u64 own_start = P.g_lo + v * P.nwin;
+            const WvDesc* d = (const WvDesc*)P.desc + v * (u64)P.desc_cap;
+            for (u32 i = 0; i < wnf[v]; i++) {
+                const WvDesc x = d[i];
+                u64 ws; u32 wn;
+                wv_window_at(own_start + wv_desc_widx(x), P.W, P.wps, P.len, &ws, &wn);
+                const u64 ao = ab[v] + wv_desc_a_local(x);
+                WriteEmit we{ &P, f2.data() + fb[v] + i, a2.data() + ao, ao, ws };
+                we(wv_desc_din(x), wv_desc_prec(x), wv_desc_completes(x), wv_desc_src_rel(x), wv_desc_src_len(x), wv_desc_out_len(x));
+                if (we.bad_len) return -3;
+            }
+        }
+        if (f && memcmp(f2.data(), fout, (size_t)f * sizeof(sx_finding)) != 0) return -4;
+        if (a && memcmp(a2.data(), aout, (size_t)a) != 0) return -5;
+    }
     return 0;
 }
 

@@ -56,6 +56,37 @@ def test_wave_path_equals_the_oracle(wave_forced, mi):
             assert wave_windows_of_a_scan(ms, data) > 0, name   # the wave kernels did run
 
 
+def test_both_writers_give_the_same(wave_forced):
+    """the lane-per-finding writer (descriptors left by the count pass, the default), the window-parallel writer (SX_WAVE_DESC=0), and the
+    way from one to the other when a wavefront finds more than its descriptors hold (SX_WAVE_DESC_CAP) — in slabs too"""
+    rng = random.Random(77)
+    cases = [(dict(encodings=["ascii"], chars_min="4"), rng.randbytes(700_000) + text_lines(rng, 300_000)),
+             (dict(encodings=["utf-8"], chars_min="3"), soup(rng, 400_000) + text_lines(rng, 200_000, 100, 700)),
+             (dict(encodings=["koi8-r"], chars_min="2", unicode_block_filter="Cyrillic"), rng.randbytes(600_000)),
+             (dict(encodings=["big5"], chars_min="3", unicode_block_filter="Cjk"), rng.randbytes(500_000) + text_lines(rng, 100_000)),
+             (dict(encodings=["shift_jis"], chars_min="10"), rng.randbytes(300_000) + "日本語のテキスト、\n".encode("shift_jis") * 9000)]
+    keys = ("SX_WAVE_DESC", "SX_WAVE_DESC_CAP", "SX_WAVE_SLABS")
+    try:
+        for flags, data in cases:
+            ms = rc.missions(**flags)
+            want = sxo.run_cli(ms, [data], radix="x")
+            for sw in ({}, {"SX_WAVE_DESC": "0"}, {"SX_WAVE_DESC_CAP": "5"}, {"SX_WAVE_DESC_CAP": "300", "SX_WAVE_SLABS": "3"}, {"SX_WAVE_SLABS": "4"}):
+                for k in keys:
+                    os.environ.pop(k, None)
+                os.environ.update(sw)
+                for chunk in (None, 1 << 17):
+                    assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (flags, sw, chunk)
+        # the overflow is seen and counted
+        os.environ["SX_WAVE_DESC_CAP"] = "5"; os.environ.pop("SX_WAVE_SLABS", None); os.environ.pop("SX_WAVE_DESC", None)
+        sc = sx.Scanner(rc.missions(encodings=["ascii"], chars_min="4"), device=0)
+        res = sc.scan(rng.randbytes(1 << 20), file_id=1)
+        assert sc.stats().wave_desc_overflows > 0
+        res.free(); sc.close()
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
+
+
 def test_wave_path_next_to_other_missions(wave_forced):
     """three Missions, two of them through the wave kernels: merge order, per-Mission state from chunk to chunk, two files"""
     ms = rc.missions(encodings=["ascii", "utf-8", "koi8-r,,,Cyrillic"], chars_min="5")

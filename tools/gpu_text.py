@@ -13,7 +13,12 @@ for _ in range(20000):
     lines.append(bytes(l[:n]) + b"\n")
 blob = b"".join(lines)
 data = (blob * (mib * (1 << 20) // len(blob) + 1))[:mib << 20]
-for flags in (dict(encodings=["ascii"], chars_min="4"), dict(encodings=["utf-8"], chars_min="10")):
+blob16 = blob.decode().encode("utf-16-le")
+data16 = (blob16 * (mib * (1 << 20) // len(blob16) + 1))[:mib << 20]
+cases = [(dict(encodings=["ascii"], chars_min="4"), data), (dict(encodings=["utf-8"], chars_min="10"), data),
+         (dict(encodings=["utf-16le"], chars_min="10"), data16)]
+if len(sys.argv) > 2: cases = [c for c in cases if c[0]["encodings"][0] in sys.argv[2:]]
+for flags, data in cases:
     ms = rc.missions(**flags)
     sc = sx.Scanner(ms, device=0)
     d = sc.alloc(len(data)); sc.upload(d, data)
