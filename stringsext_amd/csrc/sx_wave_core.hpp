@@ -747,6 +747,21 @@ struct WvDescEmit {
     }
 };
 
+// the count pass' emitter: counts, and keeps the first K findings of the window as descriptors (string offset: inside the window's own
+// output; the wavefront's prefix sums are added when they are known) — most windows hold no more, and the others are replayed once
+// more with WvDescEmit
+template <int K> struct WvCountEmit {
+    u32 nf = 0, nb = 0, widx = 0;
+    WvDesc d0{ 0, 0, 0 }, d1{ 0, 0, 0 }, d2{ 0, 0, 0 };
+    SXD void operator()(u32 din, u32 prec, bool completes, i32 src_rel, u32 src_len, u32 out_len) {
+        if (K > 0 && nf < (u32)K) {
+            const WvDesc x = wv_desc_pack(nb, widx, din, prec, completes, src_rel, src_len, out_len);
+            if (nf == 0) d0 = x; else if (K > 1 && nf == 1) d1 = x; else if (K > 2) d2 = x;
+        }
+        nf++; nb += out_len;
+    }
+};
+
 constexpr u32 kWvWarm = 4;         // windows a wavefront replays in front of its own, only for their state
 constexpr u32 kWvBatch = 64;       // windows per batch: one per lane
 constexpr u32 kWvMaxTiles = 10;    // 1 KiB tiles that cover a batch of 64 windows of <= 128 bytes (+ alignment slack)

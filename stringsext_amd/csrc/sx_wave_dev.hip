@@ -48,11 +48,6 @@ SXD u32 wv_scan_incl(u32 v, u32 lane) {
     return v;
 }
 
-struct CountEmit {
-    u32 nf = 0, nb = 0;
-    SXD void operator()(u32, u32, bool, i32, u32, u32 out_len) { nf++; nb += out_len; }
-};
-
 // the finding record and its string (single byte: transcoded byte by byte through the decoder table).  FAM: the family's code only —
 // the two-byte family's probe brings 384 B of scratch with it.  f / a: where the record and the string go, a_off: the string's offset
 // in the segment's arena, win_pos: buffer offset of the window the finding belongs to.
@@ -201,7 +196,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 }
             }
         }
-        for (int t = t_first; t < (int)n_tiles; t++) {
+        // the lane's 16 bytes of tile t (zero where the buffer has none); the next tile's are on their way while this one is classified
+        auto load_tile = [&](int t) -> u32x4 {
             const long long soff = (long long)tile0 + (long long)t * (long long)kTileBytes + 16ll * lane;
             const u64 off = soff < 0 ? 0ull : (u64)soff;
             u32x4 x = { 0, 0, 0, 0 };
@@ -212,6 +208,17 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 for (u32 k = 0; k < avail; k++) xs[k >> 2] |= (u32)P.data[off + k] << (8 * (k & 3));
                 x.x = xs[0]; x.y = xs[1]; x.z = xs[2]; x.w = xs[3];
             }
+            return x;
+        };
+        u32x4 x_next = load_tile(t_first);
+        u32 prev_w63 = 0;   // the last dword of the tile before (lane 63's x.w): the four bytes in front of lane 0
+        for (int t = t_first; t < (int)n_tiles; t++) {
+            const long long soff = (long long)tile0 + (long long)t * (long long)kTileBytes + 16ll * lane;
+            const u64 off = soff < 0 ? 0ull : (u64)soff;
+            const u32 avail = soff < 0 || off >= P.len ? 0u : (P.len - off >= 16 ? 16u : (u32)(P.len - off));
+            const u32x4 x = x_next;
+            const bool more = t + 1 < (int)n_tiles;
+            if (more) x_next = load_tile(t + 1);
             const u32 idx = (u32)(t < 0 ? 0 : t) * 64 + lane;
             if (FAM == 0) {
                 const WvMasks16 m = wv_classify16_single(lds_lut, x.x, x.y, x.z, x.w, avail);
@@ -220,15 +227,21 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 ((uint16_t*)lds_mask[2])[idx] = (uint16_t)m.o2;
                 ((uint16_t*)lds_mask[3])[idx] = (uint16_t)m.o3;
             } else {
-                // the four bytes in front of the lane's 16 and the four behind them (the neighbours' bytes: cache hits)
-                u32 back = 0, ahead = 0;
-                if (off >= 4 && avail) back = *(const u32*)(P.data + off - 4);
+                // the four bytes in front of the lane's 16 and the four behind them: the neighbours' registers (one DPP move each); lane 0
+                // of the batch's first tile and lane 63 read them from memory
+                u32 back = wv_from_prev(x.w, prev_w63);
+                if (lane == 0 && t == t_first) back = off >= 4 && avail ? *(const u32*)(P.data + off - 4) : 0u;
+                if (!(off >= 4 && avail)) back = 0;
                 u32 n_ahead = 0;
-                if (avail == 16 && off + 16 < P.len) {
-                    n_ahead = P.len - (off + 16) >= 4 ? 4u : (u32)(P.len - (off + 16));
+                if (avail == 16 && off + 16 < P.len) n_ahead = P.len - (off + 16) >= 4 ? 4u : (u32)(P.len - (off + 16));
+                u32 ahead = __builtin_amdgcn_update_dpp(0u, x.x, 0x130, 0xF, 0xF, false);   // lane i <- lane i + 1
+                if (lane == 63) {   // (not the next tile's first dword: waiting for it here would undo the prefetch)
+                    ahead = 0;
                     if (n_ahead == 4) ahead = *(const u32*)(P.data + off + 16);
                     else for (u32 k = 0; k < n_ahead; k++) ahead |= (u32)P.data[off + 16 + k] << (8 * k);
                 }
+                if (n_ahead == 0) ahead = 0;
+                prev_w63 = (u32)__builtin_amdgcn_readlane(x.w, 63);
                 const u32 ws6[6] = { back, x.x, x.y, x.z, x.w, ahead };
                 const u32 have_lo = off >= 4 ? 0u : 4u, have_hi = 4u + avail + n_ahead;
                 if (FAM == 1) {
@@ -289,8 +302,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 w = wv_win_single(wv_extract(lds_mask[0], o, n), wv_extract(lds_mask[1], o, n), wv_extract(lds_mask[2], o, n),
                                   wv_extract(lds_mask[3], o, n), n, P.n_min);
             else if (FAM == 4) {
-                const u32 eb = o >= 1 ? (u32)wv_extract(lds_mask[0], o - 1, 1).lo : 1u, mab = o >= 1 ? (u32)wv_extract(lds_mask[3], o - 1, 1).lo : 0u;
-                const u32 fb1 = o >= 1 ? (u32)wv_extract(lds_mask[2], o - 1, 1).lo : 0u;
+                // (the byte in front of the window: one bit of three masks)
+                const u32 ob = o >= 1 ? o - 1 : 0u;
+                const u32 eb = o >= 1 ? (lds_mask[0][ob >> 5] >> (ob & 31u)) & 1u : 1u, mab = o >= 1 ? (lds_mask[3][ob >> 5] >> (ob & 31u)) & 1u : 0u;
+                const u32 fb1 = o >= 1 ? (lds_mask[2][ob >> 5] >> (ob & 31u)) & 1u : 0u;
                 w = wv_win_dbcs(wv_extract(lds_mask[0], o, n), wv_extract(lds_mask[1], o, n), wv_extract(lds_mask[2], o, n),
                                 wv_extract(lds_mask[FAM == 4 ? 5 : 0], o, n), wv_extract(lds_mask[3], o, n), wv_extract(lds_mask[FAM == 4 ? 4 : 0], o, n),
                                 wv_extract(lds_mask[FAM == 4 ? 6 : 0], o, n), wv_extract(lds_mask[FAM == 4 ? 7 : 0], o, n),
@@ -309,10 +324,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         if (injected) in = P.inject;
         u32 nf = 0, nb = 0;
         bool todo = true;
+        constexpr int KD = MODE == 0 ? 2 : 0;   // findings per window whose descriptors the count pass keeps in registers
+        WvCountEmit<KD> ce;
         for (;;) {
             if (todo && active) {
                 WvState st = wv_unpack(in);
-                CountEmit ce;
+                ce = WvCountEmit<KD>{};
+                ce.widx = (u32)(g - own_start);
                 wv_window<(FAM == 0 ? 0 : FAM == 1 ? 1 : 2)>(WP, w, st, ce);
                 out = wv_pack(st); nf = ce.nf; nb = ce.nb;
             } else if (!active) out = in;
@@ -340,13 +358,20 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             WvState st = wv_unpack(in);
             wv_window<(FAM == 0 ? 0 : FAM == 1 ? 1 : 2)>(WP, w, st, we_);
         }
-        if (MODE == 0 && P.desc && (nf | nb)) {   // the lane-per-finding writer's input (beyond desc_cap: counted only, the launch falls back)
+        if (MODE == 0 && P.desc && nf) {   // the lane-per-finding writer's input (beyond desc_cap: counted only, the launch falls back)
             const u32 excl = incl - packed;
-            const u32 at = tot_f + (excl >> 18);
-            WvDescEmit de{ (WvDesc*)P.desc + v * (u64)P.desc_cap + at, at < P.desc_cap ? P.desc_cap - at : 0u, tot_b + (excl & 0x3FFFFu),
-                           (u32)(g - own_start) };
-            WvState st = wv_unpack(in);
-            wv_window<(FAM == 0 ? 0 : FAM == 1 ? 1 : 2)>(WP, w, st, de);
+            const u32 at = tot_f + (excl >> 18), ab = tot_b + (excl & 0x3FFFFu);
+            WvDesc* slot = (WvDesc*)P.desc + v * (u64)P.desc_cap + at;
+            const u32 room = at < P.desc_cap ? P.desc_cap - at : 0u;
+            if (nf <= (u32)KD) {   // the usual window: what the count kept, its string offsets moved to the wavefront's
+                if (room >= 1) { WvDesc x = ce.d0; x.w0 += ab; slot[0] = x; }
+                if (KD > 1 && nf >= 2 && room >= 2) { WvDesc x = ce.d1; x.w0 += ab; slot[1] = x; }
+                if (KD > 2 && nf >= 3 && room >= 3) { WvDesc x = ce.d2; x.w0 += ab; slot[2] = x; }
+            } else {
+                WvDescEmit de{ slot, room, ab, (u32)(g - own_start) };
+                WvState st = wv_unpack(in);
+                wv_window<(FAM == 0 ? 0 : FAM == 1 ? 1 : 2)>(WP, w, st, de);
+            }
         }
         tot_f += bt >> 18; tot_b += bt & 0x3FFFFu;
         if (g0 + kWvBatch >= own_end && MODE == 0) {

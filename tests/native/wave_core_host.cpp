@@ -189,6 +189,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
             }
         }
         u32 in[64], out[64], nf[64], nb[64];
+        WvCountEmit<2> kept[64];   // (the kernel's count pass keeps a window's first two findings as descriptors in registers)
         bool todo[64], injected[64];
         for (u32 l = 0; l < 64; l++) {
             injected[l] = g0 + l == P.g_lo;
@@ -202,7 +203,9 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
             for (u32 l = 0; l < 64; l++) {
                 if (todo[l] && active[l]) {
                     WvState st = wv_unpack(in[l]);
-                    CountEmit ce;
+                    WvCountEmit<2>& ce = kept[l];
+                    ce = WvCountEmit<2>{};
+                    ce.widx = (u32)(g0 + l - own_start);
                     if (P.family == 0) wv_window<0>(WP, w[l], st, ce, skip_idle);
                     else if (P.family == 1) wv_window<1>(WP, w[l], st, ce, skip_idle);
                     else wv_window<2>(WP, w[l], st, ce, skip_idle);
@@ -227,14 +230,21 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
         u32 bf = 0, bb = 0;
         for (u32 l = 0; l < 64; l++) {
             if (!owned[l]) { nf[l] = 0; nb[l] = 0; }
-            if (MODE == 0 && P.desc && (nf[l] | nb[l])) {   // as the kernel: the descriptors of the lane-per-finding writer
-                const u32 at = tot_f + bf;
-                WvDescEmit de{ (WvDesc*)P.desc + v * (u64)P.desc_cap + at, at < P.desc_cap ? P.desc_cap - at : 0u, tot_b + bb, (u32)(g0 + l - own_start) };
-                WvState st = wv_unpack(in[l]);
-                if (P.family == 0) wv_window<0>(WP, w[l], st, de, skip_idle);
-                else if (P.family == 1) wv_window<1>(WP, w[l], st, de, skip_idle);
-                else wv_window<2>(WP, w[l], st, de, skip_idle);
-                if (de.a_local != tot_b + bb + nb[l]) return false;
+            if (MODE == 0 && P.desc && nf[l]) {   // as the kernel: the descriptors of the lane-per-finding writer
+                const u32 at = tot_f + bf, ab = tot_b + bb;
+                WvDesc* slot = (WvDesc*)P.desc + v * (u64)P.desc_cap + at;
+                const u32 room = at < P.desc_cap ? P.desc_cap - at : 0u;
+                if (nf[l] <= 2) {
+                    if (room >= 1) { WvDesc x = kept[l].d0; x.w0 += ab; slot[0] = x; }
+                    if (nf[l] >= 2 && room >= 2) { WvDesc x = kept[l].d1; x.w0 += ab; slot[1] = x; }
+                } else {
+                    WvDescEmit de{ slot, room, ab, (u32)(g0 + l - own_start) };
+                    WvState st = wv_unpack(in[l]);
+                    if (P.family == 0) wv_window<0>(WP, w[l], st, de, skip_idle);
+                    else if (P.family == 1) wv_window<1>(WP, w[l], st, de, skip_idle);
+                    else wv_window<2>(WP, w[l], st, de, skip_idle);
+                    if (de.a_local != ab + nb[l]) return false;
+                }
             }
             if (MODE == 1 && (nf[l] | nb[l])) {
                 const u64 fo = fbase + tot_f + bf, ao = abase + tot_b + bb;
