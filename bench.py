@@ -171,7 +171,7 @@ def main():
     t0 = time.perf_counter()
     kernel_ms = [0.0] * len(missions)
     device_ms = replay_ms = d2h_ms = wave_count_ms = wave_write_ms = 0.0
-    wave_windows = rescans = 0
+    wave_windows = rescans = seq_pieces = 0
     rescan_ms = 0.0
     findings = records = replay_bytes = 0
     for _ in range(args.steps):
@@ -189,6 +189,7 @@ def main():
         wave_count_ms += st.wave_count_ms
         wave_write_ms += st.wave_write_ms
         wave_windows = st.wave_windows
+        seq_pieces = st.seq_pieces
     barrier()
     dt = time.perf_counter() - t0
     marker()
@@ -285,6 +286,9 @@ def main():
             "exchange_ms_per_step": round(timings.get("exchange_ms", 0.0), 3) if world > 1 else None,
             "findings_per_step": findings, "run_records_rank0": records,
             "replay_fraction": round(replay_bytes / (len(missions) * nbytes), 5),
+            # a buffer whose output is gigabytes (several string-dense Missions) is scanned in this many pieces, one after the other,
+            # the copy of a piece's interleaved findings next to the following piece's kernels (0: in one go)
+            "sequential_pieces": int(seq_pieces),
             "kernels_only_gib_s": round(world * nbytes / (span_all * 1e-3) / (1 << 30), 1) if span_all > 0 else None,
         }
         if not args.no_cpu_baseline:

@@ -130,6 +130,7 @@ typedef struct sx_stats {
     uint64_t rescans;                    /* scan kernels launched a second time (their records overflowed the regions / the pool) */
     double   rescan_ms;                  /* ... host time until their records were there */
     uint64_t wave_desc_overflows;        /* wave stage B: slabs written by the window-parallel writer because a wavefront found more than its descriptors hold */
+    uint64_t seq_pieces;                 /* pieces a buffer with gigabytes of output was scanned in, one after the other (0: in one go) */
 } sx_stats;
 
 typedef struct sx_ctx sx_ctx;

@@ -157,7 +157,7 @@ class Stats(C.Structure):
                 ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("replay_ms", C.c_double),
                 ("total_ms", C.c_double), ("heavy_tiles", C.c_uint64), ("wave_windows", C.c_uint64),
                 ("wave_count_ms", C.c_double), ("wave_write_ms", C.c_double), ("rescans", C.c_uint64), ("rescan_ms", C.c_double),
-                ("wave_desc_overflows", C.c_uint64)]
+                ("wave_desc_overflows", C.c_uint64), ("seq_pieces", C.c_uint64)]
 
 
 class Options(C.Structure):

@@ -72,6 +72,7 @@ int ensure_pinned2(sx_ctx* ctx, uint64_t bytes) {
 }
 int ensure_scratch(sx_ctx* ctx, uint64_t bytes) {
     if (ctx->d_scratch_cap >= bytes) return SX_OK;
+    if (ctx->merge_async) { const int rc = merge_drain(ctx); if (rc != SX_OK) return rc; }   // (a queued sort may read its cut table here)
     if (ctx->d_scratch) HIP_TRY(ctx, hipFree(ctx->d_scratch));
     ctx->d_scratch = nullptr; ctx->d_scratch_cap = 0;
     bytes += bytes / 4 + (1u << 20);
@@ -102,6 +103,7 @@ int ensure_cache(sx_ctx* ctx, uint64_t bytes) {
 }
 int ensure_rp(sx_ctx* ctx, MissionDev& d, int slot, uint64_t bytes) {
     if (d.d_rp_cap[slot] >= bytes) return SX_OK;
+    if (ctx->merge_async) { const int rc = merge_drain(ctx); if (rc != SX_OK) return rc; }   // (a queued sort may still read this Mission's findings)
     if (d.d_rp[slot]) HIP_TRY(ctx, hipFree(d.d_rp[slot]));
     d.d_rp[slot] = nullptr; d.d_rp_cap[slot] = 0;
     bytes += bytes / 4 + 4096;
@@ -293,6 +295,7 @@ void sx_destroy(sx_ctx* ctx) {
         if (ctx->d_cache) (void)hipFree(ctx->d_cache);
         if (ctx->post_stream) (void)hipStreamDestroy(ctx->post_stream);
         if (ctx->merge_copy_stream) (void)hipStreamDestroy(ctx->merge_copy_stream);
+        if (ctx->d_merge) (void)hipFree(ctx->d_merge);
         for (hipEvent_t e : ctx->merge_ev) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ctx->wave_ev) if (e) (void)hipEventDestroy(e);
         if (ctx->d_input) (void)hipFree(ctx->d_input);

@@ -137,6 +137,14 @@ struct sx_ctx {
     uint64_t d_cache_cap = 0;
     hipStream_t merge_copy_stream = nullptr;   // device_merge: the copy of one part next to the sort of the following one
     hipEvent_t merge_ev[3] = { nullptr, nullptr, nullptr };
+    // device_merge's own memory (two output buffers of merge_out_room bytes each, then the sort's scratch): the copy of a part may
+    // still read it while the next piece of the buffer is scanned and replayed (merge_async, scan_common's sequential pieces)
+    uint8_t* d_merge = nullptr; uint64_t d_merge_cap = 0, merge_out_room = 0, merge_n_out = 0;
+    bool merge_async = false;                           // device_merge returns with its last copies in flight; merge_drain() waits
+    bool merge_copy_pending[2] = { false, false };      // a copy out of output buffer 0 / 1 was queued and not waited for
+    uint64_t merge_parts = 0;                           // parts merged so far (their parity picks the output buffer)
+    uint64_t merged_out_bytes = 0;                      // bytes device_merge sent to the host (all calls)
+    double out_density = 0;                             // ... per input byte of the last whole buffer: sizes the next one's pieces
     unsigned n_cus = 256, scan_blocks_per_cu = 8;
     // sx_scan_stream: two pinned host buffers and two device buffers, filled by a reader thread
     hipStream_t copy_stream = nullptr;
@@ -240,6 +248,7 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                    const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si);
 struct ReplayJob;
 int ensure_copy_stream(sx_ctx* ctx);   // sx_stage_b.cpp
+int merge_drain(sx_ctx* ctx);          // sx_stage_b.cpp: waits for what device_merge left in flight (merge_async)
 int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_bytes, uint64_t len,
                    const std::vector<uint32_t>& parity, const std::vector<uint64_t>& min_chars, int si,
                    std::vector<RunList>* out, bool cut_into_pieces = false, const ReplayJob* wave_job = nullptr);

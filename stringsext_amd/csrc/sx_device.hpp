@@ -196,9 +196,8 @@ hipError_t merge_findings_device_part(const sx_finding* const* f, const uint8_t*
 hipError_t launch_slab_cuts(const ReplayParams& P, uint32_t n_slabs, uint64_t* idx, uint64_t* hi, hipStream_t stream);
 hipError_t launch_merge_cuts(const sx_finding* f, uint64_t n, uint64_t nb, const uint64_t* cuts, uint32_t n_cuts, uint64_t* idx,
                              uint64_t* off, hipStream_t stream);
-size_t merge_findings_scratch_bytes(uint64_t n_findings);
-hipError_t merge_findings_device(const void* const* srcs, const uint64_t* nf, const uint64_t* nb, int n_missions, void* out,
-                                 void* scratch, size_t scratch_bytes, hipStream_t stream);
+size_t merge_findings_scratch_bytes(uint64_t n_findings, int n_missions);
+hipError_t launch_copy_bytes(void* dst, const void* src, uint64_t bytes, uint32_t workgroups, hipStream_t stream);
 
 // order run records by start on the device (sx_sort.hip); unused slots end up last with start = ~0
 size_t sort_scratch_bytes(uint32_t n);

@@ -23,6 +23,32 @@ uint64_t piece_bytes(const sx_ctx* ctx, uint64_t len) {
     return piece / kInputBufLen * kInputBufLen;
 }
 
+// Bytes per piece of a buffer whose OUTPUT is large (several Missions on string-dense input: BASELINE config 5 yields 19 GB of
+// findings per 64 GiB), or `len`.  Such a scan is bound by the copy of the interleaved findings to the host (53 GB/s), which
+// device_merge can only start when every Mission has replayed the range: the buffer is cut into pieces that are scanned, replayed
+// and merged one after the other — each piece starts when the one before has left its ScannerState, exactly like consecutive
+// sx_scan calls, so the double-byte Missions' token grid is known — and the copy of a piece's findings runs next to the kernels
+// of the following piece (sx_ctx::merge_async).  Sized from the last buffer's output so that a piece's findings are one part of
+// the merger (2.25 GB); the first buffer of a stream is scanned in one go.  SX_SEQ_PIECE_MIB / SX_SEQ_PIECE_KIB set the size (0: never).
+static uint64_t seq_piece_bytes(const sx_ctx* ctx, uint64_t len) {
+    uint64_t piece = 0;
+    if (const char* e = getenv("SX_SEQ_PIECE_KIB")) {   // (tests: small buffers)
+        piece = (uint64_t)atoll(e) << 10;
+        if (piece == 0) return len;
+    } else if (const char* e = getenv("SX_SEQ_PIECE_MIB")) {
+        piece = (uint64_t)atoll(e) << 20;
+        if (piece == 0) return len;
+    } else {
+        if (ctx->missions.size() < 2 || ctx->out_density <= 0) return len;
+        const double out = ctx->out_density * (double)len;
+        if (out < 4.0 * (double)(1ull << 30)) return len;
+        const uint64_t n = (uint64_t)(out / (2.25 * (double)(1ull << 30))) + 1;
+        piece = std::max<uint64_t>((len + n - 1) / n, 1ull << 30);   // (n equal pieces: no sliver at the end)
+    }
+    piece = std::max<uint64_t>((piece + kInputBufLen - 1) / kInputBufLen, 2) * kInputBufLen;
+    return len < 2 * piece ? len : piece;
+}
+
 // What the scan kernel needs to know about the state at buffer byte 0: UTF-16 the unit parity of the stream
 // offset; Big5 / EUC-JP how many bytes finish the token pending in the carried decoder (0 without a state).
 static int entry_param(sx_ctx* ctx, size_t k, const Decoder* carried, const uint8_t* host_bytes, const uint8_t* d_bytes,
@@ -77,6 +103,8 @@ void mission_order(sx_ctx* ctx, std::vector<int>* out) {
 }
 
 int sync_streams_and_return(sx_ctx* ctx, int rc) {  // do not leave kernels running on the caller's buffer
+    ctx->merge_async = false;
+    (void)merge_drain(ctx);   // ... nor copies into blocks of a result that is about to be freed
     for (auto& d : ctx->dev) { (void)hipStreamSynchronize(d.stream); (void)hipStreamSynchronize(d.stream_b); }
     return rc;
 }
@@ -208,8 +236,11 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
     for (size_t k = 0; k < nm; k++) stream0[k] = ctx->states[k].stream_bytes;
     std::vector<int> order;
     mission_order(ctx, &order);
-    const uint64_t piece = piece_bytes(ctx, len);
+    const uint64_t seq_piece = ctx->host_only ? len : seq_piece_bytes(ctx, len);
+    const bool seq = seq_piece < len;
+    const uint64_t piece = seq ? seq_piece : piece_bytes(ctx, len);
     const uint64_t n_pieces = len ? (len + piece - 1) / piece : 1;
+    const uint64_t merged0 = ctx->merged_out_bytes;
     int entry_rc = SX_OK;   // (a failed read of the buffer's first bytes must not go unnoticed: the token grid would be wrong)
     auto make = [&](uint64_t p) {
         BufferScan b;
@@ -233,10 +264,32 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
         return b;
     };
     ResultHolder res;
+    int rc = SX_OK;
+    if (seq) {   // one piece after the other, the copy of a piece's findings next to the following piece's kernels
+        ctx->merge_async = true;
+        ctx->stats.seq_pieces += n_pieces;
+        for (uint64_t p = 0; p < n_pieces; p++) {
+            BufferScan b = make(p);   // (the ScannerStates the piece in front left)
+            if (entry_rc != SX_OK) return sync_streams_and_return(ctx, entry_rc);
+            if ((rc = b.launch(ctx)) != SX_OK) return sync_streams_and_return(ctx, rc);
+            if ((rc = b.fetch_base(ctx)) != SX_OK) return sync_streams_and_return(ctx, rc);
+            ReplayJob job = whole_chunk_job(ctx, b.len, file_id, is_last != 0 && p + 1 == n_pieces);
+            job.d_bytes = b.d_bytes;
+            job.slice_base = slice_base0 + (uint32_t)(p * piece / kInputBufLen);
+            std::vector<RunList> runs;
+            rc = b.finish_and_replay(ctx, job, nullptr, &runs, append_to ? &append_to->r : &res.r->r, nullptr);
+            if (rc != SX_OK) return sync_streams_and_return(ctx, rc);
+        }
+        ctx->merge_async = false;
+        if ((rc = merge_drain(ctx)) != SX_OK) return sync_streams_and_return(ctx, rc);
+        if (len) ctx->out_density = (double)(ctx->merged_out_bytes - merged0) / (double)len;
+        ctx->stats.total_ms = now_ms() - t_begin;
+        if (!append_to) *out = res.release();
+        return SX_OK;
+    }
     std::vector<BufferScan> pieces;
     for (uint64_t p = 0; p < n_pieces; p++) pieces.push_back(make(p));
     if (entry_rc != SX_OK) return entry_rc;
-    int rc = SX_OK;
     uint64_t launched = 0;
     for (; launched < std::min<uint64_t>(2, n_pieces); launched++)
         if ((rc = pieces[launched].launch(ctx)) != SX_OK) return sync_streams_and_return(ctx, rc);
@@ -255,6 +308,7 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
                                  &runs, append_to ? &append_to->r : &res.r->r, nullptr);
         if (rc != SX_OK) return sync_streams_and_return(ctx, rc);
     }
+    if (len) ctx->out_density = (double)(ctx->merged_out_bytes - merged0) / (double)len;
     ctx->stats.total_ms = now_ms() - t_begin;
     if (!append_to) *out = res.release();
     return SX_OK;

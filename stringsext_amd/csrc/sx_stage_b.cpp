@@ -450,11 +450,19 @@ static int fetch_deferred(sx_ctx* ctx, MissionFindings& mf) {
     return SX_OK;
 }
 
+int merge_drain(sx_ctx* ctx) {
+    if (ctx->post_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->post_stream));
+    if (ctx->merge_copy_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->merge_copy_stream));
+    ctx->merge_copy_pending[0] = ctx->merge_copy_pending[1] = false;
+    return SX_OK;
+}
+
 // The merger (src/main.rs:118-136) on the device: the missions' findings, each ordered by position and still in HBM, are
-// interleaved by a stable radix sort on the position and arrive on the host as they will be printed.  str_off has 32 bits, and
-// the sort's scratch is a multiple of its input: a large output is cut at slice boundaries into parts (each at most
-// SX_MERGE_PART_MIB of strings and SX_MERGE_PART_FINDINGS findings) that become one segment of the result each; the copy of
-// part j runs while part j+1 is sorted.  If the conditions do not hold the host merges (merge_findings).
+// interleaved there (sx_sort.hip: every finding's place follows from short searches in the other missions' lists) and arrive on
+// the host as they will be printed.  str_off has 32 bits and the place table 32-bit indices: a large output is cut at slice
+// boundaries into parts (each at most SX_MERGE_PART_MIB of strings and SX_MERGE_PART_FINDINGS findings) that become one segment
+// of the result each; the copy of part j runs while part j+1 is interleaved.  If the conditions do not hold the host merges
+// (merge_findings).
 static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFindings>& per, Result* into) {
     const size_t nm = per.size();
     size_t with = 0, on_dev = 0, deferred = 0;
@@ -526,12 +534,23 @@ static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFi
         max_out = std::max(max_out, pf * sizeof(sx_finding) + pb); max_n = std::max(max_n, pf);
     }
     const size_t out_room = (max_out + 511) & ~(size_t)255;
-    const size_t n_out = K > 1 ? 2 : 1;
-    int rc = ensure_scratch(ctx, n_out * out_room + merge_findings_scratch_bytes(max_n) + 512);
-    if (rc != SX_OK) return rc;
-    uint8_t* d_tmp = ctx->d_scratch + n_out * out_room;
-    const size_t tmp_bytes = ctx->d_scratch_cap - n_out * out_room;
+    const size_t n_out = (K > 1 || ctx->merge_async) ? 2 : 1;
+    const size_t tmp_need = merge_findings_scratch_bytes(max_n, (int)nm) + 512;
     { int rc = ensure_copy_stream(ctx); if (rc != SX_OK) return rc; }
+    if (ctx->merge_out_room < out_room || ctx->merge_n_out < n_out || ctx->d_merge_cap < ctx->merge_n_out * ctx->merge_out_room + tmp_need) {
+        // (the copy of an earlier call's last part may still read the buffers that are about to go)
+        int rc = merge_drain(ctx);
+        if (rc != SX_OK) return rc;
+        if (ctx->d_merge) HIP_TRY(ctx, hipFree(ctx->d_merge));
+        ctx->d_merge = nullptr; ctx->d_merge_cap = 0; ctx->merge_out_room = 0; ctx->merge_n_out = 0;
+        // pieces of one buffer are alike but not equal: a quarter more than this one needs
+        const size_t room = ctx->merge_async ? ((out_room + out_room / 4 + 511) & ~(size_t)255) : out_room;
+        const size_t tmp = ctx->merge_async ? tmp_need + tmp_need / 4 : tmp_need;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_merge, n_out * room + tmp));
+        ctx->d_merge_cap = n_out * room + tmp; ctx->merge_out_room = room; ctx->merge_n_out = n_out;
+    }
+    uint8_t* d_tmp = ctx->d_merge + ctx->merge_n_out * ctx->merge_out_room;
+    const size_t tmp_bytes = ctx->d_merge_cap - ctx->merge_n_out * ctx->merge_out_room;
     hipStream_t cs = ctx->merge_copy_stream;
     hipEvent_t ev_sorted = ctx->merge_ev[0], ev_copied[2] = { ctx->merge_ev[1], ctx->merge_ev[2] };
     std::vector<const sx_finding*> fp(nm);
@@ -541,17 +560,16 @@ static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFi
     std::vector<MissionFindings> outs;
     // leaving early (a HIP error, no pinned memory): no copy may still be writing into a block that goes back to the pool
     struct Guard {
-        sx_ctx* ctx; std::vector<MissionFindings>* outs; hipStream_t a, b; bool done = false;
+        sx_ctx* ctx; std::vector<MissionFindings>* outs; bool done = false;
         ~Guard() {
             if (done) return;
-            (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+            (void)merge_drain(ctx);
             for (auto& o : *outs) if (o.ext.p) ctx->pool->give(o.ext);
             outs->clear();
         }
-    } guard{ ctx, &outs, s, cs };
+    } guard{ ctx, &outs };
     uint64_t rb = 0;
     for (size_t k = 0; k < nm; k++) rb += per[k].replay_bytes;
-    bool copy_pending[2] = { false, false };
     for (uint64_t j = 0; j < K; j++) {
         uint64_t pb = 0, pf = 0;
         for (size_t k = 0; k < nm; k++) {
@@ -562,22 +580,36 @@ static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFi
             pf += pnf[k]; pb += pnb[k];
         }
         if (!pf) continue;
-        uint8_t* d_out = ctx->d_scratch + (j & (n_out - 1)) * out_room;
-        if (copy_pending[j & 1]) HIP_TRY(ctx, hipStreamWaitEvent(s, ev_copied[j & 1], 0));   // the buffer is free again
+        const unsigned ob = ctx->merge_n_out == 2 ? (unsigned)(ctx->merge_parts & 1) : 0u;   // (parts of all calls in turn: merge_async)
+        ctx->merge_parts++;
+        uint8_t* d_out = ctx->d_merge + ob * ctx->merge_out_room;
+        if (ctx->merge_copy_pending[ob]) HIP_TRY(ctx, hipStreamWaitEvent(s, ev_copied[ob], 0));   // the buffer is free again
         HIP_TRY(ctx, merge_findings_device_part(fp.data(), ap.data(), pnf.data(), pnb.data(), off0.data(), (int)nm, d_out, d_tmp, tmp_bytes, s));
         HIP_TRY(ctx, hipEventRecord(ev_sorted, s));
         const size_t out_bytes = pf * sizeof(sx_finding) + pb;
         PinnedPool::Block blk = ctx->pool->take(out_bytes + 64);
         if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
         HIP_TRY(ctx, hipStreamWaitEvent(cs, ev_sorted, 0));
-        HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_out, out_bytes, hipMemcpyDeviceToHost, cs));
-        HIP_TRY(ctx, hipEventRecord(ev_copied[j & 1], cs));
-        copy_pending[j & 1] = true;
+        {
+            // Next to the kernels of the following piece (merge_async) the copy is a kernel of two workgroups, each writing one
+            // contiguous half into the pinned block: measured on the MI355X (BASELINE config 5, 2.3 GB per piece), hipMemcpyAsync
+            // — a blit kernel that fills the chip with wavefronts waiting on PCIe — delays every kernel next to it until it is done
+            // (a 6 ms scan takes 45), eight workgroups slow the count passes by half, one does not fill the link; two copy at
+            // ~45 GB/s and cost the count passes 8 %.  With nothing next to it the runtime's copy is the faster one (53 GB/s).
+            static const int copy_wgs_env = [] { const char* e = getenv("SX_MERGE_COPY_WGS"); return e ? atoi(e) : -1; }();
+            const int copy_wgs = copy_wgs_env >= 0 ? copy_wgs_env : (ctx->merge_async ? 2 : 0);
+            if (copy_wgs > 0) HIP_TRY(ctx, launch_copy_bytes(blk.p, d_out, out_bytes, (uint32_t)copy_wgs, cs));
+            else HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_out, out_bytes, hipMemcpyDeviceToHost, cs));
+        }
+        HIP_TRY(ctx, hipEventRecord(ev_copied[ob], cs));
+        ctx->merge_copy_pending[ob] = true;
+        ctx->merged_out_bytes += out_bytes;
         outs.emplace_back();
         outs.back().ext = blk; outs.back().ext_nf = pf; outs.back().ext_na = pb;
     }
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    HIP_TRY(ctx, hipStreamSynchronize(cs));
+    // (merge_async: the last copies run on while the caller scans the next piece of the buffer; the sorts are in order with
+    // everything else stage B does — post_stream —, so the missions' findings and the scratch may be reused at once)
+    if (!ctx->merge_async) { int rc = merge_drain(ctx); if (rc != SX_OK) return rc; }
     guard.done = true;
     for (size_t k = 0; k < nm; k++) {
         if (per[k].ext.p) ctx->pool->give(per[k].ext);

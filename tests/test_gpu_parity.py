@@ -387,11 +387,16 @@ def test_every_switch_gives_the_same_text(env, monkeypatch):
 
 @pytest.mark.parametrize("env", [{}, {"SX_DEFER_MIN_BYTES": "1"}, {"SX_MERGE_PART_FINDINGS": "20000"},
                                  {"SX_DEFER_MIN_BYTES": "1", "SX_MERGE_PART_FINDINGS": "7000", "SX_MERGE_PART_MIB": "1"},
-                                 {"SX_DEFER_MIN_BYTES": "100000", "SX_MERGE_PART_FINDINGS": "1024"}],
+                                 {"SX_DEFER_MIN_BYTES": "100000", "SX_MERGE_PART_FINDINGS": "1024"},
+                                 {"SX_SEQ_PIECE_KIB": "512"}, {"SX_SEQ_PIECE_KIB": "640", "SX_DEFER_MIN_BYTES": "1"},
+                                 {"SX_SEQ_PIECE_KIB": "300", "SX_DEFER_MIN_BYTES": "1", "SX_MERGE_PART_FINDINGS": "7000"},
+                                 {"SX_SEQ_PIECE_KIB": "1024", "SX_DEFER_MIN_BYTES": "1", "SX_WAVE_REPLAY": "1"}],
                          ids=lambda e: "+".join(f"{k[3:]}={v}" for k, v in e.items()) or "default")
 def test_device_merge_in_parts(env, monkeypatch):
     """The merger on the device (sx_stage_b.cpp device_merge): several missions with many findings each, their output held
-    back on the device (SX_DEFER_MIN_BYTES) or already copied, interleaved in one part or in many (one result segment each)."""
+    back on the device (SX_DEFER_MIN_BYTES) or already copied, interleaved in one part or in many (one result segment each);
+    SX_SEQ_PIECE_KIB: the buffer in pieces scanned one after the other, a piece's findings copied while the next piece is
+    scanned (scan_common's sequential pieces, as for a buffer whose output is gigabytes)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     ms = rc.missions(encodings=["ascii", "utf-8", "windows-1252", "utf-16le"], chars_min="4")
@@ -402,8 +407,9 @@ def test_device_merge_in_parts(env, monkeypatch):
     for _ in range(2):
         sc.reset()
         res = sc.scan_device(d, len(data), file_id=1)
-        if env.get("SX_MERGE_PART_FINDINGS"):
+        if env.get("SX_MERGE_PART_FINDINGS") or env.get("SX_SEQ_PIECE_KIB"):
             assert len(res.segment_pointers()) > 1
+        assert (sc.stats().seq_pieces >= 4) == bool(env.get("SX_SEQ_PIECE_KIB"))
         assert sx.OUTPUT_BOM + res.printed(n_inputs=1, radix="x") + b"\n" == want
         res.free()
     sc.free(d); sc.close()

@@ -94,7 +94,7 @@ def regenerate(ws, n, patches):
     return bytes(host)
 
 
-def check_windows(ms, total, planted, n_windows, seed):
+def check_windows(ms, total, planted, n_windows, seed, first_starts=(), scans=1):
     rng = random.Random(seed)
     sc = sx.Scanner(ms, device=0)
     d = sc.alloc(total)
@@ -103,10 +103,13 @@ def check_windows(ms, total, planted, n_windows, seed):
     for off, rec in patches:
         sc.upload(ctypes.c_void_p(d.value + off), rec)
     res = sc.scan_device(d, total, file_id=1)
+    for _ in range(scans - 1):     # again, with what the first scan learnt (Mission order, density, output size)
+        res.free(); sc.reset()
+        res = sc.scan_device(d, total, file_id=1)
     try:
         segs = product_findings_by_slice(res)
         assert sum(len(f) for f, _ in segs) == len(res)
-        starts = [total - WINDOW]                                    # ends at the last byte
+        starts = [total - WINDOW] + list(first_starts)               # ends at the last byte
         if total > (1 << 32):
             starts += [(1 << 32) - WINDOW // 2, (1 << 33) - 4096]     # across 2^32 and 2^33
         while len(starts) < n_windows:
@@ -157,6 +160,17 @@ def test_c5_64gib_windows_equal_oracle():
     ms = product_missions(**C5)
     compared, total = check_windows(ms, 64 << 30, False, 4, 5)
     assert total > 300_000_000 and compared > 4 * 300_000
+
+
+def test_c5_16gib_in_sequential_pieces_equals_oracle(monkeypatch):
+    """The same flood in pieces of 5 GiB scanned one after the other (scan_common's sequential pieces: what a buffer with
+    gigabytes of output is cut into, each piece's merged findings copied while the next piece is scanned and replayed; the
+    double-byte Missions enter a piece with the decoder the piece in front left).  Windows across the piece boundaries."""
+    monkeypatch.setenv("SX_SEQ_PIECE_MIB", "5120")
+    ms = product_missions(**C5)
+    cuts = [(5 << 30) - WINDOW // 2, (10 << 30) - WINDOW // 4, (15 << 30) - 3 * WINDOW // 4]
+    compared, total = check_windows(ms, 16 << 30, False, 5, 55, first_starts=cuts, scans=2)
+    assert total > 75_000_000 and compared > 5 * 300_000
 
 
 def test_wave_path_6gib_windows_equal_oracle():

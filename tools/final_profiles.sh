@@ -11,9 +11,9 @@ python bench.py --workload c1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/nul
 python tools/gpu_text.py > gpurun_out/${tag}_text.txt 2>&1 < /dev/null
 for w in c2 c4; do python bench.py --workload $w --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_${w}.json; done
 sleep 20
-python bench.py --workload c5 --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_c5.json
+python bench.py --workload c5 --warmup 2 --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_c5.json
 # kernel statistics + the launch rows (warm-up / timed / alone) of the same run
-for w in c3 c5; do timeout 600 tools/kernel_stats.sh ${tag}_${w} --workload $w --steps 3 --warmup 1 > /dev/null 2>&1 < /dev/null; done
+for w in c3 c5; do timeout 600 tools/kernel_stats.sh ${tag}_${w} --workload $w --steps 3 --warmup 2 > /dev/null 2>&1 < /dev/null; done
 timeout 600 tools/kernel_stats.sh ${tag}_c1 --workload c1 --steps 20 --warmup 5 > /dev/null 2>&1 < /dev/null
 timeout 600 tools/pmc_pass.sh ${tag}_fetch "FETCH_SIZE" > /dev/null 2>&1 < /dev/null
 timeout 600 tools/pmc_pass.sh ${tag}_write "WRITE_SIZE" > /dev/null 2>&1 < /dev/null

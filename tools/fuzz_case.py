@@ -18,6 +18,8 @@ SWITCH_SETS = [{}, {}, {}, {"SX_NO_REPLAY_CACHE": "1"}, {"SX_HOST_STITCH": "1"},
                {"SX_STITCH_BLOCK": "512"}, {"SX_STITCH_BLOCK": "3"}, {"SX_MAX_REGION_WINDOWS": "2"}, {"SX_MAX_REGION_WINDOWS": "64"},
                {"SX_SLABS": "3"}, {"SX_SLABS": "8"}, {"SX_SLABS": "5", "SX_MAX_REGION_WINDOWS": "2"}, {"SX_SLABS": "2", "SX_DEVICE_JOIN_MIN": "1"},
                {"SX_DEFER_MIN_BYTES": "1"}, {"SX_DEFER_MIN_BYTES": "1", "SX_MERGE_PART_FINDINGS": "2000"}, {"SX_MERGE_PART_FINDINGS": "3000"},
+               # a buffer in pieces scanned one after the other, the copy of a piece's merged findings next to the following piece
+               {"SX_SEQ_PIECE_KIB": "8"}, {"SX_SEQ_PIECE_KIB": "16", "SX_DEFER_MIN_BYTES": "1"}, {"SX_SEQ_PIECE_KIB": "12", "SX_DEFER_MIN_BYTES": "1", "SX_WAVE_REPLAY": "1"},
                # the wave-cooperative stage B (sx_wave.cpp): forced on for every covered Mission, with odd wavefront / slab geometries,
                # with and without stage A in front of it, with its way back to the lane-per-region path, and forced off
                {"SX_WAVE_REPLAY": "1"}, {"SX_WAVE_REPLAY": "1"}, {"SX_WAVE_REPLAY": "1"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_BATCHES": "1"},
