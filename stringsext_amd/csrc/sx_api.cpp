@@ -283,6 +283,9 @@ void sx_destroy(sx_ctx* ctx) {
             for (void* q : d.d_rp) if (q) (void)hipFree(q);
             if (d.h_runs) (void)hipHostFree(d.h_runs);
             if (d.ev_runs) (void)hipEventDestroy(d.ev_runs);
+            if (d.stream_w) (void)hipStreamDestroy(d.stream_w);
+            if (d.h_tot) (void)hipHostFree(d.h_tot);
+            for (hipEvent_t e : d.wave_ev) if (e) (void)hipEventDestroy(e);
             if (d.stream && d.stream != ctx->scan_stream) (void)hipStreamDestroy(d.stream);
         }
         for (int i = 0; i < 2; i++) {
@@ -297,7 +300,7 @@ void sx_destroy(sx_ctx* ctx) {
         if (ctx->merge_copy_stream) (void)hipStreamDestroy(ctx->merge_copy_stream);
         if (ctx->d_merge) (void)hipFree(ctx->d_merge);
         for (hipEvent_t e : ctx->merge_ev) if (e) (void)hipEventDestroy(e);
-        for (hipEvent_t e : ctx->wave_ev) if (e) (void)hipEventDestroy(e);
+        if (ctx->ev_interleaved) (void)hipEventDestroy(ctx->ev_interleaved);
         if (ctx->d_input) (void)hipFree(ctx->d_input);
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
         if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);

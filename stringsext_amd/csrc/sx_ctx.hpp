@@ -111,8 +111,13 @@ struct MissionDev {
     uint8_t* d_wave_lut = nullptr;                      // wave-cooperative stage B: Mission::wave_lut (uploaded at its first use)
     sx_run* h_runs = nullptr; uint64_t h_runs_cap = 0;   // pinned: runs joined on the device
     hipEvent_t ev_runs = nullptr;                         // their copy (on sx_ctx::d2h_stream) is done
-    void* d_rp[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
-    uint64_t d_rp_cap[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // + stitch blocks, totals, pass-1 output cache, runs cut into pieces
+    void* d_rp[12] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  // runs, region outs, idx, fbase, abase, findings+arena
+    uint64_t d_rp_cap[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // + stitch blocks, totals, pass-1 output cache, runs cut into pieces, the wave kernels' own scratch (10)
+    // the wave-cooperative stage B of a Mission that runs next to the other Missions' stage B (sx_schedule.cpp: a host thread each):
+    // its own stream, totals in its own pinned words, its own timing events (4 per slab: count begin / end, write begin / end)
+    hipStream_t stream_w = nullptr;
+    uint64_t* h_tot = nullptr;
+    std::vector<hipEvent_t> wave_ev;
 };
 
 
@@ -145,6 +150,9 @@ struct sx_ctx {
     uint64_t merge_parts = 0;                           // parts merged so far (their parity picks the output buffer)
     uint64_t merged_out_bytes = 0;                      // bytes device_merge sent to the host (all calls)
     double out_density = 0;                             // ... per input byte of the last whole buffer: sizes the next one's pieces
+    hipEvent_t ev_interleaved = nullptr;                // merge_async: the last interleave that read the Missions' findings (on post_stream)
+    bool interleave_pending = false;                    // ... recorded and not yet waited for by merge_drain: writers on other streams wait for it
+    std::mutex mu;                                      // statistics and the like, when Missions' stage B run on host threads next to each other
     unsigned n_cus = 256, scan_blocks_per_cu = 8;
     // sx_scan_stream: two pinned host buffers and two device buffers, filled by a reader thread
     hipStream_t copy_stream = nullptr;
@@ -163,7 +171,6 @@ struct sx_ctx {
     std::vector<uint64_t> last_runs;  // long runs per mission of the last scanned buffer: busiest mission scans first
     std::vector<char> wave_pred;      // per mission: its last whole buffer was string-dense and went through the wave kernels: the next one does without stage A
     std::vector<double> wave_density; // per mission: findings per input byte of the last buffer that went through the wave kernels (sizes the descriptors)
-    std::vector<hipEvent_t> wave_ev;  // timing events of the wave kernels (4 per slab: count begin / end, write begin / end)
     std::vector<char> wave_off;       // per mission, for the buffer in hand: the wave-cooperative stage B gave up on it (sx_wave.cpp)
     std::vector<sx::RunList> shard_runs;  // device runs of the last sx_scan_shard* buffer (reuse_runs)
     bool shard_runs_valid = false;
@@ -288,7 +295,7 @@ constexpr int SX_WAVE_FALLBACK = 1001;   // (internal) nothing was produced: use
 constexpr int SX_NEED_RUNS = 1002;       // (internal) ... which needs the run list that stage A skipped (RunList::skipped)
 bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs, uint64_t heavy_tiles = 0);
 int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, MissionFindings* out, uint64_t* end_pos,
-                        uint64_t defer_min_bytes);
+                        uint64_t defer_min_bytes, bool own_stream = false);
 bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs);
 int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, const RunList& runs,
                           MissionFindings* out, uint64_t* end_pos, uint64_t defer_min_bytes);

@@ -2,6 +2,7 @@
 // mission's stage B with the scans still running, pieces of a large buffer, one shard of a
 // sharded scan.
 #include "sx_ctx.hpp"
+#include <thread>
 
 using namespace sx;
 
@@ -165,12 +166,55 @@ struct BufferScan {
         if (ctx->last_runs.size() != nm) ctx->last_runs.assign(nm, 0);
         ctx->wave_off.assign(nm, 0);
         if (ctx->wave_pred.size() != nm) ctx->wave_pred.assign(nm, 0);
+        // String-dense Missions that go without stage A (their last buffer went through the wave kernels) start their stage B at
+        // once, a host thread and a stream each, NEXT TO each other and to the other Missions' scans and stage B: Big5's count pass
+        // runs at two wavefronts per SIMD and waits on memory most of the time, KOI8-R's at four, the lane-per-region replay of a
+        // third Mission is latency-bound as well — one after the other on one stream (as before, SX_WAVE_THREADS=0) they leave most
+        // of the chip idle.  The threads share nothing but the context's lock for statistics (sx_wave.cpp, own_stream).
+        std::vector<std::thread> wave_threads(nm);
+        std::vector<int> wave_rc(nm, SX_OK);
+        std::vector<char> threaded(nm, 0);
+        struct Joiner {
+            std::vector<std::thread>& t;
+            ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); }
+        } joiner{ wave_threads };
+        const uint64_t defer_all = nm >= 2 ? [] { const char* e = getenv("SX_DEFER_MIN_BYTES"); return e ? (uint64_t)atoll(e) : (256ull << 20); }() : 0;
+        if (nm >= 2 && !(getenv("SX_WAVE_THREADS") && !atoi(getenv("SX_WAVE_THREADS")))) {
+            if (ctx->wave_density.size() != nm) ctx->wave_density.assign(nm, 0.0);
+            for (size_t k = 0; k < nm; k++) {
+                const bool unscanned = k < not_scanned.size() && not_scanned[k];
+                if (ctx->missions[k].host_sequential() || !unscanned || !wave_replay_wanted(ctx, job, k, len)) continue;
+                threaded[k] = 1;
+                ctx->stats.bytes_scanned += len;
+                wave_threads[k] = std::thread([ctx, k, &early_view, &job, &pre, &wave_rc, defer_all]() {
+                    (void)hipSetDevice(ctx->device);
+                    wave_rc[k] = wave_replay_mission(ctx, k, early_view, job, &pre.per[k], &pre.ends[k], defer_all, true);
+                });
+            }
+        }
+        std::vector<size_t> order2;
+        for (size_t oi = 0; oi < nm; oi++) if (!threaded[(size_t)order[oi]]) order2.push_back((size_t)order[oi]);
+        for (size_t oi = 0; oi < nm; oi++) if (threaded[(size_t)order[oi]]) order2.push_back((size_t)order[oi]);
         for (size_t oi = 0; oi < nm; oi++) {
-            const size_t k = (size_t)order[oi];
+            const size_t k = order2[oi];
             std::vector<RunList> one;
             int rc = SX_OK;
             const bool unscanned = k < not_scanned.size() && not_scanned[k];
-            if (ctx->missions[k].host_sequential()) {   // no stage A at all: every window is replayed on the host (sx_stage_b.cpp)
+            bool replayed = false;
+            if (threaded[k]) {
+                wave_threads[k].join();
+                rc = wave_rc[k];
+                if (rc == SX_WAVE_FALLBACK) {   // nothing was produced and nothing changed: the way device_replay_mission takes then, inline
+                    ctx->wave_off[k] = 1; ctx->wave_pred[k] = 0;
+                    ctx->stats.bytes_scanned -= len;
+                    rc = SX_OK;
+                } else if (rc != SX_OK) return rc;
+                else replayed = true;
+            }
+            if (replayed) {
+                one.assign(1, RunList{});
+                one[0].n = len / 16; one[0].skipped = true; one[0].complete = true;
+            } else if (ctx->missions[k].host_sequential()) {   // no stage A at all: every window is replayed on the host (sx_stage_b.cpp)
                 one.assign(1, RunList{});
                 one[0].complete = true;
             } else if (unscanned && wave_replay_wanted(ctx, job, k, len)) {   // no stage A: "as dense as the last buffer"
@@ -190,6 +234,7 @@ struct BufferScan {
             if (!(*runs)[k].own.empty()) (*runs)[k].use_own();  // the vector moved: point at it again
             ctx->last_runs[k] = (*runs)[k].size();
             if (oi + 1 == nm && after_last_finish && (rc = after_last_finish()) != SX_OK) return rc;
+            if (replayed) { pre.done[k] = 1; continue; }
             if (device_replay_wanted(ctx, job, k, (*runs)[k].size())) {
                 // (with several missions a large output stays on the device: replay_all interleaves them there, one copy instead of two)
                 uint64_t defer = nm >= 2 ? (256ull << 20) : 0;

@@ -454,6 +454,7 @@ int merge_drain(sx_ctx* ctx) {
     if (ctx->post_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->post_stream));
     if (ctx->merge_copy_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->merge_copy_stream));
     ctx->merge_copy_pending[0] = ctx->merge_copy_pending[1] = false;
+    ctx->interleave_pending = false;
     return SX_OK;
 }
 
@@ -606,6 +607,11 @@ static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFi
         ctx->merged_out_bytes += out_bytes;
         outs.emplace_back();
         outs.back().ext = blk; outs.back().ext_nf = pf; outs.back().ext_na = pb;
+    }
+    if (ctx->merge_async) {   // a Mission whose stage B writes on a stream of its own waits for this before it overwrites its findings
+        if (!ctx->ev_interleaved) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_interleaved, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_interleaved, s));
+        ctx->interleave_pending = true;
     }
     // (merge_async: the last copies run on while the caller scans the next piece of the buffer; the sorts are in order with
     // everything else stage B does — post_stream —, so the missions' findings and the scratch may be reused at once)

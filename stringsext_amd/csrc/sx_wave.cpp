@@ -51,10 +51,20 @@ static uint32_t utf8_chars(const std::string& s) {
 }
 
 // SX_OK, an error, or SX_WAVE_FALLBACK: nothing was produced and nothing changed — use the lane-per-region path.
+// own_stream: the call runs on a host thread next to the other Missions' stage B (sx_schedule.cpp): its kernels go to the Mission's own
+// stream, its scratch, totals and events are the Mission's own, statistics are added under the context's lock.
 int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& job, MissionFindings* out, uint64_t* end_pos,
-                        uint64_t defer_min_bytes) {
+                        uint64_t defer_min_bytes, bool own_stream) {
     const Mission& m = ctx->missions[k];
     MissionDev& d = ctx->dev[k];
+    if (own_stream && !d.stream_w) {
+        int lo = 0, hi = 0;   // (lo: the numerically greatest = lowest priority, hi: the highest)
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        int prio = hi;
+        if (const char* e = getenv("SX_WAVE_STREAM_PRIO")) prio = atoi(e) == 0 ? lo : atoi(e) == 1 ? (lo + hi) / 2 : hi;
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&d.stream_w, hipStreamNonBlocking, prio));
+    }
+    const hipStream_t sb = own_stream ? d.stream_w : d.stream_b;
     const uint32_t W = (uint32_t)m.window, wps = wv_wps(W);
     const uint64_t len = job.len;
     const double t0 = now_ms();
@@ -84,7 +94,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
     // leaving early: no copy may still be writing into a block that goes back to the pool
     auto abandon = [&](int rc) -> int {
         if (ctx->merge_copy_stream) (void)hipStreamSynchronize(ctx->merge_copy_stream);
-        (void)hipStreamSynchronize(d.stream_b);
+        (void)hipStreamSynchronize(sb);
         for (auto& g : segs) if (g.ext.p) ctx->pool->give(g.ext);
         return rc;
     };
@@ -135,8 +145,16 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         // per wavefront: 4 x u32 (pass 1 out) + 2 x u64 (offsets); + totals per slab
         const uint64_t per = 4 * 4 + 2 * 8;
         int rc = ensure_rp(ctx, d, 1, n_waves * per + 4096); if (rc) return rc;
-        rc = ensure_scratch(ctx, wave_scratch_bytes(n_waves)); if (rc) return rc;
-        rc = ensure_pinned2(ctx, 4096); if (rc) return rc;
+        uint8_t* w_scratch; uint64_t w_scratch_cap;
+        if (own_stream) {
+            rc = ensure_rp(ctx, d, 10, wave_scratch_bytes(n_waves)); if (rc) return rc;
+            w_scratch = (uint8_t*)d.d_rp[10]; w_scratch_cap = d.d_rp_cap[10];
+            if (!d.h_tot) HIP_TRY(ctx, hipHostMalloc((void**)&d.h_tot, 4096, hipHostMallocNonCoherent));
+        } else {
+            rc = ensure_scratch(ctx, wave_scratch_bytes(n_waves)); if (rc) return rc;
+            rc = ensure_pinned2(ctx, 4096); if (rc) return rc;
+            w_scratch = ctx->d_scratch; w_scratch_cap = ctx->d_scratch_cap;
+        }
         uint8_t* base = (uint8_t*)d.d_rp[1];
         uint64_t* d_tot = (uint64_t*)base;            // 4 x u64 per slab
         uint64_t* d_fb = (uint64_t*)(base + 2048);
@@ -169,29 +187,29 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         if (K > 1) {
             { const int rc = ensure_copy_stream(ctx); if (rc != SX_OK) return rc; }
         }
-        while (ctx->wave_ev.size() < 4 * K) {
+        while (d.wave_ev.size() < 4 * K) {
             hipEvent_t e;
             HIP_TRY(ctx, hipEventCreate(&e));
-            ctx->wave_ev.push_back(e);
+            d.wave_ev.push_back(e);
         }
         std::vector<char> wrote(K, 0);
-        uint64_t* h_tot = (uint64_t*)ctx->h_pin2;
+        uint64_t* h_tot = own_stream ? d.h_tot : (uint64_t*)ctx->h_pin2;
         hipEvent_t copied[2] = { ctx->merge_ev[1], ctx->merge_ev[2] };
         bool pending[2] = { false, false };
         for (uint64_t j = 0; j < K; j++) {
             const uint64_t v0 = n_waves * j / K, v1 = n_waves * (j + 1) / K;
             if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   wave mission %zu slab %llu: waves [%llu, %llu) of %llu, E %llu, count...\n", k, (unsigned long long)j, (unsigned long long)v0, (unsigned long long)v1, (unsigned long long)n_waves, (unsigned long long)E);
-            HIP_TRY(ctx, hipEventRecord(ctx->wave_ev[4 * j], d.stream_b));
-            HIP_TRY(ctx, launch_wave_count(P, v0, v1, d_fb, d_ab, d_tot + 4 * j, ctx->d_scratch, ctx->d_scratch_cap, d.stream_b));
-            HIP_TRY(ctx, hipEventRecord(ctx->wave_ev[4 * j + 1], d.stream_b));
-            HIP_TRY(ctx, hipMemcpyAsync(h_tot + 4 * j, d_tot + 4 * j, 4 * 8, hipMemcpyDeviceToHost, d.stream_b));
-            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            HIP_TRY(ctx, hipEventRecord(d.wave_ev[4 * j], sb));
+            HIP_TRY(ctx, launch_wave_count(P, v0, v1, d_fb, d_ab, d_tot + 4 * j, w_scratch, w_scratch_cap, sb));
+            HIP_TRY(ctx, hipEventRecord(d.wave_ev[4 * j + 1], sb));
+            HIP_TRY(ctx, hipMemcpyAsync(h_tot + 4 * j, d_tot + 4 * j, 4 * 8, hipMemcpyDeviceToHost, sb));
+            HIP_TRY(ctx, hipStreamSynchronize(sb));
             if ((h_tot[4 * j + 2] & 0xFFFFFFFFull) != 0 || getenv("SX_WAVE_FAIL")) {   // (SX_WAVE_FAIL: tests of the way back)
                 if (getenv("SX_TIMING")) fprintf(stderr, "[sx] wave replay mission %zu: %llu wavefronts assumed a wrong entry state: lane-per-region path\n", k, (unsigned long long)(h_tot[4 * j + 2] & 0xFFFFFFFFull));
                 return abandon(SX_WAVE_FALLBACK);
             }
             const bool by_desc = P.desc && (h_tot[4 * j + 2] >> 32) == 0;   // every wavefront of the slab left all its descriptors
-            if (P.desc && !by_desc) ctx->stats.wave_desc_overflows++;
+            if (P.desc && !by_desc) { std::lock_guard<std::mutex> g(ctx->mu); ctx->stats.wave_desc_overflows++; }
             const uint64_t nf = h_tot[4 * j], nb = h_tot[4 * j + 1];
             if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   ... counted %llu findings, %llu bytes at +%.2f ms\n", (unsigned long long)nf, (unsigned long long)nb, now_ms() - t0);
             final_state = (uint32_t)h_tot[4 * j + 3];
@@ -204,7 +222,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             const int slot = (j & 1) ? 8 : 5;
             if (pending[j & 1]) {   // the copy of slab j - 2 may still read this buffer
                 if (d.d_rp_cap[slot] < out_bytes + 64) HIP_TRY(ctx, hipEventSynchronize(copied[j & 1]));
-                else HIP_TRY(ctx, hipStreamWaitEvent(d.stream_b, copied[j & 1], 0));
+                else HIP_TRY(ctx, hipStreamWaitEvent(sb, copied[j & 1], 0));
             }
             rc = ensure_rp(ctx, d, slot, out_bytes + 64); if (rc) return abandon(rc);
             uint8_t* d_all = (uint8_t*)d.d_rp[slot];
@@ -212,19 +230,21 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
                 P.findings = (sx_finding*)d_all + nfh_j;
                 P.arena = d_all + (nfh_j + nf) * sizeof(sx_finding) + nbh_j;
                 P.str_off_base = (uint32_t)nbh_j; P.f_sub = 0; P.a_sub = 0;
-                HIP_TRY(ctx, hipEventRecord(ctx->wave_ev[4 * j + 2], d.stream_b));
-                HIP_TRY(ctx, by_desc ? launch_wave_emit(P, v0, v1, d.stream_b) : launch_wave_write(P, v0, v1, d.stream_b));
-                HIP_TRY(ctx, hipEventRecord(ctx->wave_ev[4 * j + 3], d.stream_b));
+                // (pieces: the interleave of the piece before may still read this Mission's findings — on post_stream, not this stream)
+                if (own_stream && ctx->interleave_pending) HIP_TRY(ctx, hipStreamWaitEvent(sb, ctx->ev_interleaved, 0));
+                HIP_TRY(ctx, hipEventRecord(d.wave_ev[4 * j + 2], sb));
+                HIP_TRY(ctx, by_desc ? launch_wave_emit(P, v0, v1, sb) : launch_wave_write(P, v0, v1, sb));
+                HIP_TRY(ctx, hipEventRecord(d.wave_ev[4 * j + 3], sb));
                 wrote[j] = 1;
             }
             if (nfh_j) {
-                HIP_TRY(ctx, hipMemcpyAsync(d_all, hf.v.data(), nfh_j * sizeof(sx_finding), hipMemcpyHostToDevice, d.stream_b));
-                if (nbh_j) HIP_TRY(ctx, hipMemcpyAsync(d_all + (nfh_j + nf) * sizeof(sx_finding), hf.arena.data(), nbh_j, hipMemcpyHostToDevice, d.stream_b));
+                HIP_TRY(ctx, hipMemcpyAsync(d_all, hf.v.data(), nfh_j * sizeof(sx_finding), hipMemcpyHostToDevice, sb));
+                if (nbh_j) HIP_TRY(ctx, hipMemcpyAsync(d_all + (nfh_j + nf) * sizeof(sx_finding), hf.arena.data(), nbh_j, hipMemcpyHostToDevice, sb));
             }
             MissionFindings seg;
             deferred = K == 1 && defer_min_bytes && nf * sizeof(sx_finding) + nb >= defer_min_bytes;
             if (deferred) {
-                HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+                HIP_TRY(ctx, hipStreamSynchronize(sb));
                 if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   ... written (left on the device) at +%.2f ms\n", now_ms() - t0);
                 seg.dev_only = true; seg.ext_nf = nfh_j + nf; seg.ext_na = nbh_j + nb; seg.dev_copy = d_all;
             } else {
@@ -233,28 +253,31 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
                 seg.ext = blk; seg.ext_nf = nfh_j + nf; seg.ext_na = nbh_j + nb;
                 if (K > 1) {   // on the copy stream: the next slab's kernels run meanwhile
                     segs.push_back(std::move(seg));
-                    HIP_TRY(ctx, hipEventRecord(ctx->merge_ev[0], d.stream_b));
+                    HIP_TRY(ctx, hipEventRecord(ctx->merge_ev[0], sb));
                     HIP_TRY(ctx, hipStreamWaitEvent(ctx->merge_copy_stream, ctx->merge_ev[0], 0));
                     HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, out_bytes, hipMemcpyDeviceToHost, ctx->merge_copy_stream));
                     HIP_TRY(ctx, hipEventRecord(copied[j & 1], ctx->merge_copy_stream));
                     pending[j & 1] = true;
-                    if (nfh_j) HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));   // (the entry part's upload reads host vectors)
+                    if (nfh_j) HIP_TRY(ctx, hipStreamSynchronize(sb));   // (the entry part's upload reads host vectors)
                     continue;
                 }
-                HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, out_bytes, hipMemcpyDeviceToHost, d.stream_b));
-                HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+                HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, out_bytes, hipMemcpyDeviceToHost, sb));
+                HIP_TRY(ctx, hipStreamSynchronize(sb));
                 seg.dev_copy = d_all;
             }
             segs.push_back(std::move(seg));
         }
         if (K > 1) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->merge_copy_stream));
-            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            HIP_TRY(ctx, hipStreamSynchronize(sb));
         }
-        for (uint64_t j = 0; j < K; j++) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, ctx->wave_ev[4 * j], ctx->wave_ev[4 * j + 1]) == hipSuccess) ctx->stats.wave_count_ms += ms;
-            if (wrote[j] && hipEventElapsedTime(&ms, ctx->wave_ev[4 * j + 2], ctx->wave_ev[4 * j + 3]) == hipSuccess) ctx->stats.wave_write_ms += ms;
+        {
+            std::lock_guard<std::mutex> g(ctx->mu);
+            for (uint64_t j = 0; j < K; j++) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, d.wave_ev[4 * j], d.wave_ev[4 * j + 1]) == hipSuccess) ctx->stats.wave_count_ms += ms;
+                if (wrote[j] && hipEventElapsedTime(&ms, d.wave_ev[4 * j + 2], d.wave_ev[4 * j + 3]) == hipSuccess) ctx->stats.wave_write_ms += ms;
+            }
         }
         (void)hipGetLastError();
     } else if (nfh) {   // the host's windows were the whole buffer
@@ -267,7 +290,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         out->replay_bytes = rb;
     } else if (g_lo < g_all && nfh) { out->v = std::move(hf.v); out->arena = std::move(hf.arena); }
     out->replay_bytes += len;
-    ctx->stats.wave_windows += g_all - g_lo;
+    { std::lock_guard<std::mutex> g(ctx->mu); ctx->stats.wave_windows += g_all - g_lo; }
     // the next whole buffer of this Mission does without stage A (sx_schedule.cpp) as long as this one was string-dense
     if (k < ctx->wave_pred.size()) ctx->wave_pred[k] = (nf_all + nfh) * wave_min_density_bytes(m.wave_family) * 2 > len ? 1 : 0;
     if (k < ctx->wave_density.size() && len) ctx->wave_density[k] = (double)(nf_all + nfh) / (double)len;   // sizes the next buffer's descriptors
