@@ -269,6 +269,9 @@ def main():
             "per_kernel_ms_alone": [round(x, 3) for x in alone_ms],
             "per_kernel_ms_alone_behind_an_identical_launch": [round(x, 3) for x in alone_warm_ms],
             "frac_alone": round(len(missions) * nbytes / (sum(alone_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if alone_ms and sum(alone_ms) > 0 else None,
+            # the same passes over the WALL time of a step (stage B, merger and copies included): what "frac" cannot say when
+            # kernels of several Missions run next to each other (their durations overlap and are counted in full above)
+            "frac_of_step_wall": round(passes * nbytes / (dt / K) / 1e9 / HBM_PEAK_GBS, 4),
         }
         out = {
             "metric": "GiB/s scanned", "value": round(value, 2), "unit": "GiB/s", "n_gpus": world,

@@ -95,6 +95,12 @@ def test_wave_path_next_to_other_missions(wave_forced):
     want = sxo.run_cli(ms, files, radix="x")
     for chunk in (None, 65536, 8192):
         assert run_cli_product(ms, files, radix="x", device=0, chunk_bytes=chunk) == want, chunk
+    os.environ["SX_WAVE_THREADS"] = "0"      # the wave Missions one after the other on the shared stream (default: a host thread and a stream each)
+    try:
+        for chunk in (65536, 8192):
+            assert run_cli_product(ms, files, radix="x", device=0, chunk_bytes=chunk) == want, chunk
+    finally:
+        del os.environ["SX_WAVE_THREADS"]
     os.environ["SX_DEFER_MIN_BYTES"] = "1"   # the Missions' outputs stay in HBM and are interleaved there
     try:
         assert run_cli_product(ms, files, radix="x", device=0) == want
