@@ -371,3 +371,29 @@ def test_remaining_single_byte_encodings_replay_equals_full_scan(enc):
 def zlib_seed(s):
     import zlib
     return zlib.crc32(s.encode())
+
+
+def test_ctypes_structs_have_the_headers_layout(tmp_path):
+    """The Python shim restates the C-ABI's structs by hand: a C program that includes include/stringsext_amd.h prints every
+    struct's size and the offset of its last field; the ctypes classes must agree (sx_stats only ever grows at its end)."""
+    import ctypes as C
+    import os
+    import subprocess
+    import stringsext_amd as sx
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    pairs = [("sx_mission", sx.Mission), ("sx_finding", sx.Finding), ("sx_run", sx.Run), ("sx_stats", sx.Stats), ("sx_options", sx.Options),
+             ("sx_cli_flags", sx.CliFlags), ("sx_enc_opt", sx.EncOpt)]
+    src = tmp_path / "layout.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "stringsext_amd.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        last = cls._fields_[-1][0]
+        lines.append(f'    printf("{cname} %zu %zu\\n", sizeof({cname}), offsetof({cname}, {last}));')
+    lines += ['    return 0;', '}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    for (cname, cls), line in zip(pairs, out):
+        name, size, off = line.split()
+        assert name == cname
+        assert (int(size), int(off)) == (C.sizeof(cls), getattr(cls, cls._fields_[-1][0]).offset), cname
