@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define SX_ABI_VERSION 1
+/* Bumped whenever a struct of this header changes size or layout or an enum value changes meaning (2: sx_stats grew by the wave /
+ * re-scan / piece fields in round 3, SX_ENC_ISO_2022_JP was added; packed findings, round 4).  A consumer compares it with
+ * sx_abi_version() before it hands the library a struct to fill. */
+#define SX_ABI_VERSION 2
 
 enum {
     SX_OK = 0,

@@ -26,6 +26,7 @@ ENC = {"x-user-defined": 0, "utf-8": 1, "utf-16le": 2, "utf-16be": 3, "koi8-r": 
 PRECISION = {0: "Before", 1: "Exact", 2: "After"}
 
 # every symbol include/stringsext_amd.h declares
+ABI_VERSION = 2   # SX_ABI_VERSION of include/stringsext_amd.h
 EXPORTS = ["sx_abi_version", "sx_create", "sx_destroy", "sx_last_error", "sx_scan", "sx_scan_device", "sx_reset",
            "sx_device_runs", "sx_replay_runs", "sx_scan_shard_device", "sx_scan_shard", "sx_replay_shard_runs",
            "sx_scan_stream", "sx_scan_file", "sx_missions_from_flags", "sx_parse_enc_opt", "sx_encoding_for_label", "sx_encoding_name",
@@ -185,6 +186,8 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, u64, cp = C.c_void_p, C.c_uint64, C.c_char_p
     L.sx_abi_version.restype = C.c_int
+    if L.sx_abi_version() != ABI_VERSION:   # the ctypes structs below mirror include/stringsext_amd.h of exactly this version
+        raise ImportError(f"{LIB_PATH} has ABI version {L.sx_abi_version()}, this binding is written for {ABI_VERSION}: rebuild the library")
     L.sx_create.argtypes = [C.POINTER(vp), C.POINTER(Mission), C.c_int, C.c_int, C.POINTER(Options)]
     L.sx_destroy.argtypes = [vp]
     L.sx_last_error.restype = cp

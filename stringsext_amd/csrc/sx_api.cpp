@@ -71,6 +71,7 @@ int ensure_pinned2(sx_ctx* ctx, uint64_t bytes) {
     return SX_OK;
 }
 int ensure_scratch(sx_ctx* ctx, uint64_t bytes) {
+    std::lock_guard<std::recursive_mutex> g(ctx->grow_mu);
     if (ctx->d_scratch_cap >= bytes) return SX_OK;
     if (ctx->merge_async) { const int rc = merge_drain(ctx); if (rc != SX_OK) return rc; }   // (a queued sort may read its cut table here)
     if (ctx->d_scratch) HIP_TRY(ctx, hipFree(ctx->d_scratch));
@@ -102,7 +103,8 @@ int ensure_cache(sx_ctx* ctx, uint64_t bytes) {
     return SX_OK;
 }
 int ensure_rp(sx_ctx* ctx, MissionDev& d, int slot, uint64_t bytes) {
-    if (d.d_rp_cap[slot] >= bytes) return SX_OK;
+    if (d.d_rp_cap[slot] >= bytes) return SX_OK;   // (a Mission's buffers are its own thread's)
+    std::lock_guard<std::recursive_mutex> g(ctx->grow_mu);
     if (ctx->merge_async) { const int rc = merge_drain(ctx); if (rc != SX_OK) return rc; }   // (a queued sort may still read this Mission's findings)
     if (d.d_rp[slot]) HIP_TRY(ctx, hipFree(d.d_rp[slot]));
     d.d_rp[slot] = nullptr; d.d_rp_cap[slot] = 0;

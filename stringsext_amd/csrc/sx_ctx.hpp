@@ -151,8 +151,13 @@ struct sx_ctx {
     uint64_t merged_out_bytes = 0;                      // bytes device_merge sent to the host (all calls)
     double out_density = 0;                             // ... per input byte of the last whole buffer: sizes the next one's pieces
     hipEvent_t ev_interleaved = nullptr;                // merge_async: the last interleave that read the Missions' findings (on post_stream)
-    bool interleave_pending = false;                    // ... recorded and not yet waited for by merge_drain: writers on other streams wait for it
+    std::atomic<bool> interleave_pending{ false };      // ... recorded and not yet waited for by merge_drain: writers on other streams wait for it
     std::mutex mu;                                      // statistics and the like, when Missions' stage B run on host threads next to each other
+    // ... and what those threads share beyond statistics: the error text (HIP_TRY on any thread -> set_err) and the
+    // merger's in-flight state, which ensure_rp / ensure_scratch -> merge_drain settle before memory a queued copy may read is freed
+    std::mutex err_mu;
+    std::recursive_mutex grow_mu;
+    void set_err(std::string text) { std::lock_guard<std::mutex> g(err_mu); err = std::move(text); }
     unsigned n_cus = 256, scan_blocks_per_cu = 8;
     // sx_scan_stream: two pinned host buffers and two device buffers, filled by a reader thread
     hipStream_t copy_stream = nullptr;
@@ -186,7 +191,7 @@ struct sx_ctx {
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
         if (e_ != hipSuccess) {                                                                \
-            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            (ctx)->set_err(std::string(#expr) + ": " + hipGetErrorString(e_));                 \
             return SX_E_HIP;                                                                   \
         }                                                                                      \
     } while (0)

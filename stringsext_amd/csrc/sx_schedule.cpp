@@ -233,8 +233,19 @@ struct BufferScan {
             (*runs)[k] = std::move(one[0]);
             if (!(*runs)[k].own.empty()) (*runs)[k].use_own();  // the vector moved: point at it again
             ctx->last_runs[k] = (*runs)[k].size();
-            if (oi + 1 == nm && after_last_finish && (rc = after_last_finish()) != SX_OK) return rc;
-            if (replayed) { pre.done[k] = 1; continue; }
+            // The record slot is free again once the last Mission's records are out of it — unless they were only COUNTED
+            // (RunList::skipped: a string-dense buffer, the wave kernels replay every window): if those give the buffer back
+            // (SX_NEED_RUNS below) stage A is launched again into this very slot, so the next piece may only be queued into it when
+            // that is settled (piece p+2's scan shared the slot with the re-scan of piece p).
+            const bool last_mission = oi + 1 == nm;
+            bool next_queued = false;
+            auto queue_next = [&]() -> int {
+                if (!last_mission || !after_last_finish || next_queued) return SX_OK;
+                next_queued = true;
+                return after_last_finish();
+            };
+            if (!(*runs)[k].skipped && (rc = queue_next()) != SX_OK) return rc;
+            if (replayed) { pre.done[k] = 1; if ((rc = queue_next()) != SX_OK) return rc; continue; }
             if (device_replay_wanted(ctx, job, k, (*runs)[k].size())) {
                 // (with several missions a large output stays on the device: replay_all interleaves them there, one copy instead of two)
                 uint64_t defer = nm >= 2 ? (256ull << 20) : 0;
@@ -248,12 +259,14 @@ struct BufferScan {
                     (*runs)[k] = std::move(one[0]);
                     if (!(*runs)[k].own.empty()) (*runs)[k].use_own();
                     ctx->last_runs[k] = (*runs)[k].size();
+                    if ((rc = queue_next()) != SX_OK) return rc;   // (the slot's records are out: now the next piece may have it)
                     if (!device_replay_wanted(ctx, job, k, (*runs)[k].size())) continue;   // few runs after all: the host's share of stage B
                     rc = device_replay_mission(ctx, k, early_view, job, (*runs)[k], &pre.per[k], &pre.ends[k], defer);
                 }
                 if (rc != SX_OK) return rc;
                 pre.done[k] = 1;
             }
+            if ((rc = queue_next()) != SX_OK) return rc;
         }
         if (host_bytes) return replay_all(ctx, host_view, job, *runs, into, ends, &pre);
         SparseDeviceBytes view(ctx, d_bytes);

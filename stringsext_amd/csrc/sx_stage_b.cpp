@@ -451,6 +451,7 @@ static int fetch_deferred(sx_ctx* ctx, MissionFindings& mf) {
 }
 
 int merge_drain(sx_ctx* ctx) {
+    std::lock_guard<std::recursive_mutex> g(ctx->grow_mu);   // (a wave Mission's thread may get here through ensure_rp)
     if (ctx->post_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->post_stream));
     if (ctx->merge_copy_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->merge_copy_stream));
     ctx->merge_copy_pending[0] = ctx->merge_copy_pending[1] = false;

@@ -182,7 +182,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             cap = std::min<uint64_t>(cap, std::max<uint64_t>(64, len / 3 / 12 / n_waves));
             if (const char* e = getenv("SX_WAVE_DESC_CAP")) cap = (uint64_t)std::max(1, atoi(e));
             if (ensure_rp(ctx, d, 2, n_waves * cap * 12 + 64) == SX_OK) { P.desc = (uint32_t*)d.d_rp[2]; P.desc_cap = (uint32_t)cap; }
-            else ctx->err.clear();   // (no room: the other writer)
+            else ctx->set_err(std::string());   // (no room: the other writer)
         }
         if (K > 1) {
             { const int rc = ensure_copy_stream(ctx); if (rc != SX_OK) return rc; }
@@ -214,7 +214,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   ... counted %llu findings, %llu bytes at +%.2f ms\n", (unsigned long long)nf, (unsigned long long)nb, now_ms() - t0);
             final_state = (uint32_t)h_tot[4 * j + 3];
             const uint64_t nfh_j = j == 0 ? nfh : 0, nbh_j = j == 0 ? nbh : 0;   // the host's entry windows go in front of the first slab
-            if (nb + nbh_j > 0xFFFFFFFFull) { ctx->err = "more than 4 GiB of strings in one chunk"; return abandon(SX_E_NOMEM); }
+            if (nb + nbh_j > 0xFFFFFFFFull) { ctx->set_err("more than 4 GiB of strings in one chunk"); return abandon(SX_E_NOMEM); }
             nf_all += nf; nb_all += nb;
             if (nf + nfh_j == 0) continue;
             // ---- pass 2 straight into the result's layout: [host findings][device findings][host strings][device strings]
@@ -249,7 +249,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
                 seg.dev_only = true; seg.ext_nf = nfh_j + nf; seg.ext_na = nbh_j + nb; seg.dev_copy = d_all;
             } else {
                 PinnedPool::Block blk = ctx->pool->take(out_bytes + 64);
-                if (!blk.p) { ctx->err = "hipHostMalloc failed"; return abandon(SX_E_NOMEM); }
+                if (!blk.p) { ctx->set_err("hipHostMalloc failed"); return abandon(SX_E_NOMEM); }
                 seg.ext = blk; seg.ext_nf = nfh_j + nf; seg.ext_na = nbh_j + nb;
                 if (K > 1) {   // on the copy stream: the next slab's kernels run meanwhile
                     segs.push_back(std::move(seg));
@@ -324,7 +324,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
                 written = 0;   // (only without leftover: the bytes of a leftover decode without error)
             }
             if (fs.lc) {
-                if (written != fs.lb) { ctx->err = "wave replay: the exit leftover does not decode to what the device counted"; return SX_E_STATE; }
+                if (written != fs.lb) { ctx->set_err("wave replay: the exit leftover does not decode to what the device counted"); return SX_E_STATE; }
                 fin.last_scan_run_leftover.assign((const char*)buf, written);
             }
             fin.last_run_str_was_printed_and_is_maybe_cut_str = fs.cut != 0;

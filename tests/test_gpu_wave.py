@@ -145,8 +145,19 @@ def test_wave_path_gives_up_and_the_other_path_takes_over(wave_forced):
         for chunk in (None, 65536):
             assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == sxo.run_cli(ms, [data], radix="x")
         assert wave_windows_of_a_scan(ms, data) == 0
+        # ... with the piece pipeline (kernels queued two pieces ahead): the re-scan of piece p must not share its record slot
+        # with the scan of piece p + 2 — the last Mission in launch order is the one that gives up
+        big = (text_lines(rng, 1 << 20) + rng.randbytes(1 << 20)) * 4
+        os.environ["SX_PIECE_MIB"] = "1"
+        for flags in (dict(encodings=["ascii", "utf-8"], chars_min="4"), dict(encodings=["utf-8", "ascii"], chars_min="6"),
+                      dict(encodings=["koi8-r"], chars_min="5", unicode_block_filter="Cyrillic")):
+            ms2 = rc.missions(**flags)
+            for busiest in ("0", "1"):
+                os.environ["SX_BUSIEST_LAST"] = busiest
+                assert run_cli_product(ms2, [big], radix="x", device=0) == sxo.run_cli(ms2, [big], radix="x"), (flags, busiest)
     finally:
-        os.environ.pop("SX_WAVE_FAIL", None)
+        for k in ("SX_WAVE_FAIL", "SX_PIECE_MIB", "SX_BUSIEST_LAST"):
+            os.environ.pop(k, None)
 
 
 from test_wave_core import DBCS_MISSIONS
