@@ -72,16 +72,25 @@ SXD i32 wm_prev(WvMask m, u32 at) {
     return -1;
 }
 SXD WvMask wm_shl1(WvMask m) { return WvMask{ m.lo << 1, (m.hi << 1) | (m.lo >> 63) }; }
-// the k-th (1-based) set bit of m at or above `from`; 128 if there are fewer
+// the k-th (1-based) set bit of m at or above `from`; 128 if there are fewer (halving by popcounts: a line of q chars is cut out of a
+// stretch of multi-byte characters this way, helper.rs:237)
 SXD u32 wm_select(WvMask m, u32 from, u32 k) {
-    WvMask r = wm_andn(m, wm_below(from));
+    const WvMask r = wm_andn(m, wm_below(from));
     const u32 pl = wv_popc64(r.lo);
     u64 v;
     u32 base;
     if (k <= pl) { v = r.lo; base = 0; } else { v = r.hi; base = 64; k -= pl; }
-    if (k > wv_popc64(v)) return 128u;
-    for (u32 t = 1; t < k; t++) v &= v - 1;
-    return base + wv_ctz64(v);
+    if (k == 0 || k > wv_popc64(v)) return 128u;
+    u32 x = (u32)v;
+    const u32 p32 = (u32)__builtin_popcount(x);
+    if (k > p32) { k -= p32; x = (u32)(v >> 32); base += 32; }
+#pragma unroll
+    for (u32 h = 16; h >= 1; h >>= 1) {   // the k-th set bit of x lies in its low h bits, or behind them
+        const u32 lowbits = x & ((1u << h) - 1u);
+        const u32 c = (u32)__builtin_popcount(lowbits);
+        if (k > c) { k -= c; x >>= h; base += h; } else x = lowbits;
+    }
+    return base;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -100,6 +109,7 @@ struct WvWin {
     WvMask F;        // first bytes of the characters (multi-byte encodings; single byte: unused)
     WvMask CS;       // bit i (1 <= i < n): a decoder call starts at byte i
     WvMask LS;       // first bytes of the stretches of accepted chars that have >= n BYTES (so every stretch of >= n chars is among them)
+    WvMask G;        // bytes of accepted characters (single byte: == A): LS's stretches; a candidate with too few CHARS is dropped by its popcount
     WvMask O2, O3;   // single byte: bytes whose UTF-8 form has 2 / 3 bytes (str_len = source bytes + popc(O2) + 2 popc(O3))
     WvMask O4;       // double byte: O2 / O3 / O4 = last bytes of the chars whose UTF-8 form has >= 2 / >= 3 / 4 bytes
     u32 n;           // bytes in the window
@@ -247,7 +257,7 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
 // One window: its decoder calls in order (finding_collection.rs:134-325).  Calls that hold no accepted char and
 // meet no leftover only clear the cut flag: they are skipped in bulk.
 template <int KIND, class EMIT>
-SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, bool skip_idle_calls = true) {
+SXD void wv_window_calls(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, bool skip_idle_calls = true) {
     u32 probe = 0;
     if (w.pre_empty) {
         if (w.slice_start && st.lb) probe = wv_probe_pack(st.lb, st.lback);
@@ -282,6 +292,207 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, b
         din = cend;
     }
     if (w.tail_empty) wv_call<KIND>(P, w, st, w.n, w.n, false, false, emit);
+}
+
+// ------------------------------------------------------------------------------------------
+// The same window, STRETCH BY STRETCH instead of call by call (round 4; what the kernels run).  wv_window_calls above walks the
+// window's decoder calls — on binary data a call starts every three or four bytes and nearly none of them yields anything; the
+// counters said 600 (single byte) to 1 800 (two-byte family) vector instructions per KiB for it.  What can yield is known from
+// the masks without visiting the calls:
+//   * the first call's text-start stretch (the leftover joins it, it may complete the string before):   once per window;
+//   * stretches of >= n accepted characters:   the LS bits, wherever they stand;
+//   * the stretch at the start of the call that follows an emission with the cut flag up (helper.rs:418-421):   `forced`, rare;
+//   * the last call's last stretch, which becomes the leftover however short (helper.rs:389-392):   `tail_a`.
+// The call a stretch belongs to is looked up when the stretch is visited (`din` = the CS bit in front of it: Finding::position,
+// finding_collection.rs:260; Exact for a call's first finding, After for the others, :289), and what the calls in between
+// would have done — clear the cut flag (:240-241) — is done when the walk crosses them.  wv_call's `stretch` is unchanged.
+// tests/native/wave_core_host.cpp runs both drivers on every window it sees and requires the same emissions and the same exit state.
+// ------------------------------------------------------------------------------------------
+template <int KIND, class EMIT>
+SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, bool = true) {
+    constexpr bool BYTES = KIND == 0;
+    const u32 n = w.n;
+    u32 probe = 0;
+    // ---- an empty call in front of byte 0 (the byte a pending sequence rejected is read again): it takes the leftover and the cut flag
+    if (w.pre_empty) {
+        if (w.slice_start && st.lb) probe = wv_probe_pack(st.lb, st.lback);
+        const bool cont = st.cut != 0;
+        const u32 lc = st.lc, lb = st.lb, lback = st.lback;
+        st.lc = 0; st.lb = 0; st.lback = 0; st.cut = 0;
+        if (lc && (cont || lc >= P.n_min))   // (its text ends with the call, the call in an error: helper.rs:410-415)
+            emit(0u, (u32)WV_BEFORE, cont, -(i32)lback, KIND == 1 ? lb : (KIND == 2 ? lback - w.head_pend : lback), lb);
+    }
+    // ---- the call in hand
+    u32 din = 0, cend = wm_next(w.CS, 1);
+    if (cend > n) cend = n;
+    bool inv_after = cend < n || w.tail_empty != 0;
+    WvMask Ec = wm_and(w.E, wm_below(cend));
+    const bool cont0 = st.cut != 0;
+    st.cut = 0;
+    const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback;
+    const u32 lsrc = KIND == 2 ? lback - w.head_pend : lback;
+    const bool has_left = lrem > 0;
+    st.lc = 0; st.lb = 0; st.lback = 0;
+    u32 prec = (has_left || w.probe_before) ? WV_BEFORE : WV_EXACT;
+    u32 cut_cend = 0;   // end of the call whose emission left st.cut up
+
+    // wv_call's stretch, for the call in hand: `pre` chars carried in front (the leftover), accepted chars = the E bits in [a, er)
+    auto stretch = [&](u32 a, u32 er, u32 pre, bool comp0) {
+        const WvMask av = wm_and(Ec, wm_range(a, er));
+        const bool ends_by_rej = er < 128;
+        u32 rem = pre + wm_popc(av);
+        u32 at = a;
+        i32 src = 0;
+        if (pre) src = -(i32)lback;
+        else if (BYTES) src = (i32)a;
+        else { const i32 f = wm_prev(w.F, a); src = f < 0 ? -(i32)w.head_back : f; }
+        bool comp = comp0;
+        u32 carried = pre, carried_b = pre ? lbytes : 0u;
+        while (rem) {
+            const u32 pn = rem < P.q ? rem : P.q;
+            const bool is_q = pn == P.q;
+            rem -= pn;
+            const bool tr = rem == 0 && !ends_by_rej;
+            if (!is_q && !tr && !comp && pn < P.n_min) return;              // helper.rs:315-330
+            const bool maybe_cut = is_q || (tr && !inv_after);              // :353-355
+            const bool again = !comp && tr && !inv_after && !is_q;          // :389-392
+            if (!comp && !again && pn < P.n_min) return;                    // :410-415
+            const u32 inw = pn - carried;
+            u32 last_e = at, out_b = carried_b;
+            i32 src_end = src + (i32)(carried ? (KIND == 1 ? lbytes : lsrc) : 0u);
+            if (inw) {
+                last_e = BYTES ? at + inw - 1 : wm_select(av, at, inw);
+                src_end = (i32)last_e + 1;
+                if (KIND == 1) out_b = (u32)(src_end - src);
+                else {
+                    const WvMask tr_ = wm_range(at, last_e + 1);
+                    out_b += inw + wm_popc(wm_and(w.O2, tr_)) + (BYTES ? 2 * wm_popc(wm_and(w.O3, tr_)) : wm_popc(wm_and(w.O3, tr_)) + wm_popc(wm_and(w.O4, tr_)));
+                }
+            }
+            if (again) { st.lc = pn; st.lb = out_b; st.lback = (u32)((i32)n - src); st.cut = 0; }   // finding_collection.rs:269-285
+            else {                                                                                   // :255-268
+                emit(din, prec, comp, src, (u32)(src_end - src), out_b);
+                st.lc = 0; st.lb = 0; st.lback = 0; st.cut = maybe_cut ? 1u : 0u;
+                cut_cend = cend;
+            }
+            prec = WV_AFTER;
+            comp = true;
+            carried = 0; carried_b = 0;
+            src = src_end;
+            if (inw) at = last_e + 1;
+        }
+    };
+    // the call behind the one in hand starts with an accepted char and the cut flag is up: its first stretch completes the string
+    // before however short it is -> the walk must stop there
+    u32 forced = 128;
+    auto look_for_forced = [&]() {
+        forced = 128;
+        if (!st.cut || cend >= n) return;
+        const u32 fe2 = wm_next(w.E, cend);
+        if (fe2 >= 128 || !wm_test(w.A, fe2)) return;
+        const u32 c2 = wm_next(w.CS, cend + 1);
+        if (fe2 < c2) forced = fe2;
+    };
+
+    // ---- the first call: its text-start stretch
+    u32 pos = 0;   // stretches whose first char ends below pos are done
+    if (has_left || wm_any(Ec)) {
+        if (!BYTES && !has_left && (probe || w.probe_hb)) {   // wv_call: the slice-start probe stays open until the writer decodes
+            const u32 fe0 = wm_next(Ec, 0);
+            const bool non_ascii = fe0 < 128 && (KIND == 1 ? !wm_test(w.F, fe0) : wm_test(w.O2, fe0));
+            if (non_ascii) prec = probe ? probe : (wv_probe_pack(0, 0) | (w.probe_hb << 27));
+        }
+        const u32 fe = wm_next(Ec, 0);
+        const bool first_acc = fe < 128 && wm_test(w.A, fe);
+        if (has_left || first_acc) {
+            const u32 er = first_acc ? wm_next(wm_andn(Ec, w.A), fe) : (fe < 128 ? fe : 128u);
+            stretch(first_acc ? fe : (fe < 128 ? fe : cend), er, lrem, cont0);
+            pos = er < 128 ? er + 1 : cend;
+            look_for_forced();
+        }
+    } else pos = cend;
+
+    // ---- the last call's last stretch, if its text ends with accepted chars and the call does not end in an error
+    u32 tail_a = 128;
+    if (!w.tail_empty) {
+        const i32 tcs = wm_prev(w.CS, 127);
+        const WvMask El = wm_andn(w.E, wm_below(tcs < 0 ? 0u : (u32)tcs));
+        const i32 el = wm_prev(El, 127);
+        if (el >= 0 && wm_test(w.A, (u32)el)) {
+            const i32 r = wm_prev(wm_andn(El, w.A), (u32)el);
+            tail_a = wm_next(El, r < 0 ? 0u : (u32)r + 1);
+        }
+    }
+
+    // ---- every other stretch that can yield, in order
+    while (pos < 128) {
+        const u32 sb = wm_next(w.LS, pos);
+        if (!BYTES && sb < 128) {
+            // a stretch of >= n BYTES: most of them (two-byte characters on binary data: two in three) have fewer than n CHARS and are
+            // neither the call's text-start stretch with the flag up nor the tail — dropped by their popcount, before the walk looks
+            // up the call they stand in
+            u32 m = 128;
+            if (forced >= pos) m = forced;
+            if (tail_a >= pos && tail_a < m) m = tail_a;
+            if (m >= sb) {
+                const u32 e = wm_next(WvMask{ ~w.G.lo, ~w.G.hi }, sb);   // first byte behind the stretch
+                if (m >= e && wm_popc(wm_and(w.A, wm_range(sb, e))) < P.n_min) { pos = e; continue; }
+            }
+        }
+        u32 a = sb < 128 ? (BYTES ? sb : wm_next(w.E, sb)) : 128u;
+        if (forced >= pos && forced < a) a = forced;
+        if (tail_a >= pos && tail_a < a) a = tail_a;
+        if (a >= 128) break;
+        bool comp0 = false;
+        if (a >= cend) {   // another call: the ones walked over cleared the cut flag, the one right behind the emission takes it
+            const i32 c = wm_prev(w.CS, a);
+            const u32 d = c < 0 ? 0u : (u32)c;
+            const bool cont = st.cut != 0 && d == cut_cend;
+            st.cut = 0;
+            din = d;
+            cend = wm_next(w.CS, a + 1);
+            if (cend > n) cend = n;
+            inv_after = cend < n || w.tail_empty != 0;
+            Ec = wm_and(w.E, wm_range(din, cend));
+            prec = WV_EXACT;
+            comp0 = cont && wm_next(Ec, 0) == a;   // (only the stretch at the very start of the text: helper.rs:327-330)
+        }
+        forced = 128;
+        const u32 er = wm_next(wm_andn(Ec, w.A), a);
+        stretch(a, er, 0u, comp0);
+        pos = er < 128 ? er + 1 : cend;
+        look_for_forced();
+    }
+    // the cut flag outlives the window only if the window's last call raised it; an empty call at the window end takes it too
+    if (st.cut && (cut_cend < n || w.tail_empty)) st.cut = 0;
+}
+
+// What the window hands on if what it was handed does not matter: every lane starts the exchange of the entry states from its
+// predecessor's guess instead of from "nothing carried" (which is wrong behind every window that ends inside a line of text or in
+// a stretch of accepted bytes: a third to all of them).  The guess is the last call's last stretch taken alone; it is wrong when
+// that stretch is the text-start stretch of its call and something is carried into it (a leftover, the cut flag) — the loop that
+// follows compares and repeats, so a wrong guess only costs a round.
+template <int KIND>
+SXD u32 wv_exit_guess(const WvParams& P, const WvWin& w) {
+    constexpr bool BYTES = KIND == 0;
+    if (w.tail_empty || w.n == 0) return 0u;
+    const i32 tcs = wm_prev(w.CS, 127);
+    const u32 t = tcs < 0 ? 0u : (u32)tcs;
+    const WvMask El = wm_andn(w.E, wm_below(t));
+    const i32 el = wm_prev(El, 127);
+    if (el < 0 || !wm_test(w.A, (u32)el)) return 0u;
+    const i32 r = wm_prev(wm_andn(El, w.A), (u32)el);
+    const u32 a = wm_next(El, r < 0 ? 0u : (u32)r + 1);
+    const WvMask rng = wm_range(a, (u32)el + 1);
+    const u32 c = wm_popc(wm_and(El, rng));
+    if (c >= P.q) return wv_pack(WvState{ 0, 0, 0, 1 });   // lines of q chars, the last piece touches the text end with the flag up
+    i32 src;
+    if (BYTES) src = (i32)a;
+    else { const i32 f = wm_prev(w.F, a); src = f < 0 ? -(i32)w.head_back : f; }
+    u32 out_b;
+    if (KIND == 1) out_b = (u32)(el + 1 - src);
+    else out_b = c + wm_popc(wm_and(w.O2, rng)) + (BYTES ? 2 * wm_popc(wm_and(w.O3, rng)) : wm_popc(wm_and(w.O3, rng)) + wm_popc(wm_and(w.O4, rng)));
+    return wv_pack(WvState{ c, out_b, (u32)((i32)w.n - src), 0 });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -339,7 +550,7 @@ SXD WvMask wv_long_starts(WvMask G, u32 n) {
 SXD WvWin wv_win_single(WvMask V, WvMask A, WvMask O2, WvMask O3, u32 n, u32 n_min) {
     WvWin w;
     w.E = V; w.A = A; w.F = V; w.O2 = O2; w.O3 = O3; w.n = n;
-    w.LS = wv_long_starts(A, n_min);
+    w.LS = wv_long_starts(A, n_min); w.G = A;
     const WvMask bad = wm_andn(wm_below(n), V);        // a byte without a character: Malformed(1, 0), the call ends behind it
     w.CS = wm_and(wm_shl1(bad), wm_below(n));
     w.tail_empty = n && wm_test(bad, n - 1) ? 1u : 0u;
@@ -419,7 +630,7 @@ SXD WvMasks16U wv_classify16_utf8(const LUT& lut, const u8* b, u32 have_lo, u32 
 SXD WvWin wv_win_utf8(WvMask E, WvMask A, WvMask F, WvMask G, WvMask MA, WvMask MB, u32 f_back, bool slice_start, u32 n, u32 n_min) {
     WvWin w;
     w.E = E; w.A = A; w.F = F; w.O2 = wm_zero(); w.O3 = wm_zero(); w.n = n;
-    w.LS = wv_long_starts(G, n_min);
+    w.LS = wv_long_starts(G, n_min); w.G = G;
     w.CS = wm_and(wm_or(wm_shl1(MA), MB), wm_andn(wm_below(n), wm_below(1)));
     w.tail_empty = n && wm_test(MA, n - 1) ? 1u : 0u;
     w.pre_empty = n && wm_test(MB, 0) ? 1u : 0u;
@@ -619,7 +830,7 @@ SXD WvWin wv_win_dbcs(WvMask E, WvMask A, WvMask F, WvMask G, WvMask MA, WvMask 
                       bool back_done, bool back_f, bool has_back, bool slice_start, u32 n, u32 n_min) {
     WvWin w;
     w.E = E; w.A = A; w.F = F; w.O2 = O2; w.O3 = O3; w.O4 = O4; w.n = n;
-    w.LS = wv_long_starts(G, n_min);
+    w.LS = wv_long_starts(G, n_min); w.G = G;
     w.CS = wm_and(wm_or(wm_shl1(MA), MB), wm_andn(wm_below(n), wm_below(1)));
     w.tail_empty = n && wm_test(MA, n - 1) ? 1u : 0u;
     w.pre_empty = n && wm_test(MB, 0) ? 1u : 0u;
@@ -757,6 +968,25 @@ template <int K> struct WvCountEmit {
         if (K > 0 && nf < (u32)K) {
             const WvDesc x = wv_desc_pack(nb, widx, din, prec, completes, src_rel, src_len, out_len);
             if (nf == 0) d0 = x; else if (K > 1 && nf == 1) d1 = x; else if (K > 2) d2 = x;
+        }
+        nf++; nb += out_len;
+    }
+};
+
+// the count pass' emitter since round 4: counts, and STAGES the window's first kWvStage findings as descriptors — in LDS, where the
+// batch's masks lay (every lane has pulled its window's masks into registers by then): [finding j][word][lane], so that a
+// wavefront's stores never meet in a bank whatever j the lanes are at.  When the batch's prefix sums are known every lane moves its
+// descriptors to the wavefront's list.  Before, two were kept in registers and any window with more was replayed once more — on
+// `-e ascii -n 4` (1.5 findings per window) nearly every batch paid that second replay: a quarter of the count pass.
+constexpr u32 kWvStage = 6;
+template <class PTR> struct WvStageEmit {
+    PTR stage;
+    u32 lane = 0, widx = 0, nf = 0, nb = 0;
+    SXD void operator()(u32 din, u32 prec, bool completes, i32 src_rel, u32 src_len, u32 out_len) {
+        if (nf < kWvStage) {
+            const WvDesc x = wv_desc_pack(nb, widx, din, prec, completes, src_rel, src_len, out_len);
+            PTR p = stage + nf * 192u + lane;
+            p[0] = x.w0; p[64] = x.w1; p[128] = x.w2;
         }
         nf++; nb += out_len;
     }

@@ -293,6 +293,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         wave_lds_sync<WPB>();
         if (FAM == 4) { dbcs_valid = have_next; if (have_next) dbcs_cov = cov_next; }   // (else the next batch walks back again)
 
+#if defined(SX_WV_EXP) && SX_WV_EXP == 1   // experiments (tools/build_variant.sh): what the classification alone costs
+        { u32 acc = 0; for (int k = 0; k < wv_n_masks(FAM); k++) acc ^= lds_mask[k][lane]; tot_f += acc & 1u; continue; }
+#endif
         // ---- 2. lane = window
         WvWin w;
         {
@@ -319,20 +322,35 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         }
 
         // ---- 3. entry states: iterate until they are consistent along the lanes
-        u32 in = lane == 0 ? carry : 0u, out = 0;
+        // (the exchange starts from every window's guess of what it hands on — wv_exit_guess: exact unless the window's last stretch is
+        // the text-start stretch of its call and something is carried into it —, not from "nothing carried": one round, not two or three)
+        constexpr int KIND = FAM == 0 ? 0 : FAM == 1 ? 1 : 2;
+        u32 out = active ? wv_exit_guess<KIND>(WP, w) : 0u;
+        u32 in = wv_from_prev(out, carry);
         const bool injected = g == P.g_lo;   // the host's exact state
         if (injected) in = P.inject;
         u32 nf = 0, nb = 0;
         bool todo = true;
-        constexpr int KD = MODE == 0 ? 2 : 0;   // findings per window whose descriptors the count pass keeps in registers
-        WvCountEmit<KD> ce;
+#if defined(SX_WV_EXP) && SX_WV_EXP == 2   // ... + the windows' masks out of LDS and the guess
+        { tot_f += (out ^ in ^ (u32)w.LS.lo ^ (u32)w.O3.hi ^ (u32)w.CS.hi) & 1u; continue; }
+#endif
+        // (MODE 0: the findings' descriptors are staged where the batch's masks lay — every lane holds its window in registers now; the
+        // LDS traffic of one wavefront is in order)
+        u32* const stage = &lds_mask[0][0];
+        static_assert(kWvStage * 192u <= (u32)wv_n_masks(FAM) * (kWvMaxTiles * 32 + 8), "the staged descriptors fit where the masks lay");
         for (;;) {
             if (todo && active) {
                 WvState st = wv_unpack(in);
-                ce = WvCountEmit<KD>{};
+#if defined(SX_WV_EXP) && SX_WV_EXP >= 3   // ... + the windows' state machine without descriptors
+                WvCountEmit<0> ce;
+#else
+                WvStageEmit<u32*> ce;
+                ce.stage = stage; ce.lane = lane;
+#endif
                 ce.widx = (u32)(g - own_start);
-                wv_window<(FAM == 0 ? 0 : FAM == 1 ? 1 : 2)>(WP, w, st, ce);
-                out = wv_pack(st); nf = ce.nf; nb = ce.nb;
+                if (MODE == 0) { wv_window<KIND>(WP, w, st, ce); nf = ce.nf; nb = ce.nb; }
+                else { WvCountEmit<0> cc; wv_window<KIND>(WP, w, st, cc); nf = cc.nf; nb = cc.nb; }
+                out = wv_pack(st);
             } else if (!active) out = in;
             u32 pin = wv_from_prev(out, carry);
             if (injected) pin = P.inject;
@@ -356,21 +374,27 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             const u64 fo = fbase + tot_f + (excl >> 18), ao = abase + tot_b + (excl & 0x3FFFFu);
             WriteEmit<FAM> we_{ &P, P.findings + fo, P.arena + ao, ao, ws };
             WvState st = wv_unpack(in);
-            wv_window<(FAM == 0 ? 0 : FAM == 1 ? 1 : 2)>(WP, w, st, we_);
+            wv_window<KIND>(WP, w, st, we_);
         }
+#if defined(SX_WV_EXP) && SX_WV_EXP >= 3
+        if (false) {
+#else
         if (MODE == 0 && P.desc && nf) {   // the lane-per-finding writer's input (beyond desc_cap: counted only, the launch falls back)
+#endif
             const u32 excl = incl - packed;
             const u32 at = tot_f + (excl >> 18), ab = tot_b + (excl & 0x3FFFFu);
             WvDesc* slot = (WvDesc*)P.desc + v * (u64)P.desc_cap + at;
             const u32 room = at < P.desc_cap ? P.desc_cap - at : 0u;
-            if (nf <= (u32)KD) {   // the usual window: what the count kept, its string offsets moved to the wavefront's
-                if (room >= 1) { WvDesc x = ce.d0; x.w0 += ab; slot[0] = x; }
-                if (KD > 1 && nf >= 2 && room >= 2) { WvDesc x = ce.d1; x.w0 += ab; slot[1] = x; }
-                if (KD > 2 && nf >= 3 && room >= 3) { WvDesc x = ce.d2; x.w0 += ab; slot[2] = x; }
+            if (nf <= kWvStage) {   // the usual window: what the count staged, its string offsets moved to the wavefront's
+                const u32 k = nf < room ? nf : room;
+                for (u32 j = 0; j < k; j++) {
+                    const u32* p = stage + j * 192u + lane;
+                    slot[j] = WvDesc{ p[0] + ab, p[64], p[128] };
+                }
             } else {
                 WvDescEmit de{ slot, room, ab, (u32)(g - own_start) };
                 WvState st = wv_unpack(in);
-                wv_window<(FAM == 0 ? 0 : FAM == 1 ? 1 : 2)>(WP, w, st, de);
+                wv_window<KIND>(WP, w, st, de);
             }
         }
         tot_f += bt >> 18; tot_b += bt & 0x3FFFFu;

@@ -62,6 +62,27 @@ struct WriteEmit {
     }
 };
 
+// both drivers of one window (sx_wave_core.hpp: call by call — the statement — and stretch by stretch — what the kernels run) must
+// emit the same findings and leave the same state
+struct RecEmit {
+    struct E { u32 din, prec; bool comp; i32 src; u32 len, out; };
+    std::vector<E> v;
+    void operator()(u32 din, u32 prec, bool completes, i32 src_rel, u32 src_len, u32 out_len) { v.push_back(E{ din, prec, completes, src_rel, src_len, out_len }); }
+};
+int g_driver_mismatch = 0;
+template <int KIND>
+bool drivers_agree(const WvParams& WP, const WvWin& w, u32 in) {
+    RecEmit a, b;
+    WvState sa = wv_unpack(in), sb = wv_unpack(in);
+    wv_window<KIND>(WP, w, sa, a);
+    wv_window_calls<KIND>(WP, w, sb, b, false);
+    if (wv_pack(sa) != wv_pack(sb) || a.v.size() != b.v.size()) return false;
+    for (size_t i = 0; i < a.v.size(); i++)
+        if (a.v[i].din != b.v[i].din || a.v[i].prec != b.v[i].prec || a.v[i].comp != b.v[i].comp || a.v[i].src != b.v[i].src ||
+            a.v[i].len != b.v[i].len || a.v[i].out != b.v[i].out) return false;
+    return true;
+}
+
 // one wavefront, MODE 0 count / 1 write; returns false if an iteration did not settle (cannot happen)
 template <int MODE>
 bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
@@ -189,13 +210,16 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
             }
         }
         u32 in[64], out[64], nf[64], nb[64];
-        WvCountEmit<2> kept[64];   // (the kernel's count pass keeps a window's first two findings as descriptors in registers)
+        std::vector<u32> stage(kWvStage * 192u, 0xDEADBEEFu);   // (the kernel's count pass stages a window's first findings as descriptors in LDS)
         bool todo[64], injected[64];
+        // (as the kernel: the exchange starts from every window's guess of what it hands on, sx_wave_core.hpp wv_exit_guess)
+        for (u32 l = 0; l < 64; l++)
+            out[l] = !active[l] ? 0u : P.family == 0 ? wv_exit_guess<0>(WP, w[l]) : P.family == 1 ? wv_exit_guess<1>(WP, w[l]) : wv_exit_guess<2>(WP, w[l]);
         for (u32 l = 0; l < 64; l++) {
             injected[l] = g0 + l == P.g_lo;
-            in[l] = l == 0 ? carry : 0u;
+            in[l] = l == 0 ? carry : out[l - 1];
             if (injected[l]) in[l] = P.inject;
-            out[l] = 0; nf[l] = nb[l] = 0; todo[l] = true;
+            nf[l] = nb[l] = 0; todo[l] = true;
         }
         u32 rounds = 0;
         for (;;) {
@@ -203,8 +227,8 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
             for (u32 l = 0; l < 64; l++) {
                 if (todo[l] && active[l]) {
                     WvState st = wv_unpack(in[l]);
-                    WvCountEmit<2>& ce = kept[l];
-                    ce = WvCountEmit<2>{};
+                    WvStageEmit<u32*> ce;
+                    ce.stage = stage.data(); ce.lane = l;
                     ce.widx = (u32)(g0 + l - own_start);
                     if (P.family == 0) wv_window<0>(WP, w[l], st, ce, skip_idle);
                     else if (P.family == 1) wv_window<1>(WP, w[l], st, ce, skip_idle);
@@ -224,6 +248,12 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
             if (!any) break;
         }
         if (rounds > *rounds_max) *rounds_max = rounds;
+        if (MODE == 0)
+            for (u32 l = 0; l < 64; l++)
+                if (active[l] && !(P.family == 0 ? drivers_agree<0>(WP, w[l], in[l]) : P.family == 1 ? drivers_agree<1>(WP, w[l], in[l]) : drivers_agree<2>(WP, w[l], in[l]))) {
+                    g_driver_mismatch++;
+                    return false;
+                }
         if (g0 == gw && v != 0) assumed_in = in[kWvWarm];
         carry = out[63];
         const u32 last_out = out[n_act - 1];
@@ -234,9 +264,12 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                 const u32 at = tot_f + bf, ab = tot_b + bb;
                 WvDesc* slot = (WvDesc*)P.desc + v * (u64)P.desc_cap + at;
                 const u32 room = at < P.desc_cap ? P.desc_cap - at : 0u;
-                if (nf[l] <= 2) {
-                    if (room >= 1) { WvDesc x = kept[l].d0; x.w0 += ab; slot[0] = x; }
-                    if (nf[l] >= 2 && room >= 2) { WvDesc x = kept[l].d1; x.w0 += ab; slot[1] = x; }
+                if (nf[l] <= kWvStage) {
+                    const u32 k = nf[l] < room ? nf[l] : room;
+                    for (u32 j = 0; j < k; j++) {
+                        const u32* sp = stage.data() + j * 192u + l;
+                        slot[j] = WvDesc{ sp[0] + ab, sp[64], sp[128] };
+                    }
                 } else {
                     WvDescEmit de{ slot, room, ab, (u32)(g0 + l - own_start) };
                     WvState st = wv_unpack(in[l]);
@@ -291,7 +324,7 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
     P.desc_cap = (nwin & 3u) == 1u ? nwin / 8 + 1 : 2 * nwin + 64;
     std::vector<u32> desc((size_t)(n_waves * P.desc_cap * 3 + 3), 0xDEADBEEFu);
     P.desc = nwin <= kWvDescMaxWin ? desc.data() : nullptr;   // (as sx_wave.cpp: larger wavefronts do without)
-    for (u64 v = 0; v < n_waves; v++) if (!wave<0>(P, v, skip_idle != 0, rounds_max)) return -1;
+    for (u64 v = 0; v < n_waves; v++) if (!wave<0>(P, v, skip_idle != 0, rounds_max)) return g_driver_mismatch ? -7 : -1;
     u64 f = 0, a = 0;
     for (u64 v = 0; v < n_waves; v++) {
         fb[v] = f; ab[v] = a; f += wnf[v]; a += wnb[v];

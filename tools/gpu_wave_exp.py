@@ -5,7 +5,7 @@ import refconfig as rc, stringsext_amd as sx
 enc = sys.argv[1] if len(sys.argv) > 1 else "big5"
 n = int(sys.argv[2]) << 30 if len(sys.argv) > 2 else 4 << 30
 os.environ["SX_WAVE_REPLAY"] = "1"
-ms = rc.missions(encodings=[enc], chars_min=os.environ.get("EXP_N", "10"))
+ms = rc.missions(encodings=[enc], chars_min=os.environ.get("EXP_N", "10"))   # enc may carry its filter: "big5,,,Cjk"
 sc = sx.Scanner(ms, device=0)
 d = sc.alloc(n); sc.fill_background(d, 0, n, 0x5EED5EED5EED5EED)
 for it in range(3):
