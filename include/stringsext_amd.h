@@ -198,6 +198,10 @@ int sx_wave_classes(const sx_mission* mission, uint8_t* classes);
  * filter, bits 2-3: its UTF-8 form has 2 / 3 / 4 bytes, 3 = it yields two code points.  out8192 or NULL. */
 const uint32_t* sx_wave_pair_codes(const sx_mission* mission, uint32_t* out8192);
 
+/* ... and the same classes as SWAR ranges, if the Mission's can be put that way (csrc/sx_device.hpp WvSwar, 25 words): what the wave
+ * kernels classify with then.  Returns 1 and fills out25, 0 if the Mission's classes stay a table, < 0 on error.  (Test harness.) */
+int sx_wave_swar(const sx_mission* mission, uint32_t* out25);
+
 int  sx_abi_version(void);
 
 /* hip_device >= 0: bind to that device.  hip_device == SX_HOST_ONLY: a context

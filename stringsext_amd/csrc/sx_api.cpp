@@ -170,6 +170,17 @@ const uint32_t* sx_wave_pair_codes(const sx_mission* mission, uint32_t* out8192)
     return out8192;
 }
 
+int sx_wave_swar(const sx_mission* mission, uint32_t* out25) {
+    if (!mission || !out25) return SX_E_INVALID;
+    Mission m;
+    std::string err;
+    const int rc = Mission::from_c(*mission, false, &m, &err);
+    if (rc != SX_OK) return rc;
+    static_assert(sizeof(WvSwar) == 25 * 4, "sx_wave_swar hands the struct out as 25 words");
+    memcpy(out25, &m.wave_swar, sizeof(WvSwar));
+    return m.wave_ok && m.wave_swar.cls ? 1 : 0;
+}
+
 int sx_wave_classes(const sx_mission* mission, uint8_t* classes) {
     if (!mission || !classes) return SX_E_INVALID;
     Mission m;

@@ -150,6 +150,14 @@ hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegion
 
 // ---- stage B for string-dense Missions, wave-cooperative (sx_wave_dev.hip, sx_wave_core.hpp) ----
 // One lane per decoder-input window, 64 consecutive windows per wavefront batch; two passes (count, write).
+// byte classes of a wave-path Mission as SWAR ranges instead of the 256-entry table (sx_wave_core.hpp wv_classify16_single_swar)
+struct WvSwar {
+    uint32_t cls;                    // 0: the class table; 1: ranges
+    uint32_t n;                      // ranges in use
+    uint32_t c1[6], c2[6], hi[6];    // per range, replicated over the four bytes: 0x80 - lo7, 0x7F - hi7, 0 for bytes >= 0x80 / ~0 for bytes below
+    uint32_t hi_len;                 // single byte: UTF-8 bytes of an accepted byte >= 0x80 (2 / 3); two-byte family: of an accepted pair
+    uint32_t lr_c1[2], lr_c2[2];     // two-byte family: the lead byte ranges (low 7 bits), as ScanParams::lr_c1
+};
 struct WaveParams {
     const uint8_t* data;      // device: buffer byte 0 (on the slice grid)
     uint64_t len;
@@ -179,6 +187,7 @@ struct WaveParams {
     // writer that works a lane per finding (launch_wave_emit); nullptr: the window-parallel writer (launch_wave_write) is the only one
     uint32_t* desc;
     uint32_t desc_cap;
+    WvSwar swar;              // cls != 0: the classes come from ranges, `lut` is not read
 };
 size_t wave_scratch_bytes(uint64_t n_waves);
 // pass 1 of wavefronts [v0, v1) + exclusive sums from v0 on + verification; totals (device, 4 x u64): findings, string bytes,

@@ -243,6 +243,30 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
                 if (!ranges.empty() && ranges.back().second == b - 1 && b != 0x80) ranges.back().second = b;
                 else ranges.emplace_back(b, b);
             }
+        // the wave kernels' classes as ranges (sx_wave_core.hpp wv_classify16_single_swar): every byte a character, the accepted ones at
+        // most six ranges, the accepted ones >= 0x80 with UTF-8 forms of one length
+        {
+            bool all_valid = true;
+            int hi_len = 0;
+            bool one_len = true;
+            for (int b = 0; b < 256; b++) {
+                const uint8_t c = m->wave_lut[(size_t)b];
+                all_valid = all_valid && (c & WVC_VALID);
+                if (b >= 0x80 && (c & WVC_ACC)) {
+                    const int len = (c & WVC_O3) ? 3 : (c & WVC_O2) ? 2 : 1;
+                    if (hi_len == 0) hi_len = len; else if (hi_len != len) one_len = false;
+                }
+            }
+            if (all_valid && one_len && hi_len != 1 && ranges.size() <= 6) {
+                WvSwar& R = m->wave_swar;
+                R.cls = 1; R.n = (uint32_t)ranges.size(); R.hi_len = (uint32_t)hi_len;
+                for (size_t k = 0; k < 6; k++) {
+                    uint32_t lo = 1, hi = 0, high = 0;   // empty
+                    if (k < ranges.size()) { lo = (uint32_t)ranges[k].first & 0x7F; hi = (uint32_t)ranges[k].second & 0x7F; high = ranges[k].first >= 0x80; }
+                    R.c1[k] = (0x80u - lo) * 0x01010101u; R.c2[k] = (0x7Fu - hi) * 0x01010101u; R.hi[k] = high ? 0u : 0xFFFFFFFFu;
+                }
+            }
+        }
         if (!force_generic && af_is_range && (hempty || high_all)) {
             m->kind = kClsSingleByteRange;
             p.high_all = high_all ? 1 : 0;

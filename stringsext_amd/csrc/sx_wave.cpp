@@ -166,6 +166,8 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         P.g_lo = g_lo; P.g_hi = g_all; P.nwin = nwin; P.inject = wv_pack(in);
         P.mission_id = m.c.mission_id; P.file_id = job.file_id; P.family = m.wave_family; P.lut = d.d_wave_lut; P.table = d.d_table;
         P.pairs = d.d_wave_pairs; P.encoding = m.c.encoding; P.entry_skip = m.buf_entry_skip;
+        P.swar = m.wave_swar;
+        if (const char* e = getenv("SX_WAVE_LUT")) if (atoi(e)) P.swar.cls = 0;   // tests: the class table also where ranges would do
         P.wave_nf = d_u; P.wave_nb = d_u + n_waves; P.wave_in = d_u + 2 * n_waves; P.wave_out = d_u + 3 * n_waves;
         P.wave_fbase = d_fb; P.wave_abase = d_ab;
         // Descriptors for the lane-per-finding writer: room for twice the findings a wavefront is expected to hold (the last buffer's

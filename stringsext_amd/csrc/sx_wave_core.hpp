@@ -308,8 +308,41 @@ SXD void wv_window_calls(const WvParams& P, const WvWin& w, WvState& st, EMIT& e
 // would have done — clear the cut flag (:240-241) — is done when the walk crosses them.  wv_call's `stretch` is unchanged.
 // tests/native/wave_core_host.cpp runs both drivers on every window it sees and requires the same emissions and the same exit state.
 // ------------------------------------------------------------------------------------------
+// The last call's last stretch, looked at once per window: where it starts (the end bit of its first char; 128: the text does not end
+// with accepted chars, or the call ends in an error) and what it leaves behind when nothing is carried into it — fewer than q chars:
+// they are the leftover (helper.rs:389-392); more: lines of q chars, the last piece touches the text end with the flag up.
+struct WvTail { u32 a, state; };
+template <int KIND>
+SXD WvTail wv_tail(const WvParams& P, const WvWin& w) {
+    constexpr bool BYTES = KIND == 0;
+    if (w.tail_empty || w.n == 0) return WvTail{ 128u, 0u };
+    const i32 tcs = wm_prev(w.CS, 127);
+    const WvMask El = wm_andn(w.E, wm_below(tcs < 0 ? 0u : (u32)tcs));
+    const i32 el = wm_prev(El, 127);
+    if (el < 0 || !wm_test(w.A, (u32)el)) return WvTail{ 128u, 0u };
+    const i32 r = wm_prev(wm_andn(El, w.A), (u32)el);
+    const u32 a = wm_next(El, r < 0 ? 0u : (u32)r + 1);
+    const WvMask rng = wm_range(a, (u32)el + 1);
+    const u32 c = wm_popc(wm_and(El, rng));
+    if (c >= P.q) return WvTail{ a, wv_pack(WvState{ 0, 0, 0, 1 }) };
+    i32 src;
+    if (BYTES) src = (i32)a;
+    else { const i32 f = wm_prev(w.F, a); src = f < 0 ? -(i32)w.head_back : f; }
+    u32 out_b;
+    if (KIND == 1) out_b = (u32)(el + 1 - src);
+    else out_b = c + wm_popc(wm_and(w.O2, rng)) + (BYTES ? 2 * wm_popc(wm_and(w.O3, rng)) : wm_popc(wm_and(w.O3, rng)) + wm_popc(wm_and(w.O4, rng)));
+    return WvTail{ a, wv_pack(WvState{ c, out_b, (u32)((i32)w.n - src), 0 }) };
+}
+// What the window hands on if what it was handed does not matter: every lane starts the exchange of the entry states from its
+// predecessor's guess instead of from "nothing carried" (which is wrong behind every window that ends inside a line of text or in
+// a stretch of accepted bytes: a third to all of them).  It is wrong when the tail is the text-start stretch of its call and something
+// is carried into it (a leftover, the cut flag) — the loop that follows compares and repeats, so a wrong guess only costs a round
+// (measured in the host harness: 1.00 rounds per batch on binary data, 1.01 on text).
+template <int KIND>
+SXD u32 wv_exit_guess(const WvParams& P, const WvWin& w) { return wv_tail<KIND>(P, w).state; }
+
 template <int KIND, class EMIT>
-SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, bool = true) {
+SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, const WvTail& tail) {
     constexpr bool BYTES = KIND == 0;
     const u32 n = w.n;
     u32 probe = 0;
@@ -335,8 +368,10 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, b
     st.lc = 0; st.lb = 0; st.lback = 0;
     u32 prec = (has_left || w.probe_before) ? WV_BEFORE : WV_EXACT;
     u32 cut_cend = 0;   // end of the call whose emission left st.cut up
+    const bool tail_simple = wv_unpack(tail.state).lc != 0;   // the tail, taken alone, is just the leftover
 
-    // wv_call's stretch, for the call in hand: `pre` chars carried in front (the leftover), accepted chars = the E bits in [a, er)
+    // wv_call's stretch, for the call in hand: `pre` chars carried in front (the leftover), accepted chars = the E bits in [a, er).
+    // It runs ONCE per trip of the loop below, and only for stretches that yield or carry (a wavefront pays for it whenever one lane needs it)
     auto stretch = [&](u32 a, u32 er, u32 pre, bool comp0) {
         const WvMask av = wm_and(Ec, wm_range(a, er));
         const bool ends_by_rej = er < 128;
@@ -361,7 +396,8 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, b
             u32 last_e = at, out_b = carried_b;
             i32 src_end = src + (i32)(carried ? (KIND == 1 ? lbytes : lsrc) : 0u);
             if (inw) {
-                last_e = BYTES ? at + inw - 1 : wm_select(av, at, inw);
+                // (a stretch that is one piece ends at its last char: no rank-select)
+                last_e = BYTES ? at + inw - 1 : (rem == 0 ? (u32)wm_prev(av, 127) : wm_select(av, at, inw));
                 src_end = (i32)last_e + 1;
                 if (KIND == 1) out_b = (u32)(src_end - src);
                 else {
@@ -382,20 +418,11 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, b
             if (inw) at = last_e + 1;
         }
     };
-    // the call behind the one in hand starts with an accepted char and the cut flag is up: its first stretch completes the string
-    // before however short it is -> the walk must stop there
-    u32 forced = 128;
-    auto look_for_forced = [&]() {
-        forced = 128;
-        if (!st.cut || cend >= n) return;
-        const u32 fe2 = wm_next(w.E, cend);
-        if (fe2 >= 128 || !wm_test(w.A, fe2)) return;
-        const u32 c2 = wm_next(w.CS, cend + 1);
-        if (fe2 < c2) forced = fe2;
-    };
 
-    // ---- the first call: its text-start stretch
+    // ---- the first call's text-start stretch: the next trip's work (`have`), or settled here
     u32 pos = 0;   // stretches whose first char ends below pos are done
+    bool have = false, comp0 = false;
+    u32 a = 128, er = 128, pre = 0;
     if (has_left || wm_any(Ec)) {
         if (!BYTES && !has_left && (probe || w.probe_hb)) {   // wv_call: the slice-start probe stays open until the writer decodes
             const u32 fe0 = wm_next(Ec, 0);
@@ -405,94 +432,70 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, b
         const u32 fe = wm_next(Ec, 0);
         const bool first_acc = fe < 128 && wm_test(w.A, fe);
         if (has_left || first_acc) {
-            const u32 er = first_acc ? wm_next(wm_andn(Ec, w.A), fe) : (fe < 128 ? fe : 128u);
-            stretch(first_acc ? fe : (fe < 128 ? fe : cend), er, lrem, cont0);
-            pos = er < 128 ? er + 1 : cend;
-            look_for_forced();
+            er = first_acc ? wm_next(wm_andn(Ec, w.A), fe) : (fe < 128 ? fe : 128u);
+            a = first_acc ? fe : (fe < 128 ? fe : cend);
+            const u32 total = lrem + (first_acc ? wm_popc(wm_and(Ec, wm_range(fe, er))) : 0u);
+            if (!cont0 && total < P.n_min && (er < 128 || inv_after)) pos = er < 128 ? er + 1 : cend;   // dropped (helper.rs:315-330, 410-415)
+            else if (!has_left && !cont0 && a == tail.a && tail_simple) { st = wv_unpack(tail.state); return; }   // the window is one call and ends inside its first stretch
+            else { have = true; pre = lrem; comp0 = cont0; }
         }
     } else pos = cend;
 
-    // ---- the last call's last stretch, if its text ends with accepted chars and the call does not end in an error
-    u32 tail_a = 128;
-    if (!w.tail_empty) {
-        const i32 tcs = wm_prev(w.CS, 127);
-        const WvMask El = wm_andn(w.E, wm_below(tcs < 0 ? 0u : (u32)tcs));
-        const i32 el = wm_prev(El, 127);
-        if (el >= 0 && wm_test(w.A, (u32)el)) {
-            const i32 r = wm_prev(wm_andn(El, w.A), (u32)el);
-            tail_a = wm_next(El, r < 0 ? 0u : (u32)r + 1);
-        }
-    }
-
-    // ---- every other stretch that can yield, in order
-    while (pos < 128) {
-        const u32 sb = wm_next(w.LS, pos);
-        if (!BYTES && sb < 128) {
-            // a stretch of >= n BYTES: most of them (two-byte characters on binary data: two in three) have fewer than n CHARS and are
-            // neither the call's text-start stretch with the flag up nor the tail — dropped by their popcount, before the walk looks
-            // up the call they stand in
-            u32 m = 128;
-            if (forced >= pos) m = forced;
-            if (tail_a >= pos && tail_a < m) m = tail_a;
-            if (m >= sb) {
-                const u32 e = wm_next(WvMask{ ~w.G.lo, ~w.G.hi }, sb);   // first byte behind the stretch
-                if (m >= e && wm_popc(wm_and(w.A, wm_range(sb, e))) < P.n_min) { pos = e; continue; }
+    // ---- every stretch that can yield, in order.  The call behind an emission with the flag up, if it starts with an accepted char:
+    // its first stretch completes the string before however short it is (helper.rs:418-421) -> the walk must stop there (`forced`)
+    u32 forced = 128;
+    for (;;) {
+        if (!have) {
+            // the next stretch worth a visit: a tight loop of its own — stretches of >= n BYTES with fewer than n CHARS (two-byte
+            // characters on binary data: two in three) are dropped by their popcount before anything else is looked up
+            for (;;) {
+                const u32 sb = pos < 128 ? wm_next(w.LS, pos) : 128u;
+                u32 m = 128;
+                if (forced >= pos) m = forced;
+                if (tail.a >= pos && tail.a < m) m = tail.a;
+                if (!BYTES && sb < 128 && m >= sb) {
+                    const u32 e = wm_next(WvMask{ ~w.G.lo, ~w.G.hi }, sb);   // first byte behind the stretch
+                    if (m >= e && wm_popc(wm_and(w.A, wm_range(sb, e))) < P.n_min) { pos = e; continue; }
+                }
+                a = sb < 128 ? (BYTES ? sb : wm_next(w.E, sb)) : 128u;
+                if (m < a) a = m;
+                break;
             }
+            if (a >= 128) break;
+            if (a == tail.a && tail_simple && st.cut == 0) { st = wv_unpack(tail.state); break; }   // the tail, nothing carried into it: the leftover
+            comp0 = false;
+            if (a >= cend) {   // another call: the ones walked over cleared the cut flag, the one right behind the emission takes it
+                const i32 c = wm_prev(w.CS, a);
+                const u32 d = c < 0 ? 0u : (u32)c;
+                const bool cont = st.cut != 0 && d == cut_cend;
+                st.cut = 0;
+                din = d;
+                cend = wm_next(w.CS, a + 1);
+                if (cend > n) cend = n;
+                inv_after = cend < n || w.tail_empty != 0;
+                Ec = wm_and(w.E, wm_range(din, cend));
+                prec = WV_EXACT;
+                comp0 = cont && wm_next(Ec, 0) == a;   // (only the stretch at the very start of the text: helper.rs:327-330)
+            }
+            er = wm_next(wm_andn(Ec, w.A), a);
+            pre = 0;
         }
-        u32 a = sb < 128 ? (BYTES ? sb : wm_next(w.E, sb)) : 128u;
-        if (forced >= pos && forced < a) a = forced;
-        if (tail_a >= pos && tail_a < a) a = tail_a;
-        if (a >= 128) break;
-        bool comp0 = false;
-        if (a >= cend) {   // another call: the ones walked over cleared the cut flag, the one right behind the emission takes it
-            const i32 c = wm_prev(w.CS, a);
-            const u32 d = c < 0 ? 0u : (u32)c;
-            const bool cont = st.cut != 0 && d == cut_cend;
-            st.cut = 0;
-            din = d;
-            cend = wm_next(w.CS, a + 1);
-            if (cend > n) cend = n;
-            inv_after = cend < n || w.tail_empty != 0;
-            Ec = wm_and(w.E, wm_range(din, cend));
-            prec = WV_EXACT;
-            comp0 = cont && wm_next(Ec, 0) == a;   // (only the stretch at the very start of the text: helper.rs:327-330)
-        }
-        forced = 128;
-        const u32 er = wm_next(wm_andn(Ec, w.A), a);
-        stretch(a, er, 0u, comp0);
+        have = false;
+        stretch(a, er, pre, comp0);
         pos = er < 128 ? er + 1 : cend;
-        look_for_forced();
+        forced = 128;
+        if (st.cut && cend < n) {
+            const u32 fe2 = wm_next(w.E, cend);
+            if (fe2 < 128 && wm_test(w.A, fe2) && fe2 < wm_next(w.CS, cend + 1)) forced = fe2;
+        }
     }
     // the cut flag outlives the window only if the window's last call raised it; an empty call at the window end takes it too
     if (st.cut && (cut_cend < n || w.tail_empty)) st.cut = 0;
 }
-
-// What the window hands on if what it was handed does not matter: every lane starts the exchange of the entry states from its
-// predecessor's guess instead of from "nothing carried" (which is wrong behind every window that ends inside a line of text or in
-// a stretch of accepted bytes: a third to all of them).  The guess is the last call's last stretch taken alone; it is wrong when
-// that stretch is the text-start stretch of its call and something is carried into it (a leftover, the cut flag) — the loop that
-// follows compares and repeats, so a wrong guess only costs a round.
-template <int KIND>
-SXD u32 wv_exit_guess(const WvParams& P, const WvWin& w) {
-    constexpr bool BYTES = KIND == 0;
-    if (w.tail_empty || w.n == 0) return 0u;
-    const i32 tcs = wm_prev(w.CS, 127);
-    const u32 t = tcs < 0 ? 0u : (u32)tcs;
-    const WvMask El = wm_andn(w.E, wm_below(t));
-    const i32 el = wm_prev(El, 127);
-    if (el < 0 || !wm_test(w.A, (u32)el)) return 0u;
-    const i32 r = wm_prev(wm_andn(El, w.A), (u32)el);
-    const u32 a = wm_next(El, r < 0 ? 0u : (u32)r + 1);
-    const WvMask rng = wm_range(a, (u32)el + 1);
-    const u32 c = wm_popc(wm_and(El, rng));
-    if (c >= P.q) return wv_pack(WvState{ 0, 0, 0, 1 });   // lines of q chars, the last piece touches the text end with the flag up
-    i32 src;
-    if (BYTES) src = (i32)a;
-    else { const i32 f = wm_prev(w.F, a); src = f < 0 ? -(i32)w.head_back : f; }
-    u32 out_b;
-    if (KIND == 1) out_b = (u32)(el + 1 - src);
-    else out_b = c + wm_popc(wm_and(w.O2, rng)) + (BYTES ? 2 * wm_popc(wm_and(w.O3, rng)) : wm_popc(wm_and(w.O3, rng)) + wm_popc(wm_and(w.O4, rng)));
-    return wv_pack(WvState{ c, out_b, (u32)((i32)w.n - src), 0 });
+template <int KIND, class EMIT>
+SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, bool = true) {
+    const WvTail tail = wv_tail<KIND>(P, w);
+    wv_window<KIND>(P, w, st, emit, tail);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -513,6 +516,47 @@ SXD WvMasks16 wv_classify16_single(const LUT& lut, u32 x0, u32 x1, u32 x2, u32 x
     }
     const u32 keep = avail >= 16 ? 0xFFFFu : ((1u << avail) - 1u);
     m.v &= keep; m.a &= keep; m.o2 &= keep; m.o3 &= keep;
+    return m;
+}
+
+// ---- the same classes WITHOUT the table (round 4): a Mission whose 256 bytes are all characters, whose accepted bytes are at most six
+// ranges (each on one side of 0x80: KOI8-R + Cyrillic is 20..7E, A3, B3, C0..FF; `ascii` one range) and whose accepted bytes >= 0x80 all
+// have UTF-8 forms of the same length needs two masks per 16 bytes — accepted, >= 0x80 — and three SWAR operations per range and
+// dword for them, no LDS lookups (16 per lane and tile, on random bytes four to five of them to the same bank).  The valid mask is
+// all ones, O2 / O3 = accepted & high by the length.  sx_mission.cpp decides (Mission::wave_swar); the table version above stays as
+// the statement the host harness compares this with, and as the path of every other Mission.
+// flags at bit 7 of every byte of four dwords -> 16 bits
+SXD u32 wv_movemask16_b7(u32 f0, u32 f1, u32 f2, u32 f3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 lo = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false);
+    lo = __builtin_amdgcn_udot4(f1, 0x80402010u, lo, false);
+    u32 hi = __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false);
+    hi = __builtin_amdgcn_udot4(f3, 0x80402010u, hi, false);
+    return (lo >> 7) | (hi << 1);   // (each flag byte is 0x80: the sums are 128 x mask)
+#else
+    const u32 f[4] = { f0, f1, f2, f3 };
+    u32 m = 0;
+    for (int k = 0; k < 16; k++) m |= ((f[k >> 2] >> (8 * (k & 3) + 7)) & 1u) << k;
+    return m;
+#endif
+}
+// accepted bytes of one dword: flags at bit 7.  K = the ranges computed (the Mission's, rounded up to 1 / 3 / 6: the count is the
+// same for every lane, so the kernels pick the instantiation with a scalar branch)
+template <int K>
+SXD u32 wv_swar_accepted(const WvSwar& R, u32 x) {
+    const u32 t = x & 0x7F7F7F7Fu;
+    u32 f = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) f |= (t + R.c1[k]) & ~(t + R.c2[k]) & (x ^ R.hi[k]);   // (ranges not in use are empty: lo 1, hi 0)
+    return f & 0x80808080u;
+}
+struct WvMasks16R { u32 a, hi; };
+template <int K = 6>
+SXD WvMasks16R wv_classify16_single_swar(const WvSwar& R, u32 x0, u32 x1, u32 x2, u32 x3, u32 avail) {
+    const u32 keep = avail >= 16 ? 0xFFFFu : ((1u << avail) - 1u);
+    WvMasks16R m;
+    m.a = wv_movemask16_b7(wv_swar_accepted<K>(R, x0), wv_swar_accepted<K>(R, x1), wv_swar_accepted<K>(R, x2), wv_swar_accepted<K>(R, x3)) & keep;
+    m.hi = wv_movemask16_b7(x0 & 0x80808080u, x1 & 0x80808080u, x2 & 0x80808080u, x3 & 0x80808080u) & keep;
     return m;
 }
 
@@ -557,6 +601,12 @@ SXD WvWin wv_win_single(WvMask V, WvMask A, WvMask O2, WvMask O3, u32 n, u32 n_m
     w.pre_empty = 0; w.head_back = 0; w.probe_before = 0; w.slice_start = 0; w.probe_hb = 0; w.head_pend = 0; w.tail_pend = 0;
     w.O4 = wm_zero();
     return w;
+}
+
+// the window of a single-byte Mission whose classes came as ranges (wv_classify16_single_swar)
+SXD WvWin wv_win_single_swar(WvMask A, WvMask HI, u32 hi_len, u32 n, u32 n_min) {
+    const WvMask ah = wm_and(A, HI);
+    return wv_win_single(wm_below(n), A, hi_len == 2 ? ah : wm_zero(), hi_len == 3 ? ah : wm_zero(), n, n_min);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -109,7 +109,13 @@ template <int WPB> SXD void wave_lds_sync() {
     else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 }
 
-constexpr int wv_n_masks(int fam) { return fam == 4 ? 9 : fam == 1 ? 6 : 4; }
+// masks a wavefront keeps per batch (16 bits per lane and tile each).  CLS 1: the classes come from ranges (sx_device.hpp WvSwar): a
+// single-byte Mission then stores accepted / >= 0x80 only
+constexpr int wv_n_masks(int fam, int cls) { return fam == 4 ? 9 : fam == 1 ? 6 : cls ? 2 : 4; }
+constexpr u32 kMaskWords = kWvMaxTiles * 32 + 8;
+constexpr u32 wv_lds_words(int fam, int cls) {   // ... and the descriptors staged in their place need kWvStage x 3 x 64 words
+    return (u32)wv_n_masks(fam, cls) * kMaskWords > kWvStage * 192u ? (u32)wv_n_masks(fam, cls) * kMaskWords : kWvStage * 192u;
+}
 
 // MODE 0: count; 1: write.  FAM 0: single-byte decoders; 1: UTF-8; 4: the two-byte family (Big5, Shift_JIS, EUC-KR: 4 wavefronts
 // per block share the 32 KB of pair codes in LDS).
@@ -126,17 +132,19 @@ constexpr int wv_n_masks(int fam) { return fam == 4 ? 9 : fam == 1 ? 6 : 4; }
 constexpr int wv_occ(int mode, int fam) {
     return mode == 0 ? (fam == 4 ? SX_WV_OCC4 : fam == 1 ? SX_WV_OCC1 : SX_WV_OCC0) : (fam == 4 ? SX_WV_OCCW4 : fam == 1 ? SX_WV_OCCW1 : SX_WV_OCCW0);
 }
-template <int MODE, int FAM, int WPB>
+template <int MODE, int FAM, int WPB, int CLS>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ(MODE, FAM)))) void wave_replay_kernel(const WaveParams P) {
-    // FAM 0: valid, accepted, O2, O3; FAM 1: E, A, F, MA, MB, G; FAM 4: E, A, F, MA, MB, G, O2, O3, O4 — 16 bits per lane and tile
-    __shared__ u32 lds_mask_all[WPB][wv_n_masks(FAM)][kWvMaxTiles * 32 + 8];
-    __shared__ u8 lds_lut[256];
+    // FAM 0: valid, accepted, O2, O3 (CLS 1: accepted, >= 0x80); FAM 1: E, A, F, MA, MB, G; FAM 4: E, A, F, MA, MB, G, O2, O3, O4 — 16 bits per lane and tile
+    __shared__ u32 lds_all[WPB][wv_lds_words(FAM, CLS)];
+    __shared__ u8 lds_lut[CLS ? 4 : 256];
     __shared__ u32 lds_pairs[FAM == 4 ? 8192 : 1];
     const u32 lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
-    if (threadIdx.x < 64) ((u32*)lds_lut)[threadIdx.x] = ((const u32*)P.lut)[threadIdx.x];
+    if (!CLS && threadIdx.x < 64) ((u32*)lds_lut)[threadIdx.x] = ((const u32*)P.lut)[threadIdx.x];
     if (FAM == 4) for (u32 i = threadIdx.x; i < 8192; i += 64 * WPB) lds_pairs[i] = P.pairs[i];
     __syncthreads();
-    u32 (*lds_mask)[kWvMaxTiles * 32 + 8] = lds_mask_all[wib];
+    u32* const lds_base = lds_all[wib];
+    auto lds_mask = [&](int k) -> u32* { return lds_base + (u32)k * kMaskWords; };
+    const WvSwar& SW = P.swar;
 
     const u64 v = P.v0 + (u64)blockIdx.x * WPB + wib;
     const u64 own_start = P.g_lo + v * P.nwin;
@@ -196,65 +204,76 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 }
             }
         }
-        // the lane's 16 bytes of tile t (zero where the buffer has none); the next tile's are on their way while this one is classified
-        auto load_tile = [&](int t) -> u32x4 {
-            const long long soff = (long long)tile0 + (long long)t * (long long)kTileBytes + 16ll * lane;
-            const u64 off = soff < 0 ? 0ull : (u64)soff;
+        // The batch's tiles through a buffer descriptor [tile0, the buffer's end rounded up to 16 — as the scan kernels read it): beyond it
+        // the loads give zeros, and what lies between the buffer's end and the next multiple of 16 is masked by `avail`.  Four tiles are in
+        // flight per wavefront (round 3: one, behind per-tile 64-bit bounds arithmetic and a byte-by-byte tail loop); bounds are 32-bit
+        // offsets from tile0.
+        const u64 rem0 = P.len - tile0;                                            // bytes from tile0 to the buffer's end (> 0: a window starts behind tile0)
+        const u32 rem32 = rem0 > (1ull << 30) ? (1u << 30) : (u32)rem0;
+        const u32 span_cap = kWvMaxTiles * kTileBytes + 16u;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(P.data + tile0), 0, (int)wv_uniform(rem32 > span_cap ? span_cap : ((rem32 + 15u) & ~15u)), 0x00020000);
+        const bool full = rem32 >= n_tiles * kTileBytes + 4u;                      // no lane of this batch is near the buffer's end
+        auto issue = [&](int t) -> u32x4 {
             u32x4 x = { 0, 0, 0, 0 };
-            const u32 avail = soff < 0 || off >= P.len ? 0u : (P.len - off >= 16 ? 16u : (u32)(P.len - off));
-            if (avail == 16) x = *(const u32x4*)(P.data + off);
-            else if (avail) {   // the buffer's last bytes: never read beyond them
-                u32 xs[4] = { 0, 0, 0, 0 };
-                for (u32 k = 0; k < avail; k++) xs[k >> 2] |= (u32)P.data[off + k] << (8 * (k & 3));
-                x.x = xs[0]; x.y = xs[1]; x.z = xs[2]; x.w = xs[3];
-            }
+            if (t < (int)n_tiles) x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((u32)t * kTileBytes + 16u * lane), 0, 0);
             return x;
         };
-        u32x4 x_next = load_tile(t_first);
-        u32 prev_w63 = 0;   // the last dword of the tile before (lane 63's x.w): the four bytes in front of lane 0
-        for (int t = t_first; t < (int)n_tiles; t++) {
-            const long long soff = (long long)tile0 + (long long)t * (long long)kTileBytes + 16ll * lane;
-            const u64 off = soff < 0 ? 0ull : (u64)soff;
-            const u32 avail = soff < 0 || off >= P.len ? 0u : (P.len - off >= 16 ? 16u : (u32)(P.len - off));
-            const u32x4 x = x_next;
-            const bool more = t + 1 < (int)n_tiles;
-            if (more) x_next = load_tile(t + 1);
+        u32x4 xa = issue(0), xb = issue(1), xc = issue(2), xd = issue(3);
+        // the four bytes in front of tile0 and behind the batch's last tile (the same address in every lane)
+        u32 edge_back = tile0 >= 4 ? *(const u32*)(P.data + (tile0 - 4)) : 0u;
+        const u32 edge_after = FAM == 0 ? 0u : (u32)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(n_tiles * kTileBytes), 0, 0);
+
+        // one tile: t < 0 = the two-byte family's way back to a token boundary (nothing is stored for those)
+        auto do_tile = [&](int t, u32x4 x, u32 back_edge, u32 ahead_edge) {
+            const int rel = t * (int)kTileBytes + 16 * (int)lane;                  // the lane's first byte, from tile0
+            const bool before = (long long)tile0 + rel < 0;                        // (in front of the buffer: a look-back tile that begins there)
+            const int left = (int)rem32 - rel;
+            const u32 avail = before ? 0u : (left >= 16 ? 16u : (left > 0 ? (u32)left : 0u));
+            if (!full || t < 0) {   // near the buffer's ends: bytes that do not exist are zero
+                const u32 xs[4] = { x.x, x.y, x.z, x.w };
+                u32 ys[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int nb = (int)avail - 4 * k; ys[k] = nb >= 4 ? xs[k] : (nb <= 0 ? 0u : xs[k] & ((1u << (8 * nb)) - 1u)); }
+                x.x = ys[0]; x.y = ys[1]; x.z = ys[2]; x.w = ys[3];
+            }
             const u32 idx = (u32)(t < 0 ? 0 : t) * 64 + lane;
-            if (FAM == 0) {
+            if (FAM == 0 && CLS) {
+                WvMasks16R m;
+                if (SW.n <= 1) m = wv_classify16_single_swar<1>(SW, x.x, x.y, x.z, x.w, avail);
+                else if (SW.n <= 3) m = wv_classify16_single_swar<3>(SW, x.x, x.y, x.z, x.w, avail);
+                else m = wv_classify16_single_swar<6>(SW, x.x, x.y, x.z, x.w, avail);
+                ((uint16_t*)lds_mask(0))[idx] = (uint16_t)m.a;
+                ((uint16_t*)lds_mask(1))[idx] = (uint16_t)m.hi;
+            } else if (FAM == 0) {
                 const WvMasks16 m = wv_classify16_single(lds_lut, x.x, x.y, x.z, x.w, avail);
-                ((uint16_t*)lds_mask[0])[idx] = (uint16_t)m.v;
-                ((uint16_t*)lds_mask[1])[idx] = (uint16_t)m.a;
-                ((uint16_t*)lds_mask[2])[idx] = (uint16_t)m.o2;
-                ((uint16_t*)lds_mask[3])[idx] = (uint16_t)m.o3;
+                ((uint16_t*)lds_mask(0))[idx] = (uint16_t)m.v;
+                ((uint16_t*)lds_mask(1))[idx] = (uint16_t)m.a;
+                ((uint16_t*)lds_mask(CLS ? 0 : 2))[idx] = (uint16_t)m.o2;
+                ((uint16_t*)lds_mask(CLS ? 0 : 3))[idx] = (uint16_t)m.o3;
             } else {
                 // the four bytes in front of the lane's 16 and the four behind them: the neighbours' registers (one DPP move each); lane 0
-                // of the batch's first tile and lane 63 read them from memory
-                u32 back = wv_from_prev(x.w, prev_w63);
-                if (lane == 0 && t == t_first) back = off >= 4 && avail ? *(const u32*)(P.data + off - 4) : 0u;
-                if (!(off >= 4 && avail)) back = 0;
-                u32 n_ahead = 0;
-                if (avail == 16 && off + 16 < P.len) n_ahead = P.len - (off + 16) >= 4 ? 4u : (u32)(P.len - (off + 16));
-                u32 ahead = __builtin_amdgcn_update_dpp(0u, x.x, 0x130, 0xF, 0xF, false);   // lane i <- lane i + 1
-                if (lane == 63) {   // (not the next tile's first dword: waiting for it here would undo the prefetch)
-                    ahead = 0;
-                    if (n_ahead == 4) ahead = *(const u32*)(P.data + off + 16);
-                    else for (u32 k = 0; k < n_ahead; k++) ahead |= (u32)P.data[off + 16 + k] << (8 * k);
-                }
-                if (n_ahead == 0) ahead = 0;
-                prev_w63 = (u32)__builtin_amdgcn_readlane(x.w, 63);
+                // and lane 63 get the tile's edges
+                const bool has_back = !before && (long long)tile0 + rel >= 4 && avail;
+                u32 back = wv_from_prev(x.w, back_edge);
+                if (!has_back) back = 0;
+                const int left2 = left - 16;
+                const u32 n_ahead = avail == 16 ? (left2 >= 4 ? 4u : (left2 > 0 ? (u32)left2 : 0u)) : 0u;
+                u32 ahead = __builtin_amdgcn_update_dpp(ahead_edge, x.x, 0x130, 0xF, 0xF, false);   // lane i <- lane i + 1, lane 63 <- the edge
+                if (n_ahead < 4) ahead = n_ahead ? ahead & ((1u << (8 * n_ahead)) - 1u) : 0u;
                 const u32 ws6[6] = { back, x.x, x.y, x.z, x.w, ahead };
-                const u32 have_lo = off >= 4 ? 0u : 4u, have_hi = 4u + avail + n_ahead;
+                const u32 have_lo = has_back ? 0u : 4u, have_hi = 4u + avail + n_ahead;
                 if (FAM == 1) {
                     u8 b[24];
 #pragma unroll
                     for (int k = 0; k < 24; k++) b[k] = (u8)(ws6[k >> 2] >> (8 * (k & 3)));
                     const WvMasks16U m = wv_classify16_utf8(lds_lut, b, have_lo, have_hi);
-                    ((uint16_t*)lds_mask[0])[idx] = (uint16_t)m.e;
-                    ((uint16_t*)lds_mask[1])[idx] = (uint16_t)m.a;
-                    ((uint16_t*)lds_mask[2])[idx] = (uint16_t)m.f;
-                    ((uint16_t*)lds_mask[3])[idx] = (uint16_t)m.ma;
-                    ((uint16_t*)lds_mask[FAM == 1 ? 4 : 0])[idx] = (uint16_t)m.mb;
-                    ((uint16_t*)lds_mask[FAM == 1 ? 5 : 0])[idx] = (uint16_t)m.g;
+                    ((uint16_t*)lds_mask(0))[idx] = (uint16_t)m.e;
+                    ((uint16_t*)lds_mask(1))[idx] = (uint16_t)m.a;
+                    ((uint16_t*)lds_mask(2))[idx] = (uint16_t)m.f;
+                    ((uint16_t*)lds_mask(3))[idx] = (uint16_t)m.ma;
+                    ((uint16_t*)lds_mask(FAM == 1 ? 4 : 0))[idx] = (uint16_t)m.mb;
+                    ((uint16_t*)lds_mask(FAM == 1 ? 5 : 0))[idx] = (uint16_t)m.g;
                 } else {
                     // token starts: the lane's trails for both cases (bit arithmetic, sx_wave_core.hpp wv_dbcs_trails), the cases
                     // composed along the wavefront
@@ -262,62 +281,92 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                     const u32 tr0 = wv_dbcs_trails(pc.lr, 0u), tr1 = wv_dbcs_trails(pc.lr, 1u);
                     const u32 o0 = tr0 >> 16, o1 = tr1 >> 16;
                     u32 fn = o0 | (o1 << 1);                       // bit c: how far the lane's last token hangs over if its first byte is at c
-                    const bool at_zero = soff == 0;                // the buffer's byte 0: the token pending on entry decides
+                    const bool at_zero = tile0 == 0 && rel == 0;   // the buffer's byte 0: the token pending on entry decides
                     if (at_zero) { const u32 o = P.entry_skip ? o1 : o0; fn = o | (o << 1); }
+                    u32 out_here;
+                    if (!__ballot(o0 != o1 && !at_zero)) out_here = fn & 1u;   // every lane holds a byte outside the lead range (binary data: always): what it hands on does not depend on what it gets
+                    else {
 #pragma unroll
-                    for (u32 d = 1; d < 64; d <<= 1) {             // inclusive composition: fn_i o ... o fn_0
-                        const u32 g = wv_shfl(fn, lane >= d ? lane - d : lane);
-                        const u32 r = ((fn >> (g & 1u)) & 1u) | (((fn >> ((g >> 1) & 1u)) & 1u) << 1);
-                        if (lane >= d) fn = r;
+                        for (u32 d = 1; d < 64; d <<= 1) {         // inclusive composition: fn_i o ... o fn_0
+                            const u32 g = wv_shfl(fn, lane >= d ? lane - d : lane);
+                            const u32 r = ((fn >> (g & 1u)) & 1u) | (((fn >> ((g >> 1) & 1u)) & 1u) << 1);
+                            if (lane >= d) fn = r;
+                        }
+                        out_here = (fn >> dbcs_cov) & 1u;
                     }
-                    const u32 out_here = (fn >> dbcs_cov) & 1u;
                     u32 cov_in = wv_from_prev(out_here, dbcs_cov);
                     if (at_zero) cov_in = P.entry_skip ? 1u : 0u;
                     dbcs_cov = (u32)__builtin_amdgcn_readlane(out_here, 63);
                     if ((long long)tile0 + (long long)(t + 1) * (long long)kTileBytes == (long long)next_t0) { cov_next = dbcs_cov; have_next = true; }
                     if (t >= 0) {
-                        const WvMasks16D m = wv_classify16_dbcs_bits(lds_pairs, ws6, pc, cov_in ? tr1 : tr0, cov_in, off > 0, avail + n_ahead);
-                        ((uint16_t*)lds_mask[0])[idx] = (uint16_t)m.e;
-                        ((uint16_t*)lds_mask[1])[idx] = (uint16_t)m.a;
-                        ((uint16_t*)lds_mask[2])[idx] = (uint16_t)m.f;
-                        ((uint16_t*)lds_mask[3])[idx] = (uint16_t)m.ma;
-                        ((uint16_t*)lds_mask[FAM == 4 ? 4 : 0])[idx] = (uint16_t)m.mb;
-                        ((uint16_t*)lds_mask[FAM == 4 ? 5 : 0])[idx] = (uint16_t)m.g;
-                        ((uint16_t*)lds_mask[FAM == 4 ? 6 : 0])[idx] = (uint16_t)m.o2;
-                        ((uint16_t*)lds_mask[FAM == 4 ? 7 : 0])[idx] = (uint16_t)m.o3;
-                        ((uint16_t*)lds_mask[FAM == 4 ? 8 : 0])[idx] = (uint16_t)m.o4;
+                        const WvMasks16D m = wv_classify16_dbcs_bits(lds_pairs, ws6, pc, cov_in ? tr1 : tr0, cov_in, (long long)tile0 + rel > 0, avail + n_ahead);
+                        ((uint16_t*)lds_mask(0))[idx] = (uint16_t)m.e;
+                        ((uint16_t*)lds_mask(1))[idx] = (uint16_t)m.a;
+                        ((uint16_t*)lds_mask(2))[idx] = (uint16_t)m.f;
+                        ((uint16_t*)lds_mask(3))[idx] = (uint16_t)m.ma;
+                        ((uint16_t*)lds_mask(FAM == 4 ? 4 : 0))[idx] = (uint16_t)m.mb;
+                        ((uint16_t*)lds_mask(FAM == 4 ? 5 : 0))[idx] = (uint16_t)m.g;
+                        ((uint16_t*)lds_mask(FAM == 4 ? 6 : 0))[idx] = (uint16_t)m.o2;
+                        ((uint16_t*)lds_mask(FAM == 4 ? 7 : 0))[idx] = (uint16_t)m.o3;
+                        ((uint16_t*)lds_mask(FAM == 4 ? 8 : 0))[idx] = (uint16_t)m.o4;
                     }
                 }
             }
+        };
+        if (FAM == 4 && t_first < 0) {   // the way back to a token boundary: plain loads, one tile after the other (a wavefront's first batch)
+            u32 eb = 0;
+            {
+                const long long first = (long long)tile0 + (long long)t_first * (long long)kTileBytes;
+                if (first >= 4) eb = *(const u32*)(P.data + (first - 4));
+            }
+            for (int t = t_first; t < 0; t++) {
+                const long long soff = (long long)tile0 + (long long)t * (long long)kTileBytes + 16ll * lane;
+                u32x4 x = { 0, 0, 0, 0 };
+                if (soff >= 0) x = *(const u32x4*)(P.data + soff);
+                // (the dword behind the tile's last lane: the next look-back tile's first, or tile 0's)
+                const long long nxt = (long long)tile0 + (long long)(t + 1) * (long long)kTileBytes;
+                const u32 ea = nxt >= 0 && (u64)nxt + 4 <= P.len ? *(const u32*)(P.data + nxt) : 0u;
+                do_tile(t, x, eb, ea);
+                eb = (u32)__builtin_amdgcn_readlane(x.w, 63);
+            }
+            edge_back = eb;
+        }
+        for (int t = 0; t < (int)n_tiles; t++) {
+            const u32x4 x = xa;
+            xa = xb; xb = xc; xc = xd; xd = issue(t + 4);
+            const u32 ea = t + 1 < (int)n_tiles ? (u32)__builtin_amdgcn_readlane(xa.x, 0) : edge_after;
+            do_tile(t, x, edge_back, ea);
+            edge_back = (u32)__builtin_amdgcn_readlane(x.w, 63);
         }
         wave_lds_sync<WPB>();
         if (FAM == 4) { dbcs_valid = have_next; if (have_next) dbcs_cov = cov_next; }   // (else the next batch walks back again)
 
 #if defined(SX_WV_EXP) && SX_WV_EXP == 1   // experiments (tools/build_variant.sh): what the classification alone costs
-        { u32 acc = 0; for (int k = 0; k < wv_n_masks(FAM); k++) acc ^= lds_mask[k][lane]; tot_f += acc & 1u; continue; }
+        { u32 acc = 0; for (int k = 0; k < wv_n_masks(FAM, CLS); k++) acc ^= lds_mask(k)[lane]; tot_f += acc & 1u; continue; }
 #endif
         // ---- 2. lane = window
         WvWin w;
         {
             const u32 o = active ? (u32)(ws - tile0) : 0u;
             const u32 n = active ? wn : 0u;
-            if (FAM == 0)
-                w = wv_win_single(wv_extract(lds_mask[0], o, n), wv_extract(lds_mask[1], o, n), wv_extract(lds_mask[2], o, n),
-                                  wv_extract(lds_mask[3], o, n), n, P.n_min);
+            if (FAM == 0 && CLS) w = wv_win_single_swar(wv_extract(lds_mask(0), o, n), wv_extract(lds_mask(1), o, n), SW.hi_len, n, P.n_min);
+            else if (FAM == 0)
+                w = wv_win_single(wv_extract(lds_mask(0), o, n), wv_extract(lds_mask(1), o, n), wv_extract(lds_mask(CLS ? 0 : 2), o, n),
+                                  wv_extract(lds_mask(CLS ? 0 : 3), o, n), n, P.n_min);
             else if (FAM == 4) {
                 // (the byte in front of the window: one bit of three masks)
                 const u32 ob = o >= 1 ? o - 1 : 0u;
-                const u32 eb = o >= 1 ? (lds_mask[0][ob >> 5] >> (ob & 31u)) & 1u : 1u, mab = o >= 1 ? (lds_mask[3][ob >> 5] >> (ob & 31u)) & 1u : 0u;
-                const u32 fb1 = o >= 1 ? (lds_mask[2][ob >> 5] >> (ob & 31u)) & 1u : 0u;
-                w = wv_win_dbcs(wv_extract(lds_mask[0], o, n), wv_extract(lds_mask[1], o, n), wv_extract(lds_mask[2], o, n),
-                                wv_extract(lds_mask[FAM == 4 ? 5 : 0], o, n), wv_extract(lds_mask[3], o, n), wv_extract(lds_mask[FAM == 4 ? 4 : 0], o, n),
-                                wv_extract(lds_mask[FAM == 4 ? 6 : 0], o, n), wv_extract(lds_mask[FAM == 4 ? 7 : 0], o, n),
-                                wv_extract(lds_mask[FAM == 4 ? 8 : 0], o, n), (eb | mab) != 0, fb1 != 0, ws > 0, ws % kWvSlice == 0, n, P.n_min);
+                const u32 eb = o >= 1 ? (lds_mask(0)[ob >> 5] >> (ob & 31u)) & 1u : 1u, mab = o >= 1 ? (lds_mask(3)[ob >> 5] >> (ob & 31u)) & 1u : 0u;
+                const u32 fb1 = o >= 1 ? (lds_mask(2)[ob >> 5] >> (ob & 31u)) & 1u : 0u;
+                w = wv_win_dbcs(wv_extract(lds_mask(0), o, n), wv_extract(lds_mask(1), o, n), wv_extract(lds_mask(2), o, n),
+                                wv_extract(lds_mask(FAM == 4 ? 5 : 0), o, n), wv_extract(lds_mask(3), o, n), wv_extract(lds_mask(FAM == 4 ? 4 : 0), o, n),
+                                wv_extract(lds_mask(FAM == 4 ? 6 : 0), o, n), wv_extract(lds_mask(FAM == 4 ? 7 : 0), o, n),
+                                wv_extract(lds_mask(FAM == 4 ? 8 : 0), o, n), (eb | mab) != 0, fb1 != 0, ws > 0, ws % kWvSlice == 0, n, P.n_min);
             } else {
-                const u32 fb = o >= 3 ? (u32)wv_extract(lds_mask[2], o - 3, 3).lo : 0u;
-                w = wv_win_utf8(wv_extract(lds_mask[0], o, n), wv_extract(lds_mask[1], o, n), wv_extract(lds_mask[2], o, n),
-                                wv_extract(lds_mask[FAM == 1 ? 5 : 0], o, n), wv_extract(lds_mask[3], o, n),
-                                wv_extract(lds_mask[FAM == 1 ? 4 : 0], o, n), fb, ws % kWvSlice == 0, n, P.n_min);
+                const u32 fb = o >= 3 ? (u32)wv_extract(lds_mask(2), o - 3, 3).lo : 0u;
+                w = wv_win_utf8(wv_extract(lds_mask(0), o, n), wv_extract(lds_mask(1), o, n), wv_extract(lds_mask(2), o, n),
+                                wv_extract(lds_mask(FAM == 1 ? 5 : 0), o, n), wv_extract(lds_mask(3), o, n),
+                                wv_extract(lds_mask(FAM == 1 ? 4 : 0), o, n), fb, ws % kWvSlice == 0, n, P.n_min);
             }
         }
 
@@ -325,19 +374,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         // (the exchange starts from every window's guess of what it hands on — wv_exit_guess: exact unless the window's last stretch is
         // the text-start stretch of its call and something is carried into it —, not from "nothing carried": one round, not two or three)
         constexpr int KIND = FAM == 0 ? 0 : FAM == 1 ? 1 : 2;
-        u32 out = active ? wv_exit_guess<KIND>(WP, w) : 0u;
+        const WvTail tail = active ? wv_tail<KIND>(WP, w) : WvTail{ 128u, 0u };   // (the window's last stretch: looked at once, used by every replay of it)
+        u32 out = tail.state;
         u32 in = wv_from_prev(out, carry);
         const bool injected = g == P.g_lo;   // the host's exact state
         if (injected) in = P.inject;
         u32 nf = 0, nb = 0;
         bool todo = true;
 #if defined(SX_WV_EXP) && SX_WV_EXP == 2   // ... + the windows' masks out of LDS and the guess
-        { tot_f += (out ^ in ^ (u32)w.LS.lo ^ (u32)w.O3.hi ^ (u32)w.CS.hi) & 1u; continue; }
+        { tot_f += (out ^ in ^ tail.a ^ (u32)w.LS.lo ^ (u32)w.O3.hi ^ (u32)w.CS.hi) & 1u; continue; }
 #endif
         // (MODE 0: the findings' descriptors are staged where the batch's masks lay — every lane holds its window in registers now; the
         // LDS traffic of one wavefront is in order)
-        u32* const stage = &lds_mask[0][0];
-        static_assert(kWvStage * 192u <= (u32)wv_n_masks(FAM) * (kWvMaxTiles * 32 + 8), "the staged descriptors fit where the masks lay");
+        u32* const stage = lds_base;
         for (;;) {
             if (todo && active) {
                 WvState st = wv_unpack(in);
@@ -348,8 +397,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 ce.stage = stage; ce.lane = lane;
 #endif
                 ce.widx = (u32)(g - own_start);
-                if (MODE == 0) { wv_window<KIND>(WP, w, st, ce); nf = ce.nf; nb = ce.nb; }
-                else { WvCountEmit<0> cc; wv_window<KIND>(WP, w, st, cc); nf = cc.nf; nb = cc.nb; }
+                if (MODE == 0) { wv_window<KIND>(WP, w, st, ce, tail); nf = ce.nf; nb = ce.nb; }
+                else { WvCountEmit<0> cc; wv_window<KIND>(WP, w, st, cc, tail); nf = cc.nf; nb = cc.nb; }
                 out = wv_pack(st);
             } else if (!active) out = in;
             u32 pin = wv_from_prev(out, carry);
@@ -374,7 +423,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             const u64 fo = fbase + tot_f + (excl >> 18), ao = abase + tot_b + (excl & 0x3FFFFu);
             WriteEmit<FAM> we_{ &P, P.findings + fo, P.arena + ao, ao, ws };
             WvState st = wv_unpack(in);
-            wv_window<KIND>(WP, w, st, we_);
+            wv_window<KIND>(WP, w, st, we_, tail);
         }
 #if defined(SX_WV_EXP) && SX_WV_EXP >= 3
         if (false) {
@@ -394,7 +443,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             } else {
                 WvDescEmit de{ slot, room, ab, (u32)(g - own_start) };
                 WvState st = wv_unpack(in);
-                wv_window<KIND>(WP, w, st, de);
+                wv_window<KIND>(WP, w, st, de, tail);
             }
         }
         tot_f += bt >> 18; tot_b += bt & 0x3FFFFu;
@@ -472,9 +521,10 @@ hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint
     WaveParams Q = P;
     Q.v0 = v0; Q.v1 = v1;
     const unsigned dyn = getenv("SX_WAVE_DYN_LDS") ? (unsigned)atoi(getenv("SX_WAVE_DYN_LDS")) : 0u;   // experiments: fewer wavefronts per CU
-    if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
-    else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<0, 1, 1>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
-    else hipLaunchKernelGGL((wave_replay_kernel<0, 0, 1>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
+    if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 0>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
+    else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<0, 1, 1, 0>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
+    else if (P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 0, 1, 1>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
+    else hipLaunchKernelGGL((wave_replay_kernel<0, 0, 1, 0>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
     void* tmp = (void*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
     size_t tmp_bytes = scratch_bytes - (size_t)((uint8_t*)tmp - (uint8_t*)scratch);
     auto itf = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), U32ToU64{ P.wave_nf + v0 });
@@ -497,9 +547,10 @@ hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipS
     WaveParams Q = P;
     Q.v0 = v0; Q.v1 = v1;
     const unsigned dyn = getenv("SX_WAVE_DYN_LDS") ? (unsigned)atoi(getenv("SX_WAVE_DYN_LDS")) : 0u;
-    if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
-    else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<1, 1, 1>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
-    else hipLaunchKernelGGL((wave_replay_kernel<1, 0, 1>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
+    if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4, 0>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
+    else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<1, 1, 1, 0>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
+    else if (P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<1, 0, 1, 1>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
+    else hipLaunchKernelGGL((wave_replay_kernel<1, 0, 1, 0>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
     return hipGetLastError();
 }
 

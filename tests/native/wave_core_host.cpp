@@ -70,6 +70,7 @@ struct RecEmit {
     void operator()(u32 din, u32 prec, bool completes, i32 src_rel, u32 src_len, u32 out_len) { v.push_back(E{ din, prec, completes, src_rel, src_len, out_len }); }
 };
 int g_driver_mismatch = 0;
+unsigned long long g_rounds_total = 0, g_batches_total = 0, g_redo_lanes = 0;
 template <int KIND>
 bool drivers_agree(const WvParams& WP, const WvWin& w, u32 in) {
     RecEmit a, b;
@@ -139,6 +140,15 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                 const u32 avail = soff < 0 || off >= P.len ? 0u : (P.len - off >= 16 ? 16u : (u32)(P.len - off));
                 for (u32 k = 0; k < avail; k++) xs[k >> 2] |= (u32)P.data[off + k] << (8 * (k & 3));
                 const u32 idx = (u32)(t < 0 ? 0 : t) * 64 + l;
+                if (P.family == 0 && P.swar.cls) {   // as the kernel: classes from ranges — and they must be the table's
+                    const WvMasks16R r = wv_classify16_single_swar(P.swar, xs[0], xs[1], xs[2], xs[3], avail);
+                    const WvMasks16 m = wv_classify16_single(P.lut, xs[0], xs[1], xs[2], xs[3], avail);
+                    const u32 keep = avail >= 16 ? 0xFFFFu : ((1u << avail) - 1u);
+                    if (m.v != keep || m.a != r.a || (m.o2 & m.a) != (P.swar.hi_len == 2 ? r.a & r.hi : 0u) || (m.o3 & m.a) != (P.swar.hi_len == 3 ? r.a & r.hi : 0u)) return false;
+                    ((uint16_t*)lds[0].data())[idx] = (uint16_t)r.a;
+                    ((uint16_t*)lds[1].data())[idx] = (uint16_t)r.hi;
+                    continue;
+                }
                 if (P.family == 0) {
                     const WvMasks16 m = wv_classify16_single(P.lut, xs[0], xs[1], xs[2], xs[3], avail);
                     ((uint16_t*)lds[0].data())[idx] = (uint16_t)m.v;
@@ -195,7 +205,8 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
         WvWin w[64];
         for (u32 l = 0; l < 64; l++) {
             const u32 o = active[l] ? (u32)(ws[l] - tile0) : 0u, n = active[l] ? wn[l] : 0u;
-            if (P.family == 0)
+            if (P.family == 0 && P.swar.cls) w[l] = wv_win_single_swar(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), P.swar.hi_len, n, P.n_min);
+            else if (P.family == 0)
                 w[l] = wv_win_single(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[3], o, n), n, P.n_min);
             else if (P.family == 4) {
                 const u32 eb = o >= 1 ? (u32)wv_extract(lds[0], o - 1, 1).lo : 1u, mab = o >= 1 ? (u32)wv_extract(lds[3], o - 1, 1).lo : 0u;
@@ -242,12 +253,14 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
             for (u32 l = 0; l < 64; l++) {
                 if (injected[l]) pin[l] = P.inject;
                 todo[l] = active[l] && pin[l] != in[l];
+                if (MODE == 0 && todo[l]) g_redo_lanes++;
                 in[l] = pin[l];
                 any = any || todo[l];
             }
             if (!any) break;
         }
         if (rounds > *rounds_max) *rounds_max = rounds;
+        if (MODE == 0) { g_rounds_total += rounds; g_batches_total++; }
         if (MODE == 0)
             for (u32 l = 0; l < 64; l++)
                 if (active[l] && !(P.family == 0 ? drivers_agree<0>(WP, w[l], in[l]) : P.family == 1 ? drivers_agree<1>(WP, w[l], in[l]) : drivers_agree<2>(WP, w[l], in[l]))) {
@@ -307,13 +320,14 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
                            uint64_t g_lo, uint32_t inject, uint32_t nwin, const uint8_t* lut, const uint16_t* table, int mission_id,
                            int file_id, sx_finding* fout, uint64_t fcap, uint8_t* aout, uint64_t acap, uint64_t* nf, uint64_t* nb,
                            uint32_t* final_state, uint64_t* bad_waves, int skip_idle, uint32_t* rounds_max, uint32_t family,
-                           const uint32_t* pairs, uint32_t encoding, uint32_t entry_skip) {
+                           const uint32_t* pairs, uint32_t encoding, uint32_t entry_skip, const uint32_t* swar25) {
     WaveParams P;
     memset(&P, 0, sizeof P);
     P.data = data; P.len = len; P.consumed0 = consumed0; P.slice_base = slice_base; P.W = W; P.wps = wv_wps(W); P.q = q; P.n_min = n_min;
     P.v0 = 0; P.v1 = ~0ull;
     P.g_lo = g_lo; P.g_hi = wv_window_count(len, W); P.nwin = nwin; P.inject = inject; P.mission_id = mission_id; P.file_id = file_id;
     P.lut = lut; P.table = table; P.family = family; P.pairs = pairs; P.encoding = encoding; P.entry_skip = entry_skip;
+    if (swar25) memcpy(&P.swar, swar25, sizeof P.swar);
     *nf = *nb = 0; *bad_waves = 0; *final_state = inject; *rounds_max = 0;
     if (P.g_hi <= P.g_lo) return 0;
     const u64 n_waves = (P.g_hi - P.g_lo + nwin - 1) / nwin;
@@ -361,3 +375,5 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
 }
 
 extern "C" uint32_t sxw_pack_state(uint32_t lc, uint32_t lb, uint32_t lback, uint32_t cut) { return wv_pack(WvState{ lc, lb, lback, cut }); }
+
+extern "C" void sxw_round_stats(unsigned long long* out) { out[0] = g_rounds_total; out[1] = g_batches_total; out[2] = g_redo_lanes; g_rounds_total = g_batches_total = g_redo_lanes = 0; }

@@ -50,7 +50,10 @@ def test_wave_path_equals_the_oracle(wave_forced, mi):
                 os.environ["SX_WAVE_BATCHES"] = batches
             else:
                 os.environ.pop("SX_WAVE_BATCHES", None)
+            if batches == "3":
+                os.environ["SX_WAVE_LUT"] = "1"   # the class table also where the kernels would classify by ranges
             got = run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk)
+            os.environ.pop("SX_WAVE_LUT", None)
             assert got == want, (name, chunk, batches)
         if len(data) >= 8192:
             assert wave_windows_of_a_scan(ms, data) > 0, name   # the wave kernels did run

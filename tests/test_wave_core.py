@@ -32,7 +32,7 @@ def load_wave():
     L.sxw_emulate.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
                               C.c_uint32, C.c_char_p, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.POINTER(sx.Finding), C.c_uint64,
                               C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
-                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
+                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.sxw_pack_state.restype = C.c_uint32
     L.sxw_pack_state.argtypes = [C.c_uint32] * 4
     return L
@@ -54,6 +54,17 @@ def wave_classes(m):
     return (bytes(out), r - 1) if r >= 1 else None   # (class table, family: 0 single byte, 1 UTF-8, 4 the two-byte family)
 
 
+def wave_swar(m):
+    """the Mission's classes as SWAR ranges (csrc/sx_device.hpp WvSwar, 25 words) if the product classifies it that way, else None"""
+    L = sx.lib()
+    L.sx_wave_swar.argtypes, L.sx_wave_swar.restype = [C.POINTER(sx.Mission), C.POINTER(C.c_uint32)], C.c_int
+    out = (C.c_uint32 * 25)()
+    cm = sx.Mission.from_dict(dict(m, mission_id=m.get("mission_id", 0)))
+    r = L.sx_wave_swar(C.byref(cm), out)
+    assert r >= 0
+    return out if r == 1 else None
+
+
 def wave_pairs(m):
     L = sx.lib()
     L.sx_wave_pair_codes.argtypes, L.sx_wave_pair_codes.restype = [C.POINTER(sx.Mission), C.POINTER(C.c_uint32)], C.c_void_p
@@ -65,7 +76,7 @@ def wave_pairs(m):
 PREC = {0: "Before", 1: "Exact", 2: "After"}
 
 
-def emulate(L, m, data, nwin=508, skip_idle=1, g_lo=0, inject=0, consumed0=None):
+def emulate(L, m, data, nwin=508, skip_idle=1, g_lo=0, inject=0, consumed0=None, swar=True):
     lut, family = wave_classes(m)
     t = sx.decoder_table(m["encoding"])
     table = t[0] if t else None
@@ -78,7 +89,8 @@ def emulate(L, m, data, nwin=508, skip_idle=1, g_lo=0, inject=0, consumed0=None)
     fin, rounds = C.c_uint32(), C.c_uint32()
     rcode = L.sxw_emulate(data, len(data), m["counter_offset"] if consumed0 is None else consumed0, 0, 2 * q, q, m["chars_min_nb"], g_lo,
                           inject, nwin, lut, table, 0, 1, fout, cap_f, aout, cap_a, C.byref(nf), C.byref(nb), C.byref(fin), C.byref(bad),
-                          skip_idle, C.byref(rounds), family, wave_pairs(m) if family == 4 else None, m["encoding"], 0)
+                          skip_idle, C.byref(rounds), family, wave_pairs(m) if family == 4 else None, m["encoding"], 0,
+                          wave_swar(m) if swar else None)
     assert rcode == 0, rcode
     arena = bytes(aout[:nb.value])
     got = []
@@ -201,9 +213,22 @@ def test_emulated_wave_pipeline_equals_the_oracle(wave, mi):
     for name, data in inputs(rng):
         want = oracle_findings([dict(m, mission_id=0)], data)
         for nwin, skip in ((508, 1), (60, 0), (7, 1), (123, 1)):
-            got, info = emulate(wave, m, data, nwin=nwin, skip_idle=skip)
+            got, info = emulate(wave, m, data, nwin=nwin, skip_idle=skip, swar=nwin != 60)   # (60: the class table also where ranges would do)
             assert info["bad"] == 0, (name, nwin, info)
             assert got == want, (name, nwin, skip, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
+
+
+def test_which_missions_classify_by_ranges():
+    """every byte a character, the accepted ones <= 6 ranges, the accepted ones >= 0x80 of one UTF-8 length: ranges; else the table"""
+    yes = [dict(encodings=["ascii"], chars_min="4"), dict(encodings=["koi8-r"], chars_min="10", unicode_block_filter="Cyrillic"),
+           dict(encodings=["x-user-defined"], chars_min="4", unicode_block_filter="All"), dict(encodings=["ibm866"], chars_min="7", ascii_filter="None", unicode_block_filter="Cyrillic")]
+    no = [dict(encodings=["windows-1253"], chars_min="2", unicode_block_filter="All"),   # bytes without a character
+          dict(encodings=["windows-1252"], chars_min="4", unicode_block_filter="All"),   # 2- and 3-byte UTF-8 forms among the accepted
+          dict(encodings=["utf-8"], chars_min="4")]
+    for kw in yes:
+        assert wave_swar(rc.missions(**kw)[0]) is not None, kw
+    for kw in no:
+        assert wave_swar(rc.missions(**kw)[0]) is None, kw
 
 
 def test_missions_the_wave_path_does_not_cover():

@@ -27,7 +27,8 @@ SWITCH_SETS = [{}, {}, {}, {"SX_NO_REPLAY_CACHE": "1"}, {"SX_HOST_STITCH": "1"},
                {"SX_WAVE_REPLAY": "1", "SX_DEFER_MIN_BYTES": "1"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_FAIL": "1"}, {"SX_WAVE_REPLAY": "0"},
                {"SX_WAVE_REPLAY": "1", "SX_WAVE_DESC": "0"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_DESC_CAP": "7"},
                {"SX_WAVE_REPLAY": "1", "SX_WAVE_THREADS": "0"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_THREADS": "0", "SX_DEFER_MIN_BYTES": "1"},
-               {"SX_WAVE_REPLAY": "1", "SX_WAVE_DESC_CAP": "40", "SX_WAVE_SLABS": "4"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_DESC": "0", "SX_WAVE_BATCHES": "2"}]
+               {"SX_WAVE_REPLAY": "1", "SX_WAVE_DESC_CAP": "40", "SX_WAVE_SLABS": "4"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_DESC": "0", "SX_WAVE_BATCHES": "2"},
+               {"SX_WAVE_REPLAY": "1", "SX_WAVE_LUT": "1"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_LUT": "1", "SX_WAVE_BATCHES": "1"}]
 ALL_SWITCHES = sorted({k for s in SWITCH_SETS for k in s})
 
 

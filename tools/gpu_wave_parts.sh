@@ -4,11 +4,22 @@
 # kernel's duration in a kernel trace is read.  tools/gpu_wave_parts.sh "ENC[,,,UBF]" [GiB] [n]
 enc=${1:-ascii}; gib=${2:-4}; export EXP_N=${3:-10}
 repo=$(pwd); export TMPDIR=/tmp
+line="$enc n=$EXP_N ${gib}GiB, us per launch:"
 for v in 0 1 2 3; do
   lib=""; [ $v != 0 ] && lib=$repo/build_exp/wvexp$v/libstringsext_amd.so
+  [ $v != 0 ] && [ ! -f "$lib" ] && continue
   rm -rf /tmp/wvp_$v
   (cd /tmp && SX_LIB=$lib timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/wvp_$v -o p -- python $repo/tools/gpu_wave_exp.py "$enc" $gib > /tmp/wvp_$v.log 2>&1)
   f=$(find /tmp/wvp_$v -name '*kernel_stats.csv' | head -1)
-  echo "variant $v: $(tail -1 /tmp/wvp_$v.log | cut -c1-160)"
-  [ -n "$f" ] && grep "wave_replay_kernel<0\|wave_emit" "$f" | awk -F, '{print "    " $1 " calls " $2 " avg_ns " $4 " min " $6}'
+  [ -n "$f" ] && line="$line v$v $(python3 - "$f" <<'PY'
+import csv, sys
+out = []
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Name"]
+    if "wave_replay_kernel<0" in n: out.append("count %.0f" % (float(r["AverageNs"]) / 1e3))
+    elif "wave_emit" in n: out.append("emit %.0f" % (float(r["AverageNs"]) / 1e3))
+print(" ".join(out))
+PY
+) |"
 done
+echo "$line"
