@@ -201,6 +201,8 @@ const uint32_t* sx_wave_pair_codes(const sx_mission* mission, uint32_t* out8192)
 /* ... and the same classes as SWAR ranges, if the Mission's can be put that way (csrc/sx_device.hpp WvSwar, 25 words): what the wave
  * kernels classify with then.  Returns 1 and fills out25, 0 if the Mission's classes stay a table, < 0 on error.  (Test harness.) */
 int sx_wave_swar(const sx_mission* mission, uint32_t* out25);
+/* ... two-byte family with sx_wave_swar() == 1: 2 bits per byte pair (bit 0 mapped, bit 1 accepted), index lead | trail << 8, sixteen per word. */
+const uint32_t* sx_wave_pair_codes2(const sx_mission* mission, uint32_t* out4096);
 
 int  sx_abi_version(void);
 

@@ -170,6 +170,15 @@ const uint32_t* sx_wave_pair_codes(const sx_mission* mission, uint32_t* out8192)
     return out8192;
 }
 
+const uint32_t* sx_wave_pair_codes2(const sx_mission* mission, uint32_t* out4096) {
+    if (!mission || !out4096) return nullptr;
+    Mission m;
+    std::string err;
+    if (Mission::from_c(*mission, false, &m, &err) != SX_OK || m.wave_pairs2.size() != 4096) return nullptr;
+    memcpy(out4096, m.wave_pairs2.data(), 4096 * 4);
+    return out4096;
+}
+
 int sx_wave_swar(const sx_mission* mission, uint32_t* out25) {
     if (!mission || !out25) return SX_E_INVALID;
     Mission m;
@@ -293,6 +302,7 @@ void sx_destroy(sx_ctx* ctx) {
             if (d.d_pair_lut) (void)hipFree(d.d_pair_lut);
             if (d.d_wave_lut) (void)hipFree(d.d_wave_lut);
             if (d.d_wave_pairs) (void)hipFree(d.d_wave_pairs);
+            if (d.d_wave_pairs2) (void)hipFree(d.d_wave_pairs2);
             for (void* q : d.d_rp) if (q) (void)hipFree(q);
             if (d.h_runs) (void)hipHostFree(d.h_runs);
             if (d.ev_runs) (void)hipEventDestroy(d.ev_runs);

@@ -108,6 +108,7 @@ struct MissionDev {
     uint16_t* d_table = nullptr;                        // decoder table: single byte (128 entries) or the Big5 / EUC-JP blob
     uint32_t* d_pair_lut = nullptr;                     // Big5 / EUC-JP: Mission::pair_lut for the scan kernel
     uint32_t* d_wave_pairs = nullptr;                   // ... two-byte family: Mission::wave_pairs
+    uint32_t* d_wave_pairs2 = nullptr;                  // ... Mission::wave_pairs2
     uint8_t* d_wave_lut = nullptr;                      // wave-cooperative stage B: Mission::wave_lut (uploaded at its first use)
     sx_run* h_runs = nullptr; uint64_t h_runs_cap = 0;   // pinned: runs joined on the device
     hipEvent_t ev_runs = nullptr;                         // their copy (on sx_ctx::d2h_stream) is done

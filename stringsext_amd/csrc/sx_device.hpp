@@ -188,6 +188,7 @@ struct WaveParams {
     uint32_t* desc;
     uint32_t desc_cap;
     WvSwar swar;              // cls != 0: the classes come from ranges, `lut` is not read
+    const uint32_t* pairs2;   // ... two-byte family then: 2 bits per byte pair (bit 0 mapped, bit 1 accepted)
 };
 size_t wave_scratch_bytes(uint64_t n_waves);
 // pass 1 of wavefronts [v0, v1) + exclusive sums from v0 on + verification; totals (device, 4 x u64): findings, string bytes,

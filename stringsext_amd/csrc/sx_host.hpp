@@ -68,6 +68,7 @@ struct Mission {
     uint32_t wave_family = 0;   // 0: single-byte decoders, 1: UTF-8, 4: the two-byte family (Big5, Shift_JIS, EUC-KR)
     std::vector<uint8_t> wave_lut;
     std::vector<uint32_t> wave_pairs;   // two-byte family: 4 bits per byte pair (sx_wave_core.hpp wv_classify16_dbcs)
+    std::vector<uint32_t> wave_pairs2;  // ... and 2 bits per pair (bit 0 mapped, bit 1 accepted) when wave_swar says the lengths need no table
     WvSwar wave_swar{};                 // cls != 0: the same classes as SWAR ranges — what the kernels use then (SX_WAVE_LUT=1: the table anyway)
     // Big5 / EUC-JP, per buffer (set by the schedule before stage A/B of a buffer; the replay only reads it):
     // how many bytes at the buffer start finish the token that was pending on entry — where its token grid begins

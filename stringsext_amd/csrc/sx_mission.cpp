@@ -186,6 +186,34 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
                 }
             }
         }
+        if (two_byte && !enc_is_gb(enc) && m->wave_ok && !p.high1) {
+            // the same classes without the byte table (sx_wave_core.hpp wv_classify16_dbcs_swar): bytes below 0x80 are characters on their
+            // own, the accepted ones at most six ranges; every accepted pair's UTF-8 form has the same length (Cjk, Asian, Kana, Hangul:
+            // three bytes) -> 2 bits per pair do, and O2 / O3 / O4 follow from the masks of the character ends
+            std::vector<std::pair<int, int>> ranges;
+            for (int b = 0; b < 128; b++)
+                if (af[b]) { if (!ranges.empty() && ranges.back().second == b - 1) ranges.back().second = b; else ranges.emplace_back(b, b); }
+            uint32_t len_seen = 0;
+            bool one_len = true;
+            m->wave_pairs2.assign(4096, 0u);
+            for (uint32_t idx = 0; idx < 65536; idx++) {
+                const uint32_t code = (m->wave_pairs[idx >> 3] >> ((idx & 7u) * 4)) & 15u;
+                if (!(code & 1u)) continue;
+                const bool acc = (code & 2u) != 0 && (code >> 2) != 3u;
+                if (acc) { const uint32_t len = 2u + (code >> 2); if (!len_seen) len_seen = len; else if (len_seen != len) one_len = false; }
+                m->wave_pairs2[idx >> 4] |= (1u | (acc ? 2u : 0u)) << ((idx & 15u) * 2);
+            }
+            if (one_len && ranges.size() <= 6) {
+                WvSwar& R = m->wave_swar;
+                R.cls = 1; R.n = (uint32_t)ranges.size(); R.hi_len = len_seen ? len_seen : 3u;
+                for (size_t k = 0; k < 6; k++) {
+                    uint32_t lo = 1, hi = 0;
+                    if (k < ranges.size()) { lo = (uint32_t)ranges[k].first; hi = (uint32_t)ranges[k].second; }
+                    R.c1[k] = (0x80u - lo) * 0x01010101u; R.c2[k] = (0x7Fu - hi) * 0x01010101u; R.hi[k] = 0xFFFFFFFFu;
+                }
+                for (int r = 0; r < 2; r++) { R.lr_c1[r] = p.lr_c1[r]; R.lr_c2[r] = p.lr_c2[r]; }
+            } else m->wave_pairs2.clear();
+        }
         p.gb4 = (enc_is_gb(enc) && m->c.ubf != 0) ? 1u : 0u;   // some character beyond ASCII is accepted: four-byte tokens may be
         p.af_is_range = (!force_generic && af_is_range && !p.high1) ? 1u : 0u;
         const uint16_t* t = decoder_table(enc, nullptr);

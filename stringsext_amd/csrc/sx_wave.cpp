@@ -142,6 +142,10 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             HIP_TRY(ctx, hipMalloc((void**)&d.d_wave_pairs, 8192 * 4));
             HIP_TRY(ctx, hipMemcpy(d.d_wave_pairs, m.wave_pairs.data(), 8192 * 4, hipMemcpyHostToDevice));
         }
+        if (m.wave_family == 4 && m.wave_pairs2.size() == 4096 && !d.d_wave_pairs2) {
+            HIP_TRY(ctx, hipMalloc((void**)&d.d_wave_pairs2, 4096 * 4));
+            HIP_TRY(ctx, hipMemcpy(d.d_wave_pairs2, m.wave_pairs2.data(), 4096 * 4, hipMemcpyHostToDevice));
+        }
         // per wavefront: 4 x u32 (pass 1 out) + 2 x u64 (offsets); + totals per slab
         const uint64_t per = 4 * 4 + 2 * 8;
         int rc = ensure_rp(ctx, d, 1, n_waves * per + 4096); if (rc) return rc;
@@ -166,7 +170,8 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         P.g_lo = g_lo; P.g_hi = g_all; P.nwin = nwin; P.inject = wv_pack(in);
         P.mission_id = m.c.mission_id; P.file_id = job.file_id; P.family = m.wave_family; P.lut = d.d_wave_lut; P.table = d.d_table;
         P.pairs = d.d_wave_pairs; P.encoding = m.c.encoding; P.entry_skip = m.buf_entry_skip;
-        P.swar = m.wave_swar;
+        P.swar = m.wave_swar; P.pairs2 = d.d_wave_pairs2;
+        if (m.wave_family == 4 && !d.d_wave_pairs2) P.swar.cls = 0;
         if (const char* e = getenv("SX_WAVE_LUT")) if (atoi(e)) P.swar.cls = 0;   // tests: the class table also where ranges would do
         P.wave_nf = d_u; P.wave_nb = d_u + n_waves; P.wave_in = d_u + 2 * n_waves; P.wave_out = d_u + 3 * n_waves;
         P.wave_fbase = d_fb; P.wave_abase = d_ab;

@@ -875,6 +875,66 @@ SXD WvMasks16D wv_classify16_dbcs_bits(const PAIRS& pairs, const u32* ws6, const
     return m;
 }
 
+// ---- the two-byte family without the byte table and with 2 bits per pair (round 4; WvSwar::cls == 1: Big5 / EUC-KR Missions whose
+// accepted pairs all have UTF-8 forms of one length — Cjk, Asian, Kana, Hangul).  Byte classes as SWAR: lead range (two ranges of the
+// low seven bits), < 0x80, accepted < 0x80 (the af filter as ranges); a byte below 0x80 is always a character on its own, one above never.
+// Five masks leave the lane (E, A, F, MA, MB) — G and the length masks follow from them where the window is built (wv_win_dbcs_swar).
+struct WvDbcsPreS { u32 lr, asc, a1; };
+template <int K>
+SXD WvDbcsPreS wv_dbcs_classes_swar(const WvSwar& R, const u32* x, u32 avail) {
+    const u32 ex = avail >= 16 ? 0xFFFFu : ((1u << avail) - 1u), kM = 0x80808080u;
+    u32 fl[4], fa[4], fs[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 v = x[k], t = v & 0x7F7F7F7Fu;
+        fl[k] = (((t + R.lr_c1[0]) & ~(t + R.lr_c2[0])) | ((t + R.lr_c1[1]) & ~(t + R.lr_c2[1]))) & v & kM;
+        fs[k] = ~v & kM;
+        fa[k] = wv_swar_accepted<K>(R, v);
+    }
+    WvDbcsPreS c;
+    c.lr = wv_movemask16_b7(fl[0], fl[1], fl[2], fl[3]) & ex;
+    c.asc = wv_movemask16_b7(fs[0], fs[1], fs[2], fs[3]) & ex;
+    c.a1 = wv_movemask16_b7(fa[0], fa[1], fa[2], fa[3]) & ex;
+    return c;
+}
+struct WvMasks16E { u32 e, a, f, ma, mb; };
+// as wv_classify16_dbcs_bits; pairs2: 2 bits per (lead | trail << 8), sixteen per word: bit 0 mapped, bit 1 accepted
+template <class PAIRS>
+SXD WvMasks16E wv_classify16_dbcs_swar(const PAIRS& pairs2, const u32* ws6, const WvDbcsPreS& c, u32 tr, u32 cov_in, bool back_exists, u32 n_exist) {
+    const u32 starts_s = ((~tr & 0xFFFFu) << 1) | cov_in;
+    const u32 lr_s = (c.lr << 1) | cov_in;
+    const u32 ex_s = ((n_exist >= 20 ? 0xFFFFFu : ((1u << n_exist) - 1u)) << 1) | (back_exists ? 1u : 0u);
+    const u32 two = starts_s & lr_s & ex_s & (ex_s >> 1);   // two-byte tokens whose both bytes exist, at their leads
+    const u32 T = two << 1;                                 // ... at their trails
+    u32 Mp = 0, Ac = 0;
+#pragma unroll
+    for (int k = 0; k <= 8; k++) {
+        const u32 has = (two >> (2 * k)) & 3u;
+        if (!has) continue;
+        const u32 odd = has >> 1;
+        const int ie = 2 * k + 3, io = 2 * k + 4;
+        const u32 u_even = (ie & 3) == 3 ? ((ws6[ie >> 2] >> 24) | ((ws6[(ie >> 2) + 1] & 0xFFu) << 8)) : ((ws6[ie >> 2] >> (8 * (ie & 3))) & 0xFFFFu);
+        const u32 u_odd = (ws6[io >> 2 > 5 ? 5 : io >> 2] >> (8 * (io & 3))) & 0xFFFFu;
+        const u32 idx = odd ? u_odd : u_even;
+        const u32 code = (pairs2[idx >> 4] >> ((idx & 15u) * 2)) & 3u;
+        const u32 sh = 2 * k + 1 + odd;
+        Mp |= (code & 1u) << sh; Ac |= (code >> 1) << sh;
+    }
+    const u32 v_s = c.asc << 1, a_s = c.a1 << 1;
+    const u32 acc2 = Ac & Mp;
+    const u32 un = T & ~Mp;                                 // unmapped: a trail below 0x80 is read again as a character of its own
+    const u32 un_a = un & v_s;
+    const u32 one = starts_s & ~lr_s & ex_s;                // tokens of one byte
+    const u32 own = (un_a | one) & v_s;                     // characters of one byte
+    WvMasks16E m;
+    m.f = (((Mp >> 1) | own) >> 1) & 0xFFFFu;
+    m.e = ((Mp | own) >> 1) & 0xFFFFu;
+    m.a = ((acc2 | (own & a_s)) >> 1) & 0xFFFFu;
+    m.ma = (((un & ~v_s) | (one & ~v_s)) >> 1) & 0xFFFFu;
+    m.mb = (un_a >> 1) & 0xFFFFu;
+    return m;
+}
+
 // the window of a two-byte Mission.  back: the E | MA bits and the F bits of the byte right in front of the window.
 SXD WvWin wv_win_dbcs(WvMask E, WvMask A, WvMask F, WvMask G, WvMask MA, WvMask MB, WvMask O2, WvMask O3, WvMask O4,
                       bool back_done, bool back_f, bool has_back, bool slice_start, u32 n, u32 n_min) {
@@ -893,6 +953,18 @@ SXD WvWin wv_win_dbcs(WvMask E, WvMask A, WvMask F, WvMask G, WvMask MA, WvMask 
     w.probe_hb = slice_start ? w.head_back : 0u;
     w.tail_pend = n && !wm_test(E, n - 1) && !wm_test(MA, n - 1) ? 1u : 0u;
     return w;
+}
+
+// ... from the five masks of wv_classify16_dbcs_swar: a pair ends where a char ends that did not begin there; its UTF-8 form has
+// pair_len bytes if it is accepted (the lengths of rejected chars are never asked for), at least two in any case (the slice-start
+// probe's "not ASCII", finding_collection.rs:176); G = the accepted chars' bytes.  (The lead byte of a pair that ends in the NEXT window is
+// not in G here: it is no character of this window.)
+SXD WvWin wv_win_dbcs_swar(WvMask E, WvMask A, WvMask F, WvMask MA, WvMask MB, u32 pair_len, bool back_done, bool back_f, bool has_back,
+                           bool slice_start, u32 n, u32 n_min) {
+    const WvMask PE = wm_andn(E, F), APE = wm_and(A, PE);
+    const WvMask G = wm_or(A, wm_shr(APE, 1));
+    return wv_win_dbcs(E, A, F, G, MA, MB, PE, pair_len >= 3 ? APE : wm_zero(), pair_len >= 4 ? APE : wm_zero(), back_done, back_f, has_back,
+                       slice_start, n, n_min);
 }
 
 // WV_PROBE settled (UTF-8): `slice` = the slice's first bytes (n of them, n <= 32 is enough), `left` = the lb bytes of the
@@ -1044,6 +1116,6 @@ template <class PTR> struct WvStageEmit {
 
 constexpr u32 kWvWarm = 4;         // windows a wavefront replays in front of its own, only for their state
 constexpr u32 kWvBatch = 64;       // windows per batch: one per lane
-constexpr u32 kWvMaxTiles = 10;    // 1 KiB tiles that cover a batch of 64 windows of <= 128 bytes (+ alignment slack)
+constexpr u32 kWvMaxTiles = 9;     // 1 KiB tiles that cover a batch of 64 windows of <= 128 bytes: 8 KiB + the 16..31 bytes in front of it (wv_tile0)
 
 }  // namespace sx

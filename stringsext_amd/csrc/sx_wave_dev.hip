@@ -110,8 +110,8 @@ template <int WPB> SXD void wave_lds_sync() {
 }
 
 // masks a wavefront keeps per batch (16 bits per lane and tile each).  CLS 1: the classes come from ranges (sx_device.hpp WvSwar): a
-// single-byte Mission then stores accepted / >= 0x80 only
-constexpr int wv_n_masks(int fam, int cls) { return fam == 4 ? 9 : fam == 1 ? 6 : cls ? 2 : 4; }
+// single-byte Mission then stores accepted / >= 0x80 only, a two-byte one E, A, F, MA, MB (G and the lengths follow from them)
+constexpr int wv_n_masks(int fam, int cls) { return fam == 4 ? (cls ? 5 : 9) : fam == 1 ? 6 : cls ? 2 : 4; }
 constexpr u32 kMaskWords = kWvMaxTiles * 32 + 8;
 constexpr u32 wv_lds_words(int fam, int cls) {   // ... and the descriptors staged in their place need kWvStage x 3 x 64 words
     return (u32)wv_n_masks(fam, cls) * kMaskWords > kWvStage * 192u ? (u32)wv_n_masks(fam, cls) * kMaskWords : kWvStage * 192u;
@@ -129,18 +129,22 @@ constexpr u32 wv_lds_words(int fam, int cls) {   // ... and the descriptors stag
 #define SX_WV_OCCW1 SX_WV_OCC1
 #define SX_WV_OCCW4 SX_WV_OCC4
 #endif
-constexpr int wv_occ(int mode, int fam) {
+#ifndef SX_WV_OCC4S
+#define SX_WV_OCC4S 4   // ... the two-byte family with SWAR classes and 2-bit pair codes (40 KB of LDS per block of four wavefronts)
+#endif
+constexpr int wv_occ(int mode, int fam, int cls) {
+    if (mode == 0 && fam == 4 && cls) return SX_WV_OCC4S;
     return mode == 0 ? (fam == 4 ? SX_WV_OCC4 : fam == 1 ? SX_WV_OCC1 : SX_WV_OCC0) : (fam == 4 ? SX_WV_OCCW4 : fam == 1 ? SX_WV_OCCW1 : SX_WV_OCCW0);
 }
 template <int MODE, int FAM, int WPB, int CLS>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ(MODE, FAM)))) void wave_replay_kernel(const WaveParams P) {
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ(MODE, FAM, CLS)))) void wave_replay_kernel(const WaveParams P) {
     // FAM 0: valid, accepted, O2, O3 (CLS 1: accepted, >= 0x80); FAM 1: E, A, F, MA, MB, G; FAM 4: E, A, F, MA, MB, G, O2, O3, O4 — 16 bits per lane and tile
     __shared__ u32 lds_all[WPB][wv_lds_words(FAM, CLS)];
     __shared__ u8 lds_lut[CLS ? 4 : 256];
-    __shared__ u32 lds_pairs[FAM == 4 ? 8192 : 1];
+    __shared__ u32 lds_pairs[FAM == 4 ? (CLS ? 4096 : 8192) : 1];
     const u32 lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
     if (!CLS && threadIdx.x < 64) ((u32*)lds_lut)[threadIdx.x] = ((const u32*)P.lut)[threadIdx.x];
-    if (FAM == 4) for (u32 i = threadIdx.x; i < 8192; i += 64 * WPB) lds_pairs[i] = P.pairs[i];
+    if (FAM == 4) for (u32 i = threadIdx.x; i < (CLS ? 4096u : 8192u); i += 64 * WPB) lds_pairs[i] = CLS ? P.pairs2[i] : P.pairs[i];
     __syncthreads();
     u32* const lds_base = lds_all[wib];
     auto lds_mask = [&](int k) -> u32* { return lds_base + (u32)k * kMaskWords; };
@@ -194,7 +198,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 if (!reset) {
                     const u32x4 x = *(const u32x4*)(P.data + o);
                     const u32 xs[4] = { x.x, x.y, x.z, x.w };
-                    for (int k = 0; k < 16; k++) reset = reset || !(lds_lut[(xs[k >> 2] >> (8 * (k & 3))) & 0xFFu] & WVC_LEAD);
+                    if (CLS) reset = wv_dbcs_classes_swar<1>(SW, xs, 16u).lr != 0xFFFFu;
+                    else for (int k = 0; k < 16; k++) reset = reset || !(lds_lut[(xs[k >> 2] >> (8 * (k & 3))) & 0xFFu] & WVC_LEAD);
                 }
                 if (__ballot(reset)) break;
                 if (t_first < -64) {   // 64 KiB of lead-range bytes and no end: a fill.  This wavefront gives up — an entry state no wavefront
@@ -277,8 +282,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 } else {
                     // token starts: the lane's trails for both cases (bit arithmetic, sx_wave_core.hpp wv_dbcs_trails), the cases
                     // composed along the wavefront
-                    const WvDbcsPre pc = wv_dbcs_classes(lds_lut, &ws6[1], avail);
-                    const u32 tr0 = wv_dbcs_trails(pc.lr, 0u), tr1 = wv_dbcs_trails(pc.lr, 1u);
+                    WvDbcsPre pc{};
+                    WvDbcsPreS ps{};
+                    if (CLS) {
+                        if (SW.n <= 1) ps = wv_dbcs_classes_swar<1>(SW, &ws6[1], avail);
+                        else if (SW.n <= 3) ps = wv_dbcs_classes_swar<3>(SW, &ws6[1], avail);
+                        else ps = wv_dbcs_classes_swar<6>(SW, &ws6[1], avail);
+                    } else pc = wv_dbcs_classes(lds_lut, &ws6[1], avail);
+                    const u32 lr16 = CLS ? ps.lr : pc.lr;
+                    const u32 tr0 = wv_dbcs_trails(lr16, 0u), tr1 = wv_dbcs_trails(lr16, 1u);
                     const u32 o0 = tr0 >> 16, o1 = tr1 >> 16;
                     u32 fn = o0 | (o1 << 1);                       // bit c: how far the lane's last token hangs over if its first byte is at c
                     const bool at_zero = tile0 == 0 && rel == 0;   // the buffer's byte 0: the token pending on entry decides
@@ -298,17 +310,24 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                     if (at_zero) cov_in = P.entry_skip ? 1u : 0u;
                     dbcs_cov = (u32)__builtin_amdgcn_readlane(out_here, 63);
                     if ((long long)tile0 + (long long)(t + 1) * (long long)kTileBytes == (long long)next_t0) { cov_next = dbcs_cov; have_next = true; }
-                    if (t >= 0) {
+                    if (t >= 0 && CLS) {
+                        const WvMasks16E m = wv_classify16_dbcs_swar(lds_pairs, ws6, ps, cov_in ? tr1 : tr0, cov_in, (long long)tile0 + rel > 0, avail + n_ahead);
+                        ((uint16_t*)lds_mask(0))[idx] = (uint16_t)m.e;
+                        ((uint16_t*)lds_mask(1))[idx] = (uint16_t)m.a;
+                        ((uint16_t*)lds_mask(2))[idx] = (uint16_t)m.f;
+                        ((uint16_t*)lds_mask(3))[idx] = (uint16_t)m.ma;
+                        ((uint16_t*)lds_mask(FAM == 4 ? 4 : 0))[idx] = (uint16_t)m.mb;
+                    } else if (t >= 0) {
                         const WvMasks16D m = wv_classify16_dbcs_bits(lds_pairs, ws6, pc, cov_in ? tr1 : tr0, cov_in, (long long)tile0 + rel > 0, avail + n_ahead);
                         ((uint16_t*)lds_mask(0))[idx] = (uint16_t)m.e;
                         ((uint16_t*)lds_mask(1))[idx] = (uint16_t)m.a;
                         ((uint16_t*)lds_mask(2))[idx] = (uint16_t)m.f;
                         ((uint16_t*)lds_mask(3))[idx] = (uint16_t)m.ma;
                         ((uint16_t*)lds_mask(FAM == 4 ? 4 : 0))[idx] = (uint16_t)m.mb;
-                        ((uint16_t*)lds_mask(FAM == 4 ? 5 : 0))[idx] = (uint16_t)m.g;
-                        ((uint16_t*)lds_mask(FAM == 4 ? 6 : 0))[idx] = (uint16_t)m.o2;
-                        ((uint16_t*)lds_mask(FAM == 4 ? 7 : 0))[idx] = (uint16_t)m.o3;
-                        ((uint16_t*)lds_mask(FAM == 4 ? 8 : 0))[idx] = (uint16_t)m.o4;
+                        ((uint16_t*)lds_mask(FAM == 4 && !CLS ? 5 : 0))[idx] = (uint16_t)m.g;
+                        ((uint16_t*)lds_mask(FAM == 4 && !CLS ? 6 : 0))[idx] = (uint16_t)m.o2;
+                        ((uint16_t*)lds_mask(FAM == 4 && !CLS ? 7 : 0))[idx] = (uint16_t)m.o3;
+                        ((uint16_t*)lds_mask(FAM == 4 && !CLS ? 8 : 0))[idx] = (uint16_t)m.o4;
                     }
                 }
             }
@@ -358,10 +377,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 const u32 ob = o >= 1 ? o - 1 : 0u;
                 const u32 eb = o >= 1 ? (lds_mask(0)[ob >> 5] >> (ob & 31u)) & 1u : 1u, mab = o >= 1 ? (lds_mask(3)[ob >> 5] >> (ob & 31u)) & 1u : 0u;
                 const u32 fb1 = o >= 1 ? (lds_mask(2)[ob >> 5] >> (ob & 31u)) & 1u : 0u;
-                w = wv_win_dbcs(wv_extract(lds_mask(0), o, n), wv_extract(lds_mask(1), o, n), wv_extract(lds_mask(2), o, n),
-                                wv_extract(lds_mask(FAM == 4 ? 5 : 0), o, n), wv_extract(lds_mask(3), o, n), wv_extract(lds_mask(FAM == 4 ? 4 : 0), o, n),
-                                wv_extract(lds_mask(FAM == 4 ? 6 : 0), o, n), wv_extract(lds_mask(FAM == 4 ? 7 : 0), o, n),
-                                wv_extract(lds_mask(FAM == 4 ? 8 : 0), o, n), (eb | mab) != 0, fb1 != 0, ws > 0, ws % kWvSlice == 0, n, P.n_min);
+                if (CLS) w = wv_win_dbcs_swar(wv_extract(lds_mask(0), o, n), wv_extract(lds_mask(1), o, n), wv_extract(lds_mask(2), o, n), wv_extract(lds_mask(3), o, n),
+                                              wv_extract(lds_mask(FAM == 4 ? 4 : 0), o, n), SW.hi_len, (eb | mab) != 0, fb1 != 0, ws > 0, ws % kWvSlice == 0, n, P.n_min);
+                else w = wv_win_dbcs(wv_extract(lds_mask(0), o, n), wv_extract(lds_mask(1), o, n), wv_extract(lds_mask(2), o, n),
+                                wv_extract(lds_mask(FAM == 4 && !CLS ? 5 : 0), o, n), wv_extract(lds_mask(3), o, n), wv_extract(lds_mask(FAM == 4 ? 4 : 0), o, n),
+                                wv_extract(lds_mask(FAM == 4 && !CLS ? 6 : 0), o, n), wv_extract(lds_mask(FAM == 4 && !CLS ? 7 : 0), o, n),
+                                wv_extract(lds_mask(FAM == 4 && !CLS ? 8 : 0), o, n), (eb | mab) != 0, fb1 != 0, ws > 0, ws % kWvSlice == 0, n, P.n_min);
             } else {
                 const u32 fb = o >= 3 ? (u32)wv_extract(lds_mask(2), o - 3, 3).lo : 0u;
                 w = wv_win_utf8(wv_extract(lds_mask(0), o, n), wv_extract(lds_mask(1), o, n), wv_extract(lds_mask(2), o, n),
@@ -521,7 +542,8 @@ hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint
     WaveParams Q = P;
     Q.v0 = v0; Q.v1 = v1;
     const unsigned dyn = getenv("SX_WAVE_DYN_LDS") ? (unsigned)atoi(getenv("SX_WAVE_DYN_LDS")) : 0u;   // experiments: fewer wavefronts per CU
-    if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 0>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
+    if (P.family == 4 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 1>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
+    else if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 0>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<0, 1, 1, 0>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
     else if (P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 0, 1, 1>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
     else hipLaunchKernelGGL((wave_replay_kernel<0, 0, 1, 0>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
@@ -547,7 +569,8 @@ hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipS
     WaveParams Q = P;
     Q.v0 = v0; Q.v1 = v1;
     const unsigned dyn = getenv("SX_WAVE_DYN_LDS") ? (unsigned)atoi(getenv("SX_WAVE_DYN_LDS")) : 0u;
-    if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4, 0>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
+    if (P.family == 4 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4, 1>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
+    else if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4, 0>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<1, 1, 1, 0>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
     else if (P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<1, 0, 1, 1>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
     else hipLaunchKernelGGL((wave_replay_kernel<1, 0, 1, 0>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);

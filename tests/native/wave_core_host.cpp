@@ -190,6 +190,16 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                 }
                 if (t < 0) continue;
                 const WvMasks16D m0 = wv_classify16_dbcs(P.lut, P.pairs, b, have_lo, have_hi, lr, cov_in ? s1 : s0, cov_in);
+                if (P.swar.cls) {   // as the kernel: SWAR classes, 2 bits per pair, five masks — which must be the statement's
+                    const WvDbcsPreS ps = wv_dbcs_classes_swar<6>(P.swar, &ws6[1], avail);
+                    const u32 t0 = wv_dbcs_trails(ps.lr, 0u), t1 = wv_dbcs_trails(ps.lr, 1u);
+                    if ((t0 >> 16) != o0 || (t1 >> 16) != o1) return false;
+                    const WvMasks16E m = wv_classify16_dbcs_swar(P.pairs2, ws6, ps, cov_in ? t1 : t0, cov_in, off > 0, avail + n_ahead);
+                    if (m.e != m0.e || m.a != m0.a || m.f != m0.f || m.ma != m0.ma || m.mb != m0.mb) return false;
+                    const u32 vals5[5] = { m.e, m.a, m.f, m.ma, m.mb };
+                    for (int k = 0; k < 5; k++) ((uint16_t*)lds[k].data())[idx] = (uint16_t)vals5[k];
+                    continue;
+                }
                 // the kernels' path: the same as bit arithmetic — compared with the statement byte by byte above
                 const WvDbcsPre pc = wv_dbcs_classes(P.lut, &ws6[1], avail);
                 const u32 tr0 = wv_dbcs_trails(pc.lr, 0u), tr1 = wv_dbcs_trails(pc.lr, 1u);
@@ -211,7 +221,9 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
             else if (P.family == 4) {
                 const u32 eb = o >= 1 ? (u32)wv_extract(lds[0], o - 1, 1).lo : 1u, mab = o >= 1 ? (u32)wv_extract(lds[3], o - 1, 1).lo : 0u;
                 const u32 fb1 = o >= 1 ? (u32)wv_extract(lds[2], o - 1, 1).lo : 0u;
-                w[l] = wv_win_dbcs(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[5], o, n),
+                if (P.swar.cls) w[l] = wv_win_dbcs_swar(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[3], o, n),
+                                                        wv_extract(lds[4], o, n), P.swar.hi_len, (eb | mab) != 0, fb1 != 0, ws[l] > 0, ws[l] % kWvSlice == 0, n, P.n_min);
+                else w[l] = wv_win_dbcs(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[5], o, n),
                                    wv_extract(lds[3], o, n), wv_extract(lds[4], o, n), wv_extract(lds[6], o, n), wv_extract(lds[7], o, n),
                                    wv_extract(lds[8], o, n), (eb | mab) != 0, fb1 != 0, ws[l] > 0, ws[l] % kWvSlice == 0, n, P.n_min);
             } else {
@@ -320,7 +332,7 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
                            uint64_t g_lo, uint32_t inject, uint32_t nwin, const uint8_t* lut, const uint16_t* table, int mission_id,
                            int file_id, sx_finding* fout, uint64_t fcap, uint8_t* aout, uint64_t acap, uint64_t* nf, uint64_t* nb,
                            uint32_t* final_state, uint64_t* bad_waves, int skip_idle, uint32_t* rounds_max, uint32_t family,
-                           const uint32_t* pairs, uint32_t encoding, uint32_t entry_skip, const uint32_t* swar25) {
+                           const uint32_t* pairs, uint32_t encoding, uint32_t entry_skip, const uint32_t* swar25, const uint32_t* pairs2) {
     WaveParams P;
     memset(&P, 0, sizeof P);
     P.data = data; P.len = len; P.consumed0 = consumed0; P.slice_base = slice_base; P.W = W; P.wps = wv_wps(W); P.q = q; P.n_min = n_min;
@@ -328,6 +340,8 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
     P.g_lo = g_lo; P.g_hi = wv_window_count(len, W); P.nwin = nwin; P.inject = inject; P.mission_id = mission_id; P.file_id = file_id;
     P.lut = lut; P.table = table; P.family = family; P.pairs = pairs; P.encoding = encoding; P.entry_skip = entry_skip;
     if (swar25) memcpy(&P.swar, swar25, sizeof P.swar);
+    P.pairs2 = pairs2;
+    if (family == 4 && !pairs2) P.swar.cls = 0;
     *nf = *nb = 0; *bad_waves = 0; *final_state = inject; *rounds_max = 0;
     if (P.g_hi <= P.g_lo) return 0;
     const u64 n_waves = (P.g_hi - P.g_lo + nwin - 1) / nwin;

@@ -32,7 +32,7 @@ def load_wave():
     L.sxw_emulate.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
                               C.c_uint32, C.c_char_p, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.POINTER(sx.Finding), C.c_uint64,
                               C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
-                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.sxw_pack_state.restype = C.c_uint32
     L.sxw_pack_state.argtypes = [C.c_uint32] * 4
     return L
@@ -65,6 +65,14 @@ def wave_swar(m):
     return out if r == 1 else None
 
 
+def wave_pairs2(m):
+    L = sx.lib()
+    L.sx_wave_pair_codes2.argtypes, L.sx_wave_pair_codes2.restype = [C.POINTER(sx.Mission), C.POINTER(C.c_uint32)], C.c_void_p
+    out = (C.c_uint32 * 4096)()
+    cm = sx.Mission.from_dict(dict(m, mission_id=m.get("mission_id", 0)))
+    return out if L.sx_wave_pair_codes2(C.byref(cm), out) else None
+
+
 def wave_pairs(m):
     L = sx.lib()
     L.sx_wave_pair_codes.argtypes, L.sx_wave_pair_codes.restype = [C.POINTER(sx.Mission), C.POINTER(C.c_uint32)], C.c_void_p
@@ -90,7 +98,7 @@ def emulate(L, m, data, nwin=508, skip_idle=1, g_lo=0, inject=0, consumed0=None,
     rcode = L.sxw_emulate(data, len(data), m["counter_offset"] if consumed0 is None else consumed0, 0, 2 * q, q, m["chars_min_nb"], g_lo,
                           inject, nwin, lut, table, 0, 1, fout, cap_f, aout, cap_a, C.byref(nf), C.byref(nb), C.byref(fin), C.byref(bad),
                           skip_idle, C.byref(rounds), family, wave_pairs(m) if family == 4 else None, m["encoding"], 0,
-                          wave_swar(m) if swar else None)
+                          wave_swar(m) if swar else None, wave_pairs2(m) if swar and family == 4 else None)
     assert rcode == 0, rcode
     arena = bytes(aout[:nb.value])
     got = []
@@ -196,7 +204,7 @@ def test_emulated_wave_pipeline_two_byte_family(wave, di):
     for name, data in datas:
         want = oracle_findings([dict(m, mission_id=0)], data)
         for nwin, skip in ((508, 1), (60, 0), (7, 1)):
-            got, info = emulate(wave, m, data, nwin=nwin, skip_idle=skip)
+            got, info = emulate(wave, m, data, nwin=nwin, skip_idle=skip, swar=nwin != 60)
             assert info["bad"] == 0, (name, nwin, info)
             assert got == want, (enc, name, nwin, skip, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
 
@@ -225,6 +233,9 @@ def test_which_missions_classify_by_ranges():
     no = [dict(encodings=["windows-1253"], chars_min="2", unicode_block_filter="All"),   # bytes without a character
           dict(encodings=["windows-1252"], chars_min="4", unicode_block_filter="All"),   # 2- and 3-byte UTF-8 forms among the accepted
           dict(encodings=["utf-8"], chars_min="4")]
+    yes += [dict(encodings=["big5"], chars_min="10", unicode_block_filter="Cjk"), dict(encodings=["euc-kr"], chars_min="20", unicode_block_filter="Hangul")]
+    no += [dict(encodings=["shift_jis"], chars_min="4", unicode_block_filter="All"),      # bytes >= 0x80 that are characters on their own
+           dict(encodings=["euc-kr"], chars_min="4", unicode_block_filter="All")]        # accepted pairs of two and three UTF-8 bytes
     for kw in yes:
         assert wave_swar(rc.missions(**kw)[0]) is not None, kw
     for kw in no:
