@@ -108,6 +108,28 @@ typedef struct sx_finding {
     uint32_t slice_index;                /* 4 KiB slice of this chunk that produced it */
 } sx_finding;
 
+/* The same finding in 16 bytes, as string-dense results cross PCIe (round 4): `-e ascii -n 4` on a binary yields a finding per 85
+ * bytes, BASELINE config 5 411 M of them per 64 GiB — such scans are bound by moving the records to the host, and half of sx_finding
+ * is the same for every record of a segment (input_file_id), follows from the others (slice_index = slice_base + (position -
+ * position of the segment's buffer byte 0 for that Mission) / 4096) or is padding.  Segments whose findings were written by the
+ * device's dense paths (the wave-cooperative stage B of a single Mission, the device-side merger of several) are stored this way;
+ * sx_result_segment_packed() hands them out as they are, sx_result_segment() expands them to sx_finding on first use, and
+ * sx_print_findings() reads either. */
+typedef struct sx_finding16 {
+    uint64_t position;
+    uint32_t str_off;
+    uint16_t str_len;
+    uint8_t  flags;                      /* bits 0-1: precision (SX_PRECISION_*), bit 2: completes_previous */
+    uint8_t  mission_id;
+} sx_finding16;
+typedef struct sx_segment_info {         /* what the records of one packed segment share */
+    int32_t  packed;                     /* 1: the segment's records are sx_finding16, 0: sx_finding */
+    int32_t  input_file_id;
+    uint32_t slice_base;                 /* slice_index of the segment's buffer byte 0 */
+    uint32_t reserved;
+    uint64_t position0[256];             /* by mission_id: `position` of the segment's buffer byte 0 (counter_offset + bytes consumed before it) */
+} sx_segment_info;
+
 /* Device run record: one maximal stretch of bytes belonging to valid,
  * filter-accepted characters (ignoring -g / -r), with its character count.
  * (Inside the library a run that crosses window starts may travel as several pieces, one per window: a piece
@@ -326,10 +348,15 @@ uint64_t          sx_result_count(const sx_result* r);
  * piece; a single Mission with millions of runs is replayed in slabs, one segment each (a slab travels to the host while
  * the next is replayed); several Missions with a large output are interleaved on the device in parts of at most 2 GiB of
  * strings, one segment each (str_off has 32 bits).  The segments' memory is pinned host memory the device wrote
- * directly.  Each segment has its own arena: str_off counts from that arena's start. */
+ * directly.  Each segment has its own arena: str_off counts from that arena's start.  A segment stored as sx_finding16 records is
+ * expanded to sx_finding on its first sx_result_segment() call (a copy in host memory; sx_result_segment_packed() avoids it). */
 uint64_t          sx_result_segments(const sx_result* r);
 int               sx_result_segment(const sx_result* r, uint64_t index, const sx_finding** findings,
                                     uint64_t* n_findings, const uint8_t** arena, uint64_t* arena_len);
+/* A segment as it is stored: *packed = 1 -> `findings` points at n_findings sx_finding16 and *info says what they share (info may
+ * be NULL if the caller only wants to know); *packed = 0 -> at sx_finding, as sx_result_segment() returns them.  No copy either way. */
+int               sx_result_segment_packed(const sx_result* r, uint64_t index, const void** findings, uint64_t* n_findings,
+                                           const uint8_t** arena, uint64_t* arena_len, int* packed, sx_segment_info* info);
 /* Contiguous view of all segments (joined by a copy on first use if there are several;
  * NULL if the strings exceed 4 GiB — use the segments then). */
 const sx_finding* sx_result_findings(const sx_result* r);

@@ -30,7 +30,7 @@ ABI_VERSION = 2   # SX_ABI_VERSION of include/stringsext_amd.h
 EXPORTS = ["sx_abi_version", "sx_create", "sx_destroy", "sx_last_error", "sx_scan", "sx_scan_device", "sx_reset",
            "sx_device_runs", "sx_replay_runs", "sx_scan_shard_device", "sx_scan_shard", "sx_replay_shard_runs",
            "sx_scan_stream", "sx_scan_file", "sx_missions_from_flags", "sx_parse_enc_opt", "sx_encoding_for_label", "sx_encoding_name",
-           "sx_decoder_table", "sx_wave_classes", "sx_wave_swar", "sx_wave_pair_codes2", "sx_wave_pair_codes", "sx_shard_bounds", "sx_scan_sharded", "sx_shard_splice",
+           "sx_decoder_table", "sx_wave_classes", "sx_result_segment_packed", "sx_wave_swar", "sx_wave_pair_codes2", "sx_wave_pair_codes", "sx_shard_bounds", "sx_scan_sharded", "sx_shard_splice",
            "sx_result_count", "sx_result_segments", "sx_result_segment", "sx_result_findings", "sx_result_arena",
            "sx_result_free", "sx_print_findings", "sx_get_stats", "sx_free", "sx_fill_background_device",
            "sx_device_alloc", "sx_device_free", "sx_device_upload", "sx_device_download",
@@ -146,6 +146,15 @@ class Finding(C.Structure):
                 ("precision", C.c_uint8), ("completes_previous", C.c_uint8), ("mission_id", C.c_uint8),
                 ("reserved", C.c_uint8), ("input_file_id", C.c_int16), ("reserved2", C.c_uint16),
                 ("slice_index", C.c_uint32)]
+
+
+class Finding16(C.Structure):   # sx_finding16: a finding as string-dense results cross PCIe
+    _fields_ = [("position", C.c_uint64), ("str_off", C.c_uint32), ("str_len", C.c_uint16), ("flags", C.c_uint8), ("mission_id", C.c_uint8)]
+
+
+class SegmentInfo(C.Structure):   # sx_segment_info
+    _fields_ = [("packed", C.c_int32), ("input_file_id", C.c_int32), ("slice_base", C.c_uint32), ("reserved", C.c_uint32),
+                ("position0", C.c_uint64 * 256)]
 
 
 class Run(C.Structure):
@@ -268,6 +277,19 @@ class Result:
             fp, n, ap, alen = C.POINTER(Finding)(), C.c_uint64(), C.POINTER(C.c_uint8)(), C.c_uint64()
             self._s._chk(L.sx_result_segment(self.h, i, C.byref(fp), C.byref(n), C.byref(ap), C.byref(alen)))
             out.append((fp, n.value))
+        return out
+
+    def packed_segments(self):
+        """[(packed?, records pointer (Finding16 or Finding), n, arena bytes, SegmentInfo)] — the segments as they are stored"""
+        L = lib()
+        L.sx_result_segment_packed.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint8)),
+                                               C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(SegmentInfo)]
+        out = []
+        for i in range(L.sx_result_segments(self.h)):
+            fp, n, ap, alen, pk, info = C.c_void_p(), C.c_uint64(), C.POINTER(C.c_uint8)(), C.c_uint64(), C.c_int(), SegmentInfo()
+            self._s._chk(L.sx_result_segment_packed(self.h, i, C.byref(fp), C.byref(n), C.byref(ap), C.byref(alen), C.byref(pk), C.byref(info)))
+            recs = C.cast(fp, C.POINTER(Finding16 if pk.value else Finding))
+            out.append((bool(pk.value), recs, n.value, C.string_at(ap, alen.value) if alen.value else b"", info))
         return out
 
     def segments(self):

@@ -436,6 +436,26 @@ int sx_result_segment(const sx_result* r, uint64_t i, const sx_finding** finding
     if (arena_len) *arena_len = s.strings_len();
     return SX_OK;
 }
+int sx_result_segment_packed(const sx_result* r, uint64_t i, const void** findings, uint64_t* n_findings, const uint8_t** arena,
+                             uint64_t* arena_len, int* packed, sx_segment_info* info) {
+    if (!r || i >= r->r.segs.size()) return SX_E_INVALID;
+    const MissionFindings& s = r->r.segs[(size_t)i];
+    if (findings) *findings = s.packed ? (const void*)s.data16() : (const void*)s.data();
+    if (n_findings) *n_findings = s.count();
+    if (arena) *arena = (const uint8_t*)s.strings();
+    if (arena_len) *arena_len = s.strings_len();
+    if (packed) *packed = s.packed ? 1 : 0;
+    if (info) {
+        memset(info, 0, sizeof *info);
+        info->packed = s.packed ? 1 : 0;
+        info->input_file_id = -1;
+        if (s.packed && s.info) {
+            info->input_file_id = s.info->file_id; info->slice_base = s.info->slice_base;
+            memcpy(info->position0, s.info->pos0, sizeof info->position0);
+        }
+    }
+    return SX_OK;
+}
 // The contiguous view: joins the segments on first use (a copy; none if there is one segment).
 const sx_finding* sx_result_findings(const sx_result* r) {
     if (!r || !const_cast<sx_result*>(r)->r.flatten(nullptr) || r->r.segs.empty()) return nullptr;

@@ -179,8 +179,9 @@ struct WaveParams {
     // pass 2 in: exclusive sums of the above; the launch's output segment starts at (f_sub, a_sub)
     const uint64_t *wave_fbase, *wave_abase;
     uint64_t f_sub, a_sub;
-    sx_finding* findings;
+    sx_finding* findings;     // (packed: sx_finding16 records)
     uint8_t* arena;
+    uint32_t packed;          // the records are written as sx_finding16 (include/stringsext_amd.h)
     uint32_t str_off_base;    // added to every str_off
     uint64_t v0, v1;          // the wavefronts of this launch: [v0, v1)
     // descriptors (sx_wave_core.hpp WvDesc, three words each): the count pass leaves one per finding, desc_cap per wavefront, for the
@@ -202,7 +203,8 @@ hipError_t launch_wave_emit(const WaveParams& P, uint64_t v0, uint64_t v1, hipSt
 // interleave several missions' findings on the device (sx_sort.hip); every src and out = [findings][string bytes]
 hipError_t merge_findings_device_part(const sx_finding* const* f, const uint8_t* const* a, const uint64_t* nf, const uint64_t* nb,
                                       const uint32_t* off0, int n_missions, void* out, void* scratch, size_t scratch_bytes,
-                                      hipStream_t stream);
+                                      hipStream_t stream, int packed = 0);
+bool merge_part_can_pack(uint64_t n, int n_missions);   // the one-pass merger takes the part (else the radix sort, which writes sx_finding only)
 hipError_t launch_slab_cuts(const ReplayParams& P, uint32_t n_slabs, uint64_t* idx, uint64_t* hi, hipStream_t stream);
 hipError_t launch_merge_cuts(const sx_finding* f, uint64_t n, uint64_t nb, const uint64_t* cuts, uint32_t n_cuts, uint64_t* idx,
                              uint64_t* off, hipStream_t stream);

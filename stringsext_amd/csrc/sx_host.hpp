@@ -191,6 +191,27 @@ struct PinnedPool {
     ~PinnedPool();
 };
 
+// What the records of a packed segment share (include/stringsext_amd.h sx_finding16, sx_segment_info)
+struct SegInfo {
+    int file_id = -1;
+    uint32_t slice_base = 0;
+    uint64_t pos0[256];   // by mission_id
+};
+inline sx_finding expand_finding(const sx_finding16& p, const SegInfo& si) {
+    sx_finding f;
+    f.position = p.position; f.str_off = p.str_off; f.str_len = p.str_len;
+    f.precision = (uint8_t)(p.flags & 3u); f.completes_previous = (uint8_t)((p.flags >> 2) & 1u);
+    f.mission_id = p.mission_id; f.reserved = 0; f.input_file_id = (int16_t)si.file_id; f.reserved2 = 0;
+    f.slice_index = si.slice_base + (uint32_t)((p.position - si.pos0[p.mission_id]) / 4096u);
+    return f;
+}
+inline sx_finding16 pack_finding(const sx_finding& f) {
+    sx_finding16 p;
+    p.position = f.position; p.str_off = f.str_off; p.str_len = (uint16_t)f.str_len;
+    p.flags = (uint8_t)((f.precision & 3u) | (f.completes_previous ? 4u : 0u)); p.mission_id = f.mission_id;
+    return p;
+}
+
 struct MissionFindings {
     std::vector<sx_finding> v;  // str_off relative to `arena`
     std::string arena;
@@ -207,9 +228,18 @@ struct MissionFindings {
     bool dev_only = false;
     // further segments of the same mission, in order (a mission replayed in slabs; only with a single mission)
     std::vector<MissionFindings> more;
+    // packed: the pinned block holds [ext_nf x sx_finding16][strings] — segments of a result that the device's dense writers
+    // produced; `info` says what the records share.  data() expands them into `expanded` on first use (get(i): one record, no copy).
+    bool packed = false;
+    std::shared_ptr<SegInfo> info;
+    mutable std::vector<sx_finding> expanded;
+    size_t rec_size() const { return packed ? sizeof(sx_finding16) : sizeof(sx_finding); }
     size_t count() const { return (ext.p || dev_only) ? ext_nf : v.size(); }
-    const sx_finding* data() const { return ext.p ? (const sx_finding*)ext.p : v.data(); }
-    const char* strings() const { return ext.p ? (const char*)ext.p + ext_nf * sizeof(sx_finding) : arena.data(); }
+    void expand() const;   // sx_replay.cpp
+    const sx_finding* data() const { if (packed) { expand(); return expanded.data(); } return ext.p ? (const sx_finding*)ext.p : v.data(); }
+    const sx_finding16* data16() const { return packed ? (const sx_finding16*)ext.p : nullptr; }
+    sx_finding get(size_t i) const { return packed ? expand_finding(data16()[i], *info) : data()[i]; }
+    const char* strings() const { return ext.p ? (const char*)ext.p + ext_nf * rec_size() : arena.data(); }
     size_t strings_len() const { return (ext.p || dev_only) ? ext_na : arena.size(); }
 };
 

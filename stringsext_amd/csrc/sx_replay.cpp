@@ -696,6 +696,21 @@ void merge_findings(std::vector<MissionFindings>& per, const std::shared_ptr<Pin
     for (auto& mf : per) release(mf);
 }
 
+// a packed segment as sx_finding records (sx_result_segment, the host-side merges and splices): once, by a few threads
+void MissionFindings::expand() const {
+    if (!packed || expanded.size() == ext_nf) return;
+    expanded.resize(ext_nf);
+    const sx_finding16* src = data16();
+    const SegInfo& si = *info;
+    const size_t n = ext_nf;
+    const unsigned nt = n < (1u << 20) ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    auto work = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) expanded[i] = expand_finding(src[i], si); };
+    if (nt <= 1) { work(0, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+    for (auto& t : th) t.join();
+}
+
 bool Result::flatten(std::string* err) {
     if (segs.size() <= 1) return true;
     size_t total = 0, bytes = 0;
@@ -721,7 +736,7 @@ void print_findings(const std::vector<Mission>& missions, const Result& r, int n
     char num[40];
     for (const MissionFindings& seg : r.segs)
     for (size_t fi = 0; fi < seg.count(); fi++) {
-        const sx_finding& f = seg.data()[fi];
+        const sx_finding f = seg.get(fi);   // (a packed segment is read as it is)
         const Mission* m = nullptr;
         for (const Mission& c : missions) if (c.c.mission_id == f.mission_id) { m = &c; break; }
         out->push_back('\n');  // src/finding.rs:113

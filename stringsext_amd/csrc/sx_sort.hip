@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void merge_bounds_kernel(MergeLists L, uint32_
     bounds[i] = (uint32_t)v;
 }
 __global__ __launch_bounds__(256) void merge_place_kernel(MergeLists L, int m, uint32_t T, const MergeRange* rg, const uint32_t* bounds,
-                                                          sx_finding* out) {
+                                                          void* out, int packed) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= L.nf[m]) return;
     sx_finding f = L.f[m][i];
@@ -332,7 +332,12 @@ __global__ __launch_bounds__(256) void merge_place_kernel(MergeLists L, int m, u
         rank += o < m ? merge_upper(L.f[o], lo, hi, p) : merge_lower(L.f[o], lo, hi, p);
     }
     f.str_off += L.arena_adj[m];   // (mod 2^32: a part's base may be "negative", see merge_findings_device_part)
-    out[rank] = f;
+    if (packed) {   // include/stringsext_amd.h sx_finding16: what crosses PCIe is half the size
+        sx_finding16 p;
+        p.position = f.position; p.str_off = f.str_off; p.str_len = (uint16_t)f.str_len;
+        p.flags = (uint8_t)((f.precision & 3u) | (f.completes_previous ? 4u : 0u)); p.mission_id = f.mission_id;
+        ((sx_finding16*)out)[rank] = p;
+    } else ((sx_finding*)out)[rank] = f;
 }
 static uint32_t merge_tiles(uint64_t n) {
     const uint64_t t = n / 64;
@@ -359,6 +364,7 @@ static size_t merge_sort_scratch_bytes(uint64_t n) {
     (void)rocprim::radix_sort_pairs(nullptr, tmp, nul, nul, nul, nul, (size_t)n, 0, 64, (hipStream_t)0);
     return n * sizeof(sx_finding) + 4 * n * 8 + tmp + 2048;
 }
+bool merge_part_can_pack(uint64_t n, int n_missions) { return n_missions <= kMergeLists && n < 0xFFFFFFFFull; }
 size_t merge_findings_scratch_bytes(uint64_t n, int n_missions) {
     if (n_missions > kMergeLists || n >= 0xFFFFFFFFull) return merge_sort_scratch_bytes(n);
     return 512 + ((size_t)merge_tiles(n) + 1) * 4 * (size_t)n_missions + 256;
@@ -367,14 +373,15 @@ size_t merge_findings_scratch_bytes(uint64_t n, int n_missions) {
 // count from off0[m] (the part's first string); out = [sum nf findings][sum nb bytes].
 hipError_t merge_findings_device_part(const sx_finding* const* f, const uint8_t* const* a, const uint64_t* nf, const uint64_t* nb,
                                       const uint32_t* off0, int n_missions, void* out, void* scratch, size_t scratch_bytes,
-                                      hipStream_t stream) {
+                                      hipStream_t stream, int packed) {
     uint64_t n = 0;
     for (int m = 0; m < n_missions; m++) n += nf[m];
     if (n == 0) return hipSuccess;
     if (scratch_bytes < merge_findings_scratch_bytes(n, n_missions)) return hipErrorInvalidValue;
     uint8_t* base = (uint8_t*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    if (packed && !(n_missions <= kMergeLists && n < 0xFFFFFFFFull)) return hipErrorInvalidValue;   // (merge_part_can_pack)
     sx_finding* out_f = (sx_finding*)out;
-    uint8_t* out_a = (uint8_t*)out + n * sizeof(sx_finding);
+    uint8_t* out_a = (uint8_t*)out + n * (packed ? sizeof(sx_finding16) : sizeof(sx_finding));
     if (n_missions <= kMergeLists && n < 0xFFFFFFFFull) {
         MergeLists L{};
         L.n = n_missions;
@@ -395,7 +402,7 @@ hipError_t merge_findings_device_part(const sx_finding* const* f, const uint8_t*
         hipLaunchKernelGGL(merge_bounds_kernel, dim3((unsigned)((nb_threads + 255) / 256)), dim3(256), 0, stream, L, T, rg, bounds);
         for (int m = 0; m < n_missions; m++)
             if (nf[m])
-                hipLaunchKernelGGL(merge_place_kernel, dim3((unsigned)((nf[m] + 255) / 256)), dim3(256), 0, stream, L, m, T, rg, bounds, out_f);
+                hipLaunchKernelGGL(merge_place_kernel, dim3((unsigned)((nf[m] + 255) / 256)), dim3(256), 0, stream, L, m, T, rg, bounds, (void*)out_f, packed);
         return hipGetLastError();
     }
     sx_finding* all = (sx_finding*)base;

@@ -484,6 +484,17 @@ static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFi
     };
     if (!(with >= 2 && on_dev == with && same_origin && total >= 4096 && !getenv("SX_HOST_MERGE"))) return give_up();
     const double tm0 = now_ms();
+    // The records cross PCIe as sx_finding16 (include/stringsext_amd.h): half the bytes of what bounds this path.  Not with lines of
+    // more than 16 000 chars (str_len has 16 bits there), nor where the one-pass merger does not apply (SX_PACKED=0: tests).
+    bool pack = !(getenv("SX_PACKED") && !atoi(getenv("SX_PACKED")));
+    for (size_t k = 0; k < nm; k++) pack = pack && ctx->missions[k].q <= 16000;
+    std::shared_ptr<SegInfo> seg_info;
+    if (pack) {
+        seg_info = std::make_shared<SegInfo>();
+        seg_info->file_id = job.file_id; seg_info->slice_base = job.slice_base;
+        for (auto& x : seg_info->pos0) x = 0;
+        for (size_t k = 0; k < nm; k++) seg_info->pos0[ctx->missions[k].c.mission_id] = job.consumed0[k];
+    }
     uint64_t part_bytes = 2048ull << 20, part_findings = 96ull << 20;
     if (const char* e = getenv("SX_MERGE_PART_MIB")) part_bytes = std::max<uint64_t>(1, (uint64_t)atoll(e)) << 20;
     if (const char* e = getenv("SX_MERGE_PART_FINDINGS")) part_findings = std::max<uint64_t>(1024, (uint64_t)atoll(e));
@@ -586,9 +597,10 @@ static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFi
         ctx->merge_parts++;
         uint8_t* d_out = ctx->d_merge + ob * ctx->merge_out_room;
         if (ctx->merge_copy_pending[ob]) HIP_TRY(ctx, hipStreamWaitEvent(s, ev_copied[ob], 0));   // the buffer is free again
-        HIP_TRY(ctx, merge_findings_device_part(fp.data(), ap.data(), pnf.data(), pnb.data(), off0.data(), (int)nm, d_out, d_tmp, tmp_bytes, s));
+        const bool pack_part = pack && merge_part_can_pack(pf, (int)nm);
+        HIP_TRY(ctx, merge_findings_device_part(fp.data(), ap.data(), pnf.data(), pnb.data(), off0.data(), (int)nm, d_out, d_tmp, tmp_bytes, s, pack_part ? 1 : 0));
         HIP_TRY(ctx, hipEventRecord(ev_sorted, s));
-        const size_t out_bytes = pf * sizeof(sx_finding) + pb;
+        const size_t out_bytes = pf * (pack_part ? sizeof(sx_finding16) : sizeof(sx_finding)) + pb;
         PinnedPool::Block blk = ctx->pool->take(out_bytes + 64);
         if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
         HIP_TRY(ctx, hipStreamWaitEvent(cs, ev_sorted, 0));
@@ -608,6 +620,7 @@ static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFi
         ctx->merged_out_bytes += out_bytes;
         outs.emplace_back();
         outs.back().ext = blk; outs.back().ext_nf = pf; outs.back().ext_na = pb;
+        if (pack_part) { outs.back().packed = true; outs.back().info = seg_info; }
     }
     if (ctx->merge_async) {   // a Mission whose stage B writes on a stream of its own waits for this before it overwrites its findings
         if (!ctx->ev_interleaved) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_interleaved, hipEventDisableTiming));

@@ -199,6 +199,21 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             HIP_TRY(ctx, hipEventCreate(&e));
             d.wave_ev.push_back(e);
         }
+        // A single Mission's slabs go to the host as they are written: as sx_finding16 (include/stringsext_amd.h), half the bytes of what
+        // bounds this path.  (Several Missions: the outputs are interleaved first, 32-byte records; device_merge packs then.)
+        const bool pack = ctx->missions.size() == 1 && defer_min_bytes == 0 && !(getenv("SX_PACKED") && !atoi(getenv("SX_PACKED")));
+        const size_t rec = pack ? sizeof(sx_finding16) : sizeof(sx_finding);
+        std::shared_ptr<SegInfo> seg_info;
+        std::vector<sx_finding16> hf16;
+        if (pack) {
+            seg_info = std::make_shared<SegInfo>();
+            seg_info->file_id = job.file_id; seg_info->slice_base = job.slice_base;
+            for (auto& x : seg_info->pos0) x = 0;
+            seg_info->pos0[m.c.mission_id] = job.consumed0[k];
+            hf16.reserve(hf.v.size());
+            for (const sx_finding& f : hf.v) hf16.push_back(pack_finding(f));
+        }
+        P.packed = pack ? 1u : 0u;
         std::vector<char> wrote(K, 0);
         uint64_t* h_tot = own_stream ? d.h_tot : (uint64_t*)ctx->h_pin2;
         hipEvent_t copied[2] = { ctx->merge_ev[1], ctx->merge_ev[2] };
@@ -225,7 +240,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             nf_all += nf; nb_all += nb;
             if (nf + nfh_j == 0) continue;
             // ---- pass 2 straight into the result's layout: [host findings][device findings][host strings][device strings]
-            const uint64_t out_bytes = (nfh_j + nf) * sizeof(sx_finding) + nbh_j + nb;
+            const uint64_t out_bytes = (nfh_j + nf) * rec + nbh_j + nb;
             const int slot = (j & 1) ? 8 : 5;
             if (pending[j & 1]) {   // the copy of slab j - 2 may still read this buffer
                 if (d.d_rp_cap[slot] < out_bytes + 64) HIP_TRY(ctx, hipEventSynchronize(copied[j & 1]));
@@ -234,8 +249,8 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             rc = ensure_rp(ctx, d, slot, out_bytes + 64); if (rc) return abandon(rc);
             uint8_t* d_all = (uint8_t*)d.d_rp[slot];
             if (nf) {
-                P.findings = (sx_finding*)d_all + nfh_j;
-                P.arena = d_all + (nfh_j + nf) * sizeof(sx_finding) + nbh_j;
+                P.findings = (sx_finding*)(d_all + nfh_j * rec);
+                P.arena = d_all + (nfh_j + nf) * rec + nbh_j;
                 P.str_off_base = (uint32_t)nbh_j; P.f_sub = 0; P.a_sub = 0;
                 // (pieces: the interleave of the piece before may still read this Mission's findings — on post_stream, not this stream)
                 if (own_stream && ctx->interleave_pending) HIP_TRY(ctx, hipStreamWaitEvent(sb, ctx->ev_interleaved, 0));
@@ -245,10 +260,11 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
                 wrote[j] = 1;
             }
             if (nfh_j) {
-                HIP_TRY(ctx, hipMemcpyAsync(d_all, hf.v.data(), nfh_j * sizeof(sx_finding), hipMemcpyHostToDevice, sb));
-                if (nbh_j) HIP_TRY(ctx, hipMemcpyAsync(d_all + (nfh_j + nf) * sizeof(sx_finding), hf.arena.data(), nbh_j, hipMemcpyHostToDevice, sb));
+                HIP_TRY(ctx, hipMemcpyAsync(d_all, pack ? (const void*)hf16.data() : (const void*)hf.v.data(), nfh_j * rec, hipMemcpyHostToDevice, sb));
+                if (nbh_j) HIP_TRY(ctx, hipMemcpyAsync(d_all + (nfh_j + nf) * rec, hf.arena.data(), nbh_j, hipMemcpyHostToDevice, sb));
             }
             MissionFindings seg;
+            if (pack) { seg.packed = true; seg.info = seg_info; }
             deferred = K == 1 && defer_min_bytes && nf * sizeof(sx_finding) + nb >= defer_min_bytes;
             if (deferred) {
                 HIP_TRY(ctx, hipStreamSynchronize(sb));

@@ -52,7 +52,7 @@ SXD u32 wv_scan_incl(u32 v, u32 lane) {
 // the two-byte family's probe brings 384 B of scratch with it.  f / a: where the record and the string go, a_off: the string's offset
 // in the segment's arena, win_pos: buffer offset of the window the finding belongs to.
 template <int FAM>
-SXD void wv_write_finding(const WaveParams& P, sx_finding* f, u8* a, u64 a_off, u64 win_pos, u32 din, u32 prec, bool completes, i32 src_rel,
+SXD void wv_write_finding(const WaveParams& P, u64 fi, u8* a, u64 a_off, u64 win_pos, u32 din, u32 prec, bool completes, i32 src_rel,
                           u32 src_len, u32 out_len) {
     const u64 soff = win_pos / kWvSlice * kWvSlice;
     sx_finding r;
@@ -75,7 +75,12 @@ SXD void wv_write_finding(const WaveParams& P, sx_finding* f, u8* a, u64 a_off, 
     r.input_file_id = (int16_t)P.file_id;
     r.reserved2 = 0;
     r.slice_index = (u32)(soff / kWvSlice) + P.slice_base;
-    *f = r;
+    if (P.packed) {   // the record as it crosses PCIe (include/stringsext_amd.h sx_finding16)
+        sx_finding16 p;
+        p.position = r.position; p.str_off = r.str_off; p.str_len = (uint16_t)out_len;
+        p.flags = (u8)((prec & 3u) | (completes ? 4u : 0u)); p.mission_id = (u8)P.mission_id;
+        ((sx_finding16*)P.findings)[fi] = p;
+    } else P.findings[fi] = r;
     const u8* s = P.data + (u64)((long long)win_pos + src_rel);
     if (FAM == 4) (void)wv_transcode_dbcs((int)P.encoding, P.table, s, src_len, a);
     else if (out_len == src_len) {     // every char is one byte on both sides (ASCII; UTF-8 input)
@@ -93,7 +98,7 @@ SXD void wv_write_finding(const WaveParams& P, sx_finding* f, u8* a, u64 a_off, 
 // the window-parallel writer's emitter (pass 2 = the count pass once more, writing)
 template <int FAM> struct WriteEmit {
     const WaveParams* P;
-    sx_finding* f;        // next record of this lane
+    u64 f;                // next record of this lane (its index in the launch's segment)
     u8* a;                // next string byte of this lane
     u64 a_off;            // ... its offset in the segment's string arena
     u64 win_pos;          // buffer offset of the window
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         if (MODE == 1 && (nf | nb)) {
             const u32 excl = incl - packed;
             const u64 fo = fbase + tot_f + (excl >> 18), ao = abase + tot_b + (excl & 0x3FFFFu);
-            WriteEmit<FAM> we_{ &P, P.findings + fo, P.arena + ao, ao, ws };
+            WriteEmit<FAM> we_{ &P, fo, P.arena + ao, ao, ws };
             WvState st = wv_unpack(in);
             wv_window<KIND>(WP, w, st, we_, tail);
         }
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(256) void wave_emit_kernel(const WaveParams P) {
         u64 ws; u32 wn;
         wv_window_at(own_start + wv_desc_widx(x), P.W, P.wps, P.len, &ws, &wn);
         const u64 ao = abase + wv_desc_a_local(x);
-        wv_write_finding<FAM>(P, P.findings + fbase + i, P.arena + ao, ao, ws, wv_desc_din(x), wv_desc_prec(x), wv_desc_completes(x),
+        wv_write_finding<FAM>(P, fbase + i, P.arena + ao, ao, ws, wv_desc_din(x), wv_desc_prec(x), wv_desc_completes(x),
                               wv_desc_src_rel(x), wv_desc_src_len(x), wv_desc_out_len(x));
     }
 }

@@ -205,3 +205,48 @@ def test_giant_runs_take_the_wave_path():
             assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (flags, chunk)
         if "big5" not in flags["encodings"]:
             assert wave_windows_of_a_scan(ms[:1], data) > 0, flags
+
+
+def test_dense_results_travel_as_16_byte_records():
+    """a single Mission's wave slabs and the device-side merger of several Missions store sx_finding16 (half the bytes over PCIe):
+    the packed view, its expansion through sx_result_segment (slice_index, input_file_id and the flags restored), the printed
+    text, and SX_PACKED=0 must all say the same"""
+    rng = random.Random(31)
+    data = rng.randbytes(3 << 20) + text_lines(rng, 1 << 20)
+    cases = [rc.missions(encodings=["ascii"], chars_min="4", counter_offset="1000"),
+             rc.missions(encodings=["ascii", "koi8-r,,,Cyrillic", "utf-8"], chars_min="4")]
+    for ms in cases:
+        want = sxo.run_cli(ms, [data], radix="x")
+        os.environ["SX_DEFER_MIN_BYTES"] = "1"
+        try:
+            sc = sx.Scanner(ms, device=0)
+            for chunk in (len(data), 1 << 20):
+                sc.reset()
+                recs = []
+                n_packed = 0
+                for off in range(0, len(data), chunk):
+                    res = sc.scan(data[off:off + chunk], file_id=2)
+                    expanded = res.findings()
+                    at = 0
+                    for packed, v, n, arena, info in res.packed_segments():
+                        n_packed += packed
+                        for i in range(n):
+                            e = expanded[at + i]
+                            if packed:
+                                f = v[i]
+                                assert (f.position, f.mission_id, sx.PRECISION[f.flags & 3], bool(f.flags & 4)) == (e["position"], e["mission_id"], e["precision"], e["completes"])
+                                assert arena[f.str_off:f.str_off + f.str_len].decode() == e["s"]
+                                assert e["file_id"] == info.input_file_id == 2
+                                assert e["slice_index"] == info.slice_base + (f.position - info.position0[f.mission_id]) // 4096
+                            if len(ms) == 1:   # (every sx_scan call counts its slices from 0)
+                                assert e["slice_index"] == (e["position"] - ms[0]["counter_offset"] - off) // 4096
+                        at += n
+                    recs += expanded
+                    res.free()
+                assert n_packed > 0, "no packed segment"
+            sc.close()
+            assert run_cli_product(ms, [data], radix="x", device=0) == want
+            os.environ["SX_PACKED"] = "0"
+            assert run_cli_product(ms, [data], radix="x", device=0) == want
+        finally:
+            os.environ.pop("SX_DEFER_MIN_BYTES", None); os.environ.pop("SX_PACKED", None)

@@ -382,7 +382,7 @@ def test_ctypes_structs_have_the_headers_layout(tmp_path):
     import stringsext_amd as sx
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     pairs = [("sx_mission", sx.Mission), ("sx_finding", sx.Finding), ("sx_run", sx.Run), ("sx_stats", sx.Stats), ("sx_options", sx.Options),
-             ("sx_cli_flags", sx.CliFlags), ("sx_enc_opt", sx.EncOpt)]
+             ("sx_cli_flags", sx.CliFlags), ("sx_enc_opt", sx.EncOpt), ("sx_finding16", sx.Finding16), ("sx_segment_info", sx.SegmentInfo)]
     src = tmp_path / "layout.c"
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "stringsext_amd.h"', 'int main(void) {']
     for cname, cls in pairs:
