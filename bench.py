@@ -76,7 +76,23 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses cuda:0")
     ap.add_argument("--generic-kernels", action="store_true",
                     help="force the table-driven (LUT) classifiers instead of the range kernels: what a Mission with an arbitrary af / ubf costs")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank scans the workload's size (N x 64 GiB at N ranks); strong: the workload's ONE image is split "
+                         "over the ranks (BASELINE.json's metric: 64 GiB at 1/2/4/8 GPUs)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks the way the driver does (one process per GPU over
+    # torch.distributed.run on 127.0.0.1) and pass their output through
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -107,10 +123,12 @@ def main():
     missions = sx.missions_from_flags(**wl["flags"])   # the product's front end, from the literal flag strings
     assert missions == rc.missions(**wl["flags"])      # (the reference's rules restated in tests/refconfig.py: the checker)
     nbytes = int((args.gib if args.gib is not None else wl["gib"]) * (1 << 30)) // 4096 * 4096
+    if args.scaling == "strong":   # ONE image of the workload's size, a byte range of it per rank
+        nbytes = nbytes // world // 4096 * 4096
     sc = sx.Scanner(missions, device=local_rank, subchunk_bytes=args.subchunk_kib * 1024, generic_kernels=args.generic_kernels)
 
-    # weak scaling: rank r owns bytes [r*nbytes, (r+1)*nbytes) of ONE world*nbytes image; for
-    # N > 1 its buffer also holds a halo on both sides (runs that cross a shard boundary)
+    # rank r owns bytes [r*nbytes, (r+1)*nbytes) of ONE world*nbytes image (weak scaling: nbytes = the workload's size; strong: its
+    # N-th part); for N > 1 its buffer also holds a halo on both sides (runs that cross a shard boundary)
     import ctypes
     from stringsext_amd import sharded
     file_len = world * nbytes
@@ -276,9 +294,16 @@ def main():
         out = {
             "metric": "GiB/s scanned", "value": round(value, 2), "unit": "GiB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic" if args.background == "random" else "constant bytes (counter pass)",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic" if args.background == "random" else "constant bytes (counter pass)",
             "config": {"workload": wl["name"], "bytes_per_gpu": nbytes, "missions": len(missions),
-                       "parallelism": f"byte-range shards x{world}", "passes": passes},
+                       "image_bytes": world * nbytes,
+                       "parallelism": f"byte-range shards x{world}" + (" on ONE device (--single-device: plumbing test)" if args.single_device and world > 1 else ""),
+                       "backend": args.backend if world > 1 else None,
+                       # the Missions' scan launches queue up in ONE HIP stream by default (measured: a stream per Mission — SX_OPT_MISSION_STREAMS,
+                       # the north star's wording — aliases onto the same hardware queues and the kernels are bound by issue, not by launch order)
+                       "mission_streams": "per mission" if os.environ.get("SX_MISSION_STREAMS") else "one scan stream + one stage-B stream",
+                       "records": "sx_finding16 (16 B) for string-dense segments, sx_finding (32 B) else",
+                       "passes": passes},
             "roofline": roofline,
             "breakdown_ms_per_step": {"scan_kernels_sum": round(sum(kernel_ms), 3),
                                       "host_waits_for_stage_a": round(device_ms, 3),

@@ -41,6 +41,10 @@ def splice(scanner, gathered, file_len):
     Result in the reference's print order (sx_shard_splice)."""
     L = lib()
     world = len(gathered)
+    for k, g in enumerate(gathered):
+        if isinstance(g, list):   # (a rank with more than 4 GiB of strings arrives segment by segment, each with its own str_off space)
+            raise ValueError(f"rank {k}'s findings came in {len(g)} segments (more than 4 GiB of strings): sx_shard_splice takes one "
+                             "(findings, arena) pair per rank — splice such a file in parts (gather=False, splice_order on the ranks' lists)")
     gathered = [(bytes(fb), bytes(ab)) for fb, ab in gathered]   # (numpy views of the gather buffer, or bytes)
     keep = [(ctypes.create_string_buffer(fb, len(fb)), ctypes.create_string_buffer(ab, len(ab))) for fb, ab in gathered]
     fptr = (ctypes.POINTER(Finding) * world)(*[ctypes.cast(f, ctypes.POINTER(Finding)) for f, _ in keep])
@@ -66,6 +70,19 @@ def _host_buffer(n, device):
     if t is None or t.numel() < n:
         t = torch.empty(n + n // 4 + 4096, dtype=torch.uint8, pin_memory=pin)
         _HOST[pin] = t
+    return t
+
+
+_DEV = {}
+
+
+def _device_buffer(kind, n, device):
+    """a device tensor of at least n bytes for the gather (kind: "send" / "recv"), kept and grown from call to call"""
+    key = (kind, str(device))
+    t = _DEV.get(key)
+    if t is None or t.numel() < n:
+        _DEV[key] = None
+        t = _DEV[key] = torch.empty(n + n // 4 + 4096, dtype=torch.uint8, device=device)
     return t
 
 
@@ -142,6 +159,7 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
     def _allgather(user, send, nbytes, recv):
         # the exchanged rows are a few hundred bytes: one pinned host tensor per direction, kept between calls (and one device
         # tensor each for backend "nccl"), filled and read with memmove — no Python-level copies of the payload
+        t_in = time.perf_counter()
         try:
             key = (nbytes, world, str(device))
             t = _XCHG.get(key)
@@ -158,6 +176,7 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
                 hr.copy_(dr, non_blocking=True)
                 torch.cuda.current_stream(device).synchronize()
             ctypes.memmove(recv, hr.data_ptr(), nbytes * world)
+            keep["exchange_s"] = keep.get("exchange_s", 0.0) + (time.perf_counter() - t_in)
             return 0
         except Exception as e:  # pragma: no cover
             errors.append(e)
@@ -211,8 +230,8 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
 
     t_exchanged = time.perf_counter()
     if timings is not None:
-        timings["scan_ms"] = 1e3 * (t_scan - t_begin)     # incl. the two small all-gathers inside sx_scan_sharded
-        timings["exchange_ms"] = 1e3 * (t_exchanged - t_scan)
+        timings["scan_ms"] = 1e3 * (t_scan - t_begin)     # incl. the small all-gathers inside sx_scan_sharded ...
+        timings["exchange_ms"] = 1e3 * keep.get("exchange_s", 0.0)   # ... which take this long (waiting for the slowest rank included)
         timings["gather_ms"] = 0.0
     if not gather:
         return counts, res
@@ -226,32 +245,34 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
     sizes = _all_gather_u64(row, device)
     out = None
     if rank == 0:
-        total = sum(sum(r[1:1 + 2 * r[0]]) for r in sizes)
-        host = _host_buffer(max(total, 1), device)
-        stage = None
-        if on_gpu:
-            biggest = max([nf + na for r in sizes[1:] for nf, na in zip(r[1:1 + 2 * r[0]:2], r[2:2 + 2 * r[0]:2])] + [1])
-            stage = torch.empty(biggest, dtype=torch.uint8, device=device)
-        off, where = 0, []
+        # every receive is posted at once (round 3: world - 1 receives one after the other, each through a staging buffer): the
+        # senders' transfers overlap; on the GPU they land in ONE device buffer laid out like the host buffer's remote part, which a
+        # single copy brings to the host
+        own_total = sum(sizes[0][1:1 + 2 * sizes[0][0]])
+        remote_total = sum(sum(r[1:1 + 2 * r[0]]) for r in sizes[1:])
+        host = _host_buffer(max(own_total + remote_total, 1), device)
+        stage = _device_buffer("recv", remote_total, device) if on_gpu and remote_total else None
+        off, where, reqs = 0, [], []
         for k, r in enumerate(sizes):
             segs_k = []
             for j in range(r[0]):
                 nf, na = r[1 + 2 * j], r[2 + 2 * j]
-                dst = host[off:off + nf + na]
                 if k == 0:
+                    dst = host[off:off + nf + na]
                     fb, ab = pairs[j]
                     if nf: dst[:nf].copy_(torch.from_numpy(fb))
                     if na: dst[nf:].copy_(torch.from_numpy(ab))
                 elif nf + na:
-                    if on_gpu:
-                        dist.recv(stage[:nf + na], src=k)
-                        dst.copy_(stage[:nf + na], non_blocking=True)
-                        torch.cuda.current_stream(device).synchronize()   # (the staging buffer is reused by the next transfer)
-                    else:
-                        dist.recv(dst, src=k)
+                    dst = stage[off - own_total:off - own_total + nf + na] if on_gpu else host[off:off + nf + na]
+                    reqs.append(dist.irecv(dst, src=k))
                 segs_k.append((off, nf, na))
                 off += nf + na
             where.append(segs_k)
+        for q in reqs:
+            q.wait()
+        if on_gpu and remote_total:
+            host[own_total:own_total + remote_total].copy_(stage[:remote_total], non_blocking=True)
+            torch.cuda.current_stream(device).synchronize()
         raw = host.numpy()   # the views are valid until the next gather
         out = []
         for segs_k in where:
@@ -262,8 +283,8 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
             n = len(fb) + len(ab)
             if not n:
                 continue
-            if on_gpu:
-                mine = torch.empty(n, dtype=torch.uint8, device=device)
+            if on_gpu:   # one send tensor, kept from call to call (round 3: a fresh device tensor per call)
+                mine = _device_buffer("send", n, device)[:n]
                 if len(fb): mine[:len(fb)].copy_(torch.from_numpy(fb), non_blocking=True)
                 if len(ab): mine[len(fb):].copy_(torch.from_numpy(ab), non_blocking=True)
             else:
