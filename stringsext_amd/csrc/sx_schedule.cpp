@@ -101,6 +101,15 @@ void mission_order(sx_ctx* ctx, std::vector<int>* out) {
     bool busiest_last = most < (16ull << 20);
     if (const char* e = getenv("SX_BUSIEST_LAST")) busiest_last = atoi(e) != 0;
     if (busiest_last) std::reverse(order.begin(), order.end());
+    // Round 4: with three or more Missions the busiest goes SECOND TO LAST (SX_BUSIEST_LAST=2; default when it would have gone last): its
+    // stage B — a few milliseconds of byte-serial kernels and the copy of its findings — then runs next to ONE scan launch, the last
+    // one, instead of after all of them (5.8 of the headline's 40 ms per step were that tail), and that launch is one of the Missions
+    // with few runs: the UTF-16 kernels wait on memory more than half of the time and have issue slots to spare, the UTF-8 kernel
+    // (bound by issue) still runs with nothing next to it.  What remains behind the last launch is the stage B of a Mission with
+    // next to no runs.
+    int mode = busiest_last ? 2 : 0;
+    if (const char* e = getenv("SX_BUSIEST_LAST")) mode = atoi(e);
+    if (mode == 2 && nm >= 3 && busiest_last) std::swap(order[nm - 1], order[nm - 2]);
 }
 
 int sync_streams_and_return(sx_ctx* ctx, int rc) {  // do not leave kernels running on the caller's buffer

@@ -455,7 +455,7 @@ hipError_t launch_copy_bytes(void* dst, const void* src, uint64_t bytes, uint32_
     if (!bytes) return hipSuccess;
     if ((((uintptr_t)dst | (uintptr_t)src) & 15) != 0) return hipErrorInvalidValue;
     static const int nt = [] { const char* e = getenv("SX_MERGE_COPY_NT"); return e ? atoi(e) : 1; }();
-    static const int threads = [] { const char* e = getenv("SX_MERGE_COPY_THREADS"); return e ? std::max(64, std::min(1024, atoi(e))) : 256; }();
+    static const int threads = [] { const char* e = getenv("SX_MERGE_COPY_THREADS"); return e ? std::max(64, std::min(1024, atoi(e))) : 512; }();   // (round 4, C5 with 16-byte records: 256 -> 474 ms per step, 512 -> 444, 1024 -> 454)
     const uint64_t n16 = bytes / 16;
     if (nt)
         hipLaunchKernelGGL(copy_bytes_kernel<true>, dim3(workgroups ? workgroups : 2), dim3((unsigned)threads), 0, stream, (copy_v4u*)dst, (const copy_v4u*)src, n16,
