@@ -220,10 +220,11 @@ int sx_wave_classes(const sx_mission* mission, uint8_t* classes);
  * filter, bits 2-3: its UTF-8 form has 2 / 3 / 4 bytes, 3 = it yields two code points.  out8192 or NULL. */
 const uint32_t* sx_wave_pair_codes(const sx_mission* mission, uint32_t* out8192);
 
-/* ... and the same classes as SWAR ranges, if the Mission's can be put that way (csrc/sx_device.hpp WvSwar, 25 words): what the wave
- * kernels classify with then.  Returns 1 and fills out25, 0 if the Mission's classes stay a table, < 0 on error.  (Test harness.) */
-int sx_wave_swar(const sx_mission* mission, uint32_t* out25);
-/* ... two-byte family with sx_wave_swar() == 1: 2 bits per byte pair (bit 0 mapped, bit 1 accepted), index lead | trail << 8, sixteen per word. */
+/* ... and the same classes as SWAR ranges, if the Mission's can be put that way (csrc/sx_device.hpp WvSwar, 26 words): what the wave
+ * kernels classify with then.  Returns 1 and fills out26, 0 if the Mission's classes stay a table, < 0 on error.  (Test harness.) */
+int sx_wave_swar(const sx_mission* mission, uint32_t* out26);
+/* ... two-byte family with sx_wave_swar() == 1: 2 bits per byte pair (bit 0 mapped, bit 1 accepted), index lead | trail << 8, sixteen per word.
+ * EUC-JP (family 5): the first 1105 words, 2 bits per cell of index jis0208 (cells 0 .. 8835: (lead - A1) * 94 + trail - A1) and of index jis0212 (from cell 8836). */
 const uint32_t* sx_wave_pair_codes2(const sx_mission* mission, uint32_t* out4096);
 
 int  sx_abi_version(void);

@@ -179,14 +179,14 @@ const uint32_t* sx_wave_pair_codes2(const sx_mission* mission, uint32_t* out4096
     return out4096;
 }
 
-int sx_wave_swar(const sx_mission* mission, uint32_t* out25) {
-    if (!mission || !out25) return SX_E_INVALID;
+int sx_wave_swar(const sx_mission* mission, uint32_t* out26) {
+    if (!mission || !out26) return SX_E_INVALID;
     Mission m;
     std::string err;
     const int rc = Mission::from_c(*mission, false, &m, &err);
     if (rc != SX_OK) return rc;
-    static_assert(sizeof(WvSwar) == 25 * 4, "sx_wave_swar hands the struct out as 25 words");
-    memcpy(out25, &m.wave_swar, sizeof(WvSwar));
+    static_assert(sizeof(WvSwar) == 26 * 4, "sx_wave_swar hands the struct out as 26 words");
+    memcpy(out26, &m.wave_swar, sizeof(WvSwar));
     return m.wave_ok && m.wave_swar.cls ? 1 : 0;
 }
 

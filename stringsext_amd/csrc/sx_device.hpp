@@ -157,6 +157,7 @@ struct WvSwar {
     uint32_t c1[6], c2[6], hi[6];    // per range, replicated over the four bytes: 0x80 - lo7, 0x7F - hi7, 0 for bytes >= 0x80 / ~0 for bytes below
     uint32_t hi_len;                 // single byte: UTF-8 bytes of an accepted byte >= 0x80 (2 / 3); two-byte family: of an accepted pair
     uint32_t lr_c1[2], lr_c2[2];     // two-byte family: the lead byte ranges (low 7 bits), as ScanParams::lr_c1
+    uint32_t kana;                   // EUC-JP: 8E + A1..DF (half-width katakana, U+FF61..) passes the filter
 };
 struct WaveParams {
     const uint8_t* data;      // device: buffer byte 0 (on the slice grid)
@@ -168,12 +169,12 @@ struct WaveParams {
     uint32_t nwin;            // windows a wavefront owns
     uint32_t inject;          // the exact state at window g_lo (wv_pack), from the host
     int32_t mission_id, file_id;
-    uint32_t family;          // 0: single-byte decoders, 1: UTF-8, 4: the two-byte family (Big5, Shift_JIS, EUC-KR)
+    uint32_t family;          // 0: single-byte decoders, 1: UTF-8, 4: the two-byte family (Big5, Shift_JIS, EUC-KR), 5: EUC-JP
     const uint8_t* lut;       // device: 256 class bytes (single byte: WVC_*; UTF-8: WVU_*)
     const uint16_t* table;    // device: the decoder table (single byte: 128 entries; nullptr = x-user-defined; two-byte family: its blob)
     const uint32_t* pairs;    // device, two-byte family: 4 bits per byte pair (lead | trail << 8), sx_wave_core.hpp wv_classify16_dbcs
     uint32_t encoding;        // SX_ENC_* (the two-byte family's decoders are picked at run time)
-    uint32_t entry_skip;      // two-byte family: bytes at the buffer's start that finish the token pending on entry (0 / 1)
+    uint32_t entry_skip;      // two-byte family / EUC-JP: bytes at the buffer's start that finish the token pending on entry (0 / 1; EUC-JP: 0 .. 2)
     // pass 1 out, per wavefront: findings, string bytes, the entry state it assumed for its first window, the state after its last
     uint32_t *wave_nf, *wave_nb, *wave_in, *wave_out;
     // pass 2 in: exclusive sums of the above; the launch's output segment starts at (f_sub, a_sub)

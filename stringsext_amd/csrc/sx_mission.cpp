@@ -214,6 +214,41 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
                 for (int r = 0; r < 2; r++) { R.lr_c1[r] = p.lr_c1[r]; R.lr_c2[r] = p.lr_c2[r]; }
             } else m->wave_pairs2.clear();
         }
+        if (!two_byte) {
+            // EUC-JP on the wave path (sx_wave_core.hpp wv_classify16_eucjp_swar): Missions whose accepted multi-byte characters all have
+            // UTF-8 forms of one length (Asian, Cjk, Kana: three bytes; half-width katakana, 8E xx, are U+FF61.. = three bytes too) and whose
+            // accepted ASCII bytes are at most six ranges.  2 bits per cell of index jis0208 and of index jis0212 (bit 0 mapped, bit 1 accepted).
+            const uint16_t* tj = decoder_table(enc, nullptr);
+            std::vector<std::pair<int, int>> ranges;
+            for (int b = 0; b < 128; b++)
+                if (af[b]) { if (!ranges.empty() && ranges.back().second == b - 1) ranges.back().second = b; else ranges.emplace_back(b, b); }
+            uint32_t len_seen = 0;
+            bool one_len = true;
+            const bool kana = m->filter.pass_lead(utf8_lead_of(0xFF61u));
+            if (kana) len_seen = 3;
+            m->wave_pairs2.assign(4096, 0u);
+            for (uint32_t cell = 0; cell < 2 * kJisN; cell++) {
+                const uint32_t cp = tj[cell];
+                if (!cp) continue;
+                const bool acc = m->filter.pass_lead(utf8_lead_of(cp));
+                if (acc) { const uint32_t len = cp < 0x800 ? 2u : 3u; if (!len_seen) len_seen = len; else if (len_seen != len) one_len = false; }
+                m->wave_pairs2[cell >> 4] |= (1u | (acc ? 2u : 0u)) << ((cell & 15u) * 2);
+            }
+            m->wave_family = 5;
+            m->wave_lut.assign(256, 0);
+            for (int b = 0; b < 256; b++)
+                m->wave_lut[(size_t)b] = b < 0x80 ? (uint8_t)(WVC_VALID | (af[b] ? WVC_ACC : 0)) : ((b >= 0xA1 && b <= 0xFE) || b == 0x8E || b == 0x8F) ? (uint8_t)WVC_LEAD : (uint8_t)0;
+            m->wave_ok = wv_mission_ok(in.grep_char, in.require_same_unicode_block, in.chars_min_nb, (uint32_t)m->q) && one_len && ranges.size() <= 6;
+            if (m->wave_ok) {
+                WvSwar& R = m->wave_swar;
+                R.cls = 1; R.n = (uint32_t)ranges.size(); R.hi_len = len_seen ? len_seen : 3u; R.kana = kana ? 1u : 0u;
+                for (size_t k = 0; k < 6; k++) {
+                    uint32_t lo = 1, hi = 0;
+                    if (k < ranges.size()) { lo = (uint32_t)ranges[k].first; hi = (uint32_t)ranges[k].second; }
+                    R.c1[k] = (0x80u - lo) * 0x01010101u; R.c2[k] = (0x7Fu - hi) * 0x01010101u; R.hi[k] = 0xFFFFFFFFu;
+                }
+            } else m->wave_pairs2.clear();
+        }
         p.gb4 = (enc_is_gb(enc) && m->c.ubf != 0) ? 1u : 0u;   // some character beyond ASCII is accepted: four-byte tokens may be
         p.af_is_range = (!force_generic && af_is_range && !p.high1) ? 1u : 0u;
         const uint16_t* t = decoder_table(enc, nullptr);

@@ -24,7 +24,9 @@ namespace sx {
 // every other byte; on text it is the single-byte figure).
 static uint64_t wave_min_density_bytes(uint32_t family = 0) {
     static const uint64_t v = [] { const char* e = getenv("SX_WAVE_BYTES_PER_RUN"); return e ? (uint64_t)atoll(e) : 0ull; }();
-    return v ? v : (family == 4 ? 560ull : family == 1 ? 480ull : 600ull);
+    // (round 4: the count passes are 2.5 to 4 times faster — single byte 0.7 ps per byte, two-byte family 1.4, EUC-JP 2.3 — and a Mission on
+    // the wave path leaves the shared stage-B stream alone: EUC-JP + Asian on random bytes, a run per 3.4 KB, C5: 444 -> 415 ms per step)
+    return v ? v : (family == 5 ? 4000ull : family == 4 ? 1600ull : family == 1 ? 480ull : 1000ull);
 }
 
 // n_runs: the long runs (or records) of the buffer; heavy_tiles: 1 KiB tiles of it that took the scan kernel's general path.  Dense =
@@ -41,7 +43,7 @@ bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_
     if ((uint64_t)n_runs * wave_min_density_bytes(m.wave_family) > job.len) return true;
     // (not the two-byte family: its wave kernels find the token grid by walking back to a byte outside the lead range — a fill is
     // the one input where that walk has no end; they give up after 64 KiB and the other path takes over)
-    return m.wave_family != 4 && heavy_tiles * 2048 > job.len && (uint64_t)n_runs * 4096 < job.len;
+    return m.wave_family < 4 && heavy_tiles * 2048 > job.len && (uint64_t)n_runs * 4096 < job.len;
 }
 
 static uint32_t utf8_chars(const std::string& s) {
@@ -103,12 +105,12 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         // source bytes from the leftover's first byte to E: single byte: one per char; UTF-8: its bytes + what the decoder holds of the next char
         const DDecoder& dd = st.decoder.raw();
         uint32_t lback = m.wave_family == 0 ? lc : lb + (dd.needed ? dd.seen + 1u : 0u);
-        if (m.wave_family == 4) {
-            // two-byte family: one or two source bytes per char — which, the text does not say: the bytes in front of E (less the
-            // lead byte the decoder holds) that decode to exactly the leftover
-            const uint32_t pend = dd.dlead ? 1u : 0u;
+        if (m.wave_family >= 4) {
+            // two-byte family / EUC-JP: one to three source bytes per char — which, the text does not say: the bytes in front of E (less
+            // the byte(s) of the token the decoder holds) that decode to exactly the leftover
+            const uint32_t pend = dd.dlead ? (m.wave_family == 5 && dd.dflag ? 2u : 1u) : 0u;
             lback = 0;
-            for (uint32_t cand = lc; lc && cand <= 2 * lc && cand + pend <= E; cand++) {
+            for (uint32_t cand = lc; lc && cand <= 3 * lc && cand + pend <= E; cand++) {
                 size_t hint = 0;
                 const uint8_t* src = view.span(E - pend - cand, cand, &hint);
                 Decoder probe(m.c.encoding);
@@ -138,11 +140,11 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             HIP_TRY(ctx, hipMalloc((void**)&d.d_wave_lut, 256));
             HIP_TRY(ctx, hipMemcpy(d.d_wave_lut, m.wave_lut.data(), 256, hipMemcpyHostToDevice));
         }
-        if (m.wave_family == 4 && !d.d_wave_pairs) {
+        if (m.wave_family == 4 && !d.d_wave_pairs) {   // (family 5 has no 4-bit table)
             HIP_TRY(ctx, hipMalloc((void**)&d.d_wave_pairs, 8192 * 4));
             HIP_TRY(ctx, hipMemcpy(d.d_wave_pairs, m.wave_pairs.data(), 8192 * 4, hipMemcpyHostToDevice));
         }
-        if (m.wave_family == 4 && m.wave_pairs2.size() == 4096 && !d.d_wave_pairs2) {
+        if (m.wave_family >= 4 && m.wave_pairs2.size() == 4096 && !d.d_wave_pairs2) {
             HIP_TRY(ctx, hipMalloc((void**)&d.d_wave_pairs2, 4096 * 4));
             HIP_TRY(ctx, hipMemcpy(d.d_wave_pairs2, m.wave_pairs2.data(), 4096 * 4, hipMemcpyHostToDevice));
         }
@@ -172,7 +174,8 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         P.pairs = d.d_wave_pairs; P.encoding = m.c.encoding; P.entry_skip = m.buf_entry_skip;
         P.swar = m.wave_swar; P.pairs2 = d.d_wave_pairs2;
         if (m.wave_family == 4 && !d.d_wave_pairs2) P.swar.cls = 0;
-        if (const char* e = getenv("SX_WAVE_LUT")) if (atoi(e)) P.swar.cls = 0;   // tests: the class table also where ranges would do
+        if (m.wave_family == 5 && !d.d_wave_pairs2) return SX_WAVE_FALLBACK;
+        if (const char* e = getenv("SX_WAVE_LUT")) if (atoi(e) && m.wave_family != 5) P.swar.cls = 0;   // tests: the class table also where ranges would do
         P.wave_nf = d_u; P.wave_nb = d_u + n_waves; P.wave_in = d_u + 2 * n_waves; P.wave_out = d_u + 3 * n_waves;
         P.wave_fbase = d_fb; P.wave_abase = d_ab;
         // Descriptors for the lane-per-finding writer: room for twice the findings a wavefront is expected to hold (the last buffer's
@@ -330,10 +333,11 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             fin.last_scan_run_leftover.clear();
             // (two-byte family without leftover: a fresh decoder cannot find the token grid in the last bytes; the device says whether
             // the buffer ends inside a token — its last byte is then the lead byte the decoder holds)
-            const bool dbcs_tail = m.wave_family == 4 && !fs.lc;
-            if (dbcs_tail && (final_state & kWvPendBit)) {
+            const bool dbcs_tail = m.wave_family >= 4 && !fs.lc;
+            if (const uint32_t pend = (final_state >> 27) & 3u; dbcs_tail && pend) {
                 size_t hint1 = 0;
                 fin.decoder.raw().dlead = *view.span(len - 1, 1, &hint1);
+                if (pend == 2) fin.decoder.raw().dflag = 1;   // EUC-JP: 8F and the byte behind it are in (sx_codec_core.hpp ddec_eucjp)
             }
             const uint64_t back = dbcs_tail ? 0 : fs.lc ? fs.lback : std::min<uint64_t>(8, len);
             size_t hint = 0;

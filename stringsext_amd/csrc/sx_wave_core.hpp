@@ -99,7 +99,7 @@ SXD u32 wm_select(WvMask m, u32 from, u32 k) {
 struct WvState { u32 lc, lb, lback, cut; };
 SXD u32 wv_pack(const WvState& s) { return s.lc | (s.lb << 7) | (s.lback << 16) | (s.cut << 26); }
 SXD WvState wv_unpack(u32 v) { return WvState{ v & 127u, (v >> 7) & 511u, (v >> 16) & 1023u, (v >> 26) & 1u }; }
-constexpr u32 kWvPendBit = 1u << 27;   // on the state after a buffer's LAST window only: it ends inside a token (double byte)
+constexpr u32 kWvPendBit = 1u << 27;   // on the state after a buffer's LAST window only, bits 27-28: bytes of the token it ends inside (two-byte family: 1; EUC-JP: 1 / 2)
 
 struct WvParams { u32 q, n_min; };
 
@@ -130,6 +130,10 @@ enum { WV_BEFORE = 0, WV_EXACT = 1, WV_AFTER = 2 };   // == SX_PRECISION_*
 // again — the leftover that call consumed still lies at the front of that buffer.)  wv_resolve_probe settles it from the bytes.
 enum { WV_PROBE = 3 };
 SXD u32 wv_probe_pack(u32 lb, u32 lback) { return WV_PROBE | (lb << 8) | (lback << 17); }
+// (bits 27-28: bytes in front of the slice the decoder of the first call holds — `hb` —; bits 29-30, with a leftover at a second
+// call at byte 0: bytes in front of the slice that were the pending token's, not the leftover's)
+SXD u32 wv_probe_hb(u32 prec) { return (prec >> 27) & 3u; }
+SXD u32 wv_probe_pend(u32 prec) { return (prec >> 29) & 3u; }
 
 SXD bool wv_mission_ok(int grep_char, u32 same_block, u32 n_min, u32 q) {
     return grep_char < 0 && !same_block && n_min >= 1 && n_min <= q && q <= 64;
@@ -260,7 +264,7 @@ template <int KIND, class EMIT>
 SXD void wv_window_calls(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, bool skip_idle_calls = true) {
     u32 probe = 0;
     if (w.pre_empty) {
-        if (w.slice_start && st.lb) probe = wv_probe_pack(st.lb, st.lback);
+        if (w.slice_start && st.lb) probe = wv_probe_pack(st.lb, st.lback) | (KIND == 2 ? w.head_pend << 29 : 0u);
         wv_call<KIND>(P, w, st, 0u, 0u, true, false, emit);
     }
     u32 din = 0;
@@ -348,7 +352,7 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, c
     u32 probe = 0;
     // ---- an empty call in front of byte 0 (the byte a pending sequence rejected is read again): it takes the leftover and the cut flag
     if (w.pre_empty) {
-        if (w.slice_start && st.lb) probe = wv_probe_pack(st.lb, st.lback);
+        if (w.slice_start && st.lb) probe = wv_probe_pack(st.lb, st.lback) | (KIND == 2 ? w.head_pend << 29 : 0u);
         const bool cont = st.cut != 0;
         const u32 lc = st.lc, lb = st.lb, lback = st.lback;
         st.lc = 0; st.lb = 0; st.lback = 0; st.cut = 0;
@@ -935,6 +939,142 @@ SXD WvMasks16E wv_classify16_dbcs_swar(const PAIRS& pairs2, const u32* ws6, cons
     return m;
 }
 
+// ------------------------------------------------------------------------------------------
+// EUC-JP (round 4; sx_codec_core.hpp ddec_eucjp): tokens of one byte, of two (a lead A1..FE or 8E with the byte behind it, whatever
+// that is; also 8F with a byte outside A1..FE) and of three (8F, A1..FE, any byte: index jis0212).  A mapped token is a character (F on
+// its first byte, E on its last); an unmapped one is Malformed and the decoder call ends: behind its last byte if that is >= 0x80
+// (MA), in front of it if it is ASCII — the byte is read again as a character of its own (MB, and its own F / E).  The token that
+// STARTS among a lane's 16 bytes is the lane's: its marks may lie one or two bytes beyond the lane (bits 16, 17 of the masks) and
+// are handed to the next lane.  The UTF-8 form of a character has 2 or 3 bytes; the wave path takes Missions whose accepted ones
+// all have the same length (Asian, Cjk, Kana: three), so the lengths need no mask (as wv_win_dbcs_swar).
+// t2: 2 bits per cell (bit 0 mapped, bit 1 accepted), sixteen per word: cells 0 .. 8835 index jis0208, from 8836 on index jis0212.
+// ------------------------------------------------------------------------------------------
+constexpr u32 kWvJisCells = 94 * 94, kWvJisWords = (2 * kWvJisCells + 15) / 16;
+struct WvMasks18 { u32 e, a, f, ma, mb; };
+template <class T2>
+SXD u32 wv_eucjp_cell(const T2& t2, u32 x, u32 y, u32 second_table) {
+    const u32 r = x - 0xA1u, c = y - 0xA1u;
+    if (r >= 94u || c >= 94u) return 0u;
+    const u32 idx = second_table * kWvJisCells + r * 94u + c;
+    return (t2[idx >> 4] >> ((idx & 15u) * 2)) & 3u;
+}
+// the code of the token that starts with `lead`: b1 / b2 = the bytes behind it, three = it has three bytes
+template <class T2>
+SXD u32 wv_eucjp_token_code(const T2& t2, u32 kana, u32 lead, u32 b1, u32 b2, bool three) {
+    if (three) return wv_eucjp_cell(t2, b1, b2, 1u);
+    if (lead == 0x8Eu) return (b1 - 0xA1u) < 0x3Fu ? (1u | (kana ? 2u : 0u)) : 0u;
+    if (lead == 0x8Fu) return 0u;
+    return wv_eucjp_cell(t2, lead, b1, 0u);
+}
+// The statement, byte by byte (the host harness compares the kernels' bit arithmetic with it): b[0..23] = the bytes at lane offset
+// -4 .. +19, n_exist = how many exist from the lane's first byte on; first = bytes at the lane's start that belong to a token begun
+// before (0 .. 2); lut1[b]: WVC_VALID / WVC_ACC of a byte below 0x80, WVC_LEAD for A1..FE, 8E, 8F.  *over = the same for the next lane.
+template <class LUT, class T2>
+SXD WvMasks18 wv_eucjp_walk(const LUT& lut1, const T2& t2, u32 kana, const u8* b, u32 n_exist, u32 first, u32* over) {
+    WvMasks18 m{ 0, 0, 0, 0, 0 };
+    u32 pos = first;
+    while (pos < 16 && pos < n_exist) {
+        const u32 c = b[4 + pos], cls = lut1[c];
+        if (!(cls & WVC_LEAD)) {
+            if (cls & WVC_VALID) { m.f |= 1u << pos; m.e |= 1u << pos; if (cls & WVC_ACC) m.a |= 1u << pos; }
+            else m.ma |= 1u << pos;
+            pos++;
+            continue;
+        }
+        const u32 b1 = pos + 1 < n_exist ? b[4 + pos + 1] : 0u;
+        const bool three = c == 0x8Fu && pos + 1 < n_exist && b1 >= 0xA1u && b1 <= 0xFEu;
+        const u32 len = three ? 3u : 2u;
+        if (pos + len > n_exist) { pos += len; break; }   // the buffer ends inside the token: it stays pending
+        const u32 b2 = three ? b[4 + pos + 2] : 0u, last = three ? b2 : b1, end = pos + len - 1;
+        const u32 code = wv_eucjp_token_code(t2, kana, c, b1, b2, three);
+        if (code & 1u) { m.f |= 1u << pos; m.e |= 1u << end; if (code & 2u) m.a |= 1u << end; }
+        else if (last < 0x80u) {
+            m.mb |= 1u << end; m.f |= 1u << end; m.e |= 1u << end;
+            if (lut1[last] & WVC_ACC) m.a |= 1u << end;
+        } else m.ma |= 1u << end;
+        pos += len;
+    }
+    *over = pos > 16 ? pos - 16 : 0u;
+    return m;
+}
+// ---- the same as bit arithmetic.  Byte classes (bit j = the lane's byte j; bits 16 .. 19 the four bytes behind the lane)
+struct WvEucPre { u32 hi, lr, c8f, asc, a1; };   // A1..FE / A1..FE, 8E, 8F / 8F / < 0x80 / accepted and < 0x80
+SXD u32 wv_swar_eq(u32 v, u32 pat) { const u32 y = v ^ pat; return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u; }
+template <int K>
+SXD WvEucPre wv_eucjp_classes_swar(const WvSwar& R, const u32* x5, u32 n_exist) {
+    const u32 kM = 0x80808080u;
+    u32 fh[5], f8[5], ff[5], fs[5], fa[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const u32 v = x5[k], t = v & 0x7F7F7F7Fu;
+        fh[k] = (t + 0x5F5F5F5Fu) & ~(t + 0x01010101u) & v & kM;      // low seven bits in 21 .. 7E, bit 7 set: A1..FE
+        f8[k] = wv_swar_eq(v & 0xFEFEFEFEu, 0x8E8E8E8Eu);              // 8E, 8F
+        ff[k] = f8[k] & (v << 7);                                      // ... 8F
+        fs[k] = ~v & kM;
+        fa[k] = wv_swar_accepted<K>(R, v);
+    }
+    const u32 ex = n_exist >= 20 ? 0xFFFFFu : ((1u << n_exist) - 1u);
+    WvEucPre c;
+    c.hi = (wv_movemask16_b7(fh[0], fh[1], fh[2], fh[3]) | (wv_movemask16_b7(fh[4], 0, 0, 0) << 16)) & ex;
+    c.lr = (wv_movemask16_b7(fh[0] | f8[0], fh[1] | f8[1], fh[2] | f8[2], fh[3] | f8[3]) | (wv_movemask16_b7(fh[4] | f8[4], 0, 0, 0) << 16)) & ex;
+    c.c8f = wv_movemask16_b7(ff[0], ff[1], ff[2], ff[3]) & ex;
+    c.asc = (wv_movemask16_b7(fs[0], fs[1], fs[2], fs[3]) | (wv_movemask16_b7(fs[4], 0, 0, 0) << 16)) & ex;
+    c.a1 = (wv_movemask16_b7(fa[0], fa[1], fa[2], fa[3]) | (wv_movemask16_b7(fa[4], 0, 0, 0) << 16)) & ex;
+    return c;
+}
+// token starts for a hang-over of 0, 1 and 2 bytes: St[s] holds bit p if a token starts at byte p (bits >= 16: in the next lane);
+// the byte behind a byte outside the lead range always starts one.  One round of wv_eucjp_orbit_step per token length in a row of
+// lead-range bytes; the kernels iterate while any lane changes.
+struct WvEucOrbit { u32 st[3], l2, l3; };
+SXD WvEucOrbit wv_eucjp_orbit_init(const WvEucPre& c) {
+    WvEucOrbit o;
+    o.l3 = c.c8f & (c.hi >> 1) & 0xFFFFu;
+    o.l2 = c.lr & ~o.l3 & 0xFFFFu;
+    const u32 known = (~c.lr & 0xFFFFu) << 1;
+    o.st[0] = known | 1u; o.st[1] = known | 2u; o.st[2] = known | 4u;
+    return o;
+}
+SXD bool wv_eucjp_orbit_step(WvEucOrbit& o) {
+    bool changed = false;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const u32 nw = o.st[s] | ((o.st[s] & o.l2) << 2) | ((o.st[s] & o.l3) << 3);
+        changed = changed || nw != o.st[s];
+        o.st[s] = nw;
+    }
+    return changed;
+}
+SXD u32 wv_eucjp_over(const WvEucOrbit& o, u32 s) { return wv_ctz64((u64)(o.st[s] >> 16) | 8ull); }   // bytes of the next lane the last token covers
+// the lane's masks from its token starts.  ws6: the dwords at lane offset -4 .. +19; cov_in: bytes at the lane's start that belong to a
+// token begun before; n_exist: existing bytes from the lane's first on (<= 20)
+template <class T2>
+SXD WvMasks18 wv_classify16_eucjp_swar(const T2& t2, u32 kana, const u32* ws6, const WvEucPre& c, const WvEucOrbit& o, u32 cov_in, u32 n_exist) {
+    const u32 ex = n_exist >= 20 ? 0xFFFFFu : ((1u << n_exist) - 1u);
+    const u32 s0 = o.st[cov_in] & ~((1u << cov_in) - 1u) & 0xFFFFu & ex;   // token starts among the lane's bytes
+    const u32 multi = s0 & c.lr;
+    WvMasks18 m{ 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const u32 has = (multi >> (2 * k)) & 3u;
+        if (!has) continue;
+        const u32 odd = has >> 1, p = 2u * (u32)k + odd;
+        const int bi = 4 + 2 * k;                                  // byte index of lane offset 2k in ws6
+        const u32 w32 = (bi & 3) == 0 ? ws6[bi >> 2] : ((ws6[bi >> 2] >> 16) | (ws6[(bi >> 2) + 1 > 5 ? 5 : (bi >> 2) + 1] << 16));
+        const u32 t = odd ? (w32 >> 8) | ((k == 7 ? ws6[5] >> 16 : 0u) << 24) : w32;   // the token's bytes (an odd start in the last slot: byte 18 too)
+        const bool three = ((o.l3 >> p) & 1u) != 0;
+        const u32 len = three ? 3u : 2u, end = p + len - 1;
+        if (p + len > n_exist) continue;                          // pending at the buffer's end
+        const u32 lead = t & 0xFFu, b1 = (t >> 8) & 0xFFu, b2 = (t >> 16) & 0xFFu, last = three ? b2 : b1;
+        const u32 code = wv_eucjp_token_code(t2, kana, lead, b1, b2, three);
+        if (code & 1u) { m.f |= 1u << p; m.e |= 1u << end; m.a |= (code >> 1) << end; }
+        else if (last < 0x80u) { m.mb |= 1u << end; m.f |= 1u << end; m.e |= 1u << end; m.a |= ((c.a1 >> end) & 1u) << end; }
+        else m.ma |= 1u << end;
+    }
+    const u32 one = s0 & ~c.lr;                                     // tokens of one byte: a character if below 0x80
+    m.f |= one & c.asc; m.e |= one & c.asc; m.a |= one & c.a1; m.ma |= one & ~c.asc;
+    return m;
+}
+
 // the window of a two-byte Mission.  back: the E | MA bits and the F bits of the byte right in front of the window.
 SXD WvWin wv_win_dbcs(WvMask E, WvMask A, WvMask F, WvMask G, WvMask MA, WvMask MB, WvMask O2, WvMask O3, WvMask O4,
                       bool back_done, bool back_f, bool has_back, bool slice_start, u32 n, u32 n_min) {
@@ -967,6 +1107,26 @@ SXD WvWin wv_win_dbcs_swar(WvMask E, WvMask A, WvMask F, WvMask MA, WvMask MB, u
                        slice_start, n, n_min);
 }
 
+// The window of an EUC-JP Mission from the five masks of wv_classify16_eucjp_swar.  done1 / done2: the byte one / two in front of the
+// window ends a token (E | MA); f1 / f2: it begins a character; has1 / has2: it exists.  A token may have two bytes in front of the
+// window (8F, A1..FE): head_pend / head_back / probe_hb go up to 2, tail_pend counts the bytes of the token the window ends inside.
+SXD WvWin wv_win_eucjp_swar(WvMask E, WvMask A, WvMask F, WvMask MA, WvMask MB, u32 char_len, bool done1, bool done2, bool f1, bool f2,
+                            bool has1, bool has2, bool slice_start, u32 n, u32 n_min) {
+    const WvMask PE = wm_andn(E, F), APE = wm_and(A, PE);
+    const WvMask g1 = wm_shr(APE, 1), g2 = wm_shr(wm_andn(g1, F), 1);        // the bytes in front of an accepted character's last one
+    const WvMask G = wm_or(A, wm_or(g1, g2));
+    WvWin w = wv_win_dbcs(E, A, F, G, MA, MB, PE, char_len >= 3 ? APE : wm_zero(), wm_zero(), done1, f1, has1, slice_start, n, n_min);
+    const bool open1 = has1 && !done1, open2 = open1 && has2 && !done2;
+    w.head_pend = open2 ? 2u : open1 ? 1u : 0u;
+    w.head_back = (open1 && f1) ? 1u : (open2 && f2) ? 2u : 0u;
+    w.probe_hb = slice_start ? w.head_back : 0u;
+    const WvMask dn = wm_or(E, MA);
+    const bool last_open = n && !wm_test(dn, n - 1);
+    const bool prev_open = n >= 2 ? !wm_test(dn, n - 2) : open1;
+    w.tail_pend = last_open ? (prev_open ? 2u : 1u) : 0u;
+    return w;
+}
+
 // WV_PROBE settled (UTF-8): `slice` = the slice's first bytes (n of them, n <= 32 is enough), `left` = the lb bytes of the
 // leftover.  The fresh decoder's output (at most 8 bytes, whole chars) must equal the first bytes of [leftover][the call's output];
 // the call's output begins like the fresh decoder's (same bytes, same neutral decoder).
@@ -989,10 +1149,12 @@ SXD u32 wv_resolve_probe_dbcs(int enc, const uint16_t* table, const u8* slice, u
     ddec_reset(real, enc, table); ddec_reset(fresh, enc, table);
     u8 sink[8], out[16], probe[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, left[64 * 4 + 8];
     if (lb) (void)wv_transcode_dbcs(enc, table, left_src, lsrc, left);
-    if (hb) (void)ddec_big5(real, slice - hb, hb, sink, sizeof sink, false);
+    const bool euc = enc == kEncEucJp;
+    if (hb) (void)(euc ? ddec_eucjp(real, slice - hb, hb, sink, sizeof sink, false) : ddec_big5(real, slice - hb, hb, sink, sizeof sink, false));
     const u32 m = n < 32 ? n : 32;
-    const DStep ro = ddec_big5(real, slice, m < 12 ? m : 12, out, sizeof out, false);   // (its first 8 bytes are all that is compared)
-    const DStep pr = ddec_big5(fresh, slice, m, probe, 8, true);
+    const DStep ro = euc ? ddec_eucjp(real, slice, m < 12 ? m : 12, out, sizeof out, false)
+                         : ddec_big5(real, slice, m < 12 ? m : 12, out, sizeof out, false);   // (its first 8 bytes are all that is compared)
+    const DStep pr = euc ? ddec_eucjp(fresh, slice, m, probe, 8, true) : ddec_big5(fresh, slice, m, probe, 8, true);
     bool same = pr.written != 0;
     for (u32 t = 0; t < pr.written && same; t++) {
         const u8 have = t < lb ? left[t] : (t - lb < ro.written ? out[t - lb] : (u8)0);
@@ -1008,6 +1170,12 @@ SXD u32 wv_transcode_dbcs(int enc, const uint16_t* table, const u8* s, u32 n, u8
     while (p < n) {
         const u8 b = s[p];
         if (b < 0x80) { dst[w++] = b; p++; continue; }
+        if (enc == kEncEucJp) {   // 8E + katakana, 8F + a cell of index jis0212, else a cell of index jis0208 (sx_codec_core.hpp ddec_eucjp)
+            if (b == 0x8E) { w += dput_cp(dst + w, 0xFF61u - 0xA1u + s[p + 1]); p += 2; }
+            else if (b == 0x8F) { w += dput_cp(dst + w, table[kJisN + (s[p + 1] - 0xA1u) * 94u + (s[p + 2] - 0xA1u)]); p += 3; }
+            else { w += dput_cp(dst + w, table[(b - 0xA1u) * 94u + (s[p + 1] - 0xA1u)]); p += 2; }
+            continue;
+        }
         if (two_byte_lead(enc, b)) {
             u32 second = 0;
             w += dput_cp(dst + w, two_byte_lookup(enc, table, b, s[p + 1], &second));

@@ -60,11 +60,11 @@ SXD void wv_write_finding(const WaveParams& P, u64 fi, u8* a, u64 a_off, u64 win
     r.str_off = (u32)(a_off + P.str_off_base);
     r.str_len = out_len;
     if ((prec & 0xFFu) == WV_PROBE) {   // sx_wave_core.hpp WV_PROBE: this call starts at the slice's byte 0
-        const u32 lb = (prec >> 8) & 511u, lback = (prec >> 17) & 1023u, hb = prec >> 27;
+        const u32 lb = (prec >> 8) & 511u, lback = (prec >> 17) & 1023u, hb = wv_probe_hb(prec), pend = wv_probe_pend(prec);
         const u64 avail = P.len - win_pos;
-        if (FAM == 4)   // (a leftover at a second call at byte 0: the byte in front of the slice was a lead byte, not the leftover's)
+        if (FAM >= 4)   // (a leftover at a second call at byte 0: the `pend` bytes in front of the slice were the pending token's, not the leftover's)
             prec = wv_resolve_probe_dbcs((int)P.encoding, P.table, P.data + win_pos, avail < 32 ? (u32)avail : 32u,
-                                         P.data + (win_pos - lback), lb ? lback - 1 : 0u, lb, hb);
+                                         P.data + (win_pos - lback), lb ? lback - pend : 0u, lb, hb);
         else if (FAM == 1) prec = wv_resolve_probe(P.data + win_pos, avail < 32 ? (u32)avail : 32u, P.data + (win_pos - lback), lb);
         else prec = WV_EXACT;   // (single-byte decoders never leave the probe open)
     }
@@ -82,7 +82,7 @@ SXD void wv_write_finding(const WaveParams& P, u64 fi, u8* a, u64 a_off, u64 win
         ((sx_finding16*)P.findings)[fi] = p;
     } else P.findings[fi] = r;
     const u8* s = P.data + (u64)((long long)win_pos + src_rel);
-    if (FAM == 4) (void)wv_transcode_dbcs((int)P.encoding, P.table, s, src_len, a);
+    if (FAM >= 4) (void)wv_transcode_dbcs((int)P.encoding, P.table, s, src_len, a);
     else if (out_len == src_len) {     // every char is one byte on both sides (ASCII; UTF-8 input)
         for (u32 t = 0; t < src_len; t++) a[t] = s[t];
     } else {
@@ -116,7 +116,7 @@ template <int WPB> SXD void wave_lds_sync() {
 
 // masks a wavefront keeps per batch (16 bits per lane and tile each).  CLS 1: the classes come from ranges (sx_device.hpp WvSwar): a
 // single-byte Mission then stores accepted / >= 0x80 only, a two-byte one E, A, F, MA, MB (G and the lengths follow from them)
-constexpr int wv_n_masks(int fam, int cls) { return fam == 4 ? (cls ? 5 : 9) : fam == 1 ? 6 : cls ? 2 : 4; }
+constexpr int wv_n_masks(int fam, int cls) { return fam == 5 ? 5 : fam == 4 ? (cls ? 5 : 9) : fam == 1 ? 6 : cls ? 2 : 4; }
 constexpr u32 kMaskWords = kWvMaxTiles * 32 + 8;
 constexpr u32 wv_lds_words(int fam, int cls) {   // ... and the descriptors staged in their place need kWvStage x 3 x 64 words
     return (u32)wv_n_masks(fam, cls) * kMaskWords > kWvStage * 192u ? (u32)wv_n_masks(fam, cls) * kMaskWords : kWvStage * 192u;
@@ -138,18 +138,19 @@ constexpr u32 wv_lds_words(int fam, int cls) {   // ... and the descriptors stag
 #define SX_WV_OCC4S 4   // ... the two-byte family with SWAR classes and 2-bit pair codes (40 KB of LDS per block of four wavefronts)
 #endif
 constexpr int wv_occ(int mode, int fam, int cls) {
-    if (mode == 0 && fam == 4 && cls) return SX_WV_OCC4S;
-    return mode == 0 ? (fam == 4 ? SX_WV_OCC4 : fam == 1 ? SX_WV_OCC1 : SX_WV_OCC0) : (fam == 4 ? SX_WV_OCCW4 : fam == 1 ? SX_WV_OCCW1 : SX_WV_OCCW0);
+    if (mode == 0 && fam >= 4 && cls) return SX_WV_OCC4S;
+    return mode == 0 ? (fam >= 4 ? SX_WV_OCC4 : fam == 1 ? SX_WV_OCC1 : SX_WV_OCC0) : (fam >= 4 ? SX_WV_OCCW4 : fam == 1 ? SX_WV_OCCW1 : SX_WV_OCCW0);
 }
 template <int MODE, int FAM, int WPB, int CLS>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ(MODE, FAM, CLS)))) void wave_replay_kernel(const WaveParams P) {
     // FAM 0: valid, accepted, O2, O3 (CLS 1: accepted, >= 0x80); FAM 1: E, A, F, MA, MB, G; FAM 4: E, A, F, MA, MB, G, O2, O3, O4 — 16 bits per lane and tile
     __shared__ u32 lds_all[WPB][wv_lds_words(FAM, CLS)];
     __shared__ u8 lds_lut[CLS ? 4 : 256];
-    __shared__ u32 lds_pairs[FAM == 4 ? (CLS ? 4096 : 8192) : 1];
+    __shared__ u32 lds_pairs[FAM == 5 ? kWvJisWords + 3 : FAM == 4 ? (CLS ? 4096 : 8192) : 1];
     const u32 lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
     if (!CLS && threadIdx.x < 64) ((u32*)lds_lut)[threadIdx.x] = ((const u32*)P.lut)[threadIdx.x];
     if (FAM == 4) for (u32 i = threadIdx.x; i < (CLS ? 4096u : 8192u); i += 64 * WPB) lds_pairs[i] = CLS ? P.pairs2[i] : P.pairs[i];
+    if (FAM == 5) for (u32 i = threadIdx.x; i < kWvJisWords; i += 64 * WPB) lds_pairs[i] = P.pairs2[i];
     __syncthreads();
     u32* const lds_base = lds_all[wib];
     auto lds_mask = [&](int k) -> u32* { return lds_base + (u32)k * kMaskWords; };
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         const u64 next_t0 = wv_tile0(span_hi);   // the next batch's first tile (the batches' windows are contiguous)
         bool have_next = false;
         u32 cov_next = 0;
-        if (FAM == 4 && (g0 == gw || !dbcs_valid)) {
+        if (FAM >= 4 && (g0 == gw || !dbcs_valid)) {
             dbcs_cov = 0;
             long long lo = (long long)tile0;
             while (lo > 0) {
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 if (!reset) {
                     const u32x4 x = *(const u32x4*)(P.data + o);
                     const u32 xs[4] = { x.x, x.y, x.z, x.w };
-                    if (CLS) reset = wv_dbcs_classes_swar<1>(SW, xs, 16u).lr != 0xFFFFu;
+                    if (FAM == 5) { const u32 x5[5] = { xs[0], xs[1], xs[2], xs[3], 0u }; reset = (wv_eucjp_classes_swar<1>(SW, x5, 16u).lr & 0xFFFFu) != 0xFFFFu; }
+                    else if (CLS) reset = wv_dbcs_classes_swar<1>(SW, xs, 16u).lr != 0xFFFFu;
                     else for (int k = 0; k < 16; k++) reset = reset || !(lds_lut[(xs[k >> 2] >> (8 * (k & 3))) & 0xFFu] & WVC_LEAD);
                 }
                 if (__ballot(reset)) break;
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         u32x4 xa = issue(0), xb = issue(1), xc = issue(2), xd = issue(3);
         // the four bytes in front of tile0 and behind the batch's last tile (the same address in every lane)
         u32 edge_back = tile0 >= 4 ? *(const u32*)(P.data + (tile0 - 4)) : 0u;
+        u32 euc_spill = 0;   // EUC-JP: marks of the tile's last tokens that lie on the next tile's first two bytes (five masks x 2 bits)
         const u32 edge_after = FAM == 0 ? 0u : (u32)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(n_tiles * kTileBytes), 0, 0);
 
         // one tile: t < 0 = the two-byte family's way back to a token boundary (nothing is stored for those)
@@ -273,7 +276,48 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 if (n_ahead < 4) ahead = n_ahead ? ahead & ((1u << (8 * n_ahead)) - 1u) : 0u;
                 const u32 ws6[6] = { back, x.x, x.y, x.z, x.w, ahead };
                 const u32 have_lo = has_back ? 0u : 4u, have_hi = 4u + avail + n_ahead;
-                if (FAM == 1) {
+                if (FAM == 5) {
+                    // EUC-JP: token starts for a hang-over of 0 / 1 / 2 bytes (a wave-uniform loop: one round per token in a row of lead-range
+                    // bytes), the hang-overs composed along the wavefront, a table cell per token, marks that lie beyond the lane handed on
+                    WvEucPre pc;
+                    if (SW.n <= 1) pc = wv_eucjp_classes_swar<1>(SW, &ws6[1], avail + n_ahead);
+                    else if (SW.n <= 3) pc = wv_eucjp_classes_swar<3>(SW, &ws6[1], avail + n_ahead);
+                    else pc = wv_eucjp_classes_swar<6>(SW, &ws6[1], avail + n_ahead);
+                    WvEucOrbit ob = wv_eucjp_orbit_init(pc);
+                    while (__ballot(wv_eucjp_orbit_step(ob))) {}
+                    u32 T = wv_eucjp_over(ob, 0) | (wv_eucjp_over(ob, 1) << 2) | (wv_eucjp_over(ob, 2) << 4);   // hang-over out for hang-over in 0 / 1 / 2
+                    const bool at_zero = tile0 == 0 && rel == 0;   // the buffer's byte 0: the token pending on entry decides
+                    if (at_zero) { const u32 o = (T >> (2 * P.entry_skip)) & 3u; T = o | (o << 2) | (o << 4); }
+                    u32 out_here;
+                    if (!__ballot((pc.lr & 0xFFFFu) == 0xFFFFu && !at_zero)) out_here = T & 3u;   // every lane holds a byte outside the lead range
+                    else {
+                        u32 Fc = T;
+#pragma unroll
+                        for (u32 d = 1; d < 64; d <<= 1) {         // inclusive composition: T_i o ... o T_0
+                            const u32 g = wv_shfl(Fc, lane >= d ? lane - d : lane);
+                            u32 r = 0;
+#pragma unroll
+                            for (int q = 0; q < 3; q++) r |= ((Fc >> (2 * ((g >> (2 * q)) & 3u))) & 3u) << (2 * q);
+                            if (lane >= d) Fc = r;
+                        }
+                        out_here = (Fc >> (2 * dbcs_cov)) & 3u;
+                    }
+                    u32 cov_in = wv_from_prev(out_here, dbcs_cov);
+                    if (at_zero) cov_in = P.entry_skip;
+                    dbcs_cov = (u32)__builtin_amdgcn_readlane(out_here, 63);
+                    if ((long long)tile0 + (long long)(t + 1) * (long long)kTileBytes == (long long)next_t0) { cov_next = dbcs_cov; have_next = true; }
+                    const WvMasks18 m = wv_classify16_eucjp_swar(lds_pairs, SW.kana, ws6, pc, ob, cov_in, avail + n_ahead);
+                    const u32 sp = (m.e >> 16) | ((m.a >> 16) << 2) | ((m.f >> 16) << 4) | ((m.ma >> 16) << 6) | ((m.mb >> 16) << 8);
+                    const u32 si = wv_from_prev(sp, euc_spill);     // what the lane in front marked on my first two bytes
+                    euc_spill = (u32)__builtin_amdgcn_readlane(sp, 63);
+                    if (t >= 0) {
+                        ((uint16_t*)lds_mask(0))[idx] = (uint16_t)(m.e | (si & 3u));
+                        ((uint16_t*)lds_mask(1))[idx] = (uint16_t)(m.a | ((si >> 2) & 3u));
+                        ((uint16_t*)lds_mask(2))[idx] = (uint16_t)(m.f | ((si >> 4) & 3u));
+                        ((uint16_t*)lds_mask(3))[idx] = (uint16_t)(m.ma | ((si >> 6) & 3u));
+                        ((uint16_t*)lds_mask(FAM == 5 ? 4 : 0))[idx] = (uint16_t)(m.mb | ((si >> 8) & 3u));
+                    }
+                } else if (FAM == 1) {
                     u8 b[24];
 #pragma unroll
                     for (int k = 0; k < 24; k++) b[k] = (u8)(ws6[k >> 2] >> (8 * (k & 3)));
@@ -337,7 +381,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 }
             }
         };
-        if (FAM == 4 && t_first < 0) {   // the way back to a token boundary: plain loads, one tile after the other (a wavefront's first batch)
+        if (FAM >= 4 && t_first < 0) {   // the way back to a token boundary: plain loads, one tile after the other (a wavefront's first batch)
             u32 eb = 0;
             {
                 const long long first = (long long)tile0 + (long long)t_first * (long long)kTileBytes;
@@ -363,7 +407,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             edge_back = (u32)__builtin_amdgcn_readlane(x.w, 63);
         }
         wave_lds_sync<WPB>();
-        if (FAM == 4) { dbcs_valid = have_next; if (have_next) dbcs_cov = cov_next; }   // (else the next batch walks back again)
+        if (FAM >= 4) { dbcs_valid = have_next; if (have_next) dbcs_cov = cov_next; }   // (else the next batch walks back again)
 
 #if defined(SX_WV_EXP) && SX_WV_EXP == 1   // experiments (tools/build_variant.sh): what the classification alone costs
         { u32 acc = 0; for (int k = 0; k < wv_n_masks(FAM, CLS); k++) acc ^= lds_mask(k)[lane]; tot_f += acc & 1u; continue; }
@@ -377,7 +421,16 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             else if (FAM == 0)
                 w = wv_win_single(wv_extract(lds_mask(0), o, n), wv_extract(lds_mask(1), o, n), wv_extract(lds_mask(CLS ? 0 : 2), o, n),
                                   wv_extract(lds_mask(CLS ? 0 : 3), o, n), n, P.n_min);
-            else if (FAM == 4) {
+            else if (FAM == 5) {
+                // (the two bytes in front of the window: one bit each of three masks)
+                auto bit = [&](int k, u32 at) -> u32 { return (lds_mask(k)[at >> 5] >> (at & 31u)) & 1u; };
+                const u32 o1 = o >= 1 ? o - 1 : 0u, o2 = o >= 2 ? o - 2 : 0u;
+                const bool has1 = ws >= 1 && o >= 1, has2 = ws >= 2 && o >= 2;
+                const bool done1 = !has1 || (bit(0, o1) | bit(3, o1)) != 0, done2 = !has2 || (bit(0, o2) | bit(3, o2)) != 0;
+                w = wv_win_eucjp_swar(wv_extract(lds_mask(0), o, n), wv_extract(lds_mask(1), o, n), wv_extract(lds_mask(2), o, n), wv_extract(lds_mask(3), o, n),
+                                      wv_extract(lds_mask(FAM == 5 ? 4 : 0), o, n), SW.hi_len, done1, done2, has1 && bit(2, o1), has2 && bit(2, o2), has1, has2,
+                                      ws % kWvSlice == 0, n, P.n_min);
+            } else if (FAM == 4) {
                 // (the byte in front of the window: one bit of three masks)
                 const u32 ob = o >= 1 ? o - 1 : 0u;
                 const u32 eb = o >= 1 ? (lds_mask(0)[ob >> 5] >> (ob & 31u)) & 1u : 1u, mab = o >= 1 ? (lds_mask(3)[ob >> 5] >> (ob & 31u)) & 1u : 0u;
@@ -475,8 +528,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         tot_f += bt >> 18; tot_b += bt & 0x3FFFFu;
         if (g0 + kWvBatch >= own_end && MODE == 0) {
             // (the state after a buffer's last window also says whether it ends inside a token: the next buffer's decoder holds that byte)
-            const u32 pend = FAM == 4 ? (u32)__builtin_amdgcn_readlane(w.tail_pend, last_lane) : 0u;
-            if (lane == 0) P.wave_out[v] = last_out | (own_end == P.g_hi && pend ? kWvPendBit : 0u);
+            const u32 pend = FAM >= 4 ? (u32)__builtin_amdgcn_readlane(w.tail_pend, last_lane) : 0u;
+            if (lane == 0) P.wave_out[v] = last_out | (own_end == P.g_hi ? pend << 27 : 0u);
         }
     }
     if (MODE == 0 && lane == 0) { P.wave_nf[v] = tot_f; P.wave_nb[v] = tot_b; P.wave_in[v] = assumed_in; }
@@ -520,7 +573,8 @@ hipError_t launch_wave_emit(const WaveParams& P, uint64_t v0, uint64_t v1, hipSt
     WaveParams Q = P;
     Q.v0 = v0; Q.v1 = v1;
     const dim3 grid((unsigned)((v1 - v0 + 3) / 4));
-    if (P.family == 4) hipLaunchKernelGGL((wave_emit_kernel<4>), grid, dim3(256), 0, stream, Q);
+    if (P.family == 5) hipLaunchKernelGGL((wave_emit_kernel<5>), grid, dim3(256), 0, stream, Q);
+    else if (P.family == 4) hipLaunchKernelGGL((wave_emit_kernel<4>), grid, dim3(256), 0, stream, Q);
     else if (P.family == 1) hipLaunchKernelGGL((wave_emit_kernel<1>), grid, dim3(256), 0, stream, Q);
     else hipLaunchKernelGGL((wave_emit_kernel<0>), grid, dim3(256), 0, stream, Q);
     return hipGetLastError();
@@ -547,7 +601,8 @@ hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint
     WaveParams Q = P;
     Q.v0 = v0; Q.v1 = v1;
     const unsigned dyn = getenv("SX_WAVE_DYN_LDS") ? (unsigned)atoi(getenv("SX_WAVE_DYN_LDS")) : 0u;   // experiments: fewer wavefronts per CU
-    if (P.family == 4 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 1>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
+    if (P.family == 5) hipLaunchKernelGGL((wave_replay_kernel<0, 5, 4, 1>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
+    else if (P.family == 4 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 1>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 0>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<0, 1, 1, 0>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
     else if (P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 0, 1, 1>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
@@ -574,7 +629,8 @@ hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipS
     WaveParams Q = P;
     Q.v0 = v0; Q.v1 = v1;
     const unsigned dyn = getenv("SX_WAVE_DYN_LDS") ? (unsigned)atoi(getenv("SX_WAVE_DYN_LDS")) : 0u;
-    if (P.family == 4 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4, 1>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
+    if (P.family == 5) hipLaunchKernelGGL((wave_replay_kernel<1, 5, 4, 1>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
+    else if (P.family == 4 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4, 1>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4, 0>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<1, 1, 1, 0>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
     else if (P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<1, 0, 1, 1>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);

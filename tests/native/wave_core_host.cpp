@@ -34,11 +34,11 @@ struct WriteEmit {
         r.str_off = (u32)(a_off + P->str_off_base);
         r.str_len = out_len;
         if ((prec & 0xFFu) == WV_PROBE) {   // sx_wave_core.hpp WV_PROBE: this call starts at the slice's byte 0
-            const u32 lb = (prec >> 8) & 511u, lback = (prec >> 17) & 1023u, hb = prec >> 27;
+            const u32 lb = (prec >> 8) & 511u, lback = (prec >> 17) & 1023u, hb = wv_probe_hb(prec), pend = wv_probe_pend(prec);
             const u64 avail = P->len - win_pos;
-            if (P->family == 4)   // (a leftover at a second call at byte 0: the byte in front of the slice was a lead byte, not the leftover's)
+            if (P->family >= 4)   // (a leftover at a second call at byte 0: the bytes in front of the slice were the pending token's, not the leftover's)
                 prec = wv_resolve_probe_dbcs((int)P->encoding, P->table, P->data + win_pos, avail < 32 ? (u32)avail : 32u,
-                                             P->data + (win_pos - lback), lb ? lback - 1 : 0u, lb, hb);
+                                             P->data + (win_pos - lback), lb ? lback - pend : 0u, lb, hb);
             else prec = wv_resolve_probe(P->data + win_pos, avail < 32 ? (u32)avail : 32u, P->data + (win_pos - lback), lb);
         }
         r.precision = (u8)prec;
@@ -48,7 +48,7 @@ struct WriteEmit {
         r.slice_index = (u32)(soff / kWvSlice) + P->slice_base;
         *f++ = r;
         const u8* s = P->data + (u64)((long long)win_pos + src_rel);
-        if (P->family == 4) { if (wv_transcode_dbcs((int)P->encoding, P->table, s, src_len, a) != out_len) bad_len = true; }
+        if (P->family >= 4) { if (wv_transcode_dbcs((int)P->encoding, P->table, s, src_len, a) != out_len) bad_len = true; }
         else if (out_len == src_len) memcpy(a, s, src_len);
         else {
             u32 w = 0;
@@ -117,7 +117,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
         const u64 next_t0 = wv_tile0(span_hi);
         bool have_next = false;
         u32 cov_next = 0;
-        if (P.family == 4 && (g0 == gw || !dbcs_valid)) {   // as the kernel: back to a tile that holds a byte outside the lead range
+        if (P.family >= 4 && (g0 == gw || !dbcs_valid)) {   // as the kernel: back to a tile that holds a byte outside the lead range
             dbcs_cov = 0;
             long long lo = (long long)tile0;
             while (lo > 0) {
@@ -177,6 +177,34 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                     ((uint16_t*)lds[5].data())[idx] = (uint16_t)m.g;
                     continue;
                 }
+                if (P.family == 5) {   // EUC-JP: the statement byte by byte, the kernels' bit arithmetic next to it, marks beyond the lane handed on
+                    static u32 spill[5];   // (of the lane in front: e, a, f, ma, mb bits 16..17)
+                    if (t == t_first && l == 0) for (u32& v5 : spill) v5 = 0;
+                    u32 cov_in = l == 0 ? dbcs_cov : outs[l - 1];
+                    if (soff == 0) cov_in = P.entry_skip;
+                    const u32 n_exist = avail + n_ahead;
+                    u8 bz[24];
+                    for (int k = 0; k < 24; k++) bz[k] = ((u32)k >= have_lo && (u32)k < have_hi) ? b[k] : (u8)0;
+                    u32 over = 0;
+                    const WvMasks18 m0 = wv_eucjp_walk(P.lut, P.pairs2, P.swar.kana, bz, n_exist, cov_in, &over);
+                    const WvEucPre pc = wv_eucjp_classes_swar<6>(P.swar, &ws6[1], n_exist);
+                    WvEucOrbit ob = wv_eucjp_orbit_init(pc);
+                    while (wv_eucjp_orbit_step(ob)) {}
+                    const WvMasks18 m = wv_classify16_eucjp_swar(P.pairs2, P.swar.kana, ws6, pc, ob, cov_in, n_exist);
+                    if (soff >= 0 && avail == 16 && wv_eucjp_over(ob, cov_in) != over) return false;
+                    if (m.e != m0.e || m.a != m0.a || m.f != m0.f || m.ma != m0.ma || m.mb != m0.mb) return false;
+                    outs[l] = soff < 0 ? 0u : (avail == 16 ? over : 0u);
+                    if (l == 63) {
+                        dbcs_cov = outs[63];
+                        if ((long long)tile0 + (long long)(t + 1) * (long long)kTileBytes == (long long)next_t0) { cov_next = dbcs_cov; have_next = true; }
+                    }
+                    const u32 vals5[5] = { m.e, m.a, m.f, m.ma, m.mb };
+                    for (int k = 0; k < 5; k++) {
+                        if (t >= 0) ((uint16_t*)lds[k].data())[idx] = (uint16_t)(vals5[k] | spill[k]);
+                        spill[k] = vals5[k] >> 16;
+                    }
+                    continue;
+                }
                 // the two-byte family: the lanes in order (the kernel composes their in -> out functions along the wavefront)
                 const u32 lr = soff < 0 ? 0u : wv_dbcs_lead_mask(P.lut, b, have_hi);
                 u32 o0, o1;
@@ -211,14 +239,21 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                 for (int k = 0; k < 9; k++) ((uint16_t*)lds[k].data())[idx] = (uint16_t)vals[k];
             }
         }
-        if (P.family == 4) { dbcs_valid = have_next; if (have_next) dbcs_cov = cov_next; }
+        if (P.family >= 4) { dbcs_valid = have_next; if (have_next) dbcs_cov = cov_next; }
         WvWin w[64];
         for (u32 l = 0; l < 64; l++) {
             const u32 o = active[l] ? (u32)(ws[l] - tile0) : 0u, n = active[l] ? wn[l] : 0u;
             if (P.family == 0 && P.swar.cls) w[l] = wv_win_single_swar(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), P.swar.hi_len, n, P.n_min);
             else if (P.family == 0)
                 w[l] = wv_win_single(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[3], o, n), n, P.n_min);
-            else if (P.family == 4) {
+            else if (P.family == 5) {
+                auto bit = [&](int k, u32 at) -> u32 { return (u32)wv_extract(lds[k], at, 1).lo; };
+                const bool has1 = ws[l] >= 1 && o >= 1, has2 = ws[l] >= 2 && o >= 2;
+                const bool done1 = !has1 || (bit(0, o - 1) | bit(3, o - 1)) != 0, done2 = !has2 || (bit(0, o - 2) | bit(3, o - 2)) != 0;
+                w[l] = wv_win_eucjp_swar(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[3], o, n),
+                                         wv_extract(lds[4], o, n), P.swar.hi_len, done1, done2, has1 && bit(2, o - 1), has2 && bit(2, o - 2), has1, has2,
+                                         ws[l] % kWvSlice == 0, n, P.n_min);
+            } else if (P.family == 4) {
                 const u32 eb = o >= 1 ? (u32)wv_extract(lds[0], o - 1, 1).lo : 1u, mab = o >= 1 ? (u32)wv_extract(lds[3], o - 1, 1).lo : 0u;
                 const u32 fb1 = o >= 1 ? (u32)wv_extract(lds[2], o - 1, 1).lo : 0u;
                 if (P.swar.cls) w[l] = wv_win_dbcs_swar(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[3], o, n),
@@ -318,7 +353,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
         if (bf >= (1u << 14) || bb >= (1u << 18)) return false;   // the kernels pack a batch's totals into 32 bits
         tot_f += bf; tot_b += bb;
         if (g0 + kWvBatch >= own_end && MODE == 0)
-            P.wave_out[v] = last_out | (P.family == 4 && own_end == P.g_hi && w[n_act - 1].tail_pend ? kWvPendBit : 0u);
+            P.wave_out[v] = last_out | (P.family >= 4 && own_end == P.g_hi ? w[n_act - 1].tail_pend << 27 : 0u);
     }
     if (MODE == 0) { P.wave_nf[v] = tot_f; P.wave_nb[v] = tot_b; P.wave_in[v] = assumed_in; }
     return true;
@@ -342,6 +377,7 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
     if (swar25) memcpy(&P.swar, swar25, sizeof P.swar);
     P.pairs2 = pairs2;
     if (family == 4 && !pairs2) P.swar.cls = 0;
+    if (family == 5 && (!pairs2 || !P.swar.cls)) return -8;
     *nf = *nb = 0; *bad_waves = 0; *final_state = inject; *rounds_max = 0;
     if (P.g_hi <= P.g_lo) return 0;
     const u64 n_waves = (P.g_hi - P.g_lo + nwin - 1) / nwin;

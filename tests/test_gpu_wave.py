@@ -171,12 +171,13 @@ def test_wave_path_two_byte_family(wave_forced, di):
     """Big5 / Shift_JIS / EUC-KR through the wave kernels: token starts composed along the wavefront, pair codes in LDS, buffers that
     begin and end inside a token (16 KiB chunks), next to a UTF-8 Mission"""
     from test_dbcs import soup as dbcs_soup, TEXT, CODEC
-    enc, flags = DBCS_MISSIONS[di]
+    enc, flags = DBCS_MISSIONS[di]   # (EUC-JP too: tokens of up to three bytes, marks handed from lane to lane)
     ms = rc.missions(**dict(flags, encodings=flags["encodings"] + ["utf-8"]))
     rng = random.Random(4000 + di)
     txt = TEXT[enc].encode(CODEC[enc], "ignore")
     datas = [("soup", dbcs_soup(enc, rng, 300_000)), ("random", rng.randbytes(200_000)), ("text", (txt + b"\n") * (100_000 // (len(txt) + 1))),
-             ("text no ascii", txt.replace(b" ", b"").replace(b"\n", b"") * 60), ("lead bytes", b"\xa4" * 9001 + b"A" + b"\xa4\xa4" * 5000 + b"\x00" * 300)]
+             ("text no ascii", txt.replace(b" ", b"").replace(b"\n", b"") * 60), ("lead bytes", b"\xa4" * 9001 + b"A" + b"\xa4\xa4" * 5000 + b"\x00" * 300),
+             ("three-byte tokens", (b"\x8f\xb0\xa1\x8f\xb0\xa2\x8e\xb1\x8f\xa1\x41\x8f\x41\xa4\xa2" * 9 + b"\n") * 2000)]
     for name, data in datas:
         want = sxo.run_cli(ms, [data], radix="x")
         for chunk, batches in ((None, None), (16384, "1"), (8192, "2")):

@@ -55,10 +55,10 @@ def wave_classes(m):
 
 
 def wave_swar(m):
-    """the Mission's classes as SWAR ranges (csrc/sx_device.hpp WvSwar, 25 words) if the product classifies it that way, else None"""
+    """the Mission's classes as SWAR ranges (csrc/sx_device.hpp WvSwar, 26 words) if the product classifies it that way, else None"""
     L = sx.lib()
     L.sx_wave_swar.argtypes, L.sx_wave_swar.restype = [C.POINTER(sx.Mission), C.POINTER(C.c_uint32)], C.c_int
-    out = (C.c_uint32 * 25)()
+    out = (C.c_uint32 * 26)()
     cm = sx.Mission.from_dict(dict(m, mission_id=m.get("mission_id", 0)))
     r = L.sx_wave_swar(C.byref(cm), out)
     assert r >= 0
@@ -98,7 +98,7 @@ def emulate(L, m, data, nwin=508, skip_idle=1, g_lo=0, inject=0, consumed0=None,
     rcode = L.sxw_emulate(data, len(data), m["counter_offset"] if consumed0 is None else consumed0, 0, 2 * q, q, m["chars_min_nb"], g_lo,
                           inject, nwin, lut, table, 0, 1, fout, cap_f, aout, cap_a, C.byref(nf), C.byref(nb), C.byref(fin), C.byref(bad),
                           skip_idle, C.byref(rounds), family, wave_pairs(m) if family == 4 else None, m["encoding"], 0,
-                          wave_swar(m) if swar else None, wave_pairs2(m) if swar and family == 4 else None)
+                          wave_swar(m) if swar or family == 5 else None, wave_pairs2(m) if (swar and family == 4) or family == 5 else None)
     assert rcode == 0, rcode
     arena = bytes(aout[:nb.value])
     got = []
@@ -186,6 +186,10 @@ DBCS_MISSIONS = [
     ("shift_jis", dict(encodings=["shift_jis"], chars_min="2", output_line_len="6", unicode_block_filter="All", ascii_filter="All")),
     ("euc-kr", dict(encodings=["euc-kr"], chars_min="4", unicode_block_filter="All")),
     ("euc-kr", dict(encodings=["euc-kr"], chars_min="20", output_line_len="20", unicode_block_filter="Hangul")),
+    ("euc-jp", dict(encodings=["euc-jp"], chars_min="10", unicode_block_filter="Asian")),
+    ("euc-jp", dict(encodings=["euc-jp"], chars_min="3", output_line_len="8", unicode_block_filter="Cjk")),
+    ("euc-jp", dict(encodings=["euc-jp"], chars_min="2", output_line_len="6", unicode_block_filter="Kana", ascii_filter="None")),
+    ("euc-jp", dict(encodings=["euc-jp"], chars_min="4", unicode_block_filter="None")),
 ]
 
 
@@ -195,11 +199,12 @@ def test_emulated_wave_pipeline_two_byte_family(wave, di):
     from test_dbcs import soup as dbcs_soup, TEXT, CODEC
     enc, flags = DBCS_MISSIONS[di]
     m = rc.missions(**flags)[0]
-    assert wave_classes(m)[1] == 4
+    assert wave_classes(m)[1] == (5 if enc == "euc-jp" else 4)
     rng = random.Random(3000 + di)
     txt = TEXT[enc].encode(CODEC[enc], "ignore")
     datas = [("soup", dbcs_soup(enc, rng, 120_000)), ("random", rng.randbytes(90_000)), ("text", (txt + b"\n") * (60_000 // (len(txt) + 1))),
              ("text no ascii", txt.replace(b" ", b"").replace(b"\n", b"") * 40), ("lead bytes", b"\xa4" * 5000 + b"A" + b"\xa4\xa4" * 3000 + b"\x00" * 300),
+             ("three-byte tokens", (b"\x8f\xb0\xa1\x8f\xb0\xa2\x8e\xb1\x8f\xa1\x41\x8f\x41\xa4\xa2" * 9 + b"\n") * 700),
              ("ascii", text_lines(rng, 50_000)), ("short tail", dbcs_soup(enc, rng, 4096 * 3 + 77))]
     for name, data in datas:
         want = oracle_findings([dict(m, mission_id=0)], data)
@@ -246,5 +251,5 @@ def test_missions_the_wave_path_does_not_cover():
     for kw in (dict(encodings=["ascii"], chars_min="4", grep_char="47"), dict(encodings=["ascii"], chars_min="4", same_unicode_block=True),
                dict(encodings=["ascii"], chars_min="0"), dict(encodings=["ascii"], chars_min="70"),
                dict(encodings=["ascii"], chars_min="4", output_line_len="100"), dict(encodings=["utf-16le"], chars_min="4"),
-               dict(encodings=["big5"], chars_min="4"), dict(encodings=["euc-jp"], chars_min="4"), dict(encodings=["gbk"], chars_min="4")):
+               dict(encodings=["big5"], chars_min="4"), dict(encodings=["euc-jp"], chars_min="4", unicode_block_filter="All"), dict(encodings=["gbk"], chars_min="4")):
         assert wave_classes(rc.missions(**kw)[0]) is None, kw
