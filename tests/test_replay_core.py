@@ -42,14 +42,8 @@ def core():
 
 
 def load_core():
-    so = os.path.join(NATIVE, "libreplay_core_host.so")
-    src = os.path.join(NATIVE, "replay_core_host.cpp")
-    hdrs = [os.path.join(ROOT, "stringsext_amd", "csrc", h) for h in ("sx_replay_core.hpp", "sx_codec_core.hpp", "sx_device.hpp")]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
-        tmp = f"{so}.{os.getpid()}.tmp"   # (several pytest-xdist workers may get here at once)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
-                               "-I/opt/rocm/include", "-o", tmp, src])
-        os.replace(tmp, so)
+    from native.build_harness import build_replay_core
+    so = build_replay_core()
     L = C.CDLL(so)
     L.sxd_replay_region_host.argtypes = [C.POINTER(ReplayParams), C.c_uint64, C.POINTER(RegionOut), C.POINTER(sx.Finding),
                                          C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]

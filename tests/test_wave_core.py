@@ -20,14 +20,8 @@ NATIVE = os.path.join(ROOT, "tests", "native")
 
 
 def load_wave():
-    so = os.path.join(NATIVE, "libwave_core_host.so")
-    src = os.path.join(NATIVE, "wave_core_host.cpp")
-    hdrs = [os.path.join(ROOT, "stringsext_amd", "csrc", h) for h in ("sx_wave_core.hpp", "sx_codec_core.hpp", "sx_device.hpp")]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
-        tmp = f"{so}.{os.getpid()}.tmp"   # (several pytest-xdist workers may get here at once)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                               "-Wno-unknown-pragmas", "-o", tmp, src])
-        os.replace(tmp, so)
+    from native.build_harness import build_wave_core
+    so = build_wave_core()
     L = C.CDLL(so)
     L.sxw_emulate.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
                               C.c_uint32, C.c_char_p, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.POINTER(sx.Finding), C.c_uint64,
