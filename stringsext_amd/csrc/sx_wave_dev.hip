@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                     WvEucOrbit ob = wv_eucjp_orbit_init(pc);
                     while (__ballot(wv_eucjp_orbit_step(ob))) {}
                     u32 T = wv_eucjp_over(ob, 0) | (wv_eucjp_over(ob, 1) << 2) | (wv_eucjp_over(ob, 2) << 4);   // hang-over out for hang-over in 0 / 1 / 2
-                    const bool at_zero = tile0 == 0 && rel == 0;   // the buffer's byte 0: the token pending on entry decides
+                    const bool at_zero = (long long)tile0 + rel == 0;   // the buffer's byte 0: the token pending on entry decides
                     if (at_zero) { const u32 o = (T >> (2 * P.entry_skip)) & 3u; T = o | (o << 2) | (o << 4); }
                     u32 out_here;
                     if (!__ballot((pc.lr & 0xFFFFu) == 0xFFFFu && !at_zero)) out_here = T & 3u;   // every lane holds a byte outside the lead range
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                     const u32 tr0 = wv_dbcs_trails(lr16, 0u), tr1 = wv_dbcs_trails(lr16, 1u);
                     const u32 o0 = tr0 >> 16, o1 = tr1 >> 16;
                     u32 fn = o0 | (o1 << 1);                       // bit c: how far the lane's last token hangs over if its first byte is at c
-                    const bool at_zero = tile0 == 0 && rel == 0;   // the buffer's byte 0: the token pending on entry decides
+                    const bool at_zero = (long long)tile0 + rel == 0;   // the buffer's byte 0: the token pending on entry decides
                     if (at_zero) { const u32 o = P.entry_skip ? o1 : o0; fn = o | (o << 1); }
                     u32 out_here;
                     if (!__ballot(o0 != o1 && !at_zero)) out_here = fn & 1u;   // every lane holds a byte outside the lead range (binary data: always): what it hands on does not depend on what it gets

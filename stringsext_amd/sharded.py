@@ -264,11 +264,12 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
                     if na: dst[nf:].copy_(torch.from_numpy(ab))
                 elif nf + na:
                     dst = stage[off - own_total:off - own_total + nf + na] if on_gpu else host[off:off + nf + na]
-                    reqs.append(dist.irecv(dst, src=k))
+                    reqs.append(dist.P2POp(dist.irecv, dst, k))
                 segs_k.append((off, nf, na))
                 off += nf + na
             where.append(segs_k)
-        for q in reqs:
+        # (one group: with RCCL the receives from different ranks then run next to each other instead of one kernel after the other)
+        for q in (dist.batch_isend_irecv(reqs) if reqs else []):
             q.wait()
         if on_gpu and remote_total:
             host[own_total:own_total + remote_total].copy_(stage[:remote_total], non_blocking=True)

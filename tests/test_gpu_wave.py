@@ -251,3 +251,24 @@ def test_dense_results_travel_as_16_byte_records():
             assert run_cli_product(ms, [data], radix="x", device=0) == want
         finally:
             os.environ.pop("SX_DEFER_MIN_BYTES", None); os.environ.pop("SX_PACKED", None)
+
+
+def test_chunks_that_begin_inside_a_token(wave_forced):
+    """two-byte family / EUC-JP: every chunk starts with the trail byte of a token begun in the chunk before (the carried decoder holds
+    the lead byte) and its first kilobyte holds no byte outside the lead range — the wavefronts' way back to a token boundary then ends
+    at the buffer's byte 0, where only the entry parameter says how the grid lies (found by the GPU fuzz in round 4: the look-back tile
+    that begins in front of the buffer did not take it)"""
+    from test_dbcs import TEXT, CODEC
+    rng = random.Random(41)
+    for enc, flt in (("big5", "Asian"), ("euc-kr", "Hangul"), ("euc-jp", "Asian")):
+        ms = rc.missions(encodings=[enc, "ascii"], chars_min="5", output_line_len="30", unicode_block_filter=flt)
+        txt = TEXT[enc].encode(CODEC[enc], "ignore").replace(b" ", b"").replace(b"\n", b"")
+        pairs = bytes(b for b in txt if b >= 0x80)
+        pairs = pairs[:len(pairs) // 2 * 2]
+        body = b""
+        while len(body) < 200_000:
+            body += pairs * 3 + rng.choice([b"", b"\xa1\x40", b"xy z", b"\n"])
+        data = b"A" + body      # odd offset: the pairs straddle every even chunk boundary
+        want = sxo.run_cli(ms, [data], radix="x")
+        for chunk in (4096, 8192, 16384):
+            assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (enc, chunk)
