@@ -166,7 +166,7 @@ struct sx_ctx {
     uint8_t* ing_pin[2] = { nullptr, nullptr };
     uint8_t* ing_dev[2] = { nullptr, nullptr };
     uint64_t ing_cap = 0, ing_dev_cap = 0;
-    uint32_t region_cap = 32;         // record slots per sub-chunk in region mode (0: never use it)
+    uint32_t region_cap = 64;         // record slots per sub-chunk in region mode (0: never use it).  Round 4: 32 -> 64 — C2 (17 records per sub-chunk on average) overflowed some regions and fell into the large-region mode with its radix sort: 2.11 -> 1.95 ms per step
     // per mission, from the last buffer: 0 = few records (small regions, packed in order); 1 = shared pool + sort;
     // > 1 = string-dense: regions of this many slots (no atomics in the scan kernel), sorted like the pool
     std::vector<uint32_t> dense;

@@ -276,8 +276,13 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->merge_copy_stream, ctx->merge_ev[0], 0));
                 HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, out_bytes, hipMemcpyDeviceToHost, ctx->merge_copy_stream));
                 HIP_TRY(ctx, hipEventRecord(sl.copied, ctx->merge_copy_stream));
-            } else
-                HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, out_bytes, hipMemcpyDeviceToHost, d.stream_b));
+            } else {
+                // (experiments, SX_REPLAY_COPY_WGS=n: the copy as a kernel of n workgroups instead of the runtime's blit, which slows every
+                // kernel next to it — here: the last Mission's scan launch, DESIGN.md section 2 "Schedule")
+                static const int wgs = [] { const char* e = getenv("SX_REPLAY_COPY_WGS"); return e ? atoi(e) : 0; }();
+                if (wgs > 0 && out_bytes >= (1u << 20)) HIP_TRY(ctx, launch_copy_bytes(blk.p, d_all, out_bytes, (uint32_t)wgs, d.stream_b));
+                else HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, out_bytes, hipMemcpyDeviceToHost, d.stream_b));
+            }
         }
         if (!sl.async_copy || nfh) HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));   // (nfh: the entry part's upload reads host vectors)
     }
