@@ -177,6 +177,9 @@ struct WaveParams {
     uint32_t entry_skip;      // two-byte family / EUC-JP: bytes at the buffer's start that finish the token pending on entry (0 / 1; EUC-JP: 0 .. 2)
     // pass 1 out, per wavefront: findings, string bytes, the entry state it assumed for its first window, the state after its last
     uint32_t *wave_nf, *wave_nb, *wave_in, *wave_out;
+    // two-byte family: per wavefront, bit 0 "the hang-over at my first tile is known", bit 1 that hang-over — a wavefront whose way back to a
+    // token boundary crosses its predecessor's whole range without meeting a byte outside the lead range takes it from there (zeroed per launch)
+    uint32_t* wave_grid;
     // pass 2 in: exclusive sums of the above; the launch's output segment starts at (f_sub, a_sub)
     const uint64_t *wave_fbase, *wave_abase;
     uint64_t f_sub, a_sub;

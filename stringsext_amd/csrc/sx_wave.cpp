@@ -41,9 +41,9 @@ bool wave_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_
     if (const char* e = getenv("SX_WAVE_REPLAY")) return atoi(e) != 0;
     if (getenv("SX_HOST_REPLAY") || getenv("SX_HOST_STITCH") || getenv("SX_NO_REPLAY_CACHE")) return false;   // tests of the other path
     if ((uint64_t)n_runs * wave_min_density_bytes(m.wave_family) > job.len) return true;
-    // (not the two-byte family: its wave kernels find the token grid by walking back to a byte outside the lead range — a fill is
-    // the one input where that walk has no end; they give up after 64 KiB and the other path takes over)
-    return m.wave_family < 4 && heavy_tiles * 2048 > job.len && (uint64_t)n_runs * 4096 < job.len;
+    // (round 4: the two-byte family too — inside a fill of lead-range bytes its wave kernels take the token grid from the wavefront in
+    // front by parity; EUC-JP, whose tokens have two or three bytes, still gives up after 64 KiB of look-back)
+    return m.wave_family <= 4 && heavy_tiles * 2048 > job.len && (uint64_t)n_runs * 4096 < job.len;
 }
 
 static uint32_t utf8_chars(const std::string& s) {
@@ -149,7 +149,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             HIP_TRY(ctx, hipMemcpy(d.d_wave_pairs2, m.wave_pairs2.data(), 4096 * 4, hipMemcpyHostToDevice));
         }
         // per wavefront: 4 x u32 (pass 1 out) + 2 x u64 (offsets); + totals per slab
-        const uint64_t per = 4 * 4 + 2 * 8;
+        const uint64_t per = 5 * 4 + 2 * 8;   // (+ the two-byte family's grid word)
         int rc = ensure_rp(ctx, d, 1, n_waves * per + 4096); if (rc) return rc;
         uint8_t* w_scratch; uint64_t w_scratch_cap;
         if (own_stream) {
@@ -177,6 +177,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         if (m.wave_family == 5 && !d.d_wave_pairs2) return SX_WAVE_FALLBACK;
         if (const char* e = getenv("SX_WAVE_LUT")) if (atoi(e) && m.wave_family != 5) P.swar.cls = 0;   // tests: the class table also where ranges would do
         P.wave_nf = d_u; P.wave_nb = d_u + n_waves; P.wave_in = d_u + 2 * n_waves; P.wave_out = d_u + 3 * n_waves;
+        P.wave_grid = m.wave_family == 4 ? d_u + 4 * n_waves : nullptr;
         P.wave_fbase = d_fb; P.wave_abase = d_ab;
         // Descriptors for the lane-per-finding writer: room for twice the findings a wavefront is expected to hold (the last buffer's
         // density; stage A's record count; else one per window), at most two per window and a third of the input's size in all.  A

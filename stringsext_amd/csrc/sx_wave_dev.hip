@@ -166,6 +166,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
     u32 tot_f = 0, tot_b = 0;
     u32 dbcs_cov = 0;   // FAM 4: bytes at the next tile's start that belong to a token begun before it (0 / 1)
     bool dbcs_valid = false;   // ... known for the next batch's first tile
+    u64 ref_pos = ~0ull;       // two-byte family: a tile start of the batch before at which the hang-over (ref_cov) is known
+    u32 ref_cov = 0;
     u64 fbase = 0, abase = 0;
     if (MODE == 1) { fbase = P.wave_fbase[v] - P.f_sub; abase = P.wave_abase[v] - P.a_sub; }   // relative to this launch's output segment
     const WvParams WP{ P.q, P.n_min };
@@ -197,6 +199,21 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         if (FAM >= 4 && (g0 == gw || !dbcs_valid)) {
             dbcs_cov = 0;
             long long lo = (long long)tile0;
+            // Two-byte family (round 4): inside a stretch of lead-range bytes every token has two bytes, so the hang-over at tile0 follows
+            // from a position where it is KNOWN by the parity of the distance — the walk need not find the stretch's beginning (a format
+            // fill of 0xF6 in a disk image is gigabytes of it; round 3: give up after 64 KiB, and the buffer went to the host replay at
+            // 0.18 GiB/s).  Known: the last tile start of the batch before (later batches), or the first tile of the wavefront in front
+            // (first batch): it publishes its hang-over there as soon as it has it (P.wave_grid; wavefronts are dispatched in order).
+            long long stop = -1;
+            if (FAM == 4 && P.wave_grid) {
+                if (g0 != gw && ref_pos != ~0ull) stop = (long long)ref_pos;
+                else if (g0 == gw && v > 0) {
+                    const u64 gp = v - 1 == 0 ? P.g_lo : P.g_lo + (v - 1) * P.nwin - kWvWarm;
+                    u64 wsp; u32 wnp;
+                    wv_window_at(gp, P.W, P.wps, P.len, &wsp, &wnp);
+                    stop = (long long)wv_tile0(wsp);
+                }
+            }
             while (lo > 0) {
                 lo -= kTileBytes; t_first--;
                 const long long o = lo + 16ll * lane;
@@ -209,7 +226,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                     else for (int k = 0; k < 16; k++) reset = reset || !(lds_lut[(xs[k >> 2] >> (8 * (k & 3))) & 0xFFu] & WVC_LEAD);
                 }
                 if (__ballot(reset)) break;
-                if (t_first < -64) {   // 64 KiB of lead-range bytes and no end: a fill.  This wavefront gives up — an entry state no wavefront
+                if (stop >= 0 && lo <= stop) {   // nothing but lead-range bytes from the known position to tile0
+                    u32 kc = ref_cov;
+                    if (g0 == gw) {
+                        u32 fv = 0;
+                        if (lane == 0) { while (((fv = __hip_atomic_load(P.wave_grid + (v - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1u) == 0) __builtin_amdgcn_s_sleep(2); }
+                        kc = (wv_uniform(fv) >> 1) & 1u;
+                    }
+                    const u64 first = (u64)stop + kc;                       // a token starts here, and every two bytes from here on
+                    dbcs_cov = tile0 >= first ? (u32)((tile0 - first) & 1ull) : (u32)(first - tile0);
+                    t_first = 0;                                           // (no look-back tile needs classifying)
+                    break;
+                }
+                if (stop < 0 && t_first < -64) {   // 64 KiB of lead-range bytes and no end, and no known position to count from (EUC-JP: token lengths differ).  This wavefront gives up — an entry state no wavefront
                                        // ever leaves makes the verification fail, and the lane-per-region path takes the buffer
                     if (lane == 0) { P.wave_in[v] = 0xFFFFFFFEu; P.wave_out[v] = 0xFFFFFFFDu; P.wave_nf[v] = 0; P.wave_nb[v] = 0; }
                     return;
@@ -399,7 +428,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             }
             edge_back = eb;
         }
+        if (FAM == 4 && P.wave_grid && g0 == gw && lane == 0)   // the hang-over at my first tile: the wavefront behind me may be waiting for it
+            __hip_atomic_store(P.wave_grid + v, 1u | (dbcs_cov << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int t_ref = next_t0 >= tile0 ? (int)((next_t0 - tile0) / kTileBytes) : 0;   // the last tile that starts at or in front of the next batch's first
         for (int t = 0; t < (int)n_tiles; t++) {
+            if (FAM == 4 && t == t_ref) { ref_pos = tile0 + (u64)t * kTileBytes; ref_cov = dbcs_cov; }
             const u32x4 x = xa;
             xa = xb; xb = xc; xc = xd; xd = issue(t + 4);
             const u32 ea = t + 1 < (int)n_tiles ? (u32)__builtin_amdgcn_readlane(xa.x, 0) : edge_after;
@@ -407,6 +440,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             edge_back = (u32)__builtin_amdgcn_readlane(x.w, 63);
         }
         wave_lds_sync<WPB>();
+        if (FAM == 4 && t_ref >= (int)n_tiles) { ref_pos = tile0 + (u64)n_tiles * kTileBytes; ref_cov = dbcs_cov; }
         if (FAM >= 4) { dbcs_valid = have_next; if (have_next) dbcs_cov = cov_next; }   // (else the next batch walks back again)
 
 #if defined(SX_WV_EXP) && SX_WV_EXP == 1   // experiments (tools/build_variant.sh): what the classification alone costs
@@ -601,6 +635,7 @@ hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint
     WaveParams Q = P;
     Q.v0 = v0; Q.v1 = v1;
     const unsigned dyn = getenv("SX_WAVE_DYN_LDS") ? (unsigned)atoi(getenv("SX_WAVE_DYN_LDS")) : 0u;   // experiments: fewer wavefronts per CU
+    if (P.wave_grid) { hipError_t ez = hipMemsetAsync(P.wave_grid + v0, 0, (size_t)n * 4, stream); if (ez != hipSuccess) return ez; }
     if (P.family == 5) hipLaunchKernelGGL((wave_replay_kernel<0, 5, 4, 1>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 1>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 0>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
@@ -629,6 +664,7 @@ hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipS
     WaveParams Q = P;
     Q.v0 = v0; Q.v1 = v1;
     const unsigned dyn = getenv("SX_WAVE_DYN_LDS") ? (unsigned)atoi(getenv("SX_WAVE_DYN_LDS")) : 0u;
+    if (P.wave_grid) { hipError_t ez = hipMemsetAsync(P.wave_grid + v0, 0, (size_t)(v1 - v0) * 4, stream); if (ez != hipSuccess) return ez; }
     if (P.family == 5) hipLaunchKernelGGL((wave_replay_kernel<1, 5, 4, 1>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4, 1>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4, 0>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);

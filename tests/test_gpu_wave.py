@@ -192,20 +192,21 @@ def test_wave_path_two_byte_family(wave_forced, di):
 def test_giant_runs_take_the_wave_path():
     """a fill of accepted bytes (megabytes of spaces, '0', 0xFF in a Latin code page, 0xF6F6 in Big5) is ONE run: few runs, but every
     tile of it on the scan kernel's general path — the buffer counts as dense and is replayed a lane per window, not handed to the
-    host as one region; next to a second Mission, chunked and in one piece.  (Not the two-byte family: inside a fill of lead-range bytes its
-    wave kernels find no token grid; the lane-per-region path keeps such a buffer, and only the text is compared.)"""
+    host as one region; next to a second Mission, chunked and in one piece.  The two-byte family's wave kernels take the token grid inside such
+    a fill from the wavefront in front (parity of the distance: every token there has two bytes)."""
     rng = random.Random(21)
     cases = [(dict(encodings=["utf-8", "utf-16le"], chars_min="4"), b"\xff" + b" " * (6 << 20) + b"\xc3"),
              (dict(encodings=["utf-8"], chars_min="10"), rng.randbytes(5000) + b"\x80" + b"0" * (5 << 20) + rng.randbytes(3000)),
              (dict(encodings=["windows-1252", "ascii"], chars_min="4", unicode_block_filter="Latin"), b"\x00" + b"\xff" * (4 << 20) + b"\x00abcd"),
-             (dict(encodings=["big5"], chars_min="4", unicode_block_filter="Cjk"), rng.randbytes(3000) + b"\x80" + b"\xf6" * ((4 << 20) + 1) + b"\n")]
+             (dict(encodings=["big5"], chars_min="4", unicode_block_filter="Cjk"), rng.randbytes(3000) + b"\x80" + b"\xf6" * ((4 << 20) + 1) + b"\n"),
+             (dict(encodings=["big5"], chars_min="10", unicode_block_filter="Cjk"), rng.randbytes(3001) + b"A" + b"\xa4" * (3 << 20) + b"\xa4\x40" * 70000 + b"\n" + b"\xf6" * (1 << 20)),
+             (dict(encodings=["euc-kr"], chars_min="6", unicode_block_filter="Hangul"), b"\xc7\xd1" * 40 + b"\n" + b"\xc7\xd1" * (2 << 20) + b"\n")]
     for flags, data in cases:
         ms = rc.missions(**flags)
         want = sxo.run_cli(ms, [data], radix="x")
         for chunk in (None, 1 << 20):
             assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (flags, chunk)
-        if "big5" not in flags["encodings"]:
-            assert wave_windows_of_a_scan(ms[:1], data) > 0, flags
+        assert wave_windows_of_a_scan(ms[:1], data) > 0, flags   # (round 4: the two-byte family too — the token grid inside the fill by parity)
 
 
 def test_dense_results_travel_as_16_byte_records():
