@@ -76,6 +76,22 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
             const bool acc = kind == WVU_ASCII ? af[b] : (kind >= WVU_LEAD2 && m->filter.pass_ubf_filter((uint8_t)b));
             m->wave_lut[(size_t)b] = (uint8_t)(kind | (acc ? WVU_ACC : 0));
         }
+        {   // the wave kernels' classes as ranges (sx_wave_core.hpp wv_classify16_utf8_swar): the accepted FIRST bytes — ASCII and lead bytes — at most six
+            std::vector<std::pair<int, int>> ranges;
+            for (int b = 0; b < 256; b++)
+                if (m->wave_lut[(size_t)b] & WVU_ACC) {
+                    if (!ranges.empty() && ranges.back().second == b - 1 && b != 0x80) ranges.back().second = b; else ranges.emplace_back(b, b);
+                }
+            if (ranges.size() <= 6) {
+                WvSwar& R = m->wave_swar;
+                R.cls = 1; R.n = (uint32_t)ranges.size();
+                for (size_t k = 0; k < 6; k++) {
+                    uint32_t lo = 1, hi = 0, high = 0;
+                    if (k < ranges.size()) { lo = (uint32_t)ranges[k].first & 0x7F; hi = (uint32_t)ranges[k].second & 0x7F; high = ranges[k].first >= 0x80; }
+                    R.c1[k] = (0x80u - lo) * 0x01010101u; R.c2[k] = (0x7Fu - hi) * 0x01010101u; R.hi[k] = high ? 0u : 0xFFFFFFFFu;
+                }
+            }
+        }
         if (!force_generic && af_is_range && ubf2_is_range && no_long_leads) {
             m->kind = kClsUtf8Range2;
             if (!uempty) { p.u_lo = 0xC0u + (uint32_t)ulo; p.u_hi = 0xC0u + (uint32_t)uhi; }

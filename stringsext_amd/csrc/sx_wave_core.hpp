@@ -678,6 +678,82 @@ SXD WvMasks16U wv_classify16_utf8(const LUT& lut, const u8* b, u32 have_lo, u32 
     return m;
 }
 
+// ---- the same classification as SWAR (round 4; WvSwar::cls == 1: the accepted first bytes — ASCII bytes and lead bytes — are at most six
+// ranges).  Everything about byte p follows from the bytes p-3 .. p: the kind of the lead byte one, two and three bytes in front of it travels in
+// one flag byte per input byte (K: E0 / ED / F0 / F4 — the leads whose first continuation is narrowed —, lead of 2 / 3 / 4, accepted), shifted by
+// one, two and three bytes with v_alignbyte.  Only F looks ahead (a lead byte begins a character if the character completes).  Five masks leave
+// the lane (E, A, F, MA, MB); G follows from A and F where the window is built.
+SXD u32 wv_alignbyte(u32 hi, u32 lo, u32 k) {   // bytes k .. k + 3 of lo:hi (k = 1 .. 3)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, k);
+#else
+    return (u32)((((u64)hi << 32) | lo) >> (8 * k));
+#endif
+}
+struct WvU8Dword { u32 k, c1, c2, e2, e3, e4, e, a, ma, mb, asc; };
+// one dword: v its bytes, p the dword in front of it (its k / c1 / c2)
+template <int KR>
+SXD WvU8Dword wv_utf8_dword_swar(const WvSwar& R, u32 v, const WvU8Dword& p) {
+    const u32 M = 0x80808080u, t = v & 0x7F7F7F7Fu;
+    const u32 asc = ~v & M, cont = v & ~(v << 1) & M;
+    const u32 l2 = (t + 0x3E3E3E3Eu) & ~(t + 0x20202020u) & v & M;     // C2..DF
+    const u32 l3 = (t + 0x20202020u) & ~(t + 0x10101010u) & v & M;     // E0..EF
+    const u32 l4 = (t + 0x10101010u) & ~(t + 0x0B0B0B0Bu) & v & M;     // F0..F4
+    const u32 bad = v & M & ~(cont | l2 | l3 | l4);                    // C0, C1, F5..FF
+    const u32 w = v & 0x0F0F0F0Fu;
+    const u32 z0 = ~(w + 0x7F7F7F7Fu) & M, zd = ~((w ^ 0x0D0D0D0Du) + 0x7F7F7F7Fu) & M, z4 = ~((w ^ 0x04040404u) + 0x7F7F7F7Fu) & M;
+    const u32 acc = wv_swar_accepted<KR>(R, v);
+    WvU8Dword d;
+    d.asc = asc;
+    d.k = (l3 & z0) | ((l3 & zd) >> 1) | ((l4 & z0) >> 2) | ((l4 & z4) >> 3) | (l2 >> 4) | (l3 >> 5) | (l4 >> 6) | (acc >> 7);
+    const u32 d1 = wv_alignbyte(d.k, p.k, 3), d2 = wv_alignbyte(d.k, p.k, 2), d3 = wv_alignbyte(d.k, p.k, 1);   // the flags of the byte 1 / 2 / 3 in front
+    const u32 b5 = (v << 2) & M, b4 = (v << 3) & M, b54 = b5 | b4;
+    const u32 lead1 = ((d1 << 4) | (d1 << 5) | (d1 << 6)) & M;
+    const u32 narrow = (d1 & ~b5) | ((d1 << 1) & b5) | ((d1 << 2) & ~b54) | ((d1 << 3) & b54);   // E0 wants A0..BF, ED 80..9F, F0 90..BF, F4 80..8F
+    d.c1 = cont & lead1 & ~narrow;
+    const u32 c1sh = wv_alignbyte(d.c1, p.c1, 3);
+    const u32 l34_2 = ((d2 << 5) | (d2 << 6)) & M;
+    d.c2 = cont & c1sh & l34_2;
+    const u32 c2sh = wv_alignbyte(d.c2, p.c2, 3);
+    const u32 l4_3 = (d3 << 6) & M;
+    const u32 c3 = cont & c2sh & l4_3;
+    d.e2 = d.c1 & (d1 << 4) & M; d.e3 = d.c2 & (d2 << 5) & M; d.e4 = c3;
+    d.e = asc | d.e2 | d.e3 | d.e4;
+    d.a = ((asc & acc) | (d.e2 & (d1 << 7)) | (d.e3 & (d2 << 7)) | (d.e4 & (d3 << 7))) & M;
+    d.ma = bad | (cont & ~(d.c1 | d.c2 | c3));
+    d.mb = ((lead1 & ~d.c1) | (l34_2 & c1sh & ~d.c2) | (l4_3 & c2sh & ~c3)) & M;
+    return d;
+}
+struct WvMasks16V { u32 e, a, f, ma, mb; };
+// ws6: the dwords at lane offset -4 .. +19 (bytes that do not exist: zero); n_own: how many of the lane's 16 bytes exist
+template <int KR>
+SXD WvMasks16V wv_classify16_utf8_swar(const WvSwar& R, const u32* ws6, u32 n_own) {
+    WvU8Dword z{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    WvU8Dword d[6];
+    d[0] = wv_utf8_dword_swar<KR>(R, ws6[0], z);   // (what lies in front of these four bytes only matters to bytes in front of the lane)
+#pragma unroll
+    for (int k = 1; k < 6; k++) d[k] = wv_utf8_dword_swar<KR>(R, ws6[k], d[k - 1]);
+    u32 f[4];
+#pragma unroll
+    for (int k = 1; k <= 4; k++)   // a lead byte begins a character if the character's last byte is there
+        f[k - 1] = d[k].asc | wv_alignbyte(d[k + 1].e2, d[k].e2, 1) | wv_alignbyte(d[k + 1].e3, d[k].e3, 2) | wv_alignbyte(d[k + 1].e4, d[k].e4, 3);
+    const u32 ex = n_own >= 16 ? 0xFFFFu : ((1u << n_own) - 1u);
+    WvMasks16V m;
+    m.e = wv_movemask16_b7(d[1].e, d[2].e, d[3].e, d[4].e) & ex;
+    m.a = wv_movemask16_b7(d[1].a, d[2].a, d[3].a, d[4].a) & ex;
+    m.f = wv_movemask16_b7(f[0], f[1], f[2], f[3]) & ex;
+    m.ma = wv_movemask16_b7(d[1].ma, d[2].ma, d[3].ma, d[4].ma) & ex;
+    m.mb = wv_movemask16_b7(d[1].mb, d[2].mb, d[3].mb, d[4].mb) & ex;
+    return m;
+}
+// G from A and F: a byte belongs to an accepted character if it is its last byte, or the byte behind it does and is not its first
+SXD WvMask wv_utf8_good_from(WvMask A, WvMask F) {
+    WvMask g = A, x = A;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { x = wm_shr(wm_andn(x, F), 1); g = wm_or(g, x); }
+    return g;
+}
+
 // the window of a UTF-8 Mission.  f_back: the F bits of the three bytes in front of the window (bit 2 = the byte right before
 // it); slice_start: the window is the first of its slice (the probe of finding_collection.rs:176-207 then runs: a fresh decoder
 // cannot reproduce a first character that began in the slice before -> `Before`).

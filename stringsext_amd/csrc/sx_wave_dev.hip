@@ -116,7 +116,7 @@ template <int WPB> SXD void wave_lds_sync() {
 
 // masks a wavefront keeps per batch (16 bits per lane and tile each).  CLS 1: the classes come from ranges (sx_device.hpp WvSwar): a
 // single-byte Mission then stores accepted / >= 0x80 only, a two-byte one E, A, F, MA, MB (G and the lengths follow from them)
-constexpr int wv_n_masks(int fam, int cls) { return fam == 5 ? 5 : fam == 4 ? (cls ? 5 : 9) : fam == 1 ? 6 : cls ? 2 : 4; }
+constexpr int wv_n_masks(int fam, int cls) { return fam == 5 ? 5 : fam == 4 ? (cls ? 5 : 9) : fam == 1 ? (cls ? 5 : 6) : cls ? 2 : 4; }
 constexpr u32 kMaskWords = kWvMaxTiles * 32 + 8;
 constexpr u32 wv_lds_words(int fam, int cls) {   // ... and the descriptors staged in their place need kWvStage x 3 x 64 words
     return (u32)wv_n_masks(fam, cls) * kMaskWords > kWvStage * 192u ? (u32)wv_n_masks(fam, cls) * kMaskWords : kWvStage * 192u;
@@ -284,6 +284,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 WvMasks16R m;
                 if (SW.n <= 1) m = wv_classify16_single_swar<1>(SW, x.x, x.y, x.z, x.w, avail);
                 else if (SW.n <= 3) m = wv_classify16_single_swar<3>(SW, x.x, x.y, x.z, x.w, avail);
+                else if (SW.n <= 4) m = wv_classify16_single_swar<4>(SW, x.x, x.y, x.z, x.w, avail);   // (KOI8-R + Cyrillic: 20..7E, A3, B3, C0..FF)
                 else m = wv_classify16_single_swar<6>(SW, x.x, x.y, x.z, x.w, avail);
                 ((uint16_t*)lds_mask(0))[idx] = (uint16_t)m.a;
                 ((uint16_t*)lds_mask(1))[idx] = (uint16_t)m.hi;
@@ -346,6 +347,18 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                         ((uint16_t*)lds_mask(3))[idx] = (uint16_t)(m.ma | ((si >> 6) & 3u));
                         ((uint16_t*)lds_mask(FAM == 5 ? 4 : 0))[idx] = (uint16_t)(m.mb | ((si >> 8) & 3u));
                     }
+                } else if (FAM == 1 && CLS) {
+                    u32 wz[6] = { ws6[0], ws6[1], ws6[2], ws6[3], ws6[4], ws6[5] };
+                    if (!has_back) wz[0] = 0;
+                    WvMasks16V m;
+                    if (SW.n <= 1) m = wv_classify16_utf8_swar<1>(SW, wz, avail);
+                    else if (SW.n <= 3) m = wv_classify16_utf8_swar<3>(SW, wz, avail);
+                    else m = wv_classify16_utf8_swar<6>(SW, wz, avail);
+                    ((uint16_t*)lds_mask(0))[idx] = (uint16_t)m.e;
+                    ((uint16_t*)lds_mask(1))[idx] = (uint16_t)m.a;
+                    ((uint16_t*)lds_mask(2))[idx] = (uint16_t)m.f;
+                    ((uint16_t*)lds_mask(3))[idx] = (uint16_t)m.ma;
+                    ((uint16_t*)lds_mask(FAM == 1 ? 4 : 0))[idx] = (uint16_t)m.mb;
                 } else if (FAM == 1) {
                     u8 b[24];
 #pragma unroll
@@ -356,7 +369,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                     ((uint16_t*)lds_mask(2))[idx] = (uint16_t)m.f;
                     ((uint16_t*)lds_mask(3))[idx] = (uint16_t)m.ma;
                     ((uint16_t*)lds_mask(FAM == 1 ? 4 : 0))[idx] = (uint16_t)m.mb;
-                    ((uint16_t*)lds_mask(FAM == 1 ? 5 : 0))[idx] = (uint16_t)m.g;
+                    ((uint16_t*)lds_mask(FAM == 1 && !CLS ? 5 : 0))[idx] = (uint16_t)m.g;
                 } else {
                     // token starts: the lane's trails for both cases (bit arithmetic, sx_wave_core.hpp wv_dbcs_trails), the cases
                     // composed along the wavefront
@@ -477,8 +490,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                                 wv_extract(lds_mask(FAM == 4 && !CLS ? 8 : 0), o, n), (eb | mab) != 0, fb1 != 0, ws > 0, ws % kWvSlice == 0, n, P.n_min);
             } else {
                 const u32 fb = o >= 3 ? (u32)wv_extract(lds_mask(2), o - 3, 3).lo : 0u;
+                if (CLS) {
+                    const WvMask A_ = wv_extract(lds_mask(1), o, n), F_ = wv_extract(lds_mask(2), o, n);
+                    w = wv_win_utf8(wv_extract(lds_mask(0), o, n), A_, F_, wv_utf8_good_from(A_, F_), wv_extract(lds_mask(3), o, n),
+                                    wv_extract(lds_mask(FAM == 1 ? 4 : 0), o, n), fb, ws % kWvSlice == 0, n, P.n_min);
+                } else
                 w = wv_win_utf8(wv_extract(lds_mask(0), o, n), wv_extract(lds_mask(1), o, n), wv_extract(lds_mask(2), o, n),
-                                wv_extract(lds_mask(FAM == 1 ? 5 : 0), o, n), wv_extract(lds_mask(3), o, n),
+                                wv_extract(lds_mask(FAM == 1 && !CLS ? 5 : 0), o, n), wv_extract(lds_mask(3), o, n),
                                 wv_extract(lds_mask(FAM == 1 ? 4 : 0), o, n), fb, ws % kWvSlice == 0, n, P.n_min);
             }
         }
@@ -639,6 +657,7 @@ hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint
     if (P.family == 5) hipLaunchKernelGGL((wave_replay_kernel<0, 5, 4, 1>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 1>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 0>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
+    else if (P.family == 1 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 1, 1, 1>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
     else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<0, 1, 1, 0>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
     else if (P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 0, 1, 1>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
     else hipLaunchKernelGGL((wave_replay_kernel<0, 0, 1, 0>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
@@ -668,6 +687,7 @@ hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipS
     if (P.family == 5) hipLaunchKernelGGL((wave_replay_kernel<1, 5, 4, 1>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4, 1>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4, 0>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
+    else if (P.family == 1 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<1, 1, 1, 1>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
     else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<1, 1, 1, 0>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
     else if (P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<1, 0, 1, 1>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
     else hipLaunchKernelGGL((wave_replay_kernel<1, 0, 1, 0>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);

@@ -167,6 +167,15 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                 const u32 ws6[6] = { back, xs[0], xs[1], xs[2], xs[3], ahead };
                 for (int k = 0; k < 24; k++) b[k] = (u8)(ws6[k >> 2] >> (8 * (k & 3)));
                 const u32 have_lo = off >= 4 ? 0u : 4u, have_hi = 4u + avail + n_ahead;
+                if (P.family == 1 && P.swar.cls) {   // as the kernel: SWAR, five masks — which must be the statement's
+                    const WvMasks16U m0 = wv_classify16_utf8(P.lut, b, have_lo, have_hi);
+                    u32 wz[6] = { have_lo ? 0u : ws6[0], ws6[1], ws6[2], ws6[3], ws6[4], ws6[5] };
+                    const WvMasks16V m = wv_classify16_utf8_swar<6>(P.swar, wz, avail);
+                    if (m.e != m0.e || m.a != m0.a || m.f != m0.f || m.ma != m0.ma || m.mb != m0.mb) return false;
+                    const u32 vals5[5] = { m.e, m.a, m.f, m.ma, m.mb };
+                    for (int k = 0; k < 5; k++) ((uint16_t*)lds[k].data())[idx] = (uint16_t)vals5[k];
+                    continue;
+                }
                 if (P.family == 1) {
                     const WvMasks16U m = wv_classify16_utf8(P.lut, b, have_lo, have_hi);
                     ((uint16_t*)lds[0].data())[idx] = (uint16_t)m.e;
@@ -263,6 +272,11 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                                    wv_extract(lds[8], o, n), (eb | mab) != 0, fb1 != 0, ws[l] > 0, ws[l] % kWvSlice == 0, n, P.n_min);
             } else {
                 const u32 fb = o >= 3 ? (u32)wv_extract(lds[2], o - 3, 3).lo : 0u;
+                if (P.swar.cls) {
+                    const WvMask A_ = wv_extract(lds[1], o, n), F_ = wv_extract(lds[2], o, n);
+                    w[l] = wv_win_utf8(wv_extract(lds[0], o, n), A_, F_, wv_utf8_good_from(A_, F_), wv_extract(lds[3], o, n), wv_extract(lds[4], o, n), fb,
+                                       ws[l] % kWvSlice == 0, n, P.n_min);
+                } else
                 w[l] = wv_win_utf8(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[5], o, n),
                                    wv_extract(lds[3], o, n), wv_extract(lds[4], o, n), fb, ws[l] % kWvSlice == 0, n, P.n_min);
             }

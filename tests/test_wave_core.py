@@ -231,7 +231,7 @@ def test_which_missions_classify_by_ranges():
            dict(encodings=["x-user-defined"], chars_min="4", unicode_block_filter="All"), dict(encodings=["ibm866"], chars_min="7", ascii_filter="None", unicode_block_filter="Cyrillic")]
     no = [dict(encodings=["windows-1253"], chars_min="2", unicode_block_filter="All"),   # bytes without a character
           dict(encodings=["windows-1252"], chars_min="4", unicode_block_filter="All"),   # 2- and 3-byte UTF-8 forms among the accepted
-          dict(encodings=["utf-8"], chars_min="4")]
+          dict(encodings=["utf-8"], chars_min="4", unicode_block_filter="0xAAAAAAA8")]   # more than six ranges of accepted lead bytes
     yes += [dict(encodings=["big5"], chars_min="10", unicode_block_filter="Cjk"), dict(encodings=["euc-kr"], chars_min="20", unicode_block_filter="Hangul")]
     no += [dict(encodings=["shift_jis"], chars_min="4", unicode_block_filter="All"),      # bytes >= 0x80 that are characters on their own
            dict(encodings=["euc-kr"], chars_min="4", unicode_block_filter="All")]        # accepted pairs of two and three UTF-8 bytes

@@ -4,6 +4,7 @@ tag=$1
 python bench.py > gpurun_out/${tag}_bench_c3_64gib.json 2> gpurun_out/${tag}_bench_c3.err < /dev/null
 tail -c 600 gpurun_out/${tag}_bench_c3_64gib.json; echo
 SX_BUSIEST_LAST=0 python bench.py --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_c3_64gib_busiest_first.json
+SX_BUSIEST_LAST=1 python bench.py --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_c3_64gib_busiest_last.json
 # (a process that held 64 GiB of HBM has just ended: for about ten seconds the driver clears that memory, and device-to-host copies
 # run at 43 instead of 53 GB/s meanwhile — C1 and the text workload, which are bound by exactly those copies, wait for it)
 sleep 20
@@ -17,4 +18,10 @@ for w in c3 c5; do timeout 600 tools/kernel_stats.sh ${tag}_${w} --workload $w -
 timeout 600 tools/kernel_stats.sh ${tag}_c1 --workload c1 --steps 20 --warmup 5 > /dev/null 2>&1 < /dev/null
 timeout 600 tools/pmc_pass.sh ${tag}_fetch "FETCH_SIZE" > /dev/null 2>&1 < /dev/null
 timeout 600 tools/pmc_pass.sh ${tag}_write "WRITE_SIZE" > /dev/null 2>&1 < /dev/null
+# two ranks sharing the one GPU (gloo: RCCL refuses two ranks on one device): the N > 1 path of bench.py, weak and strong scaling
+python bench.py --gpus 2 --backend gloo --single-device --gib 16 --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_2ranks_1gpu_gloo.json
+python bench.py --gpus 2 --backend gloo --single-device --scaling strong --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_2ranks_1gpu_gloo_strong.json
+python bench.py --gpus 2 --backend gloo --single-device --workload c5 --gib 8 --warmup 2 --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_2ranks_1gpu_gloo_c5_8gib.json
+# SQ counters of the wave kernels
+timeout 1500 tools/wave_pmc.sh ${tag} > /dev/null 2>&1 < /dev/null
 ls -la gpurun_out/ | grep ${tag}
