@@ -121,6 +121,7 @@ struct WvWin {
     u32 probe_hb;    // double byte, first window of a slice: bytes of the first char in front of the slice (the probe is settled by decoding)
     u32 head_pend;   // double byte: bytes in front of the window that belong to a token still incomplete there (a pending lead byte: 0 / 1)
     u32 tail_pend;   // double byte: the window ends inside a token (its last byte is a lead byte waiting for its trail)
+    WvMask PB;       // UTF-16: a call that starts here (in the masks) really starts two bytes later — its first character was kept from the call before
 };
 
 enum { WV_BEFORE = 0, WV_EXACT = 1, WV_AFTER = 2 };   // == SX_PRECISION_*
@@ -1013,6 +1014,166 @@ SXD WvMasks16E wv_classify16_dbcs_swar(const PAIRS& pairs2, const u32* ws6, cons
     m.ma = (((un & ~v_s) | (one & ~v_s)) >> 1) & 0xFFFFu;
     m.mb = (un_a >> 1) & 0xFFFFu;
     return m;
+}
+
+// ------------------------------------------------------------------------------------------
+// UTF-16LE / BE (round 4; sx_codec_core.hpp ddec_utf16) for buffers that begin on the unit grid (stream parity 0) and have an even length.
+// A unit is a character (B), a high (H) or a low surrogate (L); H L is one character of four bytes.  Whole units are decoded in a fast loop;
+// a unit that is the LAST of the decoder's input (the window) is read byte by byte, and so is whatever follows while a high surrogate is
+// pending.  The two modes differ where a pending H is not followed by an L:
+//   fast:  H x   -> Malformed, the call ends behind H, x is read again                                   (MA on H's last byte)
+//   slow:  H H'  -> Malformed, the call ends behind H', H' is pending                                    (MA on H''s last byte)
+//          H B   -> Malformed, the call ends behind B, and B is kept: it is the first character of the NEXT call (`pending_bmp`) — a
+//                   character whose bytes lie in the call before.  In the masks the call boundary is put IN FRONT of B (MB on its first byte:
+//                   the text of both calls is what it was) and PB says that calls starting there report their position two bytes later.
+// Slow mode begins with a window's first unit if the unit in front of it (the window before's last, which is always left pending) is H, and goes
+// on while the unit in front is H ("chain").  What the masks cannot say makes the wavefront give the buffer back (`exotic`): a kept B that is
+// its window's last unit (it would be delivered in the next window with no byte there), and chains that cross a whole lane (seven high
+// surrogates in a row).  lut: 512 bytes — [hb] for the unit's high byte: bits 0-3 "accepted" for the low byte's quadrant (lo >> 6), bit 4 hb == 0
+// (then [256 + lo] bit 0 says accepted), bit 5 high surrogate (bits 0-3: the astral character it begins), bit 6 low surrogate.
+// ------------------------------------------------------------------------------------------
+enum { WVW_ZERO = 16, WVW_HIGH = 32, WVW_LOW = 64 };
+struct WvMasks16W { u32 e, a, f, ma, mb, pb, o2, o3, o4, exotic; };
+struct WvU16Unit { u32 kind /*0 B, 1 H, 2 L*/, acc, len; };
+template <class LUT>
+SXD WvU16Unit wv_utf16_unit(const LUT& lut, u32 u) {
+    const u32 hb = u >> 8, lo = u & 0xFFu, t = lut[hb];
+    WvU16Unit r;
+    r.kind = (t & WVW_HIGH) ? 1u : (t & WVW_LOW) ? 2u : 0u;
+    r.acc = (t & WVW_ZERO) ? (u32)(lut[256 + lo] & 1u) : ((t >> (lo >> 6)) & 1u);
+    r.len = u < 0x80u ? 1u : u < 0x800u ? 2u : 3u;
+    return r;
+}
+// The statement: the decoder's state machine byte by byte over ONE window [0, n) of `w` (bytes that exist), `hs_in` = a high surrogate is pending
+// from the window before (its acceptance in hs_acc_in).  Marks per byte, window relative (F of a character begun in front: dropped); returns
+// whether a high surrogate is pending at the end (*hs_acc_out) and, through *exotic, whether a kept B was the window's last unit.
+template <class LUT>
+SXD bool wv_utf16_walk_window(const LUT& lut, bool be, const u8* w, u32 n, bool hs_in, u32 hs_acc_in, u32* hs_acc_out, WvMasks16W* out) {
+    WvMasks16W m{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    bool hs = hs_in, slow_b = false;   // slow_b: the next unit is read byte by byte (it follows a pending H, or is the last of the window)
+    u32 hs_acc = hs_acc_in;
+    i32 hs_start = -2;
+    auto put_char = [&](i32 fs, u32 end, u32 acc, u32 len) {
+        if (fs >= 0) m.f |= 1u << fs;
+        m.e |= 1u << end; m.a |= acc << end;
+        if (len >= 2) m.o2 |= 1u << end;
+        if (len >= 3) m.o3 |= 1u << end;
+        if (len >= 4) m.o4 |= 1u << end;
+    };
+    for (u32 i = 0; i + 2 <= n; i += 2) {
+        const u32 u = be ? ((u32)w[i] << 8) | w[i + 1] : ((u32)w[i + 1] << 8) | w[i];
+        const WvU16Unit x = wv_utf16_unit(lut, u);
+        const bool last_unit = i + 4 > n;
+        if (hs) {   // slow: a high surrogate is pending
+            if (x.kind == 2) { put_char(hs_start, i + 1, hs_acc, 4); hs = false; }
+            else if (x.kind == 1) { m.ma |= 1u << (i + 1); hs_start = (i32)i; hs_acc = x.acc; }
+            else {      // kept: the first character of the next call
+                m.mb |= 1u << i; m.pb |= 1u << i;
+                put_char((i32)i, i + 1, x.acc, x.len);
+                if (last_unit) m.exotic = 1;
+                hs = false;
+            }
+            continue;
+        }
+        if (x.kind == 0) put_char((i32)i, i + 1, x.acc, x.len);
+        else if (x.kind == 2) m.ma |= 1u << (i + 1);
+        else if (last_unit) { hs = true; hs_start = (i32)i; hs_acc = x.acc; }   // read byte by byte: pending
+        else {
+            const u32 v = be ? ((u32)w[i + 2] << 8) | w[i + 3] : ((u32)w[i + 3] << 8) | w[i + 2];
+            if (wv_utf16_unit(lut, v).kind == 2) { put_char((i32)i, i + 3, x.acc, 4); i += 2; }
+            else m.ma |= 1u << (i + 1);
+        }
+    }
+    *hs_acc_out = hs_acc;
+    *out = m;
+    return hs;
+}
+// The same for a lane's 16 bytes = 8 units, whatever windows they lie in.  x4: the lane's dwords; n_units: whole units that exist; hm / accm
+// etc. come out for the neighbours.  wbm: bit j = unit j is the first of a window (bit 8: the unit behind the lane is).  prev_h / prev_acc: the
+// unit in front of the lane is H / begins an accepted astral character; cin: that unit is in a chain; next_l: the unit behind the lane is L.
+struct WvU16Lane { u32 hm, lm, accm, len2, len3; };   // bit j = unit j
+template <class LUT>
+SXD WvU16Lane wv_utf16_lane_units(const LUT& lut, bool be, const u32* x4, u32 n_units) {
+    WvU16Lane r{ 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if ((u32)j >= n_units) continue;
+        const u32 raw = (x4[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        const u32 u = be ? ((raw & 0xFFu) << 8) | (raw >> 8) : raw;
+        const WvU16Unit x = wv_utf16_unit(lut, u);
+        r.hm |= (x.kind == 1 ? 1u : 0u) << j; r.lm |= (x.kind == 2 ? 1u : 0u) << j; r.accm |= x.acc << j;
+        r.len2 |= (x.len >= 2 ? 1u : 0u) << j; r.len3 |= (x.len >= 3 ? 1u : 0u) << j;
+    }
+    return r;
+}
+// chain bits: C(j) = H(j-1) && (wb(j) || C(j-1)); bit 8 = the same for the unit behind the lane
+SXD u32 wv_utf16_chain(u32 hm, u32 wbm, u32 prev_h, u32 cin) {
+    u32 c = 0, ph = prev_h, pc = cin;
+#pragma unroll
+    for (int j = 0; j <= 8; j++) {
+        const u32 cj = ph & (((wbm >> j) & 1u) | pc);
+        c |= cj << j;
+        ph = (hm >> j) & 1u; pc = cj;
+    }
+    return c;
+}
+SXD WvMasks16W wv_classify16_utf16(const WvU16Lane& L, u32 n_units, u32 wbm, u32 prev_h, u32 prev_acc, u32 cin, u32 next_l) {
+    WvMasks16W m{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const u32 c = wv_utf16_chain(L.hm, wbm, prev_h, cin);
+    const u32 lm9 = L.lm | (next_l << 8);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if ((u32)j >= n_units) continue;
+        const u32 s = 2u * (u32)j, h = (L.hm >> j) & 1u, l = (L.lm >> j) & 1u, cj = (c >> j) & 1u;
+        const u32 ph = j ? (L.hm >> (j - 1)) & 1u : prev_h, pacc = j ? (L.accm >> (j - 1)) & 1u : prev_acc;
+        const u32 last_of_window = (wbm >> (j + 1)) & 1u;
+        if (h) {
+            if ((lm9 >> (j + 1)) & 1u) m.f |= 1u << s;                      // H L: the character begins here (wherever the call does)
+            if (cj) m.ma |= 2u << s;                                       // slow: Malformed behind it, whatever follows
+            else if (!last_of_window && !((lm9 >> (j + 1)) & 1u)) m.ma |= 2u << s;
+        } else if (l) {
+            if (ph) { m.e |= 2u << s; m.a |= (pacc * 2u) << s; m.o2 |= 2u << s; m.o3 |= 2u << s; m.o4 |= 2u << s; }
+            else m.ma |= 2u << s;
+        } else {
+            const u32 acc = (L.accm >> j) & 1u;
+            m.f |= 1u << s; m.e |= 2u << s; m.a |= (acc * 2u) << s;
+            m.o2 |= (((L.len2 >> j) & 1u) * 2u) << s; m.o3 |= (((L.len3 >> j) & 1u) * 2u) << s;
+            if (cj) { m.mb |= 1u << s; m.pb |= 1u << s; if (last_of_window) m.exotic = 1; }   // kept for the next call
+        }
+    }
+    return m;
+}
+// the window of a UTF-16 Mission.  f2: a character begins two bytes in front of the window and is still open there (an H that the window's
+// first unit, an L, completes)
+SXD WvWin wv_win_utf16(WvMask E, WvMask A, WvMask F, WvMask MA, WvMask MB, WvMask PB, WvMask O2, WvMask O3, WvMask O4, bool slice_start, u32 n, u32 n_min) {
+    WvWin w;
+    w.E = E; w.A = A; w.F = F; w.O2 = O2; w.O3 = O3; w.O4 = O4; w.PB = PB; w.n = n;
+    w.G = wv_utf8_good_from(A, F);
+    w.LS = wv_long_starts(w.G, n_min);
+    w.CS = wm_and(wm_or(wm_shl1(MA), MB), wm_andn(wm_below(n), wm_below(1)));
+    w.tail_empty = n && wm_test(MA, n - 1) ? 1u : 0u;
+    w.pre_empty = n && wm_test(MB, 0) ? 1u : 0u;
+    w.head_back = 0;
+    const u32 e0 = wm_next(E, 0);
+    if (e0 < 128 && wm_prev(F, e0) < 0) w.head_back = 2;   // H in front of the window, L here
+    w.probe_before = slice_start && w.head_back ? 1u : 0u;   // (a fresh decoder meets the low surrogate alone: finding_collection.rs:176-207)
+    w.slice_start = slice_start ? 1u : 0u;
+    w.probe_hb = 0; w.head_pend = 0; w.tail_pend = 0;
+    return w;
+}
+// the string of a UTF-16 finding: its source units [s, s + n)
+SXD u32 wv_transcode_utf16(bool be, const u8* s, u32 n, u8* dst) {
+    u32 w = 0;
+    for (u32 p = 0; p + 2 <= n; p += 2) {
+        u32 u = be ? ((u32)s[p] << 8) | s[p + 1] : ((u32)s[p + 1] << 8) | s[p];
+        if ((u & 0xFC00u) == 0xD800u && p + 4 <= n) {
+            const u32 v = be ? ((u32)s[p + 2] << 8) | s[p + 3] : ((u32)s[p + 3] << 8) | s[p + 2];
+            u = 0x10000u + ((u & 0x3FFu) << 10) + (v & 0x3FFu);
+            p += 2;
+        }
+        w += dput_cp(dst + w, u);
+    }
+    return w;
 }
 
 // ------------------------------------------------------------------------------------------
