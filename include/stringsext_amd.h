@@ -212,7 +212,10 @@ const uint16_t* sx_decoder_table(uint32_t encoding, uint64_t* n_words);
  * relies on: src/helper.rs:315-322, 349-421)?  Returns 0 if not covered, < 0 on error, else the class byte it keeps per
  * input byte in classes[256] and 1 + family: 1 for a single-byte encoding (bit 0 a character, bit 1 its UTF-8 lead byte passes
  * af / ubf — src/mission.rs:333-348 —, bit 2 / 3 its UTF-8 form has 2 / 3 bytes), 2 for UTF-8 (bits 0-2: 0 never valid,
- * 1 ASCII, 2 continuation byte, 3 / 4 / 5 lead byte of 2 / 3 / 4; bit 3 a character that starts with it passes). */
+ * 1 ASCII, 2 continuation byte, 3 / 4 / 5 lead byte of 2 / 3 / 4; bit 3 a character that starts with it passes), 3 for
+ * UTF-16LE / BE — then classes[] must hold 512 bytes: [hb] per high byte of a unit: bits 0-3 the low byte's quadrants (lo >> 6)
+ * whose characters pass, bit 4 hb == 0 (then [256 + lo] bit 0 says whether U+00lo passes), bit 5 / 6 a high / low surrogate
+ * (bits 0-3 of a high surrogate: the astral character it begins passes). */
 int sx_wave_classes(const sx_mission* mission, uint8_t* classes);
 /* ... and for the two-byte family (sx_wave_classes returns 5: Big5 — only if the Mission rejects U+00C0.. and U+0300.. —,
  * Shift_JIS, EUC-KR; classes[]: as a single-byte encoding's for the bytes that are characters on their own, bit 4 = lead byte):

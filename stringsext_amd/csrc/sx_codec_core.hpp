@@ -29,6 +29,7 @@ struct DStep { int result; u32 read, written; };
 // 3 UTF-16BE, 4 Big5, 5 EUC-JP, 0 every single-byte encoding (SX_ENC_* 16.., x-user-defined).
 // Family 4 = the two-byte encodings (Big5, Shift_JIS, EUC-KR: a lead byte and one more; which one is a run-time
 // value), family 5 = EUC-JP (three-byte tokens too).
+constexpr int kEncUtf16le = 2, kEncUtf16be = 3;
 constexpr int kEncBig5 = 64, kEncEucJp = 65, kEncShiftJis = 66, kEncEucKr = 67, kEncGb18030 = 68, kEncGbk = 69;  // == SX_ENC_* (include/stringsext_amd.h)
 constexpr bool enc_is_gb(int e) { return e == kEncGb18030 || e == kEncGbk; }   // GBK decodes as gb18030
 constexpr int enc_family(u32 encoding) {

@@ -113,6 +113,29 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
             }
         }
     } else if (m->is_utf16()) {
+        {   // the wave-cooperative stage B (sx_wave_core.hpp wv_utf16_unit): per high byte — the low byte's quadrants that pass, hb == 0, high / low surrogate —, per low byte of U+0000..U+00FF
+            // (windows of >= 10 bytes: the slice-start probe, finding_collection.rs:176-207, lets a fresh decoder run over the slice until 8 bytes are
+            // written — five units at most; in a shorter window the real decoder has already met the window's last unit, which it treats differently)
+            m->wave_ok = wv_mission_ok(in.grep_char, in.require_same_unicode_block, in.chars_min_nb, (uint32_t)m->q) && m->window % 2 == 0 && m->window >= 10;
+            m->wave_family = 2;
+            m->wave_lut.assign(512, 0);
+            for (int lb = 0; lb < 256; lb++) m->wave_lut[256 + (size_t)lb] = m->filter.pass_lead(utf8_lead_of((uint32_t)lb)) ? 1 : 0;
+            for (int hb = 0; hb < 256; hb++) {
+                uint8_t v = 0;
+                if (hb == 0) v = WVW_ZERO;
+                else if (hb >= 0xD8 && hb <= 0xDB) {
+                    v = WVW_HIGH;
+                    for (int qd = 0; qd < 4; qd++) {   // (the lead byte of an astral character's UTF-8 form depends on the high surrogate only)
+                        const uint32_t u = (uint32_t)(hb << 8) | (uint32_t)(qd << 6);
+                        if (m->filter.pass_ubf_filter(utf8_lead_of(0x10000u + ((u & 0x3FF) << 10)))) v |= (uint8_t)(1 << qd);
+                    }
+                } else if (hb >= 0xDC && hb <= 0xDF) v = WVW_LOW;
+                else
+                    for (int qd = 0; qd < 4; qd++)
+                        if (m->filter.pass_ubf_filter(utf8_lead_of((uint32_t)(hb << 8) | (uint32_t)(qd << 6)))) v |= (uint8_t)(1 << qd);
+                m->wave_lut[(size_t)hb] = v;
+            }
+        }
         const bool no_bmp3 = ((in.ubf >> 32) & 0xFFFFull) == 0;   // U+0800..U+FFFF <-> bits 32..47
         const bool no_astral = ((in.ubf >> 48) & 0x1Full) == 0;   // bits 48..52
         if (!force_generic && af_is_range && ubf2_is_range && no_bmp3 && no_astral) {

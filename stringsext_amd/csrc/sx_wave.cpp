@@ -3,7 +3,7 @@
 // The lane-per-region replay costs time per long run, the wave kernels cost time per input byte (every window of the
 // buffer is replayed, a lane each, whether anything is found in it or not): they take over when a Mission has more
 // than a run per ~500 bytes — `-e ascii -n 4` on binaries, text, a legacy code page on random bytes — and cover the
-// Missions sx_wave_core.hpp names (no -g, no -r, 1 <= n <= q <= 64; a single-byte decoder, UTF-8, or Big5 / Shift_JIS / EUC-KR).
+// Missions sx_wave_core.hpp names (no -g, no -r, 1 <= n <= q <= 64; a single-byte decoder, UTF-8, UTF-16LE / BE, Big5 / Shift_JIS / EUC-KR, EUC-JP).
 //   host:   the buffer's first window(s) from the exact carried ScannerState (its leftover's bytes lie in the previous
 //           buffer) — FindingCollection::from as ever, replay_exact_windows;
 //   device: every other window: count pass -> exclusive sums + verification of the wavefronts' assumed entry states ->
@@ -26,7 +26,7 @@ static uint64_t wave_min_density_bytes(uint32_t family = 0) {
     static const uint64_t v = [] { const char* e = getenv("SX_WAVE_BYTES_PER_RUN"); return e ? (uint64_t)atoll(e) : 0ull; }();
     // (round 4: the count passes are 2.5 to 4 times faster — single byte 0.7 ps per byte, two-byte family 1.4, EUC-JP 2.3 — and a Mission on
     // the wave path leaves the shared stage-B stream alone: EUC-JP + Asian on random bytes, a run per 3.4 KB, C5: 444 -> 415 ms per step)
-    return v ? v : (family == 5 ? 4000ull : family == 4 ? 1600ull : family == 1 ? 480ull : 1000ull);
+    return v ? v : (family == 5 ? 4000ull : family == 4 ? 1600ull : family == 1 ? 480ull : family == 2 ? 960ull : 1000ull);
 }
 
 // n_runs: the long runs (or records) of the buffer; heavy_tiles: 1 KiB tiles of it that took the scan kernel's general path.  Dense =
@@ -75,15 +75,22 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
     ScannerState st = ctx->states[k];
     MissionFindings hf;
     uint64_t E = 0;
+    const size_t src_per_out = m.wave_family == 2 ? 2 : 1;   // source bytes per byte of leftover text, at most (UTF-16: 'A' is two)
     for (int guard = 0; guard < 64 && E < len; guard++) {
         uint64_t ws; uint32_t wn;
         wv_window_at(wv_window_no(E, W, wps), W, wps, len, &ws, &wn);
         const uint64_t next = ws + wn;
         replay_exact_windows(m, st, job.consumed0[k], job.stream0[k], view, len, job.file_id, E, next, &hf);
         E = next;
-        if (st.last_scan_run_leftover.size() + 4 <= E) break;
+        if (st.last_scan_run_leftover.size() * src_per_out + 4 <= E) break;
     }
-    if (st.last_scan_run_leftover.size() + 4 > E && E < len) return SX_WAVE_FALLBACK;
+    if (st.last_scan_run_leftover.size() * src_per_out + 4 > E && E < len) return SX_WAVE_FALLBACK;
+    if (m.wave_family == 2 && E < len) {
+        // UTF-16 (sx_wave_core.hpp): the device's masks assume units that begin on the buffer's even offsets, no window that ends in half a unit,
+        // and no character kept from the call before (`pending_bmp`) where its windows begin
+        const DDecoder& d0 = st.decoder.raw();
+        if ((len & 1) || d0.lead_byte >= 0 || d0.pending_bmp) return SX_WAVE_FALLBACK;
+    }
     for (sx_finding& f : hf.v) f.slice_index += job.slice_base;
     const uint64_t nfh = hf.v.size(), nbh = hf.arena.size();
 
@@ -105,6 +112,11 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         // source bytes from the leftover's first byte to E: single byte: one per char; UTF-8: its bytes + what the decoder holds of the next char
         const DDecoder& dd = st.decoder.raw();
         uint32_t lback = m.wave_family == 0 ? lc : lb + (dd.needed ? dd.seen + 1u : 0u);
+        if (m.wave_family == 2) {   // UTF-16: two source bytes per character, four for those with four bytes of UTF-8; + a pending high surrogate
+            lback = 0;
+            for (unsigned char c : st.last_scan_run_leftover) if ((c & 0xC0) != 0x80) lback += c >= 0xF0 ? 4u : 2u;
+            if (dd.lead_surrogate) lback += 2;
+        }
         if (m.wave_family >= 4) {
             // two-byte family / EUC-JP: one to three source bytes per char — which, the text does not say: the bytes in front of E (less
             // the byte(s) of the token the decoder holds) that decode to exactly the leftover
@@ -137,8 +149,8 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         K = std::min<uint64_t>(K, n_waves);
 
         if (!d.d_wave_lut) {
-            HIP_TRY(ctx, hipMalloc((void**)&d.d_wave_lut, 256));
-            HIP_TRY(ctx, hipMemcpy(d.d_wave_lut, m.wave_lut.data(), 256, hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMalloc((void**)&d.d_wave_lut, m.wave_lut.size()));   // (256 bytes; UTF-16: 512)
+            HIP_TRY(ctx, hipMemcpy(d.d_wave_lut, m.wave_lut.data(), m.wave_lut.size(), hipMemcpyHostToDevice));
         }
         if (m.wave_family == 4 && !d.d_wave_pairs) {   // (family 5 has no 4-bit table)
             HIP_TRY(ctx, hipMalloc((void**)&d.d_wave_pairs, 8192 * 4));

@@ -47,6 +47,7 @@ SXD WvMask wm_andn(WvMask a, WvMask b) { return WvMask{ a.lo & ~b.lo, a.hi & ~b.
 SXD WvMask wm_or(WvMask a, WvMask b) { return WvMask{ a.lo | b.lo, a.hi | b.hi }; }
 SXD bool wm_any(WvMask a) { return (a.lo | a.hi) != 0; }
 SXD u32 wm_popc(WvMask a) { return wv_popc64(a.lo) + wv_popc64(a.hi); }
+SXD WvMask wm_bit(u32 i) { return i < 64 ? WvMask{ 1ull << i, 0 } : WvMask{ 0, 1ull << (i - 64) }; }
 SXD bool wm_test(WvMask a, u32 i) { return i < 64 ? ((a.lo >> i) & 1) != 0 : ((a.hi >> (i - 64)) & 1) != 0; }
 SXD u64 wv_low64(u32 n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }   // the n lowest bits
 // bits [0, n)
@@ -153,14 +154,15 @@ SXD bool wv_mission_ok(int grep_char, u32 same_block, u32 n_min, u32 q) {
 // EMIT(din, precision, completes, src_rel, src_len, out_len): src_rel = first source byte relative to the window start
 // (negative: in front of it), out_len = bytes of the string.
 // KIND 0: single-byte decoders (a char per byte; string bytes from O2 / O3); 1: UTF-8 (the string is the source bytes);
-// 2: double-byte decoders (chars from E / F; string bytes from O2 / O3 / O4 at the chars' last bytes).
+// 2: double-byte decoders (chars from E / F; string bytes from O2 / O3 / O4 at the chars' last bytes); 3: UTF-16 — as 2, no slice-start
+// probe left open, and a call whose first character was kept from the call before (w.PB) reports its position two bytes later.
 template <int KIND, class EMIT>
 SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 cend, bool invalid_after, bool first_call, EMIT& emit,
                  u32 probe = 0) {
     const bool cont = st.cut != 0;   // :240-241: consumed by this call whatever it yields
     st.cut = 0;
     const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback;
-    const u32 lsrc = KIND == 2 ? lback - (first_call || din == 0 ? w.head_pend : 0u) : lback;   // the leftover's own source bytes
+    const u32 lsrc = KIND >= 2 ? lback - (first_call || din == 0 ? w.head_pend : 0u) : lback;   // the leftover's own source bytes
     const bool has_left = lrem > 0;
     st.lc = 0; st.lb = 0; st.lback = 0;   // :211-227: the leftover is prepended, then gone
     const WvMask rng = wm_range(din, cend);
@@ -210,14 +212,15 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
                 if (BYTES) {
                     const WvMask tr_ = wm_range(at, last_e + 1);
                     out_b += inwin + wm_popc(wm_and(w.O2, tr_)) + 2 * wm_popc(wm_and(w.O3, tr_));
-                } else if (KIND == 2) {
+                } else if (KIND >= 2) {
                     const WvMask tr_ = wm_range(at, last_e + 1);   // (the length bits sit on the chars' last bytes)
                     out_b += inwin + wm_popc(wm_and(w.O2, tr_)) + wm_popc(wm_and(w.O3, tr_)) + wm_popc(wm_and(w.O4, tr_));
                 } else out_b = (u32)(src_end - src);    // UTF-8 in, UTF-8 out: the string is the source bytes
             }
             if (again) { st.lc = pn; st.lb = out_b; st.lback = (u32)((i32)w.n - src); st.cut = 0; }   // finding_collection.rs:269-285
             else {                                                                                     // :255-268
-                emit(din, prec, comp, src, (u32)(src_end - src), out_b);
+                // (UTF-16: the empty call in front of byte 0 is the real call [0, 2) — it starts where it says)
+                emit(din + (KIND == 3 && cend > din && wm_test(w.PB, din) ? 2u : 0u), prec, comp, src, (u32)(src_end - src), out_b);
                 st.lc = 0; st.lb = 0; st.lback = 0; st.cut = maybe_cut ? 1u : 0u;
             }
             prec = WV_AFTER;   // :289
@@ -265,7 +268,7 @@ template <int KIND, class EMIT>
 SXD void wv_window_calls(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, bool skip_idle_calls = true) {
     u32 probe = 0;
     if (w.pre_empty) {
-        if (w.slice_start && st.lb) probe = wv_probe_pack(st.lb, st.lback) | (KIND == 2 ? w.head_pend << 29 : 0u);
+        if (KIND != 3 && w.slice_start && st.lb) probe = wv_probe_pack(st.lb, st.lback) | (KIND == 2 ? w.head_pend << 29 : 0u);
         wv_call<KIND>(P, w, st, 0u, 0u, true, false, emit);
     }
     u32 din = 0;
@@ -353,12 +356,12 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, c
     u32 probe = 0;
     // ---- an empty call in front of byte 0 (the byte a pending sequence rejected is read again): it takes the leftover and the cut flag
     if (w.pre_empty) {
-        if (w.slice_start && st.lb) probe = wv_probe_pack(st.lb, st.lback) | (KIND == 2 ? w.head_pend << 29 : 0u);
+        if (KIND != 3 && w.slice_start && st.lb) probe = wv_probe_pack(st.lb, st.lback) | (KIND == 2 ? w.head_pend << 29 : 0u);
         const bool cont = st.cut != 0;
         const u32 lc = st.lc, lb = st.lb, lback = st.lback;
         st.lc = 0; st.lb = 0; st.lback = 0; st.cut = 0;
         if (lc && (cont || lc >= P.n_min))   // (its text ends with the call, the call in an error: helper.rs:410-415)
-            emit(0u, (u32)WV_BEFORE, cont, -(i32)lback, KIND == 1 ? lb : (KIND == 2 ? lback - w.head_pend : lback), lb);
+            emit(0u, (u32)WV_BEFORE, cont, -(i32)lback, KIND == 1 ? lb : (KIND >= 2 ? lback - w.head_pend : lback), lb);
     }
     // ---- the call in hand
     u32 din = 0, cend = wm_next(w.CS, 1);
@@ -368,7 +371,7 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, c
     const bool cont0 = st.cut != 0;
     st.cut = 0;
     const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback;
-    const u32 lsrc = KIND == 2 ? lback - w.head_pend : lback;
+    const u32 lsrc = KIND >= 2 ? lback - w.head_pend : lback;
     const bool has_left = lrem > 0;
     st.lc = 0; st.lb = 0; st.lback = 0;
     u32 prec = (has_left || w.probe_before) ? WV_BEFORE : WV_EXACT;
@@ -412,7 +415,7 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, c
             }
             if (again) { st.lc = pn; st.lb = out_b; st.lback = (u32)((i32)n - src); st.cut = 0; }   // finding_collection.rs:269-285
             else {                                                                                   // :255-268
-                emit(din, prec, comp, src, (u32)(src_end - src), out_b);
+                emit(din + (KIND == 3 && wm_test(w.PB, din) ? 2u : 0u), prec, comp, src, (u32)(src_end - src), out_b);
                 st.lc = 0; st.lb = 0; st.lback = 0; st.cut = maybe_cut ? 1u : 0u;
                 cut_cend = cend;
             }
@@ -1044,53 +1047,11 @@ SXD WvU16Unit wv_utf16_unit(const LUT& lut, u32 u) {
     r.len = u < 0x80u ? 1u : u < 0x800u ? 2u : 3u;
     return r;
 }
-// The statement: the decoder's state machine byte by byte over ONE window [0, n) of `w` (bytes that exist), `hs_in` = a high surrogate is pending
-// from the window before (its acceptance in hs_acc_in).  Marks per byte, window relative (F of a character begun in front: dropped); returns
-// whether a high surrogate is pending at the end (*hs_acc_out) and, through *exotic, whether a kept B was the window's last unit.
-template <class LUT>
-SXD bool wv_utf16_walk_window(const LUT& lut, bool be, const u8* w, u32 n, bool hs_in, u32 hs_acc_in, u32* hs_acc_out, WvMasks16W* out) {
-    WvMasks16W m{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    bool hs = hs_in, slow_b = false;   // slow_b: the next unit is read byte by byte (it follows a pending H, or is the last of the window)
-    u32 hs_acc = hs_acc_in;
-    i32 hs_start = -2;
-    auto put_char = [&](i32 fs, u32 end, u32 acc, u32 len) {
-        if (fs >= 0) m.f |= 1u << fs;
-        m.e |= 1u << end; m.a |= acc << end;
-        if (len >= 2) m.o2 |= 1u << end;
-        if (len >= 3) m.o3 |= 1u << end;
-        if (len >= 4) m.o4 |= 1u << end;
-    };
-    for (u32 i = 0; i + 2 <= n; i += 2) {
-        const u32 u = be ? ((u32)w[i] << 8) | w[i + 1] : ((u32)w[i + 1] << 8) | w[i];
-        const WvU16Unit x = wv_utf16_unit(lut, u);
-        const bool last_unit = i + 4 > n;
-        if (hs) {   // slow: a high surrogate is pending
-            if (x.kind == 2) { put_char(hs_start, i + 1, hs_acc, 4); hs = false; }
-            else if (x.kind == 1) { m.ma |= 1u << (i + 1); hs_start = (i32)i; hs_acc = x.acc; }
-            else {      // kept: the first character of the next call
-                m.mb |= 1u << i; m.pb |= 1u << i;
-                put_char((i32)i, i + 1, x.acc, x.len);
-                if (last_unit) m.exotic = 1;
-                hs = false;
-            }
-            continue;
-        }
-        if (x.kind == 0) put_char((i32)i, i + 1, x.acc, x.len);
-        else if (x.kind == 2) m.ma |= 1u << (i + 1);
-        else if (last_unit) { hs = true; hs_start = (i32)i; hs_acc = x.acc; }   // read byte by byte: pending
-        else {
-            const u32 v = be ? ((u32)w[i + 2] << 8) | w[i + 3] : ((u32)w[i + 3] << 8) | w[i + 2];
-            if (wv_utf16_unit(lut, v).kind == 2) { put_char((i32)i, i + 3, x.acc, 4); i += 2; }
-            else m.ma |= 1u << (i + 1);
-        }
-    }
-    *hs_acc_out = hs_acc;
-    *out = m;
-    return hs;
-}
-// The same for a lane's 16 bytes = 8 units, whatever windows they lie in.  x4: the lane's dwords; n_units: whole units that exist; hm / accm
+// (The decoder's state machine byte by byte over one window — the statement these marks are compared with, window by window — is in
+// tests/native/wave_core_host.cpp.)  A lane's 16 bytes = 8 units, whatever windows they lie in.  x4: the lane's dwords; n_units: whole units that exist; hm / accm
 // etc. come out for the neighbours.  wbm: bit j = unit j is the first of a window (bit 8: the unit behind the lane is).  prev_h / prev_acc: the
-// unit in front of the lane is H / begins an accepted astral character; cin: that unit is in a chain; next_l: the unit behind the lane is L.
+// unit in front of the lane is H / begins an accepted astral character; c0: the lane's first unit is read in slow mode; next_l: the unit
+// behind the lane is L.
 struct WvU16Lane { u32 hm, lm, accm, len2, len3; };   // bit j = unit j
 template <class LUT>
 SXD WvU16Lane wv_utf16_lane_units(const LUT& lut, bool be, const u32* x4, u32 n_units) {
@@ -1106,20 +1067,23 @@ SXD WvU16Lane wv_utf16_lane_units(const LUT& lut, bool be, const u32* x4, u32 n_
     }
     return r;
 }
-// chain bits: C(j) = H(j-1) && (wb(j) || C(j-1)); bit 8 = the same for the unit behind the lane
-SXD u32 wv_utf16_chain(u32 hm, u32 wbm, u32 prev_h, u32 cin) {
-    u32 c = 0, ph = prev_h, pc = cin;
+// chain bits: C(j) = H(j-1) && (wb(j) || C(j-1)) for j = 1..8 (bit 8: the unit behind the lane), bit 0 = c0 as handed in by the lane in front
+SXD u32 wv_utf16_chain(u32 hm, u32 wbm, u32 c0) {
+    u32 c = c0 & 1u, pc = c0 & 1u;
 #pragma unroll
-    for (int j = 0; j <= 8; j++) {
-        const u32 cj = ph & (((wbm >> j) & 1u) | pc);
+    for (int j = 1; j <= 8; j++) {
+        const u32 cj = ((hm >> (j - 1)) & 1u) & (((wbm >> j) & 1u) | pc);
         c |= cj << j;
-        ph = (hm >> j) & 1u; pc = cj;
+        pc = cj;
     }
     return c;
 }
-SXD WvMasks16W wv_classify16_utf16(const WvU16Lane& L, u32 n_units, u32 wbm, u32 prev_h, u32 prev_acc, u32 cin, u32 next_l) {
+// what a lane hands on (bit 8 of the chain) depends on what it was handed only if all of its units are high surrogates and no window starts
+// among units 1..8: the kernels take the value for c0 = 0 and give the buffer back where the two differ
+SXD bool wv_utf16_transparent(u32 hm, u32 wbm) { return ((wv_utf16_chain(hm, wbm, 0u) ^ wv_utf16_chain(hm, wbm, 1u)) >> 8) != 0; }
+SXD WvMasks16W wv_classify16_utf16(const WvU16Lane& L, u32 n_units, u32 wbm, u32 prev_h, u32 prev_acc, u32 c0, u32 next_l) {
     WvMasks16W m{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    const u32 c = wv_utf16_chain(L.hm, wbm, prev_h, cin);
+    const u32 c = wv_utf16_chain(L.hm, wbm, c0);
     const u32 lm9 = L.lm | (next_l << 8);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -1143,22 +1107,38 @@ SXD WvMasks16W wv_classify16_utf16(const WvU16Lane& L, u32 n_units, u32 wbm, u32
     }
     return m;
 }
-// the window of a UTF-16 Mission.  f2: a character begins two bytes in front of the window and is still open there (an H that the window's
-// first unit, an L, completes)
-SXD WvWin wv_win_utf16(WvMask E, WvMask A, WvMask F, WvMask MA, WvMask MB, WvMask PB, WvMask O2, WvMask O3, WvMask O4, bool slice_start, u32 n, u32 n_min) {
+// What a wavefront keeps per lane and tile: four words of 16 bits.  The marks of a unit sit on its first byte (even bits: F, MB, "is a high
+// surrogate", O3) or on its last (odd bits: E, A, MA, O2) — two masks share a word.
+struct WvU16Packed { u32 m0, m1, m2, m3; };   // E | F,  A | MB,  MA | H,  O2 | O3 >> 1
+SXD WvU16Packed wv_utf16_pack(const WvMasks16W& m, u32 hm) {
+    u32 h = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) h |= ((hm >> j) & 1u) << (2 * j);
+    return WvU16Packed{ m.e | m.f, m.a | m.mb, m.ma | h, m.o2 | (m.o3 >> 1) };
+}
+// the window of a UTF-16 Mission from those words; h_before: the unit in front of the window is a high surrogate (it is pending there: a
+// window's last unit, if H, always is)
+SXD WvWin wv_win_utf16(WvMask M0, WvMask M1, WvMask M2, WvMask M3, bool h_before, bool slice_start, u32 n, u32 n_min) {
+    const WvMask odd{ 0xAAAAAAAAAAAAAAAAull, 0xAAAAAAAAAAAAAAAAull }, even{ 0x5555555555555555ull, 0x5555555555555555ull };
     WvWin w;
-    w.E = E; w.A = A; w.F = F; w.O2 = O2; w.O3 = O3; w.O4 = O4; w.PB = PB; w.n = n;
-    w.G = wv_utf8_good_from(A, F);
+    w.E = wm_and(M0, odd); w.F = wm_and(M0, even); w.A = wm_and(M1, odd);
+    const WvMask MB = wm_and(M1, even), MA = wm_and(M2, odd);
+    w.O2 = wm_and(M3, odd); w.O3 = wm_shl1(wm_and(M3, even));
+    w.O4 = wm_andn(w.E, wm_shl1(w.F));        // four bytes: the byte in front of the character's last one is not its first
+    w.PB = MB; w.n = n;
+    // (a high surrogate read in slow mode ends its call AND begins the character the low surrogate behind it completes, in the next call:
+    // its bytes do not count as that character's, so that a stretch of accepted bytes never begins in front of its call)
+    w.G = wm_andn(wv_utf8_good_from(w.A, w.F), wm_or(MA, wm_shr(MA, 1)));
     w.LS = wv_long_starts(w.G, n_min);
     w.CS = wm_and(wm_or(wm_shl1(MA), MB), wm_andn(wm_below(n), wm_below(1)));
     w.tail_empty = n && wm_test(MA, n - 1) ? 1u : 0u;
     w.pre_empty = n && wm_test(MB, 0) ? 1u : 0u;
     w.head_back = 0;
-    const u32 e0 = wm_next(E, 0);
-    if (e0 < 128 && wm_prev(F, e0) < 0) w.head_back = 2;   // H in front of the window, L here
+    const u32 e0 = wm_next(w.E, 0);
+    if (e0 < 128 && wm_prev(w.F, e0) < 0) w.head_back = 2;   // H in front of the window, L here
     w.probe_before = slice_start && w.head_back ? 1u : 0u;   // (a fresh decoder meets the low surrogate alone: finding_collection.rs:176-207)
     w.slice_start = slice_start ? 1u : 0u;
-    w.probe_hb = 0; w.head_pend = 0; w.tail_pend = 0;
+    w.probe_hb = 0; w.head_pend = h_before ? 2u : 0u; w.tail_pend = 0;
     return w;
 }
 // the string of a UTF-16 finding: its source units [s, s + n)

@@ -83,6 +83,7 @@ SXD void wv_write_finding(const WaveParams& P, u64 fi, u8* a, u64 a_off, u64 win
     } else P.findings[fi] = r;
     const u8* s = P.data + (u64)((long long)win_pos + src_rel);
     if (FAM >= 4) (void)wv_transcode_dbcs((int)P.encoding, P.table, s, src_len, a);
+    else if (FAM == 2) (void)wv_transcode_utf16(P.encoding == (u32)kEncUtf16be, s, src_len, a);
     else if (out_len == src_len) {     // every char is one byte on both sides (ASCII; UTF-8 input)
         for (u32 t = 0; t < src_len; t++) a[t] = s[t];
     } else {
@@ -116,7 +117,7 @@ template <int WPB> SXD void wave_lds_sync() {
 
 // masks a wavefront keeps per batch (16 bits per lane and tile each).  CLS 1: the classes come from ranges (sx_device.hpp WvSwar): a
 // single-byte Mission then stores accepted / >= 0x80 only, a two-byte one E, A, F, MA, MB (G and the lengths follow from them)
-constexpr int wv_n_masks(int fam, int cls) { return fam == 5 ? 5 : fam == 4 ? (cls ? 5 : 9) : fam == 1 ? (cls ? 5 : 6) : cls ? 2 : 4; }
+constexpr int wv_n_masks(int fam, int cls) { return fam == 5 ? 5 : fam == 4 ? (cls ? 5 : 9) : fam == 1 ? (cls ? 5 : 6) : fam == 2 ? 4 : cls ? 2 : 4; }
 constexpr u32 kMaskWords = kWvMaxTiles * 32 + 8;
 constexpr u32 wv_lds_words(int fam, int cls) {   // ... and the descriptors staged in their place need kWvStage x 3 x 64 words
     return (u32)wv_n_masks(fam, cls) * kMaskWords > kWvStage * 192u ? (u32)wv_n_masks(fam, cls) * kMaskWords : kWvStage * 192u;
@@ -145,10 +146,11 @@ template <int MODE, int FAM, int WPB, int CLS>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ(MODE, FAM, CLS)))) void wave_replay_kernel(const WaveParams P) {
     // FAM 0: valid, accepted, O2, O3 (CLS 1: accepted, >= 0x80); FAM 1: E, A, F, MA, MB, G; FAM 4: E, A, F, MA, MB, G, O2, O3, O4 — 16 bits per lane and tile
     __shared__ u32 lds_all[WPB][wv_lds_words(FAM, CLS)];
-    __shared__ u8 lds_lut[CLS ? 4 : 256];
+    __shared__ u8 lds_lut[FAM == 2 ? 512 : CLS ? 4 : 256];
     __shared__ u32 lds_pairs[FAM == 5 ? kWvJisWords + 3 : FAM == 4 ? (CLS ? 4096 : 8192) : 1];
     const u32 lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
     if (!CLS && threadIdx.x < 64) ((u32*)lds_lut)[threadIdx.x] = ((const u32*)P.lut)[threadIdx.x];
+    if (FAM == 2 && threadIdx.x < 64) ((u32*)lds_lut)[FAM == 2 ? 64 + threadIdx.x : 0] = ((const u32*)P.lut)[64 + threadIdx.x];   // (UTF-16: 512 bytes)
     if (FAM == 4) for (u32 i = threadIdx.x; i < (CLS ? 4096u : 8192u); i += 64 * WPB) lds_pairs[i] = CLS ? P.pairs2[i] : P.pairs[i];
     if (FAM == 5) for (u32 i = threadIdx.x; i < kWvJisWords; i += 64 * WPB) lds_pairs[i] = P.pairs2[i];
     __syncthreads();
@@ -263,6 +265,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         u32x4 xa = issue(0), xb = issue(1), xc = issue(2), xd = issue(3);
         // the four bytes in front of tile0 and behind the batch's last tile (the same address in every lane)
         u32 edge_back = tile0 >= 4 ? *(const u32*)(P.data + (tile0 - 4)) : 0u;
+        u32 u16_carry = 0;   // UTF-16: what lane 63 of the tile before hands on (bit 0 its last unit is a high surrogate, 1 whose character passes, 2 the unit behind it is read in slow mode)
+        bool u16_exo = false;   // ... a case the masks cannot say: the wavefront gives the buffer back
         u32 euc_spill = 0;   // EUC-JP: marks of the tile's last tokens that lie on the next tile's first two bytes (five masks x 2 bits)
         const u32 edge_after = FAM == 0 ? 0u : (u32)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(n_tiles * kTileBytes), 0, 0);
 
@@ -306,7 +310,45 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 if (n_ahead < 4) ahead = n_ahead ? ahead & ((1u << (8 * n_ahead)) - 1u) : 0u;
                 const u32 ws6[6] = { back, x.x, x.y, x.z, x.w, ahead };
                 const u32 have_lo = has_back ? 0u : 4u, have_hi = 4u + avail + n_ahead;
-                if (FAM == 5) {
+                if (FAM == 2) {
+                    // UTF-16 (sx_wave_core.hpp wv_classify16_utf16): eight units per lane; which of them begin a window; from the lane in front:
+                    // is its last unit a high surrogate, does the character that one begins pass, is my first unit read in slow mode
+                    const bool be = P.encoding == (u32)kEncUtf16be;
+                    const u32 n_units = avail >> 1;
+                    const u32 xs4[4] = { x.x, x.y, x.z, x.w };
+                    const WvU16Lane L = wv_utf16_lane_units(lds_lut, be, xs4, n_units);
+                    const u32 r = (u32)((tile0 + (u64)rel) & (kWvSlice - 1));
+                    const u32 rw = r % P.W;
+                    u32 wbm = r == kWvSlice - 16 ? 0x100u : 0u;                        // (a slice begins behind the lane)
+                    for (u32 d = rw ? P.W - rw : 0u; d <= 16u; d += P.W) wbm |= 1u << (d >> 1);
+                    if (left >= 0 && left <= 16) wbm |= 1u << ((u32)left >> 1);        // the buffer's end ends a window too
+                    if (t == 0) {   // the batch's first tile: from the dword in front of it
+                        u16_carry = 0;
+                        if (tile0 >= 4) {
+                            const u32 raw = edge_back >> 16;
+                            const WvU16Unit pu = wv_utf16_unit(lds_lut, be ? ((raw & 0xFFu) << 8) | (raw >> 8) : raw);
+                            // (whether my first unit is read in slow mode is not known here; it cannot matter 16 bytes on — unless all of lane 0's units are high surrogates)
+                            u16_carry = (pu.kind == 1 ? 5u : 0u) | (pu.acc << 1);
+                        }
+                    }
+                    const bool transparent = L.hm == 0xFFu && (wbm & 0x1FEu) == 0;
+                    if (transparent || (t == 0 && lane == 0 && (u16_carry & 1u) && L.hm == 0xFFu)) u16_exo = true;
+                    const u32 own_info = ((L.hm >> 7) & 1u) | (((L.accm >> 7) & 1u) << 1) | ((wv_utf16_chain(L.hm, wbm, 0u) >> 8) << 2);
+                    u32 in_info = wv_from_prev(own_info, u16_carry);   // (every lane takes part in the move: no lane-dependent condition around it)
+                    if (!has_back) in_info = 0;
+                    u16_carry = (u32)__builtin_amdgcn_readlane(own_info, 63);
+                    u32 edge_l = 0;
+                    { const u32 raw = ahead_edge & 0xFFFFu; edge_l = wv_utf16_unit(lds_lut, be ? ((raw & 0xFFu) << 8) | (raw >> 8) : raw).kind == 2 ? 1u : 0u; }
+                    u32 next_l = __builtin_amdgcn_update_dpp(edge_l, L.lm & 1u, 0x130, 0xF, 0xF, false);   // lane i <- lane i + 1, lane 63 <- the edge
+                    if (n_ahead < 2) next_l = 0;
+                    const WvMasks16W m = wv_classify16_utf16(L, n_units, wbm, in_info & 1u, (in_info >> 1) & 1u, (in_info >> 2) & 1u, next_l);
+                    if (m.exotic) u16_exo = true;
+                    const WvU16Packed pk = wv_utf16_pack(m, L.hm);
+                    ((uint16_t*)lds_mask(0))[idx] = (uint16_t)pk.m0;
+                    ((uint16_t*)lds_mask(1))[idx] = (uint16_t)pk.m1;
+                    ((uint16_t*)lds_mask(2))[idx] = (uint16_t)pk.m2;
+                    ((uint16_t*)lds_mask(3))[idx] = (uint16_t)pk.m3;
+                } else if (FAM == 5) {
                     // EUC-JP: token starts for a hang-over of 0 / 1 / 2 bytes (a wave-uniform loop: one round per token in a row of lead-range
                     // bytes), the hang-overs composed along the wavefront, a table cell per token, marks that lie beyond the lane handed on
                     WvEucPre pc;
@@ -452,6 +494,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             do_tile(t, x, edge_back, ea);
             edge_back = (u32)__builtin_amdgcn_readlane(x.w, 63);
         }
+        if (FAM == 2 && __ballot(u16_exo)) {   // as EUC-JP's way out: an entry state no wavefront ever leaves makes the verification fail
+            if (lane == 0 && MODE == 0) { P.wave_in[v] = 0xFFFFFFFEu; P.wave_out[v] = 0xFFFFFFFDu; P.wave_nf[v] = 0; P.wave_nb[v] = 0; }
+            return;
+        }
         wave_lds_sync<WPB>();
         if (FAM == 4 && t_ref >= (int)n_tiles) { ref_pos = tile0 + (u64)n_tiles * kTileBytes; ref_cov = dbcs_cov; }
         if (FAM >= 4) { dbcs_valid = have_next; if (have_next) dbcs_cov = cov_next; }   // (else the next batch walks back again)
@@ -468,7 +514,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             else if (FAM == 0)
                 w = wv_win_single(wv_extract(lds_mask(0), o, n), wv_extract(lds_mask(1), o, n), wv_extract(lds_mask(CLS ? 0 : 2), o, n),
                                   wv_extract(lds_mask(CLS ? 0 : 3), o, n), n, P.n_min);
-            else if (FAM == 5) {
+            else if (FAM == 2) {
+                const u32 ob2 = o >= 2 ? o - 2 : 0u;
+                const bool hb = active && ws >= 2 && o >= 2 && ((lds_mask(2)[ob2 >> 5] >> (ob2 & 31u)) & 1u);
+                w = wv_win_utf16(wv_extract(lds_mask(0), o, n), wv_extract(lds_mask(1), o, n), wv_extract(lds_mask(2), o, n), wv_extract(lds_mask(3), o, n), hb,
+                                 ws % kWvSlice == 0, n, P.n_min);
+            } else if (FAM == 5) {
                 // (the two bytes in front of the window: one bit each of three masks)
                 auto bit = [&](int k, u32 at) -> u32 { return (lds_mask(k)[at >> 5] >> (at & 31u)) & 1u; };
                 const u32 o1 = o >= 1 ? o - 1 : 0u, o2 = o >= 2 ? o - 2 : 0u;
@@ -504,7 +555,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         // ---- 3. entry states: iterate until they are consistent along the lanes
         // (the exchange starts from every window's guess of what it hands on — wv_exit_guess: exact unless the window's last stretch is
         // the text-start stretch of its call and something is carried into it —, not from "nothing carried": one round, not two or three)
-        constexpr int KIND = FAM == 0 ? 0 : FAM == 1 ? 1 : 2;
+        constexpr int KIND = FAM == 0 ? 0 : FAM == 1 ? 1 : FAM == 2 ? 3 : 2;
         const WvTail tail = active ? wv_tail<KIND>(WP, w) : WvTail{ 128u, 0u };   // (the window's last stretch: looked at once, used by every replay of it)
         u32 out = tail.state;
         u32 in = wv_from_prev(out, carry);
@@ -627,6 +678,7 @@ hipError_t launch_wave_emit(const WaveParams& P, uint64_t v0, uint64_t v1, hipSt
     const dim3 grid((unsigned)((v1 - v0 + 3) / 4));
     if (P.family == 5) hipLaunchKernelGGL((wave_emit_kernel<5>), grid, dim3(256), 0, stream, Q);
     else if (P.family == 4) hipLaunchKernelGGL((wave_emit_kernel<4>), grid, dim3(256), 0, stream, Q);
+    else if (P.family == 2) hipLaunchKernelGGL((wave_emit_kernel<2>), grid, dim3(256), 0, stream, Q);
     else if (P.family == 1) hipLaunchKernelGGL((wave_emit_kernel<1>), grid, dim3(256), 0, stream, Q);
     else hipLaunchKernelGGL((wave_emit_kernel<0>), grid, dim3(256), 0, stream, Q);
     return hipGetLastError();
@@ -657,6 +709,7 @@ hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint
     if (P.family == 5) hipLaunchKernelGGL((wave_replay_kernel<0, 5, 4, 1>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 1>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 0>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
+    else if (P.family == 2) hipLaunchKernelGGL((wave_replay_kernel<0, 2, 1, 0>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
     else if (P.family == 1 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 1, 1, 1>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
     else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<0, 1, 1, 0>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
     else if (P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 0, 1, 1>), dim3((unsigned)n), dim3(64), dyn, stream, Q);
@@ -687,6 +740,7 @@ hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipS
     if (P.family == 5) hipLaunchKernelGGL((wave_replay_kernel<1, 5, 4, 1>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4, 1>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<1, 4, 4, 0>), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
+    else if (P.family == 2) hipLaunchKernelGGL((wave_replay_kernel<1, 2, 1, 0>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
     else if (P.family == 1 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<1, 1, 1, 1>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
     else if (P.family == 1) hipLaunchKernelGGL((wave_replay_kernel<1, 1, 1, 0>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
     else if (P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<1, 0, 1, 1>), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);

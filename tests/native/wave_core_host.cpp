@@ -5,6 +5,8 @@
 // are replaced by loops; every per-lane function is the kernels' own.
 #include <stdint.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <vector>
 #define SXD inline
@@ -49,6 +51,7 @@ struct WriteEmit {
         *f++ = r;
         const u8* s = P->data + (u64)((long long)win_pos + src_rel);
         if (P->family >= 4) { if (wv_transcode_dbcs((int)P->encoding, P->table, s, src_len, a) != out_len) bad_len = true; }
+        else if (P->family == 2) { if (wv_transcode_utf16(P->encoding == kEncUtf16be, s, src_len, a) != out_len) bad_len = true; }
         else if (out_len == src_len) memcpy(a, s, src_len);
         else {
             u32 w = 0;
@@ -69,7 +72,7 @@ struct RecEmit {
     std::vector<E> v;
     void operator()(u32 din, u32 prec, bool completes, i32 src_rel, u32 src_len, u32 out_len) { v.push_back(E{ din, prec, completes, src_rel, src_len, out_len }); }
 };
-int g_driver_mismatch = 0;
+int g_driver_mismatch = 0, g_gave_up = 0;
 unsigned long long g_rounds_total = 0, g_batches_total = 0, g_redo_lanes = 0;
 template <int KIND>
 bool drivers_agree(const WvParams& WP, const WvWin& w, u32 in) {
@@ -77,6 +80,16 @@ bool drivers_agree(const WvParams& WP, const WvWin& w, u32 in) {
     WvState sa = wv_unpack(in), sb = wv_unpack(in);
     wv_window<KIND>(WP, w, sa, a);
     wv_window_calls<KIND>(WP, w, sb, b, false);
+    if (getenv("SXW_DEBUG")) {
+        bool same = wv_pack(sa) == wv_pack(sb) && a.v.size() == b.v.size();
+        for (size_t i = 0; same && i < a.v.size(); i++) same = a.v[i].din == b.v[i].din && a.v[i].prec == b.v[i].prec && a.v[i].comp == b.v[i].comp && a.v[i].src == b.v[i].src && a.v[i].len == b.v[i].len && a.v[i].out == b.v[i].out;
+        if (!same) {
+            fprintf(stderr, "drivers differ: in %08x out %08x / %08x  n %u pre_empty %u tail_empty %u head_back %u head_pend %u\n", in, wv_pack(sa), wv_pack(sb), w.n, w.pre_empty, w.tail_empty, w.head_back, w.head_pend);
+            fprintf(stderr, "  E  %016llx%016llx\n  A  %016llx%016llx\n  F  %016llx%016llx\n  CS %016llx%016llx\n  PB %016llx%016llx\n", (unsigned long long)w.E.hi, (unsigned long long)w.E.lo, (unsigned long long)w.A.hi, (unsigned long long)w.A.lo, (unsigned long long)w.F.hi, (unsigned long long)w.F.lo, (unsigned long long)w.CS.hi, (unsigned long long)w.CS.lo, (unsigned long long)w.PB.hi, (unsigned long long)w.PB.lo);
+            for (auto& e : a.v) fprintf(stderr, "  new: din %u prec %u comp %d src %d len %u out %u\n", e.din, e.prec, (int)e.comp, e.src, e.len, e.out);
+            for (auto& e : b.v) fprintf(stderr, "  old: din %u prec %u comp %d src %d len %u out %u\n", e.din, e.prec, (int)e.comp, e.src, e.len, e.out);
+        }
+    }
     if (wv_pack(sa) != wv_pack(sb) || a.v.size() != b.v.size()) return false;
     for (size_t i = 0; i < a.v.size(); i++)
         if (a.v[i].din != b.v[i].din || a.v[i].prec != b.v[i].prec || a.v[i].comp != b.v[i].comp || a.v[i].src != b.v[i].src ||
@@ -155,6 +168,33 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                     ((uint16_t*)lds[1].data())[idx] = (uint16_t)m.a;
                     ((uint16_t*)lds[2].data())[idx] = (uint16_t)m.o2;
                     ((uint16_t*)lds[3].data())[idx] = (uint16_t)m.o3;
+                    continue;
+                }
+                if (P.family == 2) {   // UTF-16: the lanes in order; what a lane hands on must not depend on what it was handed (else: give up, as the kernel)
+                    static u32 c_prev;
+                    const bool be = P.encoding == kEncUtf16be;
+                    const u32 n_units = avail >> 1;
+                    const WvU16Lane L = wv_utf16_lane_units(P.lut, be, xs, n_units);
+                    u32 wbm = 0;
+                    for (u32 j = 0; j <= 8; j++) { const u64 pp = off + 2 * j; if ((pp % kWvSlice) % P.W == 0 || pp == P.len) wbm |= 1u << j; }   // (the buffer's end ends a window too)
+                    auto unit_at = [&](u64 pp) -> u32 { return be ? ((u32)P.data[pp] << 8) | P.data[pp + 1] : ((u32)P.data[pp + 1] << 8) | P.data[pp]; };
+                    u32 prev_h = 0, prev_acc = 0, next_l = 0;
+                    if (off >= 2 && avail) { const WvU16Unit u = wv_utf16_unit(P.lut, unit_at(off - 2)); prev_h = u.kind == 1; prev_acc = u.acc; }
+                    if (avail == 16 && off + 18 <= P.len) next_l = wv_utf16_unit(P.lut, unit_at(off + 16)).kind == 2;
+                    u32 c0;
+                    if (t == 0 && l == 0) {   // the batch's first lane: whether its first unit is read in slow mode is not known — it cannot matter 16 bytes on, unless ...
+                        c0 = prev_h;
+                        if (prev_h && L.hm == 0xFFu) { g_gave_up = 1; return false; }
+                    } else c0 = c_prev;
+                    if (wv_utf16_transparent(L.hm, wbm)) { g_gave_up = 1; return false; }
+                    c_prev = wv_utf16_chain(L.hm, wbm, 0u) >> 8;
+                    const WvMasks16W m = wv_classify16_utf16(L, n_units, wbm, prev_h, prev_acc, c0, next_l);
+                    if (m.exotic) { g_gave_up = 1; return false; }
+                    const WvU16Packed pk = wv_utf16_pack(m, L.hm);
+                    ((uint16_t*)lds[0].data())[idx] = (uint16_t)pk.m0;
+                    ((uint16_t*)lds[1].data())[idx] = (uint16_t)pk.m1;
+                    ((uint16_t*)lds[2].data())[idx] = (uint16_t)pk.m2;
+                    ((uint16_t*)lds[3].data())[idx] = (uint16_t)pk.m3;
                     continue;
                 }
                 u32 back = 0, ahead = 0, n_ahead = 0;
@@ -255,6 +295,70 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
             if (P.family == 0 && P.swar.cls) w[l] = wv_win_single_swar(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), P.swar.hi_len, n, P.n_min);
             else if (P.family == 0)
                 w[l] = wv_win_single(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[3], o, n), n, P.n_min);
+            else if (P.family == 2) {
+                const bool hb = active[l] && ws[l] >= 2 && o >= 2 && wv_extract(lds[2], o - 2, 1).lo;
+                w[l] = wv_win_utf16(wv_extract(lds[0], o, n), wv_extract(lds[1], o, n), wv_extract(lds[2], o, n), wv_extract(lds[3], o, n), hb,
+                                    ws[l] % kWvSlice == 0, n, P.n_min);
+                if (active[l] && n) {   // the statement: the decoder's state machine over the window, byte by byte
+                    WvMasks16W sm;
+                    u32 acc_in = 0, acc_out = 0;
+                    if (hb) { const u64 pp = ws[l] - 2; const bool be = P.encoding == kEncUtf16be;
+                              acc_in = wv_utf16_unit(P.lut, be ? ((u32)P.data[pp] << 8) | P.data[pp + 1] : ((u32)P.data[pp + 1] << 8) | P.data[pp]).acc; }
+                    // (128 bytes: four words per mask)
+                    WvMask E{ 0, 0 }, A{ 0, 0 }, F{ 0, 0 }, MA{ 0, 0 }, MB{ 0, 0 }, O2{ 0, 0 }, O3{ 0, 0 }, O4{ 0, 0 };
+                    bool hs = hb;
+                    bool exo = false;
+                    // the statement works on <= 32 bytes at a time only through its masks' width: run it over the window in one piece with 128-bit marks
+                    {
+                        const u8* wp = P.data + ws[l];
+                        bool h = hs; u32 hacc = acc_in; i32 hstart = -2;
+                        auto put = [&](i32 fs, u32 end, u32 acc, u32 len) {
+                            if (fs >= 0) F = wm_or(F, wm_bit((u32)fs));
+                            E = wm_or(E, wm_bit(end)); if (acc) A = wm_or(A, wm_bit(end));
+                            if (len >= 2) O2 = wm_or(O2, wm_bit(end));
+                            if (len >= 3) O3 = wm_or(O3, wm_bit(end));
+                            if (len >= 4) O4 = wm_or(O4, wm_bit(end));
+                        };
+                        const bool be = P.encoding == kEncUtf16be;
+                        for (u32 i = 0; i + 2 <= n; i += 2) {
+                            const u32 u = be ? ((u32)wp[i] << 8) | wp[i + 1] : ((u32)wp[i + 1] << 8) | wp[i];
+                            const WvU16Unit x = wv_utf16_unit(P.lut, u);
+                            const bool last_unit = i + 4 > n;
+                            if (h) {
+                                if (x.kind == 2) { put(hstart, i + 1, hacc, 4); h = false; }
+                                else if (x.kind == 1) { MA = wm_or(MA, wm_bit(i + 1)); hstart = (i32)i; hacc = x.acc; }
+                                else { MB = wm_or(MB, wm_bit(i)); put((i32)i, i + 1, x.acc, x.len); if (last_unit) exo = true; h = false; }
+                                continue;
+                            }
+                            if (x.kind == 0) put((i32)i, i + 1, x.acc, x.len);
+                            else if (x.kind == 2) MA = wm_or(MA, wm_bit(i + 1));
+                            else if (last_unit) { h = true; hstart = (i32)i; hacc = x.acc; }
+                            else {
+                                const u32 v2 = be ? ((u32)wp[i + 2] << 8) | wp[i + 3] : ((u32)wp[i + 3] << 8) | wp[i + 2];
+                                if (wv_utf16_unit(P.lut, v2).kind == 2) { put((i32)i, i + 3, x.acc, 4); i += 2; }
+                                else MA = wm_or(MA, wm_bit(i + 1));
+                            }
+                        }
+                        (void)sm; (void)acc_out;
+                    }
+                    if (exo) { if (getenv("SXW_DEBUG")) fprintf(stderr, "exo not flagged: window at %llu\n", (unsigned long long)ws[l]); return false; }   // (the lanes must have given up)
+                    const WvMask MAw = wm_and(wv_extract(lds[2], o, n), WvMask{ 0xAAAAAAAAAAAAAAAAull, 0xAAAAAAAAAAAAAAAAull });
+                    auto eq = [](WvMask a, WvMask b) { return a.lo == b.lo && a.hi == b.hi; };
+                    // (a window's last unit, a high surrogate with a low one behind it: the lanes mark the character's first byte there, its
+                    // end lies in the next window — a mark nothing in this window looks at)
+                    if (n >= 2 && wm_test(wv_extract(lds[2], o, n), n - 2)) F = wm_or(F, wm_and(w[l].F, wm_bit(n - 2)));
+                    if (!eq(w[l].E, E) || !eq(w[l].A, A) || !eq(w[l].F, F) || !eq(MAw, MA) || !eq(w[l].PB, MB) || !eq(w[l].O2, O2) || !eq(w[l].O3, O3) ||
+                        !eq(w[l].O4, O4)) {
+                        if (getenv("SXW_DEBUG")) {
+                            fprintf(stderr, "utf16 masks differ: window at %llu n %u hb %d\n", (unsigned long long)ws[l], n, (int)hb);
+                            const char* nm[8] = { "E", "A", "F", "MA", "MB", "O2", "O3", "O4" };
+                            const WvMask gotm[8] = { w[l].E, w[l].A, w[l].F, MAw, w[l].PB, w[l].O2, w[l].O3, w[l].O4 }, wantm[8] = { E, A, F, MA, MB, O2, O3, O4 };
+                            for (int k = 0; k < 8; k++) if (!eq(gotm[k], wantm[k])) fprintf(stderr, "  %s got %016llx%016llx want %016llx%016llx\n", nm[k], (unsigned long long)gotm[k].hi, (unsigned long long)gotm[k].lo, (unsigned long long)wantm[k].hi, (unsigned long long)wantm[k].lo);
+                        }
+                        return false;
+                    }
+                }
+            }
             else if (P.family == 5) {
                 auto bit = [&](int k, u32 at) -> u32 { return (u32)wv_extract(lds[k], at, 1).lo; };
                 const bool has1 = ws[l] >= 1 && o >= 1, has2 = ws[l] >= 2 && o >= 2;
@@ -286,7 +390,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
         bool todo[64], injected[64];
         // (as the kernel: the exchange starts from every window's guess of what it hands on, sx_wave_core.hpp wv_exit_guess)
         for (u32 l = 0; l < 64; l++)
-            out[l] = !active[l] ? 0u : P.family == 0 ? wv_exit_guess<0>(WP, w[l]) : P.family == 1 ? wv_exit_guess<1>(WP, w[l]) : wv_exit_guess<2>(WP, w[l]);
+            out[l] = !active[l] ? 0u : P.family == 0 ? wv_exit_guess<0>(WP, w[l]) : P.family == 1 ? wv_exit_guess<1>(WP, w[l]) : P.family == 2 ? wv_exit_guess<3>(WP, w[l]) : wv_exit_guess<2>(WP, w[l]);
         for (u32 l = 0; l < 64; l++) {
             injected[l] = g0 + l == P.g_lo;
             in[l] = l == 0 ? carry : out[l - 1];
@@ -304,6 +408,8 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                     ce.widx = (u32)(g0 + l - own_start);
                     if (P.family == 0) wv_window<0>(WP, w[l], st, ce, skip_idle);
                     else if (P.family == 1) wv_window<1>(WP, w[l], st, ce, skip_idle);
+                else if (P.family == 2) wv_window<3>(WP, w[l], st, ce, skip_idle);
+                    else if (P.family == 2) wv_window<3>(WP, w[l], st, ce, skip_idle);
                     else wv_window<2>(WP, w[l], st, ce, skip_idle);
                     out[l] = wv_pack(st); nf[l] = ce.nf; nb[l] = ce.nb;
                 } else if (!active[l]) out[l] = in[l];
@@ -324,7 +430,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
         if (MODE == 0) { g_rounds_total += rounds; g_batches_total++; }
         if (MODE == 0)
             for (u32 l = 0; l < 64; l++)
-                if (active[l] && !(P.family == 0 ? drivers_agree<0>(WP, w[l], in[l]) : P.family == 1 ? drivers_agree<1>(WP, w[l], in[l]) : drivers_agree<2>(WP, w[l], in[l]))) {
+                if (active[l] && !(P.family == 0 ? drivers_agree<0>(WP, w[l], in[l]) : P.family == 1 ? drivers_agree<1>(WP, w[l], in[l]) : P.family == 2 ? drivers_agree<3>(WP, w[l], in[l]) : drivers_agree<2>(WP, w[l], in[l]))) {
                     g_driver_mismatch++;
                     return false;
                 }
@@ -349,6 +455,8 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                     WvState st = wv_unpack(in[l]);
                     if (P.family == 0) wv_window<0>(WP, w[l], st, de, skip_idle);
                     else if (P.family == 1) wv_window<1>(WP, w[l], st, de, skip_idle);
+                else if (P.family == 2) wv_window<3>(WP, w[l], st, de, skip_idle);
+                    else if (P.family == 2) wv_window<3>(WP, w[l], st, de, skip_idle);
                     else wv_window<2>(WP, w[l], st, de, skip_idle);
                     if (de.a_local != ab + nb[l]) return false;
                 }
@@ -359,6 +467,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                 WvState st = wv_unpack(in[l]);
                 if (P.family == 0) wv_window<0>(WP, w[l], st, we, skip_idle);
                 else if (P.family == 1) wv_window<1>(WP, w[l], st, we, skip_idle);
+                else if (P.family == 2) wv_window<3>(WP, w[l], st, we, skip_idle);
                 else wv_window<2>(WP, w[l], st, we, skip_idle);
                 if ((u64)(we.f - (P.findings + fo)) != nf[l] || we.a_off - ao != nb[l] || we.bad_len) return false;   // both passes must agree
             }
@@ -393,6 +502,7 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
     if (family == 4 && !pairs2) P.swar.cls = 0;
     if (family == 5 && (!pairs2 || !P.swar.cls)) return -8;
     *nf = *nb = 0; *bad_waves = 0; *final_state = inject; *rounds_max = 0;
+    g_gave_up = 0;
     if (P.g_hi <= P.g_lo) return 0;
     const u64 n_waves = (P.g_hi - P.g_lo + nwin - 1) / nwin;
     std::vector<u32> wnf(n_waves), wnb(n_waves), win(n_waves), wout(n_waves);
@@ -402,7 +512,7 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
     P.desc_cap = (nwin & 3u) == 1u ? nwin / 8 + 1 : 2 * nwin + 64;
     std::vector<u32> desc((size_t)(n_waves * P.desc_cap * 3 + 3), 0xDEADBEEFu);
     P.desc = nwin <= kWvDescMaxWin ? desc.data() : nullptr;   // (as sx_wave.cpp: larger wavefronts do without)
-    for (u64 v = 0; v < n_waves; v++) if (!wave<0>(P, v, skip_idle != 0, rounds_max)) return g_driver_mismatch ? -7 : -1;
+    for (u64 v = 0; v < n_waves; v++) if (!wave<0>(P, v, skip_idle != 0, rounds_max)) return g_gave_up ? -9 : g_driver_mismatch ? -7 : -1;
     u64 f = 0, a = 0;
     for (u64 v = 0; v < n_waves; v++) {
         fb[v] = f; ab[v] = a; f += wnf[v]; a += wnb[v];

@@ -273,3 +273,52 @@ def test_chunks_that_begin_inside_a_token(wave_forced):
         want = sxo.run_cli(ms, [data], radix="x")
         for chunk in (4096, 8192, 16384):
             assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (enc, chunk)
+
+
+from test_wave_core import UTF16_MISSIONS, utf16_soup
+
+
+@pytest.mark.parametrize("ui", range(len(UTF16_MISSIONS)))
+def test_wave_path_utf16(wave_forced, ui):
+    """UTF-16LE / BE through the wave kernels (round 4): units on the buffer's even offsets; surrogates alone, in pairs and across window and
+    chunk ends; the slow mode behind a pending high surrogate.  Where the masks cannot say what the decoder does (a character kept for the
+    next call at a window's end, seven high surrogates in a row) the wavefronts give the buffer back — the result is the oracle's either way"""
+    flags = UTF16_MISSIONS[ui]
+    be = flags["encodings"][0].endswith("be")
+    codec = "utf-16-be" if be else "utf-16-le"
+    ms = rc.missions(**dict(flags, encodings=flags["encodings"] + ["utf-8"]))
+    rng = random.Random(8000 + ui)
+    text = text_lines(rng, 150_000).decode("latin-1").encode(codec)
+    datas = [("text", text), ("soup", utf16_soup(rng, 150_000, be)), ("random", rng.randbytes(200_000)),
+             ("astral", ("a\U0001F600b\U00020000\U0001F601cd 中" * 9000).encode(codec)),
+             ("high surrogates", utf16_soup(rng, 100_000, be, (40, 10, 14, 10, 10, 4))),
+             ("odd length", text[:100_001]), ("odd start", b"x" + text[:120_000])]
+    for name, data in datas:
+        want = sxo.run_cli(ms, [data], radix="x")
+        for chunk, batches in ((None, None), (16384, "1"), (8192, "2")):
+            if batches:
+                os.environ["SX_WAVE_BATCHES"] = batches
+            else:
+                os.environ.pop("SX_WAVE_BATCHES", None)
+            assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (flags, name, chunk)
+    # a file of odd length: the next file's units begin on odd offsets (the decoder carries half a unit) — not the wave path's case
+    files = [text[:100_001], text, text[:50_000]]
+    assert run_cli_product(ms, files, radix="x", device=0, chunk_bytes=16384) == sxo.run_cli(ms, files, radix="x")
+    assert wave_windows_of_a_scan(ms[:1], text) > 0          # the wave kernels did run
+    assert wave_windows_of_a_scan(ms[:1], datas[3][1]) > 0
+
+
+def test_utf16_text_is_dense_by_default():
+    """UTF-16 text takes the wave path without being told to (a run per 960 bytes or more)"""
+    rng = random.Random(5)
+    ms = rc.missions(encodings=["utf-16le"], chars_min="4")
+    data = text_lines(rng, 2_000_000).decode("latin-1").encode("utf-16-le")
+    want = sxo.run_cli(ms, [data], radix="x")
+    assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=1 << 20) == want
+    sc = sx.Scanner(ms, device=0)
+    try:
+        for off in range(0, len(data), 1 << 20):
+            sc.scan(data[off:off + (1 << 20)], file_id=1).free()
+        assert sc.stats().wave_windows > 0
+    finally:
+        sc.close()

@@ -66,6 +66,13 @@ def make(case_seed):
     if r.random() < 0.15:  # one of the other WHATWG single-byte tables instead of the first mission's encoding
         kw["encodings"][0] = r.choice(ENCS_MORE) + kw["encodings"][0][len(kw["encodings"][0].split(",")[0]):]
         case["missions"] = rc.missions(**kw)
+    # (drawn last, so that the seeds of earlier logs still name the same cases) UTF-16 units of every kind — surrogates alone, in pairs,
+    # in rows — for the Missions that decode UTF-16: the wave path's slow mode and its way back
+    if any(m["encoding"] in (2, 3) for m in case["missions"]) and r.random() < 0.5:   # (SX_ENC_UTF16LE / BE)
+        from test_wave_core import utf16_soup
+        be = r.random() < 0.5
+        case["kind"] = "utf16soup"
+        case["files"] = [utf16_soup(r, min(size, 300_000) // 2, be, r.choice([(50, 20, 8, 8, 6, 8), (40, 10, 14, 10, 10, 4), (70, 20, 2, 2, 5, 1)]))]
     return case
 
 

@@ -11,7 +11,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
 rng = random.Random(seed)
 L = twc.load_wave()
-t0 = time.time(); n = checked = 0; max_rounds = 0
+t0 = time.time(); n = checked = gave_up = 0; max_rounds = 0
 while time.time() - t0 < budget:
     n += 1
     case_seed = rng.randrange(1 << 31)
@@ -24,11 +24,17 @@ while time.time() - t0 < budget:
             continue
         want = oracle_findings([dict(m, mission_id=0)], data)
         nwin = rng.choice([508, 508, 60, 5, 17, 64, 1000])
-        got, info = twc.emulate(L, m, data, nwin=nwin, skip_idle=rng.choice([0, 1, 1]))
+        if m["encoding"] in (2, 3) and len(data) % 2:   # (UTF-16: the wave path takes buffers of whole units)
+            data = data[:-1]
+            want = oracle_findings([dict(m, mission_id=0)], data)
+        got, info = twc.emulate(L, m, data, nwin=nwin, skip_idle=rng.choice([0, 1, 1]), may_give_up=True)
+        if got is None:   # UTF-16: the wavefronts gave the buffer back (the product then takes the lane-per-region path)
+            gave_up += 1
+            continue
         max_rounds = max(max_rounds, info["rounds"])
         if got != want or info["bad"]:
             print(f"MISMATCH wave seed {seed} case_seed {case_seed} mission {m} nwin={nwin} info={info}: {fuzz_case.describe(c)}")
             print("  first diff", next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
             sys.exit(1)
         checked += 1
-print(f"wave fuzz seed {seed}: {n} cases, {checked} mission replays (most rounds to settle a batch: {max_rounds}), all equal to the oracle")
+print(f"wave fuzz seed {seed}: {n} cases, {checked} mission replays (most rounds to settle a batch: {max_rounds}; UTF-16 buffers given back: {gave_up}), all equal to the oracle")
