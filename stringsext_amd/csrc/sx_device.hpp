@@ -69,8 +69,10 @@ struct ScanParams {
     uint32_t wave_prio;    // 1: the scan wavefronts raise their issue priority (s_setprio)
     uint32_t lr_c1[2], lr_c2[2];  // Big5 / Shift_JIS / EUC-KR: the lead byte ranges (low 7 bits; 0x80 - lo, 0x7F - hi, replicated)
     uint32_t high1;        // Shift_JIS: bytes >= 0x80 outside the lead ranges can be characters (0x80, A1..DF): lut[] holds all 256
-    uint32_t gb4;          // gb18030 / GBK: lead digit lead digit is a four-byte character: its bytes are marked good wherever the pattern
-                           // occurs (a superset of the true runs: stage B is exact; the two-byte grammar reads it as error, digit, error, digit)
+    uint32_t gb4;          // gb18030 / GBK: lead digit lead digit may be a four-byte character (the two-byte grammar reads it as error, digit, error,
+                           // digit): exact since round 4 — every other candidate of a row is a token, good if its pointer is in range and its character passes (sx_kernels.hip)
+    const uint16_t* gb_ranges; // ... device: index gb18030 ranges, [208 breakpoint pointers][208 code points]
+    uint64_t ubf;          // ... the Mission's Unicode-block filter (bit = the UTF-8 lead byte & 0x3F)
     uint32_t af_is_range;  // Big5 / EUC-JP: the accepted ASCII bytes are [a_lo,a_hi] (else lut[0..255] holds them: 0x80 / 0)
     const uint32_t* pair_lut;  // Big5 / EUC-JP: device, 2 bits per byte pair (index = the pair as a little-endian u16; EUC-JP: + 65536
                                // for the last two bytes of 8F xx xx): 0 unmapped, 1 mapped, 3 accepted, 2 accepted and two characters

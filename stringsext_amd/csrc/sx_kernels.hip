@@ -938,6 +938,50 @@ SX_DEV u32 swar_eq(u32 v, u32 pat) {  // bytes equal to pat's bytes
     return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y);
 }
 
+// ---- gb18030 / GBK: four-byte tokens, exactly (round 4; rounds 2-3 marked `lead digit lead digit` good wherever it stood: a superset).
+// The two-byte grammar reads L D L D as (L, D) malformed — D given back, a character of its own — twice: aligned with the true tokens,
+// so its token starts are a superset of the true ones and only three things are missing (WHATWG "gb18030 decoder"; sx_codec_core.hpp
+// ddec_gb18030): (1) the pattern is ONE token — a character if its pointer is in range, else an error of all four bytes; either way the
+// digits inside it are no characters; (2) of two candidates two bytes apart the first one wins (L D L D L D:
+// bytes 0..3 are a token, byte 4 starts the next) — along a row of candidates every other one, from the row's first; (3) the token's
+// character passes the filter or not (index gb18030 ranges -> code point -> UTF-8 lead byte -> ubf).  (2) is solved per parity class of the position (candidates two apart have the same parity): 8 elements per lane and
+// class, rows = runs of set bits, alternate elements from a run's first; what a lane hands on (is the class's last element a candidate,
+// and was it taken) depends on what it was handed only if all 8 are candidates.  At the first tile of a sub-chunk nothing is known about
+// a row that is already running: its members are marked as in rounds 2-3 (good if accepted, nothing cleared) — a superset there, never less.
+SX_DEV u32 gb4_compress(u32 x) {   // the bits at even positions of 16 -> 8
+    x &= 0x5555u; x = (x | (x >> 1)) & 0x3333u; x = (x | (x >> 2)) & 0x0F0Fu; x = (x | (x >> 4)) & 0x00FFu;
+    return x;
+}
+SX_DEV u32 gb4_expand(u32 x) {     // 8 bits -> the even positions of 16
+    x &= 0xFFu; x = (x | (x << 4)) & 0x0F0Fu; x = (x | (x << 2)) & 0x3333u; x = (x | (x << 1)) & 0x5555u;
+    return x;
+}
+// in-states: 0 the class's element in front is no candidate, 1 it is one and was taken, 2 it is one and was not, 3 not known
+struct Gb4Class { u32 sel0, sel1, run0, out_tab; };
+SX_DEV Gb4Class gb4_class(u32 v) {
+    Gb4Class r;
+    r.run0 = v & ~(v + 1u) & 0xFFu;                       // the run that begins at element 0
+    const u32 pair = v & (v << 1);                         // element k and k - 1 are candidates
+    auto alt = [&](u32 h) { u32 t = h; t |= (t << 2) & pair; t |= (t << 2) & pair; t |= (t << 2) & pair; return t & 0xFFu; };
+    const u32 heads = v & ~(v << 1);
+    r.sel0 = alt(heads);                                   // every run from its first element
+    r.sel1 = alt((heads & ~1u) | ((v & 1u) ? (v & 2u) : 0u));   // ... the run at element 0 from its second (the element in front was taken)
+    if (!(v & 0x80u)) r.out_tab = 0;
+    else if (r.run0 == 0xFFu) r.out_tab = 2u | (1u << 2) | (2u << 4) | (3u << 6);
+    else { const u32 o = (r.sel0 & 0x80u) ? 1u : 2u; r.out_tab = o * 0x55u; }
+    return r;
+}
+SX_DEV u32 gb4_spread(u32 q) { return q | (q << 1) | (q << 2) | (q << 3); }
+// the character of a four-byte token, 0 = the pointer is out of range (t: [208 breakpoint pointers][208 code points])
+SX_DEV u32 gb4_code_point(const uint16_t* t, u32 pointer) {
+    if ((pointer > 39419u && pointer < 189000u) || pointer > 1237575u) return 0;
+    if (pointer == 7457u) return 0xE7C7u;
+    if (pointer >= 189000u) return 0x10000u + (pointer - 189000u);
+    u32 lo = 0, hi = 208;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) / 2; if (t[mid] <= pointer) lo = mid; else hi = mid; }
+    return (u32)t[208 + lo] + (pointer - t[lo]);
+}
+
 // ENC 4: the two-byte encodings (Big5, Shift_JIS, EUC-KR: lead ranges and pair table are parameters), 5: EUC-JP.
 // AF_RANGE: the accepted ASCII bytes are one range (else a 256-entry LUT in LDS).  HIGH1: bytes >= 0x80 outside the
 // lead range can be characters too (Shift_JIS: 0x80, A1..DF) — they come from the LUT.
@@ -991,7 +1035,7 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
     {
         u64 lo = sub_start;
         const u64 stop = sub_start >= p.subchunk ? sub_start - p.subchunk : 0;
-        bool found = false, special = false;
+        bool found = false, special = false, gb_skipped = false;   // (gb_skipped: the look-back tile holds bytes outside the lead range after all)
         u64 known_at = 0;     // a position from which the hang-over is known_cov ...
         u32 known_cov = 0;
         while (lo > stop) {
@@ -1004,6 +1048,16 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
             const u32 out16 = movemask16(f0, f1, f2, f3) ^ 0xFFFFu;   // my bytes outside the lead range
             const u64 bal = __ballot(out16 != 0);
             if (bal) {
+                if (HIGH1 && p.gb4 && pre == 1) {
+                    // gb18030: the tile's FIRST byte outside the lead range is a digit — the lead byte in front of it may begin a four-byte
+                    // token, if it begins a token at all: that depends on the grid in front of it, which the usual case below does not
+                    // know.  Walk on as if this tile held no such byte: the hang-over at its start then comes out exactly (parity from a
+                    // known position further back, or the wavefront in front)
+                    const int lowl = __builtin_ctzll(bal);
+                    const u32 m0 = bcast(out16, lowl);
+                    const u8 fb = p.data[lo + 16ull * (u32)lowl + (u32)__builtin_ctz(m0)];
+                    if (fb >= 0x30 && fb <= 0x39) { gb_skipped = true; continue; }
+                }
                 const int top = 63 - __clzll((long long)bal);
                 const u32 m = bcast(out16, top);
                 known_at = lo + 16ull * (u32)top + (32u - (u32)__clz((int)m));   // the byte behind the last such byte
@@ -1031,7 +1085,7 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
                 cov = first >= tile_lo ? (u32)(first - tile_lo) : (u32)((tile_lo - first) & 1ull);
                 pre = 1;
                 // (the hang-over at my own first byte follows the same way: the wavefront behind me need not wait for my look-back tile)
-                if (lane == 0 && first <= sub_start)
+                if (lane == 0 && first <= sub_start && !gb_skipped)
                     __hip_atomic_store(p.grid_flags + wave, 1u | ((u32)((sub_start - first) & 1ull) << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -1057,6 +1111,7 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
     Carry c;
     c.g63 = 0; c.tracked = 0; c.t_chars = 0; c.t_flags = 0; c.t_start = 0;
     u32 s63c = 0;  // lane 63 of the previous tile: final start mask | own spill bits << 16
+    u32 gb_c63 = 0, gb_q63 = 0;   // gb18030: lane 63's four-byte tokens' bytes beyond its own (bits 16..18); what it hands on per parity class (2 x 2 bits)
 
     auto body = [&](auto near_tag) {
         constexpr bool NE = decltype(near_tag)::value;
@@ -1168,27 +1223,76 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
         // ---- 5. good / start masks (bits 16.. spill onto the next lane's first bytes)
         u32 g = S1 | A0 | (A0 << 1) | (A1 >> 1) | A1 | (A1 << 1) | bad_last;
         u32 s = S1 | A0 | ((Dbl & A0) << 1) | (A1 >> 1) | bad_last;
+        u32 gb_cover = 0;   // gb18030: bytes of this lane's four-byte tokens (bits 16..18: the next lane's first bytes)
         if (HIGH1 && p.gb4) {
-            // gb18030: lead digit lead digit = one four-byte character.  The two-byte grammar above reads it as (lead, digit) malformed,
-            // digit given back, twice — aligned with the true tokens, so only the marking is missing: all four bytes good, the first
-            // a start, wherever the pattern stands (a superset; ScanParams::gb4)
             u32 fd[5];
 #pragma unroll
             for (int k = 0; k < 5; k++) fd[k] = swar_range(xs[k] & 0x7F7F7F7Fu, rep4(0x80u - 0x30u), rep4(0x7Fu - 0x39u)) & ~xs[k] & kM;
             const u32 D = (movemask16(fd[0], fd[1], fd[2], fd[3]) | (movemask4(fd[4]) << 16)) & valid;
-            const u32 Q = LR & (D >> 1) & (LR >> 2) & (D >> 3) & 0xFFFFu;
-            g |= Q | (Q << 1) | (Q << 2) | (Q << 3);
-            s |= Q;
+            const u32 Qc = LR & (D >> 1) & (LR >> 2) & (D >> 3) & S0;   // lead digit lead digit at a token start of the two-byte grammar
+            const bool first = t == -pre;
+            if (t == n_tiles - 1 && lane == 0)   // what I enter my last tile with: the wavefront behind me may need it (its look-back tile is this one)
+                __hip_atomic_fetch_or(p.grid_flags + wave, 0x10u | (gb_q63 << 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(Qc != 0) || gb_q63 || first) {
+                // (1), (3): the pointer, its character, the filter — a handful of tiles per megabyte of text, every third tile of random bytes
+                const u32 V = Qc;   // (a pointer out of range is an error of all four bytes: a token all the same)
+                u32 AC = 0;
+                for (u32 rem = Qc; rem;) {
+                    const u32 i = (u32)__builtin_ctz(rem);
+                    rem &= rem - 1u;
+                    const u8* b = p.data + lane_base + i;
+                    const u32 pointer = ((((u32)b[0] - 0x81u) * 10u + ((u32)b[1] - 0x30u)) * 126u + ((u32)b[2] - 0x81u)) * 10u + ((u32)b[3] - 0x30u);
+                    const u32 cp = gb4_code_point(p.gb_ranges, pointer);
+                    if (!cp) continue;
+                    const u32 lead = cp < 0x800u ? 0xC0u | (cp >> 6) : cp < 0x10000u ? 0xE0u | (cp >> 12) : 0xF0u | (cp >> 18);
+                    if ((p.ubf >> (lead & 0x3Fu)) & 1ull) AC |= 1u << i;
+                }
+                // (2): every other candidate of a row, per parity class
+                const Gb4Class ce = gb4_class(gb4_compress(V)), co = gb4_class(gb4_compress(V >> 1));
+                // lane 0's in-state: what lane 63 of the tile before handed on.  A sub-chunk's first tile is the last tile of the sub-chunk in
+                // front: that wavefront publishes what it entered it with (grid_flags bit 4, bits 5..8; wavefronts are dispatched in order), and
+                // this one waits for it — only if a row is running there (a candidate at lane 0's first element).  The chunk's byte 0: nothing
+                // lies in front — or a token is pending on entry, then a row that is running is marked as a superset
+                u32 edge = gb_q63;
+                if (first) {
+                    edge = tile_base == 0 && p.parity == 0 ? 0u : 0xFu;
+                    if (tile_base != 0 && wave > 0) {
+                        edge = 0;
+                        if (__ballot(lane == 0 && (ce.run0 | co.run0) != 0)) {
+                            u32 v = 0;
+                            if (lane == 0) { while (((v = __hip_atomic_load(p.grid_flags + (wave - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x10u) == 0) __builtin_amdgcn_s_sleep(2); }
+                            edge = (uniform(v) >> 5) & 0xFu;
+                        }
+                    }
+                }
+                u32 in = from_prev(0u, edge);
+                for (;;) {
+                    const u32 out = ((ce.out_tab >> (2 * (in & 3u))) & 3u) | (((co.out_tab >> (2 * ((in >> 2) & 3u))) & 3u) << 2);
+                    const u32 nin = from_prev(out, edge);
+                    const bool ch = nin != in;
+                    in = nin;
+                    if (!__ballot(ch)) { gb_q63 = bcast(out, 63); break; }
+                }
+                const u32 ie = in & 3u, io = (in >> 2) & 3u;
+                const u32 se = ie == 1u ? ce.sel1 : (ie == 3u ? ce.sel0 & ~ce.run0 : ce.sel0), so = io == 1u ? co.sel1 : (io == 3u ? co.sel0 & ~co.run0 : co.sel0);
+                const u32 SEL = gb4_expand(se) | (gb4_expand(so) << 1);
+                const u32 UNC = (ie == 3u ? gb4_expand(ce.run0) : 0u) | (io == 3u ? gb4_expand(co.run0) << 1 : 0u);
+                gb_cover = gb4_spread(SEL);
+                g = (g & ~gb_cover) | gb4_spread(SEL & AC) | gb4_spread(UNC & AC);
+                s = (s & ~gb_cover) | (SEL & AC) | (UNC & AC);
+            }
         }
 
         const u32 g63_in = c.g63;
         const bool tracked_in = c.tracked != 0;
         const u32 pg = from_prev(g, g63_in);
-        const u32 gf = (g & 0xFFFFu) | (pg >> 16);
+        u32 gb_kill = 0;   // gb18030: my first bytes that lie inside a four-byte token of the lane in front (its own marks for them follow in pg / ps)
+        if (HIGH1 && p.gb4) { gb_kill = from_prev(gb_cover, gb_c63) >> 16; gb_c63 = bcast(gb_cover, 63); }
+        const u32 gf = ((g & 0xFFFFu) & ~gb_kill) | (pg >> 16);
         const u32 pgf = from_prev(gf, g63_in) & 0xFFFFu;
         const u32 g63_out = bcast(gf | (g & 0xFFFF0000u), 63);
         const u32 ps = from_prev(s, s63c);
-        const u32 sf = (s & 0xFFFFu) | (ps >> 16);
+        const u32 sf = ((s & 0xFFFFu) & ~gb_kill) | (ps >> 16);
         const u32 s63_in = s63c & 0xFFFFu;
         s63c = bcast(sf | (s & 0xFFFF0000u), 63);
 

@@ -20,6 +20,11 @@ ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const 
     ScanParams p = m.proto;
     p.data = d_bytes; p.len = len; p.subchunk = sub; p.parity = parity;
     p.pair_lut = ctx->dev[(size_t)mission].d_pair_lut;
+    if (p.gb4) {   // (sx_codec_core.hpp: the decoder's blob is [kGbN two-byte cells][breakpoints][code points])
+        p.gb_ranges = ctx->dev[(size_t)mission].d_table ? ctx->dev[(size_t)mission].d_table + kGbN : nullptr;
+        p.ubf = m.c.ubf;
+        if (!p.gb_ranges) p.gb4 = 0;
+    }
     p.wave_prio = getenv("SX_SCAN_PRIO") ? (uint32_t)atoi(getenv("SX_SCAN_PRIO")) : 0u;
     p.min_chars = (uint32_t)std::min<uint64_t>(min_chars, kRecCharsMask);
     if (p.min_chars == 0) p.min_chars = 1;

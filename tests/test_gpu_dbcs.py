@@ -39,6 +39,12 @@ def test_device_runs_equal_oracle_runs(enc, name):
         b"\x8f\xb0\xa1" * 3000 + b"\x8f" * 3001 + txt * 10 + b"\x8e\xb1" * 2000,
         txt[:1023], txt[:1025], txt[1:18], b"abcdefghijkl", b"", b"\xa4", b"\xa4\x40",
         b"A" * 5000 + rng.randbytes(3000) + txt * 7 + b"\x00" * 100 + b"zz" * 3000,
+        # gb18030: rows of `lead digit lead digit ...` — every other candidate is a token, from the row's first; rows across lanes, tiles
+        # and sub-chunks, at both parities, with pointers in range (81 30 .., 82 35 .., 90 30 ..: astral) and out of it (84 32 .., 8F 39 ..)
+        b"\x81\x30" * 5001 + b"x" + b"\x81\x30" * 700 + b"yy" + b"\x84\x32\x81\x30" * 900 + b"\x90\x30\x81\x30\x82\x35" * 1200 + b"z" +
+        b"\x8f\x39" * 333 + b"\x81\x30\x81" * 400 + b"\x82\x35\x8f\x39\x81\x30" * 800 + txt * 3,
+        b"".join(rng.choice([b"\x81\x30", b"\x82\x35", b"\x84\x32", b"\x90\x30", b"\xfe\x39", b"\x84\x31", b"\xe3\x32", b"7", b"\x81", b"A"])
+                 for _ in range(150_000)),
     ]
     for di, data in enumerate(datas):
         for sub in (1024, 4096, 65536):
@@ -46,15 +52,8 @@ def test_device_runs_equal_oracle_runs(enc, name):
                 continue
             got, mc = device_runs(m, data, subchunk=sub)
             want = sxo.runs(m, data, min_chars=mc)
-            if enc in ("gbk", "gb18030"):
-                # a SUPERSET there (ScanParams::gb4: lead digit lead digit is marked good wherever it stands, the digits may
-                # count as characters of their own): every true run lies inside a reported one with at least its characters
-                j = 0
-                for a, b, ch in want:
-                    while j < len(got) and got[j][1] < b:
-                        j += 1
-                    assert j < len(got) and got[j][0] <= a and got[j][2] >= ch, (enc, name, di, sub, (a, b, ch), got[max(0, j - 1):j + 1])
-                continue
+            # (gb18030 / GBK: exact since round 4 — of a row of `lead digit lead digit` candidates every other one is a token, a character
+            # if its pointer is in range, marked by its filter; rounds 2-3 reported a superset there)
             assert got == want, (enc, name, di, sub, len(got), len(want),
                                  next(((a, b) for a, b in zip(got, want) if a != b), None))
 
@@ -76,14 +75,7 @@ def test_long_fills_of_lead_range_bytes(enc):
             for sub in (1024, 4096, 65536):
                 got, mc = device_runs(m, data, subchunk=sub)
                 want = sxo.runs(m, data, min_chars=mc)
-                if enc in ("gbk", "gb18030"):
-                    j = 0
-                    for a, b, ch in want:
-                        while j < len(got) and got[j][1] < b:
-                            j += 1
-                        assert j < len(got) and got[j][0] <= a and got[j][2] >= ch, (enc, hex(fill), odd, sub, (a, b, ch))
-                else:
-                    assert got == want, (enc, hex(fill), odd, sub, len(got), len(want), next(((a, b) for a, b in zip(got, want) if a != b), None))
+                assert got == want, (enc, hex(fill), odd, sub, len(got), len(want), next(((a, b) for a, b in zip(got, want) if a != b), None))
             want = sxo.run_cli(ms, [data], radix="x")
             for chunk in (None, 8192, 4096 * 7):
                 assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (enc, hex(fill), odd, chunk)
