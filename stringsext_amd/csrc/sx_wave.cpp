@@ -143,7 +143,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         // Slabs of wavefronts: count -> write -> copy to the host, the copy of a slab next to the kernels of the following one.
         // (Several Missions: one slab; their outputs stay in HBM and are interleaved there, sx_stage_b.cpp device_merge.)
         uint64_t K = 1;
-        if (ctx->missions.size() == 1 && defer_min_bytes == 0) K = std::min<uint64_t>(8, std::max<uint64_t>(1, len >> 26));   // >= 64 MiB of input each
+        if (ctx->missions.size() == 1 && defer_min_bytes == 0) K = std::min<uint64_t>(8, std::max<uint64_t>(1, len >> 25));   // >= 32 MiB of input each, eight at most (measured: 256 MiB of text in 4 / 8 / 16 slabs 7.9 / 7.2 / 8.0 ms; `-e ascii -n 4` on 1 GiB in 8 / 16 / 32: 5.15 / 5.27 / 7.0 ms)
         if (const char* e = getenv("SX_WAVE_SLABS")) K = (uint64_t)std::max(1, std::min(64, atoi(e)));
         if (ctx->missions.size() != 1 || defer_min_bytes != 0) K = 1;
         K = std::min<uint64_t>(K, n_waves);
