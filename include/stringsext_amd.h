@@ -207,7 +207,8 @@ const char* sx_encoding_name(uint32_t encoding);   /* Encoding::name(), e.g. "UT
  * Big5 / EUC-JP: the index blob, layout in csrc/sx_codec_core.hpp); NULL, *n_words = 0 if the encoding has none. */
 const uint16_t* sx_decoder_table(uint32_t encoding, uint64_t* n_words);
 
-/* Lower level: does the wave-cooperative stage B (csrc/sx_wave_core.hpp) cover this Mission — no -g, no -r,
+/* Lower level: does the wave-cooperative stage B (csrc/sx_wave_core.hpp) cover this Mission — no -g, no -r (unless at most one UTF-8
+ * lead byte passes the filter: then -r never breaks a string),
  * 1 <= chars_min_nb <= output_line_char_nb_max <= 64, a single-byte encoding or UTF-8 (the reference's rules it
  * relies on: src/helper.rs:315-322, 349-421)?  Returns 0 if not covered, < 0 on error, else the class byte it keeps per
  * input byte in classes[256] and 1 + family: 1 for a single-byte encoding (bit 0 a character, bit 1 its UTF-8 lead byte passes

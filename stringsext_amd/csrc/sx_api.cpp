@@ -196,7 +196,7 @@ int sx_wave_classes(const sx_mission* mission, uint8_t* classes) {
     std::string err;
     const int rc = Mission::from_c(*mission, false, &m, &err);
     if (rc != SX_OK) return rc;
-    if (!m.wave_ok || (m.wave_lut.size() != 256 && !(m.wave_family == 2 && m.wave_lut.size() == 512))) return 0;
+    if (!m.wave_ok || m.wave_lead_check || (m.wave_lut.size() != 256 && !(m.wave_family == 2 && m.wave_lut.size() == 512))) return 0;   // (wave_lead_check: -r, covered per buffer only)
     memcpy(classes, m.wave_lut.data(), m.wave_lut.size());   // (UTF-16: 512 bytes)
     return 1 + (int)m.wave_family;
 }

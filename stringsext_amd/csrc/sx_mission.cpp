@@ -41,6 +41,11 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
     m->long_run = (uint32_t)std::min<size_t>(in.chars_min_nb, m->q);
     if (m->long_run == 0) m->long_run = 1;
     const int enc = in.encoding;
+    // -r (helper.rs:279-296) breaks a string between two multi-byte characters whose UTF-8 lead bytes pass ubf and differ.  If at most one
+    // lead byte passes — `-u` with one bit; x-user-defined ("ascii"), whose characters >= 0x80 all begin with EF — it never does: such a
+    // Mission is its own twin without -r, as far as the wave path is concerned (set below for the single-byte tables)
+    uint32_t same_block = in.require_same_unicode_block ? 1u : 0u;
+    if (same_block && __builtin_popcountll(in.ubf & 0x001FFFFFFFFFFFFCull) <= 1) same_block = 0;   // (leads C2..F4 <-> bits 2..52)
     if (!encoding_is_known(enc)) { *err = "unsupported encoding id " + std::to_string(enc); return SX_E_INVALID; }
 
     ScanParams& p = m->proto;
@@ -66,7 +71,9 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
 
     if (enc == SX_ENC_UTF8) {
         // the wave-cooperative stage B (sx_wave_dev.hip): kind of every byte + "a character with this lead byte passes the filter"
-        m->wave_ok = wv_mission_ok(in.grep_char, in.require_same_unicode_block, in.chars_min_nb, (uint32_t)m->q);
+        // (-r: the kernels check per buffer that it cannot matter there — text without, or with one kind of, multi-byte characters)
+        m->wave_ok = wv_mission_ok(in.grep_char, 0u, in.chars_min_nb, (uint32_t)m->q);
+        m->wave_lead_check = m->wave_ok && same_block != 0;
         m->wave_family = 1;
         m->wave_lut.assign(256, 0);
         for (int b = 0; b < 256; b++) {
@@ -116,7 +123,7 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
         {   // the wave-cooperative stage B (sx_wave_core.hpp wv_utf16_unit): per high byte — the low byte's quadrants that pass, hb == 0, high / low surrogate —, per low byte of U+0000..U+00FF
             // (windows of >= 10 bytes: the slice-start probe, finding_collection.rs:176-207, lets a fresh decoder run over the slice until 8 bytes are
             // written — five units at most; in a shorter window the real decoder has already met the window's last unit, which it treats differently)
-            m->wave_ok = wv_mission_ok(in.grep_char, in.require_same_unicode_block, in.chars_min_nb, (uint32_t)m->q) && m->window % 2 == 0 && m->window >= 10;
+            m->wave_ok = wv_mission_ok(in.grep_char, same_block, in.chars_min_nb, (uint32_t)m->q) && m->window % 2 == 0 && m->window >= 10;
             m->wave_family = 2;
             m->wave_lut.assign(512, 0);
             for (int lb = 0; lb < 256; lb++) m->wave_lut[256 + (size_t)lb] = m->filter.pass_lead(utf8_lead_of((uint32_t)lb)) ? 1 : 0;
@@ -198,7 +205,7 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
             // the wave-cooperative stage B (sx_wave_dev.hip): a class per byte on its own, 4 bits per byte pair.  Big5's four pointers that
             // yield two code points (U+00CA / U+00EA + U+0304 / U+030C) stand as ONE rejected char there: only for Missions that
             // reject both (UTF-8 lead bytes C3 and CC)
-            m->wave_ok = wv_mission_ok(in.grep_char, in.require_same_unicode_block, in.chars_min_nb, (uint32_t)m->q)
+            m->wave_ok = wv_mission_ok(in.grep_char, same_block, in.chars_min_nb, (uint32_t)m->q)
                          && (enc != SX_ENC_BIG5 || (!m->filter.pass_ubf_filter(0xC3) && !m->filter.pass_ubf_filter(0xCC)));
             m->wave_family = 4;
             m->wave_lut.assign(256, 0);
@@ -277,7 +284,7 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
             m->wave_lut.assign(256, 0);
             for (int b = 0; b < 256; b++)
                 m->wave_lut[(size_t)b] = b < 0x80 ? (uint8_t)(WVC_VALID | (af[b] ? WVC_ACC : 0)) : ((b >= 0xA1 && b <= 0xFE) || b == 0x8E || b == 0x8F) ? (uint8_t)WVC_LEAD : (uint8_t)0;
-            m->wave_ok = wv_mission_ok(in.grep_char, in.require_same_unicode_block, in.chars_min_nb, (uint32_t)m->q) && one_len && ranges.size() <= 6;
+            m->wave_ok = wv_mission_ok(in.grep_char, same_block, in.chars_min_nb, (uint32_t)m->q) && one_len && ranges.size() <= 6;
             if (m->wave_ok) {
                 WvSwar& R = m->wave_swar;
                 R.cls = 1; R.n = (uint32_t)ranges.size(); R.hi_len = len_seen ? len_seen : 3u; R.kana = kana ? 1u : 0u;
@@ -322,7 +329,16 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
         bool acc[256];
         const uint16_t* tab = single_byte_table(enc);
         // the wave-cooperative stage B (sx_wave_dev.hip) reads a class per byte: valid / accepted / bytes of its UTF-8 form
-        m->wave_ok = wv_mission_ok(in.grep_char, in.require_same_unicode_block, in.chars_min_nb, (uint32_t)m->q);
+        if (same_block) {   // -r: the lead bytes of the characters this table can yield and the filter lets pass
+            uint64_t leads = 0;
+            for (int b = 0x80; b < 256; b++) {
+                const uint32_t cp = tab ? tab[b - 0x80] : 0xF780u + (uint32_t)(b - 0x80);
+                const uint8_t lead = utf8_lead_of(cp);
+                if (cp >= 0x80 && m->filter.pass_ubf_filter(lead)) leads |= 1ull << (lead & 0x3F);
+            }
+            if (__builtin_popcountll(leads) <= 1) same_block = 0;
+        }
+        m->wave_ok = wv_mission_ok(in.grep_char, same_block, in.chars_min_nb, (uint32_t)m->q);
         m->wave_lut.assign(256, 0);
         for (int b = 0; b < 256; b++) {
             uint32_t cp = (uint32_t)b;

@@ -190,6 +190,16 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         if (const char* e = getenv("SX_WAVE_LUT")) if (atoi(e) && m.wave_family != 5) P.swar.cls = 0;   // tests: the class table also where ranges would do
         P.wave_nf = d_u; P.wave_nb = d_u + n_waves; P.wave_in = d_u + 2 * n_waves; P.wave_out = d_u + 3 * n_waves;
         P.wave_grid = m.wave_family == 4 ? d_u + 4 * n_waves : nullptr;
+        // -r on a UTF-8 Mission: the kernels collect the lead bytes that pass ubf; two kinds (the leftover's included) and the buffer goes back
+        uint64_t* d_leads = nullptr;
+        uint64_t left_leads = 0;
+        if (m.wave_lead_check) {
+            d_leads = (uint64_t*)(((uintptr_t)(d_u + 5 * n_waves) + 7) & ~(uintptr_t)7);   // (inside the 4096 spare bytes of d_rp[1])
+            HIP_TRY(ctx, hipMemsetAsync(d_leads, 0, 8, sb));
+            for (unsigned char c : st.last_scan_run_leftover) if (c >= 0xC2 && c <= 0xF4 && ((m.c.ubf >> (c & 0x3F)) & 1)) left_leads |= 1ull << (c & 0x3F);
+            if (__builtin_popcountll(left_leads) > 1) return SX_WAVE_FALLBACK;
+        }
+        P.lead_set = d_leads; P.ubf = m.c.ubf;
         P.wave_fbase = d_fb; P.wave_abase = d_ab;
         // Descriptors for the lane-per-finding writer: room for twice the findings a wavefront is expected to hold (the last buffer's
         // density; stage A's record count; else one per window), at most two per window and a third of the input's size in all.  A
@@ -241,7 +251,12 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             HIP_TRY(ctx, launch_wave_count(P, v0, v1, d_fb, d_ab, d_tot + 4 * j, w_scratch, w_scratch_cap, sb));
             HIP_TRY(ctx, hipEventRecord(d.wave_ev[4 * j + 1], sb));
             HIP_TRY(ctx, hipMemcpyAsync(h_tot + 4 * j, d_tot + 4 * j, 4 * 8, hipMemcpyDeviceToHost, sb));
+            if (d_leads) HIP_TRY(ctx, hipMemcpyAsync(h_tot + 4 * K, d_leads, 8, hipMemcpyDeviceToHost, sb));   // (pinned: 4096 bytes, K <= 64 slabs use 2048)
             HIP_TRY(ctx, hipStreamSynchronize(sb));
+            if (d_leads && __builtin_popcountll(h_tot[4 * K] | left_leads) > 1) {
+                if (getenv("SX_TIMING")) fprintf(stderr, "[sx] wave replay mission %zu: -r and two kinds of lead bytes in this buffer: lane-per-region path\n", k);
+                return abandon(SX_WAVE_FALLBACK);
+            }
             if ((h_tot[4 * j + 2] & 0xFFFFFFFFull) != 0 || getenv("SX_WAVE_FAIL")) {   // (SX_WAVE_FAIL: tests of the way back)
                 if (getenv("SX_TIMING")) fprintf(stderr, "[sx] wave replay mission %zu: %llu wavefronts assumed a wrong entry state: lane-per-region path\n", k, (unsigned long long)(h_tot[4 * j + 2] & 0xFFFFFFFFull));
                 return abandon(SX_WAVE_FALLBACK);

@@ -137,6 +137,7 @@ SXD u32 wv_probe_pack(u32 lb, u32 lback) { return WV_PROBE | (lb << 8) | (lback 
 SXD u32 wv_probe_hb(u32 prec) { return (prec >> 27) & 3u; }
 SXD u32 wv_probe_pend(u32 prec) { return (prec >> 29) & 3u; }
 
+// (same_block: -r as far as it can matter — csrc/sx_mission.cpp drops it where at most one UTF-8 lead byte passes the filter, helper.rs:279-296)
 SXD bool wv_mission_ok(int grep_char, u32 same_block, u32 n_min, u32 q) {
     return grep_char < 0 && !same_block && n_min >= 1 && n_min <= q && q <= 64;
 }

@@ -265,6 +265,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         u32x4 xa = issue(0), xb = issue(1), xc = issue(2), xd = issue(3);
         // the four bytes in front of tile0 and behind the batch's last tile (the same address in every lane)
         u32 edge_back = tile0 >= 4 ? *(const u32*)(P.data + (tile0 - 4)) : 0u;
+        u32 lead_lo = 0, lead_hi = 0;   // -r: the lead bytes that pass ubf among this batch's bytes (wave-uniform)
         u32 u16_carry = 0;   // UTF-16: what lane 63 of the tile before hands on (bit 0 its last unit is a high surrogate, 1 whose character passes, 2 the unit behind it is read in slow mode)
         bool u16_exo = false;   // ... a case the masks cannot say: the wavefront gives the buffer back
         u32 euc_spill = 0;   // EUC-JP: marks of the tile's last tokens that lie on the next tile's first two bytes (five masks x 2 bits)
@@ -310,6 +311,21 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 if (n_ahead < 4) ahead = n_ahead ? ahead & ((1u << (8 * n_ahead)) - 1u) : 0u;
                 const u32 ws6[6] = { back, x.x, x.y, x.z, x.w, ahead };
                 const u32 have_lo = has_back ? 0u : 4u, have_hi = 4u + avail + n_ahead;
+                if (FAM == 1 && P.lead_set) {
+                    // -r (WaveParams::lead_set): bytes C0.. among mine?  Text: hardly ever, and then of one kind
+                    const u32 hi2 = ((x.x & (x.x << 1)) | (x.y & (x.y << 1)) | (x.z & (x.z << 1)) | (x.w & (x.w << 1))) & 0x80808080u;
+                    if (__ballot(hi2 != 0)) {
+                        u32 slo = 0, shi = 0;
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const u32 b = (ws6[1 + (k >> 2)] >> (8 * (k & 3))) & 0xFFu;
+                            if (b >= 0xC2u && b <= 0xF4u && ((P.ubf >> (b & 0x3Fu)) & 1ull)) { if ((b & 0x3Fu) < 32u) slo |= 1u << (b & 31u); else shi |= 1u << (b & 31u); }
+                        }
+#pragma unroll
+                        for (u32 d = 1; d < 64; d <<= 1) { slo |= wv_shfl(slo, lane ^ d); shi |= wv_shfl(shi, lane ^ d); }
+                        lead_lo |= wv_uniform(slo); lead_hi |= wv_uniform(shi);
+                    }
+                }
                 if (FAM == 2) {
                     // UTF-16 (sx_wave_core.hpp wv_classify16_utf16): eight units per lane; which of them begin a window; from the lane in front:
                     // is its last unit a high surrogate, does the character that one begins pass, is my first unit read in slow mode
@@ -493,6 +509,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             const u32 ea = t + 1 < (int)n_tiles ? (u32)__builtin_amdgcn_readlane(xa.x, 0) : edge_after;
             do_tile(t, x, edge_back, ea);
             edge_back = (u32)__builtin_amdgcn_readlane(x.w, 63);
+        }
+        if (FAM == 1 && P.lead_set && (lead_lo | lead_hi)) {
+            if (lane == 0) atomicOr((unsigned long long*)P.lead_set, ((unsigned long long)lead_hi << 32) | lead_lo);
+            if (__popc(lead_lo) + __popc(lead_hi) > 1) {   // two kinds already: -r may matter, this buffer is not the wave path's
+                if (lane == 0 && MODE == 0) { P.wave_in[v] = 0xFFFFFFFEu; P.wave_out[v] = 0xFFFFFFFDu; P.wave_nf[v] = 0; P.wave_nb[v] = 0; }
+                return;
+            }
         }
         if (FAM == 2 && __ballot(u16_exo)) {   // as EUC-JP's way out: an entry state no wavefront ever leaves makes the verification fail
             if (lane == 0 && MODE == 0) { P.wave_in[v] = 0xFFFFFFFEu; P.wave_out[v] = 0xFFFFFFFDu; P.wave_nf[v] = 0; P.wave_nb[v] = 0; }

@@ -322,3 +322,27 @@ def test_utf16_text_is_dense_by_default():
         assert sc.stats().wave_windows > 0
     finally:
         sc.close()
+
+
+def test_same_unicode_block_on_buffers_where_it_cannot_matter(wave_forced):
+    """-r on a UTF-8 Mission (helper.rs:279-296): the wave kernels do not know it and take a buffer only if at most one lead byte that passes
+    the filter occurs in it (the leftover carried in included) — ASCII text, text with one kind of multi-byte characters.  Two kinds: the
+    wavefronts give the buffer back.  The result is the oracle's either way; chunks that change the kind at their boundary"""
+    rng = random.Random(99)
+    ms = rc.missions(encodings=["utf-8"], chars_min="4", same_unicode_block=True, unicode_block_filter="All")
+    ascii_text = text_lines(rng, 300_000)
+    def words(alphabet, n):
+        out = []
+        while sum(len(w) + 1 for w in out) < n:
+            out.append("".join(rng.choice(alphabet) for _ in range(rng.randrange(2, 30))))
+        return (" ".join(out)).encode("utf-8")
+    latin = words("abcdefg éüöàß", 200_000)            # lead byte C3 only
+    cyr = words("абвгдежзийклмнопрстуфх xyz", 200_000)  # D0 and D1
+    mixed = b"".join(rng.choice([latin[i:i + 16384], cyr[i:i + 16384], ascii_text[i:i + 16384]]) for i in range(0, 160_000, 16384))
+    boundary = (words("é", 16384)[:16384 - 3] + "éé".encode()[:3] + words("ж", 16384)) * 4      # the kind changes where the chunks do
+    for name, data in (("ascii", ascii_text), ("latin", latin), ("cyrillic", cyr), ("mixed", mixed), ("boundary", boundary), ("random", rng.randbytes(150_000))):
+        want = sxo.run_cli(ms, [data], radix="x")
+        for chunk in (None, 16384, 65536):
+            assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (name, chunk)
+    assert wave_windows_of_a_scan(ms, ascii_text) > 0 and wave_windows_of_a_scan(ms, latin) > 0    # the wave kernels took these
+    assert wave_windows_of_a_scan(ms, cyr) == 0                                                    # ... and gave this one back

@@ -170,6 +170,10 @@ MISSIONS = [
     dict(encodings=["utf-8"], chars_min="10", unicode_block_filter="African"),
     dict(encodings=["utf-8"], chars_min="2", output_line_len="16", unicode_block_filter="Cjk", ascii_filter="None"),
     dict(encodings=["utf-8"], chars_min="20", output_line_len="20", unicode_block_filter="Uncommon"),
+    # -r where it cannot break a string: at most one UTF-8 lead byte passes the filter (x-user-defined: every character >= 0x80 begins with EF)
+    dict(encodings=["ascii"], chars_min="4", same_unicode_block=True),
+    dict(encodings=["x-user-defined"], chars_min="3", output_line_len="20", unicode_block_filter="All", same_unicode_block=True),
+    dict(encodings=["utf-8"], chars_min="3", unicode_block_filter="0x10000", same_unicode_block=True),   # (lead byte D0 only)
 ]
 
 
@@ -297,7 +301,8 @@ def test_which_missions_classify_by_ranges():
 
 
 def test_missions_the_wave_path_does_not_cover():
-    for kw in (dict(encodings=["ascii"], chars_min="4", grep_char="47"), dict(encodings=["ascii"], chars_min="4", same_unicode_block=True),
+    for kw in (dict(encodings=["ascii"], chars_min="4", grep_char="47"), dict(encodings=["koi8-r"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True),
+               dict(encodings=["utf-8"], chars_min="4", same_unicode_block=True),
                dict(encodings=["ascii"], chars_min="0"), dict(encodings=["ascii"], chars_min="70"),
                dict(encodings=["ascii"], chars_min="4", output_line_len="100"), dict(encodings=["utf-16le"], chars_min="4", same_unicode_block=True),
                dict(encodings=["big5"], chars_min="4"), dict(encodings=["euc-jp"], chars_min="4", unicode_block_filter="All"), dict(encodings=["gbk"], chars_min="4")):

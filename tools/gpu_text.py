@@ -16,7 +16,9 @@ data = (blob * (mib * (1 << 20) // len(blob) + 1))[:mib << 20]
 blob16 = blob.decode().encode("utf-16-le")
 data16 = (blob16 * (mib * (1 << 20) // len(blob16) + 1))[:mib << 20]
 cases = [(dict(encodings=["ascii"], chars_min="4"), data), (dict(encodings=["utf-8"], chars_min="10"), data),
-         (dict(encodings=["utf-16le"], chars_min="10"), data16)]
+         (dict(encodings=["utf-16le"], chars_min="10"), data16),
+         # -r: `-e ascii` (no two accepted characters with different UTF-8 lead bytes exist: the wave path) and `-e utf-8` (the lane-per-region path)
+         (dict(encodings=["ascii"], chars_min="4", same_unicode_block=True), data), (dict(encodings=["utf-8"], chars_min="10", same_unicode_block=True), data)]
 if len(sys.argv) > 2: cases = [c for c in cases if c[0]["encodings"][0] in sys.argv[2:]]
 for flags, data in cases:
     ms = rc.missions(**flags)
@@ -28,5 +30,5 @@ for flags, data in cases:
         res = sc.scan_device(d, len(data), file_id=1)
         dts.append(time.perf_counter() - t0); n = len(res); res.free()
     dt = sorted(dts[2:])[len(dts[2:]) // 2]
-    print(flags["encodings"], f"{mib} MiB text: {dt*1e3:.1f} ms = {mib/1024/dt:.2f} GiB/s (median of 6; min {min(dts)*1e3:.1f}, max {max(dts[2:])*1e3:.1f} ms), {n} findings")
+    print(flags["encodings"], "-r" if flags.get("same_unicode_block") else "", f"{mib} MiB text: {dt*1e3:.1f} ms = {mib/1024/dt:.2f} GiB/s (median of 6; min {min(dts)*1e3:.1f}, max {max(dts[2:])*1e3:.1f} ms), {n} findings")
     sc.free(d); sc.close()
