@@ -196,7 +196,7 @@ struct WaveParams {
     uint32_t desc_cap;
     WvSwar swar;              // cls != 0: the classes come from ranges, `lut` is not read
     const uint32_t* pairs2;   // ... two-byte family then: 2 bits per byte pair (bit 0 mapped, bit 1 accepted)
-    // -r on a UTF-8 Mission (helper.rs:279-296): the wave path does not know it; it is right as long as -r cannot break a string in this
+    // -r on a UTF-8 / UTF-16 Mission (helper.rs:279-296): the wave path does not know it; it is right as long as -r cannot break a string in this
     // buffer — at most ONE lead byte that passes ubf occurs in it.  The count pass ORs the lead bytes it meets into *lead_set (bit = lead &
     // 0x3F); a wavefront that meets two gives up at once, and the host gives the buffer back if the set (with the leftover's) holds two
     uint64_t* lead_set;       // device, or nullptr: no -r

@@ -123,7 +123,8 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
         {   // the wave-cooperative stage B (sx_wave_core.hpp wv_utf16_unit): per high byte — the low byte's quadrants that pass, hb == 0, high / low surrogate —, per low byte of U+0000..U+00FF
             // (windows of >= 10 bytes: the slice-start probe, finding_collection.rs:176-207, lets a fresh decoder run over the slice until 8 bytes are
             // written — five units at most; in a shorter window the real decoder has already met the window's last unit, which it treats differently)
-            m->wave_ok = wv_mission_ok(in.grep_char, same_block, in.chars_min_nb, (uint32_t)m->q) && m->window % 2 == 0 && m->window >= 10;
+            m->wave_ok = wv_mission_ok(in.grep_char, 0u, in.chars_min_nb, (uint32_t)m->q) && m->window % 2 == 0 && m->window >= 10;
+            m->wave_lead_check = m->wave_ok && same_block != 0;   // (-r: per buffer, as for UTF-8)
             m->wave_family = 2;
             m->wave_lut.assign(512, 0);
             for (int lb = 0; lb < 256; lb++) m->wave_lut[256 + (size_t)lb] = m->filter.pass_lead(utf8_lead_of((uint32_t)lb)) ? 1 : 0;

@@ -333,6 +333,20 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                     const u32 n_units = avail >> 1;
                     const u32 xs4[4] = { x.x, x.y, x.z, x.w };
                     const WvU16Lane L = wv_utf16_lane_units(lds_lut, be, xs4, n_units);
+                    if (P.lead_set && __ballot((L.len2 | L.hm) != 0)) {   // -r (WaveParams::lead_set): the UTF-8 lead bytes of the units beyond ASCII that pass ubf
+                        u32 slo = 0, shi = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            if ((u32)j >= n_units) continue;
+                            const u32 raw = (xs4[j >> 1] >> (16 * (j & 1))) & 0xFFFFu, u = be ? ((raw & 0xFFu) << 8) | (raw >> 8) : raw;
+                            if (u < 0x80u || (u & 0xFC00u) == 0xDC00u) continue;   // (an astral character's lead byte follows from its high surrogate)
+                            const u32 code = (u & 0xFC00u) == 0xD800u ? 0x30u | (((0x10000u + ((u & 0x3FFu) << 10)) >> 18) & 7u) : u < 0x800u ? u >> 6 : 0x20u | (u >> 12);
+                            if ((P.ubf >> code) & 1ull) { if (code < 32u) slo |= 1u << code; else shi |= 1u << (code & 31u); }
+                        }
+#pragma unroll
+                        for (u32 d = 1; d < 64; d <<= 1) { slo |= wv_shfl(slo, lane ^ d); shi |= wv_shfl(shi, lane ^ d); }
+                        lead_lo |= wv_uniform(slo); lead_hi |= wv_uniform(shi);
+                    }
                     const u32 r = (u32)((tile0 + (u64)rel) & (kWvSlice - 1));
                     const u32 rw = r % P.W;
                     u32 wbm = r == kWvSlice - 16 ? 0x100u : 0u;                        // (a slice begins behind the lane)
@@ -510,7 +524,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             do_tile(t, x, edge_back, ea);
             edge_back = (u32)__builtin_amdgcn_readlane(x.w, 63);
         }
-        if (FAM == 1 && P.lead_set && (lead_lo | lead_hi)) {
+        if ((FAM == 1 || FAM == 2) && P.lead_set && (lead_lo | lead_hi)) {
             if (lane == 0) atomicOr((unsigned long long*)P.lead_set, ((unsigned long long)lead_hi << 32) | lead_lo);
             if (__popc(lead_lo) + __popc(lead_hi) > 1) {   // two kinds already: -r may matter, this buffer is not the wave path's
                 if (lane == 0 && MODE == 0) { P.wave_in[v] = 0xFFFFFFFEu; P.wave_out[v] = 0xFFFFFFFDu; P.wave_nf[v] = 0; P.wave_nb[v] = 0; }

@@ -346,3 +346,13 @@ def test_same_unicode_block_on_buffers_where_it_cannot_matter(wave_forced):
             assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (name, chunk)
     assert wave_windows_of_a_scan(ms, ascii_text) > 0 and wave_windows_of_a_scan(ms, latin) > 0    # the wave kernels took these
     assert wave_windows_of_a_scan(ms, cyr) == 0                                                    # ... and gave this one back
+    # the same for UTF-16: the lead bytes of the units' UTF-8 forms
+    ms16 = rc.missions(encodings=["utf-16le"], chars_min="4", same_unicode_block=True, unicode_block_filter="All")
+    to16 = lambda b: b.decode("utf-8", "ignore").encode("utf-16-le")
+    for name, data in (("ascii", to16(ascii_text[:150_000])), ("latin", to16(latin)), ("cyrillic", to16(cyr)), ("mixed", to16(mixed)),
+                       ("astral", ("ab\U0001F600cd \U0001F601\n" * 9000).encode("utf-16-le")), ("random", rng.randbytes(150_000))):
+        want = sxo.run_cli(ms16, [data], radix="x")
+        for chunk in (None, 16384):
+            assert run_cli_product(ms16, [data], radix="x", device=0, chunk_bytes=chunk) == want, ("utf-16le", name, chunk)
+    assert wave_windows_of_a_scan(ms16, to16(ascii_text[:150_000])) > 0 and wave_windows_of_a_scan(ms16, to16(latin)) > 0
+    assert wave_windows_of_a_scan(ms16, to16(cyr)) == 0

@@ -17,8 +17,9 @@ blob16 = blob.decode().encode("utf-16-le")
 data16 = (blob16 * (mib * (1 << 20) // len(blob16) + 1))[:mib << 20]
 cases = [(dict(encodings=["ascii"], chars_min="4"), data), (dict(encodings=["utf-8"], chars_min="10"), data),
          (dict(encodings=["utf-16le"], chars_min="10"), data16),
-         # -r: `-e ascii` (no two accepted characters with different UTF-8 lead bytes exist: the wave path) and `-e utf-8` (the lane-per-region path)
-         (dict(encodings=["ascii"], chars_min="4", same_unicode_block=True), data), (dict(encodings=["utf-8"], chars_min="10", same_unicode_block=True), data)]
+         # -r: `-e ascii` (no two accepted characters with different UTF-8 lead bytes exist) and `-e utf-8` / `-e utf-16le` (none in this buffer): the wave path
+         (dict(encodings=["ascii"], chars_min="4", same_unicode_block=True), data), (dict(encodings=["utf-8"], chars_min="10", same_unicode_block=True), data),
+         (dict(encodings=["utf-16le"], chars_min="10", same_unicode_block=True), data16)]
 if len(sys.argv) > 2: cases = [c for c in cases if c[0]["encodings"][0] in sys.argv[2:]]
 for flags, data in cases:
     ms = rc.missions(**flags)
