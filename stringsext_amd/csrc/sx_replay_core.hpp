@@ -364,6 +364,9 @@ SXD_NOINLINE u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& d
 
 constexpr u32 kObCap = 4 * 64 + 3 * 128 + 16;  // leftover (<= 4q bytes) + one window's output; q <= 64
 constexpr u32 kMaxWindow = 128;                 // W = 2q
+// ... and for 64 < q <= 255 (round 4: the device replays those too, in instantiations of their own — QBIG —; rounds 1-3: the host, ten
+// times slower on sparse input)
+constexpr u32 kObCapBig = 4 * 255 + 3 * 510 + 16, kMaxWindowBig = 512;
 constexpr u32 kBackBytes = 16;                  // of the buffer in front of a region's first window, staged with it (derive_at looks back 8)
 
 // Copy of one window into private memory: 16 bytes per load where the source is aligned (it is, in the
@@ -415,16 +418,17 @@ SXD CacheGeom cache_geom(u64 arena_bytes, u64 n_heads) {
 }
 // EXT_WIN: the window's staging copy lies where the caller says (the kernels: a row in LDS) instead of
 // in a private array.
-template <int MODE, int ENC, bool EXT_WIN = false>
+template <int MODE, int ENC, bool EXT_WIN = false, bool QBIG = false>
 SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_finding* fout, u8* aout, u64 abase,
                        u32 cap_f = 0, u32 cap_b = 0, u8* win_ext = nullptr) {
     const u8* bytes = P.data;
     const u64 len = P.len;
     const u32 W = P.W;
     const u64 want = win_start(P.runs[i].start, W);
-    u8 ob[kObCap];
+    constexpr u32 kOb = QBIG ? kObCapBig : kObCap, kWinMax = QBIG ? kMaxWindowBig : kMaxWindow;
+    u8 ob[kOb];
     // the staging row: [kBackBytes in front of the region's first window][the window]
-    alignas(16) u8 win_own[EXT_WIN ? 16 : kMaxWindow + kBackBytes];
+    alignas(16) u8 win_own[EXT_WIN ? 16 : kWinMax + kBackBytes];
     u8* const row = EXT_WIN ? win_ext : win_own;
     u8* const win = row + kBackBytes;
     u64 staged = ~0ull;
@@ -441,7 +445,7 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
     bool maybe_cut = false;
     if (P.runs[i].chars & kPieceCont) {   // a window start inside a run: the state is a function of the run (see kPieceCont)
         const u64 delta = P.runs[i].chars & ~kPieceCont;
-        if (delta < 4ull * P.q) leftover_len = derive_in_run<ENC>(P.q, P.encoding, P.table, bytes + (want - delta), (u32)delta, dec, ob, kObCap, &maybe_cut);
+        if (delta < 4ull * P.q) leftover_len = derive_in_run<ENC>(P.q, P.encoding, P.table, bytes + (want - delta), (u32)delta, dec, ob, kOb, &maybe_cut);
         else { (void)derive_at<ENC>(P, want, 0, dec, ob, near); leftover_len = 0; maybe_cut = true; }
     } else leftover_len = derive_at<ENC>(P, want, 0, dec, ob, near);
 
@@ -526,7 +530,7 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
                         if (vs > p) din = (u32)(vs - soff);
                     }
                 }
-                const DStep r = ddecode<ENC>(dec, win + (din - wb), dend - din, ob + dout, kObCap - dout, false);
+                const DStep r = ddecode<ENC>(dec, win + (din - wb), dend - din, ob + dout, kOb - dout, false);
                 if (r.result == RES_OUTPUT_FULL) { status = kRegionTooLong; done = true; break; }
                 u8 precision = SX_PRECISION_EXACT;
                 if (r.written > 0 && din == 0 && (ob[dout] & 0x80)) {  // slice-start probe, :176-207
@@ -607,14 +611,20 @@ SXD void replay_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_find
 template <int MODE>
 SXD void replay_region_any(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_finding* fout, u8* aout, u64 abase,
                            u32 cap_f = 0, u32 cap_b = 0) {
+#define SX_RR(E)                                                                                  \
+    do {                                                                                          \
+        if (P.q > 64) replay_region<MODE, E, false, true>(P, i, o, fout, aout, abase, cap_f, cap_b); \
+        else replay_region<MODE, E>(P, i, o, fout, aout, abase, cap_f, cap_b);                     \
+    } while (0)
     switch (enc_family(P.encoding)) {
-        case 1: replay_region<MODE, 1>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
-        case 2: replay_region<MODE, 2>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
-        case 3: replay_region<MODE, 3>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
-        case 4: replay_region<MODE, 4>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
-        case 5: replay_region<MODE, 5>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
-        default: replay_region<MODE, 0>(P, i, o, fout, aout, abase, cap_f, cap_b); break;
+        case 1: SX_RR(1); break;
+        case 2: SX_RR(2); break;
+        case 3: SX_RR(3); break;
+        case 4: SX_RR(4); break;
+        case 5: SX_RR(5); break;
+        default: SX_RR(0); break;
     }
+#undef SX_RR
 }
 
 

@@ -65,9 +65,12 @@ __global__ __launch_bounds__(256) void replay_heads_list_kernel(const ReplayPara
 }
 __global__ void replay_heads_total_kernel(const u32* head_last, const u32* slot_last, u32* n_heads) { *n_heads = *slot_last + *head_last; }
 
-template <int ENC>
+// (EQ: the encoding family, + 8 for 64 < q <= 255 — larger private buffers, sx_replay_core.hpp QBIG)
+template <int EQ>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WAVES))) void replay_count_kernel(
     const ReplayParams P, ReplayRegionOut* out) {
+    constexpr int ENC = EQ & 7;
+    constexpr bool QBIG = EQ >= 8;
     const u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
     if (i >= P.n_runs) return;
     ReplayRegionOut o;
@@ -75,16 +78,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WA
     const u64 want = win_start(P.runs[i].start, P.W);
     if (want < P.lo || want >= P.hi) o.status = kRegionNotMine;
     else if (region_is_chained(P, i, want)) o.status = kRegionChained;
-    else replay_region<0, ENC>(P, i, o, nullptr, nullptr, 0);
+    else replay_region<0, ENC, false, QBIG>(P, i, o, nullptr, nullptr, 0);
     out[i] = o;
 }
 // Pass 1 with the output cache: one lane per replaying run (on dense input half of the runs are chained: no idle lanes).
 // The window's staging copy lies in LDS, one row per lane (win_row_bytes: an odd number of dwords, the rows start in
 // different banks) — as a private array it is scratch memory, and the scratch of all resident waves is far larger than L2.
 __host__ __device__ inline u32 win_row_bytes(u32 W) { return (((W + kBackBytes + 3) / 4) | 1u) * 4; }
-template <int ENC, int WAVES>
+template <int EQ, int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void replay_count_cached_kernel(
     const ReplayParams P, ReplayRegionOut* out) {
+    constexpr int ENC = EQ & 7;
+    constexpr bool QBIG = EQ >= 8;
     extern __shared__ __align__(16) u8 lds_win[];
     u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
     if (i >= *P.n_heads) return;
@@ -97,25 +102,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
     const u64 off = (u64)P.slot_of[i] * g.slot_bytes;
     const bool room = off + g.slot_bytes <= P.arena_bytes;
     u8* slot = P.cache_arena + (room ? off : 0);
-    replay_region<2, ENC, true>(P, i, o, (sx_finding*)slot, slot + g.cap_f * sizeof(sx_finding), 0, room ? g.cap_f : 0u, room ? g.cap_b : 0u,
+    replay_region<2, ENC, true, QBIG>(P, i, o, (sx_finding*)slot, slot + g.cap_f * sizeof(sx_finding), 0, room ? g.cap_f : 0u, room ? g.cap_b : 0u,
                                 lds_win + threadIdx.x * win_row_bytes(P.W));
     out[i] = o;
 }
 
 // Pass 2: the standing regions write their findings and strings at the offsets the host assigned.
-template <int ENC>
+template <int EQ>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WAVES))) void replay_write_kernel(const ReplayParams P, const u64* region_index, const u64* fbase,
                                                           const u64* abase, u64 n_regions, sx_finding* findings, u8* arena) {
     const u64 k = (u64)blockIdx.x * 64 + threadIdx.x;
     if (k >= n_regions) return;
     ReplayRegionOut o;
-    replay_region<1, ENC>(P, region_index[k], o, findings + fbase[k], arena + abase[k], abase[k]);
+    replay_region<1, EQ & 7, false, (EQ >= 8)>(P, region_index[k], o, findings + fbase[k], arena + abase[k], abase[k]);
 }
 
 // Pass 2, flagged form: one lane per run; the standing regions (stitch below) write at the
 // offsets the device scans assigned.  A region whose output pass 1 kept in its cache slot is left to
 // replay_copy_cached_kernel below; the others are replayed once more by their lane.
-template <int ENC>
+template <int EQ>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WAVES))) void replay_write_flagged_kernel(
     const ReplayParams P, const ReplayRegionOut* ro, const u8* stands, const u64* fpos, const u64* apos, sx_finding* findings,
     u8* arena) {
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SX_REPLAY_WA
     if (P.cache_arena && ro[i].pad) return;
     const u64 fp = fpos[i], ap = apos[i];
     ReplayRegionOut o;
-    replay_region<1, ENC>(P, i, o, findings + fp, arena + ap, ap + P.str_off_base);
+    replay_region<1, EQ & 7, false, (EQ >= 8)>(P, i, o, findings + fp, arena + ap, ap + P.str_off_base);
 }
 
 // The cached outputs go into place: G lanes per region (4, 16 or 64, by the average output size), 64 / G regions of a wave
@@ -440,12 +445,18 @@ hipError_t launch_replay_write_flagged(const ReplayParams& P, const ReplayRegion
                                        uint8_t* arena, uint64_t avg_out_bytes, hipStream_t stream) {
     if (P.n_runs == 0) return hipSuccess;
     const dim3 grid((unsigned)((P.n_runs + 63) / 64));
-    switch (enc_family(P.encoding)) {
+    switch ((int)enc_family(P.encoding) + (P.q > 64 ? 8 : 0)) {
         case 1: hipLaunchKernelGGL(replay_write_flagged_kernel<1>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
         case 2: hipLaunchKernelGGL(replay_write_flagged_kernel<2>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
         case 3: hipLaunchKernelGGL(replay_write_flagged_kernel<3>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
         case 4: hipLaunchKernelGGL(replay_write_flagged_kernel<4>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
         case 5: hipLaunchKernelGGL(replay_write_flagged_kernel<5>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
+        case 9: hipLaunchKernelGGL(replay_write_flagged_kernel<9>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
+        case 10: hipLaunchKernelGGL(replay_write_flagged_kernel<10>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
+        case 11: hipLaunchKernelGGL(replay_write_flagged_kernel<11>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
+        case 12: hipLaunchKernelGGL(replay_write_flagged_kernel<12>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
+        case 13: hipLaunchKernelGGL(replay_write_flagged_kernel<13>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
+        case 8: hipLaunchKernelGGL(replay_write_flagged_kernel<8>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
         default: hipLaunchKernelGGL(replay_write_flagged_kernel<0>, grid, dim3(64), 0, stream, P, ro, stands, fpos, apos, findings, arena); break;
     }
     if (P.cache_arena) {
@@ -488,12 +499,18 @@ hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, hipS
         else if (waves >= 6) hipLaunchKernelGGL((replay_count_cached_kernel<E, 6>), grid, dim3(64), lds, stream, P, out); \
         else hipLaunchKernelGGL((replay_count_cached_kernel<E, 4>), grid, dim3(64), lds, stream, P, out);                 \
     } while (0)
-    switch (enc_family(P.encoding)) {
+    switch ((int)enc_family(P.encoding) + (P.q > 64 ? 8 : 0)) {
         case 1: SX_LAUNCH_COUNT(1); break;
         case 2: SX_LAUNCH_COUNT(2); break;
         case 3: SX_LAUNCH_COUNT(3); break;
         case 4: SX_LAUNCH_COUNT(4); break;
         case 5: SX_LAUNCH_COUNT(5); break;
+        case 8: SX_LAUNCH_COUNT(8); break;
+        case 9: SX_LAUNCH_COUNT(9); break;
+        case 10: SX_LAUNCH_COUNT(10); break;
+        case 11: SX_LAUNCH_COUNT(11); break;
+        case 12: SX_LAUNCH_COUNT(12); break;
+        case 13: SX_LAUNCH_COUNT(13); break;
         default: SX_LAUNCH_COUNT(0); break;
     }
 #undef SX_LAUNCH_COUNT
@@ -519,12 +536,18 @@ hipError_t launch_replay_write(const ReplayParams& P, const u64* region_index, c
                                u64 n_regions, sx_finding* findings, u8* arena, hipStream_t stream) {
     if (n_regions == 0) return hipSuccess;
     const dim3 grid((unsigned)((n_regions + 63) / 64));
-    switch (enc_family(P.encoding)) {
+    switch ((int)enc_family(P.encoding) + (P.q > 64 ? 8 : 0)) {
         case 1: hipLaunchKernelGGL(replay_write_kernel<1>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
         case 2: hipLaunchKernelGGL(replay_write_kernel<2>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
         case 3: hipLaunchKernelGGL(replay_write_kernel<3>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
         case 4: hipLaunchKernelGGL(replay_write_kernel<4>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
         case 5: hipLaunchKernelGGL(replay_write_kernel<5>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
+        case 9: hipLaunchKernelGGL(replay_write_kernel<9>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
+        case 10: hipLaunchKernelGGL(replay_write_kernel<10>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
+        case 11: hipLaunchKernelGGL(replay_write_kernel<11>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
+        case 12: hipLaunchKernelGGL(replay_write_kernel<12>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
+        case 13: hipLaunchKernelGGL(replay_write_kernel<13>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
+        case 8: hipLaunchKernelGGL(replay_write_kernel<8>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
         default: hipLaunchKernelGGL(replay_write_kernel<0>, grid, dim3(64), 0, stream, P, region_index, fbase, abase, n_regions, findings, arena); break;
     }
     return hipGetLastError();

@@ -15,7 +15,7 @@ static inline uint64_t win_start_h(uint64_t p, size_t W) {
 bool device_replay_wanted(const sx_ctx* ctx, const ReplayJob& job, size_t k, size_t n_runs) {
     if (!job.d_bytes || ctx->host_only || job.is_last || ctx->missions[k].host_sequential()) return false;
     if (ctx->opt.flags & SX_OPT_HOST_REPLAY) return false;
-    if (ctx->missions[k].q > 64) return false;
+    if (ctx->missions[k].q > 255) return false;   // (64 < q <= 255: the replay kernels' QBIG instantiations, round 4)
     // -n 0: SplitStr's exit 4 (helper.rs:317) then fires on a rejected char with nothing collected, which ends the
     // iteration for the whole decoder call (helper.rs:343) — accepted chars behind it are never carried, so the
     // rule "the last accepted char in front of a window start is the leftover" (derive_at) does not hold.  Such a

@@ -295,6 +295,24 @@ def test_dense_strings_device_replay_and_stitch(max_gap, opts, monkeypatch):
     assert run_cli_product(ms, [data], radix="x", device=0, device_replay=True) == want
 
 
+@pytest.mark.parametrize("q", ["100", "255", "65"])
+def test_long_output_lines_replay_on_the_device(q, monkeypatch):
+    """64 < q <= 255 (windows of up to 510 bytes): the replay kernels' QBIG instantiations (round 4; the host replayed these before) —
+    dense and sparse input, three decoder families, chunks, slabs"""
+    rng = random.Random(int(q))
+    alphabet = "abcdefghij XYZ019_-éжЖдяבשλ€"
+    data = dense(rng, 1_500_000, 40, alphabet) + dense(rng, 500_000, 3, alphabet) + synth(rng, 1_000_000, 1 / 300)
+    for flags in (dict(encodings=["utf-8"], chars_min="4", unicode_block_filter="All"), dict(encodings=["utf-16le", "koi8-r"], chars_min="3"),
+                  dict(encodings=["big5", "ascii"], chars_min="70", unicode_block_filter="All")):
+        ms = rc.missions(output_line_len=q, **flags)
+        want = sxo.run_cli(ms, [data], radix="x")
+        for chunk, slabs in ((None, None), (1 << 20, "3"), (65536, None)):
+            if slabs: monkeypatch.setenv("SX_SLABS", slabs)
+            else: monkeypatch.delenv("SX_SLABS", raising=False)
+            assert run_cli_product(ms, [data], radix="x", chunk_bytes=chunk, device=0, device_replay=True) == want, (q, flags, chunk)
+    monkeypatch.delenv("SX_SLABS", raising=False)
+
+
 @pytest.mark.parametrize("device_replay", [None, True, False])
 def test_pieces_pipeline_equals_oracle(device_replay, monkeypatch):
     """A large buffer is scanned piece by piece with the scan kernels queued two deep

@@ -118,6 +118,10 @@ CONFIGS = [
     dict(encodings=["utf-16le"], chars_min="3", same_unicode_block=True, unicode_block_filter="All"),
     dict(encodings=["iso-8859-5"], chars_min="4", output_line_len="6", same_unicode_block=True, ascii_filter="All-Ctrl",
          unicode_block_filter="Common"),
+    # 64 < q <= 255: the replay core's QBIG instantiations (round 4; windows of up to 510 bytes)
+    dict(encodings=["utf-8"], chars_min="4", output_line_len="100", unicode_block_filter="All"),
+    dict(encodings=["utf-16le"], chars_min="10", output_line_len="255"),
+    dict(encodings=["koi8-r"], chars_min="70", output_line_len="200", unicode_block_filter="Cyrillic"),
 ]
 
 
@@ -127,8 +131,8 @@ CONFIGS = [
 def test_device_replay_core_equals_host_replayer(core, flags, parity, skip):
     rng = random.Random(zlib.crc32(repr(sorted(flags.items())).encode()) & 0xFFFF)
     m = rc.missions(**flags)[0]
-    if m["output_line_char_nb_max"] > 64:
-        pytest.skip("device replay covers q <= 64")
+    if m["output_line_char_nb_max"] > 255:
+        pytest.skip("device replay covers q <= 255")
     W = 2 * m["output_line_char_nb_max"]
     long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
     table = sb_table(m["encoding"]) if m["encoding"] >= 16 else None
@@ -252,8 +256,8 @@ def test_device_pipeline_emulated_on_cpu_equals_the_oracle(core, flags):
     from test_gpu_parity import dense
     rng = random.Random(zlib.crc32(repr(sorted(flags.items())).encode()) & 0xFFFF)
     m = rc.missions(**flags)[0]
-    if m["output_line_char_nb_max"] > 64:
-        pytest.skip("device replay covers q <= 64")
+    if m["output_line_char_nb_max"] > 255:
+        pytest.skip("device replay covers q <= 255")
     long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
     done = 0
     for data in (synth(rng, 40_000, 1 / 150), soup(rng, 20_001), synth(rng, 30_000, 1 / 40), tricky(rng, 30_000),

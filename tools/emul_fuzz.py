@@ -22,7 +22,7 @@ while time.time() - t0 < budget:
     if not data:
         continue
     for m in c["missions"]:
-        if m["output_line_char_nb_max"] > 64 or m["chars_min_nb"] == 0 or m["encoding"] == 71:
+        if m["output_line_char_nb_max"] > 255 or m["chars_min_nb"] == 0 or m["encoding"] == 71:
             continue   # never replayed on the device (sx_stage_b.cpp device_replay_wanted)
         long_run = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
         runs = sxo.runs(m, data, stream_parity=0, min_chars=long_run)
