@@ -122,19 +122,19 @@ private:
             if (pc != runs_ + n_runs_ && pc->start == B && (pc->chars & kPieceCont)) {
                 const uint64_t delta = pc->chars & ~kPieceCont;
                 if (delta < 4ull * m_.q) {
-                    uint8_t ob[kObCap];
+                    uint8_t ob[kObCapBig];   // (<= 4q bytes, q <= 255)
                     bool cut = false;
                     const uint8_t* from = bytes_.span(B - delta, (size_t)delta, &hint_);
                     DDecoder& dd = st_->decoder.raw();
                     const uint16_t* table = decoder_table(m_.c.encoding, nullptr);
                     uint32_t n = 0;
                     switch (enc_family(m_.c.encoding)) {
-                    case 1: n = derive_in_run<1>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCap, &cut); break;
-                    case 2: n = derive_in_run<2>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCap, &cut); break;
-                    case 3: n = derive_in_run<3>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCap, &cut); break;
-                    case 4: n = derive_in_run<4>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCap, &cut); break;
-                    case 5: n = derive_in_run<5>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCap, &cut); break;
-                    default: n = derive_in_run<0>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCap, &cut); break;
+                    case 1: n = derive_in_run<1>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCapBig, &cut); break;
+                    case 2: n = derive_in_run<2>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCapBig, &cut); break;
+                    case 3: n = derive_in_run<3>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCapBig, &cut); break;
+                    case 4: n = derive_in_run<4>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCapBig, &cut); break;
+                    case 5: n = derive_in_run<5>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCapBig, &cut); break;
+                    default: n = derive_in_run<0>((uint32_t)m_.q, m_.c.encoding, table, from, (uint32_t)delta, dd, ob, kObCapBig, &cut); break;
                     }
                     st_->last_scan_run_leftover.assign((const char*)ob, n);
                     st_->last_run_str_was_printed_and_is_maybe_cut_str = cut;

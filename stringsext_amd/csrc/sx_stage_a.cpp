@@ -254,7 +254,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             // window instead of one serial replay per run (text: a run per line, most of them cross a window start).
             const Mission& mm = ctx->missions[(size_t)which[k]];
             if (cut_into_pieces && nruns && !getenv("SX_NO_PIECES") && mm.c.grep_char < 0 && !mm.c.require_same_unicode_block
-                && mm.c.chars_min_nb >= 1 && mm.c.chars_min_nb <= mm.q && mm.q <= 64) {
+                && mm.c.chars_min_nb >= 1 && mm.c.chars_min_nb <= mm.q && mm.q <= 255) {   // (q: what the replay kernels' buffers hold, sx_replay_core.hpp kObCapBig)
                 ReplayParams SP{};
                 SP.data = d_bytes; SP.len = len; SP.runs = d_list; SP.n_runs = nruns; SP.encoding = mm.c.encoding; SP.table = d.d_table;
                 SP.chars_min_nb = mm.c.chars_min_nb; SP.same_block = 0; SP.q = (uint32_t)mm.q; SP.W = (uint32_t)mm.window; SP.grep_char = -1;
