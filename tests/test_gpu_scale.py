@@ -197,3 +197,30 @@ def test_wave_path_6gib_windows_equal_oracle():
             assert got == want, (hex(ws), len(got), len(want), next(((a, b) for a, b in zip(got, want) if a != b), None))
     finally:
         res.free(); sc.free(d); sc.close()
+
+
+def test_wave_path_utf16_6gib_windows_equal_oracle(monkeypatch):
+    """UTF-16LE through the wave kernels (round 4) at 6 GiB: unit grid, window numbers and string offsets beyond 2^31 / 2^32; random units
+    hold lone surrogates every 32 units on average — the slow mode behind a pending high surrogate at every other window start"""
+    monkeypatch.setenv("SX_WAVE_REPLAY", "1")
+    ms = product_missions(encodings=["utf-16le,,,Cjk"], chars_min="4")
+    total = 6 << 30
+    sc = sx.Scanner(ms, device=0)
+    d = sc.alloc(total)
+    sc.fill_background(d, 0, total, SEED)
+    res = sc.scan_device(d, total, file_id=1)
+    try:
+        assert sc.stats().wave_windows == total // 128 - 1   # all but the buffer's first window (the host's): no wavefront gave up
+        segs = product_findings_by_slice(res)
+        assert sum(len(f) for f, _ in segs) == len(res) > 5_000_000
+        small = 16 << 20
+        for ws in ((1 << 31) - small // 2, (1 << 32) - small // 2, total - small, 5 * (1 << 30) + 4096 * 77):
+            host = sxo.background(ws, small, SEED)
+            want = oracle_window(ms, host, ws)
+            at_end = ws + small == total
+            lo_slice, hi_slice = (ws + MARGIN) // 4096, (ws + small - (0 if at_end else MARGIN)) // 4096
+            want = [t for t in want if lo_slice <= t[5] < hi_slice]
+            got = window_findings(segs, lo_slice, hi_slice)
+            assert got == want, (hex(ws), len(got), len(want), next(((a, b) for a, b in zip(got, want) if a != b), None))
+    finally:
+        res.free(); sc.free(d); sc.close()
