@@ -1145,10 +1145,11 @@ SXD WvWin wv_win_utf16(WvMask M0, WvMask M1, WvMask M2, WvMask M3, bool h_before
 // the string of a UTF-16 finding: its source units [s, s + n)
 SXD u32 wv_transcode_utf16(bool be, const u8* s, u32 n, u8* dst) {
     u32 w = 0;
+    auto unit = [&](u32 at) -> u32 { uint16_t r; __builtin_memcpy(&r, s + at, 2); return be ? (u32)(((r & 0xFFu) << 8) | (r >> 8)) : (u32)r; };   // (one load per unit)
     for (u32 p = 0; p + 2 <= n; p += 2) {
-        u32 u = be ? ((u32)s[p] << 8) | s[p + 1] : ((u32)s[p + 1] << 8) | s[p];
+        u32 u = unit(p);
         if ((u & 0xFC00u) == 0xD800u && p + 4 <= n) {
-            const u32 v = be ? ((u32)s[p + 2] << 8) | s[p + 3] : ((u32)s[p + 3] << 8) | s[p + 2];
+            const u32 v = unit(p + 2);
             u = 0x10000u + ((u & 0x3FFu) << 10) + (v & 0x3FFu);
             p += 2;
         }
@@ -1386,17 +1387,22 @@ SXD u32 wv_resolve_probe_dbcs(int enc, const uint16_t* table, const u8* slice, u
 SXD u32 wv_transcode_dbcs(int enc, const uint16_t* table, const u8* s, u32 n, u8* dst) {
     u32 w = 0, p = 0;
     while (p < n) {
-        const u8 b = s[p];
+        // the token's bytes in one load where four bytes are left (an unaligned dword: one trip to memory per token instead of one per byte —
+        // the writer waits for these loads most of its time)
+        u32 t4;
+        if (p + 4 <= n) __builtin_memcpy(&t4, s + p, 4);
+        else { t4 = s[p]; if (p + 1 < n) t4 |= (u32)s[p + 1] << 8; if (p + 2 < n) t4 |= (u32)s[p + 2] << 16; }
+        const u8 b = (u8)t4, b1 = (u8)(t4 >> 8), b2 = (u8)(t4 >> 16);
         if (b < 0x80) { dst[w++] = b; p++; continue; }
         if (enc == kEncEucJp) {   // 8E + katakana, 8F + a cell of index jis0212, else a cell of index jis0208 (sx_codec_core.hpp ddec_eucjp)
-            if (b == 0x8E) { w += dput_cp(dst + w, 0xFF61u - 0xA1u + s[p + 1]); p += 2; }
-            else if (b == 0x8F) { w += dput_cp(dst + w, table[kJisN + (s[p + 1] - 0xA1u) * 94u + (s[p + 2] - 0xA1u)]); p += 3; }
-            else { w += dput_cp(dst + w, table[(b - 0xA1u) * 94u + (s[p + 1] - 0xA1u)]); p += 2; }
+            if (b == 0x8E) { w += dput_cp(dst + w, 0xFF61u - 0xA1u + b1); p += 2; }
+            else if (b == 0x8F) { w += dput_cp(dst + w, table[kJisN + (b1 - 0xA1u) * 94u + (b2 - 0xA1u)]); p += 3; }
+            else { w += dput_cp(dst + w, table[(b - 0xA1u) * 94u + (b1 - 0xA1u)]); p += 2; }
             continue;
         }
         if (two_byte_lead(enc, b)) {
             u32 second = 0;
-            w += dput_cp(dst + w, two_byte_lookup(enc, table, b, s[p + 1], &second));
+            w += dput_cp(dst + w, two_byte_lookup(enc, table, b, b1, &second));
             p += 2;
             continue;
         }

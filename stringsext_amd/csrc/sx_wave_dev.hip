@@ -84,14 +84,25 @@ SXD void wv_write_finding(const WaveParams& P, u64 fi, u8* a, u64 a_off, u64 win
     const u8* s = P.data + (u64)((long long)win_pos + src_rel);
     if (FAM >= 4) (void)wv_transcode_dbcs((int)P.encoding, P.table, s, src_len, a);
     else if (FAM == 2) (void)wv_transcode_utf16(P.encoding == (u32)kEncUtf16be, s, src_len, a);
-    else if (out_len == src_len) {     // every char is one byte on both sides (ASCII; UTF-8 input)
-        for (u32 t = 0; t < src_len; t++) a[t] = s[t];
+    else if (out_len == src_len) {     // every char is one byte on both sides (ASCII; UTF-8 input): unaligned wide copies, 16 / 8 / 4 / 2 / 1 bytes
+        u32 t = 0;
+        for (; t + 16 <= src_len; t += 16) { u32x4 v; __builtin_memcpy(&v, s + t, 16); __builtin_memcpy(a + t, &v, 16); }
+        if (t + 8 <= src_len) { u64 v; __builtin_memcpy(&v, s + t, 8); __builtin_memcpy(a + t, &v, 8); t += 8; }
+        if (t + 4 <= src_len) { u32 v; __builtin_memcpy(&v, s + t, 4); __builtin_memcpy(a + t, &v, 4); t += 4; }
+        if (t + 2 <= src_len) { uint16_t v; __builtin_memcpy(&v, s + t, 2); __builtin_memcpy(a + t, &v, 2); t += 2; }
+        if (t < src_len) a[t] = s[t];
     } else {
         u32 w = 0;
-        for (u32 t = 0; t < src_len; t++) {
-            const u8 b = s[t];
-            if (b < 0x80) a[w++] = b;
-            else w += dput_cp(a + w, P.table ? (u32)P.table[b - 0x80] : 0xF780u + (b - 0x80u));
+        for (u32 t = 0; t < src_len; t += 4) {   // four source bytes per load
+            u32 x4;
+            const u32 k = src_len - t < 4 ? src_len - t : 4u;
+            if (k == 4) __builtin_memcpy(&x4, s + t, 4);
+            else { x4 = s[t]; if (k > 1) x4 |= (u32)s[t + 1] << 8; if (k > 2) x4 |= (u32)s[t + 2] << 16; }
+            for (u32 j = 0; j < k; j++) {
+                const u32 b = (x4 >> (8 * j)) & 0xFFu;
+                if (b < 0x80) a[w++] = (u8)b;
+                else w += dput_cp(a + w, P.table ? (u32)P.table[b - 0x80] : 0xF780u + (b - 0x80u));
+            }
         }
     }
 }
