@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses cuda:0")
     ap.add_argument("--generic-kernels", action="store_true",
                     help="force the table-driven (LUT) classifiers instead of the range kernels: what a Mission with an arbitrary af / ubf costs")
+    ap.add_argument("--ubf", default=None,
+                    help="another -u for the workload's Missions (what an alias filter costs: --ubf Cjk, --ubf Asian, --ubf All); the line's "
+                         "config.workload says so — not the headline configuration")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank scans the workload's size (N x 64 GiB at N ranks); strong: the workload's ONE image is split "
                          "over the ranks (BASELINE.json's metric: 64 GiB at 1/2/4/8 GPUs)")
@@ -120,6 +123,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     wl = WORKLOADS[args.workload]
+    if args.ubf:
+        wl = dict(wl, flags=dict(wl["flags"], unicode_block_filter=args.ubf), name=wl["name"].replace("-u African", "-u " + args.ubf) + f" [--ubf {args.ubf}]",
+                  kernels="the classifiers of -u %s: Utf8Range3T|Utf16RangesT x2 for an alias filter of three-byte leads, the table kernels for All" % args.ubf)
     missions = sx.missions_from_flags(**wl["flags"])   # the product's front end, from the literal flag strings
     assert missions == rc.missions(**wl["flags"])      # (the reference's rules restated in tests/refconfig.py: the checker)
     nbytes = int((args.gib if args.gib is not None else wl["gib"]) * (1 << 30)) // 4096 * 4096

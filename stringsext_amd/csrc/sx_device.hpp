@@ -40,7 +40,9 @@ enum ClassifierKind : uint32_t {
     kClsSingleByteRange = 5,// single byte, accept set = one range of bytes < 0x80 (+ all/none of >= 0x80)
     kClsBig5 = 6,           // Big5, Shift_JIS, EUC-KR: token classifier, 2-bit pair table (16 KB) in LDS
     kClsEucJp = 7,          // EUC-JP: the same with three-byte tokens and two pair tables (32 KB)
-    kClsSingleByteRanges = 8 // single byte, accept set = up to 6 byte ranges: SWAR, no LUT
+    kClsSingleByteRanges = 8,// single byte, accept set = up to 6 byte ranges: SWAR, no LUT
+    kClsUtf8Range3 = 9,     // UTF-8, af = one range, 2-byte leads = one range, 3-byte leads = one range of E1..EF, no 4-byte leads (sx_classify_ranges.hpp)
+    kClsUtf16Ranges = 10    // UTF-16, accepted units = up to 2 ranges below U+8000, 1 across it, 1 above; no astral plane accepted (sx_classify_ranges.hpp)
 };
 
 struct ScanParams {
@@ -63,9 +65,12 @@ struct ScanParams {
     // range classifiers
     uint32_t a_lo, a_hi;   // accepted ASCII / single-unit range (inclusive)
     uint32_t u_lo, u_hi;   // UTF-8: accepted 2-byte lead range; UTF-16: accepted unit range [u_lo,u_hi]
+    uint32_t l3_lo, l3_hi; // kClsUtf8Range3: accepted 3-byte lead range (within E1..EF)
     uint32_t high_all;     // single-byte range: every byte >= 0x80 accepted
     uint32_t n_ranges;     // kClsSingleByteRanges: ranges in use (the others are empty); per range, replicated over the four bytes:
     uint32_t rng_c1[6], rng_c2[6], rng_hi[6];  // 0x80 - lo7, 0x7F - hi7, and 0 for a range of bytes >= 0x80 / ~0 for one below
+                           // kClsUtf16Ranges: n_ranges = below | across << 4 | above << 8; slots 0, 1 / 2 / 3, 4; per 16-bit unit, replicated over the
+                           // two units: rng_c1 = 0x8000 - lo15, rng_c2 = 0x8000 + hi15 (an empty slot: 0, 0x7FFF)
     uint32_t wave_prio;    // 1: the scan wavefronts raise their issue priority (s_setprio)
     uint32_t lr_c1[2], lr_c2[2];  // Big5 / Shift_JIS / EUC-KR: the lead byte ranges (low 7 bits; 0x80 - lo, 0x7F - hi, replicated)
     uint32_t high1;        // Shift_JIS: bytes >= 0x80 outside the lead ranges can be characters (0x80, A1..DF): lut[] holds all 256

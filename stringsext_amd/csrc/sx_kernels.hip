@@ -341,6 +341,9 @@ struct Utf16Lut {
     }
 };
 
+// --- UTF-8 with three-byte leads / UTF-16 with up to four unit ranges: the alias filters (Cjk, Asian, Kana, Hangul ...) as SWAR ranges
+#include "sx_classify_ranges.hpp"
+
 // ------------------------------------------------------------------------------------------
 // Tile-to-tile state of one wavefront.  Everything here is wave-uniform (SGPRs).
 // ------------------------------------------------------------------------------------------
@@ -1388,6 +1391,14 @@ hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t str
         case kClsUtf16Range: return launch_v2<Utf16Range, false>(p, stream);
         case kClsSingleByteRange: return launch_v2<SingleByteRange, false>(p, stream);
         case kClsSingleByteRanges: return launch_v2<SingleByteRanges<6>, false>(p, stream);
+        case kClsUtf8Range3: return launch_v2<Utf8Range3T<true, 2>, false>(p, stream);   // (the most general instantiation)
+        case kClsUtf16Ranges:   // (the most general instantiation; unused slots are empty)
+            switch ((p.big_endian ? 2 : 0) | (p.parity & 1)) {
+            case 0: return launch_v2<Utf16RangesT<0, 0, 2, 1, 1>, false>(p, stream);
+            case 1: return launch_v2<Utf16RangesT<0, 1, 2, 1, 1>, false>(p, stream);
+            case 2: return launch_v2<Utf16RangesT<1, 0, 2, 1, 1>, false>(p, stream);
+            default: return launch_v2<Utf16RangesT<1, 1, 2, 1, 1>, false>(p, stream);
+            }
         default: break;
         }
     }
@@ -1403,6 +1414,34 @@ hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t str
         case 2: return launch_t<Utf16RangeT<1, 0>, false>(p, stream);
         default: return launch_t<Utf16RangeT<1, 1>, false>(p, stream);
         }
+    case kClsUtf8Range3: {
+        // ED (second byte 80..9F only): 0 = not among the leads, 1 = the last of them, 2 = inside the range
+        const int ed = p.l3_hi < 0xEDu || p.l3_lo > 0xEDu ? 0 : p.l3_hi == 0xEDu ? 1 : 2;
+        const bool has2 = p.u_lo <= p.u_hi;
+        switch ((has2 ? 3 : 0) + ed) {
+        case 0: return launch_t<Utf8Range3T<false, 0>, false>(p, stream);
+        case 1: return launch_t<Utf8Range3T<false, 1>, false>(p, stream);
+        case 2: return launch_t<Utf8Range3T<false, 2>, false>(p, stream);
+        case 3: return launch_t<Utf8Range3T<true, 0>, false>(p, stream);
+        case 4: return launch_t<Utf8Range3T<true, 1>, false>(p, stream);
+        default: return launch_t<Utf8Range3T<true, 2>, false>(p, stream);
+        }
+    }
+    case kClsUtf16Ranges: {
+        // ranges below U+8000 (1: af alone, 2: + a range of two-byte leads or of leads up to E7) / across it / above it
+        const u32 ns = (p.n_ranges >> 4) & 1u, nh = (p.n_ranges >> 8) & 1u, nl = (p.n_ranges & 15u) <= 1u && (ns | nh) ? 1u : 2u;   // (an unused slot is empty)
+        const u32 bo = (p.big_endian ? 2u : 0u) | (p.parity & 1u);
+#define SX_U16R(NL, NS, NH)                                                                                  \
+        if (nl == NL && ns == NS && nh == NH) switch (bo) {                                                  \
+            case 0: return launch_t<Utf16RangesT<0, 0, NL, NS, NH>, false>(p, stream);                       \
+            case 1: return launch_t<Utf16RangesT<0, 1, NL, NS, NH>, false>(p, stream);                       \
+            case 2: return launch_t<Utf16RangesT<1, 0, NL, NS, NH>, false>(p, stream);                       \
+            default: return launch_t<Utf16RangesT<1, 1, NL, NS, NH>, false>(p, stream);                      \
+        }
+        SX_U16R(1, 1, 0) SX_U16R(1, 0, 1) SX_U16R(1, 1, 1) SX_U16R(2, 0, 0) SX_U16R(2, 1, 0) SX_U16R(2, 0, 1) SX_U16R(2, 1, 1)
+#undef SX_U16R
+        break;
+    }
     case kClsSingleByteRange: return launch_t<SingleByteRange, false>(p, stream);
     case kClsSingleByteRanges:
         if (p.n_ranges <= 2) return launch_t<SingleByteRanges<2>, false>(p, stream);

@@ -99,9 +99,21 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
                 }
             }
         }
+        // three-byte leads E0..EF <-> ubf bits 32..47: the alias filters of mission.rs:167-218 (Cjk E4..E9, Kana E3, Hangul EB..ED, Asian E2..ED ...)
+        // are one range of them; E0 (second byte A0..BF only) and the four-byte leads stay with the table kernel
+        bool lead3[16];
+        for (int i = 0; i < 16; i++) lead3[i] = ((in.ubf >> (32 + i)) & 1) != 0;
+        int l3lo = 0, l3hi = 0;
+        bool l3empty = false;
+        const bool ubf3_is_range = one_range(lead3, 0, 15, &l3lo, &l3hi, &l3empty);
+        const bool no_lead4 = ((in.ubf >> 48) & 0x1Full) == 0;   // F0..F4 <-> bits 48..52
         if (!force_generic && af_is_range && ubf2_is_range && no_long_leads) {
             m->kind = kClsUtf8Range2;
             if (!uempty) { p.u_lo = 0xC0u + (uint32_t)ulo; p.u_hi = 0xC0u + (uint32_t)uhi; }
+        } else if (!force_generic && af_is_range && ubf2_is_range && ubf3_is_range && !l3empty && l3lo >= 1 && no_lead4) {
+            m->kind = kClsUtf8Range3;   // (sx_classify_ranges.hpp)
+            if (!uempty) { p.u_lo = 0xC0u + (uint32_t)ulo; p.u_hi = 0xC0u + (uint32_t)uhi; }
+            p.l3_lo = 0xE0u + (uint32_t)l3lo; p.l3_hi = 0xE0u + (uint32_t)l3hi;
         } else {
             m->kind = kClsUtf8Lut;
             for (int b = 0; b < 256; b++) {
@@ -146,10 +158,35 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
         }
         const bool no_bmp3 = ((in.ubf >> 32) & 0xFFFFull) == 0;   // U+0800..U+FFFF <-> bits 32..47
         const bool no_astral = ((in.ubf >> 48) & 0x1Full) == 0;   // bits 48..52
+        // the accepted units as ranges (no surrogate inside): what af and the lead bytes of ubf say unit by unit — C2..DF <-> U+0080..U+07FF,
+        // E0..EF <-> U+0800..U+FFFF; with an astral plane accepted a surrogate pair can be a character, which the range kernels do not
+        // know.  Up to two ranges below U+8000, one that straddles it, one above (sx_classify_ranges.hpp Utf16RangesT)
+        std::vector<std::pair<uint32_t, uint32_t>> uranges;
+        if (!force_generic && no_astral)
+            for (uint32_t u = 0; u < 0x10000u && uranges.size() <= 4; u++) {
+                const bool acc = u < 0x80 ? m->filter.pass_lead((uint8_t)u)
+                                          : (u < 0xD800u || u > 0xDFFFu) && m->filter.pass_ubf_filter(utf8_lead_of(u));
+                if (!acc) continue;
+                if (!uranges.empty() && uranges.back().second + 1 == u) uranges.back().second = u;
+                else uranges.emplace_back(u, u);
+            }
+        uint32_t n_lo = 0, n_st = 0, n_hi = 0;
+        for (const auto& r : uranges) { if (r.second < 0x8000u) n_lo++; else if (r.first >= 0x8000u) n_hi++; else n_st++; }
+        const bool uranges_fit = !force_generic && no_astral && !uranges.empty() && n_lo <= 2 && n_st <= 1 && n_hi <= 1;
         if (!force_generic && af_is_range && ubf2_is_range && no_bmp3 && no_astral) {
             m->kind = kClsUtf16Range;
             if (!uempty) { p.u_lo = (uint32_t)ulo << 6; p.u_hi = ((uint32_t)uhi << 6) | 0x3F; }
             else { p.u_lo = 1; p.u_hi = 0; }
+        } else if (uranges_fit) {
+            m->kind = kClsUtf16Ranges;   // (sx_classify_ranges.hpp)
+            p.n_ranges = n_lo | (n_st << 4) | (n_hi << 8);
+            for (int k = 0; k < 6; k++) { p.rng_c1[k] = 0u; p.rng_c2[k] = 0x7FFFu * 0x00010001u; p.rng_hi[k] = 0u; }   // (empty slots)
+            uint32_t il = 0, ih = 3;
+            for (const auto& r : uranges) {
+                const uint32_t slot = r.second < 0x8000u ? il++ : r.first >= 0x8000u ? ih++ : 2u;
+                p.rng_c1[slot] = (0x8000u - (r.first & 0x7FFFu)) * 0x00010001u;
+                p.rng_c2[slot] = (0x8000u + (r.second & 0x7FFFu)) * 0x00010001u;
+            }
         } else {
             m->kind = kClsUtf16Lut;
             uint8_t* H = p.lut;

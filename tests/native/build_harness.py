@@ -1,4 +1,4 @@
-"""Builds the two test-only harness libraries (the device replay core and the wave core compiled as host code) — no pytest, no torch, no
+"""Builds the test-only harness libraries (the device replay core, the wave core and the range classifiers compiled as host code) — no pytest, no torch, no
 package import: __graft_entry__.build() and the test modules both call this.  A library is rebuilt when its source or a header is newer."""
 import os
 import subprocess
@@ -26,6 +26,11 @@ def build_wave_core():
     return _build("libwave_core_host.so", "wave_core_host.cpp", ("sx_wave_core.hpp", "sx_codec_core.hpp", "sx_device.hpp"))
 
 
+def build_classify():
+    return _build("libclassify_host.so", "classify_host.cpp", ("sx_classify_ranges.hpp", "sx_device.hpp"))
+
+
 if __name__ == "__main__":
     print(build_replay_core())
     print(build_wave_core())
+    print(build_classify())

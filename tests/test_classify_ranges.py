@@ -1,0 +1,166 @@
+"""The range classifiers of stage A for the alias filters (stringsext_amd/csrc/sx_classify_ranges.hpp: UTF-8 with three-byte
+leads, UTF-16 with up to four unit ranges: two below U+8000, one across it, one above), compiled as host code (tests/native/classify_host.cpp) and compared byte by byte
+with the decoders' rules said one position at a time: UTF-8 per encoding_rs' utf_8.rs (lead + continuation bytes, E0 / ED /
+F0 / F4 narrowing the second byte), UTF-16 per utf_16.rs (units on the stream's parity, every lone surrogate an error), the
+filter per reference src/mission.rs:333-348 (af bit = the ASCII code, ubf bit = the UTF-8 lead byte & 0x3F).  No GPU."""
+import ctypes
+import random
+import zlib
+
+import pytest
+
+import refconfig as rc
+from native.build_harness import build_classify
+from test_host_logic import soup, synth
+
+LIB = ctypes.CDLL(build_classify())
+U8P = ctypes.POINTER(ctypes.c_uint8)
+LIB.sxh_classify_utf8_range3.argtypes = [ctypes.c_uint32] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, U8P, U8P]
+LIB.sxh_classify_utf16_ranges.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 2 + [ctypes.c_int] * 4 + [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, U8P, U8P]
+
+
+def lead_of(cp):
+    return cp if cp < 0x80 else 0xC0 | cp >> 6 if cp < 0x800 else 0xE0 | cp >> 12 if cp < 0x10000 else 0xF0 | cp >> 18
+
+
+def passes(m, lead):
+    return bool(m["af"] >> lead & 1) if lead < 0x80 else bool(m["ubf"] >> (lead & 0x3F) & 1)
+
+
+def naive_utf8(m, d):
+    good, start = bytearray(len(d)), bytearray(len(d))
+    for i, b in enumerate(d):
+        if b < 0x80: n = 1
+        elif 0xC2 <= b <= 0xDF: n = 2
+        elif 0xE0 <= b <= 0xEF: n = 3
+        elif 0xF0 <= b <= 0xF4: n = 4
+        else: continue
+        if i + n > len(d): continue
+        if n > 1:
+            lo, hi = {0xE0: (0xA0, 0xBF), 0xED: (0x80, 0x9F), 0xF0: (0x90, 0xBF), 0xF4: (0x80, 0x8F)}.get(b, (0x80, 0xBF))
+            if not lo <= d[i + 1] <= hi or any(not 0x80 <= c <= 0xBF for c in d[i + 2:i + n]): continue
+        if passes(m, b):
+            start[i] = 1
+            good[i:i + n] = b"\x01" * n
+    return bytes(good), bytes(start)
+
+
+def naive_utf16(m, d, be, parity):
+    good, start = bytearray(len(d)), bytearray(len(d))
+    unit = lambda i: d[i] << 8 | d[i + 1] if be else d[i] | d[i + 1] << 8
+    for i in range(parity, len(d) - 1, 2):
+        u = unit(i)
+        n = 2
+        if 0xD800 <= u <= 0xDBFF:
+            if i + 4 > len(d) or not 0xDC00 <= unit(i + 2) <= 0xDFFF: continue
+            u, n = 0x10000 + ((u & 0x3FF) << 10 | unit(i + 2) & 0x3FF), 4
+        elif 0xDC00 <= u <= 0xDFFF: continue
+        if passes(m, lead_of(u)):
+            start[i] = 1
+            good[i:i + n] = b"\x01" * n
+    return bytes(good), bytes(start)
+
+
+def one_range(bits, first, last):
+    """(lo, hi) of the set positions if they are one run, None if empty, False otherwise — a second statement of sx_mission.cpp's test"""
+    on = [i for i in range(first, last + 1) if bits >> i & 1]
+    if not on: return None
+    return (on[0], on[-1]) if len(on) == on[-1] - on[0] + 1 else False
+
+
+def run_utf8(m, d, near):
+    a, u2, u3 = one_range(m["af"], 0, 127), one_range(m["ubf"], 2, 31), one_range(m["ubf"], 32, 47)
+    assert a is not False and u2 is not False and u3 and u3[0] >= 33 and not m["ubf"] >> 48 & 0x1F, "not a Mission of this classifier"
+    a_lo, a_hi = a or (1, 0)
+    u_lo, u_hi = (0xC0 + u2[0], 0xC0 + u2[1]) if u2 else (0x81, 0x80)
+    l3_lo, l3_hi = 0xC0 + u3[0], 0xC0 + u3[1]
+    ed = 0 if l3_hi < 0xED or l3_lo > 0xED else 1 if l3_hi == 0xED else 2
+    out = []
+    for has2, e in {(1 if u2 else 0, ed), (1, 2)}:   # the instantiation launch_scan picks, and the most general one
+        good, start = (ctypes.c_uint8 * max(1, len(d)))(), (ctypes.c_uint8 * max(1, len(d)))()
+        assert LIB.sxh_classify_utf8_range3(a_lo, a_hi, u_lo, u_hi, l3_lo, l3_hi, has2, e, d, len(d), near, good, start) == 0
+        out.append((bytes(good[:len(d)]), bytes(start[:len(d)])))
+    return out
+
+
+def unit_ranges(m):
+    r = []
+    for u in range(0x10000):
+        if 0xD800 <= u <= 0xDFFF or not passes(m, lead_of(u)): continue
+        if r and r[-1][1] + 1 == u: r[-1][1] = u
+        else: r.append([u, u])
+    return r
+
+
+def run_utf16(m, d, be, parity, near):
+    r = unit_ranges(m)
+    below, across, above = sum(x[1] < 0x8000 for x in r), sum(x[0] < 0x8000 <= x[1] for x in r), sum(x[0] >= 0x8000 for x in r)
+    assert r and below <= 2 and across <= 1 and above <= 1 and not m["ubf"] >> 48 & 0x1F, "not a Mission of this classifier"
+    lo, hi = (ctypes.c_uint32 * 6)(*[x[0] for x in r]), (ctypes.c_uint32 * 6)(*[x[1] for x in r])
+    out = []
+    for general in (0, 1):   # the instantiation launch_scan picks, and the one with every slot
+        good, start = (ctypes.c_uint8 * max(1, len(d)))(), (ctypes.c_uint8 * max(1, len(d)))()
+        assert LIB.sxh_classify_utf16_ranges(lo, hi, len(r), general, be, parity, d, len(d), near, good, start) == 0
+        out.append((bytes(good[:len(d)]), bytes(start[:len(d)])))
+    return out
+
+
+TEXT = "中文字符串テスト한국어 텍스트ひらがなカタカナ Ελληνικά кириллица ﬁ￿퟿ꀀ ₠€ ༀ က ｶﾀｶﾅ"   # (incl. U+FFFF, U+D7FF, U+E000, U+A000)
+NASTY8 = [0xE0, 0xA0, 0x9F, 0x80, 0xBF, 0xED, 0xEC, 0xEE, 0xEF, 0xE1, 0xE3, 0xE4, 0xE9, 0xEA, 0xEB, 0xF0, 0xF4, 0x90, 0x8F, 0xC2, 0xDF, 0xC1, 0x41, 0x20, 0x7F, 0x00]
+
+
+def datas(rng):
+    enc = lambda s: rng.choice([s.encode("utf-8", "surrogatepass"), s.encode("utf-16-le", "surrogatepass"), s.encode("utf-16-be", "surrogatepass")])
+    out = [b"", b"\xe4", b"\xe4\xb8", b"\xe4\xb8\xad", b"A\xe4\xb8\xad", soup(rng, 5001), synth(rng, 20000, 1 / 100), rng.randbytes(30000),
+           bytes(rng.choice(NASTY8) for _ in range(20011))]
+    for _ in range(6):
+        parts = []
+        for _ in range(300):
+            k = rng.randrange(1, 12)
+            s = "".join(rng.choice(TEXT) for _ in range(k))
+            parts.append(enc(s))
+            parts.append(rng.choice([b"", b"\x00", b"\xff\xfe", b"\xed\xa0\x80", b"\xed\x9f\xbf", b"\xe0\x80\x80", b"\xe0\xa0\x80", b"\xe4\xb8", b"\xe9",
+                                     b"\x00\xd8", b"\xd8\x00\xdc\x00", b"\x00\xd8\x00\xdc", b"\xdc\x00", b"A", b"ab c"]) * rng.randrange(0, 3))
+        out.append(b"".join(parts))
+    for n in (15, 16, 17, 18, 19, 31, 32, 33, 34, 35):   # the end of the input at every phase of the 16-byte grid
+        out.append(("中文字符串한국어テスト" * 4).encode("utf-8")[:n])
+        out.append(("中文字符串한국어テスト" * 4).encode("utf-16-le")[:n])
+    return out
+
+
+UTF8_FILTERS = ["Cjk", "Kana", "Hangul", "Asian", "0x0000ffff00000000", "0x0000fffe00000000", "0x0000c00000000000", "0x0000200000000000",
+                "0x00003ffcfffffffc", "0x000003f0ffe00000", "0x0000fffefffffffc"]   # (Asian + Common; Cjk + African; everything but E0 and the 4-byte leads)
+
+
+@pytest.mark.parametrize("ubf", UTF8_FILTERS)
+def test_utf8_range3_equals_the_rules_byte_by_byte(ubf):
+    rng = random.Random(zlib.crc32(ubf.encode()))
+    for af in (None, "All", "None"):
+        m = rc.missions(encodings=["utf-8"], unicode_block_filter=ubf, **({"ascii_filter": af} if af else {}))[0]
+        if ubf == "0x0000ffff00000000":   # E0 among the leads: not this classifier's (sx_mission.cpp keeps the table kernel)
+            with pytest.raises(AssertionError):
+                run_utf8(m, b"", 0)
+            continue
+        for d in datas(rng):
+            want = naive_utf8(m, d)
+            for near in (0, 1):
+                for got in run_utf8(m, d, near):
+                    assert got == want, (ubf, af, len(d), near)
+
+
+UTF16_FILTERS = ["Cjk", "Kana", "Hangul", "Asian", "Common", "0x0000ffff00000000", "0x00003ffcfffffffc", "0x0000800000000000", "0x0000100000000000",
+                 "0x0000200000000000", "0x000000ff00000000", "0x00003800fffffffc"]   # (... EF alone; EC; ED alone = U+D000..U+D7FF; E0..E7 = U+0800..U+7FFF; Common + Hangul)
+
+
+@pytest.mark.parametrize("ubf", UTF16_FILTERS)
+def test_utf16_ranges_equal_the_rules_unit_by_unit(ubf):
+    rng = random.Random(zlib.crc32(ubf.encode()))
+    for af in (None, "All", "None"):
+        m = rc.missions(encodings=["utf-16le"], unicode_block_filter=ubf, **({"ascii_filter": af} if af else {}))[0]
+        for d in datas(rng):
+            for be in (0, 1):
+                for parity in (0, 1):
+                    want = naive_utf16(m, d, be, parity)
+                    for near in (0, 1):
+                        for got in run_utf16(m, d, be, parity, near):
+                            assert got == want, (ubf, af, len(d), be, parity, near)

@@ -29,6 +29,20 @@ def device_runs(mdict, data, parity=0, min_chars=None, generic=False, subchunk=0
         sc.close()
 
 
+def cjk_soup(rng, n):
+    """CJK / Hangul / kana text in the three encodings between the byte sequences the decoders narrow (E0 80.., ED A0.., lone surrogates)."""
+    text = "中文字符串テスト한국어 텍스트ひらがなカタカナ Ελληνικά ﬁ\uffff\ud7ff\ue000\ua000 ₠€ ｶﾀｶﾅ"
+    junk = [b"", b"\x00", b"\xff\xfe", b"\xed\xa0\x80", b"\xed\x9f\xbf", b"\xe0\x80\x80", b"\xe0\xa0\x80", b"\xe4\xb8", b"\xe9", b"\x00\xd8",
+            b"\xd8\x00\xdc\x00", b"\x00\xd8\x00\xdc", b"\xdc\x00", b"A", b"ab c", b"\xf0\x9f\x98\x80"]
+    out = bytearray()
+    while len(out) < n:
+        s = "".join(rng.choice(text) for _ in range(rng.randrange(1, 14)))
+        out += s.encode(rng.choice(["utf-8", "utf-16-le", "utf-16-be"]), "surrogatepass")
+        out += rng.choice(junk) * rng.randrange(0, 3)
+        if rng.random() < 0.05: out += rng.randbytes(rng.randrange(1, 200))
+    return bytes(out[:n])
+
+
 RUN_MISSIONS = {
     "ascii": dict(encodings=["ascii"], chars_min="4"),
     "ascii_all": dict(encodings=["ascii"], chars_min="3", unicode_block_filter="All"),
@@ -47,6 +61,17 @@ RUN_MISSIONS = {
     "win1255_hebrew": dict(encodings=["windows-1255"], chars_min="3", unicode_block_filter="Hebrew"),
     "win874_all": dict(encodings=["windows-874"], chars_min="4", unicode_block_filter="All"),
     "xmaccyr": dict(encodings=["x-mac-cyrillic"], chars_min="5", unicode_block_filter="Cyrillic"),
+    # the alias filters with three-byte leads (mission.rs:167-218): Utf8Range3T / Utf16RangesT (sx_classify_ranges.hpp) in "fast" mode
+    "utf8_asian": dict(encodings=["utf-8"], chars_min="3", unicode_block_filter="Asian"),
+    "utf8_hangul": dict(encodings=["utf-8"], chars_min="2", unicode_block_filter="Hangul", ascii_filter="None"),
+    "utf8_kana": dict(encodings=["utf-8"], chars_min="2", unicode_block_filter="Kana"),
+    "utf8_common_asian": dict(encodings=["utf-8"], chars_min="4", unicode_block_filter="0x00003ffcfffffffc"),
+    "utf8_e1_ef": dict(encodings=["utf-8"], chars_min="3", unicode_block_filter="0x0000fffe00000000", ascii_filter="All"),
+    "utf16le_cjk": dict(encodings=["utf-16le"], chars_min="3", unicode_block_filter="Cjk"),
+    "utf16be_asian": dict(encodings=["utf-16be"], chars_min="2", unicode_block_filter="Asian"),
+    "utf16le_hangul": dict(encodings=["utf-16le"], chars_min="2", unicode_block_filter="Hangul", ascii_filter="None"),
+    "utf16be_bmp3": dict(encodings=["utf-16be"], chars_min="3", unicode_block_filter="0x0000ffff00000000"),
+    "utf16le_common_asian": dict(encodings=["utf-16le"], chars_min="4", unicode_block_filter="0x00003ffcfffffffc"),
     "odd_af": dict(encodings=["utf-8"], chars_min="4", ascii_filter="0x7ffffffe000000007ffffffe00000000"),
 }
 
@@ -65,6 +90,7 @@ def test_device_runs_equal_oracle_runs(name, generic):
         synth(rng, 1023, 1 / 50), synth(rng, 1025, 1 / 50), synth(rng, 17, 1 / 5), b"abcdefghijkl", b"",
         ("Բարեւ" * 2000).encode("utf-16-le") + b"\x41" + ("שלום" * 2000).encode("utf-16-be"),
         "𝔘𝔫𝔦𝔠𝔬𝔡𝔢😀".encode("utf-8") * 500 + "𝔘𝔫𝔦𝔠𝔬𝔡𝔢😀".encode("utf-16-le") * 500 + "𝔘𝔫𝔦😀".encode("utf-16-be") * 500,
+        cjk_soup(rng, 150_001),
     ]
     for di, data in enumerate(datas):
         for parity in (0, 1):
