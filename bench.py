@@ -55,7 +55,7 @@ def scan_kernel_source_hash():
     as long as the scan kernels' source is the one they ran."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("sx_kernels.hip", "sx_device.hpp"):
+    for f in ("sx_kernels.hip", "sx_classify_ranges.hpp", "sx_device.hpp"):
         h.update(open(os.path.join(ROOT, "stringsext_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
