@@ -9,7 +9,7 @@ from test_gpu_parity import dense
 ENCS = ["utf-8", "ascii", "utf-16le", "utf-16be", "koi8-r", "ibm866", "windows-1252", "iso-8859-5", "x-user-defined", "big5", "euc-jp", "shift_jis", "euc-kr", "gbk", "gb18030", "iso-2022-jp"]
 ENCS_MORE = ["iso-8859-7", "windows-1255", "windows-874", "koi8-u", "macintosh", "iso-8859-6", "windows-1257", "x-mac-cyrillic"]
 AFS = [None, "All", "All-Ctrl", "All-Ctrl+Wsp", "None", "Wsp", "0x7ffffffe000000007ffffffe00000000"]
-UBFS = [None, "African", "All", "Common", "Cyrillic", "Latin", "Asian", "Uncommon", "None", "Hebrew", "Cjk"]
+UBFS = [None, "African", "All", "Common", "Cyrillic", "Latin", "Asian", "Uncommon", "None", "Hebrew", "Cjk", "Hangul", "Kana", "0x0000fffe00000000", "0x00003ffcfffffffc"]
 # alternative paths behind environment switches, read by the library at call time
 SWITCH_SETS = [{}, {}, {}, {"SX_NO_REPLAY_CACHE": "1"}, {"SX_HOST_STITCH": "1"}, {"SX_NO_REPLAY_SKIP": "1"}, {"SX_REPLAY_CACHE_MIB": "0"},
                {"SX_REGION_CAP": "2"}, {"SX_REGION_CAP": "0"}, {"SX_DEVICE_JOIN_MIN": "1"}, {"SX_HOST_MERGE": "1"},
