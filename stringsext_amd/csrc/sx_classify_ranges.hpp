@@ -78,16 +78,18 @@ struct Utf8Range3T {
 // hi15) - t iff t <= hi15 (no carry or borrow leaves a 16-bit lane).  Below U+8000: A & B & ~unit; above: A & B & unit; a straddling
 // range is "t >= lo15 where bit 15 is clear, t <= hi15 where it is set" = one v_bfi_b32 — three operations instead of the eight of two
 // split ranges.  Slots in ScanParams::rng_c1 / rng_c2: 0, 1 the ranges below, 2 the straddling one, 3, 4 the ranges above.
-template <int BE_T, int ODD_T, int NL, int NS, int NH>
+// AST: an astral plane passes the filter — a high surrogate whose plane does (one range of D800..DBFF, slot 5: the lead byte of the pair's
+// UTF-8 form, F0..F4, follows from the high surrogate alone) followed by a low surrogate is a character of four bytes; every other
+// surrogate stays a break (utf_16.rs: a lone or reversed surrogate is an error, the unit behind a lone high surrogate is read again).
+template <int BE_T, int ODD_T, int NL, int NS, int NH, int AST = 0>
 struct Utf16RangesT {
-    u32 c1[5], c2[5];
+    u32 c1[6], c2[6];
     SX_DEV void init(const ScanParams& p, const uint8_t*) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) { c1[k] = p.rng_c1[k]; c2[k] = p.rng_c2[k]; }
+        for (int k = 0; k < 6; k++) { c1[k] = p.rng_c1[k]; c2[k] = p.rng_c2[k]; }
     }
-    SX_DEV u32 unit_flags(u32 v) const {  // two units per dword -> flags at bits 15 and 31
-        if (BE_T) v = __builtin_amdgcn_perm(0u, v, 0x02030001u);
-        const u32 t = v & 0x7FFF7FFFu;
+    static SX_DEV u32 units(u32 v) { return BE_T ? __builtin_amdgcn_perm(0u, v, 0x02030001u) : v; }
+    SX_DEV u32 bmp_flags(u32 v, u32 t) const {  // two units per dword -> flags at bits 15 and 31 (and garbage below them)
         u32 lo = 0, hi = 0, f = 0;
 #pragma unroll
         for (int k = 0; k < NL; k++) lo |= (t + c1[k]) & (c2[k] - t);
@@ -96,24 +98,47 @@ struct Utf16RangesT {
         if (NS) f = (v & (c2[2] - t)) | (~v & (t + c1[2]));   // v_bfi_b32
         if (NL) f |= lo & ~v;
         if (NH) f |= hi & v;
-        return f & 0x80008000u;
+        return f;
     }
     template <bool WANT_S>
     SX_DEV u32 classify(u32x4 x, u32 nx, u32 avail, bool near_end) const {
-        u32 d0 = x.x, d1 = x.y, d2 = x.z, d3 = x.w;
+        u32 d[5] = { x.x, x.y, x.z, x.w, nx };
         if (ODD_T) {  // unit k of this lane = bytes 2k+1, 2k+2
-            d0 = __builtin_amdgcn_alignbyte(x.y, x.x, 1);
-            d1 = __builtin_amdgcn_alignbyte(x.z, x.y, 1);
-            d2 = __builtin_amdgcn_alignbyte(x.w, x.z, 1);
-            d3 = __builtin_amdgcn_alignbyte(nx, x.w, 1);
+            d[0] = __builtin_amdgcn_alignbyte(x.y, x.x, 1);
+            d[1] = __builtin_amdgcn_alignbyte(x.z, x.y, 1);
+            d[2] = __builtin_amdgcn_alignbyte(x.w, x.z, 1);
+            d[3] = __builtin_amdgcn_alignbyte(nx, x.w, 1);
+            d[4] = nx >> 8;
         }
-        const u32 f0 = unit_flags(d0), f1 = unit_flags(d1), f2 = unit_flags(d2), f3 = unit_flags(d3);
-        const u32 s0 = f0 >> 8, s1 = f1 >> 8, s2 = f2 >> 8, s3 = f3 >> 8;  // flag on the unit's first byte
-        u32 m = WANT_S ? movemask16(s0, s1, s2, s3) : movemask16(f0 | s0, f1 | s1, f2 | s2, f3 | s3);
-        if (near_end) {  // whole units only
-            const u32 nu = avail > (u32)ODD_T ? (avail - (u32)ODD_T) >> 1 : 0u;
-            m &= low_mask(2 * nu);
+        const u32 nu = near_end ? (avail > (u32)ODD_T ? (avail - (u32)ODD_T) >> 1 : 0u) : 16u;   // whole units inside the chunk
+        u32 f[4], pair[4] = { 0, 0, 0, 0 };
+        if (AST) {
+            constexpr u32 kLs1 = (0x8000u - 0x5C00u) * 0x00010001u, kLs2 = (0x8000u + 0x5FFFu) * 0x00010001u;   // DC00..DFFF
+            u32 ls[5], hs[4];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const u32 v = units(d[k]), t = v & 0x7FFF7FFFu;
+                ls[k] = (t + kLs1) & (kLs2 - t) & v;
+                if (near_end)   // a unit that is not whole inside the chunk is no low surrogate (UTF-16BE: DC + the zero behind the end)
+                    ls[k] &= ((u32)(2 * k) < nu ? 0x8000u : 0u) | ((u32)(2 * k + 1) < nu ? 0x80000000u : 0u);
+                if (k < 4) { f[k] = bmp_flags(v, t); hs[k] = (t + c1[5]) & (c2[5] - t) & v; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) pair[k] = hs[k] & __builtin_amdgcn_alignbyte(ls[k + 1], ls[k], 2) & 0x80008000u;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const u32 v = units(d[k]); f[k] = bmp_flags(v, v & 0x7FFF7FFFu); }
         }
+        u32 b[4];   // byte flags: both bytes of a good unit (WANT_S: the first byte of a character's first unit)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 u = (f[k] & 0x80008000u) | pair[k];
+            if (AST && !WANT_S) u |= k ? __builtin_amdgcn_alignbyte(pair[k], pair[k - 1], 2) : pair[0] << 16;   // the pair's second unit
+            b[k] = WANT_S ? u >> 8 : u | (u >> 8);
+        }
+        u32 m = movemask16(b[0], b[1], b[2], b[3]);
+        if (AST && !WANT_S) m |= (pair[3] >> 31) * 0x30000u;   // a pair that begins in my last unit: the next lane's first unit
+        if (near_end) m &= low_mask(2 * nu);   // whole units only
         return m << ODD_T;  // odd parity: everything sits one byte later (bit 16 spills)
     }
 };

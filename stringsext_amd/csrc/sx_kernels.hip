@@ -1394,10 +1394,10 @@ hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t str
         case kClsUtf8Range3: return launch_v2<Utf8Range3T<true, 2>, false>(p, stream);   // (the most general instantiation)
         case kClsUtf16Ranges:   // (the most general instantiation; unused slots are empty)
             switch ((p.big_endian ? 2 : 0) | (p.parity & 1)) {
-            case 0: return launch_v2<Utf16RangesT<0, 0, 2, 1, 1>, false>(p, stream);
-            case 1: return launch_v2<Utf16RangesT<0, 1, 2, 1, 1>, false>(p, stream);
-            case 2: return launch_v2<Utf16RangesT<1, 0, 2, 1, 1>, false>(p, stream);
-            default: return launch_v2<Utf16RangesT<1, 1, 2, 1, 1>, false>(p, stream);
+            case 0: return launch_v2<Utf16RangesT<0, 0, 2, 1, 1, 1>, false>(p, stream);
+            case 1: return launch_v2<Utf16RangesT<0, 1, 2, 1, 1, 1>, false>(p, stream);
+            case 2: return launch_v2<Utf16RangesT<1, 0, 2, 1, 1, 1>, false>(p, stream);
+            default: return launch_v2<Utf16RangesT<1, 1, 2, 1, 1, 1>, false>(p, stream);
             }
         default: break;
         }
@@ -1431,6 +1431,12 @@ hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t str
         // ranges below U+8000 (1: af alone, 2: + a range of two-byte leads or of leads up to E7) / across it / above it
         const u32 ns = (p.n_ranges >> 4) & 1u, nh = (p.n_ranges >> 8) & 1u, nl = (p.n_ranges & 15u) <= 1u && (ns | nh) ? 1u : 2u;   // (an unused slot is empty)
         const u32 bo = (p.big_endian ? 2u : 0u) | (p.parity & 1u);
+        if (p.n_ranges >> 12) switch (bo) {   // an astral plane passes: surrogate pairs (one instantiation; unused slots are empty)
+            case 0: return launch_t<Utf16RangesT<0, 0, 2, 1, 1, 1>, false>(p, stream);
+            case 1: return launch_t<Utf16RangesT<0, 1, 2, 1, 1, 1>, false>(p, stream);
+            case 2: return launch_t<Utf16RangesT<1, 0, 2, 1, 1, 1>, false>(p, stream);
+            default: return launch_t<Utf16RangesT<1, 1, 2, 1, 1, 1>, false>(p, stream);
+        }
 #define SX_U16R(NL, NS, NH)                                                                                  \
         if (nl == NL && ns == NS && nh == NH) switch (bo) {                                                  \
             case 0: return launch_t<Utf16RangesT<0, 0, NL, NS, NH>, false>(p, stream);                       \

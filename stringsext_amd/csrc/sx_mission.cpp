@@ -162,7 +162,7 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
         // E0..EF <-> U+0800..U+FFFF; with an astral plane accepted a surrogate pair can be a character, which the range kernels do not
         // know.  Up to two ranges below U+8000, one that straddles it, one above (sx_classify_ranges.hpp Utf16RangesT)
         std::vector<std::pair<uint32_t, uint32_t>> uranges;
-        if (!force_generic && no_astral)
+        if (!force_generic)
             for (uint32_t u = 0; u < 0x10000u && uranges.size() <= 4; u++) {
                 const bool acc = u < 0x80 ? m->filter.pass_lead((uint8_t)u)
                                           : (u < 0xD800u || u > 0xDFFFu) && m->filter.pass_ubf_filter(utf8_lead_of(u));
@@ -172,14 +172,20 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
             }
         uint32_t n_lo = 0, n_st = 0, n_hi = 0;
         for (const auto& r : uranges) { if (r.second < 0x8000u) n_lo++; else if (r.first >= 0x8000u) n_hi++; else n_st++; }
-        const bool uranges_fit = !force_generic && no_astral && !uranges.empty() && n_lo <= 2 && n_st <= 1 && n_hi <= 1;
+        // an astral plane passes: the high surrogates of such planes (the pair's UTF-8 lead byte F0..F4 follows from the high surrogate alone) must be one range
+        uint32_t hs_lo = 0, hs_hi = 0, hs_runs = 0;
+        for (uint32_t u = 0xD800u; u <= 0xDBFFu && !no_astral; u++) {
+            if (!m->filter.pass_ubf_filter(utf8_lead_of(0x10000u + ((u & 0x3FFu) << 10)))) continue;
+            if (hs_runs && hs_hi + 1 == u) hs_hi = u; else { hs_runs++; hs_lo = hs_hi = u; }
+        }
+        const bool uranges_fit = !force_generic && (no_astral || hs_runs == 1) && (!uranges.empty() || hs_runs == 1) && n_lo <= 2 && n_st <= 1 && n_hi <= 1;
         if (!force_generic && af_is_range && ubf2_is_range && no_bmp3 && no_astral) {
             m->kind = kClsUtf16Range;
             if (!uempty) { p.u_lo = (uint32_t)ulo << 6; p.u_hi = ((uint32_t)uhi << 6) | 0x3F; }
             else { p.u_lo = 1; p.u_hi = 0; }
         } else if (uranges_fit) {
             m->kind = kClsUtf16Ranges;   // (sx_classify_ranges.hpp)
-            p.n_ranges = n_lo | (n_st << 4) | (n_hi << 8);
+            p.n_ranges = n_lo | (n_st << 4) | (n_hi << 8) | (hs_runs ? 1u << 12 : 0u);
             for (int k = 0; k < 6; k++) { p.rng_c1[k] = 0u; p.rng_c2[k] = 0x7FFFu * 0x00010001u; p.rng_hi[k] = 0u; }   // (empty slots)
             uint32_t il = 0, ih = 3;
             for (const auto& r : uranges) {
@@ -187,6 +193,7 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
                 p.rng_c1[slot] = (0x8000u - (r.first & 0x7FFFu)) * 0x00010001u;
                 p.rng_c2[slot] = (0x8000u + (r.second & 0x7FFFu)) * 0x00010001u;
             }
+            if (hs_runs) { p.rng_c1[5] = (0x8000u - (hs_lo & 0x7FFFu)) * 0x00010001u; p.rng_c2[5] = (0x8000u + (hs_hi & 0x7FFFu)) * 0x00010001u; }
         } else {
             m->kind = kClsUtf16Lut;
             uint8_t* H = p.lut;

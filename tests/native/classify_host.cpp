@@ -90,8 +90,9 @@ int sxh_classify_utf8_range3(uint32_t a_lo, uint32_t a_hi, uint32_t u_lo, uint32
     return 0;
 }
 // UTF-16: n unit ranges [lo[k], hi[k]] (ascending, no surrogate inside): at most two below U+8000, one across it, one above; general = 1: the
-// instantiation with every slot (the unused ones empty) instead of the one launch_scan picks
-int sxh_classify_utf16_ranges(const uint32_t* lo, const uint32_t* hi, int n, int general, int be, int odd,
+// instantiation with every slot (the unused ones empty) instead of the one launch_scan picks; [hs_lo, hs_hi]: the high surrogates of the
+// astral planes that pass (0, 0: none)
+int sxh_classify_utf16_ranges(const uint32_t* lo, const uint32_t* hi, int n, uint32_t hs_lo, uint32_t hs_hi, int general, int be, int odd,
                               const uint8_t* d, uint64_t len, int always_near_end, uint8_t* good, uint8_t* start) {
     ScanParams p;
     memset(&p, 0, sizeof p);
@@ -105,9 +106,14 @@ int sxh_classify_utf16_ranges(const uint32_t* lo, const uint32_t* hi, int n, int
         p.rng_c1[slot] = (0x8000u - (lo[k] & 0x7FFFu)) * 0x00010001u;
         p.rng_c2[slot] = (0x8000u + (hi[k] & 0x7FFFu)) * 0x00010001u;
     }
-    p.n_ranges = nl | (ns << 4) | (nh << 8);
-    if (general) { nl = 2; ns = 1; nh = 1; }
-    else nl = nl <= 1 && (ns | nh) ? 1u : 2u;   // (launch_scan)
+    p.n_ranges = nl | (ns << 4) | (nh << 8) | (hs_hi ? 1u << 12 : 0u);
+    if (hs_hi) { p.rng_c1[5] = (0x8000u - (hs_lo & 0x7FFFu)) * 0x00010001u; p.rng_c2[5] = (0x8000u + (hs_hi & 0x7FFFu)) * 0x00010001u; }
+    if (hs_hi || general) {   // surrogate pairs: the one instantiation with every slot
+#define SXH_AST(B, O) if (be == B && odd == O) { run<Utf16RangesT<B, O, 2, 1, 1, 1>>(p, d, len, always_near_end, good, start); return 0; }
+        SXH_AST(0, 0) SXH_AST(0, 1) SXH_AST(1, 0) SXH_AST(1, 1)
+#undef SXH_AST
+    }
+    nl = nl <= 1 && (ns | nh) ? 1u : 2u;   // (launch_scan)
 #define SXH_BO(NL, NS, NH, B, O) if (be == B && odd == O) { run<Utf16RangesT<B, O, NL, NS, NH>>(p, d, len, always_near_end, good, start); return 0; }
 #define SXH_CASE(NL, NS, NH) if (nl == NL && ns == NS && nh == NH) { SXH_BO(NL, NS, NH, 0, 0) SXH_BO(NL, NS, NH, 0, 1) SXH_BO(NL, NS, NH, 1, 0) SXH_BO(NL, NS, NH, 1, 1) }
     SXH_CASE(1, 1, 0) SXH_CASE(1, 0, 1) SXH_CASE(1, 1, 1) SXH_CASE(2, 0, 0) SXH_CASE(2, 1, 0) SXH_CASE(2, 0, 1) SXH_CASE(2, 1, 1)

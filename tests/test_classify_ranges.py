@@ -16,7 +16,7 @@ from test_host_logic import soup, synth
 LIB = ctypes.CDLL(build_classify())
 U8P = ctypes.POINTER(ctypes.c_uint8)
 LIB.sxh_classify_utf8_range3.argtypes = [ctypes.c_uint32] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, U8P, U8P]
-LIB.sxh_classify_utf16_ranges.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 2 + [ctypes.c_int] * 4 + [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, U8P, U8P]
+LIB.sxh_classify_utf16_ranges.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 2 + [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32] + [ctypes.c_int] * 3 + [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, U8P, U8P]
 
 
 def lead_of(cp):
@@ -95,12 +95,14 @@ def unit_ranges(m):
 def run_utf16(m, d, be, parity, near):
     r = unit_ranges(m)
     below, across, above = sum(x[1] < 0x8000 for x in r), sum(x[0] < 0x8000 <= x[1] for x in r), sum(x[0] >= 0x8000 for x in r)
-    assert r and below <= 2 and across <= 1 and above <= 1 and not m["ubf"] >> 48 & 0x1F, "not a Mission of this classifier"
+    hs = [u for u in range(0xD800, 0xDC00) if passes(m, lead_of(0x10000 + ((u & 0x3FF) << 10)))]   # the high surrogates of the planes that pass
+    assert (r or hs) and below <= 2 and across <= 1 and above <= 1 and len(hs) == (hs[-1] - hs[0] + 1 if hs else 0), "not a Mission of this classifier"
+    hs_lo, hs_hi = (hs[0], hs[-1]) if hs else (0, 0)
     lo, hi = (ctypes.c_uint32 * 6)(*[x[0] for x in r]), (ctypes.c_uint32 * 6)(*[x[1] for x in r])
     out = []
     for general in (0, 1):   # the instantiation launch_scan picks, and the one with every slot
         good, start = (ctypes.c_uint8 * max(1, len(d)))(), (ctypes.c_uint8 * max(1, len(d)))()
-        assert LIB.sxh_classify_utf16_ranges(lo, hi, len(r), general, be, parity, d, len(d), near, good, start) == 0
+        assert LIB.sxh_classify_utf16_ranges(lo, hi, len(r), hs_lo, hs_hi, general, be, parity, d, len(d), near, good, start) == 0
         out.append((bytes(good[:len(d)]), bytes(start[:len(d)])))
     return out
 
@@ -120,11 +122,15 @@ def datas(rng):
             s = "".join(rng.choice(TEXT) for _ in range(k))
             parts.append(enc(s))
             parts.append(rng.choice([b"", b"\x00", b"\xff\xfe", b"\xed\xa0\x80", b"\xed\x9f\xbf", b"\xe0\x80\x80", b"\xe0\xa0\x80", b"\xe4\xb8", b"\xe9",
-                                     b"\x00\xd8", b"\xd8\x00\xdc\x00", b"\x00\xd8\x00\xdc", b"\xdc\x00", b"A", b"ab c"]) * rng.randrange(0, 3))
+                                     b"\x00\xd8", b"\xd8\x00\xdc\x00", b"\x00\xd8\x00\xdc", b"\xdc\x00", b"A", b"ab c", "😀𝔘\U0010ffff\U00040000".encode("utf-16-le"),
+                                     "😀\U000fffff\U00100000𝔘".encode("utf-16-be"), b"\xd8\x3d\xd8\x3d\xde\x00", b"\x3d\xd8\x3d\xd8\x00\xde", b"\xdb\xff\xdc"]) * rng.randrange(0, 3))
         out.append(b"".join(parts))
     for n in (15, 16, 17, 18, 19, 31, 32, 33, 34, 35):   # the end of the input at every phase of the 16-byte grid
         out.append(("中文字符串한국어テスト" * 4).encode("utf-8")[:n])
         out.append(("中文字符串한국어テスト" * 4).encode("utf-16-le")[:n])
+        out.append(("😀𝔘😀中😀" * 4).encode("utf-16-le")[:n])
+        out.append(("😀𝔘😀中😀" * 4).encode("utf-16-be")[:n])
+        out.append(b"A" + ("😀𝔘😀中😀" * 4).encode("utf-16-be")[:n])
     return out
 
 
@@ -149,7 +155,9 @@ def test_utf8_range3_equals_the_rules_byte_by_byte(ubf):
 
 
 UTF16_FILTERS = ["Cjk", "Kana", "Hangul", "Asian", "Common", "0x0000ffff00000000", "0x00003ffcfffffffc", "0x0000800000000000", "0x0000100000000000",
-                 "0x0000200000000000", "0x000000ff00000000", "0x00003800fffffffc"]   # (... EF alone; EC; ED alone = U+D000..U+D7FF; E0..E7 = U+0800..U+7FFF; Common + Hangul)
+                 "0x0000200000000000", "0x000000ff00000000", "0x00003800fffffffc",
+                 "All", "Uncommon", "0x001f000000000000", "0x0010ffff00000000", "0x0001000000000004"]   # (... EF alone; EC; ED alone = U+D000..U+D7FF; E0..E7 = U+0800..U+7FFF; Common + Hangul; with astral planes:
+                 # all / F0..F3 / every plane and no BMP character above ASCII / F4 + E0..EF / F0 + C2)
 
 
 @pytest.mark.parametrize("ubf", UTF16_FILTERS)

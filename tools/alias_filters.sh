@@ -17,6 +17,7 @@ for p in sys.argv[1:]:
         print(p, "unreadable:", e)
 PY
 done
+case " $filters " in *" Cjk "*) ;; *) exit 0;; esac
 timeout 600 tools/kernel_stats.sh ${tag}_ubf_cjk --ubf Cjk --steps 3 --warmup 1 > /dev/null 2>&1 < /dev/null
 head -5 gpurun_out/${tag}_ubf_cjk_kernel_stats.csv | cut -c1-200
 A="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"
