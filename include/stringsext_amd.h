@@ -231,6 +231,14 @@ int sx_wave_swar(const sx_mission* mission, uint32_t* out26);
  * EUC-JP (family 5): the first 1105 words, 2 bits per cell of index jis0208 (cells 0 .. 8835: (lead - A1) * 94 + trail - A1) and of index jis0212 (from cell 8836). */
 const uint32_t* sx_wave_pair_codes2(const sx_mission* mission, uint32_t* out4096);
 
+/* Lower level: which classifier stage A runs for this Mission (csrc/sx_device.hpp ClassifierKind: 0-2 the table kernels, 3 / 4 the
+ * two-byte range kernels of the default filters, 5 / 8 single-byte ranges, 6 / 7 the double-byte token classifiers, 9 / 10 the range
+ * kernels for filters with three-byte leads / surrogate pairs, csrc/sx_classify_ranges.hpp) and its range parameters: out20 =
+ * a_lo, a_hi, u_lo, u_hi, l3_lo, l3_hi, n_ranges, rng_c1[6], rng_c2[6], 0.  generic != 0: as with SX_OPT_GENERIC_KERNELS.
+ * Returns the kind (>= 0) or an error (< 0).  (Test harness: a filter that silently fell back to a table kernel would be a
+ * performance regression no parity test sees.) */
+int sx_scan_classifier(const sx_mission* mission, int generic, uint32_t* out20);
+
 int  sx_abi_version(void);
 
 /* hip_device >= 0: bind to that device.  hip_device == SX_HOST_ONLY: a context

@@ -190,6 +190,21 @@ int sx_wave_swar(const sx_mission* mission, uint32_t* out26) {
     return m.wave_ok && m.wave_swar.cls ? 1 : 0;
 }
 
+int sx_scan_classifier(const sx_mission* mission, int generic, uint32_t* out20) {
+    if (!mission || !out20) return SX_E_INVALID;
+    Mission m;
+    std::string err;
+    const int rc = Mission::from_c(*mission, generic != 0, &m, &err);
+    if (rc != SX_OK) return rc;
+    const ScanParams& p = m.proto;
+    const uint32_t head[7] = { p.a_lo, p.a_hi, p.u_lo, p.u_hi, p.l3_lo, p.l3_hi, p.n_ranges };
+    memcpy(out20, head, sizeof head);
+    memcpy(out20 + 7, p.rng_c1, 6 * sizeof(uint32_t));
+    memcpy(out20 + 13, p.rng_c2, 6 * sizeof(uint32_t));
+    out20[19] = 0;
+    return (int)m.kind;
+}
+
 int sx_wave_classes(const sx_mission* mission, uint8_t* classes) {
     if (!mission || !classes) return SX_E_INVALID;
     Mission m;

@@ -121,4 +121,39 @@ int sxh_classify_utf16_ranges(const uint32_t* lo, const uint32_t* hi, int n, uin
 #undef SXH_BO
     return -1;
 }
+
+// The product's own choice: kind and parameters as sx_scan_classifier hands them out (out20), dispatched as launch_scan does (sx_kernels.hip).
+// Returns -3 for a kind that is not one of this header's classifiers.
+int sxh_classify_product(int kind, const uint32_t* p20, int be, int odd, const uint8_t* d, uint64_t len, int always_near_end, uint8_t* good, uint8_t* start) {
+    ScanParams p;
+    memset(&p, 0, sizeof p);
+    p.a_lo = p20[0]; p.a_hi = p20[1]; p.u_lo = p20[2]; p.u_hi = p20[3]; p.l3_lo = p20[4]; p.l3_hi = p20[5]; p.n_ranges = p20[6];
+    for (int k = 0; k < 6; k++) { p.rng_c1[k] = p20[7 + k]; p.rng_c2[k] = p20[13 + k]; }
+    p.big_endian = (uint32_t)be; p.parity = (uint32_t)odd;
+    if (kind == (int)kClsUtf8Range3) {
+        const int ed = p.l3_hi < 0xEDu || p.l3_lo > 0xEDu ? 0 : p.l3_hi == 0xEDu ? 1 : 2;
+        switch ((p.u_lo <= p.u_hi ? 3 : 0) + ed) {
+        case 0: run<Utf8Range3T<false, 0>>(p, d, len, always_near_end, good, start); break;
+        case 1: run<Utf8Range3T<false, 1>>(p, d, len, always_near_end, good, start); break;
+        case 2: run<Utf8Range3T<false, 2>>(p, d, len, always_near_end, good, start); break;
+        case 3: run<Utf8Range3T<true, 0>>(p, d, len, always_near_end, good, start); break;
+        case 4: run<Utf8Range3T<true, 1>>(p, d, len, always_near_end, good, start); break;
+        default: run<Utf8Range3T<true, 2>>(p, d, len, always_near_end, good, start); break;
+        }
+        return 0;
+    }
+    if (kind != (int)kClsUtf16Ranges) return -3;
+    const uint32_t ns = (p.n_ranges >> 4) & 1u, nh = (p.n_ranges >> 8) & 1u, nl = (p.n_ranges & 15u) <= 1u && (ns | nh) ? 1u : 2u;
+    if (p.n_ranges >> 12) {
+#define SXH_AST(B, O) if (be == B && odd == O) { run<Utf16RangesT<B, O, 2, 1, 1, 1>>(p, d, len, always_near_end, good, start); return 0; }
+        SXH_AST(0, 0) SXH_AST(0, 1) SXH_AST(1, 0) SXH_AST(1, 1)
+#undef SXH_AST
+    }
+#define SXH_BO(NL, NS, NH, B, O) if (be == B && odd == O) { run<Utf16RangesT<B, O, NL, NS, NH>>(p, d, len, always_near_end, good, start); return 0; }
+#define SXH_CASE(NL, NS, NH) if (nl == NL && ns == NS && nh == NH) { SXH_BO(NL, NS, NH, 0, 0) SXH_BO(NL, NS, NH, 0, 1) SXH_BO(NL, NS, NH, 1, 0) SXH_BO(NL, NS, NH, 1, 1) }
+    SXH_CASE(1, 1, 0) SXH_CASE(1, 0, 1) SXH_CASE(1, 1, 1) SXH_CASE(2, 0, 0) SXH_CASE(2, 1, 0) SXH_CASE(2, 0, 1) SXH_CASE(2, 1, 1)
+#undef SXH_CASE
+#undef SXH_BO
+    return -1;
+}
 }

@@ -10,6 +10,7 @@ import zlib
 import pytest
 
 import refconfig as rc
+import stringsext_amd as sx
 from native.build_harness import build_classify
 from test_host_logic import soup, synth
 
@@ -17,6 +18,20 @@ LIB = ctypes.CDLL(build_classify())
 U8P = ctypes.POINTER(ctypes.c_uint8)
 LIB.sxh_classify_utf8_range3.argtypes = [ctypes.c_uint32] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, U8P, U8P]
 LIB.sxh_classify_utf16_ranges.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 2 + [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32] + [ctypes.c_int] * 3 + [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, U8P, U8P]
+
+
+LIB.sxh_classify_product.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, U8P, U8P]
+K_UTF8_LUT, K_UTF16_LUT, K_UTF8_RANGE2, K_UTF16_RANGE, K_UTF8_RANGE3, K_UTF16_RANGES = 1, 2, 3, 4, 9, 10   # csrc/sx_device.hpp ClassifierKind
+
+
+def product_classifier(m, generic=False):
+    """(kind, parameters) stage A runs for the Mission: the product's own choice (sx_scan_classifier)"""
+    L = sx.lib()
+    L.sx_scan_classifier.argtypes, L.sx_scan_classifier.restype = [ctypes.POINTER(sx.Mission), ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)], ctypes.c_int
+    out = (ctypes.c_uint32 * 20)()
+    kind = L.sx_scan_classifier(ctypes.byref(sx.Mission.from_dict(dict(m, mission_id=m.get("mission_id", 0)))), int(generic), out)
+    assert kind >= 0
+    return kind, out
 
 
 def lead_of(cp):
@@ -172,3 +187,35 @@ def test_utf16_ranges_equal_the_rules_unit_by_unit(ubf):
                     for near in (0, 1):
                         for got in run_utf16(m, d, be, parity, near):
                             assert got == want, (ubf, af, len(d), be, parity, near)
+
+
+# alias -> the kernel family stage A must pick (a silent fall-back to a table kernel is a 2x slowdown no parity test sees)
+EXPECTED_KINDS = [
+    ("utf-8", None, K_UTF8_RANGE2), ("utf-8", "African", K_UTF8_RANGE2), ("utf-8", "Common", K_UTF8_RANGE2), ("utf-8", "Cyrillic", K_UTF8_RANGE2),
+    ("utf-8", "Cjk", K_UTF8_RANGE3), ("utf-8", "Kana", K_UTF8_RANGE3), ("utf-8", "Hangul", K_UTF8_RANGE3), ("utf-8", "Asian", K_UTF8_RANGE3),
+    ("utf-8", "0x00003ffcfffffffc", K_UTF8_RANGE3), ("utf-8", "All", K_UTF8_LUT), ("utf-8", "Uncommon", K_UTF8_LUT), ("utf-8", "Private", K_UTF8_LUT), ("utf-8", "0x0000800600000000", K_UTF8_LUT),   # (Misc: E1, E2, EF)
+    ("utf-8", "0x0000ffff00000000", K_UTF8_LUT),
+    ("utf-16le", None, K_UTF16_RANGE), ("utf-16be", "African", K_UTF16_RANGE), ("utf-16le", "Cjk", K_UTF16_RANGES), ("utf-16be", "Kana", K_UTF16_RANGES),
+    ("utf-16le", "Hangul", K_UTF16_RANGES), ("utf-16be", "Asian", K_UTF16_RANGES), ("utf-16le", "0x0000800600000000", K_UTF16_RANGES), ("utf-16be", "Private", K_UTF16_RANGES), ("utf-16le", "All", K_UTF16_RANGES),
+    ("utf-16be", "Uncommon", K_UTF16_RANGES), ("utf-16le", "0x0000ffff00000000", K_UTF16_RANGES), ("utf-16le", "0x0005000000000000", K_UTF16_LUT),   # (F0 and F2: two ranges of high surrogates)
+]
+
+
+@pytest.mark.parametrize("enc,ubf,kind", EXPECTED_KINDS)
+def test_the_product_picks_the_range_kernels_and_their_parameters_classify_right(enc, ubf, kind):
+    """Mission -> ClassifierKind + parameters through the C-ABI (sx_scan_classifier), then THOSE parameters through the host-compiled
+    classifier, against the rules byte by byte; with generic kernels forced every Mission takes a table kernel."""
+    m = rc.missions(encodings=[enc], **({"unicode_block_filter": ubf} if ubf else {}))[0]
+    got_kind, params = product_classifier(m)
+    assert got_kind == kind, (enc, ubf, got_kind)
+    assert product_classifier(m, generic=True)[0] == (K_UTF8_LUT if enc == "utf-8" else K_UTF16_LUT)
+    if kind not in (K_UTF8_RANGE3, K_UTF16_RANGES):
+        return
+    rng = random.Random(zlib.crc32(f"{enc}{ubf}".encode()))
+    be = int(enc == "utf-16be")
+    for d in datas(rng):
+        for parity in ((0,) if enc == "utf-8" else (0, 1)):
+            want = naive_utf8(m, d) if enc == "utf-8" else naive_utf16(m, d, be, parity)
+            good, start = (ctypes.c_uint8 * max(1, len(d)))(), (ctypes.c_uint8 * max(1, len(d)))()
+            assert LIB.sxh_classify_product(got_kind, params, be, parity, d, len(d), 0, good, start) == 0
+            assert (bytes(good[:len(d)]), bytes(start[:len(d)])) == want, (enc, ubf, len(d), parity)
