@@ -196,7 +196,7 @@ EXPECTED_KINDS = [
     ("utf-8", "0x00003ffcfffffffc", K_UTF8_RANGE3), ("utf-8", "All", K_UTF8_LUT), ("utf-8", "Uncommon", K_UTF8_LUT), ("utf-8", "Private", K_UTF8_LUT), ("utf-8", "0x0000800600000000", K_UTF8_LUT),   # (Misc: E1, E2, EF)
     ("utf-8", "0x0000ffff00000000", K_UTF8_LUT),
     ("utf-16le", None, K_UTF16_RANGE), ("utf-16be", "African", K_UTF16_RANGE), ("utf-16le", "Cjk", K_UTF16_RANGES), ("utf-16be", "Kana", K_UTF16_RANGES),
-    ("utf-16le", "Hangul", K_UTF16_RANGES), ("utf-16be", "Asian", K_UTF16_RANGES), ("utf-16le", "0x0000800600000000", K_UTF16_RANGES), ("utf-16be", "Private", K_UTF16_RANGES), ("utf-16le", "All", K_UTF16_RANGES),
+    ("utf-16le", "Hangul", K_UTF16_RANGES), ("utf-16be", "Asian", K_UTF16_RANGES), ("utf-16le", "0x0000800600000000", K_UTF16_RANGES), ("utf-16be", "Private", K_UTF16_RANGES), ("utf-16le", "All", K_UTF16_RANGES), ("utf-16be", "All-Asian", K_UTF16_RANGES), ("utf-8", "All-Asian", K_UTF8_LUT),
     ("utf-16be", "Uncommon", K_UTF16_RANGES), ("utf-16le", "0x0000ffff00000000", K_UTF16_RANGES), ("utf-16le", "0x0005000000000000", K_UTF16_LUT),   # (F0 and F2: two ranges of high surrogates)
 ]
 
