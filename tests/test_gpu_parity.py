@@ -131,7 +131,8 @@ def test_tile_traversal_kernels_equal_oracle_runs(monkeypatch):
     """The experimental tile-independent grid-stride kernels (SX_TRAVERSAL=1) report the same runs."""
     monkeypatch.setenv("SX_TRAVERSAL", "1")
     rng = random.Random(11)
-    for name in ("ascii", "utf8_common", "utf8_all", "utf16le_all", "utf16be_uncommon", "koi8r"):
+    for name in ("ascii", "utf8_common", "utf8_all", "utf16le_all", "utf16be_uncommon", "koi8r", "utf8_cjk", "utf8_hangul", "utf8_common_asian", "utf16le_cjk",
+                 "utf16be_bmp3", "utf16le_hangul"):
         m = rc.missions(**RUN_MISSIONS[name])[0]
         for data in (synth(rng, 300_000, 1 / 300), soup(rng, 50_001), b"A" * 70000 + rng.randbytes(977) + b"B" * 3000,
                      synth(rng, 975, 1 / 40), synth(rng, 977, 1 / 40), synth(rng, 2000, 1 / 40)):
