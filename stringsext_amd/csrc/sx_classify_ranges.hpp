@@ -69,6 +69,45 @@ struct Utf8Range3T {
     }
 };
 
+// --- UTF-8: af = one range, TWO ranges of 2-byte leads (C2..DF), nothing longer: `-u Latin` (mission.rs:63-67: C2..C8 and CC..CD) ---------
+// Utf8Range2 of sx_kernels.hip with one more compare for the lead byte (the second range travels in ScanParams::l3_lo / l3_hi).
+struct Utf8Range2x2 {
+    u32 a1, a2, l1, l2, m1, m2;
+    SX_DEV void init(const ScanParams& p, const uint8_t*) {
+        a1 = rep4(0x80u - p.a_lo);
+        a2 = rep4(0x7Fu - p.a_hi);
+        l1 = rep4(0x80u - (p.u_lo & 0x7F));
+        l2 = rep4(0x7Fu - (p.u_hi & 0x7F));
+        m1 = rep4(0x80u - (p.l3_lo & 0x7F));
+        m2 = rep4(0x7Fu - (p.l3_hi & 0x7F));
+    }
+    template <bool WANT_S>
+    SX_DEV u32 classify(u32x4 x, u32 nx, u32 avail, bool near_end) const {
+        u32 xs[5] = { x.x, x.y, x.z, x.w, nx };
+        if (near_end) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) xs[k] = fill_ff(xs[k], (int)avail - 4 * k);
+        }
+        u32 c[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) c[k] = xs[k] & ~(xs[k] << 1);   // (bit 7 of every byte; cleaned in front of the v_dot4s)
+        u32 a[4], p[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 v = xs[k], t = v & 0x7F7F7F7Fu;
+            a[k] = ((t + a1) & ~(t + a2)) & ~v;
+            const u32 l = (((t + l1) & ~(t + l2)) | ((t + m1) & ~(t + m2))) & v;
+            p[k] = l & __builtin_amdgcn_alignbyte(c[k + 1], c[k], 1);
+        }
+        if (WANT_S) return movemask16((a[0] | p[0]) & kM, (a[1] | p[1]) & kM, (a[2] | p[2]) & kM, (a[3] | p[3]) & kM);
+        const u32 g0 = (a[0] | p[0] | (p[0] << 8)) & kM;
+        const u32 g1 = (a[1] | p[1] | __builtin_amdgcn_alignbyte(p[1], p[0], 3)) & kM;
+        const u32 g2 = (a[2] | p[2] | __builtin_amdgcn_alignbyte(p[2], p[1], 3)) & kM;
+        const u32 g3 = (a[3] | p[3] | __builtin_amdgcn_alignbyte(p[3], p[2], 3)) & kM;
+        return movemask16(g0, g1, g2, g3) | ((p[3] >> 31) << 16);
+    }
+};
+
 // --- UTF-16LE/BE: the accepted units = NL ranges below U+8000, NS (0 / 1) ranges that straddle U+8000, NH ranges above it; no surrogate
 // inside, no astral plane accepted (every surrogate is then a break, as in Utf16RangeT).  The ranges come from af (units below U+0080)
 // and from ubf through the lead byte of the unit's UTF-8 form: C2..DF <-> U+0080..U+07FF in steps of 0x40, E0..EF <-> U+0800..U+FFFF
@@ -77,7 +116,8 @@ struct Utf8Range3T {
 // Per range and pair of units, on the low 15 bits t of each unit: A = t + (0x8000 - lo15) has bit 15 set iff t >= lo15, B = (0x8000 +
 // hi15) - t iff t <= hi15 (no carry or borrow leaves a 16-bit lane).  Below U+8000: A & B & ~unit; above: A & B & unit; a straddling
 // range is "t >= lo15 where bit 15 is clear, t <= hi15 where it is set" = one v_bfi_b32 — three operations instead of the eight of two
-// split ranges.  Slots in ScanParams::rng_c1 / rng_c2: 0, 1 the ranges below, 2 the straddling one, 3, 4 the ranges above.
+// split ranges.  Slots in ScanParams::rng_c1 / rng_c2: 0, 1 the ranges below, 2 the straddling one, 3, 4 the ranges above; a third range below
+// (`-u Latin`: af, U+0080..U+023F, U+0300..U+037F) takes slot 5, which is the high surrogates' otherwise (NL = 3 only without AST).
 // AST: an astral plane passes the filter — a high surrogate whose plane does (one range of D800..DBFF, slot 5: the lead byte of the pair's
 // UTF-8 form, F0..F4, follows from the high surrogate alone) followed by a low surrogate is a character of four bytes; every other
 // surrogate stays a break (utf_16.rs: a lone or reversed surrogate is an error, the unit behind a lone high surrogate is read again).
@@ -92,7 +132,7 @@ struct Utf16RangesT {
     SX_DEV u32 bmp_flags(u32 v, u32 t) const {  // two units per dword -> flags at bits 15 and 31 (and garbage below them)
         u32 lo = 0, hi = 0, f = 0;
 #pragma unroll
-        for (int k = 0; k < NL; k++) lo |= (t + c1[k]) & (c2[k] - t);
+        for (int k = 0; k < NL; k++) lo |= (t + c1[k < 2 ? k : 5]) & (c2[k < 2 ? k : 5] - t);
 #pragma unroll
         for (int k = 0; k < NH; k++) hi |= (t + c1[3 + k]) & (c2[3 + k] - t);
         if (NS) f = (v & (c2[2] - t)) | (~v & (t + c1[2]));   // v_bfi_b32

@@ -42,6 +42,7 @@ enum ClassifierKind : uint32_t {
     kClsEucJp = 7,          // EUC-JP: the same with three-byte tokens and two pair tables (32 KB)
     kClsSingleByteRanges = 8,// single byte, accept set = up to 6 byte ranges: SWAR, no LUT
     kClsUtf8Range3 = 9,     // UTF-8, af = one range, 2-byte leads = one range, 3-byte leads = one range of E1..EF, no 4-byte leads (sx_classify_ranges.hpp)
+    kClsUtf8Range2x2 = 11,  // UTF-8, af = one range, two ranges of 2-byte leads (-u Latin), nothing longer (sx_classify_ranges.hpp; second range in l3_lo / l3_hi)
     kClsUtf16Ranges = 10    // UTF-16, accepted units = up to 2 ranges below U+8000, 1 across it, 1 above; astral: one range of high surrogates (sx_classify_ranges.hpp)
 };
 
@@ -69,7 +70,7 @@ struct ScanParams {
     uint32_t high_all;     // single-byte range: every byte >= 0x80 accepted
     uint32_t n_ranges;     // kClsSingleByteRanges: ranges in use (the others are empty); per range, replicated over the four bytes:
     uint32_t rng_c1[6], rng_c2[6], rng_hi[6];  // 0x80 - lo7, 0x7F - hi7, and 0 for a range of bytes >= 0x80 / ~0 for one below
-                           // kClsUtf16Ranges: n_ranges = below | across << 4 | above << 8 | astral << 12; slots 0, 1 / 2 / 3, 4 / 5 (high surrogates); per unit, replicated over the
+                           // kClsUtf16Ranges: n_ranges = below | across << 4 | above << 8 | astral << 12; slots 0, 1 / 2 / 3, 4 / 5 (high surrogates, or a third range below); per unit, replicated over the
                            // two units: rng_c1 = 0x8000 - lo15, rng_c2 = 0x8000 + hi15 (an empty slot: 0, 0x7FFF)
     uint32_t wave_prio;    // 1: the scan wavefronts raise their issue priority (s_setprio)
     uint32_t lr_c1[2], lr_c2[2];  // Big5 / Shift_JIS / EUC-KR: the lead byte ranges (low 7 bits; 0x80 - lo, 0x7F - hi, replicated)

@@ -1392,7 +1392,14 @@ hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t str
         case kClsSingleByteRange: return launch_v2<SingleByteRange, false>(p, stream);
         case kClsSingleByteRanges: return launch_v2<SingleByteRanges<6>, false>(p, stream);
         case kClsUtf8Range3: return launch_v2<Utf8Range3T<true, 2>, false>(p, stream);   // (the most general instantiation)
+        case kClsUtf8Range2x2: return launch_v2<Utf8Range2x2, false>(p, stream);
         case kClsUtf16Ranges:   // (the most general instantiation; unused slots are empty)
+            if ((p.n_ranges & 15u) == 3u) switch ((p.big_endian ? 2 : 0) | (p.parity & 1)) {   // (three ranges below U+8000 and nothing else)
+            case 0: return launch_v2<Utf16RangesT<0, 0, 3, 0, 0>, false>(p, stream);
+            case 1: return launch_v2<Utf16RangesT<0, 1, 3, 0, 0>, false>(p, stream);
+            case 2: return launch_v2<Utf16RangesT<1, 0, 3, 0, 0>, false>(p, stream);
+            default: return launch_v2<Utf16RangesT<1, 1, 3, 0, 0>, false>(p, stream);
+            }
             switch ((p.big_endian ? 2 : 0) | (p.parity & 1)) {
             case 0: return launch_v2<Utf16RangesT<0, 0, 2, 1, 1, 1>, false>(p, stream);
             case 1: return launch_v2<Utf16RangesT<0, 1, 2, 1, 1, 1>, false>(p, stream);
@@ -1427,9 +1434,10 @@ hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t str
         default: return launch_t<Utf8Range3T<true, 2>, false>(p, stream);
         }
     }
+    case kClsUtf8Range2x2: return launch_t<Utf8Range2x2, false>(p, stream);
     case kClsUtf16Ranges: {
         // ranges below U+8000 (1: af alone, 2: + a range of two-byte leads or of leads up to E7) / across it / above it
-        const u32 ns = (p.n_ranges >> 4) & 1u, nh = (p.n_ranges >> 8) & 1u, nl = (p.n_ranges & 15u) <= 1u && (ns | nh) ? 1u : 2u;   // (an unused slot is empty)
+        const u32 ns = (p.n_ranges >> 4) & 1u, nh = (p.n_ranges >> 8) & 1u, nl = (p.n_ranges & 15u) == 3u ? 3u : (p.n_ranges & 15u) <= 1u && (ns | nh) ? 1u : 2u;   // (an unused slot is empty)
         const u32 bo = (p.big_endian ? 2u : 0u) | (p.parity & 1u);
         if (p.n_ranges >> 12) switch (bo) {   // an astral plane passes: surrogate pairs (one instantiation; unused slots are empty)
             case 0: return launch_t<Utf16RangesT<0, 0, 2, 1, 1, 1>, false>(p, stream);
@@ -1444,7 +1452,7 @@ hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t str
             case 2: return launch_t<Utf16RangesT<1, 0, NL, NS, NH>, false>(p, stream);                       \
             default: return launch_t<Utf16RangesT<1, 1, NL, NS, NH>, false>(p, stream);                      \
         }
-        SX_U16R(1, 1, 0) SX_U16R(1, 0, 1) SX_U16R(1, 1, 1) SX_U16R(2, 0, 0) SX_U16R(2, 1, 0) SX_U16R(2, 0, 1) SX_U16R(2, 1, 1)
+        SX_U16R(3, 0, 0) SX_U16R(1, 1, 0) SX_U16R(1, 0, 1) SX_U16R(1, 1, 1) SX_U16R(2, 0, 0) SX_U16R(2, 1, 0) SX_U16R(2, 0, 1) SX_U16R(2, 1, 1)
 #undef SX_U16R
         break;
     }

@@ -110,6 +110,17 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
         if (!force_generic && af_is_range && ubf2_is_range && no_long_leads) {
             m->kind = kClsUtf8Range2;
             if (!uempty) { p.u_lo = 0xC0u + (uint32_t)ulo; p.u_hi = 0xC0u + (uint32_t)uhi; }
+        } else if (!force_generic && af_is_range && no_long_leads && [&] {   // two runs of two-byte leads: -u Latin = C2..C8 + CC..CD (mission.rs:63-67)
+                       int runs = 0;
+                       for (int i = 2; i < 32; i++) if (lead2[i] && !lead2[i - 1]) runs++;
+                       return runs == 2;
+                   }()) {
+            m->kind = kClsUtf8Range2x2;   // (sx_classify_ranges.hpp)
+            int i = 2;
+            while (!lead2[i]) i++;
+            p.u_lo = 0xC0u + (uint32_t)i; while (i < 32 && lead2[i]) i++; p.u_hi = 0xC0u + (uint32_t)i - 1;
+            while (!lead2[i]) i++;
+            p.l3_lo = 0xC0u + (uint32_t)i; while (i < 32 && lead2[i]) i++; p.l3_hi = 0xC0u + (uint32_t)i - 1;
         } else if (!force_generic && af_is_range && ubf2_is_range && ubf3_is_range && !l3empty && l3lo >= 1 && no_lead4) {
             m->kind = kClsUtf8Range3;   // (sx_classify_ranges.hpp)
             if (!uempty) { p.u_lo = 0xC0u + (uint32_t)ulo; p.u_hi = 0xC0u + (uint32_t)uhi; }
@@ -178,7 +189,8 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
             if (!m->filter.pass_ubf_filter(utf8_lead_of(0x10000u + ((u & 0x3FFu) << 10)))) continue;
             if (hs_runs && hs_hi + 1 == u) hs_hi = u; else { hs_runs++; hs_lo = hs_hi = u; }
         }
-        const bool uranges_fit = !force_generic && (no_astral || hs_runs == 1) && (!uranges.empty() || hs_runs == 1) && n_lo <= 2 && n_st <= 1 && n_hi <= 1;
+        const bool uranges_fit = !force_generic && (no_astral || hs_runs == 1) && (!uranges.empty() || hs_runs == 1) && n_st <= 1 && n_hi <= 1 &&
+                                 (n_lo <= 2 || (n_lo == 3 && n_st + n_hi == 0 && no_astral));   // (a third range below U+8000 takes the high surrogates' slot)
         if (!force_generic && af_is_range && ubf2_is_range && no_bmp3 && no_astral) {
             m->kind = kClsUtf16Range;
             if (!uempty) { p.u_lo = (uint32_t)ulo << 6; p.u_hi = ((uint32_t)uhi << 6) | 0x3F; }
@@ -189,7 +201,7 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
             for (int k = 0; k < 6; k++) { p.rng_c1[k] = 0u; p.rng_c2[k] = 0x7FFFu * 0x00010001u; p.rng_hi[k] = 0u; }   // (empty slots)
             uint32_t il = 0, ih = 3;
             for (const auto& r : uranges) {
-                const uint32_t slot = r.second < 0x8000u ? il++ : r.first >= 0x8000u ? ih++ : 2u;
+                const uint32_t slot = r.second < 0x8000u ? (il < 2 ? il++ : (il++, 5u)) : r.first >= 0x8000u ? ih++ : 2u;
                 p.rng_c1[slot] = (0x8000u - (r.first & 0x7FFFu)) * 0x00010001u;
                 p.rng_c2[slot] = (0x8000u + (r.second & 0x7FFFu)) * 0x00010001u;
             }

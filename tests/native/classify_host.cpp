@@ -142,8 +142,9 @@ int sxh_classify_product(int kind, const uint32_t* p20, int be, int odd, const u
         }
         return 0;
     }
+    if (kind == (int)kClsUtf8Range2x2) { run<Utf8Range2x2>(p, d, len, always_near_end, good, start); return 0; }
     if (kind != (int)kClsUtf16Ranges) return -3;
-    const uint32_t ns = (p.n_ranges >> 4) & 1u, nh = (p.n_ranges >> 8) & 1u, nl = (p.n_ranges & 15u) <= 1u && (ns | nh) ? 1u : 2u;
+    const uint32_t ns = (p.n_ranges >> 4) & 1u, nh = (p.n_ranges >> 8) & 1u, nl = (p.n_ranges & 15u) == 3u ? 3u : (p.n_ranges & 15u) <= 1u && (ns | nh) ? 1u : 2u;
     if (p.n_ranges >> 12) {
 #define SXH_AST(B, O) if (be == B && odd == O) { run<Utf16RangesT<B, O, 2, 1, 1, 1>>(p, d, len, always_near_end, good, start); return 0; }
         SXH_AST(0, 0) SXH_AST(0, 1) SXH_AST(1, 0) SXH_AST(1, 1)
@@ -151,7 +152,7 @@ int sxh_classify_product(int kind, const uint32_t* p20, int be, int odd, const u
     }
 #define SXH_BO(NL, NS, NH, B, O) if (be == B && odd == O) { run<Utf16RangesT<B, O, NL, NS, NH>>(p, d, len, always_near_end, good, start); return 0; }
 #define SXH_CASE(NL, NS, NH) if (nl == NL && ns == NS && nh == NH) { SXH_BO(NL, NS, NH, 0, 0) SXH_BO(NL, NS, NH, 0, 1) SXH_BO(NL, NS, NH, 1, 0) SXH_BO(NL, NS, NH, 1, 1) }
-    SXH_CASE(1, 1, 0) SXH_CASE(1, 0, 1) SXH_CASE(1, 1, 1) SXH_CASE(2, 0, 0) SXH_CASE(2, 1, 0) SXH_CASE(2, 0, 1) SXH_CASE(2, 1, 1)
+    SXH_CASE(3, 0, 0) SXH_CASE(1, 1, 0) SXH_CASE(1, 0, 1) SXH_CASE(1, 1, 1) SXH_CASE(2, 0, 0) SXH_CASE(2, 1, 0) SXH_CASE(2, 0, 1) SXH_CASE(2, 1, 1)
 #undef SXH_CASE
 #undef SXH_BO
     return -1;

@@ -21,7 +21,7 @@ LIB.sxh_classify_utf16_ranges.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 2 +
 
 
 LIB.sxh_classify_product.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, U8P, U8P]
-K_UTF8_LUT, K_UTF16_LUT, K_UTF8_RANGE2, K_UTF16_RANGE, K_UTF8_RANGE3, K_UTF16_RANGES = 1, 2, 3, 4, 9, 10   # csrc/sx_device.hpp ClassifierKind
+K_UTF8_LUT, K_UTF16_LUT, K_UTF8_RANGE2, K_UTF16_RANGE, K_UTF8_RANGE3, K_UTF16_RANGES, K_UTF8_RANGE2X2 = 1, 2, 3, 4, 9, 10, 11   # csrc/sx_device.hpp ClassifierKind
 
 
 def product_classifier(m, generic=False):
@@ -122,7 +122,7 @@ def run_utf16(m, d, be, parity, near):
     return out
 
 
-TEXT = "中文字符串テスト한국어 텍스트ひらがなカタカナ Ελληνικά кириллица ﬁ￿퟿ꀀ ₠€ ༀ က ｶﾀｶﾅ"   # (incl. U+FFFF, U+D7FF, U+E000, U+A000)
+TEXT = "中文字符串テスト한국어 텍스트ひらがなカタカナ Ελληνικά кириллица àéîõüÿĀžƀɏ̀ͯ̈Ͱ ﬁ￿퟿ꀀ ₠€ ༀ က ｶﾀｶﾅ"   # (incl. U+FFFF, U+D7FF, U+E000, U+A000)
 NASTY8 = [0xE0, 0xA0, 0x9F, 0x80, 0xBF, 0xED, 0xEC, 0xEE, 0xEF, 0xE1, 0xE3, 0xE4, 0xE9, 0xEA, 0xEB, 0xF0, 0xF4, 0x90, 0x8F, 0xC2, 0xDF, 0xC1, 0x41, 0x20, 0x7F, 0x00]
 
 
@@ -192,6 +192,7 @@ def test_utf16_ranges_equal_the_rules_unit_by_unit(ubf):
 # alias -> the kernel family stage A must pick (a silent fall-back to a table kernel is a 2x slowdown no parity test sees)
 EXPECTED_KINDS = [
     ("utf-8", None, K_UTF8_RANGE2), ("utf-8", "African", K_UTF8_RANGE2), ("utf-8", "Common", K_UTF8_RANGE2), ("utf-8", "Cyrillic", K_UTF8_RANGE2),
+    ("utf-8", "Latin", K_UTF8_RANGE2X2), ("utf-16le", "Latin", K_UTF16_RANGES), ("utf-16be", "Latin", K_UTF16_RANGES), ("utf-8", "0x00000000c00000f0", K_UTF8_RANGE2X2),
     ("utf-8", "Cjk", K_UTF8_RANGE3), ("utf-8", "Kana", K_UTF8_RANGE3), ("utf-8", "Hangul", K_UTF8_RANGE3), ("utf-8", "Asian", K_UTF8_RANGE3),
     ("utf-8", "0x00003ffcfffffffc", K_UTF8_RANGE3), ("utf-8", "All", K_UTF8_LUT), ("utf-8", "Uncommon", K_UTF8_LUT), ("utf-8", "Private", K_UTF8_LUT), ("utf-8", "0x0000800600000000", K_UTF8_LUT),   # (Misc: E1, E2, EF)
     ("utf-8", "0x0000ffff00000000", K_UTF8_LUT),
@@ -209,7 +210,7 @@ def test_the_product_picks_the_range_kernels_and_their_parameters_classify_right
     got_kind, params = product_classifier(m)
     assert got_kind == kind, (enc, ubf, got_kind)
     assert product_classifier(m, generic=True)[0] == (K_UTF8_LUT if enc == "utf-8" else K_UTF16_LUT)
-    if kind not in (K_UTF8_RANGE3, K_UTF16_RANGES):
+    if kind not in (K_UTF8_RANGE3, K_UTF16_RANGES, K_UTF8_RANGE2X2):
         return
     rng = random.Random(zlib.crc32(f"{enc}{ubf}".encode()))
     be = int(enc == "utf-16be")

@@ -31,7 +31,7 @@ def device_runs(mdict, data, parity=0, min_chars=None, generic=False, subchunk=0
 
 def cjk_soup(rng, n):
     """CJK / Hangul / kana text in the three encodings between the byte sequences the decoders narrow (E0 80.., ED A0.., lone surrogates)."""
-    text = "中文字符串テスト한국어 텍스트ひらがなカタカナ Ελληνικά ﬁ\uffff\ud7ff\ue000\ua000 ₠€ ｶﾀｶﾅ"
+    text = "中文字符串テスト한국어 텍스트ひらがなカタカナ Ελληνικά àéîõüÿĀžƀȿ\u0300\u036f\u0370\u0240 ﬁ\uffff\ud7ff\ue000\ua000 ₠€ ｶﾀｶﾅ"
     junk = [b"", b"\x00", b"\xff\xfe", b"\xed\xa0\x80", b"\xed\x9f\xbf", b"\xe0\x80\x80", b"\xe0\xa0\x80", b"\xe4\xb8", b"\xe9", b"\x00\xd8",
             b"\xd8\x00\xdc\x00", b"\x00\xd8\x00\xdc", b"\xdc\x00", b"A", b"ab c", b"\xf0\x9f\x98\x80"]
     out = bytearray()
@@ -72,6 +72,9 @@ RUN_MISSIONS = {
     "utf16le_hangul": dict(encodings=["utf-16le"], chars_min="2", unicode_block_filter="Hangul", ascii_filter="None"),
     "utf16be_bmp3": dict(encodings=["utf-16be"], chars_min="3", unicode_block_filter="0x0000ffff00000000"),
     "utf16le_common_asian": dict(encodings=["utf-16le"], chars_min="4", unicode_block_filter="0x00003ffcfffffffc"),
+    "utf8_latin": dict(encodings=["utf-8"], chars_min="3", unicode_block_filter="Latin"),          # two ranges of two-byte leads: Utf8Range2x2
+    "utf16le_latin": dict(encodings=["utf-16le"], chars_min="3", unicode_block_filter="Latin"),    # three unit ranges below U+8000
+    "utf16be_latin": dict(encodings=["utf-16be"], chars_min="2", unicode_block_filter="Latin", ascii_filter="None"),
     "odd_af": dict(encodings=["utf-8"], chars_min="4", ascii_filter="0x7ffffffe000000007ffffffe00000000"),
 }
 
@@ -132,7 +135,7 @@ def test_tile_traversal_kernels_equal_oracle_runs(monkeypatch):
     monkeypatch.setenv("SX_TRAVERSAL", "1")
     rng = random.Random(11)
     for name in ("ascii", "utf8_common", "utf8_all", "utf16le_all", "utf16be_uncommon", "koi8r", "utf8_cjk", "utf8_hangul", "utf8_common_asian", "utf16le_cjk",
-                 "utf16be_bmp3", "utf16le_hangul"):
+                 "utf16be_bmp3", "utf16le_hangul", "utf8_latin", "utf16le_latin"):
         m = rc.missions(**RUN_MISSIONS[name])[0]
         for data in (synth(rng, 300_000, 1 / 300), soup(rng, 50_001), b"A" * 70000 + rng.randbytes(977) + b"B" * 3000,
                      synth(rng, 975, 1 / 40), synth(rng, 977, 1 / 40), synth(rng, 2000, 1 / 40)):
