@@ -44,6 +44,9 @@ std::string g_create_error;
 
 namespace sx {
 
+double g_tl_t0 = 0;
+int g_tl_on = 0;
+
 double now_ms() {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -275,7 +278,7 @@ int sx_create(sx_ctx** out, const sx_mission* missions, int n_missions, int hip_
             if ((e = hipEventCreate(&s.ev0)) != hipSuccess) return fail("hipEventCreate", e);
             if ((e = hipEventCreate(&s.ev1)) != hipSuccess) return fail("hipEventCreate", e);
             if ((e = hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
-            if ((e = hipMalloc((void**)&s.d_counters, 4 * sizeof(uint32_t))) != hipSuccess) return fail("hipMalloc", e);
+            if ((e = hipMalloc((void**)&s.d_counters, kCounterWords * sizeof(uint32_t))) != hipSuccess) return fail("hipMalloc", e);
             if ((e = hipMalloc((void**)&s.d_recs, (size_t)cap * sizeof(DevRun))) != hipSuccess) return fail("hipMalloc", e);
             s.capacity = cap;
         }

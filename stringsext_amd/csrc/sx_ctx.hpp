@@ -29,6 +29,10 @@
 namespace sx {
 
 double now_ms();
+// SX_TIMELINE=1: host-side marks on stderr, milliseconds since the current scan call began (round 5: where a step's time goes)
+extern double g_tl_t0;
+extern int g_tl_on;
+#define SX_TL(...) do { if (sx::g_tl_on) { fprintf(stderr, "[tl %+8.3f] ", sx::now_ms() - sx::g_tl_t0); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
 
 // The long runs of one mission over one buffer: owned (host merge, caller-supplied) or a view
 // of the mission's pinned download buffer; `on_device` says MissionDev::d_rp[0] holds the same list.
@@ -89,7 +93,7 @@ struct RunList {
 struct ScanSlot {
     DevRun* d_recs = nullptr;
     uint32_t capacity = 0;
-    uint32_t* d_counters = nullptr;   // 4 x u32: records, heavy tiles, joined runs, -
+    uint32_t* d_counters = nullptr;   // kCounterWords x u32 (sx_device.hpp): records, (heavy tiles), (joined runs), -, then the statistics' shards
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the scan kernel
     hipEvent_t ev_free = nullptr;     // the slot's records have been consumed (recorded on stream_b)
     bool free_pending = false;

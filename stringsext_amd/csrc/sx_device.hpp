@@ -31,6 +31,11 @@ constexpr uint32_t kRecCharsMask = 0x3FFFFFFFu;
 // a reserved slot that was never filled (see Emitter in sx_kernels.hip)
 constexpr uint32_t kRecInvalidLen = 0xFFFFFFFFu, kRecInvalidFlags = 0xFFFFFFFFu;
 
+// ScanParams::counters: [0] records appended to the pool / records that found no room in their region, [3] the fullest sub-chunk's
+// records (persistent grid: the next sub-chunk); [1], [2] are the host's sums of the statistics' shards: word kStatBase + shard *
+// kStatStride (+ 0: tiles on the general path, + 1: records of the launch), shard = sub-chunk number & (kStatShards - 1)
+constexpr uint32_t kStatBase = 32, kStatShards = 16, kStatStride = 32, kCounterWords = kStatBase + kStatShards * kStatStride;
+
 enum ClassifierKind : uint32_t {
     kClsSingleByteLut = 0,  // x-user-defined and WHATWG single-byte tables: 256-entry accept LUT
     kClsUtf8Lut = 1,        // UTF-8, any af/ubf: 256-entry class LUT + SWAR validity

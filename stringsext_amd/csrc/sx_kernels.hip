@@ -60,6 +60,9 @@ SX_DEV u32 movemask16(u32 f0, u32 f1, u32 f2, u32 f3) {
 SX_DEV u32 movemask4(u32 f) { return __builtin_amdgcn_udot4(f, 0x08040201u, 0u, false) >> 7; }
 
 SX_DEV u32 rep4(u32 b) { return b * 0x01010101u; }
+// continuation bytes (10xxxxxx) of a dword as byte flags: v & ~(v << 1) & 0x80808080 — two operations (left to itself the compiler
+// shifts ~v and spends three)
+SX_DEV u32 cont_flags(u32 v) { return __builtin_amdgcn_bitop3_b32(v, v << 1, kM, 0x20); }
 
 // ------------------------------------------------------------------------------------------
 // Classifiers.  Input: the lane's 16 bytes (x), the dword that follows them (nx) and
@@ -169,9 +172,9 @@ struct Utf8Range2 {
             u32 v = xs[k], t = v & 0x7F7F7F7Fu;
             a[k] = ((t + a1) & ~(t + a2)) & ~v & kM;
             l[k] = ((t + l1) & ~(t + l2)) & v;
-            c[k] = v & ~(v << 1) & kM;
+            c[k] = cont_flags(v);
         }
-        c[4] = LA ? from_next(c[0], nx) : (xs[4] & ~(xs[4] << 1) & kM);
+        c[4] = LA ? from_next(c[0], nx) : cont_flags(xs[4]);
         u32 p[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) p[k] = l[k] & __builtin_amdgcn_alignbyte(c[k + 1], c[k], 1);
@@ -379,12 +382,17 @@ struct Emitter {
     }
     // (records beyond the region's room are only counted; one atomic per sub-chunk — one per append made the scan of a
     // string-dense buffer 30x slower: a single word takes ~90 atomics per microsecond)
+    // Round 5: the two statistics (tiles on the general path, records of the launch) are added up in kStatShards (16) words 128 bytes apart
+    // (sx_device.hpp), picked by the sub-chunk's number, and summed by the host.  One word takes ~90 atomics per microsecond: with a
+    // record in nearly every sub-chunk (the headline's UTF-8 Mission: 262 144 sub-chunks per 64 GiB, 1.4 atomics each) that is 4 ms
+    // of one L2 channel's time inside a 12 ms launch, and 64 KiB sub-chunks made the launch 20.8 ms long (r05 probe).
     SX_DEV void end_region(u64 wave) {
-        if (heavy_n && lane_id() == 0) atomicAdd(counters + 1, heavy_n);
+        u32* const shard = counters + kStatBase + ((u32)wave & (kStatShards - 1u)) * kStatStride;
+        if (heavy_n && lane_id() == 0) atomicAdd(shard, heavy_n);
         heavy_n = 0;
         if (region_cap && lane_id() == 0) {
             region_counts[wave] = rcount < region_cap ? rcount : region_cap;
-            if (rcount) atomicAdd(counters + 2, rcount);               // all records of the launch (stage A's host side: how dense is the input?)
+            if (rcount) atomicAdd(shard + 1, rcount);                  // all records of the launch (stage A's host side: how dense is the input?)
             if (rcount > region_cap) {
                 atomicAdd(counters, rcount - region_cap);              // records that found no room
                 atomicMax(counters + 3, rcount);                       // how much room the fullest sub-chunk needs
@@ -585,7 +593,7 @@ SX_DEV void heavy_path(u32 g, u32 s, u32 g_raw, u32 g63_in, u32 s63, u32 r16, u6
 // The scan kernel: one wavefront per sub-chunk.
 // ------------------------------------------------------------------------------------------
 template <class CLS, bool NEEDS_LUT>
-__global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NEEDS_LUT ? 6 : 7))) void scan_kernel(const ScanParams p) {
     __shared__ __attribute__((aligned(16))) uint8_t lds_lut[512];
     if (NEEDS_LUT) {
         lds_lut[threadIdx.x] = p.lut[threadIdx.x];
@@ -630,6 +638,22 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(((u64)base_hi << 32) | base_lo), 0, (int)uniform(((u32)(win_hi - win_lo) + 15u) & ~15u), 0x00020000);
     auto load = [&](u32 off) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0); };
+    // Round 5: a tile in flight is its 1 KiB (16 bytes per lane, `d`) plus the dword behind every lane's 16 bytes (`e`: the
+    // look-ahead of the classifiers — the next lane's first dword, for lane 63 the next TILE's), fetched by a second load from the
+    // same address register + 16 (the same eight cache lines).  Rounds 1-4 took the look-ahead from the next lane by DPP and, for
+    // lane 63, out of the next tile's registers (v_readlane) — which made every tile wait for the tile behind it: one tile in
+    // flight per wavefront whatever the code said (the compiler's s_waitcnt vmcnt(0) at the loop head), ≈ 7 MB in flight on the
+    // whole chip where 8 TB/s x 1.5 us want 12.  Now three register sets rotate through a loop unrolled three times (no register
+    // moves: rounds 1-4 spent four v_mov_b64 per tile on the rotation), the set being classified depends on nothing younger, and two
+    // tiles are in flight behind it.
+    struct TileRegs { u32x4 d; u32 e; };
+    auto fetch = [&](u32 off) -> TileRegs {
+        TileRegs r;
+        const u32 a = off + lane * 16u;
+        r.d = load(a);
+        r.e = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(a + 16u), 0, 0);
+        return r;
+    };
 
     const int n_tiles = (int)((sub_end - sub_start + kTileBytes - 1) / kTileBytes);
     // tiles whose 1 KiB + look-ahead lie fully inside the chunk need no end-of-input care
@@ -638,8 +662,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
 
     int t = has_pre ? -1 : 0;  // -1 = the look-back tile
     u32 toff = 0;              // byte offset of tile t inside the window
-    u32x4 cur = load(lane * 16u);
-    u32x4 nxt = load(lane * 16u + kTileBytes);
+    TileRegs R0 = fetch(0u), R1 = fetch(kTileBytes), R2;
     Carry c;
     c.g63 = 0; c.tracked = 0; c.t_chars = 0; c.t_flags = 0; c.t_start = 0;
 
@@ -656,9 +679,11 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
         return uniform(cls.template classify<true>(x, nx, avail, NE));
     };
 
-    auto body = [&](auto near_tag) {
+    // X: the tile to classify (arrived or about to); Z: the free set, which takes the tile two behind X
+    auto body = [&](auto near_tag, const TileRegs& X, TileRegs& Z) {
         constexpr bool NE = decltype(near_tag)::value;
-        const u32x4 nn = load(toff + lane * 16u + 2 * kTileBytes);  // in flight while this tile is classified
+        Z = fetch(toff + 2 * kTileBytes);  // in flight while this tile and the next are classified
+        const u32x4 cur = X.d;
         const u64 tile_base = sub_start + (u64)((long long)t * (long long)kTileBytes);
         const u64 lane_base = tile_base + 16ull * lane;
         u32 avail = 32;
@@ -666,12 +691,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
 
         const u32 g63_in = c.g63;  // previous tile's lane 63 (by value: c is rewritten below)
         const bool tracked_in = c.tracked != 0;
-        constexpr bool LA = has_la<CLS>::value && !NE;
-        u32 g;
-        if constexpr (LA) {
-            const u32 e = bcast(nxt.x, 0);                 // the dword behind lane 63's bytes: its continuation flags, on the scalar side
-            g = classify_la_of(cls, cur, e & ~(e << 1) & kM);
-        } else g = cls.template classify<false>(cur, from_next(cur.x, bcast(nxt.x, 0)), avail, NE);
+        const u32 g = cls.template classify<false>(cur, X.e, avail, NE);
         const u32 pg = from_prev(g, g63_in);
         const u32 gf = (g & 0xFFFFu) | (pg >> 16);       // final good mask of my 16 bytes
         const u32 g63_out = bcast(gf | (g & 0xFFFF0000u), 63);
@@ -692,8 +712,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
             // fast path (and the look-back tile, of which only the classification state matters)
             c.g63 = g63_out;
         } else {
-            const u32 nx = from_next(cur.x, bcast(nxt.x, 0));
-            const u32 s = cls.template classify<true>(cur, nx, avail, NE);
+            const u32 s = cls.template classify<true>(cur, X.e, avail, NE);
             w = (gf << 16) | (from_prev(gf, g63_in) & 0xFFFFu);   // the exact window
             const u32 s63 = (g63_in & 0x8000u) ? starts_before(toff, tile_base, near_tag) : 0u;
             const u32 sw = (s << 16) | (from_prev(s, s63) & 0xFFFFu);
@@ -706,11 +725,16 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams p) {
                 heavy_path(gf, s, g, g63_in, s63, r >> 16, tile_base, tile_end, c, em, p.min_chars, p.cand_bytes, first_tile);
             }
         }
-        cur = nxt; nxt = nn; toff += kTileBytes; t++;
+        toff += kTileBytes; t++;
     };
 
-    while (t < n_safe) body(std::false_type{});
-    while (t < n_tiles) body(std::true_type{});
+    while (t + 3 <= n_safe) {
+        body(std::false_type{}, R0, R2);
+        body(std::false_type{}, R1, R0);
+        body(std::false_type{}, R2, R1);
+    }
+    // (what is left — at most two tiles — and the tiles near the end of the input: one copy of the code, the sets rotate by moves)
+    while (t < n_tiles) { body(std::true_type{}, R0, R2); R0 = R1; R1 = R2; }
 
     // the stretch that is still open where the sub-chunk ends
     if (c.tracked || (c.g63 & 0x8000u)) {
@@ -894,7 +918,7 @@ __global__ __launch_bounds__(256) void scan_kernel_v2(const ScanParams p) {
             const u32 sw = (s << 16) | (from_prev(s, 0u) & 0xFFFFu);
             const u64 lane_base = (u64)(lb < 0 ? 0 : lb);
             if (!light_path_v2(w, sw, r, lane_base, em, p.min_chars)) {
-                if (lane == 0) atomicAdd(p.counters + 1, 1u);
+                if (lane == 0) atomicAdd(p.counters + kStatBase + ((u32)t & (kStatShards - 1u)) * kStatStride, 1u);
                 heavy_path_v2(gf, s, tb, em, p.min_chars);
             }
         }
@@ -1511,7 +1535,7 @@ __global__ __launch_bounds__(256) void read_sum_kernel(const u32x4* src, u64 n16
 
 // same traversal as scan_kernel (one wavefront streams a private sub-chunk in 1 KiB tiles, two
 // tiles in flight) but no classification: the bandwidth this access pattern can reach at all
-__global__ __launch_bounds__(256) void read_subchunk_kernel(const uint8_t* data, u64 len, u32 subchunk, u64* out) {
+__global__ __launch_bounds__(256) void read_subchunk_kernel(const uint8_t* data, u64 len, u32 subchunk, u64* out, u32 rot) {
     const u32 lane = lane_id();
     const u64 wave = (u64)blockIdx.x * 4u + uniform(threadIdx.x >> 6);
     const u64 sub_start = wave * (u64)subchunk;
@@ -1522,13 +1546,18 @@ __global__ __launch_bounds__(256) void read_subchunk_kernel(const uint8_t* data,
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(((u64)base_hi << 32) | base_lo), 0, (int)uniform((u32)(sub_end - sub_start)), 0x00020000);
     const int n_tiles = (int)((sub_end - sub_start) / kTileBytes);
-    u32x4 cur = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u), 0, 0);
-    u32x4 nxt = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16u + kTileBytes), 0, 0);
-    u32 acc = 0, off = lane * 16u;
+    // rot (round 5, SX_PROBE_ROT): wavefront w begins at tile (w * rot) mod n_tiles of its sub-chunk and wraps around — the wavefronts
+    // that are resident together then read at offsets spread over the whole sub-chunk instead of all near the same one
+    const u32 span = (u32)n_tiles * kTileBytes;
+    u32 o0 = rot && n_tiles ? (u32)((wave * rot) % (u64)n_tiles) * kTileBytes : 0u;
+    auto wrap = [&](u32 o) { return o >= span ? o - span : o; };
+    u32x4 cur = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o0 + lane * 16u), 0, 0);
+    u32x4 nxt = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(wrap(o0 + kTileBytes) + lane * 16u), 0, 0);
+    u32 acc = 0, off = wrap(o0 + 2 * kTileBytes);
     for (int t = 0; t < n_tiles; t++) {
-        u32x4 nn = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 2 * kTileBytes), 0, 0);
+        u32x4 nn = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + lane * 16u), 0, 0);
         acc += cur.x ^ cur.y ^ cur.z ^ cur.w;
-        cur = nxt; nxt = nn; off += kTileBytes;
+        cur = nxt; nxt = nn; off = wrap(off + kTileBytes);
     }
     if (acc == 0x12345678u) atomicAdd((unsigned long long*)out, 1ull);
 }
@@ -1578,7 +1607,7 @@ hipError_t launch_read_sum(const uint8_t* src, u64 len, u64* out, hipStream_t st
         u64 waves = (len + subchunk - 1) / subchunk;
         const dim3 grid((unsigned)((waves + 3) / 4));
         if (loads == 0 && mode == 0)
-            hipLaunchKernelGGL(read_subchunk_kernel, grid, dim3(256), 0, stream, src, len, subchunk, out);
+            hipLaunchKernelGGL(read_subchunk_kernel, grid, dim3(256), 0, stream, src, len, subchunk, out, (u32)(getenv("SX_PROBE_ROT") ? atoi(getenv("SX_PROBE_ROT")) : 0));
 #define SX_RP(L, M) else if (loads == L && mode == M) hipLaunchKernelGGL((read_pattern_kernel<L, M>), grid, dim3(256), 0, stream, src, len, subchunk, out)
         SX_RP(1, 0); SX_RP(2, 0); SX_RP(4, 0); SX_RP(1, 1); SX_RP(2, 1); SX_RP(4, 1);
 #undef SX_RP

@@ -84,11 +84,6 @@ int set_entry_params(sx_ctx* ctx, bool carried_state_is_entry, const uint8_t* ho
 }
 
 // Missions in the order their kernels are queued (by their number of long runs in the previous buffer).
-// The scan kernels are bound by VALU issue (profiles/r02b_pmc_*: 88-100 % of the SIMDs' issue slots), so a stage B
-// that runs next to them takes its instructions out of their time: with a few million runs (a stage B of a few
-// milliseconds) the busiest Mission is scanned LAST and its stage B runs when the scans are done — the scan
-// launches then run at the speed they have alone.  With tens of millions of runs stage B is longer than the
-// scans: the busiest Mission goes FIRST and the others' scans hide behind its stage B.
 void mission_order(sx_ctx* ctx, std::vector<int>* out) {
     const size_t nm = ctx->missions.size();
     std::vector<int>& order = *out;
@@ -96,20 +91,17 @@ void mission_order(sx_ctx* ctx, std::vector<int>* out) {
     for (size_t k = 0; k < nm; k++) order[k] = (int)k;
     if (ctx->last_runs.size() != nm) return;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ctx->last_runs[(size_t)x] > ctx->last_runs[(size_t)y]; });
-    uint64_t most = 0;
-    for (uint64_t r : ctx->last_runs) most = std::max(most, r);
-    bool busiest_last = most < (16ull << 20);
-    if (const char* e = getenv("SX_BUSIEST_LAST")) busiest_last = atoi(e) != 0;
-    if (busiest_last) std::reverse(order.begin(), order.end());
-    // Round 4: with three or more Missions the busiest goes SECOND TO LAST (SX_BUSIEST_LAST=2; default when it would have gone last): its
-    // stage B — a few milliseconds of byte-serial kernels and the copy of its findings — then runs next to ONE scan launch, the last
-    // one, instead of after all of them (5.8 of the headline's 40 ms per step were that tail), and that launch is one of the Missions
-    // with few runs: the UTF-16 kernels wait on memory more than half of the time and have issue slots to spare, the UTF-8 kernel
-    // (bound by issue) still runs with nothing next to it.  What remains behind the last launch is the stage B of a Mission with
-    // next to no runs.
-    int mode = busiest_last ? 2 : 0;
+    // Round 5: the busiest Mission goes FIRST whatever its size (SX_BUSIEST_LAST=1 / 2: last / second to last, the defaults of
+    // rounds 2-3 / 4).  Its stage B — some forty small kernels, a dozen of them waited for by the host — then has two scan launches
+    // to hide behind instead of one and is done when the last of them ends; measured in one session on the headline (three Missions,
+    // 64 GiB, 2.8 M runs in the UTF-8 Mission; profiles/r05a_order_*.json): first 38.2 ms per step, second to last 39.9, last 40.5
+    // (= the scans alone, 34.5 ms, plus the 6.0 ms stage B takes on an idle chip).  With round 4's scan kernels second to last was
+    // the best (38.1): they were bound by VALU issue and lost to stage B what it won; the round-5 kernels issue a tenth fewer
+    // instructions per tile and keep two tiles in flight.
+    int mode = 0;
     if (const char* e = getenv("SX_BUSIEST_LAST")) mode = atoi(e);
-    if (mode == 2 && nm >= 3 && busiest_last) std::swap(order[nm - 1], order[nm - 2]);
+    if (mode) std::reverse(order.begin(), order.end());
+    if (mode == 2 && nm >= 3) std::swap(order[nm - 1], order[nm - 2]);
 }
 
 int sync_streams_and_return(sx_ctx* ctx, int rc) {  // do not leave kernels running on the caller's buffer
@@ -259,7 +251,9 @@ struct BufferScan {
                 // (with several missions a large output stays on the device: replay_all interleaves them there, one copy instead of two)
                 uint64_t defer = nm >= 2 ? (256ull << 20) : 0;
                 if (const char* e = getenv("SX_DEFER_MIN_BYTES")) defer = nm >= 2 ? (uint64_t)atoll(e) : 0;
+                SX_TL("mission %zu: device replay begins (%zu runs)", k, (*runs)[k].size());
                 rc = device_replay_mission(ctx, k, early_view, job, (*runs)[k], &pre.per[k], &pre.ends[k], defer);
+                SX_TL("mission %zu: device replay done", k);
                 if (rc == SX_NEED_RUNS) {   // the wave kernels gave up on a buffer whose runs were only counted: stage A in full, then the other stage B
                     ctx->wave_off[k] = 1;
                     rc = stage_a_launch(ctx, { (int)k }, d_bytes, len, { parity[k] }, { minc[k] }, slot);
@@ -277,6 +271,7 @@ struct BufferScan {
             }
             if ((rc = queue_next()) != SX_OK) return rc;
         }
+        SX_TL("all missions finished / replayed on the device");
         if (host_bytes) return replay_all(ctx, host_view, job, *runs, into, ends, &pre);
         SparseDeviceBytes view(ctx, d_bytes);
         bool base_is_enough = false;
@@ -297,6 +292,8 @@ struct BufferScan {
 int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, uint64_t len, int file_id,
                        int is_last, sx_result** out, uint32_t slice_base0, sx_result* append_to) {
     const double t_begin = now_ms();
+    g_tl_on = getenv("SX_TIMELINE") ? atoi(getenv("SX_TIMELINE")) : 0; g_tl_t0 = t_begin;
+    SX_TL("scan_common: %llu bytes", (unsigned long long)len);
     const size_t nm = ctx->missions.size();
     ctx->shard_runs_valid = false;   // the run lists a shard call left behind are about to be overwritten
     std::vector<uint64_t> stream0(nm);
@@ -362,7 +359,9 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
         if ((rc = pieces[launched].launch(ctx)) != SX_OK) return sync_streams_and_return(ctx, rc);
     // the few bytes the host always reads: a tiny gather in the second stream, it finds room
     // next to the scan kernels within ~0.1 ms
+    SX_TL("scans queued");
     if ((rc = pieces[0].fetch_base(ctx)) != SX_OK) return sync_streams_and_return(ctx, rc);
+    SX_TL("base fetched");
     for (uint64_t p = 0; p < n_pieces; p++) {
         BufferScan& b = pieces[p];
         if (p > 0 && (rc = b.fetch_base(ctx)) != SX_OK) return sync_streams_and_return(ctx, rc);
@@ -377,6 +376,7 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
     }
     if (len) ctx->out_density = (double)(ctx->merged_out_bytes - merged0) / (double)len;
     ctx->stats.total_ms = now_ms() - t_begin;
+    SX_TL("scan_common done");
     if (!append_to) *out = res.release();
     return SX_OK;
 }

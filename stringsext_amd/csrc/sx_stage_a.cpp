@@ -109,11 +109,11 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         if (const char* e = getenv("SX_SCAN_WARM"))
             for (int w = atoi(e); w > 0; w--) {
                 if (dbcs) HIP_TRY(ctx, hipMemsetAsync(s.d_grid, 0, n_sub * 4, d.stream));
-                HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream));
+                HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, kCounterWords * sizeof(uint32_t), d.stream));
                 HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream));
             }
         if (dbcs) HIP_TRY(ctx, hipMemsetAsync(s.d_grid, 0, n_sub * 4, d.stream));
-        HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, kCounterWords * sizeof(uint32_t), d.stream));
         HIP_TRY(ctx, hipEventRecord(s.ev0, d.stream));
         HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream));
         HIP_TRY(ctx, hipEventRecord(s.ev1, d.stream));
@@ -135,14 +135,23 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         ScanSlot& s = d.slot[si];
         HIP_TRY(ctx, hipEventSynchronize(s.ev1));
         const double t_ev = now_ms();
+        SX_TL("mission %d: scan kernel done", which[k]);
         float ms = 0;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, s.ev0, s.ev1));
         if (which[k] < 16) ctx->stats.kernel_ms[which[k]] += ms;
         uint32_t counters[4] = { 0, 0, 0, 0 };
+        std::vector<uint32_t> hc(kCounterWords);
         bool skip_runs = false;
         for (int round = 0;; round++) {
-            HIP_TRY(ctx, hipMemcpyAsync(counters, s.d_counters, sizeof counters, hipMemcpyDeviceToHost, d.stream_b));
+            // (the two statistics arrive in shards — sx_device.hpp kStatBase —: one 2 KB copy, summed here)
+            HIP_TRY(ctx, hipMemcpyAsync(hc.data(), s.d_counters, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            counters[0] = hc[0]; counters[3] = hc[3];
+            {
+                uint64_t heavy = 0, recs = 0;
+                for (uint32_t sh = 0; sh < kStatShards; sh++) { heavy += hc[kStatBase + sh * kStatStride]; recs += hc[kStatBase + sh * kStatStride + 1]; }
+                counters[1] = (uint32_t)std::min<uint64_t>(heavy, 0xFFFFFFFFull); counters[2] = (uint32_t)std::min<uint64_t>(recs, 0xFFFFFFFFull);
+            }
             if (round == 0 && wave_job) {
                 // String-dense input of a Mission whose stage B can replay every window (sx_wave.cpp): the records are only
                 // counted — no second scan with larger regions, no sort, no join, no pieces.
@@ -184,13 +193,14 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             const ScanParams p = scan_params(ctx, which[k], s, d_bytes, len, parity[k], min_chars[k]);
             const double tr0 = now_ms();
             if (p.grid_flags) HIP_TRY(ctx, hipMemsetAsync(p.grid_flags, 0, ((len + p.subchunk - 1) / p.subchunk) * 4, d.stream_b));
-            HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d.stream_b));
+            HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, kCounterWords * sizeof(uint32_t), d.stream_b));
             HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
             ctx->stats.rescans++;
             ctx->stats.rescan_ms += now_ms() - tr0;
         }
         const double tc0 = now_ms();
+        SX_TL("mission %d: counters read (%u records)", which[k], s.region_cap ? counters[2] : counters[0]);
         if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   mission %d: kernel done at +%.2f ms, counters at +%.2f ms\n", which[k], t_ev - t0, tc0 - t0);
         if (skip_runs) {
             HIP_TRY(ctx, hipEventRecord(s.ev_free, d.stream_b));
@@ -225,6 +235,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             HIP_TRY(ctx, hipMemcpyAsync(&nrec, s.d_counters + 1, 4, hipMemcpyDeviceToHost, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
             d_records = s.d_packed;
+            SX_TL("mission %d: regions packed (%u)", which[k], nrec);
         } else if (ctx->region_cap && !large_regions && nrec < s.n_regions * ctx->region_cap / 4)
             ctx->dense[(size_t)which[k]] = 0;  // sparse again: regions next time
         const uint32_t join_min = getenv("SX_DEVICE_JOIN_MIN") ? (uint32_t)atoi(getenv("SX_DEVICE_JOIN_MIN")) : 65536u;
@@ -248,6 +259,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             HIP_TRY(ctx, hipMemcpyAsync(&nruns32, s.d_counters + 2, 4, hipMemcpyDeviceToHost, d.stream_b));
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
             uint64_t nruns = nruns32;
+            SX_TL("mission %d: joined (%u runs)", which[k], nruns32);
             const sx_run* d_list = (const sx_run*)d.d_rp[0];
             // Runs that cross window starts are cut into one piece per window where the state at those window
             // starts follows from the run alone (sx_replay_core.hpp kPieceCont): stage B then gets a region per
@@ -272,6 +284,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                 } else (void)hipGetLastError();
             }
             tc1 = now_ms();
+            SX_TL("mission %d: cut into pieces (%llu)", which[k], (unsigned long long)nruns);
             if ((uint64_t)nruns * sizeof(sx_run) > d.h_runs_cap) {
                 if (d.h_runs) HIP_TRY(ctx, hipHostFree(d.h_runs));
                 d.h_runs = nullptr; d.h_runs_cap = 0;

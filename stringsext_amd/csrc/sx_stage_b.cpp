@@ -169,7 +169,9 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
                                           ctx->d_scratch_cap, d.stream_b));
         HIP_TRY(ctx, hipMemcpyAsync(h_tot, d.d_rp[7], kTotCount * 8, hipMemcpyDeviceToHost, d.stream_b));
     }
+    SX_TL("  replay: pass 1 + stitch queued, host entry part done");
     if (n) HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+    SX_TL("  replay: pass 1 + stitch done");
     if (dev_stitch && h_tot[kTotTooLong] && slabbed) return SX_RETRY_WHOLE;
     if (dev_stitch && h_tot[kTotTooLong]) {  // regions for the host: it also decides what stands
         dev_stitch = false;
@@ -284,7 +286,9 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
                 else HIP_TRY(ctx, hipMemcpyAsync(blk.p, d_all, out_bytes, hipMemcpyDeviceToHost, d.stream_b));
             }
         }
+        SX_TL("  replay: pass 2 + copy queued (%llu bytes%s)", (unsigned long long)out_bytes, deferred ? ", stays on the device" : "");
         if (!sl.async_copy || nfh) HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));   // (nfh: the entry part's upload reads host vectors)
+        SX_TL("  replay: pass 2 + copy done");
     }
     const double t3 = now_ms();
 
@@ -756,13 +760,16 @@ int replay_all(sx_ctx* ctx, ByteView& bytes, const ReplayJob& job, const std::ve
     }
     if (end_pos) for (size_t k = 0; k < nm; k++) end_pos[k] = ends[k];
     const double t_stitch = now_ms();
+    SX_TL("replay_all: host parts + stitch done");
     const size_t count_before = into->count();
     {   // several missions with findings that are all still on the device: interleave them there
         // (a stable radix sort by position) instead of finding by finding on the host
         int rc = device_merge(ctx, job, per, into);
         if (rc != SX_OK) return rc;
     }
+    SX_TL("replay_all: device_merge done");
     merge_findings(per, ctx->pool, into);
+    SX_TL("replay_all: merge_findings done");
     if (getenv("SX_TIMING")) {
         double mx = 0, sum = 0;
         for (double v : task_ms) { sum += v; mx = std::max(mx, v); }
