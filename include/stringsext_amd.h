@@ -38,7 +38,7 @@ extern "C" {
 /* Bumped whenever a struct of this header changes size or layout or an enum value changes meaning (2: sx_stats grew by the wave /
  * re-scan / piece fields in round 3, SX_ENC_ISO_2022_JP was added; packed findings, round 4).  A consumer compares it with
  * sx_abi_version() before it hands the library a struct to fill. */
-#define SX_ABI_VERSION 2
+#define SX_ABI_VERSION 3
 
 enum {
     SX_OK = 0,
@@ -156,6 +156,8 @@ typedef struct sx_stats {
     double   rescan_ms;                  /* ... host time until their records were there */
     uint64_t wave_desc_overflows;        /* wave stage B: slabs written by the window-parallel writer because a wavefront found more than its descriptors hold */
     uint64_t seq_pieces;                 /* pieces a buffer with gigabytes of output was scanned in, one after the other (0: in one go) */
+    uint64_t fast_regions;               /* (ABI 3) stage B, lane per region: regions settled by the fast pre-pass (one run inside one window) ... */
+    uint64_t general_regions;            /* ... and regions it left to the general replay kernel */
 } sx_stats;
 
 typedef struct sx_ctx sx_ctx;

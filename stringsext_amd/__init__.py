@@ -26,7 +26,7 @@ ENC = {"x-user-defined": 0, "utf-8": 1, "utf-16le": 2, "utf-16be": 3, "koi8-r": 
 PRECISION = {0: "Before", 1: "Exact", 2: "After"}
 
 # every symbol include/stringsext_amd.h declares
-ABI_VERSION = 2   # SX_ABI_VERSION of include/stringsext_amd.h
+ABI_VERSION = 3   # SX_ABI_VERSION of include/stringsext_amd.h
 EXPORTS = ["sx_abi_version", "sx_create", "sx_destroy", "sx_last_error", "sx_scan", "sx_scan_device", "sx_reset",
            "sx_device_runs", "sx_replay_runs", "sx_scan_shard_device", "sx_scan_shard", "sx_replay_shard_runs",
            "sx_scan_stream", "sx_scan_file", "sx_missions_from_flags", "sx_parse_enc_opt", "sx_encoding_for_label", "sx_encoding_name",
@@ -167,7 +167,8 @@ class Stats(C.Structure):
                 ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("replay_ms", C.c_double),
                 ("total_ms", C.c_double), ("heavy_tiles", C.c_uint64), ("wave_windows", C.c_uint64),
                 ("wave_count_ms", C.c_double), ("wave_write_ms", C.c_double), ("rescans", C.c_uint64), ("rescan_ms", C.c_double),
-                ("wave_desc_overflows", C.c_uint64), ("seq_pieces", C.c_uint64)]
+                ("wave_desc_overflows", C.c_uint64), ("seq_pieces", C.c_uint64),
+                ("fast_regions", C.c_uint64), ("general_regions", C.c_uint64)]
 
 
 class Options(C.Structure):

@@ -122,7 +122,12 @@ struct ReplayParams {
     uint32_t str_off_base;       // pass 2 (flagged form): added to every str_off (strings of the host's entry part come first)
     uint32_t entry_skip;         // double-byte encodings: bytes at the buffer start that finish the token pending on entry
     uint64_t n_look;             // runs[] may be read up to here (0: n_runs) — a slab's kernels visit n_runs of them, its regions look on
+    // the fast pre-pass of pass 1 (round 5, sx_replay_dev.hip replay_fast_kernel): the slots of the replaying runs it left to the
+    // general kernel, and how many (device; nullptr: no pre-pass, the general kernel visits every replaying run)
+    uint32_t* hard_list;
+    uint32_t* n_hard;
 };
+
 struct ReplayRegionOut {
     uint64_t end;             // where the region's replay stopped (a window start, buffer relative)
     uint32_t n_find, n_bytes, status, pad;  // pad: 1 = pass 1 kept the whole output in the region's cache slot
@@ -133,6 +138,10 @@ hipError_t launch_replay_heads(const ReplayParams& P, uint32_t* slot_of, uint32_
                                void* scratch, size_t scratch_bytes,
                                hipStream_t stream);
 hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, hipStream_t stream);
+// Does the fast pre-pass cover this Mission?  (UTF-8, no -g / -r, 1 <= n <= q: a run is one stretch of accepted characters and
+// SplitStr never abandons a call's text.)
+bool replay_fast_covers(const ReplayParams& P);
+hipError_t launch_replay_fast(const ReplayParams& P, ReplayRegionOut* out, hipStream_t stream);
 hipError_t launch_replay_write(const ReplayParams& P, const uint64_t* region_index, const uint64_t* fbase,
                                const uint64_t* abase, uint64_t n_regions, sx_finding* findings, uint8_t* arena,
                                hipStream_t stream);

@@ -58,6 +58,19 @@ SX_DEV u32 movemask16(u32 f0, u32 f1, u32 f2, u32 f3) {
     return (lo >> 7) | (hi << 1);  // each flag byte is 0x80: sums are 128 * mask
 }
 SX_DEV u32 movemask4(u32 f) { return __builtin_amdgcn_udot4(f, 0x08040201u, 0u, false) >> 7; }
+// unit flags (bits 15 and 31 of four dwords, 0x80 in bytes 1 and 3) -> 16-bit byte mask; W0 / W1: the weights of the dword's two
+// units in the first / second dword of a pair (Utf16RangeT)
+template <u32 W0, u32 W1>
+SX_DEV u32 movemask_units(u32 f0, u32 f1, u32 f2, u32 f3) {
+    u32 lo = __builtin_amdgcn_udot4(f0, W0, 0u, false);
+    lo = __builtin_amdgcn_udot4(f1, W1, lo, false);
+    u32 hi = __builtin_amdgcn_udot4(f2, W0, 0u, false);
+    hi = __builtin_amdgcn_udot4(f3, W1, hi, false);
+    return (lo >> 7) | (hi << 1);
+}
+// two 16-bit additions in one instruction (v_pk_add_u16)
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+SX_DEV u32 pk_add16(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_bit_cast(u16x2_t, a) + __builtin_bit_cast(u16x2_t, b)); }
 
 SX_DEV u32 rep4(u32 b) { return b * 0x01010101u; }
 // continuation bytes (10xxxxxx) of a dword as byte flags: v & ~(v << 1) & 0x80808080 — two operations (left to itself the compiler
@@ -257,11 +270,14 @@ struct Utf16RangeT {
     }
     SX_DEV u32 odd() const { return ODD_T < 0 ? odd_rt : (u32)ODD_T; }
     SX_DEV bool be() const { return BE_T < 0 ? be_rt != 0 : BE_T != 0; }
+    // Round 5: the range compares as PACKED 16-bit additions (v_pk_add_u16: no carry from unit to unit, so the unit's bit 15 need not
+    // be cleared first — a unit >= 0x8000 wraps, and is masked out by ~v anyway), and the byte masks straight from the UNIT flags:
+    // the v_dot4 weights 3 / 12 / 48 / 192 set both bytes' bits of a good unit (1 / 4 / 16 / 64: its first byte's, the start mask)
+    // — rounds 1-4 spread the flags onto both bytes first (a shift and an OR per dword).  62 -> 50 vector instructions per tile.
     SX_DEV u32 unit_flags(u32 v) const {  // two units per dword -> flags at bits 15 and 31
         if (be()) v = __builtin_amdgcn_perm(0u, v, 0x02030001u);
-        u32 t = v & 0x7FFF7FFFu;
-        u32 ra = (t + a1) & ~(t + a2);
-        u32 ru = (t + u1) & ~(t + u2);
+        u32 ra = pk_add16(v, a1) & ~pk_add16(v, a2);
+        u32 ru = pk_add16(v, u1) & ~pk_add16(v, u2);
         return (ra | ru) & ~v & 0x80008000u;
     }
     template <bool WANT_S>
@@ -274,8 +290,8 @@ struct Utf16RangeT {
             d3 = __builtin_amdgcn_alignbyte(nx, x.w, 1);
         }
         u32 f0 = unit_flags(d0), f1 = unit_flags(d1), f2 = unit_flags(d2), f3 = unit_flags(d3);
-        u32 s0 = f0 >> 8, s1 = f1 >> 8, s2 = f2 >> 8, s3 = f3 >> 8;  // flag on the unit's first byte
-        u32 m = WANT_S ? movemask16(s0, s1, s2, s3) : movemask16(f0 | s0, f1 | s1, f2 | s2, f3 | s3);
+        u32 m = WANT_S ? movemask_units<0x04000100u, 0x40001000u>(f0, f1, f2, f3)     // the unit's first byte
+                       : movemask_units<0x0C000300u, 0xC0003000u>(f0, f1, f2, f3);    // both bytes of the unit
         if (near_end) {  // whole units only
             u32 nu = avail > odd() ? (avail - odd()) >> 1 : 0u;
             m &= low_mask(2 * nu);

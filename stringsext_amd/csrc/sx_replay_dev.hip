@@ -92,7 +92,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
     constexpr bool QBIG = EQ >= 8;
     extern __shared__ __align__(16) u8 lds_win[];
     u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
-    if (i >= *P.n_heads) return;
+    if (P.hard_list) {   // (round 5) only what the fast pre-pass left
+        if (i >= *P.n_hard) return;
+        i = P.hard_list[i];
+    } else if (i >= *P.n_heads) return;
     i = P.head_list[i];
     ReplayRegionOut o;
     o.end = 0; o.n_find = 0; o.n_bytes = 0; o.status = kRegionOk; o.pad = 0;
@@ -105,6 +108,101 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
     replay_region<2, ENC, true, QBIG>(P, i, o, (sx_finding*)slot, slot + g.cap_f * sizeof(sx_finding), 0, room ? g.cap_f : 0u, room ? g.cap_b : 0u,
                                 lds_win + threadIdx.x * win_row_bytes(P.W));
     out[i] = o;
+}
+
+// ---- Pass 1, the fast pre-pass (round 5) -----------------------------------------------------------------------------------------
+// On sparse input — the headline: 2.8 M runs per 64 GiB of random bytes — nearly every region is ONE run of a dozen characters
+// somewhere inside ONE window, and the general kernel above spends ~700 cycles per byte on it: it derives the state at the window
+// start, stages the window, decodes the run's call byte by byte and walks SplitStr over it (2.1 ms of the whole chip per step, half
+// of stage B's instructions, taken out of the scan launch that runs next to it).  For such a region everything follows from the
+// run record and a short walk back from the run's first byte:
+//   (1) the run [rs, re) is a plain run (no continuation piece), has fewer than q characters (one line, helper.rs:237), lies in the
+//       window [want, wend) with re + 4 <= wend (whatever begins at re — a rejected character, a malformed sequence — is settled
+//       inside the window: the run does not touch the end of its call's text with the call still open, helper.rs:353-355, 389-392),
+//       and the next run of the list begins at or behind wend (nothing else in this window can yield: every stretch of >= n
+//       characters is a run of the list);
+//   (2) the call that holds rs starts at vs >= want + 4, behind a malformed sequence INSIDE the window (call_start_before; with
+//       vs < want + 4 the walk may have met the tail of a character that began in front of the window, which is no error).  Then the
+//       window's first call has taken whatever was carried in (leftover, cut flag) and — ending in an error, holding no run —
+//       dropped it (helper.rs:315-330, 410-415); the calls in between yield nothing; this call's first and only yield is the run:
+//       position = the call's start (finding_collection.rs:260), precision Exact (:146: nothing was prepended, no slice-start
+//       probe: din > 0), completes = false, the string = the run's bytes (UTF-8 in, UTF-8 out);
+//   (3) behind the run nothing is pending (the cut flag stays down: :353-355 needs q characters or an open text end), the tail of
+//       the window holds no long stretch, and no run crosses wend: the region ends at wend (replay_region's shortcut (B)).
+// A lane that finds (1)-(3) writes what replay_region<2> would have written — the region's record, the finding and the string in
+// the cache slot — and is done; the others put their slot on a list (one atomic per wavefront) that the general kernel then visits
+// instead of the whole head list.  tests/test_gpu_fast_replay.py runs every Mission shape with and without the pre-pass.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int ENC>
+SXD bool replay_fast_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_finding* fout, u8* aout, u32 cap_f, u32 cap_b) {
+    static_assert(ENC == 1, "UTF-8: the string is the run's bytes");
+    const sx_run r = P.runs[i];
+    if (r.chars & kPieceCont) return false;
+    if (r.chars >= P.q) return false;                                   // (saturating count: >= q means at least q)
+    const u32 W = P.W;
+    const u64 rs = r.start, re = r.end;
+    const u64 want = win_start(rs, W), wend = next_win_start(rs, W);
+    if (wend > P.len || re + 4 > wend) return false;
+    const u64 n_look = P.n_look ? P.n_look : P.n_runs;
+    if (i + 1 < n_look && P.runs[i + 1].start < wend) return false;
+    const u64 vs = call_start_before<ENC>(P, want, rs);
+    if (vs < want + 4) return false;
+    const u32 nb = (u32)(re - rs);
+    if (cap_f < 1 || nb > cap_b) return false;
+    const u64 soff = want / kSliceLen * kSliceLen;
+    sx_finding f;
+    f.position = P.consumed0 + vs;
+    f.str_off = 0;
+    f.str_len = nb;
+    f.precision = SX_PRECISION_EXACT;
+    f.completes_previous = 0;
+    f.mission_id = (u8)P.mission_id;
+    f.reserved = 0;
+    f.input_file_id = (int16_t)P.file_id;
+    f.reserved2 = 0;
+    f.slice_index = (u32)(soff / kSliceLen) + P.slice_base;
+    fout[0] = f;
+    const u8* s = P.data + rs;
+    u32 t = 0;
+    for (; t + 16 <= nb; t += 16) { uint4 v; __builtin_memcpy(&v, s + t, 16); __builtin_memcpy(aout + t, &v, 16); }
+    if (t + 8 <= nb) { u64 v; __builtin_memcpy(&v, s + t, 8); __builtin_memcpy(aout + t, &v, 8); t += 8; }
+    if (t + 4 <= nb) { u32 v; __builtin_memcpy(&v, s + t, 4); __builtin_memcpy(aout + t, &v, 4); t += 4; }
+    for (; t < nb; t++) aout[t] = s[t];
+    o.end = wend; o.n_find = 1; o.n_bytes = nb; o.status = kRegionOk; o.pad = 1;
+    return true;
+}
+template <int ENC>
+__global__ __launch_bounds__(256) void replay_fast_kernel(const ReplayParams P, ReplayRegionOut* out) {
+    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;   // slot of a replaying run
+    const u32 nh = *P.n_heads;
+    bool hard = false;
+    if (s < nh) {
+        const u64 i = P.head_list[s];
+        const CacheGeom g = cache_geom(P.arena_bytes, nh);
+        const u64 off = (u64)P.slot_of[i] * g.slot_bytes;
+        const bool room = off + g.slot_bytes <= P.arena_bytes;
+        u8* slot = P.cache_arena + (room ? off : 0);
+        ReplayRegionOut o;
+        if (room && replay_fast_region<ENC>(P, i, o, (sx_finding*)slot, slot + g.cap_f * sizeof(sx_finding), g.cap_f, g.cap_b)) out[i] = o;
+        else hard = true;
+    }
+    const unsigned long long m = __ballot(hard);
+    if (m) {
+        const u32 lane = threadIdx.x & 63u;
+        u32 base = 0;
+        if (lane == (u32)__ffsll((long long)m) - 1u) base = atomicAdd(P.n_hard, (u32)__popcll(m));
+        base = __shfl(base, (int)__ffsll((long long)m) - 1);
+        if (hard) P.hard_list[base + (u32)__popcll(m & ((1ull << lane) - 1ull))] = (u32)s;
+    }
+}
+bool replay_fast_covers(const ReplayParams& P) {
+    return enc_family(P.encoding) == 1 && P.grep_char < 0 && !P.same_block && P.chars_min_nb >= 1 && P.chars_min_nb <= P.q && P.long_run >= 1
+           && P.cache_arena && P.head_list && P.hard_list && P.n_hard;
+}
+hipError_t launch_replay_fast(const ReplayParams& P, ReplayRegionOut* out, hipStream_t stream) {
+    if (P.n_runs == 0) return hipSuccess;
+    hipLaunchKernelGGL((replay_fast_kernel<1>), dim3((unsigned)((P.n_runs + 255) / 256)), dim3(256), 0, stream, P, out);
+    return hipGetLastError();
 }
 
 // Pass 2: the standing regions write their findings and strings at the offsets the host assigned.
@@ -282,28 +380,6 @@ hipError_t launch_split_write(const ReplayParams& P, const void* scratch, uint64
 // chain only until it meets the block's own chain again.
 struct StitchBlock { u64 first_want, end; u64 last; };  // first candidate's window, E after the block, last standing run
 
-__global__ __launch_bounds__(64) void stitch_blocks_kernel(const ReplayParams P, const ReplayRegionOut* ro, u8* stands,
-                                                           StitchBlock* blocks, u64 n_blocks, u32 per_block, u64* totals) {
-    const u64 b = (u64)blockIdx.x * 64 + threadIdx.x;
-    if (b >= n_blocks) return;
-    const u64 i0 = b * per_block, i1 = i0 + per_block < P.n_runs ? i0 + per_block : P.n_runs;
-    StitchBlock sb; sb.first_want = ~0ull; sb.end = 0; sb.last = ~0ull;
-    u32 too_long = 0;
-    for (u64 i = i0; i < i1; i++) {
-        const u32 st = ro[i].status;
-        u8 f = 0;
-        if (st == kRegionTooLong) too_long++;
-        if (st == kRegionOk) {
-            const u64 w = win_start(P.runs[i].start, P.W);
-            if (sb.first_want == ~0ull) sb.first_want = w;
-            if (w >= sb.end) { f = 1; sb.end = ro[i].end; sb.last = i; }
-        }
-        stands[i] = f;
-    }
-    blocks[b] = sb;
-    if (too_long) atomicAdd((unsigned long long*)&totals[kTotTooLong], (unsigned long long)too_long);
-}
-
 SXD u64 wave_prefix_max_excl(u64 x, u32 lane) {  // max over lanes below `lane` (0 for lane 0)
     u64 v = x;
     for (int o = 1; o < 64; o <<= 1) {
@@ -312,6 +388,55 @@ SXD u64 wave_prefix_max_excl(u64 x, u32 lane) {  // max over lanes below `lane` 
     }
     const u64 up = __shfl_up(v, 1);
     return lane ? up : 0ull;
+}
+
+__global__ __launch_bounds__(64) void stitch_blocks_kernel(const ReplayParams P, const ReplayRegionOut* ro, u8* stands,
+                                                           StitchBlock* blocks, u64 n_blocks, u32 per_block, u64* totals) {
+    // Round 5: a WAVEFRONT per block, 64 consecutive runs at a time (rounds 2-4: a lane per block walked its 512 runs one after the
+    // other, every load and store of the wavefront scattered over 64 cache lines — 87 wavefronts waiting on memory for 0.3 ms on an
+    // idle chip and for 3.5 ms next to a scan kernel).  Inside a group the rule is settled the way stitch_chain_kernel settles
+    // blocks: everything stands whose window start is not below the ends in front of it (a prefix maximum); the first run that is
+    // overrun is void, its end leaves the maximum, and the lanes behind it are looked at again — one round per void run.
+    const u64 b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const u32 lane = threadIdx.x;
+    const u64 i0 = b * per_block, i1 = i0 + per_block < P.n_runs ? i0 + per_block : P.n_runs;
+    u64 first_want = ~0ull, E = 0, last = ~0ull;   // wave-uniform
+    u32 too_long = 0;
+    for (u64 g = i0; g < i1; g += 64) {
+        const u64 i = g + lane;
+        const bool in = i < i1;
+        const u32 st = in ? ro[i].status : (u32)kRegionNotMine;
+        const bool ok = in && st == kRegionOk;
+        const u64 end = ok ? ro[i].end : 0ull;
+        const u64 w = ok ? win_start(P.runs[i].start, P.W) : 0ull;
+        too_long += (u32)__popcll(__ballot(in && st == kRegionTooLong));
+        const unsigned long long okm = __ballot(ok);
+        if (first_want == ~0ull && okm) first_want = __shfl(w, (int)__ffsll((long long)okm) - 1);
+        bool f = false;
+        u32 cur = 0;   // lanes below cur are settled
+        while (cur < 64) {
+            const bool live = ok && lane >= cur;
+            u64 e_in = wave_prefix_max_excl(live ? end : 0ull, lane);
+            if (e_in < E) e_in = E;
+            const unsigned long long badmask = __ballot(live && e_in > w);
+            const u32 v = badmask ? (u32)__ffsll((long long)badmask) - 1u : 64u;   // the first run that is overrun: void
+            if (live && lane < v) f = true;
+            const unsigned long long stood = __ballot(live && lane < v);
+            if (stood) {
+                const int top = 63 - __clzll((long long)stood);
+                E = __shfl(end, top);
+                last = g + (u64)top;
+            }
+            cur = v + 1;
+        }
+        if (in) stands[i] = f ? 1 : 0;
+    }
+    if (lane == 0) {
+        StitchBlock sb; sb.first_want = first_want; sb.end = E; sb.last = last;
+        blocks[b] = sb;
+        if (too_long) atomicAdd((unsigned long long*)&totals[kTotTooLong], (unsigned long long)too_long);
+    }
 }
 
 __global__ __launch_bounds__(64) void stitch_chain_kernel(const ReplayParams P, const ReplayRegionOut* ro, u8* stands,
@@ -416,7 +541,7 @@ hipError_t launch_stitch_blocks(const ReplayParams& P, const ReplayRegionOut* ro
                                 uint64_t* totals, hipStream_t stream) {
     if (P.n_runs == 0) return hipSuccess;
     const u64 nb = stitch_block_count(P.n_runs);
-    hipLaunchKernelGGL(stitch_blocks_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, stream, P, ro, stands,
+    hipLaunchKernelGGL(stitch_blocks_kernel, dim3((unsigned)nb), dim3(64), 0, stream, P, ro, stands,
                        (StitchBlock*)blocks, nb, stitch_block_runs(P.n_runs), totals);
     return hipGetLastError();
 }

@@ -116,20 +116,25 @@ __global__ __launch_bounds__(256) void region_sum_scan_kernel(uint32_t* block_su
 // A region holds its sub-chunk's records almost in order (tile by tile; inside a tile the lanes
 // emit their first stretches, then their second ones, ...), so every record is placed by its
 // rank among the region's records (<= region_cap of them: a handful of cached loads).
+// Round 5: kPackLanes lanes per REGION, each taking the region's records j, j + kPackLanes, ... (rounds 2-4: a thread per SLOT — with 64
+// slots per region and a dozen records in them five lanes of six did nothing, and the launch was 262 144 wavefronts per 64 GiB,
+// 1.4 ms next to a scan kernel).
+constexpr uint32_t kPackLanes = 16;
 __global__ __launch_bounds__(256) void region_pack_kernel(const DevRun* recs, const uint32_t* counts, const uint32_t* local_off,
                                                           const uint32_t* block_off, uint64_t n_regions, uint32_t region_cap,
                                                           DevRun* out) {
-    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // slot
-    const uint64_t w = s / region_cap;
-    const uint32_t j = (uint32_t)(s - w * region_cap);
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t w = t / kPackLanes;
     if (w >= n_regions) return;
     const uint32_t n = counts[w];
-    if (j >= n) return;
-    const DevRun r = recs[s];
     const DevRun* reg = recs + w * region_cap;
-    uint32_t rank = 0;
-    for (uint32_t i = 0; i < n; i++) rank += reg[i].start < r.start ? 1u : 0u;
-    out[(uint64_t)block_off[w / kScanPerBlock] + local_off[w] + rank] = r;
+    const uint64_t base = (uint64_t)block_off[w / kScanPerBlock] + local_off[w];
+    for (uint32_t j = (uint32_t)(t % kPackLanes); j < n; j += kPackLanes) {
+        const DevRun r = reg[j];
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < n; i++) rank += reg[i].start < r.start ? 1u : 0u;
+        out[base + rank] = r;
+    }
 }
 // Large regions (string-dense input): instead of packing, the unused slots are marked like the pool's
 // unused slots and the whole array goes through the radix sort.
@@ -162,8 +167,8 @@ hipError_t compact_regions(const DevRun* recs, const uint32_t* counts, uint64_t 
     uint32_t* block_sum = local_off + n_regions;
     hipLaunchKernelGGL(region_block_scan_kernel, dim3(n_blocks), dim3(256), 0, stream, counts, n_regions, local_off, block_sum);
     hipLaunchKernelGGL(region_sum_scan_kernel, dim3(1), dim3(256), 0, stream, block_sum, n_blocks, total);
-    const uint64_t slots = n_regions * region_cap;
-    hipLaunchKernelGGL(region_pack_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, recs, counts, local_off,
+    const uint64_t threads = n_regions * kPackLanes;
+    hipLaunchKernelGGL(region_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, recs, counts, local_off,
                        block_sum, n_regions, region_cap, out);
     return hipGetLastError();
 }

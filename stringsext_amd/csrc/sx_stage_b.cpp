@@ -62,15 +62,16 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
     // device) which regions stand and where each writes.  The host keeps its own version of
     // that step for buffers with regions the device gave back (kRegionTooLong).
     ReplayParams P{};
+    bool fast_pass = false;
     bool dev_stitch = n > 0 && !getenv("SX_HOST_STITCH");
     uint64_t* h_tot = nullptr;
     ReplayRegionOut* ro = nullptr;
     {
         // (the regions' records only travel to the host when it decides what stands: 24 bytes per run, 6 GB for C5's floods)
-        int rc = ensure_pinned2(ctx, (dev_stitch ? 0 : n * sizeof(ReplayRegionOut)) + 256);
+        int rc = ensure_pinned2(ctx, (dev_stitch ? 0 : n * sizeof(ReplayRegionOut)) + 512);
         if (rc != SX_OK) return rc;
-        h_tot = (uint64_t*)ctx->h_pin2;
-        ro = (ReplayRegionOut*)(ctx->h_pin2 + 128);
+        h_tot = (uint64_t*)ctx->h_pin2;   // kTotCount totals; words 32, 33: the fast pre-pass' statistics
+        ro = (ReplayRegionOut*)(ctx->h_pin2 + 384);
     }
     if (n) {
         int rc = ensure_rp(ctx, d, 0, n * sizeof(sx_run)); if (rc) return rc;
@@ -106,7 +107,7 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
             }
             if (const char* e = getenv("SX_REPLAY_CACHE_MIB")) budget = (uint64_t)atoll(e) << 20;
             uint64_t arena = std::max<uint64_t>(4096, std::min<uint64_t>(budget, (uint64_t)n * 1024));
-            const uint64_t lists = (uint64_t)(2 * n + 4) * 4 + 512;
+            const uint64_t lists = (uint64_t)(3 * n + 8) * 4 + 512;   // slot_of, n_heads, head_list; (round 5) n_hard, hard_list
             rc = ensure_cache(ctx, arena + lists);
             while (rc != SX_OK && arena > (64ull << 20)) {   // the device is short of memory: a smaller arena (more regions are replayed twice)
                 (void)hipGetLastError();
@@ -121,8 +122,20 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
             P.slot_of = slot_of; P.n_heads = slot_of + n + 1; P.head_list = slot_of + n + 2;
             HIP_TRY(ctx, launch_replay_heads(P, slot_of, slot_of + n + 1, slot_of + n + 2, (ReplayRegionOut*)d.d_rp[1], ctx->d_scratch,
                                              ctx->d_scratch_cap, d.stream_b));
+            // (round 5) the fast pre-pass settles the regions that are one run inside one window; the general kernel gets the rest
+            P.n_hard = slot_of + 2 * n + 4; P.hard_list = slot_of + 2 * n + 5;
+            if (replay_fast_covers(P) && !(getenv("SX_FAST_REPLAY") && !atoi(getenv("SX_FAST_REPLAY")))) {
+                HIP_TRY(ctx, hipMemsetAsync(P.n_hard, 0, 4, d.stream_b));
+                HIP_TRY(ctx, launch_replay_fast(P, (ReplayRegionOut*)d.d_rp[1], d.stream_b));
+                fast_pass = true;
+            } else { P.n_hard = nullptr; P.hard_list = nullptr; }
         }
         HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], d.stream_b));
+        if (fast_pass) {   // (statistics: how many regions each pass took; read with the totals below)
+            h_tot[32] = 0; h_tot[33] = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(h_tot + 32, P.n_hard, 4, hipMemcpyDeviceToHost, d.stream_b));
+            HIP_TRY(ctx, hipMemcpyAsync(h_tot + 33, P.n_heads, 4, hipMemcpyDeviceToHost, d.stream_b));
+        }
         // The host's copy of a device-joined run list: its share of this replay (the buffer's entry region, the exit state)
         // reads only the list's two ends — a large list is not copied whole (68 MB for the headline's 2.8 M runs, 1.2 ms on
         // the critical path when nothing else runs); the rest follows on demand (regions the device gives back).
@@ -176,14 +189,21 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
     if (dev_stitch && h_tot[kTotTooLong]) {  // regions for the host: it also decides what stands
         dev_stitch = false;
         HIP_TRY(ctx, runs.wait());
-        int rc = ensure_pinned2(ctx, n * sizeof(ReplayRegionOut) + 256);
+        const uint64_t keep32 = h_tot[32], keep33 = h_tot[33];
+        int rc = ensure_pinned2(ctx, n * sizeof(ReplayRegionOut) + 512);
         if (rc != SX_OK) return rc;
         h_tot = (uint64_t*)ctx->h_pin2;   // (its values are not read again)
-        ro = (ReplayRegionOut*)(ctx->h_pin2 + 128);
+        h_tot[32] = keep32; h_tot[33] = keep33;
+        ro = (ReplayRegionOut*)(ctx->h_pin2 + 384);
         HIP_TRY(ctx, hipMemcpyAsync(ro, d.d_rp[1], n * sizeof(ReplayRegionOut), hipMemcpyDeviceToHost, d.stream_b));
         HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
     }
     const double t1 = now_ms();
+    if (fast_pass && n) {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        ctx->stats.fast_regions += (uint32_t)h_tot[33] - (uint32_t)h_tot[32];
+        ctx->stats.general_regions += (uint32_t)h_tot[32];
+    }
 
     std::vector<uint64_t> valid, fbase, abase;
     uint64_t nf = 0, nb = 0, n_standing = 0;

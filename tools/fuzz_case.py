@@ -28,7 +28,11 @@ SWITCH_SETS = [{}, {}, {}, {"SX_NO_REPLAY_CACHE": "1"}, {"SX_HOST_STITCH": "1"},
                {"SX_WAVE_REPLAY": "1", "SX_WAVE_DESC": "0"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_DESC_CAP": "7"},
                {"SX_WAVE_REPLAY": "1", "SX_WAVE_THREADS": "0"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_THREADS": "0", "SX_DEFER_MIN_BYTES": "1"},
                {"SX_WAVE_REPLAY": "1", "SX_WAVE_DESC_CAP": "40", "SX_WAVE_SLABS": "4"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_DESC": "0", "SX_WAVE_BATCHES": "2"},
-               {"SX_WAVE_REPLAY": "1", "SX_WAVE_LUT": "1"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_LUT": "1", "SX_WAVE_BATCHES": "1"}]
+               {"SX_WAVE_REPLAY": "1", "SX_WAVE_LUT": "1"}, {"SX_WAVE_REPLAY": "1", "SX_WAVE_LUT": "1", "SX_WAVE_BATCHES": "1"},
+               # round 5: the lane-per-region path with and without its fast pre-pass (sx_replay_dev.hip replay_fast_kernel), on string-dense input too
+               {"SX_FAST_REPLAY": "0"}, {"SX_WAVE_REPLAY": "0"}, {"SX_WAVE_REPLAY": "0"}, {"SX_WAVE_REPLAY": "0", "SX_SLABS": "3"},
+               {"SX_WAVE_REPLAY": "0", "SX_REPLAY_CACHE_MIB": "1"}, {"SX_WAVE_REPLAY": "0", "SX_STITCH_BLOCK": "3"},
+               {"SX_WAVE_REPLAY": "0", "SX_FAST_REPLAY": "0", "SX_STITCH_BLOCK": "3"}, {"SX_WAVE_REPLAY": "0", "SX_NO_PIECES": "1"}]
 ALL_SWITCHES = sorted({k for s in SWITCH_SETS for k in s})
 
 
