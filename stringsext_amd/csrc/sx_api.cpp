@@ -64,6 +64,25 @@ int ensure_pinned(sx_ctx* ctx, uint64_t bytes) {
     ctx->h_pin_cap = bytes;
     return SX_OK;
 }
+static bool small_copy_on() { const char* e = getenv("SX_SMALL_COPY"); return !(e && !atoi(e)); }
+int read_back_async(sx_ctx* ctx, hipStream_t s, void* pinned_dst, const void* dev_src, size_t bytes) {
+    if (small_copy_on() && bytes <= (1u << 20) && ((((uintptr_t)pinned_dst | (uintptr_t)dev_src | bytes) & 3) == 0))
+        HIP_TRY(ctx, launch_small_copy(pinned_dst, dev_src, bytes, s));
+    else HIP_TRY(ctx, hipMemcpyAsync(pinned_dst, dev_src, bytes, hipMemcpyDeviceToHost, s));
+    return SX_OK;
+}
+int read_back_sync(sx_ctx* ctx, MissionDev& d, hipStream_t s, void* host_dst, const void* dev_src, size_t bytes) {
+    if (!small_copy_on() || bytes > kSmallReadBytes || ((((uintptr_t)dev_src | bytes) & 3) != 0)) {
+        HIP_TRY(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        return SX_OK;
+    }
+    if (!d.h_small) HIP_TRY(ctx, hipHostMalloc((void**)&d.h_small, kSmallReadBytes, hipHostMallocDefault));
+    HIP_TRY(ctx, launch_small_copy(d.h_small, dev_src, bytes, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    memcpy(host_dst, d.h_small, bytes);
+    return SX_OK;
+}
 int ensure_pinned2(sx_ctx* ctx, uint64_t bytes) {
     if (ctx->h_pin2_cap >= bytes) return SX_OK;
     if (ctx->h_pin2) HIP_TRY(ctx, hipHostFree(ctx->h_pin2));
@@ -326,6 +345,7 @@ void sx_destroy(sx_ctx* ctx) {
             if (d.ev_runs) (void)hipEventDestroy(d.ev_runs);
             if (d.stream_w) (void)hipStreamDestroy(d.stream_w);
             if (d.h_tot) (void)hipHostFree(d.h_tot);
+            if (d.h_small) (void)hipHostFree(d.h_small);
             for (hipEvent_t e : d.wave_ev) if (e) (void)hipEventDestroy(e);
             if (d.stream && d.stream != ctx->scan_stream) (void)hipStreamDestroy(d.stream);
         }

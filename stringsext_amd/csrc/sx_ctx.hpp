@@ -29,6 +29,7 @@
 namespace sx {
 
 double now_ms();
+constexpr size_t kSmallReadBytes = 4096;
 // SX_TIMELINE=1: host-side marks on stderr, milliseconds since the current scan call began (round 5: where a step's time goes)
 extern double g_tl_t0;
 extern int g_tl_on;
@@ -122,6 +123,7 @@ struct MissionDev {
     // its own stream, totals in its own pinned words, its own timing events (4 per slab: count begin / end, write begin / end)
     hipStream_t stream_w = nullptr;
     uint64_t* h_tot = nullptr;
+    uint8_t* h_small = nullptr;        // pinned, kSmallReadBytes: the target of read_back_sync (sx_api.cpp)
     std::vector<hipEvent_t> wave_ev;
 };
 
@@ -250,6 +252,11 @@ private:
 // grow-only buffers of the context (sx_api.cpp)
 int ensure_pinned(sx_ctx* ctx, uint64_t bytes);
 int ensure_pinned2(sx_ctx* ctx, uint64_t bytes);
+// `bytes` (<= kSmallReadBytes, 4-aligned) from device memory to `host_dst` (any host memory), waited for: a one-wavefront kernel into the
+// Mission's pinned staging words + a stream sync — not the runtime's blit copy (sx_sort.hip small_copy_kernel).  SX_SMALL_COPY=0: the runtime's
+int read_back_sync(sx_ctx* ctx, sx::MissionDev& d, hipStream_t s, void* host_dst, const void* dev_src, size_t bytes);
+// the same without the wait, into PINNED host memory (read after the caller's own sync)
+int read_back_async(sx_ctx* ctx, hipStream_t s, void* pinned_dst, const void* dev_src, size_t bytes);
 int ensure_scratch(sx_ctx* ctx, uint64_t bytes);
 int ensure_capacity(sx_ctx* ctx, ScanSlot& s, uint32_t cap);
 int ensure_rp(sx_ctx* ctx, MissionDev& d, int slot, uint64_t bytes);

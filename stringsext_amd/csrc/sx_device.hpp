@@ -241,6 +241,8 @@ hipError_t launch_merge_cuts(const sx_finding* f, uint64_t n, uint64_t nb, const
                              uint64_t* off, hipStream_t stream);
 size_t merge_findings_scratch_bytes(uint64_t n_findings, int n_missions);
 hipError_t launch_copy_bytes(void* dst, const void* src, uint64_t bytes, uint32_t workgroups, hipStream_t stream);
+// a few words (4-aligned, a multiple of 4 bytes) into pinned host memory by a one-wavefront kernel instead of the runtime's blit
+hipError_t launch_small_copy(void* pinned_dst, const void* dev_src, size_t bytes, hipStream_t stream);
 
 // order run records by start on the device (sx_sort.hip); unused slots end up last with start = ~0
 size_t sort_scratch_bytes(uint32_t n);

@@ -456,6 +456,25 @@ __global__ __launch_bounds__(1024) void copy_bytes_kernel(copy_v4u* __restrict__
     for (; i < n16; i += stride) dst[i] = src[i];
     if (blockIdx.x == 0 && threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
+// A few words from device memory into pinned host memory by ONE wavefront (round 5).  The runtime's device-to-host copy is a blit
+// kernel, and next to a scan kernel that keeps every wave slot filled its workgroups wait for room: the dozen small read-backs of a
+// stage B (counters, totals, list lengths) took anything from 0.05 to 10 ms each (profiles/r05b_kernel_timeline_*: `copyBuffer`
+// rows of 4.9 and 9.8 ms for 4 and 100 000 bytes).  A block of 64 threads finds a slot within microseconds.
+__global__ __launch_bounds__(64) void small_copy_kernel(uint32_t* dst, const uint32_t* src, uint32_t n_words) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x, nt = gridDim.x * 64;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+        const uint32_t n4 = n_words / 4;
+        for (uint32_t i = t; i < n4; i += nt) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+        for (uint32_t i = n4 * 4 + t; i < n_words; i += nt) dst[i] = src[i];
+    } else for (uint32_t i = t; i < n_words; i += nt) dst[i] = src[i];
+}
+hipError_t launch_small_copy(void* pinned_dst, const void* dev_src, size_t bytes, hipStream_t stream) {
+    if (!bytes) return hipSuccess;
+    if ((((uintptr_t)pinned_dst | (uintptr_t)dev_src | bytes) & 3) != 0 || bytes > (1u << 20)) return hipErrorInvalidValue;
+    const unsigned blocks = bytes <= 16384 ? 1u : (bytes <= 131072 ? 2u : 4u);   // (a wavefront each: room is found at once)
+    hipLaunchKernelGGL(small_copy_kernel, dim3(blocks), dim3(64), 0, stream, (uint32_t*)pinned_dst, (const uint32_t*)dev_src, (uint32_t)(bytes / 4));
+    return hipGetLastError();
+}
 hipError_t launch_copy_bytes(void* dst, const void* src, uint64_t bytes, uint32_t workgroups, hipStream_t stream) {
     if (!bytes) return hipSuccess;
     if ((((uintptr_t)dst | (uintptr_t)src) & 15) != 0) return hipErrorInvalidValue;

@@ -144,8 +144,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         bool skip_runs = false;
         for (int round = 0;; round++) {
             // (the two statistics arrive in shards — sx_device.hpp kStatBase —: one 2 KB copy, summed here)
-            HIP_TRY(ctx, hipMemcpyAsync(hc.data(), s.d_counters, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream_b));
-            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            { const int rb = read_back_sync(ctx, d, d.stream_b, hc.data(), s.d_counters, kCounterWords * sizeof(uint32_t)); if (rb != SX_OK) return rb; }
             counters[0] = hc[0]; counters[3] = hc[3];
             {
                 uint64_t heavy = 0, recs = 0;
@@ -232,8 +231,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             int rc = ensure_scratch(ctx, compact_scratch_bytes(s.n_regions)); if (rc != SX_OK) return rc;
             HIP_TRY(ctx, compact_regions(s.d_recs, s.d_cnt, s.n_regions, s.region_cap, s.d_packed, s.d_counters + 1, ctx->d_scratch,
                                          ctx->d_scratch_cap, d.stream_b));
-            HIP_TRY(ctx, hipMemcpyAsync(&nrec, s.d_counters + 1, 4, hipMemcpyDeviceToHost, d.stream_b));
-            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            { const int rb = read_back_sync(ctx, d, d.stream_b, &nrec, s.d_counters + 1, 4); if (rb != SX_OK) return rb; }
             d_records = s.d_packed;
             SX_TL("mission %d: regions packed (%u)", which[k], nrec);
         } else if (ctx->region_cap && !large_regions && nrec < s.n_regions * ctx->region_cap / 4)
@@ -256,8 +254,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             s.free_pending = true;
             if (getenv("SX_TIMING2")) { HIP_TRY(ctx, hipStreamSynchronize(d.stream_b)); fprintf(stderr, "[sx]   join done +%.2f ms\n", now_ms() - tc0); }
             uint32_t nruns32 = 0;
-            HIP_TRY(ctx, hipMemcpyAsync(&nruns32, s.d_counters + 2, 4, hipMemcpyDeviceToHost, d.stream_b));
-            HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+            { const int rb = read_back_sync(ctx, d, d.stream_b, &nruns32, s.d_counters + 2, 4); if (rb != SX_OK) return rb; }
             uint64_t nruns = nruns32;
             SX_TL("mission %d: joined (%u runs)", which[k], nruns32);
             const sx_run* d_list = (const sx_run*)d.d_rp[0];
@@ -274,8 +271,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                 uint64_t* d_total = (uint64_t*)ctx->d_scratch;   // the first 64 bytes; the rest is the split's scratch
                 HIP_TRY(ctx, launch_split_count(SP, ctx->d_scratch + 64, ctx->d_scratch_cap - 64, d_total, d.stream_b));
                 uint64_t total = 0;
-                HIP_TRY(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, d.stream_b));
-                HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
+                { const int rb = read_back_sync(ctx, d, d.stream_b, &total, d_total, 8); if (rb != SX_OK) return rb; }
                 if (total > nruns && total < (1ull << 32) && ensure_rp(ctx, d, 9, total * sizeof(sx_run)) == SX_OK) {
                     HIP_TRY(ctx, launch_split_write(SP, ctx->d_scratch + 64, total, (sx_run*)d.d_rp[9], d.stream_b));
                     HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));   // the list's copy for the host runs on another stream: complete first
@@ -308,7 +304,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             if (rc != SX_OK) return rc;
             DevRun* recs_p = (DevRun*)ctx->h_pin;
             if (nrec) {
-                HIP_TRY(ctx, hipMemcpyAsync(recs_p, d_records, (size_t)nrec * sizeof(DevRun), hipMemcpyDeviceToHost, d.stream_b));
+                { const int rb = read_back_async(ctx, d.stream_b, recs_p, d_records, (size_t)nrec * sizeof(DevRun)); if (rb != SX_OK) return rb; }   // (pinned: sx_ctx::h_pin)
                 HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
             }
             tc1 = now_ms();

@@ -133,8 +133,7 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
         HIP_TRY(ctx, launch_replay_count(P, (ReplayRegionOut*)d.d_rp[1], d.stream_b));
         if (fast_pass) {   // (statistics: how many regions each pass took; read with the totals below)
             h_tot[32] = 0; h_tot[33] = 0;
-            HIP_TRY(ctx, hipMemcpyAsync(h_tot + 32, P.n_hard, 4, hipMemcpyDeviceToHost, d.stream_b));
-            HIP_TRY(ctx, hipMemcpyAsync(h_tot + 33, P.n_heads, 4, hipMemcpyDeviceToHost, d.stream_b));
+            { int rb = read_back_async(ctx, d.stream_b, h_tot + 32, P.n_hard, 4); if (rb == SX_OK) rb = read_back_async(ctx, d.stream_b, h_tot + 33, P.n_heads, 4); if (rb != SX_OK) return rb; }
         }
         // The host's copy of a device-joined run list: its share of this replay (the buffer's entry region, the exit state)
         // reads only the list's two ends — a large list is not copied whole (68 MB for the headline's 2.8 M runs, 1.2 ms on
@@ -180,7 +179,7 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
         HIP_TRY(ctx, launch_stitch_finish(P, (const ReplayRegionOut*)d.d_rp[1], (uint8_t*)d.d_rp[2], d.d_rp[6], E,
                                           (uint64_t*)d.d_rp[3], (uint64_t*)d.d_rp[4], (uint64_t*)d.d_rp[7], ctx->d_scratch,
                                           ctx->d_scratch_cap, d.stream_b));
-        HIP_TRY(ctx, hipMemcpyAsync(h_tot, d.d_rp[7], kTotCount * 8, hipMemcpyDeviceToHost, d.stream_b));
+        { const int rb = read_back_async(ctx, d.stream_b, h_tot, d.d_rp[7], kTotCount * 8); if (rb != SX_OK) return rb; }
     }
     SX_TL("  replay: pass 1 + stitch queued, host entry part done");
     if (n) HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
@@ -412,7 +411,7 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
         P.runs = runs.dev_ptr; P.n_runs = n; P.W = (uint32_t)ctx->missions[k].window; P.grep_char = ctx->missions[k].c.grep_char;
         uint64_t* d_cut = (uint64_t*)ctx->d_scratch;
         HIP_TRY(ctx, launch_slab_cuts(P, (uint32_t)K, d_cut, d_cut + 64, d.stream_b));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin2, d_cut, 128 * 8, hipMemcpyDeviceToHost, d.stream_b));
+        { const int rb = read_back_async(ctx, d.stream_b, ctx->h_pin2, d_cut, 128 * 8); if (rb != SX_OK) return rb; }
         HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
         const uint64_t* h = (const uint64_t*)ctx->h_pin2;
         for (size_t j = 1; j < K; j++)
