@@ -158,6 +158,7 @@ typedef struct sx_stats {
     uint64_t seq_pieces;                 /* pieces a buffer with gigabytes of output was scanned in, one after the other (0: in one go) */
     uint64_t fast_regions;               /* (ABI 3) stage B, lane per region: regions settled by the fast pre-pass (one run inside one window) ... */
     uint64_t general_regions;            /* ... and regions it left to the general replay kernel */
+    uint64_t wave_repairs;               /* (ABI 3) wave stage B: count launches repeated for wavefronts whose warm-up windows gave them a wrong entry state (-g) */
 } sx_stats;
 
 typedef struct sx_ctx sx_ctx;

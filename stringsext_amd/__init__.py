@@ -168,7 +168,7 @@ class Stats(C.Structure):
                 ("total_ms", C.c_double), ("heavy_tiles", C.c_uint64), ("wave_windows", C.c_uint64),
                 ("wave_count_ms", C.c_double), ("wave_write_ms", C.c_double), ("rescans", C.c_uint64), ("rescan_ms", C.c_double),
                 ("wave_desc_overflows", C.c_uint64), ("seq_pieces", C.c_uint64),
-                ("fast_regions", C.c_uint64), ("general_regions", C.c_uint64)]
+                ("fast_regions", C.c_uint64), ("general_regions", C.c_uint64), ("wave_repairs", C.c_uint64)]
 
 
 class Options(C.Structure):

@@ -221,6 +221,14 @@ struct WaveParams {
     // 0x3F); a wavefront that meets two gives up at once, and the host gives the buffer back if the set (with the leftover's) holds two
     uint64_t* lead_set;       // device, or nullptr: no -r
     uint64_t ubf;
+    int32_t grep_char;        // -g (round 5): the ASCII code every string must hold, -1: none (sx_wave_core.hpp WvWin::GC)
+    // Round 5, repairs.  With -g the state a window hands on can depend on how far back a stretch began (a stretch of accepted chars without
+    // the grep char hands on "q chars carried" and "nothing" in turns, window by window), so a wavefront's warm-up windows may leave it with
+    // a wrong entry state — before: the whole buffer went back to the lane-per-region path.  redo: a count launch in which only the
+    // wavefronts whose assumption was wrong (wave_in[v] != wave_out[v - 1]) run again, from wave_out[v - 1] at their first own window and
+    // without warm-up; the host repeats it until the verification passes (a chain of wrong wavefronts needs a launch per link).
+    // use_entry: the window-parallel writer takes wave_out[v - 1] the same way (set after repairs; families 0-2).
+    uint32_t redo, use_entry;
 };
 size_t wave_scratch_bytes(uint64_t n_waves);
 // pass 1 of wavefronts [v0, v1) + exclusive sums from v0 on + verification; totals (device, 4 x u64): findings, string bytes,

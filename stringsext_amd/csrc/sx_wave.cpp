@@ -133,7 +133,9 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             }
             if (lc && !lback) return SX_WAVE_FALLBACK;
         }
-        const WvState in{ lc, lb, lc ? lback : 0u, st.last_run_str_was_printed_and_is_maybe_cut_str ? 1u : 0u };
+        // (-g: does the leftover hold the grep char?  SplitStr walks its chars again when it is prepended, helper.rs:252-254)
+        const uint32_t lg = m.c.grep_char >= 0 && st.last_scan_run_leftover.find((char)m.c.grep_char) != std::string::npos ? 1u : 0u;
+        const WvState in{ lc, lb, lc ? lback : 0u, st.last_run_str_was_printed_and_is_maybe_cut_str ? 1u : 0u, lc ? lg : 0u };
         const uint64_t n_windows = g_all - g_lo;
         uint64_t batches = (n_windows + (8192ull * 64) - 1) / (8192ull * 64);
         batches = std::max<uint64_t>(1, std::min<uint64_t>(8, batches));
@@ -200,6 +202,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             if (__builtin_popcountll(left_leads) > 1) return SX_WAVE_FALLBACK;
         }
         P.lead_set = d_leads; P.ubf = m.c.ubf;
+        P.grep_char = m.c.grep_char;
         P.wave_fbase = d_fb; P.wave_abase = d_ab;
         // Descriptors for the lane-per-finding writer: room for twice the findings a wavefront is expected to hold (the last buffer's
         // density; stage A's record count; else one per window), at most two per window and a third of the input's size in all.  A
@@ -257,11 +260,37 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
                 if (getenv("SX_TIMING")) fprintf(stderr, "[sx] wave replay mission %zu: -r and two kinds of lead bytes in this buffer: lane-per-region path\n", k);
                 return abandon(SX_WAVE_FALLBACK);
             }
+            // Round 5: wavefronts whose warm-up windows led them to a wrong entry state run again from what their predecessor really left
+            // (WaveParams::redo) — with -g a stretch without the grep char hands on "q chars carried" and "nothing" in turns, as far back as
+            // it began — until the verification passes; a chain of wrong wavefronts takes a launch per link.  (Before: any wrong
+            // assumption sent the whole buffer to the lane-per-region path.)
+            bool repaired = false;
+            if ((h_tot[4 * j + 2] & 0xFFFFFFFFull) != 0 && (h_tot[4 * j + 3] >> 32) == 0 && !getenv("SX_WAVE_FAIL") && !(getenv("SX_WAVE_REPAIR") && !atoi(getenv("SX_WAVE_REPAIR")))) {
+                const int max_rounds = getenv("SX_WAVE_REPAIR") ? std::max(1, atoi(getenv("SX_WAVE_REPAIR"))) : 48;
+                P.redo = 1;
+                for (int round = 0; round < max_rounds && (h_tot[4 * j + 2] & 0xFFFFFFFFull) != 0; round++) {
+                    HIP_TRY(ctx, launch_wave_count(P, v0, v1, d_fb, d_ab, d_tot + 4 * j, w_scratch, w_scratch_cap, sb));
+                    HIP_TRY(ctx, hipMemcpyAsync(h_tot + 4 * j, d_tot + 4 * j, 4 * 8, hipMemcpyDeviceToHost, sb));
+                    HIP_TRY(ctx, hipStreamSynchronize(sb));
+                    std::lock_guard<std::mutex> g(ctx->mu);
+                    ctx->stats.wave_repairs++;
+                }
+                P.redo = 0;
+                repaired = true;
+                HIP_TRY(ctx, hipEventRecord(d.wave_ev[4 * j + 1], sb));   // (the count pass' time includes its repairs)
+            }
             if ((h_tot[4 * j + 2] & 0xFFFFFFFFull) != 0 || getenv("SX_WAVE_FAIL")) {   // (SX_WAVE_FAIL: tests of the way back)
                 if (getenv("SX_TIMING")) fprintf(stderr, "[sx] wave replay mission %zu: %llu wavefronts assumed a wrong entry state: lane-per-region path\n", k, (unsigned long long)(h_tot[4 * j + 2] & 0xFFFFFFFFull));
                 return abandon(SX_WAVE_FALLBACK);
             }
             const bool by_desc = P.desc && (h_tot[4 * j + 2] >> 32) == 0;   // every wavefront of the slab left all its descriptors
+            // (after repairs the window-parallel writer must start every wavefront from the state its predecessor left, not from its own
+            // warm-up windows; the two-byte family's token grid is published per launch geometry: that combination goes back)
+            P.use_entry = 0;
+            if (repaired && !by_desc) {
+                if (m.wave_family >= 4) return abandon(SX_WAVE_FALLBACK);
+                P.use_entry = 1;
+            }
             if (P.desc && !by_desc) { std::lock_guard<std::mutex> g(ctx->mu); ctx->stats.wave_desc_overflows++; }
             const uint64_t nf = h_tot[4 * j], nb = h_tot[4 * j + 1];
             if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   ... counted %llu findings, %llu bytes at +%.2f ms\n", (unsigned long long)nf, (unsigned long long)nb, now_ms() - t0);

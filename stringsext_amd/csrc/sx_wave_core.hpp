@@ -97,12 +97,13 @@ SXD u32 wm_select(WvMask m, u32 from, u32 k) {
 // ------------------------------------------------------------------------------------------
 // State carried from window to window, packed into 32 bits for the lane-to-lane exchange
 // ------------------------------------------------------------------------------------------
-struct WvState { u32 lc, lb, lback, cut; };
-SXD u32 wv_pack(const WvState& s) { return s.lc | (s.lb << 7) | (s.lback << 16) | (s.cut << 26); }
-SXD WvState wv_unpack(u32 v) { return WvState{ v & 127u, (v >> 7) & 511u, (v >> 16) & 1023u, (v >> 26) & 1u }; }
+// (round 5, -g: lg = the leftover holds the grep char — SplitStr walks the leftover's chars again when it is prepended, helper.rs:252-254)
+struct WvState { u32 lc, lb, lback, cut, lg; };
+SXD u32 wv_pack(const WvState& s) { return s.lc | (s.lb << 7) | (s.lback << 16) | (s.cut << 26) | (s.lg << 29); }
+SXD WvState wv_unpack(u32 v) { return WvState{ v & 127u, (v >> 7) & 511u, (v >> 16) & 1023u, (v >> 26) & 1u, (v >> 29) & 1u }; }
 constexpr u32 kWvPendBit = 1u << 27;   // on the state after a buffer's LAST window only, bits 27-28: bytes of the token it ends inside (two-byte family: 1; EUC-JP: 1 / 2)
 
-struct WvParams { u32 q, n_min; };
+struct WvParams { u32 q, n_min, grep; };   // grep: the Mission has -g (WvWin::GC says where its char stands)
 
 // One window as the state machine sees it.
 struct WvWin {
@@ -123,6 +124,8 @@ struct WvWin {
     u32 head_pend;   // double byte: bytes in front of the window that belong to a token still incomplete there (a pending lead byte: 0 / 1)
     u32 tail_pend;   // double byte: the window ends inside a token (its last byte is a lead byte waiting for its trail)
     WvMask PB;       // UTF-16: a call that starts here (in the masks) really starts two bytes later — its first character was kept from the call before
+    WvMask GC;       // -g (WvParams::grep): the E bits of the characters that ARE the grep char (an ASCII character, accepted or not: helper.rs:252-254
+                     // looks at it before the filter does)
 };
 
 enum { WV_BEFORE = 0, WV_EXACT = 1, WV_AFTER = 2 };   // == SX_PRECISION_*
@@ -138,8 +141,10 @@ SXD u32 wv_probe_hb(u32 prec) { return (prec >> 27) & 3u; }
 SXD u32 wv_probe_pend(u32 prec) { return (prec >> 29) & 3u; }
 
 // (same_block: -r as far as it can matter — csrc/sx_mission.cpp drops it where at most one UTF-8 lead byte passes the filter, helper.rs:279-296)
+// (round 5: -g is covered — a stretch, or a line of q chars cut out of one, counts only if it holds the grep char, and a line of q chars without
+// it that neither completes the string before nor is carried on ends SplitStr's iteration for the rest of the call's text, helper.rs:410-415)
 SXD bool wv_mission_ok(int grep_char, u32 same_block, u32 n_min, u32 q) {
-    return grep_char < 0 && !same_block && n_min >= 1 && n_min <= q && q <= 64;
+    return grep_char < 128 && !same_block && n_min >= 1 && n_min <= q && q <= 64;
 }
 
 // One decoder call [din, cend) of the window: finding_collection.rs:146-290 with SplitStr::next (helper.rs:206-433) restated per
@@ -163,9 +168,10 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
     const bool cont = st.cut != 0;   // :240-241: consumed by this call whatever it yields
     st.cut = 0;
     const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback;
+    const bool lg_in = st.lg != 0;
     const u32 lsrc = KIND >= 2 ? lback - (first_call || din == 0 ? w.head_pend : 0u) : lback;   // the leftover's own source bytes
     const bool has_left = lrem > 0;
-    st.lc = 0; st.lb = 0; st.lback = 0;   // :211-227: the leftover is prepended, then gone
+    st.lc = 0; st.lb = 0; st.lback = 0; st.lg = 0;   // :211-227: the leftover is prepended, then gone
     const WvMask rng = wm_range(din, cend);
     const WvMask Ec = wm_and(w.E, rng);
     if (!has_left && !wm_any(Ec)) return;
@@ -181,10 +187,13 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
     }
 
     // One stretch: `pre` chars carried in front of it (the leftover), its accepted chars = the E bits in [a, er).
-    // comp0: its first piece completes the string before.
-    auto stretch = [&](u32 a, u32 er, u32 pre, bool comp0) {
+    // comp0: its first piece completes the string before.  Returns true if SplitStr's iteration ends here for the whole call (-g: a line
+    // of q chars without the grep char that neither completes the string before nor is carried on, helper.rs:410-415).
+    const bool GREP = P.grep != 0;
+    auto stretch = [&](u32 a, u32 er, u32 pre, bool comp0) -> bool {
         const WvMask av = wm_and(Ec, wm_range(a, er));
         const bool ends_by_rej = er < 128;          // a rejected char follows (else the call's text ends with it)
+        const bool rej_is_grep = GREP && ends_by_rej && wm_test(w.GC, er);   // ... and it is the grep char: it counts for the stretch it ends (helper.rs:252-254)
         u32 rem = pre + wm_popc(av);
         u32 at = a;                                  // E bit of the next char to hand out
         i32 src = 0;                                 // first source byte of the next piece
@@ -198,12 +207,21 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
             const bool is_q = pn == P.q;
             rem -= pn;
             const bool tr = rem == 0 && !ends_by_rej;                       // touches the end of the call's text
-            if (!is_q && !tr && !comp && pn < P.n_min) return;              // helper.rs:315-330: dropped
-            const bool maybe_cut = is_q || (tr && !invalid_after);          // :353-355
-            const bool again = !comp && tr && !invalid_after && !is_q;      // :389-392
-            if (!comp && !again && pn < P.n_min) return;                    // :410-415 (the text ends here anyway)
+            if (!GREP && !is_q && !tr && !comp && pn < P.n_min) return false;   // helper.rs:315-330: dropped
             // the piece's chars inside the window: pn - carried of them, from E bit `at` on
             const u32 inwin = pn - carried;
+            bool gok = true;
+            if (GREP) {   // does the piece hold the grep char?  (the leftover's chars are walked again: lg; a piece of fewer than q chars that a rejected char ends: that char too)
+                gok = (carried && lg_in) || (!is_q && rem == 0 && rej_is_grep);
+                if (!gok && inwin) {
+                    const u32 le = BYTES ? at + inwin - 1 : wm_select(av, at, inwin);
+                    gok = wm_any(wm_and(w.GC, wm_range(at, le + 1)));
+                }
+                if (!is_q && !tr && !comp && (pn < P.n_min || !gok)) return false;   // helper.rs:315-330: dropped, the walk goes on behind the rejected char
+            }
+            const bool maybe_cut = is_q || (tr && !invalid_after);          // :353-355
+            const bool again = !comp && tr && !invalid_after && (!is_q || !gok);   // :389-392 (without -g a line of q chars is never carried)
+            if (!comp && !again && (pn < P.n_min || !gok)) return is_q;     // :410-415: None — the rest of the call's text is never looked at (it only has a rest behind a line of q chars)
             u32 last_e = at, out_b = carried_b;
             // (a leftover on its own: its source bytes; UTF-8: lback also counts the bytes of a character that was pending behind it)
             i32 src_end = src + (i32)(carried ? (KIND == 1 ? lbytes : lsrc) : 0u);
@@ -218,7 +236,7 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
                     out_b += inwin + wm_popc(wm_and(w.O2, tr_)) + wm_popc(wm_and(w.O3, tr_)) + wm_popc(wm_and(w.O4, tr_));
                 } else out_b = (u32)(src_end - src);    // UTF-8 in, UTF-8 out: the string is the source bytes
             }
-            if (again) { st.lc = pn; st.lb = out_b; st.lback = (u32)((i32)w.n - src); st.cut = 0; }   // finding_collection.rs:269-285
+            if (again) { st.lc = pn; st.lb = out_b; st.lback = (u32)((i32)w.n - src); st.cut = 0; st.lg = GREP && gok ? 1u : 0u; }   // finding_collection.rs:269-285
             else {                                                                                     // :255-268
                 // (UTF-16: the empty call in front of byte 0 is the real call [0, 2) — it starts where it says)
                 emit(din + (KIND == 3 && cend > din && wm_test(w.PB, din) ? 2u : 0u), prec, comp, src, (u32)(src_end - src), out_b);
@@ -230,6 +248,7 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
             src = src_end;
             if (inwin) at = last_e + 1;
         }
+        return false;
     };
 
     // ---- the stretch at the start of the text
@@ -238,7 +257,7 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
     u32 pos = din;                                                   // stretches that begin below pos are done
     if (has_left || first_acc) {
         const u32 er = first_acc ? wm_next(Rc, fe) : (fe < 128 ? fe : 128u);   // leftover alone: the rejected char right behind it, or nothing
-        stretch(first_acc ? fe : (fe < 128 ? fe : cend), er, lrem, cont);
+        if (stretch(first_acc ? fe : (fe < 128 ? fe : cend), er, lrem, cont)) return;
         pos = er < 128 ? er + 1 : 128u;
     }
     // ---- long stretches behind it
@@ -258,7 +277,7 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
         if (tail_a >= pos && tail_a < a) a = tail_a;
         if (a >= 128) break;
         const u32 er = wm_next(Rc, a);
-        stretch(a, er, 0u, false);
+        if (stretch(a, er, 0u, false)) return;
         pos = er < 128 ? er + 1 : 128u;
     }
 }
@@ -333,14 +352,16 @@ SXD WvTail wv_tail(const WvParams& P, const WvWin& w) {
     const u32 a = wm_next(El, r < 0 ? 0u : (u32)r + 1);
     const WvMask rng = wm_range(a, (u32)el + 1);
     const u32 c = wm_popc(wm_and(El, rng));
-    if (c >= P.q) return WvTail{ a, wv_pack(WvState{ 0, 0, 0, 1 }) };
+    // (with -g this is only a guess: a line of q chars without the grep char is no string, and may end the walk — the state is then
+    // settled by wv_window like any other stretch's, tail_simple is false for it)
+    if (c >= P.q) return WvTail{ a, wv_pack(WvState{ 0, 0, 0, 1, 0 }) };
     i32 src;
     if (BYTES) src = (i32)a;
     else { const i32 f = wm_prev(w.F, a); src = f < 0 ? -(i32)w.head_back : f; }
     u32 out_b;
     if (KIND == 1) out_b = (u32)(el + 1 - src);
     else out_b = c + wm_popc(wm_and(w.O2, rng)) + (BYTES ? 2 * wm_popc(wm_and(w.O3, rng)) : wm_popc(wm_and(w.O3, rng)) + wm_popc(wm_and(w.O4, rng)));
-    return WvTail{ a, wv_pack(WvState{ c, out_b, (u32)((i32)w.n - src), 0 }) };
+    return WvTail{ a, wv_pack(WvState{ c, out_b, (u32)((i32)w.n - src), 0, P.grep && wm_any(wm_and(w.GC, rng)) ? 1u : 0u }) };
 }
 // What the window hands on if what it was handed does not matter: every lane starts the exchange of the entry states from its
 // predecessor's guess instead of from "nothing carried" (which is wrong behind every window that ends inside a line of text or in
@@ -360,8 +381,9 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, c
         if (KIND != 3 && w.slice_start && st.lb) probe = wv_probe_pack(st.lb, st.lback) | (KIND == 2 ? w.head_pend << 29 : 0u);
         const bool cont = st.cut != 0;
         const u32 lc = st.lc, lb = st.lb, lback = st.lback;
-        st.lc = 0; st.lb = 0; st.lback = 0; st.cut = 0;
-        if (lc && (cont || lc >= P.n_min))   // (its text ends with the call, the call in an error: helper.rs:410-415)
+        const bool lgp = st.lg != 0;
+        st.lc = 0; st.lb = 0; st.lback = 0; st.cut = 0; st.lg = 0;
+        if (lc && (cont || (lc >= P.n_min && (!P.grep || lgp))))   // (its text ends with the call, the call in an error: helper.rs:410-415)
             emit(0u, (u32)WV_BEFORE, cont, -(i32)lback, KIND == 1 ? lb : (KIND >= 2 ? lback - w.head_pend : lback), lb);
     }
     // ---- the call in hand
@@ -372,18 +394,22 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, c
     const bool cont0 = st.cut != 0;
     st.cut = 0;
     const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback;
+    const bool lg_in = st.lg != 0;
     const u32 lsrc = KIND >= 2 ? lback - w.head_pend : lback;
     const bool has_left = lrem > 0;
-    st.lc = 0; st.lb = 0; st.lback = 0;
+    st.lc = 0; st.lb = 0; st.lback = 0; st.lg = 0;
+    const bool GREP = P.grep != 0;
     u32 prec = (has_left || w.probe_before) ? WV_BEFORE : WV_EXACT;
     u32 cut_cend = 0;   // end of the call whose emission left st.cut up
     const bool tail_simple = wv_unpack(tail.state).lc != 0;   // the tail, taken alone, is just the leftover
 
     // wv_call's stretch, for the call in hand: `pre` chars carried in front (the leftover), accepted chars = the E bits in [a, er).
     // It runs ONCE per trip of the loop below, and only for stretches that yield or carry (a wavefront pays for it whenever one lane needs it)
-    auto stretch = [&](u32 a, u32 er, u32 pre, bool comp0) {
+    // (returns true if SplitStr's iteration ends here for the whole call: -g, wv_call)
+    auto stretch = [&](u32 a, u32 er, u32 pre, bool comp0) -> bool {
         const WvMask av = wm_and(Ec, wm_range(a, er));
         const bool ends_by_rej = er < 128;
+        const bool rej_is_grep = GREP && ends_by_rej && wm_test(w.GC, er);
         u32 rem = pre + wm_popc(av);
         u32 at = a;
         i32 src = 0;
@@ -397,11 +423,20 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, c
             const bool is_q = pn == P.q;
             rem -= pn;
             const bool tr = rem == 0 && !ends_by_rej;
-            if (!is_q && !tr && !comp && pn < P.n_min) return;              // helper.rs:315-330
-            const bool maybe_cut = is_q || (tr && !inv_after);              // :353-355
-            const bool again = !comp && tr && !inv_after && !is_q;          // :389-392
-            if (!comp && !again && pn < P.n_min) return;                    // :410-415
+            if (!GREP && !is_q && !tr && !comp && pn < P.n_min) return false;   // helper.rs:315-330
             const u32 inw = pn - carried;
+            bool gok = true;
+            if (GREP) {
+                gok = (carried && lg_in) || (!is_q && rem == 0 && rej_is_grep);
+                if (!gok && inw) {
+                    const u32 le = BYTES ? at + inw - 1 : (rem == 0 ? (u32)wm_prev(av, 127) : wm_select(av, at, inw));
+                    gok = wm_any(wm_and(w.GC, wm_range(at, le + 1)));
+                }
+                if (!is_q && !tr && !comp && (pn < P.n_min || !gok)) return false;
+            }
+            const bool maybe_cut = is_q || (tr && !inv_after);              // :353-355
+            const bool again = !comp && tr && !inv_after && (!is_q || !gok);   // :389-392
+            if (!comp && !again && (pn < P.n_min || !gok)) return is_q;     // :410-415
             u32 last_e = at, out_b = carried_b;
             i32 src_end = src + (i32)(carried ? (KIND == 1 ? lbytes : lsrc) : 0u);
             if (inw) {
@@ -414,7 +449,7 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, c
                     out_b += inw + wm_popc(wm_and(w.O2, tr_)) + (BYTES ? 2 * wm_popc(wm_and(w.O3, tr_)) : wm_popc(wm_and(w.O3, tr_)) + wm_popc(wm_and(w.O4, tr_)));
                 }
             }
-            if (again) { st.lc = pn; st.lb = out_b; st.lback = (u32)((i32)n - src); st.cut = 0; }   // finding_collection.rs:269-285
+            if (again) { st.lc = pn; st.lb = out_b; st.lback = (u32)((i32)n - src); st.cut = 0; st.lg = GREP && gok ? 1u : 0u; }   // finding_collection.rs:269-285
             else {                                                                                   // :255-268
                 emit(din + (KIND == 3 && wm_test(w.PB, din) ? 2u : 0u), prec, comp, src, (u32)(src_end - src), out_b);
                 st.lc = 0; st.lb = 0; st.lback = 0; st.cut = maybe_cut ? 1u : 0u;
@@ -426,6 +461,7 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, c
             src = src_end;
             if (inw) at = last_e + 1;
         }
+        return false;
     };
 
     // ---- the first call's text-start stretch: the next trip's work (`have`), or settled here
@@ -490,8 +526,8 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, c
             pre = 0;
         }
         have = false;
-        stretch(a, er, pre, comp0);
-        pos = er < 128 ? er + 1 : cend;
+        const bool abandoned = stretch(a, er, pre, comp0);
+        pos = abandoned ? cend : (er < 128 ? er + 1 : cend);   // (-g, a line of q chars without the grep char: nothing more of this call's text is looked at)
         forced = 128;
         if (st.cut && cend < n) {
             const u32 fe2 = wm_next(w.E, cend);
@@ -1410,6 +1446,44 @@ SXD u32 wv_transcode_dbcs(int enc, const uint16_t* table, const u8* s, u32 n, u8
         p++;
     }
     return w;
+}
+
+// ------------------------------------------------------------------------------------------
+// -g (round 5): WvWin::GC.  The bytes of the window that are the grep char, read by the window's own lane (eight loads of 16 bytes —
+// the lines are in the cache: the batch's classification has just read them; only Missions with -g do this) and compared as SWAR;
+// UTF-16 (KIND 3): the UNITS that are the grep char, marked on their last byte like E.  Restricted to characters where the window is
+// complete: wv_set_grep.
+// ------------------------------------------------------------------------------------------
+template <int KIND>
+SXD WvMask wv_grep_bytes(const u8* p, u32 n, u32 g, bool be) {
+    WvMask r{ 0, 0 };
+    const u32 pat = KIND == 3 ? (be ? (g << 8) : g) * 0x00010001u : g * 0x01010101u;
+#pragma unroll
+    for (u32 k = 0; k < 8; k++) {
+        if (16 * k >= n) break;
+        const u32 nb = n - 16 * k < 16 ? n - 16 * k : 16u;
+        u32 x[4] = { 0, 0, 0, 0 };
+        if (nb == 16) __builtin_memcpy(x, p + 16 * k, 16);
+        else for (u32 t = 0; t < nb; t++) x[t >> 2] |= (u32)p[16 * k + t] << (8 * (t & 3));
+        u32 f[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const u32 y = x[d] ^ pat;
+            if (KIND == 3) f[d] = ~(((y & 0x7FFF7FFFu) + 0x7FFF7FFFu) | y) & 0x80008000u;   // units that are zero: a flag on their last byte
+            else f[d] = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
+        }
+        u64 m = wv_movemask16_b7(f[0], f[1], f[2], f[3]);
+        if (nb < 16) m &= (1ull << nb) - 1ull;
+        if (k < 4) r.lo |= m << (16 * k); else r.hi |= m << (16 * (k - 4));
+    }
+    return r;
+}
+// KIND 0 / 1: every ASCII byte that is a character (E); 2: a byte that is a character of its own (its first and last byte); 3: a unit (E)
+template <int KIND>
+SXD void wv_set_grep(WvWin& w, const WvParams& P, const u8* win_bytes, u32 g, bool be) {
+    if (!P.grep) { w.GC = wm_zero(); return; }
+    const WvMask raw = wv_grep_bytes<KIND>(win_bytes, w.n, g, be);
+    w.GC = wm_and(raw, KIND == 2 ? wm_and(w.E, w.F) : w.E);
 }
 
 // ------------------------------------------------------------------------------------------

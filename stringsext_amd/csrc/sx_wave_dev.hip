@@ -173,8 +173,20 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
     const u64 own_start = P.g_lo + v * P.nwin;
     if (v >= P.v1 || own_start >= P.g_hi) return;
     const u64 own_end = own_start + P.nwin < P.g_hi ? own_start + P.nwin : P.g_hi;
-    const u64 gw = v == 0 ? own_start : own_start - kWvWarm;
-    u32 carry = v == 0 ? P.inject : 0u;   // entry state of the batch's first window
+    // (round 5) the entry state of the first own window is KNOWN — what the wavefront in front left: a repair launch of the count pass
+    // (WaveParams::redo), the writer after repairs (use_entry) — and there are no warm-up windows
+    bool known = false;
+    u32 known_state = 0;
+    if (v != 0 && ((MODE == 0 && P.redo) || (MODE == 1 && P.use_entry))) {
+        known_state = __hip_atomic_load(P.wave_out + (v - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MODE == 0) {
+            const u32 mine = P.wave_in[v];
+            if (mine == known_state || mine == 0xFFFFFFFEu) return;   // its assumption was right (or it gave the buffer back: nothing to repair)
+        }
+        known = true;
+    }
+    const u64 gw = (v == 0 || known) ? own_start : own_start - kWvWarm;
+    u32 carry = v == 0 ? P.inject : (known ? known_state : 0u);   // entry state of the batch's first window
     u32 assumed_in = carry;
     u32 tot_f = 0, tot_b = 0;
     u32 dbcs_cov = 0;   // FAM 4: bytes at the next tile's start that belong to a token begun before it (0 / 1)
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
     u32 ref_cov = 0;
     u64 fbase = 0, abase = 0;
     if (MODE == 1) { fbase = P.wave_fbase[v] - P.f_sub; abase = P.wave_abase[v] - P.a_sub; }   // relative to this launch's output segment
-    const WvParams WP{ P.q, P.n_min };
+    const WvParams WP{ P.q, P.n_min, P.grep_char >= 0 ? 1u : 0u };
 
     for (u64 g0 = gw; g0 < own_end; g0 += kWvBatch) {
         const u64 g = g0 + lane;
@@ -524,7 +536,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             }
             edge_back = eb;
         }
-        if (FAM == 4 && P.wave_grid && g0 == gw && lane == 0)   // the hang-over at my first tile: the wavefront behind me may be waiting for it
+        if (FAM == 4 && P.wave_grid && g0 == gw && lane == 0 && !known)   // the hang-over at my first tile: the wavefront behind me may be waiting for it (a repair launch: published by the first one, at THAT launch's first tile)
             __hip_atomic_store(P.wave_grid + v, 1u | (dbcs_cov << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int t_ref = next_t0 >= tile0 ? (int)((next_t0 - tile0) / kTileBytes) : 0;   // the last tile that starts at or in front of the next batch's first
         for (int t = 0; t < (int)n_tiles; t++) {
@@ -600,10 +612,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             }
         }
 
+        constexpr int KIND = FAM == 0 ? 0 : FAM == 1 ? 1 : FAM == 2 ? 3 : 2;
+        // -g (round 5): which of the window's characters are the grep char — every lane from its own window's bytes (in the cache: the
+        // batch's classification has just read them); a wave-uniform branch, nothing for Missions without -g
+        if (WP.grep) { if (active && wn) wv_set_grep<KIND>(w, WP, P.data + ws, (u32)P.grep_char, P.encoding == (u32)kEncUtf16be); else w.GC = wm_zero(); }
+        else w.GC = wm_zero();
+
         // ---- 3. entry states: iterate until they are consistent along the lanes
         // (the exchange starts from every window's guess of what it hands on — wv_exit_guess: exact unless the window's last stretch is
         // the text-start stretch of its call and something is carried into it —, not from "nothing carried": one round, not two or three)
-        constexpr int KIND = FAM == 0 ? 0 : FAM == 1 ? 1 : FAM == 2 ? 3 : 2;
         const WvTail tail = active ? wv_tail<KIND>(WP, w) : WvTail{ 128u, 0u };   // (the window's last stretch: looked at once, used by every replay of it)
         u32 out = tail.state;
         u32 in = wv_from_prev(out, carry);
@@ -637,7 +654,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             in = pin;
             if (!__ballot(todo)) break;
         }
-        if (g0 == gw && v != 0) {   // the state this wavefront assumes for its first own window (lane kWvWarm of the first batch)
+        if (g0 == gw && v != 0 && !known) {   // the state this wavefront assumes for its first own window (lane kWvWarm of the first batch)
             assumed_in = (u32)__builtin_amdgcn_readlane(in, (int)kWvWarm);
         }
         carry = (u32)__builtin_amdgcn_readlane(out, 63);
@@ -688,14 +705,16 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
 
 // Every wavefront after the first assumed "nothing carried" kWvWarm windows in front of its own; is the state it
 // reached for its first own window what its predecessor really left there?  totals: [0] findings, [1] string bytes,
-// [2] wavefronts whose assumption was wrong, [3] the state after the last window.
+// [2] wavefronts whose assumption was wrong (high half: wavefronts with more findings than descriptors), [3] the state after the last
+// window (high half: wavefronts that gave the buffer back).
 __global__ __launch_bounds__(256) void wave_verify_kernel(const u32* wave_in, const u32* wave_out, const u32* wave_nf, const u32* wave_nb,
                                                           const u64* fbase, const u64* abase, u64 v0, u64 v1, u64* totals, u32 desc_cap) {
     const u64 v = v0 + (u64)blockIdx.x * 256 + threadIdx.x;
     if (v >= v1) return;
     if (v > 0 && wave_in[v] != wave_out[v - 1]) atomicAdd((unsigned long long*)&totals[2], 1ull);
     if (desc_cap && wave_nf[v] > desc_cap) atomicAdd((unsigned long long*)&totals[2], 1ull << 32);   // more findings than descriptors
-    if (v + 1 == v1) { totals[0] = fbase[v] + wave_nf[v]; totals[1] = abase[v] + wave_nb[v]; totals[3] = wave_out[v]; }
+    if (wave_in[v] == 0xFFFFFFFEu) atomicAdd((unsigned long long*)&totals[3], 1ull << 32);         // it gave the buffer back (no repair launch can help)
+    if (v + 1 == v1) { totals[0] = fbase[v] + wave_nf[v]; totals[1] = abase[v] + wave_nb[v]; atomicAdd((unsigned long long*)&totals[3], (unsigned long long)wave_out[v]); }
 }
 
 // The writer that works a lane per finding: wavefront v's descriptors -> records and strings.  No classification, no state machine, no
@@ -753,7 +772,7 @@ hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint
     WaveParams Q = P;
     Q.v0 = v0; Q.v1 = v1;
     const unsigned dyn = getenv("SX_WAVE_DYN_LDS") ? (unsigned)atoi(getenv("SX_WAVE_DYN_LDS")) : 0u;   // experiments: fewer wavefronts per CU
-    if (P.wave_grid) { hipError_t ez = hipMemsetAsync(P.wave_grid + v0, 0, (size_t)n * 4, stream); if (ez != hipSuccess) return ez; }
+    if (P.wave_grid && !P.redo) { hipError_t ez = hipMemsetAsync(P.wave_grid + v0, 0, (size_t)n * 4, stream); if (ez != hipSuccess) return ez; }   // (a repair launch reads what the first one published)
     if (P.family == 5) hipLaunchKernelGGL((wave_replay_kernel<0, 5, 4, 1>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4 && P.swar.cls) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 1>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4) hipLaunchKernelGGL((wave_replay_kernel<0, 4, 4, 0>), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);

@@ -73,7 +73,7 @@ struct RecEmit {
     void operator()(u32 din, u32 prec, bool completes, i32 src_rel, u32 src_len, u32 out_len) { v.push_back(E{ din, prec, completes, src_rel, src_len, out_len }); }
 };
 int g_driver_mismatch = 0, g_gave_up = 0;
-unsigned long long g_rounds_total = 0, g_batches_total = 0, g_redo_lanes = 0;
+unsigned long long g_rounds_total = 0, g_batches_total = 0, g_redo_lanes = 0, g_repairs = 0;
 template <int KIND>
 bool drivers_agree(const WvParams& WP, const WvWin& w, u32 in) {
     RecEmit a, b;
@@ -103,12 +103,20 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
     const u64 own_start = P.g_lo + v * P.nwin;
     if (own_start >= P.g_hi) return true;
     const u64 own_end = own_start + P.nwin < P.g_hi ? own_start + P.nwin : P.g_hi;
-    const u64 gw = v == 0 ? own_start : own_start - kWvWarm;
-    u32 carry = v == 0 ? P.inject : 0u, assumed_in = carry;
+    // (as the kernel: a repair launch of the count pass / the writer after repairs start from what the wavefront in front left)
+    bool known = false;
+    u32 known_state = 0;
+    if (v != 0 && ((MODE == 0 && P.redo) || (MODE == 1 && P.use_entry))) {
+        known_state = P.wave_out[v - 1];
+        if (MODE == 0 && (P.wave_in[v] == known_state || P.wave_in[v] == 0xFFFFFFFEu)) return true;
+        known = true;
+    }
+    const u64 gw = (v == 0 || known) ? own_start : own_start - kWvWarm;
+    u32 carry = v == 0 ? P.inject : (known ? known_state : 0u), assumed_in = carry;
     u32 tot_f = 0, tot_b = 0;
     u64 fbase = 0, abase = 0;
     if (MODE == 1) { fbase = P.wave_fbase[v] - P.f_sub; abase = P.wave_abase[v] - P.a_sub; }
-    const WvParams WP{ P.q, P.n_min };
+    const WvParams WP{ P.q, P.n_min, P.grep_char >= 0 ? 1u : 0u };
     std::vector<u32> lds[9];
     u32 dbcs_cov = 0;
     bool dbcs_valid = false;
@@ -385,6 +393,15 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                                    wv_extract(lds[3], o, n), wv_extract(lds[4], o, n), fb, ws[l] % kWvSlice == 0, n, P.n_min);
             }
         }
+        for (u32 l = 0; l < 64 && WP.grep; l++) {   // -g: which characters are the grep char (every lane from its own window's bytes, as the kernel)
+            if (!active[l]) { w[l].GC = wm_zero(); continue; }
+            const bool be = P.encoding == kEncUtf16be;
+            if (P.family == 0) wv_set_grep<0>(w[l], WP, P.data + ws[l], (u32)P.grep_char, be);
+            else if (P.family == 1) wv_set_grep<1>(w[l], WP, P.data + ws[l], (u32)P.grep_char, be);
+            else if (P.family == 2) wv_set_grep<3>(w[l], WP, P.data + ws[l], (u32)P.grep_char, be);
+            else wv_set_grep<2>(w[l], WP, P.data + ws[l], (u32)P.grep_char, be);
+        }
+        if (!WP.grep) for (u32 l = 0; l < 64; l++) w[l].GC = wm_zero();
         u32 in[64], out[64], nf[64], nb[64];
         std::vector<u32> stage(kWvStage * 192u, 0xDEADBEEFu);   // (the kernel's count pass stages a window's first findings as descriptors in LDS)
         bool todo[64], injected[64];
@@ -434,7 +451,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                     g_driver_mismatch++;
                     return false;
                 }
-        if (g0 == gw && v != 0) assumed_in = in[kWvWarm];
+        if (g0 == gw && v != 0 && !known) assumed_in = in[kWvWarm];
         carry = out[63];
         const u32 last_out = out[n_act - 1];
         u32 bf = 0, bb = 0;
@@ -490,7 +507,7 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
                            uint64_t g_lo, uint32_t inject, uint32_t nwin, const uint8_t* lut, const uint16_t* table, int mission_id,
                            int file_id, sx_finding* fout, uint64_t fcap, uint8_t* aout, uint64_t acap, uint64_t* nf, uint64_t* nb,
                            uint32_t* final_state, uint64_t* bad_waves, int skip_idle, uint32_t* rounds_max, uint32_t family,
-                           const uint32_t* pairs, uint32_t encoding, uint32_t entry_skip, const uint32_t* swar25, const uint32_t* pairs2) {
+                           const uint32_t* pairs, uint32_t encoding, uint32_t entry_skip, const uint32_t* swar25, const uint32_t* pairs2, int grep_char) {
     WaveParams P;
     memset(&P, 0, sizeof P);
     P.data = data; P.len = len; P.consumed0 = consumed0; P.slice_base = slice_base; P.W = W; P.wps = wv_wps(W); P.q = q; P.n_min = n_min;
@@ -499,6 +516,7 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
     P.lut = lut; P.table = table; P.family = family; P.pairs = pairs; P.encoding = encoding; P.entry_skip = entry_skip;
     if (swar25) memcpy(&P.swar, swar25, sizeof P.swar);
     P.pairs2 = pairs2;
+    P.grep_char = grep_char;
     if (family == 4 && !pairs2) P.swar.cls = 0;
     if (family == 5 && (!pairs2 || !P.swar.cls)) return -8;
     *nf = *nb = 0; *bad_waves = 0; *final_state = inject; *rounds_max = 0;
@@ -513,19 +531,42 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
     std::vector<u32> desc((size_t)(n_waves * P.desc_cap * 3 + 3), 0xDEADBEEFu);
     P.desc = nwin <= kWvDescMaxWin ? desc.data() : nullptr;   // (as sx_wave.cpp: larger wavefronts do without)
     for (u64 v = 0; v < n_waves; v++) if (!wave<0>(P, v, skip_idle != 0, rounds_max)) return g_gave_up ? -9 : g_driver_mismatch ? -7 : -1;
+    // repairs (sx_wave.cpp): wavefronts whose assumption was wrong run again from what their predecessor left, launch after launch.  A
+    // launch's wavefronts run in any order; here from the last to the first, so that every one reads what the launch BEFORE left in front of
+    // it — the order in which a chain of wrong wavefronts takes the most launches.
+    auto count_bad = [&]() { u64 b = 0; for (u64 v = 1; v < n_waves; v++) if (win[v] != wout[v - 1]) b++; return b; };
+    bool repaired = false;
+    if (!getenv("SXW_NO_REPAIR")) {
+        for (int round = 0; round < 400 && count_bad(); round++) {
+            repaired = true;
+            g_repairs++;
+            P.redo = 1;
+            bool any = false;
+            for (u64 v = n_waves - 1; v >= 1; v--) {
+                if (win[v] == wout[v - 1] || win[v] == 0xFFFFFFFEu) continue;
+                any = true;
+                if (!wave<0>(P, v, skip_idle != 0, rounds_max)) return g_gave_up ? -9 : g_driver_mismatch ? -7 : -1;
+            }
+            if (!any) break;
+        }
+    }
+    P.redo = 0;
     u64 f = 0, a = 0;
     for (u64 v = 0; v < n_waves; v++) {
         fb[v] = f; ab[v] = a; f += wnf[v]; a += wnb[v];
         if (v > 0 && win[v] != wout[v - 1]) (*bad_waves)++;
     }
+    P.use_entry = repaired && family < 4 ? 1u : 0u;
+    const bool skip_window_writer = repaired && family >= 4;   // (the product goes back to the other path for that combination unless the descriptors hold everything)
     *nf = f; *nb = a; *final_state = wout[n_waves - 1];
     if (f > fcap || a > acap) return -2;
     P.wave_fbase = fb.data(); P.wave_abase = ab.data(); P.findings = fout; P.arena = aout;
     u32 dummy = 0;
-    for (u64 v = 0; v < n_waves; v++) if (!wave<1>(P, v, skip_idle != 0, &dummy)) return -1;
-    // the lane-per-finding writer (sx_wave_dev.hip wave_emit_kernel) from the count pass' descriptors: the same records and strings
     bool overflow = false;
     for (u64 v = 0; v < n_waves; v++) overflow = overflow || wnf[v] > P.desc_cap;
+    if (skip_window_writer && (overflow || !P.desc)) return -10;   // (the product: SX_WAVE_FALLBACK)
+    if (!skip_window_writer) for (u64 v = 0; v < n_waves; v++) if (!wave<1>(P, v, skip_idle != 0, &dummy)) return -1;
+    // the lane-per-finding writer (sx_wave_dev.hip wave_emit_kernel) from the count pass' descriptors: the same records and strings
     if (!overflow && P.desc) {
         std::vector<sx_finding> f2((size_t)f + 1);
         std::vector<u8> a2((size_t)a + 8, 0);
@@ -542,12 +583,14 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
                 if (we.bad_len) return -3;
             }
         }
+        if (skip_window_writer) { if (f) memcpy(fout, f2.data(), (size_t)f * sizeof(sx_finding)); if (a) memcpy(aout, a2.data(), (size_t)a); }
         if (f && memcmp(f2.data(), fout, (size_t)f * sizeof(sx_finding)) != 0) return -4;
         if (a && memcmp(a2.data(), aout, (size_t)a) != 0) return -5;
     }
     return 0;
 }
 
-extern "C" uint32_t sxw_pack_state(uint32_t lc, uint32_t lb, uint32_t lback, uint32_t cut) { return wv_pack(WvState{ lc, lb, lback, cut }); }
+extern "C" uint32_t sxw_pack_state(uint32_t lc, uint32_t lb, uint32_t lback, uint32_t cut) { return wv_pack(WvState{ lc, lb, lback, cut, 0 }); }
+extern "C" uint32_t sxw_pack_state_g(uint32_t lc, uint32_t lb, uint32_t lback, uint32_t cut, uint32_t lg) { return wv_pack(WvState{ lc, lb, lback, cut, lg }); }
 
-extern "C" void sxw_round_stats(unsigned long long* out) { out[0] = g_rounds_total; out[1] = g_batches_total; out[2] = g_redo_lanes; g_rounds_total = g_batches_total = g_redo_lanes = 0; }
+extern "C" void sxw_round_stats(unsigned long long* out) { out[0] = g_rounds_total; out[1] = g_batches_total; out[2] = g_redo_lanes; out[3] = g_repairs; g_rounds_total = g_batches_total = g_redo_lanes = g_repairs = 0; }

@@ -356,3 +356,98 @@ def test_same_unicode_block_on_buffers_where_it_cannot_matter(wave_forced):
             assert run_cli_product(ms16, [data], radix="x", device=0, chunk_bytes=chunk) == want, ("utf-16le", name, chunk)
     assert wave_windows_of_a_scan(ms16, to16(ascii_text[:150_000])) > 0 and wave_windows_of_a_scan(ms16, to16(latin)) > 0
     assert wave_windows_of_a_scan(ms16, to16(cyr)) == 0
+
+
+# ---- round 5: -g on the wave path (sx_wave_core.hpp WvWin::GC, the repairs of sx_wave.cpp) ----
+def _stats_of_a_scan(ms, files):
+    sc = sx.Scanner(ms, device=0)
+    try:
+        for i, data in enumerate(files):
+            res = sc.scan(data, file_id=i + 1)
+            res.free()
+        return sc.stats()
+    finally:
+        sc.close()
+
+
+def test_the_references_grep_goldens_come_out_of_the_wave_kernels(wave_forced):
+    """tests/functional/run-tests:11-29 — `-q 16 -g 63` on input1, `-n 10 -q 32 -g 58` on input1 + input2, three encodings each — byte for
+    byte, with every Mission on the wave kernels (sx_stats::wave_windows counts all their windows)"""
+    import os as _os
+    gold = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+    rd = lambda n: open(_os.path.join(gold, n), "rb").read()
+    in1, in2 = rd("input1"), rd("input2")
+    cases = [(dict(encodings=["UTF-8", "utf-16le", "utf-16be"], output_line_len="16", grep_char="63", ascii_filter="All-Ctrl", unicode_block_filter="Common"),
+              [in1], rd("expected_output1")),
+             (dict(encodings=["UTF-8", "utf-16le", "utf-16be"], chars_min="10", output_line_len="32", grep_char="58", ascii_filter="All-Ctrl",
+                   unicode_block_filter="Common"), [in1, in2], rd("expected_output2"))]
+    for flags, files, want in cases:
+        ms = sx.missions_from_flags(**flags)
+        assert ms == rc.missions(**flags)
+        got = run_cli_product(ms, files, radix="x", device=0)
+        assert got == want
+        assert got == sxo.run_cli(ms, files, radix="x")
+        st = _stats_of_a_scan(ms, files)
+        windows = sum((len(f) // 4096) * (4096 // (2 * ms[0]["output_line_char_nb_max"])) for f in files)
+        assert st.wave_windows >= 2 * windows, (st.wave_windows, windows)   # at least two of the three Missions replayed every window there
+                                                                              # (input2's UTF-16 Missions may give a buffer back: a kept character at a window's end)
+
+
+GREP_GPU = [dict(encodings=["ascii"], chars_min="4", grep_char="47"), dict(encodings=["utf-8"], chars_min="10", output_line_len="32", grep_char="58"),
+            dict(encodings=["utf-8"], output_line_len="16", grep_char="63", unicode_block_filter="All"),
+            dict(encodings=["utf-16le"], chars_min="5", output_line_len="16", grep_char="101"), dict(encodings=["utf-16be"], chars_min="4", grep_char="32"),
+            dict(encodings=["koi8-r"], chars_min="5", unicode_block_filter="Cyrillic", grep_char="32"),
+            dict(encodings=["big5"], chars_min="3", output_line_len="8", unicode_block_filter="Asian", grep_char="32"),
+            dict(encodings=["euc-jp"], chars_min="3", output_line_len="8", unicode_block_filter="Cjk", grep_char="65"),
+            dict(encodings=["ascii"], chars_min="4", grep_char="10")]
+
+
+@pytest.mark.parametrize("gi", range(len(GREP_GPU)))
+def test_wave_path_with_a_grep_char_equals_the_oracle(wave_forced, gi):
+    from test_wave_core import grep_text, utf16_soup
+    flags = GREP_GPU[gi]
+    ms = rc.missions(**flags)
+    g = ms[0]["grep_char"]
+    enc = flags["encodings"][0]
+    rng = random.Random(4000 + gi)
+    datas = [("grep text", grep_text(rng, 600_000, g)), ("text", text_lines(rng, 300_000)), ("long lines", text_lines(rng, 200_000, 100, 900)),
+             ("random", rng.randbytes(300_000)), ("no grep", bytes(c for c in text_lines(rng, 200_000, 200, 2000) if c != g))]
+    if enc.startswith("utf-16"):
+        codec = "utf-16-be" if enc.endswith("be") else "utf-16-le"
+        datas = [(n, d if n == "random" else d.decode("latin-1").encode(codec)) for n, d in datas] + [("soup", utf16_soup(rng, 100_000, enc.endswith("be")))]
+    repairs = 0
+    for name, data in datas:
+        want = sxo.run_cli(ms, [data], radix="x")
+        for chunk, batches in ((None, None), (65536, "1"), (16384, "2")):
+            if batches:
+                os.environ["SX_WAVE_BATCHES"] = batches
+            else:
+                os.environ.pop("SX_WAVE_BATCHES", None)
+            assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (name, chunk, batches)
+        os.environ["SX_WAVE_BATCHES"] = "1"
+        st = _stats_of_a_scan(ms, [data])
+        os.environ.pop("SX_WAVE_BATCHES", None)
+        repairs += st.wave_repairs
+        if name in ("grep text", "text", "no grep") and not enc.startswith(("big5", "euc")):
+            assert st.wave_windows > 0, name
+    if gi in (1, 2, 3):   # lines longer than a few windows without the grep char: wavefronts that begin inside one are repaired
+        assert repairs > 0
+
+
+def test_wave_repairs_can_be_switched_off_and_the_other_path_takes_over(wave_forced, monkeypatch):
+    from test_wave_core import grep_text
+    ms = rc.missions(encodings=["utf-8"], output_line_len="16", grep_char="63")
+    rng = random.Random(5)
+    data = bytes(c for c in text_lines(rng, 400_000, 300, 3000) if c != 63) + grep_text(rng, 100_000, 63)
+    want = sxo.run_cli(ms, [data], radix="x")
+    monkeypatch.setenv("SX_WAVE_BATCHES", "1")
+    assert run_cli_product(ms, [data], radix="x", device=0) == want
+    assert _stats_of_a_scan(ms, [data]).wave_repairs > 0
+    monkeypatch.setenv("SX_WAVE_REPAIR", "0")
+    assert run_cli_product(ms, [data], radix="x", device=0) == want
+    assert _stats_of_a_scan(ms, [data]).wave_repairs == 0
+    monkeypatch.setenv("SX_WAVE_REPAIR", "1")   # one repair launch only: a chain of wrong wavefronts is longer than that -> the other path
+    assert run_cli_product(ms, [data], radix="x", device=0) == want
+    monkeypatch.setenv("SX_WAVE_REPAIR", "48")
+    monkeypatch.setenv("SX_WAVE_DESC", "0")     # the window-parallel writer after repairs: from the states the count pass left
+    assert run_cli_product(ms, [data], radix="x", device=0) == want

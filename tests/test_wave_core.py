@@ -26,7 +26,7 @@ def load_wave():
     L.sxw_emulate.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
                               C.c_uint32, C.c_char_p, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.POINTER(sx.Finding), C.c_uint64,
                               C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
-                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int]
     L.sxw_pack_state.restype = C.c_uint32
     L.sxw_pack_state.argtypes = [C.c_uint32] * 4
     return L
@@ -92,7 +92,8 @@ def emulate(L, m, data, nwin=508, skip_idle=1, g_lo=0, inject=0, consumed0=None,
     rcode = L.sxw_emulate(data, len(data), m["counter_offset"] if consumed0 is None else consumed0, 0, 2 * q, q, m["chars_min_nb"], g_lo,
                           inject, nwin, lut, table, 0, 1, fout, cap_f, aout, cap_a, C.byref(nf), C.byref(nb), C.byref(fin), C.byref(bad),
                           skip_idle, C.byref(rounds), family, wave_pairs(m) if family == 4 else None, m["encoding"], 0,
-                          wave_swar(m) if swar or family == 5 else None, wave_pairs2(m) if (swar and family == 4) or family == 5 else None)
+                          wave_swar(m) if swar or family == 5 else None, wave_pairs2(m) if (swar and family == 4) or family == 5 else None,
+                          -1 if m.get("grep_char") is None else m["grep_char"])
     if may_give_up and rcode == -9:   # the wavefronts gave the buffer back (UTF-16: a case the masks cannot say)
         return None, dict(gave_up=True)
     assert rcode == 0, rcode
@@ -175,6 +176,102 @@ MISSIONS = [
     dict(encodings=["x-user-defined"], chars_min="3", output_line_len="20", unicode_block_filter="All", same_unicode_block=True),
     dict(encodings=["utf-8"], chars_min="3", unicode_block_filter="0x10000", same_unicode_block=True),   # (lead byte D0 only)
 ]
+
+
+# -g (round 5): a string counts only if it holds the grep char; a line of q chars without it that neither completes the string before nor
+# is carried on ends SplitStr's walk over the call's text (helper.rs:410-415).  The first two are the reference's functional tests 1 and 2
+# (tests/functional/run-tests:11-29), one Mission each.
+GREP_MISSIONS = [
+    dict(encodings=["utf-8"], output_line_len="16", grep_char="63", ascii_filter="All-Ctrl", unicode_block_filter="Common"),
+    dict(encodings=["utf-8"], chars_min="10", output_line_len="32", grep_char="58", ascii_filter="All-Ctrl", unicode_block_filter="Common"),
+    dict(encodings=["ascii"], chars_min="4", grep_char="47"),
+    dict(encodings=["ascii"], chars_min="3", output_line_len="6", grep_char="101"),
+    dict(encodings=["ascii"], chars_min="6", output_line_len="6", grep_char="32"),
+    dict(encodings=["ascii"], chars_min="4", grep_char="10"),                                   # a grep char the filter rejects: it counts for the string it ends
+    dict(encodings=["koi8-r"], chars_min="5", unicode_block_filter="Cyrillic", grep_char="32"),
+    dict(encodings=["windows-1253"], chars_min="2", output_line_len="8", unicode_block_filter="All", grep_char="97"),
+    dict(encodings=["utf-8"], chars_min="4", unicode_block_filter="All", grep_char="32"),
+    dict(encodings=["utf-8"], chars_min="3", output_line_len="6", unicode_block_filter="All", grep_char="111"),
+    dict(encodings=["utf-8"], chars_min="2", output_line_len="16", unicode_block_filter="Cjk", ascii_filter="None", grep_char="32"),   # ... rejected too
+]
+GREP_UTF16 = [
+    dict(encodings=["utf-16le"], output_line_len="16", grep_char="63", ascii_filter="All-Ctrl", unicode_block_filter="Common"),
+    dict(encodings=["utf-16be"], chars_min="10", output_line_len="32", grep_char="58", ascii_filter="All-Ctrl", unicode_block_filter="Common"),
+    dict(encodings=["utf-16be"], chars_min="2", unicode_block_filter="All", output_line_len="10", grep_char="97"),
+    dict(encodings=["utf-16le"], chars_min="3", unicode_block_filter="Cjk", ascii_filter="None", grep_char="32"),
+]
+GREP_DBCS = [
+    ("big5", dict(encodings=["big5"], chars_min="3", output_line_len="8", unicode_block_filter="Asian", grep_char="32")),
+    ("shift_jis", dict(encodings=["shift_jis"], chars_min="4", unicode_block_filter="All", grep_char="65")),
+    ("euc-kr", dict(encodings=["euc-kr"], chars_min="4", unicode_block_filter="All", grep_char="32")),
+    ("euc-jp", dict(encodings=["euc-jp"], chars_min="3", output_line_len="8", unicode_block_filter="Cjk", grep_char="65")),
+]
+
+
+def grep_text(rng, n, g):
+    """lines of every length with and without the grep char, next to window edges"""
+    out = bytearray()
+    alpha = bytes(c for c in b"abcdefghijklmnopqrstuvwxyzABCDEFGH0123456789_-.=" if c != g)
+    while len(out) < n:
+        ln = bytearray(rng.choice(alpha) for _ in range(rng.choice([2, 5, 6, 7, 12, 16, 17, 31, 32, 33, 63, 64, 65, 100, 130, 200])))
+        for _ in range(rng.choice([0, 0, 1, 1, 2, 5])):
+            ln[rng.randrange(len(ln))] = g
+        out += ln + rng.choice([b"\n", b"\x00", b"\xff", bytes([g]), b"\n\n", b"\x01\x02"])
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("gi", range(len(GREP_MISSIONS)))
+def test_emulated_wave_pipeline_with_a_grep_char(wave, gi):
+    m = rc.missions(**GREP_MISSIONS[gi])[0]
+    assert wave_classes(m) is not None
+    rng = random.Random(9000 + gi)
+    golden = open(os.path.join(ROOT, "tests", "golden", "input1"), "rb").read()
+    extra = [("grep text", grep_text(rng, 80_000, m["grep_char"])), ("input1", golden),
+             ("all grep", bytes([m["grep_char"]]) * 9000), ("no grep", bytes(c for c in text_lines(rng, 30_000) if c != m["grep_char"]))]
+    for name, data in list(inputs(rng)) + extra:
+        want = oracle_findings([dict(m, mission_id=0)], data)
+        for nwin, skip in ((508, 1), (60, 0), (7, 1)):
+            got, info = emulate(wave, m, data, nwin=nwin, skip_idle=skip, swar=nwin != 60)
+            assert info["bad"] == 0, (name, nwin, info)
+            assert got == want, (name, nwin, skip, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
+
+
+@pytest.mark.parametrize("gi", range(len(GREP_UTF16)))
+def test_emulated_wave_pipeline_utf16_with_a_grep_char(wave, gi):
+    m = rc.missions(**GREP_UTF16[gi])[0]
+    be = GREP_UTF16[gi]["encodings"][0].endswith("be")
+    codec = "utf-16-be" if be else "utf-16-le"
+    rng = random.Random(9500 + gi)
+    golden2 = open(os.path.join(ROOT, "tests", "golden", "input2"), "rb").read()
+    datas = [("grep text", grep_text(rng, 30_000, m["grep_char"]).decode("latin-1").encode(codec)), ("soup", utf16_soup(rng, 30_000, be)),
+             ("text", text_lines(rng, 30_000).decode("latin-1").encode(codec)), ("input2", golden2[:len(golden2) // 2 * 2]),
+             ("astral", ("a\U0001F600b:\U00020000\U0001F601c?d \u4e2d" * 2000).encode(codec)), ("random", rng.randbytes(60_000))]
+    for name, data in datas:
+        want = oracle_findings([dict(m, mission_id=0)], data)
+        for nwin, skip in ((508, 1), (60, 0), (7, 1)):
+            got, info = emulate(wave, m, data, nwin=nwin, skip_idle=skip, may_give_up=True)
+            if got is None:
+                assert name in ("soup", "random", "input2"), name
+                continue
+            assert info["bad"] == 0, (name, nwin, info)
+            assert got == want, (name, nwin, skip, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
+
+
+@pytest.mark.parametrize("gi", range(len(GREP_DBCS)))
+def test_emulated_wave_pipeline_two_byte_family_with_a_grep_char(wave, gi):
+    from test_dbcs import soup as dbcs_soup, TEXT, CODEC
+    enc, flags = GREP_DBCS[gi]
+    m = rc.missions(**flags)[0]
+    rng = random.Random(9800 + gi)
+    txt = TEXT[enc].encode(CODEC[enc], "ignore")
+    datas = [("soup", dbcs_soup(enc, rng, 80_000)), ("random", rng.randbytes(60_000)), ("text", (txt + b"\n") * (40_000 // (len(txt) + 1))),
+             ("ascii", grep_text(rng, 40_000, m["grep_char"]))]
+    for name, data in datas:
+        want = oracle_findings([dict(m, mission_id=0)], data)
+        for nwin, skip in ((508, 1), (60, 0), (7, 1)):
+            got, info = emulate(wave, m, data, nwin=nwin, skip_idle=skip, swar=nwin != 60)
+            assert info["bad"] == 0, (name, nwin, info)
+            assert got == want, (enc, name, nwin, skip, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
 
 
 DBCS_MISSIONS = [
@@ -301,7 +398,7 @@ def test_which_missions_classify_by_ranges():
 
 
 def test_missions_the_wave_path_does_not_cover():
-    for kw in (dict(encodings=["ascii"], chars_min="4", grep_char="47"), dict(encodings=["koi8-r"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True),
+    for kw in (dict(encodings=["koi8-r"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True),
                dict(encodings=["utf-8"], chars_min="4", same_unicode_block=True),
                dict(encodings=["ascii"], chars_min="0"), dict(encodings=["ascii"], chars_min="70"),
                dict(encodings=["ascii"], chars_min="4", output_line_len="100"), dict(encodings=["utf-16le"], chars_min="4", same_unicode_block=True),

@@ -20,6 +20,9 @@ cases = [(dict(encodings=["ascii"], chars_min="4"), data), (dict(encodings=["utf
          # -r: `-e ascii` (no two accepted characters with different UTF-8 lead bytes exist) and `-e utf-8` / `-e utf-16le` (none in this buffer): the wave path
          (dict(encodings=["ascii"], chars_min="4", same_unicode_block=True), data), (dict(encodings=["utf-8"], chars_min="10", same_unicode_block=True), data),
          (dict(encodings=["utf-16le"], chars_min="10", same_unicode_block=True), data16)]
+# -g (round 5: on the wave path — the char of the reference's functional test 2, `:`, which a tenth of these lines hold; and a char none holds)
+cases += [(dict(encodings=["ascii"], chars_min="4", grep_char="58"), data), (dict(encodings=["utf-8"], chars_min="10", grep_char="58"), data),
+          (dict(encodings=["utf-16le"], chars_min="10", grep_char="58"), data16), (dict(encodings=["utf-8"], chars_min="10", grep_char="63"), data)]
 if len(sys.argv) > 2: cases = [c for c in cases if c[0]["encodings"][0] in sys.argv[2:]]
 for flags, data in cases:
     ms = rc.missions(**flags)
@@ -31,5 +34,5 @@ for flags, data in cases:
         res = sc.scan_device(d, len(data), file_id=1)
         dts.append(time.perf_counter() - t0); n = len(res); res.free()
     dt = sorted(dts[2:])[len(dts[2:]) // 2]
-    print(flags["encodings"], "-r" if flags.get("same_unicode_block") else "", f"{mib} MiB text: {dt*1e3:.1f} ms = {mib/1024/dt:.2f} GiB/s (median of 6; min {min(dts)*1e3:.1f}, max {max(dts[2:])*1e3:.1f} ms), {n} findings")
+    print(flags["encodings"], "-r" if flags.get("same_unicode_block") else "", f"-g {flags['grep_char']}" if flags.get("grep_char") else "", f"{mib} MiB text: {dt*1e3:.1f} ms = {mib/1024/dt:.2f} GiB/s (median of 6; min {min(dts)*1e3:.1f}, max {max(dts[2:])*1e3:.1f} ms), {n} findings")
     sc.free(d); sc.close()
