@@ -79,10 +79,13 @@ def main():
     ap.add_argument("--ubf", default=None,
                     help="another -u for the workload's Missions (what an alias filter costs: --ubf Cjk, --ubf Asian, --ubf All); the line's "
                          "config.workload says so — not the headline configuration")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank scans the workload's size (N x 64 GiB at N ranks); strong: the workload's ONE image is split "
-                         "over the ranks (BASELINE.json's metric: 64 GiB at 1/2/4/8 GPUs)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong: the workload's ONE image is split over the ranks — the default for `--gpus N` with N > 1 (BASELINE.json's "
+                         "metric: 64 GiB at 1/2/4/8 GPUs); weak: every rank scans the workload's size — the default of `--workload c4` "
+                         "(BASELINE config 4: 32 GiB per rank, 256 GiB over eight) and of N = 1")
     args = ap.parse_args()
+    if args.scaling is None:   # (round 5: the driver's `--gpus N` line is on the metric's configuration; round 4 defaulted to N x 64 GiB)
+        args.scaling = "strong" if args.gpus > 1 and args.workload != "c4" else "weak"
 
     # `python bench.py --gpus N` without a launcher: start the N ranks the way the driver does (one process per GPU over
     # torch.distributed.run on 127.0.0.1) and pass their output through
@@ -289,7 +292,7 @@ def main():
             "algorithmic_bytes_per_launch": nbytes,
             "per_kernel_ms": [round(x, 3) for x in kernel_ms],
             "per_kernel_gbs": [round(nbytes / (x * 1e-3) / 1e9, 1) if x > 0 else None for x in kernel_ms],
-            "note": "durations inside the timed region; default schedule: the busiest mission is scanned last and its stage B follows the scans (SX_BUSIEST_LAST=0: it is scanned first and its stage B runs next to the other missions' kernels)",
+            "note": "durations inside the timed region; default schedule (round 5): the busiest mission is scanned first and its stage B runs next to the other missions' scan launches (SX_BUSIEST_LAST=1 / 2: it is scanned last / second to last)",
             "per_kernel_ms_alone": [round(x, 3) for x in alone_ms],
             "per_kernel_ms_alone_behind_an_identical_launch": [round(x, 3) for x in alone_warm_ms],
             "frac_alone": round(len(missions) * nbytes / (sum(alone_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if alone_ms and sum(alone_ms) > 0 else None,
@@ -301,7 +304,9 @@ def main():
             "metric": "GiB/s scanned", "value": round(value, 2), "unit": "GiB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic" if args.background == "random" else "constant bytes (counter pass)",
-            "config": {"workload": wl["name"], "bytes_per_gpu": nbytes, "missions": len(missions),
+            "config": {"workload": wl["name"] + (f" — ONE image of {world * nbytes / 2**30:g} GiB split over {world} ranks (strong scaling)" if world > 1 and args.scaling == "strong"
+                                                  else f" — {nbytes / 2**30:g} GiB per rank, {world * nbytes / 2**30:g} GiB in all (weak scaling)" if world > 1 else ""),
+                       "bytes_per_gpu": nbytes, "missions": len(missions),
                        "image_bytes": world * nbytes,
                        "parallelism": f"byte-range shards x{world}" + (" on ONE device (--single-device: plumbing test)" if args.single_device and world > 1 else ""),
                        "backend": args.backend if world > 1 else None,

@@ -358,6 +358,11 @@ int sx_scan_sharded(sx_ctx* ctx, int rank, int world, uint64_t file_len, uint64_
  * merged into the head of rank k+1's: slice, position, Mission).  str_off of findings[k] is relative to arenas[k]. */
 int sx_shard_splice(const sx_finding* const* findings, const uint64_t* n_findings, const uint8_t* const* arenas,
                     const uint64_t* arena_lens, int world, uint64_t file_len, sx_result** out);
+/* (ABI 3) The same for ranks whose findings arrive in SEGMENTS (a rank with more than 4 GiB of strings ships its result segment by segment,
+ * every segment with its own str_off space): seg s = (findings[s], n_findings[s], arenas[s], arena_lens[s]); rank 0's n_segs_of_rank[0]
+ * segments come first, then rank 1's, ...  The result has as many segments as its strings need (< 2 GiB each, cut between findings). */
+int sx_shard_splice_segs(const sx_finding* const* findings, const uint64_t* n_findings, const uint8_t* const* arenas,
+                         const uint64_t* arena_lens, const uint32_t* n_segs_of_rank, int world, uint64_t file_len, sx_result** out);
 
 uint64_t          sx_result_count(const sx_result* r);
 /* The findings come in one or more segments, in print order: a buffer scanned piece by piece adds a segment per

@@ -646,7 +646,9 @@ void merge_findings(std::vector<MissionFindings>& per, const std::shared_ptr<Pin
     size_t total = 0, bytes = 0;
     for (auto& mf : per) { total += mf.count(); bytes += mf.strings_len(); }
     std::vector<size_t> idx(per.size(), 0);
-    if (bytes <= 0xFFFFFFF0ull) {   // the usual case: the arenas are copied whole, the offsets rebased
+    uint64_t seg_cap = 0xFFFFFFF0ull;
+    if (const char* e = getenv("SX_HOST_MERGE_SEG_BYTES")) seg_cap = std::max<uint64_t>(1, (uint64_t)atoll(e));   // (tests: results of several segments without gigabytes of strings)
+    if (bytes <= seg_cap) {   // the usual case: the arenas are copied whole, the offsets rebased
         out->segs.emplace_back();
         MissionFindings& m = out->segs.back();
         m.v.reserve(total);
@@ -685,7 +687,7 @@ void merge_findings(std::vector<MissionFindings>& per, const std::shared_ptr<Pin
             }
             if (best < 0) break;
             const sx_finding& src = per[best].data()[idx[best]];
-            if (m.arena.size() + src.str_len > 0xFFFFFFF0ull) break;   // next segment
+            if (!m.v.empty() && m.arena.size() + src.str_len > seg_cap) break;   // next segment
             sx_finding f = src;
             f.str_off = (uint32_t)m.arena.size();
             m.arena.append(per[best].strings() + src.str_off, src.str_len);

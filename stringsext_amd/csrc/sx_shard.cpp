@@ -181,30 +181,39 @@ int sx_scan_sharded(sx_ctx* ctx, int rank, int world, uint64_t file_len, uint64_
 // The ranks' findings (rank k: findings[k][0..n_findings[k]) with strings in arenas[k]) -> one result in the
 // reference's order: a rank's findings that lie behind its range end are merged into the head of the next rank's
 // (slice, position, then Mission: the library's own merge key; both sides are sorted already).
-int sx_shard_splice(const sx_finding* const* findings, const uint64_t* n_findings, const uint8_t* const* arenas,
-                    const uint64_t* arena_lens, int world, uint64_t file_len, sx_result** out) {
-    if (!findings || !n_findings || !arenas || !arena_lens || !out || world < 1) return SX_E_INVALID;
-    struct Ref { int rank; const sx_finding* f; };
+// The general form (round 5): rank k's findings arrive in n_segs_of_rank[k] segments in a row — a rank with more than 4 GiB of strings ships
+// its result segment by segment, every segment with its own str_off space (BASELINE config 5 at 8 x 32 GiB: 2.4 GB of strings per GiB-eighth)
+// — and the result has as many segments as its strings need (each < 2 GiB), cut between findings.  seg s = (findings[s], n_findings[s],
+// arenas[s], arena_lens[s]); the segments of rank 0 come first, then rank 1's, ...
+int sx_shard_splice_segs(const sx_finding* const* findings, const uint64_t* n_findings, const uint8_t* const* arenas,
+                         const uint64_t* arena_lens, const uint32_t* n_segs_of_rank, int world, uint64_t file_len, sx_result** out) {
+    if (!findings || !n_findings || !arenas || !arena_lens || !n_segs_of_rank || !out || world < 1) return SX_E_INVALID;
+    struct Ref { uint32_t seg; int rank; const sx_finding* f; };
     auto less_eq = [](const Ref& a, const Ref& b) {   // a goes first on a tie if it is of the lower Mission (then the earlier rank)
         if (a.f->slice_index != b.f->slice_index) return a.f->slice_index < b.f->slice_index;
         if (a.f->position != b.f->position) return a.f->position < b.f->position;
         return a.f->mission_id <= b.f->mission_id;
     };
     std::vector<Ref> order, carry;
-    uint64_t total = 0, bytes = 0;
-    for (int k = 0; k < world; k++) { total += n_findings[k]; bytes += arena_lens[k]; }
-    if (bytes > 0xFFFFFFFFull) return SX_E_NOMEM;
+    uint64_t total = 0;
+    uint32_t n_all = 0;
+    for (int k = 0; k < world; k++) n_all += n_segs_of_rank[k];
+    for (uint32_t s = 0; s < n_all; s++) { total += n_findings[s]; if (arena_lens[s] > 0xFFFFFFFFull) return SX_E_INVALID; }
     order.reserve(total);
+    uint32_t s0 = 0;
     for (int k = 0; k < world; k++) {
         uint64_t hi;
         sx_shard_bounds(file_len, world, k, nullptr, &hi);
         const uint32_t b = (uint32_t)(hi / kInputBufLen);
         const bool last = k + 1 == world;
         std::vector<Ref> own, nxt;
-        uint64_t cut = n_findings[k];
-        while (!last && cut > 0 && findings[k][cut - 1].slice_index >= b) cut--;
-        for (uint64_t i = 0; i < cut; i++) own.push_back({ k, &findings[k][i] });
-        for (uint64_t i = cut; i < n_findings[k]; i++) nxt.push_back({ k, &findings[k][i] });
+        for (uint32_t s = s0; s < s0 + n_segs_of_rank[k]; s++)
+            for (uint64_t i = 0; i < n_findings[s]; i++) own.push_back({ s, k, &findings[s][i] });
+        s0 += n_segs_of_rank[k];
+        size_t cut = own.size();
+        while (!last && cut > 0 && own[cut - 1].f->slice_index >= b) cut--;
+        nxt.assign(own.begin() + (long)cut, own.end());
+        own.resize(cut);
         if (!carry.empty()) {
             std::vector<Ref> merged;
             merged.reserve(own.size() + carry.size());
@@ -233,14 +242,36 @@ int sx_shard_splice(const sx_finding* const* findings, const uint64_t* n_finding
     }
     order.insert(order.end(), carry.begin(), carry.end());
     ResultHolder res;
+    // the strings are copied finding by finding: an output segment ends where its arena would pass 2 GiB (SX_SPLICE_SEG_BYTES: tests)
+    uint64_t seg_cap = 2048ull << 20;
+    if (const char* e = getenv("SX_SPLICE_SEG_BYTES")) seg_cap = std::max<uint64_t>(1, (uint64_t)atoll(e));
     res.r->r.segs.emplace_back();
-    MissionFindings& m = res.r->r.segs.back();
-    std::vector<uint32_t> base((size_t)world, 0);
-    for (int k = 0; k < world; k++) { base[(size_t)k] = (uint32_t)m.arena.size(); m.arena.append((const char*)arenas[k], arena_lens[k]); }
-    m.v.reserve(order.size());
-    for (const Ref& r : order) { sx_finding f = *r.f; f.str_off += base[(size_t)r.rank]; m.v.push_back(f); }
+    for (const Ref& r : order) {
+        MissionFindings* m = &res.r->r.segs.back();
+        if (!m->v.empty() && m->arena.size() + r.f->str_len > seg_cap) { res.r->r.segs.emplace_back(); m = &res.r->r.segs.back(); }
+        if ((uint64_t)r.f->str_off + r.f->str_len > arena_lens[r.seg]) return SX_E_INVALID;
+        sx_finding f = *r.f;
+        f.str_off = (uint32_t)m->arena.size();
+        m->arena.append((const char*)arenas[r.seg] + r.f->str_off, r.f->str_len);
+        m->v.push_back(f);
+    }
     *out = res.release();
     return SX_OK;
+}
+
+int sx_shard_splice(const sx_finding* const* findings, const uint64_t* n_findings, const uint8_t* const* arenas,
+                    const uint64_t* arena_lens, int world, uint64_t file_len, sx_result** out) {
+    if (world < 1) return SX_E_INVALID;
+    uint64_t bytes = 0;
+    if (arena_lens) for (int k = 0; k < world; k++) bytes += arena_lens[k];
+    if (bytes > 0xFFFFFFFFull) return SX_E_NOMEM;   // (ONE result segment: callers with more take sx_shard_splice_segs)
+    std::vector<uint32_t> one((size_t)world, 1u);
+    const char* keep = getenv("SX_SPLICE_SEG_BYTES");
+    std::string saved = keep ? keep : "";
+    if (keep) unsetenv("SX_SPLICE_SEG_BYTES");
+    const int rc = sx_shard_splice_segs(findings, n_findings, arenas, arena_lens, one.data(), world, file_len, out);
+    if (keep) setenv("SX_SPLICE_SEG_BYTES", saved.c_str(), 1);
+    return rc;
 }
 
 }  // extern "C"

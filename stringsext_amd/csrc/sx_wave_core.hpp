@@ -340,8 +340,10 @@ SXD void wv_window_calls(const WvParams& P, const WvWin& w, WvState& st, EMIT& e
 // with accepted chars, or the call ends in an error) and what it leaves behind when nothing is carried into it — fewer than q chars:
 // they are the leftover (helper.rs:389-392); more: lines of q chars, the last piece touches the text end with the flag up.
 struct WvTail { u32 a, state; };
-template <int KIND>
-SXD WvTail wv_tail(const WvParams& P, const WvWin& w) {
+// (GREPT: -g as a compile-time constant — the kernels are instantiated with and without it: WvWin::GC costs four registers that a Mission
+// without -g must not pay for, and did, in spills: `-e ascii -n 4` 192 -> 146 GiB/s with -g decided at run time)
+template <int KIND, bool GREPT>
+SXD WvTail wv_tail_g(const WvParams& P, const WvWin& w) {
     constexpr bool BYTES = KIND == 0;
     if (w.tail_empty || w.n == 0) return WvTail{ 128u, 0u };
     const i32 tcs = wm_prev(w.CS, 127);
@@ -361,8 +363,12 @@ SXD WvTail wv_tail(const WvParams& P, const WvWin& w) {
     u32 out_b;
     if (KIND == 1) out_b = (u32)(el + 1 - src);
     else out_b = c + wm_popc(wm_and(w.O2, rng)) + (BYTES ? 2 * wm_popc(wm_and(w.O3, rng)) : wm_popc(wm_and(w.O3, rng)) + wm_popc(wm_and(w.O4, rng)));
-    return WvTail{ a, wv_pack(WvState{ c, out_b, (u32)((i32)w.n - src), 0, P.grep && wm_any(wm_and(w.GC, rng)) ? 1u : 0u }) };
+    u32 lg = 0;
+    if (GREPT) lg = wm_any(wm_and(w.GC, rng)) ? 1u : 0u;
+    return WvTail{ a, wv_pack(WvState{ c, out_b, (u32)((i32)w.n - src), 0, lg }) };
 }
+template <int KIND>
+SXD WvTail wv_tail(const WvParams& P, const WvWin& w) { return P.grep ? wv_tail_g<KIND, true>(P, w) : wv_tail_g<KIND, false>(P, w); }
 // What the window hands on if what it was handed does not matter: every lane starts the exchange of the entry states from its
 // predecessor's guess instead of from "nothing carried" (which is wrong behind every window that ends inside a line of text or in
 // a stretch of accepted bytes: a third to all of them).  It is wrong when the tail is the text-start stretch of its call and something
@@ -371,8 +377,8 @@ SXD WvTail wv_tail(const WvParams& P, const WvWin& w) {
 template <int KIND>
 SXD u32 wv_exit_guess(const WvParams& P, const WvWin& w) { return wv_tail<KIND>(P, w).state; }
 
-template <int KIND, class EMIT>
-SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, const WvTail& tail) {
+template <int KIND, bool GREPT, class EMIT>
+SXD void wv_window_g(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, const WvTail& tail) {
     constexpr bool BYTES = KIND == 0;
     const u32 n = w.n;
     u32 probe = 0;
@@ -383,7 +389,7 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, c
         const u32 lc = st.lc, lb = st.lb, lback = st.lback;
         const bool lgp = st.lg != 0;
         st.lc = 0; st.lb = 0; st.lback = 0; st.cut = 0; st.lg = 0;
-        if (lc && (cont || (lc >= P.n_min && (!P.grep || lgp))))   // (its text ends with the call, the call in an error: helper.rs:410-415)
+        if (lc && (cont || (lc >= P.n_min && (!GREPT || lgp))))   // (its text ends with the call, the call in an error: helper.rs:410-415)
             emit(0u, (u32)WV_BEFORE, cont, -(i32)lback, KIND == 1 ? lb : (KIND >= 2 ? lback - w.head_pend : lback), lb);
     }
     // ---- the call in hand
@@ -398,7 +404,7 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, c
     const u32 lsrc = KIND >= 2 ? lback - w.head_pend : lback;
     const bool has_left = lrem > 0;
     st.lc = 0; st.lb = 0; st.lback = 0; st.lg = 0;
-    const bool GREP = P.grep != 0;
+    constexpr bool GREP = GREPT;
     u32 prec = (has_left || w.probe_before) ? WV_BEFORE : WV_EXACT;
     u32 cut_cend = 0;   // end of the call whose emission left st.cut up
     const bool tail_simple = wv_unpack(tail.state).lc != 0;   // the tail, taken alone, is just the leftover
@@ -536,6 +542,10 @@ SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, c
     }
     // the cut flag outlives the window only if the window's last call raised it; an empty call at the window end takes it too
     if (st.cut && (cut_cend < n || w.tail_empty)) st.cut = 0;
+}
+template <int KIND, class EMIT>
+SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, const WvTail& tail) {
+    if (P.grep) wv_window_g<KIND, true>(P, w, st, emit, tail); else wv_window_g<KIND, false>(P, w, st, emit, tail);
 }
 template <int KIND, class EMIT>
 SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, bool = true) {

@@ -41,21 +41,26 @@ def splice(scanner, gathered, file_len):
     Result in the reference's print order (sx_shard_splice)."""
     L = lib()
     world = len(gathered)
-    for k, g in enumerate(gathered):
-        if isinstance(g, list):   # (a rank with more than 4 GiB of strings arrives segment by segment, each with its own str_off space)
-            raise ValueError(f"rank {k}'s findings came in {len(g)} segments (more than 4 GiB of strings): sx_shard_splice takes one "
-                             "(findings, arena) pair per rank — splice such a file in parts (gather=False, splice_order on the ranks' lists)")
-    gathered = [(bytes(fb), bytes(ab)) for fb, ab in gathered]   # (numpy views of the gather buffer, or bytes)
-    keep = [(ctypes.create_string_buffer(fb, len(fb)), ctypes.create_string_buffer(ab, len(ab))) for fb, ab in gathered]
-    fptr = (ctypes.POINTER(Finding) * world)(*[ctypes.cast(f, ctypes.POINTER(Finding)) for f, _ in keep])
-    aptr = (ctypes.POINTER(ctypes.c_uint8) * world)(*[ctypes.cast(a, ctypes.POINTER(ctypes.c_uint8)) for _, a in keep])
-    nf = (ctypes.c_uint64 * world)(*[len(fb) // ctypes.sizeof(Finding) for fb, _ in gathered])
-    na = (ctypes.c_uint64 * world)(*[len(ab) for _, ab in gathered])
-    L.sx_shard_splice.argtypes = [ctypes.POINTER(ctypes.POINTER(Finding)), ctypes.POINTER(ctypes.c_uint64),
-                                  ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), ctypes.POINTER(ctypes.c_uint64), ctypes.c_int,
-                                  ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+    # (round 5) a rank with more than 4 GiB of strings arrives segment by segment, each with its own str_off space: a LIST of
+    # (findings, arena) pairs for that rank — sx_shard_splice_segs takes every rank's segments in a row and yields as many result
+    # segments as the strings need (round 4 refused such a rank)
+    segs, per_rank = [], []
+    for g in gathered:
+        mine = g if isinstance(g, list) else [g]
+        per_rank.append(len(mine))
+        segs += [(bytes(fb), bytes(ab)) for fb, ab in mine]   # (numpy views of the gather buffer, or bytes)
+    n = len(segs)
+    keep = [(ctypes.create_string_buffer(fb, len(fb)), ctypes.create_string_buffer(ab, len(ab))) for fb, ab in segs]
+    fptr = (ctypes.POINTER(Finding) * n)(*[ctypes.cast(f, ctypes.POINTER(Finding)) for f, _ in keep])
+    aptr = (ctypes.POINTER(ctypes.c_uint8) * n)(*[ctypes.cast(a, ctypes.POINTER(ctypes.c_uint8)) for _, a in keep])
+    nf = (ctypes.c_uint64 * n)(*[len(fb) // ctypes.sizeof(Finding) for fb, _ in segs])
+    na = (ctypes.c_uint64 * n)(*[len(ab) for _, ab in segs])
+    cnt = (ctypes.c_uint32 * world)(*per_rank)
+    L.sx_shard_splice_segs.argtypes = [ctypes.POINTER(ctypes.POINTER(Finding)), ctypes.POINTER(ctypes.c_uint64),
+                                       ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), ctypes.POINTER(ctypes.c_uint64),
+                                       ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
     r = ctypes.c_void_p()
-    scanner._chk(L.sx_shard_splice(fptr, nf, aptr, na, world, file_len, ctypes.byref(r)))
+    scanner._chk(L.sx_shard_splice_segs(fptr, nf, aptr, na, cnt, world, file_len, ctypes.byref(r)))
     return Result(scanner, r)
 
 
@@ -111,16 +116,20 @@ def _payload(res):
         a = np.ctypeslib.as_array(ap, shape=(alen,)) if alen else np.zeros(0, np.uint8)
         if n or alen:
             segs.append((f, a))
-    if sum(len(a) for _, a in segs) <= 0xFFFFFFFF:
+    limit = int(os.environ.get("SX_GATHER_SEG_BYTES", 0xFFFFFFFF))   # (tests: ranks that ship several segments without gigabytes of strings)
+    if sum(len(a) for _, a in segs) <= limit:
+        # (copies and the concatenation go through the records' BYTES: the dtype above names four of a record's fields, and numpy need
+        # not carry the bytes between named fields — precision, flags, Mission — through a structured copy; round 5: it did not)
         fs, ars, base = [], [], 0
         for f, a in segs:
+            fb = f.view(np.uint8)
             if base and len(f):
-                f = f.copy()
-                f["str_off"] += base
-            fs.append(f); ars.append(a); base += len(a)
-        f = fs[0] if len(fs) == 1 else (np.concatenate(fs) if fs else np.zeros(0, fdt))
+                fb = fb.copy()
+                fb.view(fdt)["str_off"] += base
+            fs.append(fb); ars.append(a); base += len(a)
+        f = fs[0] if len(fs) == 1 else (np.concatenate(fs) if fs else np.zeros(0, np.uint8))
         a = ars[0] if len(ars) == 1 else (np.concatenate(ars) if ars else np.zeros(0, np.uint8))
-        return [(f.view(np.uint8), a)]
+        return [(f, a)]
     if len(segs) > MAX_SEGMENTS:
         raise ValueError(f"{len(segs)} result segments on one rank: more than the gather ships ({MAX_SEGMENTS})")
     return [(f.view(np.uint8), a) for f, a in segs]
@@ -280,18 +289,28 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
             views = [(raw[o:o + nf], raw[o + nf:o + nf + na]) for o, nf, na in segs_k]
             out.append(views[0] if len(views) == 1 else (views if views else (raw[0:0], raw[0:0])))
     else:
+        # The same API as the receiving side (round 5): rank 0 posts its receives through batch_isend_irecv, and with
+        # ProcessGroupNCCL batched point-to-point runs on the group's communicator while a plain dist.send creates a two-rank communicator
+        # that BOTH peers must initialise — rank 0 never would, and the gather would hang with two or more real GPUs.  All segments of
+        # this rank go in one batch, each from its own slice of the send buffer (a segment's tensor must stay untouched until the batch is done).
+        total = sum(len(fb) + len(ab) for fb, ab in pairs)
+        ops, off = [], 0
+        buf = _device_buffer("send", total, device) if on_gpu and total else None   # one send buffer, kept from call to call
         for fb, ab in pairs:
             n = len(fb) + len(ab)
             if not n:
                 continue
-            if on_gpu:   # one send tensor, kept from call to call (round 3: a fresh device tensor per call)
-                mine = _device_buffer("send", n, device)[:n]
+            if on_gpu:
+                mine = buf[off:off + n]
                 if len(fb): mine[:len(fb)].copy_(torch.from_numpy(fb), non_blocking=True)
                 if len(ab): mine[len(fb):].copy_(torch.from_numpy(ab), non_blocking=True)
             else:
                 import numpy as np
                 mine = torch.from_numpy(np.concatenate([fb, ab]) if len(ab) and len(fb) else (fb if len(fb) else ab))
-            dist.send(mine, dst=0)
+            off += n
+            ops.append(dist.P2POp(dist.isend, mine, 0))
+        for q in (dist.batch_isend_irecv(ops) if ops else []):
+            q.wait()
     if timings is not None:
         timings["gather_ms"] = 1e3 * (time.perf_counter() - t_exchanged)
     return out, res

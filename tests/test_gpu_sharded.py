@@ -102,3 +102,23 @@ def test_the_nccl_transport_runs_once_on_one_gpu():
     p.join(timeout=120)
     assert res[0] == "ok", res[1]
     assert res[1], res
+
+
+def test_bench_with_eight_ranks_on_one_gpu_through_gloo():
+    """The driver's `bench.py --gpus N` line, N = 8, as far as one GPU can carry it: eight ranks sharing cuda:0, the exchange and the
+    gather through gloo.  The default is STRONG scaling (BASELINE.json's metric: one image at 1/2/4/8 GPUs) — here a 1 GiB image —, the
+    line says so, and every rank's shard went through the kernels."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--single-device", "--gib", "1",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong"
+    assert line["config"]["image_bytes"] == 1 << 30 and line["config"]["bytes_per_gpu"] == (1 << 30) // 8
+    assert "strong scaling" in line["config"]["workload"]
+    assert line["gather_ms_per_step"] is not None and line["exchange_ms_per_step"] is not None
+    assert line["findings_per_step"] > 0

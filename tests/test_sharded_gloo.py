@@ -89,10 +89,15 @@ def _worker(rank, world, port, kind, flags, halo, q, gather=True):
             dist.gather_object(res.findings(), parts if rank == 0 else None, dst=0)
         if rank == 0:
             if gather:
-                parts = [sharded.decode_findings(fb, ab) for fb, ab in gathered]
+                # (a rank whose result has several segments — more than 4 GiB of strings; here: SX_HOST_MERGE_SEG_BYTES — arrives as a LIST of pairs)
+                parts = [sum((sharded.decode_findings(fb, ab) for fb, ab in (g if isinstance(g, list) else [g])), []) for g in gathered]
+                if os.environ.get("SX_HOST_MERGE_SEG_BYTES"):
+                    assert any(isinstance(g, list) for g in gathered)
                 # the library's own splice (sx_shard_splice) == the Python restatement of it below
                 spliced = sharded.splice(sc, gathered, len(data))
                 assert [key(f) for f in spliced.findings()] == [key(f) for f in sharded.splice_order(parts, len(data))]
+                if os.environ.get("SX_SPLICE_SEG_BYTES"):
+                    assert sx.lib().sx_result_segments(spliced.h) > 1
                 spliced.free()
             else:
                 assert [sum(1 for f in p_[-o:] if o) for p_, o in zip(parts, gathered.overflow)] == gathered.overflow
@@ -125,6 +130,10 @@ CASES = [
     (4, "c4", dict(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African"), 1 << 14),
     (4, "giant", dict(encodings=["utf-8", "utf-16le"], chars_min="10"), 1 << 13),
     (3, "cjk", dict(encodings=["big5", "euc-jp", "utf-8"], chars_min="4", unicode_block_filter="Asian"), 1 << 12),
+    # round 5: BASELINE config 4's real layout — eight ranks —, and config 5's Mission set on them
+    (8, "c4", dict(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African"), 1 << 14),
+    (8, "giant", dict(encodings=["utf-8", "ascii"], chars_min="10"), 1 << 12),
+    (8, "cjk", dict(encodings=["utf-8,,,African", "utf-16le,,,African", "utf-16be,,,African", "big5,,,Cjk", "euc-jp,,,Asian", "koi8-r,,,Cyrillic"], chars_min="10"), 1 << 13),
 ]
 
 
@@ -135,6 +144,27 @@ def test_sharded_scan_equals_sequential(world, kind, flags, halo, gather):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, kind, flags, halo, q, gather)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+    assert res[0] == "ok", res[1]
+    assert res[1], f"sharded != sequential: {res[2]} vs {res[3]} findings, first diff {res[4]}"
+
+
+def test_ranks_whose_results_come_in_segments_are_gathered_and_spliced(monkeypatch):
+    """BASELINE config 5 at 8 x 32 GiB yields more than 4 GiB of strings per rank: a rank's result then has several segments, each
+    with its own str_off space, the gather ships them one by one and sx_shard_splice_segs puts them in order into a result of several
+    segments (round 4: splice() raised).  Here the segment sizes are forced down (SX_HOST_MERGE_SEG_BYTES, SX_SPLICE_SEG_BYTES)."""
+    monkeypatch.setenv("SX_HOST_MERGE_SEG_BYTES", "20000")
+    monkeypatch.setenv("SX_GATHER_SEG_BYTES", "30000")
+    monkeypatch.setenv("SX_SPLICE_SEG_BYTES", "50000")
+    world, kind, flags, halo = 3, "planted", dict(encodings=["ascii", "utf-8"], chars_min="5"), 1 << 14
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, flags, halo, q, True)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=600)
