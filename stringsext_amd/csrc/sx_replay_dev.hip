@@ -129,32 +129,73 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 //       probe: din > 0), completes = false, the string = the run's bytes (UTF-8 in, UTF-8 out);
 //   (3) behind the run nothing is pending (the cut flag stays down: :353-355 needs q characters or an open text end), the tail of
 //       the window holds no long stretch, and no run crosses wend: the region ends at wend (replay_region's shortcut (B)).
+// Also the pieces of a run that was cut at a window start ((4), (5) in replay_fast_region: a run across one window start, 9 % of the headline's).
 // A lane that finds (1)-(3) writes what replay_region<2> would have written — the region's record, the finding and the string in
 // the cache slot — and is done; the others put their slot on a list (one atomic per wavefront) that the general kernel then visits
 // instead of the whole head list.  tests/test_gpu_fast_replay.py runs every Mission shape with and without the pre-pass.
 // ---------------------------------------------------------------------------------------------------------------------------------
+// characters that BEGIN in [p, p + n): bytes that are no continuation bytes (valid UTF-8: a run's bytes)
+SXD u32 fast_count_chars(const u8* p, u32 n) {
+    u32 c = 0, t = 0;
+    for (; t + 8 <= n; t += 8) {
+        u64 v; __builtin_memcpy(&v, p + t, 8);
+        const u64 cont = v & ~(v << 1) & 0x8080808080808080ull;
+        c += 8u - (u32)__builtin_popcountll(cont);
+    }
+    for (; t < n; t++) c += (p[t] & 0xC0) != 0x80;
+    return c;
+}
 template <int ENC>
 SXD bool replay_fast_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx_finding* fout, u8* aout, u32 cap_f, u32 cap_b) {
     static_assert(ENC == 1, "UTF-8: the string is the run's bytes");
     const sx_run r = P.runs[i];
-    if (r.chars & kPieceCont) return false;
-    if (r.chars >= P.q) return false;                                   // (saturating count: >= q means at least q)
     const u32 W = P.W;
     const u64 rs = r.start, re = r.end;
     const u64 want = win_start(rs, W), wend = next_win_start(rs, W);
-    if (wend > P.len || re + 4 > wend) return false;
+    if (wend > P.len) return false;
     const u64 n_look = P.n_look ? P.n_look : P.n_runs;
-    if (i + 1 < n_look && P.runs[i + 1].start < wend) return false;
-    const u64 vs = call_start_before<ENC>(P, want, rs);
-    if (vs < want + 4) return false;
-    const u32 nb = (u32)(re - rs);
+    const bool has_next = i + 1 < n_look;
+    u64 nx_start = ~0ull, nx_chars = 0;
+    if (has_next) { nx_start = P.runs[i + 1].start; nx_chars = P.runs[i + 1].chars; }
+    const bool goes_on = re == wend;                                   // the run crosses the window end: it was cut there, if its piece is next
+    if (goes_on && !(has_next && nx_start == wend && (nx_chars & kPieceCont))) return false;
+    if (!goes_on && (re + 4 > wend || (has_next && nx_start < wend))) return false;
+    u64 vs = want, str0 = rs;
+    u8 precision = SX_PRECISION_EXACT;
+    if (r.chars & kPieceCont) {
+        // (4) a continuation piece (sx_replay_core.hpp kPieceCont): the window starts inside the run, delta bytes behind its beginning.  Carried in:
+        // the run's characters that complete in front of the window as the leftover — fewer than q: else the first line was cut and the
+        // cut flag is pending, the general kernel's —, the bytes of a character across the window start in the decoder.  The window's
+        // first call holds the rest of the run, which (leftover prepended) is its text-start stretch: position = the window start
+        // (din = 0), precision Before (:214-221), the string = the run's bytes from its beginning.  A piece that goes on into the next
+        // window only adds to the leftover (helper.rs:389-392): nothing is written.
+        const u64 delta = r.chars & ~kPieceCont;
+        if (delta == 0 || delta >= 4ull * P.q || delta > rs) return false;
+        str0 = rs - delta;
+        const u32 total = fast_count_chars(P.data + str0, (u32)(re - str0));     // characters of the run up to this piece's end
+        if (total >= P.q) return false;
+        if (!goes_on) {
+            const u32 before = fast_count_chars(P.data + str0, (u32)delta) - ((P.data[rs] & 0xC0) == 0x80 ? 1u : 0u);   // ... that complete in front of the window
+            if (before == 0) return false;                                      // (no leftover: the slice-start probe may speak, :176-207)
+        }
+        precision = SX_PRECISION_BEFORE;
+    } else {
+        if (r.chars >= P.q) return false;                                   // (saturating count: >= q means at least q)
+        vs = call_start_before<ENC>(P, want, rs);
+        if (vs < want + 4) return false;
+    }
+    if (goes_on) {   // (5) the run's first / a middle piece: it touches the end of its call's text with the call still open -> carried (helper.rs:389-392)
+        o.end = wend; o.n_find = 0; o.n_bytes = 0; o.status = kRegionOk; o.pad = 1;
+        return true;
+    }
+    const u32 nb = (u32)(re - str0);
     if (cap_f < 1 || nb > cap_b) return false;
     const u64 soff = want / kSliceLen * kSliceLen;
     sx_finding f;
     f.position = P.consumed0 + vs;
     f.str_off = 0;
     f.str_len = nb;
-    f.precision = SX_PRECISION_EXACT;
+    f.precision = precision;
     f.completes_previous = 0;
     f.mission_id = (u8)P.mission_id;
     f.reserved = 0;
@@ -162,7 +203,7 @@ SXD bool replay_fast_region(const ReplayParams& P, u64 i, ReplayRegionOut& o, sx
     f.reserved2 = 0;
     f.slice_index = (u32)(soff / kSliceLen) + P.slice_base;
     fout[0] = f;
-    const u8* s = P.data + rs;
+    const u8* s = P.data + str0;
     u32 t = 0;
     for (; t + 16 <= nb; t += 16) { uint4 v; __builtin_memcpy(&v, s + t, 16); __builtin_memcpy(aout + t, &v, 16); }
     if (t + 8 <= nb) { u64 v; __builtin_memcpy(&v, s + t, 8); __builtin_memcpy(aout + t, &v, 8); t += 8; }
