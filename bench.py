@@ -198,7 +198,7 @@ def main():
     t0 = time.perf_counter()
     kernel_ms = [0.0] * len(missions)
     device_ms = replay_ms = d2h_ms = wave_count_ms = wave_write_ms = 0.0
-    wave_windows = rescans = seq_pieces = 0
+    wave_windows = rescans = seq_pieces = fast_regions = general_regions = 0
     rescan_ms = 0.0
     findings = records = replay_bytes = 0
     for _ in range(args.steps):
@@ -217,6 +217,7 @@ def main():
         wave_write_ms += st.wave_write_ms
         wave_windows = st.wave_windows
         seq_pieces = st.seq_pieces
+        fast_regions, general_regions = st.fast_regions, st.general_regions
     barrier()
     dt = time.perf_counter() - t0
     marker()
@@ -324,6 +325,8 @@ def main():
             "gather_ms_per_step": round(timings.get("gather_ms", 0.0), 3) if world > 1 else None,
             "exchange_ms_per_step": round(timings.get("exchange_ms", 0.0), 3) if world > 1 else None,
             "findings_per_step": findings, "run_records_rank0": records,
+            # stage B, lane per region (round 5): regions the fast pre-pass settled / left to the general replay kernel (all steps)
+            "stage_b_regions": {"fast_prepass": fast_regions, "general_kernel": general_regions},
             "replay_fraction": round(replay_bytes / (len(missions) * nbytes), 5),
             # a buffer whose output is gigabytes (several string-dense Missions) is scanned in this many pieces, one after the other,
             # the copy of a piece's interleaved findings next to the following piece's kernels (0: in one go)

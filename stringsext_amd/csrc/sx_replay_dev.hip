@@ -91,23 +91,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
     constexpr int ENC = EQ & 7;
     constexpr bool QBIG = EQ >= 8;
     extern __shared__ __align__(16) u8 lds_win[];
-    u64 i = (u64)blockIdx.x * 64 + threadIdx.x;
-    if (P.hard_list) {   // (round 5) only what the fast pre-pass left
-        if (i >= *P.n_hard) return;
-        i = P.hard_list[i];
-    } else if (i >= *P.n_heads) return;
-    i = P.head_list[i];
-    ReplayRegionOut o;
-    o.end = 0; o.n_find = 0; o.n_bytes = 0; o.status = kRegionOk; o.pad = 0;
-    // slots have a minimum size: with more replaying regions than the arena has room for, the ones
-    // behind its end go without (cap 0: nothing fits, o.pad stays 0, pass 2 replays them)
-    const CacheGeom g = cache_geom(P.arena_bytes, *P.n_heads);
-    const u64 off = (u64)P.slot_of[i] * g.slot_bytes;
-    const bool room = off + g.slot_bytes <= P.arena_bytes;
-    u8* slot = P.cache_arena + (room ? off : 0);
-    replay_region<2, ENC, true, QBIG>(P, i, o, (sx_finding*)slot, slot + g.cap_f * sizeof(sx_finding), 0, room ? g.cap_f : 0u, room ? g.cap_b : 0u,
-                                lds_win + threadIdx.x * win_row_bytes(P.W));
-    out[i] = o;
+    // (round 5) with the fast pre-pass in front only what it left is visited: the list's length is known on the device only, so the grid is
+    // the whole head list's (a block that finds nothing to do returns at once) — bounded: the blocks stride through the list
+    const u64 n_todo = P.hard_list ? (u64)*P.n_hard : (u64)*P.n_heads;
+    for (u64 j = (u64)blockIdx.x * 64 + threadIdx.x; j < n_todo; j += (u64)gridDim.x * 64) {
+        u64 i = P.hard_list ? P.hard_list[j] : j;
+        i = P.head_list[i];
+        ReplayRegionOut o;
+        o.end = 0; o.n_find = 0; o.n_bytes = 0; o.status = kRegionOk; o.pad = 0;
+        // slots have a minimum size: with more replaying regions than the arena has room for, the ones
+        // behind its end go without (cap 0: nothing fits, o.pad stays 0, pass 2 replays them)
+        const CacheGeom g = cache_geom(P.arena_bytes, *P.n_heads);
+        const u64 off = (u64)P.slot_of[i] * g.slot_bytes;
+        const bool room = off + g.slot_bytes <= P.arena_bytes;
+        u8* slot = P.cache_arena + (room ? off : 0);
+        replay_region<2, ENC, true, QBIG>(P, i, o, (sx_finding*)slot, slot + g.cap_f * sizeof(sx_finding), 0, room ? g.cap_f : 0u, room ? g.cap_b : 0u,
+                                    lds_win + threadIdx.x * win_row_bytes(P.W));
+        out[i] = o;
+    }
 }
 
 // ---- Pass 1, the fast pre-pass (round 5) -----------------------------------------------------------------------------------------
@@ -654,8 +655,9 @@ hipError_t launch_replay_heads(const ReplayParams& P, uint32_t* slot_of, uint32_
 }
 hipError_t launch_replay_count(const ReplayParams& P, ReplayRegionOut* out, hipStream_t stream) {
     if (P.n_runs == 0) return hipSuccess;
-    const dim3 grid((unsigned)((P.n_runs + 63) / 64));
+    dim3 grid((unsigned)((P.n_runs + 63) / 64));
     const bool cache = P.cache_arena != nullptr;
+    if (cache && P.hard_list && grid.x > 4096u) grid.x = 4096u;   // (behind the fast pre-pass: a short list, walked by a bounded grid)
     const unsigned lds = 64u * win_row_bytes(P.W);
     static const int waves = [] { const char* e = getenv("SX_COUNT_WAVES"); return e ? atoi(e) : 4; }();
 #define SX_LAUNCH_COUNT(E)                                                                                              \
