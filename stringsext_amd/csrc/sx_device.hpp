@@ -229,6 +229,8 @@ struct WaveParams {
     // without warm-up; the host repeats it until the verification passes (a chain of wrong wavefronts needs a launch per link).
     // use_entry: the window-parallel writer takes wave_out[v - 1] the same way (set after repairs; families 0-2).
     uint32_t redo, use_entry;
+    // -r on the wave path itself (round 5; sx_wave_core.hpp wv_stretch_same, WvWin::D): families 0 - 2 without -g; lead_set is nullptr then
+    uint32_t same;
 };
 size_t wave_scratch_bytes(uint64_t n_waves);
 // pass 1 of wavefronts [v0, v1) + exclusive sums from v0 on + verification; totals (device, 4 x u64): findings, string bytes,

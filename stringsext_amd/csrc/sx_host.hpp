@@ -66,6 +66,7 @@ struct Mission {
     // wave-cooperative stage B (sx_wave_core.hpp): the Mission is one it covers, and its class byte per input byte
     bool wave_ok = false;
     bool wave_lead_check = false;   // -r on a UTF-8 / UTF-16 Mission: the wave path only for buffers in which at most one lead byte passes ubf (WaveParams::lead_set)
+    bool wave_same = false;         // -r without -g, families 0 - 2 (round 5): the wave kernels apply it themselves (WaveParams::same); no lead check then
     uint32_t wave_family = 0;   // 0: single-byte decoders, 1: UTF-8, 4: the two-byte family (Big5, Shift_JIS, EUC-KR)
     std::vector<uint8_t> wave_lut;
     std::vector<uint32_t> wave_pairs;   // two-byte family: 4 bits per byte pair (sx_wave_core.hpp wv_classify16_dbcs)

@@ -135,7 +135,11 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         }
         // (-g: does the leftover hold the grep char?  SplitStr walks its chars again when it is prepended, helper.rs:252-254)
         const uint32_t lg = m.c.grep_char >= 0 && st.last_scan_run_leftover.find((char)m.c.grep_char) != std::string::npos ? 1u : 0u;
-        const WvState in{ lc, lb, lc ? lback : 0u, st.last_run_str_was_printed_and_is_maybe_cut_str ? 1u : 0u, lc ? lg : 0u };
+        // (-r in the kernels: the lead byte of the leftover's last multi-byte character, as a code — helper.rs:279-296 meets it again first)
+        uint32_t lm = 0;
+        if (m.wave_same)
+            for (unsigned char c : st.last_scan_run_leftover) if (c >= 0xC2) lm = wv_lead_code(m.c.ubf, c);
+        const WvState in{ lc, lb, lc ? lback : 0u, st.last_run_str_was_printed_and_is_maybe_cut_str ? 1u : 0u, lc ? lg : 0u, lc ? lm : 0u };
         const uint64_t n_windows = g_all - g_lo;
         uint64_t batches = (n_windows + (8192ull * 64) - 1) / (8192ull * 64);
         batches = std::max<uint64_t>(1, std::min<uint64_t>(8, batches));
@@ -203,6 +207,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         }
         P.lead_set = d_leads; P.ubf = m.c.ubf;
         P.grep_char = m.c.grep_char;
+        P.same = m.wave_same ? 1u : 0u;
         P.wave_fbase = d_fb; P.wave_abase = d_ab;
         // Descriptors for the lane-per-finding writer: room for twice the findings a wavefront is expected to hold (the last buffer's
         // density; stage A's record count; else one per window), at most two per window and a third of the input's size in all.  A

@@ -98,12 +98,21 @@ SXD u32 wm_select(WvMask m, u32 from, u32 k) {
 // State carried from window to window, packed into 32 bits for the lane-to-lane exchange
 // ------------------------------------------------------------------------------------------
 // (round 5, -g: lg = the leftover holds the grep char — SplitStr walks the leftover's chars again when it is prepended, helper.rs:252-254)
-struct WvState { u32 lc, lb, lback, cut, lg; };
-SXD u32 wv_pack(const WvState& s) { return s.lc | (s.lb << 7) | (s.lback << 16) | (s.cut << 26) | (s.lg << 29); }
-SXD WvState wv_unpack(u32 v) { return WvState{ v & 127u, (v >> 7) & 511u, (v >> 16) & 1023u, (v >> 26) & 1u, (v >> 29) & 1u }; }
+// (-r: lm = the code — 1 .. 63, 0: none — of the lead byte of the leftover's last multi-byte character: where SplitStr's
+// last_multi_char_leading_byte stands when it has walked the prepended leftover again, helper.rs:279-296.  Six bits where room is: 25, 27-28,
+// 30-31 and 29 — lg's: a Mission with -g and -r does not come here, and neither mode reads the other's field; lback <= 4q + 3 needs nine.)
+struct WvState { u32 lc, lb, lback, cut, lg, lm; };
+SXD u32 wv_pack(const WvState& s) {
+    return s.lc | (s.lb << 7) | (s.lback << 16) | (s.cut << 26) | (s.lg << 29) | ((s.lm & 1u) << 25) | (((s.lm >> 1) & 3u) << 27) | (((s.lm >> 3) & 3u) << 30) |
+           (((s.lm >> 5) & 1u) << 29);
+}
+SXD WvState wv_unpack(u32 v) {
+    return WvState{ v & 127u, (v >> 7) & 511u, (v >> 16) & 511u, (v >> 26) & 1u, (v >> 29) & 1u,
+                    ((v >> 25) & 1u) | (((v >> 27) & 3u) << 1) | (((v >> 30) & 3u) << 3) | (((v >> 29) & 1u) << 5) };
+}
 constexpr u32 kWvPendBit = 1u << 27;   // on the state after a buffer's LAST window only, bits 27-28: bytes of the token it ends inside (two-byte family: 1; EUC-JP: 1 / 2)
 
-struct WvParams { u32 q, n_min, grep; };   // grep: the Mission has -g (WvWin::GC says where its char stands)
+struct WvParams { u32 q, n_min, grep, same; };   // grep: the Mission has -g (WvWin::GC says where its char stands); same: -r (WvWin::D, MBA)
 
 // One window as the state machine sees it.
 struct WvWin {
@@ -126,6 +135,13 @@ struct WvWin {
     WvMask PB;       // UTF-16: a call that starts here (in the masks) really starts two bytes later — its first character was kept from the call before
     WvMask GC;       // -g (WvParams::grep): the E bits of the characters that ARE the grep char (an ASCII character, accepted or not: helper.rs:252-254
                      // looks at it before the filter does)
+    // -r (WvParams::same, round 5; helper.rs:279-296).  MBA: the E bits of the accepted multi-byte characters; D: those whose lead byte differs
+    // from the one of the multi-byte character in front of them in the same call's text, that one accepted too (a rejected one, or the
+    // call's start, clears last_multi_char_leading_byte) — a BREAK in front of them unless SplitStr began a new walk in between (wv_stretch_same).
+    // mb0_e / mb0_code: the first call's first multi-byte character, if accepted (128: none): what stands in front of it is the leftover;
+    // mbl_code: the lead code of the window's last accepted multi-byte character
+    WvMask MBA, D;
+    u32 mb0_e, mb0_code, mbl_code;
 };
 
 enum { WV_BEFORE = 0, WV_EXACT = 1, WV_AFTER = 2 };   // == SX_PRECISION_*
@@ -145,6 +161,97 @@ SXD u32 wv_probe_pend(u32 prec) { return (prec >> 29) & 3u; }
 // it that neither completes the string before nor is carried on ends SplitStr's iteration for the rest of the call's text, helper.rs:410-415)
 SXD bool wv_mission_ok(int grep_char, u32 same_block, u32 n_min, u32 q) {
     return grep_char < 128 && !same_block && n_min >= 1 && n_min <= q && q <= 64;
+}
+
+// ------------------------------------------------------------------------------------------
+// -r (require_same_unicode_block, helper.rs:279-296; round 5).  SplitStr keeps the lead byte of the last multi-byte character that passed
+// (last_multi_char_leading_byte: cleared when a walk — a next() call — begins and by a multi-byte character that does not pass; an ASCII
+// character leaves it alone); a multi-byte character that passes but has ANOTHER lead byte is "rejected, and looked at again": the string in
+// hand ends in front of it as if a rejected character stood there, and it begins the next one.  In masks: w.D holds such characters as if the
+// variable were never cleared by a new walk (a property of the call's text alone), and a D bit is a break only if a multi-byte accepted
+// character lies between the walk's beginning `r` (the call's start, or where the last chunk that was handed out ended) and it — the first
+// multi-byte character of a walk never breaks.  What the leftover contributes is in the state (lm: the code of its last multi-byte
+// character's lead byte) and meets the first call's first multi-byte character (w.mb0_e, w.mb0_code) here.
+// One stretch of accepted chars [a, er) of the call in hand, sub-stretch by sub-stretch; otherwise wv_call's `stretch` (no -g: Missions with
+// both stay on the other path).
+// ------------------------------------------------------------------------------------------
+template <int KIND, class EMIT>
+struct WvSameCtx {
+    const WvParams& P; const WvWin& w; WvState& st; EMIT& emit;
+    WvMask Ec; u32 din, cend, n; bool inv_after;
+    u32 lbytes, lback, lsrc, lm_in;
+    u32* prec; u32* cut_cend;   // (cut_cend: the stretch-by-stretch driver's; else nullptr)
+    u32* r; bool* rv;           // the walk's beginning (a bound on E bits) / the leftover's characters still belong to the walk
+};
+template <int KIND, class EMIT>
+SXD void wv_stretch_same(const WvSameCtx<KIND, EMIT>& c, u32 a, u32 er, u32 pre, bool comp0) {
+    constexpr bool BYTES = KIND == 0;
+    const WvParams& P = c.P; const WvWin& w = c.w; WvState& st = c.st;
+    const WvMask av = wm_and(c.Ec, wm_range(a, er));
+    auto first_src = [&](u32 e) -> i32 { if (BYTES) return (i32)e; const i32 f = wm_prev(w.F, e); return f < 0 ? -(i32)w.head_back : f; };
+    u32 at = a, carried = pre, carried_b = pre ? c.lbytes : 0u;
+    i32 src = pre ? -(i32)c.lback : first_src(a);
+    bool comp = comp0;
+    for (;;) {
+        const WvMask left = wm_andn(av, wm_below(at));
+        const u32 e_first = wm_next(left, 0);
+        if (!carried && e_first >= 128) return;
+        // the sub-stretch in hand ends in front of the first BREAK: a D bit with a multi-byte accepted character between the walk's beginning and it
+        WvMask Dx = w.D;
+        u32 lb_eff;
+        if (*c.rv && c.lm_in) {   // the leftover holds one: every D bit counts, and so does the first call's first multi-byte character if its lead byte is another
+            lb_eff = 0;
+            if (w.mb0_e < 128 && w.mb0_code != c.lm_in) Dx = wm_or(Dx, wm_bit(w.mb0_e));
+        } else { const u32 m0 = wm_next(w.MBA, *c.r); lb_eff = m0 < 128 ? m0 + 1 : 129u; }
+        u32 lower = carried ? e_first : e_first + 1;   // (the sub-stretch's own first character never ends it)
+        if (lb_eff > lower) lower = lb_eff;
+        const u32 be_c = lower < 128 ? wm_next(wm_and(Dx, left), lower) : 128u;
+        const bool by_break = be_c < 128;
+        const u32 be = by_break ? be_c : 128u;
+        const WvMask sub = wm_and(left, wm_below(be));
+        const u32 cnt = carried + wm_popc(sub);
+        const bool ends_by_rej = by_break || er < 128;
+        const u32 pn = cnt < P.q ? cnt : P.q;
+        const bool is_q = pn == P.q;
+        const u32 rem = cnt - pn;
+        const bool tr = rem == 0 && !ends_by_rej;
+        if (!is_q && !tr && !comp && pn < P.n_min) {   // helper.rs:315-330: dropped; the walk goes on (no new next(): r stays)
+            if (!by_break) return;
+            at = be; carried = 0; carried_b = 0; src = first_src(be);
+            continue;
+        }
+        const bool maybe_cut = is_q || (tr && !c.inv_after);
+        const bool again = !comp && tr && !c.inv_after && !is_q;
+        if (!comp && !again && pn < P.n_min) return;   // (the text ends here)
+        const u32 inw = pn - carried;
+        u32 last_e = at, out_b = carried_b;
+        i32 src_end = src + (i32)(carried ? (KIND == 1 ? c.lbytes : c.lsrc) : 0u);
+        if (inw) {
+            last_e = BYTES ? e_first + inw - 1 : (rem == 0 ? (u32)wm_prev(sub, 127) : wm_select(sub, at, inw));
+            src_end = (i32)last_e + 1;
+            if (KIND == 1) out_b = (u32)(src_end - src);
+            else {
+                const WvMask tr_ = wm_range(e_first, last_e + 1);
+                out_b += inw + wm_popc(wm_and(w.O2, tr_)) + (BYTES ? 2 * wm_popc(wm_and(w.O3, tr_)) : wm_popc(wm_and(w.O3, tr_)) + wm_popc(wm_and(w.O4, tr_)));
+            }
+        }
+        if (again) {   // carried (it touches the text's end): nothing follows
+            const bool mb_here = inw && wm_any(wm_and(w.MBA, wm_range(e_first, last_e + 1)));
+            st.lc = pn; st.lb = out_b; st.lback = (u32)((i32)c.n - src); st.cut = 0; st.lg = 0;
+            st.lm = mb_here ? w.mbl_code : (carried ? c.lm_in : 0u);
+            return;
+        }
+        c.emit(c.din + (KIND == 3 && c.cend > c.din && wm_test(w.PB, c.din) ? 2u : 0u), *c.prec, comp, src, (u32)(src_end - src), out_b);
+        st.lc = 0; st.lb = 0; st.lback = 0; st.lm = 0; st.cut = maybe_cut ? 1u : 0u;
+        if (c.cut_cend) *c.cut_cend = c.cend;
+        *c.prec = WV_AFTER;
+        *c.r = inw ? last_e + 1 : at;   // a new walk begins behind what was handed out (the leftover alone: where the stretch stood)
+        *c.rv = false;
+        comp = is_q;   // helper.rs:418-421: what follows a full line touches inp_start_p with the cut flag up; what follows a break does not
+        carried = 0; carried_b = 0;
+        src = src_end;
+        if (inw) at = last_e + 1;
+    }
 }
 
 // One decoder call [din, cend) of the window: finding_collection.rs:146-290 with SplitStr::next (helper.rs:206-433) restated per
@@ -167,11 +274,11 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
                  u32 probe = 0) {
     const bool cont = st.cut != 0;   // :240-241: consumed by this call whatever it yields
     st.cut = 0;
-    const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback;
+    const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback, lm_in = st.lm;
     const bool lg_in = st.lg != 0;
     const u32 lsrc = KIND >= 2 ? lback - (first_call || din == 0 ? w.head_pend : 0u) : lback;   // the leftover's own source bytes
     const bool has_left = lrem > 0;
-    st.lc = 0; st.lb = 0; st.lback = 0; st.lg = 0;   // :211-227: the leftover is prepended, then gone
+    st.lc = 0; st.lb = 0; st.lback = 0; st.lg = 0; st.lm = 0;   // :211-227: the leftover is prepended, then gone
     const WvMask rng = wm_range(din, cend);
     const WvMask Ec = wm_and(w.E, rng);
     if (!has_left && !wm_any(Ec)) return;
@@ -190,7 +297,14 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
     // comp0: its first piece completes the string before.  Returns true if SplitStr's iteration ends here for the whole call (-g: a line
     // of q chars without the grep char that neither completes the string before nor is carried on, helper.rs:410-415).
     const bool GREP = P.grep != 0;
+    u32 walk_r = din;          // -r: where SplitStr's walk in hand began
+    bool walk_rv = has_left;   // ... with the leftover's characters in it
     auto stretch = [&](u32 a, u32 er, u32 pre, bool comp0) -> bool {
+        if (P.same) {   // -r: sub-stretch by sub-stretch (wv_stretch_same)
+            const WvSameCtx<KIND, EMIT> sc{ P, w, st, emit, Ec, din, cend, w.n, invalid_after, lbytes, lback, lsrc, lm_in, &prec, nullptr, &walk_r, &walk_rv };
+            wv_stretch_same<KIND, EMIT>(sc, a, er, pre, comp0);
+            return false;
+        }
         const WvMask av = wm_and(Ec, wm_range(a, er));
         const bool ends_by_rej = er < 128;          // a rejected char follows (else the call's text ends with it)
         const bool rej_is_grep = GREP && ends_by_rej && wm_test(w.GC, er);   // ... and it is the grep char: it counts for the stretch it ends (helper.rs:252-254)
@@ -342,7 +456,7 @@ SXD void wv_window_calls(const WvParams& P, const WvWin& w, WvState& st, EMIT& e
 struct WvTail { u32 a, state; };
 // (GREPT: -g as a compile-time constant — the kernels are instantiated with and without it: WvWin::GC costs four registers that a Mission
 // without -g must not pay for, and did, in spills: `-e ascii -n 4` 192 -> 146 GiB/s with -g decided at run time)
-template <int KIND, bool GREPT>
+template <int KIND, bool GREPT, bool SAMET = false>
 SXD WvTail wv_tail_g(const WvParams& P, const WvWin& w) {
     constexpr bool BYTES = KIND == 0;
     if (w.tail_empty || w.n == 0) return WvTail{ 128u, 0u };
@@ -356,19 +470,25 @@ SXD WvTail wv_tail_g(const WvParams& P, const WvWin& w) {
     const u32 c = wm_popc(wm_and(El, rng));
     // (with -g this is only a guess: a line of q chars without the grep char is no string, and may end the walk — the state is then
     // settled by wv_window like any other stretch's, tail_simple is false for it)
-    if (c >= P.q) return WvTail{ a, wv_pack(WvState{ 0, 0, 0, 1, 0 }) };
+    if (c >= P.q) return WvTail{ a, wv_pack(WvState{ 0, 0, 0, 1, 0, 0 }) };
     i32 src;
     if (BYTES) src = (i32)a;
     else { const i32 f = wm_prev(w.F, a); src = f < 0 ? -(i32)w.head_back : f; }
     u32 out_b;
     if (KIND == 1) out_b = (u32)(el + 1 - src);
     else out_b = c + wm_popc(wm_and(w.O2, rng)) + (BYTES ? 2 * wm_popc(wm_and(w.O3, rng)) : wm_popc(wm_and(w.O3, rng)) + wm_popc(wm_and(w.O4, rng)));
-    u32 lg = 0;
+    u32 lg = 0, lm = 0;
     if (GREPT) lg = wm_any(wm_and(w.GC, rng)) ? 1u : 0u;
-    return WvTail{ a, wv_pack(WvState{ c, out_b, (u32)((i32)w.n - src), 0, lg }) };
+    if (SAMET) {   // -r: a tail with a break inside is no plain leftover (state 0 here = "not simple": wv_window walks it); else the code of its last multi-byte character
+        if (wm_any(wm_and(w.D, wm_range(a + 1, (u32)el + 1)))) return WvTail{ a, 0u };
+        lm = wm_any(wm_and(w.MBA, rng)) ? w.mbl_code : 0u;
+    }
+    return WvTail{ a, wv_pack(WvState{ c, out_b, (u32)((i32)w.n - src), 0, lg, lm }) };
 }
 template <int KIND>
-SXD WvTail wv_tail(const WvParams& P, const WvWin& w) { return P.grep ? wv_tail_g<KIND, true>(P, w) : wv_tail_g<KIND, false>(P, w); }
+SXD WvTail wv_tail(const WvParams& P, const WvWin& w) {
+    return P.grep ? wv_tail_g<KIND, true>(P, w) : P.same ? wv_tail_g<KIND, false, true>(P, w) : wv_tail_g<KIND, false>(P, w);
+}
 // What the window hands on if what it was handed does not matter: every lane starts the exchange of the entry states from its
 // predecessor's guess instead of from "nothing carried" (which is wrong behind every window that ends inside a line of text or in
 // a stretch of accepted bytes: a third to all of them).  It is wrong when the tail is the text-start stretch of its call and something
@@ -377,7 +497,7 @@ SXD WvTail wv_tail(const WvParams& P, const WvWin& w) { return P.grep ? wv_tail_
 template <int KIND>
 SXD u32 wv_exit_guess(const WvParams& P, const WvWin& w) { return wv_tail<KIND>(P, w).state; }
 
-template <int KIND, bool GREPT, class EMIT>
+template <int KIND, bool GREPT, bool SAMET, class EMIT>
 SXD void wv_window_g(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, const WvTail& tail) {
     constexpr bool BYTES = KIND == 0;
     const u32 n = w.n;
@@ -388,7 +508,7 @@ SXD void wv_window_g(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit,
         const bool cont = st.cut != 0;
         const u32 lc = st.lc, lb = st.lb, lback = st.lback;
         const bool lgp = st.lg != 0;
-        st.lc = 0; st.lb = 0; st.lback = 0; st.cut = 0; st.lg = 0;
+        st.lc = 0; st.lb = 0; st.lback = 0; st.cut = 0; st.lg = 0; st.lm = 0;
         if (lc && (cont || (lc >= P.n_min && (!GREPT || lgp))))   // (its text ends with the call, the call in an error: helper.rs:410-415)
             emit(0u, (u32)WV_BEFORE, cont, -(i32)lback, KIND == 1 ? lb : (KIND >= 2 ? lback - w.head_pend : lback), lb);
     }
@@ -399,12 +519,14 @@ SXD void wv_window_g(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit,
     WvMask Ec = wm_and(w.E, wm_below(cend));
     const bool cont0 = st.cut != 0;
     st.cut = 0;
-    const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback;
+    const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback, lm_in = st.lm;
     const bool lg_in = st.lg != 0;
     const u32 lsrc = KIND >= 2 ? lback - w.head_pend : lback;
     const bool has_left = lrem > 0;
-    st.lc = 0; st.lb = 0; st.lback = 0; st.lg = 0;
+    st.lc = 0; st.lb = 0; st.lback = 0; st.lg = 0; st.lm = 0;
     constexpr bool GREP = GREPT;
+    u32 walk_r = 0;            // -r: where SplitStr's walk in hand began (wv_stretch_same)
+    bool walk_rv = has_left;   // ... with the leftover's characters in it
     u32 prec = (has_left || w.probe_before) ? WV_BEFORE : WV_EXACT;
     u32 cut_cend = 0;   // end of the call whose emission left st.cut up
     const bool tail_simple = wv_unpack(tail.state).lc != 0;   // the tail, taken alone, is just the leftover
@@ -413,6 +535,11 @@ SXD void wv_window_g(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit,
     // It runs ONCE per trip of the loop below, and only for stretches that yield or carry (a wavefront pays for it whenever one lane needs it)
     // (returns true if SplitStr's iteration ends here for the whole call: -g, wv_call)
     auto stretch = [&](u32 a, u32 er, u32 pre, bool comp0) -> bool {
+        if (SAMET) {   // -r: sub-stretch by sub-stretch
+            const WvSameCtx<KIND, EMIT> sc{ P, w, st, emit, Ec, din, cend, n, inv_after, lbytes, lback, lsrc, lm_in, &prec, &cut_cend, &walk_r, &walk_rv };
+            wv_stretch_same<KIND, EMIT>(sc, a, er, pre, comp0);
+            return false;
+        }
         const WvMask av = wm_and(Ec, wm_range(a, er));
         const bool ends_by_rej = er < 128;
         const bool rej_is_grep = GREP && ends_by_rej && wm_test(w.GC, er);
@@ -513,7 +640,9 @@ SXD void wv_window_g(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit,
                 break;
             }
             if (a >= 128) break;
-            if (a == tail.a && tail_simple && st.cut == 0) { st = wv_unpack(tail.state); break; }   // the tail, nothing carried into it: the leftover
+            // (-r: unless the leftover's multi-byte character still stands in the walk — its stretch was dropped — and the first one of the tail has another lead byte)
+            const bool lead_meets = SAMET && walk_rv && lm_in && w.mb0_e < 128 && w.mb0_e > tail.a && w.mb0_code != lm_in;
+            if (a == tail.a && tail_simple && st.cut == 0 && !lead_meets) { st = wv_unpack(tail.state); break; }   // the tail, nothing carried into it: the leftover
             comp0 = false;
             if (a >= cend) {   // another call: the ones walked over cleared the cut flag, the one right behind the emission takes it
                 const i32 c = wm_prev(w.CS, a);
@@ -526,6 +655,7 @@ SXD void wv_window_g(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit,
                 inv_after = cend < n || w.tail_empty != 0;
                 Ec = wm_and(w.E, wm_range(din, cend));
                 prec = WV_EXACT;
+                walk_r = din; walk_rv = false;
                 comp0 = cont && wm_next(Ec, 0) == a;   // (only the stretch at the very start of the text: helper.rs:327-330)
             }
             er = wm_next(wm_andn(Ec, w.A), a);
@@ -545,7 +675,9 @@ SXD void wv_window_g(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit,
 }
 template <int KIND, class EMIT>
 SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, const WvTail& tail) {
-    if (P.grep) wv_window_g<KIND, true>(P, w, st, emit, tail); else wv_window_g<KIND, false>(P, w, st, emit, tail);
+    if (P.grep) wv_window_g<KIND, true, false>(P, w, st, emit, tail);
+    else if (P.same) wv_window_g<KIND, false, true>(P, w, st, emit, tail);
+    else wv_window_g<KIND, false, false>(P, w, st, emit, tail);
 }
 template <int KIND, class EMIT>
 SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, bool = true) {
@@ -1494,6 +1626,64 @@ SXD void wv_set_grep(WvWin& w, const WvParams& P, const u8* win_bytes, u32 g, bo
     if (!P.grep) { w.GC = wm_zero(); return; }
     const WvMask raw = wv_grep_bytes<KIND>(win_bytes, w.n, g, be);
     w.GC = wm_and(raw, KIND == 2 ? wm_and(w.E, w.F) : w.E);
+}
+
+// ------------------------------------------------------------------------------------------
+// -r (round 5): WvWin::MBA / D / mb0 / mbl, by the window's own lane from its bytes — one trip per multi-byte character, in order (text in a
+// script beyond ASCII: up to W / 2 of them; only Missions with -r that can matter do this).  The lead byte of a character's UTF-8 form:
+// UTF-8: its first byte; single byte: from the decoder's table (x-user-defined: EF); UTF-16: from the unit (a pair: F0 | plane bits).
+// Codes: 1 + the rank of (lead & 0x3F) among the bits of ubf — five bits in the state (sx_mission.cpp takes Missions with <= 31 such leads).
+// ------------------------------------------------------------------------------------------
+SXD u32 wv_lead_code(u64 ubf, u32 lead) { return 1u + wv_popc64(ubf & ((1ull << (lead & 0x3Fu)) - 1ull)); }
+SXD u32 wv_lead_of_cp(u32 cp) { return cp < 0x800u ? 0xC0u | (cp >> 6) : cp < 0x10000u ? 0xE0u | (cp >> 12) : 0xF0u | (cp >> 18); }
+template <int KIND>
+SXD void wv_set_same(WvWin& w, const u8* win, u64 ubf, const uint16_t* table, bool be) {
+    w.MBA = wm_zero(); w.D = wm_zero(); w.mb0_e = 128; w.mb0_code = 0; w.mbl_code = 0;
+    // the characters beyond ASCII, at their last bytes
+    WvMask mb;
+    if (KIND == 1) mb = wm_andn(w.E, w.F);
+    else if (KIND == 3) mb = wm_and(w.E, w.O2);
+    else {   // single byte: bytes >= 0x80 that are characters
+        WvMask hi{ 0, 0 };
+        for (u32 k = 0; k < 8 && 16 * k < w.n; k++) {
+            const u32 nb = w.n - 16 * k < 16 ? w.n - 16 * k : 16u;
+            u32 x[4] = { 0, 0, 0, 0 };
+            if (nb == 16) __builtin_memcpy(x, win + 16 * k, 16);
+            else for (u32 t = 0; t < nb; t++) x[t >> 2] |= (u32)win[16 * k + t] << (8 * (t & 3));
+            const u64 m = wv_movemask16_b7(x[0] & 0x80808080u, x[1] & 0x80808080u, x[2] & 0x80808080u, x[3] & 0x80808080u);
+            if (k < 4) hi.lo |= m << (16 * k); else hi.hi |= m << (16 * (k - 4));
+        }
+        mb = wm_and(w.E, hi);
+    }
+    u32 lm = 0;          // last_multi_char_leading_byte as the call's text alone determines it
+    i32 cur_cs = -2;     // the call in hand (its CS bit; 0: the window's first call)
+    bool first_seen = false;
+    for (u32 e = wm_next(mb, 0); e < 128; e = wm_next(mb, e + 1)) {
+        i32 cs = wm_prev(w.CS, e);
+        if (cs < 0) cs = 0;   // (the window's first call, with or without a CS bit at 0)
+        if (cs != cur_cs) { cur_cs = cs; lm = 0; }
+        u32 lead;
+        if (KIND == 1) { const i32 f = wm_prev(w.F, e); lead = win[f < 0 ? -(i32)w.head_back : f]; }
+        else if (KIND == 3) {
+            const u32 u = be ? ((u32)win[(i32)e - 1] << 8) | win[e] : ((u32)win[e] << 8) | win[(i32)e - 1];
+            if ((u & 0xFC00u) == 0xDC00u) {   // the pair's low surrogate: its high one stands in front (in front of the window: head_back)
+                const u32 h = be ? ((u32)win[(i32)e - 3] << 8) | win[(i32)e - 2] : ((u32)win[(i32)e - 2] << 8) | win[(i32)e - 3];
+                lead = wv_lead_of_cp(0x10000u + ((h & 0x3FFu) << 10) + (u & 0x3FFu));
+            } else lead = wv_lead_of_cp(u);
+        } else {
+            const u32 b = win[e];
+            lead = wv_lead_of_cp(table ? (u32)table[b - 0x80u] : 0xF780u + (b - 0x80u));
+        }
+        if (wm_test(w.A, e)) {
+            w.MBA = wm_or(w.MBA, wm_bit(e));
+            if (lm && lm != lead) w.D = wm_or(w.D, wm_bit(e));
+            const u32 code = wv_lead_code(ubf, lead);
+            if (cs == 0 && !first_seen) { w.mb0_e = e; w.mb0_code = code; }
+            w.mbl_code = code;
+            lm = lead;
+        } else lm = 0;
+        if (cs == 0) first_seen = true;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -154,7 +154,8 @@ constexpr int wv_occ(int mode, int fam, int cls) {
     return mode == 0 ? (fam >= 4 ? SX_WV_OCC4 : fam == 1 ? SX_WV_OCC1 : SX_WV_OCC0) : (fam >= 4 ? SX_WV_OCCW4 : fam == 1 ? SX_WV_OCCW1 : SX_WV_OCCW0);
 }
 // GREP: the Mission has -g (round 5) — a compile-time constant: WvWin::GC and the grep rules cost registers a Mission without -g must not pay for
-template <int MODE, int FAM, int WPB, int CLS, bool GREP>
+// (OPT 0: neither; 1: -g; 2: -r, families 0 - 2 — WvWin::MBA / D and wv_stretch_same, round 5)
+template <int MODE, int FAM, int WPB, int CLS, int OPT>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ(MODE, FAM, CLS)))) void wave_replay_kernel(const WaveParams P) {
     // FAM 0: valid, accepted, O2, O3 (CLS 1: accepted, >= 0x80); FAM 1: E, A, F, MA, MB, G; FAM 4: E, A, F, MA, MB, G, O2, O3, O4 — 16 bits per lane and tile
     __shared__ u32 lds_all[WPB][wv_lds_words(FAM, CLS)];
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
     u32 ref_cov = 0;
     u64 fbase = 0, abase = 0;
     if (MODE == 1) { fbase = P.wave_fbase[v] - P.f_sub; abase = P.wave_abase[v] - P.a_sub; }   // relative to this launch's output segment
-    const WvParams WP{ P.q, P.n_min, GREP ? 1u : 0u };
+    constexpr bool GREP = OPT == 1, SAME = OPT == 2;
+    const WvParams WP{ P.q, P.n_min, GREP ? 1u : 0u, SAME ? 1u : 0u };
 
     for (u64 g0 = gw; g0 < own_end; g0 += kWvBatch) {
         const u64 g = g0 + lane;
@@ -617,11 +619,16 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         // -g (round 5): which of the window's characters are the grep char — every lane from its own window's bytes (in the cache: the
         // batch's classification has just read them); a wave-uniform branch, nothing for Missions without -g
         if (GREP) { if (active && wn) wv_set_grep<KIND>(w, WP, P.data + ws, (u32)P.grep_char, P.encoding == (u32)kEncUtf16be); else w.GC = wm_zero(); }
+        // -r (round 5): the accepted multi-byte characters and where their lead byte changes, the same way (a trip per such character)
+        if (SAME) {
+            if (active && wn) wv_set_same<KIND>(w, P.data + ws, P.ubf, P.table, P.encoding == (u32)kEncUtf16be);
+            else { w.MBA = wm_zero(); w.D = wm_zero(); w.mb0_e = 128; w.mb0_code = 0; w.mbl_code = 0; }
+        }
 
         // ---- 3. entry states: iterate until they are consistent along the lanes
         // (the exchange starts from every window's guess of what it hands on — wv_exit_guess: exact unless the window's last stretch is
         // the text-start stretch of its call and something is carried into it —, not from "nothing carried": one round, not two or three)
-        const WvTail tail = active ? wv_tail_g<KIND, GREP>(WP, w) : WvTail{ 128u, 0u };   // (the window's last stretch: looked at once, used by every replay of it)
+        const WvTail tail = active ? wv_tail_g<KIND, GREP, SAME>(WP, w) : WvTail{ 128u, 0u };   // (the window's last stretch: looked at once, used by every replay of it)
         u32 out = tail.state;
         u32 in = wv_from_prev(out, carry);
         const bool injected = g == P.g_lo;   // the host's exact state
@@ -644,8 +651,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 ce.stage = stage; ce.lane = lane;
 #endif
                 ce.widx = (u32)(g - own_start);
-                if (MODE == 0) { wv_window_g<KIND, GREP>(WP, w, st, ce, tail); nf = ce.nf; nb = ce.nb; }
-                else { WvCountEmit<0> cc; wv_window_g<KIND, GREP>(WP, w, st, cc, tail); nf = cc.nf; nb = cc.nb; }
+                if (MODE == 0) { wv_window_g<KIND, GREP, SAME>(WP, w, st, ce, tail); nf = ce.nf; nb = ce.nb; }
+                else { WvCountEmit<0> cc; wv_window_g<KIND, GREP, SAME>(WP, w, st, cc, tail); nf = cc.nf; nb = cc.nb; }
                 out = wv_pack(st);
             } else if (!active) out = in;
             u32 pin = wv_from_prev(out, carry);
@@ -670,7 +677,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             const u64 fo = fbase + tot_f + (excl >> 18), ao = abase + tot_b + (excl & 0x3FFFFu);
             WriteEmit<FAM> we_{ &P, fo, P.arena + ao, ao, ws };
             WvState st = wv_unpack(in);
-            wv_window_g<KIND, GREP>(WP, w, st, we_, tail);
+            wv_window_g<KIND, GREP, SAME>(WP, w, st, we_, tail);
         }
 #if defined(SX_WV_EXP) && SX_WV_EXP >= 3
         if (false) {
@@ -690,7 +697,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             } else {
                 WvDescEmit de{ slot, room, ab, (u32)(g - own_start) };
                 WvState st = wv_unpack(in);
-                wv_window_g<KIND, GREP>(WP, w, st, de, tail);
+                wv_window_g<KIND, GREP, SAME>(WP, w, st, de, tail);
             }
         }
         tot_f += bt >> 18; tot_b += bt & 0x3FFFFu;
@@ -767,8 +774,14 @@ size_t wave_scratch_bytes(uint64_t n_waves) {
 #define SX_WV_UNPACK(...) __VA_ARGS__
 #define SX_WV_LAUNCH(targs, grid, block, dyn, stream, Q)                                                        \
     do {                                                                                                       \
-        if ((Q).grep_char >= 0) hipLaunchKernelGGL((wave_replay_kernel<SX_WV_UNPACK targs, true>), grid, block, dyn, stream, Q);   \
-        else hipLaunchKernelGGL((wave_replay_kernel<SX_WV_UNPACK targs, false>), grid, block, dyn, stream, Q);                      \
+        if ((Q).grep_char >= 0) hipLaunchKernelGGL((wave_replay_kernel<SX_WV_UNPACK targs, 1>), grid, block, dyn, stream, Q);   \
+        else hipLaunchKernelGGL((wave_replay_kernel<SX_WV_UNPACK targs, 0>), grid, block, dyn, stream, Q);                      \
+    } while (0)
+// (families 0 - 2: with -r as well)
+#define SX_WV_LAUNCH_S(targs, grid, block, dyn, stream, Q)                                                      \
+    do {                                                                                                       \
+        if ((Q).same) hipLaunchKernelGGL((wave_replay_kernel<SX_WV_UNPACK targs, 2>), grid, block, dyn, stream, Q);   \
+        else SX_WV_LAUNCH(targs, grid, block, dyn, stream, Q);                                                  \
     } while (0)
 // pass 1 of wavefronts [v0, v1): counts, their exclusive sums from v0 on (fbase[v], abase[v]), the verification against
 // wavefront v0 - 1 (an earlier launch on the same stream) and among themselves
@@ -783,11 +796,11 @@ hipError_t launch_wave_count(const WaveParams& P, uint64_t v0, uint64_t v1, uint
     if (P.family == 5) SX_WV_LAUNCH((0, 5, 4, 1), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4 && P.swar.cls) SX_WV_LAUNCH((0, 4, 4, 1), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4) SX_WV_LAUNCH((0, 4, 4, 0), dim3((unsigned)((n + 3) / 4)), dim3(256), dyn, stream, Q);
-    else if (P.family == 2) SX_WV_LAUNCH((0, 2, 1, 0), dim3((unsigned)n), dim3(64), dyn, stream, Q);
-    else if (P.family == 1 && P.swar.cls) SX_WV_LAUNCH((0, 1, 1, 1), dim3((unsigned)n), dim3(64), dyn, stream, Q);
-    else if (P.family == 1) SX_WV_LAUNCH((0, 1, 1, 0), dim3((unsigned)n), dim3(64), dyn, stream, Q);
-    else if (P.swar.cls) SX_WV_LAUNCH((0, 0, 1, 1), dim3((unsigned)n), dim3(64), dyn, stream, Q);
-    else SX_WV_LAUNCH((0, 0, 1, 0), dim3((unsigned)n), dim3(64), dyn, stream, Q);
+    else if (P.family == 2) SX_WV_LAUNCH_S((0, 2, 1, 0), dim3((unsigned)n), dim3(64), dyn, stream, Q);
+    else if (P.family == 1 && P.swar.cls) SX_WV_LAUNCH_S((0, 1, 1, 1), dim3((unsigned)n), dim3(64), dyn, stream, Q);
+    else if (P.family == 1) SX_WV_LAUNCH_S((0, 1, 1, 0), dim3((unsigned)n), dim3(64), dyn, stream, Q);
+    else if (P.swar.cls) SX_WV_LAUNCH_S((0, 0, 1, 1), dim3((unsigned)n), dim3(64), dyn, stream, Q);
+    else SX_WV_LAUNCH_S((0, 0, 1, 0), dim3((unsigned)n), dim3(64), dyn, stream, Q);
     void* tmp = (void*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
     size_t tmp_bytes = scratch_bytes - (size_t)((uint8_t*)tmp - (uint8_t*)scratch);
     auto itf = rocprim::make_transform_iterator(rocprim::counting_iterator<u64>(0), U32ToU64{ P.wave_nf + v0 });
@@ -814,11 +827,11 @@ hipError_t launch_wave_write(const WaveParams& P, uint64_t v0, uint64_t v1, hipS
     if (P.family == 5) SX_WV_LAUNCH((1, 5, 4, 1), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4 && P.swar.cls) SX_WV_LAUNCH((1, 4, 4, 1), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
     else if (P.family == 4) SX_WV_LAUNCH((1, 4, 4, 0), dim3((unsigned)(((v1 - v0) + 3) / 4)), dim3(256), dyn, stream, Q);
-    else if (P.family == 2) SX_WV_LAUNCH((1, 2, 1, 0), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
-    else if (P.family == 1 && P.swar.cls) SX_WV_LAUNCH((1, 1, 1, 1), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
-    else if (P.family == 1) SX_WV_LAUNCH((1, 1, 1, 0), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
-    else if (P.swar.cls) SX_WV_LAUNCH((1, 0, 1, 1), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
-    else SX_WV_LAUNCH((1, 0, 1, 0), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
+    else if (P.family == 2) SX_WV_LAUNCH_S((1, 2, 1, 0), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
+    else if (P.family == 1 && P.swar.cls) SX_WV_LAUNCH_S((1, 1, 1, 1), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
+    else if (P.family == 1) SX_WV_LAUNCH_S((1, 1, 1, 0), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
+    else if (P.swar.cls) SX_WV_LAUNCH_S((1, 0, 1, 1), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
+    else SX_WV_LAUNCH_S((1, 0, 1, 0), dim3((unsigned)(v1 - v0)), dim3(64), dyn, stream, Q);
     return hipGetLastError();
 }
 

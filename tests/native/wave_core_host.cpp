@@ -85,6 +85,7 @@ bool drivers_agree(const WvParams& WP, const WvWin& w, u32 in) {
         for (size_t i = 0; same && i < a.v.size(); i++) same = a.v[i].din == b.v[i].din && a.v[i].prec == b.v[i].prec && a.v[i].comp == b.v[i].comp && a.v[i].src == b.v[i].src && a.v[i].len == b.v[i].len && a.v[i].out == b.v[i].out;
         if (!same) {
             fprintf(stderr, "drivers differ: in %08x out %08x / %08x  n %u pre_empty %u tail_empty %u head_back %u head_pend %u\n", in, wv_pack(sa), wv_pack(sb), w.n, w.pre_empty, w.tail_empty, w.head_back, w.head_pend);
+            fprintf(stderr, "  MBA %016llx%016llx\n  D  %016llx%016llx  mb0 %u/%u mbl %u\n", (unsigned long long)w.MBA.hi, (unsigned long long)w.MBA.lo, (unsigned long long)w.D.hi, (unsigned long long)w.D.lo, w.mb0_e, w.mb0_code, w.mbl_code);
             fprintf(stderr, "  E  %016llx%016llx\n  A  %016llx%016llx\n  F  %016llx%016llx\n  CS %016llx%016llx\n  PB %016llx%016llx\n", (unsigned long long)w.E.hi, (unsigned long long)w.E.lo, (unsigned long long)w.A.hi, (unsigned long long)w.A.lo, (unsigned long long)w.F.hi, (unsigned long long)w.F.lo, (unsigned long long)w.CS.hi, (unsigned long long)w.CS.lo, (unsigned long long)w.PB.hi, (unsigned long long)w.PB.lo);
             for (auto& e : a.v) fprintf(stderr, "  new: din %u prec %u comp %d src %d len %u out %u\n", e.din, e.prec, (int)e.comp, e.src, e.len, e.out);
             for (auto& e : b.v) fprintf(stderr, "  old: din %u prec %u comp %d src %d len %u out %u\n", e.din, e.prec, (int)e.comp, e.src, e.len, e.out);
@@ -116,7 +117,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
     u32 tot_f = 0, tot_b = 0;
     u64 fbase = 0, abase = 0;
     if (MODE == 1) { fbase = P.wave_fbase[v] - P.f_sub; abase = P.wave_abase[v] - P.a_sub; }
-    const WvParams WP{ P.q, P.n_min, P.grep_char >= 0 ? 1u : 0u };
+    const WvParams WP{ P.q, P.n_min, P.grep_char >= 0 ? 1u : 0u, P.same };
     std::vector<u32> lds[9];
     u32 dbcs_cov = 0;
     bool dbcs_valid = false;
@@ -402,6 +403,13 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
             else wv_set_grep<2>(w[l], WP, P.data + ws[l], (u32)P.grep_char, be);
         }
         if (!WP.grep) for (u32 l = 0; l < 64; l++) w[l].GC = wm_zero();
+        for (u32 l = 0; l < 64; l++) {   // -r: the accepted multi-byte characters and where their lead byte changes (as the kernel)
+            if (!active[l] || !WP.same || !wn[l]) { w[l].MBA = wm_zero(); w[l].D = wm_zero(); w[l].mb0_e = 128; w[l].mb0_code = 0; w[l].mbl_code = 0; continue; }
+            const bool be = P.encoding == kEncUtf16be;
+            if (P.family == 0) wv_set_same<0>(w[l], P.data + ws[l], P.ubf, P.table, be);
+            else if (P.family == 1) wv_set_same<1>(w[l], P.data + ws[l], P.ubf, P.table, be);
+            else wv_set_same<3>(w[l], P.data + ws[l], P.ubf, P.table, be);
+        }
         u32 in[64], out[64], nf[64], nb[64];
         std::vector<u32> stage(kWvStage * 192u, 0xDEADBEEFu);   // (the kernel's count pass stages a window's first findings as descriptors in LDS)
         bool todo[64], injected[64];
@@ -507,7 +515,7 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
                            uint64_t g_lo, uint32_t inject, uint32_t nwin, const uint8_t* lut, const uint16_t* table, int mission_id,
                            int file_id, sx_finding* fout, uint64_t fcap, uint8_t* aout, uint64_t acap, uint64_t* nf, uint64_t* nb,
                            uint32_t* final_state, uint64_t* bad_waves, int skip_idle, uint32_t* rounds_max, uint32_t family,
-                           const uint32_t* pairs, uint32_t encoding, uint32_t entry_skip, const uint32_t* swar25, const uint32_t* pairs2, int grep_char) {
+                           const uint32_t* pairs, uint32_t encoding, uint32_t entry_skip, const uint32_t* swar25, const uint32_t* pairs2, int grep_char, int same, uint64_t ubf) {
     WaveParams P;
     memset(&P, 0, sizeof P);
     P.data = data; P.len = len; P.consumed0 = consumed0; P.slice_base = slice_base; P.W = W; P.wps = wv_wps(W); P.q = q; P.n_min = n_min;
@@ -517,6 +525,7 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
     if (swar25) memcpy(&P.swar, swar25, sizeof P.swar);
     P.pairs2 = pairs2;
     P.grep_char = grep_char;
+    P.same = same && family <= 2 && grep_char < 0 ? 1u : 0u; P.ubf = ubf;
     if (family == 4 && !pairs2) P.swar.cls = 0;
     if (family == 5 && (!pairs2 || !P.swar.cls)) return -8;
     *nf = *nb = 0; *bad_waves = 0; *final_state = inject; *rounds_max = 0;
@@ -592,5 +601,8 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
 
 extern "C" uint32_t sxw_pack_state(uint32_t lc, uint32_t lb, uint32_t lback, uint32_t cut) { return wv_pack(WvState{ lc, lb, lback, cut, 0 }); }
 extern "C" uint32_t sxw_pack_state_g(uint32_t lc, uint32_t lb, uint32_t lback, uint32_t cut, uint32_t lg) { return wv_pack(WvState{ lc, lb, lback, cut, lg }); }
+
+extern "C" uint32_t sxw_pack_state_m(uint32_t lc, uint32_t lb, uint32_t lback, uint32_t cut, uint32_t lm) { return wv_pack(WvState{ lc, lb, lback, cut, 0, lm }); }
+extern "C" uint32_t sxw_lead_code(uint64_t ubf, uint32_t lead) { return wv_lead_code(ubf, lead); }
 
 extern "C" void sxw_round_stats(unsigned long long* out) { out[0] = g_rounds_total; out[1] = g_batches_total; out[2] = g_redo_lanes; out[3] = g_repairs; g_rounds_total = g_batches_total = g_redo_lanes = g_repairs = 0; }

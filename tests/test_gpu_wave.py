@@ -324,10 +324,13 @@ def test_utf16_text_is_dense_by_default():
         sc.close()
 
 
-def test_same_unicode_block_on_buffers_where_it_cannot_matter(wave_forced):
-    """-r on a UTF-8 Mission (helper.rs:279-296): the wave kernels do not know it and take a buffer only if at most one lead byte that passes
-    the filter occurs in it (the leftover carried in included) — ASCII text, text with one kind of multi-byte characters.  Two kinds: the
-    wavefronts give the buffer back.  The result is the oracle's either way; chunks that change the kind at their boundary"""
+@pytest.mark.parametrize("in_kernels", ["0", "1"])
+def test_same_unicode_block_on_buffers_where_it_cannot_matter(wave_forced, in_kernels, monkeypatch):
+    """-r on a UTF-8 Mission (helper.rs:279-296).  SX_WAVE_SAME=0 (and, always, Missions with -g as well): the wave kernels do not know it and
+    take a buffer only if at most one lead byte that passes the filter occurs in it (the leftover carried in included) — ASCII text, text with
+    one kind of multi-byte characters.  Two kinds: the wavefronts give the buffer back.  Round 5, the default: the kernels apply -r themselves
+    (sx_wave_core.hpp wv_stretch_same) and take every buffer.  The result is the oracle's either way; chunks that change the kind at their boundary"""
+    monkeypatch.setenv("SX_WAVE_SAME", in_kernels)
     rng = random.Random(99)
     ms = rc.missions(encodings=["utf-8"], chars_min="4", same_unicode_block=True, unicode_block_filter="All")
     ascii_text = text_lines(rng, 300_000)
@@ -345,7 +348,7 @@ def test_same_unicode_block_on_buffers_where_it_cannot_matter(wave_forced):
         for chunk in (None, 16384, 65536):
             assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (name, chunk)
     assert wave_windows_of_a_scan(ms, ascii_text) > 0 and wave_windows_of_a_scan(ms, latin) > 0    # the wave kernels took these
-    assert wave_windows_of_a_scan(ms, cyr) == 0                                                    # ... and gave this one back
+    assert (wave_windows_of_a_scan(ms, cyr) > 0) == (in_kernels == "1")                            # ... and gave this one back / took it too
     # the same for UTF-16: the lead bytes of the units' UTF-8 forms
     ms16 = rc.missions(encodings=["utf-16le"], chars_min="4", same_unicode_block=True, unicode_block_filter="All")
     to16 = lambda b: b.decode("utf-8", "ignore").encode("utf-16-le")
@@ -355,7 +358,25 @@ def test_same_unicode_block_on_buffers_where_it_cannot_matter(wave_forced):
         for chunk in (None, 16384):
             assert run_cli_product(ms16, [data], radix="x", device=0, chunk_bytes=chunk) == want, ("utf-16le", name, chunk)
     assert wave_windows_of_a_scan(ms16, to16(ascii_text[:150_000])) > 0 and wave_windows_of_a_scan(ms16, to16(latin)) > 0
-    assert wave_windows_of_a_scan(ms16, to16(cyr)) == 0
+    assert (wave_windows_of_a_scan(ms16, to16(cyr)) > 0) == (in_kernels == "1")
+
+
+def test_same_unicode_block_in_the_wave_kernels(wave_forced):
+    """-r applied by the wave kernels (round 5): the Missions and inputs of tests/test_wave_core.py's host run of the same code, through the
+    library — text that changes script every few characters, whole and in chunks"""
+    import test_wave_core as twc
+    rng = random.Random(404)
+    for kw in twc.SAME_MISSIONS + twc.SAME_UTF16:
+        ms = rc.missions(**kw)
+        codec = kw["encodings"][0]
+        enc = lambda t: t.encode(codec, errors="replace" if not codec.startswith("utf-") else "strict")
+        datas = [("scripts", enc(twc.same_text(rng, 150_000))), ("long runs", enc(twc.same_text(rng, 60_000, runs=(1, 7, 30, 64, 65, 130)))),
+                 ("russian", enc(twc.russian(rng, 100_000))), ("random", rng.randbytes(100_000))]
+        for name, data in datas:
+            want = sxo.run_cli(ms, [data], radix="x")
+            for chunk in (None, 16384):
+                assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (kw, name, chunk)
+        assert wave_windows_of_a_scan(ms, datas[0][1]) > 0, kw
 
 
 # ---- round 5: -g on the wave path (sx_wave_core.hpp WvWin::GC, the repairs of sx_wave.cpp) ----

@@ -26,7 +26,7 @@ def load_wave():
     L.sxw_emulate.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
                               C.c_uint32, C.c_char_p, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.POINTER(sx.Finding), C.c_uint64,
                               C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
-                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int]
+                              C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_uint64]
     L.sxw_pack_state.restype = C.c_uint32
     L.sxw_pack_state.argtypes = [C.c_uint32] * 4
     return L
@@ -93,8 +93,9 @@ def emulate(L, m, data, nwin=508, skip_idle=1, g_lo=0, inject=0, consumed0=None,
                           inject, nwin, lut, table, 0, 1, fout, cap_f, aout, cap_a, C.byref(nf), C.byref(nb), C.byref(fin), C.byref(bad),
                           skip_idle, C.byref(rounds), family, wave_pairs(m) if family == 4 else None, m["encoding"], 0,
                           wave_swar(m) if swar or family == 5 else None, wave_pairs2(m) if (swar and family == 4) or family == 5 else None,
-                          -1 if m.get("grep_char") is None else m["grep_char"])
-    if may_give_up and rcode == -9:   # the wavefronts gave the buffer back (UTF-16: a case the masks cannot say)
+                          -1 if m.get("grep_char") is None else m["grep_char"],
+                          1 if m.get("require_same_unicode_block") and m.get("grep_char") is None else 0, m["ubf"])
+    if may_give_up and rcode in (-9, -10):   # the wavefronts gave the buffer back (UTF-16: a case the masks cannot say; -10: the two-byte family after repairs, no descriptors)
         return None, dict(gave_up=True)
     assert rcode == 0, rcode
     arena = bytes(aout[:nb.value])
@@ -257,6 +258,98 @@ def test_emulated_wave_pipeline_utf16_with_a_grep_char(wave, gi):
             assert got == want, (name, nwin, skip, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
 
 
+# -r (round 5, helper.rs:279-296): a multi-byte character that passes the filter but whose lead byte differs from the one of the multi-byte
+# character before it in the same walk ends the string in front of it and begins the next one
+SAME_MISSIONS = [
+    dict(encodings=["utf-8"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True),
+    dict(encodings=["utf-8"], chars_min="2", output_line_len="8", unicode_block_filter="All", same_unicode_block=True),
+    dict(encodings=["utf-8"], chars_min="3", output_line_len="16", unicode_block_filter="All", ascii_filter="None", same_unicode_block=True),
+    dict(encodings=["utf-8"], chars_min="1", output_line_len="6", unicode_block_filter="Common", same_unicode_block=True),
+    dict(encodings=["utf-8"], chars_min="5", unicode_block_filter="All", ascii_filter="All-Ctrl", same_unicode_block=True),
+    dict(encodings=["koi8-r"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True),
+    dict(encodings=["koi8-r"], chars_min="2", output_line_len="6", unicode_block_filter="All", same_unicode_block=True),
+    dict(encodings=["windows-1253"], chars_min="2", output_line_len="8", unicode_block_filter="All", same_unicode_block=True),
+    dict(encodings=["windows-1252"], chars_min="3", unicode_block_filter="All", ascii_filter="None", same_unicode_block=True),
+]
+SAME_UTF16 = [
+    dict(encodings=["utf-16le"], chars_min="3", unicode_block_filter="All", same_unicode_block=True),
+    dict(encodings=["utf-16be"], chars_min="4", output_line_len="10", unicode_block_filter="Cyrillic", same_unicode_block=True),
+    dict(encodings=["utf-16le"], chars_min="2", output_line_len="6", unicode_block_filter="All", ascii_filter="None", same_unicode_block=True),
+    dict(encodings=["utf-16be"], chars_min="1", output_line_len="8", unicode_block_filter="Common", same_unicode_block=True),
+]
+SCRIPTS = ["abcdefghijklmnopqrstuvwxyz 0123456789", "\u0430\u0431\u0432\u0433\u0434\u0435\u0436\u0437\u0438\u0439\u043a\u043b\u043c\u043d\u043e\u043f",   # Cyrillic, lead D0
+           "\u0440\u0441\u0442\u0443\u0444\u0445\u0446\u0447\u0448\u0449\u044a\u044b\u044c\u044d\u044e\u044f",                                       # ... D1
+           "\u03b1\u03b2\u03b3\u03b4\u03b5\u03b6\u03b7\u03b8\u03b9\u03ba\u03bb\u03bc\u03bd\u03be\u03bf", "\u03c0\u03c1\u03c3\u03c4\u03c5\u03c6\u03c7\u03c8\u03c9",   # Greek CE / CF
+           "\u00e0\u00e9\u00ee\u00f5\u00fc\u00df\u00c6", "\u00a1\u00a9\u00ae\u00b5\u00bf",                                                              # Latin-1 C3 / C2
+           "\u4e2d\u6587\u5b57\u7b26", "\u3042\u3044\u3046\u30a2\u30a4", "\u20ac\u2013\u2022", "\U0001F600\U0001F601\U00020000", "\x01\x02\x7f", "\n"]
+
+
+def same_text(rng, n_chars, weights=(30, 20, 20, 6, 6, 6, 3, 4, 3, 3, 2, 2, 4), runs=(1, 1, 2, 3, 4, 5, 8, 13, 40)):
+    """runs of characters of one script each: lead bytes change inside lines, at their ends, next to window edges"""
+    out = []
+    k = 0
+    while k < n_chars:
+        sc = rng.choices(SCRIPTS, weights)[0]
+        ln = rng.choice(runs)
+        out.append("".join(rng.choice(sc) for _ in range(ln)))
+        k += ln
+    return "".join(out)
+
+
+def russian(rng, n_chars):
+    words = ["\u043f\u0440\u0438\u0432\u0435\u0442", "\u043c\u0438\u0440", "\u0441\u0442\u0440\u043e\u043a\u0430", "\u0434\u0430", "\u043d\u0435\u0442", "\u0430\u0431\u0432\u0433\u0434", "\u0440\u0441\u0442\u0443\u0444", "hello", "x", "42"]
+    out = []
+    k = 0
+    while k < n_chars:
+        wd = rng.choice(words)
+        out.append(wd + rng.choice([" ", " ", " ", ", ", ".\n", "\n"]))
+        k += len(wd) + 1
+    return "".join(out)
+
+
+@pytest.mark.parametrize("si", range(len(SAME_MISSIONS)))
+def test_emulated_wave_pipeline_with_same_unicode_block(wave, si):
+    m = rc.missions(**SAME_MISSIONS[si])[0]
+    assert wave_classes(m) is not None
+    codec = SAME_MISSIONS[si]["encodings"][0]
+    rng = random.Random(9700 + si)
+    golden = open(os.path.join(ROOT, "tests", "golden", "input1"), "rb").read()
+    enc = lambda t: t.encode(codec, errors="replace" if codec != "utf-8" else "strict")
+    extra = [("scripts", enc(same_text(rng, 40_000))), ("scripts, long runs", enc(same_text(rng, 30_000, runs=(1, 7, 30, 64, 65, 130)))),
+             ("russian", enc(russian(rng, 30_000))), ("input1", golden),
+             ("two leads", enc("".join(rng.choice("\u043f\u0440") for _ in range(20_000)))),
+             ("scripts, no ascii", enc(same_text(rng, 30_000, weights=(0, 20, 20, 6, 6, 6, 3, 4, 3, 3, 2, 1, 1))))]
+    for name, data in list(inputs(rng)) + extra:
+        want = oracle_findings([dict(m, mission_id=0)], data)
+        for nwin, skip in ((508, 1), (60, 0), (7, 1)):
+            got, info = emulate(wave, m, data, nwin=nwin, skip_idle=skip, swar=nwin != 60)
+            assert info["bad"] == 0, (name, nwin, info)
+            assert got == want, (name, nwin, skip, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
+
+
+@pytest.mark.parametrize("si", range(len(SAME_UTF16)))
+def test_emulated_wave_pipeline_utf16_with_same_unicode_block(wave, si):
+    m = rc.missions(**SAME_UTF16[si])[0]
+    assert wave_classes(m) is not None
+    be = SAME_UTF16[si]["encodings"][0].endswith("be")
+    codec = "utf-16-be" if be else "utf-16-le"
+    rng = random.Random(9800 + si)
+    golden2 = open(os.path.join(ROOT, "tests", "golden", "input2"), "rb").read()
+    datas = [("scripts", same_text(rng, 30_000).encode(codec)), ("scripts, long runs", same_text(rng, 20_000, runs=(1, 7, 30, 64, 65, 130)).encode(codec)),
+             ("russian", russian(rng, 20_000).encode(codec)), ("soup", utf16_soup(rng, 30_000, be)), ("input2", golden2[:len(golden2) // 2 * 2]),
+             ("astral", ("a\U0001F600b:\U00020000\U0001F601c?d \u4e2d" * 2000).encode(codec)), ("random", rng.randbytes(60_000))]
+    for name, data in datas:
+        want = oracle_findings([dict(m, mission_id=0)], data)
+        for nwin, skip in ((508, 1), (60, 0), (7, 1)):
+            got, info = emulate(wave, m, data, nwin=nwin, skip_idle=skip, may_give_up=True)
+            if got is None:
+                assert name in ("soup", "random", "input2"), name
+                continue
+            assert info["bad"] == 0, (name, nwin, info)
+            assert got == want, (name, nwin, skip, next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
+
+
+
 @pytest.mark.parametrize("gi", range(len(GREP_DBCS)))
 def test_emulated_wave_pipeline_two_byte_family_with_a_grep_char(wave, gi):
     from test_dbcs import soup as dbcs_soup, TEXT, CODEC
@@ -398,9 +491,9 @@ def test_which_missions_classify_by_ranges():
 
 
 def test_missions_the_wave_path_does_not_cover():
-    for kw in (dict(encodings=["koi8-r"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True),
-               dict(encodings=["utf-8"], chars_min="4", same_unicode_block=True),
+    for kw in (dict(encodings=["koi8-r"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True, grep_char="32"),
+               dict(encodings=["utf-8"], chars_min="4", same_unicode_block=True, grep_char="32"),
                dict(encodings=["ascii"], chars_min="0"), dict(encodings=["ascii"], chars_min="70"),
-               dict(encodings=["ascii"], chars_min="4", output_line_len="100"), dict(encodings=["utf-16le"], chars_min="4", same_unicode_block=True),
+               dict(encodings=["ascii"], chars_min="4", output_line_len="100"), dict(encodings=["utf-16le"], chars_min="4", same_unicode_block=True, grep_char="32"),
                dict(encodings=["big5"], chars_min="4"), dict(encodings=["euc-jp"], chars_min="4", unicode_block_filter="All"), dict(encodings=["gbk"], chars_min="4")):
         assert wave_classes(rc.missions(**kw)[0]) is None, kw

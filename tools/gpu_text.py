@@ -23,8 +23,25 @@ cases = [(dict(encodings=["ascii"], chars_min="4"), data), (dict(encodings=["utf
 # -g (round 5: on the wave path — the char of the reference's functional test 2, `:`, which a tenth of these lines hold; and a char none holds)
 cases += [(dict(encodings=["ascii"], chars_min="4", grep_char="58"), data), (dict(encodings=["utf-8"], chars_min="10", grep_char="58"), data),
           (dict(encodings=["utf-16le"], chars_min="10", grep_char="58"), data16), (dict(encodings=["utf-8"], chars_min="10", grep_char="63"), data)]
+# -r that matters (round 5: in the wave kernels): Russian text — the lead byte of its letters changes inside nearly every word (D0 / D1) —,
+# as UTF-8, KOI8-R and UTF-16LE; and the same text without -r beside it
+cyr_words = ["".join(rng.choice("абвгдежзийклмнопрстуфхцчшщъыьэюя") for _ in range(rng.randrange(2, 12))) for _ in range(500)]
+cl = []
+for _ in range(20000):
+    n = rng.randrange(10, 120); l = ""
+    while len(l) < n: l += rng.choice(cyr_words) + " "
+    cl.append(l[:n] + "\n")
+cyr = "".join(cl)
+def rep(b): return (b * (mib * (1 << 20) // len(b) + 1))[:mib << 20 if len(b) % 2 == 0 else mib << 20]
+c8, ck, c16 = cyr.encode("utf-8"), cyr.encode("koi8-r"), cyr.encode("utf-16-le")
+c8 = c8 + b" " * (-len(c8) % 4)   # (repeated whole: no character is cut where the copies meet)
+cases += [(dict(encodings=["utf-8"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True, name="russian"), rep(c8)),
+          (dict(encodings=["utf-8"], chars_min="4", unicode_block_filter="Cyrillic", name="russian"), rep(c8)),
+          (dict(encodings=["koi8-r"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True, name="russian"), rep(ck)),
+          (dict(encodings=["utf-16le"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True, name="russian"), rep(c16))]
 if len(sys.argv) > 2: cases = [c for c in cases if c[0]["encodings"][0] in sys.argv[2:]]
 for flags, data in cases:
+    what = flags.pop("name", "text")
     ms = rc.missions(**flags)
     sc = sx.Scanner(ms, device=0)
     d = sc.alloc(len(data)); sc.upload(d, data)
@@ -34,5 +51,5 @@ for flags, data in cases:
         res = sc.scan_device(d, len(data), file_id=1)
         dts.append(time.perf_counter() - t0); n = len(res); res.free()
     dt = sorted(dts[2:])[len(dts[2:]) // 2]
-    print(flags["encodings"], "-r" if flags.get("same_unicode_block") else "", f"-g {flags['grep_char']}" if flags.get("grep_char") else "", f"{mib} MiB text: {dt*1e3:.1f} ms = {mib/1024/dt:.2f} GiB/s (median of 6; min {min(dts)*1e3:.1f}, max {max(dts[2:])*1e3:.1f} ms), {n} findings")
+    print(flags["encodings"], "-r" if flags.get("same_unicode_block") else "", f"-g {flags['grep_char']}" if flags.get("grep_char") else "", f"{mib} MiB {what}: {dt*1e3:.1f} ms = {mib/1024/dt:.2f} GiB/s (median of 6; min {min(dts)*1e3:.1f}, max {max(dts[2:])*1e3:.1f} ms), {n} findings, wave windows {sc.stats().wave_windows}")
     sc.free(d); sc.close()

@@ -1,6 +1,7 @@
 """CPU-only randomized check of the wave-cooperative stage B (no GPU): sx_wave_core.hpp compiled for the host and driven as
 sx_wave_dev.hip drives it (tests/native/wave_core_host.cpp) against the oracle, on the cases of gpu_fuzz.py whose Missions
-the wave path covers, with random wavefront sizes.  usage: tools/wave_fuzz.py SECONDS [SEED]"""
+the wave path covers, with random wavefront sizes.  usage: tools/wave_fuzz.py SECONDS [SEED]
+SAME=1: every Mission with -r and without -g (round 5: -r in the wave kernels), half the inputs text that changes script every few characters"""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import fuzz_case
@@ -20,6 +21,12 @@ while time.time() - t0 < budget:
     if not data:
         continue
     for m in c["missions"]:
+        if os.environ.get("SAME"):
+            m = dict(m, require_same_unicode_block=True, grep_char=None)
+            if rng.random() < 0.5:
+                txt = twc.same_text(rng, rng.choice([300, 3000, 30_000]), runs=rng.choice([(1, 1, 2, 3, 4, 5, 8, 13, 40), (1, 2, 3), (1, 7, 30, 64, 65, 130)]))
+                codec = {1: "utf-8", 2: "utf-16-le", 3: "utf-16-be"}.get(m["encoding"])
+                data = txt.encode(codec) if codec else txt.encode("utf-8") if rng.random() < 0.3 else bytes(rng.choice(b"abc \xc1\xd2\xe3\xf4\xa5\xb6\n\x00") for _ in range(len(txt)))
         if twc.wave_classes(m) is None:
             continue
         want = oracle_findings([dict(m, mission_id=0)], data)
