@@ -39,6 +39,9 @@ while time.time() - t0 < budget:
             gave_up += 1
             continue
         max_rounds = max(max_rounds, info["rounds"])
+        if info["bad"] and m.get("grep_char") is not None:   # -g: a chain of wrong wavefronts longer than the repair rounds (the product: the other path)
+            gave_up += 1
+            continue
         if got != want or info["bad"]:
             print(f"MISMATCH wave seed {seed} case_seed {case_seed} mission {m} nwin={nwin} info={info}: {fuzz_case.describe(c)}")
             print("  first diff", next(((a, b) for a, b in zip(got, want) if a != b), (len(got), len(want))))
