@@ -143,6 +143,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         const uint64_t n_windows = g_all - g_lo;
         uint64_t batches = (n_windows + (8192ull * 64) - 1) / (8192ull * 64);
         batches = std::max<uint64_t>(1, std::min<uint64_t>(8, batches));
+        if (m.wave_same) batches = 1;   // (-r in the kernels: a window costs 5 to 20 times the usual, one wavefront per SIMD does not hide it — Russian text 51 -> 26 ms per 256 MiB)
         if (const char* e = getenv("SX_WAVE_BATCHES")) batches = (uint64_t)std::max(1, std::min(64, atoi(e)));
         const uint32_t nwin = (uint32_t)(batches * kWvBatch - kWvWarm);
         n_waves = (n_windows + nwin - 1) / nwin;
@@ -221,8 +222,12 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             uint64_t cap = per_byte > 0 ? (uint64_t)(2.0 * per_byte * bytes_per_wave) + 128 : (uint64_t)nwin + 64;
             cap = std::min<uint64_t>(cap, 2ull * nwin + 64);
             cap = std::min<uint64_t>(cap, std::max<uint64_t>(64, len / 3 / 12 / n_waves));
+            // (more findings expected than descriptors may be kept: the count pass would leave them for nothing — the window-parallel writer at once)
+            const bool too_dense = per_byte > 0 && per_byte * bytes_per_wave > (double)(2ull * nwin + 64) && !getenv("SX_WAVE_DESC_CAP");
             if (const char* e = getenv("SX_WAVE_DESC_CAP")) cap = (uint64_t)std::max(1, atoi(e));
-            if (ensure_rp(ctx, d, 2, n_waves * cap * 12 + 64) == SX_OK) { P.desc = (uint32_t*)d.d_rp[2]; P.desc_cap = (uint32_t)cap; }
+            if (too_dense) cap = 0;
+            if (cap == 0) { }
+            else if (ensure_rp(ctx, d, 2, n_waves * cap * 12 + 64) == SX_OK) { P.desc = (uint32_t*)d.d_rp[2]; P.desc_cap = (uint32_t)cap; }
             else ctx->set_err(std::string());   // (no room: the other writer)
         }
         if (K > 1) {

@@ -466,23 +466,24 @@ SXD WvTail wv_tail_g(const WvParams& P, const WvWin& w) {
     if (el < 0 || !wm_test(w.A, (u32)el)) return WvTail{ 128u, 0u };
     const i32 r = wm_prev(wm_andn(El, w.A), (u32)el);
     const u32 a = wm_next(El, r < 0 ? 0u : (u32)r + 1);
-    const WvMask rng = wm_range(a, (u32)el + 1);
+    // -r: a tail with a lead byte change inside is no plain leftover (wv_window walks it: tail_simple there is false); what it most likely
+    // leaves is what stands behind the LAST change — the exchange of the entry states starts from that guess
+    u32 a2 = a;
+    if (SAMET) { const i32 d = wm_prev(wm_and(w.D, wm_range(a + 1, (u32)el + 1)), 127); if (d >= 0) a2 = (u32)d; }
+    const WvMask rng = wm_range(a2, (u32)el + 1);
     const u32 c = wm_popc(wm_and(El, rng));
     // (with -g this is only a guess: a line of q chars without the grep char is no string, and may end the walk — the state is then
     // settled by wv_window like any other stretch's, tail_simple is false for it)
     if (c >= P.q) return WvTail{ a, wv_pack(WvState{ 0, 0, 0, 1, 0, 0 }) };
     i32 src;
-    if (BYTES) src = (i32)a;
-    else { const i32 f = wm_prev(w.F, a); src = f < 0 ? -(i32)w.head_back : f; }
+    if (BYTES) src = (i32)a2;
+    else { const i32 f = wm_prev(w.F, a2); src = f < 0 ? -(i32)w.head_back : f; }
     u32 out_b;
     if (KIND == 1) out_b = (u32)(el + 1 - src);
     else out_b = c + wm_popc(wm_and(w.O2, rng)) + (BYTES ? 2 * wm_popc(wm_and(w.O3, rng)) : wm_popc(wm_and(w.O3, rng)) + wm_popc(wm_and(w.O4, rng)));
     u32 lg = 0, lm = 0;
     if (GREPT) lg = wm_any(wm_and(w.GC, rng)) ? 1u : 0u;
-    if (SAMET) {   // -r: a tail with a break inside is no plain leftover (state 0 here = "not simple": wv_window walks it); else the code of its last multi-byte character
-        if (wm_any(wm_and(w.D, wm_range(a + 1, (u32)el + 1)))) return WvTail{ a, 0u };
-        lm = wm_any(wm_and(w.MBA, rng)) ? w.mbl_code : 0u;
-    }
+    if (SAMET) lm = wm_any(wm_and(w.MBA, rng)) ? w.mbl_code : 0u;
     return WvTail{ a, wv_pack(WvState{ c, out_b, (u32)((i32)w.n - src), 0, lg, lm }) };
 }
 template <int KIND>
@@ -529,7 +530,8 @@ SXD void wv_window_g(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit,
     bool walk_rv = has_left;   // ... with the leftover's characters in it
     u32 prec = (has_left || w.probe_before) ? WV_BEFORE : WV_EXACT;
     u32 cut_cend = 0;   // end of the call whose emission left st.cut up
-    const bool tail_simple = wv_unpack(tail.state).lc != 0;   // the tail, taken alone, is just the leftover
+    // the tail, taken alone, is just the leftover (-r: not if the lead byte changes inside it — tail.state is only a guess then)
+    const bool tail_simple = wv_unpack(tail.state).lc != 0 && !(SAMET && tail.a < 127 && wm_any(wm_andn(w.D, wm_below(tail.a + 1))));
 
     // wv_call's stretch, for the call in hand: `pre` chars carried in front (the leftover), accepted chars = the E bits in [a, er).
     // It runs ONCE per trip of the loop below, and only for stretches that yield or carry (a wavefront pays for it whenever one lane needs it)
@@ -1647,10 +1649,13 @@ SXD void wv_set_same(WvWin& w, const u8* win, u64 ubf, const uint16_t* table, bo
         WvMask hi{ 0, 0 };
         for (u32 k = 0; k < 8 && 16 * k < w.n; k++) {
             const u32 nb = w.n - 16 * k < 16 ? w.n - 16 * k : 16u;
-            u32 x[4] = { 0, 0, 0, 0 };
-            if (nb == 16) __builtin_memcpy(x, win + 16 * k, 16);
-            else for (u32 t = 0; t < nb; t++) x[t >> 2] |= (u32)win[16 * k + t] << (8 * (t & 3));
-            const u64 m = wv_movemask16_b7(x[0] & 0x80808080u, x[1] & 0x80808080u, x[2] & 0x80808080u, x[3] & 0x80808080u);
+            const u8* p = win + 16 * k;
+            u64 m = 0;
+            if (nb == 16) {   // (no array here: scalars only)
+                u32 x0, x1, x2, x3;
+                __builtin_memcpy(&x0, p, 4); __builtin_memcpy(&x1, p + 4, 4); __builtin_memcpy(&x2, p + 8, 4); __builtin_memcpy(&x3, p + 12, 4);
+                m = wv_movemask16_b7(x0 & 0x80808080u, x1 & 0x80808080u, x2 & 0x80808080u, x3 & 0x80808080u);
+            } else for (u32 t = 0; t < nb; t++) m |= (u64)(p[t] >> 7) << t;
             if (k < 4) hi.lo |= m << (16 * k); else hi.hi |= m << (16 * (k - 4));
         }
         mb = wm_and(w.E, hi);

@@ -149,14 +149,18 @@ constexpr u32 wv_lds_words(int fam, int cls) {   // ... and the descriptors stag
 #ifndef SX_WV_OCC4S
 #define SX_WV_OCC4S 4   // ... the two-byte family with SWAR classes and 2-bit pair codes (40 KB of LDS per block of four wavefronts)
 #endif
-constexpr int wv_occ(int mode, int fam, int cls) {
+#ifndef SX_WV_OCCS
+#define SX_WV_OCCS 2   // the -r kernels (OPT 2): 256 registers each — at 128 they spill 30 to 65 of them, and came out wrong (see the writer's `ws2`)
+#endif
+constexpr int wv_occ(int mode, int fam, int cls, int opt = 0) {
+    if (opt == 2) return SX_WV_OCCS;
     if (mode == 0 && fam >= 4 && cls) return SX_WV_OCC4S;
     return mode == 0 ? (fam >= 4 ? SX_WV_OCC4 : fam == 1 ? SX_WV_OCC1 : SX_WV_OCC0) : (fam >= 4 ? SX_WV_OCCW4 : fam == 1 ? SX_WV_OCCW1 : SX_WV_OCCW0);
 }
 // GREP: the Mission has -g (round 5) — a compile-time constant: WvWin::GC and the grep rules cost registers a Mission without -g must not pay for
 // (OPT 0: neither; 1: -g; 2: -r, families 0 - 2 — WvWin::MBA / D and wv_stretch_same, round 5)
 template <int MODE, int FAM, int WPB, int CLS, int OPT>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ(MODE, FAM, CLS)))) void wave_replay_kernel(const WaveParams P) {
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ(MODE, FAM, CLS, OPT)))) void wave_replay_kernel(const WaveParams P) {
     // FAM 0: valid, accepted, O2, O3 (CLS 1: accepted, >= 0x80); FAM 1: E, A, F, MA, MB, G; FAM 4: E, A, F, MA, MB, G, O2, O3, O4 — 16 bits per lane and tile
     __shared__ u32 lds_all[WPB][wv_lds_words(FAM, CLS)];
     __shared__ u8 lds_lut[FAM == 2 ? 512 : CLS ? 4 : 256];
@@ -675,7 +679,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         if (MODE == 1 && (nf | nb)) {
             const u32 excl = incl - packed;
             const u64 fo = fbase + tot_f + (excl >> 18), ao = abase + tot_b + (excl & 0x3FFFFu);
-            WriteEmit<FAM> we_{ &P, fo, P.arena + ao, ao, ws };
+            // (the window's offset once more, from its number: with the -r kernels — 30 to 45 spilled registers — `ws` came out of the loop
+            // above as the lane's number less one in the lanes that had run it twice, on gfx950 with ROCm 7.2.0's compiler; nothing else
+            // that lives across the loop is used here, and tools/gpu_fuzz.py compares every byte of the output)
+            u64 ws2 = 0; u32 wn2 = 0;
+            wv_window_at(g, P.W, P.wps, P.len, &ws2, &wn2);
+            WriteEmit<FAM> we_{ &P, fo, P.arena + ao, ao, ws2 };
             WvState st = wv_unpack(in);
             wv_window_g<KIND, GREP, SAME>(WP, w, st, we_, tail);
         }

@@ -3,6 +3,7 @@ fed with the oracle's runs — no GPU needed): random missions (encodings, -n, -
 -g, -r), random inputs (planted strings, adversarial soup, dense strings, text), random chunking,
 stage-B placement and alternative code paths (the environment switches of DESIGN.md §9), each compared
 byte for byte with the oracle's CLI output.  A failing case is replayed with tools/gpu_repro.py CASE_SEED.
+SX_FUZZ_TRACE=FILE: the case in hand is written there before it runs (a hang or a fault then names its case).
 usage: tools/gpu_fuzz.py SECONDS [SEED]"""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -21,6 +22,9 @@ while time.time() - t0 < budget:
     c = fuzz_case.make(case_seed)
     want = sxo.run_cli(c["missions"], c["files"], radix="x", flush_at_eof=c["flush"])
     fuzz_case.set_switches({} if host_only else c["switches"])
+    if os.environ.get("SX_FUZZ_TRACE"):
+        with open(os.environ["SX_FUZZ_TRACE"], "w") as tf:
+            tf.write(f"seed {seed} case {n} case_seed {case_seed}: {fuzz_case.describe(c)}\n")
     try:
         if host_only:
             got = run_cli_product(c["missions"], c["files"], radix="x", chunk_bytes=c["chunk"], device=None, flush_at_eof=c["flush"])

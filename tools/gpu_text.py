@@ -1,5 +1,5 @@
 """Text-like input (lines of 10-120 printable chars ended by \\n): how the whole path behaves when nearly every
-window start is crossed by a run.  usage: tools/gpu_text.py [MIB]"""
+window start is crossed by a run.  usage: tools/gpu_text.py [MIB [ENCODING | russian ...]]"""
 import os, random, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import refconfig as rc, stringsext_amd as sx
@@ -39,7 +39,7 @@ cases += [(dict(encodings=["utf-8"], chars_min="4", unicode_block_filter="Cyrill
           (dict(encodings=["utf-8"], chars_min="4", unicode_block_filter="Cyrillic", name="russian"), rep(c8)),
           (dict(encodings=["koi8-r"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True, name="russian"), rep(ck)),
           (dict(encodings=["utf-16le"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True, name="russian"), rep(c16))]
-if len(sys.argv) > 2: cases = [c for c in cases if c[0]["encodings"][0] in sys.argv[2:]]
+if len(sys.argv) > 2: cases = [c for c in cases if c[0]["encodings"][0] in sys.argv[2:] or c[0].get("name") in sys.argv[2:]]
 for flags, data in cases:
     what = flags.pop("name", "text")
     ms = rc.missions(**flags)
