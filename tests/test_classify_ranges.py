@@ -98,7 +98,19 @@ def run_utf8(m, d, near):
     return out
 
 
+_UNIT_RANGES = {}
+
+
 def unit_ranges(m):
+    """the Mission's accepted UTF-16 units as ranges (+ its high surrogates) — once per filter: 65 536 trips of Python, and run_utf16 is
+    called for every input, byte order, parity and `near` (this loop was 9 of the file's 9.6 minutes)"""
+    key = (m["af"], m["ubf"])
+    if key not in _UNIT_RANGES:
+        _UNIT_RANGES[key] = (_unit_ranges(m), [u for u in range(0xD800, 0xDC00) if passes(m, lead_of(0x10000 + ((u & 0x3FF) << 10)))])
+    return _UNIT_RANGES[key]
+
+
+def _unit_ranges(m):
     r = []
     for u in range(0x10000):
         if 0xD800 <= u <= 0xDFFF or not passes(m, lead_of(u)): continue
@@ -108,9 +120,8 @@ def unit_ranges(m):
 
 
 def run_utf16(m, d, be, parity, near):
-    r = unit_ranges(m)
+    r, hs = unit_ranges(m)   # (hs: the high surrogates of the planes that pass)
     below, across, above = sum(x[1] < 0x8000 for x in r), sum(x[0] < 0x8000 <= x[1] for x in r), sum(x[0] >= 0x8000 for x in r)
-    hs = [u for u in range(0xD800, 0xDC00) if passes(m, lead_of(0x10000 + ((u & 0x3FF) << 10)))]   # the high surrogates of the planes that pass
     assert (r or hs) and below <= 2 and across <= 1 and above <= 1 and len(hs) == (hs[-1] - hs[0] + 1 if hs else 0), "not a Mission of this classifier"
     hs_lo, hs_hi = (hs[0], hs[-1]) if hs else (0, 0)
     lo, hi = (ctypes.c_uint32 * 6)(*[x[0] for x in r]), (ctypes.c_uint32 * 6)(*[x[1] for x in r])
