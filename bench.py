@@ -90,14 +90,11 @@ def main():
     # `python bench.py --gpus N` without a launcher: start the N ranks the way the driver does (one process per GPU over
     # torch.distributed.run on 127.0.0.1) and pass their output through
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        import socket
         import subprocess
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # (--standalone: torchrun picks the rendezvous port itself — a port found by bind-and-close here could be taken before it is used)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=env))
 
     import torch

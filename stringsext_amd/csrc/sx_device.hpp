@@ -71,6 +71,9 @@ struct ScanParams {
     // range classifiers
     uint32_t a_lo, a_hi;   // accepted ASCII / single-unit range (inclusive)
     uint32_t u_lo, u_hi;   // UTF-8: accepted 2-byte lead range; UTF-16: accepted unit range [u_lo,u_hi]
+                           // (an EMPTY range is lo > hi with lo >= 0x81 — Mission::from_c writes 0x81 / 0x80 — and an empty unit slot is rng_c1 = 0,
+                           // rng_c2 = 0x7FFF7FFF: launch_v2 always runs the most general instantiations, Utf8Range3T<true, 2> / Utf16RangesT<.., 2, 1, 1, 1>,
+                           // which rely on exactly these encodings; tests/test_classify_ranges.py runs those instantiations with empty slots)
     uint32_t l3_lo, l3_hi; // kClsUtf8Range3: accepted 3-byte lead range (within E1..EF)
     uint32_t high_all;     // single-byte range: every byte >= 0x80 accepted
     uint32_t n_ranges;     // kClsSingleByteRanges: ranges in use (the others are empty); per range, replicated over the four bytes:

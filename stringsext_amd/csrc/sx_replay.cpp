@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <atomic>
 #include <deque>
+#include <mutex>
 #include <thread>
 
 #include "sx_host.hpp"
@@ -698,19 +699,28 @@ void merge_findings(std::vector<MissionFindings>& per, const std::shared_ptr<Pin
     for (auto& mf : per) release(mf);
 }
 
-// a packed segment as sx_finding records (sx_result_segment, the host-side merges and splices): once, by a few threads
+// a packed segment as sx_finding records (sx_result_segment, the host-side merges and splices): once, by a few threads.  Two callers at once
+// (ADVICE r4): one lock for all results — the records are filled into a vector of their own and swapped in when they are complete, so no
+// reader ever sees a vector of the right size with half of its records.  (32 bytes per finding on top of the packed 16: callers that
+// mind read sx_result_segment_packed.)
 void MissionFindings::expand() const {
-    if (!packed || expanded.size() == ext_nf) return;
-    expanded.resize(ext_nf);
+    static std::mutex mu;
+    if (!packed) return;
+    std::lock_guard<std::mutex> g(mu);
+    if (expanded.size() == ext_nf) return;
+    std::vector<sx_finding> out(ext_nf);
     const sx_finding16* src = data16();
     const SegInfo& si = *info;
     const size_t n = ext_nf;
     const unsigned nt = n < (1u << 20) ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
-    auto work = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) expanded[i] = expand_finding(src[i], si); };
-    if (nt <= 1) { work(0, n); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
-    for (auto& t : th) t.join();
+    auto work = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) out[i] = expand_finding(src[i], si); };
+    if (nt <= 1) work(0, n);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+        for (auto& t : th) t.join();
+    }
+    expanded.swap(out);
 }
 
 bool Result::flatten(std::string* err) {

@@ -223,7 +223,9 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             cap = std::min<uint64_t>(cap, 2ull * nwin + 64);
             cap = std::min<uint64_t>(cap, std::max<uint64_t>(64, len / 3 / 12 / n_waves));
             // (more findings expected than descriptors may be kept: the count pass would leave them for nothing — the window-parallel writer at once)
-            const bool too_dense = per_byte > 0 && per_byte * bytes_per_wave > (double)(2ull * nwin + 64) && !getenv("SX_WAVE_DESC_CAP");
+            // (clearly more: `-e ascii -n 4` on random bytes expects 1.0 to 1.15 times the room and its wavefronts mostly fit — with the lane-per-finding
+            // writer 12.4 -> 6 ms per GiB; Russian text with -r: 1.65 times)
+            const bool too_dense = per_byte > 0 && per_byte * bytes_per_wave > 1.4 * (double)(2ull * nwin + 64) && !getenv("SX_WAVE_DESC_CAP");
             if (const char* e = getenv("SX_WAVE_DESC_CAP")) cap = (uint64_t)std::max(1, atoi(e));
             if (too_dense) cap = 0;
             if (cap == 0) { }
