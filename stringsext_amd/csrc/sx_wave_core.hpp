@@ -190,24 +190,27 @@ SXD void wv_stretch_same(const WvSameCtx<KIND, EMIT>& c, u32 a, u32 er, u32 pre,
     const WvMask av = wm_and(c.Ec, wm_range(a, er));
     auto first_src = [&](u32 e) -> i32 { if (BYTES) return (i32)e; const i32 f = wm_prev(w.F, e); return f < 0 ? -(i32)w.head_back : f; };
     u32 at = a, carried = pre, carried_b = pre ? c.lbytes : 0u;
-    i32 src = pre ? -(i32)c.lback : first_src(a);
     bool comp = comp0;
+    // the BREAKS of this stretch as the walk in hand sees them: D bits with a multi-byte accepted character between the walk's beginning and
+    // them (again after every chunk that is handed out: a new walk begins there)
+    auto breaks = [&]() -> WvMask {
+        if (*c.rv && c.lm_in) {   // the leftover holds one: every D bit counts, and so does the first call's first multi-byte character if its lead byte is another
+            WvMask Dx = w.D;
+            if (w.mb0_e < 128 && w.mb0_code != c.lm_in) Dx = wm_or(Dx, wm_bit(w.mb0_e));
+            return wm_and(Dx, av);
+        }
+        const u32 m0 = wm_next(w.MBA, *c.r);
+        return m0 < 127 ? wm_and(wm_andn(w.D, wm_below(m0 + 1)), av) : wm_zero();
+    };
+    WvMask B = breaks();
     for (;;) {
         const WvMask left = wm_andn(av, wm_below(at));
         const u32 e_first = wm_next(left, 0);
         if (!carried && e_first >= 128) return;
-        // the sub-stretch in hand ends in front of the first BREAK: a D bit with a multi-byte accepted character between the walk's beginning and it
-        WvMask Dx = w.D;
-        u32 lb_eff;
-        if (*c.rv && c.lm_in) {   // the leftover holds one: every D bit counts, and so does the first call's first multi-byte character if its lead byte is another
-            lb_eff = 0;
-            if (w.mb0_e < 128 && w.mb0_code != c.lm_in) Dx = wm_or(Dx, wm_bit(w.mb0_e));
-        } else { const u32 m0 = wm_next(w.MBA, *c.r); lb_eff = m0 < 128 ? m0 + 1 : 129u; }
-        u32 lower = carried ? e_first : e_first + 1;   // (the sub-stretch's own first character never ends it)
-        if (lb_eff > lower) lower = lb_eff;
-        const u32 be_c = lower < 128 ? wm_next(wm_and(Dx, left), lower) : 128u;
-        const bool by_break = be_c < 128;
-        const u32 be = by_break ? be_c : 128u;
+        // the sub-stretch in hand ends in front of the first break (its own first character never ends it; a leftover in front: it may)
+        const u32 lower = carried ? e_first : e_first + 1;
+        const u32 be = lower < 128 ? wm_next(B, lower) : 128u;
+        const bool by_break = be < 128;
         const WvMask sub = wm_and(left, wm_below(be));
         const u32 cnt = carried + wm_popc(sub);
         const bool ends_by_rej = by_break || er < 128;
@@ -215,15 +218,16 @@ SXD void wv_stretch_same(const WvSameCtx<KIND, EMIT>& c, u32 a, u32 er, u32 pre,
         const bool is_q = pn == P.q;
         const u32 rem = cnt - pn;
         const bool tr = rem == 0 && !ends_by_rej;
-        if (!is_q && !tr && !comp && pn < P.n_min) {   // helper.rs:315-330: dropped; the walk goes on (no new next(): r stays)
+        if (!is_q && !tr && !comp && pn < P.n_min) {   // helper.rs:315-330: dropped; the walk goes on (no new next(): its beginning stays)
             if (!by_break) return;
-            at = be; carried = 0; carried_b = 0; src = first_src(be);
+            at = be; carried = 0; carried_b = 0;
             continue;
         }
         const bool maybe_cut = is_q || (tr && !c.inv_after);
         const bool again = !comp && tr && !c.inv_after && !is_q;
         if (!comp && !again && pn < P.n_min) return;   // (the text ends here)
         const u32 inw = pn - carried;
+        const i32 src = carried ? -(i32)c.lback : first_src(e_first);   // (the chunk's first source byte: looked up only for chunks that count)
         u32 last_e = at, out_b = carried_b;
         i32 src_end = src + (i32)(carried ? (KIND == 1 ? c.lbytes : c.lsrc) : 0u);
         if (inw) {
@@ -247,9 +251,9 @@ SXD void wv_stretch_same(const WvSameCtx<KIND, EMIT>& c, u32 a, u32 er, u32 pre,
         *c.prec = WV_AFTER;
         *c.r = inw ? last_e + 1 : at;   // a new walk begins behind what was handed out (the leftover alone: where the stretch stood)
         *c.rv = false;
+        B = breaks();
         comp = is_q;   // helper.rs:418-421: what follows a full line touches inp_start_p with the cut flag up; what follows a break does not
         carried = 0; carried_b = 0;
-        src = src_end;
         if (inw) at = last_e + 1;
     }
 }
@@ -1632,64 +1636,88 @@ SXD void wv_set_grep(WvWin& w, const WvParams& P, const u8* win_bytes, u32 g, bo
 
 // ------------------------------------------------------------------------------------------
 // -r (round 5): WvWin::MBA / D / mb0 / mbl, by the window's own lane from its bytes — one trip per multi-byte character, in order (text in a
-// script beyond ASCII: up to W / 2 of them; only Missions with -r that can matter do this).  The lead byte of a character's UTF-8 form:
+// script beyond ASCII: up to W / 2 of them; only Missions with -r that can matter do this; W = 128 bytes at most: 8 chunks).  The lead byte of a character's UTF-8 form:
 // UTF-8: its first byte; single byte: from the decoder's table (x-user-defined: EF); UTF-16: from the unit (a pair: F0 | plane bits).
 // Codes: 1 + the rank of (lead & 0x3F) among the bits of ubf — five bits in the state (sx_mission.cpp takes Missions with <= 31 such leads).
 // ------------------------------------------------------------------------------------------
 SXD u32 wv_lead_code(u64 ubf, u32 lead) { return 1u + wv_popc64(ubf & ((1ull << (lead & 0x3Fu)) - 1ull)); }
 SXD u32 wv_lead_of_cp(u32 cp) { return cp < 0x800u ? 0xC0u | (cp >> 6) : cp < 0x10000u ? 0xE0u | (cp >> 12) : 0xF0u | (cp >> 18); }
-template <int KIND>
-SXD void wv_set_same(WvWin& w, const u8* win, u64 ubf, const uint16_t* table, bool be) {
+// The window's bytes are read 16 at a time into registers and the characters' bytes are taken from there (a load per character, each
+// waiting for the one before, was a third of the -r kernels' time); LEADF: the lead byte of the UTF-8 form of a single-byte decoder's
+// character b >= 0x80 (the kernels: from the decoder table).
+template <int KIND, class LEADF>
+SXD void wv_set_same(WvWin& w, const u8* win, u64 ubf, bool be, LEADF lead_of_high) {
     w.MBA = wm_zero(); w.D = wm_zero(); w.mb0_e = 128; w.mb0_code = 0; w.mbl_code = 0;
-    // the characters beyond ASCII, at their last bytes
-    WvMask mb;
-    if (KIND == 1) mb = wm_andn(w.E, w.F);
-    else if (KIND == 3) mb = wm_and(w.E, w.O2);
-    else {   // single byte: bytes >= 0x80 that are characters
-        WvMask hi{ 0, 0 };
-        for (u32 k = 0; k < 8 && 16 * k < w.n; k++) {
-            const u32 nb = w.n - 16 * k < 16 ? w.n - 16 * k : 16u;
-            const u8* p = win + 16 * k;
-            u64 m = 0;
-            if (nb == 16) {   // (no array here: scalars only)
-                u32 x0, x1, x2, x3;
-                __builtin_memcpy(&x0, p, 4); __builtin_memcpy(&x1, p + 4, 4); __builtin_memcpy(&x2, p + 8, 4); __builtin_memcpy(&x3, p + 12, 4);
-                m = wv_movemask16_b7(x0 & 0x80808080u, x1 & 0x80808080u, x2 & 0x80808080u, x3 & 0x80808080u);
-            } else for (u32 t = 0; t < nb; t++) m |= (u64)(p[t] >> 7) << t;
-            if (k < 4) hi.lo |= m << (16 * k); else hi.hi |= m << (16 * (k - 4));
-        }
-        mb = wm_and(w.E, hi);
-    }
+    // where a multi-byte character is looked up — KIND 0: at its byte (found chunk by chunk: the bytes >= 0x80 that are characters);
+    // 1 (UTF-8): at its lead byte; 3 (UTF-16): at its unit's last byte (a pair: the low surrogate's)
+    WvMask vis = wm_zero();
+    if (KIND == 1) vis = wm_andn(w.F, w.E);
+    else if (KIND == 3) vis = wm_and(w.E, w.O2);
+    const bool any_cs = wm_any(wm_andn(w.CS, wm_bit(0)));
     u32 lm = 0;          // last_multi_char_leading_byte as the call's text alone determines it
     i32 cur_cs = -2;     // the call in hand (its CS bit; 0: the window's first call)
     bool first_seen = false;
-    for (u32 e = wm_next(mb, 0); e < 128; e = wm_next(mb, e + 1)) {
-        i32 cs = wm_prev(w.CS, e);
-        if (cs < 0) cs = 0;   // (the window's first call, with or without a CS bit at 0)
+    u32 mb0_lead = 0, mbl_lead = 0;
+    // one character: its last byte e, the lead byte of its UTF-8 form
+    auto visit = [&](u32 e, u32 lead) {
+        i32 cs = 0;
+        if (any_cs) { cs = wm_prev(w.CS, e); if (cs < 0) cs = 0; }   // (the window's first call, with or without a CS bit at 0)
         if (cs != cur_cs) { cur_cs = cs; lm = 0; }
-        u32 lead;
-        if (KIND == 1) { const i32 f = wm_prev(w.F, e); lead = win[f < 0 ? -(i32)w.head_back : f]; }
-        else if (KIND == 3) {
-            const u32 u = be ? ((u32)win[(i32)e - 1] << 8) | win[e] : ((u32)win[e] << 8) | win[(i32)e - 1];
-            if ((u & 0xFC00u) == 0xDC00u) {   // the pair's low surrogate: its high one stands in front (in front of the window: head_back)
-                const u32 h = be ? ((u32)win[(i32)e - 3] << 8) | win[(i32)e - 2] : ((u32)win[(i32)e - 2] << 8) | win[(i32)e - 3];
-                lead = wv_lead_of_cp(0x10000u + ((h & 0x3FFu) << 10) + (u & 0x3FFu));
-            } else lead = wv_lead_of_cp(u);
-        } else {
-            const u32 b = win[e];
-            lead = wv_lead_of_cp(table ? (u32)table[b - 0x80u] : 0xF780u + (b - 0x80u));
-        }
         if (wm_test(w.A, e)) {
             w.MBA = wm_or(w.MBA, wm_bit(e));
             if (lm && lm != lead) w.D = wm_or(w.D, wm_bit(e));
-            const u32 code = wv_lead_code(ubf, lead);
-            if (cs == 0 && !first_seen) { w.mb0_e = e; w.mb0_code = code; }
-            w.mbl_code = code;
+            if (cs == 0 && !first_seen) { w.mb0_e = e; mb0_lead = lead; }
+            mbl_lead = lead;
             lm = lead;
         } else lm = 0;
         if (cs == 0) first_seen = true;
+    };
+    if (KIND == 1 && w.head_back) {   // a character that began in front of the window and ends in it: its lead byte stands there
+        const u32 e0 = wm_next(w.E, 0);
+        if (e0 < 128 && wm_prev(w.F, e0) < 0) visit(e0, win[-(i32)w.head_back]);
     }
+    u32 prev3 = 0;   // UTF-16: the last dword of the chunk before (a high surrogate may stand there)
+    for (u32 k = 0; k < 8 && 16 * k < w.n; k++) {
+        const u32 nb = w.n - 16 * k < 16 ? w.n - 16 * k : 16u;
+        const u8* p = win + 16 * k;
+        u32 x0 = 0, x1 = 0, x2 = 0, x3 = 0;   // (scalars, no array: nothing here may end up in scratch)
+        if (nb == 16) { __builtin_memcpy(&x0, p, 4); __builtin_memcpy(&x1, p + 4, 4); __builtin_memcpy(&x2, p + 8, 4); __builtin_memcpy(&x3, p + 12, 4); }
+        else for (u32 t = 0; t < nb; t++) { const u32 v = (u32)p[t] << (8 * (t & 3)); if (t < 4) x0 |= v; else if (t < 8) x1 |= v; else if (t < 12) x2 |= v; else x3 |= v; }
+        u32 m;
+        if (KIND == 0) m = (u32)wv_movemask16_b7(x0 & 0x80808080u, x1 & 0x80808080u, x2 & 0x80808080u, x3 & 0x80808080u) & (u32)((k < 4 ? w.E.lo >> (16 * k) : w.E.hi >> (16 * (k - 4))) & 0xFFFFu);
+        else m = (u32)((k < 4 ? vis.lo >> (16 * k) : vis.hi >> (16 * (k - 4))) & 0xFFFFu);
+        while (m) {
+            const u32 jb = (u32)__builtin_ctz(m);
+            m &= m - 1;
+            const u32 pos = 16 * k + jb, sel = jb >> 2;
+            const u32 xx = sel == 0 ? x0 : sel == 1 ? x1 : sel == 2 ? x2 : x3;
+            if (KIND == 0) visit(pos, lead_of_high((xx >> (8 * (jb & 3))) & 0xFFu));
+            else if (KIND == 1) {
+                const u32 e = wm_next(w.E, pos);   // (its last byte; a character that ends in the next window is that window's)
+                if (e < 128) visit(e, (xx >> (8 * (jb & 3))) & 0xFFu);
+            } else {   // the unit's two bytes stand in one dword (jb is odd)
+                const u32 raw = (xx >> (8 * ((jb & 3) - 1))) & 0xFFFFu, u = be ? ((raw & 0xFFu) << 8) | (raw >> 8) : raw;
+                if ((u & 0xFC00u) == 0xDC00u) {   // the pair's low surrogate: its high one is the unit in front (in the dword in front: the chunk's, the chunk before's, or in front of the window)
+                    u32 hraw;
+                    if ((jb & 3) == 3) hraw = xx & 0xFFFFu;
+                    else if (jb >= 4) { const u32 xp = sel == 1 ? x0 : sel == 2 ? x1 : x2; hraw = xp >> 16; }
+                    else if (k > 0) hraw = prev3 >> 16;
+                    else hraw = (u32)win[-2] | ((u32)win[-1] << 8);
+                    const u32 h = be ? ((hraw & 0xFFu) << 8) | (hraw >> 8) : hraw;
+                    visit(pos, wv_lead_of_cp(0x10000u + ((h & 0x3FFu) << 10) + (u & 0x3FFu)));
+                } else visit(pos, wv_lead_of_cp(u));
+            }
+        }
+        prev3 = x3;
+    }
+    if (mb0_lead) w.mb0_code = wv_lead_code(ubf, mb0_lead);
+    if (mbl_lead) w.mbl_code = wv_lead_code(ubf, mbl_lead);
 }
+// (single-byte decoders: the lead byte from the decoder's table; nullptr: x-user-defined, U+F780 + b - 0x80)
+struct WvLeadOfTable {
+    const uint16_t* table;
+    SXD u32 operator()(u32 b) const { return wv_lead_of_cp(table ? (u32)table[b - 0x80u] : 0xF780u + (b - 0x80u)); }
+};
 
 // ------------------------------------------------------------------------------------------
 // Geometry: windows numbered through the buffer (slices of 4096 bytes, windows of W inside; the last window of a

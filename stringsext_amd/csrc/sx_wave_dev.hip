@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         if (GREP) { if (active && wn) wv_set_grep<KIND>(w, WP, P.data + ws, (u32)P.grep_char, P.encoding == (u32)kEncUtf16be); else w.GC = wm_zero(); }
         // -r (round 5): the accepted multi-byte characters and where their lead byte changes, the same way (a trip per such character)
         if (SAME) {
-            if (active && wn) wv_set_same<KIND>(w, P.data + ws, P.ubf, P.table, P.encoding == (u32)kEncUtf16be);
+            if (active && wn) wv_set_same<KIND>(w, P.data + ws, P.ubf, P.encoding == (u32)kEncUtf16be, WvLeadOfTable{ P.table });
             else { w.MBA = wm_zero(); w.D = wm_zero(); w.mb0_e = 128; w.mb0_code = 0; w.mbl_code = 0; }
         }
 

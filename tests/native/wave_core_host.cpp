@@ -406,9 +406,9 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
         for (u32 l = 0; l < 64; l++) {   // -r: the accepted multi-byte characters and where their lead byte changes (as the kernel)
             if (!active[l] || !WP.same || !wn[l]) { w[l].MBA = wm_zero(); w[l].D = wm_zero(); w[l].mb0_e = 128; w[l].mb0_code = 0; w[l].mbl_code = 0; continue; }
             const bool be = P.encoding == kEncUtf16be;
-            if (P.family == 0) wv_set_same<0>(w[l], P.data + ws[l], P.ubf, P.table, be);
-            else if (P.family == 1) wv_set_same<1>(w[l], P.data + ws[l], P.ubf, P.table, be);
-            else wv_set_same<3>(w[l], P.data + ws[l], P.ubf, P.table, be);
+            if (P.family == 0) wv_set_same<0>(w[l], P.data + ws[l], P.ubf, be, WvLeadOfTable{ P.table });
+            else if (P.family == 1) wv_set_same<1>(w[l], P.data + ws[l], P.ubf, be, WvLeadOfTable{ P.table });
+            else wv_set_same<3>(w[l], P.data + ws[l], P.ubf, be, WvLeadOfTable{ P.table });
         }
         u32 in[64], out[64], nf[64], nb[64];
         std::vector<u32> stage(kWvStage * 192u, 0xDEADBEEFu);   // (the kernel's count pass stages a window's first findings as descriptors in LDS)
