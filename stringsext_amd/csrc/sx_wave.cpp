@@ -220,12 +220,16 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             if (per_byte <= 0 && k < ctx->last_runs.size() && ctx->last_runs[k] && ctx->last_runs[k] < len / 16) per_byte = (double)ctx->last_runs[k] / (double)len;
             const double bytes_per_wave = (double)len / (double)n_waves;
             uint64_t cap = per_byte > 0 ? (uint64_t)(2.0 * per_byte * bytes_per_wave) + 128 : (uint64_t)nwin + 64;
-            cap = std::min<uint64_t>(cap, 2ull * nwin + 64);
-            cap = std::min<uint64_t>(cap, std::max<uint64_t>(64, len / 3 / 12 / n_waves));
+            // (-r in the kernels: text whose lead bytes change every few characters holds 5 to 10 findings per window, and the writer that
+            // works a lane per window pays for every one of them in turn — 1.5 / 3.5 ms per 32 MiB against 0.8 / 1.4 for the count pass:
+            // room for 16 per window, descriptors up to the input's size)
+            const uint64_t per_win = m.wave_same ? 16 : 2, share = m.wave_same ? 1 : 3;
+            cap = std::min<uint64_t>(cap, per_win * nwin + 64);
+            cap = std::min<uint64_t>(cap, std::max<uint64_t>(64, len / share / 12 / n_waves));
             // (more findings expected than descriptors may be kept: the count pass would leave them for nothing — the window-parallel writer at once)
             // (clearly more: `-e ascii -n 4` on random bytes expects 1.0 to 1.15 times the room and its wavefronts mostly fit — with the lane-per-finding
             // writer 12.4 -> 6 ms per GiB; Russian text with -r: 1.65 times)
-            const bool too_dense = per_byte > 0 && per_byte * bytes_per_wave > 1.4 * (double)(2ull * nwin + 64) && !getenv("SX_WAVE_DESC_CAP");
+            const bool too_dense = per_byte > 0 && per_byte * bytes_per_wave > 1.4 * (double)(per_win * nwin + 64) && !getenv("SX_WAVE_DESC_CAP");
             if (const char* e = getenv("SX_WAVE_DESC_CAP")) cap = (uint64_t)std::max(1, atoi(e));
             if (too_dense) cap = 0;
             if (cap == 0) { }

@@ -1799,12 +1799,14 @@ template <int K> struct WvCountEmit {
 // wavefront's stores never meet in a bank whatever j the lanes are at.  When the batch's prefix sums are known every lane moves its
 // descriptors to the wavefront's list.  Before, two were kept in registers and any window with more was replayed once more — on
 // `-e ascii -n 4` (1.5 findings per window) nearly every batch paid that second replay: a quarter of the count pass.
-constexpr u32 kWvStage = 6;
+// (-r kernels, round 5: twice as many — text whose lead bytes change every few characters leaves 5 to 10 findings per window, and their
+// wavefronts have LDS to spare)
+constexpr u32 kWvStage = 6, kWvStageSame = 12;
 template <class PTR> struct WvStageEmit {
     PTR stage;
-    u32 lane = 0, widx = 0, nf = 0, nb = 0;
+    u32 lane = 0, widx = 0, nf = 0, nb = 0, cap = kWvStage;
     SXD void operator()(u32 din, u32 prec, bool completes, i32 src_rel, u32 src_len, u32 out_len) {
-        if (nf < kWvStage) {
+        if (nf < cap) {
             const WvDesc x = wv_desc_pack(nb, widx, din, prec, completes, src_rel, src_len, out_len);
             PTR p = stage + nf * 192u + lane;
             p[0] = x.w0; p[64] = x.w1; p[128] = x.w2;

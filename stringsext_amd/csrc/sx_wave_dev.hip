@@ -130,8 +130,8 @@ template <int WPB> SXD void wave_lds_sync() {
 // single-byte Mission then stores accepted / >= 0x80 only, a two-byte one E, A, F, MA, MB (G and the lengths follow from them)
 constexpr int wv_n_masks(int fam, int cls) { return fam == 5 ? 5 : fam == 4 ? (cls ? 5 : 9) : fam == 1 ? (cls ? 5 : 6) : fam == 2 ? 4 : cls ? 2 : 4; }
 constexpr u32 kMaskWords = kWvMaxTiles * 32 + 8;
-constexpr u32 wv_lds_words(int fam, int cls) {   // ... and the descriptors staged in their place need kWvStage x 3 x 64 words
-    return (u32)wv_n_masks(fam, cls) * kMaskWords > kWvStage * 192u ? (u32)wv_n_masks(fam, cls) * kMaskWords : kWvStage * 192u;
+constexpr u32 wv_lds_words(int fam, int cls, int opt = 0) {   // ... and the descriptors staged in their place need kWvStage x 3 x 64 words (-r: kWvStageSame)
+    return (u32)wv_n_masks(fam, cls) * kMaskWords > (opt == 2 ? kWvStageSame : kWvStage) * 192u ? (u32)wv_n_masks(fam, cls) * kMaskWords : (opt == 2 ? kWvStageSame : kWvStage) * 192u;
 }
 
 // MODE 0: count; 1: write.  FAM 0: single-byte decoders; 1: UTF-8; 4: the two-byte family (Big5, Shift_JIS, EUC-KR: 4 wavefronts
@@ -162,7 +162,7 @@ constexpr int wv_occ(int mode, int fam, int cls, int opt = 0) {
 template <int MODE, int FAM, int WPB, int CLS, int OPT>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ(MODE, FAM, CLS, OPT)))) void wave_replay_kernel(const WaveParams P) {
     // FAM 0: valid, accepted, O2, O3 (CLS 1: accepted, >= 0x80); FAM 1: E, A, F, MA, MB, G; FAM 4: E, A, F, MA, MB, G, O2, O3, O4 — 16 bits per lane and tile
-    __shared__ u32 lds_all[WPB][wv_lds_words(FAM, CLS)];
+    __shared__ u32 lds_all[WPB][wv_lds_words(FAM, CLS, OPT)];
     __shared__ u8 lds_lut[FAM == 2 ? 512 : CLS ? 4 : 256];
     __shared__ u32 lds_pairs[FAM == 5 ? kWvJisWords + 3 : FAM == 4 ? (CLS ? 4096 : 8192) : 1];
     const u32 lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
@@ -652,6 +652,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 WvCountEmit<0> ce;
 #else
                 WvStageEmit<u32*> ce;
+                ce.cap = SAME ? kWvStageSame : kWvStage;
                 ce.stage = stage; ce.lane = lane;
 #endif
                 ce.widx = (u32)(g - own_start);
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             const u32 at = tot_f + (excl >> 18), ab = tot_b + (excl & 0x3FFFFu);
             WvDesc* slot = (WvDesc*)P.desc + v * (u64)P.desc_cap + at;
             const u32 room = at < P.desc_cap ? P.desc_cap - at : 0u;
-            if (nf <= kWvStage) {   // the usual window: what the count staged, its string offsets moved to the wavefront's
+            if (nf <= (SAME ? kWvStageSame : kWvStage)) {   // the usual window: what the count staged, its string offsets moved to the wavefront's
                 const u32 k = nf < room ? nf : room;
                 for (u32 j = 0; j < k; j++) {
                     const u32* p = stage + j * 192u + lane;

@@ -411,7 +411,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
             else wv_set_same<3>(w[l], P.data + ws[l], P.ubf, be, WvLeadOfTable{ P.table });
         }
         u32 in[64], out[64], nf[64], nb[64];
-        std::vector<u32> stage(kWvStage * 192u, 0xDEADBEEFu);   // (the kernel's count pass stages a window's first findings as descriptors in LDS)
+        std::vector<u32> stage(kWvStageSame * 192u, 0xDEADBEEFu);   // (the kernel's count pass stages a window's first findings as descriptors in LDS)
         bool todo[64], injected[64];
         // (as the kernel: the exchange starts from every window's guess of what it hands on, sx_wave_core.hpp wv_exit_guess)
         for (u32 l = 0; l < 64; l++)
@@ -429,6 +429,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                 if (todo[l] && active[l]) {
                     WvState st = wv_unpack(in[l]);
                     WvStageEmit<u32*> ce;
+                    ce.cap = P.same ? kWvStageSame : kWvStage;
                     ce.stage = stage.data(); ce.lane = l;
                     ce.widx = (u32)(g0 + l - own_start);
                     if (P.family == 0) wv_window<0>(WP, w[l], st, ce, skip_idle);
@@ -469,7 +470,7 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                 const u32 at = tot_f + bf, ab = tot_b + bb;
                 WvDesc* slot = (WvDesc*)P.desc + v * (u64)P.desc_cap + at;
                 const u32 room = at < P.desc_cap ? P.desc_cap - at : 0u;
-                if (nf[l] <= kWvStage) {
+                if (nf[l] <= (P.same ? kWvStageSame : kWvStage)) {
                     const u32 k = nf[l] < room ? nf[l] : room;
                     for (u32 j = 0; j < k; j++) {
                         const u32* sp = stage.data() + j * 192u + l;
@@ -536,7 +537,7 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
     std::vector<u64> fb(n_waves), ab(n_waves);
     P.wave_nf = wnf.data(); P.wave_nb = wnb.data(); P.wave_in = win.data(); P.wave_out = wout.data();
     // descriptors: two per window, or few enough that some wavefronts overflow (then only the window-parallel writer's output is checked)
-    P.desc_cap = (nwin & 3u) == 1u ? nwin / 8 + 1 : 2 * nwin + 64;
+    P.desc_cap = (nwin & 3u) == 1u ? nwin / 8 + 1 : (P.same ? 16 : 2) * nwin + 64;   // (-r: as sx_wave.cpp)
     std::vector<u32> desc((size_t)(n_waves * P.desc_cap * 3 + 3), 0xDEADBEEFu);
     P.desc = nwin <= kWvDescMaxWin ? desc.data() : nullptr;   // (as sx_wave.cpp: larger wavefronts do without)
     for (u64 v = 0; v < n_waves; v++) if (!wave<0>(P, v, skip_idle != 0, rounds_max)) return g_gave_up ? -9 : g_driver_mismatch ? -7 : -1;
