@@ -64,7 +64,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)   # (two: the first pass learns which Missions are string-dense, the second sizes the pools of the path they then take)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--gib", type=float, default=None, help="bytes per GPU in GiB (default: the workload's size)")
     ap.add_argument("--subchunk-kib", type=int, default=0)

@@ -22,6 +22,8 @@ timeout 600 tools/pmc_pass.sh ${tag}_write "WRITE_SIZE" > /dev/null 2>&1 < /dev/
 python bench.py --gpus 2 --backend gloo --single-device --gib 16 --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_2ranks_1gpu_gloo.json
 python bench.py --gpus 2 --backend gloo --single-device --scaling strong --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_2ranks_1gpu_gloo_strong.json
 python bench.py --gpus 2 --backend gloo --single-device --workload c5 --gib 8 --warmup 2 --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_2ranks_1gpu_gloo_c5_8gib.json
+python bench.py --gpus 8 --backend gloo --single-device --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_8ranks_1gpu_gloo_strong.json
+tools/sort_reach.sh ${tag} > /dev/null 2>&1 < /dev/null
 # SQ counters of the wave kernels
 timeout 1500 tools/wave_pmc.sh ${tag} > /dev/null 2>&1 < /dev/null
 ls -la gpurun_out/ | grep ${tag}
