@@ -149,11 +149,15 @@ constexpr u32 wv_lds_words(int fam, int cls, int opt = 0) {   // ... and the des
 #ifndef SX_WV_OCC4S
 #define SX_WV_OCC4S 4   // ... the two-byte family with SWAR classes and 2-bit pair codes (40 KB of LDS per block of four wavefronts)
 #endif
+#ifndef SX_WV_OCCG
+#define SX_WV_OCCG 2   // the -g kernels (OPT 1) likewise: no spilled register at 256 (17 to 81 at 128), and text with -g runs as fast (72 / 70 / 51 GiB/s)
+#endif
 #ifndef SX_WV_OCCS
 #define SX_WV_OCCS 2   // the -r kernels (OPT 2): 256 registers each — at 128 they spill 30 to 65 of them, and came out wrong (see the writer's `ws2`)
 #endif
 constexpr int wv_occ(int mode, int fam, int cls, int opt = 0) {
     if (opt == 2) return SX_WV_OCCS;
+    if (opt == 1) return SX_WV_OCCG;
     if (mode == 0 && fam >= 4 && cls) return SX_WV_OCC4S;
     return mode == 0 ? (fam >= 4 ? SX_WV_OCC4 : fam == 1 ? SX_WV_OCC1 : SX_WV_OCC0) : (fam >= 4 ? SX_WV_OCCW4 : fam == 1 ? SX_WV_OCCW1 : SX_WV_OCCW0);
 }
