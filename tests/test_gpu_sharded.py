@@ -104,6 +104,51 @@ def test_the_nccl_transport_runs_once_on_one_gpu():
     assert res[1], res
 
 
+def _nccl2_worker(rank, port, q):
+    """two ranks on two GPUs over RCCL: the exchange and the gather (batched point-to-point on both ends) as the 8-GPU run takes them"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=2, device_id=torch.device("cuda", rank))
+    try:
+        import stringsext_amd as sx
+        from stringsext_amd import sharded
+        data = make_data("c4", 4321)
+        ms = rc.missions(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African")
+        sc = sx.Scanner(ms, device=rank)
+        d = sc.alloc(len(data)); sc.upload(d, data)
+        gathered, res = sharded.scan_sharded(sc, lambda lo, hi: ctypes.c_void_p(d.value + lo), len(data), file_id=1, device=f"cuda:{rank}", gather=True)
+        if rank == 0:
+            parts = [sharded.decode_findings(fb, ab) for fb, ab in gathered]
+            got = [(f["position"], f["precision"], f["s"], f["completes"], f["mission_id"], f["slice_index"]) for f in sharded.splice_order(parts, len(data))]
+            want = oracle_findings(ms, data)
+            q.put(("ok", got == want, len(got), len(want)))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_two_gpus_over_rccl():
+    """skipped on a box with one GPU (the driver's test box); on a multi-GPU node: the gather over RCCL must not hang and must give the
+    sequential scan's findings"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl2_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+    assert res[0] == "ok", res[1]
+    assert res[1], res
+
+
 def test_bench_with_eight_ranks_on_one_gpu_through_gloo():
     """The driver's `bench.py --gpus N` line, N = 8, as far as one GPU can carry it: eight ranks sharing cuda:0, the exchange and the
     gather through gloo.  The default is STRONG scaling (BASELINE.json's metric: one image at 1/2/4/8 GPUs) — here a 1 GiB image —, the
