@@ -1303,7 +1303,14 @@ __global__ __launch_bounds__(256) void scan_kernel_dbcs(const ScanParams p) {
                         edge = 0;
                         if (__ballot(lane == 0 && (ce.run0 | co.run0) != 0)) {
                             u32 v = 0;
-                            if (lane == 0) { while (((v = __hip_atomic_load(p.grid_flags + (wave - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x10u) == 0) __builtin_amdgcn_s_sleep(2); }
+                            // (bounded, ADVICE r4: the wavefront in front publishes on entering its LAST tile — a fill of `81 30 81 30 ...` would hand
+                            // the grid through wavefront by wavefront, each waiting for a whole sub-chunk; after ~1 ms the row is marked as a
+                            // superset instead, the state the chunk's byte 0 uses when a token is pending there: stage B decides exactly)
+                            if (lane == 0) {
+                                u32 spins = 0;
+                                while (((v = __hip_atomic_load(p.grid_flags + (wave - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x10u) == 0 && ++spins < (1u << 14)) __builtin_amdgcn_s_sleep(2);
+                                if ((v & 0x10u) == 0) v = 0xFu << 5;
+                            }
                             edge = (uniform(v) >> 5) & 0xFu;
                         }
                     }

@@ -128,3 +128,19 @@ def test_c5_six_missions_on_a_planted_image():
     assert want.count(b"(d Big5)") > 50 and want.count(b"(e EUC-JP)") > 50 and want.count(b"(f KOI8-R)") > 20
     for dev_replay in (None, True):
         assert run_cli_product(ms, [data], radix="x", device=0, device_replay=dev_replay) == want
+
+
+def test_a_gb18030_row_of_megabytes_is_scanned_in_bounded_time():
+    """`81 30 81 30 ...` for megabytes: every other candidate is a four-byte token, and which one is known only from the row's beginning —
+    a sub-chunk's wavefront takes it from the one in front, which publishes it on entering its last tile.  The wait is bounded (ADVICE r4:
+    after ~1 ms the row is marked as a superset and stage B decides); the result is the oracle's and the scan takes seconds, not minutes."""
+    import time
+    ms = rc.missions(encodings=["gb18030"], chars_min="4", unicode_block_filter=ALL)
+    for odd in (0, 1):
+        data = b"text in front\n" + b"\x81" * odd + b"\x81\x30" * (3 << 20) + b"\nand behind it " + "中文字符".encode("gb18030") * 50 + b"\n"
+        want = sxo.run_cli(ms, [data], radix="x")
+        t0 = time.time()
+        got = run_cli_product(ms, [data], radix="x", device=0)
+        dt = time.time() - t0
+        assert got == want, odd
+        assert dt < 60, dt

@@ -34,7 +34,12 @@ while time.time() - t0 < budget:
         if m["encoding"] in (2, 3) and len(data) % 2:   # (UTF-16: the wave path takes buffers of whole units)
             data = data[:-1]
             want = oracle_findings([dict(m, mission_id=0)], data)
-        got, info = twc.emulate(L, m, data, nwin=nwin, skip_idle=rng.choice([0, 1, 1]), may_give_up=True)
+        skip = rng.choice([0, 1, 1])
+        try:
+            got, info = twc.emulate(L, m, data, nwin=nwin, skip_idle=skip, may_give_up=True)
+        except AssertionError as e:
+            print(f"HARNESS ERROR {e} wave seed {seed} case_seed {case_seed} mission {m} nwin={nwin} skip={skip} len={len(data)}: {fuzz_case.describe(c)}")
+            sys.exit(1)
         if got is None:   # UTF-16: the wavefronts gave the buffer back (the product then takes the lane-per-region path)
             gave_up += 1
             continue
