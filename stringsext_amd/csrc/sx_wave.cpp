@@ -304,7 +304,10 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             // warm-up windows; the two-byte family's token grid is published per launch geometry: that combination goes back)
             P.use_entry = 0;
             if (repaired && !by_desc) {
-                if (m.wave_family >= 4) return abandon(SX_WAVE_FALLBACK);
+                // (UTF-16 too, round 5: a wavefront that starts its batch at its own first window can meet a case its masks cannot say — a
+                // unit pair across the batch's first tile edge — which the count pass, with its warm-up windows in front, did not; found by
+                // tools/wave_fuzz.py after 20 minutes)
+                if (m.wave_family >= 2) return abandon(SX_WAVE_FALLBACK);
                 P.use_entry = 1;
             }
             if (P.desc && !by_desc) { std::lock_guard<std::mutex> g(ctx->mu); ctx->stats.wave_desc_overflows++; }

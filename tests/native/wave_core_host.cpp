@@ -566,8 +566,8 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
         fb[v] = f; ab[v] = a; f += wnf[v]; a += wnb[v];
         if (v > 0 && win[v] != wout[v - 1]) (*bad_waves)++;
     }
-    P.use_entry = repaired && family < 4 ? 1u : 0u;
-    const bool skip_window_writer = repaired && family >= 4;   // (the product goes back to the other path for that combination unless the descriptors hold everything)
+    P.use_entry = repaired && family < 2 ? 1u : 0u;
+    const bool skip_window_writer = repaired && family >= 2;   // (the product goes back to the other path for that combination unless the descriptors hold everything)
     *nf = f; *nb = a; *final_state = wout[n_waves - 1];
     if (f > fcap || a > acap) return -2;
     P.wave_fbase = fb.data(); P.wave_abase = ab.data(); P.findings = fout; P.arena = aout;
