@@ -74,6 +74,9 @@ def main():
                     help="zero: a constant-byte buffer instead of the synthetic background (counter passes: same instructions, other data)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (testing the N>1 path on one GPU: gloo)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses cuda:0")
+    ap.add_argument("--result-on-device", action="store_true",
+                    help="SX_OPT_RESULT_ON_DEVICE: a single-Mission workload's dense result stays in HBM (c1) — NOT the headline boundary, the line's "
+                         "config says so")
     ap.add_argument("--generic-kernels", action="store_true",
                     help="force the table-driven (LUT) classifiers instead of the range kernels: what a Mission with an arbitrary af / ubf costs")
     ap.add_argument("--ubf", default=None,
@@ -131,7 +134,8 @@ def main():
     nbytes = int((args.gib if args.gib is not None else wl["gib"]) * (1 << 30)) // 4096 * 4096
     if args.scaling == "strong":   # ONE image of the workload's size, a byte range of it per rank
         nbytes = nbytes // world // 4096 * 4096
-    sc = sx.Scanner(missions, device=local_rank, subchunk_bytes=args.subchunk_kib * 1024, generic_kernels=args.generic_kernels)
+    sc = sx.Scanner(missions, device=local_rank, subchunk_bytes=args.subchunk_kib * 1024, generic_kernels=args.generic_kernels,
+                    result_on_device=args.result_on_device)
 
     # rank r owns bytes [r*nbytes, (r+1)*nbytes) of ONE world*nbytes image (weak scaling: nbytes = the workload's size; strong: its
     # N-th part); for N > 1 its buffer also holds a halo on both sides (runs that cross a shard boundary)
@@ -312,6 +316,7 @@ def main():
                        # the north star's wording — aliases onto the same hardware queues and the kernels are bound by issue, not by launch order)
                        "mission_streams": "per mission" if os.environ.get("SX_MISSION_STREAMS") else "one scan stream + one stage-B stream",
                        "records": "sx_finding16 (16 B) for string-dense segments, sx_finding (32 B) else",
+                       **({"result": "left in HBM (SX_OPT_RESULT_ON_DEVICE): the step ends when the writer is done, no copy to the host"} if args.result_on_device else {}),
                        "passes": passes},
             "roofline": roofline,
             "breakdown_ms_per_step": {"scan_kernels_sum": round(sum(kernel_ms), 3),

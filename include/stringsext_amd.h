@@ -177,7 +177,14 @@ enum {
     SX_OPT_HOST_REPLAY = 4u,      /* never run stage B on the device */
     SX_OPT_TILE_TRAVERSAL = 8u,   /* scan kernels: independent overlapping tiles visited grid-stride (experimental;
                                      measured slower than the default: one private sub-chunk per wavefront) */
-    SX_OPT_MISSION_STREAMS = 16u  /* a scan stream per mission (default: one scan stream + one for everything else) */
+    SX_OPT_MISSION_STREAMS = 16u, /* a scan stream per mission (default: one scan stream + one for everything else) */
+    SX_OPT_RESULT_ON_DEVICE = 32u /* (round 5) a context with ONE Mission: the result of a string-dense buffer (the wave path: text, `-e ascii -n 4`
+                                     on binaries — where moving the findings to the host is what bounds the scan) stays in HBM as the device wrote
+                                     it: sx_result_segment_device() hands out device pointers to its sx_finding16 records and strings, for hosts that
+                                     go on working there.  Valid until the NEXT sx_scan* call on the context (the memory is the context's).  The
+                                     host accessors (sx_result_segment, ..._packed, sx_print_findings, ...) still work: the first one copies the
+                                     segment to the host (SX_E_STATE if a later scan has overwritten it).  Every other result is in host memory
+                                     as without the flag; the sharded entry points ignore it. */
 };
 
 /* ---- Mission front end (src/mission.rs:448-749, src/options.rs:12-33) ------------------------------
@@ -364,6 +371,11 @@ int sx_shard_splice(const sx_finding* const* findings, const uint64_t* n_finding
 int sx_shard_splice_segs(const sx_finding* const* findings, const uint64_t* n_findings, const uint8_t* const* arenas,
                          const uint64_t* arena_lens, const uint32_t* n_segs_of_rank, int world, uint64_t file_len, sx_result** out);
 
+/* (round 5, SX_OPT_RESULT_ON_DEVICE) Segment i where it lies in HBM: *d_records = n records (sx_finding16 if *packed, else sx_finding;
+ * what they share: *info), *d_arena = arena_len bytes of strings (str_off counts from there).  *d_records == NULL: the segment is in host
+ * memory (read it with sx_result_segment / sx_result_segment_packed).  SX_E_STATE: a later scan has reused the memory. */
+int               sx_result_segment_device(const sx_result* r, uint64_t i, const void** d_records, uint64_t* n_findings,
+                                           const uint8_t** d_arena, uint64_t* arena_len, int* packed, sx_segment_info* info);
 uint64_t          sx_result_count(const sx_result* r);
 /* The findings come in one or more segments, in print order: a buffer scanned piece by piece adds a segment per
  * piece; a single Mission with millions of runs is replayed in slabs, one segment each (a slab travels to the host while

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("SX_LIB") or os.path.join(_HERE, "libstringsext_amd.so
 SX_OK, SX_E_INVALID, SX_E_NO_DEVICE, SX_E_HIP, SX_E_NOMEM, SX_E_STATE, SX_E_HALO = 0, -1, -2, -3, -4, -5, -6
 SX_HOST_ONLY = -1
 SX_OPT_GENERIC_KERNELS, SX_OPT_DEVICE_REPLAY, SX_OPT_HOST_REPLAY = 1, 2, 4
+SX_OPT_RESULT_ON_DEVICE = 32   # round 5: a string-dense buffer's result stays in HBM (Result.device_segments)
 ENC = {"x-user-defined": 0, "utf-8": 1, "utf-16le": 2, "utf-16be": 3, "koi8-r": 16, "ibm866": 17,
        "iso-8859-2": 18, "iso-8859-5": 19, "iso-8859-15": 20, "windows-1251": 21, "windows-1252": 22,
        "iso-8859-3": 23, "iso-8859-4": 24, "iso-8859-6": 25, "iso-8859-7": 26, "iso-8859-8": 27,
@@ -31,7 +32,7 @@ EXPORTS = ["sx_abi_version", "sx_create", "sx_destroy", "sx_last_error", "sx_sca
            "sx_device_runs", "sx_replay_runs", "sx_scan_shard_device", "sx_scan_shard", "sx_replay_shard_runs",
            "sx_scan_stream", "sx_scan_file", "sx_missions_from_flags", "sx_parse_enc_opt", "sx_encoding_for_label", "sx_encoding_name",
            "sx_decoder_table", "sx_wave_classes", "sx_scan_classifier", "sx_result_segment_packed", "sx_wave_swar", "sx_wave_pair_codes2", "sx_wave_pair_codes", "sx_shard_bounds", "sx_scan_sharded", "sx_shard_splice", "sx_shard_splice_segs",
-           "sx_result_count", "sx_result_segments", "sx_result_segment", "sx_result_findings", "sx_result_arena",
+           "sx_result_count", "sx_result_segments", "sx_result_segment", "sx_result_segment_device", "sx_result_findings", "sx_result_arena",
            "sx_result_free", "sx_print_findings", "sx_get_stats", "sx_free", "sx_fill_background_device",
            "sx_device_alloc", "sx_device_free", "sx_device_upload", "sx_device_download",
            "sx_device_read_bandwidth"]
@@ -293,6 +294,19 @@ class Result:
             out.append((bool(pk.value), recs, n.value, C.string_at(ap, alen.value) if alen.value else b"", info))
         return out
 
+    def device_segments(self):
+        """[(device pointer to the records or None, n, device pointer to the strings, bytes of strings, packed?, SegmentInfo)] —
+        SX_OPT_RESULT_ON_DEVICE: the segments that still lie in HBM (None: that segment is in host memory)"""
+        L = lib()
+        L.sx_result_segment_device.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(SegmentInfo)]
+        out = []
+        for i in range(L.sx_result_segments(self.h)):
+            fp, n, ap, alen, pk, info = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64(), C.c_int(), SegmentInfo()
+            self._s._chk(L.sx_result_segment_device(self.h, i, C.byref(fp), C.byref(n), C.byref(ap), C.byref(alen), C.byref(pk), C.byref(info)))
+            out.append((fp.value, n.value, ap.value, alen.value, bool(pk.value), info))
+        return out
+
     def segments(self):
         """[(Finding array, n, arena bytes)]: the result as the library holds it (no copy on the C side)."""
         L = lib()
@@ -338,7 +352,7 @@ class Scanner:
     """One sx_ctx: N missions bound to one HIP device (device=SX_HOST_ONLY: replay stage only)."""
 
     def __init__(self, mission_dicts, device=0, subchunk_bytes=0, record_capacity=0, generic_kernels=False,
-                 replay_threads=0, device_replay=None):
+                 replay_threads=0, device_replay=None, result_on_device=False):
         L = lib()
         self.n = len(mission_dicts)
         self._ms = (Mission * self.n)(*[Mission.from_dict(d) for d in mission_dicts])
@@ -347,6 +361,8 @@ class Scanner:
             flags |= SX_OPT_DEVICE_REPLAY   # stage B on the device even for small inputs
         elif device_replay is False:
             flags |= SX_OPT_HOST_REPLAY
+        if result_on_device:
+            flags |= SX_OPT_RESULT_ON_DEVICE
         opt = Options(subchunk_bytes, record_capacity, replay_threads, flags)
         self.h = C.c_void_p()
         rc = L.sx_create(C.byref(self.h), self._ms, self.n, device, C.byref(opt))

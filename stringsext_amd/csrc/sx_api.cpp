@@ -167,6 +167,25 @@ unsigned replay_threads(const sx_ctx* ctx) {
 void begin_call(sx_ctx* ctx) {
     memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->err.clear();
+    ctx->sharded_call = false;
+    ctx->dev_epoch->fetch_add(1);   // (results left on the device by an earlier call — SX_OPT_RESULT_ON_DEVICE — are the context's memory: gone now)
+}
+
+// SX_OPT_RESULT_ON_DEVICE: a segment that still lies in HBM comes to the host (the host accessors' first use of it)
+static int fetch_to_host(sx_result* r, MissionFindings& s) {
+    if (!s.dev_only) return SX_OK;
+    if (!s.keep_on_device || !s.dev_epoch_ref || s.dev_epoch_ref->load() != s.dev_epoch) return SX_E_STATE;   // (a later scan has reused the memory)
+    const size_t bytes = s.ext_nf * s.rec_size() + s.ext_na;
+    PinnedPool::Block blk = r->r.pool ? r->r.pool->take(bytes + 64) : PinnedPool::Block{};
+    if (!blk.p) return SX_E_NOMEM;
+    if (hipMemcpy(blk.p, s.dev_copy, bytes, hipMemcpyDeviceToHost) != hipSuccess) { r->r.pool->give(blk); return SX_E_HIP; }
+    s.ext = blk; s.dev_only = false;
+    return SX_OK;
+}
+static int fetch_all_to_host(const sx_result* r) {
+    sx_result* w = const_cast<sx_result*>(r);
+    for (auto& s : w->r.segs) { const int rc = fetch_to_host(w, s); if (rc != SX_OK) return rc; }
+    return SX_OK;
 }
 
 
@@ -467,6 +486,7 @@ uint64_t sx_result_segments(const sx_result* r) { return r ? r->r.segs.size() : 
 int sx_result_segment(const sx_result* r, uint64_t i, const sx_finding** findings, uint64_t* n_findings,
                       const uint8_t** arena, uint64_t* arena_len) {
     if (!r || i >= r->r.segs.size()) return SX_E_INVALID;
+    { const int rc = fetch_to_host(const_cast<sx_result*>(r), const_cast<sx_result*>(r)->r.segs[(size_t)i]); if (rc != SX_OK) return rc; }
     const MissionFindings& s = r->r.segs[(size_t)i];
     if (findings) *findings = s.data();
     if (n_findings) *n_findings = s.count();
@@ -477,6 +497,7 @@ int sx_result_segment(const sx_result* r, uint64_t i, const sx_finding** finding
 int sx_result_segment_packed(const sx_result* r, uint64_t i, const void** findings, uint64_t* n_findings, const uint8_t** arena,
                              uint64_t* arena_len, int* packed, sx_segment_info* info) {
     if (!r || i >= r->r.segs.size()) return SX_E_INVALID;
+    { const int rc = fetch_to_host(const_cast<sx_result*>(r), const_cast<sx_result*>(r)->r.segs[(size_t)i]); if (rc != SX_OK) return rc; }
     const MissionFindings& s = r->r.segs[(size_t)i];
     if (findings) *findings = s.packed ? (const void*)s.data16() : (const void*)s.data();
     if (n_findings) *n_findings = s.count();
@@ -494,14 +515,38 @@ int sx_result_segment_packed(const sx_result* r, uint64_t i, const void** findin
     }
     return SX_OK;
 }
+int sx_result_segment_device(const sx_result* r, uint64_t i, const void** d_records, uint64_t* n_findings, const uint8_t** d_arena,
+                             uint64_t* arena_len, int* packed, sx_segment_info* info) {
+    if (!r || i >= r->r.segs.size()) return SX_E_INVALID;
+    const MissionFindings& s = r->r.segs[(size_t)i];
+    if (d_records) *d_records = nullptr;
+    if (d_arena) *d_arena = nullptr;
+    if (n_findings) *n_findings = s.count();
+    if (arena_len) *arena_len = s.strings_len();
+    if (packed) *packed = s.packed ? 1 : 0;
+    if (info) {
+        memset(info, 0, sizeof *info);
+        info->packed = s.packed ? 1 : 0;
+        info->input_file_id = -1;
+        if (s.packed && s.info) {
+            info->input_file_id = s.info->file_id; info->slice_base = s.info->slice_base;
+            memcpy(info->position0, s.info->pos0, sizeof info->position0);
+        }
+    }
+    if (!s.dev_only) return SX_OK;   // (in host memory: the host accessors)
+    if (!s.keep_on_device || !s.dev_epoch_ref || s.dev_epoch_ref->load() != s.dev_epoch) return SX_E_STATE;
+    if (d_records) *d_records = s.dev_copy;
+    if (d_arena) *d_arena = (const uint8_t*)s.dev_copy + s.ext_nf * s.rec_size();
+    return SX_OK;
+}
 // The contiguous view: joins the segments on first use (a copy; none if there is one segment).
 const sx_finding* sx_result_findings(const sx_result* r) {
-    if (!r || !const_cast<sx_result*>(r)->r.flatten(nullptr) || r->r.segs.empty()) return nullptr;
+    if (!r || fetch_all_to_host(r) != SX_OK || !const_cast<sx_result*>(r)->r.flatten(nullptr) || r->r.segs.empty()) return nullptr;
     return r->r.segs[0].data();
 }
 const uint8_t* sx_result_arena(const sx_result* r, uint64_t* len) {
     if (len) *len = 0;
-    if (!r || !const_cast<sx_result*>(r)->r.flatten(nullptr) || r->r.segs.empty()) return nullptr;
+    if (!r || fetch_all_to_host(r) != SX_OK || !const_cast<sx_result*>(r)->r.flatten(nullptr) || r->r.segs.empty()) return nullptr;
     if (len) *len = r->r.segs[0].strings_len();
     return (const uint8_t*)r->r.segs[0].strings();
 }
@@ -511,6 +556,7 @@ int sx_print_findings(const sx_ctx* ctx, const sx_result* r, int n_inputs, int r
                       uint64_t* out_len) {
     if (!ctx || !r || !out || !out_len) return SX_E_INVALID;
     if (radix != 0 && radix != 'x' && radix != 'd' && radix != 'o') return SX_E_INVALID;
+    { const int rc = fetch_all_to_host(r); if (rc != SX_OK) return rc; }
     std::string s;
     print_findings(ctx->missions, r->r, n_inputs, radix, no_metadata != 0, &s);
     *out = (uint8_t*)malloc(s.size() ? s.size() : 1);

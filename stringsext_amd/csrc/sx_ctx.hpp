@@ -136,10 +136,12 @@ struct sx_result {
 
 struct sx_ctx {
     std::shared_ptr<sx::PinnedPool> pool = std::make_shared<sx::PinnedPool>();
+    std::shared_ptr<std::atomic<uint64_t>> dev_epoch = std::make_shared<std::atomic<uint64_t>>(0);   // SX_OPT_RESULT_ON_DEVICE: advanced by every scan call
     std::vector<sx::Mission> missions;
     std::vector<sx::ScannerState> states;
     std::vector<sx::MissionDev> dev;
     bool host_only = false;
+    bool sharded_call = false, single_piece = true;   // (SX_OPT_RESULT_ON_DEVICE applies to plain scans of one piece only)
     int device = -1;
     sx_options opt{};
     std::string err;

@@ -12,6 +12,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -228,6 +229,11 @@ struct MissionFindings {
     // dev_only: the copy to the host was put off (several missions are interleaved on the device first); ext_nf / ext_na
     // count what dev_copy holds, data() / strings() are not valid until it is fetched
     bool dev_only = false;
+    // round 5, SX_OPT_RESULT_ON_DEVICE: the caller wants it there (dev_only stays up in the finished result; the host accessors fetch it on
+    // first use).  dev_copy is the context's memory: valid while *dev_epoch_ref == dev_epoch (every scan call advances the context's epoch)
+    bool keep_on_device = false;
+    std::shared_ptr<std::atomic<uint64_t>> dev_epoch_ref;
+    uint64_t dev_epoch = 0;
     // further segments of the same mission, in order (a mission replayed in slabs; only with a single mission)
     std::vector<MissionFindings> more;
     // packed: the pinned block holds [ext_nf x sx_finding16][strings] — segments of a result that the device's dense writers

@@ -304,6 +304,7 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
     const bool seq = seq_piece < len;
     const uint64_t piece = seq ? seq_piece : piece_bytes(ctx, len);
     const uint64_t n_pieces = len ? (len + piece - 1) / piece : 1;
+    ctx->single_piece = n_pieces == 1;
     const uint64_t merged0 = ctx->merged_out_bytes;
     int entry_rc = SX_OK;   // (a failed read of the buffer's first bytes must not go unnoticed: the token grid would be wrong)
     auto make = [&](uint64_t p) {
@@ -389,6 +390,7 @@ int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
     if (!out || !end_pos || (buf_off % kInputBufLen) != 0 || own_lo < buf_off || own_hi < own_lo || own_hi > buf_off + buf_len) {
         ctx->err = "bad shard geometry"; return SX_E_INVALID;
     }
+    ctx->sharded_call = true;   // (results stay host-side: the shard machinery reads them)
     const size_t nm = ctx->missions.size();
     const double t_begin = now_ms();
     for (const Mission& m : ctx->missions)

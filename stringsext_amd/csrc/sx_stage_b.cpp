@@ -507,7 +507,7 @@ static int device_merge(sx_ctx* ctx, const ReplayJob& job, std::vector<MissionFi
         same_origin = same_origin && job.consumed0[k] == job.consumed0[0];
     }
     auto give_up = [&]() -> int {
-        for (auto& mf : per) { int rc = fetch_deferred(ctx, mf); if (rc != SX_OK) return rc; }
+        for (auto& mf : per) { if (mf.keep_on_device) continue; int rc = fetch_deferred(ctx, mf); if (rc != SX_OK) return rc; }   // (SX_OPT_RESULT_ON_DEVICE: it stays)
         return SX_OK;
     };
     if (!(with >= 2 && on_dev == with && same_origin && total >= 4096 && !getenv("SX_HOST_MERGE"))) return give_up();

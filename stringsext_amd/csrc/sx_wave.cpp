@@ -153,6 +153,9 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         if (ctx->missions.size() == 1 && defer_min_bytes == 0) K = std::min<uint64_t>(8, std::max<uint64_t>(1, len >> 25));   // >= 32 MiB of input each, eight at most (measured: 256 MiB of text in 4 / 8 / 16 slabs 7.9 / 7.2 / 8.0 ms; `-e ascii -n 4` on 1 GiB in 8 / 16 / 32: 5.15 / 5.27 / 7.0 ms)
         if (const char* e = getenv("SX_WAVE_SLABS")) K = (uint64_t)std::max(1, std::min(64, atoi(e)));
         if (ctx->missions.size() != 1 || defer_min_bytes != 0) K = 1;
+        // SX_OPT_RESULT_ON_DEVICE (round 5): one Mission, no pieces — the result stays where the writer put it (one slab: one block of the context's)
+        const bool keep_dev = (ctx->opt.flags & SX_OPT_RESULT_ON_DEVICE) && ctx->missions.size() == 1 && defer_min_bytes == 0 && job.commit_state && !ctx->sharded_call && ctx->single_piece;
+        if (keep_dev) K = 1;
         K = std::min<uint64_t>(K, n_waves);
 
         if (!d.d_wave_lut) {
@@ -345,7 +348,11 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
             MissionFindings seg;
             if (pack) { seg.packed = true; seg.info = seg_info; }
             deferred = K == 1 && defer_min_bytes && nf * sizeof(sx_finding) + nb >= defer_min_bytes;
-            if (deferred) {
+            if (keep_dev) {
+                HIP_TRY(ctx, hipStreamSynchronize(sb));
+                seg.dev_only = true; seg.keep_on_device = true; seg.dev_epoch_ref = ctx->dev_epoch; seg.dev_epoch = ctx->dev_epoch->load();
+                seg.ext_nf = nfh_j + nf; seg.ext_na = nbh_j + nb; seg.dev_copy = d_all;
+            } else if (deferred) {
                 HIP_TRY(ctx, hipStreamSynchronize(sb));
                 if (getenv("SX_TIMING2")) fprintf(stderr, "[sx]   ... written (left on the device) at +%.2f ms\n", now_ms() - t0);
                 seg.dev_only = true; seg.ext_nf = nfh_j + nf; seg.ext_na = nbh_j + nb; seg.dev_copy = d_all;

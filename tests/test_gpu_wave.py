@@ -472,3 +472,52 @@ def test_wave_repairs_can_be_switched_off_and_the_other_path_takes_over(wave_for
     monkeypatch.setenv("SX_WAVE_REPAIR", "48")
     monkeypatch.setenv("SX_WAVE_DESC", "0")     # the window-parallel writer after repairs: from the states the count pass left
     assert run_cli_product(ms, [data], radix="x", device=0) == want
+
+
+# ---- round 5: SX_OPT_RESULT_ON_DEVICE ----
+def test_a_dense_result_can_stay_on_the_device(wave_forced):
+    """SX_OPT_RESULT_ON_DEVICE (include/stringsext_amd.h): one Mission, a string-dense buffer — the records (sx_finding16) and strings stay in
+    HBM where the writer put them; sx_result_segment_device hands out the pointers; the bytes there are the bytes the host result holds;
+    the host accessors fetch on first use; after the next scan the pointers are gone (SX_E_STATE)."""
+    rng = random.Random(77)
+    data = text_lines(rng, 3_000_000)
+    for kw in (dict(encodings=["ascii"], chars_min="4"), dict(encodings=["utf-8"], chars_min="10", grep_char="58"),
+               dict(encodings=["utf-16le"], chars_min="4")):
+        ms = rc.missions(**kw)
+        d = data.decode("latin-1").encode("utf-16-le") if kw["encodings"][0].startswith("utf-16") else data
+        want = sxo.run_cli(ms, [d], radix="x")
+        ref = sx.Scanner(ms, device=0)
+        host = ref.scan(d, file_id=1)
+        host_segs = host.packed_segments()
+        sc = sx.Scanner(ms, device=0, result_on_device=True)
+        try:
+            res = sc.scan(d, file_id=1)
+            dsegs = res.device_segments()
+            assert len(dsegs) == 1 and dsegs[0][0] is not None and dsegs[0][4], kw          # one segment, in HBM, packed records
+            fp, n, ap, alen, packed, info = dsegs[0]
+            assert n == len(host) and alen == sum(len(a) for _, _, _, a, _ in host_segs), kw
+            recs = sc.download(fp, n * 16)
+            arena = sc.download(ap, alen)
+            # the same findings as the host result's segments, joined (their str_off spaces are per segment: compare position + string)
+            def strings(pk, records, count, ar):
+                return [(records[i].position, ar[records[i].str_off:records[i].str_off + records[i].str_len], records[i].flags) for i in range(count)]
+            want_list = [x for pk, r16, cnt, ar, _ in host_segs for x in strings(pk, r16, cnt, ar)]
+            import ctypes as C
+            r16 = (sx.Finding16 * n).from_buffer_copy(recs)
+            assert strings(True, r16, n, arena) == want_list, kw
+            # the host accessors fetch the segment on first use
+            assert res.findings() == host.findings(), kw
+            assert res.printed(n_inputs=1, radix="x") == host.printed(n_inputs=1, radix="x") and res.printed(n_inputs=1, radix="x") in want, kw
+            assert res.device_segments()[0][0] is None                                       # ... and then it lies in host memory
+            # a second result left on the device is gone after the next scan
+            res2 = sc.scan(d, file_id=1)
+            assert res2.device_segments()[0][0] is not None
+            res3 = sc.scan(d[:4096 * 10], file_id=1)
+            with pytest.raises(sx.SxError):
+                res2.device_segments()
+            with pytest.raises(sx.SxError):
+                res2.segments()
+            for r in (res, res2, res3):
+                r.free()
+        finally:
+            sc.close(); host.free(); ref.close()

@@ -45,7 +45,7 @@ if len(sys.argv) > 2: cases = [c for c in cases if c[0]["encodings"][0] in sys.a
 for flags, data in cases:
     what = flags.pop("name", "text")
     ms = rc.missions(**flags)
-    sc = sx.Scanner(ms, device=0)
+    sc = sx.Scanner(ms, device=0, result_on_device=bool(os.environ.get("RESULT_ON_DEVICE")))   # (RESULT_ON_DEVICE=1: SX_OPT_RESULT_ON_DEVICE — the findings stay in HBM)
     d = sc.alloc(len(data)); sc.upload(d, data)
     dts = []
     for it in range(8):   # the first passes size the pinned pool and the record regions
