@@ -10,6 +10,8 @@
 
 // SX_WAVE_SAME=0: Missions with -r as before round 5 (UTF-8 / UTF-16: the wave path for buffers with one kind of lead byte; single byte: not at all)
 static bool wave_same_on() { const char* e = getenv("SX_WAVE_SAME"); return !(e && atoi(e) == 0); }
+// (-g AND -r: the state has five bits for the lead code, sx_wave_core.hpp WvState)
+static bool wave_same_fits(int grep_char, uint64_t ubf) { return grep_char < 0 || __builtin_popcountll(ubf & 0x001FFFFFFFFFFFFCull) <= 31; }
 
 namespace sx {
 
@@ -76,7 +78,7 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
         // the wave-cooperative stage B (sx_wave_dev.hip): kind of every byte + "a character with this lead byte passes the filter"
         // (-r: the kernels check per buffer that it cannot matter there — text without, or with one kind of, multi-byte characters)
         m->wave_ok = wv_mission_ok(in.grep_char, 0u, in.chars_min_nb, (uint32_t)m->q);
-        m->wave_same = m->wave_ok && same_block != 0 && in.grep_char < 0 && wave_same_on();   // (round 5: -r in the wave kernels; with -g the check per buffer stays)
+        m->wave_same = m->wave_ok && same_block != 0 && wave_same_on() && wave_same_fits(in.grep_char, in.ubf);   // (round 5: -r in the wave kernels, with or without -g)
         m->wave_lead_check = m->wave_ok && same_block != 0 && !m->wave_same;
         m->wave_family = 1;
         m->wave_lut.assign(256, 0);
@@ -151,8 +153,8 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
             // (windows of >= 10 bytes: the slice-start probe, finding_collection.rs:176-207, lets a fresh decoder run over the slice until 8 bytes are
             // written — five units at most; in a shorter window the real decoder has already met the window's last unit, which it treats differently)
             m->wave_ok = wv_mission_ok(in.grep_char, 0u, in.chars_min_nb, (uint32_t)m->q) && m->window % 2 == 0 && m->window >= 10;
-            m->wave_same = m->wave_ok && same_block != 0 && in.grep_char < 0 && wave_same_on();
-            m->wave_lead_check = m->wave_ok && same_block != 0 && !m->wave_same;   // (-r with -g: per buffer, as for UTF-8)
+            m->wave_same = m->wave_ok && same_block != 0 && wave_same_on() && wave_same_fits(in.grep_char, in.ubf);
+            m->wave_lead_check = m->wave_ok && same_block != 0 && !m->wave_same;   // (SX_WAVE_SAME=0: per buffer, as for UTF-8)
             m->wave_family = 2;
             m->wave_lut.assign(512, 0);
             for (int lb = 0; lb < 256; lb++) m->wave_lut[256 + (size_t)lb] = m->filter.pass_lead(utf8_lead_of((uint32_t)lb)) ? 1 : 0;
@@ -400,7 +402,7 @@ int Mission::from_c(const sx_mission& in, bool force_generic, Mission* m, std::s
             }
             if (__builtin_popcountll(leads) <= 1) same_block = 0;
         }
-        m->wave_same = same_block != 0 && in.grep_char < 0 && wave_same_on() && wv_mission_ok(in.grep_char, 0u, in.chars_min_nb, (uint32_t)m->q);
+        m->wave_same = same_block != 0 && wave_same_on() && wave_same_fits(in.grep_char, in.ubf) && wv_mission_ok(in.grep_char, 0u, in.chars_min_nb, (uint32_t)m->q);
         m->wave_ok = wv_mission_ok(in.grep_char, m->wave_same ? 0u : same_block, in.chars_min_nb, (uint32_t)m->q);
         m->wave_lut.assign(256, 0);
         for (int b = 0; b < 256; b++) {

@@ -100,7 +100,8 @@ SXD u32 wm_select(WvMask m, u32 from, u32 k) {
 // (round 5, -g: lg = the leftover holds the grep char — SplitStr walks the leftover's chars again when it is prepended, helper.rs:252-254)
 // (-r: lm = the code — 1 .. 63, 0: none — of the lead byte of the leftover's last multi-byte character: where SplitStr's
 // last_multi_char_leading_byte stands when it has walked the prepended leftover again, helper.rs:279-296.  Six bits where room is: 25, 27-28,
-// 30-31 and 29 — lg's: a Mission with -g and -r does not come here, and neither mode reads the other's field; lback <= 4q + 3 needs nine.)
+// 30-31 and 29 — lg's: with -g AND -r the code has five bits (Missions with more than 31 accepted multi-byte lead bytes keep the check per
+// buffer) and the readers mask it; lback <= 4q + 3 needs nine.)
 struct WvState { u32 lc, lb, lback, cut, lg, lm; };
 SXD u32 wv_pack(const WvState& s) {
     return s.lc | (s.lb << 7) | (s.lback << 16) | (s.cut << 26) | (s.lg << 29) | ((s.lm & 1u) << 25) | (((s.lm >> 1) & 3u) << 27) | (((s.lm >> 3) & 3u) << 30) |
@@ -180,11 +181,14 @@ struct WvSameCtx {
     const WvParams& P; const WvWin& w; WvState& st; EMIT& emit;
     WvMask Ec; u32 din, cend, n; bool inv_after;
     u32 lbytes, lback, lsrc, lm_in;
+    bool grep, lg_in;           // -g as well (round 5, last): the stretch's chunks count only with the grep char (wv_call's rules)
     u32* prec; u32* cut_cend;   // (cut_cend: the stretch-by-stretch driver's; else nullptr)
     u32* r; bool* rv;           // the walk's beginning (a bound on E bits) / the leftover's characters still belong to the walk
 };
+// Returns true if SplitStr's iteration ends here for the whole call (-g: a line of q chars without the grep char that neither completes the
+// string before nor is carried on, helper.rs:410-415).
 template <int KIND, class EMIT>
-SXD void wv_stretch_same(const WvSameCtx<KIND, EMIT>& c, u32 a, u32 er, u32 pre, bool comp0) {
+SXD bool wv_stretch_same(const WvSameCtx<KIND, EMIT>& c, u32 a, u32 er, u32 pre, bool comp0) {
     constexpr bool BYTES = KIND == 0;
     const WvParams& P = c.P; const WvWin& w = c.w; WvState& st = c.st;
     const WvMask av = wm_and(c.Ec, wm_range(a, er));
@@ -203,10 +207,11 @@ SXD void wv_stretch_same(const WvSameCtx<KIND, EMIT>& c, u32 a, u32 er, u32 pre,
         return m0 < 127 ? wm_and(wm_andn(w.D, wm_below(m0 + 1)), av) : wm_zero();
     };
     WvMask B = breaks();
+    const bool rej_is_grep = c.grep && er < 128 && wm_test(w.GC, er);   // the rejected char behind the stretch is the grep char: it counts for the chunk it ends
     for (;;) {
         const WvMask left = wm_andn(av, wm_below(at));
         const u32 e_first = wm_next(left, 0);
-        if (!carried && e_first >= 128) return;
+        if (!carried && e_first >= 128) return false;
         // the sub-stretch in hand ends in front of the first break (its own first character never ends it; a leftover in front: it may)
         const u32 lower = carried ? e_first : e_first + 1;
         const u32 be = lower < 128 ? wm_next(B, lower) : 128u;
@@ -218,20 +223,27 @@ SXD void wv_stretch_same(const WvSameCtx<KIND, EMIT>& c, u32 a, u32 er, u32 pre,
         const bool is_q = pn == P.q;
         const u32 rem = cnt - pn;
         const bool tr = rem == 0 && !ends_by_rej;
-        if (!is_q && !tr && !comp && pn < P.n_min) {   // helper.rs:315-330: dropped; the walk goes on (no new next(): its beginning stays)
-            if (!by_break) return;
+        const u32 inw = pn - carried;
+        // the chunk's last character in the window (-g needs it before it knows whether the chunk counts)
+        u32 last_e = at;
+        if (inw) last_e = BYTES ? e_first + inw - 1 : (rem == 0 ? (u32)wm_prev(sub, 127) : wm_select(sub, at, inw));
+        bool gok = true;
+        if (c.grep) {   // (a break is a multi-byte character: it never is the grep char — only the rejected char at the stretch's end can count, wv_call)
+            gok = (carried && c.lg_in) || (!is_q && rem == 0 && !by_break && rej_is_grep);
+            if (!gok && inw) gok = wm_any(wm_and(w.GC, wm_range(e_first, last_e + 1)));
+        }
+        if (!is_q && !tr && !comp && (pn < P.n_min || !gok)) {   // helper.rs:315-330: dropped; the walk goes on (no new next(): its beginning stays)
+            if (!by_break) return false;
             at = be; carried = 0; carried_b = 0;
             continue;
         }
         const bool maybe_cut = is_q || (tr && !c.inv_after);
-        const bool again = !comp && tr && !c.inv_after && !is_q;
-        if (!comp && !again && pn < P.n_min) return;   // (the text ends here)
-        const u32 inw = pn - carried;
+        const bool again = !comp && tr && !c.inv_after && (!is_q || !gok);
+        if (!comp && !again && (pn < P.n_min || !gok)) return is_q;   // helper.rs:410-415: None (what could follow stands behind a line of q chars: never looked at)
         const i32 src = carried ? -(i32)c.lback : first_src(e_first);   // (the chunk's first source byte: looked up only for chunks that count)
-        u32 last_e = at, out_b = carried_b;
+        u32 out_b = carried_b;
         i32 src_end = src + (i32)(carried ? (KIND == 1 ? c.lbytes : c.lsrc) : 0u);
         if (inw) {
-            last_e = BYTES ? e_first + inw - 1 : (rem == 0 ? (u32)wm_prev(sub, 127) : wm_select(sub, at, inw));
             src_end = (i32)last_e + 1;
             if (KIND == 1) out_b = (u32)(src_end - src);
             else {
@@ -241,12 +253,12 @@ SXD void wv_stretch_same(const WvSameCtx<KIND, EMIT>& c, u32 a, u32 er, u32 pre,
         }
         if (again) {   // carried (it touches the text's end): nothing follows
             const bool mb_here = inw && wm_any(wm_and(w.MBA, wm_range(e_first, last_e + 1)));
-            st.lc = pn; st.lb = out_b; st.lback = (u32)((i32)c.n - src); st.cut = 0; st.lg = 0;
+            st.lc = pn; st.lb = out_b; st.lback = (u32)((i32)c.n - src); st.cut = 0; st.lg = c.grep && gok ? 1u : 0u;
             st.lm = mb_here ? w.mbl_code : (carried ? c.lm_in : 0u);
-            return;
+            return false;
         }
         c.emit(c.din + (KIND == 3 && c.cend > c.din && wm_test(w.PB, c.din) ? 2u : 0u), *c.prec, comp, src, (u32)(src_end - src), out_b);
-        st.lc = 0; st.lb = 0; st.lback = 0; st.lm = 0; st.cut = maybe_cut ? 1u : 0u;
+        st.lc = 0; st.lb = 0; st.lback = 0; st.lm = 0; st.lg = 0; st.cut = maybe_cut ? 1u : 0u;
         if (c.cut_cend) *c.cut_cend = c.cend;
         *c.prec = WV_AFTER;
         *c.r = inw ? last_e + 1 : at;   // a new walk begins behind what was handed out (the leftover alone: where the stretch stood)
@@ -278,7 +290,7 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
                  u32 probe = 0) {
     const bool cont = st.cut != 0;   // :240-241: consumed by this call whatever it yields
     st.cut = 0;
-    const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback, lm_in = st.lm;
+    const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback, lm_in = P.grep ? st.lm & 31u : st.lm;   // (-g AND -r: the state's bit 29 is lg's — five bits of lead code, sx_mission.cpp sees to it)
     const bool lg_in = st.lg != 0;
     const u32 lsrc = KIND >= 2 ? lback - (first_call || din == 0 ? w.head_pend : 0u) : lback;   // the leftover's own source bytes
     const bool has_left = lrem > 0;
@@ -304,10 +316,9 @@ SXD void wv_call(const WvParams& P, const WvWin& w, WvState& st, u32 din, u32 ce
     u32 walk_r = din;          // -r: where SplitStr's walk in hand began
     bool walk_rv = has_left;   // ... with the leftover's characters in it
     auto stretch = [&](u32 a, u32 er, u32 pre, bool comp0) -> bool {
-        if (P.same) {   // -r: sub-stretch by sub-stretch (wv_stretch_same)
-            const WvSameCtx<KIND, EMIT> sc{ P, w, st, emit, Ec, din, cend, w.n, invalid_after, lbytes, lback, lsrc, lm_in, &prec, nullptr, &walk_r, &walk_rv };
-            wv_stretch_same<KIND, EMIT>(sc, a, er, pre, comp0);
-            return false;
+        if (P.same) {   // -r: sub-stretch by sub-stretch (wv_stretch_same; with -g too)
+            const WvSameCtx<KIND, EMIT> sc{ P, w, st, emit, Ec, din, cend, w.n, invalid_after, lbytes, lback, lsrc, lm_in, GREP, lg_in, &prec, nullptr, &walk_r, &walk_rv };
+            return wv_stretch_same<KIND, EMIT>(sc, a, er, pre, comp0);
         }
         const WvMask av = wm_and(Ec, wm_range(a, er));
         const bool ends_by_rej = er < 128;          // a rejected char follows (else the call's text ends with it)
@@ -492,7 +503,7 @@ SXD WvTail wv_tail_g(const WvParams& P, const WvWin& w) {
 }
 template <int KIND>
 SXD WvTail wv_tail(const WvParams& P, const WvWin& w) {
-    return P.grep ? wv_tail_g<KIND, true>(P, w) : P.same ? wv_tail_g<KIND, false, true>(P, w) : wv_tail_g<KIND, false>(P, w);
+    return P.grep ? (P.same ? wv_tail_g<KIND, true, true>(P, w) : wv_tail_g<KIND, true>(P, w)) : P.same ? wv_tail_g<KIND, false, true>(P, w) : wv_tail_g<KIND, false>(P, w);
 }
 // What the window hands on if what it was handed does not matter: every lane starts the exchange of the entry states from its
 // predecessor's guess instead of from "nothing carried" (which is wrong behind every window that ends inside a line of text or in
@@ -524,7 +535,7 @@ SXD void wv_window_g(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit,
     WvMask Ec = wm_and(w.E, wm_below(cend));
     const bool cont0 = st.cut != 0;
     st.cut = 0;
-    const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback, lm_in = st.lm;
+    const u32 lrem = st.lc, lbytes = st.lb, lback = st.lback, lm_in = GREPT ? st.lm & 31u : st.lm;   // (-g AND -r: bit 29 is lg's)
     const bool lg_in = st.lg != 0;
     const u32 lsrc = KIND >= 2 ? lback - w.head_pend : lback;
     const bool has_left = lrem > 0;
@@ -541,10 +552,9 @@ SXD void wv_window_g(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit,
     // It runs ONCE per trip of the loop below, and only for stretches that yield or carry (a wavefront pays for it whenever one lane needs it)
     // (returns true if SplitStr's iteration ends here for the whole call: -g, wv_call)
     auto stretch = [&](u32 a, u32 er, u32 pre, bool comp0) -> bool {
-        if (SAMET) {   // -r: sub-stretch by sub-stretch
-            const WvSameCtx<KIND, EMIT> sc{ P, w, st, emit, Ec, din, cend, n, inv_after, lbytes, lback, lsrc, lm_in, &prec, &cut_cend, &walk_r, &walk_rv };
-            wv_stretch_same<KIND, EMIT>(sc, a, er, pre, comp0);
-            return false;
+        if (SAMET) {   // -r: sub-stretch by sub-stretch (with -g too)
+            const WvSameCtx<KIND, EMIT> sc{ P, w, st, emit, Ec, din, cend, n, inv_after, lbytes, lback, lsrc, lm_in, GREP, lg_in, &prec, &cut_cend, &walk_r, &walk_rv };
+            return wv_stretch_same<KIND, EMIT>(sc, a, er, pre, comp0);
         }
         const WvMask av = wm_and(Ec, wm_range(a, er));
         const bool ends_by_rej = er < 128;
@@ -681,7 +691,8 @@ SXD void wv_window_g(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit,
 }
 template <int KIND, class EMIT>
 SXD void wv_window(const WvParams& P, const WvWin& w, WvState& st, EMIT& emit, const WvTail& tail) {
-    if (P.grep) wv_window_g<KIND, true, false>(P, w, st, emit, tail);
+    if (P.grep && P.same) wv_window_g<KIND, true, true>(P, w, st, emit, tail);
+    else if (P.grep) wv_window_g<KIND, true, false>(P, w, st, emit, tail);
     else if (P.same) wv_window_g<KIND, false, true>(P, w, st, emit, tail);
     else wv_window_g<KIND, false, false>(P, w, st, emit, tail);
 }
@@ -1640,7 +1651,7 @@ SXD void wv_set_grep(WvWin& w, const WvParams& P, const u8* win_bytes, u32 g, bo
 // UTF-8: its first byte; single byte: from the decoder's table (x-user-defined: EF); UTF-16: from the unit (a pair: F0 | plane bits).
 // Codes: 1 + the rank of (lead & 0x3F) among the bits of ubf — five bits in the state (sx_mission.cpp takes Missions with <= 31 such leads).
 // ------------------------------------------------------------------------------------------
-SXD u32 wv_lead_code(u64 ubf, u32 lead) { return 1u + wv_popc64(ubf & ((1ull << (lead & 0x3Fu)) - 1ull)); }
+SXD u32 wv_lead_code(u64 ubf, u32 lead) { return 1u + wv_popc64(ubf & 0x001FFFFFFFFFFFFCull & ((1ull << (lead & 0x3Fu)) - 1ull)); }   // (bits 2 .. 52: the lead bytes C2 .. F4)
 SXD u32 wv_lead_of_cp(u32 cp) { return cp < 0x800u ? 0xC0u | (cp >> 6) : cp < 0x10000u ? 0xE0u | (cp >> 12) : 0xF0u | (cp >> 18); }
 // The window's bytes are read 16 at a time into registers and the characters' bytes are taken from there (a load per character, each
 // waiting for the one before, was a third of the -r kernels' time); LEADF: the lead byte of the UTF-8 form of a single-byte decoder's

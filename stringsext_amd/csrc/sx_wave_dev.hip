@@ -131,7 +131,7 @@ template <int WPB> SXD void wave_lds_sync() {
 constexpr int wv_n_masks(int fam, int cls) { return fam == 5 ? 5 : fam == 4 ? (cls ? 5 : 9) : fam == 1 ? (cls ? 5 : 6) : fam == 2 ? 4 : cls ? 2 : 4; }
 constexpr u32 kMaskWords = kWvMaxTiles * 32 + 8;
 constexpr u32 wv_lds_words(int fam, int cls, int opt = 0) {   // ... and the descriptors staged in their place need kWvStage x 3 x 64 words (-r: kWvStageSame)
-    return (u32)wv_n_masks(fam, cls) * kMaskWords > (opt == 2 ? kWvStageSame : kWvStage) * 192u ? (u32)wv_n_masks(fam, cls) * kMaskWords : (opt == 2 ? kWvStageSame : kWvStage) * 192u;
+    return (u32)wv_n_masks(fam, cls) * kMaskWords > (opt >= 2 ? kWvStageSame : kWvStage) * 192u ? (u32)wv_n_masks(fam, cls) * kMaskWords : (opt >= 2 ? kWvStageSame : kWvStage) * 192u;
 }
 
 // MODE 0: count; 1: write.  FAM 0: single-byte decoders; 1: UTF-8; 4: the two-byte family (Big5, Shift_JIS, EUC-KR: 4 wavefronts
@@ -156,13 +156,13 @@ constexpr u32 wv_lds_words(int fam, int cls, int opt = 0) {   // ... and the des
 #define SX_WV_OCCS 2   // the -r kernels (OPT 2): 256 registers each — at 128 they spill 30 to 65 of them, and came out wrong (see the writer's `ws2`)
 #endif
 constexpr int wv_occ(int mode, int fam, int cls, int opt = 0) {
-    if (opt == 2) return SX_WV_OCCS;
+    if (opt >= 2) return SX_WV_OCCS;
     if (opt == 1) return SX_WV_OCCG;
     if (mode == 0 && fam >= 4 && cls) return SX_WV_OCC4S;
     return mode == 0 ? (fam >= 4 ? SX_WV_OCC4 : fam == 1 ? SX_WV_OCC1 : SX_WV_OCC0) : (fam >= 4 ? SX_WV_OCCW4 : fam == 1 ? SX_WV_OCCW1 : SX_WV_OCCW0);
 }
 // GREP: the Mission has -g (round 5) — a compile-time constant: WvWin::GC and the grep rules cost registers a Mission without -g must not pay for
-// (OPT 0: neither; 1: -g; 2: -r, families 0 - 2 — WvWin::MBA / D and wv_stretch_same, round 5)
+// (OPT 0: neither; 1: -g; 2: -r, families 0 - 2 — WvWin::MBA / D and wv_stretch_same, round 5; 3: both)
 template <int MODE, int FAM, int WPB, int CLS, int OPT>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ(MODE, FAM, CLS, OPT)))) void wave_replay_kernel(const WaveParams P) {
     // FAM 0: valid, accepted, O2, O3 (CLS 1: accepted, >= 0x80); FAM 1: E, A, F, MA, MB, G; FAM 4: E, A, F, MA, MB, G, O2, O3, O4 — 16 bits per lane and tile
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
     u32 ref_cov = 0;
     u64 fbase = 0, abase = 0;
     if (MODE == 1) { fbase = P.wave_fbase[v] - P.f_sub; abase = P.wave_abase[v] - P.a_sub; }   // relative to this launch's output segment
-    constexpr bool GREP = OPT == 1, SAME = OPT == 2;
+    constexpr bool GREP = OPT == 1 || OPT == 3, SAME = OPT == 2 || OPT == 3;
     const WvParams WP{ P.q, P.n_min, GREP ? 1u : 0u, SAME ? 1u : 0u };
 
     for (u64 g0 = gw; g0 < own_end; g0 += kWvBatch) {
@@ -794,7 +794,8 @@ size_t wave_scratch_bytes(uint64_t n_waves) {
 // (families 0 - 2: with -r as well)
 #define SX_WV_LAUNCH_S(targs, grid, block, dyn, stream, Q)                                                      \
     do {                                                                                                       \
-        if ((Q).same) hipLaunchKernelGGL((wave_replay_kernel<SX_WV_UNPACK targs, 2>), grid, block, dyn, stream, Q);   \
+        if ((Q).same && (Q).grep_char >= 0) hipLaunchKernelGGL((wave_replay_kernel<SX_WV_UNPACK targs, 3>), grid, block, dyn, stream, Q);   \
+        else if ((Q).same) hipLaunchKernelGGL((wave_replay_kernel<SX_WV_UNPACK targs, 2>), grid, block, dyn, stream, Q);   \
         else SX_WV_LAUNCH(targs, grid, block, dyn, stream, Q);                                                  \
     } while (0)
 // pass 1 of wavefronts [v0, v1): counts, their exclusive sums from v0 on (fbase[v], abase[v]), the verification against

@@ -526,7 +526,7 @@ extern "C" int sxw_emulate(const uint8_t* data, uint64_t len, uint64_t consumed0
     if (swar25) memcpy(&P.swar, swar25, sizeof P.swar);
     P.pairs2 = pairs2;
     P.grep_char = grep_char;
-    P.same = same && family <= 2 && grep_char < 0 ? 1u : 0u; P.ubf = ubf;
+    P.same = same && family <= 2 ? 1u : 0u; P.ubf = ubf;
     if (family == 4 && !pairs2) P.swar.cls = 0;
     if (family == 5 && (!pairs2 || !P.swar.cls)) return -8;
     *nf = *nb = 0; *bad_waves = 0; *final_state = inject; *rounds_max = 0;

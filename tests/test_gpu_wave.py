@@ -366,7 +366,7 @@ def test_same_unicode_block_in_the_wave_kernels(wave_forced):
     library — text that changes script every few characters, whole and in chunks"""
     import test_wave_core as twc
     rng = random.Random(404)
-    for kw in twc.SAME_MISSIONS + twc.SAME_UTF16:
+    for kw in twc.SAME_MISSIONS + twc.SAME_UTF16 + twc.SAME_GREP_MISSIONS:   # (the last: with -g as well)
         ms = rc.missions(**kw)
         codec = kw["encodings"][0]
         enc = lambda t: t.encode(codec, errors="replace" if not codec.startswith("utf-") else "strict")

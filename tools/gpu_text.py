@@ -38,7 +38,8 @@ c8 = c8 + b" " * (-len(c8) % 4)   # (repeated whole: no character is cut where t
 cases += [(dict(encodings=["utf-8"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True, name="russian"), rep(c8)),
           (dict(encodings=["utf-8"], chars_min="4", unicode_block_filter="Cyrillic", name="russian"), rep(c8)),
           (dict(encodings=["koi8-r"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True, name="russian"), rep(ck)),
-          (dict(encodings=["utf-16le"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True, name="russian"), rep(c16))]
+          (dict(encodings=["utf-16le"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True, name="russian"), rep(c16)),
+          (dict(encodings=["utf-8"], chars_min="4", unicode_block_filter="Cyrillic", same_unicode_block=True, grep_char="32", name="russian"), rep(c8))]   # -g AND -r
 # -q beyond the wave path's 64: text at -q 255 on the lane-per-region path
 cases += [(dict(encodings=["ascii"], chars_min="4", output_line_len="255", name="q255"), data), (dict(encodings=["utf-8"], chars_min="10", output_line_len="255", name="q255"), data)]
 if len(sys.argv) > 2: cases = [c for c in cases if c[0]["encodings"][0] in sys.argv[2:] or c[0].get("name") in sys.argv[2:]]

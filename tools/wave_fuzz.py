@@ -1,7 +1,8 @@
 """CPU-only randomized check of the wave-cooperative stage B (no GPU): sx_wave_core.hpp compiled for the host and driven as
 sx_wave_dev.hip drives it (tests/native/wave_core_host.cpp) against the oracle, on the cases of gpu_fuzz.py whose Missions
 the wave path covers, with random wavefront sizes.  usage: tools/wave_fuzz.py SECONDS [SEED]
-SAME=1: every Mission with -r and without -g (round 5: -r in the wave kernels), half the inputs text that changes script every few characters"""
+SAME=1: every Mission with -r and without -g (round 5: -r in the wave kernels), half the inputs text that changes script every few characters;
+SAME=2: with -r and, most of them, with -g too"""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import fuzz_case
@@ -22,7 +23,7 @@ while time.time() - t0 < budget:
         continue
     for m in c["missions"]:
         if os.environ.get("SAME"):
-            m = dict(m, require_same_unicode_block=True, grep_char=None)
+            m = dict(m, require_same_unicode_block=True, grep_char=None if os.environ["SAME"] == "1" else rng.choice([None, 32, 101, 58, m.get("grep_char")]))
             if rng.random() < 0.5:
                 txt = twc.same_text(rng, rng.choice([300, 3000, 30_000]), runs=rng.choice([(1, 1, 2, 3, 4, 5, 8, 13, 40), (1, 2, 3), (1, 7, 30, 64, 65, 130)]))
                 codec = {1: "utf-8", 2: "utf-16-le", 3: "utf-16-be"}.get(m["encoding"])
@@ -35,6 +36,9 @@ while time.time() - t0 < budget:
             data = data[:-1]
             want = oracle_findings([dict(m, mission_id=0)], data)
         skip = rng.choice([0, 1, 1])
+        if os.environ.get("SX_FUZZ_TRACE"):   # (the case in hand, before it runs: a crash of the harness names it)
+            with open(os.environ["SX_FUZZ_TRACE"], "w") as tf:
+                tf.write(f"wave seed {seed} case {n} case_seed {case_seed} mission {m} nwin={nwin} skip={skip} len={len(data)}\n")
         try:
             got, info = twc.emulate(L, m, data, nwin=nwin, skip_idle=skip, may_give_up=True)
         except AssertionError as e:
