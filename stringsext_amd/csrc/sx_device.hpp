@@ -124,6 +124,9 @@ struct ReplayParams {
     uint32_t max_windows;        // a region that needs more windows is given back (kRegionTooLong)
     uint32_t str_off_base;       // pass 2 (flagged form): added to every str_off (strings of the host's entry part come first)
     uint32_t entry_skip;         // double-byte encodings: bytes at the buffer start that finish the token pending on entry
+    // (round 5) the token grid of stage A (ScanParams::grid_flags: per sub-chunk of grid_sub bytes, bit 0 known, bits 1-2 the hang-over at its
+    // first byte), or nullptr: dbcs_sync_before's walk back ends at a sub-chunk start
+    const uint32_t* grid_flags; uint32_t grid_sub;
     uint64_t n_look;             // runs[] may be read up to here (0: n_runs) — a slab's kernels visit n_runs of them, its regions look on
     // the fast pre-pass of pass 1 (round 5, sx_replay_dev.hip replay_fast_kernel): the slots of the replaying runs it left to the
     // general kernel, and how many (device; nullptr: no pre-pass, the general kernel visits every replaying run)

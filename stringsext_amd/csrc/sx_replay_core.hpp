@@ -303,8 +303,15 @@ SXD u32 derive_in_run(u32 q, u32 encoding, const uint16_t* table, const u8* from
 // is neutral right after such a byte — or from `floor`, where it is neutral too (a clean call start; at the
 // buffer start after `skip0` bytes that finish the token pending on entry), jumping token by token from there.
 // The walk back is as long as the stretch of lead-range bytes in front of lim.
+// Round 5: the walk back is bounded — where stage A has published its token grid (grid: per sub-chunk of grid_sub bytes the hang-over at its
+// first byte, ScanParams::grid_flags) it ends at the start of lim's sub-chunk, where the tokens are known to begin after that many bytes.
+// (Before: to the nearest byte outside the lead range however far — inside a fill of lead-range bytes every region walked to its beginning.)
 template <int ENC>
-SXD u64 dbcs_sync_before(const u8* bytes, u64 len, u64 at, u64 floor, u32 skip0, u64 lim, int enc) {
+SXD u64 dbcs_sync_before(const u8* bytes, u64 len, u64 at, u64 floor, u32 skip0, u64 lim, int enc, const u32* grid = nullptr, u32 grid_sub = 0) {
+    if (grid && grid_sub) {
+        const u64 sub = lim / grid_sub, s0 = sub * grid_sub;
+        if (s0 > floor) { const u32 v = grid[sub]; if (v & 1u) { floor = s0; skip0 = (v >> 1) & 3u; } }
+    }
     u64 r = lim;
     while (r > floor && dbcs_may_be_pending_after<ENC>(bytes[r - 1], enc)) r--;
     if (r == floor) r += skip0;
@@ -329,7 +336,7 @@ SXD_NOINLINE u32 derive_at(const ReplayParams& P, u64 at, u64 floor, DDecoder& d
     if ((ENC == 2 || ENC == 3) && ((P.stream0 + p) & 1)) p = p ? p - 1 : p + 1;
     if (p < floor) p = floor;
     if (p > at) p = at;
-    if (ENC == 4 || ENC == 5) p = dbcs_sync_before<ENC>(bytes, P.len, at, floor, floor == 0 ? P.entry_skip : 0u, p, (int)P.encoding);
+    if (ENC == 4 || ENC == 5) p = dbcs_sync_before<ENC>(bytes, P.len, at, floor, floor == 0 ? P.entry_skip : 0u, p, (int)P.encoding, P.grid_flags, P.grid_sub);
     u8 sink[40], last[4], mb[4];
     u32 last_len = 0, mb_len = 0;
     while (p < at) {   // in pieces: the sink is small

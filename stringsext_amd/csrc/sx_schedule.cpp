@@ -138,7 +138,7 @@ struct BufferScan {
     int fetch_base(sx_ctx* ctx) {
         base_view.reset();
         if (host_bytes) return SX_OK;
-        base_view.reset(new SparseDeviceBytes(ctx, d_bytes));
+        base_view.reset(new SparseDeviceBytes(ctx, d_bytes, len));
         if (none_scanned(ctx)) return SX_OK;   // the wave path reads two windows' worth: fetched when asked for (SparseDeviceBytes::span)
         ReplayJob none;
         return download_for_replay(ctx, d_bytes, len, nullptr, base_view.get(), none);
@@ -273,7 +273,7 @@ struct BufferScan {
         }
         SX_TL("all missions finished / replayed on the device");
         if (host_bytes) return replay_all(ctx, host_view, job, *runs, into, ends, &pre);
-        SparseDeviceBytes view(ctx, d_bytes);
+        SparseDeviceBytes view(ctx, d_bytes, len);
         bool base_is_enough = false;
         int rc = download_for_replay(ctx, d_bytes, len, runs, &view, job, &pre.done, &base_is_enough);
         if (rc != SX_OK) return rc;
@@ -488,7 +488,7 @@ int shard_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes,
         HostBytes view(host_bytes);
         rc = replay_all(ctx, view, job, ctx->shard_runs, &res.r->r, ends.data());
     } else {
-        SparseDeviceBytes view(ctx, d_bytes);
+        SparseDeviceBytes view(ctx, d_bytes, buf_len);
         rc = download_for_replay(ctx, d_bytes, buf_len, &ctx->shard_runs, &view, job);
         if (rc != SX_OK) return rc;
         rc = replay_all(ctx, view, job, ctx->shard_runs, &res.r->r, ends.data());

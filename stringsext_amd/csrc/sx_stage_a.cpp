@@ -117,6 +117,7 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         HIP_TRY(ctx, hipEventRecord(s.ev0, d.stream));
         HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream));
         HIP_TRY(ctx, hipEventRecord(s.ev1, d.stream));
+        if (dbcs) { d.grid_of_scan = s.d_grid; d.grid_sub = p.subchunk; d.grid_data = d_bytes; d.grid_len = len; }
     }
     return SX_OK;
 }
@@ -194,6 +195,7 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             if (p.grid_flags) HIP_TRY(ctx, hipMemsetAsync(p.grid_flags, 0, ((len + p.subchunk - 1) / p.subchunk) * 4, d.stream_b));
             HIP_TRY(ctx, hipMemsetAsync(s.d_counters, 0, kCounterWords * sizeof(uint32_t), d.stream_b));
             HIP_TRY(ctx, launch_scan(ctx->missions[(size_t)which[k]].kind, p, d.stream_b));
+            if (p.grid_flags) { d.grid_of_scan = p.grid_flags; d.grid_sub = p.subchunk; d.grid_data = d_bytes; d.grid_len = len; }
             HIP_TRY(ctx, hipStreamSynchronize(d.stream_b));
             ctx->stats.rescans++;
             ctx->stats.rescan_ms += now_ms() - tr0;

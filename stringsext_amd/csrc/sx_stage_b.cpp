@@ -93,6 +93,8 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
         P.file_id = job.file_id; P.af_lo = m.c.af_lo; P.af_hi = m.c.af_hi; P.ubf = m.c.ubf;
         P.max_windows = kMaxRegionWindowsDefault;
         P.entry_skip = m.buf_entry_skip;
+        P.grid_flags = nullptr; P.grid_sub = 0;
+        if (d.grid_of_scan && d.grid_data == job.d_bytes && d.grid_len == job.len && !getenv("SX_NO_GRID_BOUND")) { P.grid_flags = d.grid_of_scan; P.grid_sub = d.grid_sub; }
         if (const char* e = getenv("SX_MAX_REGION_WINDOWS")) P.max_windows = (uint32_t)std::max(1, atoi(e));
         // pass-1 output cache: one arena for all replaying regions (slot = arena / their number, on the device)
         if (dev_stitch && !getenv("SX_NO_REPLAY_CACHE")) {

@@ -144,3 +144,22 @@ def test_a_gb18030_row_of_megabytes_is_scanned_in_bounded_time():
         dt = time.time() - t0
         assert got == want, odd
         assert dt < 60, dt
+
+
+def test_regions_inside_a_fill_of_lead_range_bytes_replay_in_bounded_time(monkeypatch):
+    """stage B's walk back to a token boundary (sx_replay_core.hpp dbcs_sync_before) went to the nearest byte outside the lead
+    range however far — megabytes of valid two-byte characters the filter rejects, with a short accepted string every kilobyte, made every
+    region walk to the fill's beginning.  It ends at a sub-chunk start now, where stage A has published the token grid.  Lane-per-region path
+    forced; both parities of the fill."""
+    import time
+    monkeypatch.setenv("SX_WAVE_REPLAY", "0")
+    ms = rc.missions(encodings=["euc-kr"], chars_min="4", unicode_block_filter="Kana")
+    fill, kana = "가".encode("euc_kr"), "あいうえおかきくけこさし".encode("euc_kr")
+    for odd in (0, 1):
+        data = b"x" + b"\xb0" * odd + (fill * 500 + kana) * 3000 + b"\n"
+        want = sxo.run_cli(ms, [data], radix="x")
+        t0 = time.time()
+        got = run_cli_product(ms, [data], radix="x", device=0, device_replay=True)
+        dt = time.time() - t0
+        assert got == want, odd
+        assert dt < 30, dt
