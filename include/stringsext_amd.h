@@ -178,10 +178,11 @@ enum {
     SX_OPT_TILE_TRAVERSAL = 8u,   /* scan kernels: independent overlapping tiles visited grid-stride (experimental;
                                      measured slower than the default: one private sub-chunk per wavefront) */
     SX_OPT_MISSION_STREAMS = 16u, /* a scan stream per mission (default: one scan stream + one for everything else) */
-    SX_OPT_RESULT_ON_DEVICE = 32u /* (round 5) a context with ONE Mission: the result of a string-dense buffer (the wave path: text, `-e ascii -n 4`
-                                     on binaries — where moving the findings to the host is what bounds the scan) stays in HBM as the device wrote
-                                     it: sx_result_segment_device() hands out device pointers to its sx_finding16 records and strings, for hosts that
-                                     go on working there.  Valid until the NEXT sx_scan* call on the context (the memory is the context's).  The
+    SX_OPT_RESULT_ON_DEVICE = 32u /* (round 5) a context with ONE Mission: a buffer's result that the device wrote in one block — a string-dense
+                                     buffer (the wave path: text, `-e ascii -n 4` on binaries, where moving the findings to the host is what bounds
+                                     the scan: sx_finding16 records) or a sparse one replayed on the device (sx_finding records) — stays in HBM:
+                                     sx_result_segment_device() hands out device pointers to its records and strings, for hosts that go on
+                                     working there.  Valid until the NEXT sx_scan* call on the context (the memory is the context's).  The
                                      host accessors (sx_result_segment, ..._packed, sx_print_findings, ...) still work: the first one copies the
                                      segment to the host (SX_E_STATE if a later scan has overwritten it).  Every other result is in host memory
                                      as without the flag; the sharded entry points ignore it. */

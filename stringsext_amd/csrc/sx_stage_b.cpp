@@ -253,7 +253,7 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
     // its str_off already shifted by that part's strings.  Only regions the device gave back to the host
     // (somewhere in the middle) need the finding-by-finding splice.
     PinnedPool::Block blk{};
-    bool deferred = false;
+    bool deferred = false, keep_dev = false;
     std::vector<sx_finding> entry_f;
     const bool entry_only = dev_stitch && host_parts.size() == 1 && true;
     const MissionFindings* hf0 = entry_only ? &host_parts[0].findings : nullptr;
@@ -291,6 +291,10 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
         }
         // a large output of one of several missions: the caller interleaves the missions on the device first, one copy instead of two
         deferred = defer_min_bytes && nf * sizeof(sx_finding) + nb >= defer_min_bytes && dev_stitch && (host_parts.empty() || entry_only);
+        // SX_OPT_RESULT_ON_DEVICE (round 5): one Mission, the whole buffer in this one slab, nothing the host has to splice in — it stays here
+        keep_dev = (ctx->opt.flags & SX_OPT_RESULT_ON_DEVICE) && ctx->missions.size() == 1 && defer_min_bytes == 0 && job.commit_state && !ctx->sharded_call &&
+                   ctx->single_piece && sl.first && sl.last && !sl.async_copy && dev_stitch && (host_parts.empty() || entry_only);
+        deferred = deferred || keep_dev;
         if (!deferred) {
             blk = ctx->pool->take(out_bytes + 64);
             if (!blk.p) { ctx->err = "hipHostMalloc failed"; return SX_E_NOMEM; }
@@ -315,7 +319,10 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
 
     // ---- splice (almost always: device findings only, or the entry part in front of them)
     if (host_parts.empty() || (entry_only && (blk.p || deferred))) {
-        if (deferred) { out->dev_only = true; out->ext_nf = nfh + nf; out->ext_na = nbh + nb; out->dev_copy = d.d_rp[sl.out_slot]; }
+        if (deferred) {
+            out->dev_only = true; out->ext_nf = nfh + nf; out->ext_na = nbh + nb; out->dev_copy = d.d_rp[sl.out_slot];
+            if (keep_dev) { out->keep_on_device = true; out->dev_epoch_ref = ctx->dev_epoch; out->dev_epoch = ctx->dev_epoch->load(); }
+        }
         else if (blk.p) { out->ext = blk; out->ext_nf = nfh + nf; out->ext_na = nbh + nb; out->dev_copy = sl.async_copy ? nullptr : d.d_rp[sl.out_slot]; }
         if (hf0) out->replay_bytes += hf0->replay_bytes;
     } else {
@@ -402,7 +409,8 @@ int device_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob
     if (runs.skipped) return SX_NEED_RUNS;
     size_t K = 1;
     const bool can = ctx->missions.size() == 1 && runs.on_device && !getenv("SX_HOST_STITCH") && defer_min_bytes == 0;
-    if (can && n >= (1u << 20)) K = 3;   // (measured on string-dense and text-like input: 3 beats 2, 4 and 6)
+    const bool keep_dev_wanted = (ctx->opt.flags & SX_OPT_RESULT_ON_DEVICE) && ctx->missions.size() == 1 && defer_min_bytes == 0 && job.commit_state && !ctx->sharded_call && ctx->single_piece;   // (one slab then: one block of the context's)
+    if (can && n >= (1u << 20) && !keep_dev_wanted) K = 3;   // (measured on string-dense and text-like input: 3 beats 2, 4 and 6)
     if (const char* e = getenv("SX_SLABS")) { K = (size_t)std::max(1, std::min(64, atoi(e))); if (!can || n < 8 * K) K = 1; }
     std::vector<uint64_t> idx{ 0 }, his{ 0 };
     if (K > 1) {   // where to cut

@@ -521,3 +521,28 @@ def test_a_dense_result_can_stay_on_the_device(wave_forced):
                 r.free()
         finally:
             sc.close(); host.free(); ref.close()
+
+
+def test_a_sparse_result_of_one_mission_can_stay_on_the_device():
+    """SX_OPT_RESULT_ON_DEVICE on the lane-per-region path (a single Mission's sparse buffer: sx_finding records, 32 bytes each): the same
+    contract — device pointers, the host accessors fetch, the bytes equal the host result's"""
+    rng = random.Random(78)
+    from test_host_logic import synth
+    data = synth(rng, 8_000_000, 1 / 400)
+    ms = rc.missions(encodings=["utf-8"], chars_min="10")
+    ref = sx.Scanner(ms, device=0, device_replay=True)
+    host = ref.scan(data, file_id=1)
+    sc = sx.Scanner(ms, device=0, device_replay=True, result_on_device=True)
+    try:
+        res = sc.scan(data, file_id=1)
+        dsegs = res.device_segments()
+        assert len(dsegs) == 1 and dsegs[0][0] is not None and not dsegs[0][4]       # one segment, in HBM, sx_finding records
+        fp, n, ap, alen, packed, info = dsegs[0]
+        assert n == len(host) and n > 1000
+        fb, ab = host.raw()
+        assert sc.download(fp, n * 32) == fb and sc.download(ap, alen) == ab
+        assert res.findings() == host.findings()
+        assert res.device_segments()[0][0] is None
+        res.free()
+    finally:
+        sc.close(); host.free(); ref.close()
