@@ -261,6 +261,7 @@ int sx_create(sx_ctx** out, const sx_mission* missions, int n_missions, int hip_
     if (!out || !missions || n_missions <= 0 || n_missions > 26) { g_create_error = "bad arguments"; return SX_E_INVALID; }
     sx_ctx* ctx = new sx_ctx();
     if (opt) ctx->opt = *opt;
+    if (const char* e = getenv("SX_RESULT_ON_DEVICE")) if (atoi(e)) ctx->opt.flags |= SX_OPT_RESULT_ON_DEVICE;   // (tests / fuzz: the flag through the environment)
     ctx->missions.resize((size_t)n_missions);
     ctx->states.resize((size_t)n_missions);
     for (int k = 0; k < n_missions; k++) {

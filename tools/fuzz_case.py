@@ -11,7 +11,7 @@ ENCS_MORE = ["iso-8859-7", "windows-1255", "windows-874", "koi8-u", "macintosh",
 AFS = [None, "All", "All-Ctrl", "All-Ctrl+Wsp", "None", "Wsp", "0x7ffffffe000000007ffffffe00000000"]
 UBFS = [None, "African", "All", "Common", "Cyrillic", "Latin", "Asian", "Uncommon", "None", "Hebrew", "Cjk", "Hangul", "Kana", "0x0000fffe00000000", "0x00003ffcfffffffc"]
 # alternative paths behind environment switches, read by the library at call time
-SWITCH_SETS = [{}, {}, {}, {"SX_NO_REPLAY_CACHE": "1"}, {"SX_HOST_STITCH": "1"}, {"SX_NO_REPLAY_SKIP": "1"}, {"SX_REPLAY_CACHE_MIB": "0"},
+SWITCH_SETS = [{}, {}, {}, {"SX_RESULT_ON_DEVICE": "1"}, {"SX_RESULT_ON_DEVICE": "1", "SX_WAVE_REPLAY": "1"}, {"SX_RESULT_ON_DEVICE": "1", "SX_DEVICE_JOIN_MIN": "1"}, {"SX_NO_REPLAY_CACHE": "1"}, {"SX_HOST_STITCH": "1"}, {"SX_NO_REPLAY_SKIP": "1"}, {"SX_REPLAY_CACHE_MIB": "0"},
                {"SX_REGION_CAP": "2"}, {"SX_REGION_CAP": "0"}, {"SX_DEVICE_JOIN_MIN": "1"}, {"SX_HOST_MERGE": "1"},
                {"SX_NO_REPLAY_CACHE": "1", "SX_NO_REPLAY_SKIP": "1"}, {"SX_HOST_STITCH": "1", "SX_DEVICE_JOIN_MIN": "1"},
                {"SX_REGION_CAP": "1"}, {"SX_REGION_CAP": "2", "SX_NO_LARGE_REGIONS": "1"}, {"SX_REGION_CAP": "1", "SX_DEVICE_JOIN_MIN": "1"},
