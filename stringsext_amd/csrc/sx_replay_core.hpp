@@ -313,6 +313,17 @@ SXD u64 dbcs_sync_before(const u8* bytes, u64 len, u64 at, u64 floor, u32 skip0,
         if (s0 > floor) { const u32 v = grid[sub]; if (v & 1u) { floor = s0; skip0 = (v >> 1) & 3u; } }
     }
     u64 r = lim;
+    // (four bytes per load while at least four are left: a lane's loads wait for one another — a byte per load was 70 ms for regions 150 KB
+    // into a fill)
+    while (r >= floor + 4) {
+        u32 x;
+        __builtin_memcpy(&x, bytes + r - 4, 4);
+        if (!dbcs_may_be_pending_after<ENC>((u8)(x >> 24), enc)) break;
+        if (!dbcs_may_be_pending_after<ENC>((u8)(x >> 16), enc)) { r -= 1; break; }
+        if (!dbcs_may_be_pending_after<ENC>((u8)(x >> 8), enc)) { r -= 2; break; }
+        if (!dbcs_may_be_pending_after<ENC>((u8)x, enc)) { r -= 3; break; }
+        r -= 4;
+    }
     while (r > floor && dbcs_may_be_pending_after<ENC>(bytes[r - 1], enc)) r--;
     if (r == floor) r += skip0;
     while (r < lim) r += dbcs_token_len<ENC>(bytes + r, len - r, enc);

@@ -35,6 +35,8 @@ extern "C" int sxd_replay_region_host(const sx::ReplayParams* P, uint64_t i, sx:
 }
 
 // Runs cut into pieces at the window starts they cross, exactly as the device does it (split_count / split_piece).
+// (tests/test_replay_core.py mirrors ReplayParams with ctypes: the sizes must agree)
+extern "C" uint64_t sxd_sizeof_replay_params() { return sizeof(sx::ReplayParams); }
 extern "C" uint64_t sxd_split_runs_host(const sx::ReplayParams* P, sx_run* out, uint64_t cap) {
     uint64_t n = 0;
     for (uint64_t i = 0; i < P->n_runs; i++) {

@@ -28,7 +28,16 @@ class ReplayParams(C.Structure):
                 ("af_lo", C.c_uint64), ("af_hi", C.c_uint64), ("ubf", C.c_uint64),
                 ("slot_of", C.c_void_p), ("n_heads", C.c_void_p), ("cache_arena", C.c_void_p), ("arena_bytes", C.c_uint64),
                 ("head_list", C.c_void_p), ("max_windows", C.c_uint32), ("str_off_base", C.c_uint32), ("entry_skip", C.c_uint32),
-                ("n_look", C.c_uint64)]
+                ("grid_flags", C.c_void_p), ("grid_sub", C.c_uint32),
+                ("n_look", C.c_uint64), ("hard_list", C.c_void_p), ("n_hard", C.c_void_p)]   # (csrc/sx_device.hpp ReplayParams, every field: the core reads the whole struct)
+
+
+def test_the_ctypes_mirror_of_replay_params_has_the_cores_size():
+    """a field added to csrc/sx_device.hpp ReplayParams and not here shifts everything behind it (round 5: n_look read garbage)"""
+    from native.build_harness import build_replay_core
+    L = C.CDLL(build_replay_core())
+    L.sxd_sizeof_replay_params.restype = C.c_uint64
+    assert L.sxd_sizeof_replay_params() == C.sizeof(ReplayParams)
 
 
 class RegionOut(C.Structure):
