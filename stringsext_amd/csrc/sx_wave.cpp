@@ -199,7 +199,7 @@ int wave_replay_mission(sx_ctx* ctx, size_t k, ByteView& view, const ReplayJob& 
         if (m.wave_family == 5 && !d.d_wave_pairs2) return SX_WAVE_FALLBACK;
         if (const char* e = getenv("SX_WAVE_LUT")) if (atoi(e) && m.wave_family != 5) P.swar.cls = 0;   // tests: the class table also where ranges would do
         P.wave_nf = d_u; P.wave_nb = d_u + n_waves; P.wave_in = d_u + 2 * n_waves; P.wave_out = d_u + 3 * n_waves;
-        P.wave_grid = m.wave_family == 4 ? d_u + 4 * n_waves : nullptr;
+        P.wave_grid = m.wave_family == 4 || m.wave_family == 5 ? d_u + 4 * n_waves : nullptr;   // (EUC-JP since round 5: fills without 8E / 8F)
         // -r on a UTF-8 Mission: the kernels collect the lead bytes that pass ubf; two kinds (the leftover's included) and the buffer goes back
         uint64_t* d_leads = nullptr;
         uint64_t left_leads = 0;

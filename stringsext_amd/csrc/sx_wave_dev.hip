@@ -241,7 +241,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             // 0.18 GiB/s).  Known: the last tile start of the batch before (later batches), or the first tile of the wavefront in front
             // (first batch): it publishes its hang-over there as soon as it has it (P.wave_grid; wavefronts are dispatched in order).
             long long stop = -1;
-            if (FAM == 4 && P.wave_grid) {
+            bool special = false;   // EUC-JP: an 8E / 8F among the walked bytes — tokens of other lengths, the parity does not hold
+            if ((FAM == 4 || FAM == 5) && P.wave_grid) {
                 if (g0 != gw && ref_pos != ~0ull) stop = (long long)ref_pos;
                 else if (g0 == gw && v > 0) {
                     const u64 gp = v - 1 == 0 ? P.g_lo : P.g_lo + (v - 1) * P.nwin - kWvWarm;
@@ -257,17 +258,32 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 if (!reset) {
                     const u32x4 x = *(const u32x4*)(P.data + o);
                     const u32 xs[4] = { x.x, x.y, x.z, x.w };
-                    if (FAM == 5) { const u32 x5[5] = { xs[0], xs[1], xs[2], xs[3], 0u }; reset = (wv_eucjp_classes_swar<1>(SW, x5, 16u).lr & 0xFFFFu) != 0xFFFFu; }
+                    if (FAM == 5) {
+                        const u32 x5[5] = { xs[0], xs[1], xs[2], xs[3], 0u };
+                        reset = (wv_eucjp_classes_swar<1>(SW, x5, 16u).lr & 0xFFFFu) != 0xFFFFu;
+                        u32 sp8 = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { const u32 y = (xs[k] & 0xFEFEFEFEu) ^ 0x8E8E8E8Eu; sp8 |= (y - 0x01010101u) & ~y & 0x80808080u; }   // a byte 8E or 8F
+                        special = special || __ballot(sp8 != 0) != 0;
+                    }
                     else if (CLS) reset = wv_dbcs_classes_swar<1>(SW, xs, 16u).lr != 0xFFFFu;
                     else for (int k = 0; k < 16; k++) reset = reset || !(lds_lut[(xs[k >> 2] >> (8 * (k & 3))) & 0xFFu] & WVC_LEAD);
                 }
                 if (__ballot(reset)) break;
-                if (stop >= 0 && lo <= stop) {   // nothing but lead-range bytes from the known position to tile0
+                if (FAM == 5 && special) stop = -1;   // (as before round 5: walk on, give up after 64 KiB)
+                if (stop >= 0 && lo <= stop) {   // nothing but lead-range bytes from the known position to tile0 (EUC-JP, round 5: and no 8E / 8F — two bytes per token)
                     u32 kc = ref_cov;
                     if (g0 == gw) {
                         u32 fv = 0;
                         if (lane == 0) { while (((fv = __hip_atomic_load(P.wave_grid + (v - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1u) == 0) __builtin_amdgcn_s_sleep(2); }
-                        kc = (wv_uniform(fv) >> 1) & 1u;
+                        if (wv_uniform(fv) >> 31) {   // the wavefront in front gave the buffer back: so does this one
+                            if (lane == 0) {
+                                P.wave_in[v] = 0xFFFFFFFEu; P.wave_out[v] = 0xFFFFFFFDu; P.wave_nf[v] = 0; P.wave_nb[v] = 0;
+                                if (!known) __hip_atomic_store(P.wave_grid + v, 0x80000001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            return;
+                        }
+                        kc = (wv_uniform(fv) >> 1) & (FAM == 5 ? 3u : 1u);   // (EUC-JP: a token of three bytes can hang over by two)
                     }
                     const u64 first = (u64)stop + kc;                       // a token starts here, and every two bytes from here on
                     dbcs_cov = tile0 >= first ? (u32)((tile0 - first) & 1ull) : (u32)(first - tile0);
@@ -276,7 +292,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 }
                 if (stop < 0 && t_first < -64) {   // 64 KiB of lead-range bytes and no end, and no known position to count from (EUC-JP: token lengths differ).  This wavefront gives up — an entry state no wavefront
                                        // ever leaves makes the verification fail, and the lane-per-region path takes the buffer
-                    if (lane == 0) { P.wave_in[v] = 0xFFFFFFFEu; P.wave_out[v] = 0xFFFFFFFDu; P.wave_nf[v] = 0; P.wave_nb[v] = 0; }
+                    if (lane == 0) {
+                        P.wave_in[v] = 0xFFFFFFFEu; P.wave_out[v] = 0xFFFFFFFDu; P.wave_nf[v] = 0; P.wave_nb[v] = 0;
+                        // (the wavefront behind may be waiting for my hang-over: it gets "gave up" instead, and does the same)
+                        if (P.wave_grid && g0 == gw && !known) __hip_atomic_store(P.wave_grid + v, 0x80000001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     return;
                 }
             }
@@ -547,11 +567,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             }
             edge_back = eb;
         }
-        if (FAM == 4 && P.wave_grid && g0 == gw && lane == 0 && !known)   // the hang-over at my first tile: the wavefront behind me may be waiting for it (a repair launch: published by the first one, at THAT launch's first tile)
+        if ((FAM == 4 || FAM == 5) && P.wave_grid && g0 == gw && lane == 0 && !known)   // the hang-over at my first tile: the wavefront behind me may be waiting for it (a repair launch: published by the first one, at THAT launch's first tile)
             __hip_atomic_store(P.wave_grid + v, 1u | (dbcs_cov << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int t_ref = next_t0 >= tile0 ? (int)((next_t0 - tile0) / kTileBytes) : 0;   // the last tile that starts at or in front of the next batch's first
         for (int t = 0; t < (int)n_tiles; t++) {
-            if (FAM == 4 && t == t_ref) { ref_pos = tile0 + (u64)t * kTileBytes; ref_cov = dbcs_cov; }
+            if ((FAM == 4 || FAM == 5) && t == t_ref) { ref_pos = tile0 + (u64)t * kTileBytes; ref_cov = dbcs_cov; }
             const u32x4 x = xa;
             xa = xb; xb = xc; xc = xd; xd = issue(t + 4);
             const u32 ea = t + 1 < (int)n_tiles ? (u32)__builtin_amdgcn_readlane(xa.x, 0) : edge_after;
@@ -570,7 +590,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             return;
         }
         wave_lds_sync<WPB>();
-        if (FAM == 4 && t_ref >= (int)n_tiles) { ref_pos = tile0 + (u64)n_tiles * kTileBytes; ref_cov = dbcs_cov; }
+        if ((FAM == 4 || FAM == 5) && t_ref >= (int)n_tiles) { ref_pos = tile0 + (u64)n_tiles * kTileBytes; ref_cov = dbcs_cov; }
         if (FAM >= 4) { dbcs_valid = have_next; if (have_next) dbcs_cov = cov_next; }   // (else the next batch walks back again)
 
 #if defined(SX_WV_EXP) && SX_WV_EXP == 1   // experiments (tools/build_variant.sh): what the classification alone costs

@@ -546,3 +546,26 @@ def test_a_sparse_result_of_one_mission_can_stay_on_the_device():
         res.free()
     finally:
         sc.close(); host.free(); ref.close()
+
+
+def test_eucjp_fills_stay_on_the_wave_path(wave_forced):
+    """a fill of lead-range bytes longer than 64 KiB made EUC-JP's wavefronts give the buffer back (token lengths differ: no
+    parity).  Without an 8E / 8F among the bytes walked over every token has two bytes there, and the hang-over follows from the wavefront in
+    front as it does for Big5 (WaveParams::wave_grid, two bits); with one, the wavefronts still give up — and tell the ones behind them.  The
+    result is the oracle's either way."""
+    from test_dbcs import TEXT
+    txt = TEXT["euc-jp"].encode("euc_jp", "ignore")
+    ms = rc.missions(encodings=["euc-jp"], chars_min="4", unicode_block_filter="Asian")   # (a Mission the wave path takes: UTF-8 forms of one length)
+    for fill in (0xA4, 0xF6, 0xFE):
+        for odd in (0, 1):
+            f = bytes([fill])
+            data = txt * 150 + f * (300_000 + odd) + b"A" + f * (150_001 + odd) + txt * 150 + f * (70_000 + odd) + txt * 20
+            want = sxo.run_cli(ms, [data], radix="x")
+            for chunk in (None, 65536):
+                assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, (fill, odd, chunk)
+            assert wave_windows_of_a_scan(ms, data) > 0, (fill, odd)       # the wave kernels kept the buffer
+    # 8E / 8F inside a long fill: tokens of two and three bytes — no parity; given back, the other path's result
+    data = txt * 100 + (b"\xa4" * 999 + b"\x8f") * 300 + b"\n" + (b"\xb0" * 1001 + b"\x8e") * 200 + txt * 100
+    want = sxo.run_cli(ms, [data], radix="x")
+    for chunk in (None, 16384):
+        assert run_cli_product(ms, [data], radix="x", device=0, chunk_bytes=chunk) == want, chunk
