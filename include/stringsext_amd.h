@@ -374,7 +374,8 @@ int sx_shard_splice_segs(const sx_finding* const* findings, const uint64_t* n_fi
 
 /* (round 5, SX_OPT_RESULT_ON_DEVICE) Segment i where it lies in HBM: *d_records = n records (sx_finding16 if *packed, else sx_finding;
  * what they share: *info), *d_arena = arena_len bytes of strings (str_off counts from there).  *d_records == NULL: the segment is in host
- * memory (read it with sx_result_segment / sx_result_segment_packed).  SX_E_STATE: a later scan has reused the memory. */
+ * memory (read it with sx_result_segment / sx_result_segment_packed).  SX_E_STATE: a later scan has reused the memory.  One caller at a
+ * time per result: the host accessors' first use of such a segment moves it to host memory. */
 int               sx_result_segment_device(const sx_result* r, uint64_t i, const void** d_records, uint64_t* n_findings,
                                            const uint8_t** d_arena, uint64_t* arena_len, int* packed, sx_segment_info* info);
 uint64_t          sx_result_count(const sx_result* r);
