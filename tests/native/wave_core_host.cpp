@@ -434,7 +434,6 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                     ce.widx = (u32)(g0 + l - own_start);
                     if (P.family == 0) wv_window<0>(WP, w[l], st, ce, skip_idle);
                     else if (P.family == 1) wv_window<1>(WP, w[l], st, ce, skip_idle);
-                else if (P.family == 2) wv_window<3>(WP, w[l], st, ce, skip_idle);
                     else if (P.family == 2) wv_window<3>(WP, w[l], st, ce, skip_idle);
                     else wv_window<2>(WP, w[l], st, ce, skip_idle);
                     out[l] = wv_pack(st); nf[l] = ce.nf; nb[l] = ce.nb;
@@ -481,7 +480,6 @@ bool wave(const WaveParams& P, u64 v, bool skip_idle, u32* rounds_max) {
                     WvState st = wv_unpack(in[l]);
                     if (P.family == 0) wv_window<0>(WP, w[l], st, de, skip_idle);
                     else if (P.family == 1) wv_window<1>(WP, w[l], st, de, skip_idle);
-                else if (P.family == 2) wv_window<3>(WP, w[l], st, de, skip_idle);
                     else if (P.family == 2) wv_window<3>(WP, w[l], st, de, skip_idle);
                     else wv_window<2>(WP, w[l], st, de, skip_idle);
                     if (de.a_local != ab + nb[l]) return false;
