@@ -55,7 +55,7 @@ def scan_kernel_source_hash():
     as long as the scan kernels' source is the one they ran."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("sx_kernels.hip", "sx_classify_ranges.hpp", "sx_device.hpp"):
+    for f in ("sx_kernels.hip", "sx_fused.hip", "sx_scan_core.hpp", "sx_classify_ranges.hpp", "sx_device.hpp"):
         h.update(open(os.path.join(ROOT, "stringsext_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--result-on-device", action="store_true",
                     help="SX_OPT_RESULT_ON_DEVICE: a single-Mission workload's dense result stays in HBM (c1) — NOT the headline boundary, the line's "
                          "config says so")
+    ap.add_argument("--per-mission-launches", action="store_true",
+                    help="SX_OPT_NO_FUSED_SCAN: one scan launch per Mission, each reading the whole buffer (rounds 1-5; the line's config.passes says so) "
+                         "instead of the fused launch that reads it once")
     ap.add_argument("--generic-kernels", action="store_true",
                     help="force the table-driven (LUT) classifiers instead of the range kernels: what a Mission with an arbitrary af / ubf costs")
     ap.add_argument("--ubf", default=None,
@@ -135,7 +138,7 @@ def main():
     if args.scaling == "strong":   # ONE image of the workload's size, a byte range of it per rank
         nbytes = nbytes // world // 4096 * 4096
     sc = sx.Scanner(missions, device=local_rank, subchunk_bytes=args.subchunk_kib * 1024, generic_kernels=args.generic_kernels,
-                    result_on_device=args.result_on_device)
+                    result_on_device=args.result_on_device, fused_scan=not args.per_mission_launches)
 
     # rank r owns bytes [r*nbytes, (r+1)*nbytes) of ONE world*nbytes image (weak scaling: nbytes = the workload's size; strong: its
     # N-th part); for N > 1 its buffer also holds a halo on both sides (runs that cross a shard boundary)
@@ -198,6 +201,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     kernel_ms = [0.0] * len(missions)
+    fused_ms, fused_mask = 0.0, 0
     device_ms = replay_ms = d2h_ms = wave_count_ms = wave_write_ms = 0.0
     wave_windows = rescans = seq_pieces = fast_regions = general_regions = 0
     rescan_ms = 0.0
@@ -209,6 +213,8 @@ def main():
         replay_bytes = st.replay_bytes
         for k in range(len(missions)):
             kernel_ms[k] += st.kernel_ms[k]
+        fused_ms += st.fused_ms
+        fused_mask = st.fused_mask
         device_ms += st.device_ms
         rescans += st.rescans
         rescan_ms += st.rescan_ms
@@ -240,6 +246,14 @@ def main():
                 t = sc.stats().kernel_ms[k]
                 best = t if best is None else min(best, t)
             alone_ms.append(best)
+        fused_alone_ms = None
+        if fused_mask:   # the fused launch alone: stage A of its Missions in one call
+            idx = [k for k in range(len(missions)) if (fused_mask >> k) & 1]
+            mcs = [max(1, min(missions[k]["chars_min_nb"], missions[k]["output_line_char_nb_max"])) for k in idx]
+            for _ in range(3):
+                sc.device_runs_multi(idx, dptr, nbytes, stream_parity=0, min_chars=mcs)
+                t = sc.stats().fused_ms
+                fused_alone_ms = t if fused_alone_ms is None else min(fused_alone_ms, t)
         # the same launch right behind an identical one (SX_SCAN_WARM): the chip is busy when it starts, as inside the job
         os.environ["SX_SCAN_WARM"] = "1"
         for k, m in enumerate(missions):
@@ -250,6 +264,7 @@ def main():
 
     K = max(args.steps, 1)
     kernel_ms = [x / K for x in kernel_ms]
+    fused_ms /= K
     device_ms /= K
     out = None
     if rank == 0:
@@ -264,13 +279,18 @@ def main():
         # A Mission whose last buffer was string-dense has no scan kernel: its stage B replays every window with the
         # wave-cooperative kernels (sx_wave_dev.hip), a count pass and a write pass that each read the shard once — they are the
         # Mission's passes over the input and enter the average as such (their durations: HIP events around their launches).
-        n_scanned = sum(1 for x in kernel_ms if x > 0)
+        # Round 6: the Missions of fused_mask share ONE launch that reads the shard once (sx_fused.hip): one pass, its duration counted once
+        # (stats.fused_ms; kernel_ms[k] of each of them repeats it).  SURVEY.md 8(d): passes = 1 for Missions fused into one read.
+        fused_ks = [k for k in range(len(missions)) if (fused_mask >> k) & 1 and kernel_ms[k] > 0]
+        own_ms = [0.0 if k in fused_ks else kernel_ms[k] for k in range(len(missions))]
+        n_scanned = sum(1 for x in own_ms if x > 0) + (1 if fused_ks else 0)
+        n_missions_scanned = sum(1 for x in kernel_ms if x > 0)
         n_wave = int(round(wave_windows / (nbytes / 128.0))) if wave_windows else 0
         wave_count_ms /= K
         wave_write_ms /= K
-        span_ms = max(kernel_ms) if os.environ.get("SX_MISSION_STREAMS") else sum(kernel_ms)
-        passes = n_scanned + (2 * n_wave if (n_wave and n_scanned < len(missions)) else 0)
-        span_all = span_ms + ((wave_count_ms + wave_write_ms) if n_scanned < len(missions) else 0.0)
+        span_ms = max(kernel_ms) if os.environ.get("SX_MISSION_STREAMS") else sum(own_ms) + (fused_ms if fused_ks else 0.0)
+        passes = n_scanned + (2 * n_wave if (n_wave and n_missions_scanned < len(missions)) else 0)
+        span_all = span_ms + ((wave_count_ms + wave_write_ms) if n_missions_scanned < len(missions) else 0.0)
         agg_gbs = passes * nbytes / (span_all * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters: they cannot be read inside this process, so the
         # value comes from the committed counter passes of this very command line (profiles/traffic.json
@@ -285,18 +305,23 @@ def main():
         roofline = {
             "bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "sx::scan_kernel<%s>, %d launches per step, average" % (wl.get("kernels", "Utf8Range2|Utf16Range"), n_scanned)
+            "kernel": (("sx::scan_kernel_fused: ONE launch reads the shard once for Missions %s" % fused_ks
+                        + ("; + sx::scan_kernel, %d launch(es) of the other Missions, average over all launches" % (n_scanned - 1) if n_scanned > 1 else ""))
+                       if fused_ks else "sx::scan_kernel<%s>, %d launches per step, average" % (wl.get("kernels", "Utf8Range2|Utf16Range"), n_scanned))
                       + (" + sx::wave_replay_kernel count and write pass of %d string-dense Mission(s) (no scan kernel: every window is replayed)" % n_wave
-                         if n_scanned < len(missions) and n_wave else ""),
+                         if n_missions_scanned < len(missions) and n_wave else ""),
             "wave_passes_ms": {"missions": n_wave, "count": round(wave_count_ms, 3), "write": round(wave_write_ms, 3),
                                "count_gbs": round(n_wave * nbytes / (wave_count_ms * 1e-3) / 1e9, 1) if wave_count_ms > 0 else None,
                                "write_gbs": round(n_wave * nbytes / (wave_write_ms * 1e-3) / 1e9, 1) if wave_write_ms > 0 else None},
             "algorithmic_bytes_per_launch": nbytes,
+            "fused": {"missions": fused_ks, "ms": round(fused_ms, 3), "gbs": round(nbytes / (fused_ms * 1e-3) / 1e9, 1) if fused_ms > 0 else None,
+                      "ms_alone": round(fused_alone_ms, 3) if rank == 0 and fused_alone_ms else None} if fused_ks else None,
             "per_kernel_ms": [round(x, 3) for x in kernel_ms],
             "per_kernel_gbs": [round(nbytes / (x * 1e-3) / 1e9, 1) if x > 0 else None for x in kernel_ms],
             "note": "durations inside the timed region; default schedule (round 5): the busiest mission is scanned first and its stage B runs next to the other missions' scan launches (SX_BUSIEST_LAST=1 / 2: it is scanned last / second to last)",
             "per_kernel_ms_alone": [round(x, 3) for x in alone_ms],
             "per_kernel_ms_alone_behind_an_identical_launch": [round(x, 3) for x in alone_warm_ms],
+            # (the per-Mission kernels, one launch each over the whole shard: what a Mission costs when it is not fused)
             "frac_alone": round(len(missions) * nbytes / (sum(alone_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if alone_ms and sum(alone_ms) > 0 else None,
             # the same passes over the WALL time of a step (stage B, merger and copies included): what "frac" cannot say when
             # kernels of several Missions run next to each other (their durations overlap and are counted in full above)
@@ -315,11 +340,12 @@ def main():
                        # the Missions' scan launches queue up in ONE HIP stream by default (measured: a stream per Mission — SX_OPT_MISSION_STREAMS,
                        # the north star's wording — aliases onto the same hardware queues and the kernels are bound by issue, not by launch order)
                        "mission_streams": "per mission" if os.environ.get("SX_MISSION_STREAMS") else "one scan stream + one stage-B stream",
+                       "scan": ("fused: one launch, one read of the shard for Missions %s" % fused_ks) if fused_ks else "one launch per Mission, each reads the shard",
                        "records": "sx_finding16 (16 B) for string-dense segments, sx_finding (32 B) else",
                        **({"result": "left in HBM (SX_OPT_RESULT_ON_DEVICE): the step ends when the writer is done, no copy to the host"} if args.result_on_device else {}),
                        "passes": passes},
             "roofline": roofline,
-            "breakdown_ms_per_step": {"scan_kernels_sum": round(sum(kernel_ms), 3),
+            "breakdown_ms_per_step": {"scan_kernels_sum": round(span_ms, 3),
                                       "host_waits_for_stage_a": round(device_ms, 3),
                                       "scan_kernels_launched_again": {"launches": round(rescans / K, 3), "ms": round(rescan_ms / K, 3)},
                                       "sparse_download_for_host_replay": round(d2h_ms / K, 3),

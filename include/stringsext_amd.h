@@ -20,7 +20,9 @@
  * success or a negative SX_E_* code, with text from sx_last_error(); the
  * caller owns inputs, the library owns sx_result until sx_result_free(); a
  * context is bound to ONE HIP device and is not thread-safe; internally the
- * Missions' scan kernels queue up in one HIP stream and everything after them
+ * Missions are scanned by ONE fused kernel that reads the buffer once where
+ * their classifiers allow (round 6, csrc/sx_fused.hip; else their scan kernels
+ * queue up in one HIP stream) and everything after them
  * (records -> runs, the exact replay, copies) runs in a second one
  * (SX_OPT_MISSION_STREAMS: a scan stream per Mission, the reference's one
  * thread per Mission, src/main.rs:97,151).  There is no CPU fallback: without
@@ -36,9 +38,10 @@ extern "C" {
 #endif
 
 /* Bumped whenever a struct of this header changes size or layout or an enum value changes meaning (2: sx_stats grew by the wave /
- * re-scan / piece fields in round 3, SX_ENC_ISO_2022_JP was added; packed findings, round 4).  A consumer compares it with
+ * re-scan / piece fields in round 3, SX_ENC_ISO_2022_JP was added; packed findings, round 4; 4: sx_stats grew by the fused scan's fields,
+ * round 6).  A consumer compares it with
  * sx_abi_version() before it hands the library a struct to fill. */
-#define SX_ABI_VERSION 3
+#define SX_ABI_VERSION 4
 
 enum {
     SX_OK = 0,
@@ -159,6 +162,10 @@ typedef struct sx_stats {
     uint64_t fast_regions;               /* (ABI 3) stage B, lane per region: regions settled by the fast pre-pass (one run inside one window) ... */
     uint64_t general_regions;            /* ... and regions it left to the general replay kernel */
     uint64_t wave_repairs;               /* (ABI 3) wave stage B: count launches repeated for wavefronts whose warm-up windows gave them a wrong entry state (-g) */
+    double   fused_ms;                   /* (ABI 4) fused scan launches (one read of the buffer for several Missions), HIP events around them; kernel_ms[k] of
+                                            every Mission such a launch scanned holds the same duration */
+    uint64_t fused_launches;             /* (ABI 4) ... how many */
+    uint64_t fused_mask;                 /* (ABI 4) ... bit k: Mission k's last buffer was scanned by a fused launch */
 } sx_stats;
 
 typedef struct sx_ctx sx_ctx;
@@ -175,9 +182,11 @@ enum {
     SX_OPT_GENERIC_KERNELS = 1u,  /* force the table-driven classifiers (testing) */
     SX_OPT_DEVICE_REPLAY = 2u,    /* run the exact replay (stage B) on the device even for small inputs */
     SX_OPT_HOST_REPLAY = 4u,      /* never run stage B on the device */
-    SX_OPT_TILE_TRAVERSAL = 8u,   /* scan kernels: independent overlapping tiles visited grid-stride (experimental;
-                                     measured slower than the default: one private sub-chunk per wavefront) */
+    SX_OPT_TILE_TRAVERSAL = 8u,   /* (rounds 1-5: scan kernels over independent overlapping tiles, grid-stride — measured slower in every round
+                                     and removed in round 6; the flag is accepted and ignored) */
     SX_OPT_MISSION_STREAMS = 16u, /* a scan stream per mission (default: one scan stream + one for everything else) */
+    SX_OPT_NO_FUSED_SCAN = 64u,   /* (round 6) one scan launch per Mission, each reading the whole buffer (rounds 1-5), instead of ONE launch that
+                                     reads it once for all Missions whose classifiers the fused kernel holds (csrc/sx_fused.hip) */
     SX_OPT_RESULT_ON_DEVICE = 32u /* (round 5) a context with ONE Mission: a buffer's result that the device wrote in one block — a string-dense
                                      buffer (the wave path: text, `-e ascii -n 4` on binaries, where moving the findings to the host is what bounds
                                      the scan: sx_finding16 records) or a sparse one replayed on the device (sx_finding records) — stays in HBM:
@@ -296,6 +305,12 @@ int sx_reset(sx_ctx* ctx);
  * *runs is malloc'd; release with sx_free(). */
 int sx_device_runs(sx_ctx* ctx, int mission_index, const void* device_bytes, uint64_t len,
                    int stream_parity, uint64_t min_chars, sx_run** runs, uint64_t* n_runs);
+
+/* (ABI 4) The same for n Missions of the context in one call (mission_indices[i], min_chars[i] -> runs[i], n_runs[i]; every runs[i]
+ * is malloc'd: sx_free()).  Missions whose classifiers the fused kernel holds (csrc/sx_fused.hip) share ONE launch that reads the
+ * buffer once — what sx_scan* does for them; sx_get_stats().fused_mask says which did. */
+int sx_device_runs_multi(sx_ctx* ctx, const int* mission_indices, int n, const void* device_bytes, uint64_t len,
+                         int stream_parity, const uint64_t* min_chars, sx_run** runs, uint64_t* n_runs);
 
 /* Lower level, stage B: exact replay on the host given run records per
  * mission (runs[m] sorted by start, chunk-relative).  Works on SX_HOST_ONLY

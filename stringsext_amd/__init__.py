@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("SX_LIB") or os.path.join(_HERE, "libstringsext_amd.so
 SX_OK, SX_E_INVALID, SX_E_NO_DEVICE, SX_E_HIP, SX_E_NOMEM, SX_E_STATE, SX_E_HALO = 0, -1, -2, -3, -4, -5, -6
 SX_HOST_ONLY = -1
 SX_OPT_GENERIC_KERNELS, SX_OPT_DEVICE_REPLAY, SX_OPT_HOST_REPLAY = 1, 2, 4
+SX_OPT_NO_FUSED_SCAN = 64      # round 6: one scan launch per Mission instead of the fused one (one read of the buffer for several Missions)
 SX_OPT_RESULT_ON_DEVICE = 32   # round 5: a string-dense buffer's result stays in HBM (Result.device_segments)
 ENC = {"x-user-defined": 0, "utf-8": 1, "utf-16le": 2, "utf-16be": 3, "koi8-r": 16, "ibm866": 17,
        "iso-8859-2": 18, "iso-8859-5": 19, "iso-8859-15": 20, "windows-1251": 21, "windows-1252": 22,
@@ -27,9 +28,9 @@ ENC = {"x-user-defined": 0, "utf-8": 1, "utf-16le": 2, "utf-16be": 3, "koi8-r": 
 PRECISION = {0: "Before", 1: "Exact", 2: "After"}
 
 # every symbol include/stringsext_amd.h declares
-ABI_VERSION = 3   # SX_ABI_VERSION of include/stringsext_amd.h
+ABI_VERSION = 4   # SX_ABI_VERSION of include/stringsext_amd.h
 EXPORTS = ["sx_abi_version", "sx_create", "sx_destroy", "sx_last_error", "sx_scan", "sx_scan_device", "sx_reset",
-           "sx_device_runs", "sx_replay_runs", "sx_scan_shard_device", "sx_scan_shard", "sx_replay_shard_runs",
+           "sx_device_runs", "sx_device_runs_multi", "sx_replay_runs", "sx_scan_shard_device", "sx_scan_shard", "sx_replay_shard_runs",
            "sx_scan_stream", "sx_scan_file", "sx_missions_from_flags", "sx_parse_enc_opt", "sx_encoding_for_label", "sx_encoding_name",
            "sx_decoder_table", "sx_wave_classes", "sx_scan_classifier", "sx_result_segment_packed", "sx_wave_swar", "sx_wave_pair_codes2", "sx_wave_pair_codes", "sx_shard_bounds", "sx_scan_sharded", "sx_shard_splice", "sx_shard_splice_segs",
            "sx_result_count", "sx_result_segments", "sx_result_segment", "sx_result_segment_device", "sx_result_findings", "sx_result_arena",
@@ -169,7 +170,8 @@ class Stats(C.Structure):
                 ("total_ms", C.c_double), ("heavy_tiles", C.c_uint64), ("wave_windows", C.c_uint64),
                 ("wave_count_ms", C.c_double), ("wave_write_ms", C.c_double), ("rescans", C.c_uint64), ("rescan_ms", C.c_double),
                 ("wave_desc_overflows", C.c_uint64), ("seq_pieces", C.c_uint64),
-                ("fast_regions", C.c_uint64), ("general_regions", C.c_uint64), ("wave_repairs", C.c_uint64)]
+                ("fast_regions", C.c_uint64), ("general_regions", C.c_uint64), ("wave_repairs", C.c_uint64),
+                ("fused_ms", C.c_double), ("fused_launches", C.c_uint64), ("fused_mask", C.c_uint64)]
 
 
 class Options(C.Structure):
@@ -207,6 +209,7 @@ def lib():
     L.sx_scan_device.argtypes = [vp, vp, u64, C.c_int, C.c_int, C.POINTER(vp)]
     L.sx_reset.argtypes = [vp]
     L.sx_device_runs.argtypes = [vp, C.c_int, vp, u64, C.c_int, u64, C.POINTER(C.POINTER(Run)), C.POINTER(u64)]
+    L.sx_device_runs_multi.argtypes = [vp, C.POINTER(C.c_int), C.c_int, vp, u64, C.c_int, C.POINTER(u64), C.POINTER(C.POINTER(Run)), C.POINTER(u64)]
     L.sx_replay_runs.argtypes = [vp, cp, u64, C.c_int, C.c_int, C.POINTER(C.POINTER(Run)), C.POINTER(u64),
                                  C.POINTER(vp)]
     pu64 = C.POINTER(u64)
@@ -352,7 +355,7 @@ class Scanner:
     """One sx_ctx: N missions bound to one HIP device (device=SX_HOST_ONLY: replay stage only)."""
 
     def __init__(self, mission_dicts, device=0, subchunk_bytes=0, record_capacity=0, generic_kernels=False,
-                 replay_threads=0, device_replay=None, result_on_device=False):
+                 replay_threads=0, device_replay=None, result_on_device=False, fused_scan=True):
         L = lib()
         self.n = len(mission_dicts)
         self._ms = (Mission * self.n)(*[Mission.from_dict(d) for d in mission_dicts])
@@ -363,6 +366,8 @@ class Scanner:
             flags |= SX_OPT_HOST_REPLAY
         if result_on_device:
             flags |= SX_OPT_RESULT_ON_DEVICE
+        if not fused_scan:
+            flags |= SX_OPT_NO_FUSED_SCAN
         opt = Options(subchunk_bytes, record_capacity, replay_threads, flags)
         self.h = C.c_void_p()
         rc = L.sx_create(C.byref(self.h), self._ms, self.n, device, C.byref(opt))
@@ -428,6 +433,21 @@ class Scanner:
                                        C.byref(runs), C.byref(n)))
         out = n.value if count_only else [(runs[i].start, runs[i].end, runs[i].chars) for i in range(n.value)]
         lib().sx_free(runs)
+        return out
+
+    def device_runs_multi(self, mission_indices, dptr, length, stream_parity=0, min_chars=None):
+        """Stage A for several missions in one call (sx_device_runs_multi): the missions the fused kernel holds share one
+        launch that reads the buffer once.  Returns a list of run lists."""
+        n = len(mission_indices)
+        idx = (C.c_int * n)(*mission_indices)
+        mc = (C.c_uint64 * n)(*(min_chars if min_chars is not None else [1] * n))
+        runs = (C.POINTER(Run) * n)()
+        cnt = (C.c_uint64 * n)()
+        self._chk(lib().sx_device_runs_multi(self.h, idx, n, dptr, length, stream_parity, mc, runs, cnt))
+        out = []
+        for i in range(n):
+            out.append([(runs[i][j].start, runs[i][j].end, runs[i][j].chars) for j in range(cnt[i])])
+            lib().sx_free(runs[i])
         return out
 
     def scan_file(self, path, chunk_bytes=0, file_id=1):

@@ -422,6 +422,36 @@ int sx_device_runs(sx_ctx* ctx, int mission_index, const void* device_bytes, uin
     return SX_OK;
 }
 
+int sx_device_runs_multi(sx_ctx* ctx, const int* mission_indices, int n, const void* device_bytes, uint64_t len, int stream_parity,
+                         const uint64_t* min_chars, sx_run** runs, uint64_t* n_runs) {
+    if (!ctx || !mission_indices || n <= 0 || !min_chars || !runs || !n_runs) return SX_E_INVALID;
+    begin_call(ctx);
+    if (ctx->host_only) { ctx->err = "host-only context: no device scan"; return SX_E_STATE; }
+    if ((uintptr_t)device_bytes & 15) { ctx->err = "device_bytes must be 16-byte aligned"; return SX_E_INVALID; }
+    std::vector<int> which; std::vector<uint32_t> par; std::vector<uint64_t> mc;
+    for (int i = 0; i < n; i++) {
+        const int k = mission_indices[i];
+        if (k < 0 || (size_t)k >= ctx->missions.size() || std::find(which.begin(), which.end(), k) != which.end()) { ctx->err = "bad mission index"; return SX_E_INVALID; }
+        if (ctx->missions[(size_t)k].host_sequential()) { ctx->err = "an ISO-2022-JP mission has no stage A (one sequential pass on the host)"; return SX_E_INVALID; }
+        which.push_back(k); par.push_back((uint32_t)(stream_parity & 1)); mc.push_back(min_chars[i]);
+        runs[i] = nullptr; n_runs[i] = 0;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<RunList> out;
+    ctx->shard_runs_valid = false;
+    int rc = device_runs(ctx, which, (const uint8_t*)device_bytes, len, par, mc, &out);
+    if (rc != SX_OK) return rc;
+    for (int i = 0; i < n; i++) {
+        if (!out[(size_t)i].own.empty()) out[(size_t)i].use_own();
+        HIP_TRY(ctx, out[(size_t)i].wait());
+        n_runs[i] = out[(size_t)i].size();
+        runs[i] = (sx_run*)malloc(sizeof(sx_run) * (n_runs[i] ? n_runs[i] : 1));
+        if (!runs[i]) { for (int j = 0; j < i; j++) { free(runs[j]); runs[j] = nullptr; } return SX_E_NOMEM; }
+        memcpy(runs[i], out[(size_t)i].data(), sizeof(sx_run) * n_runs[i]);
+    }
+    return SX_OK;
+}
+
 int sx_replay_runs(sx_ctx* ctx, const uint8_t* bytes, uint64_t len, int input_file_id, int is_last_input_buffer,
                    const sx_run* const* runs, const uint64_t* n_runs, sx_result** out) {
     if (!ctx || !out || (!bytes && len) || !runs || !n_runs) return SX_E_INVALID;

@@ -105,6 +105,7 @@ struct ScanSlot {
     DevRun* d_packed = nullptr; uint64_t packed_cap = 0;
     uint32_t region_cap = 0;    // of the launch in flight (0: shared pool)
     uint64_t n_regions = 0;
+    bool fused = false, fused_first = false;   // the launch in flight is a fused one (sx_fused.hip) shared with other Missions; ... and this is its first slot
 };
 struct MissionDev {
     hipStream_t stream = nullptr;     // scan kernels only

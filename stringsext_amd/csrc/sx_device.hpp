@@ -62,7 +62,6 @@ struct ScanParams {
     uint32_t big_endian;   // UTF-16BE
     uint32_t capacity;     // record slots
     uint32_t persistent;   // 0: one wavefront per sub-chunk; else: this many blocks, sub-chunks handed out by counters[3]
-    uint32_t traversal;    // 0: one sub-chunk per wavefront (carry in SGPRs); 1: independent overlapping tiles, grid-stride
     DevRun* recs;
     uint32_t region_cap;   // 0: shared record pool; else: slots per sub-chunk (region mode, see Emitter)
     uint32_t* region_counts; // region mode: records of sub-chunk w
@@ -276,6 +275,12 @@ hipError_t merge_sorted_records(const DevRun* recs, uint32_t n, uint64_t min_cha
                                 sx_run* out, uint32_t* out_count, hipStream_t stream);
 
 hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t stream);
+// One launch that reads the buffer once for up to kFusedMax Missions (sx_fused.hip): slot s of FusedParams holds the Mission whose
+// classifier fused_slot_of() puts there (-1: the Mission cannot be fused and keeps its own launch); used = bit mask of the slots filled.
+constexpr int kFusedMax = 3;
+struct FusedParams { ScanParams m[kFusedMax]; };
+int fused_slot_of(ClassifierKind kind, const ScanParams& p);
+hipError_t launch_scan_fused(const FusedParams& fp, uint32_t used, hipStream_t stream);
 hipError_t launch_fill_background(uint8_t* dst, uint64_t first_index, uint64_t len, uint64_t seed,
                                   hipStream_t stream);
 hipError_t launch_read_sum(const uint8_t* src, uint64_t len, uint64_t* out, hipStream_t stream, uint32_t subchunk = 0);

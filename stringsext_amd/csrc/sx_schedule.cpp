@@ -146,12 +146,13 @@ struct BufferScan {
     std::vector<char> not_scanned;        // per mission: launch() left its scan kernel out (skip_scan)
     int launch(sx_ctx* ctx) {
         not_scanned.assign(ctx->missions.size(), 0);
+        // (one call for all of them: the Missions the fused kernel holds share a launch — sx_stage_a.cpp —, the others follow in `order`)
+        std::vector<int> ks; std::vector<uint32_t> par; std::vector<uint64_t> mc;
         for (int k : order) {
             if (ctx->missions[(size_t)k].host_sequential() || skip_scan(ctx, (size_t)k)) { not_scanned[(size_t)k] = 1; continue; }
-            int rc = stage_a_launch(ctx, { k }, d_bytes, len, { parity[(size_t)k] }, { minc[(size_t)k] }, slot);
-            if (rc != SX_OK) return rc;
+            ks.push_back(k); par.push_back(parity[(size_t)k]); mc.push_back(minc[(size_t)k]);
         }
-        return SX_OK;
+        return ks.empty() ? SX_OK : stage_a_launch(ctx, ks, d_bytes, len, par, mc, slot);
     }
     // Collect stage A mission by mission (in launch order); a mission whose stage B runs on the
     // device is replayed at once, while the kernels of the missions behind it still scan; the

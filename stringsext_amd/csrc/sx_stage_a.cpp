@@ -41,8 +41,6 @@ ScanParams scan_params(const sx_ctx* ctx, int mission, const ScanSlot& s, const 
     }
     p.capacity = s.capacity; p.recs = s.d_recs; p.counters = s.d_counters;
     p.region_cap = s.region_cap; p.region_counts = s.d_cnt; p.grid_flags = s.d_grid;
-    p.traversal = (ctx->opt.flags & SX_OPT_TILE_TRAVERSAL) ? 1u : 0u;
-    if (const char* e = getenv("SX_TRAVERSAL")) p.traversal = (uint32_t)atoi(e);
     // Blocks (of 4 wavefronts) per CU the scan kernel occupies.  8 fills every wave slot; with
     // fewer the kernel runs as a persistent grid and leaves the rest to the second stream
     // (sort/join and stage B of a mission that is already scanned).
@@ -64,12 +62,11 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 256u * 1024u;
             sub = std::max<uint32_t>(kTileBytes, sub / kTileBytes * kTileBytes);
             const uint64_t n_regions = (len + sub - 1) / sub;
-            const bool tile_traversal = (ctx->opt.flags & SX_OPT_TILE_TRAVERSAL) || (getenv("SX_TRAVERSAL") && atoi(getenv("SX_TRAVERSAL")));
             if (ctx->dense.size() != ctx->missions.size()) ctx->dense.assign(ctx->missions.size(), 0);
             s.region_cap = 0; s.n_regions = n_regions;
             const uint32_t dn = ctx->dense[(size_t)which[k]];
             const uint32_t want_cap = dn > 1 ? dn : (dn == 0 ? ctx->region_cap : 0u);
-            if (ctx->region_cap && want_cap && !tile_traversal &&
+            if (ctx->region_cap && want_cap &&
                 (dn > 1 ? large_regions_fit(len, n_regions, want_cap) : n_regions * want_cap < (1ull << 28))) {
                 s.region_cap = want_cap;
                 int rc = ensure_capacity(ctx, s, (uint32_t)(n_regions * s.region_cap));
@@ -91,11 +88,10 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         }
     launch:
         const bool dbcs = ctx->missions[(size_t)which[k]].is_dbcs();
-        uint64_t n_sub = 0;
         if (dbcs) {   // a flag word per sub-chunk: where its token grid stands, for the sub-chunks behind it (sx_kernels.hip scan_kernel_dbcs)
             uint32_t sub = ctx->opt.subchunk_bytes ? ctx->opt.subchunk_bytes : 256u * 1024u;
             sub = std::max<uint32_t>(kTileBytes, sub / kTileBytes * kTileBytes);
-            n_sub = (len + sub - 1) / sub;
+            const uint64_t n_sub = (len + sub - 1) / sub;
             if (s.grid_cap < n_sub) {
                 if (s.d_grid) HIP_TRY(ctx, hipFree(s.d_grid));
                 s.d_grid = nullptr; s.grid_cap = 0;
@@ -103,7 +99,53 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
                 s.grid_cap = n_sub + n_sub / 4 + 64;
             }
         }
-        const ScanParams p = scan_params(ctx, which[k], s, d_bytes, len, parity[k], min_chars[k]);
+    }
+    // Round 6: the Missions whose classifiers have a slot in the fused kernel (sx_fused.hip) share ONE launch — the buffer is read once for
+    // all of them, as the reference hands one slice to every Mission (src/main.rs:153-168).  Per Mission everything else is as before: its
+    // own record slot, counters and events (ev0 / ev1 of every fused Mission bracket the same launch, whose time stats.fused_ms counts once).
+    std::vector<char> fused(which.size(), 0);
+    std::vector<ScanParams> params(which.size());
+    for (size_t k = 0; k < which.size(); k++)
+        params[k] = scan_params(ctx, which[k], ctx->dev[(size_t)which[k]].slot[si], d_bytes, len, parity[k], min_chars[k]);
+    const bool may_fuse = which.size() >= 2 && !(ctx->opt.flags & (SX_OPT_NO_FUSED_SCAN | SX_OPT_MISSION_STREAMS)) && !getenv("SX_MISSION_STREAMS") &&
+                          !(getenv("SX_FUSED") && !atoi(getenv("SX_FUSED"))) && !getenv("SX_SCAN_WARM");
+    if (may_fuse) {
+        FusedParams fp{};
+        uint32_t used = 0;
+        size_t member[kFusedMax] = { 0, 0, 0 };
+        for (size_t k = 0; k < which.size(); k++) {
+            if (params[k].persistent) continue;
+            const int sl = fused_slot_of(ctx->missions[(size_t)which[k]].kind, params[k]);
+            if (sl < 0 || (used >> sl) & 1u) continue;   // (a second Mission of the same slot keeps its own launch)
+            used |= 1u << sl; fp.m[sl] = params[k]; member[sl] = k;
+        }
+        if (__builtin_popcount(used) >= 2) {
+            hipStream_t st = nullptr;
+            for (int sl = 0; sl < kFusedMax; sl++) if ((used >> sl) & 1u) {
+                MissionDev& d = ctx->dev[(size_t)which[member[sl]]];
+                if (!st) st = d.stream;
+                HIP_TRY(ctx, hipMemsetAsync(d.slot[si].d_counters, 0, kCounterWords * sizeof(uint32_t), st));
+            }
+            for (int sl = 0; sl < kFusedMax; sl++) if ((used >> sl) & 1u) HIP_TRY(ctx, hipEventRecord(ctx->dev[(size_t)which[member[sl]]].slot[si].ev0, st));
+            HIP_TRY(ctx, launch_scan_fused(fp, used, st));
+            bool first = true;
+            for (int sl = 0; sl < kFusedMax; sl++) if ((used >> sl) & 1u) {
+                ScanSlot& s = ctx->dev[(size_t)which[member[sl]]].slot[si];
+                HIP_TRY(ctx, hipEventRecord(s.ev1, st));
+                s.fused = true; s.fused_first = first; first = false;
+                fused[member[sl]] = 1;
+            }
+            ctx->stats.fused_launches++;
+        }
+    }
+    for (size_t k = 0; k < which.size(); k++) {
+        if (fused[k]) continue;
+        MissionDev& d = ctx->dev[(size_t)which[k]];
+        ScanSlot& s = d.slot[si];
+        s.fused = false; s.fused_first = false;
+        const bool dbcs = ctx->missions[(size_t)which[k]].is_dbcs();
+        const ScanParams& p = params[k];
+        const uint64_t n_sub = (len + p.subchunk - 1) / p.subchunk;
         // SX_SCAN_WARM=n (measurements): the launch is preceded by n identical ones, so that the timed one starts on a busy chip
         // (bench.py's "alone" launches start from an idle one and take ~1 ms longer: DESIGN §6)
         if (const char* e = getenv("SX_SCAN_WARM"))
@@ -140,6 +182,8 @@ int stage_a_finish(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
         float ms = 0;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, s.ev0, s.ev1));
         if (which[k] < 16) ctx->stats.kernel_ms[which[k]] += ms;
+        if (s.fused && s.fused_first) ctx->stats.fused_ms += ms;
+        if (which[k] < 64) { if (s.fused) ctx->stats.fused_mask |= 1ull << which[k]; else ctx->stats.fused_mask &= ~(1ull << which[k]); }
         uint32_t counters[4] = { 0, 0, 0, 0 };
         std::vector<uint32_t> hc(kCounterWords);
         bool skip_runs = false;

@@ -130,19 +130,81 @@ def test_long_thresholds_with_characters_across_lane_edges(n):
         assert run_cli_product(ms, [data], radix="x", device=0) == sxo.run_cli(ms, [data], radix="x"), (n, flags)
 
 
-def test_tile_traversal_kernels_equal_oracle_runs(monkeypatch):
-    """The experimental tile-independent grid-stride kernels (SX_TRAVERSAL=1) report the same runs."""
-    monkeypatch.setenv("SX_TRAVERSAL", "1")
-    rng = random.Random(11)
-    for name in ("ascii", "utf8_common", "utf8_all", "utf16le_all", "utf16be_uncommon", "koi8r", "utf8_cjk", "utf8_hangul", "utf8_common_asian", "utf16le_cjk",
-                 "utf16be_bmp3", "utf16le_hangul", "utf8_latin", "utf16le_latin"):
-        m = rc.missions(**RUN_MISSIONS[name])[0]
-        for data in (synth(rng, 300_000, 1 / 300), soup(rng, 50_001), b"A" * 70000 + rng.randbytes(977) + b"B" * 3000,
-                     synth(rng, 975, 1 / 40), synth(rng, 977, 1 / 40), synth(rng, 2000, 1 / 40)):
-            for parity in (0, 1):
-                for generic in (False, True):
-                    got, mc = device_runs(m, data, parity=parity, generic=generic)
-                    assert got == sxo.runs(m, data, stream_parity=parity, min_chars=mc), (name, len(data), parity, generic)
+def fused_runs(mdicts, data, parity=0, subchunk=0, min_chars=None):
+    """Stage A of several Missions in one call (sx_device_runs_multi): -> run lists, thresholds, fused_mask."""
+    sc = sx.Scanner(mdicts, device=0, subchunk_bytes=subchunk)
+    try:
+        d = sc.alloc(len(data))
+        sc.upload(d, data)
+        mc = min_chars or [max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"])) for m in mdicts]
+        got = sc.device_runs_multi(list(range(len(mdicts))), d, len(data), stream_parity=parity, min_chars=mc)
+        mask = sc.stats().fused_mask
+        sc.free(d)
+        return got, mc, mask
+    finally:
+        sc.close()
+
+
+FUSED_SETS = {
+    # BASELINE's headline Missions: all three in one launch, the UTF-16 ones behind the prefilter (n >= 7)
+    "c3": (dict(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African"), 0b111),
+    # thresholds below 7: the UTF-16 slots classify every tile (no prefilter)
+    "n4": (dict(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="4", unicode_block_filter="Common"), 0b111),
+    "n7_mixed": (dict(encodings=["utf-16be,7,,Armenian", "utf-8,3,,Greek", "utf-16le,12,,Hebrew"]), 0b111),   # slots in another order, a filter per Mission
+    "pairs": (dict(encodings=["utf-16le", "utf-8"], chars_min="8", unicode_block_filter="Arabic"), 0b11),
+    "le_be": (dict(encodings=["utf-16le", "utf-16be"], chars_min="9", unicode_block_filter="Cyrillic"), 0b11),
+    "ascii_only_af": (dict(encodings=["utf-8", "utf-16be"], chars_min="7", unicode_block_filter="None"), 0b11),
+    # a Mission the fused kernel has no slot for keeps its own launch next to the fused pair
+    "with_koi8r": (dict(encodings=["utf-8,,,African", "koi8-r,,,Cyrillic", "utf-16le,,,African"], chars_min="10"), 0b101),
+    # two Missions for the same slot: the second one keeps its own launch
+    "two_utf8": (dict(encodings=["utf-8,,,African", "utf-8,,,Greek", "utf-16be,,,Greek"], chars_min="10"), 0b101),
+}
+
+
+def utf16_dense(rng, n):
+    """What the UTF-16 prefilter has to get right: stretches of accepted units of every length around 7 .. 40 at every byte phase, across
+    tile (1 KiB) and sub-chunk edges, between bytes whose high-byte positions pass or fail the prefilter's mask."""
+    words = ["Բարեւ", "שלום", "مرحبا", "abc XYZ", "Жук", "Ελλάς", "/usr/lib"]
+    out = bytearray()
+    while len(out) < n:
+        k = rng.choice([1, 3, 6, 7, 8, 10, 13, 14, 20, 40, 600])
+        txt = "".join(rng.choice(words) for _ in range(k))[:k]
+        out += txt.encode(rng.choice(["utf-16-le", "utf-16-be", "utf-8"]))
+        r = rng.random()
+        if r < 0.3: out += rng.randbytes(rng.randrange(0, 9))
+        elif r < 0.5: out += b"\x00" * rng.randrange(0, 2100)          # high bytes that pass: the prefilter must not matter
+        elif r < 0.7: out += b"\xff" * rng.randrange(0, 2100)          # ... that fail: skipped tiles between stretches
+        elif r < 0.8: out += bytes([rng.randrange(8), rng.randrange(256)]) * rng.randrange(0, 600)
+        else: out += rng.randbytes(rng.randrange(900, 1200))
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("name", sorted(FUSED_SETS))
+def test_fused_scan_runs_equal_oracle_runs(name):
+    """The fused stage A (one read of the buffer for several Missions, sx_fused.hip) reports, per Mission, the oracle's runs — and did fuse."""
+    flags, want_mask = FUSED_SETS[name]
+    ms = rc.missions(**flags)
+    rng = random.Random(hash(name) & 0xFFFF)
+    datas = [
+        utf16_dense(rng, 300_001), utf16_dense(rng, 70_000),
+        synth(rng, 200_000, 1 / 400), soup(rng, 70_001), rng.randbytes(1 << 20),
+        b"A" * 5000 + rng.randbytes(3000) + "Ж".encode() * 4000 + b"\x00" * 100 + b"zz" * 3000,
+        ("Բարեւ" * 2000).encode("utf-16-le") + b"\x41" + ("שלום" * 2000).encode("utf-16-be"),
+        b"\x00" * 3000 + ("a\x00" * 7).encode("latin-1") + b"\xff" * 5000 + ("\x00b" * 7).encode("latin-1") + b"\xff" * 1017 + ("c\x00" * 9).encode("latin-1"),
+        synth(rng, 1023, 1 / 50), synth(rng, 1025, 1 / 50), synth(rng, 2049, 1 / 50), synth(rng, 17, 1 / 5), b"abcdefghijkl", b"",
+        cjk_soup(rng, 100_001),
+    ]
+    for di, data in enumerate(datas):
+        for parity in (0, 1):
+            for sub in (1024, 4096, 65536):
+                if sub != 65536 and len(data) > 350_000:
+                    continue
+                got, mc, mask = fused_runs(ms, data, parity=parity, subchunk=sub)
+                if data:
+                    assert mask == want_mask, (name, di, bin(mask))
+                for k, m in enumerate(ms):
+                    want = sxo.runs(m, data, stream_parity=parity, min_chars=mc[k])
+                    assert got[k] == want, (name, di, parity, sub, k, len(got[k]), len(want))
 
 
 def test_device_runs_min_chars_sweep_and_overflow():

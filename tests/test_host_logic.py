@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert set(sx.EXPORTS) == declared
-    assert L.sx_abi_version() == 3
+    assert L.sx_abi_version() == 4
 
 
 def test_no_gpu_means_no_scan():
