@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — GiB/s scanned on BASELINE.json's headline workload (C3(i): 64 GiB synthetic
-background, `-e utf-8 -e utf-16le -e utf-16be -n 10 -u African`, three concurrent mission
-streams), one process per GPU.
+background, `-e utf-8 -e utf-16le -e utf-16be -n 10 -u African`), one process per GPU.
 
-A step = one pass of the hot path (sx_scan_device: one HIP scan kernel per mission, records sorted
-and joined on the device, exact replay of the regions around long runs on the device -> findings in
-reference order in pinned host memory) over the rank's HBM-resident shard.
+A step = one pass of the hot path (sx_scan_device: ONE fused HIP scan kernel that reads the shard once for
+the three Missions — round 6; `--per-mission-launches`: one kernel per Mission, three reads, rounds 1-5 —,
+records packed and joined on the device, exact replay of the regions around long runs on the device ->
+findings in reference order in pinned host memory) over the rank's HBM-resident shard.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
 (HIP-event kernel time vs the 8 TB/s HBM peak) and `cpu_baseline` (the oracle, the only
 runnable restatement of the reference, on a bounded sample).
@@ -318,7 +318,9 @@ def main():
                       "ms_alone": round(fused_alone_ms, 3) if rank == 0 and fused_alone_ms else None} if fused_ks else None,
             "per_kernel_ms": [round(x, 3) for x in kernel_ms],
             "per_kernel_gbs": [round(nbytes / (x * 1e-3) / 1e9, 1) if x > 0 else None for x in kernel_ms],
-            "note": "durations inside the timed region; default schedule (round 5): the busiest mission is scanned first and its stage B runs next to the other missions' scan launches (SX_BUSIEST_LAST=1 / 2: it is scanned last / second to last)",
+            "note": ("durations inside the timed region; round 6: the fused launch reads the shard ONCE for its Missions (frac = 1 x bytes / its time, SURVEY 8(d)); a shard of >= 16 GiB is scanned "
+                     "in two halves, the first half's stage B and copy to the host under the second half's scan (fused.ms = both launches)") if fused_ks else
+                    "durations inside the timed region; one launch per Mission: the busiest mission is scanned first and its stage B runs next to the other missions' scan launches",
             "per_kernel_ms_alone": [round(x, 3) for x in alone_ms],
             "per_kernel_ms_alone_behind_an_identical_launch": [round(x, 3) for x in alone_warm_ms],
             # (the per-Mission kernels, one launch each over the whole shard: what a Mission costs when it is not fused)

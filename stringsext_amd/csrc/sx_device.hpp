@@ -278,7 +278,15 @@ hipError_t launch_scan(ClassifierKind kind, const ScanParams& p, hipStream_t str
 // One launch that reads the buffer once for up to kFusedMax Missions (sx_fused.hip): slot s of FusedParams holds the Mission whose
 // classifier fused_slot_of() puts there (-1: the Mission cannot be fused and keeps its own launch); used = bit mask of the slots filled.
 constexpr int kFusedMax = 3;
-struct FusedParams { ScanParams m[kFusedMax]; };
+struct FusedParams {
+    ScanParams m[kFusedMax];          // (first: the kernel reads the slow paths' parameters out of the kernel-argument segment by slot number)
+    const uint8_t* data;              // what all slots share (set by launch_scan_fused from the used slots)
+    uint64_t len;
+    uint32_t subchunk;
+    uint32_t fsh[kFusedMax][4];       // per slot: the shifts of the fast loop's candidate test (reach cand_f = min(cand_bytes, 12) bytes)
+    uint32_t cand_f[kFusedMax];
+    uint32_t pf_zero[kFusedMax];      // prefilter slots: the bits that are clear in the high byte of every accepted unit
+};
 int fused_slot_of(ClassifierKind kind, const ScanParams& p);
 hipError_t launch_scan_fused(const FusedParams& fp, uint32_t used, hipStream_t stream);
 hipError_t launch_fill_background(uint8_t* dst, uint64_t first_index, uint64_t len, uint64_t seed,

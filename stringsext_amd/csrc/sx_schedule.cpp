@@ -10,14 +10,20 @@ namespace sx {
 
 // Bytes per piece of a large buffer (a multiple of the slice length), or `len` if the buffer is
 // scanned in one go.  With pieces, stage A of piece p+1 and p+2 is queued while piece p is
-// sorted, joined and replayed.  Measured on MI355X (C3(i), 64 GiB): no gain — the replay
-// kernels are latency-bound and run ~3x slower next to a scan kernel that saturates HBM, and
-// the host waits on them six times per piece — so the default is one piece; SX_PIECE_MIB
-// turns the pipeline on (tests do, to keep it correct for an asynchronous stage B later).
+// sorted, joined and replayed.  Rounds 1-5 (one scan launch per Mission, 35 ms per 64 GiB): no gain — a Mission's stage B already
+// ran next to the other Missions' scans.  Round 6 (ONE fused launch, 13 ms): every Mission's stage B — 0.5 ms of joins, 1.3 ms of
+// replay, 2.5 ms for 120 MB of findings over PCIe on the headline — would follow the scan; cut in two, the first half's stage B and
+// copy run under the second half's scan: 18.2 -> 16.5 ms per 64 GiB (four pieces: 17.8, eight: 21.2 — a piece costs ~1 ms of fixed
+// host waits; profiles/r06d_*).  So: two pieces from 16 GiB on when a fused launch is in play; SX_PIECE_MIB sets the size (0: one piece).
 uint64_t piece_bytes(const sx_ctx* ctx, uint64_t len) {
     uint64_t piece = 0;
+    bool halves = false;
     if (const char* e = getenv("SX_PIECE_MIB")) piece = (uint64_t)atoll(e) << 20;
-    if (piece == 0 || len < 2 * piece) return len;
+    else if (len >= (16ull << 30) && ctx->missions.size() >= 2 && !(ctx->opt.flags & (SX_OPT_NO_FUSED_SCAN | SX_OPT_MISSION_STREAMS | SX_OPT_RESULT_ON_DEVICE))) {
+        piece = (len / 2 + kInputBufLen - 1) / kInputBufLen * kInputBufLen;
+        halves = true;
+    }
+    if (piece == 0 || (!halves && len < 2 * piece)) return len;
     // a double-byte mission's token grid at a piece start follows from the bytes in front of it, which the
     // kernels of a piece queued ahead cannot be told: such buffers are scanned in one go
     for (const Mission& m : ctx->missions) if (m.is_dbcs()) return len;
