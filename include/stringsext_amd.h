@@ -191,7 +191,9 @@ enum {
                                      buffer (the wave path: text, `-e ascii -n 4` on binaries, where moving the findings to the host is what bounds
                                      the scan: sx_finding16 records) or a sparse one replayed on the device (sx_finding records) — stays in HBM:
                                      sx_result_segment_device() hands out device pointers to its records and strings, for hosts that go on
-                                     working there.  Valid until the NEXT sx_scan* call on the context (the memory is the context's).  The
+                                     working there.  Valid until the NEXT buffer is scanned on the context — every chunk of sx_scan_stream / sx_scan_file is one; a
+                                     call that accumulates its chunks into one result keeps them in host memory — or the context is destroyed (the memory
+                                     is the context's).  The
                                      host accessors (sx_result_segment, ..._packed, sx_print_findings, ...) still work: the first one copies the
                                      segment to the host (SX_E_STATE if a later scan has overwritten it).  Every other result is in host memory
                                      as without the flag; the sharded entry points ignore it. */

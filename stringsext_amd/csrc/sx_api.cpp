@@ -340,6 +340,9 @@ int sx_create(sx_ctx** out, const sx_mission* missions, int n_missions, int hip_
 
 void sx_destroy(sx_ctx* ctx) {
     if (!ctx) return;
+    // results may outlive the context (they share the pinned pool and the epoch word): what they left in HBM is freed below, so the
+    // accessors must answer SX_E_STATE from here on
+    ctx->dev_epoch->fetch_add(1);
     if (!ctx->host_only && ctx->device >= 0) {
         (void)hipSetDevice(ctx->device);
         for (auto& d : ctx->dev) {

@@ -302,6 +302,10 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
     g_tl_on = getenv("SX_TIMELINE") ? atoi(getenv("SX_TIMELINE")) : 0; g_tl_t0 = t_begin;
     SX_TL("scan_common: %llu bytes", (unsigned long long)len);
     const size_t nm = ctx->missions.size();
+    // SX_OPT_RESULT_ON_DEVICE: a result left in HBM is the context's memory, and every BUFFER reuses it — the chunks of one sx_scan_stream /
+    // sx_scan_file call too (the epoch only advanced per API call, so an earlier chunk's segment still passed the check
+    // after the next chunk had overwritten it)
+    ctx->dev_epoch->fetch_add(1);
     ctx->shard_runs_valid = false;   // the run lists a shard call left behind are about to be overwritten
     std::vector<uint64_t> stream0(nm);
     for (size_t k = 0; k < nm; k++) stream0[k] = ctx->states[k].stream_bytes;
@@ -311,7 +315,7 @@ int scan_common(sx_ctx* ctx, const uint8_t* host_bytes, const uint8_t* d_bytes, 
     const bool seq = seq_piece < len;
     const uint64_t piece = seq ? seq_piece : piece_bytes(ctx, len);
     const uint64_t n_pieces = len ? (len + piece - 1) / piece : 1;
-    ctx->single_piece = n_pieces == 1;
+    ctx->single_piece = n_pieces == 1 && !append_to;   // (a result that accumulates several buffers lives in host memory: the device block is reused per buffer)
     const uint64_t merged0 = ctx->merged_out_bytes;
     int entry_rc = SX_OK;   // (a failed read of the buffer's first bytes must not go unnoticed: the token grid would be wrong)
     auto make = [&](uint64_t p) {

@@ -185,8 +185,8 @@ int sx_scan_sharded(sx_ctx* ctx, int rank, int world, uint64_t file_len, uint64_
 // its result segment by segment, every segment with its own str_off space (BASELINE config 5 at 8 x 32 GiB: 2.4 GB of strings per GiB-eighth)
 // — and the result has as many segments as its strings need (each < 2 GiB), cut between findings.  seg s = (findings[s], n_findings[s],
 // arenas[s], arena_lens[s]); the segments of rank 0 come first, then rank 1's, ...
-int sx_shard_splice_segs(const sx_finding* const* findings, const uint64_t* n_findings, const uint8_t* const* arenas,
-                         const uint64_t* arena_lens, const uint32_t* n_segs_of_rank, int world, uint64_t file_len, sx_result** out) {
+static int splice_segs(const sx_finding* const* findings, const uint64_t* n_findings, const uint8_t* const* arenas,
+                       const uint64_t* arena_lens, const uint32_t* n_segs_of_rank, int world, uint64_t file_len, uint64_t seg_cap, sx_result** out) {
     if (!findings || !n_findings || !arenas || !arena_lens || !n_segs_of_rank || !out || world < 1) return SX_E_INVALID;
     struct Ref { uint32_t seg; int rank; const sx_finding* f; };
     auto less_eq = [](const Ref& a, const Ref& b) {   // a goes first on a tie if it is of the lower Mission (then the earlier rank)
@@ -242,9 +242,7 @@ int sx_shard_splice_segs(const sx_finding* const* findings, const uint64_t* n_fi
     }
     order.insert(order.end(), carry.begin(), carry.end());
     ResultHolder res;
-    // the strings are copied finding by finding: an output segment ends where its arena would pass 2 GiB (SX_SPLICE_SEG_BYTES: tests)
-    uint64_t seg_cap = 2048ull << 20;
-    if (const char* e = getenv("SX_SPLICE_SEG_BYTES")) seg_cap = std::max<uint64_t>(1, (uint64_t)atoll(e));
+    // the strings are copied finding by finding: an output segment ends where its arena would pass seg_cap
     res.r->r.segs.emplace_back();
     for (const Ref& r : order) {
         MissionFindings* m = &res.r->r.segs.back();
@@ -259,19 +257,22 @@ int sx_shard_splice_segs(const sx_finding* const* findings, const uint64_t* n_fi
     return SX_OK;
 }
 
+// (an output segment ends where its arena would pass 2 GiB; SX_SPLICE_SEG_BYTES: tests)
+int sx_shard_splice_segs(const sx_finding* const* findings, const uint64_t* n_findings, const uint8_t* const* arenas,
+                         const uint64_t* arena_lens, const uint32_t* n_segs_of_rank, int world, uint64_t file_len, sx_result** out) {
+    uint64_t seg_cap = 2048ull << 20;
+    if (const char* e = getenv("SX_SPLICE_SEG_BYTES")) seg_cap = std::max<uint64_t>(1, (uint64_t)atoll(e));
+    return splice_segs(findings, n_findings, arenas, arena_lens, n_segs_of_rank, world, file_len, seg_cap, out);
+}
+
 int sx_shard_splice(const sx_finding* const* findings, const uint64_t* n_findings, const uint8_t* const* arenas,
                     const uint64_t* arena_lens, int world, uint64_t file_len, sx_result** out) {
     if (world < 1) return SX_E_INVALID;
     uint64_t bytes = 0;
     if (arena_lens) for (int k = 0; k < world; k++) bytes += arena_lens[k];
-    if (bytes > 0xFFFFFFFFull) return SX_E_NOMEM;   // (ONE result segment: callers with more take sx_shard_splice_segs)
+    if (bytes > 0xFFFFFFFFull) return SX_E_NOMEM;   // (ONE result segment — str_off has 32 bits —: callers with more take sx_shard_splice_segs)
     std::vector<uint32_t> one((size_t)world, 1u);
-    const char* keep = getenv("SX_SPLICE_SEG_BYTES");
-    std::string saved = keep ? keep : "";
-    if (keep) unsetenv("SX_SPLICE_SEG_BYTES");
-    const int rc = sx_shard_splice_segs(findings, n_findings, arenas, arena_lens, one.data(), world, file_len, out);
-    if (keep) setenv("SX_SPLICE_SEG_BYTES", saved.c_str(), 1);
-    return rc;
+    return splice_segs(findings, n_findings, arenas, arena_lens, one.data(), world, file_len, 0xFFFFFFFFull, out);
 }
 
 }  // extern "C"

@@ -94,7 +94,9 @@ static int device_replay_slab(sx_ctx* ctx, size_t k, ByteView& view, const Repla
         P.max_windows = kMaxRegionWindowsDefault;
         P.entry_skip = m.buf_entry_skip;
         P.grid_flags = nullptr; P.grid_sub = 0;
-        if (d.grid_of_scan && d.grid_data == job.d_bytes && d.grid_len == job.len && !getenv("SX_NO_GRID_BOUND")) { P.grid_flags = d.grid_of_scan; P.grid_sub = d.grid_sub; }
+        // (not for gb18030 / GBK — ADVICE round 5: the scan kernel publishes the hang-over of the TWO-byte grammar; a four-byte token that
+        //  straddles a sub-chunk start followed by lead / digit bytes only would start the walk two bytes off and never resynchronise)
+        if (d.grid_of_scan && d.grid_data == job.d_bytes && d.grid_len == job.len && !getenv("SX_NO_GRID_BOUND") && !enc_is_gb(m.c.encoding)) { P.grid_flags = d.grid_of_scan; P.grid_sub = d.grid_sub; }
         if (const char* e = getenv("SX_MAX_REGION_WINDOWS")) P.max_windows = (uint32_t)std::max(1, atoi(e));
         // pass-1 output cache: one arena for all replaying regions (slot = arena / their number, on the device)
         if (dev_stitch && !getenv("SX_NO_REPLAY_CACHE")) {

@@ -163,3 +163,22 @@ def test_regions_inside_a_fill_of_lead_range_bytes_replay_in_bounded_time(monkey
         dt = time.time() - t0
         assert got == want, odd
         assert dt < 30, dt
+
+
+@pytest.mark.parametrize("enc", ["gb18030", "gbk"])
+def test_gb18030_four_byte_passage_across_sub_chunk_starts(monkeypatch, enc):
+    """a passage of four-byte characters the filter rejects (lead digit lead digit ..., nothing but lead and digit bytes) that
+    crosses sub-chunk starts at every phase, an accepted string right behind it.  Stage B's walk back to a token boundary must not end at
+    a sub-chunk start there: stage A publishes the hang-over of the TWO-byte grammar, which is two bytes off inside a four-byte token.
+    Lane-per-region path forced; sub-chunks of 4 KiB so that many starts fall inside the passage."""
+    monkeypatch.setenv("SX_WAVE_REPLAY", "0")
+    ms = rc.missions(encodings=[enc], chars_min="4", unicode_block_filter="Cjk")
+    four = "ᠠᠡᠢᠣᠤ".encode("gb18030")       # Mongolian: four bytes each, UTF-8 lead E1 — not in Cjk
+    assert len(four) == 20
+    good = "中文字符串测试内容".encode("gb18030")
+    for shift in range(4):
+        data = b"x" * (1 + shift) + (four * 3000 + good) * 12 + b"\n" + four * 20000 + good + b"\n"
+        want = sxo.run_cli(ms, [data], radix="x")
+        for sub in (4096, 0):
+            got = run_cli_product(ms, [data], radix="x", device=0, device_replay=True, subchunk_bytes=sub)
+            assert got == want, (enc, shift, sub)

@@ -548,6 +548,41 @@ def test_a_sparse_result_of_one_mission_can_stay_on_the_device():
         sc.close(); host.free(); ref.close()
 
 
+def test_a_result_left_on_the_device_dies_with_the_next_buffer_and_with_the_context(tmp_path):
+    """(1) every BUFFER reuses the context's device block — the chunks of one sx_scan_file call too: a chunk's result that was
+    left in HBM answers SX_E_STATE once the next chunk has been scanned (before: the epoch advanced per API call only and it handed out the next
+    chunk's bytes); (2) sx_destroy frees the block: a result that outlives its context answers SX_E_STATE instead of reading freed memory."""
+    rng = random.Random(79)
+    data = text_lines(rng, 3 * (1 << 20) + 12345)
+    ms = rc.missions(encodings=["ascii"], chars_min="4")
+    path = tmp_path / "in.bin"
+    path.write_bytes(data)
+    ref = sx.Scanner(ms, device=0)
+    want = [r for r in ref.scan_file(str(path), chunk_bytes=1 << 20)]
+    sc = sx.Scanner(ms, device=0, result_on_device=True)
+    got = sc.scan_file(str(path), chunk_bytes=1 << 20)
+    assert len(got) == len(want) >= 3
+    # the last chunk's result is the one that may still lie in HBM; it is the host result's
+    assert got[-1].findings() == want[-1].findings()
+    for r, w in zip(got[:-1], want[:-1]):
+        try:
+            segs = r.device_segments()
+        except sx.SxError:
+            continue                                   # it was left in HBM and a later chunk has reused the block: refused, not wrong
+        assert all(s[0] is None for s in segs)          # ... or it was moved to the host in time: then it is right
+        assert r.findings() == w.findings()
+    last = sc.scan(data[:1 << 20], file_id=1)
+    assert last.device_segments()[0][0] is not None
+    sc.close()
+    with pytest.raises(sx.SxError):
+        last.device_segments()
+    with pytest.raises(sx.SxError):
+        last.segments()
+    for r in want:
+        r.free()
+    ref.close()
+
+
 def test_eucjp_fills_stay_on_the_wave_path(wave_forced):
     """a fill of lead-range bytes longer than 64 KiB made EUC-JP's wavefronts give the buffer back (token lengths differ: no
     parity).  Without an 8E / 8F among the bytes walked over every token has two bytes there, and the hang-over follows from the wavefront in
