@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--per-mission-launches", action="store_true",
                     help="SX_OPT_NO_FUSED_SCAN: one scan launch per Mission, each reading the whole buffer (rounds 1-5; the line's config.passes says so) "
                          "instead of the fused launch that reads it once")
+    ap.add_argument("--no-alone", action="store_true", help="skip the launches outside the timed region (counter passes: the step's launches only)")
     ap.add_argument("--generic-kernels", action="store_true",
                     help="force the table-driven (LUT) classifiers instead of the range kernels: what a Mission with an arbitrary af / ubf costs")
     ap.add_argument("--ubf", default=None,
@@ -201,7 +202,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     kernel_ms = [0.0] * len(missions)
-    fused_ms, fused_mask = 0.0, 0
+    fused_ms, fused_mask, fused_launches = 0.0, 0, 0
     device_ms = replay_ms = d2h_ms = wave_count_ms = wave_write_ms = 0.0
     wave_windows = rescans = seq_pieces = fast_regions = general_regions = 0
     rescan_ms = 0.0
@@ -214,6 +215,7 @@ def main():
         for k in range(len(missions)):
             kernel_ms[k] += st.kernel_ms[k]
         fused_ms += st.fused_ms
+        fused_launches += st.fused_launches
         fused_mask = st.fused_mask
         device_ms += st.device_ms
         rescans += st.rescans
@@ -237,7 +239,8 @@ def main():
     # device), for the roofline's "what the kernel can do" next to "what it did in the job"
     alone_ms = []
     alone_warm_ms = []
-    if rank == 0:
+    fused_alone_ms = None
+    if rank == 0 and not args.no_alone:
         for k, m in enumerate(missions):
             mc = max(1, min(m["chars_min_nb"], m["output_line_char_nb_max"]))
             best = None
@@ -246,7 +249,6 @@ def main():
                 t = sc.stats().kernel_ms[k]
                 best = t if best is None else min(best, t)
             alone_ms.append(best)
-        fused_alone_ms = None
         if fused_mask:   # the fused launch alone: stage A of its Missions in one call
             idx = [k for k in range(len(missions)) if (fused_mask >> k) & 1]
             mcs = [max(1, min(missions[k]["chars_min_nb"], missions[k]["output_line_char_nb_max"])) for k in idx]
@@ -315,6 +317,7 @@ def main():
                                "write_gbs": round(n_wave * nbytes / (wave_write_ms * 1e-3) / 1e9, 1) if wave_write_ms > 0 else None},
             "algorithmic_bytes_per_launch": nbytes,
             "fused": {"missions": fused_ks, "ms": round(fused_ms, 3), "gbs": round(nbytes / (fused_ms * 1e-3) / 1e9, 1) if fused_ms > 0 else None,
+                      "launches_per_step": fused_launches // K,   # (a shard of >= 16 GiB: two halves)
                       "ms_alone": round(fused_alone_ms, 3) if rank == 0 and fused_alone_ms else None} if fused_ks else None,
             "per_kernel_ms": [round(x, 3) for x in kernel_ms],
             "per_kernel_gbs": [round(nbytes / (x * 1e-3) / 1e9, 1) if x > 0 else None for x in kernel_ms],

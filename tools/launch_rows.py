@@ -9,13 +9,15 @@ bench = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
 nbytes = bench["config"]["bytes_per_gpu"]
 # a buffer whose output is gigabytes is scanned in pieces (bench.py "sequential_pieces"): a timed launch then covers one piece
 pieces = max(1, int(bench.get("sequential_pieces") or 0))
+# ... and a large shard with a fused scan in two halves (bench.py roofline.fused.launches_per_step): a fused launch then covers one half
+fused_pieces = max(1, int(((bench.get("roofline") or {}).get("fused") or {}).get("launches_per_step") or 1))
 fills = [i for i, r in enumerate(rows) if "fill_kernel" in r["Kernel_Name"]]
 # the markers are the last two fill launches (the first ones generate the input)
 m0, m1 = fills[-2], fills[-1]
 def cls(i):
     return "warm-up" if i < m0 else "timed" if i < m1 else "alone"
 import re
-want = re.compile(r"\bsx::(scan_kernel(_dbcs)?|wave_replay_kernel|wave_emit_kernel)<")
+want = re.compile(r"\bsx::(scan_kernel(_dbcs|_fused)?|wave_replay_kernel|wave_emit_kernel)<")
 is_scan = lambda name: name.startswith("scan_kernel")
 # Warm-up launches are listed one by one: that is where a Mission's first launch finds its record regions too small and is launched
 # AGAIN with larger ones (the library then remembers the size: bench.py's "scan_kernels_launched_again" counts them per timed step).
@@ -35,16 +37,17 @@ for i, r in enumerate(rows):
         c = "%s launch %d" % (c, seen_warm[(name, c)])
     agg.setdefault((name, c), []).append(ms)
 print("kernel,class,launches,avg_ms,min_ms,max_ms,gbs_at_avg")
-tot_ms = tot_launch = 0
+tot_ms = tot_launch = tot_bytes = 0
 for (name, c), v in sorted(agg.items()):
     avg = sum(v) / len(v)
-    per_launch_bytes = (nbytes / pieces if c == "timed" else nbytes) if is_scan(name) else nbytes / max(1, len(v) / max(1, bench["steps"]) ) if c == "timed" else nbytes
+    pcs = fused_pieces if name.startswith("scan_kernel_fused") else pieces
+    per_launch_bytes = (nbytes / pcs if c == "timed" else nbytes) if is_scan(name) else nbytes / max(1, len(v) / max(1, bench["steps"]) ) if c == "timed" else nbytes
     print(f'"{name}",{c},{len(v)},{avg:.3f},{min(v):.3f},{max(v):.3f},{per_launch_bytes / (avg * 1e-3) / 1e9:.1f}')
     if c == "timed" and is_scan(name):
-        tot_ms += sum(v); tot_launch += len(v)
+        tot_ms += sum(v); tot_launch += len(v); tot_bytes += len(v) * nbytes / pcs
 if tot_launch:
-    frac = tot_launch * (nbytes / pieces) / (tot_ms * 1e-3) / 1e9 / 8000.0
-    print(f'# scan launches inside the timed region: {tot_launch} launches{" of a piece (1/%d of the buffer) each" % pieces if pieces > 1 else ""}, {tot_ms:.3f} ms -> {tot_launch * (nbytes / pieces) / (tot_ms * 1e-3) / 1e9:.1f} GB/s = {frac:.4f} of the 8 TB/s peak '
+    frac = tot_bytes / (tot_ms * 1e-3) / 1e9 / 8000.0
+    print(f'# scan launches inside the timed region: {tot_launch} launches{" of a piece (1/%d of the buffer) each" % max(pieces, fused_pieces) if max(pieces, fused_pieces) > 1 else ""}, {tot_ms:.3f} ms -> {tot_bytes / (tot_ms * 1e-3) / 1e9:.1f} GB/s = {frac:.4f} of the 8 TB/s peak '
           f'(bench.py in the same run: {bench["roofline"]["frac"]}); a step = {tot_ms / bench["steps"]:.3f} ms of scan launches')
 # string-dense Missions: their passes over the input are the wave kernels' count pass (MODE 0) and write pass (MODE 1); a pass of a
 # single Mission is cut into slabs, i.e. several launches.  bench.py's figure for them comes from HIP events around each pass
