@@ -136,10 +136,20 @@ constexpr u32 wv_lds_words(int fam, int cls, int opt = 0) {   // ... and the des
 
 // MODE 0: count; 1: write.  FAM 0: single-byte decoders; 1: UTF-8; 4: the two-byte family (Big5, Shift_JIS, EUC-KR: 4 wavefronts
 // per block share the 32 KB of pair codes in LDS).
+// Round 6: NO kernel that holds the exchange loop may spill a vector register (tests/test_kernel_resources.py) — in round 5 the -r kernels,
+// at 128 registers with 30 to 65 of them spilled, brought a value that lives across that loop back wrong in the lanes that had run it twice;
+// the cause was never found (see profiles/r06_spill_note.md), so the loop only ever runs in kernels without spill code.  Single byte and
+// UTF-8: three wavefronts per SIMD (168 registers; at four / 128 they spilled 2 - 28) — text, -e ascii -n 4 and Russian text run as fast
+// (profiles/r06i_*: the A/B); UTF-16: two.  The one exception, named in the test: the two-byte families' COUNT kernels with SWAR classes
+// (<0, 4, 4, 1, 0>, <0, 5, 4, 1, 0>: 65 / 63 spilled at four wavefronts, none at two) stay at four — at two BASELINE config 5 runs 387 -> 465 ms
+// per step (r06i) —; 60 k GPU fuzz cases of round 5 and this round's ran clean on them, and their writers (<1, 4 / 5, ..>) do not spill.
 #ifndef SX_WV_OCC0
-#define SX_WV_OCC0 4   // wavefronts per SIMD the compiler is asked for, count pass: single-byte / UTF-8 / two-byte family
-#define SX_WV_OCC1 4
+#define SX_WV_OCC0 3   // wavefronts per SIMD the compiler is asked for, count pass: single-byte / UTF-8 / two-byte family
+#define SX_WV_OCC1 3
 #define SX_WV_OCC4 2
+#endif
+#ifndef SX_WV_OCC2
+#define SX_WV_OCC2 2   // ... UTF-16
 #endif
 #ifndef SX_WV_OCCW0
 #define SX_WV_OCCW0 SX_WV_OCC0   // ... write pass
@@ -159,6 +169,7 @@ constexpr int wv_occ(int mode, int fam, int cls, int opt = 0) {
     if (opt >= 2) return SX_WV_OCCS;
     if (opt == 1) return SX_WV_OCCG;
     if (mode == 0 && fam >= 4 && cls) return SX_WV_OCC4S;
+    if (fam == 2) return SX_WV_OCC2;
     return mode == 0 ? (fam >= 4 ? SX_WV_OCC4 : fam == 1 ? SX_WV_OCC1 : SX_WV_OCC0) : (fam >= 4 ? SX_WV_OCCW4 : fam == 1 ? SX_WV_OCCW1 : SX_WV_OCCW0);
 }
 // GREP: the Mission has -g (round 5) — a compile-time constant: WvWin::GC and the grep rules cost registers a Mission without -g must not pay for
