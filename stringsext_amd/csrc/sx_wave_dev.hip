@@ -669,7 +669,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
         // the text-start stretch of its call and something is carried into it —, not from "nothing carried": one round, not two or three)
         const WvTail tail = active ? wv_tail_g<KIND, GREP, SAME>(WP, w) : WvTail{ 128u, 0u };   // (the window's last stretch: looked at once, used by every replay of it)
         u32 out = tail.state;
-        u32 in = wv_from_prev(out, carry);
+#if defined(SX_WV_XCHG_BPERM)   // (tools/repro: the exchange through ds_bpermute instead of a DPP wave shift)
+#define SX_XCHG(v, edge) (lane ? wv_shfl((v), lane - 1u) : (edge))
+#else
+#define SX_XCHG(v, edge) wv_from_prev((v), (edge))
+#endif
+        u32 in = SX_XCHG(out, carry);
         const bool injected = g == P.g_lo;   // the host's exact state
         if (injected) in = P.inject;
         u32 nf = 0, nb = 0;
@@ -695,7 +700,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
                 else { WvCountEmit<0> cc; wv_window_g<KIND, GREP, SAME>(WP, w, st, cc, tail); nf = cc.nf; nb = cc.nb; }
                 out = wv_pack(st);
             } else if (!active) out = in;
-            u32 pin = wv_from_prev(out, carry);
+            u32 pin = SX_XCHG(out, carry);
             if (injected) pin = P.inject;
             todo = active && pin != in;
             in = pin;
@@ -720,6 +725,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(wv_occ
             // that lives across the loop is used here, and tools/gpu_fuzz.py compares every byte of the output)
             u64 ws2 = 0; u32 wn2 = 0;
             wv_window_at(g, P.W, P.wps, P.len, &ws2, &wn2);
+#if defined(SX_WV_USE_WS)   // (tools/repro: the round-5 build — the offset as it comes out of the loop)
+            ws2 = ws;
+#endif
             WriteEmit<FAM> we_{ &P, fo, P.arena + ao, ao, ws2 };
             WvState st = wv_unpack(in);
             wv_window_g<KIND, GREP, SAME>(WP, w, st, we_, tail);
