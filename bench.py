@@ -74,6 +74,9 @@ def main():
                     help="zero: a constant-byte buffer instead of the synthetic background (counter passes: same instructions, other data)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (testing the N>1 path on one GPU: gloo)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses cuda:0")
+    ap.add_argument("--transport", default="torch", choices=["torch", "library"],
+                    help="N > 1: the exchange and the gather through torch.distributed (default) or through the library's own RCCL transport "
+                         "(csrc/sx_transport.cpp: sx_transport_allgather / sx_transport_gather; the process group then only ships rank 0's 128-byte id)")
     ap.add_argument("--result-on-device", action="store_true",
                     help="SX_OPT_RESULT_ON_DEVICE: a single-Mission workload's dense result stays in HBM (c1) — NOT the headline boundary, the line's "
                          "config says so")
@@ -180,9 +183,15 @@ def main():
         else:
             # shard scan + one all_gather over RCCL ("where did everybody start and stop", finding counts), then the
             # gather of the Finding buffers to rank 0 (BASELINE config 4) — all inside the timed region
-            gathered, res = sharded.scan_sharded(sc, get_buffer, file_len, file_id=1, halo=halo,
-                                                 device=xdev, gather=True, timings=timings)
-            n = sum(len(fb) // 32 for fb, _ in gathered) if rank == 0 else 0
+            if args.transport == "library":
+                whole, res, _counts = sharded.scan_sharded_library(sc, get_buffer, file_len, local_rank, file_id=1, halo=halo, timings=timings)
+                n = len(whole) if whole is not None else 0
+                if whole is not None:
+                    whole.free()
+            else:
+                gathered, res = sharded.scan_sharded(sc, get_buffer, file_len, file_id=1, halo=halo,
+                                                     device=xdev, gather=True, timings=timings)
+                n = sum(len(fb) // 32 for fb, _ in gathered) if rank == 0 else 0
         st = sc.stats()
         res.free()
         return n, st
@@ -342,6 +351,7 @@ def main():
                        "image_bytes": world * nbytes,
                        "parallelism": f"byte-range shards x{world}" + (" on ONE device (--single-device: plumbing test)" if args.single_device and world > 1 else ""),
                        "backend": args.backend if world > 1 else None,
+                       "transport": (args.transport if world > 1 else None),
                        # the Missions' scan launches queue up in ONE HIP stream by default (measured: a stream per Mission — SX_OPT_MISSION_STREAMS,
                        # the north star's wording — aliases onto the same hardware queues and the kernels are bound by issue, not by launch order)
                        "mission_streams": "per mission" if os.environ.get("SX_MISSION_STREAMS") else "one scan stream + one stage-B stream",

@@ -389,6 +389,24 @@ int sx_shard_splice(const sx_finding* const* findings, const uint64_t* n_finding
 int sx_shard_splice_segs(const sx_finding* const* findings, const uint64_t* n_findings, const uint8_t* const* arenas,
                          const uint64_t* arena_lens, const uint32_t* n_segs_of_rank, int world, uint64_t file_len, sx_result** out);
 
+/* ---- (round 6) The sharded scan's transport inside the library: RCCL over xGMI, loaded with dlopen ("librccl.so.1"; a host without
+ * it still loads this library and scans one GPU).  One process per GPU:
+ *     rank 0: sx_transport_rccl_id(id);  ship the 128 bytes to every rank (the launcher's job: a file, an env var, MPI, a socket);
+ *     every rank: sx_transport_rccl_create(&t, hip_device, rank, world, id);              -- ncclCommInitRank, a stream of its own
+ *     sx_scan_sharded(ctx, rank, world, ..., sx_transport_allgather, t, &mine, counts, overflow);   -- the transport is the callback's `user`
+ *     sx_transport_gather(t, mine, 0, file_len, &all);    -- rank 0: ONE result in the reference's order (sx_shard_splice_segs inside); else NULL
+ * The gather: an all-gather of the segment sizes, then grouped ncclSend / ncclRecv of exactly those sizes into one device buffer at
+ * the root and one copy to the host — no collective on the data path.  Errors: SX_E_STATE without librccl,
+ * SX_E_HIP for a failing HIP / RCCL call; text from sx_transport_last_error (NULL: the last failed id / create call). */
+#define SX_TRANSPORT_ID_BYTES 128
+typedef struct sx_transport sx_transport;
+int  sx_transport_rccl_id(uint8_t* id128);
+int  sx_transport_rccl_create(sx_transport** out, int hip_device, int rank, int world, const uint8_t* id128);
+void sx_transport_destroy(sx_transport* t);
+const char* sx_transport_last_error(const sx_transport* t);
+int  sx_transport_allgather(void* transport, const void* send, uint64_t bytes, void* recv);   /* an sx_allgather_fn */
+int  sx_transport_gather(sx_transport* t, const sx_result* mine, int root, uint64_t file_len, sx_result** out);
+
 /* (round 5, SX_OPT_RESULT_ON_DEVICE) Segment i where it lies in HBM: *d_records = n records (sx_finding16 if *packed, else sx_finding;
  * what they share: *info), *d_arena = arena_len bytes of strings (str_off counts from there).  *d_records == NULL: the segment is in host
  * memory (read it with sx_result_segment / sx_result_segment_packed).  SX_E_STATE: a later scan has reused the memory.  One caller at a

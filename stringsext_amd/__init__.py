@@ -32,7 +32,7 @@ ABI_VERSION = 4   # SX_ABI_VERSION of include/stringsext_amd.h
 EXPORTS = ["sx_abi_version", "sx_create", "sx_destroy", "sx_last_error", "sx_scan", "sx_scan_device", "sx_reset",
            "sx_device_runs", "sx_device_runs_multi", "sx_replay_runs", "sx_scan_shard_device", "sx_scan_shard", "sx_replay_shard_runs",
            "sx_scan_stream", "sx_scan_file", "sx_missions_from_flags", "sx_parse_enc_opt", "sx_encoding_for_label", "sx_encoding_name",
-           "sx_decoder_table", "sx_wave_classes", "sx_scan_classifier", "sx_result_segment_packed", "sx_wave_swar", "sx_wave_pair_codes2", "sx_wave_pair_codes", "sx_shard_bounds", "sx_scan_sharded", "sx_shard_splice", "sx_shard_splice_segs",
+           "sx_decoder_table", "sx_wave_classes", "sx_scan_classifier", "sx_result_segment_packed", "sx_wave_swar", "sx_wave_pair_codes2", "sx_wave_pair_codes", "sx_shard_bounds", "sx_scan_sharded", "sx_shard_splice", "sx_shard_splice_segs", "sx_transport_rccl_id", "sx_transport_rccl_create", "sx_transport_destroy", "sx_transport_last_error", "sx_transport_allgather", "sx_transport_gather",
            "sx_result_count", "sx_result_segments", "sx_result_segment", "sx_result_segment_device", "sx_result_findings", "sx_result_arena",
            "sx_result_free", "sx_print_findings", "sx_get_stats", "sx_free", "sx_fill_background_device",
            "sx_device_alloc", "sx_device_free", "sx_device_upload", "sx_device_download",

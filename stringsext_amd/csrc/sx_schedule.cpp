@@ -20,7 +20,11 @@ uint64_t piece_bytes(const sx_ctx* ctx, uint64_t len) {
     bool halves = false;
     if (const char* e = getenv("SX_PIECE_MIB")) piece = (uint64_t)atoll(e) << 20;
     else if (len >= (16ull << 30) && ctx->missions.size() >= 2 && !(ctx->opt.flags & (SX_OPT_NO_FUSED_SCAN | SX_OPT_MISSION_STREAMS | SX_OPT_RESULT_ON_DEVICE))) {
-        piece = (len / 2 + kInputBufLen - 1) / kInputBufLen * kInputBufLen;
+        // (the first piece the larger one: its stage B must fit under the second piece's scan, and what follows the second piece's
+        // scan — its own stage B and copy — is the step's tail; SX_PIECE_FRAC: percent of the buffer in the first piece)
+        uint64_t pct = 50;
+        if (const char* e = getenv("SX_PIECE_FRAC")) pct = (uint64_t)std::min(95, std::max(5, atoi(e)));
+        piece = ((len / 100) * pct + kInputBufLen - 1) / kInputBufLen * kInputBufLen;
         halves = true;
     }
     if (piece == 0 || (!halves && len < 2 * piece)) return len;

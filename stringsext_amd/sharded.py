@@ -21,7 +21,7 @@ import time
 import torch
 import torch.distributed as dist
 
-from . import Finding, PRECISION, Result, Run, lib
+from . import Finding, PRECISION, Result, Run, SX_OK, SxError, lib
 
 HALO_DEFAULT = 1 << 20
 
@@ -314,6 +314,101 @@ def scan_sharded(scanner, get_buffer, file_len, file_id=1, file_stream_off=0, ha
     if timings is not None:
         timings["gather_ms"] = 1e3 * (time.perf_counter() - t_exchanged)
     return out, res
+
+
+# ---- the transport inside the library (round 6: csrc/sx_transport.cpp — RCCL through dlopen; the C-ABI a Rust host binds) ----
+_LIB_TRANSPORT = {}
+
+
+def library_transport(device_index, id_exchange=None):
+    """The library's own RCCL transport for this rank (sx_transport_rccl_create), made once per process and device.  Rank 0's
+    unique id travels through `id_exchange(id_bytes_or_None) -> id_bytes` (default: a broadcast over the torch.distributed group
+    the launcher set up — any backend: it only ships 128 bytes once)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    key = (device_index, world, rank)
+    if key in _LIB_TRANSPORT:
+        return _LIB_TRANSPORT[key]
+    L = lib()
+    L.sx_transport_rccl_id.argtypes = [ctypes.c_char_p]
+    L.sx_transport_rccl_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    L.sx_transport_last_error.restype = ctypes.c_char_p
+    L.sx_transport_last_error.argtypes = [ctypes.c_void_p]
+    ident = None
+    if rank == 0:
+        buf = ctypes.create_string_buffer(128)
+        rc = L.sx_transport_rccl_id(buf)
+        if rc != SX_OK:
+            raise SxError(rc, L.sx_transport_last_error(None).decode())
+        ident = buf.raw
+    if id_exchange is not None:
+        ident = id_exchange(ident)
+    elif world > 1:
+        box = [ident]
+        dist.broadcast_object_list(box, src=0)
+        ident = box[0]
+    t = ctypes.c_void_p()
+    rc = L.sx_transport_rccl_create(ctypes.byref(t), device_index, rank, world, ident)
+    if rc != SX_OK:
+        raise SxError(rc, L.sx_transport_last_error(None).decode())
+    _LIB_TRANSPORT[key] = t
+    return t
+
+
+def scan_sharded_library(scanner, get_buffer, file_len, device_index, file_id=1, halo=HALO_DEFAULT, file_stream_off=0, gather=True,
+                         timings=None, id_exchange=None):
+    """scan_sharded with the LIBRARY's transport: sx_scan_sharded gets sx_transport_allgather as its callback (no Python in the
+    exchange), sx_transport_gather brings every rank's segments to rank 0 and splices them there.  Returns (the file's findings as one
+    Result on rank 0 — None elsewhere or without gather —, this rank's own Result, ShardCounts)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    L = lib()
+    tr = library_transport(device_index, id_exchange)
+    keep, errors = {}, []
+
+    def _buffer(user, lo, hi, ptr, is_device):
+        try:
+            buf = get_buffer(lo, hi)
+            if isinstance(buf, ctypes.c_void_p):
+                ptr[0] = buf.value
+                is_device[0] = 1
+            else:
+                keep["buf"] = ctypes.create_string_buffer(bytes(buf), hi - lo)
+                ptr[0] = ctypes.cast(keep["buf"], ctypes.c_void_p).value
+                is_device[0] = 0
+            return 0
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            return 1
+
+    cb_buffer = BUFFER_FN(_buffer)
+    cb_gather = ctypes.cast(L.sx_transport_allgather, ALLGATHER_FN)
+    L.sx_scan_sharded.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int,
+                                  ctypes.c_uint64, BUFFER_FN, ctypes.c_void_p, RUNS_FN, ctypes.c_void_p, ALLGATHER_FN, ctypes.c_void_p,
+                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    t0 = time.perf_counter()
+    r = ctypes.c_void_p()
+    cnt, over = (ctypes.c_uint64 * world)(), (ctypes.c_uint64 * world)()
+    rc = L.sx_scan_sharded(scanner.h, rank, world, file_len, file_stream_off, file_id, halo, cb_buffer, None, ctypes.cast(None, RUNS_FN), None,
+                           cb_gather, tr, ctypes.byref(r), cnt, over)
+    if errors:
+        raise errors[0]
+    scanner._chk(rc)
+    res = Result(scanner, r)
+    counts = ShardCounts(cnt)
+    counts.overflow = list(over)
+    t1 = time.perf_counter()
+    whole = None
+    if gather:
+        L.sx_transport_gather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+        out = ctypes.c_void_p()
+        rc = L.sx_transport_gather(tr, res.h, 0, file_len, ctypes.byref(out))
+        if rc != SX_OK:
+            raise SxError(rc, L.sx_transport_last_error(tr).decode())
+        if out.value:
+            whole = Result(scanner, out)
+    if timings is not None:
+        timings["scan_ms"] = 1e3 * (t1 - t0)
+        timings["gather_ms"] = 1e3 * (time.perf_counter() - t1)
+    return whole, res, counts
 
 
 class ShardCounts(list):

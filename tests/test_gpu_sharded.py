@@ -149,6 +149,59 @@ def test_two_ranks_on_two_gpus_over_rccl():
     assert res[1], res
 
 
+def _library_worker(rank, world, port, q):
+    """the LIBRARY's transport (csrc/sx_transport.cpp: RCCL through dlopen): sx_scan_sharded with sx_transport_allgather as its callback,
+    sx_transport_gather + splice on rank 0; the torch.distributed group (gloo) only ships rank 0's 128-byte id"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import stringsext_amd as sx
+        from stringsext_amd import sharded
+        data = make_data("c4", 777)
+        ms = rc.missions(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African")
+        sc = sx.Scanner(ms, device=rank)
+        d = sc.alloc(len(data)); sc.upload(d, data)
+        timings = {}
+        for _ in range(2):   # (twice: the transport and its buffers are kept from call to call)
+            whole, res, counts = sharded.scan_sharded_library(sc, lambda lo, hi: ctypes.c_void_p(d.value + lo), len(data), rank, file_id=1, timings=timings)
+        if rank == 0:
+            got = [(f["position"], f["precision"], f["s"], f["completes"], f["mission_id"], f["slice_index"]) for f in whole.findings()]
+            want = oracle_findings(ms, data)
+            q.put(("ok", got == want and sum(counts) == len(want), len(got), len(want), timings))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_library(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_library_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+    assert res[0] == "ok", res[1]
+    assert res[1], res
+
+
+def test_the_librarys_rccl_transport_runs_on_one_gpu():
+    """world size 1: ncclCommInitRank, ncclAllGather (sx_scan_sharded's exchanges and the gather's size table) and the splice run once — the
+    code a Rust host binds, no torch in the path"""
+    _run_library(1)
+
+
+def test_the_librarys_rccl_transport_on_two_gpus():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_library(2)
+
+
 def test_bench_with_eight_ranks_on_one_gpu_through_gloo():
     """The driver's `bench.py --gpus N` line, N = 8, as far as one GPU can carry it: eight ranks sharing cuda:0, the exchange and the
     gather through gloo.  The default is STRONG scaling (BASELINE.json's metric: one image at 1/2/4/8 GPUs) — here a 1 GiB image —, the
