@@ -107,7 +107,7 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
     std::vector<ScanParams> params(which.size());
     for (size_t k = 0; k < which.size(); k++)
         params[k] = scan_params(ctx, which[k], ctx->dev[(size_t)which[k]].slot[si], d_bytes, len, parity[k], min_chars[k]);
-    const bool may_fuse = which.size() >= 2 && !(ctx->opt.flags & (SX_OPT_NO_FUSED_SCAN | SX_OPT_MISSION_STREAMS)) && !getenv("SX_MISSION_STREAMS") &&
+    const bool may_fuse = !(ctx->opt.flags & (SX_OPT_NO_FUSED_SCAN | SX_OPT_MISSION_STREAMS)) && !getenv("SX_MISSION_STREAMS") &&
                           !(getenv("SX_FUSED") && !atoi(getenv("SX_FUSED"))) && !getenv("SX_SCAN_WARM");
     if (may_fuse) {
         FusedParams fp{};
@@ -119,7 +119,8 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             if (sl < 0 || (used >> sl) & 1u) continue;   // (a second Mission of the same slot keeps its own launch)
             used |= 1u << sl; fp.m[sl] = params[k]; member[sl] = k;
         }
-        if (__builtin_popcount(used) >= 2) {
+        // (two Missions or more — or the UTF-8 range Mission alone: the fused kernel's fast loop is the faster scan of it)
+        if (__builtin_popcount(used) >= 2 || used == 1u) {
             hipStream_t st = nullptr;
             for (int sl = 0; sl < kFusedMax; sl++) if ((used >> sl) & 1u) {
                 MissionDev& d = ctx->dev[(size_t)which[member[sl]]];
