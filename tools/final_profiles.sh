@@ -3,8 +3,10 @@
 tag=$1
 python bench.py > gpurun_out/${tag}_bench_c3_64gib.json 2> gpurun_out/${tag}_bench_c3.err < /dev/null
 tail -c 600 gpurun_out/${tag}_bench_c3_64gib.json; echo
-SX_BUSIEST_LAST=0 python bench.py --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_c3_64gib_busiest_first.json
-SX_BUSIEST_LAST=1 python bench.py --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_c3_64gib_busiest_last.json
+# the same Missions with one launch each (rounds 1-5), and the fused launch over the buffer in one piece
+python bench.py --no-cpu-baseline --per-mission-launches 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_c3_64gib_per_mission.json
+SX_PIECE_MIB=0 python bench.py --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_c3_64gib_one_piece.json
+python bench.py --gib 8 --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_c3_8gib.json
 # (a process that held 64 GiB of HBM has just ended: for about ten seconds the driver clears that memory, and device-to-host copies
 # run at 43 instead of 53 GB/s meanwhile — C1 and the text workload, which are bound by exactly those copies, wait for it)
 sleep 20
@@ -16,8 +18,10 @@ python bench.py --workload c5 --warmup 2 --no-cpu-baseline 2>/dev/null < /dev/nu
 # kernel statistics + the launch rows (warm-up / timed / alone) of the same run
 for w in c3 c5; do timeout 600 tools/kernel_stats.sh ${tag}_${w} --workload $w --steps 3 --warmup 2 > /dev/null 2>&1 < /dev/null; done
 timeout 600 tools/kernel_stats.sh ${tag}_c1 --workload c1 --steps 20 --warmup 5 > /dev/null 2>&1 < /dev/null
-timeout 600 tools/pmc_pass.sh ${tag}_fetch "FETCH_SIZE" > /dev/null 2>&1 < /dev/null
-timeout 600 tools/pmc_pass.sh ${tag}_write "WRITE_SIZE" > /dev/null 2>&1 < /dev/null
+timeout 600 tools/pmc_pass.sh ${tag}_fetch "FETCH_SIZE" --no-alone > /dev/null 2>&1 < /dev/null
+timeout 600 tools/pmc_pass.sh ${tag}_write "WRITE_SIZE" --no-alone > /dev/null 2>&1 < /dev/null
+timeout 600 tools/pmc_pass.sh ${tag}_sq "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" --no-alone > /dev/null 2>&1 < /dev/null
+timeout 600 tools/pmc_pass.sh ${tag}_sq2 "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE" --no-alone > /dev/null 2>&1 < /dev/null
 # two ranks sharing the one GPU (gloo: RCCL refuses two ranks on one device): the N > 1 path of bench.py, weak and strong scaling
 python bench.py --gpus 2 --backend gloo --single-device --gib 16 --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_2ranks_1gpu_gloo.json
 python bench.py --gpus 2 --backend gloo --single-device --scaling strong --no-cpu-baseline 2>/dev/null < /dev/null | tail -1 > gpurun_out/${tag}_bench_2ranks_1gpu_gloo_strong.json

@@ -33,7 +33,7 @@ SWITCH_SETS = [{}, {}, {}, {"SX_RESULT_ON_DEVICE": "1"}, {"SX_RESULT_ON_DEVICE":
                {"SX_FAST_REPLAY": "0"}, {"SX_WAVE_REPLAY": "0"}, {"SX_WAVE_REPLAY": "0"}, {"SX_WAVE_REPLAY": "0", "SX_SLABS": "3"},
                {"SX_WAVE_REPLAY": "0", "SX_REPLAY_CACHE_MIB": "1"}, {"SX_WAVE_REPLAY": "0", "SX_STITCH_BLOCK": "3"},
                {"SX_WAVE_REPLAY": "0", "SX_FAST_REPLAY": "0", "SX_STITCH_BLOCK": "3"}, {"SX_WAVE_REPLAY": "0", "SX_NO_PIECES": "1"}]
-ALL_SWITCHES = sorted({k for s in SWITCH_SETS for k in s})
+ALL_SWITCHES = sorted({k for s in SWITCH_SETS for k in s} | {"SX_FUSED", "SX_FUSED_PREFILTER", "SX_PIECE_MIB"})
 
 
 def make(case_seed):
@@ -77,6 +77,30 @@ def make(case_seed):
         be = r.random() < 0.5
         case["kind"] = "utf16soup"
         case["files"] = [utf16_soup(r, min(size, 300_000) // 2, be, r.choice([(50, 20, 8, 8, 6, 8), (40, 10, 14, 10, 10, 4), (70, 20, 2, 2, 5, 1)]))]
+    # Round 6, SX_FUZZ_FUSED=1: the fused stage A (sx_fused.hip) — two or three of the UTF-8 / UTF-16LE / UTF-16BE Missions with filters whose
+    # classifiers it holds, thresholds on both sides of the UTF-16 prefilter's 7, inputs with stretches of accepted units of every length at
+    # every phase between bytes that pass or fail the prefilter; with and without the prefilter, fused and not
+    if os.environ.get("SX_FUZZ_FUSED"):
+        from test_gpu_parity import utf16_dense
+        encs = r.sample(["utf-8", "utf-16le", "utf-16be"], r.choice([2, 3, 3]))
+        if r.random() < 0.3:
+            encs = [e + "," + r.choice(["", "3", "7", "9"]) + ",," + r.choice(["", "Greek", "Armenian", "Hebrew"]) for e in encs]
+        if r.random() < 0.15:
+            encs.insert(r.randrange(len(encs) + 1), r.choice(["koi8-r", "ascii", "utf-8,,,Cjk", "big5"]))
+        kw = dict(encodings=encs, chars_min=r.choice(["4", "6", "7", "8", "10", "12", "20"]), output_line_len=r.choice([None, None, "10", "64", "100"]),
+                  ascii_filter=r.choice([None, None, "All-Ctrl", "None"]), unicode_block_filter=r.choice([None, "African", "Common", "Cyrillic", "Arabic", "None"]),
+                  grep_char=None, same_unicode_block=False, counter_offset=r.choice([None, "1000"]))
+        case["kw"], case["missions"] = kw, rc.missions(**kw)
+        k2 = r.choice(["utf16_dense", "utf16_dense", "synth", "soup", "random", "multi"])
+        case["kind"] = "fused:" + k2
+        if k2 == "utf16_dense": case["files"] = [utf16_dense(r, size)]
+        elif k2 == "synth": case["files"] = [synth(r, size, 1 / 300)]
+        elif k2 == "soup": case["files"] = [soup(r, min(size, 200_000))]
+        elif k2 == "random": case["files"] = [r.randbytes(size)]
+        else: case["files"] = [utf16_dense(r, r.randrange(1, 30000)) for _ in range(r.randrange(2, 5))]
+        case["switches"] = r.choice([{}, {}, {}, {"SX_FUSED_PREFILTER": "0"}, {"SX_FUSED": "0"}, {"SX_PIECE_MIB": "0"}, {"SX_REGION_CAP": "2"}, {"SX_REGION_CAP": "0"},
+                                     {"SX_WAVE_REPLAY": "0"}, {"SX_DEVICE_JOIN_MIN": "1"}])
+        case["generic"] = False
     return case
 
 
