@@ -11,10 +11,10 @@
 // ~2.2 GHz issue 560 G of them per second, the 67 M tiles of 64 GiB want to be through in 11 ms = 92 per tile), so:
 //
 // (1) A FAST LOOP that only knows the fast path.  Three tiles per trip (the three register sets rotate without moves); per slot a
-//     handful of instructions decide "nothing in this tile can yield a record"; a tile in which some slot is not sure leaves the loop
-//     and goes through generic_tile — one copy of everything else (exact windows, start masks, light / heavy path, tiles near the end
-//     of the input, the look-back tile and tile 0 of the sub-chunk) —, the register sets rotate by moves, and the loop is entered
-//     again.  What is live across the fast loop is small: per slot the carry, two counters and — instead of the parameters of the slow
+//     handful of instructions decide "nothing in this tile can yield a record"; a tile in which some slot is not sure goes through
+//     generic_tile for those slots — everything else: exact windows, start masks, light / heavy path —, out of whichever register set
+//     holds it (no move touches a set with a load in flight); the look-back tile, tile 0 of the sub-chunk and the tiles near the end
+//     of the input go through generic_tile one at a time.  What is live across the fast loop is small: per slot the carry, two counters and — instead of the parameters of the slow
 //     paths (record pointers, thresholds, the UTF-16 classifiers' constants) — nothing: those are read from the kernel-argument
 //     segment where they are used (late_params).
 // (2) FULL slots (UTF-8): classify, one DPP shift whose lane 0 takes the previous tile's lane 63 out of a register that the tile
@@ -53,6 +53,7 @@ SX_DEV u32 ror1(u32 v) { return __builtin_amdgcn_mov_dpp(v, 0x13C, 0xF, 0xF, fal
 // Parameters of slot `slot`, read from the kernel-argument segment at the point of use (FusedParams is the kernel's only argument and
 // m[] its first member, so m[slot] sits at slot * sizeof(ScanParams)); the empty asm keeps the compiler from loading them once at the
 // kernel's top and carrying — i.e. spilling — them through the fast loop.
+static_assert(offsetof(FusedParams, m) == 0, "late_params addresses m[slot] from the start of the kernel-argument segment");
 typedef const __attribute__((address_space(4))) ScanParams* KArgMission;
 SX_DEV KArgMission late_params(u32 slot) {
     asm volatile("" : "+s"(slot));
