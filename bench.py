@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--ubf", default=None,
                     help="another -u for the workload's Missions (what an alias filter costs: --ubf Cjk, --ubf Asian, --ubf All); the line's "
                          "config.workload says so — not the headline configuration")
+    ap.add_argument("--chars-min", default=None,
+                    help="another -n for the workload's Missions (the reference's default is 4); the line's config.workload says so — not the headline configuration")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="strong: the workload's ONE image is split over the ranks — the default for `--gpus N` with N > 1 (BASELINE.json's "
                          "metric: 64 GiB at 1/2/4/8 GPUs); weak: every rank scans the workload's size — the default of `--workload c4` "
@@ -136,6 +138,8 @@ def main():
     if args.ubf:
         wl = dict(wl, flags=dict(wl["flags"], unicode_block_filter=args.ubf), name=wl["name"].replace("-u African", "-u " + args.ubf) + f" [--ubf {args.ubf}]",
                   kernels="the classifiers of -u %s: Utf8Range3T|Utf16RangesT x2 for an alias filter of three-byte leads, the table kernels for All" % args.ubf)
+    if args.chars_min:
+        wl = dict(wl, flags=dict(wl["flags"], chars_min=args.chars_min), name=wl["name"].replace("-n %s" % wl["flags"]["chars_min"], "-n " + args.chars_min) + f" [--chars-min {args.chars_min}]")
     missions = sx.missions_from_flags(**wl["flags"])   # the product's front end, from the literal flag strings
     assert missions == rc.missions(**wl["flags"])      # (the reference's rules restated in tests/refconfig.py: the checker)
     nbytes = int((args.gib if args.gib is not None else wl["gib"]) * (1 << 30)) // 4096 * 4096

@@ -102,8 +102,9 @@ template <class CLS>
 struct Prefilter {
     static constexpr bool kHas = false;
     SX_DEV void init(u32) {}
-    SX_DEV bool hit(u32x4) const { return true; }
-    static bool usable(const ScanParams&) { return false; }
+    template <int MODE> SX_DEV bool hit(u32x4) const { return true; }
+    SX_DEV bool last_unit_may_pass(u32, u32) const { return true; }
+    static int mode_for(const ScanParams&) { return 0; }
     static u32 zero_bits(const ScanParams&) { return 0; }
 };
 template <int BE_T, int ODD_T>
@@ -121,11 +122,27 @@ struct Prefilter<Utf16RangeT<BE_T, ODD_T>> {
     }
     // where the units' high bytes sit in a raw dword: LE at even parity and BE at odd parity in bytes 1 and 3, else in bytes 0 and 2
     SX_DEV void init(u32 z) { zz = (BE_T ^ ODD_T) ? z * 0x00010001u : z * 0x01000100u; }
-    // (host) a stretch that can yield a record holds >= 7 units, and the mask says something
-    static bool usable(const ScanParams& p) { return p.min_chars >= 7u && zero_bits(p) != 0u; }
-    SX_DEV bool hit(u32x4 x) const {
-        const u32 q0 = (x.x | x.y) & zz, q1 = (x.z | x.w) & zz;
-        return (q0 < q1 ? q0 : q1) == 0u;
+    // (host) which prefilter this Mission allows: 1 = a stretch that can yield a record holds >= 7 units (aligned groups of FOUR high
+    // bytes), 2 = >= 3 units (aligned PAIRS: the high bytes of 3 consecutive units are 3 consecutive even — or odd — positions, two
+    // of which share an aligned dword; the reference's default -n 4), 0 = none (fewer units, or the mask says nothing)
+    static int mode_for(const ScanParams& p) { return zero_bits(p) == 0u ? 0 : p.min_chars >= 7u ? 1 : p.min_chars >= 3u ? 2 : 0; }
+    template <int MODE> SX_DEV bool hit(u32x4 x) const {
+        if (MODE == 1) {
+            const u32 q0 = (x.x | x.y) & zz, q1 = (x.z | x.w) & zz;
+            return (q0 < q1 ? q0 : q1) == 0u;
+        }
+        const u32 a = x.x & zz, b = x.y & zz, c = x.z & zz, d = x.w & zz;
+        const u32 ab = a < b ? a : b, cd = c < d ? c : d;
+        return (ab < cd ? ab : cd) == 0u;
+    }
+    // Can the LAST byte of the tile in front of a tile be good at all?  It belongs to the unit whose high byte is the tile's byte 1023
+    // (LE at even parity, BE at odd), its byte 1022 (BE, even) or the next tile's byte 0 (LE, odd).  prev_w: the last dword of that tile
+    // (lane 63's x.w), cur_x: the first dword of the tile behind it (lane 0's x.x).  False: nothing is open at the tile's end and
+    // nothing of it spills over — the carry word is 0, no classification of that tile is needed to know it.
+    SX_DEV bool last_unit_may_pass(u32 prev_w, u32 cur_x) const {
+        const u32 z8 = (zz | (zz >> 8)) & 0xFFu;
+        const u32 hi = BE_T == ODD_T ? prev_w >> 24 : (BE_T ? prev_w >> 16 : cur_x);
+        return (hi & z8) == 0u;
     }
 };
 
@@ -140,12 +157,13 @@ SX_DEV u32 classify_fast(const CLS& c, u32x4 x, u32 nx) {
 template <class T, class = void> struct has_starts_from_good : std::false_type {};
 template <class T> struct has_starts_from_good<T, std::void_t<decltype(T::kStartsFromGood)>> : std::true_type {};
 
-template <class CLS, bool PFON, int SLOT>
+template <class CLS, int PFM, int SLOT>
 struct Slot {
     static constexpr bool kUsed = !std::is_same<CLS, NoCls>::value;
     static constexpr u32 kSlot = SLOT;
     using PF = Prefilter<CLS>;
-    static constexpr bool kPf = PFON && PF::kHas;
+    static constexpr bool kPf = PFM != 0 && PF::kHas;
+    static constexpr int kPfMode = PFM;
     CLS cls;         // FULL slots: the classifier's constants stay in SGPRs; prefilter slots build theirs where a tile is classified
     PF pf;
     Carry c;         // (FULL slots: c.g63 is only valid inside generic_tile; between tiles lane 0 of E holds it)
@@ -156,11 +174,12 @@ struct Slot {
     u32 sh0, sh1, sh2, sh3;   // the candidate test's shifts
 };
 
-// PFON: the slots that have a prefilter use it (the host says so when every such Mission qualifies: Prefilter::usable)
-template <class C0, class C1, class C2, bool PFON>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PFON ? 6 : 5))) void scan_kernel_fused(const FusedParams fp) {
+// PFM: the prefilter of the slots that have one (Prefilter::mode_for; the host picks the weakest any such Mission allows: 0 none, 1 groups
+// of four, 2 pairs)
+template <class C0, class C1, class C2, int PFM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PFM ? 6 : 5))) void scan_kernel_fused(const FusedParams fp) {
     const u32 lane = lane_id();
-    Slot<C0, PFON, 0> s0; Slot<C1, PFON, 1> s1; Slot<C2, PFON, 2> s2;
+    Slot<C0, PFM, 0> s0; Slot<C1, PFM, 1> s1; Slot<C2, PFM, 2> s2;
 
     const u32 wave = blockIdx.x * 4u + uniform(threadIdx.x >> 6);
     const u64 len = fp.len;
@@ -259,7 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PFON ? 6 : 
             if constexpr (ST::kPf) {
                 // (unknown context: c.g63 is kept at 0 and nothing is tracked)
                 const u32 open = S.c.tracked | (S.c.g63 & 0x8000u) | ((S.known == 0u && t == 0) ? 1u : 0u);
-                if (t < 0 || (__ballot(S.pf.hit(X.d)) == 0 && open == 0u)) { S.known = 0; S.c.g63 = 0; return; }
+                if (t < 0 || (__ballot(S.pf.template hit<ST::kPfMode>(X.d)) == 0 && open == 0u)) { S.known = 0; S.c.g63 = 0; return; }
                 make_cls(local, slot);
                 cls = &local;
                 if (!S.known) S.c.g63 = context_before(local, toff, tile_base);   // (tracked implies known)
@@ -318,12 +337,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PFON ? 6 : 
     };
 
     // ---- the fast path of one slot: true = the tile is settled for this slot ----
-    auto fast_slot = [&](auto& S, const TileRegs& X) -> bool {
+    // (Zp: the register set that still holds the tile in front of X — zprev —, or anything)
+    auto fast_slot = [&](auto& S, const TileRegs& X, const TileRegs& Zp, bool zprev) -> bool {
         using ST = std::decay_t<decltype(S)>;
         if constexpr (!ST::kUsed) return true;
         else if constexpr (ST::kPf) {
             const u32 open = S.c.tracked | (S.c.g63 & 0x8000u);   // (unknown context: both are 0)
-            if ((__ballot(S.pf.hit(X.d)) | (u64)open) != 0) return false;
+            if ((__ballot(S.pf.template hit<ST::kPfMode>(X.d)) | (u64)open) != 0) {
+                // The tile will be classified.  If the one in front was skipped, its carry word is unknown: 0 for certain if its last
+                // byte cannot be good (no classification, no load), else generic_tile recomputes it from memory.
+                if (!S.known && zprev && !S.pf.last_unit_may_pass(bcast(Zp.d.w, 63), bcast(X.d.x, 0))) { S.c.g63 = 0; S.known = 1; }
+                return false;
+            }
             S.known = 0; S.c.g63 = 0;
             return true;
         } else {
@@ -345,17 +370,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PFON ? 6 : 
         }
     };
     // tile t out of X, Z <- tile t + 2.  0: settled; else the slots that want generic_tile (the others are done with the tile)
-    auto fast_tile = [&](const TileRegs& X, TileRegs& Z) -> u32 {
+    auto fast_tile = [&](const TileRegs& X, TileRegs& Z, bool zprev) -> u32 {
+        u32 zero = 0, two = 2;
+        asm volatile("" : "+s"(zero), "+s"(two));   // (constants the compiler cannot see through: `slow` stays a scalar select, not a v_cndmask + v_readfirstlane of a bool)
+        // the prefilter slots first: Z still holds the tile in front of X
+        u32 slow = fast_slot(s1, X, Z, zprev) ? zero : two;
+        if (!fast_slot(s2, X, Z, zprev)) slow |= 4u;
         Z = fetch(toff + 2 * kTileBytes);
-        u32 zero = 0, one = 1;
-        asm volatile("" : "+s"(zero), "+s"(one));   // (constants the compiler cannot see through: `slow` stays a scalar select, not a v_cndmask + v_readfirstlane of a bool)
-        u32 slow = fast_slot(s0, X) ? zero : one;
-        if (!fast_slot(s1, X)) slow |= 2u;
-        if (!fast_slot(s2, X)) slow |= 4u;
+        if (!fast_slot(s0, X, Z, false)) slow |= 1u;
         if (slow == 0) { toff += kTileBytes; t++; }
         return slow;
     };
-    constexpr u32 kAll = (Slot<C0, PFON, 0>::kUsed ? 1u : 0u) | (Slot<C1, PFON, 1>::kUsed ? 2u : 0u) | (Slot<C2, PFON, 2>::kUsed ? 4u : 0u);
+    constexpr u32 kAll = (Slot<C0, PFM, 0>::kUsed ? 1u : 0u) | (Slot<C1, PFM, 1>::kUsed ? 2u : 0u) | (Slot<C2, PFM, 2>::kUsed ? 4u : 0u);
 
     for (;;) {
         // one tile at a time, the register sets rotating by moves: the look-back tile (classification state only), tile 0 (a stretch
@@ -368,11 +394,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PFON ? 6 : 
         if (t >= n_tiles) break;
         // the fast loop: three tiles per trip, no register moves; a tile that some slot is not sure of goes through generic_tile
         // for those slots, out of the register set it is in
+        bool zprev = false;   // (at the loop's entry R2 is a copy of R1, not the tile in front of R0)
         do {
             u32 slow;
-            if ((slow = fast_tile(R0, R2)) != 0) generic_tile(R0, slow, true);
-            if ((slow = fast_tile(R1, R0)) != 0) generic_tile(R1, slow, true);
-            if ((slow = fast_tile(R2, R1)) != 0) generic_tile(R2, slow, true);
+            if ((slow = fast_tile(R0, R2, zprev)) != 0) generic_tile(R0, slow, true);
+            if ((slow = fast_tile(R1, R0, true)) != 0) generic_tile(R1, slow, true);
+            if ((slow = fast_tile(R2, R1, true)) != 0) generic_tile(R2, slow, true);
+            zprev = true;
         } while (t + 3 <= n_safe);
     }
 
@@ -414,13 +442,16 @@ static hipError_t launch_f(const FusedParams& fp, uint32_t used, hipStream_t str
     const u64 blocks = (waves + 3) / 4;
     if (blocks == 0) return hipSuccess;
     FusedParams q = fp;
-    // the prefilter: only if every slot that has one may use it
-    bool pf = !(getenv("SX_FUSED_PREFILTER") && !atoi(getenv("SX_FUSED_PREFILTER")));
-    if ((used & 2u) && !Prefilter<C1>::usable(fp.m[1])) pf = false;
-    if ((used & 4u) && !Prefilter<C2>::usable(fp.m[2])) pf = false;
+    // the prefilter: the weakest one any slot that has one allows (pairs are right wherever groups of four are); SX_FUSED_PREFILTER=0 / 2: none / pairs
+    int mode = 1;
+    if ((used & 2u) && Prefilter<C1>::mode_for(fp.m[1]) != 1) mode = Prefilter<C1>::mode_for(fp.m[1]);
+    if ((used & 4u) && mode && Prefilter<C2>::mode_for(fp.m[2]) != 1) mode = Prefilter<C2>::mode_for(fp.m[2]) == 0 ? 0 : 2;
+    if (!(used & 6u)) mode = 0;
+    if (const char* e = getenv("SX_FUSED_PREFILTER")) { const int v = atoi(e); if (v == 0) mode = 0; else if (v == 2 && mode == 1) mode = 2; }
     q.pf_zero[0] = 0; q.pf_zero[1] = Prefilter<C1>::zero_bits(fp.m[1]); q.pf_zero[2] = Prefilter<C2>::zero_bits(fp.m[2]);
-    if (pf) hipLaunchKernelGGL((scan_kernel_fused<C0, C1, C2, true>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
-    else hipLaunchKernelGGL((scan_kernel_fused<C0, C1, C2, false>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    if (mode == 1) hipLaunchKernelGGL((scan_kernel_fused<C0, C1, C2, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    else if (mode == 2) hipLaunchKernelGGL((scan_kernel_fused<C0, C1, C2, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
+    else hipLaunchKernelGGL((scan_kernel_fused<C0, C1, C2, 0>), dim3((unsigned)blocks), dim3(256), 0, stream, q);
     return hipGetLastError();
 }
 

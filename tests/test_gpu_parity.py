@@ -148,8 +148,10 @@ def fused_runs(mdicts, data, parity=0, subchunk=0, min_chars=None):
 FUSED_SETS = {
     # BASELINE's headline Missions: all three in one launch, the UTF-16 ones behind the prefilter (n >= 7)
     "c3": (dict(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="10", unicode_block_filter="African"), 0b111),
-    # thresholds below 7: the UTF-16 slots classify every tile (no prefilter)
+    # thresholds 3 .. 6: the prefilter on aligned PAIRS of high bytes (the reference's default -n 4); below 3: the UTF-16 slots classify every tile
     "n4": (dict(encodings=["utf-8", "utf-16le", "utf-16be"], chars_min="4", unicode_block_filter="Common"), 0b111),
+    "n3": (dict(encodings=["utf-16le", "utf-16be", "utf-8"], chars_min="3", unicode_block_filter="Hebrew"), 0b111),
+    "n2": (dict(encodings=["utf-8", "utf-16be", "utf-16le"], chars_min="2", unicode_block_filter="Armenian", ascii_filter="None"), 0b111),
     "n7_mixed": (dict(encodings=["utf-16be,7,,Armenian", "utf-8,3,,Greek", "utf-16le,12,,Hebrew"]), 0b111),   # slots in another order, a filter per Mission
     "pairs": (dict(encodings=["utf-16le", "utf-8"], chars_min="8", unicode_block_filter="Arabic"), 0b11),
     "le_be": (dict(encodings=["utf-16le", "utf-16be"], chars_min="9", unicode_block_filter="Cyrillic"), 0b11),
