@@ -310,16 +310,19 @@ def main():
         # HBM bytes per launch from the PMC counters: they cannot be read inside this process, so the
         # value comes from the committed counter passes of this very command line (profiles/traffic.json
         # says how); null for any other workload or size
-        traffic = None
+        traffic = valu = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj["workload"] == args.workload and tj["bytes_per_gpu"] == nbytes and tj.get("scan_kernel_source") == scan_kernel_source_hash():
                 traffic = tj["traffic_bytes_per_launch"]   # else null: the counters were taken with other kernels
+                valu = tj.get("valu")
         except (OSError, KeyError, ValueError):
             pass
         roofline = {
             "bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+            # what bounds the fused kernel instead of HBM: vector-instruction issue (separate SQ counter passes of this command, like `traffic`)
+            "valu_issue": valu,
             "kernel": (("sx::scan_kernel_fused: ONE launch reads the shard once for Missions %s" % fused_ks
                         + ("; + sx::scan_kernel, %d launch(es) of the other Missions, average over all launches" % (n_scanned - 1) if n_scanned > 1 else ""))
                        if fused_ks else "sx::scan_kernel<%s>, %d launches per step, average" % (wl.get("kernels", "Utf8Range2|Utf16Range"), n_scanned))

@@ -38,6 +38,12 @@
 //   length), and the sub-chunk's end recomputes the context it needs for the kRecEndOpen part.  On random bytes (8 / 256)^4 per
 //   group = 1.2e-4 of the tiles pass.
 //
+//   For 3 <= min_chars <= 6 (the reference's default -n 4) the same argument holds with PAIRS: the high bytes of 3 consecutive units
+//   cover one aligned dword's two high-byte positions; 22 % of the tiles of random bytes pass.  There the skipped tile's carry word
+//   usually needs no recomputing: if the last byte of that tile cannot be good — the high byte of the unit it belongs to is outside M,
+//   read from the register set that still holds that tile — the word is 0.  (Kernel alone at -n 7, 64 GiB: no prefilter 25.0 ms, pairs
+//   21.2, groups of four 17.7.)
+//
 // Records, flags and statistics are those of scan_kernel (same light / heavy paths, sx_scan_core.hpp); stage B never sees a difference.
 #include "sx_scan_core.hpp"
 
@@ -128,7 +134,7 @@ struct Prefilter<Utf16RangeT<BE_T, ODD_T>> {
     static int mode_for(const ScanParams& p) { return zero_bits(p) == 0u ? 0 : p.min_chars >= 7u ? 1 : p.min_chars >= 3u ? 2 : 0; }
     template <int MODE> SX_DEV bool hit(u32x4 x) const {
         if (MODE == 1) {
-            const u32 q0 = (x.x | x.y) & zz, q1 = (x.z | x.w) & zz;
+            const u32 q0 = __builtin_amdgcn_bitop3_b32(x.x, zz, x.y, 0xC8), q1 = __builtin_amdgcn_bitop3_b32(x.z, zz, x.w, 0xC8);   // (a | c) & b
             return (q0 < q1 ? q0 : q1) == 0u;
         }
         const u32 a = x.x & zz, b = x.y & zz, c = x.z & zz, d = x.w & zz;
@@ -157,6 +163,8 @@ SX_DEV u32 classify_fast(const CLS& c, u32x4 x, u32 nx) {
 template <class T, class = void> struct has_starts_from_good : std::false_type {};
 template <class T> struct has_starts_from_good<T, std::void_t<decltype(T::kStartsFromGood)>> : std::true_type {};
 
+constexpr u32 kUnknown = 0x80000000u;   // c.g63 of a prefilter slot: the tile in front was skipped (bit 15 — "open" — is clear, like every bit a test looks at)
+
 template <class CLS, int PFM, int SLOT>
 struct Slot {
     static constexpr bool kUsed = !std::is_same<CLS, NoCls>::value;
@@ -168,7 +176,8 @@ struct Slot {
     PF pf;
     Carry c;         // (FULL slots: c.g63 is only valid inside generic_tile; between tiles lane 0 of E holds it)
     LateEmitter em;
-    u32 known;       // prefilter slots: c.g63 describes the tile before the current one (not after a skipped tile: then it is 0)
+    // (prefilter slots: after a skipped tile the carry word is not known — c.g63 == kUnknown, a value no carry word takes: one state
+    //  word instead of two keeps it in an SGPR through the fast loop)
     u32 E;           // FULL slots: lane 0 = the previous tile's lane 63 (final good mask | its spill bits << 16)
     u32 gtmp, pgtmp, rtmp; // FULL slots: what the fast loop knows of the tile it hands to generic_tile: the classification, the same one lane up (lane 0: the carry), the candidate test
     u32 sh0, sh1, sh2, sh3;   // the candidate test's shifts
@@ -206,7 +215,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PFM ? 6 : 5
             S.sh0 = fp.fsh[slot][0]; S.sh1 = fp.fsh[slot][1]; S.sh2 = fp.fsh[slot][2]; S.sh3 = fp.fsh[slot][3];
             S.em.slot = slot; S.em.wave = wave; S.em.rcount = 0; S.em.heavy_n = 0;
             S.c.g63 = 0; S.c.tracked = 0; S.c.t_chars = 0; S.c.t_flags = 0; S.c.t_start = 0;
-            S.known = 1;   // (nothing lies before window offset 0)
             S.E = 0; S.gtmp = 0; S.pgtmp = 0; S.rtmp = 0;
         }
     };
@@ -277,11 +285,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PFM ? 6 : 5
             const CLS* cls = &S.cls;
             if constexpr (ST::kPf) {
                 // (unknown context: c.g63 is kept at 0 and nothing is tracked)
-                const u32 open = S.c.tracked | (S.c.g63 & 0x8000u) | ((S.known == 0u && t == 0) ? 1u : 0u);
-                if (t < 0 || (__ballot(S.pf.template hit<ST::kPfMode>(X.d)) == 0 && open == 0u)) { S.known = 0; S.c.g63 = 0; return; }
+                const u32 open = S.c.tracked | (S.c.g63 & 0x8000u) | ((S.c.g63 == kUnknown && t == 0) ? 1u : 0u);
+                if (t < 0 || (__ballot(S.pf.template hit<ST::kPfMode>(X.d)) == 0 && open == 0u)) { S.c.g63 = kUnknown; return; }
                 make_cls(local, slot);
                 cls = &local;
-                if (!S.known) S.c.g63 = context_before(local, toff, tile_base);   // (tracked implies known)
+                if (S.c.g63 == kUnknown) S.c.g63 = context_before(local, toff, tile_base);   // (tracked implies known)
             } else {
                 S.c.g63 = bcast(have_g ? S.pgtmp : S.E, 0);   // (the fast loop has replaced E already)
             }
@@ -301,7 +309,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PFM ? 6 : 5
             const bool any_cand = __ballot((r & 0xFFFF0000u) != 0) != 0;
             const bool first_tile = t == 0;
             const bool first_open = first_tile && (g63_in & 0x8000u);
-            S.known = 1;
             if (t < 0 || (!any_cand && !tracked_in && !first_open)) {
                 S.c.g63 = g63_out;
             } else {
@@ -346,10 +353,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PFM ? 6 : 5
             if ((__ballot(S.pf.template hit<ST::kPfMode>(X.d)) | (u64)open) != 0) {
                 // The tile will be classified.  If the one in front was skipped, its carry word is unknown: 0 for certain if its last
                 // byte cannot be good (no classification, no load), else generic_tile recomputes it from memory.
-                if (!S.known && zprev && !S.pf.last_unit_may_pass(bcast(Zp.d.w, 63), bcast(X.d.x, 0))) { S.c.g63 = 0; S.known = 1; }
+                if (S.c.g63 == kUnknown && zprev && !S.pf.last_unit_may_pass(bcast(Zp.d.w, 63), bcast(X.d.x, 0))) S.c.g63 = 0;
                 return false;
             }
-            S.known = 0; S.c.g63 = 0;
+            S.c.g63 = kUnknown;
             return true;
         } else {
             const u32 g = classify_fast(S.cls, X.d, X.e);
@@ -371,13 +378,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PFM ? 6 : 5
     };
     // tile t out of X, Z <- tile t + 2.  0: settled; else the slots that want generic_tile (the others are done with the tile)
     auto fast_tile = [&](const TileRegs& X, TileRegs& Z, bool zprev) -> u32 {
-        u32 zero = 0, two = 2;
-        asm volatile("" : "+s"(zero), "+s"(two));   // (constants the compiler cannot see through: `slow` stays a scalar select, not a v_cndmask + v_readfirstlane of a bool)
+        u32 zero = 0, one = 1, two = 2;
+        asm volatile("" : "+s"(zero), "+s"(one), "+s"(two));   // (constants the compiler cannot see through: `slow` stays a scalar select, not a v_cndmask + v_readfirstlane of a bool)
         // the prefilter slots first: Z still holds the tile in front of X
         u32 slow = fast_slot(s1, X, Z, zprev) ? zero : two;
         if (!fast_slot(s2, X, Z, zprev)) slow |= 4u;
         Z = fetch(toff + 2 * kTileBytes);
-        if (!fast_slot(s0, X, Z, false)) slow |= 1u;
+        slow |= fast_slot(s0, X, Z, false) ? zero : one;
         if (slow == 0) { toff += kTileBytes; t++; }
         return slow;
     };
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PFM ? 6 : 5
             if constexpr (ST::kPf) {
                 make_cls(local, slot);
                 cls = &local;
-                if (!S.known) S.c.g63 = context_before(local, toff, after);
+                if (S.c.g63 == kUnknown) S.c.g63 = context_before(local, toff, after);
             } else S.c.g63 = bcast(S.E, 0);
             if (S.c.tracked || (S.c.g63 & 0x8000u)) {
                 u64 os; u32 och, ofl;
