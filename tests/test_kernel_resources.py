@@ -52,7 +52,7 @@ def test_no_kernel_with_the_exchange_loop_spills_vector_registers():
 
 def test_headline_kernels_keep_their_registers():
     fused = remarks("sx_fused")
-    head = [k for k in fused if k.startswith("scan_kernel_fused<Utf8Range2, Utf16RangeT<0, 0>, Utf16RangeT<1, 0>, true>")]
+    head = [k for k in fused if k.startswith("scan_kernel_fused<Utf8Range2, Utf16RangeT<0, 0>, Utf16RangeT<1, 0>, 1>")]
     assert len(head) == 1, sorted(fused)
     for k, v in fused.items():
         assert v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)       # (the late parameters must not turn into a stack copy of the argument)
