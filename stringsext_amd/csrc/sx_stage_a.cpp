@@ -117,6 +117,9 @@ int stage_a_launch(sx_ctx* ctx, const std::vector<int>& which, const uint8_t* d_
             if (params[k].persistent) continue;
             const int sl = fused_slot_of(ctx->missions[(size_t)which[k]].kind, params[k]);
             if (sl < 0 || (used >> sl) & 1u) continue;   // (a second Mission of the same slot keeps its own launch)
+            // (the kernel knows ONE unit parity at compile time: the UTF-16 Missions of a stream share it — they have consumed the same
+            //  bytes —; one that does not keeps its own launch)
+            if (sl >= 1 && (used & 6u) && ((fp.m[(used & 2u) ? 1 : 2].parity ^ params[k].parity) & 1u)) continue;
             used |= 1u << sl; fp.m[sl] = params[k]; member[sl] = k;
         }
         // (two Missions or more — or the UTF-8 range Mission alone: the fused kernel's fast loop is the faster scan of it)
